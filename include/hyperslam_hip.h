@@ -1,0 +1,181 @@
+/* hyperslam_hip.h — C ABI of the MI355X-native continuous-time NLLS backend (libhyperslam_hip.so).
+ *
+ * This is the drop-in boundary for HyperSLAM's optimisation hot path: everything that happens
+ * inside `Optimizer<OptimizerSuite::CERES>::optimize()` -> `ceres::Solve`
+ * (/root/reference/internal/hyper/optimizers/ceres/optimizer.cpp:276-280) and, per residual block, inside
+ * `ExteroceptiveCost<CERES>::Evaluate` (/root/reference/internal/hyper/optimizers/ceres/costs/exteroceptive.cpp:101-160)
+ * -> `Evaluator<Obs, SE3>::evaluate` (/root/reference/internal/hyper/optimizers/evaluators/*.cpp).
+ *
+ * The reference walks a pointer graph (ceres::Problem) one residual at a time; this ABI takes the same content as
+ * flat tables (control points, sensors, landmarks, per-type residual records), keeps them resident in HBM and runs
+ * linearise -> robustify -> landmark Schur complement -> reduced solve -> retract -> accept/reject on the GPU.
+ *
+ * Conventions
+ *   - plain C, opaque handle, every call returns int (0 = HS_OK); hs_last_error(handle) gives the message.
+ *   - host buffers are caller-owned and only read/written during the call; device memory is library-owned.
+ *   - a handle is used by one thread at a time (the reference calls its optimizer from the single backend thread,
+ *     /root/reference/internal/hyper/system/components/backend.cpp:143-145); no internal host threads.
+ *   - all arithmetic fp64 (/root/reference/include/hyper/optimizers/ceres/manifolds/variables/wrapper.hpp:22).
+ *   - quaternions are (x, y, z, w) (su2.cpp:21, settings.yaml:34-36); a control point is the reference's
+ *     Stamped<SE3> block [qx qy qz qw px py pz t] (stamped.hpp:35-36, se3.cpp:20-23).
+ */
+#ifndef HYPERSLAM_HIP_H_
+#define HYPERSLAM_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HS_OK 0
+#define HS_ERR_INVALID 1   /* bad argument / inconsistent tables */
+#define HS_ERR_DEVICE 2    /* HIP runtime error */
+#define HS_ERR_STATE 3     /* call order (e.g. solve before tables are set) */
+#define HS_ERR_NUMERIC 4   /* non-finite values / factorisation failure surfaced to the caller */
+
+/* Factor types = the four in-tree evaluators (optimizer.cpp:189,212,234,253). */
+#define HS_PIXEL 0     /* VisualPixelEvaluator   pixel.cpp:16     2 rows, CartesianMetric, Huber(0.5)      optimizer.cpp:226 */
+#define HS_BEARING 1   /* VisualBearingEvaluator bearing.cpp:14   1 row,  AngularMetric,   Huber(1.6e-3)   optimizer.cpp:204 */
+#define HS_PRIOR 2     /* ManifoldEvaluator      manifold.cpp:12  6 rows, ManifoldMetric,  no loss         optimizer.cpp:250 */
+#define HS_INERTIAL 3  /* InertialEvaluator      inertial.cpp:13  6 rows, CartesianMetric, Scaled(1.6e-5)  optimizer.cpp:267 */
+
+typedef struct hs_problem hs_problem;
+
+/* Termination (ceres::TerminationType as used by TrustRegionMinimizer). */
+#define HS_NO_CONVERGENCE 0 /* max_num_iterations reached (optimizer.cpp:40: 5) */
+#define HS_CONVERGENCE 1
+#define HS_FAILURE 2
+
+typedef struct hs_iteration {
+  int32_t iteration;
+  int32_t step_is_valid;
+  int32_t step_is_successful;
+  int32_t reserved;
+  double cost;              /* cost after this iteration (0.5 * sum rho(|r|^2)) */
+  double cost_change;
+  double gradient_max_norm;
+  double step_norm;
+  double relative_decrease;
+  double radius;            /* trust-region radius after this iteration */
+} hs_iteration;
+
+typedef struct hs_summary {
+  double initial_cost;
+  double final_cost;
+  int32_t num_iterations;        /* LM iterations executed (linear solves), <= max_iterations */
+  int32_t num_successful_steps;
+  int32_t termination;           /* HS_NO_CONVERGENCE | HS_CONVERGENCE | HS_FAILURE */
+  int32_t num_residual_blocks;   /* residual blocks evaluated per linearisation on this handle */
+  double linearize_ms;           /* accumulated device time per stage over the solve (HIP events) */
+  double schur_ms;
+  double solve_ms;
+  double update_ms;
+  double total_ms;
+} hs_summary;
+
+/* Output pointers for hs_linearize (each nullable). Rows are residual blocks in table order.
+ * Jacobians are Ceres *local* Jacobians (J_ambient * PlusJacobian — the quantity the reference's own tests compare,
+ * tests/include/tests/optimizers/evaluators/evaluator.hpp:52), row-major per residual block. */
+typedef struct hs_linearization {
+  double* r;            /* n x n_res                                                           */
+  double* J_state;      /* n x n_res x 6k   columns: k control points x [d_rot(3) d_trans(3)]   */
+  double* J_landmark;   /* n x n_res x 3    (pixel / bearing)                                   */
+  double* J_bias_g;     /* n x 6 x 3kb      (inertial)                                          */
+  double* J_bias_a;     /* n x 6 x 3kb      (inertial)                                          */
+  double* J_gravity;    /* n x 6 x 2        (inertial; SphereManifold<3> tangent basis of Ceres) */
+  int32_t* first_cp;    /* n   index of the first of the k control points used                  */
+  int32_t* first_bias;  /* n   (inertial)                                                       */
+  double* cost;         /* n   0.5 * rho(|r|^2)                                                 */
+} hs_linearization;
+
+/* Exchange hook for the multi-GPU path: called once per linearisation with a device buffer of
+ * `count` doubles ([S | g | cost]) that must be summed in place across ranks (RCCL all-reduce, fp64), enqueued on
+ * `stream` (the handle's HIP stream). Return 0 on success. NULL = single GPU. */
+typedef int (*hs_allreduce_fn)(void* user, void* device_buffer, int64_t count, void* stream);
+
+/* ---- lifetime ---------------------------------------------------------------------------------------------- */
+/* Replaces: construction of Optimizer<CERES> in Backend::Backend (backend.cpp:37-46). `stream` is a hipStream_t
+ * (NULL = the library creates its own). */
+int hs_create(int device, void* stream, hs_problem** out);
+int hs_destroy(hs_problem* p);
+const char* hs_last_error(const hs_problem* p);
+/* Library/ABI version and the gfx arch the device code was built for (e.g. "gfx950"). */
+int hs_version(void);
+const char* hs_arch(void);
+
+/* ---- tables (host -> HBM) ------------------------------------------------------------------------------------ */
+/* Replaces swapState/updateState (optimizer.cpp:110-128, 286-345) + setStateManifold (backend.cpp:52-55):
+ * uniform spline of order k (k control points per segment; BasisInterpolator(k-1, true)), control point j at stamp
+ * t0 + j*dt. cp = n_cp x 8. cp_constant[j] != 0 freezes control point j (optimizer.cpp:323-328); may be NULL. */
+int hs_set_spline(hs_problem* p, int order, double t0, double dt, int n_cp, const double* cp, const uint8_t* cp_constant,
+                  int rotation_constant, int translation_constant);
+/* Replaces setSensorManifold for cameras (optimizer.cpp:143-155; constant blocks, camera.hpp:18).
+ * T_bs n x 7, intrinsics n x 4 [cx cy fx fy] (settings.yaml:38-40), distortion n x 4 radtan [k1 k2 p1 p2] (:42-45). */
+int hs_set_cameras(hs_problem* p, int n, const double* T_bs, const double* intrinsics, const double* distortion);
+/* Plain sensors (extrinsics only) used by pose-prior factors (manifold.cpp:30-33). T_bs n x 7. */
+int hs_set_sensors(hs_problem* p, int n, const double* T_bs);
+/* Replaces addLandmark/updateLandmarks (optimizer.cpp:347-382). xyz n x 3; constant may be NULL. */
+int hs_set_landmarks(hs_problem* p, int n, const double* xyz, const uint8_t* constant);
+/* Replaces setSensorManifold for the IMU (optimizer.cpp:59-64) + its bias splines (imu.cpp:64-81):
+ * T_bs[7], i_g[6], i_a[6] ([c00 c11 c22 c10 c20 c21], settings.yaml:87-89), S_g[9], X_a[9] (column-major, inertial.cpp:48-49);
+ * bias splines: uniform R^3 splines of order bias_order, control point j at bias_t0 + j*bias_dt, n_bias x 4 [x y z t]. */
+int hs_set_imu(hs_problem* p, const double* T_bs, const double* i_g, const double* i_a, const double* S_g, const double* X_a,
+               int bias_order, double bias_t0, double bias_dt, int n_bias, const double* bias_g, const double* bias_a, int bias_constant);
+/* Replaces swapEnvironment gravity block + setGravityConstant (optimizer.cpp:84-108, 130-141; rule abstract.cpp:57-61). */
+int hs_set_gravity(hs_problem* p, const double* g, int constant);
+
+/* Residual tables = the content of problem_.AddResidualBlock calls (optimizer.cpp:189-274). Any order is accepted;
+ * the library keeps its own landmark-major permutation and reports results in table order. */
+int hs_set_pixel_residuals(hs_problem* p, int n, const double* stamps, const double* pixels, const int32_t* landmark, const int32_t* camera);
+int hs_set_bearing_residuals(hs_problem* p, int n, const double* stamps, const double* bearings, const int32_t* landmark, const int32_t* camera);
+int hs_set_prior_residuals(hs_problem* p, int n, const double* stamps, const double* poses, const int32_t* sensor);
+int hs_set_inertial_residuals(hs_problem* p, int n, const double* stamps, const double* measurements);
+
+/* ---- structure (bit-exact parity target) ------------------------------------------------------- */
+/* Restates ExteroceptiveCost::update (exteroceptive.cpp:25-99) for residual `idx` of `type`:
+ * indices[4] = {static_state_idx, static_sensor_idx, dynamic_sensor_idx, static_observation_idx},
+ * sizes/offsets/block_ids have *num_blocks entries (caller provides room for 32),
+ * block_ids: control-point index for state blocks, sensor id for sensor blocks, bias control-point index for bias
+ * blocks, landmark id (or 0 for gravity) for the observation block. */
+int hs_residual_layout(hs_problem* p, int type, int idx, int32_t* num_blocks, int32_t* indices, int32_t* sizes, int32_t* offsets,
+                       int32_t* block_ids, int32_t* num_parameters, int32_t* num_residuals);
+
+/* ---- evaluation (parity / debugging surface) ------------------------------------------------------------------ */
+int hs_num_residuals(hs_problem* p, int type);
+int hs_dim_pose(hs_problem* p); /* 6*n_cp (+ 6*n_bias + 2 with an IMU): size of the reduced system */
+/* Batched replacement of ExteroceptiveCost::Evaluate + Ceres' local-Jacobian projection for every residual of `type`.
+ * robustify != 0 additionally applies Ceres' loss corrector (sqrt(rho') scaling of r and J). */
+int hs_linearize(hs_problem* p, int type, int robustify, const hs_linearization* out);
+/* Ceres-compatible single-block entry: same contract as
+ * `bool ExteroceptiveCost::Evaluate(double const* const* parameters, double* residuals, double** jacobians)`
+ * (exteroceptive.hpp:31): parameters in update() block order, jacobians[i] row-major num_residuals x size_i, nullable
+ * individually or as a whole. Evaluated on the GPU at the *given* parameter values. */
+int hs_cost_function_evaluate(hs_problem* p, int type, int idx, const double* const* parameters, double* residuals, double** jacobians);
+/* Total cost 0.5*sum rho(|r|^2) at the current point. */
+int hs_cost(hs_problem* p, double* cost);
+/* Reduced (landmark-eliminated), Jacobi-scaled, LM-damped system of the first iteration at the current point:
+ * S (dim x dim, row-major, symmetric) and g (dim). What one LM iteration factors; parity target for the Schur build. */
+int hs_reduced_system(hs_problem* p, double radius, double* S, double* g);
+
+/* ---- solve ------------------------------------------------------------------------------------------------------ */
+/* Replaces CeresOptimizer::optimize (optimizer.cpp:276-280) with the options of optimizer.cpp:38-54 (trust-region LM,
+ * Jacobi scaling, monotonic steps). iterations (nullable) receives max_iterations + 1 records (record 0 = initial point). */
+int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteration* iterations);
+int hs_set_allreduce(hs_problem* p, hs_allreduce_fn fn, void* user);
+
+/* ---- read back (the reference mutates the variables in place through raw double*, optimizer.cpp:299-305) ------- */
+int hs_get_control_points(hs_problem* p, double* cp);
+int hs_get_landmarks(hs_problem* p, double* xyz);
+int hs_get_bias(hs_problem* p, double* bias_g, double* bias_a);
+int hs_get_gravity(hs_problem* p, double* g);
+
+/* ---- batched trajectory sampling (main.cpp:72-79) -------------------------------------------- */
+/* Evaluates the spline at n stamps: pose n x 7 [qx qy qz qw px py pz]; velocity/acceleration (nullable) n x 6
+ * [angular(3) body ; linear(3) world]. */
+int hs_sample_trajectory(hs_problem* p, int n, const double* stamps, double* pose, double* velocity, double* acceleration);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYPERSLAM_HIP_H_ */

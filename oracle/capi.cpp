@@ -1,0 +1,270 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see hs_math.hpp header). PARITY UNPINNED.
+// C entry points of the CPU restatement, mirroring include/hyperslam_hip.h one-to-one with the prefix `hso_`
+// so the parity tests drive both sides with the same tables.
+#include <chrono>
+#include <cstring>
+#include <string>
+
+#include "../include/hyperslam_hip.h"
+#include "hs_problem.hpp"
+
+using namespace hso;
+
+struct hso_problem {
+  Problem P;
+  std::string err;
+};
+
+#define CHECK_ARG(cond, msg)  \
+  do {                        \
+    if (!(cond)) {            \
+      p->err = msg;           \
+      return HS_ERR_INVALID;  \
+    }                         \
+  } while (0)
+
+extern "C" {
+
+int hso_create(int, void*, hso_problem** out) {
+  *out = new hso_problem();
+  return HS_OK;
+}
+int hso_destroy(hso_problem* p) {
+  delete p;
+  return HS_OK;
+}
+const char* hso_last_error(const hso_problem* p) { return p ? p->err.c_str() : "null handle"; }
+
+int hso_set_spline(hso_problem* p, int order, double t0, double dt, int n_cp, const double* cp, const uint8_t* cp_constant, int rot_c, int trans_c) {
+  CHECK_ARG(order >= 2 && order <= kMaxOrder, "order out of range");
+  CHECK_ARG(n_cp >= order && dt > 0, "need n_cp >= order and dt > 0");
+  Problem& P = p->P;
+  P.k = order, P.t0 = t0, P.dt = dt, P.n_cp = n_cp;
+  P.cp.assign(cp, cp + size_t(8) * n_cp);
+  P.cp_const.assign(n_cp, 0);
+  if (cp_constant) P.cp_const.assign(cp_constant, cp_constant + n_cp);
+  P.rot_const = rot_c != 0, P.trans_const = trans_c != 0;
+  return HS_OK;
+}
+int hso_set_cameras(hso_problem* p, int n, const double* T, const double* in, const double* di) {
+  Problem& P = p->P;
+  P.n_cam = n;
+  P.cam_T_bs.assign(T, T + 7 * n), P.cam_intr.assign(in, in + 4 * n), P.cam_dist.assign(di, di + 4 * n);
+  return HS_OK;
+}
+int hso_set_sensors(hso_problem* p, int n, const double* T) {
+  p->P.n_sensor = n;
+  p->P.sensor_T_bs.assign(T, T + 7 * n);
+  return HS_OK;
+}
+int hso_set_landmarks(hso_problem* p, int n, const double* xyz, const uint8_t* c) {
+  Problem& P = p->P;
+  P.n_lm = n;
+  P.lm.assign(xyz, xyz + 3 * n);
+  P.lm_const.assign(n, 0);
+  if (c) P.lm_const.assign(c, c + n);
+  return HS_OK;
+}
+int hso_set_imu(hso_problem* p, const double* T, const double* ig, const double* ia, const double* Sg, const double* Xa, int kb, double bt0,
+                double bdt, int nb, const double* bg, const double* ba, int bias_constant) {
+  CHECK_ARG(kb >= 2 && kb <= kMaxOrder && nb >= kb && bdt > 0, "bad bias spline");
+  Problem& P = p->P;
+  P.has_imu = true;
+  std::memcpy(P.imu_T_bs, T, 7 * 8), std::memcpy(P.imu_i_g, ig, 6 * 8), std::memcpy(P.imu_i_a, ia, 6 * 8);
+  std::memcpy(P.imu_S_g, Sg, 9 * 8), std::memcpy(P.imu_X_a, Xa, 9 * 8);
+  P.kb = kb, P.bias_t0 = bt0, P.bias_dt = bdt, P.n_bias = nb;
+  P.bias_g.assign(bg, bg + 4 * nb), P.bias_a.assign(ba, ba + 4 * nb);
+  P.bias_const = bias_constant != 0;
+  return HS_OK;
+}
+int hso_set_gravity(hso_problem* p, const double* g, int constant) {
+  std::memcpy(p->P.gravity, g, 24);
+  p->P.gravity_const = constant != 0;
+  return HS_OK;
+}
+int hso_set_pixel_residuals(hso_problem* p, int n, const double* st, const double* px, const int32_t* lm, const int32_t* cam) {
+  Problem& P = p->P;
+  P.px_stamp.assign(st, st + n), P.px_meas.assign(px, px + 2 * n), P.px_lm.assign(lm, lm + n), P.px_cam.assign(cam, cam + n);
+  return HS_OK;
+}
+int hso_set_bearing_residuals(hso_problem* p, int n, const double* st, const double* b, const int32_t* lm, const int32_t* cam) {
+  Problem& P = p->P;
+  P.br_stamp.assign(st, st + n), P.br_meas.assign(b, b + 3 * n), P.br_lm.assign(lm, lm + n), P.br_cam.assign(cam, cam + n);
+  return HS_OK;
+}
+int hso_set_prior_residuals(hso_problem* p, int n, const double* st, const double* poses, const int32_t* sensor) {
+  Problem& P = p->P;
+  P.pr_stamp.assign(st, st + n), P.pr_meas.assign(poses, poses + 7 * n), P.pr_sensor.assign(sensor, sensor + n);
+  return HS_OK;
+}
+int hso_set_inertial_residuals(hso_problem* p, int n, const double* st, const double* m) {
+  Problem& P = p->P;
+  P.in_stamp.assign(st, st + n), P.in_meas.assign(m, m + 6 * n);
+  return HS_OK;
+}
+
+int hso_num_residuals(hso_problem* p, int type) { return p->P.n_res(FactorType(type)); }
+int hso_dim_pose(hso_problem* p) { return p->P.dim_pose(); }
+
+int hso_residual_layout(hso_problem* p, int type, int idx, int32_t* num_blocks, int32_t* indices, int32_t* sizes, int32_t* offsets,
+                        int32_t* block_ids, int32_t* num_parameters, int32_t* num_residuals) {
+  const Problem& P = p->P;
+  CHECK_ARG(type >= 0 && type < 4 && idx >= 0 && idx < P.n_res(FactorType(type)), "residual index out of range");
+  const Layout L = make_layout(FactorType(type), P.k, P.kb);
+  *num_blocks = int(L.sizes.size());
+  indices[0] = L.static_state_idx, indices[1] = L.static_sensor_idx, indices[2] = L.dynamic_sensor_idx, indices[3] = L.static_observation_idx;
+  for (size_t i = 0; i < L.sizes.size(); ++i) sizes[i] = L.sizes[i], offsets[i] = L.offsets[i];
+  *num_parameters = L.num_parameters, *num_residuals = L.num_residuals;
+  double st = 0, u;
+  switch (type) {
+    case kPixel: st = P.px_stamp[idx]; break;
+    case kBearing: st = P.br_stamp[idx]; break;
+    case kPrior: st = P.pr_stamp[idx]; break;
+    case kInertial: st = P.in_stamp[idx]; break;
+  }
+  const int first = segment_of(st, P.t0, P.dt, P.k, &u);
+  int b = 0;
+  for (int j = 0; j < P.k; ++j) block_ids[b++] = first + j;
+  if (type == kPixel || type == kBearing) {
+    const int cam = type == kPixel ? P.px_cam[idx] : P.br_cam[idx];
+    block_ids[b++] = cam, block_ids[b++] = cam, block_ids[b++] = cam;
+    block_ids[b++] = type == kPixel ? P.px_lm[idx] : P.br_lm[idx];
+  } else if (type == kPrior) {
+    block_ids[b++] = P.pr_sensor[idx];
+  } else {
+    for (int j = 0; j < 5; ++j) block_ids[b++] = 0;
+    const int fb = segment_of(st, P.bias_t0, P.bias_dt, P.kb, &u);
+    for (int j = 0; j < P.kb; ++j) block_ids[b++] = fb + j;
+    for (int j = 0; j < P.kb; ++j) block_ids[b++] = fb + j;
+    block_ids[b++] = 0;
+  }
+  return HS_OK;
+}
+
+int hso_linearize(hso_problem* p, int type, int robustify, const hs_linearization* out) {
+  const Problem& P = p->P;
+  const FactorType t = FactorType(type);
+  const int n = P.n_res(t), k = P.k, kb = P.kb;
+  Evaluator ev(P);
+  Linearized lin;
+  for (int i = 0; i < n; ++i) {
+    ev.evaluate(t, i, robustify != 0, &lin);
+    const int nr = lin.n_res;
+    if (out->r)
+      for (int r = 0; r < nr; ++r) out->r[size_t(i) * nr + r] = lin.r[r];
+    if (out->J_state) std::memcpy(out->J_state + size_t(i) * nr * 6 * k, lin.J_state.data(), sizeof(double) * nr * 6 * k);
+    if (out->J_landmark && lin.lm >= 0) std::memcpy(out->J_landmark + size_t(i) * nr * 3, lin.J_lm, sizeof(double) * nr * 3);
+    if (t == kInertial) {
+      if (out->J_bias_g) std::memcpy(out->J_bias_g + size_t(i) * 6 * 3 * kb, lin.J_bias_g.data(), sizeof(double) * 6 * 3 * kb);
+      if (out->J_bias_a) std::memcpy(out->J_bias_a + size_t(i) * 6 * 3 * kb, lin.J_bias_a.data(), sizeof(double) * 6 * 3 * kb);
+      if (out->J_gravity) std::memcpy(out->J_gravity + size_t(i) * 12, lin.J_grav, sizeof(double) * 12);
+      if (out->first_bias) out->first_bias[i] = lin.first_bias;
+    }
+    if (out->first_cp) out->first_cp[i] = lin.first_cp;
+    if (out->cost) out->cost[i] = lin.cost;
+  }
+  return HS_OK;
+}
+
+int hso_cost_function_evaluate(hso_problem* p, int type, int idx, const double* const* parameters, double* residuals, double** jacobians) {
+  const Problem& P = p->P;
+  const FactorType t = FactorType(type);
+  CHECK_ARG(idx >= 0 && idx < P.n_res(t), "residual index out of range");
+  const Basis basis = make_basis(P.k), bias_basis = make_basis(P.kb);
+  const Layout L = make_layout(t, P.k, P.kb);
+  double stamp = 0;
+  const double* meas = nullptr;
+  switch (t) {
+    case kPixel: stamp = P.px_stamp[idx], meas = &P.px_meas[2 * idx]; break;
+    case kBearing: stamp = P.br_stamp[idx], meas = &P.br_meas[3 * idx]; break;
+    case kPrior: stamp = P.pr_stamp[idx], meas = &P.pr_meas[7 * idx]; break;
+    case kInertial: stamp = P.in_stamp[idx], meas = &P.in_meas[6 * idx]; break;
+  }
+  const CostContext ctx = {t, &basis, &bias_basis, stamp, meas};
+  cost_evaluate(ctx, L, parameters, residuals, jacobians);
+  return HS_OK;
+}
+
+int hso_cost(hso_problem* p, double* cost) {
+  *cost = Solver(p->P).total_cost();
+  return HS_OK;
+}
+
+int hso_reduced_system(hso_problem* p, double radius, double* S, double* g) {
+  LM lm(p->P);
+  lm.radius = radius;
+  NormalEquations ne;
+  lm.solver.build(&ne);
+  lm.compute_scaling(ne);
+  std::vector<double> sp, sl;
+  ReducedSystem rs;
+  if (!lm.solve_step(ne, &sp, &sl, &rs)) {
+    p->err = "reduced system not positive definite";
+    // still export the system
+  }
+  std::memcpy(S, rs.S.data(), sizeof(double) * rs.S.size());
+  std::memcpy(g, rs.g.data(), sizeof(double) * rs.g.size());
+  return HS_OK;
+}
+
+int hso_solve(hso_problem* p, int max_iterations, hs_summary* summary, hs_iteration* iterations) {
+  const auto t0 = std::chrono::steady_clock::now();
+  LM lm(p->P);
+  const Summary s = lm.run(max_iterations);
+  const auto t1 = std::chrono::steady_clock::now();
+  std::memset(summary, 0, sizeof(*summary));
+  summary->initial_cost = s.initial_cost, summary->final_cost = s.final_cost;
+  summary->num_iterations = s.num_iterations, summary->num_successful_steps = s.num_successful_steps;
+  summary->termination = s.termination;
+  summary->num_residual_blocks = p->P.n_res(kPixel) + p->P.n_res(kBearing) + p->P.n_res(kPrior) + p->P.n_res(kInertial);
+  summary->total_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+  if (iterations) {
+    std::memset(iterations, 0, sizeof(hs_iteration) * (max_iterations + 1));
+    for (size_t i = 0; i < s.iterations.size() && int(i) <= max_iterations; ++i) {
+      const IterationRecord& r = s.iterations[i];
+      iterations[i] = {r.iteration, r.step_is_valid, r.step_is_successful, 0, r.cost, r.cost_change, r.gradient_max_norm, r.step_norm, r.relative_decrease, r.radius};
+    }
+  }
+  return HS_OK;
+}
+
+int hso_get_control_points(hso_problem* p, double* cp) {
+  std::memcpy(cp, p->P.cp.data(), sizeof(double) * p->P.cp.size());
+  return HS_OK;
+}
+int hso_get_landmarks(hso_problem* p, double* xyz) {
+  std::memcpy(xyz, p->P.lm.data(), sizeof(double) * p->P.lm.size());
+  return HS_OK;
+}
+int hso_get_bias(hso_problem* p, double* bg, double* ba) {
+  std::memcpy(bg, p->P.bias_g.data(), sizeof(double) * p->P.bias_g.size());
+  std::memcpy(ba, p->P.bias_a.data(), sizeof(double) * p->P.bias_a.size());
+  return HS_OK;
+}
+int hso_get_gravity(hso_problem* p, double* g) {
+  std::memcpy(g, p->P.gravity, 24);
+  return HS_OK;
+}
+
+int hso_sample_trajectory(hso_problem* p, int n, const double* stamps, double* pose, double* velocity, double* acceleration) {
+  const Problem& P = p->P;
+  const Basis basis = make_basis(P.k);
+  for (int i = 0; i < n; ++i) {
+    double u;
+    const int first = segment_of(stamps[i], P.t0, P.dt, P.k, &u);
+    CHECK_ARG(first >= 0 && first + P.k <= P.n_cp, "stamp outside the spline's valid range");
+    const double* cps[kMaxOrder];
+    for (int j = 0; j < P.k; ++j) cps[j] = &P.cp[8 * (first + j)];
+    SplineValue s;
+    spline_evaluate(basis, cps, u, 1.0 / P.dt, 2, false, &s);
+    double* o = pose + 7 * i;
+    o[0] = s.q.x, o[1] = s.q.y, o[2] = s.q.z, o[3] = s.q.w, o[4] = s.p[0], o[5] = s.p[1], o[6] = s.p[2];
+    if (velocity)
+      for (int c = 0; c < 3; ++c) velocity[6 * i + c] = s.w[c], velocity[6 * i + 3 + c] = s.v[c];
+    if (acceleration)
+      for (int c = 0; c < 3; ++c) acceleration[6 * i + c] = s.al[c], acceleration[6 * i + 3 + c] = s.a[c];
+  }
+  return HS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,7 @@
+"""hyperslam_amd — MI355X-native continuous-time NLLS backend for HyperSLAM (hot path only).
+
+The product is the HIP library ``libhyperslam_hip.so`` behind the C ABI of ``include/hyperslam_hip.h``; this package is the
+thin host-side mirror used by tests, bench.py and the integration examples.
+"""
+from ._lib import HS_BEARING, HS_INERTIAL, HS_PIXEL, HS_PRIOR, load  # noqa: F401
+from .problem import HsError, Problem, Window  # noqa: F401

@@ -1,0 +1,738 @@
+// capi.hip — C ABI of libhyperslam_hip.so (include/hyperslam_hip.h): host-side table management, structure building
+// and the launch sequence of the device-resident Levenberg-Marquardt loop.
+//
+// Replaces CeresOptimizer::{add(...), updateState, addLandmark, updateLandmarks, optimize}
+// (/root/reference/internal/hyper/optimizers/ceres/optimizer.cpp:189-382) behind flat tables. There is no CPU fallback:
+// every evaluation entry point runs the gfx950 kernels of kernels.hpp and fails with HS_ERR_DEVICE if no GPU is usable.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "host_structure.hpp"
+#include "kernels.hpp"
+
+using namespace hs;
+
+namespace {
+
+template <class T>
+struct DBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  ~DBuf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t reserve(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr, cap = 0;
+    const hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(T));
+    if (e == hipSuccess) cap = std::max<size_t>(n, 1);
+    return e;
+  }
+  hipError_t upload(const std::vector<T>& h, hipStream_t s) {
+    hipError_t e = reserve(h.size());
+    if (e != hipSuccess || h.empty()) return e;
+    return hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s);
+  }
+};
+
+}  // namespace
+
+struct hs_problem {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  bool dirty = true;  // tables changed since the last prepare()
+
+  // host tables (caller's table order)
+  int k = 0, n_cp = 0;
+  double t0 = 0, dt = 0;
+  std::vector<double> cp;
+  std::vector<uint8_t> cp_const;
+  int rot_const = 0, trans_const = 0;
+  int n_cam = 0;
+  std::vector<double> cam;  // n x 16
+  int n_sensor = 0;
+  std::vector<double> sensor;  // n x 8
+  int n_lm = 0;
+  std::vector<double> lm;
+  std::vector<uint8_t> lm_const;
+  std::vector<double> px_stamp, px_meas, br_stamp, br_meas, pr_stamp, pr_meas, in_stamp, in_meas;
+  std::vector<int32_t> px_lm, px_cam, br_lm, br_cam, pr_sensor;
+  bool has_imu = false;
+  double imu_T_bs[7], imu_i_g[6], imu_i_a[6], imu_S_g[9], imu_X_a[9];
+  int kb = 4, n_bias = 0;
+  double bias_t0 = 0, bias_dt = 1;
+  std::vector<double> bias_g, bias_a;
+  int bias_const = 0;
+  double gravity[3] = {0, 0, -9.80665};
+  int gravity_const = 1;
+
+  // structure
+  VisualStructure vs;
+  std::vector<int> pr_order;  // segment-major order of prior residuals (device index -> table index)
+  std::vector<int> pr_first, pr_seg_ptr;
+
+  // device
+  DBuf<double> d_cp, d_cp_cand, d_cam, d_sensor, d_lm, d_lm_cand;
+  DBuf<uint8_t> d_cp_const, d_lm_const;
+  DBuf<int> d_lm_ptr, d_lm_cfirst, d_lm_ncp, d_lm_yoff, d_cf_ptr;
+  DBuf<double> d_lm_scale, d_lm_L, d_lm_yhat, d_lm_sb, d_lm_D2, d_lm_mcc, d_Y;
+  DBuf<double> d_v_stamp, d_v_meas, d_v_rec;
+  DBuf<int> d_v_lm, d_v_info, d_v_first, d_v_pos, d_v_seg_ptr, d_v_dbgpos;
+  DBuf<double> d_p_stamp, d_p_meas, d_p_rec;
+  DBuf<int> d_p_sensor, d_p_first, d_p_seg_ptr;
+  DBuf<double> d_scale_p, d_Sb, d_Ub, d_g_s, d_g_full, d_D2p, d_step_p, d_delta_p;
+  DBuf<double> d_cost_part, d_cand_part, d_norm_part, d_dbg, d_dbg_cost;
+  DBuf<DevState> d_state;
+  Tables T;
+  int nb_vis = 0, nb_pri = 0, nb_cp = 0;
+  hs_allreduce_fn allreduce = nullptr;
+  void* allreduce_user = nullptr;
+};
+
+#define HS_FAIL(code, msg) \
+  do {                     \
+    p->err = (msg);        \
+    return (code);         \
+  } while (0)
+#define HIP_TRY(expr)                                                                             \
+  do {                                                                                            \
+    const hipError_t e__ = (expr);                                                                \
+    if (e__ != hipSuccess) {                                                                      \
+      p->err = std::string(#expr) + ": " + hipGetErrorString(e__);                                \
+      return HS_ERR_DEVICE;                                                                       \
+    }                                                                                             \
+  } while (0)
+
+namespace {
+
+int prepare(hs_problem* p) {
+  if (!p->dirty) return HS_OK;
+  if (p->n_cp == 0) HS_FAIL(HS_ERR_STATE, "hs_set_spline has not been called");
+  if (p->k != 4 && p->k != 6) HS_FAIL(HS_ERR_INVALID, "device kernels are instantiated for spline order 4 and 6");
+  HIP_TRY(hipSetDevice(p->device));
+  hipStream_t s = p->stream;
+  const int k = p->k, n_seg = p->n_cp - k + 1;
+  const int n_px = int(p->px_stamp.size()), n_br = int(p->br_stamp.size());
+  for (int i = 0; i < n_px; ++i)
+    if (p->px_cam[i] < 0 || p->px_cam[i] >= p->n_cam) HS_FAIL(HS_ERR_INVALID, "pixel residual references a camera outside the camera table");
+  for (int i = 0; i < n_br; ++i)
+    if (p->br_cam[i] < 0 || p->br_cam[i] >= p->n_cam) HS_FAIL(HS_ERR_INVALID, "bearing residual references a camera outside the camera table");
+  VisualInput in = {k, p->n_cp, p->n_lm, p->t0, p->dt, n_px, n_br, p->px_stamp.data(), p->br_stamp.data(), p->px_lm.data(), p->br_lm.data()};
+  if (!build_visual_structure(in, &p->vs, &p->err)) return HS_ERR_INVALID;
+  const VisualStructure& vs = p->vs;
+  if (6 * vs.bw > kBlock || size_t(6 * vs.bw) * (6 * vs.bw + 2) * 8 + size_t(6) * p->n_cp * 8 > 160 * 1024 - 1024)
+    HS_FAIL(HS_ERR_INVALID, "landmark tracks span too many control points for the LDS-resident banded factorisation");
+  const int n_vis = n_px + n_br;
+
+  // ---- visual tables (landmark-major) ----
+  std::vector<double> v_stamp(n_vis), v_meas(size_t(3) * n_vis, 0.0);
+  std::vector<int> v_info(n_vis), v_dbgpos(n_vis);
+  for (int q = 0; q < n_vis; ++q) {
+    const int ti = vs.table_idx[q];
+    if (vs.table_type[q] == HS_PIXEL) {
+      v_stamp[q] = p->px_stamp[ti];
+      v_meas[3 * q] = p->px_meas[2 * ti], v_meas[3 * q + 1] = p->px_meas[2 * ti + 1];
+      v_info[q] = p->px_cam[ti];
+      v_dbgpos[q] = ti;
+    } else {
+      v_stamp[q] = p->br_stamp[ti];
+      for (int c = 0; c < 3; ++c) v_meas[3 * q + c] = p->br_meas[3 * ti + c];
+      v_info[q] = p->br_cam[ti] | (1 << 16);
+      v_dbgpos[q] = n_px + ti;
+    }
+  }
+  // landmarks in device order
+  std::vector<double> lm_dev(size_t(3) * p->n_lm);
+  std::vector<uint8_t> lmc_dev(p->n_lm);
+  for (int d = 0; d < p->n_lm; ++d) {
+    const int t = vs.table_of_dev[d];
+    for (int c = 0; c < 3; ++c) lm_dev[3 * d + c] = p->lm[3 * t + c];
+    lmc_dev[d] = p->lm_const[t];
+  }
+  // ---- prior tables (segment-major) ----
+  const int n_pri = int(p->pr_stamp.size());
+  p->pr_order.resize(n_pri);
+  std::vector<int> first_tab(n_pri);
+  for (int i = 0; i < n_pri; ++i) {
+    first_tab[i] = h_segment_first(p->pr_stamp[i], p->t0, p->dt, k);
+    if (first_tab[i] < 0 || first_tab[i] >= n_seg) HS_FAIL(HS_ERR_INVALID, "prior residual stamp outside the valid range of the spline");
+    if (p->pr_sensor[i] < 0 || p->pr_sensor[i] >= p->n_sensor) HS_FAIL(HS_ERR_INVALID, "prior residual references a sensor outside the sensor table");
+    p->pr_order[i] = i;
+  }
+  std::stable_sort(p->pr_order.begin(), p->pr_order.end(), [&](int a, int b) { return first_tab[a] < first_tab[b]; });
+  std::vector<double> p_stamp(n_pri), p_meas(size_t(7) * n_pri);
+  std::vector<int> p_sensor(n_pri);
+  p->pr_first.resize(n_pri);
+  p->pr_seg_ptr.assign(n_seg + 1, 0);
+  for (int d = 0; d < n_pri; ++d) {
+    const int t = p->pr_order[d];
+    p_stamp[d] = p->pr_stamp[t], p_sensor[d] = p->pr_sensor[t], p->pr_first[d] = first_tab[t];
+    for (int c = 0; c < 7; ++c) p_meas[7 * d + c] = p->pr_meas[7 * t + c];
+    p->pr_seg_ptr[first_tab[t] + 1]++;
+  }
+  for (int sgm = 0; sgm < n_seg; ++sgm) p->pr_seg_ptr[sgm + 1] += p->pr_seg_ptr[sgm];
+  if (!p->in_stamp.empty()) HS_FAIL(HS_ERR_INVALID, "inertial residuals are not supported by this build yet");
+
+  // ---- upload ----
+  HIP_TRY(p->d_cp.upload(p->cp, s));
+  HIP_TRY(p->d_cp_cand.reserve(p->cp.size()));
+  HIP_TRY(p->d_cp_const.upload(p->cp_const, s));
+  HIP_TRY(p->d_cam.upload(p->cam, s));
+  HIP_TRY(p->d_sensor.upload(p->sensor, s));
+  HIP_TRY(p->d_lm.upload(lm_dev, s));
+  HIP_TRY(p->d_lm_cand.reserve(lm_dev.size()));
+  HIP_TRY(p->d_lm_const.upload(lmc_dev, s));
+  HIP_TRY(p->d_lm_ptr.upload(vs.lm_ptr, s));
+  HIP_TRY(p->d_lm_cfirst.upload(vs.lm_cfirst, s));
+  HIP_TRY(p->d_lm_ncp.upload(vs.lm_ncp, s));
+  HIP_TRY(p->d_lm_yoff.upload(vs.lm_yoff, s));
+  HIP_TRY(p->d_cf_ptr.upload(vs.cf_ptr, s));
+  const size_t nl = size_t(std::max(p->n_lm, 1));
+  HIP_TRY(p->d_lm_scale.reserve(3 * nl));
+  HIP_TRY(p->d_lm_L.reserve(6 * nl));
+  HIP_TRY(p->d_lm_yhat.reserve(3 * nl));
+  HIP_TRY(p->d_lm_sb.reserve(3 * nl));
+  HIP_TRY(p->d_lm_D2.reserve(3 * nl));
+  HIP_TRY(p->d_lm_mcc.reserve(2 * nl));
+  HIP_TRY(p->d_Y.reserve(size_t(vs.y_total) + 1));
+  HIP_TRY(p->d_v_stamp.upload(v_stamp, s));
+  HIP_TRY(p->d_v_meas.upload(v_meas, s));
+  HIP_TRY(p->d_v_lm.upload(vs.lm_dev, s));
+  HIP_TRY(p->d_v_info.upload(v_info, s));
+  HIP_TRY(p->d_v_first.upload(vs.first, s));
+  HIP_TRY(p->d_v_pos.upload(vs.pos, s));
+  HIP_TRY(p->d_v_dbgpos.upload(v_dbgpos, s));
+  HIP_TRY(p->d_v_seg_ptr.upload(vs.seg_ptr, s));
+  HIP_TRY(p->d_v_rec.reserve(size_t(n_vis) * (8 + 12 * k) + 1));
+  HIP_TRY(p->d_p_stamp.upload(p_stamp, s));
+  HIP_TRY(p->d_p_meas.upload(p_meas, s));
+  HIP_TRY(p->d_p_sensor.upload(p_sensor, s));
+  HIP_TRY(p->d_p_first.upload(p->pr_first, s));
+  HIP_TRY(p->d_p_seg_ptr.upload(p->pr_seg_ptr, s));
+  HIP_TRY(p->d_p_rec.reserve(size_t(n_pri) * (6 + 36 * k) + 1));
+  const int np = 6 * p->n_cp, ncb = 6 * vs.bw;
+  HIP_TRY(p->d_scale_p.reserve(np));
+  HIP_TRY(p->d_Sb.reserve(size_t(np) * ncb));
+  HIP_TRY(p->d_Ub.reserve(size_t(np) * ncb));
+  HIP_TRY(p->d_g_s.reserve(np));
+  HIP_TRY(p->d_g_full.reserve(np));
+  HIP_TRY(p->d_D2p.reserve(np));
+  HIP_TRY(p->d_step_p.reserve(np));
+  HIP_TRY(p->d_delta_p.reserve(np));
+  p->nb_vis = (n_vis + kBlock - 1) / kBlock, p->nb_pri = (n_pri + kBlock - 1) / kBlock;
+  p->nb_cp = std::max((p->n_cp + kBlock - 1) / kBlock, 1);
+  HIP_TRY(p->d_cost_part.reserve(p->nb_vis + p->nb_pri + 1));
+  HIP_TRY(p->d_cand_part.reserve(p->nb_vis + p->nb_pri + 1));
+  const int nb_norm = std::max(p->nb_cp, std::min(64, (p->n_lm + kBlock - 1) / kBlock));
+  HIP_TRY(p->d_norm_part.reserve(2 * size_t(nb_norm)));
+  HIP_TRY(p->d_state.reserve(1));
+
+  Tables& T = p->T;
+  std::memset(&T, 0, sizeof(T));
+  T.sp = Spline{k, p->n_cp, p->t0, p->dt, 1.0 / p->dt, p->rot_const, p->trans_const};
+  T.basis = make_basis_coef(k);
+  T.cp = p->d_cp.p, T.cp_cand = p->d_cp_cand.p, T.cp_const = p->d_cp_const.p;
+  T.cam = p->d_cam.p, T.sensor = p->d_sensor.p;
+  T.n_lm = p->n_lm, T.lm = p->d_lm.p, T.lm_cand = p->d_lm_cand.p, T.lm_const = p->d_lm_const.p;
+  T.lm_ptr = p->d_lm_ptr.p, T.lm_cfirst = p->d_lm_cfirst.p, T.lm_ncp = p->d_lm_ncp.p, T.lm_yoff = p->d_lm_yoff.p, T.cf_ptr = p->d_cf_ptr.p;
+  T.lm_scale = p->d_lm_scale.p, T.lm_L = p->d_lm_L.p, T.lm_yhat = p->d_lm_yhat.p, T.lm_sb = p->d_lm_sb.p, T.lm_D2 = p->d_lm_D2.p;
+  T.lm_mcc = p->d_lm_mcc.p, T.Y = p->d_Y.p;
+  T.n_vis = n_vis, T.v_stamp = p->d_v_stamp.p, T.v_meas = p->d_v_meas.p, T.v_lm = p->d_v_lm.p, T.v_info = p->d_v_info.p;
+  T.v_first = p->d_v_first.p, T.v_pos = p->d_v_pos.p, T.v_rec = p->d_v_rec.p, T.v_seg_ptr = p->d_v_seg_ptr.p;
+  T.n_pri = n_pri, T.p_stamp = p->d_p_stamp.p, T.p_meas = p->d_p_meas.p, T.p_sensor = p->d_p_sensor.p, T.p_first = p->d_p_first.p;
+  T.p_rec = p->d_p_rec.p, T.p_seg_ptr = p->d_p_seg_ptr.p;
+  T.n_seg = n_seg, T.bw = vs.bw, T.np = np;
+  T.scale_p = p->d_scale_p.p, T.Sb = p->d_Sb.p, T.Ub = p->d_Ub.p, T.g_s = p->d_g_s.p, T.g_full = p->d_g_full.p, T.D2p = p->d_D2p.p;
+  T.step_p = p->d_step_p.p, T.delta_p = p->d_delta_p.p;
+  T.cost_part = p->d_cost_part.p, T.cand_part = p->d_cand_part.p, T.n_cost_part = p->nb_vis + p->nb_pri;
+  T.norm_part = p->d_norm_part.p, T.n_norm_part = nb_norm;
+  T.st = p->d_state.p;
+  HIP_TRY(hipStreamSynchronize(s));  // host staging vectors go out of scope
+  p->dirty = false;
+  return HS_OK;
+}
+
+int reset_state(hs_problem* p, int max_iterations, double radius) {
+  DevState st;
+  std::memset(&st, 0, sizeof(st));
+  st.radius = radius, st.decrease_factor = 2.0, st.max_iterations = max_iterations;
+  HIP_TRY(hipMemcpyAsync(p->d_state.p, &st, sizeof(st), hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));  // `st` is a stack object
+  return HS_OK;
+}
+
+size_t cp_lds_bytes(const hs_problem* p) { return size_t(8) * p->n_cp * sizeof(double); }
+
+template <int K>
+int launch_linearize(hs_problem* p) {
+  const Tables& T = p->T;
+  hipStream_t s = p->stream;
+  if (T.n_vis) k_linearize_visual<K><<<p->nb_vis, kBlock, cp_lds_bytes(p), s>>>(T, T.v_rec, T.v_pos, 1, T.cost_part, nullptr);
+  if (T.n_pri) k_linearize_prior<K><<<p->nb_pri, kBlock, cp_lds_bytes(p), s>>>(T, T.p_rec, T.cost_part + p->nb_vis, nullptr);
+  HIP_TRY(hipGetLastError());
+  return HS_OK;
+}
+
+template <int K>
+int launch_build(hs_problem* p) {
+  const Tables& T = p->T;
+  hipStream_t s = p->stream;
+  if (T.n_lm) k_landmark<K><<<(T.n_lm + kBlock / 64 - 1) / (kBlock / 64), kBlock, 0, s>>>(T);
+  k_hpp_diag<K><<<T.sp.n_cp, kBlock, 0, s>>>(T);
+  const size_t lds = (size_t(6) * 6 * T.bw + 16 + 6 * kBlock + 64) * sizeof(double);
+  k_build_reduced<K><<<T.sp.n_cp, kBlock, lds, s>>>(T);
+  k_mark_scaling<<<1, 64, 0, s>>>(T);
+  k_cost_reduce<<<1, kBlock, 0, s>>>(T);
+  HIP_TRY(hipGetLastError());
+  return HS_OK;
+}
+
+template <int K>
+int launch_step(hs_problem* p) {
+  const Tables& T = p->T;
+  hipStream_t s = p->stream;
+  const int ncb = 6 * T.bw;
+  const size_t chol_lds = (size_t(ncb) * (ncb + 2) + T.np) * sizeof(double);
+  k_band_cholesky_solve<<<1, kCholThreads, chol_lds, s>>>(T);
+  if (T.n_lm) k_backsub_landmarks<<<(T.n_lm + kBlock / 64 - 1) / (kBlock / 64), kBlock, 0, s>>>(T);
+  k_model_cost<<<1, kBlock, 0, s>>>(T);
+  k_retract<<<T.n_norm_part, kBlock, 0, s>>>(T);
+  if (T.n_vis) k_cost_visual<K><<<p->nb_vis, kBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.lm_cand, T.cand_part);
+  if (T.n_pri) k_cost_prior<K><<<p->nb_pri, kBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.cand_part + p->nb_vis);
+  k_decide<<<1, kBlock, 0, s>>>(T);
+  const int nb_commit = std::max((8 * T.sp.n_cp + kBlock - 1) / kBlock, 1);
+  k_commit<<<nb_commit, kBlock, 0, s>>>(T);
+  HIP_TRY(hipGetLastError());
+  return HS_OK;
+}
+
+int set_func_attributes(hs_problem* p) {
+  // opt in to > 64 KiB dynamic LDS for the factorisation
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_cholesky_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+  return HS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hs_version(void) { return 1; }
+const char* hs_arch(void) { return "gfx950"; }
+
+int hs_create(int device, void* stream, hs_problem** out) {
+  if (!out) return HS_ERR_INVALID;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return HS_ERR_DEVICE;
+  hs_problem* p = new hs_problem();
+  p->device = device;
+  if (hipSetDevice(device) != hipSuccess) {
+    delete p;
+    return HS_ERR_DEVICE;
+  }
+  if (stream) {
+    p->stream = static_cast<hipStream_t>(stream);
+  } else {
+    if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete p;
+      return HS_ERR_DEVICE;
+    }
+    p->own_stream = true;
+  }
+  if (set_func_attributes(p) != HS_OK) {
+    const std::string e = p->err;
+    std::fprintf(stderr, "hyperslam_hip: %s\n", e.c_str());
+    delete p;
+    return HS_ERR_DEVICE;
+  }
+  *out = p;
+  return HS_OK;
+}
+
+int hs_destroy(hs_problem* p) {
+  if (!p) return HS_OK;
+  (void)hipSetDevice(p->device);
+  (void)hipStreamSynchronize(p->stream);
+  if (p->own_stream) (void)hipStreamDestroy(p->stream);
+  delete p;
+  return HS_OK;
+}
+
+const char* hs_last_error(const hs_problem* p) { return p ? p->err.c_str() : "null handle"; }
+
+int hs_set_spline(hs_problem* p, int order, double t0, double dt, int n_cp, const double* cp, const uint8_t* cp_constant, int rc, int tc) {
+  if (!p) return HS_ERR_INVALID;
+  if (order < 2 || order > hsd::kMaxOrder) HS_FAIL(HS_ERR_INVALID, "spline order out of range");
+  if (n_cp < order || !(dt > 0) || !cp) HS_FAIL(HS_ERR_INVALID, "need n_cp >= order, dt > 0 and a control-point table");
+  p->k = order, p->t0 = t0, p->dt = dt, p->n_cp = n_cp;
+  p->cp.assign(cp, cp + size_t(8) * n_cp);
+  p->cp_const.assign(n_cp, 0);
+  if (cp_constant) p->cp_const.assign(cp_constant, cp_constant + n_cp);
+  p->rot_const = rc != 0, p->trans_const = tc != 0;
+  p->dirty = true;
+  return HS_OK;
+}
+
+int hs_set_cameras(hs_problem* p, int n, const double* T_bs, const double* intr, const double* dist) {
+  if (!p) return HS_ERR_INVALID;
+  if (n < 0 || n > 0xffff || (n && (!T_bs || !intr || !dist))) HS_FAIL(HS_ERR_INVALID, "bad camera table");
+  p->n_cam = n;
+  p->cam.assign(size_t(kCamStride) * n, 0.0);
+  for (int i = 0; i < n; ++i) {
+    double* c = &p->cam[size_t(kCamStride) * i];
+    std::memcpy(c, T_bs + 7 * i, 56), std::memcpy(c + 7, intr + 4 * i, 32), std::memcpy(c + 11, dist + 4 * i, 32);
+  }
+  p->dirty = true;
+  return HS_OK;
+}
+
+int hs_set_sensors(hs_problem* p, int n, const double* T_bs) {
+  if (!p) return HS_ERR_INVALID;
+  if (n < 0 || (n && !T_bs)) HS_FAIL(HS_ERR_INVALID, "bad sensor table");
+  p->n_sensor = n;
+  p->sensor.assign(size_t(8) * n, 0.0);
+  for (int i = 0; i < n; ++i) std::memcpy(&p->sensor[size_t(8) * i], T_bs + 7 * i, 56);
+  p->dirty = true;
+  return HS_OK;
+}
+
+int hs_set_landmarks(hs_problem* p, int n, const double* xyz, const uint8_t* constant) {
+  if (!p) return HS_ERR_INVALID;
+  if (n < 0 || (n && !xyz)) HS_FAIL(HS_ERR_INVALID, "bad landmark table");
+  p->n_lm = n;
+  p->lm.assign(xyz, xyz + size_t(3) * n);
+  p->lm_const.assign(n, 0);
+  if (constant) p->lm_const.assign(constant, constant + n);
+  p->dirty = true;
+  return HS_OK;
+}
+
+int hs_set_imu(hs_problem* p, const double* T_bs, const double* i_g, const double* i_a, const double* S_g, const double* X_a, int bias_order,
+               double bias_t0, double bias_dt, int n_bias, const double* bias_g, const double* bias_a, int bias_constant) {
+  if (!p) return HS_ERR_INVALID;
+  if (!T_bs || !i_g || !i_a || !S_g || !X_a || !bias_g || !bias_a) HS_FAIL(HS_ERR_INVALID, "null IMU table");
+  if (bias_order < 2 || bias_order > hsd::kMaxOrder || n_bias < bias_order || !(bias_dt > 0)) HS_FAIL(HS_ERR_INVALID, "bad bias spline");
+  p->has_imu = true;
+  std::memcpy(p->imu_T_bs, T_bs, 56), std::memcpy(p->imu_i_g, i_g, 48), std::memcpy(p->imu_i_a, i_a, 48);
+  std::memcpy(p->imu_S_g, S_g, 72), std::memcpy(p->imu_X_a, X_a, 72);
+  p->kb = bias_order, p->bias_t0 = bias_t0, p->bias_dt = bias_dt, p->n_bias = n_bias;
+  p->bias_g.assign(bias_g, bias_g + size_t(4) * n_bias), p->bias_a.assign(bias_a, bias_a + size_t(4) * n_bias);
+  p->bias_const = bias_constant != 0;
+  p->dirty = true;
+  return HS_OK;
+}
+
+int hs_set_gravity(hs_problem* p, const double* g, int constant) {
+  if (!p || !g) return HS_ERR_INVALID;
+  std::memcpy(p->gravity, g, 24);
+  p->gravity_const = constant != 0;
+  p->dirty = true;
+  return HS_OK;
+}
+
+int hs_set_pixel_residuals(hs_problem* p, int n, const double* st, const double* px, const int32_t* lm, const int32_t* cam) {
+  if (!p) return HS_ERR_INVALID;
+  if (n < 0 || (n && (!st || !px || !lm || !cam))) HS_FAIL(HS_ERR_INVALID, "bad pixel residual table");
+  p->px_stamp.assign(st, st + n), p->px_meas.assign(px, px + size_t(2) * n), p->px_lm.assign(lm, lm + n), p->px_cam.assign(cam, cam + n);
+  p->dirty = true;
+  return HS_OK;
+}
+int hs_set_bearing_residuals(hs_problem* p, int n, const double* st, const double* b, const int32_t* lm, const int32_t* cam) {
+  if (!p) return HS_ERR_INVALID;
+  if (n < 0 || (n && (!st || !b || !lm || !cam))) HS_FAIL(HS_ERR_INVALID, "bad bearing residual table");
+  p->br_stamp.assign(st, st + n), p->br_meas.assign(b, b + size_t(3) * n), p->br_lm.assign(lm, lm + n), p->br_cam.assign(cam, cam + n);
+  p->dirty = true;
+  return HS_OK;
+}
+int hs_set_prior_residuals(hs_problem* p, int n, const double* st, const double* poses, const int32_t* sensor) {
+  if (!p) return HS_ERR_INVALID;
+  if (n < 0 || (n && (!st || !poses || !sensor))) HS_FAIL(HS_ERR_INVALID, "bad prior residual table");
+  p->pr_stamp.assign(st, st + n), p->pr_meas.assign(poses, poses + size_t(7) * n), p->pr_sensor.assign(sensor, sensor + n);
+  p->dirty = true;
+  return HS_OK;
+}
+int hs_set_inertial_residuals(hs_problem* p, int n, const double* st, const double* m) {
+  if (!p) return HS_ERR_INVALID;
+  if (n < 0 || (n && (!st || !m))) HS_FAIL(HS_ERR_INVALID, "bad inertial residual table");
+  p->in_stamp.assign(st, st + n), p->in_meas.assign(m, m + size_t(6) * n);
+  p->dirty = true;
+  return HS_OK;
+}
+
+int hs_num_residuals(hs_problem* p, int type) {
+  if (!p) return -1;
+  switch (type) {
+    case HS_PIXEL: return int(p->px_stamp.size());
+    case HS_BEARING: return int(p->br_stamp.size());
+    case HS_PRIOR: return int(p->pr_stamp.size());
+    case HS_INERTIAL: return int(p->in_stamp.size());
+  }
+  return -1;
+}
+int hs_dim_pose(hs_problem* p) { return p ? 6 * p->n_cp + (p->has_imu ? 6 * p->n_bias + 2 : 0) : -1; }
+
+int hs_residual_layout(hs_problem* p, int type, int idx, int32_t* num_blocks, int32_t* indices, int32_t* sizes, int32_t* offsets, int32_t* block_ids,
+                       int32_t* num_parameters, int32_t* num_residuals) {
+  if (!p) return HS_ERR_INVALID;
+  if (type < 0 || type > 3 || idx < 0 || idx >= hs_num_residuals(p, type)) HS_FAIL(HS_ERR_INVALID, "residual index out of range");
+  if (p->n_cp == 0) HS_FAIL(HS_ERR_STATE, "hs_set_spline has not been called");
+  const BlockLayout L = make_block_layout(type, p->k, p->kb);
+  *num_blocks = L.num_blocks, *num_parameters = L.num_parameters, *num_residuals = L.num_residuals;
+  for (int i = 0; i < 4; ++i) indices[i] = L.indices[i];
+  for (int i = 0; i < L.num_blocks; ++i) sizes[i] = L.sizes[i], offsets[i] = L.offsets[i];
+  double st = 0;
+  switch (type) {
+    case HS_PIXEL: st = p->px_stamp[idx]; break;
+    case HS_BEARING: st = p->br_stamp[idx]; break;
+    case HS_PRIOR: st = p->pr_stamp[idx]; break;
+    case HS_INERTIAL: st = p->in_stamp[idx]; break;
+  }
+  const int first = h_segment_first(st, p->t0, p->dt, p->k);
+  int b = 0;
+  for (int j = 0; j < p->k; ++j) block_ids[b++] = first + j;
+  if (type == HS_PIXEL || type == HS_BEARING) {
+    const int cam = type == HS_PIXEL ? p->px_cam[idx] : p->br_cam[idx];
+    block_ids[b++] = cam, block_ids[b++] = cam, block_ids[b++] = cam;
+    block_ids[b++] = type == HS_PIXEL ? p->px_lm[idx] : p->br_lm[idx];
+  } else if (type == HS_PRIOR) {
+    block_ids[b++] = p->pr_sensor[idx];
+  } else {
+    for (int j = 0; j < 5; ++j) block_ids[b++] = 0;
+    const int fb = h_segment_first(st, p->bias_t0, p->bias_dt, p->kb);
+    for (int j = 0; j < p->kb; ++j) block_ids[b++] = fb + j;
+    for (int j = 0; j < p->kb; ++j) block_ids[b++] = fb + j;
+    block_ids[b++] = 0;
+  }
+  return HS_OK;
+}
+
+int hs_linearize(hs_problem* p, int type, int robustify, const hs_linearization* out) {
+  if (!p || !out) return HS_ERR_INVALID;
+  int rc = prepare(p);
+  if (rc) return rc;
+  rc = reset_state(p, 0, 1e4);
+  if (rc) return rc;
+  const Tables& T = p->T;
+  hipStream_t s = p->stream;
+  const int k = p->k;
+  if (type == HS_PIXEL || type == HS_BEARING) {
+    const int n_px = int(p->px_stamp.size()), n_br = int(p->br_stamp.size());
+    const int n = T.n_vis, REC = 8 + 12 * k;
+    if (n == 0) return HS_OK;
+    HIP_TRY(p->d_dbg.reserve(size_t(n) * REC));
+    HIP_TRY(p->d_dbg_cost.reserve(n));
+    if (k == 4)
+      k_linearize_visual<4><<<p->nb_vis, kBlock, cp_lds_bytes(p), s>>>(T, p->d_dbg.p, p->d_v_dbgpos.p, robustify, nullptr, p->d_dbg_cost.p);
+    else
+      k_linearize_visual<6><<<p->nb_vis, kBlock, cp_lds_bytes(p), s>>>(T, p->d_dbg.p, p->d_v_dbgpos.p, robustify, nullptr, p->d_dbg_cost.p);
+    HIP_TRY(hipGetLastError());
+    std::vector<double> rec(size_t(n) * REC), cost(n);
+    HIP_TRY(hipMemcpyAsync(rec.data(), p->d_dbg.p, rec.size() * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(cost.data(), p->d_dbg_cost.p, cost.size() * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const int base = type == HS_PIXEL ? 0 : n_px, cnt = type == HS_PIXEL ? n_px : n_br, nres = type == HS_PIXEL ? 2 : 1;
+    for (int i = 0; i < cnt; ++i) {
+      const double* r = &rec[size_t(base + i) * REC];
+      for (int rr = 0; rr < nres; ++rr) {
+        if (out->r) out->r[size_t(i) * nres + rr] = r[rr];
+        if (out->J_landmark)
+          for (int c = 0; c < 3; ++c) out->J_landmark[(size_t(i) * nres + rr) * 3 + c] = r[2 + 3 * rr + c];
+        if (out->J_state)
+          for (int c = 0; c < 6 * k; ++c) out->J_state[(size_t(i) * nres + rr) * 6 * k + c] = r[8 + rr * 6 * k + c];
+      }
+      if (out->cost) out->cost[i] = cost[base + i];
+      if (out->first_cp) out->first_cp[i] = h_segment_first(type == HS_PIXEL ? p->px_stamp[i] : p->br_stamp[i], p->t0, p->dt, k);
+    }
+    return HS_OK;
+  }
+  if (type == HS_PRIOR) {
+    const int n = T.n_pri, REC = 6 + 36 * k;
+    if (n == 0) return HS_OK;
+    HIP_TRY(p->d_dbg.reserve(size_t(n) * REC));
+    HIP_TRY(p->d_dbg_cost.reserve(n));
+    if (k == 4)
+      k_linearize_prior<4><<<p->nb_pri, kBlock, cp_lds_bytes(p), s>>>(T, p->d_dbg.p, nullptr, p->d_dbg_cost.p);
+    else
+      k_linearize_prior<6><<<p->nb_pri, kBlock, cp_lds_bytes(p), s>>>(T, p->d_dbg.p, nullptr, p->d_dbg_cost.p);
+    HIP_TRY(hipGetLastError());
+    std::vector<double> rec(size_t(n) * REC), cost(n);
+    HIP_TRY(hipMemcpyAsync(rec.data(), p->d_dbg.p, rec.size() * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(cost.data(), p->d_dbg_cost.p, cost.size() * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int d = 0; d < n; ++d) {
+      const int i = p->pr_order[d];
+      const double* r = &rec[size_t(d) * REC];
+      if (out->r) std::memcpy(out->r + size_t(i) * 6, r, 48);
+      if (out->J_state) std::memcpy(out->J_state + size_t(i) * 36 * k, r + 6, sizeof(double) * 36 * k);
+      if (out->cost) out->cost[i] = cost[d];
+      if (out->first_cp) out->first_cp[i] = p->pr_first[d];
+    }
+    return HS_OK;
+  }
+  HS_FAIL(HS_ERR_INVALID, "inertial residuals are not supported by this build yet");
+}
+
+int hs_cost(hs_problem* p, double* cost) {
+  if (!p || !cost) return HS_ERR_INVALID;
+  int rc = prepare(p);
+  if (rc) return rc;
+  rc = reset_state(p, 0, 1e4);
+  if (rc) return rc;
+  rc = p->k == 4 ? launch_linearize<4>(p) : launch_linearize<6>(p);
+  if (rc) return rc;
+  k_cost_reduce<<<1, kBlock, 0, p->stream>>>(p->T);
+  HIP_TRY(hipGetLastError());
+  DevState st;
+  HIP_TRY(hipMemcpyAsync(&st, p->d_state.p, sizeof(st), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  *cost = st.cost;
+  return HS_OK;
+}
+
+int hs_reduced_system(hs_problem* p, double radius, double* S, double* g) {
+  if (!p || !S || !g) return HS_ERR_INVALID;
+  int rc = prepare(p);
+  if (rc) return rc;
+  rc = reset_state(p, 1, radius);
+  if (rc) return rc;
+  rc = p->k == 4 ? launch_linearize<4>(p) : launch_linearize<6>(p);
+  if (rc) return rc;
+  rc = p->k == 4 ? launch_build<4>(p) : launch_build<6>(p);
+  if (rc) return rc;
+  const int np = p->T.np, ncb = 6 * p->T.bw;
+  std::vector<double> Sb(size_t(np) * ncb), gs(np);
+  HIP_TRY(hipMemcpyAsync(Sb.data(), p->d_Sb.p, Sb.size() * 8, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipMemcpyAsync(gs.data(), p->d_g_s.p, gs.size() * 8, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  const int dim = hs_dim_pose(p);
+  std::memset(S, 0, sizeof(double) * size_t(dim) * dim);
+  for (int rho = 0; rho < np; ++rho) {
+    const int c0 = 6 * (rho / 6);
+    for (int c = 0; c < ncb && c0 + c < np; ++c) {
+      const double v = Sb[size_t(rho) * ncb + c];
+      if (c0 + c >= rho) S[size_t(rho) * dim + c0 + c] = v, S[size_t(c0 + c) * dim + rho] = v;
+    }
+    g[rho] = gs[rho];
+  }
+  return HS_OK;
+}
+
+int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteration* iterations) {
+  if (!p || !summary) return HS_ERR_INVALID;
+  if (max_iterations < 0 || max_iterations > kMaxIterations) HS_FAIL(HS_ERR_INVALID, "max_iterations out of range");
+  int rc = prepare(p);
+  if (rc) return rc;
+  rc = reset_state(p, max_iterations, 1e4);
+  if (rc) return rc;
+  hipStream_t s = p->stream;
+  std::vector<hipEvent_t> ev(size_t(3) * max_iterations + 2);
+  for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+  HIP_TRY(hipEventRecord(ev[0], s));
+  for (int it = 0; it < max_iterations; ++it) {
+    rc = p->k == 4 ? launch_linearize<4>(p) : launch_linearize<6>(p);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ev[3 * it + 1], s));
+    rc = p->k == 4 ? launch_build<4>(p) : launch_build<6>(p);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ev[3 * it + 2], s));
+    rc = p->k == 4 ? launch_step<4>(p) : launch_step<6>(p);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ev[3 * it + 3], s));
+  }
+  if (max_iterations == 0) {
+    rc = p->k == 4 ? launch_linearize<4>(p) : launch_linearize<6>(p);
+    if (rc) return rc;
+    k_cost_reduce<<<1, kBlock, 0, s>>>(p->T);
+  }
+  DevState st;
+  HIP_TRY(hipMemcpyAsync(&st, p->d_state.p, sizeof(st), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  std::memset(summary, 0, sizeof(*summary));
+  summary->initial_cost = st.records[0].cost;
+  summary->final_cost = st.cost;
+  summary->num_iterations = st.num_iterations;
+  summary->num_successful_steps = st.num_successful;
+  summary->termination = st.termination;
+  summary->num_residual_blocks = p->T.n_vis + p->T.n_pri;
+  for (int it = 0; it < max_iterations; ++it) {
+    float a = 0, b = 0, c = 0;
+    (void)hipEventElapsedTime(&a, ev[3 * it], ev[3 * it + 1]);
+    (void)hipEventElapsedTime(&b, ev[3 * it + 1], ev[3 * it + 2]);
+    (void)hipEventElapsedTime(&c, ev[3 * it + 2], ev[3 * it + 3]);
+    summary->linearize_ms += a, summary->schur_ms += b, summary->solve_ms += c;
+  }
+  if (max_iterations > 0) {
+    float t = 0;
+    (void)hipEventElapsedTime(&t, ev[0], ev[3 * max_iterations]);
+    summary->total_ms = t;
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  if (iterations) {
+    std::memset(iterations, 0, sizeof(hs_iteration) * (size_t(max_iterations) + 1));
+    const int n = std::min(st.num_iterations, max_iterations);
+    for (int i = 0; i <= n; ++i) iterations[i] = st.records[i];
+  }
+  if (st.chol_failed && st.termination == HS_FAILURE) p->err = "reduced system not positive definite";
+  return HS_OK;
+}
+
+int hs_set_allreduce(hs_problem* p, hs_allreduce_fn fn, void* user) {
+  if (!p) return HS_ERR_INVALID;
+  p->allreduce = fn, p->allreduce_user = user;
+  return HS_OK;
+}
+
+int hs_get_control_points(hs_problem* p, double* cp) {
+  if (!p || !cp) return HS_ERR_INVALID;
+  if (p->dirty) {
+    std::memcpy(cp, p->cp.data(), p->cp.size() * 8);
+    return HS_OK;
+  }
+  HIP_TRY(hipMemcpyAsync(cp, p->d_cp.p, size_t(8) * p->n_cp * 8, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  std::memcpy(p->cp.data(), cp, p->cp.size() * 8);
+  return HS_OK;
+}
+int hs_get_landmarks(hs_problem* p, double* xyz) {
+  if (!p || !xyz) return HS_ERR_INVALID;
+  if (p->dirty || p->n_lm == 0) {
+    std::memcpy(xyz, p->lm.data(), p->lm.size() * 8);
+    return HS_OK;
+  }
+  std::vector<double> dev(size_t(3) * p->n_lm);
+  HIP_TRY(hipMemcpyAsync(dev.data(), p->d_lm.p, dev.size() * 8, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  for (int d = 0; d < p->n_lm; ++d) {
+    const int t = p->vs.table_of_dev[d];
+    for (int c = 0; c < 3; ++c) xyz[3 * t + c] = p->lm[3 * t + c] = dev[3 * d + c];
+  }
+  return HS_OK;
+}
+int hs_get_bias(hs_problem* p, double* bg, double* ba) {
+  if (!p || !bg || !ba) return HS_ERR_INVALID;
+  std::memcpy(bg, p->bias_g.data(), p->bias_g.size() * 8), std::memcpy(ba, p->bias_a.data(), p->bias_a.size() * 8);
+  return HS_OK;
+}
+int hs_get_gravity(hs_problem* p, double* g) {
+  if (!p || !g) return HS_ERR_INVALID;
+  std::memcpy(g, p->gravity, 24);
+  return HS_OK;
+}
+
+int hs_cost_function_evaluate(hs_problem* p, int, int, const double* const*, double*, double**) {
+  if (!p) return HS_ERR_INVALID;
+  HS_FAIL(HS_ERR_STATE, "hs_cost_function_evaluate: not available in this build yet");
+}
+int hs_sample_trajectory(hs_problem* p, int, const double*, double*, double*, double*) {
+  if (!p) return HS_ERR_INVALID;
+  HS_FAIL(HS_ERR_STATE, "hs_sample_trajectory: not available in this build yet");
+}
+
+}  // extern "C"

@@ -1,0 +1,192 @@
+// host_structure.hpp — host-side graph structure of the window (index arithmetic only, bit-exact parity target).
+//
+// Restates, for whole tables, what the reference does per residual block at add-time:
+//   ExteroceptiveCost::update   /root/reference/internal/hyper/optimizers/ceres/costs/exteroceptive.cpp:25-99
+//     (block list state || sensor || observation, indices, sizes, exclusive-prefix offsets, num_residuals)
+//   segment lookup of the uniform basis (control points [i-(k-1)/2, i-(k-1)/2+k-1], /root/reference/internal/hyper/optimizers/abstract.cpp:89)
+// and builds the sort orders the kernels rely on (landmark-major residuals, segment-major records, landmarks ordered by the
+// first control point they touch).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/hyperslam_hip.h"
+#include "device_math.hpp"
+
+namespace hs {
+
+inline double h_binom(int n, int r) {
+  if (r < 0 || r > n) return 0.0;
+  double v = 1.0;
+  for (int i = 1; i <= r; ++i) v = v * (n - r + i) / i;
+  return v;
+}
+
+/// Cumulative blending matrix of the uniform B-spline of order k.
+inline hsd::BasisCoef make_basis_coef(int k) {
+  hsd::BasisCoef b;
+  for (double& v : b.c) v = 0.0;
+  std::vector<double> M(size_t(k) * k, 0.0);
+  double fact = 1.0;
+  for (int i = 2; i <= k - 1; ++i) fact *= i;
+  for (int s = 0; s < k; ++s)
+    for (int n = 0; n < k; ++n) {
+      double sum = 0.0;
+      for (int l = s; l <= k - 1; ++l) sum += (((l - s) & 1) ? -1.0 : 1.0) * h_binom(k, l - s) * std::pow(double(k - 1 - l), double(k - 1 - n));
+      M[size_t(s) * k + n] = h_binom(k - 1, n) / fact * sum;
+    }
+  for (int j = 0; j < k; ++j)
+    for (int n = 0; n < k; ++n) {
+      double sum = 0.0;
+      for (int s = j; s < k; ++s) sum += M[size_t(s) * k + n];
+      b.c[j * hsd::kMaxOrder + n] = sum;
+    }
+  return b;
+}
+
+inline int h_segment_first(double t, double t0, double dt, int k) {
+  // same expression as the device (IEEE division) so that stamps on a knot land in the same segment
+  const double x = (t - t0) / dt;
+  return int(std::floor(x)) - (k - 1) / 2;
+}
+
+/// Block structure of one residual (ExteroceptiveCost::update).
+struct BlockLayout {
+  int num_blocks = 0, num_parameters = 0, num_residuals = 0;
+  int indices[4] = {0, 0, 0, 0};
+  int sizes[32], offsets[32];
+};
+inline BlockLayout make_block_layout(int type, int k, int kb) {
+  BlockLayout L;
+  int n = 0;
+  for (int j = 0; j < k; ++j) L.sizes[n++] = 8;
+  int n_static = 0, n_sensor = 0;
+  if (type == HS_PIXEL || type == HS_BEARING) {
+    L.sizes[n++] = 7, L.sizes[n++] = 4, L.sizes[n++] = 4;
+    n_static = n_sensor = 3;
+    L.sizes[n++] = 3;
+    L.num_residuals = type == HS_PIXEL ? 2 : 1;
+  } else if (type == HS_PRIOR) {
+    L.sizes[n++] = 7;
+    n_static = n_sensor = 1;
+    L.num_residuals = 6;
+  } else {
+    L.sizes[n++] = 7, L.sizes[n++] = 6, L.sizes[n++] = 6, L.sizes[n++] = 9, L.sizes[n++] = 9;
+    n_static = 5;
+    for (int j = 0; j < 2 * kb; ++j) L.sizes[n++] = 4;
+    n_sensor = 5 + 2 * kb;
+    L.sizes[n++] = 3;
+    L.num_residuals = 6;
+  }
+  L.num_blocks = n;
+  L.indices[0] = 0, L.indices[1] = k, L.indices[2] = k + n_static, L.indices[3] = k + n_sensor;
+  L.offsets[0] = 0;
+  for (int i = 1; i < n; ++i) L.offsets[i] = L.offsets[i - 1] + L.sizes[i - 1];
+  for (int i = 0; i < n; ++i) L.num_parameters += L.sizes[i];
+  return L;
+}
+
+/// Sorted structure of the visual part of the window.
+struct VisualStructure {
+  // landmark-major residual list (index q)
+  std::vector<int> table_type, table_idx;  // origin of residual q (HS_PIXEL / HS_BEARING, index in that table)
+  std::vector<int> lm_dev;                 // device landmark id
+  std::vector<int> first;                  // first control point
+  std::vector<int> pos;                    // record slot (segment-major)
+  std::vector<int> seg_ptr;                // n_seg + 1
+  // landmarks
+  std::vector<int> dev_of_table, table_of_dev;  // permutation (all landmarks; unobserved ones last)
+  std::vector<int> lm_ptr, lm_cfirst, lm_ncp, lm_yoff, cf_ptr;
+  int bw = 0;
+  int y_total = 0;
+};
+
+struct VisualInput {
+  int k, n_cp, n_lm;
+  double t0, dt;
+  int n_px, n_br;
+  const double *px_stamp, *br_stamp;
+  const int32_t *px_lm, *br_lm;
+};
+
+inline bool build_visual_structure(const VisualInput& in, VisualStructure* vs, std::string* err) {
+  const int n = in.n_px + in.n_br, n_seg = in.n_cp - in.k + 1;
+  std::vector<int> type(n), idx(n), lm(n), first(n);
+  for (int i = 0; i < n; ++i) {
+    const bool px = i < in.n_px;
+    type[i] = px ? HS_PIXEL : HS_BEARING;
+    idx[i] = px ? i : i - in.n_px;
+    lm[i] = px ? in.px_lm[idx[i]] : in.br_lm[idx[i]];
+    const double st = px ? in.px_stamp[idx[i]] : in.br_stamp[idx[i]];
+    first[i] = h_segment_first(st, in.t0, in.dt, in.k);
+    if (lm[i] < 0 || lm[i] >= in.n_lm) {
+      *err = "visual residual references a landmark outside the landmark table";
+      return false;
+    }
+    if (first[i] < 0 || first[i] >= n_seg) {
+      *err = "visual residual stamp outside the valid range of the spline";
+      return false;
+    }
+  }
+  // landmark cp ranges
+  std::vector<int> cf(in.n_lm, 1 << 30), cl(in.n_lm, -1);
+  for (int i = 0; i < n; ++i) {
+    cf[lm[i]] = std::min(cf[lm[i]], first[i]);
+    cl[lm[i]] = std::max(cl[lm[i]], first[i] + in.k - 1);
+  }
+  // device order: observed landmarks by first control point (stable), unobserved last
+  vs->table_of_dev.resize(in.n_lm);
+  std::iota(vs->table_of_dev.begin(), vs->table_of_dev.end(), 0);
+  std::stable_sort(vs->table_of_dev.begin(), vs->table_of_dev.end(), [&](int a, int b) { return cf[a] < cf[b]; });
+  vs->dev_of_table.resize(in.n_lm);
+  for (int d = 0; d < in.n_lm; ++d) vs->dev_of_table[vs->table_of_dev[d]] = d;
+  vs->lm_cfirst.assign(in.n_lm, 0), vs->lm_ncp.assign(in.n_lm, 0), vs->lm_yoff.assign(in.n_lm + 1, 0);
+  vs->bw = in.k;
+  for (int d = 0; d < in.n_lm; ++d) {
+    const int t = vs->table_of_dev[d];
+    if (cl[t] >= 0) {
+      vs->lm_cfirst[d] = cf[t];
+      vs->lm_ncp[d] = cl[t] - cf[t] + 1;
+      vs->bw = std::max(vs->bw, vs->lm_ncp[d]);
+    } else {
+      vs->lm_cfirst[d] = in.n_cp;  // sorts after every control point
+      vs->lm_ncp[d] = 0;
+    }
+    vs->lm_yoff[d + 1] = vs->lm_yoff[d] + 18 * vs->lm_ncp[d];
+  }
+  vs->y_total = vs->lm_yoff[in.n_lm];
+  vs->cf_ptr.assign(in.n_cp + 2, 0);
+  for (int c = 0, d = 0; c <= in.n_cp + 1; ++c) {
+    while (d < in.n_lm && vs->lm_cfirst[d] < c) ++d;
+    vs->cf_ptr[c] = d;
+  }
+  // landmark-major residual order (stable: table order within a landmark, pixel before bearing)
+  std::vector<int> order(n);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return vs->dev_of_table[lm[a]] < vs->dev_of_table[lm[b]]; });
+  vs->table_type.resize(n), vs->table_idx.resize(n), vs->lm_dev.resize(n), vs->first.resize(n), vs->pos.resize(n);
+  vs->lm_ptr.assign(in.n_lm + 1, 0);
+  for (int q = 0; q < n; ++q) {
+    const int i = order[q];
+    vs->table_type[q] = type[i], vs->table_idx[q] = idx[i], vs->lm_dev[q] = vs->dev_of_table[lm[i]], vs->first[q] = first[i];
+    vs->lm_ptr[vs->lm_dev[q] + 1]++;
+  }
+  for (int d = 0; d < in.n_lm; ++d) vs->lm_ptr[d + 1] += vs->lm_ptr[d];
+  // segment-major record slots (stable over the landmark-major order)
+  std::vector<int> by_seg(n);
+  std::iota(by_seg.begin(), by_seg.end(), 0);
+  std::stable_sort(by_seg.begin(), by_seg.end(), [&](int a, int b) { return vs->first[a] < vs->first[b]; });
+  vs->seg_ptr.assign(n_seg + 1, 0);
+  for (int p = 0; p < n; ++p) {
+    vs->pos[by_seg[p]] = p;
+    vs->seg_ptr[vs->first[by_seg[p]] + 1]++;
+  }
+  for (int s = 0; s < n_seg; ++s) vs->seg_ptr[s + 1] += vs->seg_ptr[s];
+  return true;
+}
+
+}  // namespace hs

@@ -1,0 +1,761 @@
+// kernels.hpp — gfx950 kernels of one Levenberg-Marquardt iteration (included once by capi.hip).
+//
+// Launch sequence per iteration (all on one HIP stream, no host synchronisation; kernels early-exit when the device
+// state machine has terminated):
+//   k_linearize_visual / k_linearize_prior   one residual block per lane -> segment-major records + cost partials
+//   k_landmark                               one wave per landmark: H_ll, b_l, W_l -> damped 3x3 Cholesky -> Y-hat, y-hat
+//   k_hpp_diag            (iteration 0)      Jacobi column scaling of the pose-side unknowns
+//   k_build_reduced                          one workgroup per control-point block row: gather J'J and the Schur terms
+//                                            into the block-banded reduced system (deterministic, no atomics on doubles)
+//   k_band_cholesky_solve                    single-workgroup block-banded Cholesky with an LDS sliding window + solves
+//   k_backsub_landmarks / k_retract          step for landmarks, candidate point = Plus(x, delta)
+//   k_cost_visual / k_cost_prior             cost at the candidate point
+//   k_decide / k_commit                      trust-region logic and acceptance
+#pragma once
+#include "factors.hpp"
+
+namespace hs {
+
+constexpr int kBlock = 256;
+
+HSD double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+/// Deterministic block sum (fixed butterfly inside each wave, waves combined in index order). Result valid on thread 0.
+HSD double block_sum(double v, double* lds /* >= blockDim/64 */) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) lds[w] = v;
+  __syncthreads();
+  double s = 0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < int(blockDim.x >> 6); ++i) s += lds[i];
+  __syncthreads();
+  return s;
+}
+
+HSD void stage_cps(const double* __restrict__ src, double* dst, int n_doubles) {
+  for (int i = threadIdx.x; i < n_doubles; i += blockDim.x) dst[i] = src[i];
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Linearisation
+// ---------------------------------------------------------------------------------------------------------------------
+/// out_rec/out_pos: where the record of residual q goes (solver: T.v_rec at T.v_pos[q]; debug export: table order).
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_linearize_visual(Tables T, double* out_rec, const int* out_pos, int robustify, double* cost_part,
+                                                            double* cost_each) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (T.st->done) return;
+  double* cps = smem;
+  stage_cps(T.cp, cps, 8 * T.sp.n_cp);
+  __shared__ double red[kBlock / 64];
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  double cost = 0.0;
+  if (q < T.n_vis) {
+    VisualOut<K> o;
+    visual_linearize<K>(T, cps, q, robustify != 0, &o);
+    cost = o.cost;
+    constexpr int REC = 8 + 12 * K;
+    double* rec = out_rec + size_t(out_pos[q]) * REC;
+    rec[0] = o.r[0], rec[1] = o.r[1];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) rec[2 + i] = o.Jl[i];
+#pragma unroll
+    for (int i = 0; i < 12 * K; ++i) rec[8 + i] = o.Jp[i];
+    if (cost_each) cost_each[out_pos[q]] = cost;
+  }
+  const double s = block_sum(cost, red);
+  if (threadIdx.x == 0 && cost_part) cost_part[blockIdx.x] = s;
+}
+
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_linearize_prior(Tables T, double* out_rec, double* cost_part, double* cost_each) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (T.st->done) return;
+  double* cps = smem;
+  stage_cps(T.cp, cps, 8 * T.sp.n_cp);
+  __shared__ double red[kBlock / 64];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double cost = 0.0;
+  if (i < T.n_pri) {
+    PriorOut<K> o;
+    prior_linearize<K>(T, cps, i, &o);
+    cost = o.cost;
+    constexpr int REC = 6 + 36 * K;
+    double* rec = out_rec + size_t(i) * REC;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) rec[c] = o.r[c];
+#pragma unroll
+    for (int c = 0; c < 36 * K; ++c) rec[6 + c] = o.Jp[c];
+    if (cost_each) cost_each[i] = cost;
+  }
+  const double s = block_sum(cost, red);
+  if (threadIdx.x == 0 && cost_part) cost_part[blockIdx.x] = s;
+}
+
+/// Cost at the candidate point (residual-only branch).
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_cost_visual(Tables T, const double* cp_src, const double* lm_src, double* cost_part) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (T.st->done || !T.st->step_valid) return;
+  double* cps = smem;
+  stage_cps(cp_src, cps, 8 * T.sp.n_cp);
+  __shared__ double red[kBlock / 64];
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  const double cost = (q < T.n_vis) ? visual_cost<K>(T, cps, lm_src, q) : 0.0;
+  const double s = block_sum(cost, red);
+  if (threadIdx.x == 0) cost_part[blockIdx.x] = s;
+}
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_cost_prior(Tables T, const double* cp_src, double* cost_part) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (T.st->done || !T.st->step_valid) return;
+  double* cps = smem;
+  stage_cps(cp_src, cps, 8 * T.sp.n_cp);
+  __shared__ double red[kBlock / 64];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const double cost = (i < T.n_pri) ? prior_cost<K>(T, cps, i) : 0.0;
+  const double s = block_sum(cost, red);
+  if (threadIdx.x == 0) cost_part[blockIdx.x] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Landmark pass: one wave per landmark.  H_ll = sum Jl'Jl, b_l = sum Jl'r, W_l = sum Jp'Jl over the landmark's
+// residuals; V = S_l H_ll S_l + D_l^2 = L L';  Y-hat = W S_l L^-T (pose-side row scaling is applied by the consumer),
+// y-hat = L^-1 S_l b_l.  Jacobi scaling S_l is fixed at iteration 0 (TrustRegionMinimizer, jacobi_scaling = true).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_landmark(Tables T) {
+  if (T.st->done) return;
+  constexpr int REC = 8 + 12 * K;
+  const int lane = threadIdx.x & 63;
+  const int dl = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (dl >= T.n_lm) return;
+  const int q0 = T.lm_ptr[dl], q1 = T.lm_ptr[dl + 1];
+  const int c_first = T.lm_cfirst[dl], rows = 6 * T.lm_ncp[dl];
+  // H_ll (upper 6) and b_l
+  double h[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+  for (int q = q0 + lane; q < q1; q += 64) {
+    const double* rec = T.v_rec + size_t(T.v_pos[q]) * REC;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const double rr = rec[r], j0 = rec[2 + 3 * r], j1 = rec[3 + 3 * r], j2 = rec[4 + 3 * r];
+      h[0] = fma(j0, j0, h[0]), h[1] = fma(j0, j1, h[1]), h[2] = fma(j0, j2, h[2]);
+      h[3] = fma(j1, j1, h[3]), h[4] = fma(j1, j2, h[4]), h[5] = fma(j2, j2, h[5]);
+      b[0] = fma(j0, rr, b[0]), b[1] = fma(j1, rr, b[1]), b[2] = fma(j2, rr, b[2]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) h[i] = wave_sum(h[i]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) b[i] = wave_sum(b[i]);
+
+  const bool active = (q1 > q0) && !T.lm_const[dl];
+  double sl[3];
+  if (!T.st->scaling_ready) {
+    sl[0] = 1.0 / (1.0 + sqrt(h[0])), sl[1] = 1.0 / (1.0 + sqrt(h[3])), sl[2] = 1.0 / (1.0 + sqrt(h[5]));
+    if (lane < 3) T.lm_scale[3 * dl + lane] = sl[lane];
+  } else {
+    sl[0] = T.lm_scale[3 * dl], sl[1] = T.lm_scale[3 * dl + 1], sl[2] = T.lm_scale[3 * dl + 2];
+  }
+  const double radius = T.st->radius;
+  // V = S H S + clamp(diag)/radius
+  double v00 = sl[0] * sl[0] * h[0], v01 = sl[0] * sl[1] * h[1], v02 = sl[0] * sl[2] * h[2];
+  double v11 = sl[1] * sl[1] * h[3], v12 = sl[1] * sl[2] * h[4], v22 = sl[2] * sl[2] * h[5];
+  const double d0 = fmin(fmax(v00, 1e-6), 1e32) / radius, d1 = fmin(fmax(v11, 1e-6), 1e32) / radius, d2 = fmin(fmax(v22, 1e-6), 1e32) / radius;
+  v00 += d0, v11 += d1, v22 += d2;
+  // Cholesky V = L L'
+  const double l00 = sqrt(v00), l10 = v01 / l00, l20 = v02 / l00;
+  const double l11 = sqrt(v11 - l10 * l10), l21 = (v12 - l20 * l10) / l11;
+  const double l22 = sqrt(v22 - l20 * l20 - l21 * l21);
+  const double sb0 = sl[0] * b[0], sb1 = sl[1] * b[1], sb2 = sl[2] * b[2];
+  const double y0 = sb0 / l00, y1 = (sb1 - l10 * y0) / l11, y2 = (sb2 - l20 * y0 - l21 * y1) / l22;
+  if (lane == 0) {
+    double* L = T.lm_L + 6 * dl;
+    L[0] = l00, L[1] = l10, L[2] = l11, L[3] = l20, L[4] = l21, L[5] = l22;
+    T.lm_yhat[3 * dl] = active ? y0 : 0.0, T.lm_yhat[3 * dl + 1] = active ? y1 : 0.0, T.lm_yhat[3 * dl + 2] = active ? y2 : 0.0;
+    T.lm_sb[3 * dl] = sb0, T.lm_sb[3 * dl + 1] = sb1, T.lm_sb[3 * dl + 2] = sb2;
+    T.lm_D2[3 * dl] = d0, T.lm_D2[3 * dl + 1] = d1, T.lm_D2[3 * dl + 2] = d2;
+    if (active) {
+      const double gm = fmax(fabs(b[0]), fmax(fabs(b[1]), fabs(b[2])));
+      atomicMax(&T.st->gmax_bits, (unsigned long long)__double_as_longlong(gm));
+    }
+  }
+  // W rows -> Y-hat rows
+  double* Y = T.Y + T.lm_yoff[dl];
+  for (int rho = lane; rho < rows; rho += 64) {
+    double w0 = 0, w1 = 0, w2 = 0;
+    for (int q = q0; q < q1; ++q) {
+      const int c = rho - 6 * (T.v_first[q] - c_first);
+      if (c >= 0 && c < 6 * K) {
+        const double* rec = T.v_rec + size_t(T.v_pos[q]) * REC;
+        const double ja = rec[8 + c], jb = rec[8 + 6 * K + c];
+        w0 = fma(ja, rec[2], fma(jb, rec[5], w0));
+        w1 = fma(ja, rec[3], fma(jb, rec[6], w1));
+        w2 = fma(ja, rec[4], fma(jb, rec[7], w2));
+      }
+    }
+    w0 *= sl[0], w1 *= sl[1], w2 *= sl[2];
+    // y L' = w  (forward substitution on the columns of L')
+    const double a0 = w0 / l00, a1 = (w1 - a0 * l10) / l11, a2 = (w2 - a0 * l20 - a1 * l21) / l22;
+    Y[3 * rho] = active ? a0 : 0.0, Y[3 * rho + 1] = active ? a1 : 0.0, Y[3 * rho + 2] = active ? a2 : 0.0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Jacobi scaling of the pose-side unknowns: s = 1 / (1 + sqrt(diag(J'J))) at iteration 0.
+// One workgroup per control point; threads stride over the records of the k segments that touch it.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_hpp_diag(Tables T) {
+  if (T.st->done || T.st->scaling_ready) return;
+  constexpr int VREC = 8 + 12 * K, PREC = 6 + 36 * K;
+  const int i = blockIdx.x;
+  __shared__ double red[kBlock / 64];
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  const int f0 = max(0, i - K + 1), f1 = min(i, T.n_seg - 1);
+  for (int first = f0; first <= f1; ++first) {
+    const int ao = 6 * (i - first);
+    for (int pos = T.v_seg_ptr[first] + threadIdx.x; pos < T.v_seg_ptr[first + 1]; pos += kBlock) {
+      const double* rec = T.v_rec + size_t(pos) * VREC + 8 + ao;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) acc[a] = fma(rec[a], rec[a], fma(rec[6 * K + a], rec[6 * K + a], acc[a]));
+    }
+    if (T.n_pri)
+      for (int pos = T.p_seg_ptr[first] + threadIdx.x; pos < T.p_seg_ptr[first + 1]; pos += kBlock) {
+        const double* rec = T.p_rec + size_t(pos) * PREC + 6 + ao;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int a = 0; a < 6; ++a) acc[a] = fma(rec[r * 6 * K + a], rec[r * 6 * K + a], acc[a]);
+      }
+  }
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    const double s = block_sum(acc[a], red);
+    if (threadIdx.x == 0) T.scale_p[6 * i + a] = 1.0 / (1.0 + sqrt(s));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Reduced system: block row i of  S = Sp (J_p'J_p) Sp + D_p^2 - Sp (sum_l Yh_l Yh_l') Sp,   g = Sp (g_p - sum_l Yh_l yh_l).
+// Gather formulation: each workgroup owns one block row, walks the records of the k segments touching control point i and
+// the Y-hat rows of the landmarks covering it.  The K dimension is split over thread groups and combined in a fixed
+// order, so the result is bit-reproducible (no floating-point atomics).  Requires 6*bw <= kBlock.
+// LDS (doubles): tile 6*ncb | gacc 8 | dj 8 | red 6*kBlock + 64.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_build_reduced(Tables T) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (T.st->done) return;
+  constexpr int VREC = 8 + 12 * K, PREC = 6 + 36 * K;
+  constexpr int NCA = 6 * K;        // columns of the J'J part
+  constexpr int GA = kBlock / NCA;  // thread groups splitting the record loop
+  const int i = blockIdx.x;
+  const int ncb = 6 * T.bw;  // columns of the band row
+  const int tid = threadIdx.x;
+  double* tile = smem;            // 6 x ncb accumulated block row (unscaled)
+  double* gacc = smem + 6 * ncb;  // [0..5] J'r, [6..7] unused
+  double* dj = gacc + 8;          // [0..5] unscaled diag(J'J) of this block row
+  double* red = dj + 8;           // reduction scratch
+
+  // ---- part A: J'J and J'r ------------------------------------------------------------------------------------
+  {
+    const int grp = tid / NCA, col = tid % NCA;
+    double acc[6] = {0, 0, 0, 0, 0, 0}, gsum = 0.0;
+    if (grp < GA) {
+      const int f0 = max(0, i - K + 1), f1 = min(i, T.n_seg - 1);
+      for (int first = f0; first <= f1; ++first) {
+        const int ao = 6 * (i - first);
+        const int cidx = ao + col;
+        const bool valid = cidx < NCA;
+        for (int pos = T.v_seg_ptr[first] + grp; pos < T.v_seg_ptr[first + 1]; pos += GA) {
+          const double* rec = T.v_rec + size_t(pos) * VREC;
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const double* jp = rec + 8 + r * NCA;
+            const double v = valid ? jp[cidx] : 0.0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) acc[a] = fma(jp[ao + a], v, acc[a]);
+            if (col < 6) gsum = fma(jp[ao + col], rec[r], gsum);
+          }
+        }
+        if (T.n_pri)
+          for (int pos = T.p_seg_ptr[first] + grp; pos < T.p_seg_ptr[first + 1]; pos += GA) {
+            const double* rec = T.p_rec + size_t(pos) * PREC;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+              const double* jp = rec + 6 + r * NCA;
+              const double v = valid ? jp[cidx] : 0.0;
+#pragma unroll
+              for (int a = 0; a < 6; ++a) acc[a] = fma(jp[ao + a], v, acc[a]);
+              if (col < 6) gsum = fma(jp[ao + col], rec[r], gsum);
+            }
+          }
+      }
+#pragma unroll
+      for (int a = 0; a < 6; ++a) red[(grp * 6 + a) * NCA + col] = acc[a];
+      if (col < 6) red[GA * 6 * NCA + grp * 6 + col] = gsum;
+    }
+    __syncthreads();
+    for (int e = tid; e < 6 * ncb; e += kBlock) {
+      const int a = e / ncb, c = e % ncb;
+      double s = 0.0;
+      if (c < NCA)
+        for (int g = 0; g < GA; ++g) s += red[(g * 6 + a) * NCA + c];
+      tile[e] = s;
+      if (c == a) dj[a] = s;
+    }
+    if (tid < 6) {
+      double s = 0.0;
+      for (int g = 0; g < GA; ++g) s += red[GA * 6 * NCA + g * 6 + tid];
+      gacc[tid] = s;
+    }
+    __syncthreads();
+  }
+  // unscaled gradient max norm (pose side; Ceres uses the gradient of the full problem)
+  if (tid < 6) atomicMax(&T.st->gmax_bits, (unsigned long long)__double_as_longlong(fabs(gacc[tid])));
+
+  // ---- part B: Schur terms ---------------------------------------------------------------------------------------
+  double gschur = 0.0;  // valid on tid < 6
+  if (T.n_lm > 0) {
+    const int gb = kBlock / ncb;
+    const int grp = tid / ncb, col = tid % ncb;
+    const int dl0 = T.cf_ptr[max(0, i - T.bw + 1)], dl1 = T.cf_ptr[i + 1];
+    double acc[6] = {0, 0, 0, 0, 0, 0}, gsum = 0.0;
+    if (grp < gb) {
+      for (int dl = dl0 + grp; dl < dl1; dl += gb) {
+        const int off = i - T.lm_cfirst[dl], rows = 6 * T.lm_ncp[dl];
+        if (6 * off >= rows) continue;
+        const double* Y = T.Y + T.lm_yoff[dl] + 18 * off;
+        if (6 * off + col < rows) {
+          const double v0 = Y[3 * col], v1 = Y[3 * col + 1], v2 = Y[3 * col + 2];
+#pragma unroll
+          for (int a = 0; a < 6; ++a) acc[a] -= fma(Y[3 * a], v0, fma(Y[3 * a + 1], v1, Y[3 * a + 2] * v2));
+          if (col < 6) {
+            const double* yh = T.lm_yhat + 3 * dl;
+            gsum -= fma(v0, yh[0], fma(v1, yh[1], v2 * yh[2]));
+          }
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 6; ++a) red[(grp * 6 + a) * ncb + col] = acc[a];
+      if (col < 6) red[gb * 6 * ncb + grp * 6 + col] = gsum;
+    }
+    __syncthreads();
+    for (int e = tid; e < 6 * ncb; e += kBlock) {
+      const int a = e / ncb, c = e % ncb;
+      double s = 0.0;
+      for (int g = 0; g < gb; ++g) s += red[(g * 6 + a) * ncb + c];
+      tile[e] += s;
+    }
+    if (tid < 6)
+      for (int g = 0; g < gb; ++g) gschur += red[gb * 6 * ncb + g * 6 + tid];
+    __syncthreads();
+  }
+
+  // ---- finalise: Jacobi scaling, LM diagonal, inactive coordinates ------------------------------------------------
+  const double radius = T.st->radius;
+  for (int e = tid; e < 6 * ncb; e += kBlock) {
+    const int a = e / ncb, c = e % ncb;
+    const int rho = 6 * i + a, sigma = 6 * i + c;
+    double out = 0.0;
+    if (sigma < T.np) {
+      const double sr = T.scale_p[rho], sc = T.scale_p[sigma];
+      out = sr * sc * tile[e];
+      if (c == a) {
+        if (dj[a] > 0.0) {
+          const double d2 = fmin(fmax(sr * sr * dj[a], 1e-6), 1e32) / radius;
+          out += d2;
+          T.D2p[rho] = d2;
+        } else {  // structurally zero column (constant / unobserved): keep the system non-singular, step = 0
+          out = 1.0;
+          T.D2p[rho] = 0.0;
+        }
+      }
+    }
+    T.Sb[size_t(rho) * ncb + c] = out;
+  }
+  if (tid < 6) {
+    const int rho = 6 * i + tid;
+    const double sr = T.scale_p[rho];
+    T.g_full[rho] = sr * gacc[tid];
+    T.g_s[rho] = sr * (gacc[tid] + gschur);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Block-banded Cholesky S = U'U with an LDS sliding window, fused forward solve, then backward solve.
+// Single workgroup (the factorisation is a dependency chain over n_cp block rows); the window holds 6*bw band rows of
+// 6*bw (+1 rhs, +1 pad) doubles. Row rho of the band stores S[rho][6*(rho/6) + c].
+//   step i:  U_ii = chol(S_ii);  X = U_ii^-T [S_i,i+1.. | g_i];  trailing rows j>i: S_j,* -= X_j' X_*;  g_j -= X_j' y_i.
+// Outputs: Ub (factor), step_p = -S^-1 g (scaled step), delta_p = scale_p o step_p, and the two pose-side reductions
+// of the model cost change.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kCholThreads = 512;
+
+__global__ void __launch_bounds__(kCholThreads) k_band_cholesky_solve(Tables T) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  DevState* st = T.st;
+  if (st->done) return;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int ncb = 6 * T.bw, ld = ncb + 2;  // row: [band 0..ncb) | rhs | pad
+  const int nrows = ncb;                   // window rows (6*bw)
+  const int n_blk = T.np / 6;
+  double* win = smem;                      // nrows x ld, circular by block row
+  double* xs = smem + size_t(nrows) * ld;  // np solution / rhs vector
+  __shared__ double Uii[36];
+  __shared__ int fail;
+  if (tid == 0) fail = 0;
+
+  auto load_block_row = [&](int blk) {
+    // all threads: copy band rows of block `blk` (or zeros past the end) into the window
+    const int slot = (blk % T.bw) * 6;
+    for (int e = tid; e < 6 * ld; e += nthr) {
+      const int a = e / ld, c = e % ld;
+      double v = 0.0;
+      if (blk < n_blk) {
+        const int rho = 6 * blk + a;
+        if (c < ncb)
+          v = T.Sb[size_t(rho) * ncb + c];
+        else if (c == ncb)
+          v = T.g_s[rho];
+      }
+      win[(slot + a) * ld + c] = v;
+    }
+  };
+  for (int b = 0; b < T.bw; ++b) load_block_row(b);
+  __syncthreads();
+
+  for (int i = 0; i < n_blk; ++i) {
+    const int s0 = (i % T.bw) * 6;  // slot of block row i
+    // 1. factor the 6x6 diagonal block (upper): thread 0 (36 entries, serial; tiny)
+    if (tid == 0) {
+      double A[36];
+      for (int a = 0; a < 6; ++a)
+        for (int c = 0; c < 6; ++c) A[6 * a + c] = win[(s0 + a) * ld + c];
+      for (int a = 0; a < 6; ++a) {
+        double d = A[7 * a];
+        for (int k = 0; k < a; ++k) d -= A[6 * k + a] * A[6 * k + a];
+        if (!(d > 0.0)) {
+          fail = 1;
+          d = 1.0;
+        }
+        d = sqrt(d);
+        A[7 * a] = d;
+        for (int c = a + 1; c < 6; ++c) {
+          double v = A[6 * a + c];
+          for (int k = 0; k < a; ++k) v -= A[6 * k + a] * A[6 * k + c];
+          A[6 * a + c] = v / d;
+        }
+        for (int c = 0; c < a; ++c) A[6 * a + c] = 0.0;
+      }
+      for (int e = 0; e < 36; ++e) Uii[e] = A[e];
+      for (int a = 0; a < 6; ++a)
+        for (int c = 0; c < 6; ++c) win[(s0 + a) * ld + c] = A[6 * a + c];
+    }
+    __syncthreads();
+    // 2. X = U_ii^-T [columns 6..ncb and the rhs]: one thread per column, forward substitution with U_ii'
+    for (int c = 6 + tid; c <= ncb; c += nthr) {
+      double x[6];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        double v = win[(s0 + a) * ld + c];
+#pragma unroll
+        for (int k = 0; k < a; ++k) v -= Uii[6 * k + a] * x[k];
+        x[a] = v / Uii[7 * a];
+      }
+#pragma unroll
+      for (int a = 0; a < 6; ++a) win[(s0 + a) * ld + c] = x[a];
+    }
+    __syncthreads();
+    // 3. trailing update of block rows i+1 .. i+bw-1 (entries whose column is still inside row i's band) and their rhs
+    //    entry (j, a', c): row 6(i+j)+a', band column c  <->  columns 6j+a' and 6j+c of block row i.
+    {
+      const int per_j = 6 * (ncb + 1);  // upper bound of entries per block row j (a' x (c + rhs))
+      const int total = (T.bw - 1) * per_j;
+      for (int e = tid; e < total; e += nthr) {
+        const int j = 1 + e / per_j, rem = e % per_j;
+        const int ap = rem / (ncb + 1), c = rem % (ncb + 1);
+        const int ci = 6 * j + ap;        // column (in row i) matching the updated row
+        const int cj = (c == ncb) ? ncb : 6 * j + c;  // column (in row i) matching the updated column; rhs stays rhs
+        if (c < ncb && cj >= ncb) continue;           // outside row i's band
+        if (i + j >= n_blk) continue;
+        double s = 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) s = fma(win[(s0 + a) * ld + ci], win[(s0 + a) * ld + cj], s);
+        const int sj = ((i + j) % T.bw) * 6;
+        win[(sj + ap) * ld + c] -= s;
+      }
+    }
+    __syncthreads();
+    // 4. block row i is final: write U row and y_i, then reuse the slot for block row i + bw
+    for (int e = tid; e < 6 * ncb; e += nthr) {
+      const int a = e / ncb, c = e % ncb;
+      T.Ub[size_t(6 * i + a) * ncb + c] = win[(s0 + a) * ld + c];
+    }
+    if (tid < 6) xs[6 * i + tid] = win[(s0 + tid) * ld + ncb];
+    __syncthreads();
+    load_block_row(i + T.bw);
+    __syncthreads();
+  }
+
+  // ---- backward solve U x = y (column oriented: once x_j is final, every pending row above subtracts U[rho][x_j]) ----
+  for (int j = n_blk - 1; j >= 0; --j) {
+    if (tid == 0) {
+      double x[6];
+      for (int a = 5; a >= 0; --a) {
+        double v = xs[6 * j + a];
+        for (int c = a + 1; c < 6; ++c) v -= T.Ub[size_t(6 * j + a) * ncb + c] * x[c];
+        x[a] = v / T.Ub[size_t(6 * j + a) * ncb + a];
+      }
+      for (int a = 0; a < 6; ++a) xs[6 * j + a] = x[a];
+    }
+    __syncthreads();
+    const int rows_above = min(6 * (T.bw - 1), 6 * j);
+    for (int t = tid; t < rows_above; t += nthr) {
+      const int rho = 6 * j - 1 - t;          // row above block j
+      const int cb = 6 * j - 6 * (rho / 6);   // band column of x_j[0] in row rho
+      const double* u = T.Ub + size_t(rho) * ncb + cb;
+      double s = 0.0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) s = fma(u[a], xs[6 * j + a], s);
+      xs[rho] -= s;
+    }
+    __syncthreads();
+  }
+
+  // ---- outputs: step = -x, delta = scale o step, reductions for the model cost change ---------------------------------
+  __shared__ double red[kCholThreads / 64];
+  double gd = 0.0, dd = 0.0;
+  for (int rho = tid; rho < T.np; rho += nthr) {
+    const double step = -xs[rho];
+    T.step_p[rho] = step;
+    T.delta_p[rho] = T.scale_p[rho] * step;
+    gd = fma(T.g_full[rho], step, gd);
+    dd = fma(T.D2p[rho] * step, step, dd);
+  }
+  gd = block_sum(gd, red);
+  dd = block_sum(dd, red);
+  if (tid == 0) {
+    st->g_dot_step_pose = gd;
+    st->d2_step2_pose = dd;
+    st->chol_failed = fail;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Landmark back-substitution (one wave per landmark):
+//   y_l = L^-T (yh_l - Yh_l' (Sp o y_p)),  step_l = -y_l, with y_p = -step_p;   candidate = lm + S_l o step_l.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_backsub_landmarks(Tables T) {
+  if (T.st->done) return;
+  const int lane = threadIdx.x & 63;
+  const int dl = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (dl >= T.n_lm) return;
+  const int rows = 6 * T.lm_ncp[dl], r0 = 6 * T.lm_cfirst[dl];
+  const double* Y = T.Y + T.lm_yoff[dl];
+  double t0 = 0, t1 = 0, t2 = 0;
+  for (int rho = lane; rho < rows; rho += 64) {
+    const double yp = -T.step_p[r0 + rho] * T.scale_p[r0 + rho];
+    t0 = fma(Y[3 * rho], yp, t0), t1 = fma(Y[3 * rho + 1], yp, t1), t2 = fma(Y[3 * rho + 2], yp, t2);
+  }
+  t0 = wave_sum(t0), t1 = wave_sum(t1), t2 = wave_sum(t2);
+  if (lane == 0) {
+    const double* L = T.lm_L + 6 * dl;
+    const double* yh = T.lm_yhat + 3 * dl;
+    const bool active = (T.lm_ptr[dl + 1] > T.lm_ptr[dl]) && !T.lm_const[dl];
+    // L' y = z
+    const double z0 = yh[0] - t0, z1 = yh[1] - t1, z2 = yh[2] - t2;
+    const double y2 = z2 / L[5], y1 = (z1 - L[4] * y2) / L[2], y0 = (z0 - L[1] * y1 - L[3] * y2) / L[0];
+    const double s[3] = {active ? -y0 : 0.0, active ? -y1 : 0.0, active ? -y2 : 0.0};
+    double gd = 0, dd = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      T.lm_cand[3 * dl + a] = T.lm[3 * dl + a] + T.lm_scale[3 * dl + a] * s[a];
+      gd = fma(T.lm_sb[3 * dl + a], s[a], gd);
+      dd = fma(T.lm_D2[3 * dl + a] * s[a], s[a], dd);
+    }
+    T.lm_mcc[2 * dl] = active ? gd : 0.0, T.lm_mcc[2 * dl + 1] = active ? dd : 0.0;
+  }
+}
+
+/// Candidate control points: Plus(x, delta) per Ceres manifold (quaternion left-multiplicative half-angle, R^3 additive,
+/// stamp constant). Also accumulates |x|^2 and |x - x+|^2 partials for the parameter-tolerance test.
+__global__ void __launch_bounds__(kBlock) k_retract(Tables T) {
+  if (T.st->done) return;
+  __shared__ double red[kBlock / 64];
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  double xs = 0.0, ss = 0.0;
+  if (j < T.sp.n_cp) {
+    const double* x = T.cp + 8 * j;
+    double* y = T.cp_cand + 8 * j;
+    const double* d = T.delta_p + 6 * j;
+    bool any = false;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) any |= (T.D2p[6 * j + c] != 0.0);
+    const Quat q = quat_plus(Quat{x[0], x[1], x[2], x[3]}, V3{d[0], d[1], d[2]});
+    y[0] = q.x, y[1] = q.y, y[2] = q.z, y[3] = q.w;
+    y[4] = x[4] + d[3], y[5] = x[5] + d[4], y[6] = x[6] + d[5];
+    y[7] = x[7];
+    if (any) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) xs = fma(x[c], x[c], xs), ss = fma(x[c] - y[c], x[c] - y[c], ss);
+    }
+  }
+  // landmarks handled by the same grid (thread j also covers landmark j when in range)
+  for (int l = j; l < T.n_lm; l += gridDim.x * blockDim.x) {
+    const bool active = (T.lm_ptr[l + 1] > T.lm_ptr[l]) && !T.lm_const[l];
+    if (active) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const double x = T.lm[3 * l + a], y = T.lm_cand[3 * l + a];
+        xs = fma(x, x, xs), ss = fma(x - y, x - y, ss);
+      }
+    }
+  }
+  xs = block_sum(xs, red);
+  ss = block_sum(ss, red);
+  if (threadIdx.x == 0) T.norm_part[2 * blockIdx.x] = xs, T.norm_part[2 * blockIdx.x + 1] = ss;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Trust-region state machine (one workgroup). Restates TrustRegionMinimizer::Minimize + LevenbergMarquardtStrategy
+// (Ceres) with the in-tree options of optimizer.cpp:38-54.
+//   phase 0: after the first linearisation — record iteration 0.
+//   phase 1: after the candidate cost — accept / reject, radius update, termination tests.
+// ---------------------------------------------------------------------------------------------------------------------
+HSD double ordered_sum(const double* p, int n, double* lds) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += p[i];
+  return block_sum(s, lds);
+}
+
+__global__ void __launch_bounds__(kBlock) k_cost_reduce(Tables T) {
+  // cost of the current linearisation point -> st->cost, gradient max norm -> st->gmax
+  __shared__ double red[kBlock / 64];
+  DevState* st = T.st;
+  if (st->done) return;
+  const double c = ordered_sum(T.cost_part, T.n_cost_part, red);
+  if (threadIdx.x == 0) {
+    st->cost = c;
+    st->gmax = __longlong_as_double((long long)st->gmax_bits);
+    if (st->iteration == 0) {
+      hs_iteration& r = st->records[0];
+      r.iteration = 0, r.step_is_valid = 1, r.step_is_successful = 1, r.cost = c, r.cost_change = 0, r.gradient_max_norm = st->gmax;
+      r.step_norm = 0, r.relative_decrease = 0, r.radius = st->radius;
+      st->iteration = 1;
+    }
+    // FinalizeIterationAndCheckIfMinimizerCanContinue
+    if (st->iteration - 1 >= st->max_iterations) {
+      st->done = 1, st->termination = HS_NO_CONVERGENCE;
+    } else if (st->gmax <= 1e-10) {
+      st->done = 1, st->termination = HS_CONVERGENCE;
+    } else if (st->radius <= 1e-32) {
+      st->done = 1, st->termination = HS_CONVERGENCE;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_model_cost(Tables T) {
+  // model_cost_change = -g.step/2 + step'D^2 step/2 (exact for the solved system); validity of the step
+  __shared__ double red[kBlock / 64];
+  DevState* st = T.st;
+  if (st->done) return;
+  double gd = 0.0, dd = 0.0;
+  for (int l = threadIdx.x; l < T.n_lm; l += blockDim.x) gd += T.lm_mcc[2 * l], dd += T.lm_mcc[2 * l + 1];
+  gd = block_sum(gd, red);
+  dd = block_sum(dd, red);
+  if (threadIdx.x == 0) {
+    const double g_step = st->g_dot_step_pose + gd, d_step = st->d2_step2_pose + dd;
+    const double mcc = -0.5 * g_step + 0.5 * d_step;
+    st->model_cost_change = mcc;
+    const bool finite = isfinite(mcc) && !st->chol_failed;
+    st->step_valid = (finite && mcc >= 0.0) ? 1 : 0;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_decide(Tables T) {
+  __shared__ double red[kBlock / 64];
+  DevState* st = T.st;
+  if (st->done) return;
+  double cand = 0.0, xs = 0.0, ss = 0.0;
+  if (st->step_valid) {
+    cand = ordered_sum(T.cand_part, T.n_cost_part, red);
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < T.n_norm_part; i += blockDim.x) a += T.norm_part[2 * i], b += T.norm_part[2 * i + 1];
+    xs = block_sum(a, red);
+    ss = block_sum(b, red);
+  }
+  if (threadIdx.x != 0) return;
+  const int it = st->iteration;
+  hs_iteration& r = st->records[it];
+  r.iteration = it, r.cost = st->cost, r.cost_change = 0, r.gradient_max_norm = st->gmax, r.step_norm = 0, r.relative_decrease = 0;
+  r.step_is_valid = st->step_valid, r.step_is_successful = 0;
+  st->num_iterations = it;
+  st->accepted = 0;
+  st->gmax_bits = 0ull;  // the next linearisation re-accumulates it
+  if (!st->step_valid) {  // HandleInvalidStep
+    if (++st->invalid_streak >= 5) {
+      st->done = 1, st->termination = HS_FAILURE;
+    } else {
+      st->radius *= 0.5;
+    }
+    r.radius = st->radius;
+    st->iteration = it + 1;
+    return;
+  }
+  st->invalid_streak = 0;
+  st->cand_cost = cand;
+  r.step_norm = sqrt(ss);
+  // ParameterToleranceReached
+  if (r.step_norm <= 1e-8 * (sqrt(xs) + 1e-8)) {
+    st->done = 1, st->termination = HS_CONVERGENCE;
+    r.radius = st->radius;
+    return;
+  }
+  // FunctionToleranceReached
+  r.cost_change = st->cost - cand;
+  if (fabs(r.cost_change) <= 1e-6 * st->cost) {
+    st->done = 1, st->termination = HS_CONVERGENCE;
+    r.radius = st->radius;
+    return;
+  }
+  r.relative_decrease = (st->cost - cand) / st->model_cost_change;
+  if (r.relative_decrease > 1e-3) {  // HandleSuccessfulStep
+    r.step_is_successful = 1;
+    st->accepted = 1;
+    st->num_successful++;
+    st->cost = cand;
+    r.cost = cand;
+    const double q = 2.0 * r.relative_decrease - 1.0;
+    st->radius = fmin(1e16, st->radius / fmax(1.0 / 3.0, 1.0 - q * q * q));
+    st->decrease_factor = 2.0;
+  } else {
+    st->radius = st->radius / st->decrease_factor;
+    st->decrease_factor *= 2.0;
+  }
+  r.radius = st->radius;
+  st->iteration = it + 1;
+}
+
+/// x <- candidate when the step was accepted.
+__global__ void __launch_bounds__(kBlock) k_commit(Tables T) {
+  // note: reads `accepted` even when `done` was just set by a convergence test (those leave accepted = 0)
+  if (!T.st->accepted) return;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < 8 * T.sp.n_cp) T.cp[idx] = T.cp_cand[idx];
+  for (int l = idx; l < 3 * T.n_lm; l += gridDim.x * blockDim.x) T.lm[l] = T.lm_cand[l];
+}
+
+/// Marks the Jacobi scaling as fixed after the first build (jacobian scaling is computed at iteration 0 only).
+__global__ void k_mark_scaling(Tables T) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) T.st->scaling_ready = 1;
+}
+
+}  // namespace hs

@@ -1,0 +1,125 @@
+// problem.hpp — HBM-resident window tables and the device-side LM state shared by kernels.hip / capi.hip.
+//
+// The reference keeps the window as a ceres::Problem pointer graph that is walked one residual block at a time on
+// one host thread (/root/reference/internal/hyper/optimizers/ceres/optimizer.cpp:41,278). Here the same content is a
+// set of flat, sorted tables:
+//   control points   n_cp x 8  [qx qy qz qw px py pz t]                       (Stamped<SE3>, stamped.hpp:35-36)
+//   cameras          n x 16    [T_bs(7) | cx cy fx fy | k1 k2 p1 p2 | pad]     (sensors/camera.cpp:30-48)
+//   landmarks        n x 3, device order = sorted by first control point touched
+//   visual residuals landmark-major: stamp, meas[3], landmark, camera|type, first control point, record slot
+//   records          one per residual block, segment-major (sorted by first control point):
+//                      visual  [r(2) | J_landmark(2x3) | J_state(2 x 6k)]      = 8 + 12k doubles  (B_out of SURVEY.md §8d)
+//                      prior   [r(6) | J_state(6 x 6k)]                        = 6 + 36k doubles
+//   reduced system   block-banded upper storage: row rho holds S[rho][6*(rho/6) + c], c in [0, 6*BW)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hyperslam_hip.h"
+#include "device_math.hpp"
+
+namespace hs {
+
+constexpr int kMaxIterations = 64;
+constexpr int kCamStride = 16;
+
+struct Spline {
+  int k, n_cp;
+  double t0, dt, inv_dt;
+  int rot_const, trans_const;
+};
+
+/// LM state machine living in device memory (TrustRegionMinimizer + LevenbergMarquardtStrategy).
+struct DevState {
+  double radius, decrease_factor;
+  double cost;            // cost at the current point
+  double cand_cost;       // cost at the candidate point
+  double model_cost_change;
+  unsigned long long gmax_bits;  // max |gradient| as raw bits (atomicMax on non-negative doubles)
+  double gmax;            // gradient max norm of the current linearisation
+  double x_sqnorm, step_sqnorm;
+  // reduction scratch for the model cost change (scaled coordinates)
+  double g_dot_step_pose, d2_step2_pose;
+  int iteration;          // index of the LM iteration being executed (1-based; 0 = initial evaluation)
+  int done;               // 1 once a termination criterion fired: all later kernels early-exit
+  int termination;
+  int accepted;           // decision of the current iteration (consumed by k_commit)
+  int step_valid;
+  int invalid_streak;
+  int num_successful;
+  int num_iterations;
+  int scaling_ready;      // Jacobi scaling computed (iteration 0 only)
+  int max_iterations;
+  int chol_failed;
+  int pad;
+  hs_iteration records[kMaxIterations + 1];
+};
+
+/// Everything a kernel needs, passed by value (pointers into HBM).
+struct Tables {
+  Spline sp;
+  hsd::BasisCoef basis;
+  // control points
+  double* cp;
+  double* cp_cand;
+  const uint8_t* cp_const;
+  // cameras / plain sensors
+  const double* cam;       // n_cam x 16
+  const double* sensor;    // n_sensor x 8 (T_bs 7 + pad)
+  // landmarks (device order)
+  int n_lm;
+  double* lm;
+  double* lm_cand;
+  const uint8_t* lm_const;
+  const int* lm_ptr;       // n_lm + 1 : range of visual residuals (landmark-major)
+  const int* lm_cfirst;    // first control point touched
+  const int* lm_ncp;       // number of control points touched
+  const int* lm_yoff;      // offset (in doubles) of Y-hat rows in `Y`
+  const int* cf_ptr;       // n_cp + 1 : first device landmark with c_first >= c
+  double* lm_scale;        // n_lm x 3 Jacobi scaling
+  double* lm_L;            // n_lm x 6 Cholesky factor of V (l00 l10 l11 l20 l21 l22)
+  double* lm_yhat;         // n_lm x 3  L^-1 (s_l o b_l)
+  double* lm_sb;           // n_lm x 3  s_l o b_l
+  double* lm_D2;           // n_lm x 3  LM diagonal
+  double* lm_mcc;          // n_lm x 2  per-landmark (g.step, step D2 step) terms
+  double* Y;               // concatenated Y-hat (6 n_l x 3 per landmark)
+  // visual residuals (landmark-major)
+  int n_vis;
+  const double* v_stamp;
+  const double* v_meas;    // n x 3
+  const int* v_lm;
+  const int* v_info;       // camera | type << 16
+  const int* v_first;
+  const int* v_pos;        // record slot (segment-major)
+  double* v_rec;           // n x (8 + 12k)
+  const int* v_seg_ptr;    // n_seg + 1 over record slots
+  // prior residuals (segment-major == record order)
+  int n_pri;
+  const double* p_stamp;
+  const double* p_meas;    // n x 7
+  const int* p_sensor;
+  const int* p_first;
+  double* p_rec;           // n x (6 + 36k)
+  const int* p_seg_ptr;
+  int n_seg;               // n_cp - k + 1
+  // reduced system
+  int bw;                  // band width in blocks
+  int np;                  // 6 * n_cp
+  double* scale_p;         // np
+  double* Sb;              // np x (6 bw)   scaled + damped band (input of the factorisation)
+  double* Ub;              // np x (6 bw)   Cholesky factor (upper, band rows)
+  double* g_s;             // np  reduced scaled gradient
+  double* g_full;          // np  scaled full gradient s_p o g_p
+  double* D2p;             // np  LM diagonal (pose side)
+  double* step_p;          // np  scaled step
+  double* delta_p;         // np  unscaled step (tangent update)
+  // reductions
+  double* cost_part;       // per-block cost partial sums (current point)
+  double* cand_part;       // per-block cost partial sums (candidate point)
+  int n_cost_part;
+  double* norm_part;       // per-block (x_sqnorm, step_sqnorm) pairs
+  int n_norm_part;
+  DevState* st;
+};
+
+}  // namespace hs

@@ -4,7 +4,7 @@
  * inside `Optimizer<OptimizerSuite::CERES>::optimize()` -> `ceres::Solve`
  * (/root/reference/internal/hyper/optimizers/ceres/optimizer.cpp:276-280) and, per residual block, inside
  * `ExteroceptiveCost<CERES>::Evaluate` (/root/reference/internal/hyper/optimizers/ceres/costs/exteroceptive.cpp:101-160)
- * -> `Evaluator<Obs, SE3>::evaluate` (/root/reference/internal/hyper/optimizers/evaluators/*.cpp).
+ * -> `Evaluator<Obs, SE3>::evaluate` (the four files under /root/reference/internal/hyper/optimizers/evaluators/).
  *
  * The reference walks a pointer graph (ceres::Problem) one residual at a time; this ABI takes the same content as
  * flat tables (control points, sensors, landmarks, per-type residual records), keeps them resident in HBM and runs

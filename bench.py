@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path (BASELINE.json: residuals/sec + ms/Gauss-Newton iter, 128-ctrl-pt window).
+
+Step = one optimize() call (the reference's unit of work: Ceres trust-region LM with max_num_iterations = 5,
+/root/reference/internal/hyper/optimizers/ceres/optimizer.cpp:40,276-280) on the BASELINE.json configs[1] window
+(order-4 spline, 128 control points, 50 000 pixel-reprojection residual blocks, 5 000 landmarks), restarted from the same
+HBM-resident window state every step (device-side restore; tables are uploaded before the timed region).
+Every step executes exactly 5 LM iterations (asserted), each = linearise all residual blocks -> robustify -> landmark
+Schur complement -> banded reduced solve -> retract -> cost re-evaluation -> accept/reject.
+value = residual blocks linearised per second over the whole job (all ranks) = blocks * 5 * steps / time.
+
+N > 1 (torchrun, one rank per GPU): residual blocks are sharded by landmark; every rank holds the
+replicated control points, eliminates its own landmarks and the reduced normal equations are summed with one RCCL
+all-reduce per iteration. Weak scaling: each rank gets a full configs[1]-sized shard (global = N x 50k residual blocks
+observing N x 5k landmarks on the same 128 control points).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LM_ITERATIONS = 5           # optimizer.cpp:40
+B_ALG_PIXEL_K4 = 480        # algorithmic bytes per pixel residual block linearised, SURVEY.md §8(d)
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def cpu_baseline(window, budget_s=20.0):
+    """Oracle (CPU restatement, 1 thread like the reference's num_threads = 1) timed on the same workload, bounded."""
+    import hyperslam_amd as ha
+    from hyperslam_amd import _lib
+    lib = _lib.Library(os.path.join(ROOT, "oracle", "liboracle.so"), "hso_")
+    n_blocks = window.num_residual_blocks()
+    runs, spent, iters = 0, 0.0, 0
+    while runs < 1 or (spent < budget_s and runs < 5):
+        with ha.Problem(window, lib=lib) as p:
+            t = time.perf_counter()
+            s = p.solve(LM_ITERATIONS)
+            spent += time.perf_counter() - t
+        iters += s["num_iterations"]
+        runs += 1
+    return {"value": n_blocks * iters / spent, "unit": "residual_blocks/s", "cores": 1, "kind": "port",
+            "ms_per_iteration": 1e3 * spent / iters,
+            "sample": f"{runs} x optimize() ({LM_ITERATIONS} LM iterations) of the full workload on 1 host thread; own C++ restatement, not Ceres"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import hyperslam_amd as ha
+    from hyperslam_amd import synthetic
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # weak scaling: world x configs[1]; landmarks l with l % world == rank live on this rank
+    full = synthetic.config1(n_cp=128, n_landmarks=5000 * world, obs_pairs=5)
+    window = synthetic.shard_by_landmark(full, rank, world) if world > 1 else full
+    n_blocks_local = window.num_residual_blocks()
+    n_blocks_global = full.num_residual_blocks()
+
+    from hyperslam_amd.distributed import attach_allreduce
+    problem = ha.Problem(window, device=local_rank)
+    keep = attach_allreduce(problem, dist) if world > 1 else None
+    problem.snapshot()
+
+    def step():
+        problem.restore()
+        s = problem.solve(LM_ITERATIONS)
+        assert s["num_iterations"] == LM_ITERATIONS, s
+        return s
+
+    for _ in range(args.warmup):
+        step()
+    stage = {"linearize_ms": 0.0, "schur_ms": 0.0, "solve_ms": 0.0, "update_ms": 0.0, "total_ms": 0.0}
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        s = step()
+        for k in stage:
+            stage[k] += s[k]
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        n_lin = args.steps * LM_ITERATIONS  # launches of the linearise kernel in the timed region
+        lin_ms = stage["linearize_ms"] / n_lin
+        achieved = B_ALG_PIXEL_K4 * n_blocks_local / (lin_ms * 1e-3) / 1e9
+        out = {
+            "metric": "residual blocks linearised per second (LM iteration = linearise + Schur + solve + update), 128-control-point window",
+            "value": n_blocks_global * LM_ITERATIONS * args.steps / elapsed,
+            "unit": "residual_blocks/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_gn_iteration": 1e3 * elapsed / (args.steps * LM_ITERATIONS),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: order-4 SE3 B-spline, 128 control points, 50k pixel reprojection residual blocks "
+                                   "+ 5k landmarks per GPU, Schur on landmarks",
+                       "residual_blocks_per_gpu": n_blocks_local, "landmarks_per_gpu": int(len(window.landmarks) if world == 1 else 5000),
+                       "lm_iterations_per_step": LM_ITERATIONS, "parallelism": f"residual-sharded x{world}" if world > 1 else "single GPU"},
+            "final_cost": s["final_cost"], "initial_cost": s["initial_cost"],
+            "device_ms_per_iteration": {k: v / n_lin for k, v in stage.items()},
+            "roofline": {"kernel": "k_linearize_visual<4>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": B_ALG_PIXEL_K4 * n_blocks_local, "avg_launch_ms": lin_ms},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(full if world == 1 else window)
+            out["speedup_vs_cpu_1thread"] = out["value"] / world / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    problem.close()
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

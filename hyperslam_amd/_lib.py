@@ -99,6 +99,10 @@ _SIGNATURES = {
 }
 _PRODUCT_ONLY = {
     "set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
+    "set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "band_blocks": (C.c_int, [C.c_void_p]),
+    "snapshot": (C.c_int, [C.c_void_p]),
+    "restore": (C.c_int, [C.c_void_p]),
     "version": (C.c_int, []),
     "arch": (C.c_char_p, []),
 }

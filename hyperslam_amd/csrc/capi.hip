@@ -90,8 +90,15 @@ struct hs_problem {
   DBuf<double> d_scale_p, d_Sb, d_Ub, d_g_s, d_g_full, d_D2p, d_step_p, d_delta_p;
   DBuf<double> d_cost_part, d_cand_part, d_norm_part, d_dbg, d_dbg_cost;
   DBuf<DevState> d_state;
+  DBuf<double> d_xbuf;
+  int rank = 0, world = 1, min_bw = 0;
+  DBuf<double> d_cp_snap, d_lm_snap;
+  bool has_snapshot = false;
+  DevState* h_state = nullptr;  // pinned
+  std::vector<hipEvent_t> events;
   Tables T;
   int nb_vis = 0, nb_pri = 0, nb_cp = 0;
+  int chol_lds_max = 64 * 1024;
   hs_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
 };
@@ -126,8 +133,9 @@ int prepare(hs_problem* p) {
     if (p->br_cam[i] < 0 || p->br_cam[i] >= p->n_cam) HS_FAIL(HS_ERR_INVALID, "bearing residual references a camera outside the camera table");
   VisualInput in = {k, p->n_cp, p->n_lm, p->t0, p->dt, n_px, n_br, p->px_stamp.data(), p->br_stamp.data(), p->px_lm.data(), p->br_lm.data()};
   if (!build_visual_structure(in, &p->vs, &p->err)) return HS_ERR_INVALID;
+  p->vs.bw = std::max(p->vs.bw, p->min_bw);
   const VisualStructure& vs = p->vs;
-  if (6 * vs.bw > kBlock || size_t(6 * vs.bw) * (6 * vs.bw + 2) * 8 + size_t(6) * p->n_cp * 8 > 160 * 1024 - 1024)
+  if (6 * vs.bw > kBlock || size_t(6 * vs.bw) * (6 * vs.bw + 2) * 8 + size_t(6) * p->n_cp * 8 > size_t(p->chol_lds_max))
     HS_FAIL(HS_ERR_INVALID, "landmark tracks span too many control points for the LDS-resident banded factorisation");
   const int n_vis = n_px + n_br;
 
@@ -231,7 +239,9 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_cost_part.reserve(p->nb_vis + p->nb_pri + 1));
   HIP_TRY(p->d_cand_part.reserve(p->nb_vis + p->nb_pri + 1));
   const int nb_norm = std::max(p->nb_cp, std::min(64, (p->n_lm + kBlock - 1) / kBlock));
-  HIP_TRY(p->d_norm_part.reserve(2 * size_t(nb_norm)));
+  HIP_TRY(p->d_norm_part.reserve(4 * size_t(nb_norm)));
+  const int x_count1 = np * (ncb + 3) + 1 + p->world;
+  HIP_TRY(p->d_xbuf.reserve(size_t(x_count1) + 8));
   HIP_TRY(p->d_state.reserve(1));
 
   Tables& T = p->T;
@@ -253,6 +263,10 @@ int prepare(hs_problem* p) {
   T.step_p = p->d_step_p.p, T.delta_p = p->d_delta_p.p;
   T.cost_part = p->d_cost_part.p, T.cand_part = p->d_cand_part.p, T.n_cost_part = p->nb_vis + p->nb_pri;
   T.norm_part = p->d_norm_part.p, T.n_norm_part = nb_norm;
+  T.xbuf = p->d_xbuf.p;
+  T.xo_g = np * ncb, T.xo_gs = T.xo_g + np, T.xo_dj = T.xo_gs + np, T.xo_cost = T.xo_dj + np, T.xo_gmax = T.xo_cost + 1;
+  T.x_count1 = x_count1, T.xo_dec = x_count1;
+  T.rank = p->rank, T.world = p->world;
   T.st = p->d_state.p;
   HIP_TRY(hipStreamSynchronize(s));  // host staging vectors go out of scope
   p->dirty = false;
@@ -260,11 +274,8 @@ int prepare(hs_problem* p) {
 }
 
 int reset_state(hs_problem* p, int max_iterations, double radius) {
-  DevState st;
-  std::memset(&st, 0, sizeof(st));
-  st.radius = radius, st.decrease_factor = 2.0, st.max_iterations = max_iterations;
-  HIP_TRY(hipMemcpyAsync(p->d_state.p, &st, sizeof(st), hipMemcpyHostToDevice, p->stream));
-  HIP_TRY(hipStreamSynchronize(p->stream));  // `st` is a stack object
+  k_reset_state<<<1, 64, 0, p->stream>>>(p->d_state.p, max_iterations, radius);
+  HIP_TRY(hipGetLastError());
   return HS_OK;
 }
 
@@ -280,33 +291,51 @@ int launch_linearize(hs_problem* p) {
   return HS_OK;
 }
 
+int exchange(hs_problem* p, double* buf, int64_t count) {
+  if (!p->allreduce) return HS_OK;
+  if (p->allreduce(p->allreduce_user, buf, count, p->stream) != 0) HS_FAIL(HS_ERR_DEVICE, "all-reduce hook reported a failure");
+  return HS_OK;
+}
+
 template <int K>
 int launch_build(hs_problem* p) {
   const Tables& T = p->T;
   hipStream_t s = p->stream;
   if (T.n_lm) k_landmark<K><<<(T.n_lm + kBlock / 64 - 1) / (kBlock / 64), kBlock, 0, s>>>(T);
-  k_hpp_diag<K><<<T.sp.n_cp, kBlock, 0, s>>>(T);
   const size_t lds = (size_t(6) * 6 * T.bw + 16 + 6 * kBlock + 64) * sizeof(double);
-  k_build_reduced<K><<<T.sp.n_cp, kBlock, lds, s>>>(T);
-  k_mark_scaling<<<1, 64, 0, s>>>(T);
-  k_cost_reduce<<<1, kBlock, 0, s>>>(T);
+  k_build_raw<K><<<T.sp.n_cp, kBlock, lds, s>>>(T);
+  k_pack_exchange<<<1, kBlock, 0, s>>>(T);
+  HIP_TRY(hipGetLastError());
+  const int rc = exchange(p, T.xbuf, T.x_count1);  // one RCCL all-reduce of [S | g | diag | cost] per linearisation
+  if (rc) return rc;
+  k_finalize_reduced<<<T.sp.n_cp, kBlock, 0, s>>>(T);
+  k_cost_reduce<<<1, 64, 0, s>>>(T);
+  HIP_TRY(hipGetLastError());
+  return HS_OK;
+}
+
+int launch_factor(hs_problem* p) {
+  const Tables& T = p->T;
+  const int ncb = 6 * T.bw;
+  const size_t chol_lds = (size_t(ncb) * (ncb + 2) + T.np) * sizeof(double);
+  k_band_cholesky_solve<<<1, kCholThreads, chol_lds, p->stream>>>(T);
   HIP_TRY(hipGetLastError());
   return HS_OK;
 }
 
 template <int K>
-int launch_step(hs_problem* p) {
+int launch_update(hs_problem* p) {
   const Tables& T = p->T;
   hipStream_t s = p->stream;
-  const int ncb = 6 * T.bw;
-  const size_t chol_lds = (size_t(ncb) * (ncb + 2) + T.np) * sizeof(double);
-  k_band_cholesky_solve<<<1, kCholThreads, chol_lds, s>>>(T);
   if (T.n_lm) k_backsub_landmarks<<<(T.n_lm + kBlock / 64 - 1) / (kBlock / 64), kBlock, 0, s>>>(T);
-  k_model_cost<<<1, kBlock, 0, s>>>(T);
   k_retract<<<T.n_norm_part, kBlock, 0, s>>>(T);
   if (T.n_vis) k_cost_visual<K><<<p->nb_vis, kBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.lm_cand, T.cand_part);
   if (T.n_pri) k_cost_prior<K><<<p->nb_pri, kBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.cand_part + p->nb_vis);
-  k_decide<<<1, kBlock, 0, s>>>(T);
+  k_pack_decision<<<1, kBlock, 0, s>>>(T);
+  HIP_TRY(hipGetLastError());
+  const int rc = exchange(p, T.xbuf + T.xo_dec, 5);  // candidate cost + norms + landmark-side model-cost terms
+  if (rc) return rc;
+  k_decide<<<1, 64, 0, s>>>(T);
   const int nb_commit = std::max((8 * T.sp.n_cp + kBlock - 1) / kBlock, 1);
   k_commit<<<nb_commit, kBlock, 0, s>>>(T);
   HIP_TRY(hipGetLastError());
@@ -315,7 +344,10 @@ int launch_step(hs_problem* p) {
 
 int set_func_attributes(hs_problem* p) {
   // opt in to > 64 KiB dynamic LDS for the factorisation
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_cholesky_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+  hipFuncAttributes fa;
+  HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_band_cholesky_solve)));
+  p->chol_lds_max = 160 * 1024 - int(fa.sharedSizeBytes);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_cholesky_solve), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
   return HS_OK;
 }
 
@@ -346,6 +378,10 @@ int hs_create(int device, void* stream, hs_problem** out) {
     }
     p->own_stream = true;
   }
+  if (hipHostMalloc(reinterpret_cast<void**>(&p->h_state), sizeof(DevState), hipHostMallocDefault) != hipSuccess) {
+    delete p;
+    return HS_ERR_DEVICE;
+  }
   if (set_func_attributes(p) != HS_OK) {
     const std::string e = p->err;
     std::fprintf(stderr, "hyperslam_hip: %s\n", e.c_str());
@@ -360,6 +396,8 @@ int hs_destroy(hs_problem* p) {
   if (!p) return HS_OK;
   (void)hipSetDevice(p->device);
   (void)hipStreamSynchronize(p->stream);
+  for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
+  if (p->h_state) (void)hipHostFree(p->h_state);
   if (p->own_stream) (void)hipStreamDestroy(p->stream);
   delete p;
   return HS_OK;
@@ -587,7 +625,10 @@ int hs_cost(hs_problem* p, double* cost) {
   if (rc) return rc;
   rc = p->k == 4 ? launch_linearize<4>(p) : launch_linearize<6>(p);
   if (rc) return rc;
-  k_cost_reduce<<<1, kBlock, 0, p->stream>>>(p->T);
+  k_pack_exchange<<<1, kBlock, 0, p->stream>>>(p->T);
+  rc = exchange(p, p->T.xbuf + p->T.xo_cost, 1);
+  if (rc) return rc;
+  k_cost_reduce<<<1, 64, 0, p->stream>>>(p->T);
   HIP_TRY(hipGetLastError());
   DevState st;
   HIP_TRY(hipMemcpyAsync(&st, p->d_state.p, sizeof(st), hipMemcpyDeviceToHost, p->stream));
@@ -632,26 +673,38 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
   rc = reset_state(p, max_iterations, 1e4);
   if (rc) return rc;
   hipStream_t s = p->stream;
-  std::vector<hipEvent_t> ev(size_t(3) * max_iterations + 2);
-  for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+  // stage timing: 4 stages per iteration bracketed by HIP events on the launch stream
+  const size_t n_ev = size_t(4) * max_iterations + 1;
+  while (p->events.size() < n_ev) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    p->events.push_back(e);
+  }
+  std::vector<hipEvent_t>& ev = p->events;
   HIP_TRY(hipEventRecord(ev[0], s));
   for (int it = 0; it < max_iterations; ++it) {
     rc = p->k == 4 ? launch_linearize<4>(p) : launch_linearize<6>(p);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(ev[3 * it + 1], s));
+    HIP_TRY(hipEventRecord(ev[4 * it + 1], s));
     rc = p->k == 4 ? launch_build<4>(p) : launch_build<6>(p);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(ev[3 * it + 2], s));
-    rc = p->k == 4 ? launch_step<4>(p) : launch_step<6>(p);
+    HIP_TRY(hipEventRecord(ev[4 * it + 2], s));
+    rc = launch_factor(p);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(ev[3 * it + 3], s));
+    HIP_TRY(hipEventRecord(ev[4 * it + 3], s));
+    rc = p->k == 4 ? launch_update<4>(p) : launch_update<6>(p);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ev[4 * it + 4], s));
   }
   if (max_iterations == 0) {
     rc = p->k == 4 ? launch_linearize<4>(p) : launch_linearize<6>(p);
     if (rc) return rc;
-    k_cost_reduce<<<1, kBlock, 0, s>>>(p->T);
+    k_pack_exchange<<<1, kBlock, 0, s>>>(p->T);
+    rc = exchange(p, p->T.xbuf + p->T.xo_cost, 1);
+    if (rc) return rc;
+    k_cost_reduce<<<1, 64, 0, s>>>(p->T);
   }
-  DevState st;
+  DevState& st = *p->h_state;
   HIP_TRY(hipMemcpyAsync(&st, p->d_state.p, sizeof(st), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   std::memset(summary, 0, sizeof(*summary));
@@ -662,18 +715,15 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
   summary->termination = st.termination;
   summary->num_residual_blocks = p->T.n_vis + p->T.n_pri;
   for (int it = 0; it < max_iterations; ++it) {
-    float a = 0, b = 0, c = 0;
-    (void)hipEventElapsedTime(&a, ev[3 * it], ev[3 * it + 1]);
-    (void)hipEventElapsedTime(&b, ev[3 * it + 1], ev[3 * it + 2]);
-    (void)hipEventElapsedTime(&c, ev[3 * it + 2], ev[3 * it + 3]);
-    summary->linearize_ms += a, summary->schur_ms += b, summary->solve_ms += c;
+    float t[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 4; ++k) (void)hipEventElapsedTime(&t[k], ev[4 * it + k], ev[4 * it + k + 1]);
+    summary->linearize_ms += t[0], summary->schur_ms += t[1], summary->solve_ms += t[2], summary->update_ms += t[3];
   }
   if (max_iterations > 0) {
     float t = 0;
-    (void)hipEventElapsedTime(&t, ev[0], ev[3 * max_iterations]);
+    (void)hipEventElapsedTime(&t, ev[0], ev[4 * max_iterations]);
     summary->total_ms = t;
   }
-  for (auto& e : ev) (void)hipEventDestroy(e);
   if (iterations) {
     std::memset(iterations, 0, sizeof(hs_iteration) * (size_t(max_iterations) + 1));
     const int n = std::min(st.num_iterations, max_iterations);
@@ -683,10 +733,44 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
   return HS_OK;
 }
 
+int hs_snapshot(hs_problem* p) {
+  if (!p) return HS_ERR_INVALID;
+  int rc = prepare(p);
+  if (rc) return rc;
+  HIP_TRY(p->d_cp_snap.reserve(p->cp.size()));
+  HIP_TRY(p->d_lm_snap.reserve(p->lm.size() + 1));
+  HIP_TRY(hipMemcpyAsync(p->d_cp_snap.p, p->d_cp.p, p->cp.size() * 8, hipMemcpyDeviceToDevice, p->stream));
+  if (p->n_lm) HIP_TRY(hipMemcpyAsync(p->d_lm_snap.p, p->d_lm.p, p->lm.size() * 8, hipMemcpyDeviceToDevice, p->stream));
+  p->has_snapshot = true;
+  return HS_OK;
+}
+
+int hs_restore(hs_problem* p) {
+  if (!p) return HS_ERR_INVALID;
+  if (!p->has_snapshot || p->dirty) HS_FAIL(HS_ERR_STATE, "hs_restore without a valid hs_snapshot");
+  HIP_TRY(hipMemcpyAsync(p->d_cp.p, p->d_cp_snap.p, p->cp.size() * 8, hipMemcpyDeviceToDevice, p->stream));
+  if (p->n_lm) HIP_TRY(hipMemcpyAsync(p->d_lm.p, p->d_lm_snap.p, p->lm.size() * 8, hipMemcpyDeviceToDevice, p->stream));
+  return HS_OK;
+}
+
 int hs_set_allreduce(hs_problem* p, hs_allreduce_fn fn, void* user) {
   if (!p) return HS_ERR_INVALID;
   p->allreduce = fn, p->allreduce_user = user;
   return HS_OK;
+}
+
+int hs_set_shard(hs_problem* p, int rank, int world, int min_band_blocks) {
+  if (!p) return HS_ERR_INVALID;
+  if (world < 1 || rank < 0 || rank >= world || min_band_blocks < 0) HS_FAIL(HS_ERR_INVALID, "bad shard description");
+  p->rank = rank, p->world = world, p->min_bw = min_band_blocks;
+  p->dirty = true;
+  return HS_OK;
+}
+
+int hs_band_blocks(hs_problem* p) {
+  if (!p) return -1;
+  if (prepare(p) != HS_OK) return -1;
+  return p->T.bw;
 }
 
 int hs_get_control_points(hs_problem* p, double* cp) {

@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(kBlock) k_linearize_prior(Tables T, double* ou
 template <int K>
 __global__ void __launch_bounds__(kBlock) k_cost_visual(Tables T, const double* cp_src, const double* lm_src, double* cost_part) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  if (T.st->done || !T.st->step_valid) return;
+  if (T.st->done) return;
   double* cps = smem;
   stage_cps(cp_src, cps, 8 * T.sp.n_cp);
   __shared__ double red[kBlock / 64];
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(kBlock) k_cost_visual(Tables T, const double* 
 template <int K>
 __global__ void __launch_bounds__(kBlock) k_cost_prior(Tables T, const double* cp_src, double* cost_part) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  if (T.st->done || !T.st->step_valid) return;
+  if (T.st->done) return;
   double* cps = smem;
   stage_cps(cp_src, cps, 8 * T.sp.n_cp);
   __shared__ double red[kBlock / 64];
@@ -208,41 +208,6 @@ __global__ void __launch_bounds__(kBlock) k_landmark(Tables T) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Jacobi scaling of the pose-side unknowns: s = 1 / (1 + sqrt(diag(J'J))) at iteration 0.
-// One workgroup per control point; threads stride over the records of the k segments that touch it.
-// ---------------------------------------------------------------------------------------------------------------------
-template <int K>
-__global__ void __launch_bounds__(kBlock) k_hpp_diag(Tables T) {
-  if (T.st->done || T.st->scaling_ready) return;
-  constexpr int VREC = 8 + 12 * K, PREC = 6 + 36 * K;
-  const int i = blockIdx.x;
-  __shared__ double red[kBlock / 64];
-  double acc[6] = {0, 0, 0, 0, 0, 0};
-  const int f0 = max(0, i - K + 1), f1 = min(i, T.n_seg - 1);
-  for (int first = f0; first <= f1; ++first) {
-    const int ao = 6 * (i - first);
-    for (int pos = T.v_seg_ptr[first] + threadIdx.x; pos < T.v_seg_ptr[first + 1]; pos += kBlock) {
-      const double* rec = T.v_rec + size_t(pos) * VREC + 8 + ao;
-#pragma unroll
-      for (int a = 0; a < 6; ++a) acc[a] = fma(rec[a], rec[a], fma(rec[6 * K + a], rec[6 * K + a], acc[a]));
-    }
-    if (T.n_pri)
-      for (int pos = T.p_seg_ptr[first] + threadIdx.x; pos < T.p_seg_ptr[first + 1]; pos += kBlock) {
-        const double* rec = T.p_rec + size_t(pos) * PREC + 6 + ao;
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-          for (int a = 0; a < 6; ++a) acc[a] = fma(rec[r * 6 * K + a], rec[r * 6 * K + a], acc[a]);
-      }
-  }
-#pragma unroll
-  for (int a = 0; a < 6; ++a) {
-    const double s = block_sum(acc[a], red);
-    if (threadIdx.x == 0) T.scale_p[6 * i + a] = 1.0 / (1.0 + sqrt(s));
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // Reduced system: block row i of  S = Sp (J_p'J_p) Sp + D_p^2 - Sp (sum_l Yh_l Yh_l') Sp,   g = Sp (g_p - sum_l Yh_l yh_l).
 // Gather formulation: each workgroup owns one block row, walks the records of the k segments touching control point i and
 // the Y-hat rows of the landmarks covering it.  The K dimension is split over thread groups and combined in a fixed
@@ -250,7 +215,7 @@ __global__ void __launch_bounds__(kBlock) k_hpp_diag(Tables T) {
 // LDS (doubles): tile 6*ncb | gacc 8 | dj 8 | red 6*kBlock + 64.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int K>
-__global__ void __launch_bounds__(kBlock) k_build_reduced(Tables T) {
+__global__ void __launch_bounds__(kBlock) k_build_raw(Tables T) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (T.st->done) return;
   constexpr int VREC = 8 + 12 * K, PREC = 6 + 36 * K;
@@ -318,8 +283,6 @@ __global__ void __launch_bounds__(kBlock) k_build_reduced(Tables T) {
     }
     __syncthreads();
   }
-  // unscaled gradient max norm (pose side; Ceres uses the gradient of the full problem)
-  if (tid < 6) atomicMax(&T.st->gmax_bits, (unsigned long long)__double_as_longlong(fabs(gacc[tid])));
 
   // ---- part B: Schur terms ---------------------------------------------------------------------------------------
   double gschur = 0.0;  // valid on tid < 6
@@ -359,18 +322,56 @@ __global__ void __launch_bounds__(kBlock) k_build_reduced(Tables T) {
     __syncthreads();
   }
 
-  // ---- finalise: Jacobi scaling, LM diagonal, inactive coordinates ------------------------------------------------
-  const double radius = T.st->radius;
+  // ---- raw (unscaled, undamped) block row into the exchange buffer: additive across residual shards --------------
+  double* X = T.xbuf;
+  for (int e = tid; e < 6 * ncb; e += kBlock) {
+    const int a = e / ncb, c = e % ncb;
+    X[size_t(6 * i + a) * ncb + c] = tile[e];
+  }
+  if (tid < 6) {
+    const int rho = 6 * i + tid;
+    X[T.xo_g + rho] = gacc[tid];
+    X[T.xo_gs + rho] = gschur;
+    X[T.xo_dj + rho] = dj[tid];
+  }
+}
+
+/// Local cost and landmark-side gradient max norm into the exchange buffer (slot per rank so that a SUM all-reduce
+/// delivers every rank's value to every rank).
+__global__ void __launch_bounds__(kBlock) k_pack_exchange(Tables T) {
+  __shared__ double red[kBlock / 64];
+  DevState* st = T.st;
+  if (st->done) return;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < T.n_cost_part; i += blockDim.x) s += T.cost_part[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) T.xbuf[T.xo_cost] = s;
+  for (int r = threadIdx.x; r < T.world; r += blockDim.x)
+    T.xbuf[T.xo_gmax + r] = (r == T.rank) ? __longlong_as_double((long long)st->gmax_bits) : 0.0;
+}
+
+/// After the (optional) all-reduce: Jacobi scaling (fixed at iteration 0), LM diagonal, inactive coordinates.
+///   S = Sp Sraw Sp + D_p^2,  g = Sp (g_p + g_schur),  g_full = Sp g_p,  D_p^2 = clamp(Sp^2 diag(J'J), 1e-6, 1e32) / radius.
+__global__ void __launch_bounds__(kBlock) k_finalize_reduced(Tables T) {
+  DevState* st = T.st;
+  if (st->done) return;
+  const int i = blockIdx.x, tid = threadIdx.x;
+  const int ncb = 6 * T.bw;
+  const double* X = T.xbuf;
+  const double radius = st->radius;
+  const bool fresh = !st->scaling_ready;
+  auto scale_of = [&](int rho) { return fresh ? 1.0 / (1.0 + sqrt(X[T.xo_dj + rho])) : T.scale_p[rho]; };
   for (int e = tid; e < 6 * ncb; e += kBlock) {
     const int a = e / ncb, c = e % ncb;
     const int rho = 6 * i + a, sigma = 6 * i + c;
     double out = 0.0;
     if (sigma < T.np) {
-      const double sr = T.scale_p[rho], sc = T.scale_p[sigma];
-      out = sr * sc * tile[e];
+      const double sr = scale_of(rho), sc = scale_of(sigma);
+      out = sr * sc * X[size_t(rho) * ncb + c];
       if (c == a) {
-        if (dj[a] > 0.0) {
-          const double d2 = fmin(fmax(sr * sr * dj[a], 1e-6), 1e32) / radius;
+        const double d = X[T.xo_dj + rho];
+        if (d > 0.0) {
+          const double d2 = fmin(fmax(sr * sr * d, 1e-6), 1e32) / radius;
           out += d2;
           T.D2p[rho] = d2;
         } else {  // structurally zero column (constant / unobserved): keep the system non-singular, step = 0
@@ -383,9 +384,12 @@ __global__ void __launch_bounds__(kBlock) k_build_reduced(Tables T) {
   }
   if (tid < 6) {
     const int rho = 6 * i + tid;
-    const double sr = T.scale_p[rho];
-    T.g_full[rho] = sr * gacc[tid];
-    T.g_s[rho] = sr * (gacc[tid] + gschur);
+    const double sr = scale_of(rho);
+    const double gp = X[T.xo_g + rho];
+    T.g_full[rho] = sr * gp;
+    T.g_s[rho] = sr * (gp + X[T.xo_gs + rho]);
+    if (fresh) T.scale_p[rho] = sr;
+    atomicMax(&st->gmax_pose_bits, (unsigned long long)__double_as_longlong(fabs(gp)));
   }
 }
 
@@ -591,7 +595,7 @@ __global__ void __launch_bounds__(kBlock) k_retract(Tables T) {
   if (T.st->done) return;
   __shared__ double red[kBlock / 64];
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  double xs = 0.0, ss = 0.0;
+  double xs = 0.0, ss = 0.0, xl = 0.0, sl = 0.0;
   if (j < T.sp.n_cp) {
     const double* x = T.cp + 8 * j;
     double* y = T.cp_cand + 8 * j;
@@ -608,20 +612,21 @@ __global__ void __launch_bounds__(kBlock) k_retract(Tables T) {
       for (int c = 0; c < 8; ++c) xs = fma(x[c], x[c], xs), ss = fma(x[c] - y[c], x[c] - y[c], ss);
     }
   }
-  // landmarks handled by the same grid (thread j also covers landmark j when in range)
   for (int l = j; l < T.n_lm; l += gridDim.x * blockDim.x) {
     const bool active = (T.lm_ptr[l + 1] > T.lm_ptr[l]) && !T.lm_const[l];
     if (active) {
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         const double x = T.lm[3 * l + a], y = T.lm_cand[3 * l + a];
-        xs = fma(x, x, xs), ss = fma(x - y, x - y, ss);
+        xl = fma(x, x, xl), sl = fma(x - y, x - y, sl);
       }
     }
   }
-  xs = block_sum(xs, red);
-  ss = block_sum(ss, red);
-  if (threadIdx.x == 0) T.norm_part[2 * blockIdx.x] = xs, T.norm_part[2 * blockIdx.x + 1] = ss;
+  xs = block_sum(xs, red), ss = block_sum(ss, red), xl = block_sum(xl, red), sl = block_sum(sl, red);
+  if (threadIdx.x == 0) {
+    double* o = T.norm_part + 4 * blockIdx.x;
+    o[0] = xs, o[1] = ss, o[2] = xl, o[3] = sl;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -637,69 +642,69 @@ HSD double ordered_sum(const double* p, int n, double* lds) {
 }
 
 __global__ void __launch_bounds__(kBlock) k_cost_reduce(Tables T) {
-  // cost of the current linearisation point -> st->cost, gradient max norm -> st->gmax
-  __shared__ double red[kBlock / 64];
+  // (global) cost of the current linearisation point -> st->cost, gradient max norm -> st->gmax; iteration bookkeeping
   DevState* st = T.st;
-  if (st->done) return;
-  const double c = ordered_sum(T.cost_part, T.n_cost_part, red);
-  if (threadIdx.x == 0) {
-    st->cost = c;
-    st->gmax = __longlong_as_double((long long)st->gmax_bits);
-    if (st->iteration == 0) {
-      hs_iteration& r = st->records[0];
-      r.iteration = 0, r.step_is_valid = 1, r.step_is_successful = 1, r.cost = c, r.cost_change = 0, r.gradient_max_norm = st->gmax;
-      r.step_norm = 0, r.relative_decrease = 0, r.radius = st->radius;
-      st->iteration = 1;
-    }
-    // FinalizeIterationAndCheckIfMinimizerCanContinue
-    if (st->iteration - 1 >= st->max_iterations) {
-      st->done = 1, st->termination = HS_NO_CONVERGENCE;
-    } else if (st->gmax <= 1e-10) {
-      st->done = 1, st->termination = HS_CONVERGENCE;
-    } else if (st->radius <= 1e-32) {
-      st->done = 1, st->termination = HS_CONVERGENCE;
-    }
+  if (st->done || threadIdx.x != 0) return;
+  const double c = T.xbuf[T.xo_cost];
+  double gm = __longlong_as_double((long long)st->gmax_pose_bits);
+  for (int r = 0; r < T.world; ++r) gm = fmax(gm, T.xbuf[T.xo_gmax + r]);
+  st->cost = c;
+  st->gmax = gm;
+  st->scaling_ready = 1;  // Jacobi scaling is computed at iteration 0 only
+  if (st->iteration == 0) {
+    hs_iteration& r = st->records[0];
+    r.iteration = 0, r.step_is_valid = 1, r.step_is_successful = 1, r.cost = c, r.cost_change = 0, r.gradient_max_norm = gm;
+    r.step_norm = 0, r.relative_decrease = 0, r.radius = st->radius;
+    st->iteration = 1;
+  }
+  // FinalizeIterationAndCheckIfMinimizerCanContinue
+  if (st->iteration - 1 >= st->max_iterations) {
+    st->done = 1, st->termination = HS_NO_CONVERGENCE;
+  } else if (gm <= 1e-10) {
+    st->done = 1, st->termination = HS_CONVERGENCE;
+  } else if (st->radius <= 1e-32) {
+    st->done = 1, st->termination = HS_CONVERGENCE;
   }
 }
 
-__global__ void __launch_bounds__(kBlock) k_model_cost(Tables T) {
-  // model_cost_change = -g.step/2 + step'D^2 step/2 (exact for the solved system); validity of the step
+/// Second exchange buffer (5 doubles, additive across shards): candidate cost, |x|^2, |x - x+|^2 and the landmark-side
+/// terms of the model cost change. The replicated control-point part of the norms is contributed by rank 0 only.
+__global__ void __launch_bounds__(kBlock) k_pack_decision(Tables T) {
   __shared__ double red[kBlock / 64];
   DevState* st = T.st;
   if (st->done) return;
-  double gd = 0.0, dd = 0.0;
+  double cand = 0.0, xs = 0.0, ss = 0.0, gd = 0.0, dd = 0.0;
+  for (int i = threadIdx.x; i < T.n_cost_part; i += blockDim.x) cand += T.cand_part[i];
+  for (int i = threadIdx.x; i < T.n_norm_part; i += blockDim.x) {
+    xs += T.norm_part[4 * i + 2], ss += T.norm_part[4 * i + 3];                        // landmarks (local)
+    if (T.rank == 0) xs += T.norm_part[4 * i], ss += T.norm_part[4 * i + 1];           // control points (replicated)
+  }
   for (int l = threadIdx.x; l < T.n_lm; l += blockDim.x) gd += T.lm_mcc[2 * l], dd += T.lm_mcc[2 * l + 1];
-  gd = block_sum(gd, red);
-  dd = block_sum(dd, red);
+  cand = block_sum(cand, red), xs = block_sum(xs, red), ss = block_sum(ss, red), gd = block_sum(gd, red), dd = block_sum(dd, red);
   if (threadIdx.x == 0) {
-    const double g_step = st->g_dot_step_pose + gd, d_step = st->d2_step2_pose + dd;
-    const double mcc = -0.5 * g_step + 0.5 * d_step;
-    st->model_cost_change = mcc;
-    const bool finite = isfinite(mcc) && !st->chol_failed;
-    st->step_valid = (finite && mcc >= 0.0) ? 1 : 0;
+    double* D = T.xbuf + T.xo_dec;
+    D[0] = cand, D[1] = xs, D[2] = ss, D[3] = gd, D[4] = dd;
   }
 }
 
 __global__ void __launch_bounds__(kBlock) k_decide(Tables T) {
-  __shared__ double red[kBlock / 64];
   DevState* st = T.st;
-  if (st->done) return;
-  double cand = 0.0, xs = 0.0, ss = 0.0;
-  if (st->step_valid) {
-    cand = ordered_sum(T.cand_part, T.n_cost_part, red);
-    double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < T.n_norm_part; i += blockDim.x) a += T.norm_part[2 * i], b += T.norm_part[2 * i + 1];
-    xs = block_sum(a, red);
-    ss = block_sum(b, red);
-  }
-  if (threadIdx.x != 0) return;
+  if (st->done || threadIdx.x != 0) return;
+  const double* D = T.xbuf + T.xo_dec;
+  const double cand = D[0], xs = D[1], ss = D[2];
+  // model_cost_change = -g.step/2 + step'D^2 step/2 (exact for the solved system; TrustRegionMinimizer evaluates
+  // -(J step).(r + J step/2), identical algebraically)
+  const double g_step = st->g_dot_step_pose + D[3], d_step = st->d2_step2_pose + D[4];
+  const double mcc = -0.5 * g_step + 0.5 * d_step;
+  st->model_cost_change = mcc;
+  st->step_valid = (isfinite(mcc) && !st->chol_failed && mcc >= 0.0) ? 1 : 0;
   const int it = st->iteration;
   hs_iteration& r = st->records[it];
   r.iteration = it, r.cost = st->cost, r.cost_change = 0, r.gradient_max_norm = st->gmax, r.step_norm = 0, r.relative_decrease = 0;
   r.step_is_valid = st->step_valid, r.step_is_successful = 0;
   st->num_iterations = it;
   st->accepted = 0;
-  st->gmax_bits = 0ull;  // the next linearisation re-accumulates it
+  st->gmax_bits = 0ull, st->gmax_pose_bits = 0ull;  // the next linearisation re-accumulates them
   if (!st->step_valid) {  // HandleInvalidStep
     if (++st->invalid_streak >= 5) {
       st->done = 1, st->termination = HS_FAILURE;
@@ -753,9 +758,16 @@ __global__ void __launch_bounds__(kBlock) k_commit(Tables T) {
   for (int l = idx; l < 3 * T.n_lm; l += gridDim.x * blockDim.x) T.lm[l] = T.lm_cand[l];
 }
 
-/// Marks the Jacobi scaling as fixed after the first build (jacobian scaling is computed at iteration 0 only).
-__global__ void k_mark_scaling(Tables T) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) T.st->scaling_ready = 1;
+/// Fresh trust-region state (LevenbergMarquardtStrategy: initial radius 1e4, decrease factor 2).
+__global__ void k_reset_state(DevState* st, int max_iterations, double radius) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  st->radius = radius, st->decrease_factor = 2.0;
+  st->cost = st->cand_cost = st->model_cost_change = 0.0;
+  st->gmax_bits = 0ull, st->gmax_pose_bits = 0ull, st->gmax = 0.0, st->x_sqnorm = st->step_sqnorm = 0.0;
+  st->g_dot_step_pose = st->d2_step2_pose = 0.0;
+  st->iteration = 0, st->done = 0, st->termination = HS_NO_CONVERGENCE, st->accepted = 0, st->step_valid = 0;
+  st->invalid_streak = 0, st->num_successful = 0, st->num_iterations = 0, st->scaling_ready = 0;
+  st->max_iterations = max_iterations, st->chol_failed = 0;
 }
 
 }  // namespace hs

@@ -35,7 +35,8 @@ struct DevState {
   double cost;            // cost at the current point
   double cand_cost;       // cost at the candidate point
   double model_cost_change;
-  unsigned long long gmax_bits;  // max |gradient| as raw bits (atomicMax on non-negative doubles)
+  unsigned long long gmax_bits;       // landmark-side max |gradient| as raw bits (atomicMax on non-negative doubles)
+  unsigned long long gmax_pose_bits;  // pose-side max |gradient| (after the exchange)
   double gmax;            // gradient max norm of the current linearisation
   double x_sqnorm, step_sqnorm;
   // reduction scratch for the model cost change (scaled coordinates)
@@ -119,6 +120,10 @@ struct Tables {
   int n_cost_part;
   double* norm_part;       // per-block (x_sqnorm, step_sqnorm) pairs
   int n_norm_part;
+  // exchange buffer (additive across residual shards): [Sraw np*6bw | g_p np | g_schur np | diag np | cost | gmax[world] | decision 5]
+  double* xbuf;
+  int xo_g, xo_gs, xo_dj, xo_cost, xo_gmax, xo_dec, x_count1;
+  int rank, world;
   DevState* st;
 };
 

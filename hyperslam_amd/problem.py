@@ -222,6 +222,12 @@ class Problem:
         summary["iterations"] = iterations
         return summary
 
+    def snapshot(self):
+        self._check(self.lib.snapshot(self.h), "snapshot")
+
+    def restore(self):
+        self._check(self.lib.restore(self.h), "restore")
+
     # -- read back ---------------------------------------------------------------------------------------------
     def control_points(self):
         cp = np.zeros((self.window.n_cp, 8))

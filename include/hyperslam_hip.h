@@ -163,6 +163,16 @@ int hs_reduced_system(hs_problem* p, double radius, double* S, double* g);
  * Jacobi scaling, monotonic steps). iterations (nullable) receives max_iterations + 1 records (record 0 = initial point). */
 int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteration* iterations);
 int hs_set_allreduce(hs_problem* p, hs_allreduce_fn fn, void* user);
+/* Residual-sharded operation: this handle holds shard `rank` of `world` (all observations of a landmark on one rank,
+ * control points / sensors replicated). min_band_blocks = max over ranks of hs_band_blocks() so that every rank uses the
+ * same band layout for the exchanged reduced system. */
+int hs_set_shard(hs_problem* p, int rank, int world, int min_band_blocks);
+/* Width of the block band of the reduced system in control-point blocks (max control points touched by one landmark). */
+int hs_band_blocks(hs_problem* p);
+/* Device-side copy / restore of the current point (control points, landmarks): lets a caller re-run optimize() from the
+ * same window state without a host round trip (the reference's equivalent is re-creating the problem). */
+int hs_snapshot(hs_problem* p);
+int hs_restore(hs_problem* p);
 
 /* ---- read back (the reference mutates the variables in place through raw double*, optimizer.cpp:299-305) ------- */
 int hs_get_control_points(hs_problem* p, double* cp);

@@ -69,8 +69,11 @@ def test_solve_trajectory(name, w, hip, oracle):
         assert sg["termination"] == sc["termination"]
         for ig, ic in zip(sg["iterations"], sc["iterations"]):
             assert ig["step_is_successful"] == ic["step_is_successful"]
-            for k in ("cost", "radius", "step_norm", "relative_decrease"):
-                assert abs(ig[k] - ic[k]) <= 1e-6 * max(abs(ic[k]), 1e-12), (name, ig["iteration"], k, ig[k], ic[k])
+            # round-off differences between the two factorisations are amplified from one iteration to the next; the cost
+            # is therefore compared relative to the scale of the problem (initial cost), the rest relatively
+            assert abs(ig["cost"] - ic["cost"]) <= 1e-6 * abs(ic["cost"]) + 1e-8 * sc["initial_cost"], (name, ig["iteration"], ig["cost"], ic["cost"])
+            for k in ("radius", "step_norm", "relative_decrease"):
+                assert abs(ig[k] - ic[k]) <= 1e-5 * max(abs(ic[k]), 1e-12), (name, ig["iteration"], k, ig[k], ic[k])
         assert rel(g.control_points(), c.control_points()) < 1e-7
         if len(w.landmarks):
             assert rel(g.landmarks(), c.landmarks()) < 1e-7

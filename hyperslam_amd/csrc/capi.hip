@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -87,10 +88,11 @@ struct hs_problem {
   DBuf<int> d_v_lm, d_v_info, d_v_first, d_v_pos, d_v_seg_ptr, d_v_dbgpos;
   DBuf<double> d_p_stamp, d_p_meas, d_p_rec;
   DBuf<int> d_p_sensor, d_p_first, d_p_seg_ptr;
-  DBuf<double> d_scale_p, d_Sb, d_Ub, d_g_s, d_g_full, d_D2p, d_step_p, d_delta_p;
+  DBuf<double> d_scale_p, d_Sb, d_Ub, d_Ubk, d_g_s, d_g_full, d_D2p, d_step_p, d_delta_p;
   DBuf<double> d_cost_part, d_cand_part, d_norm_part, d_dbg, d_dbg_cost;
   DBuf<DevState> d_state;
-  DBuf<double> d_xbuf;
+  DBuf<double> d_xbuf, d_xpart;
+  int n_split = 1;
   int rank = 0, world = 1, min_bw = 0;
   DBuf<double> d_cp_snap, d_lm_snap;
   bool has_snapshot = false;
@@ -135,7 +137,7 @@ int prepare(hs_problem* p) {
   if (!build_visual_structure(in, &p->vs, &p->err)) return HS_ERR_INVALID;
   p->vs.bw = std::max(p->vs.bw, p->min_bw);
   const VisualStructure& vs = p->vs;
-  if (6 * vs.bw > kBlock || size_t(6 * vs.bw) * (6 * vs.bw + 2) * 8 + size_t(6) * p->n_cp * 8 > size_t(p->chol_lds_max))
+  if (6 * vs.bw > kBlock || vs.bw * vs.bw > 2 * kCholThreads || size_t(12) * (6 * vs.bw + 2) * 8 + size_t(12) * p->n_cp * 8 > size_t(p->chol_lds_max))
     HS_FAIL(HS_ERR_INVALID, "landmark tracks span too many control points for the LDS-resident banded factorisation");
   const int n_vis = n_px + n_br;
 
@@ -229,6 +231,7 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_scale_p.reserve(np));
   HIP_TRY(p->d_Sb.reserve(size_t(np) * ncb));
   HIP_TRY(p->d_Ub.reserve(size_t(np) * ncb));
+  HIP_TRY(p->d_Ubk.reserve(size_t(p->n_cp) * 24));
   HIP_TRY(p->d_g_s.reserve(np));
   HIP_TRY(p->d_g_full.reserve(np));
   HIP_TRY(p->d_D2p.reserve(np));
@@ -242,6 +245,9 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_norm_part.reserve(4 * size_t(nb_norm)));
   const int x_count1 = np * (ncb + 3) + 1 + p->world;
   HIP_TRY(p->d_xbuf.reserve(size_t(x_count1) + 8));
+  // split the accumulation over enough workgroups to fill the chip (256 CUs x a few workgroups)
+  p->n_split = std::max(1, std::min(16, 2048 / std::max(p->n_cp, 1)));
+  HIP_TRY(p->d_xpart.reserve(size_t(x_count1) * p->n_split));
   HIP_TRY(p->d_state.reserve(1));
 
   Tables& T = p->T;
@@ -259,14 +265,16 @@ int prepare(hs_problem* p) {
   T.n_pri = n_pri, T.p_stamp = p->d_p_stamp.p, T.p_meas = p->d_p_meas.p, T.p_sensor = p->d_p_sensor.p, T.p_first = p->d_p_first.p;
   T.p_rec = p->d_p_rec.p, T.p_seg_ptr = p->d_p_seg_ptr.p;
   T.n_seg = n_seg, T.bw = vs.bw, T.np = np;
-  T.scale_p = p->d_scale_p.p, T.Sb = p->d_Sb.p, T.Ub = p->d_Ub.p, T.g_s = p->d_g_s.p, T.g_full = p->d_g_full.p, T.D2p = p->d_D2p.p;
+  T.scale_p = p->d_scale_p.p, T.Sb = p->d_Sb.p, T.Ub = p->d_Ub.p, T.Ubk = p->d_Ubk.p, T.g_s = p->d_g_s.p, T.g_full = p->d_g_full.p, T.D2p = p->d_D2p.p;
   T.step_p = p->d_step_p.p, T.delta_p = p->d_delta_p.p;
   T.cost_part = p->d_cost_part.p, T.cand_part = p->d_cand_part.p, T.n_cost_part = p->nb_vis + p->nb_pri;
   T.norm_part = p->d_norm_part.p, T.n_norm_part = nb_norm;
   T.xbuf = p->d_xbuf.p;
+  T.xpart = p->d_xpart.p;
   T.xo_g = np * ncb, T.xo_gs = T.xo_g + np, T.xo_dj = T.xo_gs + np, T.xo_cost = T.xo_dj + np, T.xo_gmax = T.xo_cost + 1;
   T.x_count1 = x_count1, T.xo_dec = x_count1;
   T.rank = p->rank, T.world = p->world;
+  T.debug_flags = std::getenv("HS_DEBUG_FLAGS") ? std::atoi(std::getenv("HS_DEBUG_FLAGS")) : 0;
   T.st = p->d_state.p;
   HIP_TRY(hipStreamSynchronize(s));  // host staging vectors go out of scope
   p->dirty = false;
@@ -303,7 +311,8 @@ int launch_build(hs_problem* p) {
   hipStream_t s = p->stream;
   if (T.n_lm) k_landmark<K><<<(T.n_lm + kBlock / 64 - 1) / (kBlock / 64), kBlock, 0, s>>>(T);
   const size_t lds = (size_t(6) * 6 * T.bw + 16 + 6 * kBlock + 64) * sizeof(double);
-  k_build_raw<K><<<T.sp.n_cp, kBlock, lds, s>>>(T);
+  k_build_raw<K><<<dim3(T.sp.n_cp, p->n_split), kBlock, lds, s>>>(T);
+  k_reduce_partials<<<std::min(1024, (T.xo_cost + kBlock - 1) / kBlock), kBlock, 0, s>>>(T, p->n_split);
   k_pack_exchange<<<1, kBlock, 0, s>>>(T);
   HIP_TRY(hipGetLastError());
   const int rc = exchange(p, T.xbuf, T.x_count1);  // one RCCL all-reduce of [S | g | diag | cost] per linearisation
@@ -317,8 +326,11 @@ int launch_build(hs_problem* p) {
 int launch_factor(hs_problem* p) {
   const Tables& T = p->T;
   const int ncb = 6 * T.bw;
-  const size_t chol_lds = (size_t(ncb) * (ncb + 2) + T.np) * sizeof(double);
-  k_band_cholesky_solve<<<1, kCholThreads, chol_lds, p->stream>>>(T);
+  const size_t chol_lds = (size_t(12) * (ncb + 2) + 2 * size_t(T.np)) * sizeof(double);
+  if (T.bw * T.bw <= kCholThreads)
+    k_band_cholesky_solve<1><<<1, kCholThreads, chol_lds, p->stream>>>(T);
+  else
+    k_band_cholesky_solve<2><<<1, kCholThreads, chol_lds, p->stream>>>(T);
   HIP_TRY(hipGetLastError());
   return HS_OK;
 }
@@ -345,9 +357,10 @@ int launch_update(hs_problem* p) {
 int set_func_attributes(hs_problem* p) {
   // opt in to > 64 KiB dynamic LDS for the factorisation
   hipFuncAttributes fa;
-  HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_band_cholesky_solve)));
+  HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_band_cholesky_solve<2>)));
   p->chol_lds_max = 160 * 1024 - int(fa.sharedSizeBytes);
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_cholesky_solve), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_cholesky_solve<1>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_cholesky_solve<2>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
   return HS_OK;
 }
 
@@ -730,6 +743,13 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
     for (int i = 0; i <= n; ++i) iterations[i] = st.records[i];
   }
   if (st.chol_failed && st.termination == HS_FAILURE) p->err = "reduced system not positive definite";
+  return HS_OK;
+}
+
+int hs_debug_read(hs_problem* p, double* dst, int n) {
+  if (!p || !dst) return HS_ERR_INVALID;
+  HIP_TRY(hipMemcpyAsync(dst, p->d_xpart.p, size_t(n) * 8, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
   return HS_OK;
 }
 

@@ -24,6 +24,10 @@ HSD double wave_sum(double v) {
   return v;
 }
 
+/// Workgroup barrier that only drains LDS traffic: global loads / stores stay in flight across it (the factorisation
+/// prefetches the next band row while the current step runs; __syncthreads() would wait for vmcnt(0) every step).
+HSD void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 /// Deterministic block sum (fixed butterfly inside each wave, waves combined in index order). Result valid on thread 0.
 HSD double block_sum(double v, double* lds /* >= blockDim/64 */) {
   v = wave_sum(v);
@@ -138,16 +142,40 @@ __global__ void __launch_bounds__(kBlock) k_landmark(Tables T) {
   if (dl >= T.n_lm) return;
   const int q0 = T.lm_ptr[dl], q1 = T.lm_ptr[dl + 1];
   const int c_first = T.lm_cfirst[dl], rows = 6 * T.lm_ncp[dl];
-  // H_ll (upper 6) and b_l
+  // One pass over the landmark's residuals: lane q of a 64-chunk fetches (first control point, record slot) of residual q
+  // once; the chunk is then walked with register broadcasts, every lane accumulating its own W row(s) (rho = lane, lane + 64)
+  // and lane q the H_ll / b_l terms of residual q.
   double h[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-  for (int q = q0 + lane; q < q1; q += 64) {
-    const double* rec = T.v_rec + size_t(T.v_pos[q]) * REC;
+  double w[2][3] = {{0, 0, 0}, {0, 0, 0}};
+  for (int base = q0; base < q1; base += 64) {
+    const int myq = base + lane;
+    const int my_first = myq < q1 ? T.v_first[myq] : 0, my_pos = myq < q1 ? T.v_pos[myq] : 0;
+    if (myq < q1) {
+      const double* rec = T.v_rec + size_t(my_pos) * REC;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const double rr = rec[r], j0 = rec[2 + 3 * r], j1 = rec[3 + 3 * r], j2 = rec[4 + 3 * r];
-      h[0] = fma(j0, j0, h[0]), h[1] = fma(j0, j1, h[1]), h[2] = fma(j0, j2, h[2]);
-      h[3] = fma(j1, j1, h[3]), h[4] = fma(j1, j2, h[4]), h[5] = fma(j2, j2, h[5]);
-      b[0] = fma(j0, rr, b[0]), b[1] = fma(j1, rr, b[1]), b[2] = fma(j2, rr, b[2]);
+      for (int r = 0; r < 2; ++r) {
+        const double rr = rec[r], j0 = rec[2 + 3 * r], j1 = rec[3 + 3 * r], j2 = rec[4 + 3 * r];
+        h[0] = fma(j0, j0, h[0]), h[1] = fma(j0, j1, h[1]), h[2] = fma(j0, j2, h[2]);
+        h[3] = fma(j1, j1, h[3]), h[4] = fma(j1, j2, h[4]), h[5] = fma(j2, j2, h[5]);
+        b[0] = fma(j0, rr, b[0]), b[1] = fma(j1, rr, b[1]), b[2] = fma(j2, rr, b[2]);
+      }
+    }
+    const int cnt = min(64, q1 - base);
+#pragma unroll 4
+    for (int t = 0; t < cnt; ++t) {
+      const int ft = __builtin_amdgcn_readlane(my_first, t), pt = __builtin_amdgcn_readlane(my_pos, t);  // wave-uniform
+      const double* rec = T.v_rec + size_t(pt) * REC;
+      const int off = 6 * (ft - c_first);
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) {
+        const int c = lane + 64 * ps - off;
+        if (c >= 0 && c < 6 * K && lane + 64 * ps < rows) {
+          const double ja = rec[8 + c], jb = rec[8 + 6 * K + c];
+          w[ps][0] = fma(ja, rec[2], fma(jb, rec[5], w[ps][0]));
+          w[ps][1] = fma(ja, rec[3], fma(jb, rec[6], w[ps][1]));
+          w[ps][2] = fma(ja, rec[4], fma(jb, rec[7], w[ps][2]));
+        }
+      }
     }
   }
 #pragma unroll
@@ -188,22 +216,15 @@ __global__ void __launch_bounds__(kBlock) k_landmark(Tables T) {
   }
   // W rows -> Y-hat rows
   double* Y = T.Y + T.lm_yoff[dl];
-  for (int rho = lane; rho < rows; rho += 64) {
-    double w0 = 0, w1 = 0, w2 = 0;
-    for (int q = q0; q < q1; ++q) {
-      const int c = rho - 6 * (T.v_first[q] - c_first);
-      if (c >= 0 && c < 6 * K) {
-        const double* rec = T.v_rec + size_t(T.v_pos[q]) * REC;
-        const double ja = rec[8 + c], jb = rec[8 + 6 * K + c];
-        w0 = fma(ja, rec[2], fma(jb, rec[5], w0));
-        w1 = fma(ja, rec[3], fma(jb, rec[6], w1));
-        w2 = fma(ja, rec[4], fma(jb, rec[7], w2));
-      }
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int rho = lane + 64 * ps;
+    if (rho < rows) {
+      const double w0 = w[ps][0] * sl[0], w1 = w[ps][1] * sl[1], w2 = w[ps][2] * sl[2];
+      // y L' = w  (forward substitution on the columns of L')
+      const double a0 = w0 / l00, a1 = (w1 - a0 * l10) / l11, a2 = (w2 - a0 * l20 - a1 * l21) / l22;
+      Y[3 * rho] = active ? a0 : 0.0, Y[3 * rho + 1] = active ? a1 : 0.0, Y[3 * rho + 2] = active ? a2 : 0.0;
     }
-    w0 *= sl[0], w1 *= sl[1], w2 *= sl[2];
-    // y L' = w  (forward substitution on the columns of L')
-    const double a0 = w0 / l00, a1 = (w1 - a0 * l10) / l11, a2 = (w2 - a0 * l20 - a1 * l21) / l22;
-    Y[3 * rho] = active ? a0 : 0.0, Y[3 * rho + 1] = active ? a1 : 0.0, Y[3 * rho + 2] = active ? a2 : 0.0;
   }
 }
 
@@ -222,6 +243,7 @@ __global__ void __launch_bounds__(kBlock) k_build_raw(Tables T) {
   constexpr int NCA = 6 * K;        // columns of the J'J part
   constexpr int GA = kBlock / NCA;  // thread groups splitting the record loop
   const int i = blockIdx.x;
+  const int sp = blockIdx.y, nsp = gridDim.y;  // split of the accumulation (K) dimension over workgroups
   const int ncb = 6 * T.bw;  // columns of the band row
   const int tid = threadIdx.x;
   double* tile = smem;            // 6 x ncb accumulated block row (unscaled)
@@ -239,7 +261,8 @@ __global__ void __launch_bounds__(kBlock) k_build_raw(Tables T) {
         const int ao = 6 * (i - first);
         const int cidx = ao + col;
         const bool valid = cidx < NCA;
-        for (int pos = T.v_seg_ptr[first] + grp; pos < T.v_seg_ptr[first + 1]; pos += GA) {
+#pragma unroll 4
+        for (int pos = T.v_seg_ptr[first] + grp * nsp + sp; pos < T.v_seg_ptr[first + 1]; pos += GA * nsp) {
           const double* rec = T.v_rec + size_t(pos) * VREC;
 #pragma unroll
           for (int r = 0; r < 2; ++r) {
@@ -251,7 +274,7 @@ __global__ void __launch_bounds__(kBlock) k_build_raw(Tables T) {
           }
         }
         if (T.n_pri)
-          for (int pos = T.p_seg_ptr[first] + grp; pos < T.p_seg_ptr[first + 1]; pos += GA) {
+          for (int pos = T.p_seg_ptr[first] + grp * nsp + sp; pos < T.p_seg_ptr[first + 1]; pos += GA * nsp) {
             const double* rec = T.p_rec + size_t(pos) * PREC;
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
@@ -292,9 +315,9 @@ __global__ void __launch_bounds__(kBlock) k_build_raw(Tables T) {
     const int dl0 = T.cf_ptr[max(0, i - T.bw + 1)], dl1 = T.cf_ptr[i + 1];
     double acc[6] = {0, 0, 0, 0, 0, 0}, gsum = 0.0;
     if (grp < gb) {
-      for (int dl = dl0 + grp; dl < dl1; dl += gb) {
+#pragma unroll 4
+      for (int dl = dl0 + grp * nsp + sp; dl < dl1; dl += gb * nsp) {
         const int off = i - T.lm_cfirst[dl], rows = 6 * T.lm_ncp[dl];
-        if (6 * off >= rows) continue;
         const double* Y = T.Y + T.lm_yoff[dl] + 18 * off;
         if (6 * off + col < rows) {
           const double v0 = Y[3 * col], v1 = Y[3 * col + 1], v2 = Y[3 * col + 2];
@@ -322,8 +345,8 @@ __global__ void __launch_bounds__(kBlock) k_build_raw(Tables T) {
     __syncthreads();
   }
 
-  // ---- raw (unscaled, undamped) block row into the exchange buffer: additive across residual shards --------------
-  double* X = T.xbuf;
+  // ---- raw (unscaled, undamped) partial block row; k_reduce_partials sums the splits in a fixed order ---------------
+  double* X = T.xpart + size_t(sp) * T.x_count1;
   for (int e = tid; e < 6 * ncb; e += kBlock) {
     const int a = e / ncb, c = e % ncb;
     X[size_t(6 * i + a) * ncb + c] = tile[e];
@@ -333,6 +356,17 @@ __global__ void __launch_bounds__(kBlock) k_build_raw(Tables T) {
     X[T.xo_g + rho] = gacc[tid];
     X[T.xo_gs + rho] = gschur;
     X[T.xo_dj + rho] = dj[tid];
+  }
+}
+
+/// xbuf[e] = sum over the accumulation splits (fixed order => bit-reproducible). The result is additive across residual shards.
+__global__ void __launch_bounds__(kBlock) k_reduce_partials(Tables T, int nsp) {
+  if (T.st->done) return;
+  const int n = T.xo_cost;  // [Sraw | g_p | g_schur | diag]
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int k = 0; k < nsp; ++k) s += T.xpart[size_t(k) * T.x_count1 + e];
+    T.xbuf[e] = s;
   }
 }
 
@@ -394,151 +428,256 @@ __global__ void __launch_bounds__(kBlock) k_finalize_reduced(Tables T) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Block-banded Cholesky S = U'U with an LDS sliding window, fused forward solve, then backward solve.
-// Single workgroup (the factorisation is a dependency chain over n_cp block rows); the window holds 6*bw band rows of
-// 6*bw (+1 rhs, +1 pad) doubles. Row rho of the band stores S[rho][6*(rho/6) + c].
-//   step i:  U_ii = chol(S_ii);  X = U_ii^-T [S_i,i+1.. | g_i];  trailing rows j>i: S_j,* -= X_j' X_*;  g_j -= X_j' y_i.
+// Block-banded Cholesky S = U'U, fused forward solve, then backward solve.  Single workgroup: the factorisation is a
+// dependency chain over the n_cp block rows, so the design minimises the latency of one step instead of spreading
+// work over CUs.  Row rho of the band stores S[rho][6*(rho/6) + c].
+//   * the trailing window (bw block rows x bw band blocks of 6x6) lives in REGISTERS: thread t owns tile
+//     (slot = t / bw, band block = t % bw) for the whole lifetime of a block row (slot = row % bw), so the rank-6 updates
+//     never read-modify-write LDS; LDS only carries the current pivot row (rowbuf) and its solved form X (xbuf).
+//   * step i :  owners of row i publish their tiles -> rowbuf, then immediately start loading row i + bw into the freed
+//               registers (global latency hidden behind the rest of the step)          --- LDS barrier ---
+//               P1: every thread factors the 6x6 diagonal block redundantly in registers (no serial section) and
+//                   thread c solves column c of X = U_ii^-T [S_i,i+1.. | g_i] -> xbuf     --- LDS barrier ---
+//               P2: each live tile (j, kk):  S_(i+j),kk -= X_j' X_(j+kk);  rhs: g_(i+j) -= X_j' y_i;  U row i streamed to HBM
+//   * barriers drain LDS only (lds_barrier), so global prefetches stay in flight across them.
+//   * backward: column oriented, U entries and U_jj^-1 prefetched three steps ahead, one barrier per block row.
 // Outputs: Ub (factor), step_p = -S^-1 g (scaled step), delta_p = scale_p o step_p, and the two pose-side reductions
-// of the model cost change.
+// of the model cost change.  f64 MFMA is not used here: the update has K = 6 and is bound by the pivot-row latency, the
+// 16x16x4 f64 MFMA runs at the VALU FMA rate on gfx950 (78.6 TF both) and would only add operand shuffling.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kCholThreads = 512;
+constexpr int kCholThreads = 256;
 
+template <int TPT>  // tiles per thread: bw * bw <= TPT * kCholThreads
 __global__ void __launch_bounds__(kCholThreads) k_band_cholesky_solve(Tables T) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   DevState* st = T.st;
   if (st->done) return;
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const int ncb = 6 * T.bw, ld = ncb + 2;  // row: [band 0..ncb) | rhs | pad
-  const int nrows = ncb;                   // window rows (6*bw)
+  const int tid = threadIdx.x;
+  constexpr int nthr = kCholThreads;
+  const int bw = T.bw, ncb = 6 * bw, ld = ncb + 2;
   const int n_blk = T.np / 6;
-  double* win = smem;                      // nrows x ld, circular by block row
-  double* xs = smem + size_t(nrows) * ld;  // np solution / rhs vector
-  __shared__ double Uii[36];
+  double* rowbuf = smem;            // 6 x ld : pivot row as published by its owners [band | rhs | pad]
+  double* xbuf = smem + 6 * ld;     // 6 x ld : [U_ii | X | y_i]
+  double* xs = smem + 12 * ld;      // np : y (forward), pending rows (backward)
+  double* xout = xs + T.np;         // np : final x
   __shared__ int fail;
+  __shared__ double Wl[2][24];
   if (tid == 0) fail = 0;
 
-  auto load_block_row = [&](int blk) {
-    // all threads: copy band rows of block `blk` (or zeros past the end) into the window
-    const int slot = (blk % T.bw) * 6;
-    for (int e = tid; e < 6 * ld; e += nthr) {
-      const int a = e / ld, c = e % ld;
-      double v = 0.0;
-      if (blk < n_blk) {
-        const int rho = 6 * blk + a;
-        if (c < ncb)
-          v = T.Sb[size_t(rho) * ncb + c];
-        else if (c == ncb)
-          v = T.g_s[rho];
-      }
-      win[(slot + a) * ld + c] = v;
+  // ---- static tile ownership ------------------------------------------------------------------------------------
+  int t_slot[TPT], t_kk[TPT];
+  bool t_ok[TPT];
+  double acc[TPT][36], rhs[TPT][6];
+#pragma unroll
+  for (int m = 0; m < TPT; ++m) {
+    const int tl = tid + m * nthr;
+    t_ok[m] = tl < bw * bw;
+    t_slot[m] = t_ok[m] ? tl / bw : 0;
+    t_kk[m] = t_ok[m] ? tl % bw : 0;
+  }
+  auto load_tile = [&](int m, int r) {  // block row r into tile m's registers (zeros past the end)
+    const bool in = t_ok[m] && r < n_blk;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const double* src = T.Sb + size_t(6 * r + a) * ncb + 6 * t_kk[m];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc[m][6 * a + c] = in ? src[c] : 0.0;
+      rhs[m][a] = (in && t_kk[m] == 0) ? T.g_s[6 * r + a] : 0.0;
     }
   };
-  for (int b = 0; b < T.bw; ++b) load_block_row(b);
-  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < TPT; ++m) load_tile(m, t_slot[m]);
+  // streamed-out factor row: entries e = tid + m * nthr of the 6 x ncb row block
+  int o_a[3], o_c[3];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const int e = tid + m * nthr;
+    o_a[m] = e < 6 * ncb ? e / ncb : -1;
+    o_c[m] = e < 6 * ncb ? e % ncb : 0;
+  }
+  const bool prof = (T.debug_flags & 16) && tid == 0;
+  long long* tlog = reinterpret_cast<long long*>(T.xpart);
 
+#define UIDX(a, c) ((a) * 6 - (a) * ((a)-1) / 2 + ((c) - (a)))
   for (int i = 0; i < n_blk; ++i) {
-    const int s0 = (i % T.bw) * 6;  // slot of block row i
-    // 1. factor the 6x6 diagonal block (upper): thread 0 (36 entries, serial; tiny)
-    if (tid == 0) {
-      double A[36];
-      for (int a = 0; a < 6; ++a)
-        for (int c = 0; c < 6; ++c) A[6 * a + c] = win[(s0 + a) * ld + c];
-      for (int a = 0; a < 6; ++a) {
-        double d = A[7 * a];
-        for (int k = 0; k < a; ++k) d -= A[6 * k + a] * A[6 * k + a];
-        if (!(d > 0.0)) {
-          fail = 1;
-          d = 1.0;
+    const int si = i % bw;
+    if (prof) tlog[8 * i + 0] = wall_clock64();
+    // ---- publish the pivot row, then refill the freed registers with block row i + bw ----
+#pragma unroll
+    for (int m = 0; m < TPT; ++m)
+      if (t_ok[m] && t_slot[m] == si) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+          for (int c = 0; c < 6; c += 2)
+            *reinterpret_cast<double2*>(&rowbuf[a * ld + 6 * t_kk[m] + c]) = make_double2(acc[m][6 * a + c], acc[m][6 * a + c + 1]);
+          if (t_kk[m] == 0) rowbuf[a * ld + ncb] = rhs[m][a];
         }
-        d = sqrt(d);
-        A[7 * a] = d;
-        for (int c = a + 1; c < 6; ++c) {
-          double v = A[6 * a + c];
-          for (int k = 0; k < a; ++k) v -= A[6 * k + a] * A[6 * k + c];
-          A[6 * a + c] = v / d;
-        }
-        for (int c = 0; c < a; ++c) A[6 * a + c] = 0.0;
+        load_tile(m, i + bw);
       }
-      for (int e = 0; e < 36; ++e) Uii[e] = A[e];
-      for (int a = 0; a < 6; ++a)
-        for (int c = 0; c < 6; ++c) win[(s0 + a) * ld + c] = A[6 * a + c];
-    }
-    __syncthreads();
-    // 2. X = U_ii^-T [columns 6..ncb and the rhs]: one thread per column, forward substitution with U_ii'
-    for (int c = 6 + tid; c <= ncb; c += nthr) {
-      double x[6];
-#pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        double v = win[(s0 + a) * ld + c];
-#pragma unroll
-        for (int k = 0; k < a; ++k) v -= Uii[6 * k + a] * x[k];
-        x[a] = v / Uii[7 * a];
-      }
-#pragma unroll
-      for (int a = 0; a < 6; ++a) win[(s0 + a) * ld + c] = x[a];
-    }
-    __syncthreads();
-    // 3. trailing update of block rows i+1 .. i+bw-1 (entries whose column is still inside row i's band) and their rhs
-    //    entry (j, a', c): row 6(i+j)+a', band column c  <->  columns 6j+a' and 6j+c of block row i.
+    lds_barrier();
+    if (prof) tlog[8 * i + 1] = wall_clock64();
+    // ---- P1: redundant register factorisation of the diagonal block + one column of X per thread ----
+    double U[21], inv[6];
     {
-      const int per_j = 6 * (ncb + 1);  // upper bound of entries per block row j (a' x (c + rhs))
-      const int total = (T.bw - 1) * per_j;
-      for (int e = tid; e < total; e += nthr) {
-        const int j = 1 + e / per_j, rem = e % per_j;
-        const int ap = rem / (ncb + 1), c = rem % (ncb + 1);
-        const int ci = 6 * j + ap;        // column (in row i) matching the updated row
-        const int cj = (c == ncb) ? ncb : 6 * j + c;  // column (in row i) matching the updated column; rhs stays rhs
-        if (c < ncb && cj >= ncb) continue;           // outside row i's band
-        if (i + j >= n_blk) continue;
-        double s = 0.0;
+      int p = 0;
 #pragma unroll
-        for (int a = 0; a < 6; ++a) s = fma(win[(s0 + a) * ld + ci], win[(s0 + a) * ld + cj], s);
-        const int sj = ((i + j) % T.bw) * 6;
-        win[(sj + ap) * ld + c] -= s;
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c = a; c < 6; ++c) U[p++] = rowbuf[a * ld + c];
+    }
+    bool bad = false;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      double d = U[UIDX(a, a)];
+#pragma unroll
+      for (int k = 0; k < a; ++k) d = fma(-U[UIDX(k, a)], U[UIDX(k, a)], d);
+      if (!(d > 0.0)) bad = true, d = 1.0;
+      const double r = rsqrt(d);
+      inv[a] = r;
+      U[UIDX(a, a)] = d * r;
+#pragma unroll
+      for (int c = a + 1; c < 6; ++c) {
+        double v = U[UIDX(a, c)];
+#pragma unroll
+        for (int k = 0; k < a; ++k) v = fma(-U[UIDX(k, a)], U[UIDX(k, c)], v);
+        U[UIDX(a, c)] = v * r;
       }
     }
-    __syncthreads();
-    // 4. block row i is final: write U row and y_i, then reuse the slot for block row i + bw
-    for (int e = tid; e < 6 * ncb; e += nthr) {
-      const int a = e / ncb, c = e % ncb;
-      T.Ub[size_t(6 * i + a) * ncb + c] = win[(s0 + a) * ld + c];
-    }
-    if (tid < 6) xs[6 * i + tid] = win[(s0 + tid) * ld + ncb];
-    __syncthreads();
-    load_block_row(i + T.bw);
-    __syncthreads();
-  }
-
-  // ---- backward solve U x = y (column oriented: once x_j is final, every pending row above subtracts U[rho][x_j]) ----
-  for (int j = n_blk - 1; j >= 0; --j) {
-    if (tid == 0) {
+    if (bad && tid == 0) fail = 1;
+    if (tid + 6 <= ncb) {  // columns 6 .. ncb (ncb = rhs)
+      const int c = tid + 6;
       double x[6];
-      for (int a = 5; a >= 0; --a) {
-        double v = xs[6 * j + a];
-        for (int c = a + 1; c < 6; ++c) v -= T.Ub[size_t(6 * j + a) * ncb + c] * x[c];
-        x[a] = v / T.Ub[size_t(6 * j + a) * ncb + a];
-      }
-      for (int a = 0; a < 6; ++a) xs[6 * j + a] = x[a];
-    }
-    __syncthreads();
-    const int rows_above = min(6 * (T.bw - 1), 6 * j);
-    for (int t = tid; t < rows_above; t += nthr) {
-      const int rho = 6 * j - 1 - t;          // row above block j
-      const int cb = 6 * j - 6 * (rho / 6);   // band column of x_j[0] in row rho
-      const double* u = T.Ub + size_t(rho) * ncb + cb;
-      double s = 0.0;
 #pragma unroll
-      for (int a = 0; a < 6; ++a) s = fma(u[a], xs[6 * j + a], s);
-      xs[rho] -= s;
+      for (int a = 0; a < 6; ++a) {
+        double v = rowbuf[a * ld + c];
+#pragma unroll
+        for (int k = 0; k < a; ++k) v = fma(-U[UIDX(k, a)], x[k], v);
+        x[a] = v * inv[a];
+      }
+#pragma unroll
+      for (int a = 0; a < 6; ++a) xbuf[a * ld + c] = x[a];
+    } else if (tid >= nthr - 36) {  // the last 36 threads publish U_ii (upper, zeros below)
+      const int e = tid - (nthr - 36), a = e / 6, c = e % 6;
+      double v = 0.0;
+#pragma unroll
+      for (int aa = 0; aa < 6; ++aa)
+#pragma unroll
+        for (int cc = aa; cc < 6; ++cc)
+          if (aa == a && cc == c) v = U[UIDX(aa, cc)];
+      xbuf[a * ld + c] = v;
     }
-    __syncthreads();
+    if (tid == nthr - 37) {  // W = U_ii^-1 (upper triangular) for the backward sweep: x_i = W y_i, no divisions there
+      double W[21];
+#pragma unroll
+      for (int c = 5; c >= 0; --c) {
+        W[UIDX(c, c)] = inv[c];
+#pragma unroll
+        for (int a = c - 1; a >= 0; --a) {
+          double v = 0.0;
+#pragma unroll
+          for (int k = a + 1; k <= c; ++k) v = fma(U[UIDX(a, k)], W[UIDX(k, c)], v);
+          W[UIDX(a, c)] = -v * inv[a];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 21; ++e) T.Ubk[size_t(i) * 24 + e] = W[e];
+    }
+    lds_barrier();
+    if (prof) tlog[8 * i + 2] = wall_clock64();
+    // ---- P2: rank-6 update of the register tiles ----
+#pragma unroll
+    for (int m = 0; m < TPT; ++m) {
+      int j = t_slot[m] - si;
+      if (j < 0) j += bw;
+      if (!t_ok[m] || j == 0 || j + t_kk[m] > bw - 1 || (T.debug_flags & 2)) continue;
+      const int ca = 6 * j, cb = 6 * (j + t_kk[m]);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        double xa[6], xb[6];
+#pragma unroll
+        for (int c = 0; c < 6; c += 2) {
+          const double2 va = *reinterpret_cast<const double2*>(&xbuf[a * ld + ca + c]);
+          const double2 vb = *reinterpret_cast<const double2*>(&xbuf[a * ld + cb + c]);
+          xa[c] = va.x, xa[c + 1] = va.y, xb[c] = vb.x, xb[c + 1] = vb.y;
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int c = 0; c < 6; ++c) acc[m][6 * r + c] = fma(-xa[r], xb[c], acc[m][6 * r + c]);
+        if (t_kk[m] == 0) {
+          const double y = xbuf[a * ld + ncb];
+#pragma unroll
+          for (int r = 0; r < 6; ++r) rhs[m][r] = fma(-xa[r], y, rhs[m][r]);
+        }
+      }
+    }
+    if (prof) tlog[8 * i + 3] = wall_clock64();
+    // ---- stream the factor row out ----
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+      if (o_a[m] >= 0) T.Ub[size_t(6 * i + o_a[m]) * ncb + o_c[m]] = xbuf[o_a[m] * ld + o_c[m]];
+    if (tid < 6) xs[6 * i + tid] = xbuf[tid * ld + ncb];
+    if (prof) tlog[8 * i + 4] = wall_clock64();
   }
+#undef UIDX
+  lds_barrier();
+  if (T.debug_flags & 1) return;  // timing experiments only (HS_DEBUG_FLAGS)
+
+  // ---- backward solve U x = y, column oriented: once x_j is final every pending row above subtracts U[rho][x_j] ----
+  // thread t owns pending row rho = 6 j - 1 - t of step j; its six U entries (contiguous in the band row) and U_jj^-1
+  // are prefetched three steps ahead. One barrier per block row.
+  const int n_above = 6 * (bw - 1);
+  auto load_u = [&](int j, double* u) {
+    const int rho = 6 * j - 1 - tid;
+    const bool ok = j >= 0 && tid < n_above && rho >= 0;
+    const double* src = T.Ub + (ok ? size_t(rho) * ncb + (6 * j - 6 * (rho / 6)) : 0);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) u[a] = ok ? src[a] : 0.0;
+  };
+  auto load_w = [&](int j) -> double { return (j >= 0 && tid < 21) ? T.Ubk[size_t(j) * 24 + tid] : 0.0; };
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // Ub / Ubk written above by other waves of this workgroup
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  double u0[6], u1[6], u2[6], u3[6], w0, w1, w2, w3;
+  load_u(n_blk - 1, u0), load_u(n_blk - 2, u1), load_u(n_blk - 3, u2);
+  w0 = load_w(n_blk - 1), w1 = load_w(n_blk - 2), w2 = load_w(n_blk - 3);
+  for (int j = n_blk - 1; j >= 0; --j) {
+    if (tid < 21) Wl[j & 1][tid] = w0;
+    load_u(j - 3, u3), w3 = load_w(j - 3);
+    lds_barrier();  // publishes Wl and the pending-row updates of the previous step
+    const double* W = Wl[j & 1];
+    double y[6], x[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) y[a] = xs[6 * j + a];
+    {
+      int p = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        double v = 0.0;
+#pragma unroll
+        for (int c = a; c < 6; ++c) v = fma(W[p++], y[c], v);
+        x[a] = v;
+      }
+    }
+    if (tid < 6) xout[6 * j + tid] = x[tid];
+    if (tid < n_above && 6 * j - 1 - tid >= 0) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) sacc = fma(u0[a], x[a], sacc);
+      xs[6 * j - 1 - tid] -= sacc;
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) u0[a] = u1[a], u1[a] = u2[a], u2[a] = u3[a];
+    w0 = w1, w1 = w2, w2 = w3;
+  }
+  __syncthreads();
 
   // ---- outputs: step = -x, delta = scale o step, reductions for the model cost change ---------------------------------
   __shared__ double red[kCholThreads / 64];
   double gd = 0.0, dd = 0.0;
   for (int rho = tid; rho < T.np; rho += nthr) {
-    const double step = -xs[rho];
+    const double step = -xout[rho];
     T.step_p[rho] = step;
     T.delta_p[rho] = T.scale_p[rho] * step;
     gd = fma(T.g_full[rho], step, gd);

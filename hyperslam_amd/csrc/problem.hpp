@@ -109,6 +109,7 @@ struct Tables {
   double* scale_p;         // np
   double* Sb;              // np x (6 bw)   scaled + damped band (input of the factorisation)
   double* Ub;              // np x (6 bw)   Cholesky factor (upper, band rows)
+  double* Ubk;             // n_cp x 24  inverse of the factored diagonal blocks (packed upper) for the backward sweep
   double* g_s;             // np  reduced scaled gradient
   double* g_full;          // np  scaled full gradient s_p o g_p
   double* D2p;             // np  LM diagonal (pose side)
@@ -122,8 +123,10 @@ struct Tables {
   int n_norm_part;
   // exchange buffer (additive across residual shards): [Sraw np*6bw | g_p np | g_schur np | diag np | cost | gmax[world] | decision 5]
   double* xbuf;
+  double* xpart;  // per-split partial copies of [Sraw | g_p | g_schur | diag] (stride x_count1)
   int xo_g, xo_gs, xo_dj, xo_cost, xo_gmax, xo_dec, x_count1;
   int rank, world;
+  int debug_flags;  // HS_DEBUG_FLAGS env (timing experiments; 0 in production)
   DevState* st;
 };
 

@@ -819,7 +819,7 @@ inline void manifold_plus_jacobian(ManifoldKind m, int ambient, const double* x,
 /// Local Jacobian of one block: J_local (n_res x local) = J_block (n_res x ambient, row-major) * PlusJacobian.
 inline void to_local(ManifoldKind m, int ambient, int n_res, const double* x, const double* J_block, double* J_local) {
   const int local = manifold_local_size(m, ambient);
-  double P[8 * 6];
+  double P[9 * 9];  // largest block: 9-parameter Euclidean (S_g, X_a)
   manifold_plus_jacobian(m, ambient, x, P);
   for (int r = 0; r < n_res; ++r)
     for (int c = 0; c < local; ++c) {

@@ -90,3 +90,16 @@ def test_run_to_run_bit_reproducible(hip):
             outs.append((g.control_points().copy(), g.landmarks().copy()))
     for cp, lm in outs[1:]:
         assert np.array_equal(cp, outs[0][0]) and np.array_equal(lm, outs[0][1])
+
+
+from util import check_against_golden, golden_cases, golden_window  # noqa: E402
+
+
+@pytest.mark.parametrize("idx", range(len(golden_cases())))
+def test_hip_matches_golden(idx, hip):
+    """The HIP path against the independent 50-digit vectors (same bar as the oracle)."""
+    case = golden_cases()[idx]
+    if case["type"] == "inertial":
+        pytest.skip("inertial factor: see test_gpu_inertial.py")
+    with ha.Problem(golden_window(case), lib=hip) as p:
+        check_against_golden(p, case, 1e-9)

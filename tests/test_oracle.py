@@ -1,0 +1,114 @@
+"""CPU tests (no GPU): the oracle against the committed 50-digit golden vectors and its own reference-style gradient probe;
+host-side structure; synthetic generators; the C ABI library loads and exports every declared symbol."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import hyperslam_amd as ha
+from hyperslam_amd import _lib, synthetic
+from util import check_against_golden, golden_cases, golden_window, rel
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_golden_file_present_and_complete():
+    cases = golden_cases()
+    kinds = {(c["type"], c["inputs"]["k"]) for c in cases}
+    assert kinds == {(t, k) for t in ("pixel", "bearing", "prior", "inertial") for k in (4, 6)}
+
+
+@pytest.mark.parametrize("idx", range(len(golden_cases())))
+def test_oracle_matches_golden(idx, oracle):
+    case = golden_cases()[idx]
+    with ha.Problem(golden_window(case), lib=oracle) as p:
+        # pixel Jacobians reach 1e3 in magnitude: relative 1e-9 == the reference's own 1e-5 probe, four digits tighter
+        check_against_golden(p, case, 1e-9)
+
+
+def test_oracle_gradient_probe():
+    """Mirror of the reference's four `Gradients` tests (tests/internal/tests/optimizers/evaluators/*.cpp)."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "selftest"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(ROOT, "oracle", "selftest")], capture_output=True, text=True)
+    assert out.returncode == 0 and "SELFTEST OK" in out.stdout, out.stdout[-2000:]
+
+
+def test_layout_matches_exteroceptive_update(oracle):
+    """Block structure of ExteroceptiveCost::update (exteroceptive.cpp:25-99): sizes, offsets, indices, counts."""
+    w = synthetic.small_visual(order=4, n_cp=12, n_landmarks=5, obs_pairs=2, with_priors=3)
+    with ha.Problem(w, lib=oracle) as p:
+        L = p.residual_layout(ha.HS_PIXEL, 0)
+        assert L["sizes"].tolist() == [8, 8, 8, 8, 7, 4, 4, 3] and L["num_parameters"] == 8 * 4 + 18 and L["num_residuals"] == 2
+        assert L["offsets"].tolist() == [0, 8, 16, 24, 32, 39, 43, 47] and L["indices"].tolist() == [0, 4, 7, 7]
+        L = p.residual_layout(ha.HS_PRIOR, 1)
+        assert L["sizes"].tolist() == [8] * 4 + [7] and L["num_residuals"] == 6 and L["indices"].tolist() == [0, 4, 5, 5]
+        first = L["block_ids"][0]
+        assert L["block_ids"][:4].tolist() == list(range(first, first + 4))
+
+
+def test_oracle_lm_converges_and_is_deterministic(oracle):
+    w = synthetic.small_visual(order=4, n_cp=14, n_landmarks=30, obs_pairs=3, with_priors=10)
+    runs = []
+    for _ in range(2):
+        with ha.Problem(w, lib=oracle) as p:
+            s = p.solve(5)
+            runs.append((s["final_cost"], p.control_points().copy()))
+            assert s["final_cost"] < 0.2 * s["initial_cost"] and s["num_iterations"] == 5
+            costs = [it["cost"] for it in s["iterations"]]
+            assert all(b <= a * (1 + 1e-12) for a, b in zip(costs, costs[1:]))  # monotonic steps
+    assert runs[0][0] == runs[1][0] and np.array_equal(runs[0][1], runs[1][1])
+
+
+def test_frozen_control_points_do_not_move(oracle):
+    w = synthetic.small_visual(order=4, n_cp=14, n_landmarks=30, obs_pairs=3)
+    w.cp_constant = np.r_[np.ones(5, np.uint8), np.zeros(9, np.uint8)]
+    with ha.Problem(w, lib=oracle) as p:
+        p.solve(3)
+        cp = p.control_points()
+    assert np.array_equal(cp[:5], w.control_points[:5]) and not np.array_equal(cp[5:], w.control_points[5:])
+
+
+def test_synthetic_configs_are_deterministic_and_sized():
+    a, b = synthetic.config1(), synthetic.config1()
+    assert a.num_residual_blocks() == 50000 and len(a.landmarks) == 5000 and a.n_cp == 128
+    assert np.array_equal(a.pixels, b.pixels) and np.array_equal(a.control_points, b.control_points)
+    lo, hi = a.valid_range()
+    assert a.pixel_stamps.min() >= lo and a.pixel_stamps.max() < hi
+    c0 = synthetic.config0()
+    assert c0.n_cp == 32 and len(c0.prior_stamps) == 1000
+    # SplitMix64 known answer (first outputs for seed 0 of the published algorithm)
+    r = synthetic.SplitMix64(0)
+    assert [int(x) for x in r._raw(3)] == [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4, 0x06C45D188009454F]
+
+
+def test_shard_by_landmark_partitions_residuals():
+    w = synthetic.small_visual(order=4, n_cp=16, n_landmarks=37, obs_pairs=3, with_priors=9)
+    shards = [synthetic.shard_by_landmark(w, r, 3) for r in range(3)]
+    assert sum(len(s.pixel_stamps) for s in shards) == len(w.pixel_stamps)
+    assert sum(len(s.prior_stamps) for s in shards) == len(w.prior_stamps)
+    owners = [set(s.pixel_landmark.tolist()) for s in shards]
+    assert not (owners[0] & owners[1]) and not (owners[0] & owners[2]) and not (owners[1] & owners[2])
+
+
+def test_product_library_exports_every_declared_symbol():
+    """libhyperslam_hip.so loads on a machine without a GPU and exports each function include/hyperslam_hip.h declares."""
+    header = open(os.path.join(ROOT, "include", "hyperslam_hip.h")).read()
+    declared = set(re.findall(r"\b(hs_[a-z_]+)\s*\(", header)) - {"hs_allreduce_fn"}
+    assert declared == set(_lib.ABI_SYMBOLS), declared ^ set(_lib.ABI_SYMBOLS)
+    assert os.path.exists(_lib.PRODUCT_LIB), "run __graft_entry__.build() first"
+    lib = ctypes.CDLL(_lib.PRODUCT_LIB)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    lib.hs_arch.restype = ctypes.c_char_p
+    assert lib.hs_arch() == b"gfx950"
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(ha.HsError):
+        ha.Problem(synthetic.small_visual())

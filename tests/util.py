@@ -1,0 +1,63 @@
+"""Shared helpers of the test-suite."""
+import json
+import os
+
+import numpy as np
+
+from hyperslam_amd import HS_BEARING, HS_INERTIAL, HS_PIXEL, HS_PRIOR, Window
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TYPE_ID = {"pixel": HS_PIXEL, "bearing": HS_BEARING, "prior": HS_PRIOR, "inertial": HS_INERTIAL}
+
+
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.abs(a - b).max() / max(1e-300, np.abs(b).max()))
+
+
+def golden_cases():
+    with open(os.path.join(HERE, "golden", "factors.json")) as f:
+        return json.load(f)["cases"]
+
+
+def golden_window(case) -> Window:
+    """One-residual window reproducing a golden case (tests/golden/make_golden.py)."""
+    P = case["inputs"]
+    k = P["k"]
+    cps = np.array(P["cps"], float)
+    w = Window(order=k, t0=float(cps[0, 7]), dt=0.1, control_points=cps)
+    st = np.array([P["stamp"]])
+    t = case["type"]
+    if t in ("pixel", "bearing"):
+        w.cam_T_bs = np.array([P["T_bs"]])
+        w.cam_intrinsics = np.array([P["intrinsics"]])
+        w.cam_distortion = np.array([P["distortion"]])
+        w.landmarks = np.array([P["landmark"]])
+        z = np.zeros(1, np.int32)
+        if t == "pixel":
+            w.pixel_stamps, w.pixels, w.pixel_landmark, w.pixel_camera = st, np.array([P["meas"]]), z, z
+        else:
+            w.bearing_stamps, w.bearings, w.bearing_landmark, w.bearing_camera = st, np.array([P["meas"]]), z, z
+    elif t == "prior":
+        w.sensor_T_bs = np.array([P["T_bs"]])
+        w.prior_stamps, w.prior_poses, w.prior_sensor = st, np.array([P["meas"]]), np.zeros(1, np.int32)
+    else:
+        bg, ba = np.array(P["bias_g"], float), np.array(P["bias_a"], float)
+        w.imu = dict(T_bs=P["T_bs"], i_g=P["i_g"], i_a=P["i_a"], S_g=P["S_g"], X_a=P["X_a"], bias_order=P["kb"], bias_t0=float(bg[0, 3]), bias_dt=1.0,
+                     bias_g=bg, bias_a=ba, bias_constant=False)
+        w.gravity, w.gravity_constant = np.array(P["gravity"]), False
+        w.inertial_stamps, w.inertial_measurements = st, np.array([P["meas"]])
+    return w
+
+
+def check_against_golden(problem, case, tol):
+    """Compares an un-robustified linearisation (oracle or HIP) of a golden window with the 50-digit vectors."""
+    out = case["outputs"]
+    lin = problem.linearize(TYPE_ID[case["type"]], robustify=False)
+    errs = {"r": rel(lin["r"][0], out["r"]), "J_state": rel(lin["J_state"][0], out["J_state"])}
+    for key in ("J_landmark", "J_bias_g", "J_bias_a", "J_gravity"):
+        if key in out:
+            errs[key] = rel(lin[key][0], out[key])
+    bad = {k: v for k, v in errs.items() if not v < tol}
+    assert not bad, (case["type"], case["inputs"]["k"], bad)
+    return errs

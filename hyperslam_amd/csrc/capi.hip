@@ -87,6 +87,11 @@ struct hs_problem {
   DBuf<double> d_v_stamp, d_v_meas, d_v_rec;
   DBuf<int> d_v_lm, d_v_info, d_v_first, d_v_pos, d_v_seg_ptr, d_v_dbgpos;
   DBuf<double> d_p_stamp, d_p_meas, d_p_rec;
+  DBuf<double> d_i_stamp, d_i_meas, d_i_rec, d_bias_g, d_bias_a, d_bias_g_cand, d_bias_a_cand, d_gravity, d_gravity_cand;
+  DBuf<int> d_i_first, d_i_first_bias, d_i_seg_ptr;
+  DBuf<ImuParams> d_imu;
+  std::vector<int> in_order, in_first, in_first_bias, in_seg_ptr;
+  int nb_ine = 0;
   DBuf<int> d_p_sensor, d_p_first, d_p_seg_ptr;
   DBuf<double> d_scale_p, d_Sb, d_Ub, d_Ubk, d_g_s, d_g_full, d_D2p, d_step_p, d_delta_p;
   DBuf<double> d_cost_part, d_cand_part, d_norm_part, d_dbg, d_dbg_cost;
@@ -188,7 +193,32 @@ int prepare(hs_problem* p) {
     p->pr_seg_ptr[first_tab[t] + 1]++;
   }
   for (int sgm = 0; sgm < n_seg; ++sgm) p->pr_seg_ptr[sgm + 1] += p->pr_seg_ptr[sgm];
-  if (!p->in_stamp.empty()) HS_FAIL(HS_ERR_INVALID, "inertial residuals are not supported by this build yet");
+  // ---- inertial tables (segment-major) ----
+  const int n_ine = int(p->in_stamp.size());
+  if (n_ine && !p->has_imu) HS_FAIL(HS_ERR_STATE, "inertial residuals need hs_set_imu");
+  if (n_ine && p->kb != 4) HS_FAIL(HS_ERR_INVALID, "device kernels are instantiated for bias-spline order 4");
+  std::vector<double> i_stamp(n_ine), i_meas(size_t(6) * n_ine);
+  {
+    std::vector<int> ft(n_ine), fbt(n_ine);
+    p->in_order.resize(n_ine);
+    for (int i = 0; i < n_ine; ++i) {
+      ft[i] = h_segment_first(p->in_stamp[i], p->t0, p->dt, k);
+      fbt[i] = h_segment_first(p->in_stamp[i], p->bias_t0, p->bias_dt, p->kb);
+      if (ft[i] < 0 || ft[i] >= n_seg) HS_FAIL(HS_ERR_INVALID, "inertial residual stamp outside the valid range of the spline");
+      if (fbt[i] < 0 || fbt[i] + p->kb > p->n_bias) HS_FAIL(HS_ERR_INVALID, "inertial residual stamp outside the valid range of the bias splines");
+      p->in_order[i] = i;
+    }
+    std::stable_sort(p->in_order.begin(), p->in_order.end(), [&](int a, int b) { return ft[a] < ft[b]; });
+    p->in_first.resize(n_ine), p->in_first_bias.resize(n_ine);
+    p->in_seg_ptr.assign(n_seg + 1, 0);
+    for (int d = 0; d < n_ine; ++d) {
+      const int t = p->in_order[d];
+      i_stamp[d] = p->in_stamp[t], p->in_first[d] = ft[t], p->in_first_bias[d] = fbt[t];
+      for (int c = 0; c < 6; ++c) i_meas[6 * d + c] = p->in_meas[6 * t + c];
+      p->in_seg_ptr[ft[t] + 1]++;
+    }
+    for (int sgm = 0; sgm < n_seg; ++sgm) p->in_seg_ptr[sgm + 1] += p->in_seg_ptr[sgm];
+  }
 
   // ---- upload ----
   HIP_TRY(p->d_cp.upload(p->cp, s));
@@ -227,6 +257,28 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_p_first.upload(p->pr_first, s));
   HIP_TRY(p->d_p_seg_ptr.upload(p->pr_seg_ptr, s));
   HIP_TRY(p->d_p_rec.reserve(size_t(n_pri) * (6 + 36 * k) + 1));
+  HIP_TRY(p->d_i_stamp.upload(i_stamp, s));
+  HIP_TRY(p->d_i_meas.upload(i_meas, s));
+  HIP_TRY(p->d_i_first.upload(p->in_first, s));
+  HIP_TRY(p->d_i_first_bias.upload(p->in_first_bias, s));
+  HIP_TRY(p->d_i_seg_ptr.upload(p->in_seg_ptr, s));
+  HIP_TRY(p->d_i_rec.reserve(size_t(n_ine) * (18 + 36 * k + 2 * p->kb) + 1));
+  {
+    std::vector<ImuParams> ip(1);
+    std::memcpy(ip[0].T_bs, p->imu_T_bs, 56), std::memcpy(ip[0].i_g, p->imu_i_g, 48), std::memcpy(ip[0].i_a, p->imu_i_a, 48);
+    std::memcpy(ip[0].S_g, p->imu_S_g, 72), std::memcpy(ip[0].X_a, p->imu_X_a, 72);
+    HIP_TRY(p->d_imu.upload(ip, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<double> grav(p->gravity, p->gravity + 3);
+    HIP_TRY(p->d_gravity.upload(grav, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  HIP_TRY(p->d_gravity_cand.reserve(3));
+  HIP_TRY(p->d_bias_g.upload(p->bias_g, s));
+  HIP_TRY(p->d_bias_a.upload(p->bias_a, s));
+  HIP_TRY(p->d_bias_g_cand.reserve(p->bias_g.size() + 1));
+  HIP_TRY(p->d_bias_a_cand.reserve(p->bias_a.size() + 1));
+  p->nb_ine = (n_ine + kBlock - 1) / kBlock;
   const int np = 6 * p->n_cp, ncb = 6 * vs.bw;
   HIP_TRY(p->d_scale_p.reserve(np));
   HIP_TRY(p->d_Sb.reserve(size_t(np) * ncb));
@@ -239,8 +291,8 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_delta_p.reserve(np));
   p->nb_vis = (n_vis + kBlock - 1) / kBlock, p->nb_pri = (n_pri + kBlock - 1) / kBlock;
   p->nb_cp = std::max((p->n_cp + kBlock - 1) / kBlock, 1);
-  HIP_TRY(p->d_cost_part.reserve(p->nb_vis + p->nb_pri + 1));
-  HIP_TRY(p->d_cand_part.reserve(p->nb_vis + p->nb_pri + 1));
+  HIP_TRY(p->d_cost_part.reserve(p->nb_vis + p->nb_pri + (n_ine + kBlock - 1) / kBlock + 1));
+  HIP_TRY(p->d_cand_part.reserve(p->nb_vis + p->nb_pri + (n_ine + kBlock - 1) / kBlock + 1));
   const int nb_norm = std::max(p->nb_cp, std::min(64, (p->n_lm + kBlock - 1) / kBlock));
   HIP_TRY(p->d_norm_part.reserve(4 * size_t(nb_norm)));
   const int x_count1 = np * (ncb + 3) + 1 + p->world;
@@ -264,10 +316,16 @@ int prepare(hs_problem* p) {
   T.v_first = p->d_v_first.p, T.v_pos = p->d_v_pos.p, T.v_rec = p->d_v_rec.p, T.v_seg_ptr = p->d_v_seg_ptr.p;
   T.n_pri = n_pri, T.p_stamp = p->d_p_stamp.p, T.p_meas = p->d_p_meas.p, T.p_sensor = p->d_p_sensor.p, T.p_first = p->d_p_first.p;
   T.p_rec = p->d_p_rec.p, T.p_seg_ptr = p->d_p_seg_ptr.p;
+  T.n_ine = n_ine, T.i_stamp = p->d_i_stamp.p, T.i_meas = p->d_i_meas.p, T.i_first = p->d_i_first.p, T.i_first_bias = p->d_i_first_bias.p;
+  T.i_rec = p->d_i_rec.p, T.i_seg_ptr = p->d_i_seg_ptr.p, T.imu = p->d_imu.p;
+  T.bias_basis = make_basis_coef(p->kb), T.kb = p->kb, T.n_bias = p->has_imu ? p->n_bias : 0, T.bias_t0 = p->bias_t0, T.bias_dt = p->bias_dt;
+  T.bias_g = p->d_bias_g.p, T.bias_a = p->d_bias_a.p, T.bias_g_cand = p->d_bias_g_cand.p, T.bias_a_cand = p->d_bias_a_cand.p;
+  T.gravity = p->d_gravity.p, T.gravity_cand = p->d_gravity_cand.p, T.bias_const = p->bias_const, T.gravity_const = p->gravity_const;
+  T.nb = p->has_imu ? 6 * p->n_bias + 2 : 0;
   T.n_seg = n_seg, T.bw = vs.bw, T.np = np;
   T.scale_p = p->d_scale_p.p, T.Sb = p->d_Sb.p, T.Ub = p->d_Ub.p, T.Ubk = p->d_Ubk.p, T.g_s = p->d_g_s.p, T.g_full = p->d_g_full.p, T.D2p = p->d_D2p.p;
   T.step_p = p->d_step_p.p, T.delta_p = p->d_delta_p.p;
-  T.cost_part = p->d_cost_part.p, T.cand_part = p->d_cand_part.p, T.n_cost_part = p->nb_vis + p->nb_pri;
+  T.cost_part = p->d_cost_part.p, T.cand_part = p->d_cand_part.p, T.n_cost_part = p->nb_vis + p->nb_pri + p->nb_ine;
   T.norm_part = p->d_norm_part.p, T.n_norm_part = nb_norm;
   T.xbuf = p->d_xbuf.p;
   T.xpart = p->d_xpart.p;
@@ -295,6 +353,7 @@ int launch_linearize(hs_problem* p) {
   hipStream_t s = p->stream;
   if (T.n_vis) k_linearize_visual<K><<<p->nb_vis, kBlock, cp_lds_bytes(p), s>>>(T, T.v_rec, T.v_pos, 1, T.cost_part, nullptr);
   if (T.n_pri) k_linearize_prior<K><<<p->nb_pri, kBlock, cp_lds_bytes(p), s>>>(T, T.p_rec, T.cost_part + p->nb_vis, nullptr);
+  if (T.n_ine) k_linearize_inertial<K, 4><<<p->nb_ine, kBlock, cp_lds_bytes(p), s>>>(T, T.i_rec, 1, T.cost_part + p->nb_vis + p->nb_pri, nullptr);
   HIP_TRY(hipGetLastError());
   return HS_OK;
 }
@@ -627,7 +686,42 @@ int hs_linearize(hs_problem* p, int type, int robustify, const hs_linearization*
     }
     return HS_OK;
   }
-  HS_FAIL(HS_ERR_INVALID, "inertial residuals are not supported by this build yet");
+  {
+    const int n = T.n_ine, kb = p->kb, REC = 18 + 36 * k + 2 * kb;
+    if (n == 0) return HS_OK;
+    HIP_TRY(p->d_dbg.reserve(size_t(n) * REC));
+    HIP_TRY(p->d_dbg_cost.reserve(n));
+    if (k == 4)
+      k_linearize_inertial<4, 4><<<p->nb_ine, kBlock, cp_lds_bytes(p), s>>>(T, p->d_dbg.p, robustify, nullptr, p->d_dbg_cost.p);
+    else
+      k_linearize_inertial<6, 4><<<p->nb_ine, kBlock, cp_lds_bytes(p), s>>>(T, p->d_dbg.p, robustify, nullptr, p->d_dbg_cost.p);
+    HIP_TRY(hipGetLastError());
+    std::vector<double> rec(size_t(n) * REC), cost(n);
+    HIP_TRY(hipMemcpyAsync(rec.data(), p->d_dbg.p, rec.size() * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(cost.data(), p->d_dbg_cost.p, cost.size() * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int d = 0; d < n; ++d) {
+      const int i = p->in_order[d];
+      const double* r = &rec[size_t(d) * REC];
+      if (out->r) std::memcpy(out->r + size_t(i) * 6, r, 48);
+      if (out->J_state) std::memcpy(out->J_state + size_t(i) * 36 * k, r + 6, sizeof(double) * 36 * k);
+      const double* wg = r + 6 + 36 * k;
+      const double* wa = wg + kb;
+      const double* jg = wa + kb;
+      if (out->J_bias_g || out->J_bias_a)
+        for (int row = 0; row < 6; ++row)
+          for (int j = 0; j < kb; ++j)
+            for (int c = 0; c < 3; ++c) {
+              if (out->J_bias_g) out->J_bias_g[(size_t(i) * 6 + row) * 3 * kb + 3 * j + c] = (row == c) ? wg[j] : 0.0;
+              if (out->J_bias_a) out->J_bias_a[(size_t(i) * 6 + row) * 3 * kb + 3 * j + c] = (row == 3 + c) ? wa[j] : 0.0;
+            }
+      if (out->J_gravity) std::memcpy(out->J_gravity + size_t(i) * 12, jg, 96);
+      if (out->cost) out->cost[i] = cost[d];
+      if (out->first_cp) out->first_cp[i] = p->in_first[d];
+      if (out->first_bias) out->first_bias[i] = p->in_first_bias[d];
+    }
+    return HS_OK;
+  }
 }
 
 int hs_cost(hs_problem* p, double* cost) {
@@ -726,7 +820,7 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
   summary->num_iterations = st.num_iterations;
   summary->num_successful_steps = st.num_successful;
   summary->termination = st.termination;
-  summary->num_residual_blocks = p->T.n_vis + p->T.n_pri;
+  summary->num_residual_blocks = p->T.n_vis + p->T.n_pri + p->T.n_ine;
   for (int it = 0; it < max_iterations; ++it) {
     float t[4] = {0, 0, 0, 0};
     for (int k = 0; k < 4; ++k) (void)hipEventElapsedTime(&t[k], ev[4 * it + k], ev[4 * it + k + 1]);

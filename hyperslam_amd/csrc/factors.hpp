@@ -245,3 +245,140 @@ HSD void prior_linearize(const Tables& T, const double* cps, int i, PriorOut<K>*
 }
 
 }  // namespace hs
+
+namespace hs {
+
+// ---- inertial factor (inertial.cpp:13-205; CartesianMetric<6>; ScaledLoss(1.6e-5), optimizer.cpp:267-268) ---------------
+// prediction = [ I_g R_sb w_b + S_g a_m + b_g ;  I_a R_sb a_m + b_a ],   a_m[i] = a_i[i] + F_a.row(i) (X_a.col(i) + t_bs),
+// a_i = R_bw (p'' - g),  F_a = hat(w)^2 + hat(alpha).  Linear rows use I_a and the S_g / X_a terms are kept in every
+// Jacobian block (the in-tree text uses I_g and drops them; identical wherever the reference is exercised).
+struct ImuParams {
+  double T_bs[7], i_g[6], i_a[6], S_g[9], X_a[9];
+};
+
+template <int K, int KB>
+struct InertialOut {
+  double r[6];
+  double Jp[6 * 6 * K];  // 6 x 6K local state Jacobian
+  double wg[KB], wa[KB]; // bias-spline weights (d r_ang / d b_g,j = wg[j] I, d r_lin / d b_a,j = wa[j] I)
+  double Jg[12];         // 6 x 2 gravity (SphereManifold<3> tangent)
+  double cost;
+};
+
+HSD M3 lower_tri(const double* c) { return M3{{c[0], 0, 0, c[3], c[1], 0, c[4], c[5], c[2]}}; }
+HSD M3 colmajor3(const double* c) { return M3{{c[0], c[3], c[6], c[1], c[4], c[7], c[2], c[5], c[8]}}; }
+
+template <int KB>
+HSD V3 bias_value(const BasisCoef& bb, const double* cps, double u, double* wts) {
+  double lam[KB], dl[1], ddl[1];
+  basis_weights<KB>(bb, u, 1.0, lam, dl, ddl, 0);
+  V3 b = V3{0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < KB; ++j) {
+    const double Bj = lam[j] - (j + 1 < KB ? lam[j + 1] : 0.0);
+    wts[j] = Bj;
+    b = b + Bj * V3{cps[4 * j], cps[4 * j + 1], cps[4 * j + 2]};
+  }
+  return b;
+}
+
+/// Shared by value-only and full paths. JAC selects the Jacobian outputs.
+template <int K, int KB, bool JAC>
+HSD void inertial_evaluate(const Tables& T, const double* cps, const double* bias_g, const double* bias_a, const double* gravity, int i,
+                           bool robustify, InertialOut<K, KB>* o) {
+  const ImuParams& P = *T.imu;
+  const int first = T.i_first[i], fb = T.i_first_bias[i];
+  double u;
+  segment_of(T.i_stamp[i], T.sp.t0, T.sp.dt, K, &u);
+  double lam[K], dlam[K], ddlam[K];
+  basis_weights<K>(T.basis, u, T.sp.inv_dt, lam, dlam, ddlam, 2);
+  SplineFull<K> S;
+  spline_full<K, JAC>(cps + 8 * first, lam, dlam, ddlam, &S);
+  double ub;
+  segment_of(T.i_stamp[i], T.bias_t0, T.bias_dt, KB, &ub);
+  const V3 b_g = bias_value<KB>(T.bias_basis, bias_g + 4 * fb, ub, o->wg);
+  const V3 b_a = bias_value<KB>(T.bias_basis, bias_a + 4 * fb, ub, o->wa);
+
+  const M3 R = qmat(S.q);                       // R_wb
+  const M3 R_bs = qmat(Quat{P.T_bs[0], P.T_bs[1], P.T_bs[2], P.T_bs[3]});
+  const V3 t_bs = V3{P.T_bs[4], P.T_bs[5], P.T_bs[6]};
+  const M3 I_g = lower_tri(P.i_g), I_a = lower_tri(P.i_a), S_g = colmajor3(P.S_g), X_a = colmajor3(P.X_a);
+  const V3 g = V3{gravity[0], gravity[1], gravity[2]};
+  const V3 a_i = mul_t(R, S.a - g);             // R_bw (p'' - g)
+  const M3 wx = hat(S.w);
+  const M3 F_a = add(mul(wx, wx), hat(S.al));
+  V3 lever[3];
+  double am[3];
+  const double ai[3] = {a_i.x, a_i.y, a_i.z};
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    lever[r] = V3{X_a.m[r] + t_bs.x, X_a.m[3 + r] + t_bs.y, X_a.m[6 + r] + t_bs.z};  // X_a.col(r) + t_bs
+    am[r] = ai[r] + F_a.m[3 * r] * lever[r].x + F_a.m[3 * r + 1] * lever[r].y + F_a.m[3 * r + 2] * lever[r].z;
+  }
+  const V3 a_m = V3{am[0], am[1], am[2]};
+  const M3 IgRsb = mul_nt(I_g, R_bs), IaRsb = mul_nt(I_a, R_bs);  // I * R_sb = I * R_bs^T
+  const V3 ang = mul(IgRsb, S.w) + mul(S_g, a_m) + b_g;
+  const V3 lin = mul(IaRsb, a_m) + b_a;
+  const double* m = T.i_meas + 6 * i;
+  o->r[0] = ang.x - m[0], o->r[1] = ang.y - m[1], o->r[2] = ang.z - m[2];
+  o->r[3] = lin.x - m[3], o->r[4] = lin.y - m[4], o->r[5] = lin.z - m[5];
+  double s = 0;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) s += o->r[c] * o->r[c];
+  o->cost = 0.5 * kScaleInertial * s;
+  const double sr = robustify ? sqrt(kScaleInertial) : 1.0;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) o->r[c] *= sr;
+  if (!JAC) return;
+
+  // d a_m / d w (L_w) and d a_m / d alpha (L_al) with per-row lever arms
+  M3 L_w, L_al;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const M3 lx = hat(lever[r]);
+    const M3 mw = sub(mul(lx, wx), scale(2.0, mul(wx, lx)));  // -(2 wx lx - lx wx)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) L_w.m[3 * r + c] = mw.m[3 * r + c], L_al.m[3 * r + c] = -lx.m[3 * r + c];
+  }
+  const M3 Rt = transpose(R);
+  const M3 HaRt = mul(hat(a_i), Rt);  // hat(a_i) R_bw
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const bool frozen = T.cp_const[first + j] != 0;
+    const bool rot_free = !frozen && !T.sp.rot_const, tr_free = !frozen && !T.sp.trans_const;
+    // d a_m / d phi_j, d a_m / d dp_j
+    const M3 dam_rot = add(mul(HaRt, S.dth[j]), add(mul(L_w, S.dw[j]), mul(L_al, S.dal[j])));
+    const M3 dam_tr = scale(S.Bdd[j], Rt);
+    const M3 ang_rot = add(mul(IgRsb, S.dw[j]), mul(S_g, dam_rot));
+    const M3 ang_tr = mul(S_g, dam_tr);
+    const M3 lin_rot = mul(IaRsb, dam_rot);
+    const M3 lin_tr = mul(IaRsb, dam_tr);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        o->Jp[r * 6 * K + 6 * j + c] = rot_free ? 2.0 * sr * ang_rot.m[3 * r + c] : 0.0;
+        o->Jp[r * 6 * K + 6 * j + 3 + c] = tr_free ? sr * ang_tr.m[3 * r + c] : 0.0;
+        o->Jp[(3 + r) * 6 * K + 6 * j + c] = rot_free ? 2.0 * sr * lin_rot.m[3 * r + c] : 0.0;
+        o->Jp[(3 + r) * 6 * K + 6 * j + 3 + c] = tr_free ? sr * lin_tr.m[3 * r + c] : 0.0;
+      }
+  }
+  const double bscale = T.bias_const ? 0.0 : sr;
+#pragma unroll
+  for (int j = 0; j < KB; ++j) o->wg[j] *= bscale, o->wa[j] *= bscale;
+  // gravity: d a_m / d g = -R_bw, through the SphereManifold<3> tangent basis
+  double Pg[6];
+  sphere_plus_jacobian(gravity, Pg);
+  const M3 nRt = scale(-1.0, Rt);
+  const M3 ang_g = mul(S_g, nRt), lin_g = mul(IaRsb, nRt);
+  const double gs = T.gravity_const ? 0.0 : sr;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      o->Jg[2 * r + c] = gs * (ang_g.m[3 * r] * Pg[c] + ang_g.m[3 * r + 1] * Pg[2 + c] + ang_g.m[3 * r + 2] * Pg[4 + c]);
+      o->Jg[2 * (3 + r) + c] = gs * (lin_g.m[3 * r] * Pg[c] + lin_g.m[3 * r + 1] * Pg[2 + c] + lin_g.m[3 * r + 2] * Pg[4 + c]);
+    }
+}
+
+}  // namespace hs

@@ -102,6 +102,55 @@ __global__ void __launch_bounds__(kBlock) k_linearize_prior(Tables T, double* ou
   if (threadIdx.x == 0 && cost_part) cost_part[blockIdx.x] = s;
 }
 
+/// Inertial residual blocks (inertial.cpp:13-205): record = [r(6) | J_state(6 x 6K) | wg(KB) | wa(KB) | J_gravity(6 x 2)].
+template <int K, int KB>
+__global__ void __launch_bounds__(kBlock) k_linearize_inertial(Tables T, double* out_rec, int robustify, double* cost_part, double* cost_each) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (T.st->done) return;
+  double* cps = smem;
+  stage_cps(T.cp, cps, 8 * T.sp.n_cp);
+  __shared__ double red[kBlock / 64];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double cost = 0.0;
+  if (i < T.n_ine) {
+    InertialOut<K, KB> o;
+    inertial_evaluate<K, KB, true>(T, cps, T.bias_g, T.bias_a, T.gravity, i, robustify != 0, &o);
+    cost = o.cost;
+    constexpr int REC = 18 + 36 * K + 2 * KB;
+    double* rec = out_rec + size_t(i) * REC;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) rec[c] = o.r[c];
+#pragma unroll
+    for (int c = 0; c < 36 * K; ++c) rec[6 + c] = o.Jp[c];
+#pragma unroll
+    for (int c = 0; c < KB; ++c) rec[6 + 36 * K + c] = o.wg[c], rec[6 + 36 * K + KB + c] = o.wa[c];
+#pragma unroll
+    for (int c = 0; c < 12; ++c) rec[6 + 36 * K + 2 * KB + c] = o.Jg[c];
+    if (cost_each) cost_each[i] = cost;
+  }
+  const double s = block_sum(cost, red);
+  if (threadIdx.x == 0 && cost_part) cost_part[blockIdx.x] = s;
+}
+
+template <int K, int KB>
+__global__ void __launch_bounds__(kBlock) k_cost_inertial(Tables T, const double* cp_src, const double* bg, const double* ba, const double* grav,
+                                                         double* cost_part) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (T.st->done) return;
+  double* cps = smem;
+  stage_cps(cp_src, cps, 8 * T.sp.n_cp);
+  __shared__ double red[kBlock / 64];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double cost = 0.0;
+  if (i < T.n_ine) {
+    InertialOut<K, KB> o;
+    inertial_evaluate<K, KB, false>(T, cps, bg, ba, grav, i, false, &o);
+    cost = o.cost;
+  }
+  const double s = block_sum(cost, red);
+  if (threadIdx.x == 0) cost_part[blockIdx.x] = s;
+}
+
 /// Cost at the candidate point (residual-only branch).
 template <int K>
 __global__ void __launch_bounds__(kBlock) k_cost_visual(Tables T, const double* cp_src, const double* lm_src, double* cost_part) {

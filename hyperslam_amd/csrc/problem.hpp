@@ -103,6 +103,26 @@ struct Tables {
   double* p_rec;           // n x (6 + 36k)
   const int* p_seg_ptr;
   int n_seg;               // n_cp - k + 1
+  // inertial residuals (segment-major == record order) + IMU / bias splines / gravity (SURVEY a-4)
+  int n_ine;
+  const double* i_stamp;
+  const double* i_meas;    // n x 6
+  const int* i_first;      // first state control point
+  const int* i_first_bias; // first bias control point
+  double* i_rec;           // n x (18 + 36k + 2kb): [r(6) | J_state(6 x 6k) | wg(kb) | wa(kb) | J_gravity(6x2)]
+  const int* i_seg_ptr;
+  const struct ImuParams* imu;
+  hsd::BasisCoef bias_basis;
+  int kb, n_bias;
+  double bias_t0, bias_dt;
+  double* bias_g;          // n_bias x 4 [x y z t]
+  double* bias_a;
+  double* bias_g_cand;
+  double* bias_a_cand;
+  double* gravity;         // 3
+  double* gravity_cand;
+  int bias_const, gravity_const;
+  int nb;                  // border unknowns: 6 n_bias + 2 (0 without an IMU)
   // reduced system
   int bw;                  // band width in blocks
   int np;                  // 6 * n_cp

@@ -217,6 +217,62 @@ def small_visual(order=4, n_cp=16, n_landmarks=40, obs_pairs=3, bearing=False, s
     return w
 
 
+def add_imu(w: Window, rng: SplitMix64, n_inertial: int, bias_dt=1.0, bias_order=4, identity=True, gravity_constant=False):
+    """Adds an IMU (EuRoC parameters, settings.yaml:83-109), its R^3 bias splines (free, optimizer.cpp:62-63), gravity and
+    `n_inertial` direct inertial residuals (model of inertial.cpp:200-203 evaluated on the ground truth + noise)."""
+    lo, hi = w.valid_range()
+    kb = bias_order
+    n_bias = int(np.ceil((hi - lo) / bias_dt)) + kb
+    bias_t0 = lo - ((kb - 1) // 2) * bias_dt - 1e-3
+    stamps_b = bias_t0 + bias_dt * np.arange(n_bias)
+    bg = np.concatenate([rng.normal(n_bias, 3, sigma=1e-3), stamps_b[:, None]], -1)
+    ba = np.concatenate([rng.normal(n_bias, 3, sigma=1e-2), stamps_b[:, None]], -1)
+    if identity:
+        T_bs = np.array([0, 0, 0, 1, 0, 0, 0.0])
+        i_g = np.array([1, 1, 1, 0, 0, 0.0])
+        i_a = i_g.copy()
+        S_g, X_a = np.zeros(9), np.zeros(9)
+    else:
+        T_bs = np.concatenate([quat_exp(rng.uniform(3, lo=-0.3, hi=0.3)), rng.uniform(3, lo=-0.1, hi=0.1)])
+        i_g = np.array([1, 1, 1, 0, 0, 0.0]) + rng.uniform(6, lo=-0.05, hi=0.05)
+        i_a = np.array([1, 1, 1, 0, 0, 0.0]) + rng.uniform(6, lo=-0.05, hi=0.05)
+        S_g, X_a = rng.uniform(9, lo=-1e-3, hi=1e-3), rng.uniform(9, lo=-0.02, hi=0.02)
+    w.imu = dict(T_bs=T_bs, i_g=i_g, i_a=i_a, S_g=S_g, X_a=X_a, bias_order=kb, bias_t0=bias_t0, bias_dt=bias_dt, bias_g=bg, bias_a=ba,
+                 bias_constant=False)
+    g_true = np.array([0.0, 0.0, -GRAVITY_NORM])
+    # initial gravity slightly tilted (the reference initialises (-kNorm, 0, 0)-style and frees it while window == state range)
+    tilt = quat_to_matrix(quat_exp(rng.normal(3, sigma=0.02)))
+    w.gravity, w.gravity_constant = tilt @ g_true, gravity_constant
+    st = rng.uniform(n_inertial, lo=lo, hi=min(hi, stamps_b[-1] - (kb // 2) * bias_dt) - 1e-9)
+    # ground-truth body rates by differentiating the analytic trajectory numerically (central differences, h = 1e-4)
+    h = 1e-4
+    q0, _ = gt_pose(st)
+    qp, _ = gt_pose(st + h)
+    qm, _ = gt_pose(st - h)
+    R0 = quat_to_matrix(q0)
+    dR = (quat_to_matrix(qp) - quat_to_matrix(qm)) / (2 * h)
+    Om = np.einsum("nji,njk->nik", R0, dR)
+    w_b = np.stack([Om[:, 2, 1], Om[:, 0, 2], Om[:, 1, 0]], -1)
+    a_w = (gt_position(st + h) - 2 * gt_position(st) + gt_position(st - h)) / (h * h)
+    a_b = np.einsum("nji,nj->ni", R0, a_w - g_true)
+    meas = np.concatenate([w_b, a_b], -1)  # identity-IMU model at the ground truth (lever arm 0)
+    meas[:, :3] += rng.normal(n_inertial, 3, sigma=GYRO_NOISE_DENSITY * np.sqrt(IMU_RATE))
+    meas[:, 3:] += rng.normal(n_inertial, 3, sigma=ACCEL_NOISE_DENSITY * np.sqrt(IMU_RATE))
+    w.inertial_stamps, w.inertial_measurements = st, meas
+    return w
+
+
+def config2(n_cp=128, n_landmarks=5000, obs_pairs=5, n_inertial=10000):
+    """configs[2]: stereo-inertial, order-6 spline, 128 control points, 10k IMU + 50k stereo residuals, Schur on landmarks."""
+    w, rng = _visual_window(SEED ^ 2, 6, n_cp, n_landmarks, obs_pairs)
+    return add_imu(w, rng, n_inertial)
+
+
+def small_inertial(order=4, n_cp=16, n_landmarks=30, obs_pairs=3, n_inertial=80, seed=21, identity=False):
+    w, rng = _visual_window(SEED ^ (0x200 + seed), order, n_cp, n_landmarks, obs_pairs)
+    return add_imu(w, rng, n_inertial, identity=identity)
+
+
 def shard_by_landmark(w: Window, rank: int, world: int) -> Window:
     """Residual-block sharding of SURVEY.md §8(e): all observations of a landmark stay on one rank (landmark l -> rank
     l % world); pose-prior / inertial residuals are split by contiguous index ranges. Tables that are replicated

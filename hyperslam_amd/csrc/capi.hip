@@ -90,13 +90,15 @@ struct hs_problem {
   DBuf<double> d_i_stamp, d_i_meas, d_i_rec, d_bias_g, d_bias_a, d_bias_g_cand, d_bias_a_cand, d_gravity, d_gravity_cand;
   DBuf<int> d_i_first, d_i_first_bias, d_i_seg_ptr;
   DBuf<ImuParams> d_imu;
-  std::vector<int> in_order, in_first, in_first_bias, in_seg_ptr;
+  std::vector<int> in_order, in_first, in_first_bias, in_seg_ptr, in_bias_ptr;
   int nb_ine = 0;
   DBuf<int> d_p_sensor, d_p_first, d_p_seg_ptr;
   DBuf<double> d_scale_p, d_Sb, d_Ub, d_Ubk, d_g_s, d_g_full, d_D2p, d_step_p, d_delta_p;
   DBuf<double> d_cost_part, d_cand_part, d_norm_part, d_dbg, d_dbg_cost;
   DBuf<DevState> d_state;
   DBuf<double> d_xbuf, d_xpart;
+  DBuf<double> d_ybuf, d_scale_b, d_Spb, d_Sbb, d_gb_s, d_D2b, d_Zb, d_Cb, d_hb, d_xb, d_delta_b, d_bias_g_snap, d_bias_a_snap, d_gravity_snap;
+  DBuf<int> d_i_bias_ptr;
   int n_split = 1;
   int rank = 0, world = 1, min_bw = 0;
   DBuf<double> d_cp_snap, d_lm_snap;
@@ -142,7 +144,8 @@ int prepare(hs_problem* p) {
   if (!build_visual_structure(in, &p->vs, &p->err)) return HS_ERR_INVALID;
   p->vs.bw = std::max(p->vs.bw, p->min_bw);
   const VisualStructure& vs = p->vs;
-  if (6 * vs.bw > kBlock || vs.bw * vs.bw > 2 * kCholThreads || size_t(12) * (6 * vs.bw + 2) * 8 + size_t(12) * p->n_cp * 8 > size_t(p->chol_lds_max))
+  if (6 * vs.bw > kBlock || vs.bw * vs.bw > 2 * kCholThreads || size_t(12) * (6 * vs.bw + 2) * 8 + size_t(12) * p->n_cp * 8 > size_t(p->chol_lds_max) ||
+      size_t(12) * p->n_cp * 8 > 60 * 1024)
     HS_FAIL(HS_ERR_INVALID, "landmark tracks span too many control points for the LDS-resident banded factorisation");
   const int n_vis = n_px + n_br;
 
@@ -218,6 +221,13 @@ int prepare(hs_problem* p) {
       p->in_seg_ptr[ft[t] + 1]++;
     }
     for (int sgm = 0; sgm < n_seg; ++sgm) p->in_seg_ptr[sgm + 1] += p->in_seg_ptr[sgm];
+    // records are time-sorted, so first_bias is non-decreasing: i_bias_ptr[f] = first record with first_bias >= f
+    const int nbias = p->has_imu ? p->n_bias : 0;
+    p->in_bias_ptr.assign(nbias + 2, n_ine);
+    for (int f = 0, d = 0; f <= nbias + 1; ++f) {
+      while (d < n_ine && p->in_first_bias[d] < f) ++d;
+      p->in_bias_ptr[f] = d;
+    }
   }
 
   // ---- upload ----
@@ -262,6 +272,7 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_i_first.upload(p->in_first, s));
   HIP_TRY(p->d_i_first_bias.upload(p->in_first_bias, s));
   HIP_TRY(p->d_i_seg_ptr.upload(p->in_seg_ptr, s));
+  HIP_TRY(p->d_i_bias_ptr.upload(p->in_bias_ptr, s));
   HIP_TRY(p->d_i_rec.reserve(size_t(n_ine) * (18 + 36 * k + 2 * p->kb) + 1));
   {
     std::vector<ImuParams> ip(1);
@@ -295,7 +306,20 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_cand_part.reserve(p->nb_vis + p->nb_pri + (n_ine + kBlock - 1) / kBlock + 1));
   const int nb_norm = std::max(p->nb_cp, std::min(64, (p->n_lm + kBlock - 1) / kBlock));
   HIP_TRY(p->d_norm_part.reserve(4 * size_t(nb_norm)));
-  const int x_count1 = np * (ncb + 3) + 1 + p->world;
+  const int nbd = p->has_imu ? 6 * p->n_bias + 2 : 0;
+  if (nbd && size_t(np) * 8 * 8 > 150 * 1024) HS_FAIL(HS_ERR_INVALID, "window too long for the LDS-resident border forward sweep");
+  const int x_count1 = np * (ncb + 3) + np * nbd + nbd * nbd + nbd + 1 + p->world;
+  HIP_TRY(p->d_ybuf.reserve(np));
+  HIP_TRY(p->d_scale_b.reserve(nbd + 1));
+  HIP_TRY(p->d_Spb.reserve(size_t(np) * nbd + 1));
+  HIP_TRY(p->d_Sbb.reserve(size_t(nbd) * nbd + 1));
+  HIP_TRY(p->d_gb_s.reserve(nbd + 1));
+  HIP_TRY(p->d_D2b.reserve(nbd + 1));
+  HIP_TRY(p->d_Zb.reserve(size_t(np) * nbd + 1));
+  HIP_TRY(p->d_Cb.reserve(size_t(nbd) * nbd + 1));
+  HIP_TRY(p->d_hb.reserve(nbd + 1));
+  HIP_TRY(p->d_xb.reserve(nbd + 1));
+  HIP_TRY(p->d_delta_b.reserve(nbd + 1));
   HIP_TRY(p->d_xbuf.reserve(size_t(x_count1) + 8));
   // split the accumulation over enough workgroups to fill the chip (256 CUs x a few workgroups)
   p->n_split = std::max(1, std::min(16, 2048 / std::max(p->n_cp, 1)));
@@ -329,7 +353,10 @@ int prepare(hs_problem* p) {
   T.norm_part = p->d_norm_part.p, T.n_norm_part = nb_norm;
   T.xbuf = p->d_xbuf.p;
   T.xpart = p->d_xpart.p;
-  T.xo_g = np * ncb, T.xo_gs = T.xo_g + np, T.xo_dj = T.xo_gs + np, T.xo_cost = T.xo_dj + np, T.xo_gmax = T.xo_cost + 1;
+  T.xo_g = np * ncb, T.xo_gs = T.xo_g + np, T.xo_dj = T.xo_gs + np, T.xo_pb = T.xo_dj + np, T.xo_bb = T.xo_pb + np * nbd;
+  T.xo_gb = T.xo_bb + nbd * nbd, T.xo_cost = T.xo_gb + nbd, T.xo_gmax = T.xo_cost + 1;
+  T.ybuf = p->d_ybuf.p, T.scale_b = p->d_scale_b.p, T.Spb = p->d_Spb.p, T.Sbb = p->d_Sbb.p, T.gb_s = p->d_gb_s.p, T.D2b = p->d_D2b.p;
+  T.Zb = p->d_Zb.p, T.Cb = p->d_Cb.p, T.hb = p->d_hb.p, T.xb = p->d_xb.p, T.delta_b = p->d_delta_b.p, T.i_bias_ptr = p->d_i_bias_ptr.p;
   T.x_count1 = x_count1, T.xo_dec = x_count1;
   T.rank = p->rank, T.world = p->world;
   T.debug_flags = std::getenv("HS_DEBUG_FLAGS") ? std::atoi(std::getenv("HS_DEBUG_FLAGS")) : 0;
@@ -371,12 +398,18 @@ int launch_build(hs_problem* p) {
   if (T.n_lm) k_landmark<K><<<(T.n_lm + kBlock / 64 - 1) / (kBlock / 64), kBlock, 0, s>>>(T);
   const size_t lds = (size_t(6) * 6 * T.bw + 16 + 6 * kBlock + 64) * sizeof(double);
   k_build_raw<K><<<dim3(T.sp.n_cp, p->n_split), kBlock, lds, s>>>(T);
-  k_reduce_partials<<<std::min(1024, (T.xo_cost + kBlock - 1) / kBlock), kBlock, 0, s>>>(T, p->n_split);
+  if (T.nb) {
+    k_border_pb<K><<<dim3(T.sp.n_cp, p->n_split), 128, 0, s>>>(T);
+    k_border_zero<<<std::min(64, (T.nb * T.nb + T.nb + kBlock - 1) / kBlock), kBlock, 0, s>>>(T);
+    k_border_bb<K><<<(T.n_bias + 1 + kBlock / 64 - 1) / (kBlock / 64), kBlock, 0, s>>>(T);
+  }
+  k_reduce_partials<<<std::min(1024, (T.xo_bb + kBlock - 1) / kBlock), kBlock, 0, s>>>(T, p->n_split);
   k_pack_exchange<<<1, kBlock, 0, s>>>(T);
   HIP_TRY(hipGetLastError());
   const int rc = exchange(p, T.xbuf, T.x_count1);  // one RCCL all-reduce of [S | g | diag | cost] per linearisation
   if (rc) return rc;
   k_finalize_reduced<<<T.sp.n_cp, kBlock, 0, s>>>(T);
+  if (T.nb) k_finalize_border<<<std::min(256, ((T.np + T.nb) * T.nb + kBlock - 1) / kBlock), kBlock, 0, s>>>(T);
   k_cost_reduce<<<1, 64, 0, s>>>(T);
   HIP_TRY(hipGetLastError());
   return HS_OK;
@@ -384,12 +417,19 @@ int launch_build(hs_problem* p) {
 
 int launch_factor(hs_problem* p) {
   const Tables& T = p->T;
+  hipStream_t s = p->stream;
   const int ncb = 6 * T.bw;
-  const size_t chol_lds = (size_t(12) * (ncb + 2) + 2 * size_t(T.np)) * sizeof(double);
+  const size_t chol_lds = (size_t(12) * (ncb + 2) + size_t(T.np)) * sizeof(double);
   if (T.bw * T.bw <= kCholThreads)
-    k_band_cholesky_solve<1><<<1, kCholThreads, chol_lds, p->stream>>>(T);
+    k_band_factor<1><<<1, kCholThreads, chol_lds, s>>>(T);
   else
-    k_band_cholesky_solve<2><<<1, kCholThreads, chol_lds, p->stream>>>(T);
+    k_band_factor<2><<<1, kCholThreads, chol_lds, s>>>(T);
+  if (T.nb) {  // bordered system (bias splines + gravity)
+    k_border_forward<<<(T.nb + kBorderCols - 1) / kBorderCols, 128, size_t(T.np) * kBorderCols * sizeof(double), s>>>(T);
+    k_border_schur<<<T.nb, kBlock, 0, s>>>(T);
+    k_border_solve<<<1, kBlock, (size_t(T.nb) * (T.nb + 1) + T.nb) * sizeof(double), s>>>(T);
+  }
+  k_band_backward<<<1, kCholThreads, 2 * size_t(T.np) * sizeof(double), s>>>(T);
   HIP_TRY(hipGetLastError());
   return HS_OK;
 }
@@ -402,6 +442,9 @@ int launch_update(hs_problem* p) {
   k_retract<<<T.n_norm_part, kBlock, 0, s>>>(T);
   if (T.n_vis) k_cost_visual<K><<<p->nb_vis, kBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.lm_cand, T.cand_part);
   if (T.n_pri) k_cost_prior<K><<<p->nb_pri, kBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.cand_part + p->nb_vis);
+  if (T.n_ine)
+    k_cost_inertial<K, 4><<<p->nb_ine, kBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.bias_g_cand, T.bias_a_cand, T.gravity_cand,
+                                                                        T.cand_part + p->nb_vis + p->nb_pri);
   k_pack_decision<<<1, kBlock, 0, s>>>(T);
   HIP_TRY(hipGetLastError());
   const int rc = exchange(p, T.xbuf + T.xo_dec, 5);  // candidate cost + norms + landmark-side model-cost terms
@@ -416,10 +459,12 @@ int launch_update(hs_problem* p) {
 int set_func_attributes(hs_problem* p) {
   // opt in to > 64 KiB dynamic LDS for the factorisation
   hipFuncAttributes fa;
-  HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_band_cholesky_solve<2>)));
+  HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_band_factor<2>)));
   p->chol_lds_max = 160 * 1024 - int(fa.sharedSizeBytes);
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_cholesky_solve<1>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_cholesky_solve<2>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor<1>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor<2>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_forward), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   return HS_OK;
 }
 
@@ -769,6 +814,20 @@ int hs_reduced_system(hs_problem* p, double radius, double* S, double* g) {
     }
     g[rho] = gs[rho];
   }
+  if (p->T.nb) {
+    const int nb = p->T.nb;
+    std::vector<double> Spb(size_t(np) * nb), Sbb(size_t(nb) * nb), gb(nb);
+    HIP_TRY(hipMemcpyAsync(Spb.data(), p->d_Spb.p, Spb.size() * 8, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(Sbb.data(), p->d_Sbb.p, Sbb.size() * 8, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(gb.data(), p->d_gb_s.p, gb.size() * 8, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    for (int rho = 0; rho < np; ++rho)
+      for (int b = 0; b < nb; ++b) S[size_t(rho) * dim + np + b] = S[size_t(np + b) * dim + rho] = Spb[size_t(rho) * nb + b];
+    for (int a = 0; a < nb; ++a) {
+      for (int b = 0; b < nb; ++b) S[size_t(np + a) * dim + np + b] = Sbb[size_t(a) * nb + b];
+      g[np + a] = gb[a];
+    }
+  }
   return HS_OK;
 }
 
@@ -855,6 +914,14 @@ int hs_snapshot(hs_problem* p) {
   HIP_TRY(p->d_lm_snap.reserve(p->lm.size() + 1));
   HIP_TRY(hipMemcpyAsync(p->d_cp_snap.p, p->d_cp.p, p->cp.size() * 8, hipMemcpyDeviceToDevice, p->stream));
   if (p->n_lm) HIP_TRY(hipMemcpyAsync(p->d_lm_snap.p, p->d_lm.p, p->lm.size() * 8, hipMemcpyDeviceToDevice, p->stream));
+  if (p->has_imu) {
+    HIP_TRY(p->d_bias_g_snap.reserve(p->bias_g.size() + 1));
+    HIP_TRY(p->d_bias_a_snap.reserve(p->bias_a.size() + 1));
+    HIP_TRY(p->d_gravity_snap.reserve(3));
+    HIP_TRY(hipMemcpyAsync(p->d_bias_g_snap.p, p->d_bias_g.p, p->bias_g.size() * 8, hipMemcpyDeviceToDevice, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->d_bias_a_snap.p, p->d_bias_a.p, p->bias_a.size() * 8, hipMemcpyDeviceToDevice, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->d_gravity_snap.p, p->d_gravity.p, 24, hipMemcpyDeviceToDevice, p->stream));
+  }
   p->has_snapshot = true;
   return HS_OK;
 }
@@ -864,6 +931,11 @@ int hs_restore(hs_problem* p) {
   if (!p->has_snapshot || p->dirty) HS_FAIL(HS_ERR_STATE, "hs_restore without a valid hs_snapshot");
   HIP_TRY(hipMemcpyAsync(p->d_cp.p, p->d_cp_snap.p, p->cp.size() * 8, hipMemcpyDeviceToDevice, p->stream));
   if (p->n_lm) HIP_TRY(hipMemcpyAsync(p->d_lm.p, p->d_lm_snap.p, p->lm.size() * 8, hipMemcpyDeviceToDevice, p->stream));
+  if (p->has_imu) {
+    HIP_TRY(hipMemcpyAsync(p->d_bias_g.p, p->d_bias_g_snap.p, p->bias_g.size() * 8, hipMemcpyDeviceToDevice, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->d_bias_a.p, p->d_bias_a_snap.p, p->bias_a.size() * 8, hipMemcpyDeviceToDevice, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->d_gravity.p, p->d_gravity_snap.p, 24, hipMemcpyDeviceToDevice, p->stream));
+  }
   return HS_OK;
 }
 
@@ -915,11 +987,20 @@ int hs_get_landmarks(hs_problem* p, double* xyz) {
 }
 int hs_get_bias(hs_problem* p, double* bg, double* ba) {
   if (!p || !bg || !ba) return HS_ERR_INVALID;
+  if (!p->dirty && p->has_imu && !p->bias_g.empty()) {
+    HIP_TRY(hipMemcpyAsync(p->bias_g.data(), p->d_bias_g.p, p->bias_g.size() * 8, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->bias_a.data(), p->d_bias_a.p, p->bias_a.size() * 8, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+  }
   std::memcpy(bg, p->bias_g.data(), p->bias_g.size() * 8), std::memcpy(ba, p->bias_a.data(), p->bias_a.size() * 8);
   return HS_OK;
 }
 int hs_get_gravity(hs_problem* p, double* g) {
   if (!p || !g) return HS_ERR_INVALID;
+  if (!p->dirty && p->has_imu) {
+    HIP_TRY(hipMemcpyAsync(p->gravity, p->d_gravity.p, 24, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+  }
   std::memcpy(g, p->gravity, 24);
   return HS_OK;
 }

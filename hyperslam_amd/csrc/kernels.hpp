@@ -7,7 +7,7 @@
 //   k_hpp_diag            (iteration 0)      Jacobi column scaling of the pose-side unknowns
 //   k_build_reduced                          one workgroup per control-point block row: gather J'J and the Schur terms
 //                                            into the block-banded reduced system (deterministic, no atomics on doubles)
-//   k_band_cholesky_solve                    single-workgroup block-banded Cholesky with an LDS sliding window + solves
+//   k_band_factor                    single-workgroup block-banded Cholesky with an LDS sliding window + solves
 //   k_backsub_landmarks / k_retract          step for landmarks, candidate point = Plus(x, delta)
 //   k_cost_visual / k_cost_prior             cost at the candidate point
 //   k_decide / k_commit                      trust-region logic and acceptance
@@ -334,6 +334,20 @@ __global__ void __launch_bounds__(kBlock) k_build_raw(Tables T) {
               if (col < 6) gsum = fma(jp[ao + col], rec[r], gsum);
             }
           }
+        if (T.n_ine) {
+          const int IREC = 18 + 36 * K + 2 * T.kb;
+          for (int pos = T.i_seg_ptr[first] + grp * nsp + sp; pos < T.i_seg_ptr[first + 1]; pos += GA * nsp) {
+            const double* rec = T.i_rec + size_t(pos) * IREC;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+              const double* jp = rec + 6 + r * NCA;
+              const double v = valid ? jp[cidx] : 0.0;
+#pragma unroll
+              for (int a = 0; a < 6; ++a) acc[a] = fma(jp[ao + a], v, acc[a]);
+              if (col < 6) gsum = fma(jp[ao + col], rec[r], gsum);
+            }
+          }
+        }
       }
 #pragma unroll
       for (int a = 0; a < 6; ++a) red[(grp * 6 + a) * NCA + col] = acc[a];
@@ -411,7 +425,7 @@ __global__ void __launch_bounds__(kBlock) k_build_raw(Tables T) {
 /// xbuf[e] = sum over the accumulation splits (fixed order => bit-reproducible). The result is additive across residual shards.
 __global__ void __launch_bounds__(kBlock) k_reduce_partials(Tables T, int nsp) {
   if (T.st->done) return;
-  const int n = T.xo_cost;  // [Sraw | g_p | g_schur | diag]
+  const int n = T.xo_bb;  // [Sraw | g_p | g_schur | diag | Hpb]
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
     double s = 0.0;
     for (int k = 0; k < nsp; ++k) s += T.xpart[size_t(k) * T.x_count1 + e];
@@ -431,6 +445,305 @@ __global__ void __launch_bounds__(kBlock) k_pack_exchange(Tables T) {
   if (threadIdx.x == 0) T.xbuf[T.xo_cost] = s;
   for (int r = threadIdx.x; r < T.world; r += blockDim.x)
     T.xbuf[T.xo_gmax + r] = (r == T.rank) ? __longlong_as_double((long long)st->gmax_bits) : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Border unknowns (IMU bias-spline control points + gravity; SURVEY a-4): the inertial factor couples every control point of
+// the window with a few *dense* unknowns, ordered last:  [gyro bias 3 n_bias | accel bias 3 n_bias | gravity 2] = nb.
+//   H_pb (np x nb), H_bb (nb x nb), g_b (nb) are gathered deterministically from the inertial records.
+// Record structure exploited: d r_ang / d b_g,j = wg[j] I_3, d r_lin / d b_a,j = wa[j] I_3 (only the weights are stored).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int K>
+__global__ void __launch_bounds__(128) k_border_pb(Tables T) {
+  // block (i, split): rows 6 i .. 6 i + 5 of H_pb, thread <-> border column
+  if (T.st->done) return;
+  const int i = blockIdx.x, sp = blockIdx.y, nsp = gridDim.y;
+  const int kb = T.kb, nbias = T.n_bias, nb = T.nb;
+  const int IREC = 18 + 36 * K + 2 * kb;
+  double* out = T.xpart + size_t(sp) * T.x_count1 + T.xo_pb;
+  for (int beta = threadIdx.x; beta < nb; beta += blockDim.x) {
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    // classify the column once
+    const int kind = beta < 3 * nbias ? 0 : (beta < 6 * nbias ? 1 : 2);
+    const int bb = kind == 2 ? 0 : (beta - 3 * nbias * kind) / 3, cc = kind == 2 ? beta - 6 * nbias : (beta - 3 * nbias * kind) % 3;
+    const int f0 = max(0, i - K + 1), f1 = min(i, T.n_seg - 1);
+    for (int first = f0; first <= f1; ++first) {
+      const int ao = 6 * (i - first);
+#pragma unroll 2
+      for (int pos = T.i_seg_ptr[first] + sp; pos < T.i_seg_ptr[first + 1]; pos += nsp) {
+        const double* rec = T.i_rec + size_t(pos) * IREC;
+        const double* jp = rec + 6;
+        if (kind == 2) {
+          const double* jg = rec + 6 + 36 * K + 2 * kb;
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+            const double g = jg[2 * r + cc];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) acc[a] = fma(jp[r * 6 * K + ao + a], g, acc[a]);
+          }
+        } else {
+          const int j = bb - T.i_first_bias[pos];
+          if (j >= 0 && j < kb) {
+            const double wgt = rec[6 + 36 * K + kind * kb + j];
+            const double* row = jp + (3 * kind + cc) * 6 * K + ao;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) acc[a] = fma(row[a], wgt, acc[a]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) out[size_t(6 * i + a) * nb + beta] = acc[a];
+  }
+}
+
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_border_bb(Tables T) {
+  // one wave per bias control point b (gyro and accel parts) + one extra wave for the gravity block; written straight into
+  // the exchange buffer (single writer per entry; the region is zero-filled first by k_border_zero)
+  if (T.st->done) return;
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int kb = T.kb, nbias = T.n_bias, nb = T.nb;
+  if (b > nbias) return;
+  const int IREC = 18 + 36 * K + 2 * kb;
+  double* Hbb = T.xbuf + T.xo_bb;
+  double* gb = T.xbuf + T.xo_gb;
+  const int og = 0, oa = 3 * nbias, ogr = 6 * nbias;
+  if (b == nbias) {  // gravity-gravity and J_g' r
+    double h00 = 0, h01 = 0, h11 = 0, g0 = 0, g1 = 0;
+    for (int pos = lane; pos < T.n_ine; pos += 64) {
+      const double* rec = T.i_rec + size_t(pos) * IREC;
+      const double* jg = rec + 6 + 36 * K + 2 * kb;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        h00 = fma(jg[2 * r], jg[2 * r], h00), h01 = fma(jg[2 * r], jg[2 * r + 1], h01), h11 = fma(jg[2 * r + 1], jg[2 * r + 1], h11);
+        g0 = fma(jg[2 * r], rec[r], g0), g1 = fma(jg[2 * r + 1], rec[r], g1);
+      }
+    }
+    h00 = wave_sum(h00), h01 = wave_sum(h01), h11 = wave_sum(h11), g0 = wave_sum(g0), g1 = wave_sum(g1);
+    if (lane == 0) {
+      Hbb[size_t(ogr) * nb + ogr] = h00, Hbb[size_t(ogr) * nb + ogr + 1] = h01;
+      Hbb[size_t(ogr + 1) * nb + ogr] = h01, Hbb[size_t(ogr + 1) * nb + ogr + 1] = h11;
+      gb[ogr] = g0, gb[ogr + 1] = g1;
+    }
+    return;
+  }
+  // records whose bias window covers b: first_bias in [b - kb + 1, b]
+  const int p0 = T.i_bias_ptr[max(0, b - kb + 1)], p1 = T.i_bias_ptr[b + 1];
+  double gg[hsd::kMaxOrder], aa[hsd::kMaxOrder];  // weights against b' = b + d, d = 0 .. kb - 1
+  double ggr[6] = {0, 0, 0, 0, 0, 0}, agr[6] = {0, 0, 0, 0, 0, 0}, rg[3] = {0, 0, 0}, ra[3] = {0, 0, 0};
+#pragma unroll
+  for (int d = 0; d < hsd::kMaxOrder; ++d) gg[d] = aa[d] = 0.0;
+  for (int pos = p0 + lane; pos < p1; pos += 64) {
+    const double* rec = T.i_rec + size_t(pos) * IREC;
+    const int j = b - T.i_first_bias[pos];
+    const double* wgp = rec + 6 + 36 * K;
+    const double* wap = wgp + kb;
+    const double* jg = wap + kb;
+    const double wgb = wgp[j], wab = wap[j];
+#pragma unroll
+    for (int d = 0; d < hsd::kMaxOrder; ++d)
+      if (d < kb && j + d < kb) gg[d] = fma(wgb, wgp[j + d], gg[d]), aa[d] = fma(wab, wap[j + d], aa[d]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      ggr[2 * c] = fma(wgb, jg[2 * c], ggr[2 * c]), ggr[2 * c + 1] = fma(wgb, jg[2 * c + 1], ggr[2 * c + 1]);
+      agr[2 * c] = fma(wab, jg[2 * (3 + c)], agr[2 * c]), agr[2 * c + 1] = fma(wab, jg[2 * (3 + c) + 1], agr[2 * c + 1]);
+      rg[c] = fma(wgb, rec[c], rg[c]), ra[c] = fma(wab, rec[3 + c], ra[c]);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < hsd::kMaxOrder; ++d) gg[d] = wave_sum(gg[d]), aa[d] = wave_sum(aa[d]);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) ggr[c] = wave_sum(ggr[c]), agr[c] = wave_sum(agr[c]);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) rg[c] = wave_sum(rg[c]), ra[c] = wave_sum(ra[c]);
+  if (lane == 0) {
+    for (int d = 0; d < kb && b + d < nbias; ++d)
+      for (int c = 0; c < 3; ++c) {
+        const int r0 = og + 3 * b + c, c0 = og + 3 * (b + d) + c;
+        Hbb[size_t(r0) * nb + c0] = gg[d], Hbb[size_t(c0) * nb + r0] = gg[d];
+        const int r1 = oa + 3 * b + c, c1 = oa + 3 * (b + d) + c;
+        Hbb[size_t(r1) * nb + c1] = aa[d], Hbb[size_t(c1) * nb + r1] = aa[d];
+      }
+    for (int c = 0; c < 3; ++c)
+      for (int e = 0; e < 2; ++e) {
+        Hbb[size_t(og + 3 * b + c) * nb + ogr + e] = ggr[2 * c + e], Hbb[size_t(ogr + e) * nb + og + 3 * b + c] = ggr[2 * c + e];
+        Hbb[size_t(oa + 3 * b + c) * nb + ogr + e] = agr[2 * c + e], Hbb[size_t(ogr + e) * nb + oa + 3 * b + c] = agr[2 * c + e];
+      }
+    for (int c = 0; c < 3; ++c) gb[og + 3 * b + c] = rg[c], gb[oa + 3 * b + c] = ra[c];
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_border_zero(Tables T) {
+  if (T.st->done) return;
+  const int n = T.nb * T.nb + T.nb;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) T.xbuf[T.xo_bb + e] = 0.0;
+}
+
+/// Scaling / damping of the border blocks after the exchange:  S_pb = Sp H_pb Sb,  S_bb = Sb H_bb Sb + D_b^2,  g_b = Sb g_b.
+__global__ void __launch_bounds__(kBlock) k_finalize_border(Tables T) {
+  DevState* st = T.st;
+  if (st->done) return;
+  const int nb = T.nb, np = T.np;
+  const double* X = T.xbuf;
+  const bool fresh = !st->scaling_ready;
+  const double radius = st->radius;
+  auto sb_of = [&](int b) { return fresh ? 1.0 / (1.0 + sqrt(X[T.xo_bb + size_t(b) * nb + b])) : T.scale_b[b]; };
+  auto sp_of = [&](int rho) { return fresh ? 1.0 / (1.0 + sqrt(X[T.xo_dj + rho])) : T.scale_p[rho]; };
+  const int total = (np + nb) * nb;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int row = e / nb, c = e % nb;
+    if (row < np) {
+      T.Spb[e] = sp_of(row) * X[T.xo_pb + e] * sb_of(c);
+    } else {
+      const int b = row - np;
+      const double sr = sb_of(b), sc = sb_of(c);
+      double out = sr * sc * X[T.xo_bb + size_t(b) * nb + c];
+      if (b == c) {
+        const double d = X[T.xo_bb + size_t(b) * nb + b];
+        if (d > 0.0) {
+          const double d2 = fmin(fmax(sr * sr * d, 1e-6), 1e32) / radius;
+          out += d2;
+          T.D2b[b] = d2;
+        } else {
+          out = 1.0;
+          T.D2b[b] = 0.0;
+        }
+        const double g = X[T.xo_gb + b];
+        T.gb_s[b] = sr * g;
+        if (fresh) T.scale_b[b] = sr;
+        atomicMax(&st->gmax_pose_bits, (unsigned long long)__double_as_longlong(fabs(g)));
+      }
+      T.Sbb[size_t(b) * nb + c] = out;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Bordered solve:  [S_pp S_pb; S_bp S_bb][x_p; x_b] = [g_p; g_b] with S_pp = U'U banded.
+//   Z = U^-T S_pb  (k_border_forward: one workgroup per group of border columns, column-oriented forward sweep)
+//   C = S_bb - Z'Z, h = g_b - Z'y  (k_border_schur, one workgroup per border row)
+//   C x_b = h (dense Cholesky in LDS), y' = y - Z x_b  (k_border_solve, one workgroup)   then the banded backward sweep on y'.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kBorderCols = 8;  // right-hand sides per workgroup in the forward sweep
+
+__global__ void __launch_bounds__(128) k_border_forward(Tables T) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (T.st->done) return;
+  const int tid = threadIdx.x;
+  const int bw = T.bw, ncb = 6 * bw, nb = T.nb, np = T.np, n_blk = np / 6;
+  const int c0 = blockIdx.x * kBorderCols, ncols = min(kBorderCols, nb - c0);
+  double* z = smem;  // np x kBorderCols: pending right-hand side rows, overwritten by the solution
+  for (int e = tid; e < np * kBorderCols; e += blockDim.x) {
+    const int rho = e / kBorderCols, c = e % kBorderCols;
+    z[e] = c < ncols ? T.Spb[size_t(rho) * nb + c0 + c] : 0.0;
+  }
+  __syncthreads();
+  __shared__ double zi[6 * kBorderCols];
+  const int n_pend = 6 * (bw - 1);
+  for (int m = 0; m < n_blk; ++m) {
+    // z_m = U_mm^-T s_m = W' s_m with W = U_mm^-1 (packed upper): thread (a, c) for a < 6, c < kBorderCols
+    if (tid < 6 * kBorderCols) {
+      const int a = tid / kBorderCols, c = tid % kBorderCols;
+      const double* W = T.Ubk + size_t(m) * 24;
+      double v = 0.0;
+      // (W')[a][k] = W[k][a], k <= a ; packed index of (k, a) = k*6 - k(k-1)/2 + (a - k)
+      for (int k = 0; k <= a; ++k) v = fma(W[k * 6 - k * (k - 1) / 2 + (a - k)], z[(6 * m + k) * kBorderCols + c], v);
+      zi[tid] = v;
+    }
+    __syncthreads();
+    if (tid < 6 * kBorderCols) z[(6 * m + tid / kBorderCols) * kBorderCols + tid % kBorderCols] = zi[tid];
+    // pending rows of blocks m+1 .. m+bw-1: s_(i,c') -= sum_a U[6m+a][6(i-m)+c'] z_m[a]
+    for (int t = tid; t < n_pend; t += blockDim.x) {
+      const int rho = 6 * (m + 1) + t;
+      if (rho < np) {
+        double u[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) u[a] = T.Ub[size_t(6 * m + a) * ncb + 6 + t];
+#pragma unroll
+        for (int c = 0; c < kBorderCols; ++c) {
+          double sacc = 0.0;
+#pragma unroll
+          for (int a = 0; a < 6; ++a) sacc = fma(u[a], zi[a * kBorderCols + c], sacc);
+          z[rho * kBorderCols + c] -= sacc;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < np * kBorderCols; e += blockDim.x) {
+    const int rho = e / kBorderCols, c = e % kBorderCols;
+    if (c < ncols) T.Zb[size_t(rho) * nb + c0 + c] = z[e];
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) k_border_schur(Tables T) {
+  // block b: C[b][:] = S_bb[b][:] - sum_rho Z[rho][b] Z[rho][:],  h[b] = g_b[b] - sum_rho Z[rho][b] y[rho]
+  __shared__ double red[kBlock / 64];
+  if (T.st->done) return;
+  const int b = blockIdx.x, nb = T.nb, np = T.np;
+  for (int c = threadIdx.x; c < nb; c += blockDim.x) {
+    double acc = T.Sbb[size_t(b) * nb + c];
+    for (int rho = 0; rho < np; ++rho) acc = fma(-T.Zb[size_t(rho) * nb + b], T.Zb[size_t(rho) * nb + c], acc);
+    T.Cb[size_t(b) * nb + c] = acc;
+  }
+  double hacc = 0.0;
+  for (int rho = threadIdx.x; rho < np; rho += blockDim.x) hacc = fma(T.Zb[size_t(rho) * nb + b], T.ybuf[rho], hacc);
+  hacc = block_sum(hacc, red);
+  if (threadIdx.x == 0) T.hb[b] = T.gb_s[b] - hacc;
+}
+
+__global__ void __launch_bounds__(kBlock) k_border_solve(Tables T) {
+  // dense Cholesky of C (nb x nb, LDS) + solve, then y' = y - Z x_b
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  DevState* st = T.st;
+  if (st->done) return;
+  const int nb = T.nb, np = T.np, tid = threadIdx.x;
+  const int ld = nb + 1;
+  double* C = smem;            // nb x ld
+  double* x = smem + nb * ld;  // nb
+  for (int e = tid; e < nb * nb; e += blockDim.x) C[(e / nb) * ld + e % nb] = T.Cb[e];
+  for (int e = tid; e < nb; e += blockDim.x) x[e] = T.hb[e];
+  __shared__ int bad;
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  for (int j = 0; j < nb; ++j) {  // right-looking, lower triangle
+    if (tid == 0) {
+      double d = C[j * ld + j];
+      if (!(d > 0.0)) bad = 1, d = 1.0;
+      C[j * ld + j] = sqrt(d);
+    }
+    __syncthreads();
+    const double dj = C[j * ld + j];
+    for (int i = j + 1 + tid; i < nb; i += blockDim.x) C[i * ld + j] /= dj;
+    __syncthreads();
+    for (int e = tid; e < (nb - j - 1) * (nb - j - 1); e += blockDim.x) {
+      const int i = j + 1 + e / (nb - j - 1), c = j + 1 + e % (nb - j - 1);
+      if (c <= i) C[i * ld + c] -= C[i * ld + j] * C[c * ld + j];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    for (int i = 0; i < nb; ++i) {
+      double v = x[i];
+      for (int k = 0; k < i; ++k) v -= C[i * ld + k] * x[k];
+      x[i] = v / C[i * ld + i];
+    }
+    for (int i = nb - 1; i >= 0; --i) {
+      double v = x[i];
+      for (int k = i + 1; k < nb; ++k) v -= C[k * ld + i] * x[k];
+      x[i] = v / C[i * ld + i];
+    }
+    if (bad) st->chol_failed = 1;
+  }
+  __syncthreads();
+  for (int b = tid; b < nb; b += blockDim.x) T.xb[b] = x[b];
+  for (int rho = tid; rho < np; rho += blockDim.x) {
+    double v = T.ybuf[rho];
+    for (int b = 0; b < nb; ++b) v = fma(-T.Zb[size_t(rho) * nb + b], x[b], v);
+    T.ybuf[rho] = v;
+  }
 }
 
 /// After the (optional) all-reduce: Jacobi scaling (fixed at iteration 0), LM diagonal, inactive coordinates.
@@ -497,7 +810,7 @@ __global__ void __launch_bounds__(kBlock) k_finalize_reduced(Tables T) {
 constexpr int kCholThreads = 256;
 
 template <int TPT>  // tiles per thread: bw * bw <= TPT * kCholThreads
-__global__ void __launch_bounds__(kCholThreads) k_band_cholesky_solve(Tables T) {
+__global__ void __launch_bounds__(kCholThreads) k_band_factor(Tables T) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   DevState* st = T.st;
   if (st->done) return;
@@ -507,10 +820,8 @@ __global__ void __launch_bounds__(kCholThreads) k_band_cholesky_solve(Tables T) 
   const int n_blk = T.np / 6;
   double* rowbuf = smem;            // 6 x ld : pivot row as published by its owners [band | rhs | pad]
   double* xbuf = smem + 6 * ld;     // 6 x ld : [U_ii | X | y_i]
-  double* xs = smem + 12 * ld;      // np : y (forward), pending rows (backward)
-  double* xout = xs + T.np;         // np : final x
+  double* xs = smem + 12 * ld;      // np : y (forward solve)
   __shared__ int fail;
-  __shared__ double Wl[2][24];
   if (tid == 0) fail = 0;
 
   // ---- static tile ownership ------------------------------------------------------------------------------------
@@ -671,6 +982,23 @@ __global__ void __launch_bounds__(kCholThreads) k_band_cholesky_solve(Tables T) 
   }
 #undef UIDX
   lds_barrier();
+  for (int rho = tid; rho < T.np; rho += nthr) T.ybuf[rho] = xs[rho];  // y = U^-T g, input of the (bordered) backward sweep
+  if (tid == 0) st->chol_failed = fail;
+}
+
+/// Backward sweep U x = y (y in T.ybuf, possibly corrected by the border solve) + step outputs and model-cost reductions.
+__global__ void __launch_bounds__(kCholThreads) k_band_backward(Tables T) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  DevState* st = T.st;
+  if (st->done) return;
+  const int tid = threadIdx.x;
+  constexpr int nthr = kCholThreads;
+  const int bw = T.bw, ncb = 6 * bw;
+  const int n_blk = T.np / 6;
+  double* xs = smem;         // np : pending rows
+  double* xout = xs + T.np;  // np : final x
+  __shared__ double Wl[2][24];
+  for (int rho = tid; rho < T.np; rho += nthr) xs[rho] = T.ybuf[rho];
   if (T.debug_flags & 1) return;  // timing experiments only (HS_DEBUG_FLAGS)
 
   // ---- backward solve U x = y, column oriented: once x_j is final every pending row above subtracts U[rho][x_j] ----
@@ -685,8 +1013,6 @@ __global__ void __launch_bounds__(kCholThreads) k_band_cholesky_solve(Tables T) 
     for (int a = 0; a < 6; ++a) u[a] = ok ? src[a] : 0.0;
   };
   auto load_w = [&](int j) -> double { return (j >= 0 && tid < 21) ? T.Ubk[size_t(j) * 24 + tid] : 0.0; };
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // Ub / Ubk written above by other waves of this workgroup
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   double u0[6], u1[6], u2[6], u3[6], w0, w1, w2, w3;
   load_u(n_blk - 1, u0), load_u(n_blk - 2, u1), load_u(n_blk - 3, u2);
@@ -732,12 +1058,17 @@ __global__ void __launch_bounds__(kCholThreads) k_band_cholesky_solve(Tables T) 
     gd = fma(T.g_full[rho], step, gd);
     dd = fma(T.D2p[rho] * step, step, dd);
   }
+  for (int b = tid; b < T.nb; b += nthr) {
+    const double step = -T.xb[b];
+    T.delta_b[b] = T.scale_b[b] * step;
+    gd = fma(T.gb_s[b], step, gd);
+    dd = fma(T.D2b[b] * step, step, dd);
+  }
   gd = block_sum(gd, red);
   dd = block_sum(dd, red);
   if (tid == 0) {
     st->g_dot_step_pose = gd;
     st->d2_step2_pose = dd;
-    st->chol_failed = fail;
   }
 }
 
@@ -807,6 +1138,33 @@ __global__ void __launch_bounds__(kBlock) k_retract(Tables T) {
       for (int a = 0; a < 3; ++a) {
         const double x = T.lm[3 * l + a], y = T.lm_cand[3 * l + a];
         xl = fma(x, x, xl), sl = fma(x - y, x - y, sl);
+      }
+    }
+  }
+  // border unknowns (replicated like the control points): bias control points [x y z t] and gravity
+  if (T.nb > 0) {
+    for (int b = j; b < 2 * T.n_bias; b += gridDim.x * blockDim.x) {
+      const bool acc = b >= T.n_bias;
+      const int bi = acc ? b - T.n_bias : b;
+      const double* x = (acc ? T.bias_a : T.bias_g) + 4 * bi;
+      double* y = (acc ? T.bias_a_cand : T.bias_g_cand) + 4 * bi;
+      const double* d = T.delta_b + 3 * b;
+      const bool any = T.D2b[3 * b] != 0.0 || T.D2b[3 * b + 1] != 0.0 || T.D2b[3 * b + 2] != 0.0;
+      y[0] = x[0] + d[0], y[1] = x[1] + d[1], y[2] = x[2] + d[2], y[3] = x[3];
+      if (any) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xs = fma(x[c], x[c], xs), ss = fma(x[c] - y[c], x[c] - y[c], ss);
+      }
+    }
+    if (j == 0) {
+      const double* d = T.delta_b + 6 * T.n_bias;
+      double y[3];
+      sphere_plus(T.gravity, d, y);
+      const bool any = T.D2b[6 * T.n_bias] != 0.0 || T.D2b[6 * T.n_bias + 1] != 0.0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        T.gravity_cand[c] = y[c];
+        if (any) xs = fma(T.gravity[c], T.gravity[c], xs), ss = fma(T.gravity[c] - y[c], T.gravity[c] - y[c], ss);
       }
     }
   }
@@ -944,6 +1302,10 @@ __global__ void __launch_bounds__(kBlock) k_commit(Tables T) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < 8 * T.sp.n_cp) T.cp[idx] = T.cp_cand[idx];
   for (int l = idx; l < 3 * T.n_lm; l += gridDim.x * blockDim.x) T.lm[l] = T.lm_cand[l];
+  if (T.nb > 0) {
+    for (int e = idx; e < 4 * T.n_bias; e += gridDim.x * blockDim.x) T.bias_g[e] = T.bias_g_cand[e], T.bias_a[e] = T.bias_a_cand[e];
+    if (idx < 3) T.gravity[idx] = T.gravity_cand[idx];
+  }
 }
 
 /// Fresh trust-region state (LevenbergMarquardtStrategy: initial radius 1e4, decrease factor 2).

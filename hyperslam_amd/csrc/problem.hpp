@@ -135,16 +135,29 @@ struct Tables {
   double* D2p;             // np  LM diagonal (pose side)
   double* step_p;          // np  scaled step
   double* delta_p;         // np  unscaled step (tangent update)
+  double* ybuf;            // np  y = U^-T g (forward-solved right-hand side)
+  // border blocks (scaled + damped) and the bordered solve
+  double* scale_b;         // nb
+  double* Spb;             // np x nb
+  double* Sbb;             // nb x nb
+  double* gb_s;            // nb
+  double* D2b;             // nb
+  double* Zb;              // np x nb   U^-T S_pb
+  double* Cb;              // nb x nb   S_bb - Z'Z
+  double* hb;              // nb
+  double* xb;              // nb        border solution
+  double* delta_b;         // nb        unscaled border step
+  const int* i_bias_ptr;   // n_bias + 1: first inertial record with first_bias >= f
   // reductions
   double* cost_part;       // per-block cost partial sums (current point)
   double* cand_part;       // per-block cost partial sums (candidate point)
   int n_cost_part;
   double* norm_part;       // per-block (x_sqnorm, step_sqnorm) pairs
   int n_norm_part;
-  // exchange buffer (additive across residual shards): [Sraw np*6bw | g_p np | g_schur np | diag np | cost | gmax[world] | decision 5]
+  // exchange buffer (additive across residual shards): [Sraw np*6bw | g_p np | g_schur np | diag np | H_pb np*nb | H_bb nb*nb | g_b nb | cost | gmax[world] | decision 5]
   double* xbuf;
   double* xpart;  // per-split partial copies of [Sraw | g_p | g_schur | diag] (stride x_count1)
-  int xo_g, xo_gs, xo_dj, xo_cost, xo_gmax, xo_dec, x_count1;
+  int xo_g, xo_gs, xo_dj, xo_pb, xo_bb, xo_gb, xo_cost, xo_gmax, xo_dec, x_count1;
   int rank, world;
   int debug_flags;  // HS_DEBUG_FLAGS env (timing experiments; 0 in production)
   DevState* st;

@@ -29,3 +29,34 @@ def test_inertial_linearization_vs_oracle(order, identity, robustify, hip, oracl
         Lc = c.residual_layout(ha.HS_INERTIAL, 3)
         for k in L:
             assert np.array_equal(L[k], Lc[k]), k
+
+
+@pytest.mark.parametrize("order,identity", [(4, False), (6, True)])
+def test_bordered_reduced_system(order, identity, hip, oracle):
+    w = synthetic.small_inertial(order=order, n_cp=18, identity=identity)
+    with ha.Problem(w, lib=hip) as g, ha.Problem(w, lib=oracle) as c:
+        assert g.dim_pose() == c.dim_pose() == 6 * 18 + 6 * len(w.imu["bias_g"]) + 2
+        Sg, gg = g.reduced_system(1e4)
+        Sc, gc = c.reduced_system(1e4)
+        assert rel(Sg, Sc) < 1e-9 and rel(gg, gc) < 1e-9, (rel(Sg, Sc), rel(gg, gc))
+
+
+@pytest.mark.parametrize("order,identity,grav_const", [(4, False, False), (6, True, False), (4, True, True)])
+def test_bordered_solve_trajectory(order, identity, grav_const, hip, oracle):
+    w = synthetic.small_inertial(order=order, n_cp=18, identity=identity)
+    w.gravity_constant = grav_const
+    w.cp_constant = np.r_[np.ones(order, np.uint8), np.zeros(18 - order, np.uint8)]
+    with ha.Problem(w, lib=hip) as g, ha.Problem(w, lib=oracle) as c:
+        sg, sc = g.solve(5), c.solve(5)
+        assert sg["num_iterations"] == sc["num_iterations"] and sg["num_successful_steps"] == sc["num_successful_steps"]
+        for ig, ic in zip(sg["iterations"], sc["iterations"]):
+            assert ig["step_is_successful"] == ic["step_is_successful"]
+            assert abs(ig["cost"] - ic["cost"]) <= 1e-6 * abs(ic["cost"]) + 1e-8 * sc["initial_cost"], (ig["iteration"], ig["cost"], ic["cost"])
+        assert rel(g.control_points(), c.control_points()) < 1e-6
+        assert rel(g.landmarks(), c.landmarks()) < 1e-6
+        assert rel(g.gravity(), c.gravity()) < 1e-6
+        bg, ba = g.bias()
+        cg, ca = c.bias()
+        assert rel(bg, cg) < 1e-6 and rel(ba, ca) < 1e-6
+        if grav_const:
+            assert np.array_equal(g.gravity(), w.gravity)

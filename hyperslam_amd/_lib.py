@@ -96,11 +96,11 @@ _SIGNATURES = {
     "get_bias": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "get_gravity": (C.c_int, [C.c_void_p, c_double_p]),
     "sample_trajectory": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]),
-}
-_PRODUCT_ONLY = {
     "set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
     "set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "band_blocks": (C.c_int, [C.c_void_p]),
+}
+_PRODUCT_ONLY = {
     "snapshot": (C.c_int, [C.c_void_p]),
     "restore": (C.c_int, [C.c_void_p]),
     "version": (C.c_int, []),

@@ -1,15 +1,20 @@
 """Multi-GPU glue: one process per GPU, residual blocks sharded by landmark, one RCCL all-reduce (sum, fp64) of the reduced
-normal equations per LM linearisation. torch.distributed is plumbing only: the library hands a device
-pointer + count to the hook, the hook wraps it as a tensor and calls dist.all_reduce on the library's stream.
+normal equations per LM linearisation. torch.distributed is plumbing only: the library hands a pointer +
+count to the hook, the hook wraps it as a tensor (zero copy) and calls dist.all_reduce on the library's stream.
+
+The same hook drives the oracle on CPU tensors with the gloo backend (tests/test_distributed_cpu.py).
 """
 from __future__ import annotations
 
 import ctypes as C
+import sys
+
+import numpy as np
 
 from . import _lib
 
 
-def _as_tensor(ptr: int, count: int, device):
+def _device_tensor(ptr: int, count: int, device):
     """Zero-copy fp64 view of library-owned device memory."""
     import torch
 
@@ -19,17 +24,28 @@ def _as_tensor(ptr: int, count: int, device):
     return torch.as_tensor(_Iface(), device=device)
 
 
-def attach_allreduce(problem, dist, group=None):
-    """Registers the exchange hook on `problem` and agrees on the band layout across ranks. Returns an object that must be
-    kept alive as long as the problem (it owns the ctypes callback)."""
+def _host_tensor(ptr: int, count: int):
+    import torch
+    arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(count,))
+    return torch.from_numpy(arr)
+
+
+def attach_allreduce(problem, dist, group=None, device_memory=None):
+    """Registers the exchange hook on `problem` and agrees on the band layout across ranks.
+
+    device_memory: True if the library hands out GPU pointers (product library), False for host pointers (oracle);
+    default: product library <=> True. With a backend that cannot reduce GPU tensors (gloo) the buffer is staged through
+    the host. Returns the ctypes callback (kept alive on the problem)."""
     import torch
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     backend = dist.get_backend(group)
-    on_gpu = backend == "nccl"
-    device = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    if device_memory is None:
+        device_memory = problem.lib.prefix == "hs_"
+    device = torch.device("cuda", torch.cuda.current_device()) if device_memory else torch.device("cpu")
+    comm_device = device if backend == "nccl" else torch.device("cpu")
     # same band width everywhere
     problem._check(problem.lib.set_shard(problem.h, rank, world, 0), "set_shard")
-    bw = torch.tensor([problem.lib.band_blocks(problem.h)], dtype=torch.int64, device=device)
+    bw = torch.tensor([problem.lib.band_blocks(problem.h)], dtype=torch.int64, device=comm_device)
     dist.all_reduce(bw, op=dist.ReduceOp.MAX, group=group)
     problem._check(problem.lib.set_shard(problem.h, rank, world, int(bw.item())), "set_shard")
     views = {}
@@ -39,13 +55,21 @@ def attach_allreduce(problem, dist, group=None):
             key = (ptr, count)
             t = views.get(key)
             if t is None:
-                t = views[key] = _as_tensor(ptr, count, device)
-            ext = torch.cuda.ExternalStream(stream) if stream else torch.cuda.current_stream()
-            with torch.cuda.stream(ext):
+                t = views[key] = _device_tensor(ptr, count, device) if device_memory else _host_tensor(ptr, count)
+            if device_memory:
+                ext = torch.cuda.ExternalStream(stream) if stream else torch.cuda.current_stream()
+                with torch.cuda.stream(ext):
+                    if backend == "nccl":
+                        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                    else:  # host staging (tests on a single GPU with gloo)
+                        h = t.cpu()
+                        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                        t.copy_(h)
+                        ext.synchronize()
+            else:
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
             return 0
         except Exception as e:  # never let an exception cross the C boundary
-            import sys
             print(f"hyperslam_amd all-reduce hook failed: {e!r}", file=sys.stderr)
             return 1
 

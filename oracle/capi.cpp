@@ -13,7 +13,15 @@ using namespace hso;
 struct hso_problem {
   Problem P;
   std::string err;
+  hs_allreduce_fn allreduce = nullptr;
+  void* allreduce_user = nullptr;
+  int rank = 0, world = 1;
 };
+
+static void attach(hso_problem* p, LM* lm) {
+  lm->rank = p->rank, lm->world = p->world;
+  if (p->allreduce) lm->allreduce = [p](double* buf, int64_t n) { p->allreduce(p->allreduce_user, buf, n, nullptr); };
+}
 
 #define CHECK_ARG(cond, msg)  \
   do {                        \
@@ -192,9 +200,11 @@ int hso_cost(hso_problem* p, double* cost) {
 
 int hso_reduced_system(hso_problem* p, double radius, double* S, double* g) {
   LM lm(p->P);
+  attach(p, &lm);
   lm.radius = radius;
   NormalEquations ne;
   lm.solver.build(&ne);
+  lm.globalize(&ne);
   lm.compute_scaling(ne);
   std::vector<double> sp, sl;
   ReducedSystem rs;
@@ -207,9 +217,20 @@ int hso_reduced_system(hso_problem* p, double radius, double* S, double* g) {
   return HS_OK;
 }
 
+int hso_set_allreduce(hso_problem* p, hs_allreduce_fn fn, void* user) {
+  p->allreduce = fn, p->allreduce_user = user;
+  return HS_OK;
+}
+int hso_set_shard(hso_problem* p, int rank, int world, int) {
+  p->rank = rank, p->world = world;
+  return HS_OK;
+}
+int hso_band_blocks(hso_problem*) { return 0; }
+
 int hso_solve(hso_problem* p, int max_iterations, hs_summary* summary, hs_iteration* iterations) {
   const auto t0 = std::chrono::steady_clock::now();
   LM lm(p->P);
+  attach(p, &lm);
   const Summary s = lm.run(max_iterations);
   const auto t1 = std::chrono::steady_clock::now();
   std::memset(summary, 0, sizeof(*summary));

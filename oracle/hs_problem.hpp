@@ -9,6 +9,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdio>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -415,7 +416,25 @@ struct LM {
   std::vector<double> scale_p, scale_l;  // Jacobi scaling (TrustRegionMinimizer, jacobi_scaling = true)
   double radius = 1e4, decrease_factor = 2.0;
   static constexpr double kMinDiag = 1e-6, kMaxDiag = 1e32;
+  // Residual-sharded operation: every additive quantity goes through this sum-all-reduce (no-op when unset).
+  std::function<void(double*, int64_t)> allreduce;
+  int rank = 0, world = 1;
   explicit LM(Problem& p) : P(p), solver(p) {}
+  void sum(std::vector<double>& v) const {
+    if (allreduce && !v.empty()) allreduce(v.data(), int64_t(v.size()));
+  }
+  /// Makes the pose-side normal equations and the cost global (landmark blocks stay local to their shard).
+  void globalize(NormalEquations* ne) const {
+    if (!allreduce) return;
+    std::vector<double> buf(ne->Hpp);
+    buf.insert(buf.end(), ne->gp.begin(), ne->gp.end());
+    buf.push_back(ne->cost);
+    sum(buf);
+    const size_t n2 = ne->Hpp.size();
+    std::copy(buf.begin(), buf.begin() + n2, ne->Hpp.begin());
+    std::copy(buf.begin() + n2, buf.begin() + n2 + ne->gp.size(), ne->gp.begin());
+    ne->cost = buf.back();
+  }
 
   std::vector<uint8_t> active_pose_mask(const NormalEquations& ne) const {
     // A pose-side coordinate is active iff its column of J is not structurally zero (constant blocks / never observed).
@@ -444,6 +463,9 @@ struct LM {
       const double diag = std::min(std::max(rs->S[size_t(i) * np + i], kMinDiag), kMaxDiag);
       rs->S[size_t(i) * np + i] += diag / radius;
     }
+    std::vector<double> schur(size_t(np) * np + np, 0.0);  // [dS | dg]: this shard's landmark eliminations (additive)
+    double* dS = schur.data();
+    double* dg = schur.data() + size_t(np) * np;
     for (int l = 0; l < nl; ++l) {
       if (ne.w_count[l] == 0 || P.lm_const[l]) continue;
       double V[9];
@@ -465,12 +487,15 @@ struct LM {
       double sb[3];
       for (int a = 0; a < 3; ++a) sb[a] = scale_l[3 * l + a] * ne.bl[3 * l + a];
       for (int r = 0; r < rows; ++r) {
-        rs->g[r0 + r] -= WV[size_t(r) * 3] * sb[0] + WV[size_t(r) * 3 + 1] * sb[1] + WV[size_t(r) * 3 + 2] * sb[2];
-        double* Srow = &rs->S[size_t(r0 + r) * np + r0];
+        dg[r0 + r] -= WV[size_t(r) * 3] * sb[0] + WV[size_t(r) * 3 + 1] * sb[1] + WV[size_t(r) * 3 + 2] * sb[2];
+        double* Srow = &dS[size_t(r0 + r) * np + r0];
         for (int c = 0; c < rows; ++c)
           Srow[c] -= WV[size_t(r) * 3] * Ws[size_t(c) * 3] + WV[size_t(r) * 3 + 1] * Ws[size_t(c) * 3 + 1] + WV[size_t(r) * 3 + 2] * Ws[size_t(c) * 3 + 2];
       }
     }
+    sum(schur);
+    for (size_t e = 0; e < size_t(np) * np; ++e) rs->S[e] += dS[e];
+    for (int i = 0; i < np; ++i) rs->g[i] += dg[i];
   }
 
   /// Solves the LM system; outputs the *scaled* step (trust_region_step) for pose-side and landmark unknowns.
@@ -564,8 +589,8 @@ struct LM {
   }
 
   /// Squared norm of the ambient parameter vector over the non-constant blocks (x_norm in Ceres).
-  double x_squared_norm(const NormalEquations& ne) const {
-    double s = 0;
+  void x_squared_norm(const NormalEquations& ne, double* replicated, double* landmarks) const {
+    double s = 0, sl = 0;
     const std::vector<uint8_t> active = active_pose_mask(ne);
     for (int j = 0; j < P.n_cp; ++j) {
       bool a = false;
@@ -575,7 +600,7 @@ struct LM {
     }
     for (int l = 0; l < P.n_lm; ++l)
       if (!P.lm_const[l] && ne.w_count[l] > 0)
-        for (int a = 0; a < 3; ++a) s += P.lm[3 * l + a] * P.lm[3 * l + a];
+        for (int a = 0; a < 3; ++a) sl += P.lm[3 * l + a] * P.lm[3 * l + a];
     if (P.has_imu) {
       if (!P.bias_const)
         for (int j = 0; j < P.n_bias; ++j) {
@@ -587,15 +612,19 @@ struct LM {
       if (!P.gravity_const && active[P.off_gravity()])
         for (int a = 0; a < 3; ++a) s += P.gravity[a] * P.gravity[a];
     }
-    return s;
+    *replicated = s, *landmarks = sl;
   }
 
-  static double gradient_max_norm(const NormalEquations& ne, const Problem& P) {
-    double m = 0;
-    for (double v : ne.gp) m = std::max(m, std::fabs(v));
+  double gradient_max_norm(const NormalEquations& ne, const Problem& P) const {
+    double m = 0, ml = 0;
+    for (double v : ne.gp) m = std::max(m, std::fabs(v));  // global after globalize()
     for (int l = 0; l < ne.nl; ++l)
       if (!P.lm_const[l])
-        for (int a = 0; a < 3; ++a) m = std::max(m, std::fabs(ne.bl[3 * l + a]));
+        for (int a = 0; a < 3; ++a) ml = std::max(ml, std::fabs(ne.bl[3 * l + a]));
+    std::vector<double> slots(world, 0.0);  // a SUM all-reduce of one slot per rank delivers every rank's maximum
+    slots[rank] = ml;
+    sum(slots);
+    for (double v : slots) m = std::max(m, v);
     return m;
   }
 
@@ -605,6 +634,7 @@ struct LM {
     Summary sum;
     NormalEquations ne;
     solver.build(&ne);
+    globalize(&ne);
     compute_scaling(ne);
     double cost = ne.cost;
     sum.initial_cost = cost;
@@ -627,7 +657,9 @@ struct LM {
         delta_p = step_p, delta_l = step_l;
         for (size_t i = 0; i < delta_p.size(); ++i) delta_p[i] *= scale_p[i];
         for (size_t i = 0; i < delta_l.size(); ++i) delta_l[i] *= scale_l[i];
-        mcc = model_cost_change(delta_p, delta_l);
+        std::vector<double> m1(1, model_cost_change(delta_p, delta_l));  // per-residual sum: additive across shards
+        this->sum(m1);
+        mcc = m1[0];
         if (mcc < 0.0) valid = false;
       }
       if (!valid) {  // HandleInvalidStep
@@ -641,16 +673,20 @@ struct LM {
       rec.step_is_valid = 1;
       Problem cand;
       apply(delta_p, delta_l, &cand);
-      const double cand_cost = Solver(cand).total_cost();
-      // ParameterToleranceReached
-      double sn = 0;
-      for (size_t i = 0; i < P.cp.size(); ++i) sn += (P.cp[i] - cand.cp[i]) * (P.cp[i] - cand.cp[i]);
+      // candidate cost and norms: replicated unknowns (control points, biases, gravity) are counted by rank 0 only
+      double sn = 0, sn_rep = 0;
+      for (size_t i = 0; i < P.cp.size(); ++i) sn_rep += (P.cp[i] - cand.cp[i]) * (P.cp[i] - cand.cp[i]);
       for (size_t i = 0; i < P.lm.size(); ++i) sn += (P.lm[i] - cand.lm[i]) * (P.lm[i] - cand.lm[i]);
-      for (size_t i = 0; i < P.bias_g.size(); ++i) sn += (P.bias_g[i] - cand.bias_g[i]) * (P.bias_g[i] - cand.bias_g[i]);
-      for (size_t i = 0; i < P.bias_a.size(); ++i) sn += (P.bias_a[i] - cand.bias_a[i]) * (P.bias_a[i] - cand.bias_a[i]);
-      for (int i = 0; i < 3; ++i) sn += (P.gravity[i] - cand.gravity[i]) * (P.gravity[i] - cand.gravity[i]);
-      rec.step_norm = std::sqrt(sn);
-      const double x_norm = std::sqrt(x_squared_norm(ne));
+      for (size_t i = 0; i < P.bias_g.size(); ++i) sn_rep += (P.bias_g[i] - cand.bias_g[i]) * (P.bias_g[i] - cand.bias_g[i]);
+      for (size_t i = 0; i < P.bias_a.size(); ++i) sn_rep += (P.bias_a[i] - cand.bias_a[i]) * (P.bias_a[i] - cand.bias_a[i]);
+      for (int i = 0; i < 3; ++i) sn_rep += (P.gravity[i] - cand.gravity[i]) * (P.gravity[i] - cand.gravity[i]);
+      double xs_rep = 0, xs_lm = 0;
+      x_squared_norm(ne, &xs_rep, &xs_lm);
+      std::vector<double> dec = {Solver(cand).total_cost(), sn + (rank == 0 ? sn_rep : 0.0), xs_lm + (rank == 0 ? xs_rep : 0.0)};
+      this->sum(dec);
+      const double cand_cost = dec[0];
+      rec.step_norm = std::sqrt(dec[1]);
+      const double x_norm = std::sqrt(dec[2]);
       if (rec.step_norm <= kParameterTolerance * (x_norm + kParameterTolerance)) {
         sum.termination = 1;
         sum.iterations.push_back(rec);
@@ -669,6 +705,7 @@ struct LM {
         sum.num_successful_steps++;
         P = cand;
         solver.build(&ne);
+        globalize(&ne);
         cost = ne.cost;
         gmax = gradient_max_norm(ne, P);
         rec.cost = cost, rec.gradient_max_norm = gmax;

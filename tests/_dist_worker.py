@@ -1,0 +1,42 @@
+"""Worker of the multi-process tests: rank r solves its landmark shard with the all-reduce hook and dumps the result."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    which, out_dir = sys.argv[1], sys.argv[2]
+    import torch
+    import torch.distributed as dist
+    import hyperslam_amd as ha
+    from hyperslam_amd import _lib, synthetic
+    from hyperslam_amd.distributed import attach_allreduce
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if which.endswith("inertial"):
+        full = synthetic.small_inertial(order=4, n_cp=18, n_landmarks=40)
+    else:
+        full = synthetic.small_visual(order=4, n_cp=18, n_landmarks=64, obs_pairs=3, with_priors=21)
+    shard = synthetic.shard_by_landmark(full, rank, world)
+    if which.startswith("oracle"):
+        lib = _lib.Library(os.path.join(ROOT, "oracle", "liboracle.so"), "hso_")
+    else:
+        torch.cuda.set_device(0)
+        lib = _lib.load()
+    with ha.Problem(shard, lib=lib) as p:
+        attach_allreduce(p, dist)
+        S, g = p.reduced_system(1e4)
+        s = p.solve(5)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), S=S, g=g, cp=p.control_points(), lm=p.landmarks(),
+                 lm_ids=np.unique(np.concatenate([shard.pixel_landmark, shard.bearing_landmark])),
+                 costs=np.array([it["cost"] for it in s["iterations"]]), final=s["final_cost"], iters=s["num_iterations"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

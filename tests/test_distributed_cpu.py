@@ -1,0 +1,44 @@
+"""world_size-2 test of the residual-sharded path on CPU (gloo): shard_by_landmark + the all-reduce hook protocol of
+hyperslam_amd.distributed drive the oracle; the sharded solve must reproduce the single-process solve."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import hyperslam_amd as ha
+from hyperslam_amd import synthetic
+from util import rel
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_workers(which, tmp_path, world=2):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + (os.getpid() % 2000)), WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_worker.py"), which, str(tmp_path)],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    return [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+
+
+@pytest.mark.parametrize("which", ["oracle_visual", "oracle_inertial"])
+def test_sharded_oracle_matches_single_process(which, tmp_path, oracle):
+    full = synthetic.small_inertial(order=4, n_cp=18, n_landmarks=40) if which.endswith("inertial") else \
+        synthetic.small_visual(order=4, n_cp=18, n_landmarks=64, obs_pairs=3, with_priors=21)
+    with ha.Problem(full, lib=oracle) as p:
+        S, g = p.reduced_system(1e4)
+        s = p.solve(5)
+        cp, lm = p.control_points(), p.landmarks()
+    ranks = run_workers(which, tmp_path)
+    for r in ranks:  # every rank holds the identical global reduced system and trajectory
+        assert rel(r["S"], S) < 1e-10 and rel(r["g"], g) < 1e-10
+        assert int(r["iters"]) == s["num_iterations"]
+        assert np.allclose(r["costs"], [it["cost"] for it in s["iterations"]], rtol=1e-7, atol=0)
+        assert rel(r["cp"], cp) < 1e-7
+    assert np.array_equal(ranks[0]["S"], ranks[1]["S"]) and np.array_equal(ranks[0]["cp"], ranks[1]["cp"])
+    for r in ranks:  # each rank owns the landmarks it observes
+        ids = r["lm_ids"]
+        assert rel(r["lm"][ids], lm[ids]) < 1e-7

@@ -1005,13 +1005,147 @@ int hs_get_gravity(hs_problem* p, double* g) {
   return HS_OK;
 }
 
-int hs_cost_function_evaluate(hs_problem* p, int, int, const double* const*, double*, double**) {
-  if (!p) return HS_ERR_INVALID;
-  HS_FAIL(HS_ERR_STATE, "hs_cost_function_evaluate: not available in this build yet");
+// Left inverse of EigenQuaternionManifold's PlusJacobian (orthonormal columns e_i (x) q): J_ambient = J_local * P^T.
+static void quat_plus_jacobian_T(const double* q, double* PT /* 3 x 4 */) {
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  // column i of P = (e_i, 0) (x) q  (Hamilton, xyzw)
+  const double P[4][3] = {{w, z, -y}, {-z, w, x}, {y, -x, w}, {-x, -y, -z}};
+  for (int i = 0; i < 3; ++i)
+    for (int r = 0; r < 4; ++r) PT[4 * i + r] = P[r][i];
 }
-int hs_sample_trajectory(hs_problem* p, int, const double*, double*, double*, double*) {
-  if (!p) return HS_ERR_INVALID;
-  HS_FAIL(HS_ERR_STATE, "hs_sample_trajectory: not available in this build yet");
+
+int hs_cost_function_evaluate(hs_problem* p, int type, int idx, const double* const* parameters, double* residuals, double** jacobians) {
+  if (!p || !parameters || !residuals) return HS_ERR_INVALID;
+  if (type < 0 || type > 3 || idx < 0 || idx >= hs_num_residuals(p, type)) HS_FAIL(HS_ERR_INVALID, "residual index out of range");
+  const int k = p->k, kb = p->kb;
+  const BlockLayout L = make_block_layout(type, k, kb);
+  // Jacobians w.r.t. sensor blocks are not produced: those blocks are constant in the reference (camera.hpp:18, imu.hpp:18,
+  // optimizer.cpp:59-64) and Ceres passes nullptr for constant blocks.
+  if (jacobians) {
+    const int s0 = L.indices[1], s1 = (type == HS_INERTIAL) ? L.indices[1] + 5 : L.indices[3];
+    for (int b = s0; b < s1; ++b)
+      if (jacobians[b]) HS_FAIL(HS_ERR_INVALID, "Jacobians w.r.t. sensor parameter blocks are not available (constant blocks in the reference)");
+  }
+  // one-residual window at the given parameter values
+  hs_problem* q = nullptr;
+  int rc = hs_create(p->device, p->stream, &q);
+  if (rc) HS_FAIL(rc, "temporary handle");
+  struct Guard {
+    hs_problem* q;
+    ~Guard() { hs_destroy(q); }
+  } guard{q};
+  std::vector<double> cps(size_t(8) * k);
+  for (int j = 0; j < k; ++j) std::memcpy(&cps[8 * j], parameters[j], 64);
+  const double t0 = cps[7], dt = cps[15] - cps[7];
+  rc = hs_set_spline(q, k, t0, dt, k, cps.data(), nullptr, 0, 0);
+  int32_t zero = 0;
+  double stamp = 0;
+  int nres = L.num_residuals;
+  if (!rc && (type == HS_PIXEL || type == HS_BEARING)) {
+    rc = hs_set_cameras(q, 1, parameters[k], parameters[k + 1], parameters[k + 2]);
+    if (!rc) rc = hs_set_landmarks(q, 1, parameters[k + 3], nullptr);
+    stamp = type == HS_PIXEL ? p->px_stamp[idx] : p->br_stamp[idx];
+    if (!rc) rc = type == HS_PIXEL ? hs_set_pixel_residuals(q, 1, &stamp, &p->px_meas[2 * idx], &zero, &zero)
+                                   : hs_set_bearing_residuals(q, 1, &stamp, &p->br_meas[3 * idx], &zero, &zero);
+  } else if (!rc && type == HS_PRIOR) {
+    rc = hs_set_sensors(q, 1, parameters[k]);
+    stamp = p->pr_stamp[idx];
+    if (!rc) rc = hs_set_prior_residuals(q, 1, &stamp, &p->pr_meas[7 * idx], &zero);
+  } else if (!rc) {
+    std::vector<double> bg(size_t(4) * kb), ba(size_t(4) * kb);
+    for (int j = 0; j < kb; ++j) std::memcpy(&bg[4 * j], parameters[k + 5 + j], 32), std::memcpy(&ba[4 * j], parameters[k + 5 + kb + j], 32);
+    rc = hs_set_imu(q, parameters[k], parameters[k + 1], parameters[k + 2], parameters[k + 3], parameters[k + 4], kb, bg[3], bg[7] - bg[3], kb,
+                    bg.data(), ba.data(), 0);
+    if (!rc) rc = hs_set_gravity(q, parameters[k + 5 + 2 * kb], 0);
+    stamp = p->in_stamp[idx];
+    if (!rc) rc = hs_set_inertial_residuals(q, 1, &stamp, &p->in_meas[6 * idx]);
+  }
+  if (rc) HS_FAIL(rc, std::string("hs_cost_function_evaluate: ") + hs_last_error(q));
+  std::vector<double> r(6), Js(size_t(6) * 6 * k), Jl(18), Jbg(size_t(18) * kb), Jba(size_t(18) * kb), Jg(12);
+  hs_linearization lin;
+  std::memset(&lin, 0, sizeof(lin));
+  lin.r = r.data(), lin.J_state = Js.data(), lin.J_landmark = Jl.data(), lin.J_bias_g = Jbg.data(), lin.J_bias_a = Jba.data(), lin.J_gravity = Jg.data();
+  rc = hs_linearize(q, type, /*robustify=*/0, &lin);
+  if (rc) HS_FAIL(rc, std::string("hs_cost_function_evaluate: ") + hs_last_error(q));
+  for (int i = 0; i < nres; ++i) residuals[i] = r[i];
+  if (!jacobians) return HS_OK;
+  for (int j = 0; j < k; ++j) {  // Stamped<SE3>: [q(4) p(3) t(1)], local [rot(3) trans(3)]
+    if (!jacobians[j]) continue;
+    double PT[12];
+    quat_plus_jacobian_T(parameters[j], PT);
+    for (int row = 0; row < nres; ++row) {
+      const double* jl = &Js[(size_t(row) * k + j) * 6];
+      double* out = jacobians[j] + size_t(row) * 8;
+      for (int c = 0; c < 4; ++c) out[c] = jl[0] * PT[c] + jl[1] * PT[4 + c] + jl[2] * PT[8 + c];
+      out[4] = jl[3], out[5] = jl[4], out[6] = jl[5], out[7] = 0.0;
+    }
+  }
+  if (type == HS_PIXEL || type == HS_BEARING) {
+    if (jacobians[k + 3])
+      for (int e = 0; e < nres * 3; ++e) jacobians[k + 3][e] = Jl[e];
+  } else if (type == HS_INERTIAL) {
+    for (int j = 0; j < kb; ++j)
+      for (int part = 0; part < 2; ++part) {
+        double* out = jacobians[k + 5 + part * kb + j];
+        if (!out) continue;
+        const std::vector<double>& J = part ? Jba : Jbg;
+        for (int row = 0; row < 6; ++row) {
+          for (int c = 0; c < 3; ++c) out[row * 4 + c] = J[(size_t(row) * kb + j) * 3 + c];
+          out[row * 4 + 3] = 0.0;
+        }
+      }
+    if (double* out = jacobians[k + 5 + 2 * kb]) {  // gravity: left inverse of the SphereManifold PlusJacobian = P^T / |x|^2
+      const double* x = parameters[k + 5 + 2 * kb];
+      // Householder basis as in Ceres (same code path as the device: recompute on the host)
+      double v[3] = {x[0], x[1], 1.0}, beta = 0.0;
+      const double sigma = x[0] * x[0] + x[1] * x[1];
+      if (sigma <= 2.220446049250313e-16) {
+        if (x[2] < 0) beta = 2.0;
+      } else {
+        const double mu = std::sqrt(x[2] * x[2] + sigma);
+        const double vp = (x[2] <= 0.0) ? (x[2] - mu) : (-sigma / (x[2] + mu));
+        beta = 2.0 * vp * vp / (sigma + vp * vp);
+        v[0] /= vp, v[1] /= vp;
+      }
+      const double nx2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2], nx = std::sqrt(nx2);
+      double P[6];
+      for (int i = 0; i < 2; ++i)
+        for (int rr = 0; rr < 3; ++rr) P[rr * 2 + i] = nx * ((rr == i ? 1.0 : 0.0) - beta * v[rr] * v[i]);
+      for (int row = 0; row < 6; ++row)
+        for (int c = 0; c < 3; ++c) out[row * 3 + c] = (Jg[row * 2] * P[c * 2] + Jg[row * 2 + 1] * P[c * 2 + 1]) / nx2;
+    }
+  }
+  return HS_OK;
+}
+
+int hs_sample_trajectory(hs_problem* p, int n, const double* stamps, double* pose, double* velocity, double* acceleration) {
+  if (!p || n < 0 || (n && (!stamps || !pose))) return HS_ERR_INVALID;
+  int rc = prepare(p);
+  if (rc) return rc;
+  if (n == 0) return HS_OK;
+  const int k = p->k, n_seg = p->n_cp - k + 1;
+  for (int i = 0; i < n; ++i) {
+    const int f = h_segment_first(stamps[i], p->t0, p->dt, k);
+    if (f < 0 || f >= n_seg) HS_FAIL(HS_ERR_INVALID, "stamp outside the valid range of the spline");
+  }
+  hipStream_t s = p->stream;
+  DBuf<double> d_st, d_pose, d_vel, d_acc;
+  std::vector<double> st(stamps, stamps + n);
+  HIP_TRY(d_st.upload(st, s));
+  HIP_TRY(d_pose.reserve(size_t(7) * n));
+  if (velocity) HIP_TRY(d_vel.reserve(size_t(6) * n));
+  if (acceleration) HIP_TRY(d_acc.reserve(size_t(6) * n));
+  const int nb = (n + kBlock - 1) / kBlock;
+  if (k == 4)
+    k_sample_trajectory<4><<<nb, kBlock, cp_lds_bytes(p), s>>>(p->T, n, d_st.p, d_pose.p, velocity ? d_vel.p : nullptr, acceleration ? d_acc.p : nullptr);
+  else
+    k_sample_trajectory<6><<<nb, kBlock, cp_lds_bytes(p), s>>>(p->T, n, d_st.p, d_pose.p, velocity ? d_vel.p : nullptr, acceleration ? d_acc.p : nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(pose, d_pose.p, size_t(7) * n * 8, hipMemcpyDeviceToHost, s));
+  if (velocity) HIP_TRY(hipMemcpyAsync(velocity, d_vel.p, size_t(6) * n * 8, hipMemcpyDeviceToHost, s));
+  if (acceleration) HIP_TRY(hipMemcpyAsync(acceleration, d_acc.p, size_t(6) * n * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return HS_OK;
 }
 
 }  // extern "C"

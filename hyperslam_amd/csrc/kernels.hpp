@@ -1308,6 +1308,27 @@ __global__ void __launch_bounds__(kBlock) k_commit(Tables T) {
   }
 }
 
+/// Batched trajectory sampling (state.evaluate(StateQuery{t, derivative}) loop of apps/hyperslam/main.cpp:72-79):
+/// pose n x 7, velocity / acceleration n x 6 [angular (body) ; linear (world)], nullable.
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_sample_trajectory(Tables T, int n, const double* stamps, double* pose, double* vel, double* acc) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* cps = smem;
+  stage_cps(T.cp, cps, 8 * T.sp.n_cp);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double u;
+  const int first = segment_of(stamps[i], T.sp.t0, T.sp.dt, K, &u);
+  double lam[K], dlam[K], ddlam[K];
+  basis_weights<K>(T.basis, u, T.sp.inv_dt, lam, dlam, ddlam, 2);
+  SplineFull<K> S;
+  spline_full<K, false>(cps + 8 * first, lam, dlam, ddlam, &S);
+  double* o = pose + 7 * i;
+  o[0] = S.q.x, o[1] = S.q.y, o[2] = S.q.z, o[3] = S.q.w, o[4] = S.p.x, o[5] = S.p.y, o[6] = S.p.z;
+  if (vel) vel[6 * i] = S.w.x, vel[6 * i + 1] = S.w.y, vel[6 * i + 2] = S.w.z, vel[6 * i + 3] = S.v.x, vel[6 * i + 4] = S.v.y, vel[6 * i + 5] = S.v.z;
+  if (acc) acc[6 * i] = S.al.x, acc[6 * i + 1] = S.al.y, acc[6 * i + 2] = S.al.z, acc[6 * i + 3] = S.a.x, acc[6 * i + 4] = S.a.y, acc[6 * i + 5] = S.a.z;
+}
+
 /// Fresh trust-region state (LevenbergMarquardtStrategy: initial radius 1e4, decrease factor 2).
 __global__ void k_reset_state(DevState* st, int max_iterations, double radius) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;

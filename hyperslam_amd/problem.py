@@ -199,6 +199,41 @@ class Problem:
         self._check(self.lib.linearize(self.h, ftype, int(robustify), C.byref(lin)), "linearize")
         return out
 
+    def parameter_blocks(self, ftype, idx):
+        """Values of the parameter blocks of residual idx in ExteroceptiveCost::update order (state || sensor || observation)."""
+        w, L = self.window, self.residual_layout(ftype, idx)
+        ids, k = L["block_ids"], w.order
+        blocks = [np.array(w.control_points[ids[j]], float) for j in range(k)]
+        if ftype in (HS_PIXEL, HS_BEARING):
+            c = ids[k]
+            blocks += [np.array(w.cam_T_bs[c], float), np.array(w.cam_intrinsics[c], float), np.array(w.cam_distortion[c], float),
+                       np.array(w.landmarks[ids[k + 3]], float)]
+        elif ftype == HS_PRIOR:
+            blocks.append(np.array(w.sensor_T_bs[ids[k]], float))
+        else:
+            m, kb = w.imu, int(w.imu["bias_order"])
+            blocks += [np.array(m[n], float) for n in ("T_bs", "i_g", "i_a", "S_g", "X_a")]
+            blocks += [np.array(m["bias_g"][ids[k + 5 + j]], float) for j in range(kb)]
+            blocks += [np.array(m["bias_a"][ids[k + 5 + kb + j]], float) for j in range(kb)]
+            blocks.append(np.array(w.gravity, float))
+        return blocks
+
+    def cost_function_evaluate(self, ftype, idx, blocks, want=None):
+        """ceres::CostFunction::Evaluate contract (exteroceptive.hpp:31): residuals + row-major per-block ambient Jacobians
+        (None where `want[i]` is False, like Ceres' nullptr for constant blocks)."""
+        L = self.residual_layout(ftype, idx)
+        nb, nres = L["num_blocks"], L["num_residuals"]
+        blocks = [np.ascontiguousarray(b, dtype=_f64) for b in blocks]
+        params = (_lib.c_double_p * nb)(*[_d(b) for b in blocks])
+        res = np.zeros(nres)
+        if want is None:
+            self._check(self.lib.cost_function_evaluate(self.h, ftype, idx, params, _d(res), None), "cost_function_evaluate")
+            return res, None
+        jac = [np.zeros((nres, int(L["sizes"][i]))) if want[i] else None for i in range(nb)]
+        jptr = (_lib.c_double_p * nb)(*[(_d(j) if j is not None else None) for j in jac])
+        self._check(self.lib.cost_function_evaluate(self.h, ftype, idx, params, _d(res), jptr), "cost_function_evaluate")
+        return res, jac
+
     def cost(self):
         c = C.c_double()
         self._check(self.lib.cost(self.h, C.byref(c)), "cost")

@@ -103,3 +103,50 @@ def test_hip_matches_golden(idx, hip):
         pytest.skip("inertial factor: see test_gpu_inertial.py")
     with ha.Problem(golden_window(case), lib=hip) as p:
         check_against_golden(p, case, 1e-9)
+
+
+def _quat_plus_jacobian(q):
+    x, y, z, w = q
+    return np.array([[w, z, -y], [-z, w, x], [y, -x, w], [-x, -y, -z]])  # columns e_i (x) q, rows (x, y, z, w)
+
+
+@pytest.mark.parametrize("ftype", [ha.HS_PIXEL, ha.HS_BEARING, ha.HS_PRIOR])
+def test_cost_function_evaluate_contract(ftype, hip, oracle):
+    """Ceres-style single-block entry (exteroceptive.hpp:31): residuals equal the oracle's; ambient Jacobians agree after
+    projection by the manifold's PlusJacobian (the ambient quaternion Jacobian is only defined up to its gauge)."""
+    w = synthetic.small_visual(order=4, n_cp=16, n_landmarks=20, obs_pairs=2, bearing=(ftype == ha.HS_BEARING), seed=12, with_priors=6)
+    with ha.Problem(w, lib=hip) as g, ha.Problem(w, lib=oracle) as c:
+        for idx in (0, 3):
+            blocks = g.parameter_blocks(ftype, idx)
+            # evaluate away from the stored values to show the entry point honours `parameters`
+            blocks[1] = blocks[1].copy()
+            blocks[1][4:7] += 0.01
+            n = len(blocks)
+            want = [i < 4 or (ftype != ha.HS_PRIOR and i == n - 1) for i in range(n)]
+            rg, Jg = g.cost_function_evaluate(ftype, idx, blocks, want)
+            rc, Jc = c.cost_function_evaluate(ftype, idx, blocks, want)
+            assert rel(rg, rc) < 1e-9
+            r0, _ = g.cost_function_evaluate(ftype, idx, blocks)
+            assert np.array_equal(r0, rg)
+            scale = max(np.abs(J).max() for J in Jc if J is not None)  # a block's weight can vanish (B_3 = u^3/6 at u -> 0)
+            for i in range(4):
+                P = np.zeros((8, 6))
+                P[:4, :3], P[4:7, 3:] = _quat_plus_jacobian(blocks[i][:4]), np.eye(3)
+                assert np.abs(Jg[i] @ P - Jc[i] @ P).max() < 1e-9 * scale
+                assert np.all(Jg[i][:, 7] == 0)
+            if ftype != ha.HS_PRIOR:
+                assert rel(Jg[-1], Jc[-1]) < 1e-9
+            with pytest.raises(ha.HsError):  # sensor blocks are constant in the reference: no Jacobian is produced for them
+                g.cost_function_evaluate(ftype, idx, blocks, [True] * n)
+
+
+def test_sample_trajectory(hip, oracle):
+    w = synthetic.small_visual(order=6, n_cp=24, n_landmarks=10, obs_pairs=2, seed=13)
+    lo, hi = w.valid_range()
+    st = np.linspace(lo, hi - 1e-6, 257)
+    with ha.Problem(w, lib=hip) as g, ha.Problem(w, lib=oracle) as c:
+        a, b = g.sample_trajectory(st, derivatives=True), c.sample_trajectory(st, derivatives=True)
+        for x, y in zip(a, b):
+            assert rel(x, y) < 1e-10
+        with pytest.raises(ha.HsError):
+            g.sample_trajectory([hi + 1.0])

@@ -83,7 +83,7 @@ struct hs_problem {
   DBuf<double> d_cp, d_cp_cand, d_cam, d_sensor, d_lm, d_lm_cand;
   DBuf<uint8_t> d_cp_const, d_lm_const;
   DBuf<int> d_lm_ptr, d_lm_cfirst, d_lm_ncp, d_lm_yoff, d_cf_ptr;
-  DBuf<double> d_lm_scale, d_lm_L, d_lm_yhat, d_lm_sb, d_lm_D2, d_lm_mcc, d_Y;
+  DBuf<double> d_lm_scale, d_lm_L, d_lm_yhat, d_lm_sb, d_lm_D2, d_lm_mcc, d_lm_gmax, d_gabs, d_Y;
   DBuf<double> d_v_stamp, d_v_meas, d_v_rec;
   DBuf<int> d_v_lm, d_v_info, d_v_first, d_v_pos, d_v_seg_ptr, d_v_dbgpos;
   DBuf<double> d_p_stamp, d_p_meas, d_p_rec;
@@ -245,12 +245,17 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_lm_yoff.upload(vs.lm_yoff, s));
   HIP_TRY(p->d_cf_ptr.upload(vs.cf_ptr, s));
   const size_t nl = size_t(std::max(p->n_lm, 1));
-  HIP_TRY(p->d_lm_scale.reserve(3 * nl));
+  {
+    std::vector<double> ones(3 * nl, 1.0);  // unobserved landmarks keep scale 1 (never visited by the landmark pass)
+    HIP_TRY(p->d_lm_scale.upload(ones, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
   HIP_TRY(p->d_lm_L.reserve(6 * nl));
   HIP_TRY(p->d_lm_yhat.reserve(3 * nl));
   HIP_TRY(p->d_lm_sb.reserve(3 * nl));
   HIP_TRY(p->d_lm_D2.reserve(3 * nl));
   HIP_TRY(p->d_lm_mcc.reserve(2 * nl));
+  HIP_TRY(p->d_lm_gmax.reserve(nl));
   HIP_TRY(p->d_Y.reserve(size_t(vs.y_total) + 1));
   HIP_TRY(p->d_v_stamp.upload(v_stamp, s));
   HIP_TRY(p->d_v_meas.upload(v_meas, s));
@@ -298,9 +303,11 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_g_s.reserve(np));
   HIP_TRY(p->d_g_full.reserve(np));
   HIP_TRY(p->d_D2p.reserve(np));
+  HIP_TRY(p->d_gabs.reserve(np + (p->has_imu ? 6 * p->n_bias + 2 : 0) + 1));
   HIP_TRY(p->d_step_p.reserve(np));
   HIP_TRY(p->d_delta_p.reserve(np));
-  p->nb_vis = (n_vis + kBlock - 1) / kBlock, p->nb_pri = (n_pri + kBlock - 1) / kBlock;
+  p->nb_vis = (n_vis + kBlock - 1) / kBlock;
+  p->nb_pri = (n_pri + kBlock - 1) / kBlock;
   p->nb_cp = std::max((p->n_cp + kBlock - 1) / kBlock, 1);
   HIP_TRY(p->d_cost_part.reserve(p->nb_vis + p->nb_pri + (n_ine + kBlock - 1) / kBlock + 1));
   HIP_TRY(p->d_cand_part.reserve(p->nb_vis + p->nb_pri + (n_ine + kBlock - 1) / kBlock + 1));
@@ -335,7 +342,12 @@ int prepare(hs_problem* p) {
   T.n_lm = p->n_lm, T.lm = p->d_lm.p, T.lm_cand = p->d_lm_cand.p, T.lm_const = p->d_lm_const.p;
   T.lm_ptr = p->d_lm_ptr.p, T.lm_cfirst = p->d_lm_cfirst.p, T.lm_ncp = p->d_lm_ncp.p, T.lm_yoff = p->d_lm_yoff.p, T.cf_ptr = p->d_cf_ptr.p;
   T.lm_scale = p->d_lm_scale.p, T.lm_L = p->d_lm_L.p, T.lm_yhat = p->d_lm_yhat.p, T.lm_sb = p->d_lm_sb.p, T.lm_D2 = p->d_lm_D2.p;
-  T.lm_mcc = p->d_lm_mcc.p, T.Y = p->d_Y.p;
+  T.lm_mcc = p->d_lm_mcc.p, T.lm_gmax = p->d_lm_gmax.p, T.Y = p->d_Y.p;
+  {
+    int n_obs = p->n_lm;
+    while (n_obs > 0 && vs.lm_ptr[n_obs] == vs.lm_ptr[n_obs - 1]) --n_obs;
+    T.n_obs_lm = n_obs;
+  }
   T.n_vis = n_vis, T.v_stamp = p->d_v_stamp.p, T.v_meas = p->d_v_meas.p, T.v_lm = p->d_v_lm.p, T.v_info = p->d_v_info.p;
   T.v_first = p->d_v_first.p, T.v_pos = p->d_v_pos.p, T.v_rec = p->d_v_rec.p, T.v_seg_ptr = p->d_v_seg_ptr.p;
   T.n_pri = n_pri, T.p_stamp = p->d_p_stamp.p, T.p_meas = p->d_p_meas.p, T.p_sensor = p->d_p_sensor.p, T.p_first = p->d_p_first.p;
@@ -347,7 +359,7 @@ int prepare(hs_problem* p) {
   T.gravity = p->d_gravity.p, T.gravity_cand = p->d_gravity_cand.p, T.bias_const = p->bias_const, T.gravity_const = p->gravity_const;
   T.nb = p->has_imu ? 6 * p->n_bias + 2 : 0;
   T.n_seg = n_seg, T.bw = vs.bw, T.np = np;
-  T.scale_p = p->d_scale_p.p, T.Sb = p->d_Sb.p, T.Ub = p->d_Ub.p, T.Ubk = p->d_Ubk.p, T.g_s = p->d_g_s.p, T.g_full = p->d_g_full.p, T.D2p = p->d_D2p.p;
+  T.scale_p = p->d_scale_p.p, T.Sb = p->d_Sb.p, T.Ub = p->d_Ub.p, T.Ubk = p->d_Ubk.p, T.g_s = p->d_g_s.p, T.g_full = p->d_g_full.p, T.D2p = p->d_D2p.p, T.gabs = p->d_gabs.p;
   T.step_p = p->d_step_p.p, T.delta_p = p->d_delta_p.p;
   T.cost_part = p->d_cost_part.p, T.cand_part = p->d_cand_part.p, T.n_cost_part = p->nb_vis + p->nb_pri + p->nb_ine;
   T.norm_part = p->d_norm_part.p, T.n_norm_part = nb_norm;
@@ -410,7 +422,7 @@ int launch_build(hs_problem* p) {
   if (rc) return rc;
   k_finalize_reduced<<<T.sp.n_cp, kBlock, 0, s>>>(T);
   if (T.nb) k_finalize_border<<<std::min(256, ((T.np + T.nb) * T.nb + kBlock - 1) / kBlock), kBlock, 0, s>>>(T);
-  k_cost_reduce<<<1, 64, 0, s>>>(T);
+  k_cost_reduce<<<1, kBlock, 0, s>>>(T);
   HIP_TRY(hipGetLastError());
   return HS_OK;
 }
@@ -780,7 +792,7 @@ int hs_cost(hs_problem* p, double* cost) {
   k_pack_exchange<<<1, kBlock, 0, p->stream>>>(p->T);
   rc = exchange(p, p->T.xbuf + p->T.xo_cost, 1);
   if (rc) return rc;
-  k_cost_reduce<<<1, 64, 0, p->stream>>>(p->T);
+  k_cost_reduce<<<1, kBlock, 0, p->stream>>>(p->T);
   HIP_TRY(hipGetLastError());
   DevState st;
   HIP_TRY(hipMemcpyAsync(&st, p->d_state.p, sizeof(st), hipMemcpyDeviceToHost, p->stream));
@@ -868,7 +880,7 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
     k_pack_exchange<<<1, kBlock, 0, s>>>(p->T);
     rc = exchange(p, p->T.xbuf + p->T.xo_cost, 1);
     if (rc) return rc;
-    k_cost_reduce<<<1, 64, 0, s>>>(p->T);
+    k_cost_reduce<<<1, kBlock, 0, s>>>(p->T);
   }
   DevState& st = *p->h_state;
   HIP_TRY(hipMemcpyAsync(&st, p->d_state.p, sizeof(st), hipMemcpyDeviceToHost, s));

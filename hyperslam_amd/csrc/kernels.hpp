@@ -177,6 +177,52 @@ __global__ void __launch_bounds__(kBlock) k_cost_prior(Tables T, const double* c
   if (threadIdx.x == 0) cost_part[blockIdx.x] = s;
 }
 
+/// Second half of the landmark pass (shared by k_landmark and the fused linearise kernel): given the wave-reduced H_ll, b_l and
+/// this lane's W rows, forms V = S_l H_ll S_l + D_l^2 = L L', stores L, y-hat, the scaled gradient and the Y-hat rows.
+HSD void landmark_finish(const Tables& T, int dl, int lane, bool active, bool fresh, double radius, const double* sl_old, int yoff, int rows,
+                         const double* h, const double* b, double (*w)[3]) {
+  double sl[3];
+  if (fresh) {
+    sl[0] = 1.0 / (1.0 + sqrt(h[0])), sl[1] = 1.0 / (1.0 + sqrt(h[3])), sl[2] = 1.0 / (1.0 + sqrt(h[5]));
+    if (lane < 3) T.lm_scale[3 * dl + lane] = sl[lane];
+  } else {
+    sl[0] = sl_old[0], sl[1] = sl_old[1], sl[2] = sl_old[2];
+  }
+  // V = S H S + clamp(diag)/radius
+  double v00 = sl[0] * sl[0] * h[0], v01 = sl[0] * sl[1] * h[1], v02 = sl[0] * sl[2] * h[2];
+  double v11 = sl[1] * sl[1] * h[3], v12 = sl[1] * sl[2] * h[4], v22 = sl[2] * sl[2] * h[5];
+  const double d0 = fmin(fmax(v00, 1e-6), 1e32) / radius, d1 = fmin(fmax(v11, 1e-6), 1e32) / radius, d2 = fmin(fmax(v22, 1e-6), 1e32) / radius;
+  v00 += d0, v11 += d1, v22 += d2;
+  // Cholesky V = L L'
+  const double l00 = sqrt(v00), l10 = v01 / l00, l20 = v02 / l00;
+  const double l11 = sqrt(v11 - l10 * l10), l21 = (v12 - l20 * l10) / l11;
+  const double l22 = sqrt(v22 - l20 * l20 - l21 * l21);
+  const double sb0 = sl[0] * b[0], sb1 = sl[1] * b[1], sb2 = sl[2] * b[2];
+  const double y0 = sb0 / l00, y1 = (sb1 - l10 * y0) / l11, y2 = (sb2 - l20 * y0 - l21 * y1) / l22;
+  if (lane == 0) {
+    double* L = T.lm_L + 6 * dl;
+    L[0] = l00, L[1] = l10, L[2] = l11, L[3] = l20, L[4] = l21, L[5] = l22;
+    T.lm_yhat[3 * dl] = active ? y0 : 0.0, T.lm_yhat[3 * dl + 1] = active ? y1 : 0.0, T.lm_yhat[3 * dl + 2] = active ? y2 : 0.0;
+    T.lm_sb[3 * dl] = sb0, T.lm_sb[3 * dl + 1] = sb1, T.lm_sb[3 * dl + 2] = sb2;
+    T.lm_D2[3 * dl] = d0, T.lm_D2[3 * dl + 1] = d1, T.lm_D2[3 * dl + 2] = d2;
+    // gradient max norm: per-landmark value, max-reduced by k_pack_exchange (thousands of atomics on one word would
+    // serialise at ~12 ns each and dominate this pass)
+    T.lm_gmax[dl] = active ? fmax(fabs(b[0]), fmax(fabs(b[1]), fabs(b[2]))) : 0.0;
+  }
+  // W rows -> Y-hat rows
+  double* Y = T.Y + yoff;
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    const int rho = lane + 64 * ps;
+    if (rho < rows) {
+      const double w0 = w[ps][0] * sl[0], w1 = w[ps][1] * sl[1], w2 = w[ps][2] * sl[2];
+      // y L' = w  (forward substitution on the columns of L')
+      const double a0 = w0 / l00, a1 = (w1 - a0 * l10) / l11, a2 = (w2 - a0 * l20 - a1 * l21) / l22;
+      Y[3 * rho] = active ? a0 : 0.0, Y[3 * rho + 1] = active ? a1 : 0.0, Y[3 * rho + 2] = active ? a2 : 0.0;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Landmark pass: one wave per landmark.  H_ll = sum Jl'Jl, b_l = sum Jl'r, W_l = sum Jp'Jl over the landmark's
 // residuals; V = S_l H_ll S_l + D_l^2 = L L';  Y-hat = W S_l L^-T (pose-side row scaling is applied by the consumer),
@@ -232,49 +278,10 @@ __global__ void __launch_bounds__(kBlock) k_landmark(Tables T) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) b[i] = wave_sum(b[i]);
 
-  const bool active = (q1 > q0) && !T.lm_const[dl];
-  double sl[3];
-  if (!T.st->scaling_ready) {
-    sl[0] = 1.0 / (1.0 + sqrt(h[0])), sl[1] = 1.0 / (1.0 + sqrt(h[3])), sl[2] = 1.0 / (1.0 + sqrt(h[5]));
-    if (lane < 3) T.lm_scale[3 * dl + lane] = sl[lane];
-  } else {
-    sl[0] = T.lm_scale[3 * dl], sl[1] = T.lm_scale[3 * dl + 1], sl[2] = T.lm_scale[3 * dl + 2];
-  }
-  const double radius = T.st->radius;
-  // V = S H S + clamp(diag)/radius
-  double v00 = sl[0] * sl[0] * h[0], v01 = sl[0] * sl[1] * h[1], v02 = sl[0] * sl[2] * h[2];
-  double v11 = sl[1] * sl[1] * h[3], v12 = sl[1] * sl[2] * h[4], v22 = sl[2] * sl[2] * h[5];
-  const double d0 = fmin(fmax(v00, 1e-6), 1e32) / radius, d1 = fmin(fmax(v11, 1e-6), 1e32) / radius, d2 = fmin(fmax(v22, 1e-6), 1e32) / radius;
-  v00 += d0, v11 += d1, v22 += d2;
-  // Cholesky V = L L'
-  const double l00 = sqrt(v00), l10 = v01 / l00, l20 = v02 / l00;
-  const double l11 = sqrt(v11 - l10 * l10), l21 = (v12 - l20 * l10) / l11;
-  const double l22 = sqrt(v22 - l20 * l20 - l21 * l21);
-  const double sb0 = sl[0] * b[0], sb1 = sl[1] * b[1], sb2 = sl[2] * b[2];
-  const double y0 = sb0 / l00, y1 = (sb1 - l10 * y0) / l11, y2 = (sb2 - l20 * y0 - l21 * y1) / l22;
-  if (lane == 0) {
-    double* L = T.lm_L + 6 * dl;
-    L[0] = l00, L[1] = l10, L[2] = l11, L[3] = l20, L[4] = l21, L[5] = l22;
-    T.lm_yhat[3 * dl] = active ? y0 : 0.0, T.lm_yhat[3 * dl + 1] = active ? y1 : 0.0, T.lm_yhat[3 * dl + 2] = active ? y2 : 0.0;
-    T.lm_sb[3 * dl] = sb0, T.lm_sb[3 * dl + 1] = sb1, T.lm_sb[3 * dl + 2] = sb2;
-    T.lm_D2[3 * dl] = d0, T.lm_D2[3 * dl + 1] = d1, T.lm_D2[3 * dl + 2] = d2;
-    if (active) {
-      const double gm = fmax(fabs(b[0]), fmax(fabs(b[1]), fabs(b[2])));
-      atomicMax(&T.st->gmax_bits, (unsigned long long)__double_as_longlong(gm));
-    }
-  }
-  // W rows -> Y-hat rows
-  double* Y = T.Y + T.lm_yoff[dl];
-#pragma unroll
-  for (int ps = 0; ps < 2; ++ps) {
-    const int rho = lane + 64 * ps;
-    if (rho < rows) {
-      const double w0 = w[ps][0] * sl[0], w1 = w[ps][1] * sl[1], w2 = w[ps][2] * sl[2];
-      // y L' = w  (forward substitution on the columns of L')
-      const double a0 = w0 / l00, a1 = (w1 - a0 * l10) / l11, a2 = (w2 - a0 * l20 - a1 * l21) / l22;
-      Y[3 * rho] = active ? a0 : 0.0, Y[3 * rho + 1] = active ? a1 : 0.0, Y[3 * rho + 2] = active ? a2 : 0.0;
-    }
-  }
+  const bool fresh = !T.st->scaling_ready;
+  double sl_old[3] = {1.0, 1.0, 1.0};
+  if (!fresh) sl_old[0] = T.lm_scale[3 * dl], sl_old[1] = T.lm_scale[3 * dl + 1], sl_old[2] = T.lm_scale[3 * dl + 2];
+  landmark_finish(T, dl, lane, (q1 > q0) && !T.lm_const[dl], fresh, T.st->radius, sl_old, T.lm_yoff[dl], rows, h, b, w);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -443,8 +450,16 @@ __global__ void __launch_bounds__(kBlock) k_pack_exchange(Tables T) {
   for (int i = threadIdx.x; i < T.n_cost_part; i += blockDim.x) s += T.cost_part[i];
   s = block_sum(s, red);
   if (threadIdx.x == 0) T.xbuf[T.xo_cost] = s;
-  for (int r = threadIdx.x; r < T.world; r += blockDim.x)
-    T.xbuf[T.xo_gmax + r] = (r == T.rank) ? __longlong_as_double((long long)st->gmax_bits) : 0.0;
+  double gm = 0.0;
+  for (int l = threadIdx.x; l < T.n_obs_lm; l += blockDim.x) gm = fmax(gm, T.lm_gmax[l]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) gm = fmax(gm, __shfl_xor(gm, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gm;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < int(blockDim.x >> 6); ++i) gm = fmax(gm, red[i]);
+    for (int r = 0; r < T.world; ++r) T.xbuf[T.xo_gmax + r] = (r == T.rank) ? gm : 0.0;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -613,7 +628,7 @@ __global__ void __launch_bounds__(kBlock) k_finalize_border(Tables T) {
         const double g = X[T.xo_gb + b];
         T.gb_s[b] = sr * g;
         if (fresh) T.scale_b[b] = sr;
-        atomicMax(&st->gmax_pose_bits, (unsigned long long)__double_as_longlong(fabs(g)));
+        T.gabs[T.np + b] = fabs(g);
       }
       T.Sbb[size_t(b) * nb + c] = out;
     }
@@ -785,7 +800,7 @@ __global__ void __launch_bounds__(kBlock) k_finalize_reduced(Tables T) {
     T.g_full[rho] = sr * gp;
     T.g_s[rho] = sr * (gp + X[T.xo_gs + rho]);
     if (fresh) T.scale_p[rho] = sr;
-    atomicMax(&st->gmax_pose_bits, (unsigned long long)__double_as_longlong(fabs(gp)));
+    T.gabs[rho] = fabs(gp);
   }
 }
 
@@ -1189,10 +1204,18 @@ HSD double ordered_sum(const double* p, int n, double* lds) {
 
 __global__ void __launch_bounds__(kBlock) k_cost_reduce(Tables T) {
   // (global) cost of the current linearisation point -> st->cost, gradient max norm -> st->gmax; iteration bookkeeping
+  __shared__ double red[kBlock / 64];
   DevState* st = T.st;
-  if (st->done || threadIdx.x != 0) return;
+  if (st->done) return;
+  double gm = 0.0;
+  for (int e = threadIdx.x; e < T.np + T.nb; e += blockDim.x) gm = fmax(gm, T.gabs[e]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) gm = fmax(gm, __shfl_xor(gm, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gm;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  for (int i = 1; i < int(blockDim.x >> 6); ++i) gm = fmax(gm, red[i]);
   const double c = T.xbuf[T.xo_cost];
-  double gm = __longlong_as_double((long long)st->gmax_pose_bits);
   for (int r = 0; r < T.world; ++r) gm = fmax(gm, T.xbuf[T.xo_gmax + r]);
   st->cost = c;
   st->gmax = gm;

@@ -83,6 +83,8 @@ struct Tables {
   double* lm_sb;           // n_lm x 3  s_l o b_l
   double* lm_D2;           // n_lm x 3  LM diagonal
   double* lm_mcc;          // n_lm x 2  per-landmark (g.step, step D2 step) terms
+  double* lm_gmax;         // n_lm      per-landmark max |b_l| (gradient max norm)
+  int n_obs_lm;            // observed landmarks (device order puts unobserved ones last)
   double* Y;               // concatenated Y-hat (6 n_l x 3 per landmark)
   // visual residuals (landmark-major)
   int n_vis;
@@ -133,6 +135,7 @@ struct Tables {
   double* g_s;             // np  reduced scaled gradient
   double* g_full;          // np  scaled full gradient s_p o g_p
   double* D2p;             // np  LM diagonal (pose side)
+  double* gabs;            // np + nb  |unscaled gradient| (max-reduced into the gradient tolerance test)
   double* step_p;          // np  scaled step
   double* delta_p;         // np  unscaled step (tangent update)
   double* ybuf;            // np  y = U^-T g (forward-solved right-hand side)

@@ -47,6 +47,17 @@ def cpu_baseline(window, budget_s=20.0):
             "sample": f"{runs} x optimize() ({LM_ITERATIONS} LM iterations) of the full workload on 1 host thread; own C++ restatement, not Ceres"}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            k = json.load(f)["kernels"][kernel]
+        return 1024.0 * (k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"])
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,12 +77,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if os.environ.get("HS_DIST_BACKEND", "nccl") != "nccl":
+        local_rank = 0  # all ranks share GPU 0 (path test only)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("HS_DIST_BACKEND", "nccl")  # "gloo" only to exercise the N > 1 path on a 1-GPU box
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     # weak scaling: world x configs[1]; landmarks l with l % world == rank live on this rank
     full = synthetic.config1(n_cp=128, n_landmarks=5000 * world, obs_pairs=5)
@@ -106,7 +123,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -128,9 +145,14 @@ def main():
                        "lm_iterations_per_step": LM_ITERATIONS, "parallelism": f"residual-sharded x{world}" if world > 1 else "single GPU"},
             "final_cost": s["final_cost"], "initial_cost": s["initial_cost"],
             "device_ms_per_iteration": {k: v / n_lin for k, v in stage.items()},
-            "roofline": {"kernel": "k_linearize_visual<4>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": B_ALG_PIXEL_K4 * n_blocks_local, "avg_launch_ms": lin_ms},
+            # roofline of the kernel SURVEY.md §8(d)'s B_alg is defined for (linearisation: 480 B per pixel residual block); its
+            # launch time is measured with HIP events on the launch stream inside hs_solve. The factorisation kernel that
+            # dominates the iteration time is a single-workgroup dependency chain (latency-bound, no meaningful roofline); its
+            # share is visible in device_ms_per_iteration["solve_ms"].
+            "roofline": {"kernel": "hs::k_linearize_visual<4>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("hs::k_linearize_visual<4>"),
+                         "algorithmic_bytes_per_launch": B_ALG_PIXEL_K4 * n_blocks_local, "avg_launch_ms": lin_ms,
+                         "note": "traffic = FETCH_SIZE + WRITE_SIZE of profiles/r01_pmc_hbm_traffic.json (separate rocprofv3 --pmc passes)"},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(full if world == 1 else window)

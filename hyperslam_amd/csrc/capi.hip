@@ -144,7 +144,7 @@ int prepare(hs_problem* p) {
   if (!build_visual_structure(in, &p->vs, &p->err)) return HS_ERR_INVALID;
   p->vs.bw = std::max(p->vs.bw, p->min_bw);
   const VisualStructure& vs = p->vs;
-  if (6 * vs.bw > kBlock || vs.bw * vs.bw > 2 * kCholThreads || size_t(12) * (6 * vs.bw + 2) * 8 + size_t(12) * p->n_cp * 8 > size_t(p->chol_lds_max) ||
+  if (6 * vs.bw > kBlock || vs.bw * vs.bw > 2 * kCholThreads || size_t(24) * (6 * vs.bw + 2) * 8 + size_t(12) * p->n_cp * 8 > size_t(p->chol_lds_max) ||
       size_t(12) * p->n_cp * 8 > 60 * 1024)
     HS_FAIL(HS_ERR_INVALID, "landmark tracks span too many control points for the LDS-resident banded factorisation");
   const int n_vis = n_px + n_br;
@@ -431,11 +431,11 @@ int launch_factor(hs_problem* p) {
   const Tables& T = p->T;
   hipStream_t s = p->stream;
   const int ncb = 6 * T.bw;
-  const size_t chol_lds = (size_t(12) * (ncb + 2) + size_t(T.np)) * sizeof(double);
+  const size_t chol_lds = (size_t(24) * (ncb + 2) + size_t(T.np)) * sizeof(double);
   if (T.bw * T.bw <= kCholThreads)
-    k_band_factor<1><<<1, kCholThreads, chol_lds, s>>>(T);
+    k_band_factor<1><<<1, kCholThreads + kCholIo, chol_lds, s>>>(T);
   else
-    k_band_factor<2><<<1, kCholThreads, chol_lds, s>>>(T);
+    k_band_factor<2><<<1, kCholThreads + kCholIo, chol_lds, s>>>(T);
   if (T.nb) {  // bordered system (bias splines + gravity)
     k_border_forward<<<(T.nb + kBorderCols - 1) / kBorderCols, 128, size_t(T.np) * kBorderCols * sizeof(double), s>>>(T);
     k_border_schur<<<T.nb, kBlock, 0, s>>>(T);

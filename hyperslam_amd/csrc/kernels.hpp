@@ -824,8 +824,10 @@ __global__ void __launch_bounds__(kBlock) k_finalize_reduced(Tables T) {
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kCholThreads = 256;
 
+constexpr int kCholIo = 128;  // two extra waves that own all global traffic of the factorisation (loader, storer)
+
 template <int TPT>  // tiles per thread: bw * bw <= TPT * kCholThreads
-__global__ void __launch_bounds__(kCholThreads) k_band_factor(Tables T) {
+__global__ void __launch_bounds__(kCholThreads + kCholIo) k_band_factor(Tables T) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   DevState* st = T.st;
   if (st->done) return;
@@ -835,9 +837,75 @@ __global__ void __launch_bounds__(kCholThreads) k_band_factor(Tables T) {
   const int n_blk = T.np / 6;
   double* rowbuf = smem;            // 6 x ld : pivot row as published by its owners [band | rhs | pad]
   double* xbuf = smem + 6 * ld;     // 6 x ld : [U_ii | X | y_i]
-  double* xs = smem + 12 * ld;      // np : y (forward solve)
+  double* stage = smem + 12 * ld;   // 2 x 6 x ld : block rows i + bw (+1) staged by the IO wave ahead of their use
+  double* xs = smem + 24 * ld;      // np : y (forward solve)
   __shared__ int fail;
   if (tid == 0) fail = 0;
+  const bool io = tid >= nthr;  // the IO wave streams S rows in (global -> registers -> LDS stage) and factor rows out
+  constexpr int kIoEnt = 12;    // entries per IO lane per block row: 6 * (6 * 21 + 1) = 762 <= 12 * 64
+  const int n_ent = 6 * (ncb + 1);
+  if (io) {  // ============ IO waves: a loader (wave 4) and a storer (wave 5); neither ever blocks the compute waves' math ============
+    // Two separate waves because vmcnt is one in-order counter per wave: a wave that both loads and stores would wait for its
+    // own (slow, just-issued) stores whenever it needs a prefetched load.
+    const int l = (tid - nthr) & 63;
+    const bool loader = tid < nthr + 64;
+    // loop-invariant addressing of this lane's entries of a block row (no integer divisions inside the step loop)
+    const double* e_base[kIoEnt];
+    int e_stride[kIoEnt], e_lds[kIoEnt], e_dst[kIoEnt];
+#pragma unroll
+    for (int m = 0; m < kIoEnt; ++m) {
+      const int e = l + m * 64;
+      const bool ok = e < n_ent;
+      const int a = ok ? e / (ncb + 1) : 0, c = ok ? e % (ncb + 1) : 0;
+      e_lds[m] = ok ? a * ld + c : -1;
+      e_base[m] = c < ncb ? T.Sb + a * ncb + c : T.g_s + a;
+      e_stride[m] = c < ncb ? 6 * ncb : 6;
+      e_dst[m] = c < ncb ? a * ncb + c : -1 - a;  // offset in the Ub block row, or -(1 + a): y entry
+    }
+    if (loader) {
+      double v[kIoEnt];
+      auto fetch = [&](int r) {
+        const int rr = r < n_blk ? r : 0;
+#pragma unroll
+        for (int m = 0; m < kIoEnt; ++m) v[m] = (e_lds[m] >= 0 && r < n_blk) ? e_base[m][size_t(rr) * e_stride[m]] : 0.0;
+      };
+      auto put = [&](int r) {
+        double* dst = stage + (r & 1) * 6 * ld;
+#pragma unroll
+        for (int m = 0; m < kIoEnt; ++m)
+          if (e_lds[m] >= 0) dst[e_lds[m]] = v[m];
+      };
+      fetch(bw), put(bw), fetch(bw + 1);
+      lds_barrier();  // initial window loaded / staged
+      for (int i = 0; i < n_blk; ++i) {
+        lds_barrier();  // B1
+        put(i + bw + 1);
+        fetch(i + bw + 2);
+        lds_barrier();  // B2
+      }
+      lds_barrier();
+    } else {
+      lds_barrier();
+      for (int i = 0; i < n_blk; ++i) {
+        lds_barrier();  // B1
+        lds_barrier();  // B2: xbuf = [U_ii | X | y_i] is complete
+        double* Urow = T.Ub + size_t(6) * i * ncb;
+#pragma unroll
+        for (int m = 0; m < kIoEnt; ++m) {
+          if (e_lds[m] < 0) continue;
+          const double x = xbuf[e_lds[m]];
+          if (e_dst[m] >= 0)
+            Urow[e_dst[m]] = x;
+          else
+            xs[6 * i + (-1 - e_dst[m])] = x;
+        }
+      }
+      lds_barrier();
+      for (int rho = l; rho < T.np; rho += 64) T.ybuf[rho] = xs[rho];  // y = U^-T g
+      if (l == 0) st->chol_failed = fail;
+    }
+    return;
+  }
 
   // ---- static tile ownership ------------------------------------------------------------------------------------
   int t_slot[TPT], t_kk[TPT];
@@ -862,14 +930,19 @@ __global__ void __launch_bounds__(kCholThreads) k_band_factor(Tables T) {
   };
 #pragma unroll
   for (int m = 0; m < TPT; ++m) load_tile(m, t_slot[m]);
-  // streamed-out factor row: entries e = tid + m * nthr of the 6 x ncb row block
-  int o_a[3], o_c[3];
+  auto refill_tile = [&](int m, int r) {  // block row r from the LDS stage written by the IO wave (no global access here)
+    const double* src = stage + (r & 1) * 6 * ld;
 #pragma unroll
-  for (int m = 0; m < 3; ++m) {
-    const int e = tid + m * nthr;
-    o_a[m] = e < 6 * ncb ? e / ncb : -1;
-    o_c[m] = e < 6 * ncb ? e % ncb : 0;
-  }
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+      for (int c = 0; c < 6; c += 2) {
+        const double2 v = *reinterpret_cast<const double2*>(&src[a * ld + 6 * t_kk[m] + c]);
+        acc[m][6 * a + c] = v.x, acc[m][6 * a + c + 1] = v.y;
+      }
+      rhs[m][a] = t_kk[m] == 0 ? src[a * ld + ncb] : 0.0;
+    }
+  };
+  lds_barrier();  // initial window loaded / staged
   const bool prof = (T.debug_flags & 16) && tid == 0;
   long long* tlog = reinterpret_cast<long long*>(T.xpart);
 
@@ -888,7 +961,7 @@ __global__ void __launch_bounds__(kCholThreads) k_band_factor(Tables T) {
             *reinterpret_cast<double2*>(&rowbuf[a * ld + 6 * t_kk[m] + c]) = make_double2(acc[m][6 * a + c], acc[m][6 * a + c + 1]);
           if (t_kk[m] == 0) rowbuf[a * ld + ncb] = rhs[m][a];
         }
-        load_tile(m, i + bw);
+        refill_tile(m, i + bw);
       }
     lds_barrier();
     if (prof) tlog[8 * i + 1] = wall_clock64();
@@ -908,9 +981,15 @@ __global__ void __launch_bounds__(kCholThreads) k_band_factor(Tables T) {
 #pragma unroll
       for (int k = 0; k < a; ++k) d = fma(-U[UIDX(k, a)], U[UIDX(k, a)], d);
       if (!(d > 0.0)) bad = true, d = 1.0;
-      const double r = rsqrt(d);
+      // hardware estimate + two Newton steps (full double precision; the library rsqrt's scaling / special cases are not needed
+      // for a positive, well-scaled pivot) and a final correction of the square root
+      double r = __builtin_amdgcn_rsq(d);
+      r = r * fma(-0.5 * d * r, r, 1.5);
+      r = r * fma(-0.5 * d * r, r, 1.5);
+      double u = d * r;
+      u = fma(0.5 * r, fma(-u, u, d), u);
       inv[a] = r;
-      U[UIDX(a, a)] = d * r;
+      U[UIDX(a, a)] = u;
 #pragma unroll
       for (int c = a + 1; c < 6; ++c) {
         double v = U[UIDX(a, c)];
@@ -942,7 +1021,10 @@ __global__ void __launch_bounds__(kCholThreads) k_band_factor(Tables T) {
           if (aa == a && cc == c) v = U[UIDX(aa, cc)];
       xbuf[a * ld + c] = v;
     }
-    if (tid == nthr - 37) {  // W = U_ii^-1 (upper triangular) for the backward sweep: x_i = W y_i, no divisions there
+    lds_barrier();
+    if (prof) tlog[8 * i + 2] = wall_clock64();
+    // off the critical path (after the barrier): one otherwise idle lane inverts the factored diagonal block
+    if (tid == nthr - 1) {  // W = U_ii^-1 (upper triangular) for the backward sweep: x_i = W y_i, no divisions there
       double W[21];
 #pragma unroll
       for (int c = 5; c >= 0; --c) {
@@ -958,8 +1040,6 @@ __global__ void __launch_bounds__(kCholThreads) k_band_factor(Tables T) {
 #pragma unroll
       for (int e = 0; e < 21; ++e) T.Ubk[size_t(i) * 24 + e] = W[e];
     }
-    lds_barrier();
-    if (prof) tlog[8 * i + 2] = wall_clock64();
     // ---- P2: rank-6 update of the register tiles ----
 #pragma unroll
     for (int m = 0; m < TPT; ++m) {
@@ -988,17 +1068,10 @@ __global__ void __launch_bounds__(kCholThreads) k_band_factor(Tables T) {
       }
     }
     if (prof) tlog[8 * i + 3] = wall_clock64();
-    // ---- stream the factor row out ----
-#pragma unroll
-    for (int m = 0; m < 3; ++m)
-      if (o_a[m] >= 0) T.Ub[size_t(6 * i + o_a[m]) * ncb + o_c[m]] = xbuf[o_a[m] * ld + o_c[m]];
-    if (tid < 6) xs[6 * i + tid] = xbuf[tid * ld + ncb];
     if (prof) tlog[8 * i + 4] = wall_clock64();
   }
 #undef UIDX
   lds_barrier();
-  for (int rho = tid; rho < T.np; rho += nthr) T.ybuf[rho] = xs[rho];  // y = U^-T g, input of the (bordered) backward sweep
-  if (tid == 0) st->chol_failed = fail;
 }
 
 /// Backward sweep U x = y (y in T.ybuf, possibly corrected by the border solve) + step outputs and model-cost reductions.

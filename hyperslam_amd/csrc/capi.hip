@@ -306,7 +306,8 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_gabs.reserve(np + (p->has_imu ? 6 * p->n_bias + 2 : 0) + 1));
   HIP_TRY(p->d_step_p.reserve(np));
   HIP_TRY(p->d_delta_p.reserve(np));
-  p->nb_vis = (n_vis + kBlock - 1) / kBlock;
+  const int vis_block = k == 4 ? lin_block<4>() : lin_block<6>();
+  p->nb_vis = (n_vis + vis_block - 1) / vis_block;
   p->nb_pri = (n_pri + kBlock - 1) / kBlock;
   p->nb_cp = std::max((p->n_cp + kBlock - 1) / kBlock, 1);
   HIP_TRY(p->d_cost_part.reserve(p->nb_vis + p->nb_pri + (n_ine + kBlock - 1) / kBlock + 1));
@@ -331,6 +332,10 @@ int prepare(hs_problem* p) {
   // split the accumulation over enough workgroups to fill the chip (256 CUs x a few workgroups)
   p->n_split = std::max(1, std::min(16, 2048 / std::max(p->n_cp, 1)));
   HIP_TRY(p->d_xpart.reserve(size_t(x_count1) * p->n_split));
+  for (int i = 0; i < p->n_cp; ++i) {
+    const int cover = vs.cf_ptr[i + 1] - vs.cf_ptr[std::max(0, i - vs.bw + 1)];
+    if ((cover + p->n_split - 1) / p->n_split > kMaxMine) HS_FAIL(HS_ERR_INVALID, "too many landmarks cover one control point for the reduced-system gather");
+  }
   HIP_TRY(p->d_state.reserve(1));
 
   Tables& T = p->T;
@@ -385,12 +390,16 @@ int reset_state(hs_problem* p, int max_iterations, double radius) {
 }
 
 size_t cp_lds_bytes(const hs_problem* p) { return size_t(8) * p->n_cp * sizeof(double); }
+template <int K>
+size_t lin_lds_bytes(const hs_problem* p) {  // control points + one record slab per wave
+  return (cp_lds_bytes(p) <= 24 * 1024 ? cp_lds_bytes(p) : 0) + size_t(lin_block<K>()) * (8 + 12 * K + 2) * sizeof(double);
+}
 
 template <int K>
 int launch_linearize(hs_problem* p) {
   const Tables& T = p->T;
   hipStream_t s = p->stream;
-  if (T.n_vis) k_linearize_visual<K><<<p->nb_vis, kBlock, cp_lds_bytes(p), s>>>(T, T.v_rec, T.v_pos, 1, T.cost_part, nullptr);
+  if (T.n_vis) k_linearize_visual<K><<<p->nb_vis, lin_block<K>(), lin_lds_bytes<K>(p), s>>>(T, T.v_rec, T.v_pos, 1, T.cost_part, nullptr);
   if (T.n_pri) k_linearize_prior<K><<<p->nb_pri, kBlock, cp_lds_bytes(p), s>>>(T, T.p_rec, T.cost_part + p->nb_vis, nullptr);
   if (T.n_ine) k_linearize_inertial<K, 4><<<p->nb_ine, kBlock, cp_lds_bytes(p), s>>>(T, T.i_rec, 1, T.cost_part + p->nb_vis + p->nb_pri, nullptr);
   HIP_TRY(hipGetLastError());
@@ -408,7 +417,7 @@ int launch_build(hs_problem* p) {
   const Tables& T = p->T;
   hipStream_t s = p->stream;
   if (T.n_lm) k_landmark<K><<<(T.n_lm + kBlock / 64 - 1) / (kBlock / 64), kBlock, 0, s>>>(T);
-  const size_t lds = (size_t(6) * 6 * T.bw + 16 + 6 * kBlock + 64) * sizeof(double);
+  const size_t lds = (size_t(6) * 6 * T.bw + 16 + 6 * kBlock + 64) * sizeof(double) + 3 * kMaxMine * sizeof(int);
   k_build_raw<K><<<dim3(T.sp.n_cp, p->n_split), kBlock, lds, s>>>(T);
   if (T.nb) {
     k_border_pb<K><<<dim3(T.sp.n_cp, p->n_split), 128, 0, s>>>(T);
@@ -475,6 +484,8 @@ int set_func_attributes(hs_problem* p) {
   p->chol_lds_max = 160 * 1024 - int(fa.sharedSizeBytes);
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor<1>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor<2>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_visual<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_visual<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_forward), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   return HS_OK;
@@ -696,9 +707,9 @@ int hs_linearize(hs_problem* p, int type, int robustify, const hs_linearization*
     HIP_TRY(p->d_dbg.reserve(size_t(n) * REC));
     HIP_TRY(p->d_dbg_cost.reserve(n));
     if (k == 4)
-      k_linearize_visual<4><<<p->nb_vis, kBlock, cp_lds_bytes(p), s>>>(T, p->d_dbg.p, p->d_v_dbgpos.p, robustify, nullptr, p->d_dbg_cost.p);
+      k_linearize_visual<4><<<p->nb_vis, lin_block<4>(), lin_lds_bytes<4>(p), s>>>(T, p->d_dbg.p, p->d_v_dbgpos.p, robustify, nullptr, p->d_dbg_cost.p);
     else
-      k_linearize_visual<6><<<p->nb_vis, kBlock, cp_lds_bytes(p), s>>>(T, p->d_dbg.p, p->d_v_dbgpos.p, robustify, nullptr, p->d_dbg_cost.p);
+      k_linearize_visual<6><<<p->nb_vis, lin_block<6>(), lin_lds_bytes<6>(p), s>>>(T, p->d_dbg.p, p->d_v_dbgpos.p, robustify, nullptr, p->d_dbg_cost.p);
     HIP_TRY(hipGetLastError());
     std::vector<double> rec(size_t(n) * REC), cost(n);
     HIP_TRY(hipMemcpyAsync(rec.data(), p->d_dbg.p, rec.size() * 8, hipMemcpyDeviceToHost, s));

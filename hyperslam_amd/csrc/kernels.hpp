@@ -17,6 +17,7 @@
 namespace hs {
 
 constexpr int kBlock = 256;
+constexpr int kMaxMine = 1024;  // landmarks one reduced-system workgroup may own (checked by the host)
 
 HSD double wave_sum(double v) {
 #pragma unroll
@@ -50,28 +51,49 @@ HSD void stage_cps(const double* __restrict__ src, double* dst, int n_doubles) {
 // Linearisation
 // ---------------------------------------------------------------------------------------------------------------------
 /// out_rec/out_pos: where the record of residual q goes (solver: T.v_rec at T.v_pos[q]; debug export: table order).
+/// Records are transposed through a per-wave LDS slab so that the scattered 448-byte (k = 4) records leave the CU as full
+/// 16-byte-per-lane stores (7 cache lines per record instead of 56 partial-line writes).
 template <int K>
-__global__ void __launch_bounds__(kBlock) k_linearize_visual(Tables T, double* out_rec, const int* out_pos, int robustify, double* cost_part,
-                                                            double* cost_each) {
+constexpr int lin_block() { return K <= 4 ? 256 : 128; }  // 2 waves at k = 6: the record slab is 42 KB per wave
+
+template <int K>
+__global__ void __launch_bounds__(lin_block<K>()) k_linearize_visual(Tables T, double* out_rec, const int* out_pos, int robustify,
+                                                                     double* cost_part, double* cost_each) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (T.st->done) return;
-  double* cps = smem;
-  stage_cps(T.cp, cps, 8 * T.sp.n_cp);
-  __shared__ double red[kBlock / 64];
+  constexpr int REC = 8 + 12 * K, LREC = REC + 2, NCH = REC / 2;  // LDS record stride (16-byte aligned, bank-spread), 16-B chunks
+  constexpr int NW = lin_block<K>() / 64;
+  // control points: LDS copy when it fits next to the record slabs, otherwise straight from L2 (long windows)
+  const bool cps_in_lds = size_t(8) * T.sp.n_cp * sizeof(double) <= 24 * 1024;
+  const double* cps = cps_in_lds ? smem : T.cp;
+  double* slab = smem + (cps_in_lds ? 8 * T.sp.n_cp : 0) + (threadIdx.x >> 6) * 64 * LREC;  // this wave's 64 records
+  if (cps_in_lds) stage_cps(T.cp, smem, 8 * T.sp.n_cp);
+  __shared__ double red[NW];
+  __shared__ int slots[NW * 64];
+  const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   double cost = 0.0;
+  int slot = -1;
   if (q < T.n_vis) {
     VisualOut<K> o;
     visual_linearize<K>(T, cps, q, robustify != 0, &o);
     cost = o.cost;
-    constexpr int REC = 8 + 12 * K;
-    double* rec = out_rec + size_t(out_pos[q]) * REC;
-    rec[0] = o.r[0], rec[1] = o.r[1];
+    slot = out_pos[q];
+    double* rec = slab + lane * LREC;
+    *reinterpret_cast<double2*>(rec) = make_double2(o.r[0], o.r[1]);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) rec[2 + i] = o.Jl[i];
+    for (int i = 0; i < 6; i += 2) *reinterpret_cast<double2*>(rec + 2 + i) = make_double2(o.Jl[i], o.Jl[i + 1]);
 #pragma unroll
-    for (int i = 0; i < 12 * K; ++i) rec[8 + i] = o.Jp[i];
-    if (cost_each) cost_each[out_pos[q]] = cost;
+    for (int i = 0; i < 12 * K; i += 2) *reinterpret_cast<double2*>(rec + 8 + i) = make_double2(o.Jp[i], o.Jp[i + 1]);
+    if (cost_each) cost_each[slot] = cost;
+  }
+  slots[threadIdx.x] = slot;
+  __builtin_amdgcn_wave_barrier();  // LDS is in-order within a wave: the slab written above is visible to the reads below
+  const int* wslots = slots + (threadIdx.x & ~63);
+  for (int g = lane; g < 64 * NCH; g += 64) {
+    const int r = g / NCH, c = g % NCH;
+    const int sl = wslots[r];
+    if (sl >= 0) *reinterpret_cast<double2*>(out_rec + size_t(sl) * REC + 2 * c) = *reinterpret_cast<const double2*>(slab + r * LREC + 2 * c);
   }
   const double s = block_sum(cost, red);
   if (threadIdx.x == 0 && cost_part) cost_part[blockIdx.x] = s;
@@ -312,7 +334,7 @@ __global__ void __launch_bounds__(kBlock) k_build_raw(Tables T) {
     const int grp = tid / NCA, col = tid % NCA;
     double acc[6] = {0, 0, 0, 0, 0, 0}, gsum = 0.0;
     if (grp < GA) {
-      const int f0 = max(0, i - K + 1), f1 = min(i, T.n_seg - 1);
+      const int f0 = max(0, i - K + 1), f1 = (T.debug_flags & 64) ? -1 : min(i, T.n_seg - 1);
       for (int first = f0; first <= f1; ++first) {
         const int ao = 6 * (i - first);
         const int cidx = ao + col;
@@ -383,22 +405,49 @@ __global__ void __launch_bounds__(kBlock) k_build_raw(Tables T) {
     const int gb = kBlock / ncb;
     const int grp = tid / ncb, col = tid % ncb;
     const int dl0 = T.cf_ptr[max(0, i - T.bw + 1)], dl1 = T.cf_ptr[i + 1];
+    // this workgroup's landmarks: dl = dl0 + sp + t * nsp; metadata fetched once, coalesced, into LDS
+    const int n_mine = (T.debug_flags & 128) ? 0 : (dl1 > dl0 + sp ? (dl1 - dl0 - sp + nsp - 1) / nsp : 0);
+    int* m_off = reinterpret_cast<int*>(red + 6 * kBlock + 64);
+    int* m_rows = m_off + kMaxMine;
+    int* m_y = m_rows + kMaxMine;
+    for (int t = tid; t < n_mine; t += kBlock) {
+      const int dl = dl0 + sp + t * nsp;
+      const int off = i - T.lm_cfirst[dl];
+      m_off[t] = off, m_rows[t] = 6 * T.lm_ncp[dl], m_y[t] = T.lm_yoff[dl] + 18 * off;
+    }
+    __syncthreads();
     double acc[6] = {0, 0, 0, 0, 0, 0}, gsum = 0.0;
     if (grp < gb) {
-#pragma unroll 4
-      for (int dl = dl0 + grp * nsp + sp; dl < dl1; dl += gb * nsp) {
-        const int off = i - T.lm_cfirst[dl], rows = 6 * T.lm_ncp[dl];
-        const double* Y = T.Y + T.lm_yoff[dl] + 18 * off;
-        if (6 * off + col < rows) {
-          const double v0 = Y[3 * col], v1 = Y[3 * col + 1], v2 = Y[3 * col + 2];
+      // batches of four landmarks: all Y-hat loads of a batch are issued before any is consumed (one L2 round trip per
+      // batch instead of one per landmark); the landmark metadata comes from LDS (m_off / m_rows / m_y, filled above)
+      const int stride = gb * nsp;
+      for (int t0 = grp; t0 < n_mine; t0 += 4 * gb) {
+        double v[4][3], u[4][18], yh[4][3];
+        bool live[4];
 #pragma unroll
-          for (int a = 0; a < 6; ++a) acc[a] -= fma(Y[3 * a], v0, fma(Y[3 * a + 1], v1, Y[3 * a + 2] * v2));
-          if (col < 6) {
-            const double* yh = T.lm_yhat + 3 * dl;
-            gsum -= fma(v0, yh[0], fma(v1, yh[1], v2 * yh[2]));
+        for (int b = 0; b < 4; ++b) {
+          const int t = t0 + b * gb;
+          live[b] = t < n_mine && 6 * m_off[t < n_mine ? t : 0] + col < m_rows[t < n_mine ? t : 0];
+          if (live[b]) {
+            const double* Y = T.Y + m_y[t];
+            v[b][0] = Y[3 * col], v[b][1] = Y[3 * col + 1], v[b][2] = Y[3 * col + 2];
+#pragma unroll
+            for (int e = 0; e < 18; ++e) u[b][e] = Y[e];
+            if (col < 6) {
+              const double* y3 = T.lm_yhat + 3 * (dl0 + sp + t * nsp);
+              yh[b][0] = y3[0], yh[b][1] = y3[1], yh[b][2] = y3[2];
+            }
           }
         }
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if (live[b]) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) acc[a] -= fma(u[b][3 * a], v[b][0], fma(u[b][3 * a + 1], v[b][1], u[b][3 * a + 2] * v[b][2]));
+            if (col < 6) gsum -= fma(v[b][0], yh[b][0], fma(v[b][1], yh[b][1], v[b][2] * yh[b][2]));
+          }
       }
+      (void)stride;
 #pragma unroll
       for (int a = 0; a < 6; ++a) red[(grp * 6 + a) * ncb + col] = acc[a];
       if (col < 6) red[gb * 6 * ncb + grp * 6 + col] = gsum;

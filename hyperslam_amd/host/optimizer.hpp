@@ -1,0 +1,465 @@
+// optimizer.hpp — C++ host-side mirror of HyperSLAM's optimizer plugin surface on top of the C ABI.
+//
+// Restates the *structure-producing* behaviour of
+//   AbstractOptimizer::submit / setWindow / process   /root/reference/internal/hyper/optimizers/abstract.cpp:40-292
+//   CeresOptimizer::updateState / updateLandmarks     /root/reference/internal/hyper/optimizers/ceres/optimizer.cpp:286-382
+// with the same names and argument meaning, using plain structs instead of the (absent) HyperVariables / HyperSensors types:
+// which residuals exist, which control points are frozen, when optimize() runs and how the window grows / slides.
+// All arithmetic of optimize() happens behind hs_solve (gfx950 kernels); this file is host bookkeeping only.
+//
+// The C ABI prefix is a macro so that the identical driver can be linked against the oracle (prefix hso_) in CPU tests.
+#pragma once
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/hyperslam_hip.h"
+
+#ifndef HS_ABI_PREFIX
+#define HS_ABI_PREFIX hs_
+#endif
+#define HS_CAT2(a, b) a##b
+#define HS_CAT(a, b) HS_CAT2(a, b)
+#define HSF(name) HS_CAT(HS_ABI_PREFIX, name)
+
+// the oracle exports the same entry points under its own prefix
+extern "C" {
+int HSF(create)(int, void*, hs_problem**);
+int HSF(destroy)(hs_problem*);
+const char* HSF(last_error)(const hs_problem*);
+int HSF(set_spline)(hs_problem*, int, double, double, int, const double*, const uint8_t*, int, int);
+int HSF(set_cameras)(hs_problem*, int, const double*, const double*, const double*);
+int HSF(set_landmarks)(hs_problem*, int, const double*, const uint8_t*);
+int HSF(set_imu)(hs_problem*, const double*, const double*, const double*, const double*, const double*, int, double, double, int, const double*,
+                 const double*, int);
+int HSF(set_gravity)(hs_problem*, const double*, int);
+int HSF(set_bearing_residuals)(hs_problem*, int, const double*, const double*, const int32_t*, const int32_t*);
+int HSF(set_pixel_residuals)(hs_problem*, int, const double*, const double*, const int32_t*, const int32_t*);
+int HSF(set_prior_residuals)(hs_problem*, int, const double*, const double*, const int32_t*);
+int HSF(set_inertial_residuals)(hs_problem*, int, const double*, const double*);
+int HSF(solve)(hs_problem*, int, hs_summary*, hs_iteration*);
+int HSF(get_control_points)(hs_problem*, double*);
+int HSF(get_landmarks)(hs_problem*, double*);
+int HSF(get_bias)(hs_problem*, double*, double*);
+int HSF(get_gravity)(hs_problem*, double*);
+}
+
+namespace hyper_hip {
+
+using Stamp = double;
+using Scalar = double;
+
+// ---- minimal value types (stand-ins for hyper::SE3 / Bearing / ...) ------------------------------------------------------
+struct Quat {
+  double x = 0, y = 0, z = 0, w = 1;
+};
+inline Quat mul(const Quat& a, const Quat& b) {
+  return {a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w,
+          a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+}
+inline Quat conj(const Quat& a) { return {-a.x, -a.y, -a.z, a.w}; }
+using Vec3 = std::array<double, 3>;
+inline Vec3 rotate(const Quat& q, const Vec3& v) {
+  const Quat r = mul(mul(q, Quat{v[0], v[1], v[2], 0}), conj(q));
+  return {r.x, r.y, r.z};
+}
+struct SE3 {
+  Quat q;
+  Vec3 p{0, 0, 0};
+};
+inline SE3 groupPlus(const SE3& a, const SE3& b) {  // a o b
+  const Vec3 t = rotate(a.q, b.p);
+  return {mul(a.q, b.q), {t[0] + a.p[0], t[1] + a.p[1], t[2] + a.p[2]}};
+}
+inline SE3 groupInverse(const SE3& a) {
+  const Quat qi = conj(a.q);
+  const Vec3 t = rotate(qi, a.p);
+  return {qi, {-t[0], -t[1], -t[2]}};
+}
+inline Vec3 vectorPlus(const SE3& a, const Vec3& v) {
+  const Vec3 t = rotate(a.q, v);
+  return {t[0] + a.p[0], t[1] + a.p[1], t[2] + a.p[2]};
+}
+
+struct Camera {  // sensors[] entry of settings.yaml (transformation, intrinsics [cx cy fx fy], radtan distortion)
+  SE3 transformation;
+  std::array<double, 4> intrinsics{0, 0, 1, 1};
+  std::array<double, 4> distortion{0, 0, 0, 0};
+
+  /// EXTERNAL Camera::convertPixelsToBearings (call site abstract.cpp:222-223): undistort (fixed point) and normalise.
+  Vec3 pixelToBearing(double u, double v) const {
+    const double xd = (u - intrinsics[0]) / intrinsics[2], yd = (v - intrinsics[1]) / intrinsics[3];
+    double x = xd, y = yd;
+    const double k1 = distortion[0], k2 = distortion[1], p1 = distortion[2], p2 = distortion[3];
+    for (int it = 0; it < 20; ++it) {
+      const double r2 = x * x + y * y, rad = 1 + k1 * r2 + k2 * r2 * r2;
+      const double dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x), dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+      x = (xd - dx) / rad, y = (yd - dy) / rad;
+    }
+    const double n = std::sqrt(x * x + y * y + 1);
+    return {x / n, y / n, 1 / n};
+  }
+  /// EXTERNAL Camera::Triangulate(T_01, b0, b1) (call site abstract.cpp:252): midpoint of the two rays, in frame 0.
+  static Vec3 Triangulate(const SE3& T_01, const Vec3& b0, const Vec3& b1) {
+    const Vec3 d1 = rotate(T_01.q, b1), o = T_01.p;
+    const double a = b0[0] * b0[0] + b0[1] * b0[1] + b0[2] * b0[2], b = b0[0] * d1[0] + b0[1] * d1[1] + b0[2] * d1[2];
+    const double c = d1[0] * d1[0] + d1[1] * d1[1] + d1[2] * d1[2];
+    const double e = b0[0] * o[0] + b0[1] * o[1] + b0[2] * o[2], f = d1[0] * o[0] + d1[1] * o[1] + d1[2] * o[2];
+    const double den = a * c - b * b;
+    const double s0 = den > 1e-12 ? (c * e - b * f) / den : 1.0, s1 = den > 1e-12 ? (b * e - a * f) / den : 1.0;
+    return {0.5 * (s0 * b0[0] + o[0] + s1 * d1[0]), 0.5 * (s0 * b0[1] + o[1] + s1 * d1[1]), 0.5 * (s0 * b0[2] + o[2] + s1 * d1[2])};
+  }
+};
+
+struct IMU {  // IMU entry of settings.yaml:74-109 + bias splines (imu.cpp:64-81)
+  SE3 transformation;
+  std::array<double, 6> gyroscope_intrinsics{1, 1, 1, 0, 0, 0}, accelerometer_intrinsics{1, 1, 1, 0, 0, 0};
+  std::array<double, 9> gyroscope_sensitivity{}, accelerometer_axes_offsets{};
+  int bias_order = 4;
+  double bias_separation = 1.0;
+};
+
+// ---- messages (hyper/messages/**, EXTERNAL) ------------------------------------------------------------------------------
+struct VisualTracks {  // one stereo frame: identifiers[i] seen at pixel P0[i] in camera 0 and P1[i] in camera 1
+  Stamp stamp = 0;
+  std::vector<int64_t> identifiers;
+  std::vector<std::array<double, 2>> P0, P1;
+};
+struct InertialMeasurement {
+  Stamp stamp = 0;
+  std::array<double, 6> value{};  // [gyroscope; accelerometer]
+};
+struct ManifoldMeasurement {  // pose prior
+  Stamp stamp = 0;
+  std::array<double, 7> value{};
+};
+
+struct Range {
+  Stamp lower = 0, upper = 0;  // LOWER_INCLUSIVE_ONLY (abstract.hpp:29-30)
+  bool contains(Stamp t) const { return lower <= t && t < upper; }
+  Stamp size() const { return upper - lower; }
+};
+
+struct Options {  // backend YAML keys actually read: separation, max_window, constancy flags
+  Stamp separation = 0.1, max_window = 3.0;
+  int order = 4;  // EXTERNAL BasisInterpolator() default is not visible; BASELINE configs use 4 and 6
+  bool rotation_constant = false, translation_constant = false;
+  int max_num_iterations = 5;  // optimizer.cpp:40
+};
+
+/// Mirror of `Optimizer<OptimizerSuite::CERES>` + the non-virtual logic of `AbstractOptimizer` behind the C ABI.
+class Optimizer {
+ public:
+  Optimizer(const Options& options, const std::vector<Camera>& cameras, const IMU* imu = nullptr, int device = 0)
+      : opt_(options), cameras_(cameras), has_imu_(imu != nullptr) {
+    if (imu) imu_ = *imu;
+    if (HSF(create)(device, nullptr, &handle_) != HS_OK) throw std::runtime_error("hs_create failed (no usable GPU?)");
+  }
+  ~Optimizer() {
+    if (handle_) HSF(destroy)(handle_);
+  }
+  Optimizer(const Optimizer&) = delete;
+  Optimizer& operator=(const Optimizer&) = delete;
+
+  const Stamp& root() const { return root_stamp_; }
+  const Range& window() const { return window_; }
+  int numOptimizations() const { return num_optimizations_; }
+  const hs_summary& lastSummary() const { return last_summary_; }
+  size_t numLandmarks() const { return landmarks_.size(); }
+  size_t numControlPoints() const { return cp_.size(); }
+
+  /// State range = stamps for which all k control points exist (EXTERNAL AbstractState::range()).
+  Range stateRange() const {
+    const int k = opt_.order;
+    return {cp_[(k - 1) / 2].stamp, cp_[cp_.size() - 1 - k / 2].stamp};
+  }
+
+  // ---- AbstractOptimizer::submit (abstract.cpp:74-147) ----
+  void submit(const VisualTracks& m) { submitImpl(m.stamp, [&](Stamp s) { process(m, s); }); }
+  void submit(const InertialMeasurement& m) { submitImpl(m.stamp, [&](Stamp s) { process(m, s); }); }
+  void submit(const ManifoldMeasurement& m) { submitImpl(m.stamp, [&](Stamp s) { process(m, s); }); }
+
+  // ---- AbstractOptimizer::setWindow (abstract.cpp:40-62) ----
+  void setWindow(const Range& window) {
+    window_ = window;
+    updateLandmarks(window_);
+    updateState(window_);
+    const Range r = stateRange();
+    gravity_constant_ = window_.size() < r.size();  // abstract.cpp:57-61
+  }
+
+  /// CeresOptimizer::optimize (optimizer.cpp:276-280): flat tables -> hs_solve -> write back in place.
+  void optimize() {
+    const int k = opt_.order, n_cp = int(cp_.size());
+    std::vector<double> cp(size_t(8) * n_cp);
+    std::vector<uint8_t> frozen(n_cp);
+    for (int j = 0; j < n_cp; ++j) {
+      const ControlPoint& c = cp_[j];
+      double* o = &cp[8 * j];
+      o[0] = c.T.q.x, o[1] = c.T.q.y, o[2] = c.T.q.z, o[3] = c.T.q.w, o[4] = c.T.p[0], o[5] = c.T.p[1], o[6] = c.T.p[2], o[7] = c.stamp;
+      frozen[j] = c.constant;
+    }
+    check(HSF(set_spline)(handle_, k, cp_.front().stamp, opt_.separation, n_cp, cp.data(), frozen.data(), opt_.rotation_constant, opt_.translation_constant),
+          "set_spline");
+    std::vector<double> T(7 * cameras_.size()), I(4 * cameras_.size()), D(4 * cameras_.size());
+    for (size_t c = 0; c < cameras_.size(); ++c) {
+      const SE3& t = cameras_[c].transformation;
+      const double v[7] = {t.q.x, t.q.y, t.q.z, t.q.w, t.p[0], t.p[1], t.p[2]};
+      std::copy(v, v + 7, &T[7 * c]);
+      std::copy(cameras_[c].intrinsics.begin(), cameras_[c].intrinsics.end(), &I[4 * c]);
+      std::copy(cameras_[c].distortion.begin(), cameras_[c].distortion.end(), &D[4 * c]);
+    }
+    check(HSF(set_cameras)(handle_, int(cameras_.size()), T.data(), I.data(), D.data()), "set_cameras");
+    // landmarks + bearing residuals (the runtime uses bearing factors, abstract.cpp:243-260)
+    std::vector<double> xyz, st, b;
+    std::vector<int32_t> lmi, cam;
+    std::vector<Landmark*> order;
+    for (auto& [id, lm] : landmarks_) {
+      const int32_t li = int32_t(order.size());
+      order.push_back(&lm);
+      xyz.insert(xyz.end(), lm.position.begin(), lm.position.end());
+      for (const Observation& ob : lm.observations) {
+        st.push_back(ob.stamp), lmi.push_back(li), cam.push_back(ob.camera);
+        b.insert(b.end(), ob.bearing.begin(), ob.bearing.end());
+      }
+    }
+    check(HSF(set_landmarks)(handle_, int(order.size()), xyz.data(), nullptr), "set_landmarks");
+    check(HSF(set_bearing_residuals)(handle_, int(st.size()), st.data(), b.data(), lmi.data(), cam.data()), "set_bearing_residuals");
+    check(HSF(set_pixel_residuals)(handle_, 0, nullptr, nullptr, nullptr, nullptr), "set_pixel_residuals");
+    std::vector<double> pst, pval;
+    std::vector<int32_t> psen;
+    (void)psen;
+    check(HSF(set_prior_residuals)(handle_, 0, nullptr, nullptr, nullptr), "set_prior_residuals");
+    std::vector<double> ist, ival;
+    if (has_imu_) {
+      for (const InertialMeasurement& m : inertials_) ist.push_back(m.stamp), ival.insert(ival.end(), m.value.begin(), m.value.end());
+      const SE3& t = imu_.transformation;
+      const double Tb[7] = {t.q.x, t.q.y, t.q.z, t.q.w, t.p[0], t.p[1], t.p[2]};
+      std::vector<double> bg(4 * bias_.size()), ba(4 * bias_.size());
+      for (size_t j = 0; j < bias_.size(); ++j)
+        for (int c = 0; c < 4; ++c) bg[4 * j + c] = c < 3 ? bias_[j].g[c] : bias_[j].stamp, ba[4 * j + c] = c < 3 ? bias_[j].a[c] : bias_[j].stamp;
+      check(HSF(set_imu)(handle_, Tb, imu_.gyroscope_intrinsics.data(), imu_.accelerometer_intrinsics.data(), imu_.gyroscope_sensitivity.data(),
+                         imu_.accelerometer_axes_offsets.data(), imu_.bias_order, bias_.front().stamp, imu_.bias_separation, int(bias_.size()), bg.data(),
+                         ba.data(), 0),
+            "set_imu");
+      check(HSF(set_gravity)(handle_, gravity_.data(), gravity_constant_), "set_gravity");
+    }
+    check(HSF(set_inertial_residuals)(handle_, int(ist.size()), ist.data(), ival.data()), "set_inertial_residuals");
+    if (st.empty() && ist.empty()) return;  // nothing to optimise yet
+    check(HSF(solve)(handle_, opt_.max_num_iterations, &last_summary_, nullptr), "solve");
+    ++num_optimizations_;
+    // write back in place (the reference's solver mutates the variables through raw double*, optimizer.cpp:299-305,354-356)
+    check(HSF(get_control_points)(handle_, cp.data()), "get_control_points");
+    for (int j = 0; j < n_cp; ++j) {
+      const double* o = &cp[8 * j];
+      cp_[j].T = SE3{Quat{o[0], o[1], o[2], o[3]}, {o[4], o[5], o[6]}};
+    }
+    check(HSF(get_landmarks)(handle_, xyz.data()), "get_landmarks");
+    for (size_t l = 0; l < order.size(); ++l) order[l]->position = {xyz[3 * l], xyz[3 * l + 1], xyz[3 * l + 2]};
+    if (has_imu_) {
+      std::vector<double> bg(4 * bias_.size()), ba(4 * bias_.size());
+      check(HSF(get_bias)(handle_, bg.data(), ba.data()), "get_bias");
+      for (size_t j = 0; j < bias_.size(); ++j)
+        for (int c = 0; c < 3; ++c) bias_[j].g[c] = bg[4 * j + c], bias_[j].a[c] = ba[4 * j + c];
+      check(HSF(get_gravity)(handle_, gravity_.data()), "get_gravity");
+    }
+  }
+
+  /// Pose of control point j (for tests / trajectory dumps).
+  const SE3& controlPoint(size_t j) const { return cp_[j].T; }
+  Stamp controlPointStamp(size_t j) const { return cp_[j].stamp; }
+  bool controlPointConstant(size_t j) const { return cp_[j].constant; }
+  void setGravity(const Vec3& g) { gravity_ = g; }
+  const Vec3& gravity() const { return gravity_; }
+
+  /// EXTERNAL AbstractState::evaluate(StateQuery{stamp}) restricted to what process(VisualTracks) needs (abstract.cpp:197-198):
+  /// the value of the spline. The control points are still at their held/extrapolated values when a frame arrives, so the value is
+  /// computed on the host with the same cumulative formulation (only used to place new landmarks).
+  SE3 evaluate(Stamp stamp) const {
+    const int k = opt_.order;
+    const double x = (stamp - cp_.front().stamp) / opt_.separation;
+    const int first = int(std::floor(x)) - (k - 1) / 2;
+    const double u = x - std::floor(x);
+    std::vector<double> lam(k);
+    cumulativeBasis(k, u, lam.data());
+    Quat q = cp_[first].T.q;
+    Vec3 p = cp_[first].T.p;
+    for (int j = 1; j < k; ++j) {
+      const Quat rel = mul(conj(cp_[first + j - 1].T.q), cp_[first + j].T.q);
+      q = mul(q, quatPow(rel, lam[j]));
+      for (int c = 0; c < 3; ++c) p[c] += lam[j] * (cp_[first + j].T.p[c] - cp_[first + j - 1].T.p[c]);
+    }
+    return {q, p};
+  }
+
+ private:
+  struct ControlPoint {
+    Stamp stamp;
+    SE3 T;
+    uint8_t constant = 0;
+  };
+  struct Observation {
+    Stamp stamp;
+    int32_t camera;
+    Vec3 bearing;
+  };
+  struct Landmark {
+    Vec3 position{0, 0, 0};
+    std::vector<Observation> observations;
+    Stamp lower = 0, upper = 0;  // AbstractLandmark::range() (landmarks/abstract.cpp:62-99)
+  };
+  struct BiasPoint {
+    Stamp stamp;
+    Vec3 g{0, 0, 0}, a{0, 0, 0};
+  };
+
+  void check(int rc, const char* what) const {
+    if (rc != HS_OK) throw std::runtime_error(std::string(what) + " failed: " + HSF(last_error)(handle_));
+  }
+
+  static void cumulativeBasis(int k, double u, double* lam) {  // SURVEY.md A.1 via Cox-de Boor (host, tiny)
+    std::vector<double> N(k, 0.0);
+    N[k - 1] = 1.0;  // order 1 on the segment; raise the order
+    for (int ord = 2; ord <= k; ++ord)
+      for (int j = k - ord; j < k; ++j) {
+        const double jj = double(j - (k - 1));  // knot index of basis j
+        const double left = (u - jj) / (ord - 1) * N[j];
+        const double right = j + 1 < k ? (jj + ord - u) / (ord - 1) * N[j + 1] : 0.0;
+        N[j] = left + right;
+      }
+    for (int j = 0; j < k; ++j) {
+      double s = 0;
+      for (int m = j; m < k; ++m) s += N[m];
+      lam[j] = s;
+    }
+  }
+  static Quat quatPow(Quat q, double t) {  // Exp(t Log(q)), principal branch
+    if (q.w < 0) q = {-q.x, -q.y, -q.z, -q.w};
+    const double n = std::sqrt(q.x * q.x + q.y * q.y + q.z * q.z);
+    if (n < 1e-15) return {0, 0, 0, 1};
+    const double half = std::atan2(n, q.w) * t, s = std::sin(half) / n;
+    return {s * q.x, s * q.y, s * q.z, std::cos(half)};
+  }
+
+  template <class F>
+  void submitImpl(Stamp raw_stamp, F&& do_process) {
+    if (cp_.empty()) {  // first message: bootstrap (abstract.cpp:76-96)
+      root_stamp_ = raw_stamp;
+      const int k = opt_.order;
+      for (int i = 0; i < k; ++i) cp_.push_back({0.0 + (i - (k - 1) / 2) * opt_.separation, SE3{}, 0});
+      if (has_imu_) extendBias(Range{0, opt_.separation});
+      setWindow(Range{0, opt_.separation});
+    }
+    const Stamp stamp = raw_stamp - root_stamp_;
+    const Range state_range = stateRange();
+    if (state_range.contains(stamp)) {
+      if (window_.contains(stamp)) do_process(stamp);
+      else throw std::runtime_error("message inside the state but outside the window: not implemented (abstract.cpp:109-112)");
+      return;
+    }
+    if (stamp < state_range.lower) return;  // "Discarding out-of-scope message." (abstract.cpp:116)
+    optimize();                             // abstract.cpp:119
+    const Stamp delta = stamp - window_.upper;
+    const int n = std::max(1, int(std::ceil(delta)));  // abstract.cpp:124 (in seconds, as written upstream)
+    for (int i = 1; i <= n; ++i) {                       // abstract.cpp:127-137: hold the second-to-last pose
+      const Stamp new_stamp = cp_.back().stamp + opt_.separation;
+      const SE3 held = cp_[cp_.size() - 2].T;
+      cp_.back().T = held;
+      cp_.push_back({new_stamp, held, 0});
+    }
+    const Stamp x = n * opt_.separation, upper = window_.upper + x, size = window_.size();
+    if (has_imu_) extendBias(Range{window_.lower, upper});
+    setWindow(size + x <= opt_.max_window + 1e-12 ? Range{window_.lower, upper} : Range{upper - size, upper});  // abstract.cpp:139-143
+    do_process(stamp);
+  }
+
+  // ---- process(VisualTracks) (abstract.cpp:186-264) ----
+  void process(const VisualTracks& m, Stamp stamp) {
+    if (cameras_.size() != 2) throw std::runtime_error("Unsupported camera configuration.");
+    const SE3 T_w0 = groupPlus(evaluate(stamp), cameras_[0].transformation);
+    const SE3 T_01 = groupPlus(groupInverse(cameras_[0].transformation), cameras_[1].transformation);
+    for (size_t i = 0; i < m.identifiers.size(); ++i) {
+      const Vec3 b0 = cameras_[0].pixelToBearing(m.P0[i][0], m.P0[i][1]), b1 = cameras_[1].pixelToBearing(m.P1[i][0], m.P1[i][1]);
+      auto [it, inserted] = landmarks_.try_emplace(m.identifiers[i]);
+      Landmark& lm = it->second;
+      if (inserted) {
+        lm.position = vectorPlus(T_w0, Camera::Triangulate(T_01, b0, b1));
+        lm.lower = lm.upper = stamp;
+      }
+      lm.observations.push_back({stamp, 0, b0});
+      lm.observations.push_back({stamp, 1, b1});
+      lm.lower = std::min(lm.lower, stamp), lm.upper = std::max(lm.upper, stamp);
+    }
+  }
+  void process(const InertialMeasurement& m, Stamp stamp) {  // abstract.cpp:272-292
+    InertialMeasurement c = m;
+    c.stamp = stamp;
+    inertials_.push_back(c);
+  }
+  void process(const ManifoldMeasurement&, Stamp) { throw std::runtime_error("pose priors are not fed by the runtime front-ends"); }
+
+  // ---- CeresOptimizer::updateLandmarks (optimizer.cpp:360-382): retire landmarks whose observation range left the window ----
+  void updateLandmarks(const Range& range) {
+    for (auto it = landmarks_.begin(); it != landmarks_.end();) {
+      const bool intersects = it->second.upper >= range.lower && it->second.lower < range.upper;
+      it = intersects ? std::next(it) : landmarks_.erase(it);
+    }
+  }
+  // ---- CeresOptimizer::updateState (optimizer.cpp:286-345): freeze control points at or before the window's lower bound;
+  //      drop the ones no residual can reach any more ----
+  void updateState(const Range& range) {
+    for (ControlPoint& c : cp_) c.constant = c.stamp <= range.lower ? 1 : 0;  // optimizer.cpp:323-328
+    // oldest stamp any retained residual refers to
+    Stamp oldest = range.lower;
+    for (const auto& [id, lm] : landmarks_) oldest = std::min(oldest, lm.lower);
+    if (has_imu_) {
+      // inertial residuals older than every retained visual residual and the window only touch frozen control points: drop them
+      inertials_.erase(std::remove_if(inertials_.begin(), inertials_.end(), [&](const InertialMeasurement& m) { return m.stamp < oldest; }),
+                       inertials_.end());
+    }
+    const int k = opt_.order;
+    size_t drop = 0;  // control points entirely before the segment of `oldest` (optimizer.cpp:331-341)
+    while (drop + k < cp_.size() && cp_[drop + (k - 1) / 2 + 1].stamp <= oldest) ++drop;
+    if (drop) cp_.erase(cp_.begin(), cp_.begin() + drop);
+  }
+  // ---- updateSensor(IMU&, Range) is CHECK(false) upstream (optimizer.cpp:384-386); here: keep the bias splines covering the range ----
+  void extendBias(const Range& range) {
+    const int kb = imu_.bias_order;
+    const double sep = imu_.bias_separation;
+    if (bias_.empty()) {
+      const Stamp first = std::floor(range.lower / sep) * sep - ((kb - 1) / 2) * sep;
+      for (int j = 0; j < kb; ++j) bias_.push_back({first + j * sep});
+    }
+    while (bias_[bias_.size() - 1 - kb / 2].stamp <= range.upper + opt_.separation) {
+      BiasPoint b = bias_.back();
+      b.stamp += sep;
+      bias_.push_back(b);
+    }
+  }
+
+  Options opt_;
+  std::vector<Camera> cameras_;
+  bool has_imu_ = false;
+  IMU imu_;
+  hs_problem* handle_ = nullptr;
+  Stamp root_stamp_ = 0;
+  Range window_;
+  bool gravity_constant_ = false;
+  Vec3 gravity_{0, 0, -9.80665};
+  std::vector<ControlPoint> cp_;
+  std::map<int64_t, Landmark> landmarks_;
+  std::vector<InertialMeasurement> inertials_;
+  std::vector<BiasPoint> bias_;
+  hs_summary last_summary_{};
+  int num_optimizations_ = 0;
+};
+
+}  // namespace hyper_hip

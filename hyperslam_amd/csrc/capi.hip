@@ -144,8 +144,7 @@ int prepare(hs_problem* p) {
   if (!build_visual_structure(in, &p->vs, &p->err)) return HS_ERR_INVALID;
   p->vs.bw = std::max(p->vs.bw, p->min_bw);
   const VisualStructure& vs = p->vs;
-  if (6 * vs.bw > kBlock || vs.bw * vs.bw > 2 * kCholThreads || size_t(24) * (6 * vs.bw + 2) * 8 + size_t(12) * p->n_cp * 8 > size_t(p->chol_lds_max) ||
-      size_t(12) * p->n_cp * 8 > 60 * 1024)
+  if (6 * vs.bw > kBlock || size_t(24) * (6 * vs.bw + 2) * 8 + size_t(12) * p->n_cp * 8 > size_t(p->chol_lds_max) || size_t(12) * p->n_cp * 8 > 60 * 1024)
     HS_FAIL(HS_ERR_INVALID, "landmark tracks span too many control points for the LDS-resident banded factorisation");
   const int n_vis = n_px + n_br;
 
@@ -416,7 +415,13 @@ template <int K>
 int launch_build(hs_problem* p) {
   const Tables& T = p->T;
   hipStream_t s = p->stream;
-  if (T.n_lm) k_landmark<K><<<(T.n_lm + kBlock / 64 - 1) / (kBlock / 64), kBlock, 0, s>>>(T);
+  if (T.n_lm) {
+    const int grid = (T.n_lm + kBlock / 64 - 1) / (kBlock / 64);
+    if (6 * T.bw <= 128)
+      k_landmark<K, 2><<<grid, kBlock, 0, s>>>(T);
+    else  // long feature tracks (6 * bw <= kBlock is checked in prepare())
+      k_landmark<K, 4><<<grid, kBlock, 0, s>>>(T);
+  }
   const size_t lds = (size_t(6) * 6 * T.bw + 16 + 6 * kBlock + 64) * sizeof(double) + 3 * kMaxMine * sizeof(int);
   k_build_raw<K><<<dim3(T.sp.n_cp, p->n_split), kBlock, lds, s>>>(T);
   if (T.nb) {
@@ -443,8 +448,10 @@ int launch_factor(hs_problem* p) {
   const size_t chol_lds = (size_t(24) * (ncb + 2) + size_t(T.np)) * sizeof(double);
   if (T.bw * T.bw <= kCholThreads)
     k_band_factor<1><<<1, kCholThreads + kCholIo, chol_lds, s>>>(T);
-  else
+  else if (T.bw * T.bw <= 2 * kCholThreads)
     k_band_factor<2><<<1, kCholThreads + kCholIo, chol_lds, s>>>(T);
+  else  // long feature tracks: trailing window in L2 instead of registers
+    k_band_factor_wide<<<1, kWideThreads, size_t(6) * (ncb + 2) * sizeof(double), s>>>(T);
   if (T.nb) {  // bordered system (bias splines + gravity)
     k_border_forward<<<(T.nb + kBorderCols - 1) / kBorderCols, 128, size_t(T.np) * kBorderCols * sizeof(double), s>>>(T);
     k_border_schur<<<T.nb, kBlock, 0, s>>>(T);

@@ -201,6 +201,7 @@ __global__ void __launch_bounds__(kBlock) k_cost_prior(Tables T, const double* c
 
 /// Second half of the landmark pass (shared by k_landmark and the fused linearise kernel): given the wave-reduced H_ll, b_l and
 /// this lane's W rows, forms V = S_l H_ll S_l + D_l^2 = L L', stores L, y-hat, the scaled gradient and the Y-hat rows.
+template <int PS>
 HSD void landmark_finish(const Tables& T, int dl, int lane, bool active, bool fresh, double radius, const double* sl_old, int yoff, int rows,
                          const double* h, const double* b, double (*w)[3]) {
   double sl[3];
@@ -234,7 +235,7 @@ HSD void landmark_finish(const Tables& T, int dl, int lane, bool active, bool fr
   // W rows -> Y-hat rows
   double* Y = T.Y + yoff;
 #pragma unroll
-  for (int ps = 0; ps < 2; ++ps) {
+  for (int ps = 0; ps < PS; ++ps) {
     const int rho = lane + 64 * ps;
     if (rho < rows) {
       const double w0 = w[ps][0] * sl[0], w1 = w[ps][1] * sl[1], w2 = w[ps][2] * sl[2];
@@ -249,8 +250,9 @@ HSD void landmark_finish(const Tables& T, int dl, int lane, bool active, bool fr
 // Landmark pass: one wave per landmark.  H_ll = sum Jl'Jl, b_l = sum Jl'r, W_l = sum Jp'Jl over the landmark's
 // residuals; V = S_l H_ll S_l + D_l^2 = L L';  Y-hat = W S_l L^-T (pose-side row scaling is applied by the consumer),
 // y-hat = L^-1 S_l b_l.  Jacobi scaling S_l is fixed at iteration 0 (TrustRegionMinimizer, jacobi_scaling = true).
+// PS = 64-row passes a lane owns (rows of W = 6 * control points the landmark touches <= 64 * PS).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int K>
+template <int K, int PS>
 __global__ void __launch_bounds__(kBlock) k_landmark(Tables T) {
   if (T.st->done) return;
   constexpr int REC = 8 + 12 * K;
@@ -263,7 +265,9 @@ __global__ void __launch_bounds__(kBlock) k_landmark(Tables T) {
   // once; the chunk is then walked with register broadcasts, every lane accumulating its own W row(s) (rho = lane, lane + 64)
   // and lane q the H_ll / b_l terms of residual q.
   double h[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-  double w[2][3] = {{0, 0, 0}, {0, 0, 0}};
+  double w[PS][3];
+#pragma unroll
+  for (int ps = 0; ps < PS; ++ps) w[ps][0] = w[ps][1] = w[ps][2] = 0.0;
   for (int base = q0; base < q1; base += 64) {
     const int myq = base + lane;
     const int my_first = myq < q1 ? T.v_first[myq] : 0, my_pos = myq < q1 ? T.v_pos[myq] : 0;
@@ -284,7 +288,7 @@ __global__ void __launch_bounds__(kBlock) k_landmark(Tables T) {
       const double* rec = T.v_rec + size_t(pt) * REC;
       const int off = 6 * (ft - c_first);
 #pragma unroll
-      for (int ps = 0; ps < 2; ++ps) {
+      for (int ps = 0; ps < PS; ++ps) {
         const int c = lane + 64 * ps - off;
         if (c >= 0 && c < 6 * K && lane + 64 * ps < rows) {
           const double ja = rec[8 + c], jb = rec[8 + 6 * K + c];
@@ -303,7 +307,7 @@ __global__ void __launch_bounds__(kBlock) k_landmark(Tables T) {
   const bool fresh = !T.st->scaling_ready;
   double sl_old[3] = {1.0, 1.0, 1.0};
   if (!fresh) sl_old[0] = T.lm_scale[3 * dl], sl_old[1] = T.lm_scale[3 * dl + 1], sl_old[2] = T.lm_scale[3 * dl + 2];
-  landmark_finish(T, dl, lane, (q1 > q0) && !T.lm_const[dl], fresh, T.st->radius, sl_old, T.lm_yoff[dl], rows, h, b, w);
+  landmark_finish<PS>(T, dl, lane, (q1 > q0) && !T.lm_const[dl], fresh, T.st->radius, sl_old, T.lm_yoff[dl], rows, h, b, w);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1121,6 +1125,102 @@ __global__ void __launch_bounds__(kCholThreads + kCholIo) k_band_factor(Tables T
   }
 #undef UIDX
   lds_barrier();
+}
+
+/// Fallback factorisation for wide bands (long feature tracks: bw * bw > 2 * kCholThreads): same algorithm and outputs
+/// (Ub, U_ii^-1, y) but the trailing window stays in HBM/L2 (in place in Sb) instead of registers. One workgroup of 1024 lanes.
+constexpr int kWideThreads = 1024;
+
+__global__ void __launch_bounds__(kWideThreads) k_band_factor_wide(Tables T) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  DevState* st = T.st;
+  if (st->done) return;
+  const int tid = threadIdx.x;
+  const int bw = T.bw, ncb = 6 * bw, ld = ncb + 2;
+  const int n_blk = T.np / 6;
+  double* xbuf = smem;  // 6 x ld : [U_ii | X | y_i]
+  __shared__ double Uii[36], Winv[24];
+  __shared__ int fail;
+  if (tid == 0) fail = 0;
+  __syncthreads();
+  for (int i = 0; i < n_blk; ++i) {
+    double* rowS = T.Sb + size_t(6) * i * ncb;
+    if (tid == 0) {  // 6x6 upper Cholesky + inverse of the factor
+      double A[36];
+      for (int a = 0; a < 6; ++a)
+        for (int c = 0; c < 6; ++c) A[6 * a + c] = rowS[size_t(a) * ncb + c];
+      for (int a = 0; a < 6; ++a) {
+        double d = A[7 * a];
+        for (int k = 0; k < a; ++k) d -= A[6 * k + a] * A[6 * k + a];
+        if (!(d > 0.0)) fail = 1, d = 1.0;
+        d = sqrt(d);
+        A[7 * a] = d;
+        for (int c = a + 1; c < 6; ++c) {
+          double v = A[6 * a + c];
+          for (int k = 0; k < a; ++k) v -= A[6 * k + a] * A[6 * k + c];
+          A[6 * a + c] = v / d;
+        }
+        for (int c = 0; c < a; ++c) A[6 * a + c] = 0.0;
+      }
+      double W[36] = {0};
+      for (int c = 5; c >= 0; --c) {
+        W[7 * c] = 1.0 / A[7 * c];
+        for (int a = c - 1; a >= 0; --a) {
+          double v = 0.0;
+          for (int k = a + 1; k <= c; ++k) v += A[6 * a + k] * W[6 * k + c];
+          W[6 * a + c] = -v / A[7 * a];
+        }
+      }
+      int pidx = 0;
+      for (int a = 0; a < 6; ++a)
+        for (int c = a; c < 6; ++c) Winv[pidx++] = W[6 * a + c];
+      for (int e = 0; e < 36; ++e) Uii[e] = A[e];
+    }
+    __syncthreads();
+    if (tid < 21) T.Ubk[size_t(i) * 24 + tid] = Winv[tid];
+    for (int c = tid; c <= ncb; c += kWideThreads) {  // X = U_ii^-T [S_i,: | g_i]
+      double x[6];
+      if (c < 6) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) x[a] = Uii[6 * a + c];
+      } else {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          double v = c < ncb ? rowS[size_t(a) * ncb + c] : T.g_s[6 * i + a];
+#pragma unroll
+          for (int k = 0; k < a; ++k) v -= Uii[6 * k + a] * x[k];
+          x[a] = v / Uii[7 * a];
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        xbuf[a * ld + c] = x[a];
+        if (c < ncb)
+          T.Ub[size_t(6 * i + a) * ncb + c] = x[a];
+        else
+          T.ybuf[6 * i + a] = x[a];
+      }
+    }
+    __syncthreads();
+    // trailing update in place: row 6(i+j)+a', band column c  <->  columns 6j+a' and 6j+c of block row i
+    const int per_j = 6 * (ncb + 1);
+    for (int e = tid; e < (bw - 1) * per_j; e += kWideThreads) {
+      const int j = 1 + e / per_j, rem = e % per_j;
+      const int ap = rem / (ncb + 1), c = rem % (ncb + 1);
+      if (i + j >= n_blk) continue;
+      const int ci = 6 * j + ap, cj = c == ncb ? ncb : 6 * j + c;
+      if (c < ncb && cj >= ncb) continue;
+      double sacc = 0.0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) sacc = fma(xbuf[a * ld + ci], xbuf[a * ld + cj], sacc);
+      if (c < ncb)
+        T.Sb[size_t(6 * (i + j) + ap) * ncb + c] -= sacc;
+      else
+        T.g_s[6 * (i + j) + ap] -= sacc;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) st->chol_failed = fail;
 }
 
 /// Backward sweep U x = y (y in T.ybuf, possibly corrected by the border solve) + step outputs and model-cost reductions.

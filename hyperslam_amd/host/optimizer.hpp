@@ -426,8 +426,9 @@ class Optimizer {
                        inertials_.end());
     }
     const int k = opt_.order;
-    size_t drop = 0;  // control points entirely before the segment of `oldest` (optimizer.cpp:331-341)
-    while (drop + k < cp_.size() && cp_[drop + (k - 1) / 2 + 1].stamp <= oldest) ++drop;
+    size_t drop = 0;  // control points entirely before the segment of `oldest` (optimizer.cpp:331-341); the margin keeps a stamp that
+                      // sits exactly on a knot inside the valid range whatever the rounding of (stamp - t0) / separation
+    while (drop + k < cp_.size() && cp_[drop + (k - 1) / 2 + 1].stamp <= oldest - 1e-6 * opt_.separation) ++drop;
     if (drop) cp_.erase(cp_.begin(), cp_.begin() + drop);
   }
   // ---- updateSensor(IMU&, Range) is CHECK(false) upstream (optimizer.cpp:384-386); here: keep the bias splines covering the range ----

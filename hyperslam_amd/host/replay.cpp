@@ -57,7 +57,7 @@ int main(int argc, char** argv) {
   int64_t next_id = 0;
   const int max_tracks = 150;  // settings.yaml:118
   const double t_start = 10.0;  // arbitrary root stamp (the optimizer subtracts it)
-  double total_solve_ms = 0, max_solve_ms = 0;
+  double total_solve_ms = 0, max_solve_ms = 0, stage_ms[4] = {0, 0, 0, 0};
   long total_blocks = 0;
   int solves_seen = 0;
   const auto wall0 = std::chrono::steady_clock::now();
@@ -124,6 +124,10 @@ int main(int argc, char** argv) {
       const hs_summary& s = optimizer.lastSummary();
       total_solve_ms += s.total_ms, max_solve_ms = std::max(max_solve_ms, s.total_ms);
       total_blocks += long(s.num_residual_blocks) * s.num_iterations;
+      stage_ms[0] += s.linearize_ms, stage_ms[1] += s.schur_ms, stage_ms[2] += s.solve_ms, stage_ms[3] += s.update_ms;
+      if (std::getenv("HS_REPLAY_TRACE"))
+        std::fprintf(stderr, "opt %3d  cps %3zu  lms %4zu  blocks %6d  iters %d  ok %d  term %d  cost %.12g -> %.12g\n", solves_seen, optimizer.numControlPoints(),
+                     optimizer.numLandmarks(), s.num_residual_blocks, s.num_iterations, s.num_successful_steps, s.termination, s.initial_cost, s.final_cost);
     }
   }
   const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
@@ -131,17 +135,19 @@ int main(int argc, char** argv) {
   const SE3 A = groupPlus(gt_pose(optimizer.controlPointStamp(0)), groupInverse(optimizer.controlPoint(0)));
   double se = 0;
   int n = 0;
-  for (size_t j = 0; j + 2 < optimizer.numControlPoints(); ++j) {
+  for (size_t j = 0; j + opt.order < optimizer.numControlPoints(); ++j) {  // control points the data already constrains
     const Vec3 e = vectorPlus(A, optimizer.controlPoint(j).p), g = gt_position(optimizer.controlPointStamp(j));
     se += (e[0] - g[0]) * (e[0] - g[0]) + (e[1] - g[1]) * (e[1] - g[1]) + (e[2] - g[2]) * (e[2] - g[2]);
     ++n;
   }
   std::printf("{\"replay_seconds\": %.2f, \"imu\": %d, \"order\": %d, \"optimizations\": %d, \"control_points\": %zu, \"landmarks\": %zu, "
               "\"mean_solve_ms\": %.4f, \"max_solve_ms\": %.4f, \"residual_blocks_per_s_in_solve\": %.1f, \"wall_ms\": %.1f, "
-              "\"window\": [%.2f, %.2f], \"position_rmse_m\": %.4f, \"last_cost\": [%.6g, %.6g]}\n",
+              "\"window\": [%.2f, %.2f], \"position_rmse_m\": %.4f, \"last_cost\": [%.6g, %.6g], "
+              "\"mean_stage_ms\": {\"linearize\": %.4f, \"schur\": %.4f, \"solve\": %.4f, \"update\": %.4f}}\n",
               seconds, int(with_imu), opt.order, optimizer.numOptimizations(), optimizer.numControlPoints(), optimizer.numLandmarks(),
               total_solve_ms / std::max(1, solves_seen), max_solve_ms, total_solve_ms > 0 ? 1e3 * total_blocks / total_solve_ms : 0.0, wall_ms,
               optimizer.window().lower, optimizer.window().upper, std::sqrt(se / std::max(1, n)), optimizer.lastSummary().initial_cost,
-              optimizer.lastSummary().final_cost);
+              optimizer.lastSummary().final_cost, stage_ms[0] / std::max(1, solves_seen), stage_ms[1] / std::max(1, solves_seen),
+              stage_ms[2] / std::max(1, solves_seen), stage_ms[3] / std::max(1, solves_seen));
   return 0;
 }

@@ -200,9 +200,9 @@ def config3(n_cp=512, n_landmarks=20000, obs_pairs=5):
     return w
 
 
-def small_visual(order=4, n_cp=16, n_landmarks=40, obs_pairs=3, bearing=False, seed=7, with_priors=0):
-    """Small window for oracle-sized parity tests."""
-    w, rng = _visual_window(SEED ^ (0x100 + seed), order, n_cp, n_landmarks, obs_pairs, bearing=bearing)
+def small_visual(order=4, n_cp=16, n_landmarks=40, obs_pairs=3, bearing=False, seed=7, with_priors=0, span=1.0):
+    """Small window for oracle-sized parity tests (`span` = seconds a landmark's observations are spread over)."""
+    w, rng = _visual_window(SEED ^ (0x100 + seed), order, n_cp, n_landmarks, obs_pairs, bearing=bearing, span=span)
     if with_priors:
         lo, hi = w.valid_range()
         q_bs = quat_exp(rng.uniform(1, 3, lo=-0.5, hi=0.5))

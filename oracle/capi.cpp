@@ -31,6 +31,32 @@ static void attach(hso_problem* p, LM* lm) {
     }                         \
   } while (0)
 
+/// Same input validation (and message) as the product library: every residual stamp must have all its control points.
+static int validate(hso_problem* p) {
+  const Problem& P = p->P;
+  const int n_seg = int(P.cp.size() / 8) - P.k + 1;
+  double u;
+  auto bad = [&](const std::vector<double>& st) {
+    for (double t : st) {
+      const int f = segment_of(t, P.t0, P.dt, P.k, &u);
+      if (f < 0 || f >= n_seg) return true;
+    }
+    return false;
+  };
+  if (bad(P.px_stamp) || bad(P.br_stamp)) return p->err = "visual residual stamp outside the valid range of the spline", HS_ERR_INVALID;
+  if (bad(P.pr_stamp)) return p->err = "prior residual stamp outside the valid range of the spline", HS_ERR_INVALID;
+  if (bad(P.in_stamp)) return p->err = "inertial residual stamp outside the valid range of the spline", HS_ERR_INVALID;
+  for (double t : P.in_stamp) {
+    const int f = segment_of(t, P.bias_t0, P.bias_dt, P.kb, &u);
+    if (f < 0 || f + P.kb > int(P.bias_g.size() / 4)) return p->err = "inertial residual stamp outside the valid range of the bias splines", HS_ERR_INVALID;
+  }
+  return HS_OK;
+}
+#define VALIDATE()                        \
+  do {                                    \
+    if (int rc_ = validate(p)) return rc_; \
+  } while (0)
+
 extern "C" {
 
 int hso_create(int, void*, hso_problem** out) {
@@ -150,6 +176,7 @@ int hso_residual_layout(hso_problem* p, int type, int idx, int32_t* num_blocks, 
 }
 
 int hso_linearize(hso_problem* p, int type, int robustify, const hs_linearization* out) {
+  VALIDATE();
   const Problem& P = p->P;
   const FactorType t = FactorType(type);
   const int n = P.n_res(t), k = P.k, kb = P.kb;
@@ -194,11 +221,13 @@ int hso_cost_function_evaluate(hso_problem* p, int type, int idx, const double* 
 }
 
 int hso_cost(hso_problem* p, double* cost) {
+  VALIDATE();
   *cost = Solver(p->P).total_cost();
   return HS_OK;
 }
 
 int hso_reduced_system(hso_problem* p, double radius, double* S, double* g) {
+  VALIDATE();
   LM lm(p->P);
   attach(p, &lm);
   lm.radius = radius;
@@ -228,6 +257,7 @@ int hso_set_shard(hso_problem* p, int rank, int world, int) {
 int hso_band_blocks(hso_problem*) { return 0; }
 
 int hso_solve(hso_problem* p, int max_iterations, hs_summary* summary, hs_iteration* iterations) {
+  VALIDATE();
   const auto t0 = std::chrono::steady_clock::now();
   LM lm(p->P);
   attach(p, &lm);

@@ -24,6 +24,10 @@ def windows():
     yield "bearing_k4", wb
     yield "pixel_prior_k4", synthetic.small_visual(order=4, n_cp=18, n_landmarks=40, obs_pairs=4, seed=10, with_priors=30)
     yield "prior_only", synthetic.config0(n_cp=32, n_prior=200)
+    # feature tracks as long as the window (EuRoC-like 3 s tracks): every landmark couples ~all control points, the band is
+    # wider than the register-resident factorisation handles and the wide-band kernel takes over
+    yield "pixel_long_tracks_k4", synthetic.small_visual(order=4, n_cp=34, n_landmarks=80, obs_pairs=6, seed=11, span=3.2)
+    yield "pixel_long_tracks_k6", synthetic.small_visual(order=6, n_cp=30, n_landmarks=80, obs_pairs=6, seed=12, span=3.0)
 
 
 @pytest.mark.parametrize("name,w", list(windows()), ids=[n for n, _ in windows()])

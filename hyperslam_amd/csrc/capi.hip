@@ -144,7 +144,7 @@ int prepare(hs_problem* p) {
   if (!build_visual_structure(in, &p->vs, &p->err)) return HS_ERR_INVALID;
   p->vs.bw = std::max(p->vs.bw, p->min_bw);
   const VisualStructure& vs = p->vs;
-  if (6 * vs.bw > kBlock || size_t(24) * (6 * vs.bw + 2) * 8 + size_t(12) * p->n_cp * 8 > size_t(p->chol_lds_max) || size_t(12) * p->n_cp * 8 > 60 * 1024)
+  if (6 * vs.bw > kBlock || (size_t(36) * (6 * vs.bw + 2) + size_t(6) * p->n_cp + 48) * 8 > size_t(p->chol_lds_max) || size_t(12) * p->n_cp * 8 > 60 * 1024)
     HS_FAIL(HS_ERR_INVALID, "landmark tracks span too many control points for the LDS-resident banded factorisation");
   const int n_vis = n_px + n_br;
 
@@ -446,9 +446,15 @@ int launch_factor(hs_problem* p) {
   hipStream_t s = p->stream;
   const int ncb = 6 * T.bw;
   const size_t chol_lds = (size_t(24) * (ncb + 2) + size_t(T.np)) * sizeof(double);
-  if (T.bw * T.bw <= kCholThreads)
+  const size_t la_lds = (size_t(36) * (ncb + 2) + size_t(T.np) + 48) * sizeof(double);
+  const bool legacy = T.debug_flags & 4;  // A/B switch: pre-look-ahead kernel
+  if (!legacy && T.bw * (T.bw - 2) <= kLaCompute)
+    k_band_factor_la<1><<<1, kLaThreads, la_lds, s>>>(T);
+  // (two tiles per lane need 168 accumulator registers: with six waves per workgroup the budget is 256 and the look-ahead
+  //  kernel spills in its update loop - wider bands stay on the kernel below)
+  else if (T.bw * T.bw <= kCholThreads)
     k_band_factor<1><<<1, kCholThreads + kCholIo, chol_lds, s>>>(T);
-  else if (T.bw * T.bw <= 2 * kCholThreads)
+  else if (T.bw * T.bw <= 2 * kCholThreads)  // bw = 21, 22: too many tiles for the look-ahead kernel's 192 compute lanes
     k_band_factor<2><<<1, kCholThreads + kCholIo, chol_lds, s>>>(T);
   else  // long feature tracks: trailing window in L2 instead of registers
     k_band_factor_wide<<<1, kWideThreads, size_t(6) * (ncb + 2) * sizeof(double), s>>>(T);
@@ -491,6 +497,7 @@ int set_func_attributes(hs_problem* p) {
   p->chol_lds_max = 160 * 1024 - int(fa.sharedSizeBytes);
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor<1>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor<2>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_la<1>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_visual<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_visual<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_forward), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));

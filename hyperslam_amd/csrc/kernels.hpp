@@ -1127,6 +1127,378 @@ __global__ void __launch_bounds__(kCholThreads + kCholIo) k_band_factor(Tables T
   lds_barrier();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Look-ahead variant (the one launched): the panel work of step i + 1 (finish the pivot row, factor its diagonal block,
+// solve X) is taken off the compute waves and runs in a dedicated PANEL wave concurrently with the rank-6 update of step i.
+//   waves 0-2  compute : register tiles of rows i + 2 .. i + bw - 1 (+ prefetched rows); P2(i) with X_i, then the owners of
+//                        row i + 2 publish it to rowbuf[(i + 2) & 1] and refill their registers with row i + 2 + bw.
+//                        Only band blocks kk <= bw - 3 ever receive an update before their row becomes the panel row, so only
+//                        those bw (bw - 2) tiles live in registers; the last two blocks go HBM -> rowbuf through the loader.
+//   wave  3    panel   : row i + 1 (in LDS since step i - 1, updated through X_(i-1)) -= X_i,1' X_i ; U_(i+1) = chol ; X_(i+1).
+//                        Waves are placed round-robin on the 4 SIMDs, so wave 3 has SIMD 3 to itself: sharing a SIMD with a
+//                        compute wave stretched this latency chain 2-3x (tools/microbench/factor_probe.hip: 750 clk alone).
+//   wave  4    loader  : streams block rows from HBM into the LDS stage two steps ahead (+ the tail blocks of row i + 2)
+//   wave  5    storer  : streams X_i (the factor row) to HBM, keeps y in LDS, inverts U_ii for the backward sweep
+// One LDS-only barrier per block row; critical path per step = max(panel chain, rank-6 update) instead of their sum.
+// LDS (doubles): rowbuf 2 x 6 x ld | xbuf 2 x 6 x ld | stage 2 x 6 x ld | y np | diagonal scratch 36.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kLaCompute = 192;
+constexpr int kLaThreads = kLaCompute + 3 * 64;
+
+template <int TPT>  // tiles per compute thread: bw * (bw - 2) <= TPT * kLaCompute
+__global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  DevState* st = T.st;
+  if (st->done) return;
+  const int tid = threadIdx.x;
+  constexpr int nthr = kLaCompute;
+  constexpr int PC = 2;  // columns of the pivot row per panel lane: 6 * bw + 1 <= 128 (bw <= 20)
+  const int bw = T.bw, ncb = 6 * bw, ld = ncb + 2;
+  const int n_blk = T.np / 6;
+  double* rowbuf = smem;            // row r (published by its owners, updated through X_(r-2)) in rowbuf[r & 1]
+  double* xbuf = smem + 12 * ld;    // [U_rr | X_r | y_r] in xbuf[r & 1]
+  double* stage = smem + 24 * ld;   // block row r staged by the loader in stage[r & 1]
+  double* xs = smem + 36 * ld;      // np : y (forward solve)
+  double* dscr = xs + T.np;         // 36 : updated diagonal block of the panel row
+  double* dinv = dscr + 36;         // 2 x 6 : 1 / diag(U_rr) in dinv[r & 1]
+  __shared__ int fail;
+  if (tid == 0) fail = 0;
+  const int wave = tid >> 6, l = tid & 63;
+  if (wave == 4 || wave == 5) {  // ================================ IO waves ================================
+    // lane l owns columns l and l + 64 of a block row ([band | rhs], 6 * bw + 1 <= 128 columns), all six rows: no index tables
+    int c_col[2];
+    bool c_ok[2], c_rhs[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int c = l + 64 * m;
+      c_ok[m] = c <= ncb, c_rhs[m] = c == ncb;
+      c_col[m] = c_ok[m] ? c : 0;
+    }
+    if (wave == 4) {
+      // two register sets: a block row is requested two steps before it is staged (the rows were written by another XCD's
+      // workgroups and come from HBM / MALL; one step of prefetch distance does not always cover that)
+      double va[12], vb[12];
+      auto fetch = [&](double* v, int r) {
+        const bool in = r < n_blk;
+        const int rr = in ? r : 0;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const double* src = c_rhs[m] ? T.g_s + 6 * rr : T.Sb + size_t(6 * rr) * ncb + c_col[m];
+          const int stride = c_rhs[m] ? 1 : ncb;
+#pragma unroll
+          for (int a = 0; a < 6; ++a) v[6 * m + a] = (c_ok[m] && in) ? src[a * stride] : 0.0;
+        }
+      };
+      auto put = [&](const double* v, double* dst) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          if (c_ok[m]) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) dst[a * ld + c_col[m]] = v[6 * m + a];
+          }
+      };
+      // tail blocks (band blocks bw - 2, bw - 1: 6 x 12 entries) of the row that is published this step: never modified before
+      // the row becomes the panel row, so they bypass the register tiles
+      const double* t_base[2];
+      int t_lds[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int e = l + 64 * m;
+        const int a = e < 72 ? e / 12 : 0, c = 6 * (bw - 2) + (e < 72 ? e % 12 : 0);
+        t_lds[m] = e < 72 ? a * ld + c : -1;
+        t_base[m] = T.Sb + a * ncb + c;
+      }
+      double ta[2], tb[2];
+      auto tfetch = [&](double* v, int r) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) v[m] = (t_lds[m] >= 0 && r < n_blk) ? t_base[m][size_t(r < n_blk ? r : 0) * 6 * ncb] : 0.0;
+      };
+      auto tput = [&](const double* v, double* dst) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          if (t_lds[m] >= 0) dst[t_lds[m]] = v[m];
+      };
+      fetch(va, 0), fetch(vb, 1);
+      put(va, rowbuf), put(vb, rowbuf + 6 * ld);
+      fetch(va, bw + 2), fetch(vb, bw + 3);
+      tfetch(tb, 2), tfetch(ta, 3);
+      put(va, stage + ((bw + 2) & 1) * 6 * ld);
+      fetch(va, bw + 4);
+      lds_barrier();  // init
+      lds_barrier();  // prologue
+      for (int i = 0; i < n_blk; i += 2) {
+        put(vb, stage + ((i + 3 + bw) & 1) * 6 * ld);
+        tput(tb, rowbuf + (i & 1) * 6 * ld);  // row i + 2
+        fetch(vb, i + 5 + bw);
+        tfetch(tb, i + 4);
+        if ((T.debug_flags & 16) && l == 0) reinterpret_cast<long long*>(T.xpart)[8 * i + 7] = wall_clock64();
+        lds_barrier();
+        if (i + 1 < n_blk) {
+          put(va, stage + ((i + 4 + bw) & 1) * 6 * ld);
+          tput(ta, rowbuf + ((i + 1) & 1) * 6 * ld);  // row i + 3
+          fetch(va, i + 6 + bw);
+          tfetch(ta, i + 5);
+          lds_barrier();
+        }
+      }
+      lds_barrier();
+    } else {
+      lds_barrier();  // init
+      lds_barrier();  // prologue: X_0 complete
+      for (int i = 0; i < n_blk; ++i) {
+        const double* xb = xbuf + (i & 1) * 6 * ld;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          if (c_ok[m]) {
+            double x[6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) x[a] = xb[a * ld + c_col[m]];
+            if (c_rhs[m]) {  // y stays in LDS until the end
+#pragma unroll
+              for (int a = 0; a < 6; ++a) xs[6 * i + a] = x[a];
+            } else {
+              double* dst = T.Ub + size_t(6 * i) * ncb + c_col[m];
+#pragma unroll
+              for (int a = 0; a < 6; ++a) dst[a * ncb] = x[a];
+            }
+          }
+        {  // W = U_ii^-1 (upper triangular) for the backward sweep (x_i = W y_i, no divisions there): lane c < 6 solves U w = e_c;
+           // 1 / u_aa comes from the panel wave (dinv), entries below the diagonal come out as exact zeros
+          const double* di = dinv + (i & 1) * 6;
+          const int c = l < 6 ? l : 0;
+          double w[6];
+#pragma unroll
+          for (int a = 5; a >= 0; --a) {
+            double t = a == c ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = a + 1; k < 6; ++k) t = fma(-xb[a * ld + k], w[k], t);
+            w[a] = t * di[a];
+          }
+          if (l < 6) {
+            // packed upper storage index of (a, c), a <= c
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+              if (a <= c) T.Ubk[size_t(i) * 24 + (a * 6 - a * (a - 1) / 2 + (c - a))] = w[a];
+          }
+        }
+        if ((T.debug_flags & 16) && l == 0) reinterpret_cast<long long*>(T.xpart)[8 * i + 6] = wall_clock64();
+        lds_barrier();
+      }
+      lds_barrier();
+      for (int rho = l; rho < T.np; rho += 64) T.ybuf[rho] = xs[rho];  // y = U^-T g
+      if (l == 0) st->chol_failed = fail;
+    }
+    return;
+  }
+
+  if (wave == 3) {  // ================================ panel wave (alone on SIMD 3) ================================
+#define UIDX(a, c) ((a) * 6 - (a) * ((a)-1) / 2 + ((c) - (a)))
+    const bool pprof = (T.debug_flags & 16) && l == 0;
+    long long* plog = reinterpret_cast<long long*>(T.xpart);
+    // column bookkeeping of this lane (loop invariant): c = l + 64 m; lanes past the row write to the pad column ncb + 1
+    int c_rd[PC], c_src[PC], c_wr[PC];
+    bool c_live[PC];
+#pragma unroll
+    for (int m = 0; m < PC; ++m) {
+      const int c = l + 64 * m;
+      c_rd[m] = c <= ncb ? c : ncb + 1;
+      c_wr[m] = c_rd[m];
+      const int cs = c == ncb ? ncb : 6 + c;  // column of X_(r-1) that lands on column c of row r
+      c_live[m] = c <= ncb && (c == ncb || cs < ncb);
+      c_src[m] = c_live[m] ? cs : ncb + 1;
+    }
+    // Branch-free on purpose: a taken branch costs ~40 cycles on this chain (tools/microbench/clock_probe.hip).
+    auto panel = [&](int r, bool update) {  // pivot row r: rowbuf[r & 1] (- X_(r-1),1' X_(r-1)) -> xbuf[r & 1]
+      if (pprof) plog[8 * r + 2] = wall_clock64();
+      const double* row = rowbuf + (r & 1) * 6 * ld;
+      const double* xp = xbuf + ((r - 1) & 1) * 6 * ld;
+      double* xo = xbuf + (r & 1) * 6 * ld;
+      double v[PC][6];
+#pragma unroll
+      for (int m = 0; m < PC; ++m)
+#pragma unroll
+        for (int a = 0; a < 6; ++a) v[m][a] = row[a * ld + c_rd[m]];
+      if (update) {
+        double B[6][6];  // block 1 of X_(r-1): couples row r - 1 to row r
+#pragma unroll
+        for (int ap = 0; ap < 6; ++ap)
+#pragma unroll
+          for (int a = 0; a < 6; a += 2) {
+            const double2 t = *reinterpret_cast<const double2*>(&xp[ap * ld + 6 + a]);
+            B[ap][a] = t.x, B[ap][a + 1] = t.y;
+          }
+#pragma unroll
+        for (int m = 0; m < PC; ++m) {
+          double xc[6];
+#pragma unroll
+          for (int ap = 0; ap < 6; ++ap) {
+            const double t = xp[ap * ld + c_src[m]];
+            xc[ap] = c_live[m] ? t : 0.0;
+          }
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int ap = 0; ap < 6; ++ap) v[m][a] = fma(-B[ap][a], xc[ap], v[m][a]);
+        }
+      }
+      if (pprof) plog[8 * r + 3] = wall_clock64();
+      if (l < 6) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) dscr[6 * a + l] = v[0][a];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave: LDS is in order, only the compiler must not reorder
+      double U[21], inv[6], dmin;
+      {
+        int pidx = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int c = a; c < 6; ++c) U[pidx++] = dscr[6 * a + c];
+      }
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        double d = U[UIDX(a, a)];
+#pragma unroll
+        for (int k = 0; k < a; ++k) d = fma(-U[UIDX(k, a)], U[UIDX(k, a)], d);
+        // A non-positive pivot is not patched on this chain: it turns the rest of the factor into NaN / inf, `fail` is raised
+        // below and the step is rejected as invalid (k_decide also requires a finite model cost change).
+        dmin = a == 0 ? d : fmin(dmin, d);  // fmin drops a NaN operand only if the other is a number: checked with !(x > 0)
+        // 1 / sqrt(d): hardware estimate (2^-24 relative) + one third-order step, e = 1 - d y^2, y (1 + e/2 + 3 e^2/8): error ~ e^3
+        const double y = __builtin_amdgcn_rsq(d);
+        const double e = fma(-d * y, y, 1.0);
+        const double rs = fma(y * e, fma(0.375, e, 0.5), y);
+        inv[a] = rs;
+#pragma unroll
+        for (int c = a + 1; c < 6; ++c) {
+          double t = U[UIDX(a, c)];
+#pragma unroll
+          for (int k = 0; k < a; ++k) t = fma(-U[UIDX(k, a)], U[UIDX(k, c)], t);
+          U[UIDX(a, c)] = t * rs;
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 6; ++a) dinv[(r & 1) * 6 + a] = inv[a];  // every lane, same value
+      if (!(dmin > 0.0) && l == 0) fail = 1;
+      if (pprof) plog[8 * r + 4] = wall_clock64();
+#pragma unroll
+      for (int m = 0; m < PC; ++m) {
+        // x = U^-T v. For the diagonal-block columns (c < 6) this reproduces column c of U itself in its upper part (same
+        // operations as the factorisation above); the diagonal and the part below it are never read (the backward sweep and the
+        // border use U_ii^-1 from Ubk, W is built from the strict upper part and dinv).
+        double x[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          double t = v[m][a];
+#pragma unroll
+          for (int k = 0; k < a; ++k) t = fma(-U[UIDX(k, a)], x[k], t);
+          x[a] = t * inv[a];
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) xo[a * ld + c_wr[m]] = x[a];
+      }
+      if (pprof) plog[8 * r + 5] = wall_clock64();
+    };
+    lds_barrier();  // init: rows 0, 1 in rowbuf
+    panel(0, false);
+    lds_barrier();  // prologue
+    for (int i = 0; i < n_blk; ++i) {
+      if (i + 1 < n_blk) panel(i + 1, true);
+      lds_barrier();
+    }
+    lds_barrier();
+#undef UIDX
+    return;
+  }
+
+  // ================================ compute waves: static tile ownership ================================
+  int t_kk[TPT], t_row[TPT];
+  bool t_ok[TPT];
+  double acc[TPT][36], rhs[TPT][6];
+#pragma unroll
+  for (int m = 0; m < TPT; ++m) {
+    const int tl = tid + m * nthr;
+    t_ok[m] = tl < bw * (bw - 2);
+    const int slot = t_ok[m] ? tl / (bw - 2) : 0;
+    t_kk[m] = t_ok[m] ? tl % (bw - 2) : 0;
+    t_row[m] = slot < 2 ? slot + bw : slot;  // rows 0 and 1 start in LDS (loader); their slots prefetch rows bw, bw + 1
+  }
+#pragma unroll
+  for (int m = 0; m < TPT; ++m) {
+    const int r = t_row[m];
+    const bool in = t_ok[m] && r < n_blk;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const double* src = T.Sb + size_t(6 * (in ? r : 0) + a) * ncb + 6 * t_kk[m];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc[m][6 * a + c] = in ? src[c] : 0.0;
+      rhs[m][a] = (in && t_kk[m] == 0) ? T.g_s[6 * r + a] : 0.0;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  lds_barrier();  // init
+  lds_barrier();  // prologue: X_0 complete
+  const bool prof = (T.debug_flags & 16) && tid == 0;
+  long long* tlog = reinterpret_cast<long long*>(T.xpart);
+  for (int i = 0; i < n_blk; ++i) {
+    if (prof) tlog[8 * i + 0] = wall_clock64();
+    const double* xb = xbuf + (i & 1) * 6 * ld;
+#pragma unroll
+    for (int m = 0; m < TPT; ++m) {
+      const int j = t_row[m] - i;
+      if (!t_ok[m] || j < 2 || j > bw - 1) continue;
+      if (j + t_kk[m] <= bw - 1 && !(T.debug_flags & 2)) {  // rank-6 update  S_(i+j),kk -= X_j' X_(j+kk)
+        const int ca = 6 * j, cb = 6 * (j + t_kk[m]);
+        // software pipelined over the six rows of X: the operands of row a + 1 are requested before the 36 FMAs of row a, and
+        // the scheduler may not hoist more than that (all 72 operands in flight at once spills the register tiles at TPT = 2)
+        double xa[2][6], xc[2][6];
+        auto fetch_x = [&](int a, int b) {
+#pragma unroll
+          for (int c = 0; c < 6; c += 2) {
+            const double2 va = *reinterpret_cast<const double2*>(&xb[a * ld + ca + c]);
+            const double2 vb = *reinterpret_cast<const double2*>(&xb[a * ld + cb + c]);
+            xa[b][c] = va.x, xa[b][c + 1] = va.y, xc[b][c] = vb.x, xc[b][c + 1] = vb.y;
+          }
+        };
+        fetch_x(0, 0);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          const int b = a & 1;
+          if (a < 5) fetch_x(a + 1, b ^ 1);
+#pragma unroll
+          for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) acc[m][6 * r + c] = fma(-xa[b][r], xc[b][c], acc[m][6 * r + c]);
+          if (t_kk[m] == 0) {
+            const double y = xb[a * ld + ncb];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) rhs[m][r] = fma(-xa[b][r], y, rhs[m][r]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (j == 2) {  // row i + 2 becomes the panel row of the next step: publish, then prefetch row i + 2 + bw into the registers
+        double* dst = rowbuf + (i & 1) * 6 * ld;
+        const double* src = stage + ((i + 2 + bw) & 1) * 6 * ld;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+          for (int c = 0; c < 6; c += 2) {
+            *reinterpret_cast<double2*>(&dst[a * ld + 6 * t_kk[m] + c]) = make_double2(acc[m][6 * a + c], acc[m][6 * a + c + 1]);
+            const double2 t = *reinterpret_cast<const double2*>(&src[a * ld + 6 * t_kk[m] + c]);
+            acc[m][6 * a + c] = t.x, acc[m][6 * a + c + 1] = t.y;
+          }
+          if (t_kk[m] == 0) dst[a * ld + ncb] = rhs[m][a];
+          rhs[m][a] = t_kk[m] == 0 ? src[a * ld + ncb] : 0.0;
+        }
+        t_row[m] = i + 2 + bw;
+      }
+    }
+    if (prof) tlog[8 * i + 1] = wall_clock64();
+    lds_barrier();
+  }
+  lds_barrier();
+}
+
 /// Fallback factorisation for wide bands (long feature tracks: bw * bw > 2 * kCholThreads): same algorithm and outputs
 /// (Ub, U_ii^-1, y) but the trailing window stays in HBM/L2 (in place in Sb) instead of registers. One workgroup of 1024 lanes.
 constexpr int kWideThreads = 1024;

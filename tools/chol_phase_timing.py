@@ -6,10 +6,16 @@ w=synthetic.config1()
 p=ha.Problem(w); p.snapshot()
 for i in range(2): p.restore(); s=p.solve(1)
 lib=_lib.load().cdll
-buf=np.zeros(8*128, np.int64)
+buf=np.zeros(16*1024+8*128, np.int64)
 lib.hs_debug_read.argtypes=[C.c_void_p, C.c_void_p, C.c_int]
-lib.hs_debug_read(p.h, buf.ctypes.data, 8*128)
-t=buf.reshape(128,8)
-d=np.diff(t[:, :6], axis=1)
-print("wall_clock units; median per phase [P1, barA, P2, P3, barB]:", np.median(d[10:110],axis=0), "step:", np.median(np.diff(t[10:110,0])))
+lib.hs_debug_read(p.h, buf.ctypes.data, len(buf))
+t=buf[:8*128].reshape(128,8); t2=buf[8*1024:8*1024+8*128].reshape(128,8); t3=buf[16*1024:].reshape(128,8)
+# compute wave 0: [0] step start, [1] rank-6 update + publish done; panel wave (row r): [2] start, [3] row updated, [4] factored, [5] X written
+r = slice(10, 110)
+print("units of 10 ns. step:", np.median(np.diff(t[r, 0])), " compute P2+publish:", np.median(t[r, 1] - t[r, 0]))
+print("panel: update", np.median(t[r, 3] - t[r, 2]), " factor", np.median(t[r, 4] - t[r, 3]), " solve+write", np.median(t[r, 5] - t[r, 4]),
+      " panel start after step start (row r vs step r-1):", np.median(t[11:111, 2] - t[10:110, 0]))
+ev = slice(10, 110, 2)
+print("arrival at the step barrier relative to step start: compute", np.median(t[ev, 1] - t[ev, 0]), " panel(row r+1)", np.median(t[11:111:2, 5] - t[ev, 0]),
+      " storer", np.median(t[ev, 6] - t[ev, 0]), " loader", np.median(t[ev, 7] - t[ev, 0]))
 print("solve_ms", s["solve_ms"])

@@ -58,6 +58,23 @@ def pmc_traffic(kernel):
         return None
 
 
+def rocprof_kernel_ms(kernel_prefix):
+    """Average duration of the kernel in the committed rocprofv3 --kernel-trace --stats summary of this command, or None."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            for row in csv.DictReader(f):
+                if row["Name"].startswith(kernel_prefix):
+                    return float(row["AverageNs"]) * 1e-6
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,7 +169,10 @@ def main():
             "roofline": {"kernel": "hs::k_linearize_visual<4>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("hs::k_linearize_visual<4>"),
                          "algorithmic_bytes_per_launch": B_ALG_PIXEL_K4 * n_blocks_local, "avg_launch_ms": lin_ms,
-                         "note": "traffic = FETCH_SIZE + WRITE_SIZE of profiles/r01_pmc_hbm_traffic.json (separate rocprofv3 --pmc passes)"},
+                         "rocprof_avg_kernel_ms": rocprof_kernel_ms("void hs::k_linearize_visual<4>"),
+                         "note": "avg_launch_ms = HIP events around the launch on the library's stream (includes ~6 us dispatch latency); "
+                                 "rocprof_avg_kernel_ms = committed rocprofv3 kernel-trace average of this command (profiles/); "
+                                 "traffic = FETCH_SIZE + WRITE_SIZE of profiles/r01_pmc_hbm_traffic.json (separate rocprofv3 --pmc passes)"},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(full if world == 1 else window)

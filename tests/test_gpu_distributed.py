@@ -28,3 +28,17 @@ def test_sharded_hip_matches_single_process(which, tmp_path, hip):
         ids = r["lm_ids"]
         assert rel(r["lm"][ids], lm[ids]) < 1e-7
     assert np.array_equal(ranks[0]["S"], ranks[1]["S"]) and np.array_equal(ranks[0]["cp"], ranks[1]["cp"])
+
+
+def test_rccl_hook_single_rank(tmp_path):
+    """backend "nccl" (= RCCL) on the library's device buffer and stream; a one-rank sum must leave the solve bit-identical."""
+    import os
+    import subprocess
+    import sys
+    out = str(tmp_path / "rccl.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_rccl_worker.py"), out], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = np.load(out)
+    assert np.array_equal(d["c0"], d["c1"]) and np.array_equal(d["cp0"], d["cp1"])

@@ -96,7 +96,9 @@ struct hs_problem {
   DBuf<double> d_scale_p, d_Sb, d_Ub, d_Ubk, d_g_s, d_g_full, d_D2p, d_step_p, d_delta_p;
   DBuf<double> d_cost_part, d_cand_part, d_norm_part, d_dbg, d_dbg_cost;
   DBuf<DevState> d_state;
-  DBuf<double> d_xbuf, d_xpart;
+  DBuf<double> d_xbuf, d_xpart, d_segP, d_grpQ;
+  DBuf<int> d_gw_ptr, d_gw_cf, d_sw_ptr, d_sw_seg;
+  int n_seg_wg = 0, n_group_wg = 0;
   DBuf<double> d_ybuf, d_scale_b, d_Spb, d_Sbb, d_gb_s, d_D2b, d_Zb, d_Cb, d_hb, d_xb, d_delta_b, d_bias_g_snap, d_bias_a_snap, d_gravity_snap;
   DBuf<int> d_i_bias_ptr;
   int n_split = 1;
@@ -331,6 +333,35 @@ int prepare(hs_problem* p) {
   // split the accumulation over enough workgroups to fill the chip (256 CUs x a few workgroups)
   p->n_split = std::max(1, std::min(16, 2048 / std::max(p->n_cp, 1)));
   HIP_TRY(p->d_xpart.reserve(size_t(x_count1) * p->n_split));
+  {  // owner-computes reduced system: segment partials and landmark-group partials
+    const int n_seg_ = p->n_cp - k + 1, nca = 6 * k, ntile = vs.bw * (vs.bw + 1) / 2;
+    // k_seg_gram work list: ~96 visual-record equivalents per workgroup (one LDS stage)
+    std::vector<int> sw_ptr(n_seg_ + 1, 0), sw_seg;
+    for (int f = 0; f < n_seg_; ++f) {
+      const int load = (vs.seg_ptr[f + 1] - vs.seg_ptr[f]) + 3 * (p->pr_seg_ptr[f + 1] - p->pr_seg_ptr[f]) +
+                       (p->in_seg_ptr.empty() ? 0 : 3 * (p->in_seg_ptr[f + 1] - p->in_seg_ptr[f]));
+      const int nw = std::max(1, (load + 95) / 96);
+      sw_ptr[f + 1] = sw_ptr[f] + nw;
+      for (int w = 0; w < nw; ++w) sw_seg.push_back(f);
+    }
+    p->n_seg_wg = sw_ptr[n_seg_];
+    sw_seg.push_back(0);
+    HIP_TRY(p->d_sw_ptr.upload(sw_ptr, s));
+    HIP_TRY(p->d_sw_seg.upload(sw_seg, s));
+    // k_group_gram work list: ~8 landmarks per workgroup
+    std::vector<int> gw_ptr(p->n_cp + 1, 0), gw_cf;
+    for (int c = 0; c < p->n_cp; ++c) {
+      const int cnt = vs.cf_ptr[c + 1] - vs.cf_ptr[c], nw = (cnt + 7) / 8;
+      gw_ptr[c + 1] = gw_ptr[c] + nw;
+      for (int w = 0; w < nw; ++w) gw_cf.push_back(c);
+    }
+    p->n_group_wg = gw_ptr[p->n_cp];
+    gw_cf.push_back(0);
+    HIP_TRY(p->d_gw_ptr.upload(gw_ptr, s));
+    HIP_TRY(p->d_gw_cf.upload(gw_cf, s));
+    HIP_TRY(p->d_segP.reserve(size_t(p->n_seg_wg) * (size_t(nca) * nca + nca)));
+    HIP_TRY(p->d_grpQ.reserve(size_t(p->n_group_wg) * (size_t(ntile) * 36 + 6 * vs.bw) + 1));
+  }
   for (int i = 0; i < p->n_cp; ++i) {
     const int cover = vs.cf_ptr[i + 1] - vs.cf_ptr[std::max(0, i - vs.bw + 1)];
     if ((cover + p->n_split - 1) / p->n_split > kMaxMine) HS_FAIL(HS_ERR_INVALID, "too many landmarks cover one control point for the reduced-system gather");
@@ -368,7 +399,7 @@ int prepare(hs_problem* p) {
   T.cost_part = p->d_cost_part.p, T.cand_part = p->d_cand_part.p, T.n_cost_part = p->nb_vis + p->nb_pri + p->nb_ine;
   T.norm_part = p->d_norm_part.p, T.n_norm_part = nb_norm;
   T.xbuf = p->d_xbuf.p;
-  T.xpart = p->d_xpart.p;
+  T.xpart = p->d_xpart.p, T.segP = p->d_segP.p, T.grpQ = p->d_grpQ.p, T.gw_ptr = p->d_gw_ptr.p, T.gw_cf = p->d_gw_cf.p, T.sw_ptr = p->d_sw_ptr.p, T.sw_seg = p->d_sw_seg.p;
   T.xo_g = np * ncb, T.xo_gs = T.xo_g + np, T.xo_dj = T.xo_gs + np, T.xo_pb = T.xo_dj + np, T.xo_bb = T.xo_pb + np * nbd;
   T.xo_gb = T.xo_bb + nbd * nbd, T.xo_cost = T.xo_gb + nbd, T.xo_gmax = T.xo_cost + 1;
   T.ybuf = p->d_ybuf.p, T.scale_b = p->d_scale_b.p, T.Spb = p->d_Spb.p, T.Sbb = p->d_Sbb.p, T.gb_s = p->d_gb_s.p, T.D2b = p->d_D2b.p;
@@ -422,14 +453,35 @@ int launch_build(hs_problem* p) {
     else  // long feature tracks (6 * bw <= kBlock is checked in prepare())
       k_landmark<K, 4><<<grid, kBlock, 0, s>>>(T);
   }
-  const size_t lds = (size_t(6) * 6 * T.bw + 16 + 6 * kBlock + 64) * sizeof(double) + 3 * kMaxMine * sizeof(int);
-  k_build_raw<K><<<dim3(T.sp.n_cp, p->n_split), kBlock, lds, s>>>(T);
+  const bool gather = T.debug_flags & 8;  // A/B switch: gather formulation (re-reads every record K times)
+  if (gather) {
+    const size_t lds = (size_t(6) * 6 * T.bw + 16 + 6 * kBlock + 64) * sizeof(double) + 3 * kMaxMine * sizeof(int);
+    k_build_raw<K><<<dim3(T.sp.n_cp, p->n_split), kBlock, lds, s>>>(T);
+  } else {
+    k_seg_gram<K><<<p->n_seg_wg, kBlock, kSegStage * sizeof(double), s>>>(T);
+    if (T.n_lm && p->n_group_wg) {
+      const int ntile = T.bw * (T.bw + 1) / 2;
+      const int batch = std::max(2, std::min(kGroupBatch, int(48 * 1024 / (size_t(18) * T.bw * sizeof(double)))));
+      const size_t lds = std::max((size_t(batch) * 18 * T.bw + 4 * batch) * sizeof(double), size_t(128) * 42 * sizeof(double));
+      const dim3 grid(p->n_group_wg);
+      if (ntile <= kBlock)
+        k_group_gram<1><<<grid, kBlock, lds, s>>>(T, batch);
+      else if (ntile <= 2 * kBlock)
+        k_group_gram<2><<<grid, kBlock, lds, s>>>(T, batch);
+      else
+        k_group_gram<4><<<grid, kBlock, lds, s>>>(T, batch);
+    }
+    k_assemble<K><<<dim3(T.sp.n_cp, 6), kAsmThreads, 0, s>>>(T);
+  }
   if (T.nb) {
     k_border_pb<K><<<dim3(T.sp.n_cp, p->n_split), 128, 0, s>>>(T);
     k_border_zero<<<std::min(64, (T.nb * T.nb + T.nb + kBlock - 1) / kBlock), kBlock, 0, s>>>(T);
     k_border_bb<K><<<(T.n_bias + 1 + kBlock / 64 - 1) / (kBlock / 64), kBlock, 0, s>>>(T);
   }
-  k_reduce_partials<<<std::min(1024, (T.xo_bb + kBlock - 1) / kBlock), kBlock, 0, s>>>(T, p->n_split);
+  if (gather)
+    k_reduce_partials<<<std::min(1024, (T.xo_bb + kBlock - 1) / kBlock), kBlock, 0, s>>>(T, p->n_split, 0);
+  else if (T.nb)
+    k_reduce_partials<<<std::min(1024, (T.xo_bb - T.xo_pb + kBlock - 1) / kBlock), kBlock, 0, s>>>(T, p->n_split, T.xo_pb);
   k_pack_exchange<<<1, kBlock, 0, s>>>(T);
   HIP_TRY(hipGetLastError());
   const int rc = exchange(p, T.xbuf, T.x_count1);  // one RCCL all-reduce of [S | g | diag | cost] per linearisation
@@ -498,6 +550,8 @@ int set_func_attributes(hs_problem* p) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor<1>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor<2>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_la<1>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seg_gram<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seg_gram<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_visual<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_visual<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_forward), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));

@@ -482,11 +482,328 @@ __global__ void __launch_bounds__(kBlock) k_build_raw(Tables T) {
   }
 }
 
-/// xbuf[e] = sum over the accumulation splits (fixed order => bit-reproducible). The result is additive across residual shards.
-__global__ void __launch_bounds__(kBlock) k_reduce_partials(Tables T, int nsp) {
+// ---------------------------------------------------------------------------------------------------------------------
+// Reduced system, owner-computes formulation (the one launched): every record and every Y-hat row is read ONCE.
+//   k_seg_gram<K>   : one workgroup per (segment, split): P = sum J_p' J_p (6K x 6K) and J_p' r over the segment's records
+//   k_group_gram<NT>: one workgroup per (first control point c, split): Q = - sum_l Yh_l Yh_l' over the landmarks whose
+//                     track starts at c (6 bw x 6 bw window, upper 6x6 tiles), q = - sum_l Yh_l yh_l
+//   k_assemble<K>   : block row i = sum of the <= K segment partials and <= bw group partials that overlap it, in a fixed
+//                     order (bit-reproducible, no floating-point atomics), written straight into the exchange buffer
+// The gather version above (k_build_raw) re-read each record K times and each Y-hat row once per covered control point.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kSegStage = 6144;  // doubles of record data staged in LDS per round (48 KB)
+
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_seg_gram(Tables T) {
+  extern __shared__ __attribute__((aligned(16))) double stage[];  // kSegStage doubles: a contiguous run of records
+  __shared__ __attribute__((aligned(16))) double red[kBlock * 12 + kBlock * 3];
   if (T.st->done) return;
-  const int n = T.xo_bb;  // [Sraw | g_p | g_schur | diag | Hpb]
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+  constexpr int NCA = 6 * K, RG = NCA / 3, CG = NCA / 4, TPS = RG * CG, NS = kBlock / TPS;  // 3x4 register tiles, NS record streams
+  constexpr int VREC = 8 + 12 * K, PREC = 6 + 36 * K;
+  // work list: workgroup w serves segment sw_seg[w] as split sp of nsp (splits proportional to the segment's record count: the
+  // first and last segment of a window collect the clamped stamps)
+  const int first = T.sw_seg[blockIdx.x], sp = blockIdx.x - T.sw_ptr[first], nsp = T.sw_ptr[first + 1] - T.sw_ptr[first];
+  const int tid = threadIdx.x;
+  const int stream = tid / TPS, tb = tid % TPS, rg = tb / CG, cg = tb % CG;
+  const bool sprof = (T.debug_flags & 32) && tid == 0 && sp == 0 && first < 128;
+  long long* slog = reinterpret_cast<long long*>(T.xpart) + 8 * 1024 + 8 * first;
+  if (sprof) slog[0] = wall_clock64();
+  // a tile is needed if some column block >= the row block (upper block triangle); column group 0 also carries J'r
+  const bool live = stream < NS && (cg == 0 || (4 * cg + 3) / 6 >= (3 * rg) / 6);
+  double acc[3][4], gacc[3] = {0, 0, 0};
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
+  // Records of a segment are contiguous (segment-major), split `sp` takes a contiguous share: one coalesced sweep brings a run
+  // of records into LDS (a single HBM round trip instead of one per record), the streams then walk it from LDS.
+  auto run = [&](const double* recs, int r0, int r1, int REC, int n_rows, int joff) {
+    const int n = r1 - r0, lo = r0 + int((long long)n * sp / nsp), hi = r0 + int((long long)n * (sp + 1) / nsp);
+    const int per = kSegStage / REC;
+    for (int c0 = lo; c0 < hi; c0 += per) {
+      const int cnt = min(per, hi - c0);
+      __syncthreads();
+      const double2* src = reinterpret_cast<const double2*>(recs + size_t(c0) * REC);
+      const int n2 = cnt * REC / 2;
+      for (int e0 = tid; e0 < n2; e0 += 8 * kBlock) {  // eight independent 16-byte loads in flight per lane
+        double2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * kBlock;
+          v[u] = e < n2 ? src[e] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * kBlock;
+          if (e < n2) reinterpret_cast<double2*>(stage)[e] = v[u];
+        }
+      }
+      __syncthreads();
+      if (sprof) slog[1] = wall_clock64();
+      if (live)
+        for (int c = stream; c < cnt; c += NS) {
+          const double* rec = stage + c * REC;
+#pragma unroll 2
+          for (int r = 0; r < n_rows; ++r) {
+            const double* j = rec + joff + r * NCA;
+            const double a0 = j[3 * rg], a1 = j[3 * rg + 1], a2 = j[3 * rg + 2];
+            const double2 b01 = *reinterpret_cast<const double2*>(j + 4 * cg), b23 = *reinterpret_cast<const double2*>(j + 4 * cg + 2);
+            acc[0][0] = fma(a0, b01.x, acc[0][0]), acc[0][1] = fma(a0, b01.y, acc[0][1]), acc[0][2] = fma(a0, b23.x, acc[0][2]), acc[0][3] = fma(a0, b23.y, acc[0][3]);
+            acc[1][0] = fma(a1, b01.x, acc[1][0]), acc[1][1] = fma(a1, b01.y, acc[1][1]), acc[1][2] = fma(a1, b23.x, acc[1][2]), acc[1][3] = fma(a1, b23.y, acc[1][3]);
+            acc[2][0] = fma(a2, b01.x, acc[2][0]), acc[2][1] = fma(a2, b01.y, acc[2][1]), acc[2][2] = fma(a2, b23.x, acc[2][2]), acc[2][3] = fma(a2, b23.y, acc[2][3]);
+            if (cg == 0) {
+              const double rr = rec[r];
+              gacc[0] = fma(a0, rr, gacc[0]), gacc[1] = fma(a1, rr, gacc[1]), gacc[2] = fma(a2, rr, gacc[2]);
+            }
+          }
+        }
+    }
+  };
+  run(T.v_rec, T.v_seg_ptr[first], T.v_seg_ptr[first + 1], VREC, 2, 8);
+  if (T.n_pri) run(T.p_rec, T.p_seg_ptr[first], T.p_seg_ptr[first + 1], PREC, 6, 6);
+  if (T.n_ine) run(T.i_rec, T.i_seg_ptr[first], T.i_seg_ptr[first + 1], 18 + 36 * K + 2 * T.kb, 6, 6);
+  if (sprof) slog[2] = wall_clock64();
+  // combine the record streams in index order
+  double* racc = red;                 // [stream][TPS][12]
+  double* rg3 = red + kBlock * 12;    // [stream][RG][3]
+  if (stream < NS) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) racc[(stream * TPS + tb) * 12 + 4 * r + c] = acc[r][c];
+    if (cg == 0)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) rg3[(stream * RG + rg) * 3 + r] = gacc[r];
+  }
+  __syncthreads();
+  double* P = T.segP + size_t(blockIdx.x) * (NCA * NCA + NCA);
+  for (int e = tid; e < NCA * NCA; e += kBlock) {
+    const int a = e / NCA, c = e % NCA;
+    const int t = (a / 3) * CG + c / 4, in = 4 * (a % 3) + c % 4;
+    double v = 0.0;
+#pragma unroll
+    for (int st = 0; st < NS; ++st) v += racc[(st * TPS + t) * 12 + in];
+    P[e] = v;  // tiles below the block diagonal were never accumulated (zeros) and are never read
+  }
+  if (tid < NCA) {
+    double v = 0.0;
+#pragma unroll
+    for (int st = 0; st < NS; ++st) v += rg3[(st * RG + tid / 3) * 3 + tid % 3];
+    P[NCA * NCA + tid] = v;
+  }
+  if (sprof) slog[3] = wall_clock64();
+}
+
+HSD int ok_index(int b, int nb) { return b < nb ? b : 0; }
+
+/// Upper 6x6 tiles of the 6 bw x 6 bw window of a landmark group: tile index of (rb, cb), rb <= cb < bw.
+HSD int group_tile_index(int rb, int cb, int bw) { return rb * bw - rb * (rb - 1) / 2 + (cb - rb); }
+
+constexpr int kGroupBatch = 16;  // landmarks staged in LDS per round (host caps it so that the stage fits 48 KB)
+
+template <int NT>  // tiles per thread: NT == 1: two landmark streams of 128 lanes (bw <= 15); NT > 1: one stream, bw (bw + 1) / 2 <= NT * kBlock
+__global__ void __launch_bounds__(kBlock) k_group_gram(Tables T, int batch) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  __shared__ int m_ncp[kBlock], m_off[kBlock];
+  if (T.st->done) return;
+  // work list: workgroup w serves group cf = gw_cf[w] as split sp of nsp (splits proportional to the group's landmark count:
+  // the first control point of a window collects every track that started before it)
+  const int cf = T.gw_cf[blockIdx.x], sp = blockIdx.x - T.gw_ptr[cf], nsp = T.gw_ptr[cf + 1] - T.gw_ptr[cf];
+  const int tid = threadIdx.x;
+  const int bw = T.bw, R = 6 * bw, ntile = bw * (bw + 1) / 2;
+  double* ybuf = smem;                          // batch x (R x 3): Y-hat rows (zero past the landmark's rows)
+  double* yh = smem + size_t(batch) * R * 3;    // batch x 4: y-hat
+  const bool two = NT == 1 && ntile <= kBlock / 2;  // two landmark streams
+  const int stream = two ? tid / (kBlock / 2) : 0, nstream = two ? 2 : 1;
+  const int lt = two ? tid % (kBlock / 2) : tid, lthreads = two ? kBlock / 2 : kBlock;
+  int t_rb[NT], t_cb[NT];
+  bool t_ok[NT];
+  double acc[NT][36], qacc[NT][6];
+#pragma unroll
+  for (int m = 0; m < NT; ++m) {
+    const int t = lt + m * lthreads;
+    t_ok[m] = t < ntile;
+    int rb = 0, rem = t_ok[m] ? t : 0;
+    while (rem >= bw - rb) rem -= bw - rb, ++rb;  // row rb holds bw - rb tiles
+    t_rb[m] = rb, t_cb[m] = rb + rem;
+#pragma unroll
+    for (int e = 0; e < 36; ++e) acc[m][e] = 0.0;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) qacc[m][e] = 0.0;
+  }
+  const bool gprof = (T.debug_flags & 32) && tid == 0 && sp == 0 && cf < 128;
+  long long* glog = reinterpret_cast<long long*>(T.xpart) + 8 * cf;
+  if (gprof) glog[0] = wall_clock64();
+  const int dl0 = T.cf_ptr[cf], dl1 = T.cf_ptr[cf + 1];
+  const int n_mine = dl1 > dl0 + sp ? (dl1 - dl0 - sp + nsp - 1) / nsp : 0;  // landmarks dl = dl0 + sp + t * nsp
+  for (int t0 = 0; t0 < n_mine; t0 += kBlock) {  // (one pass unless a group holds more than 256 landmarks per split)
+    __syncthreads();
+    if (t0 + tid < n_mine) {
+      const int dl = dl0 + sp + (t0 + tid) * nsp;
+      m_ncp[tid] = T.lm_ncp[dl], m_off[tid] = T.lm_yoff[dl];
+    }
+    __syncthreads();
+    const int n_pass = min(kBlock, n_mine - t0);
+    if (gprof) glog[1] = wall_clock64();
+    for (int b0 = 0; b0 < n_pass; b0 += batch) {
+      const int nb = min(batch, n_pass - b0);
+      __syncthreads();
+      for (int e0 = tid; e0 < nb * R * 3; e0 += 8 * kBlock) {  // eight independent loads in flight per lane
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * kBlock, b = e / (R * 3), w = e % (R * 3);
+          const bool ok = e < nb * R * 3 && w < 18 * m_ncp[b0 + (ok_index(b, nb))];
+          v[u] = ok ? T.Y[m_off[b0 + ok_index(b, nb)] + w] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * kBlock;
+          if (e < nb * R * 3) ybuf[e] = v[u];
+        }
+      }
+      if (tid < 3 * nb) yh[4 * (tid / 3) + tid % 3] = T.lm_yhat[3 * (dl0 + sp + (t0 + b0 + tid / 3) * nsp) + tid % 3];
+      __syncthreads();
+      if (gprof) glog[2] = wall_clock64();
+      for (int b = stream; b < nb; b += nstream) {
+        const int ncp = m_ncp[b0 + b];
+        const double* Yb = ybuf + size_t(b) * R * 3;
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+          if (!t_ok[m] || t_cb[m] >= ncp) continue;
+          double A[18], B[18];
+#pragma unroll
+          for (int e = 0; e < 18; e += 2) {
+            const double2 va = *reinterpret_cast<const double2*>(Yb + 18 * t_rb[m] + e), vb = *reinterpret_cast<const double2*>(Yb + 18 * t_cb[m] + e);
+            A[e] = va.x, A[e + 1] = va.y, B[e] = vb.x, B[e + 1] = vb.y;
+          }
+#pragma unroll
+          for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+              acc[m][6 * r + c] = fma(-A[3 * r + 2], B[3 * c + 2], fma(-A[3 * r + 1], B[3 * c + 1], fma(-A[3 * r], B[3 * c], acc[m][6 * r + c])));
+          if (t_rb[m] == t_cb[m]) {
+            const double y0 = yh[4 * b], y1 = yh[4 * b + 1], y2 = yh[4 * b + 2];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) qacc[m][r] = fma(-A[3 * r + 2], y2, fma(-A[3 * r + 1], y1, fma(-A[3 * r], y0, qacc[m][r])));
+          }
+        }
+      }
+    }
+  }
+  if (gprof) glog[3] = wall_clock64(), glog[5] = n_mine;
+  double* Q = T.grpQ + size_t(blockIdx.x) * (size_t(ntile) * 36 + R);
+  if (two) {  // stream 1 hands its partial to stream 0 through LDS (fixed order: stream 0 + stream 1)
+    __syncthreads();
+    double* xch = smem;  // 128 x 42 doubles <= the stage
+    if (stream == 1 && t_ok[0]) {
+#pragma unroll
+      for (int e = 0; e < 36; ++e) xch[lt * 42 + e] = acc[0][e];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) xch[lt * 42 + 36 + e] = qacc[0][e];
+    }
+    __syncthreads();
+    if (stream == 0 && t_ok[0]) {
+#pragma unroll
+      for (int e = 0; e < 36; ++e) acc[0][e] += xch[lt * 42 + e];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) qacc[0][e] += xch[lt * 42 + 36 + e];
+    }
+    if (stream == 1) return;
+  }
+#pragma unroll
+  for (int m = 0; m < NT; ++m) {
+    if (!t_ok[m]) continue;
+    const int t = lt + m * lthreads;
+#pragma unroll
+    for (int e = 0; e < 36; e += 2) *reinterpret_cast<double2*>(Q + size_t(t) * 36 + e) = make_double2(acc[m][e], acc[m][e + 1]);
+    if (t_rb[m] == t_cb[m])
+#pragma unroll
+      for (int r = 0; r < 6; ++r) Q[size_t(ntile) * 36 + 6 * t_rb[m] + r] = qacc[m][r];
+  }
+  if (gprof) glog[4] = wall_clock64();
+}
+
+constexpr int kAsmThreads = 512, kAsmU = 8;  // lanes per scalar row, loads in flight per lane
+
+/// Scalar row rho = 6 i + a of the raw (unscaled, undamped) reduced system from the segment and group partials; writes xbuf
+/// directly. Grid (n_cp, 6). The sources of an entry are dealt round-robin to `nsl` thread slices (loads of a slice are
+/// issued kAsmU at a time), the slices are combined through LDS in index order: fixed summation order, bit-reproducible.
+template <int K>
+__global__ void __launch_bounds__(kAsmThreads) k_assemble(Tables T) {
+  __shared__ double part[2][kAsmThreads];
+  if (T.st->done) return;
+  constexpr int NCA = 6 * K;
+  const int i = blockIdx.x, a = blockIdx.y, tid = threadIdx.x;
+  const int bw = T.bw, ncb = 6 * bw, R = 6 * bw, ntile = bw * (bw + 1) / 2;
+  const size_t pstride = NCA * NCA + NCA, qstride = size_t(ntile) * 36 + R;
+  const int f0 = max(0, i - K + 1), f1 = min(i, T.n_seg - 1);
+  const int c0 = max(0, i - bw + 1);
+  const int nent = ncb + 2;  // band entries + [J'r | Y-hat y-hat] of this row
+  const int nsl = max(1, kAsmThreads / nent), sl = tid / nent, c = tid % nent;
+  double va = 0.0, vb = 0.0;  // J'J part / Schur part
+  if (sl < nsl) {
+    const int kk = c / 6, cc = c % 6;
+    // ---- segment partials: the workgroups of segments f0 .. f1 are contiguous in the work list
+    const bool a_live = c < ncb ? kk < K : c == ncb;
+    if (a_live && f1 >= f0) {
+      const int p_lo = T.sw_ptr[f0], np_ = T.sw_ptr[f1 + 1] - p_lo;
+      for (int p0 = sl; p0 < np_; p0 += kAsmU * nsl) {
+        double v[kAsmU];
+#pragma unroll
+        for (int u = 0; u < kAsmU; ++u) {
+          const int p = p0 + u * nsl;
+          const int w = p_lo + (p < np_ ? p : 0), bi = i - T.sw_seg[w];
+          const bool ok = p < np_ && (c == ncb || bi + kk < K);
+          const size_t off = size_t(w) * pstride + (c == ncb ? NCA * NCA + 6 * bi + a : (6 * bi + a) * NCA + 6 * bi + c);
+          v[u] = ok ? T.segP[off] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kAsmU; ++u) va += v[u];
+      }
+    }
+    // ---- landmark-group partials: the workgroups of groups c0 .. i are contiguous in the work list
+    const bool b_live = T.n_lm > 0 && (c < ncb || c == ncb + 1);
+    if (b_live) {
+      const int q_lo = T.gw_ptr[c0], nq = T.gw_ptr[i + 1] - q_lo;
+      for (int q0 = sl; q0 < nq; q0 += kAsmU * nsl) {
+        double v[kAsmU];
+#pragma unroll
+        for (int u = 0; u < kAsmU; ++u) {
+          const int q = q0 + u * nsl;
+          const int w = q_lo + (q < nq ? q : 0), rb = i - T.gw_cf[w];
+          const bool ok = q < nq && (c > ncb || rb + kk < bw);
+          const size_t off = size_t(w) * qstride +
+                             (c > ncb ? size_t(ntile) * 36 + 6 * rb + a : size_t(group_tile_index(rb, ok ? rb + kk : rb, bw)) * 36 + 6 * a + cc);
+          v[u] = ok ? T.grpQ[off] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kAsmU; ++u) vb += v[u];
+      }
+    }
+  }
+  part[0][tid] = va, part[1][tid] = vb;
+  __syncthreads();
+  if (tid < nent) {
+    double sa = 0.0, sb = 0.0;
+    for (int q = 0; q < nsl; ++q) sa += part[0][q * nent + tid], sb += part[1][q * nent + tid];
+    const int rho = 6 * i + a;
+    if (tid < ncb) {
+      T.xbuf[size_t(rho) * ncb + tid] = sa + sb;
+      if (tid == a) T.xbuf[T.xo_dj + rho] = sa;
+    } else if (tid == ncb) {
+      T.xbuf[T.xo_g + rho] = sa;
+    } else {
+      T.xbuf[T.xo_gs + rho] = sb;
+    }
+  }
+}
+
+/// xbuf[e] = sum over the accumulation splits (fixed order => bit-reproducible). The result is additive across residual shards.
+__global__ void __launch_bounds__(kBlock) k_reduce_partials(Tables T, int nsp, int e0) {
+  if (T.st->done) return;
+  const int n = T.xo_bb;  // [Sraw | g_p | g_schur | diag | Hpb]; e0 = xo_pb when the pose part comes from k_assemble
+  for (int e = e0 + blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
     double s = 0.0;
     for (int k = 0; k < nsp; ++k) s += T.xpart[size_t(k) * T.x_count1 + e];
     T.xbuf[e] = s;

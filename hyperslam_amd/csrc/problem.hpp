@@ -159,6 +159,12 @@ struct Tables {
   int n_norm_part;
   // exchange buffer (additive across residual shards): [Sraw np*6bw | g_p np | g_schur np | diag np | H_pb np*nb | H_bb nb*nb | g_b nb | cost | gmax[world] | decision 5]
   double* xbuf;
+  const int* sw_ptr;  // n_seg + 1: workgroups of k_seg_gram serving segment f (splits ~ record count)
+  const int* sw_seg;  // segment of workgroup w
+  double* segP;   // per k_seg_gram workgroup: [J'J (6k x 6k) | J'r (6k)]
+  const int* gw_ptr;  // n_cp + 1: workgroups of k_group_gram serving landmark group c (splits ~ landmark count)
+  const int* gw_cf;   // group of workgroup w
+  double* grpQ;   // per k_group_gram workgroup: [upper 6x6 tiles of -sum Yh Yh' | -sum Yh yh (6 bw)]
   double* xpart;  // per-split partial copies of [Sraw | g_p | g_schur | diag] (stride x_count1)
   int xo_g, xo_gs, xo_dj, xo_pb, xo_bb, xo_gb, xo_cost, xo_gmax, xo_dec, x_count1;
   int rank, world;

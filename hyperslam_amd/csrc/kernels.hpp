@@ -42,6 +42,37 @@ HSD double block_sum(double v, double* lds /* >= blockDim/64 */) {
   return s;
 }
 
+/// Per-lane partial sum / max of a strided array with eight independent loads in flight (a plain `s += p[i]` loop keeps one
+/// load in flight per lane and pays the full memory latency per element). Fixed order: bit-reproducible.
+HSD double strided_sum(const double* __restrict__ p, int n, int stride = 1, int offset = 0) {
+  double s = 0.0;
+  for (int i0 = threadIdx.x; i0 < n; i0 += 8 * blockDim.x) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * blockDim.x;
+      v[u] = i < n ? p[size_t(i) * stride + offset] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  return s;
+}
+HSD double strided_max(const double* __restrict__ p, int n) {  // entries >= 0
+  double m = 0.0;
+  for (int i0 = threadIdx.x; i0 < n; i0 += 8 * blockDim.x) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * blockDim.x;
+      v[u] = i < n ? p[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) m = fmax(m, v[u]);
+  }
+  return m;
+}
+
 HSD void stage_cps(const double* __restrict__ src, double* dst, int n_doubles) {
   for (int i = threadIdx.x; i < n_doubles; i += blockDim.x) dst[i] = src[i];
   __syncthreads();
@@ -816,12 +847,10 @@ __global__ void __launch_bounds__(kBlock) k_pack_exchange(Tables T) {
   __shared__ double red[kBlock / 64];
   DevState* st = T.st;
   if (st->done) return;
-  double s = 0.0;
-  for (int i = threadIdx.x; i < T.n_cost_part; i += blockDim.x) s += T.cost_part[i];
+  double s = strided_sum(T.cost_part, T.n_cost_part);
+  double gm = strided_max(T.lm_gmax, T.n_obs_lm);
   s = block_sum(s, red);
   if (threadIdx.x == 0) T.xbuf[T.xo_cost] = s;
-  double gm = 0.0;
-  for (int l = threadIdx.x; l < T.n_obs_lm; l += blockDim.x) gm = fmax(gm, T.lm_gmax[l]);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) gm = fmax(gm, __shfl_xor(gm, o));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gm;
@@ -2108,9 +2137,7 @@ __global__ void __launch_bounds__(kBlock) k_retract(Tables T) {
 //   phase 1: after the candidate cost — accept / reject, radius update, termination tests.
 // ---------------------------------------------------------------------------------------------------------------------
 HSD double ordered_sum(const double* p, int n, double* lds) {
-  double s = 0.0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) s += p[i];
-  return block_sum(s, lds);
+  return block_sum(strided_sum(p, n), lds);
 }
 
 __global__ void __launch_bounds__(kBlock) k_cost_reduce(Tables T) {
@@ -2118,8 +2145,7 @@ __global__ void __launch_bounds__(kBlock) k_cost_reduce(Tables T) {
   __shared__ double red[kBlock / 64];
   DevState* st = T.st;
   if (st->done) return;
-  double gm = 0.0;
-  for (int e = threadIdx.x; e < T.np + T.nb; e += blockDim.x) gm = fmax(gm, T.gabs[e]);
+  double gm = strided_max(T.gabs, T.np + T.nb);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) gm = fmax(gm, __shfl_xor(gm, o));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gm;
@@ -2153,13 +2179,10 @@ __global__ void __launch_bounds__(kBlock) k_pack_decision(Tables T) {
   __shared__ double red[kBlock / 64];
   DevState* st = T.st;
   if (st->done) return;
-  double cand = 0.0, xs = 0.0, ss = 0.0, gd = 0.0, dd = 0.0;
-  for (int i = threadIdx.x; i < T.n_cost_part; i += blockDim.x) cand += T.cand_part[i];
-  for (int i = threadIdx.x; i < T.n_norm_part; i += blockDim.x) {
-    xs += T.norm_part[4 * i + 2], ss += T.norm_part[4 * i + 3];                        // landmarks (local)
-    if (T.rank == 0) xs += T.norm_part[4 * i], ss += T.norm_part[4 * i + 1];           // control points (replicated)
-  }
-  for (int l = threadIdx.x; l < T.n_lm; l += blockDim.x) gd += T.lm_mcc[2 * l], dd += T.lm_mcc[2 * l + 1];
+  double cand = strided_sum(T.cand_part, T.n_cost_part);
+  double xs = strided_sum(T.norm_part, T.n_norm_part, 4, 2), ss = strided_sum(T.norm_part, T.n_norm_part, 4, 3);  // landmarks (local)
+  if (T.rank == 0) xs += strided_sum(T.norm_part, T.n_norm_part, 4, 0), ss += strided_sum(T.norm_part, T.n_norm_part, 4, 1);  // control points (replicated)
+  double gd = strided_sum(T.lm_mcc, T.n_lm, 2, 0), dd = strided_sum(T.lm_mcc, T.n_lm, 2, 1);
   cand = block_sum(cand, red), xs = block_sum(xs, red), ss = block_sum(ss, red), gd = block_sum(gd, red), dd = block_sum(dd, red);
   if (threadIdx.x == 0) {
     double* D = T.xbuf + T.xo_dec;

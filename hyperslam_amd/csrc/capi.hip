@@ -512,8 +512,10 @@ int launch_factor(hs_problem* p) {
     k_band_factor_wide<<<1, kWideThreads, size_t(6) * (ncb + 2) * sizeof(double), s>>>(T);
   if (T.nb) {  // bordered system (bias splines + gravity)
     k_border_forward<<<(T.nb + kBorderCols - 1) / kBorderCols, 128, size_t(T.np) * kBorderCols * sizeof(double), s>>>(T);
-    k_border_schur<<<T.nb, kBlock, 0, s>>>(T);
-    k_border_solve<<<1, kBlock, (size_t(T.nb) * (T.nb + 1) + T.nb) * sizeof(double), s>>>(T);
+    const int nt = (T.nb + kSchurTile - 1) / kSchurTile;
+    k_border_schur<<<dim3(nt, nt), kBlock, 0, s>>>(T);
+    k_border_solve<<<1, kBlock, (size_t(T.nb + 1) * (T.nb + 1) + T.nb) * sizeof(double), s>>>(T);
+    k_border_apply<<<(T.np + kBlock / 64 - 1) / (kBlock / 64), kBlock, 0, s>>>(T);
   }
   k_band_backward<<<1, kCholThreads, 2 * size_t(T.np) * sizeof(double), s>>>(T);
   HIP_TRY(hipGetLastError());

@@ -1056,35 +1056,55 @@ __global__ void __launch_bounds__(128) k_border_forward(Tables T) {
   __syncthreads();
   __shared__ double zi[6 * kBorderCols];
   const int n_pend = 6 * (bw - 1);
-  for (int m = 0; m < n_blk; ++m) {
-    // z_m = U_mm^-T s_m = W' s_m with W = U_mm^-1 (packed upper): thread (a, c) for a < 6, c < kBorderCols
-    if (tid < 6 * kBorderCols) {
-      const int a = tid / kBorderCols, c = tid % kBorderCols;
-      const double* W = T.Ubk + size_t(m) * 24;
-      double v = 0.0;
-      // (W')[a][k] = W[k][a], k <= a ; packed index of (k, a) = k*6 - k(k-1)/2 + (a - k)
-      for (int k = 0; k <= a; ++k) v = fma(W[k * 6 - k * (k - 1) / 2 + (a - k)], z[(6 * m + k) * kBorderCols + c], v);
-      zi[tid] = v;
-    }
-    __syncthreads();
-    if (tid < 6 * kBorderCols) z[(6 * m + tid / kBorderCols) * kBorderCols + tid % kBorderCols] = zi[tid];
-    // pending rows of blocks m+1 .. m+bw-1: s_(i,c') -= sum_a U[6m+a][6(i-m)+c'] z_m[a]
-    for (int t = tid; t < n_pend; t += blockDim.x) {
-      const int rho = 6 * (m + 1) + t;
-      if (rho < np) {
-        double u[6];
+  // Operands of step m are requested D steps ahead (the sweep is a dependency chain over the block rows: a load issued inside
+  // the step would put a full L2 round trip on it). Thread t < n_pend: the six factor entries U[6m + a][6 + t]; thread
+  // (a, c) < 6 x kBorderCols: column a of W_m = U_mm^-1.
+  constexpr int D = 4;
+  const bool pend = tid < n_pend, diag = tid < 6 * kBorderCols;
+  const int da = diag ? tid / kBorderCols : 0, dc = diag ? tid % kBorderCols : 0;
+  double ur[D][6], wr[D][6];
+  auto request = [&](int m, double* u, double* w) {
+    const int mm = m < n_blk ? m : 0;
+    const double* src = T.Ub + size_t(6 * mm) * ncb + 6 + (pend ? tid : 0);
 #pragma unroll
-        for (int a = 0; a < 6; ++a) u[a] = T.Ub[size_t(6 * m + a) * ncb + 6 + t];
+    for (int a = 0; a < 6; ++a) u[a] = src[size_t(a) * ncb];
+    // (W')[a][k] = W[k][a], k <= a ; packed index of (k, a) = k*6 - k(k-1)/2 + (a - k)
+    const double* W = T.Ubk + size_t(mm) * 24;
 #pragma unroll
-        for (int c = 0; c < kBorderCols; ++c) {
-          double sacc = 0.0;
+    for (int k = 0; k < 6; ++k) w[k] = W[k <= da ? k * 6 - k * (k - 1) / 2 + (da - k) : 0];
+  };
 #pragma unroll
-          for (int a = 0; a < 6; ++a) sacc = fma(u[a], zi[a * kBorderCols + c], sacc);
-          z[rho * kBorderCols + c] -= sacc;
+  for (int d = 0; d < D; ++d) request(d, ur[d], wr[d]);
+  for (int mb = 0; mb < n_blk; mb += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int m = mb + d;
+      if (m >= n_blk) break;
+      // z_m = U_mm^-T s_m = W' s_m
+      if (diag) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v = fma(k <= da ? wr[d][k] : 0.0, z[(6 * m + k) * kBorderCols + dc], v);
+        zi[tid] = v;
+      }
+      __syncthreads();
+      if (diag) z[(6 * m + da) * kBorderCols + dc] = zi[tid];
+      // pending rows of blocks m+1 .. m+bw-1: s_(i,c') -= sum_a U[6m+a][6(i-m)+c'] z_m[a]
+      if (pend) {
+        const int rho = 6 * (m + 1) + tid;
+        if (rho < np) {
+#pragma unroll
+          for (int c = 0; c < kBorderCols; ++c) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) sacc = fma(ur[d][a], zi[a * kBorderCols + c], sacc);
+            z[rho * kBorderCols + c] -= sacc;
+          }
         }
       }
+      request(m + D, ur[d], wr[d]);
+      __syncthreads();
     }
-    __syncthreads();
   }
   for (int e = tid; e < np * kBorderCols; e += blockDim.x) {
     const int rho = e / kBorderCols, c = e % kBorderCols;
@@ -1092,72 +1112,107 @@ __global__ void __launch_bounds__(128) k_border_forward(Tables T) {
   }
 }
 
+/// C = S_bb - Z'Z (16 x 16 tile per workgroup, upper tile triangle mirrored) and h = g_b - Z'y. Z rows are staged through LDS
+/// in chunks (coalesced, eight loads in flight per lane), the tile is accumulated from LDS.
+constexpr int kSchurTile = 16, kSchurRows = 128;
+
 __global__ void __launch_bounds__(kBlock) k_border_schur(Tables T) {
-  // block b: C[b][:] = S_bb[b][:] - sum_rho Z[rho][b] Z[rho][:],  h[b] = g_b[b] - sum_rho Z[rho][b] y[rho]
-  __shared__ double red[kBlock / 64];
+  __shared__ double za[kSchurRows][kSchurTile + 1], zc[kSchurRows][kSchurTile + 1], ys[kSchurRows];
   if (T.st->done) return;
-  const int b = blockIdx.x, nb = T.nb, np = T.np;
-  for (int c = threadIdx.x; c < nb; c += blockDim.x) {
-    double acc = T.Sbb[size_t(b) * nb + c];
-    for (int rho = 0; rho < np; ++rho) acc = fma(-T.Zb[size_t(rho) * nb + b], T.Zb[size_t(rho) * nb + c], acc);
-    T.Cb[size_t(b) * nb + c] = acc;
+  const int nb = T.nb, np = T.np, tid = threadIdx.x;
+  const int bt = blockIdx.x, ct = blockIdx.y;
+  if (ct < bt) return;  // lower tiles are written by their mirror
+  const int ti = tid / kSchurTile, tj = tid % kSchurTile;
+  const int b = bt * kSchurTile + ti, c = ct * kSchurTile + tj;
+  double acc = 0.0, hacc = 0.0;
+  for (int r0 = 0; r0 < np; r0 += kSchurRows) {
+    const int nr = min(kSchurRows, np - r0);
+    __syncthreads();
+    // 2 x (kSchurRows x 16) operand entries + y: 16 + 1 loads per lane, issued together
+    double va[8], vc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = tid + u * kBlock, r = e / kSchurTile, k = e % kSchurTile;
+      const bool ok = r < nr;
+      va[u] = ok && bt * kSchurTile + k < nb ? T.Zb[size_t(r0 + r) * nb + bt * kSchurTile + k] : 0.0;
+      vc[u] = ok && ct * kSchurTile + k < nb ? T.Zb[size_t(r0 + r) * nb + ct * kSchurTile + k] : 0.0;
+    }
+    const double yv = tid < nr ? T.ybuf[r0 + tid] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = tid + u * kBlock, r = e / kSchurTile, k = e % kSchurTile;
+      za[r][k] = va[u], zc[r][k] = vc[u];
+    }
+    if (tid < kSchurRows) ys[tid] = yv;
+    __syncthreads();
+#pragma unroll 8
+    for (int r = 0; r < kSchurRows; ++r) {
+      const double a = za[r][ti];
+      acc = fma(a, zc[r][tj], acc);
+      if (ct == bt && tj == 0) hacc = fma(a, ys[r], hacc);
+    }
   }
-  double hacc = 0.0;
-  for (int rho = threadIdx.x; rho < np; rho += blockDim.x) hacc = fma(T.Zb[size_t(rho) * nb + b], T.ybuf[rho], hacc);
-  hacc = block_sum(hacc, red);
-  if (threadIdx.x == 0) T.hb[b] = T.gb_s[b] - hacc;
+  if (b < nb && c < nb) {
+    const double v = T.Sbb[size_t(b) * nb + c] - acc;
+    T.Cb[size_t(b) * nb + c] = v;
+    if (ct != bt) T.Cb[size_t(c) * nb + b] = v;
+  }
+  if (ct == bt && tj == 0 && b < nb) T.hb[b] = T.gb_s[b] - hacc;
 }
 
+/// Dense Cholesky of the border Schur complement C (nb x nb, in LDS, augmented with h as an extra row so that the forward
+/// solve comes out of the elimination), column-oriented backward solve, x_b. One barrier per column in both sweeps.
 __global__ void __launch_bounds__(kBlock) k_border_solve(Tables T) {
-  // dense Cholesky of C (nb x nb, LDS) + solve, then y' = y - Z x_b
   extern __shared__ __attribute__((aligned(16))) double smem[];
   DevState* st = T.st;
   if (st->done) return;
-  const int nb = T.nb, np = T.np, tid = threadIdx.x;
-  const int ld = nb + 1;
-  double* C = smem;            // nb x ld
-  double* x = smem + nb * ld;  // nb
+  const int nb = T.nb, tid = threadIdx.x;
+  const int ld = nb + 1, n1 = nb + 1;  // rows 0 .. nb-1: C (lower), row nb: h'
+  double* C = smem;                    // (nb + 1) x ld
   for (int e = tid; e < nb * nb; e += blockDim.x) C[(e / nb) * ld + e % nb] = T.Cb[e];
-  for (int e = tid; e < nb; e += blockDim.x) x[e] = T.hb[e];
+  for (int e = tid; e < nb; e += blockDim.x) C[nb * ld + e] = T.hb[e];
   __shared__ int bad;
   if (tid == 0) bad = 0;
   __syncthreads();
-  for (int j = 0; j < nb; ++j) {  // right-looking, lower triangle
-    if (tid == 0) {
-      double d = C[j * ld + j];
-      if (!(d > 0.0)) bad = 1, d = 1.0;
-      C[j * ld + j] = sqrt(d);
+  const int ti = tid / 16, tj = tid % 16;  // 16 x 16 lanes over the trailing (i, c) entries
+  for (int j = 0; j < nb; ++j) {           // right-looking on the lower triangle; column j is scaled on the fly
+    const double d = C[j * ld + j];
+    if (tid == 0 && !(d > 0.0)) bad = 1;
+    const double inv = 1.0 / (d > 0.0 ? d : 1.0);  // 1 / l_jj^2
+    for (int i = j + 1 + ti; i < n1; i += 16) {
+      const double lij = C[i * ld + j];
+      for (int c = j + 1 + tj; c <= i && c < nb; c += 16) C[i * ld + c] = fma(-lij * inv, C[c * ld + j], C[i * ld + c]);
     }
-    __syncthreads();
-    const double dj = C[j * ld + j];
-    for (int i = j + 1 + tid; i < nb; i += blockDim.x) C[i * ld + j] /= dj;
-    __syncthreads();
-    for (int e = tid; e < (nb - j - 1) * (nb - j - 1); e += blockDim.x) {
-      const int i = j + 1 + e / (nb - j - 1), c = j + 1 + e % (nb - j - 1);
-      if (c <= i) C[i * ld + c] -= C[i * ld + j] * C[c * ld + j];
-    }
-    __syncthreads();
+    lds_barrier();
+    // scale column j (not read again by later columns' updates except through these scaled values in the backward sweep)
+    const double rs = sqrt(inv);
+    for (int i = j + tid; i < n1; i += blockDim.x) C[i * ld + j] = i == j ? d * rs : C[i * ld + j] * rs;
+    // (no barrier needed here: column j is not touched by the update of column j + 1, which reads columns > j only ... except
+    //  C[c][j+1] entries, which were finalised by the update above and published by the barrier)
   }
-  if (tid == 0) {
-    for (int i = 0; i < nb; ++i) {
-      double v = x[i];
-      for (int k = 0; k < i; ++k) v -= C[i * ld + k] * x[k];
-      x[i] = v / C[i * ld + i];
-    }
-    for (int i = nb - 1; i >= 0; --i) {
-      double v = x[i];
-      for (int k = i + 1; k < nb; ++k) v -= C[k * ld + i] * x[k];
-      x[i] = v / C[i * ld + i];
-    }
-    if (bad) st->chol_failed = 1;
+  lds_barrier();
+  // backward: L' x = y, y = row nb; column oriented, one barrier per column (x goes to its own array)
+  double* y = C + nb * ld;
+  double* x = C + n1 * ld;
+  for (int j = nb - 1; j >= 0; --j) {
+    const double xj = y[j] / C[j * ld + j];
+    if (tid == 0) x[j] = xj;
+    for (int i = tid; i < j; i += blockDim.x) y[i] = fma(-C[j * ld + i], xj, y[i]);
+    lds_barrier();
   }
-  __syncthreads();
-  for (int b = tid; b < nb; b += blockDim.x) T.xb[b] = x[b];
-  for (int rho = tid; rho < np; rho += blockDim.x) {
-    double v = T.ybuf[rho];
-    for (int b = 0; b < nb; ++b) v = fma(-T.Zb[size_t(rho) * nb + b], x[b], v);
-    T.ybuf[rho] = v;
-  }
+  if (tid == 0 && bad) st->chol_failed = 1;
+  for (int bq = tid; bq < nb; bq += blockDim.x) T.xb[bq] = x[bq];
+}
+
+/// y' = y - Z x_b (one wave per row of Z, lanes over the border columns).
+__global__ void __launch_bounds__(kBlock) k_border_apply(Tables T) {
+  if (T.st->done) return;
+  const int lane = threadIdx.x & 63, rho = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (rho >= T.np) return;
+  double v = 0.0;
+  for (int bq = lane; bq < T.nb; bq += 64) v = fma(T.Zb[size_t(rho) * T.nb + bq], T.xb[bq], v);
+  v = wave_sum(v);
+  if (lane == 0) T.ybuf[rho] -= v;
 }
 
 /// After the (optional) all-reduce: Jacobi scaling (fixed at iteration 0), LM diagonal, inactive coordinates.

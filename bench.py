@@ -49,9 +49,10 @@ def cpu_baseline(window, budget_s=20.0):
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/), or None."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
     try:
-        with open(path) as f:
+        with open(files[-1]) as f:
             k = json.load(f)["kernels"][kernel]
         return 1024.0 * (k["FETCH_SIZE_KiB"] + k["WRITE_SIZE_KiB"])
     except Exception:
@@ -172,8 +173,13 @@ def main():
                          "rocprof_avg_kernel_ms": rocprof_kernel_ms("void hs::k_linearize_visual<4>"),
                          "note": "avg_launch_ms = HIP events around the launch on the library's stream (includes ~6 us dispatch latency); "
                                  "rocprof_avg_kernel_ms = committed rocprofv3 kernel-trace average of this command (profiles/); "
-                                 "traffic = FETCH_SIZE + WRITE_SIZE of profiles/r01_pmc_hbm_traffic.json (separate rocprofv3 --pmc passes)"},
+                                 "traffic = FETCH_SIZE + WRITE_SIZE of the newest profiles/r*_pmc_hbm_traffic.json (separate rocprofv3 --pmc passes, tools/pmc_traffic.sh)"},
         }
+        # the same algorithmic bytes against the whole LM iteration (linearise + Schur + solve + update): the path is a latency-bound
+        # dependency chain after the linearisation, so this fraction is low by construction
+        it_ms = out["ms_per_gn_iteration"]
+        out["roofline_iteration"] = {"bound": "hbm", "achieved": B_ALG_PIXEL_K4 * n_blocks_local / (it_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": B_ALG_PIXEL_K4 * n_blocks_local / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": it_ms}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(full if world == 1 else window)
             out["speedup_vs_cpu_1thread"] = out["value"] / world / out["cpu_baseline"]["value"]

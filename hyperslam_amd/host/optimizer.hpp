@@ -15,6 +15,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <fstream>
+#include <iomanip>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -50,6 +52,7 @@ int HSF(get_control_points)(hs_problem*, double*);
 int HSF(get_landmarks)(hs_problem*, double*);
 int HSF(get_bias)(hs_problem*, double*, double*);
 int HSF(get_gravity)(hs_problem*, double*);
+int HSF(sample_trajectory)(hs_problem*, int, const double*, double*, double*, double*);
 }
 
 namespace hyper_hip {
@@ -271,6 +274,36 @@ class Optimizer {
         for (int c = 0; c < 3; ++c) bias_[j].g[c] = bg[4 * j + c], bias_[j].a[c] = ba[4 * j + c];
       check(HSF(get_gravity)(handle_, gravity_.data()), "get_gravity");
     }
+  }
+
+  /// The SIGUSR1 dump of apps/hyperslam/main.cpp:52-80: the state sampled at `rate` Hz over its range, one line per sample
+  /// `stamp, qx, qy, qz, qw, px, py, pz` (scientific, 20 digits, stamp = root + sample). The samples are evaluated by the
+  /// library (batched spline evaluation on the device), not on the host. Returns the number of samples written.
+  int writeEstimation(const std::string& path, double rate = 100.0) {
+    const int k = opt_.order, n_cp = int(cp_.size());
+    std::vector<double> cp(size_t(8) * n_cp);
+    std::vector<uint8_t> frozen(n_cp, 0);
+    for (int j = 0; j < n_cp; ++j) {
+      const ControlPoint& c = cp_[j];
+      double* o = &cp[8 * j];
+      o[0] = c.T.q.x, o[1] = c.T.q.y, o[2] = c.T.q.z, o[3] = c.T.q.w, o[4] = c.T.p[0], o[5] = c.T.p[1], o[6] = c.T.p[2], o[7] = c.stamp;
+    }
+    check(HSF(set_spline)(handle_, k, cp_.front().stamp, opt_.separation, n_cp, cp.data(), frozen.data(), opt_.rotation_constant, opt_.translation_constant),
+          "set_spline");
+    const Range r = stateRange();
+    std::vector<double> stamps;
+    for (int i = 0; r.lower + i / rate < r.upper - 1e-9; ++i) stamps.push_back(r.lower + i / rate);  // EXTERNAL Range::sample(rate)
+    std::vector<double> pose(7 * stamps.size());
+    if (!stamps.empty()) check(HSF(sample_trajectory)(handle_, int(stamps.size()), stamps.data(), pose.data(), nullptr, nullptr), "sample_trajectory");
+    std::ofstream f(path);
+    if (!f) throw std::runtime_error("cannot open " + path);
+    f << std::scientific << std::setprecision(20);
+    for (size_t i = 0; i < stamps.size(); ++i) {
+      f << root_stamp_ + stamps[i];
+      for (int c = 0; c < 7; ++c) f << ", " << pose[7 * i + c];
+      f << "\n";
+    }
+    return int(stamps.size());
   }
 
   /// Pose of control point j (for tests / trajectory dumps).

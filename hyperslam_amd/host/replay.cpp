@@ -4,7 +4,7 @@
 // stream is synthetic with the real window shape: separation 0.1 s, max_window 3.0 s (settings.yaml:145,148), <= 150 stereo tracks
 // at 20 Hz through the EuRoC cameras (settings.yaml:20-72), optional IMU at 200 Hz, one optimize() per separation of data exactly
 // as AbstractOptimizer::submit drives it (abstract.cpp:74-147).  Prints one JSON line.
-//   usage: replay [seconds=6] [imu=0|1] [order=4]
+//   usage: replay [seconds=6] [imu=0|1] [order=4] [estimation.hyper]   (4th argument: write the 100 Hz trajectory dump of main.cpp:52-80)
 #include <chrono>
 #include <cstring>
 #include <random>
@@ -131,6 +131,10 @@ int main(int argc, char** argv) {
     }
   }
   const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+  if (argc > 4) {
+    const int n_samples = optimizer.writeEstimation(argv[4]);
+    std::fprintf(stderr, "wrote %d samples to %s\n", n_samples, argv[4]);
+  }
   // accuracy: control points vs ground truth after aligning the first frozen control point (gauge)
   const SE3 A = groupPlus(gt_pose(optimizer.controlPointStamp(0)), groupInverse(optimizer.controlPoint(0)));
   double se = 0;

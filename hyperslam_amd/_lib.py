@@ -96,6 +96,7 @@ _SIGNATURES = {
     "get_bias": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "get_gravity": (C.c_int, [C.c_void_p, c_double_p]),
     "sample_trajectory": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]),
+    "process_tracks": (C.c_int, [C.c_void_p, C.c_double, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     "set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
     "set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "band_blocks": (C.c_int, [C.c_void_p]),

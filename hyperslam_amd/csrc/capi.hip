@@ -1211,11 +1211,61 @@ int hs_cost_function_evaluate(hs_problem* p, int type, int idx, const double* co
   return HS_OK;
 }
 
+/// Evaluation-only device tables (spline + cameras) for the entry points that do not touch residuals: the residual tables of the
+/// last solve may refer to control points that the sliding window has already dropped, so prepare() is not run here.
+static int eval_tables(hs_problem* p, Tables* T, DBuf<double>* d_cp, DBuf<double>* d_cam) {
+  if (p->n_cp < p->k || p->cp.empty()) HS_FAIL(HS_ERR_STATE, "hs_set_spline has not been called");
+  hipStream_t s = p->stream;
+  HIP_TRY(d_cp->upload(p->cp, s));
+  if (!p->cam.empty()) HIP_TRY(d_cam->upload(p->cam, s));
+  std::memset(T, 0, sizeof(*T));
+  T->sp = Spline{p->k, p->n_cp, p->t0, p->dt, 1.0 / p->dt, p->rot_const, p->trans_const};
+  T->basis = make_basis_coef(p->k);
+  T->cp = d_cp->p, T->cam = d_cam->p;
+  return HS_OK;
+}
+
+int hs_process_tracks(hs_problem* p, double stamp, int n, const double* pixels0, const double* pixels1, double* bearings0, double* bearings1,
+                      double* positions_w) {
+  if (!p || n < 0 || (n && (!pixels0 || !pixels1))) return HS_ERR_INVALID;
+  if (p->cam.size() < 32) HS_FAIL(HS_ERR_STATE, "hs_process_tracks needs a stereo pair (two cameras)");
+  if (n == 0) return HS_OK;
+  Tables T;
+  DBuf<double> d_cp, d_cam;
+  int rc = eval_tables(p, &T, &d_cp, &d_cam);
+  if (rc) return rc;
+  const int k = p->k, n_seg = p->n_cp - k + 1;
+  const int f = h_segment_first(stamp, p->t0, p->dt, k);
+  if (positions_w && (f < 0 || f >= n_seg)) HS_FAIL(HS_ERR_INVALID, "stamp outside the valid range of the spline");
+  hipStream_t s = p->stream;
+  DBuf<double> d_p0, d_p1, d_b0, d_b1, d_pw;
+  HIP_TRY(d_p0.upload(std::vector<double>(pixels0, pixels0 + 2 * size_t(n)), s));
+  HIP_TRY(d_p1.upload(std::vector<double>(pixels1, pixels1 + 2 * size_t(n)), s));
+  if (bearings0) HIP_TRY(d_b0.reserve(size_t(3) * n));
+  if (bearings1) HIP_TRY(d_b1.reserve(size_t(3) * n));
+  if (positions_w) HIP_TRY(d_pw.reserve(size_t(3) * n));
+  const int nb = (n + kBlock - 1) / kBlock;
+  if (k == 4)
+    k_process_tracks<4><<<nb, kBlock, cp_lds_bytes(p), s>>>(T, stamp, n, d_p0.p, d_p1.p, bearings0 ? d_b0.p : nullptr, bearings1 ? d_b1.p : nullptr,
+                                                           positions_w ? d_pw.p : nullptr);
+  else
+    k_process_tracks<6><<<nb, kBlock, cp_lds_bytes(p), s>>>(T, stamp, n, d_p0.p, d_p1.p, bearings0 ? d_b0.p : nullptr, bearings1 ? d_b1.p : nullptr,
+                                                           positions_w ? d_pw.p : nullptr);
+  HIP_TRY(hipGetLastError());
+  if (bearings0) HIP_TRY(hipMemcpyAsync(bearings0, d_b0.p, size_t(3) * n * 8, hipMemcpyDeviceToHost, s));
+  if (bearings1) HIP_TRY(hipMemcpyAsync(bearings1, d_b1.p, size_t(3) * n * 8, hipMemcpyDeviceToHost, s));
+  if (positions_w) HIP_TRY(hipMemcpyAsync(positions_w, d_pw.p, size_t(3) * n * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return HS_OK;
+}
+
 int hs_sample_trajectory(hs_problem* p, int n, const double* stamps, double* pose, double* velocity, double* acceleration) {
   if (!p || n < 0 || (n && (!stamps || !pose))) return HS_ERR_INVALID;
-  int rc = prepare(p);
-  if (rc) return rc;
   if (n == 0) return HS_OK;
+  Tables T;
+  DBuf<double> d_cp, d_cam;
+  int rc = eval_tables(p, &T, &d_cp, &d_cam);
+  if (rc) return rc;
   const int k = p->k, n_seg = p->n_cp - k + 1;
   for (int i = 0; i < n; ++i) {
     const int f = h_segment_first(stamps[i], p->t0, p->dt, k);
@@ -1230,9 +1280,9 @@ int hs_sample_trajectory(hs_problem* p, int n, const double* stamps, double* pos
   if (acceleration) HIP_TRY(d_acc.reserve(size_t(6) * n));
   const int nb = (n + kBlock - 1) / kBlock;
   if (k == 4)
-    k_sample_trajectory<4><<<nb, kBlock, cp_lds_bytes(p), s>>>(p->T, n, d_st.p, d_pose.p, velocity ? d_vel.p : nullptr, acceleration ? d_acc.p : nullptr);
+    k_sample_trajectory<4><<<nb, kBlock, cp_lds_bytes(p), s>>>(T, n, d_st.p, d_pose.p, velocity ? d_vel.p : nullptr, acceleration ? d_acc.p : nullptr);
   else
-    k_sample_trajectory<6><<<nb, kBlock, cp_lds_bytes(p), s>>>(p->T, n, d_st.p, d_pose.p, velocity ? d_vel.p : nullptr, acceleration ? d_acc.p : nullptr);
+    k_sample_trajectory<6><<<nb, kBlock, cp_lds_bytes(p), s>>>(T, n, d_st.p, d_pose.p, velocity ? d_vel.p : nullptr, acceleration ? d_acc.p : nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(pose, d_pose.p, size_t(7) * n * 8, hipMemcpyDeviceToHost, s));
   if (velocity) HIP_TRY(hipMemcpyAsync(velocity, d_vel.p, size_t(6) * n * 8, hipMemcpyDeviceToHost, s));

@@ -2341,6 +2341,57 @@ __global__ void __launch_bounds__(kBlock) k_sample_trajectory(Tables T, int n, c
   if (acc) acc[6 * i] = S.al.x, acc[6 * i + 1] = S.al.y, acc[6 * i + 2] = S.al.z, acc[6 * i + 3] = S.a.x, acc[6 * i + 4] = S.a.y, acc[6 * i + 5] = S.a.z;
 }
 
+/// Pixel -> unit bearing in the sensor frame (radtan undistortion by fixed-point iteration; cam = [T_bs(7) | cx cy fx fy | k1 k2 p1 p2]).
+HSD V3 pixel_to_bearing(const double* cam, double u, double v) {
+  const double xd = (u - cam[7]) / cam[9], yd = (v - cam[8]) / cam[10];
+  const double k1 = cam[11], k2 = cam[12], p1 = cam[13], p2 = cam[14];
+  double x = xd, y = yd;
+  for (int it = 0; it < 20; ++it) {
+    const double r2 = x * x + y * y, rad = 1 + k1 * r2 + k2 * r2 * r2;
+    const double dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x), dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+    x = (xd - dx) / rad, y = (yd - dy) / rad;
+  }
+  const double n = sqrt(x * x + y * y + 1);
+  return V3{x / n, y / n, 1 / n};
+}
+
+/// AbstractOptimizer::process(VisualTracks) front half (abstract.cpp:197-223,250-255): one stereo track per lane.
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_process_tracks(Tables T, double stamp, int n, const double* px0, const double* px1, double* b0o, double* b1o,
+                                                           double* pwo) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* cps = smem;
+  stage_cps(T.cp, cps, 8 * T.sp.n_cp);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* c0 = T.cam, *c1 = T.cam + 16;
+  const V3 b0 = pixel_to_bearing(c0, px0[2 * i], px0[2 * i + 1]), b1 = pixel_to_bearing(c1, px1[2 * i], px1[2 * i + 1]);
+  if (b0o) b0o[3 * i] = b0.x, b0o[3 * i + 1] = b0.y, b0o[3 * i + 2] = b0.z;
+  if (b1o) b1o[3 * i] = b1.x, b1o[3 * i + 1] = b1.y, b1o[3 * i + 2] = b1.z;
+  if (!pwo) return;
+  // T_wb(stamp), T_w0 = T_wb o T_b0, T_01 = T_b0^-1 o T_b1
+  double u;
+  const int first = segment_of(stamp, T.sp.t0, T.sp.dt, K, &u);
+  double lam[K], dlam[K], ddlam[K];
+  basis_weights<K>(T.basis, u, T.sp.inv_dt, lam, dlam, ddlam, 0);
+  Quat q_wb;
+  V3 p_wb;
+  spline_pose<K>(cps + 8 * first, lam, &q_wb, &p_wb);
+  const Quat q_b0 = load_quat(c0), q_b1 = load_quat(c1);
+  const V3 t_b0 = V3{c0[4], c0[5], c0[6]}, t_b1 = V3{c1[4], c1[5], c1[6]};
+  const M3 R_wb = qmat(q_wb), R_b0 = qmat(q_b0), R_b1 = qmat(q_b1);
+  const M3 R_01 = mul_tn(R_b0, R_b1);
+  const V3 o = mul_t(R_b0, t_b1 - t_b0);  // origin of camera 1 in frame 0
+  const V3 d1 = mul(R_01, b1);
+  const double a = dot(b0, b0), b = dot(b0, d1), c = dot(d1, d1), e = dot(b0, o), f = dot(d1, o);
+  const double den = a * c - b * b;
+  const double s0 = den > 1e-12 ? (c * e - b * f) / den : 1.0, s1 = den > 1e-12 ? (b * e - a * f) / den : 1.0;
+  const V3 p0 = 0.5 * (s0 * b0 + o + s1 * d1);  // midpoint of the two rays, frame 0
+  const V3 pb = mul(R_b0, p0) + t_b0;
+  const V3 pw = mul(R_wb, pb) + p_wb;
+  pwo[3 * i] = pw.x, pwo[3 * i + 1] = pw.y, pwo[3 * i + 2] = pw.z;
+}
+
 /// Fresh trust-region state (LevenbergMarquardtStrategy: initial radius 1e4, decrease factor 2).
 __global__ void k_reset_state(DevState* st, int max_iterations, double radius) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;

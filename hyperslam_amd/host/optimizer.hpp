@@ -53,6 +53,7 @@ int HSF(get_landmarks)(hs_problem*, double*);
 int HSF(get_bias)(hs_problem*, double*, double*);
 int HSF(get_gravity)(hs_problem*, double*);
 int HSF(sample_trajectory)(hs_problem*, int, const double*, double*, double*, double*);
+int HSF(process_tracks)(hs_problem*, double, int, const double*, const double*, double*, double*, double*);
 }
 
 namespace hyper_hip {
@@ -414,23 +415,50 @@ class Optimizer {
     do_process(stamp);
   }
 
-  // ---- process(VisualTracks) (abstract.cpp:186-264) ----
+  // ---- process(VisualTracks) (abstract.cpp:186-264): pixel -> bearing conversion and triangulation of new tracks run in the
+  //      library (hs_process_tracks, batched on the device); this function only keeps the books ----
   void process(const VisualTracks& m, Stamp stamp) {
     if (cameras_.size() != 2) throw std::runtime_error("Unsupported camera configuration.");
-    const SE3 T_w0 = groupPlus(evaluate(stamp), cameras_[0].transformation);
-    const SE3 T_01 = groupPlus(groupInverse(cameras_[0].transformation), cameras_[1].transformation);
-    for (size_t i = 0; i < m.identifiers.size(); ++i) {
-      const Vec3 b0 = cameras_[0].pixelToBearing(m.P0[i][0], m.P0[i][1]), b1 = cameras_[1].pixelToBearing(m.P1[i][0], m.P1[i][1]);
+    const int n = int(m.identifiers.size());
+    if (n == 0) return;
+    uploadState();
+    std::vector<double> p0(2 * size_t(n)), p1(2 * size_t(n)), b0(3 * size_t(n)), b1(3 * size_t(n)), pw(3 * size_t(n));
+    for (int i = 0; i < n; ++i) p0[2 * i] = m.P0[i][0], p0[2 * i + 1] = m.P0[i][1], p1[2 * i] = m.P1[i][0], p1[2 * i + 1] = m.P1[i][1];
+    check(HSF(process_tracks)(handle_, stamp, n, p0.data(), p1.data(), b0.data(), b1.data(), pw.data()), "process_tracks");
+    for (int i = 0; i < n; ++i) {
       auto [it, inserted] = landmarks_.try_emplace(m.identifiers[i]);
       Landmark& lm = it->second;
       if (inserted) {
-        lm.position = vectorPlus(T_w0, Camera::Triangulate(T_01, b0, b1));
+        lm.position = {pw[3 * i], pw[3 * i + 1], pw[3 * i + 2]};
         lm.lower = lm.upper = stamp;
       }
-      lm.observations.push_back({stamp, 0, b0});
-      lm.observations.push_back({stamp, 1, b1});
+      lm.observations.push_back({stamp, 0, {b0[3 * i], b0[3 * i + 1], b0[3 * i + 2]}});
+      lm.observations.push_back({stamp, 1, {b1[3 * i], b1[3 * i + 1], b1[3 * i + 2]}});
       lm.lower = std::min(lm.lower, stamp), lm.upper = std::max(lm.upper, stamp);
     }
+  }
+  /// Control points and cameras as the library needs them for evaluation-only calls (tracks, trajectory samples).
+  void uploadState() {
+    const int k = opt_.order, n_cp = int(cp_.size());
+    std::vector<double> cp(size_t(8) * n_cp);
+    std::vector<uint8_t> frozen(n_cp);
+    for (int j = 0; j < n_cp; ++j) {
+      const ControlPoint& c = cp_[j];
+      double* o = &cp[8 * j];
+      o[0] = c.T.q.x, o[1] = c.T.q.y, o[2] = c.T.q.z, o[3] = c.T.q.w, o[4] = c.T.p[0], o[5] = c.T.p[1], o[6] = c.T.p[2], o[7] = c.stamp;
+      frozen[j] = c.constant;
+    }
+    check(HSF(set_spline)(handle_, k, cp_.front().stamp, opt_.separation, n_cp, cp.data(), frozen.data(), opt_.rotation_constant, opt_.translation_constant),
+          "set_spline");
+    std::vector<double> T(7 * cameras_.size()), I(4 * cameras_.size()), D(4 * cameras_.size());
+    for (size_t c = 0; c < cameras_.size(); ++c) {
+      const SE3& t = cameras_[c].transformation;
+      const double v[7] = {t.q.x, t.q.y, t.q.z, t.q.w, t.p[0], t.p[1], t.p[2]};
+      std::copy(v, v + 7, &T[7 * c]);
+      std::copy(cameras_[c].intrinsics.begin(), cameras_[c].intrinsics.end(), &I[4 * c]);
+      std::copy(cameras_[c].distortion.begin(), cameras_[c].distortion.end(), &D[4 * c]);
+    }
+    check(HSF(set_cameras)(handle_, int(cameras_.size()), T.data(), I.data(), D.data()), "set_cameras");
   }
   void process(const InertialMeasurement& m, Stamp stamp) {  // abstract.cpp:272-292
     InertialMeasurement c = m;

@@ -286,6 +286,14 @@ class Problem:
         self._check(self.lib.get_bias(self.h, _d(bg), _d(ba)), "get_bias")
         return bg, ba
 
+    def process_tracks(self, stamp, pixels0, pixels1):
+        """AbstractOptimizer::process(VisualTracks) front half: (bearings0, bearings1, positions_w) of n stereo tracks."""
+        p0, p1 = _arr(pixels0, _f64).reshape(-1, 2), _arr(pixels1, _f64).reshape(-1, 2)
+        n = len(p0)
+        b0, b1, pw = np.zeros((n, 3)), np.zeros((n, 3)), np.zeros((n, 3))
+        self._check(self.lib.process_tracks(self.h, float(stamp), n, _d(p0), _d(p1), _d(b0), _d(b1), _d(pw)), "process_tracks")
+        return b0, b1, pw
+
     def sample_trajectory(self, stamps, derivatives=False):
         st = _arr(stamps, _f64)
         pose = np.zeros((len(st), 7))

@@ -185,6 +185,15 @@ int hs_get_gravity(hs_problem* p, double* g);
  * [angular(3) body ; linear(3) world]. */
 int hs_sample_trajectory(hs_problem* p, int n, const double* stamps, double* pose, double* velocity, double* acceleration);
 
+/* AbstractOptimizer::process(VisualTracks) (internal/hyper/optimizers/abstract.cpp:186-264), the step right before the path:
+ * pixel -> bearing conversion in both cameras of a stereo pair (Camera::convertPixelsToBearings, abstract.cpp:222-223; radtan
+ * undistortion by 20 fixed-point iterations, unit norm) and triangulation of each pair into the world frame through the
+ * current spline value at `stamp` (state evaluate abstract.cpp:197-198, Camera::Triangulate abstract.cpp:252: midpoint of the
+ * two rays). Cameras 0 and 1 of hs_set_cameras, control points of hs_set_spline. pixels: n x 2; bearings: n x 3 (sensor
+ * frames); positions_w: n x 3. Any output may be NULL. */
+int hs_process_tracks(hs_problem* p, double stamp, int n, const double* pixels0, const double* pixels1, double* bearings0, double* bearings1,
+                      double* positions_w);
+
 #ifdef __cplusplus
 }
 #endif

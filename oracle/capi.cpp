@@ -297,6 +297,63 @@ int hso_get_gravity(hso_problem* p, double* g) {
   return HS_OK;
 }
 
+/// AbstractOptimizer::process(VisualTracks) front half (abstract.cpp:197-223,250-255) with the EXTERNAL pieces restated:
+/// Camera::convertPixelsToBearings = radtan undistortion by 20 fixed-point iterations + normalisation, Camera::Triangulate =
+/// midpoint of the two rays in the frame of camera 0, lifted to the world through the spline value at `stamp`.
+static V3 pixel_to_bearing(const double* intr, const double* dist, double u, double v) {
+  const double xd = (u - intr[0]) / intr[2], yd = (v - intr[1]) / intr[3];
+  const double k1 = dist[0], k2 = dist[1], p1 = dist[2], p2 = dist[3];
+  double x = xd, y = yd;
+  for (int it = 0; it < 20; ++it) {
+    const double r2 = x * x + y * y, rad = 1 + k1 * r2 + k2 * r2 * r2;
+    const double dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x), dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+    x = (xd - dx) / rad, y = (yd - dy) / rad;
+  }
+  const double n = std::sqrt(x * x + y * y + 1);
+  return v3(x / n, y / n, 1 / n);
+}
+
+int hso_process_tracks(hso_problem* p, double stamp, int n, const double* pixels0, const double* pixels1, double* bearings0, double* bearings1,
+                       double* positions_w) {
+  const Problem& P = p->P;
+  CHECK_ARG(P.cam_T_bs.size() >= 14, "hs_process_tracks needs a stereo pair (two cameras)");
+  Quat q_wb{0, 0, 0, 1};
+  V3 p_wb = v3(0, 0, 0);
+  if (positions_w) {
+    double u;
+    const int first = segment_of(stamp, P.t0, P.dt, P.k, &u);
+    CHECK_ARG(first >= 0 && first + P.k <= P.n_cp, "stamp outside the valid range of the spline");
+    const Basis basis = make_basis(P.k);
+    const double* cps[kMaxOrder];
+    for (int j = 0; j < P.k; ++j) cps[j] = &P.cp[8 * (first + j)];
+    SplineValue sv;
+    spline_evaluate(basis, cps, u, 1.0 / P.dt, 0, false, &sv);
+    q_wb = sv.q, p_wb = v3(sv.p[0], sv.p[1], sv.p[2]);
+  }
+  const double* T0 = &P.cam_T_bs[0], *T1 = &P.cam_T_bs[7];
+  const M3 R_wb = qmat(q_wb), R_b0 = qmat(Quat{T0[0], T0[1], T0[2], T0[3]}), R_b1 = qmat(Quat{T1[0], T1[1], T1[2], T1[3]});
+  const V3 t_b0 = v3(T0[4], T0[5], T0[6]), t_b1 = v3(T1[4], T1[5], T1[6]);
+  const M3 R_01 = T(R_b0) * R_b1;
+  const V3 o = T(R_b0) * (t_b1 - t_b0);
+  for (int i = 0; i < n; ++i) {
+    const V3 b0 = pixel_to_bearing(&P.cam_intr[0], &P.cam_dist[0], pixels0[2 * i], pixels0[2 * i + 1]);
+    const V3 b1 = pixel_to_bearing(&P.cam_intr[4], &P.cam_dist[4], pixels1[2 * i], pixels1[2 * i + 1]);
+    if (bearings0)
+      for (int c = 0; c < 3; ++c) bearings0[3 * i + c] = b0[c];
+    if (bearings1)
+      for (int c = 0; c < 3; ++c) bearings1[3 * i + c] = b1[c];
+    if (!positions_w) continue;
+    const V3 d1 = R_01 * b1;
+    const double a = dot(b0, b0), b = dot(b0, d1), c = dot(d1, d1), e = dot(b0, o), f = dot(d1, o);
+    const double den = a * c - b * b;
+    const double s0 = den > 1e-12 ? (c * e - b * f) / den : 1.0, s1 = den > 1e-12 ? (b * e - a * f) / den : 1.0;
+    const V3 p0 = 0.5 * (s0 * b0 + o + s1 * d1);
+    const V3 pw = R_wb * (R_b0 * p0 + t_b0) + p_wb;
+    for (int cc = 0; cc < 3; ++cc) positions_w[3 * i + cc] = pw[cc];
+  }
+  return HS_OK;
+}
+
 int hso_sample_trajectory(hso_problem* p, int n, const double* stamps, double* pose, double* velocity, double* acceleration) {
   const Problem& P = p->P;
   const Basis basis = make_basis(P.k);

@@ -154,3 +154,19 @@ def test_sample_trajectory(hip, oracle):
             assert rel(x, y) < 1e-10
         with pytest.raises(ha.HsError):
             g.sample_trajectory([hi + 1.0])
+
+
+@pytest.mark.parametrize("order", [4, 6])
+def test_process_tracks(order, hip, oracle):
+    """Pixel -> bearing conversion and stereo triangulation through the spline (abstract.cpp:197-223,250-255)."""
+    w = synthetic.small_visual(order=order, n_cp=14, n_landmarks=10, obs_pairs=2, seed=5)
+    lo, hi = w.valid_range()
+    rng = np.random.default_rng(11)
+    n = 300
+    px0 = np.stack([rng.uniform(0, 752, n), rng.uniform(0, 480, n)], -1)
+    px1 = px0 + np.stack([rng.uniform(-40, -2, n), rng.normal(0, 0.5, n)], -1)
+    with ha.Problem(w, lib=hip) as g, ha.Problem(w, lib=oracle) as c:
+        for stamp in (lo, 0.5 * (lo + hi), hi - 1e-6):
+            a, b = g.process_tracks(stamp, px0, px1), c.process_tracks(stamp, px0, px1)
+            for x, y in zip(a, b):
+                assert np.abs(x - y).max() <= 1e-11 * max(1.0, np.abs(y).max())

@@ -112,3 +112,32 @@ def test_product_path_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(ha.HsError):
         ha.Problem(synthetic.small_visual())
+
+
+def test_process_tracks_round_trip(oracle):
+    """Front half of AbstractOptimizer::process(VisualTracks): bearings are unit vectors that re-project onto the pixels and the
+    triangulated midpoint recovers a synthetic point seen by both cameras."""
+    from hyperslam_amd import synthetic
+    w = synthetic.small_visual(order=4, n_cp=12, n_landmarks=8, obs_pairs=2)
+    lo, hi = w.valid_range()
+    stamp = 0.5 * (lo + hi)
+    rng = np.random.default_rng(3)
+    n = 50
+    # points in front of camera 0, projected through the radtan model into both cameras
+    px0 = np.stack([rng.uniform(100, 650, n), rng.uniform(80, 400, n)], -1)
+    with ha.Problem(w, lib=oracle) as p:
+        b0, _, _ = p.process_tracks(stamp, px0, px0)
+        assert np.allclose(np.linalg.norm(b0, axis=1), 1.0, atol=1e-14)
+        depth = rng.uniform(2.0, 8.0, n)
+        p0 = b0 / b0[:, 2:3] * depth[:, None]                      # sensor frame of camera 0
+        T0, T1 = w.cam_T_bs[0], w.cam_T_bs[1]
+        R0, R1 = synthetic.quat_to_matrix(T0[None, :4])[0], synthetic.quat_to_matrix(T1[None, :4])[0]
+        pb = p0 @ R0.T + T0[4:]
+        p1 = (pb - T1[4:]) @ R1
+        px1 = synthetic.project_radtan(p1, np.broadcast_to(w.cam_intrinsics[1], (n, 4)), np.broadcast_to(w.cam_distortion[1], (n, 4)))
+        re0 = synthetic.project_radtan(p0, np.broadcast_to(w.cam_intrinsics[0], (n, 4)), np.broadcast_to(w.cam_distortion[0], (n, 4)))
+        assert np.abs(re0 - px0).max() < 1e-6                       # undistortion inverts the projection
+        b0, b1, pw = p.process_tracks(stamp, px0, px1)
+        pose = p.sample_trajectory([stamp])[0]
+        Rwb = synthetic.quat_to_matrix(pose[None, :4])[0]
+        assert np.abs(pw - (pb @ Rwb.T + pose[4:])).max() < 1e-6    # midpoint triangulation recovers the point

@@ -96,7 +96,7 @@ struct hs_problem {
   DBuf<double> d_scale_p, d_Sb, d_Ub, d_Ubk, d_g_s, d_g_full, d_D2p, d_step_p, d_delta_p;
   DBuf<double> d_cost_part, d_cand_part, d_norm_part, d_dbg, d_dbg_cost;
   DBuf<DevState> d_state;
-  DBuf<double> d_xbuf, d_xpart, d_segP, d_grpQ;
+  DBuf<double> d_xbuf, d_xpart, d_segP, d_grpQ, d_gravity_part;
   DBuf<int> d_gw_ptr, d_gw_cf, d_sw_ptr, d_sw_seg;
   int n_seg_wg = 0, n_group_wg = 0;
   DBuf<double> d_ybuf, d_scale_b, d_Spb, d_Sbb, d_gb_s, d_D2b, d_Zb, d_Cb, d_hb, d_xb, d_delta_b, d_bias_g_snap, d_bias_a_snap, d_gravity_snap;
@@ -330,6 +330,7 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_xb.reserve(nbd + 1));
   HIP_TRY(p->d_delta_b.reserve(nbd + 1));
   HIP_TRY(p->d_xbuf.reserve(size_t(x_count1) + 8));
+  HIP_TRY(p->d_gravity_part.reserve(size_t(5) * std::max(p->n_bias, 1)));
   // split the accumulation over enough workgroups to fill the chip (256 CUs x a few workgroups)
   p->n_split = std::max(1, std::min(16, 2048 / std::max(p->n_cp, 1)));
   HIP_TRY(p->d_xpart.reserve(size_t(x_count1) * p->n_split));
@@ -399,7 +400,7 @@ int prepare(hs_problem* p) {
   T.cost_part = p->d_cost_part.p, T.cand_part = p->d_cand_part.p, T.n_cost_part = p->nb_vis + p->nb_pri + p->nb_ine;
   T.norm_part = p->d_norm_part.p, T.n_norm_part = nb_norm;
   T.xbuf = p->d_xbuf.p;
-  T.xpart = p->d_xpart.p, T.segP = p->d_segP.p, T.grpQ = p->d_grpQ.p, T.gw_ptr = p->d_gw_ptr.p, T.gw_cf = p->d_gw_cf.p, T.sw_ptr = p->d_sw_ptr.p, T.sw_seg = p->d_sw_seg.p;
+  T.xpart = p->d_xpart.p, T.gravity_part = p->d_gravity_part.p, T.segP = p->d_segP.p, T.grpQ = p->d_grpQ.p, T.gw_ptr = p->d_gw_ptr.p, T.gw_cf = p->d_gw_cf.p, T.sw_ptr = p->d_sw_ptr.p, T.sw_seg = p->d_sw_seg.p;
   T.xo_g = np * ncb, T.xo_gs = T.xo_g + np, T.xo_dj = T.xo_gs + np, T.xo_pb = T.xo_dj + np, T.xo_bb = T.xo_pb + np * nbd;
   T.xo_gb = T.xo_bb + nbd * nbd, T.xo_cost = T.xo_gb + nbd, T.xo_gmax = T.xo_cost + 1;
   T.ybuf = p->d_ybuf.p, T.scale_b = p->d_scale_b.p, T.Spb = p->d_Spb.p, T.Sbb = p->d_Sbb.p, T.gb_s = p->d_gb_s.p, T.D2b = p->d_D2b.p;
@@ -476,7 +477,8 @@ int launch_build(hs_problem* p) {
   if (T.nb) {
     k_border_pb<K><<<dim3(T.sp.n_cp, p->n_split), 128, 0, s>>>(T);
     k_border_zero<<<std::min(64, (T.nb * T.nb + T.nb + kBlock - 1) / kBlock), kBlock, 0, s>>>(T);
-    k_border_bb<K><<<(T.n_bias + 1 + kBlock / 64 - 1) / (kBlock / 64), kBlock, 0, s>>>(T);
+    k_border_bb<K><<<T.n_bias, kBlock, 0, s>>>(T);
+    k_border_gravity<<<1, 64, 0, s>>>(T);
   }
   if (gather)
     k_reduce_partials<<<std::min(1024, (T.xo_bb + kBlock - 1) / kBlock), kBlock, 0, s>>>(T, p->n_split, 0);

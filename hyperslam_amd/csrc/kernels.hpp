@@ -883,11 +883,11 @@ __global__ void __launch_bounds__(128) k_border_pb(Tables T) {
     const int f0 = max(0, i - K + 1), f1 = min(i, T.n_seg - 1);
     for (int first = f0; first <= f1; ++first) {
       const int ao = 6 * (i - first);
+      if (kind == 2) {
 #pragma unroll 2
-      for (int pos = T.i_seg_ptr[first] + sp; pos < T.i_seg_ptr[first + 1]; pos += nsp) {
-        const double* rec = T.i_rec + size_t(pos) * IREC;
-        const double* jp = rec + 6;
-        if (kind == 2) {
+        for (int pos = T.i_seg_ptr[first] + sp; pos < T.i_seg_ptr[first + 1]; pos += nsp) {
+          const double* rec = T.i_rec + size_t(pos) * IREC;
+          const double* jp = rec + 6;
           const double* jg = rec + 6 + 36 * K + 2 * kb;
 #pragma unroll
           for (int r = 0; r < 6; ++r) {
@@ -895,14 +895,19 @@ __global__ void __launch_bounds__(128) k_border_pb(Tables T) {
 #pragma unroll
             for (int a = 0; a < 6; ++a) acc[a] = fma(jp[r * 6 * K + ao + a], g, acc[a]);
           }
-        } else {
+        }
+      } else {
+        // branch-free body (clamped weight index, masked weight) so that the loads of four records are in flight together
+#pragma unroll 4
+        for (int pos = T.i_seg_ptr[first] + sp; pos < T.i_seg_ptr[first + 1]; pos += nsp) {
+          const double* rec = T.i_rec + size_t(pos) * IREC;
           const int j = bb - T.i_first_bias[pos];
-          if (j >= 0 && j < kb) {
-            const double wgt = rec[6 + 36 * K + kind * kb + j];
-            const double* row = jp + (3 * kind + cc) * 6 * K + ao;
+          const bool ok = j >= 0 && j < kb;
+          const double wv = rec[6 + 36 * K + kind * kb + (ok ? j : 0)];
+          const double wgt = ok ? wv : 0.0;
+          const double* row = rec + 6 + (3 * kind + cc) * 6 * K + ao;
 #pragma unroll
-            for (int a = 0; a < 6; ++a) acc[a] = fma(row[a], wgt, acc[a]);
-          }
+          for (int a = 0; a < 6; ++a) acc[a] = fma(row[a], wgt, acc[a]);
         }
       }
     }
@@ -911,45 +916,29 @@ __global__ void __launch_bounds__(128) k_border_pb(Tables T) {
   }
 }
 
+/// H_bb and J_b' r. One workgroup per bias control point b (gyro and accel parts): the records whose bias window covers b are
+/// dealt to 256 lanes, sums are combined wave by wave in a fixed order; each entry of the exchange buffer has a single writer
+/// (the region is zero-filled first by k_border_zero). The gravity block is accumulated per b over the records that START at b
+/// (every record exactly once) into T.gravity_part[b][5] and summed by k_border_gravity.
 template <int K>
 __global__ void __launch_bounds__(kBlock) k_border_bb(Tables T) {
-  // one wave per bias control point b (gyro and accel parts) + one extra wave for the gravity block; written straight into
-  // the exchange buffer (single writer per entry; the region is zero-filled first by k_border_zero)
+  constexpr int NV = 2 * hsd::kMaxOrder + 18 + 5;
+  __shared__ double red[kBlock / 64][NV];
   if (T.st->done) return;
-  const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x;
   const int kb = T.kb, nbias = T.n_bias, nb = T.nb;
-  if (b > nbias) return;
   const int IREC = 18 + 36 * K + 2 * kb;
   double* Hbb = T.xbuf + T.xo_bb;
   double* gb = T.xbuf + T.xo_gb;
   const int og = 0, oa = 3 * nbias, ogr = 6 * nbias;
-  if (b == nbias) {  // gravity-gravity and J_g' r
-    double h00 = 0, h01 = 0, h11 = 0, g0 = 0, g1 = 0;
-    for (int pos = lane; pos < T.n_ine; pos += 64) {
-      const double* rec = T.i_rec + size_t(pos) * IREC;
-      const double* jg = rec + 6 + 36 * K + 2 * kb;
-#pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        h00 = fma(jg[2 * r], jg[2 * r], h00), h01 = fma(jg[2 * r], jg[2 * r + 1], h01), h11 = fma(jg[2 * r + 1], jg[2 * r + 1], h11);
-        g0 = fma(jg[2 * r], rec[r], g0), g1 = fma(jg[2 * r + 1], rec[r], g1);
-      }
-    }
-    h00 = wave_sum(h00), h01 = wave_sum(h01), h11 = wave_sum(h11), g0 = wave_sum(g0), g1 = wave_sum(g1);
-    if (lane == 0) {
-      Hbb[size_t(ogr) * nb + ogr] = h00, Hbb[size_t(ogr) * nb + ogr + 1] = h01;
-      Hbb[size_t(ogr + 1) * nb + ogr] = h01, Hbb[size_t(ogr + 1) * nb + ogr + 1] = h11;
-      gb[ogr] = g0, gb[ogr + 1] = g1;
-    }
-    return;
-  }
   // records whose bias window covers b: first_bias in [b - kb + 1, b]
-  const int p0 = T.i_bias_ptr[max(0, b - kb + 1)], p1 = T.i_bias_ptr[b + 1];
-  double gg[hsd::kMaxOrder], aa[hsd::kMaxOrder];  // weights against b' = b + d, d = 0 .. kb - 1
-  double ggr[6] = {0, 0, 0, 0, 0, 0}, agr[6] = {0, 0, 0, 0, 0, 0}, rg[3] = {0, 0, 0}, ra[3] = {0, 0, 0};
+  const int p0 = T.i_bias_ptr[max(0, b - kb + 1)], p1 = T.i_bias_ptr[b + 1], pown = T.i_bias_ptr[b];
+  double v[NV];  // [gg(kMaxOrder) | aa(kMaxOrder) | ggr 6 | agr 6 | rg 3 | ra 3 | gravity h00 h01 h11 g0 g1]
 #pragma unroll
-  for (int d = 0; d < hsd::kMaxOrder; ++d) gg[d] = aa[d] = 0.0;
-  for (int pos = p0 + lane; pos < p1; pos += 64) {
+  for (int e = 0; e < NV; ++e) v[e] = 0.0;
+  double* gg = v, *aa = v + hsd::kMaxOrder, *ggr = v + 2 * hsd::kMaxOrder, *agr = ggr + 6, *rg = agr + 6, *ra = rg + 3, *hg = ra + 3;
+  for (int pos = p0 + tid; pos < p1; pos += kBlock) {
     const double* rec = T.i_rec + size_t(pos) * IREC;
     const int j = b - T.i_first_bias[pos];
     const double* wgp = rec + 6 + 36 * K;
@@ -965,28 +954,54 @@ __global__ void __launch_bounds__(kBlock) k_border_bb(Tables T) {
       agr[2 * c] = fma(wab, jg[2 * (3 + c)], agr[2 * c]), agr[2 * c + 1] = fma(wab, jg[2 * (3 + c) + 1], agr[2 * c + 1]);
       rg[c] = fma(wgb, rec[c], rg[c]), ra[c] = fma(wab, rec[3 + c], ra[c]);
     }
+    if (pos >= pown) {  // j == 0: this record starts at b -> its gravity terms are counted here
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        hg[0] = fma(jg[2 * r], jg[2 * r], hg[0]), hg[1] = fma(jg[2 * r], jg[2 * r + 1], hg[1]), hg[2] = fma(jg[2 * r + 1], jg[2 * r + 1], hg[2]);
+        hg[3] = fma(jg[2 * r], rec[r], hg[3]), hg[4] = fma(jg[2 * r + 1], rec[r], hg[4]);
+      }
+    }
   }
 #pragma unroll
-  for (int d = 0; d < hsd::kMaxOrder; ++d) gg[d] = wave_sum(gg[d]), aa[d] = wave_sum(aa[d]);
+  for (int e = 0; e < NV; ++e) v[e] = wave_sum(v[e]);
+  if (lane == 0)
 #pragma unroll
-  for (int c = 0; c < 6; ++c) ggr[c] = wave_sum(ggr[c]), agr[c] = wave_sum(agr[c]);
+    for (int e = 0; e < NV; ++e) red[wave][e] = v[e];
+  __syncthreads();
+  if (tid != 0) return;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) rg[c] = wave_sum(rg[c]), ra[c] = wave_sum(ra[c]);
-  if (lane == 0) {
-    for (int d = 0; d < kb && b + d < nbias; ++d)
-      for (int c = 0; c < 3; ++c) {
-        const int r0 = og + 3 * b + c, c0 = og + 3 * (b + d) + c;
-        Hbb[size_t(r0) * nb + c0] = gg[d], Hbb[size_t(c0) * nb + r0] = gg[d];
-        const int r1 = oa + 3 * b + c, c1 = oa + 3 * (b + d) + c;
-        Hbb[size_t(r1) * nb + c1] = aa[d], Hbb[size_t(c1) * nb + r1] = aa[d];
-      }
-    for (int c = 0; c < 3; ++c)
-      for (int e = 0; e < 2; ++e) {
-        Hbb[size_t(og + 3 * b + c) * nb + ogr + e] = ggr[2 * c + e], Hbb[size_t(ogr + e) * nb + og + 3 * b + c] = ggr[2 * c + e];
-        Hbb[size_t(oa + 3 * b + c) * nb + ogr + e] = agr[2 * c + e], Hbb[size_t(ogr + e) * nb + oa + 3 * b + c] = agr[2 * c + e];
-      }
-    for (int c = 0; c < 3; ++c) gb[og + 3 * b + c] = rg[c], gb[oa + 3 * b + c] = ra[c];
+  for (int e = 0; e < NV; ++e) {
+    double t = 0.0;
+    for (int w = 0; w < kBlock / 64; ++w) t += red[w][e];
+    v[e] = t;
   }
+  for (int d = 0; d < kb && b + d < nbias; ++d)
+    for (int c = 0; c < 3; ++c) {
+      const int r0 = og + 3 * b + c, c0 = og + 3 * (b + d) + c;
+      Hbb[size_t(r0) * nb + c0] = gg[d], Hbb[size_t(c0) * nb + r0] = gg[d];
+      const int r1 = oa + 3 * b + c, c1 = oa + 3 * (b + d) + c;
+      Hbb[size_t(r1) * nb + c1] = aa[d], Hbb[size_t(c1) * nb + r1] = aa[d];
+    }
+  for (int c = 0; c < 3; ++c)
+    for (int e = 0; e < 2; ++e) {
+      Hbb[size_t(og + 3 * b + c) * nb + ogr + e] = ggr[2 * c + e], Hbb[size_t(ogr + e) * nb + og + 3 * b + c] = ggr[2 * c + e];
+      Hbb[size_t(oa + 3 * b + c) * nb + ogr + e] = agr[2 * c + e], Hbb[size_t(ogr + e) * nb + oa + 3 * b + c] = agr[2 * c + e];
+    }
+  for (int c = 0; c < 3; ++c) gb[og + 3 * b + c] = rg[c], gb[oa + 3 * b + c] = ra[c];
+  for (int e = 0; e < 5; ++e) T.gravity_part[5 * b + e] = hg[e];
+}
+
+/// Gravity-gravity block and J_g' r: sum of the per-bias-point partials in index order.
+__global__ void k_border_gravity(Tables T) {
+  if (T.st->done || threadIdx.x != 0) return;
+  double h[5] = {0, 0, 0, 0, 0};
+  for (int b = 0; b < T.n_bias; ++b)
+    for (int e = 0; e < 5; ++e) h[e] += T.gravity_part[5 * b + e];
+  const int nb = T.nb, ogr = 6 * T.n_bias;
+  double* Hbb = T.xbuf + T.xo_bb;
+  Hbb[size_t(ogr) * nb + ogr] = h[0], Hbb[size_t(ogr) * nb + ogr + 1] = h[1];
+  Hbb[size_t(ogr + 1) * nb + ogr] = h[1], Hbb[size_t(ogr + 1) * nb + ogr + 1] = h[2];
+  T.xbuf[T.xo_gb + ogr] = h[3], T.xbuf[T.xo_gb + ogr + 1] = h[4];
 }
 
 __global__ void __launch_bounds__(kBlock) k_border_zero(Tables T) {

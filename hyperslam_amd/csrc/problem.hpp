@@ -161,6 +161,7 @@ struct Tables {
   double* xbuf;
   const int* sw_ptr;  // n_seg + 1: workgroups of k_seg_gram serving segment f (splits ~ record count)
   const int* sw_seg;  // segment of workgroup w
+  double* gravity_part;  // n_bias x 5: gravity block partials of k_border_bb
   double* segP;   // per k_seg_gram workgroup: [J'J (6k x 6k) | J'r (6k)]
   const int* gw_ptr;  // n_cp + 1: workgroups of k_group_gram serving landmark group c (splits ~ landmark count)
   const int* gw_cf;   // group of workgroup w

@@ -4,7 +4,7 @@
 #include <vector>
 #include <chrono>
 int main() {
-  for (int n : {216, 384}) {
+  for (int n : {216, 384, 768}) {
     std::vector<double> A(size_t(n) * n, 0.0);
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) A[size_t(i) * n + j] = (i == j ? n : 0.0) + 1.0 / (1 + abs(i - j));
     double* dA; int* info; double* dB;

@@ -114,9 +114,14 @@ def main():
     n_blocks_local = window.num_residual_blocks()
     n_blocks_global = full.num_residual_blocks()
 
-    from hyperslam_amd.distributed import attach_allreduce
+    from hyperslam_amd.distributed import attach_allreduce, attach_rccl
     problem = ha.Problem(window, device=local_rank)
-    keep = attach_allreduce(problem, dist) if world > 1 else None
+    keep = None
+    if world > 1:
+        if dist.get_backend() == "nccl" and os.environ.get("HS_EXCHANGE", "rccl") == "rccl":
+            attach_rccl(problem, dist)          # ncclAllReduce enqueued by the library on its own stream
+        else:
+            keep = attach_allreduce(problem, dist)  # Python hook (gloo test path / HS_EXCHANGE=hook)
     problem.snapshot()
 
     def step():

@@ -106,6 +106,8 @@ _PRODUCT_ONLY = {
     "restore": (C.c_int, [C.c_void_p]),
     "version": (C.c_int, []),
     "arch": (C.c_char_p, []),
+    "rccl_unique_id": (C.c_int, [C.c_char_p]),
+    "rccl_init": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
 }
 
 # every symbol include/hyperslam_hip.h declares (checked by tests/test_abi.py)

@@ -4,7 +4,9 @@
 // Replaces CeresOptimizer::{add(...), updateState, addLandmark, updateLandmarks, optimize}
 // (/root/reference/internal/hyper/optimizers/ceres/optimizer.cpp:189-382) behind flat tables. There is no CPU fallback:
 // every evaluation entry point runs the gfx950 kernels of kernels.hpp and fails with HS_ERR_DEVICE if no GPU is usable.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -112,6 +114,7 @@ struct hs_problem {
   int chol_lds_max = 64 * 1024;
   hs_allreduce_fn allreduce = nullptr;
   void* allreduce_user = nullptr;
+  void* rccl_comm = nullptr;  // ncclComm_t when hs_rccl_init was called
 };
 
 #define HS_FAIL(code, msg) \
@@ -437,7 +440,42 @@ int launch_linearize(hs_problem* p) {
   return HS_OK;
 }
 
+// ---- RCCL, loaded on first use ---------------------------------------------------------------------------------------------------
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi* rccl_api() {
+  static RcclApi api;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (api.lib) break;
+    }
+    if (api.lib) {
+      api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.lib, "ncclGetUniqueId"));
+      api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.lib, "ncclCommInitRank"));
+      api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.lib, "ncclAllReduce"));
+      api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.lib, "ncclCommDestroy"));
+      api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.lib, "ncclGetErrorString"));
+      if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) api.lib = nullptr;
+    }
+  }
+  return api.lib ? &api : nullptr;
+}
+
 int exchange(hs_problem* p, double* buf, int64_t count) {
+  if (p->rccl_comm) {  // one in-place sum all-reduce on the library's stream, no host involvement
+    const ncclResult_t r = rccl_api()->AllReduce(buf, buf, size_t(count), ncclDouble, ncclSum, static_cast<ncclComm_t>(p->rccl_comm), p->stream);
+    if (r != ncclSuccess) HS_FAIL(HS_ERR_DEVICE, std::string("ncclAllReduce failed: ") + (rccl_api()->GetErrorString ? rccl_api()->GetErrorString(r) : "?"));
+    return HS_OK;
+  }
   if (!p->allreduce) return HS_OK;
   if (p->allreduce(p->allreduce_user, buf, count, p->stream) != 0) HS_FAIL(HS_ERR_DEVICE, "all-reduce hook reported a failure");
   return HS_OK;
@@ -610,6 +648,7 @@ int hs_destroy(hs_problem* p) {
   (void)hipStreamSynchronize(p->stream);
   for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
   if (p->h_state) (void)hipHostFree(p->h_state);
+  if (p->rccl_comm && rccl_api()) (void)rccl_api()->CommDestroy(static_cast<ncclComm_t>(p->rccl_comm));
   if (p->own_stream) (void)hipStreamDestroy(p->stream);
   delete p;
   return HS_OK;
@@ -1031,6 +1070,31 @@ int hs_restore(hs_problem* p) {
     HIP_TRY(hipMemcpyAsync(p->d_bias_a.p, p->d_bias_a_snap.p, p->bias_a.size() * 8, hipMemcpyDeviceToDevice, p->stream));
     HIP_TRY(hipMemcpyAsync(p->d_gravity.p, p->d_gravity_snap.p, 24, hipMemcpyDeviceToDevice, p->stream));
   }
+  return HS_OK;
+}
+
+int hs_rccl_unique_id(char id[128]) {
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  if (!id) return HS_ERR_INVALID;
+  RcclApi* api = rccl_api();
+  if (!api) return HS_ERR_DEVICE;
+  ncclUniqueId u;
+  if (api->GetUniqueId(&u) != ncclSuccess) return HS_ERR_DEVICE;
+  std::memcpy(id, &u, 128);
+  return HS_OK;
+}
+
+int hs_rccl_init(hs_problem* p, const char id[128], int rank, int world) {
+  if (!p || !id || world < 1 || rank < 0 || rank >= world) return HS_ERR_INVALID;
+  RcclApi* api = rccl_api();
+  if (!api) HS_FAIL(HS_ERR_DEVICE, "librccl.so could not be loaded");
+  HIP_TRY(hipSetDevice(p->device));
+  ncclUniqueId u;
+  std::memcpy(&u, id, 128);
+  ncclComm_t comm = nullptr;
+  const ncclResult_t r = api->CommInitRank(&comm, world, u, rank);
+  if (r != ncclSuccess) HS_FAIL(HS_ERR_DEVICE, std::string("ncclCommInitRank failed: ") + (api->GetErrorString ? api->GetErrorString(r) : "?"));
+  p->rccl_comm = comm;
   return HS_OK;
 }
 

@@ -77,3 +77,24 @@ def attach_allreduce(problem, dist, group=None, device_memory=None):
     problem._check(problem.lib.set_allreduce(problem.h, cb, None), "set_allreduce")
     problem._allreduce_cb = cb
     return cb
+
+
+def attach_rccl(problem, dist, group=None):
+    """RCCL directly on the data path (no Python in the solve loop): torch.distributed is used once, to agree on the band layout and
+    to hand rank 0's ncclUniqueId to the other ranks; the library then owns its communicator and enqueues ncclAllReduce on its own
+    stream. Needs one GPU per rank."""
+    import torch
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    comm_device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    problem._check(problem.lib.set_shard(problem.h, rank, world, 0), "set_shard")
+    bw = torch.tensor([problem.lib.band_blocks(problem.h)], dtype=torch.int64, device=comm_device)
+    dist.all_reduce(bw, op=dist.ReduceOp.MAX, group=group)
+    problem._check(problem.lib.set_shard(problem.h, rank, world, int(bw.item())), "set_shard")
+    buf = C.create_string_buffer(128)
+    if rank == 0 and problem.lib.rccl_unique_id(buf) != 0:
+        raise RuntimeError("hs_rccl_unique_id failed (librccl.so not loadable?)")
+    uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).to(comm_device)
+    dist.broadcast(uid, src=0, group=group)
+    raw = bytes(uid.cpu().numpy().tobytes())
+    problem._check(problem.lib.rccl_init(problem.h, raw, rank, world), "rccl_init")

@@ -163,6 +163,12 @@ int hs_reduced_system(hs_problem* p, double radius, double* S, double* g);
  * Jacobi scaling, monotonic steps). iterations (nullable) receives max_iterations + 1 records (record 0 = initial point). */
 int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteration* iterations);
 int hs_set_allreduce(hs_problem* p, hs_allreduce_fn fn, void* user);
+/* RCCL on the data path without a host hook: rank 0 obtains a 128-byte unique id (ncclGetUniqueId), the caller distributes it
+ * by any means (torch.distributed in bench.py), every rank then creates its communicator (ncclCommInitRank on the handle's
+ * device). From then on both per-iteration exchanges are ncclAllReduce(sum, f64, in place) enqueued on the handle's stream; the
+ * hook of hs_set_allreduce, if any, is ignored. librccl.so is loaded on first use (no link-time dependency). */
+int hs_rccl_unique_id(char id[128]);
+int hs_rccl_init(hs_problem* p, const char id[128], int rank, int world);
 /* Residual-sharded operation: this handle holds shard `rank` of `world` (all observations of a landmark on one rank,
  * control points / sensors replicated). min_band_blocks = max over ranks of hs_band_blocks() so that every rank uses the
  * same band layout for the exchanged reduced system. */

@@ -27,7 +27,13 @@ def main():
         attach_allreduce(p, dist)
         s1 = p.solve(5)
         cp1 = p.control_points()
-    np.savez(out, c0=[it["cost"] for it in s0["iterations"]], c1=[it["cost"] for it in s1["iterations"]], cp0=cp0, cp1=cp1)
+    from hyperslam_amd.distributed import attach_rccl
+    with ha.Problem(w) as p:
+        attach_rccl(p, dist)  # library-owned communicator, ncclAllReduce on the library's stream
+        s2 = p.solve(5)
+        cp2 = p.control_points()
+    np.savez(out, c0=[it["cost"] for it in s0["iterations"]], c1=[it["cost"] for it in s1["iterations"]], cp0=cp0, cp1=cp1,
+             c2=[it["cost"] for it in s2["iterations"]], cp2=cp2)
     dist.destroy_process_group()
 
 

@@ -42,3 +42,4 @@ def test_rccl_hook_single_rank(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     d = np.load(out)
     assert np.array_equal(d["c0"], d["c1"]) and np.array_equal(d["cp0"], d["cp1"])
+    assert np.array_equal(d["c0"], d["c2"]) and np.array_equal(d["cp0"], d["cp2"])   # hs_rccl_init path (no Python hook)

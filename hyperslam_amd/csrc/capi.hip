@@ -551,7 +551,8 @@ int launch_factor(hs_problem* p) {
   else  // long feature tracks: trailing window in L2 instead of registers
     k_band_factor_wide<<<1, kWideThreads, size_t(6) * (ncb + 2) * sizeof(double), s>>>(T);
   if (T.nb) {  // bordered system (bias splines + gravity)
-    k_border_forward<<<(T.nb + kBorderCols - 1) / kBorderCols, 128, size_t(T.np) * kBorderCols * sizeof(double), s>>>(T);
+    const int fwd_threads = std::max(128, 64 * ((6 * (T.bw - 1) + 63) / 64));  // one lane per pending row
+    k_border_forward<<<(T.nb + kBorderCols - 1) / kBorderCols, fwd_threads, size_t(T.np) * kBorderCols * sizeof(double), s>>>(T);
     const int nt = (T.nb + kSchurTile - 1) / kSchurTile;
     k_border_schur<<<dim3(nt, nt), kBlock, 0, s>>>(T);
     k_border_solve<<<1, kBlock, (size_t(T.nb + 1) * (T.nb + 1) + T.nb) * sizeof(double), s>>>(T);

@@ -1092,7 +1092,7 @@ __global__ void __launch_bounds__(kBlock) k_finalize_border(Tables T) {
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kBorderCols = 8;  // right-hand sides per workgroup in the forward sweep
 
-__global__ void __launch_bounds__(128) k_border_forward(Tables T) {
+__global__ void __launch_bounds__(kBlock) k_border_forward(Tables T) {  // blockDim = 64 x waves covering the 6 (bw - 1) pending rows (>= 128)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (T.st->done) return;
   const int tid = threadIdx.x;

@@ -1,0 +1,165 @@
+"""Edge cases of the hot path, HIP vs oracle: the shapes the reference's window maintenance produces (frozen / unobserved
+control points, constant or unobserved landmarks, clamped boundary stamps, minimal windows, rotation- or translation-constant
+splines, constant biases) plus degenerate inputs (empty tables)."""
+import copy
+
+import numpy as np
+import pytest
+
+import hyperslam_amd as ha
+from hyperslam_amd import synthetic
+from util import rel
+
+pytestmark = pytest.mark.gpu
+
+
+def compare(w, hip, oracle, iters=5, tol=1e-6, check_lm=True):
+    with ha.Problem(w, lib=hip) as g, ha.Problem(w, lib=oracle) as c:
+        cg, cc = g.cost(), c.cost()
+        assert abs(cg - cc) <= 1e-11 * max(cc, 1e-300)
+        Sg, gg = g.reduced_system(1e4)
+        Sc, gc = c.reduced_system(1e4)
+        assert rel(Sg, Sc) < 1e-9 and rel(gg, gc) < 1e-9
+        sg, sc = g.solve(iters), c.solve(iters)
+        assert sg["num_iterations"] == sc["num_iterations"] and sg["termination"] == sc["termination"]
+        assert abs(sg["final_cost"] - sc["final_cost"]) <= tol * abs(sc["final_cost"]) + 1e-8 * sc["initial_cost"]
+        assert rel(g.control_points(), c.control_points()) < tol
+        if check_lm and len(w.landmarks):
+            assert rel(g.landmarks(), c.landmarks()) < tol
+        return sg
+
+
+def test_minimal_window(hip, oracle):
+    """n_cp == k: a single segment (the bootstrap state of abstract.cpp:76-96 right after the first frames)."""
+    for k in (4, 6):
+        w = synthetic.small_visual(order=k, n_cp=k, n_landmarks=12, obs_pairs=2, seed=31)
+        w.cp_constant = np.r_[np.ones(2, np.uint8), np.zeros(k - 2, np.uint8)]
+        compare(w, hip, oracle)
+
+
+def test_frozen_and_unobserved_control_points(hip, oracle):
+    """Old control points frozen (optimizer.cpp:323-328); the newest ones carry no residual at all (held poses after an extension,
+    abstract.cpp:127-137): their diagonal blocks are pure LM damping."""
+    w = synthetic.small_visual(order=4, n_cp=20, n_landmarks=50, obs_pairs=3, seed=32)
+    lo, hi = w.valid_range()
+    cut = lo + 0.7 * (hi - lo)  # no observation after `cut`
+    keep = w.pixel_stamps < cut
+    for name in ("pixel_stamps", "pixels", "pixel_landmark", "pixel_camera"):
+        setattr(w, name, getattr(w, name)[keep])
+    w.cp_constant = np.r_[np.ones(5, np.uint8), np.zeros(15, np.uint8)]
+    compare(w, hip, oracle)
+
+
+def test_constant_and_unobserved_landmarks(hip, oracle):
+    w = synthetic.small_visual(order=4, n_cp=16, n_landmarks=40, obs_pairs=3, seed=33)
+    lc = np.zeros(40, np.uint8)
+    lc[::5] = 1  # every fifth landmark constant
+    w.landmark_constant = lc
+    drop = np.isin(w.pixel_landmark, [3, 17])  # two landmarks lose all their observations (still in the table)
+    for name in ("pixel_stamps", "pixels", "pixel_landmark", "pixel_camera"):
+        setattr(w, name, getattr(w, name)[~drop])
+    before = w.landmarks.copy()
+    with ha.Problem(w, lib=hip) as g:
+        g.solve(5)
+        after = g.landmarks()
+    assert np.array_equal(after[lc == 1], before[lc == 1]) and np.array_equal(after[[3, 17]], before[[3, 17]])
+    compare(w, hip, oracle)
+
+
+def test_boundary_stamps(hip, oracle):
+    """Residual stamps exactly on the first knot of the valid range and one ulp below its end."""
+    w = synthetic.small_visual(order=4, n_cp=14, n_landmarks=30, obs_pairs=3, seed=34)
+    lo, hi = w.valid_range()
+    st = w.pixel_stamps.copy()
+    st[:10] = lo
+    st[10:20] = np.nextafter(hi, lo)
+    w.pixel_stamps = st
+    compare(w, hip, oracle, tol=1e-5)
+
+
+@pytest.mark.parametrize("which", ["rotation", "translation"])
+def test_constancy_flags(which, hip, oracle):
+    """`rotation_constant` / `translation_constant` of the backend YAML: half of every control point frozen."""
+    w = synthetic.small_visual(order=4, n_cp=14, n_landmarks=40, obs_pairs=3, seed=35, with_priors=10)
+    setattr(w, which + "_constant", True)
+    cp0 = w.control_points.copy()
+    with ha.Problem(w, lib=hip) as g:
+        g.solve(5)
+        cp1 = g.control_points()
+    frozen = slice(0, 4) if which == "rotation" else slice(4, 7)
+    assert np.array_equal(cp1[:, frozen], cp0[:, frozen])
+    compare(w, hip, oracle)
+
+
+def test_constant_biases_and_gravity(hip, oracle):
+    w = synthetic.small_inertial(order=4, n_cp=16, n_landmarks=30, obs_pairs=3, n_inertial=80, seed=36)
+    w.imu["bias_constant"] = True
+    w.gravity_constant = True
+    bg0 = w.imu["bias_g"].copy()
+    with ha.Problem(w, lib=hip) as g:
+        g.solve(5)
+        bg1, _ = g.bias()
+        assert np.array_equal(bg1[:, :3], bg0[:, :3]) and np.array_equal(g.gravity(), w.gravity)
+    compare(w, hip, oracle)
+
+
+def test_inertial_only_window(hip, oracle):
+    """No visual residual at all: the reduced system is the pose block + border, no landmark elimination."""
+    w = synthetic.small_inertial(order=4, n_cp=14, n_landmarks=10, obs_pairs=2, n_inertial=120, seed=37)
+    for name in ("pixel_stamps", "pixels", "pixel_landmark", "pixel_camera"):
+        setattr(w, name, getattr(w, name)[:0])
+    w.landmarks = w.landmarks[:0]
+    w.cp_constant = np.r_[np.ones(3, np.uint8), np.zeros(11, np.uint8)]
+    compare(w, hip, oracle, check_lm=False)
+
+
+def test_empty_problem(hip):
+    """A spline without any residual: cost 0, the solve terminates at once, nothing moves."""
+    w = synthetic.small_visual(order=4, n_cp=10, n_landmarks=5, obs_pairs=2, seed=38)
+    for name in ("pixel_stamps", "pixels", "pixel_landmark", "pixel_camera"):
+        setattr(w, name, getattr(w, name)[:0])
+    w.landmarks = w.landmarks[:0]
+    with ha.Problem(w, lib=hip) as g:
+        assert g.cost() == 0.0
+        s = g.solve(5)
+        assert s["final_cost"] == 0.0 and np.array_equal(g.control_points(), w.control_points)
+
+
+def test_many_observations_of_one_landmark(hip, oracle):
+    """One landmark seen in every frame (a long track next to short ones): exercises uneven group / segment work lists."""
+    w = synthetic.small_visual(order=4, n_cp=18, n_landmarks=30, obs_pairs=3, seed=39)
+    lo, hi = w.valid_range()
+    n_extra = 120
+    st = np.linspace(lo, hi - 1e-6, n_extra)
+    rng = np.random.default_rng(5)
+    w2 = copy.deepcopy(w)
+    w2.pixel_stamps = np.r_[w.pixel_stamps, st]
+    w2.pixels = np.r_[w.pixels, np.stack([rng.uniform(100, 600, n_extra), rng.uniform(100, 400, n_extra)], -1)]
+    w2.pixel_landmark = np.r_[w.pixel_landmark, np.zeros(n_extra, np.int32)]
+    w2.pixel_camera = np.r_[w.pixel_camera, np.zeros(n_extra, np.int32)]
+    compare(w2, hip, oracle, tol=1e-5)
+
+
+def test_long_tracks_with_imu(hip, oracle):
+    """Window-wide feature tracks (wide-band factorisation) together with the bias / gravity border, as in the sliding-window replay."""
+    w = synthetic.small_visual(order=4, n_cp=30, n_landmarks=60, obs_pairs=6, seed=40, span=2.8)
+    synthetic.add_imu(w, synthetic.SplitMix64(77), 150, identity=True, gravity_constant=False)
+    w.cp_constant = np.r_[np.ones(3, np.uint8), np.zeros(27, np.uint8)]
+    with ha.Problem(w, lib=hip) as g:
+        g.cost()
+        assert g.lib.band_blocks(g.h) > 22  # really on the wide path
+    compare(w, hip, oracle, tol=1e-5)
+
+
+def test_band_width_limits(hip, oracle):
+    """Tracks touching up to 42 control points are supported (6 bw <= 256); wider ones are rejected with a message, never silently."""
+    w = synthetic.small_visual(order=4, n_cp=44, n_landmarks=60, obs_pairs=8, seed=41, span=3.75)
+    with ha.Problem(w, lib=hip) as g:
+        g.cost()
+        bw = g.lib.band_blocks(g.h)
+    assert 36 <= bw <= 42, bw
+    compare(w, hip, oracle, tol=1e-5)
+    w = synthetic.small_visual(order=4, n_cp=60, n_landmarks=40, obs_pairs=10, seed=42, span=5.6)
+    with ha.Problem(w, lib=hip) as g:
+        with pytest.raises(RuntimeError, match="span too many control points"):
+            g.solve(2)

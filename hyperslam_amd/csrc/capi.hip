@@ -549,7 +549,7 @@ int launch_factor(hs_problem* p) {
   else if (T.bw * T.bw <= 2 * kCholThreads)  // bw = 21, 22: too many tiles for the look-ahead kernel's 192 compute lanes
     k_band_factor<2><<<1, kCholThreads + kCholIo, chol_lds, s>>>(T);
   else  // long feature tracks: trailing window in L2 instead of registers
-    k_band_factor_wide<<<1, kWideThreads, size_t(6) * (ncb + 2) * sizeof(double), s>>>(T);
+    k_band_factor_wide<<<1, kWideThreads, size_t(12) * (ncb + 2) * sizeof(double), s>>>(T);
   if (T.nb) {  // bordered system (bias splines + gravity)
     const int fwd_threads = std::max(128, 64 * ((6 * (T.bw - 1) + 63) / 64));  // one lane per pending row
     k_border_forward<<<(T.nb + kBorderCols - 1) / kBorderCols, fwd_threads, size_t(T.np) * kBorderCols * sizeof(double), s>>>(T);

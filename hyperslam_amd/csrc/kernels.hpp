@@ -1950,9 +1950,15 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
   lds_barrier();
 }
 
-/// Fallback factorisation for wide bands (long feature tracks: bw * bw > 2 * kCholThreads): same algorithm and outputs
-/// (Ub, U_ii^-1, y) but the trailing window stays in HBM/L2 (in place in Sb) instead of registers. One workgroup of 1024 lanes.
-constexpr int kWideThreads = 1024;
+/// Factorisation for wide bands (long feature tracks: more tiles than the register-resident kernels can hold): same algorithm and
+/// outputs (Ub, U_ii^-1, y). The trailing window stays in HBM / L2 (in place in Sb), one 6x6 tile per lane and step:
+///   P1  every lane factors the 6x6 diagonal block of the pivot row redundantly in registers (the row sits in LDS), lane c solves
+///       column c of X = U_ii^-T [S_i,: | g_i] -> LDS (for the update) and HBM (the factor row);           --- barrier ---
+///   P2  lane (j, kk), 1 <= j < bw, j + kk <= bw - 1: tile (i + j, kk) -= X_j' X_(j+kk) (load from L2, 216 FMAs, store back);
+///       the lanes of row i + 1 also publish their tile as the next pivot row in LDS;  stores drained   --- barrier ---
+/// One workgroup of 512 lanes, two tiles per lane (bw <= 42: at most 862 tiles; 1024 lanes would leave 128 registers per lane and
+/// spill the 6x6 accumulator). LDS (doubles): rowbuf 6 x ld | xbuf 6 x ld.
+constexpr int kWideThreads = 512, kWideTiles = 2;
 
 __global__ void __launch_bounds__(kWideThreads) k_band_factor_wide(Tables T) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -1961,88 +1967,157 @@ __global__ void __launch_bounds__(kWideThreads) k_band_factor_wide(Tables T) {
   const int tid = threadIdx.x;
   const int bw = T.bw, ncb = 6 * bw, ld = ncb + 2;
   const int n_blk = T.np / 6;
-  double* xbuf = smem;  // 6 x ld : [U_ii | X | y_i]
-  __shared__ double Uii[36], Winv[24];
+  double* rowbuf = smem;          // 6 x ld : pivot row [band | rhs]
+  double* xbuf = smem + 6 * ld;   // 6 x ld : [U_ii | X | y_i]
   __shared__ int fail;
   if (tid == 0) fail = 0;
-  __syncthreads();
-  for (int i = 0; i < n_blk; ++i) {
-    double* rowS = T.Sb + size_t(6) * i * ncb;
-    if (tid == 0) {  // 6x6 upper Cholesky + inverse of the factor
-      double A[36];
-      for (int a = 0; a < 6; ++a)
-        for (int c = 0; c < 6; ++c) A[6 * a + c] = rowS[size_t(a) * ncb + c];
-      for (int a = 0; a < 6; ++a) {
-        double d = A[7 * a];
-        for (int k = 0; k < a; ++k) d -= A[6 * k + a] * A[6 * k + a];
-        if (!(d > 0.0)) fail = 1, d = 1.0;
-        d = sqrt(d);
-        A[7 * a] = d;
-        for (int c = a + 1; c < 6; ++c) {
-          double v = A[6 * a + c];
-          for (int k = 0; k < a; ++k) v -= A[6 * k + a] * A[6 * k + c];
-          A[6 * a + c] = v / d;
-        }
-        for (int c = 0; c < a; ++c) A[6 * a + c] = 0.0;
-      }
-      double W[36] = {0};
-      for (int c = 5; c >= 0; --c) {
-        W[7 * c] = 1.0 / A[7 * c];
-        for (int a = c - 1; a >= 0; --a) {
-          double v = 0.0;
-          for (int k = a + 1; k <= c; ++k) v += A[6 * a + k] * W[6 * k + c];
-          W[6 * a + c] = -v / A[7 * a];
-        }
-      }
-      int pidx = 0;
-      for (int a = 0; a < 6; ++a)
-        for (int c = a; c < 6; ++c) Winv[pidx++] = W[6 * a + c];
-      for (int e = 0; e < 36; ++e) Uii[e] = A[e];
-    }
-    __syncthreads();
-    if (tid < 21) T.Ubk[size_t(i) * 24 + tid] = Winv[tid];
-    for (int c = tid; c <= ncb; c += kWideThreads) {  // X = U_ii^-T [S_i,: | g_i]
-      double x[6];
-      if (c < 6) {
+  // lane -> update tile (j, kk): row i + j, band block kk; row j holds bw - j tiles (kk <= bw - 1 - j), plus for j = 1 the tile
+  // kk = bw - 1 that is only copied into the next pivot row
+  int tj[kWideTiles], tk[kWideTiles];
+  bool t_ok[kWideTiles], t_copy[kWideTiles];
 #pragma unroll
-        for (int a = 0; a < 6; ++a) x[a] = Uii[6 * a + c];
-      } else {
+  for (int m = 0; m < kWideTiles; ++m) {
+    tj[m] = 1, tk[m] = 0, t_ok[m] = false, t_copy[m] = false;
+    int rem = tid + m * kWideThreads;
+    for (int j = 1; j < bw; ++j) {
+      const int cnt = bw - j + (j == 1 ? 1 : 0);
+      if (rem < cnt) {
+        tj[m] = j, tk[m] = rem, t_ok[m] = true, t_copy[m] = (j == 1 && rem == bw - 1);
+        break;
+      }
+      rem -= cnt;
+    }
+  }
+  for (int e = tid; e < 6 * (ncb + 1); e += kWideThreads) {  // pivot row 0
+    const int a = e / (ncb + 1), c = e % (ncb + 1);
+    rowbuf[a * ld + c] = c < ncb ? T.Sb[size_t(a) * ncb + c] : T.g_s[a];
+  }
+  __syncthreads();
+#define UIDX(a, c) ((a) * 6 - (a) * ((a)-1) / 2 + ((c) - (a)))
+  for (int i = 0; i < n_blk; ++i) {
+    // ---- P1 ----
+    {
+      double U[21], inv[6], dmin = 1.0;
+      {
+        int pidx = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int c = a; c < 6; ++c) U[pidx++] = rowbuf[a * ld + c];
+      }
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        double d = U[UIDX(a, a)];
+#pragma unroll
+        for (int k = 0; k < a; ++k) d = fma(-U[UIDX(k, a)], U[UIDX(k, a)], d);
+        dmin = a == 0 ? d : fmin(dmin, d);
+        const double y = __builtin_amdgcn_rsq(d);
+        const double e = fma(-d * y, y, 1.0);
+        const double rs = fma(y * e, fma(0.375, e, 0.5), y);
+        inv[a] = rs;
+#pragma unroll
+        for (int c = a + 1; c < 6; ++c) {
+          double t = U[UIDX(a, c)];
+#pragma unroll
+          for (int k = 0; k < a; ++k) t = fma(-U[UIDX(k, a)], U[UIDX(k, c)], t);
+          U[UIDX(a, c)] = t * rs;
+        }
+      }
+      if (!(dmin > 0.0) && tid == 0) fail = 1;
+      if (tid <= ncb) {  // column tid of [U_ii | X | y]
+        const int c = tid;
+        double x[6];
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
-          double v = c < ncb ? rowS[size_t(a) * ncb + c] : T.g_s[6 * i + a];
+          double t = rowbuf[a * ld + c];
 #pragma unroll
-          for (int k = 0; k < a; ++k) v -= Uii[6 * k + a] * x[k];
-          x[a] = v / Uii[7 * a];
+          for (int k = 0; k < a; ++k) t = fma(-U[UIDX(k, a)], x[k], t);
+          x[a] = t * inv[a];
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          xbuf[a * ld + c] = x[a];
+          if (c < ncb)
+            T.Ub[size_t(6 * i + a) * ncb + c] = x[a];
+          else
+            T.ybuf[6 * i + a] = x[a];
+        }
+      } else if (tid >= kWideThreads - 6) {  // W = U_ii^-1 (upper): lane c solves U w = e_c
+        const int c = tid - (kWideThreads - 6);
+        double w[6];
+#pragma unroll
+        for (int a = 5; a >= 0; --a) {
+          double t = a == c ? 1.0 : 0.0;
+#pragma unroll
+          for (int k = a + 1; k < 6; ++k) t = fma(-U[UIDX(a, k)], w[k], t);
+          w[a] = t * inv[a];
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+          if (a <= c) T.Ubk[size_t(i) * 24 + UIDX(a, c)] = w[a];
+      }
+    }
+    __syncthreads();
+    // ---- P2 ---- (the lane's tiles one after the other: two accumulators at once do not fit 256 registers without spilling)
+#pragma unroll 1
+    for (int m = 0; m < kWideTiles; ++m) {
+      // (register selects: indexing the bookkeeping arrays with the runtime m would put them in scratch)
+      const int tjm = m == 0 ? tj[0] : tj[1], tkm = m == 0 ? tk[0] : tk[1];
+      const bool okm = m == 0 ? t_ok[0] : t_ok[1], copym = m == 0 ? t_copy[0] : t_copy[1];
+      if (!okm || i + tjm >= n_blk) continue;
+      double* tile = T.Sb + size_t(6) * (i + tjm) * ncb + 6 * tkm;
+      double acc[36], rhs[6];
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c = 0; c < 6; c += 2) {
+          const double2 t = *reinterpret_cast<const double2*>(tile + size_t(a) * ncb + c);
+          acc[6 * a + c] = t.x, acc[6 * a + c + 1] = t.y;
+        }
+#pragma unroll
+      for (int a = 0; a < 6; ++a) rhs[a] = tkm == 0 ? T.g_s[6 * (i + tjm) + a] : 0.0;
+      if (!copym) {
+        const int ca = 6 * tjm, cb = 6 * (tjm + tkm);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          double xa[6], xc[6];
+#pragma unroll
+          for (int c = 0; c < 6; c += 2) {
+            const double2 va = *reinterpret_cast<const double2*>(&xbuf[a * ld + ca + c]);
+            const double2 vb = *reinterpret_cast<const double2*>(&xbuf[a * ld + cb + c]);
+            xa[c] = va.x, xa[c + 1] = va.y, xc[c] = vb.x, xc[c + 1] = vb.y;
+          }
+#pragma unroll
+          for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) acc[6 * r + c] = fma(-xa[r], xc[c], acc[6 * r + c]);
+          if (tkm == 0) {
+            const double y = xbuf[a * ld + ncb];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) rhs[r] = fma(-xa[r], y, rhs[r]);
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int c = 0; c < 6; c += 2) *reinterpret_cast<double2*>(tile + size_t(a) * ncb + c) = make_double2(acc[6 * a + c], acc[6 * a + c + 1]);
+        if (tkm == 0)
+#pragma unroll
+          for (int a = 0; a < 6; ++a) T.g_s[6 * (i + tjm) + a] = rhs[a];
+      }
+      if (tjm == 1) {  // next pivot row
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+          for (int c = 0; c < 6; c += 2) *reinterpret_cast<double2*>(&rowbuf[a * ld + 6 * tkm + c]) = make_double2(acc[6 * a + c], acc[6 * a + c + 1]);
+          if (tkm == 0) rowbuf[a * ld + ncb] = rhs[a];
         }
       }
-#pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        xbuf[a * ld + c] = x[a];
-        if (c < ncb)
-          T.Ub[size_t(6 * i + a) * ncb + c] = x[a];
-        else
-          T.ybuf[6 * i + a] = x[a];
-      }
     }
-    __syncthreads();
-    // trailing update in place: row 6(i+j)+a', band column c  <->  columns 6j+a' and 6j+c of block row i
-    const int per_j = 6 * (ncb + 1);
-    for (int e = tid; e < (bw - 1) * per_j; e += kWideThreads) {
-      const int j = 1 + e / per_j, rem = e % per_j;
-      const int ap = rem / (ncb + 1), c = rem % (ncb + 1);
-      if (i + j >= n_blk) continue;
-      const int ci = 6 * j + ap, cj = c == ncb ? ncb : 6 * j + c;
-      if (c < ncb && cj >= ncb) continue;
-      double sacc = 0.0;
-#pragma unroll
-      for (int a = 0; a < 6; ++a) sacc = fma(xbuf[a * ld + ci], xbuf[a * ld + cj], sacc);
-      if (c < ncb)
-        T.Sb[size_t(6 * (i + j) + ap) * ncb + c] -= sacc;
-      else
-        T.g_s[6 * (i + j) + ap] -= sacc;
-    }
+    __threadfence_block();  // the tiles stored above are read by other lanes in the next step
     __syncthreads();
   }
+#undef UIDX
   if (tid == 0) st->chol_failed = fail;
 }
 

@@ -28,12 +28,16 @@ struct DBuf {
   ~DBuf() {
     if (p) (void)hipFree(p);
   }
+  /// Capacity grows geometrically: a sliding window changes every table size by a little at every optimize(), and an exact-fit
+  /// hipFree + hipMalloc per table and solve costs more than the solve itself (hipFree synchronises the device).
   hipError_t reserve(size_t n) {
     if (n <= cap) return hipSuccess;
     if (p) (void)hipFree(p);
-    p = nullptr, cap = 0;
-    const hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(n, 1) * sizeof(T));
-    if (e == hipSuccess) cap = std::max<size_t>(n, 1);
+    p = nullptr;
+    const size_t want = std::max<size_t>(std::max<size_t>(n, 256), 2 * cap);
+    cap = 0;
+    const hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
+    if (e == hipSuccess) cap = want;
     return e;
   }
   hipError_t upload(const std::vector<T>& h, hipStream_t s) {

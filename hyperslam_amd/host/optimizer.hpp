@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <chrono>
 #include <cstdlib>
 #include <fstream>
 #include <iomanip>
@@ -202,6 +203,7 @@ class Optimizer {
 
   /// CeresOptimizer::optimize (optimizer.cpp:276-280): flat tables -> hs_solve -> write back in place.
   void optimize() {
+    const auto wall0 = std::chrono::steady_clock::now();
     const int k = opt_.order, n_cp = int(cp_.size());
     std::vector<double> cp(size_t(8) * n_cp);
     std::vector<uint8_t> frozen(n_cp);
@@ -258,7 +260,9 @@ class Optimizer {
     }
     check(HSF(set_inertial_residuals)(handle_, int(ist.size()), ist.data(), ival.data()), "set_inertial_residuals");
     if (st.empty() && ist.empty()) return;  // nothing to optimise yet
+    const auto wall1 = std::chrono::steady_clock::now();
     check(HSF(solve)(handle_, opt_.max_num_iterations, &last_summary_, nullptr), "solve");
+    const auto wall2 = std::chrono::steady_clock::now();
     ++num_optimizations_;
     // write back in place (the reference's solver mutates the variables through raw double*, optimizer.cpp:299-305,354-356)
     check(HSF(get_control_points)(handle_, cp.data()), "get_control_points");
@@ -275,7 +279,12 @@ class Optimizer {
         for (int c = 0; c < 3; ++c) bias_[j].g[c] = bg[4 * j + c], bias_[j].a[c] = ba[4 * j + c];
       check(HSF(get_gravity)(handle_, gravity_.data()), "get_gravity");
     }
+    const auto wall3 = std::chrono::steady_clock::now();
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    wall_tables_ms_ += ms(wall0, wall1), wall_solve_ms_ += ms(wall1, wall2), wall_readback_ms_ += ms(wall2, wall3);
   }
+  /// Host wall-clock split of all optimize() calls so far: building + uploading the tables, hs_solve (structure, launches, sync), read-back.
+  std::array<double, 3> wallSplitMs() const { return {wall_tables_ms_, wall_solve_ms_, wall_readback_ms_}; }
 
   /// The SIGUSR1 dump of apps/hyperslam/main.cpp:52-80: the state sampled at `rate` Hz over its range, one line per sample
   /// `stamp, qx, qy, qz, qw, px, py, pz` (scientific, 20 digits, stamp = root + sample). The samples are evaluated by the
@@ -522,6 +531,7 @@ class Optimizer {
   std::vector<BiasPoint> bias_;
   hs_summary last_summary_{};
   int num_optimizations_ = 0;
+  double wall_tables_ms_ = 0, wall_solve_ms_ = 0, wall_readback_ms_ = 0;
 };
 
 }  // namespace hyper_hip

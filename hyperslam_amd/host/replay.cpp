@@ -147,11 +147,13 @@ int main(int argc, char** argv) {
   std::printf("{\"replay_seconds\": %.2f, \"imu\": %d, \"order\": %d, \"optimizations\": %d, \"control_points\": %zu, \"landmarks\": %zu, "
               "\"mean_solve_ms\": %.4f, \"max_solve_ms\": %.4f, \"residual_blocks_per_s_in_solve\": %.1f, \"wall_ms\": %.1f, "
               "\"window\": [%.2f, %.2f], \"position_rmse_m\": %.4f, \"last_cost\": [%.6g, %.6g], "
-              "\"mean_stage_ms\": {\"linearize\": %.4f, \"schur\": %.4f, \"solve\": %.4f, \"update\": %.4f}}\n",
+              "\"mean_stage_ms\": {\"linearize\": %.4f, \"schur\": %.4f, \"solve\": %.4f, \"update\": %.4f}, "
+              "\"mean_host_wall_ms\": {\"tables\": %.4f, \"hs_solve\": %.4f, \"readback\": %.4f}}\n",
               seconds, int(with_imu), opt.order, optimizer.numOptimizations(), optimizer.numControlPoints(), optimizer.numLandmarks(),
               total_solve_ms / std::max(1, solves_seen), max_solve_ms, total_solve_ms > 0 ? 1e3 * total_blocks / total_solve_ms : 0.0, wall_ms,
               optimizer.window().lower, optimizer.window().upper, std::sqrt(se / std::max(1, n)), optimizer.lastSummary().initial_cost,
               optimizer.lastSummary().final_cost, stage_ms[0] / std::max(1, solves_seen), stage_ms[1] / std::max(1, solves_seen),
-              stage_ms[2] / std::max(1, solves_seen), stage_ms[3] / std::max(1, solves_seen));
+              stage_ms[2] / std::max(1, solves_seen), stage_ms[3] / std::max(1, solves_seen), optimizer.wallSplitMs()[0] / std::max(1, solves_seen),
+              optimizer.wallSplitMs()[1] / std::max(1, solves_seen), optimizer.wallSplitMs()[2] / std::max(1, solves_seen));
   return 0;
 }

@@ -370,10 +370,6 @@ int prepare(hs_problem* p) {
     HIP_TRY(p->d_segP.reserve(size_t(p->n_seg_wg) * (size_t(nca) * nca + nca)));
     HIP_TRY(p->d_grpQ.reserve(size_t(p->n_group_wg) * (size_t(ntile) * 36 + 6 * vs.bw) + 1));
   }
-  for (int i = 0; i < p->n_cp; ++i) {
-    const int cover = vs.cf_ptr[i + 1] - vs.cf_ptr[std::max(0, i - vs.bw + 1)];
-    if ((cover + p->n_split - 1) / p->n_split > kMaxMine) HS_FAIL(HS_ERR_INVALID, "too many landmarks cover one control point for the reduced-system gather");
-  }
   HIP_TRY(p->d_state.reserve(1));
 
   Tables& T = p->T;
@@ -496,35 +492,27 @@ int launch_build(hs_problem* p) {
     else  // long feature tracks (6 * bw <= kBlock is checked in prepare())
       k_landmark<K, 4><<<grid, kBlock, 0, s>>>(T);
   }
-  const bool gather = T.debug_flags & 8;  // A/B switch: gather formulation (re-reads every record K times)
-  if (gather) {
-    const size_t lds = (size_t(6) * 6 * T.bw + 16 + 6 * kBlock + 64) * sizeof(double) + 3 * kMaxMine * sizeof(int);
-    k_build_raw<K><<<dim3(T.sp.n_cp, p->n_split), kBlock, lds, s>>>(T);
-  } else {
-    k_seg_gram<K><<<p->n_seg_wg, kBlock, kSegStage * sizeof(double), s>>>(T);
-    if (T.n_lm && p->n_group_wg) {
-      const int ntile = T.bw * (T.bw + 1) / 2;
-      const int batch = std::max(2, std::min(kGroupBatch, int(48 * 1024 / (size_t(18) * T.bw * sizeof(double)))));
-      const size_t lds = std::max((size_t(batch) * 18 * T.bw + 4 * batch) * sizeof(double), size_t(128) * 42 * sizeof(double));
-      const dim3 grid(p->n_group_wg);
-      if (ntile <= kBlock)
-        k_group_gram<1><<<grid, kBlock, lds, s>>>(T, batch);
-      else if (ntile <= 2 * kBlock)
-        k_group_gram<2><<<grid, kBlock, lds, s>>>(T, batch);
-      else
-        k_group_gram<4><<<grid, kBlock, lds, s>>>(T, batch);
-    }
-    k_assemble<K><<<dim3(T.sp.n_cp, 6), kAsmThreads, 0, s>>>(T);
+  k_seg_gram<K><<<p->n_seg_wg, kBlock, kSegStage * sizeof(double), s>>>(T);
+  if (T.n_lm && p->n_group_wg) {
+    const int ntile = T.bw * (T.bw + 1) / 2;
+    const int batch = std::max(2, std::min(kGroupBatch, int(48 * 1024 / (size_t(18) * T.bw * sizeof(double)))));
+    const size_t lds = std::max((size_t(batch) * 18 * T.bw + 4 * batch) * sizeof(double), size_t(128) * 42 * sizeof(double));
+    const dim3 grid(p->n_group_wg);
+    if (ntile <= kBlock)
+      k_group_gram<1><<<grid, kBlock, lds, s>>>(T, batch);
+    else if (ntile <= 2 * kBlock)
+      k_group_gram<2><<<grid, kBlock, lds, s>>>(T, batch);
+    else
+      k_group_gram<4><<<grid, kBlock, lds, s>>>(T, batch);
   }
+  k_assemble<K><<<dim3(T.sp.n_cp, 6), kAsmThreads, 0, s>>>(T);
   if (T.nb) {
     k_border_pb<K><<<dim3(T.sp.n_cp, p->n_split), 128, 0, s>>>(T);
     k_border_zero<<<std::min(64, (T.nb * T.nb + T.nb + kBlock - 1) / kBlock), kBlock, 0, s>>>(T);
     k_border_bb<K><<<T.n_bias, kBlock, 0, s>>>(T);
     k_border_gravity<<<1, 64, 0, s>>>(T);
   }
-  if (gather)
-    k_reduce_partials<<<std::min(1024, (T.xo_bb + kBlock - 1) / kBlock), kBlock, 0, s>>>(T, p->n_split, 0);
-  else if (T.nb)
+  if (T.nb)
     k_reduce_partials<<<std::min(1024, (T.xo_bb - T.xo_pb + kBlock - 1) / kBlock), kBlock, 0, s>>>(T, p->n_split, T.xo_pb);
   k_pack_exchange<<<1, kBlock, 0, s>>>(T);
   HIP_TRY(hipGetLastError());

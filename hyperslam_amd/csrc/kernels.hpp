@@ -17,7 +17,6 @@
 namespace hs {
 
 constexpr int kBlock = 256;
-constexpr int kMaxMine = 1024;  // landmarks one reduced-system workgroup may own (checked by the host)
 
 HSD double wave_sum(double v) {
 #pragma unroll
@@ -377,185 +376,14 @@ __global__ void __launch_bounds__(kBlock) k_landmark(Tables T) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Reduced system: block row i of  S = Sp (J_p'J_p) Sp + D_p^2 - Sp (sum_l Yh_l Yh_l') Sp,   g = Sp (g_p - sum_l Yh_l yh_l).
-// Gather formulation: each workgroup owns one block row, walks the records of the k segments touching control point i and
-// the Y-hat rows of the landmarks covering it.  The K dimension is split over thread groups and combined in a fixed
-// order, so the result is bit-reproducible (no floating-point atomics).  Requires 6*bw <= kBlock.
-// LDS (doubles): tile 6*ncb | gacc 8 | dj 8 | red 6*kBlock + 64.
-// ---------------------------------------------------------------------------------------------------------------------
-template <int K>
-__global__ void __launch_bounds__(kBlock) k_build_raw(Tables T) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  if (T.st->done) return;
-  constexpr int VREC = 8 + 12 * K, PREC = 6 + 36 * K;
-  constexpr int NCA = 6 * K;        // columns of the J'J part
-  constexpr int GA = kBlock / NCA;  // thread groups splitting the record loop
-  const int i = blockIdx.x;
-  const int sp = blockIdx.y, nsp = gridDim.y;  // split of the accumulation (K) dimension over workgroups
-  const int ncb = 6 * T.bw;  // columns of the band row
-  const int tid = threadIdx.x;
-  double* tile = smem;            // 6 x ncb accumulated block row (unscaled)
-  double* gacc = smem + 6 * ncb;  // [0..5] J'r, [6..7] unused
-  double* dj = gacc + 8;          // [0..5] unscaled diag(J'J) of this block row
-  double* red = dj + 8;           // reduction scratch
-
-  // ---- part A: J'J and J'r ------------------------------------------------------------------------------------
-  {
-    const int grp = tid / NCA, col = tid % NCA;
-    double acc[6] = {0, 0, 0, 0, 0, 0}, gsum = 0.0;
-    if (grp < GA) {
-      const int f0 = max(0, i - K + 1), f1 = (T.debug_flags & 64) ? -1 : min(i, T.n_seg - 1);
-      for (int first = f0; first <= f1; ++first) {
-        const int ao = 6 * (i - first);
-        const int cidx = ao + col;
-        const bool valid = cidx < NCA;
-#pragma unroll 4
-        for (int pos = T.v_seg_ptr[first] + grp * nsp + sp; pos < T.v_seg_ptr[first + 1]; pos += GA * nsp) {
-          const double* rec = T.v_rec + size_t(pos) * VREC;
-#pragma unroll
-          for (int r = 0; r < 2; ++r) {
-            const double* jp = rec + 8 + r * NCA;
-            const double v = valid ? jp[cidx] : 0.0;
-#pragma unroll
-            for (int a = 0; a < 6; ++a) acc[a] = fma(jp[ao + a], v, acc[a]);
-            if (col < 6) gsum = fma(jp[ao + col], rec[r], gsum);
-          }
-        }
-        if (T.n_pri)
-          for (int pos = T.p_seg_ptr[first] + grp * nsp + sp; pos < T.p_seg_ptr[first + 1]; pos += GA * nsp) {
-            const double* rec = T.p_rec + size_t(pos) * PREC;
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-              const double* jp = rec + 6 + r * NCA;
-              const double v = valid ? jp[cidx] : 0.0;
-#pragma unroll
-              for (int a = 0; a < 6; ++a) acc[a] = fma(jp[ao + a], v, acc[a]);
-              if (col < 6) gsum = fma(jp[ao + col], rec[r], gsum);
-            }
-          }
-        if (T.n_ine) {
-          const int IREC = 18 + 36 * K + 2 * T.kb;
-          for (int pos = T.i_seg_ptr[first] + grp * nsp + sp; pos < T.i_seg_ptr[first + 1]; pos += GA * nsp) {
-            const double* rec = T.i_rec + size_t(pos) * IREC;
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-              const double* jp = rec + 6 + r * NCA;
-              const double v = valid ? jp[cidx] : 0.0;
-#pragma unroll
-              for (int a = 0; a < 6; ++a) acc[a] = fma(jp[ao + a], v, acc[a]);
-              if (col < 6) gsum = fma(jp[ao + col], rec[r], gsum);
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int a = 0; a < 6; ++a) red[(grp * 6 + a) * NCA + col] = acc[a];
-      if (col < 6) red[GA * 6 * NCA + grp * 6 + col] = gsum;
-    }
-    __syncthreads();
-    for (int e = tid; e < 6 * ncb; e += kBlock) {
-      const int a = e / ncb, c = e % ncb;
-      double s = 0.0;
-      if (c < NCA)
-        for (int g = 0; g < GA; ++g) s += red[(g * 6 + a) * NCA + c];
-      tile[e] = s;
-      if (c == a) dj[a] = s;
-    }
-    if (tid < 6) {
-      double s = 0.0;
-      for (int g = 0; g < GA; ++g) s += red[GA * 6 * NCA + g * 6 + tid];
-      gacc[tid] = s;
-    }
-    __syncthreads();
-  }
-
-  // ---- part B: Schur terms ---------------------------------------------------------------------------------------
-  double gschur = 0.0;  // valid on tid < 6
-  if (T.n_lm > 0) {
-    const int gb = kBlock / ncb;
-    const int grp = tid / ncb, col = tid % ncb;
-    const int dl0 = T.cf_ptr[max(0, i - T.bw + 1)], dl1 = T.cf_ptr[i + 1];
-    // this workgroup's landmarks: dl = dl0 + sp + t * nsp; metadata fetched once, coalesced, into LDS
-    const int n_mine = (T.debug_flags & 128) ? 0 : (dl1 > dl0 + sp ? (dl1 - dl0 - sp + nsp - 1) / nsp : 0);
-    int* m_off = reinterpret_cast<int*>(red + 6 * kBlock + 64);
-    int* m_rows = m_off + kMaxMine;
-    int* m_y = m_rows + kMaxMine;
-    for (int t = tid; t < n_mine; t += kBlock) {
-      const int dl = dl0 + sp + t * nsp;
-      const int off = i - T.lm_cfirst[dl];
-      m_off[t] = off, m_rows[t] = 6 * T.lm_ncp[dl], m_y[t] = T.lm_yoff[dl] + 18 * off;
-    }
-    __syncthreads();
-    double acc[6] = {0, 0, 0, 0, 0, 0}, gsum = 0.0;
-    if (grp < gb) {
-      // batches of four landmarks: all Y-hat loads of a batch are issued before any is consumed (one L2 round trip per
-      // batch instead of one per landmark); the landmark metadata comes from LDS (m_off / m_rows / m_y, filled above)
-      const int stride = gb * nsp;
-      for (int t0 = grp; t0 < n_mine; t0 += 4 * gb) {
-        double v[4][3], u[4][18], yh[4][3];
-        bool live[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const int t = t0 + b * gb;
-          live[b] = t < n_mine && 6 * m_off[t < n_mine ? t : 0] + col < m_rows[t < n_mine ? t : 0];
-          if (live[b]) {
-            const double* Y = T.Y + m_y[t];
-            v[b][0] = Y[3 * col], v[b][1] = Y[3 * col + 1], v[b][2] = Y[3 * col + 2];
-#pragma unroll
-            for (int e = 0; e < 18; ++e) u[b][e] = Y[e];
-            if (col < 6) {
-              const double* y3 = T.lm_yhat + 3 * (dl0 + sp + t * nsp);
-              yh[b][0] = y3[0], yh[b][1] = y3[1], yh[b][2] = y3[2];
-            }
-          }
-        }
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-          if (live[b]) {
-#pragma unroll
-            for (int a = 0; a < 6; ++a) acc[a] -= fma(u[b][3 * a], v[b][0], fma(u[b][3 * a + 1], v[b][1], u[b][3 * a + 2] * v[b][2]));
-            if (col < 6) gsum -= fma(v[b][0], yh[b][0], fma(v[b][1], yh[b][1], v[b][2] * yh[b][2]));
-          }
-      }
-      (void)stride;
-#pragma unroll
-      for (int a = 0; a < 6; ++a) red[(grp * 6 + a) * ncb + col] = acc[a];
-      if (col < 6) red[gb * 6 * ncb + grp * 6 + col] = gsum;
-    }
-    __syncthreads();
-    for (int e = tid; e < 6 * ncb; e += kBlock) {
-      const int a = e / ncb, c = e % ncb;
-      double s = 0.0;
-      for (int g = 0; g < gb; ++g) s += red[(g * 6 + a) * ncb + c];
-      tile[e] += s;
-    }
-    if (tid < 6)
-      for (int g = 0; g < gb; ++g) gschur += red[gb * 6 * ncb + g * 6 + tid];
-    __syncthreads();
-  }
-
-  // ---- raw (unscaled, undamped) partial block row; k_reduce_partials sums the splits in a fixed order ---------------
-  double* X = T.xpart + size_t(sp) * T.x_count1;
-  for (int e = tid; e < 6 * ncb; e += kBlock) {
-    const int a = e / ncb, c = e % ncb;
-    X[size_t(6 * i + a) * ncb + c] = tile[e];
-  }
-  if (tid < 6) {
-    const int rho = 6 * i + tid;
-    X[T.xo_g + rho] = gacc[tid];
-    X[T.xo_gs + rho] = gschur;
-    X[T.xo_dj + rho] = dj[tid];
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Reduced system, owner-computes formulation (the one launched): every record and every Y-hat row is read ONCE.
+// Reduced system  S = Sp (J_p'J_p) Sp + D_p^2 - Sp (sum_l Yh_l Yh_l') Sp,   g = Sp (g_p - sum_l Yh_l yh_l)  (raw, unscaled parts here;
+// scaling and damping in k_finalize_reduced). Owner-computes formulation: every record and every Y-hat row is read ONCE.
 //   k_seg_gram<K>   : one workgroup per (segment, split): P = sum J_p' J_p (6K x 6K) and J_p' r over the segment's records
 //   k_group_gram<NT>: one workgroup per (first control point c, split): Q = - sum_l Yh_l Yh_l' over the landmarks whose
 //                     track starts at c (6 bw x 6 bw window, upper 6x6 tiles), q = - sum_l Yh_l yh_l
 //   k_assemble<K>   : block row i = sum of the <= K segment partials and <= bw group partials that overlap it, in a fixed
 //                     order (bit-reproducible, no floating-point atomics), written straight into the exchange buffer
-// The gather version above (k_build_raw) re-read each record K times and each Y-hat row once per covered control point.
+// (The first version gathered per block row and re-read each record K times and each Y-hat row once per covered control point.)
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kSegStage = 6144;  // doubles of record data staged in LDS per round (48 KB)
 

@@ -113,6 +113,8 @@ struct hs_problem {
   bool has_snapshot = false;
   DevState* h_state = nullptr;  // pinned
   std::vector<hipEvent_t> events;
+  hipStream_t side = nullptr;           // second stream: the segment partials run next to the landmark pass (independent inputs)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   Tables T;
   int nb_vis = 0, nb_pri = 0, nb_cp = 0;
   int chol_lds_max = 64 * 1024;
@@ -485,6 +487,19 @@ template <int K>
 int launch_build(hs_problem* p) {
   const Tables& T = p->T;
   hipStream_t s = p->stream;
+  // k_seg_gram only needs the records, k_landmark -> k_group_gram only records and landmarks: fork / join on a side stream
+  if (!p->side) {
+    HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+  }
+  const bool fork = T.n_lm > 0 && !(T.debug_flags & 1024);
+  if (fork) {
+    HIP_TRY(hipEventRecord(p->ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+  }
+  k_seg_gram<K><<<p->n_seg_wg, kBlock, kSegStage * sizeof(double), fork ? p->side : s>>>(T);
+  if (fork) HIP_TRY(hipEventRecord(p->ev_join, p->side));
   if (T.n_lm) {
     const int grid = (T.n_lm + kBlock / 64 - 1) / (kBlock / 64);
     if (6 * T.bw <= 128)
@@ -492,7 +507,6 @@ int launch_build(hs_problem* p) {
     else  // long feature tracks (6 * bw <= kBlock is checked in prepare())
       k_landmark<K, 4><<<grid, kBlock, 0, s>>>(T);
   }
-  k_seg_gram<K><<<p->n_seg_wg, kBlock, kSegStage * sizeof(double), s>>>(T);
   if (T.n_lm && p->n_group_wg) {
     const int ntile = T.bw * (T.bw + 1) / 2;
     const int batch = std::max(2, std::min(kGroupBatch, int(48 * 1024 / (size_t(18) * T.bw * sizeof(double)))));
@@ -505,6 +519,7 @@ int launch_build(hs_problem* p) {
     else
       k_group_gram<4><<<grid, kBlock, lds, s>>>(T, batch);
   }
+  if (fork) HIP_TRY(hipStreamWaitEvent(s, p->ev_join, 0));
   k_assemble<K><<<dim3(T.sp.n_cp, 6), kAsmThreads, 0, s>>>(T);
   if (T.nb) {
     k_border_pb<K><<<dim3(T.sp.n_cp, p->n_split), 128, 0, s>>>(T);
@@ -640,6 +655,9 @@ int hs_destroy(hs_problem* p) {
   (void)hipSetDevice(p->device);
   (void)hipStreamSynchronize(p->stream);
   for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
+  if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+  if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+  if (p->side) (void)hipStreamDestroy(p->side);
   if (p->h_state) (void)hipHostFree(p->h_state);
   if (p->rccl_comm && rccl_api()) (void)rccl_api()->CommDestroy(static_cast<ncclComm_t>(p->rccl_comm));
   if (p->own_stream) (void)hipStreamDestroy(p->stream);

@@ -1429,6 +1429,8 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   DevState* st = T.st;
   if (st->done) return;
+  const FactorJob J = T.fj[blockIdx.x];
+  const int n_steps = J.n_steps;
   const int tid = threadIdx.x;
   constexpr int nthr = kLaCompute;
   constexpr int PC = 2;  // columns of the pivot row per panel lane: 6 * bw + 1 <= 128 (bw <= 20)
@@ -1462,7 +1464,7 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
         const int rr = in ? r : 0;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-          const double* src = c_rhs[m] ? T.g_s + 6 * rr : T.Sb + size_t(6 * rr) * ncb + c_col[m];
+          const double* src = c_rhs[m] ? J.g_s + 6 * rr : J.Sb + size_t(6 * rr) * ncb + c_col[m];
           const int stride = c_rhs[m] ? 1 : ncb;
 #pragma unroll
           for (int a = 0; a < 6; ++a) v[6 * m + a] = (c_ok[m] && in) ? src[a * stride] : 0.0;
@@ -1485,7 +1487,7 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
         const int e = l + 64 * m;
         const int a = e < 72 ? e / 12 : 0, c = 6 * (bw - 2) + (e < 72 ? e % 12 : 0);
         t_lds[m] = e < 72 ? a * ld + c : -1;
-        t_base[m] = T.Sb + a * ncb + c;
+        t_base[m] = J.Sb + a * ncb + c;
       }
       double ta[2], tb[2];
       auto tfetch = [&](double* v, int r) {
@@ -1505,14 +1507,14 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
       fetch(va, bw + 4);
       lds_barrier();  // init
       lds_barrier();  // prologue
-      for (int i = 0; i < n_blk; i += 2) {
+      for (int i = 0; i < n_steps; i += 2) {
         put(vb, stage + ((i + 3 + bw) & 1) * 6 * ld);
         tput(tb, rowbuf + (i & 1) * 6 * ld);  // row i + 2
         fetch(vb, i + 5 + bw);
         tfetch(tb, i + 4);
         if ((T.debug_flags & 16) && l == 0) reinterpret_cast<long long*>(T.xpart)[8 * i + 7] = wall_clock64();
         lds_barrier();
-        if (i + 1 < n_blk) {
+        if (i + 1 < n_steps) {
           put(va, stage + ((i + 4 + bw) & 1) * 6 * ld);
           tput(ta, rowbuf + ((i + 1) & 1) * 6 * ld);  // row i + 3
           fetch(va, i + 6 + bw);
@@ -1524,7 +1526,7 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
     } else {
       lds_barrier();  // init
       lds_barrier();  // prologue: X_0 complete
-      for (int i = 0; i < n_blk; ++i) {
+      for (int i = 0; i < n_steps; ++i) {
         const double* xb = xbuf + (i & 1) * 6 * ld;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -1536,7 +1538,7 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
 #pragma unroll
               for (int a = 0; a < 6; ++a) xs[6 * i + a] = x[a];
             } else {
-              double* dst = T.Ub + size_t(6 * i) * ncb + c_col[m];
+              double* dst = J.Ub + size_t(6 * i) * ncb + c_col[m];
 #pragma unroll
               for (int a = 0; a < 6; ++a) dst[a * ncb] = x[a];
             }
@@ -1557,15 +1559,15 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
             // packed upper storage index of (a, c), a <= c
 #pragma unroll
             for (int a = 0; a < 6; ++a)
-              if (a <= c) T.Ubk[size_t(i) * 24 + (a * 6 - a * (a - 1) / 2 + (c - a))] = w[a];
+              if (a <= c) J.Ubk[size_t(i) * 24 + (a * 6 - a * (a - 1) / 2 + (c - a))] = w[a];
           }
         }
         if ((T.debug_flags & 16) && l == 0) reinterpret_cast<long long*>(T.xpart)[8 * i + 6] = wall_clock64();
         lds_barrier();
       }
       lds_barrier();
-      for (int rho = l; rho < T.np; rho += 64) T.ybuf[rho] = xs[rho];  // y = U^-T g
-      if (l == 0) st->chol_failed = fail;
+      for (int rho = l; rho < 6 * n_steps; rho += 64) J.ybuf[rho] = xs[rho];  // y = U^-T g
+      if (l == 0 && fail) st->chol_failed = 1;  // (cleared by k_finalize_reduced)
     }
     return;
   }
@@ -1680,8 +1682,8 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
     lds_barrier();  // init: rows 0, 1 in rowbuf
     panel(0, false);
     lds_barrier();  // prologue
-    for (int i = 0; i < n_blk; ++i) {
-      if (i + 1 < n_blk) panel(i + 1, true);
+    for (int i = 0; i < n_steps; ++i) {
+      if (i + 1 < n_steps) panel(i + 1, true);
       lds_barrier();
     }
     lds_barrier();
@@ -1707,10 +1709,10 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
     const bool in = t_ok[m] && r < n_blk;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-      const double* src = T.Sb + size_t(6 * (in ? r : 0) + a) * ncb + 6 * t_kk[m];
+      const double* src = J.Sb + size_t(6 * (in ? r : 0) + a) * ncb + 6 * t_kk[m];
 #pragma unroll
       for (int c = 0; c < 6; ++c) acc[m][6 * a + c] = in ? src[c] : 0.0;
-      rhs[m][a] = (in && t_kk[m] == 0) ? T.g_s[6 * r + a] : 0.0;
+      rhs[m][a] = (in && t_kk[m] == 0) ? J.g_s[6 * r + a] : 0.0;
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1718,7 +1720,7 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
   lds_barrier();  // prologue: X_0 complete
   const bool prof = (T.debug_flags & 16) && tid == 0;
   long long* tlog = reinterpret_cast<long long*>(T.xpart);
-  for (int i = 0; i < n_blk; ++i) {
+  for (int i = 0; i < n_steps; ++i) {
     if (prof) tlog[8 * i + 0] = wall_clock64();
     const double* xb = xbuf + (i & 1) * 6 * ld;
 #pragma unroll
@@ -2164,6 +2166,7 @@ __global__ void __launch_bounds__(kBlock) k_cost_reduce(Tables T) {
   for (int r = 0; r < T.world; ++r) gm = fmax(gm, T.xbuf[T.xo_gmax + r]);
   st->cost = c;
   st->gmax = gm;
+  st->chol_failed = 0;    // raised by the factorisation kernels of this iteration
   st->scaling_ready = 1;  // Jacobi scaling is computed at iteration 0 only
   if (st->iteration == 0) {
     hs_iteration& r = st->records[0];

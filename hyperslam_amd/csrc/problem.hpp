@@ -57,6 +57,18 @@ struct DevState {
 };
 
 /// Everything a kernel needs, passed by value (pointers into HBM).
+/// One banded factorisation job of k_band_factor_la (two jobs when the reduced system is factored from both ends at once).
+struct FactorJob {
+  const double* Sb;   // band rows of the system (natural order for job 0, reversed order for job 1)
+  const double* g_s;  // right-hand side
+  double* Ub;         // factor rows out
+  double* Ubk;        // inverted diagonal blocks out
+  double* ybuf;       // forward-solved right-hand side out
+  double* win;        // job 1: trailing window after n_steps (w x 6 x (ncb + 1)); job 0: the other end's window to merge
+  int n_steps;        // block rows to factor
+  int merge_at;       // job 0, two-ended mode: first block row of the middle part (-1: none)
+};
+
 struct Tables {
   Spline sp;
   hsd::BasisCoef basis;
@@ -161,6 +173,9 @@ struct Tables {
   double* xbuf;
   const int* sw_ptr;  // n_seg + 1: workgroups of k_seg_gram serving segment f (splits ~ record count)
   const int* sw_seg;  // segment of workgroup w
+  FactorJob fj[2];       // k_band_factor_la jobs (blockIdx.x)
+  unsigned* join_flag;   // device word: epoch of the last finished bottom-end factorisation / published middle solution
+  unsigned join_epoch;
   double* gravity_part;  // n_bias x 5: gravity block partials of k_border_bb
   double* segP;   // per k_seg_gram workgroup: [J'J (6k x 6k) | J'r (6k)]
   const int* gw_ptr;  // n_cp + 1: workgroups of k_group_gram serving landmark group c (splits ~ landmark count)

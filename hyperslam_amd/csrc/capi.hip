@@ -103,6 +103,9 @@ struct hs_problem {
   DBuf<double> d_cost_part, d_cand_part, d_norm_part, d_dbg, d_dbg_cost;
   DBuf<DevState> d_state;
   DBuf<double> d_xbuf, d_xpart, d_segP, d_grpQ, d_gravity_part;
+  DBuf<double> d_Sb2, d_g2, d_Ub2, d_Ubk2, d_ybuf2, d_win, d_xsol;  // two-ended factorisation: reversed system, its factor, junction window
+  DBuf<unsigned> d_join;
+  unsigned join_epoch = 0;
   DBuf<int> d_gw_ptr, d_gw_cf, d_sw_ptr, d_sw_seg;
   int n_seg_wg = 0, n_group_wg = 0;
   DBuf<double> d_ybuf, d_scale_b, d_Spb, d_Sbb, d_gb_s, d_D2b, d_Zb, d_Cb, d_hb, d_xb, d_delta_b, d_bias_g_snap, d_bias_a_snap, d_gravity_snap;
@@ -340,6 +343,18 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_delta_b.reserve(nbd + 1));
   HIP_TRY(p->d_xbuf.reserve(size_t(x_count1) + 8));
   HIP_TRY(p->d_gravity_part.reserve(size_t(5) * std::max(p->n_bias, 1)));
+  HIP_TRY(p->d_Sb2.reserve(size_t(np) * ncb));
+  HIP_TRY(p->d_g2.reserve(np));
+  HIP_TRY(p->d_Ub2.reserve(size_t(np) * ncb));
+  HIP_TRY(p->d_Ubk2.reserve(size_t(p->n_cp) * 24));
+  HIP_TRY(p->d_ybuf2.reserve(np));
+  HIP_TRY(p->d_xsol.reserve(np));
+  HIP_TRY(p->d_win.reserve(size_t(6) * vs.bw * (ncb + 1)));
+  if (!p->d_join.p) {
+    HIP_TRY(p->d_join.reserve(1));
+    HIP_TRY(hipMemsetAsync(p->d_join.p, 0, sizeof(unsigned), s));
+    p->join_epoch = 0;
+  }
   // split the accumulation over enough workgroups to fill the chip (256 CUs x a few workgroups)
   p->n_split = std::max(1, std::min(16, 2048 / std::max(p->n_cp, 1)));
   HIP_TRY(p->d_xpart.reserve(size_t(x_count1) * p->n_split));
@@ -411,6 +426,7 @@ int prepare(hs_problem* p) {
   T.ybuf = p->d_ybuf.p;
   T.fj[0] = FactorJob{T.Sb, T.g_s, T.Ub, T.Ubk, T.ybuf, nullptr, np / 6, -1};
   T.fj[1] = FactorJob{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, -1};
+  T.xsol = p->d_xsol.p, T.join_flag = p->d_join.p, T.join_epoch = 0;
   T.scale_b = p->d_scale_b.p, T.Spb = p->d_Spb.p, T.Sbb = p->d_Sbb.p, T.gb_s = p->d_gb_s.p, T.D2b = p->d_D2b.p;
   T.Zb = p->d_Zb.p, T.Cb = p->d_Cb.p, T.hb = p->d_hb.p, T.xb = p->d_xb.p, T.delta_b = p->d_delta_b.p, T.i_bias_ptr = p->d_i_bias_ptr.p;
   T.x_count1 = x_count1, T.xo_dec = x_count1;
@@ -550,7 +566,29 @@ int launch_factor(hs_problem* p) {
   const size_t chol_lds = (size_t(24) * (ncb + 2) + size_t(T.np)) * sizeof(double);
   const size_t la_lds = (size_t(36) * (ncb + 2) + size_t(T.np) + 48) * sizeof(double);
   const bool legacy = T.debug_flags & 4;  // A/B switch: pre-look-ahead kernel
-  if (!legacy && T.bw * (T.bw - 2) <= kLaCompute)
+  // Factoring from both ends at once (visual-only systems, look-ahead kernel, window long enough to pay for the junction)
+  const int n_blk = T.np / 6, w_mid = T.bw - 1;
+  const bool la_ok = !legacy && T.bw * (T.bw - 2) <= kLaCompute;
+  const bool two_ended = la_ok && T.nb == 0 && n_blk >= 4 * T.bw && !(T.debug_flags & 2048);
+  if (two_ended) {
+    const int m = (n_blk - w_mid) / 2, mB = n_blk - w_mid - m;
+    Tables T2 = T;
+    T2.fj[0] = FactorJob{T.Sb, T.g_s, T.Ub, T.Ubk, T.ybuf, p->d_win.p, m + w_mid, m};
+    T2.fj[1] = FactorJob{p->d_Sb2.p, p->d_g2.p, p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, p->d_win.p, mB, -1};
+    T2.join_epoch = ++p->join_epoch;
+    k_reverse_band<<<std::min(512, (T.np * (ncb + 1) + kBlock - 1) / kBlock), kBlock, 0, s>>>(T, p->d_Sb2.p, p->d_g2.p, T.np);
+    // (more than half of the 160 KB of LDS per workgroup: the two ends must not share a CU - their chains would share SIMDs)
+    const size_t apart = size_t(96) * 1024;
+    k_band_factor_la<1><<<2, kLaThreads, std::max(la_lds, apart), s>>>(T2);
+    Tables T3 = T2;
+    T3.join_epoch = ++p->join_epoch;
+    const BackJob j0{T.Ub, T.Ubk, T.ybuf, m + w_mid, 0, 0}, j1{p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, mB, w_mid, 1};
+    k_band_backward2<<<(T.debug_flags & 4096) ? 1 : 2, kCholThreads, std::max(2 * size_t(T.np) * sizeof(double), apart), s>>>(T3, j0, j1, m);
+    k_step_outputs<<<1, kBlock, 0, s>>>(T3);
+    HIP_TRY(hipGetLastError());
+    return HS_OK;
+  }
+  if (la_ok)
     k_band_factor_la<1><<<1, kLaThreads, la_lds, s>>>(T);
   // (two tiles per lane need 168 accumulator registers: with six waves per workgroup the budget is 256 and the look-ahead
   //  kernel spills in its update loop - wider bands stay on the kernel below)
@@ -568,7 +606,13 @@ int launch_factor(hs_problem* p) {
     k_border_solve<<<1, kBlock, (size_t(T.nb + 1) * (T.nb + 1) + T.nb) * sizeof(double), s>>>(T);
     k_border_apply<<<(T.np + kBlock / 64 - 1) / (kBlock / 64), kBlock, 0, s>>>(T);
   }
-  k_band_backward<<<1, kCholThreads, 2 * size_t(T.np) * sizeof(double), s>>>(T);
+  if ((T.debug_flags & 8192) && !T.nb) {  // A/B: the generalised sweep on the whole system
+    const BackJob j0{T.Ub, T.Ubk, T.ybuf, T.np / 6, 0, 0};
+    k_band_backward2<<<1, kCholThreads, 2 * size_t(T.np) * sizeof(double), s>>>(T, j0, j0, -1);
+    k_step_outputs<<<1, kBlock, 0, s>>>(T);
+  } else {
+    k_band_backward<<<1, kCholThreads, 2 * size_t(T.np) * sizeof(double), s>>>(T);
+  }
   HIP_TRY(hipGetLastError());
   return HS_OK;
 }

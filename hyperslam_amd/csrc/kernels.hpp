@@ -12,6 +12,8 @@
 //   k_cost_visual / k_cost_prior             cost at the candidate point
 //   k_decide / k_commit                      trust-region logic and acceptance
 #pragma once
+#include <type_traits>
+
 #include "factors.hpp"
 
 namespace hs {
@@ -1420,6 +1422,14 @@ __global__ void __launch_bounds__(kCholThreads + kCholIo) k_band_factor(Tables T
 //   wave  5    storer  : streams X_i (the factor row) to HBM, keeps y in LDS, inverts U_ii for the backward sweep
 // One LDS-only barrier per block row; critical path per step = max(panel chain, rank-6 update) instead of their sum.
 // LDS (doubles): rowbuf 2 x 6 x ld | xbuf 2 x 6 x ld | stage 2 x 6 x ld | y np | diagonal scratch 36.
+//
+// Two-ended mode (grid = 2, visual-only systems): the chain over the block rows is halved by eliminating from both ends at once.
+// Workgroup 1 factors the REVERSED system (k_reverse_band) for the last n - m - w block rows (w = bw - 1), dumps its trailing
+// window (the Schur contribution of those rows to the middle block rows m .. m + w - 1) and raises a flag. Workgroup 0 factors
+// rows 0 .. m - 1, waits for the flag, adds the other end's contribution to its own trailing window (entries of the middle
+// rows that couple to the eliminated end become zero) and simply continues through the middle rows: it ends with the Cholesky
+// factor of the system in which the far end has been eliminated. k_band_backward2 solves the top part normally and the bottom
+// part in reversed coordinates once the middle solution is known.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kLaCompute = 192;
 constexpr int kLaThreads = kLaCompute + 3 * 64;
@@ -1431,6 +1441,23 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
   if (st->done) return;
   const FactorJob J = T.fj[blockIdx.x];
   const int n_steps = J.n_steps;
+  const int m_at = J.merge_at;                                  // job 0, two-ended: first middle block row (junction before it)
+  const bool dump = J.win != nullptr && m_at < 0;                // job 1, two-ended: hand the trailing window to job 0 at the end
+  const int w_mid = T.bw - 1;
+  // Job 1 hands its window over as the CORRECTION the other end has to add, already in the other end's coordinates: entry
+  // (vr, off) of the reversed window (scalar row vr of the middle block, band offset off) is entry (r, cl) of the natural one with
+  // cl = dm - 1 - vr, r = dm - 1 - off - 6 floor(vr / 6); stored at win[r][cl - 6 floor(r / 6)] (both triangles of a diagonal block).
+  auto hand_over = [&](int vr, int off, double value_minus_original) {
+    const int dm = 6 * w_mid, wl = 6 * T.bw + 1;
+    const int cl = dm - 1 - vr, r = dm - 1 - off - 6 * (vr / 6);
+    if (r < 0 || cl < 0) return;
+    const int rb = 6 * (r / 6);
+    if (cl >= rb) J.win[size_t(r) * wl + (cl - rb)] = value_minus_original;
+    if (cl / 6 == r / 6) J.win[size_t(cl) * wl + (r - rb)] = value_minus_original;  // mirrored entry of the diagonal block
+  };
+  auto junction_wait = [&]() {                                  // job 0: the other end has published its window
+    while (__hip_atomic_load(T.join_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < T.join_epoch) __builtin_amdgcn_s_sleep(8);
+  };
   const int tid = threadIdx.x;
   constexpr int nthr = kLaCompute;
   constexpr int PC = 2;  // columns of the pivot row per panel lane: 6 * bw + 1 <= 128 (bw <= 20)
@@ -1494,10 +1521,20 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) v[m] = (t_lds[m] >= 0 && r < n_blk) ? t_base[m][size_t(r < n_blk ? r : 0) * 6 * ncb] : 0.0;
       };
-      auto tput = [&](const double* v, double* dst) {
+      auto tput = [&](const double* v, double* dst, int r) {
+        // two-ended job 0: the tail blocks of the middle rows couple to the end that the other workgroup eliminates -> zero
+        // (rows m, m + 1 are in LDS at the junction and are fixed there)
+        const bool zero = m_at >= 0 && r >= m_at + 2 && r < m_at + w_mid;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
-          if (t_lds[m] >= 0) dst[t_lds[m]] = v[m];
+          if (t_lds[m] >= 0) dst[t_lds[m]] = zero ? 0.0 : v[m];
+      };
+      auto junction_io = [&](int i_done) {  // after the barrier that ends step i_done
+        if (m_at >= 0 && i_done + 1 == m_at) {
+          junction_wait();
+          lds_barrier();  // merge done
+          lds_barrier();  // panel(m) done
+        }
       };
       fetch(va, 0), fetch(vb, 1);
       put(va, rowbuf), put(vb, rowbuf + 6 * ld);
@@ -1509,20 +1546,23 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
       lds_barrier();  // prologue
       for (int i = 0; i < n_steps; i += 2) {
         put(vb, stage + ((i + 3 + bw) & 1) * 6 * ld);
-        tput(tb, rowbuf + (i & 1) * 6 * ld);  // row i + 2
+        tput(tb, rowbuf + (i & 1) * 6 * ld, i + 2);
         fetch(vb, i + 5 + bw);
         tfetch(tb, i + 4);
         if ((T.debug_flags & 16) && l == 0) reinterpret_cast<long long*>(T.xpart)[8 * i + 7] = wall_clock64();
         lds_barrier();
+        junction_io(i);
         if (i + 1 < n_steps) {
           put(va, stage + ((i + 4 + bw) & 1) * 6 * ld);
-          tput(ta, rowbuf + ((i + 1) & 1) * 6 * ld);  // row i + 3
+          tput(ta, rowbuf + ((i + 1) & 1) * 6 * ld, i + 3);
           fetch(va, i + 6 + bw);
           tfetch(ta, i + 5);
           lds_barrier();
+          junction_io(i + 1);
         }
       }
       lds_barrier();
+      if (dump) lds_barrier();  // window written by the panel / compute waves
     } else {
       lds_barrier();  // init
       lds_barrier();  // prologue: X_0 complete
@@ -1564,8 +1604,14 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
         }
         if ((T.debug_flags & 16) && l == 0) reinterpret_cast<long long*>(T.xpart)[8 * i + 6] = wall_clock64();
         lds_barrier();
+        if (m_at >= 0 && i + 1 == m_at) {
+          junction_wait();
+          lds_barrier();  // merge done
+          lds_barrier();  // panel(m) done
+        }
       }
       lds_barrier();
+      if (dump) lds_barrier();
       for (int rho = l; rho < 6 * n_steps; rho += 64) J.ybuf[rho] = xs[rho];  // y = U^-T g
       if (l == 0 && fail) st->chol_failed = 1;  // (cleared by k_finalize_reduced)
     }
@@ -1683,10 +1729,56 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
     panel(0, false);
     lds_barrier();  // prologue
     for (int i = 0; i < n_steps; ++i) {
-      if (i + 1 < n_steps) panel(i + 1, true);
+      const bool junction = m_at >= 0 && i + 1 == m_at;  // no look-ahead across the junction: row m changes there
+      if (i + 1 < n_steps && !junction) panel(i + 1, true);
       lds_barrier();
+      if (junction) {
+        junction_wait();
+        lds_barrier();  // merge done (compute waves)
+        panel(m_at, true);
+        lds_barrier();
+      }
     }
     lds_barrier();
+    if (dump) {
+      // trailing window rows 0 and 1 (block rows n_steps, n_steps + 1) are in LDS: row 0 still needs the update by X_(n_steps-1)
+      const int r = n_steps;
+      const double* row = rowbuf + (r & 1) * 6 * ld;
+      const double* xp = xbuf + ((r - 1) & 1) * 6 * ld;
+      const double* row1 = rowbuf + ((r + 1) & 1) * 6 * ld;
+      double B[6][6];
+#pragma unroll
+      for (int ap = 0; ap < 6; ++ap)
+#pragma unroll
+        for (int a = 0; a < 6; ++a) B[ap][a] = xp[ap * ld + 6 + a];
+#pragma unroll
+      for (int m = 0; m < PC; ++m) {
+        const int c = l + 64 * m;
+        if (c > ncb) continue;
+        double xc[6];
+#pragma unroll
+        for (int ap = 0; ap < 6; ++ap) xc[ap] = c_live[m] ? xp[ap * ld + c_src[m]] : 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          double v = row[a * ld + c];
+#pragma unroll
+          for (int ap = 0; ap < 6; ++ap) v = fma(-B[ap][a], xc[ap], v);
+          if (c == ncb) {  // right-hand side: row vr of the reversed middle block is row dm - 1 - vr of the natural one
+            J.win[size_t(6 * w_mid - 1 - a) * (ncb + 1) + ncb] = v - J.g_s[6 * r + a];
+            J.win[size_t(6 * w_mid - 1 - (6 + a)) * (ncb + 1) + ncb] = row1[a * ld + c] - J.g_s[6 * (r + 1) + a];
+          } else {
+            hand_over(a, c, v - J.Sb[size_t(6 * r + a) * ncb + c]);
+            hand_over(6 + a, c, row1[a * ld + c] - J.Sb[size_t(6 * (r + 1) + a) * ncb + c]);
+          }
+        }
+      }
+      __threadfence();
+      lds_barrier();
+      if (l == 0) {
+        __threadfence();
+        __hip_atomic_store(T.join_flag, T.join_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
 #undef UIDX
     return;
   }
@@ -1776,8 +1868,195 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
     }
     if (prof) tlog[8 * i + 1] = wall_clock64();
     lds_barrier();
+    if (m_at >= 0 && i + 1 == m_at) {  // ---- junction: add the other end's Schur contribution to the middle rows ----
+      junction_wait();
+      const int dm = 6 * w_mid, wl = ncb + 1;
+      const double* WD = J.win;  // correction in this job's own band layout, local to the middle rows (see hand_over)
+      // rows m and m + 1 sit in LDS
+      for (int e = tid; e < 2 * 6 * (ncb + 1); e += nthr) {
+        const int jr = e / (6 * (ncb + 1)), rem = e % (6 * (ncb + 1)), a = rem / (ncb + 1), c = rem % (ncb + 1);
+        double* dst = rowbuf + ((m_at + jr) & 1) * 6 * ld + a * ld + c;
+        const double d = WD[size_t(6 * jr + a) * wl + c];
+        *dst = (c == ncb || 6 * jr + c < dm) ? *dst + d : 0.0;  // columns beyond the middle couple to the eliminated end
+      }
+#pragma unroll
+      for (int m = 0; m < TPT; ++m) {
+        const int jr = t_row[m] - m_at;
+        if (!t_ok[m] || jr < 2 || jr >= w_mid) continue;
+        const bool inside = jr + t_kk[m] <= w_mid - 1;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) acc[m][6 * a + c] = inside ? acc[m][6 * a + c] + WD[size_t(6 * jr + a) * wl + 6 * t_kk[m] + c] : 0.0;
+          if (t_kk[m] == 0) rhs[m][a] += WD[size_t(6 * jr + a) * wl + ncb];
+        }
+      }
+      lds_barrier();  // merge done
+      lds_barrier();  // panel(m) done
+    }
   }
   lds_barrier();
+  if (dump) {  // rows n_steps + 2 .. n_steps + w - 1 of the trailing window live in the register tiles
+#pragma unroll
+    for (int m = 0; m < TPT; ++m) {
+      const int jr = t_row[m] - n_steps;
+      if (!t_ok[m] || jr < 2 || jr >= w_mid) continue;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+          hand_over(6 * jr + a, 6 * t_kk[m] + c, acc[m][6 * a + c] - J.Sb[size_t(6 * t_row[m] + a) * ncb + 6 * t_kk[m] + c]);
+        if (t_kk[m] == 0) J.win[size_t(6 * w_mid - 1 - (6 * jr + a)) * (ncb + 1) + ncb] = rhs[m][a] - J.g_s[6 * t_row[m] + a];
+      }
+    }
+    __threadfence();
+    lds_barrier();
+  }
+}
+
+/// Reversed copy of the finalised band system for the bottom end of the two-ended factorisation: row / column rho -> np - 1 - rho
+/// (blocks stay aligned, np is a multiple of 6). Only the first `n_rows` scalar rows of the reversed system are produced.
+__global__ void __launch_bounds__(kBlock) k_reverse_band(Tables T, double* Sb2, double* g2, int n_rows) {
+  if (T.st->done) return;
+  const int np = T.np, ncb = 6 * T.bw;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_rows * (ncb + 1); e += gridDim.x * blockDim.x) {
+    const int rv = e / (ncb + 1), cp = e % (ncb + 1);
+    if (cp == ncb) {
+      g2[rv] = T.g_s[np - 1 - rv];
+      continue;
+    }
+    const int cv = 6 * (rv / 6) + cp;  // absolute column in the reversed system
+    double v = 0.0;
+    if (cv < np) {
+      const int r = np - 1 - rv, c = np - 1 - cv;  // original entry, c <= r + 5
+      const int rb = 6 * (r / 6);
+      if (c >= rb) {
+        v = T.Sb[size_t(r) * ncb + (c - rb)];  // same diagonal block (stored in full)
+      } else {
+        const int off = r - 6 * (c / 6);       // symmetric entry (c, r) of the upper band
+        v = off < ncb ? T.Sb[size_t(c) * ncb + off] : 0.0;
+      }
+    }
+    Sb2[size_t(rv) * ncb + cp] = v;
+  }
+}
+
+/// Backward sweeps of the two-ended factorisation (grid = 2). Block 0: the top system (block rows 0 .. m + w - 1), ordinary sweep,
+/// publishes the middle solution (raises the flag once block row m is done). Block 1: the reversed bottom system: its first w
+/// block rows in sweep order are the middle rows (given), the others are solved as usual. Both write the solution in natural
+/// order to T.xsol; k_step_outputs finishes.
+struct BackJob {
+  const double* Ub;
+  const double* Ubk;
+  const double* ybuf;
+  int n_rows;   // block rows of this factor
+  int given;    // block rows above them in sweep order whose solution comes from the other job
+  int reversed; // solution index = np - 1 - rho
+};
+
+__global__ void __launch_bounds__(kCholThreads) k_band_backward2(Tables T, BackJob j0, BackJob j1, int m_mid) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  DevState* st = T.st;
+  if (st->done) return;
+  const BackJob J = blockIdx.x == 0 ? j0 : j1;
+  const int tid = threadIdx.x;
+  constexpr int nthr = kCholThreads;
+  const int bw = T.bw, ncb = 6 * bw, np = T.np;
+  const int n_own = 6 * J.n_rows, n_all = 6 * (J.n_rows + J.given);
+  double* xs = smem;          // n_all : pending rows (own) / given solution
+  double* xout = smem + n_all;  // n_own : solution of the own rows (flushed to T.xsol at the end / when the middle is complete)
+  __shared__ double Wl[2][24];
+  if (J.given) {  // wait for the middle solution
+    while (__hip_atomic_load(T.join_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < T.join_epoch) __builtin_amdgcn_s_sleep(8);
+  }
+  for (int rho = tid; rho < n_all; rho += nthr) xs[rho] = rho < n_own ? J.ybuf[rho] : T.xsol[J.reversed ? np - 1 - rho : rho];
+  const int n_above = 6 * (bw - 1);
+  auto load_u = [&](int j, double* u) {
+    const int rho = 6 * j - 1 - tid;
+    const bool ok = j >= 0 && tid < n_above && rho >= 0 && rho < n_own;
+    const double* src = J.Ub + (ok ? size_t(rho) * ncb + (6 * j - 6 * (rho / 6)) : 0);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) u[a] = ok ? src[a] : 0.0;
+  };
+  auto load_w = [&](int j) -> double { return (j >= 0 && j < J.n_rows && tid < 21) ? J.Ubk[size_t(j) * 24 + tid] : 0.0; };
+  __syncthreads();
+  const int jtop = J.n_rows + J.given - 1;
+  double u0[6], u1[6], u2[6], u3[6], w0, w1, w2, w3;
+  load_u(jtop, u0), load_u(jtop - 1, u1), load_u(jtop - 2, u2);
+  w0 = load_w(jtop), w1 = load_w(jtop - 1), w2 = load_w(jtop - 2);
+  // one block row of the sweep; `own` is a compile-time tag so that the hot loops below carry no extra control flow
+  auto step = [&](int j, auto own_tag) {
+    constexpr bool own = decltype(own_tag)::value;
+    if (own && tid < 21) Wl[j & 1][tid] = w0;
+    load_u(j - 3, u3), w3 = load_w(j - 3);
+    lds_barrier();
+    double y[6], x[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) y[a] = xs[6 * j + a];
+    if (own) {
+      const double* W = Wl[j & 1];
+      int pidx = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        double v = 0.0;
+#pragma unroll
+        for (int c = a; c < 6; ++c) v = fma(W[pidx++], y[c], v);
+        x[a] = v;
+      }
+      if (tid < 6) xout[6 * j + tid] = x[tid];
+    } else {
+#pragma unroll
+      for (int a = 0; a < 6; ++a) x[a] = y[a];  // given by the other sweep
+    }
+    const int rho_p = 6 * j - 1 - tid;
+    if (tid < n_above && rho_p >= 0 && rho_p < n_own) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) sacc = fma(u0[a], x[a], sacc);
+      xs[rho_p] -= sacc;
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) u0[a] = u1[a], u1[a] = u2[a], u2[a] = u3[a];
+    w0 = w1, w1 = w2, w2 = w3;
+  };
+  for (int j = jtop; j >= J.n_rows; --j) step(j, std::false_type{});
+  const int j_pub = (blockIdx.x == 0 && m_mid >= 0) ? m_mid : 0;  // block 0 publishes the middle solution after block row m_mid
+  for (int j = J.n_rows - 1; j >= j_pub; --j) step(j, std::true_type{});
+  if (blockIdx.x == 0 && m_mid >= 0) {
+    lds_barrier();
+    for (int rho = 6 * m_mid + tid; rho < n_own; rho += nthr) T.xsol[rho] = xout[rho];
+    __threadfence();
+    lds_barrier();
+    if (tid == 0) {
+      __threadfence();
+      __hip_atomic_store(T.join_flag, T.join_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int j = m_mid - 1; j >= 0; --j) step(j, std::true_type{});
+  }
+  __syncthreads();
+  const int flush_to = (blockIdx.x == 0 && m_mid >= 0) ? 6 * m_mid : n_own;  // (the middle rows of block 0 are already out)
+  for (int rho = tid; rho < flush_to; rho += nthr) T.xsol[J.reversed ? np - 1 - rho : rho] = xout[rho];
+}
+
+/// step = -x, delta = scale o step and the pose-side reductions of the model cost change, from T.xsol (two-ended path).
+__global__ void __launch_bounds__(kBlock) k_step_outputs(Tables T) {
+  __shared__ double red[kBlock / 64];
+  DevState* st = T.st;
+  if (st->done) return;
+  double gd = 0.0, dd = 0.0;
+  for (int rho = threadIdx.x; rho < T.np; rho += kBlock) {
+    const double step = -T.xsol[rho];
+    T.step_p[rho] = step;
+    T.delta_p[rho] = T.scale_p[rho] * step;
+    gd = fma(T.g_full[rho], step, gd);
+    dd = fma(T.D2p[rho] * step, step, dd);
+  }
+  gd = block_sum(gd, red);
+  dd = block_sum(dd, red);
+  if (threadIdx.x == 0) {
+    st->g_dot_step_pose = gd;
+    st->d2_step2_pose = dd;
+  }
 }
 
 /// Factorisation for wide bands (long feature tracks: more tiles than the register-resident kernels can hold): same algorithm and

@@ -27,6 +27,9 @@ def windows():
     # feature tracks as long as the window (EuRoC-like 3 s tracks): every landmark couples ~all control points, the band is
     # wider than the register-resident factorisation handles and the wide-band kernel takes over
     yield "pixel_long_tracks_k4", synthetic.small_visual(order=4, n_cp=34, n_landmarks=80, obs_pairs=6, seed=11, span=3.2)
+    # a window long enough (n_cp >= 4 bw) for the reduced system to be factored from both ends at once
+    yield "pixel_two_ended_k4", synthetic.small_visual(order=4, n_cp=60, n_landmarks=150, obs_pairs=3, seed=13, span=0.5)
+    yield "pixel_two_ended_k6", synthetic.small_visual(order=6, n_cp=72, n_landmarks=150, obs_pairs=3, seed=14, span=0.4)
     yield "pixel_long_tracks_k6", synthetic.small_visual(order=6, n_cp=30, n_landmarks=80, obs_pairs=6, seed=12, span=3.0)
 
 

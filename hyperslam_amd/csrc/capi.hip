@@ -343,7 +343,13 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_delta_b.reserve(nbd + 1));
   HIP_TRY(p->d_xbuf.reserve(size_t(x_count1) + 8));
   HIP_TRY(p->d_gravity_part.reserve(size_t(5) * std::max(p->n_bias, 1)));
-  HIP_TRY(p->d_Sb2.reserve(size_t(np) * ncb));
+  {
+    const size_t cap0 = p->d_Sb2.cap;
+    HIP_TRY(p->d_Sb2.reserve(size_t(np) * ncb));
+    // entries past the end of the matrix are never written: zero once per allocation / layout
+    (void)cap0;
+    HIP_TRY(hipMemsetAsync(p->d_Sb2.p, 0, p->d_Sb2.cap * sizeof(double), s));
+  }
   HIP_TRY(p->d_g2.reserve(np));
   HIP_TRY(p->d_Ub2.reserve(size_t(np) * ncb));
   HIP_TRY(p->d_Ubk2.reserve(size_t(p->n_cp) * 24));
@@ -427,6 +433,10 @@ int prepare(hs_problem* p) {
   T.fj[0] = FactorJob{T.Sb, T.g_s, T.Ub, T.Ubk, T.ybuf, nullptr, np / 6, -1};
   T.fj[1] = FactorJob{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, -1};
   T.xsol = p->d_xsol.p, T.join_flag = p->d_join.p, T.join_epoch = 0;
+  {
+    const bool la_ok = vs.bw * (vs.bw - 2) <= kLaCompute, two_ended = la_ok && nbd == 0 && np / 6 >= 4 * vs.bw;
+    T.Sb2 = two_ended ? p->d_Sb2.p : nullptr, T.g2 = two_ended ? p->d_g2.p : nullptr;
+  }
   T.scale_b = p->d_scale_b.p, T.Spb = p->d_Spb.p, T.Sbb = p->d_Sbb.p, T.gb_s = p->d_gb_s.p, T.D2b = p->d_D2b.p;
   T.Zb = p->d_Zb.p, T.Cb = p->d_Cb.p, T.hb = p->d_hb.p, T.xb = p->d_xb.p, T.delta_b = p->d_delta_b.p, T.i_bias_ptr = p->d_i_bias_ptr.p;
   T.x_count1 = x_count1, T.xo_dec = x_count1;
@@ -569,14 +579,13 @@ int launch_factor(hs_problem* p) {
   // Factoring from both ends at once (visual-only systems, look-ahead kernel, window long enough to pay for the junction)
   const int n_blk = T.np / 6, w_mid = T.bw - 1;
   const bool la_ok = !legacy && T.bw * (T.bw - 2) <= kLaCompute;
-  const bool two_ended = la_ok && T.nb == 0 && n_blk >= 4 * T.bw && !(T.debug_flags & 2048);
+  const bool two_ended = la_ok && T.nb == 0 && n_blk >= 4 * T.bw && T.Sb2 && !(T.debug_flags & 2048);
   if (two_ended) {
     const int m = (n_blk - w_mid) / 2, mB = n_blk - w_mid - m;
     Tables T2 = T;
     T2.fj[0] = FactorJob{T.Sb, T.g_s, T.Ub, T.Ubk, T.ybuf, p->d_win.p, m + w_mid, m};
     T2.fj[1] = FactorJob{p->d_Sb2.p, p->d_g2.p, p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, p->d_win.p, mB, -1};
     T2.join_epoch = ++p->join_epoch;
-    k_reverse_band<<<std::min(512, (T.np * (ncb + 1) + kBlock - 1) / kBlock), kBlock, 0, s>>>(T, p->d_Sb2.p, p->d_g2.p, T.np);
     // (more than half of the 160 KB of LDS per workgroup: the two ends must not share a CU - their chains would share SIMDs)
     const size_t apart = size_t(96) * 1024;
     k_band_factor_la<1><<<2, kLaThreads, std::max(la_lds, apart), s>>>(T2);

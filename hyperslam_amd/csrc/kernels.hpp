@@ -1126,6 +1126,10 @@ __global__ void __launch_bounds__(kBlock) k_finalize_reduced(Tables T) {
       }
     }
     T.Sb[size_t(rho) * ncb + c] = out;
+    if (T.Sb2 && sigma < T.np) {  // reversed copy for the far end of the two-ended factorisation: (rho, sigma) -> (np-1-sigma, np-1-rho)
+      const int rv = T.np - 1 - sigma, cv = T.np - 1 - rho;
+      T.Sb2[size_t(rv) * ncb + (cv - 6 * (rv / 6))] = out;
+    }
   }
   if (tid < 6) {
     const int rho = 6 * i + tid;
@@ -1133,6 +1137,7 @@ __global__ void __launch_bounds__(kBlock) k_finalize_reduced(Tables T) {
     const double gp = X[T.xo_g + rho];
     T.g_full[rho] = sr * gp;
     T.g_s[rho] = sr * (gp + X[T.xo_gs + rho]);
+    if (T.Sb2) T.g2[T.np - 1 - rho] = sr * (gp + X[T.xo_gs + rho]);
     if (fresh) T.scale_p[rho] = sr;
     T.gabs[rho] = fabs(gp);
   }
@@ -1424,7 +1429,7 @@ __global__ void __launch_bounds__(kCholThreads + kCholIo) k_band_factor(Tables T
 // LDS (doubles): rowbuf 2 x 6 x ld | xbuf 2 x 6 x ld | stage 2 x 6 x ld | y np | diagonal scratch 36.
 //
 // Two-ended mode (grid = 2, visual-only systems): the chain over the block rows is halved by eliminating from both ends at once.
-// Workgroup 1 factors the REVERSED system (k_reverse_band) for the last n - m - w block rows (w = bw - 1), dumps its trailing
+// Workgroup 1 factors the REVERSED system (written by k_finalize_reduced next to the natural one) for the last n - m - w block rows (w = bw - 1), dumps its trailing
 // window (the Schur contribution of those rows to the middle block rows m .. m + w - 1) and raises a flag. Workgroup 0 factors
 // rows 0 .. m - 1, waits for the flag, adds the other end's contribution to its own trailing window (entries of the middle
 // rows that couple to the eliminated end become zero) and simply continues through the middle rows: it ends with the Cholesky
@@ -1911,33 +1916,6 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
     }
     __threadfence();
     lds_barrier();
-  }
-}
-
-/// Reversed copy of the finalised band system for the bottom end of the two-ended factorisation: row / column rho -> np - 1 - rho
-/// (blocks stay aligned, np is a multiple of 6). Only the first `n_rows` scalar rows of the reversed system are produced.
-__global__ void __launch_bounds__(kBlock) k_reverse_band(Tables T, double* Sb2, double* g2, int n_rows) {
-  if (T.st->done) return;
-  const int np = T.np, ncb = 6 * T.bw;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_rows * (ncb + 1); e += gridDim.x * blockDim.x) {
-    const int rv = e / (ncb + 1), cp = e % (ncb + 1);
-    if (cp == ncb) {
-      g2[rv] = T.g_s[np - 1 - rv];
-      continue;
-    }
-    const int cv = 6 * (rv / 6) + cp;  // absolute column in the reversed system
-    double v = 0.0;
-    if (cv < np) {
-      const int r = np - 1 - rv, c = np - 1 - cv;  // original entry, c <= r + 5
-      const int rb = 6 * (r / 6);
-      if (c >= rb) {
-        v = T.Sb[size_t(r) * ncb + (c - rb)];  // same diagonal block (stored in full)
-      } else {
-        const int off = r - 6 * (c / 6);       // symmetric entry (c, r) of the upper band
-        v = off < ncb ? T.Sb[size_t(c) * ncb + off] : 0.0;
-      }
-    }
-    Sb2[size_t(rv) * ncb + cp] = v;
   }
 }
 

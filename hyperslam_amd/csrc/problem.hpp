@@ -174,6 +174,8 @@ struct Tables {
   const int* sw_ptr;  // n_seg + 1: workgroups of k_seg_gram serving segment f (splits ~ record count)
   const int* sw_seg;  // segment of workgroup w
   FactorJob fj[2];       // k_band_factor_la jobs (blockIdx.x)
+  double* Sb2;           // reversed copy of Sb / g_s (nullptr unless the two-ended factorisation will run)
+  double* g2;
   double* xsol;          // np: solution of the reduced system in natural order (two-ended path)
   unsigned* join_flag;   // device word: epoch of the last finished bottom-end factorisation / published middle solution
   unsigned join_epoch;

@@ -357,8 +357,8 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_xsol.reserve(np));
   HIP_TRY(p->d_win.reserve(size_t(6) * vs.bw * (ncb + 1)));
   if (!p->d_join.p) {
-    HIP_TRY(p->d_join.reserve(1));
-    HIP_TRY(hipMemsetAsync(p->d_join.p, 0, sizeof(unsigned), s));
+    HIP_TRY(p->d_join.reserve(2));
+    HIP_TRY(hipMemsetAsync(p->d_join.p, 0, 2 * sizeof(unsigned), s));
     p->join_epoch = 0;
   }
   // split the accumulation over enough workgroups to fill the chip (256 CUs x a few workgroups)
@@ -586,14 +586,11 @@ int launch_factor(hs_problem* p) {
     T2.fj[0] = FactorJob{T.Sb, T.g_s, T.Ub, T.Ubk, T.ybuf, p->d_win.p, m + w_mid, m};
     T2.fj[1] = FactorJob{p->d_Sb2.p, p->d_g2.p, p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, p->d_win.p, mB, -1};
     T2.join_epoch = ++p->join_epoch;
-    // (more than half of the 160 KB of LDS per workgroup: the two ends must not share a CU - their chains would share SIMDs)
-    const size_t apart = size_t(96) * 1024;
-    k_band_factor_la<1><<<2, kLaThreads, std::max(la_lds, apart), s>>>(T2);
+    k_band_factor_la<1><<<2, kLaThreads, la_lds, s>>>(T2);
     Tables T3 = T2;
     T3.join_epoch = ++p->join_epoch;
     const BackJob j0{T.Ub, T.Ubk, T.ybuf, m + w_mid, 0, 0}, j1{p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, mB, w_mid, 1};
-    k_band_backward2<<<(T.debug_flags & 4096) ? 1 : 2, kCholThreads, std::max(2 * size_t(T.np) * sizeof(double), apart), s>>>(T3, j0, j1, m);
-    k_step_outputs<<<1, kBlock, 0, s>>>(T3);
+    k_band_backward2<<<2, kCholThreads, 2 * size_t(T.np) * sizeof(double), s>>>(T3, j0, j1, m);
     HIP_TRY(hipGetLastError());
     return HS_OK;
   }
@@ -637,11 +634,12 @@ int launch_update(hs_problem* p) {
   if (T.n_ine)
     k_cost_inertial<K, 4><<<p->nb_ine, kBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.bias_g_cand, T.bias_a_cand, T.gravity_cand,
                                                                         T.cand_part + p->nb_vis + p->nb_pri);
-  k_pack_decision<<<1, kBlock, 0, s>>>(T);
+  const bool local_decision = !p->allreduce && !p->rccl_comm;  // single shard: decide in the packing kernel
+  k_pack_decision<<<1, kBlock, 0, s>>>(T, local_decision ? 1 : 0);
   HIP_TRY(hipGetLastError());
   const int rc = exchange(p, T.xbuf + T.xo_dec, 5);  // candidate cost + norms + landmark-side model-cost terms
   if (rc) return rc;
-  k_decide<<<1, 64, 0, s>>>(T);
+  if (!local_decision) k_decide<<<1, 64, 0, s>>>(T);
   const int nb_commit = std::max((8 * T.sp.n_cp + kBlock - 1) / kBlock, 1);
   k_commit<<<nb_commit, kBlock, 0, s>>>(T);
   HIP_TRY(hipGetLastError());

@@ -2014,7 +2014,32 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward2(Tables T, BackJ
   __syncthreads();
   const int flush_to = (blockIdx.x == 0 && m_mid >= 0) ? 6 * m_mid : n_own;  // (the middle rows of block 0 are already out)
   for (int rho = tid; rho < flush_to; rho += nthr) T.xsol[J.reversed ? np - 1 - rho : rho] = xout[rho];
+  if (gridDim.x == 1) return;  // (A/B runs on the whole system: k_step_outputs follows)
+  // the block that finishes last turns the solution into the step outputs (saves a launch); join_flag[1] advances by two per launch
+  __shared__ int is_last;
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) is_last = (atomicAdd(T.join_flag + 1, 1u) & 1u) == 1u;
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  __shared__ double red[kCholThreads / 64];
+  double gd = 0.0, dd = 0.0;
+  for (int rho = tid; rho < np; rho += nthr) {
+    const double step = -__builtin_nontemporal_load(T.xsol + rho);
+    T.step_p[rho] = step;
+    T.delta_p[rho] = T.scale_p[rho] * step;
+    gd = fma(T.g_full[rho], step, gd);
+    dd = fma(T.D2p[rho] * step, step, dd);
+  }
+  gd = block_sum(gd, red);
+  dd = block_sum(dd, red);
+  if (tid == 0) {
+    st->g_dot_step_pose = gd;
+    st->d2_step2_pose = dd;
+  }
 }
+
 
 /// step = -x, delta = scale o step and the pose-side reductions of the model cost change, from T.xsol (two-ended path).
 __global__ void __launch_bounds__(kBlock) k_step_outputs(Tables T) {
@@ -2441,9 +2466,11 @@ __global__ void __launch_bounds__(kBlock) k_cost_reduce(Tables T) {
   }
 }
 
+HSD void decide_step(const Tables& T);
+
 /// Second exchange buffer (5 doubles, additive across shards): candidate cost, |x|^2, |x - x+|^2 and the landmark-side
 /// terms of the model cost change. The replicated control-point part of the norms is contributed by rank 0 only.
-__global__ void __launch_bounds__(kBlock) k_pack_decision(Tables T) {
+__global__ void __launch_bounds__(kBlock) k_pack_decision(Tables T, int decide_here /* no exchange between packing and deciding */) {
   __shared__ double red[kBlock / 64];
   DevState* st = T.st;
   if (st->done) return;
@@ -2455,12 +2482,13 @@ __global__ void __launch_bounds__(kBlock) k_pack_decision(Tables T) {
   if (threadIdx.x == 0) {
     double* D = T.xbuf + T.xo_dec;
     D[0] = cand, D[1] = xs, D[2] = ss, D[3] = gd, D[4] = dd;
+    if (decide_here) decide_step(T);
   }
 }
 
-__global__ void __launch_bounds__(kBlock) k_decide(Tables T) {
+/// Trust-region decision of one LM iteration (single lane): step quality, acceptance, radius update, termination tests.
+HSD void decide_step(const Tables& T) {
   DevState* st = T.st;
-  if (st->done || threadIdx.x != 0) return;
   const double* D = T.xbuf + T.xo_dec;
   const double cand = D[0], xs = D[1], ss = D[2];
   // model_cost_change = -g.step/2 + step'D^2 step/2 (exact for the solved system; TrustRegionMinimizer evaluates
@@ -2518,6 +2546,11 @@ __global__ void __launch_bounds__(kBlock) k_decide(Tables T) {
   }
   r.radius = st->radius;
   st->iteration = it + 1;
+}
+
+__global__ void __launch_bounds__(kBlock) k_decide(Tables T) {
+  if (T.st->done || threadIdx.x != 0) return;
+  decide_step(T);
 }
 
 /// x <- candidate when the step was accepted.

@@ -441,6 +441,11 @@ int prepare(hs_problem* p) {
   T.Zb = p->d_Zb.p, T.Cb = p->d_Cb.p, T.hb = p->d_hb.p, T.xb = p->d_xb.p, T.delta_b = p->d_delta_b.p, T.i_bias_ptr = p->d_i_bias_ptr.p;
   T.x_count1 = x_count1, T.xo_dec = x_count1;
   T.rank = p->rank, T.world = p->world;
+  // HS_DEBUG_FLAGS (measurement switches only, never needed for correct operation):
+  //    1 skip the backward sweep          2 skip the rank-6 updates (timing of the panel chain alone; results are garbage)
+  //    4 one-ended pre-look-ahead factorisation kernel                16 phase timestamps of the factorisation -> hs_debug_read
+  //   32 per-workgroup timestamps of the linearise / gram kernels   1024 no side stream for the segment partials
+  // 2048 one-ended factorisation (no second workgroup)              8192 generalised backward sweep on the one-ended factor
   T.debug_flags = std::getenv("HS_DEBUG_FLAGS") ? std::atoi(std::getenv("HS_DEBUG_FLAGS")) : 0;
   T.st = p->d_state.p;
   HIP_TRY(hipStreamSynchronize(s));  // host staging vectors go out of scope

@@ -1700,12 +1700,14 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
         const double e = fma(-d * y, y, 1.0);
         const double rs = fma(y * e, fma(0.375, e, 0.5), y);
         inv[a] = rs;
+        const double nrs = -rs;  // the off-diagonal entries are kept NEGATED: products of two of them are unchanged, and the
+                                 // column solves below become plain multiply-adds without sign flips
 #pragma unroll
         for (int c = a + 1; c < 6; ++c) {
           double t = U[UIDX(a, c)];
 #pragma unroll
           for (int k = 0; k < a; ++k) t = fma(-U[UIDX(k, a)], U[UIDX(k, c)], t);
-          U[UIDX(a, c)] = t * rs;
+          U[UIDX(a, c)] = t * nrs;
         }
       }
 #pragma unroll
@@ -1722,7 +1724,7 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
         for (int a = 0; a < 6; ++a) {
           double t = v[m][a];
 #pragma unroll
-          for (int k = 0; k < a; ++k) t = fma(-U[UIDX(k, a)], x[k], t);
+          for (int k = 0; k < a; ++k) t = fma(U[UIDX(k, a)], x[k], t);  // U holds -u_ka
           x[a] = t * inv[a];
         }
 #pragma unroll

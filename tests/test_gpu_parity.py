@@ -30,6 +30,8 @@ def windows():
     # a window long enough (n_cp >= 4 bw) for the reduced system to be factored from both ends at once
     yield "pixel_two_ended_k4", synthetic.small_visual(order=4, n_cp=60, n_landmarks=150, obs_pairs=3, seed=13, span=0.5)
     yield "pixel_two_ended_k6", synthetic.small_visual(order=6, n_cp=72, n_landmarks=150, obs_pairs=3, seed=14, span=0.4)
+    # medium tracks: band width 17 .. 22 (register-resident one-ended kernel with two tiles per lane)
+    yield "pixel_medium_tracks_k4", synthetic.small_visual(order=4, n_cp=30, n_landmarks=80, obs_pairs=5, seed=15, span=1.6)
     yield "pixel_long_tracks_k6", synthetic.small_visual(order=6, n_cp=30, n_landmarks=80, obs_pairs=6, seed=12, span=3.0)
 
 
@@ -173,3 +175,17 @@ def test_process_tracks(order, hip, oracle):
             a, b = g.process_tracks(stamp, px0, px1), c.process_tracks(stamp, px0, px1)
             for x, y in zip(a, b):
                 assert np.abs(x - y).max() <= 1e-11 * max(1.0, np.abs(y).max())
+
+
+def test_band_width_classes(hip):
+    """The parametrised windows above really cover every factorisation path (look-ahead, two-ended, two tiles per lane, wide)."""
+    got = {}
+    for name, w in windows():
+        with ha.Problem(w, lib=hip) as g:
+            g.cost()
+            got[name] = (g.lib.band_blocks(g.h), w.n_cp)
+    assert got["pixel_k4"][0] <= 14
+    assert 17 <= got["pixel_medium_tracks_k4"][0] <= 22, got
+    assert got["pixel_long_tracks_k4"][0] >= 23
+    bw, n = got["pixel_two_ended_k4"]
+    assert bw <= 14 and n >= 4 * bw, got

@@ -1,16 +1,18 @@
 // kernels.hpp — gfx950 kernels of one Levenberg-Marquardt iteration (included once by capi.hip).
 //
-// Launch sequence per iteration (all on one HIP stream, no host synchronisation; kernels early-exit when the device
-// state machine has terminated):
-//   k_linearize_visual / k_linearize_prior   one residual block per lane -> segment-major records + cost partials
+// Launch sequence per iteration (one HIP stream + one side stream, no host synchronisation; every kernel early-exits once the
+// device state machine has terminated):
+//   k_linearize_visual / _prior / _inertial  one residual block per lane -> segment-major records + cost partials
 //   k_landmark                               one wave per landmark: H_ll, b_l, W_l -> damped 3x3 Cholesky -> Y-hat, y-hat
-//   k_hpp_diag            (iteration 0)      Jacobi column scaling of the pose-side unknowns
-//   k_build_reduced                          one workgroup per control-point block row: gather J'J and the Schur terms
-//                                            into the block-banded reduced system (deterministic, no atomics on doubles)
-//   k_band_factor                    single-workgroup block-banded Cholesky with an LDS sliding window + solves
+//   k_seg_gram / k_group_gram / k_assemble   reduced system from per-segment J'J and per-landmark-group Y-hat Y-hat' partials
+//   k_border_pb / k_border_bb                border blocks of the inertial factors (bias splines, gravity)
+//   k_pack_exchange -> [all-reduce] -> k_finalize_reduced / _border -> k_cost_reduce     scaling, damping, gradient test
+//   k_band_factor_la (look-ahead, one or two ends) | k_band_factor (bw <= 22) | k_band_factor_wide (bw <= 42)   S = U'U, y
+//   k_border_forward / _schur / _solve / _apply                                         bordered part of the solve
+//   k_band_backward | k_band_backward2       U x = y, step outputs
 //   k_backsub_landmarks / k_retract          step for landmarks, candidate point = Plus(x, delta)
-//   k_cost_visual / k_cost_prior             cost at the candidate point
-//   k_decide / k_commit                      trust-region logic and acceptance
+//   k_cost_visual / _prior / _inertial       cost at the candidate point
+//   k_pack_decision -> [all-reduce] -> k_decide -> k_commit      trust-region logic and acceptance
 #pragma once
 #include <type_traits>
 
@@ -266,7 +268,7 @@ __global__ void __launch_bounds__(kBlock) k_cost_prior(Tables T, const double* c
   if (threadIdx.x == 0) cost_part[blockIdx.x] = s;
 }
 
-/// Second half of the landmark pass (shared by k_landmark and the fused linearise kernel): given the wave-reduced H_ll, b_l and
+/// Second half of the landmark pass: given the wave-reduced H_ll, b_l and
 /// this lane's W rows, forms V = S_l H_ll S_l + D_l^2 = L L', stores L, y-hat, the scaled gradient and the Y-hat rows.
 template <int PS>
 HSD void landmark_finish(const Tables& T, int dl, int lane, bool active, bool fresh, double radius, const double* sl_old, int yoff, int rows,

@@ -184,7 +184,7 @@ struct Tables {
   const int* gw_ptr;  // n_cp + 1: workgroups of k_group_gram serving landmark group c (splits ~ landmark count)
   const int* gw_cf;   // group of workgroup w
   double* grpQ;   // per k_group_gram workgroup: [upper 6x6 tiles of -sum Yh Yh' | -sum Yh yh (6 bw)]
-  double* xpart;  // per-split partial copies of [Sraw | g_p | g_schur | diag] (stride x_count1)
+  double* xpart;  // per-split partial copies of the H_pb part of the exchange buffer (stride x_count1); scratch for timestamps
   int xo_g, xo_gs, xo_dj, xo_pb, xo_bb, xo_gb, xo_cost, xo_gmax, xo_dec, x_count1;
   int rank, world;
   int debug_flags;  // HS_DEBUG_FLAGS env (timing experiments; 0 in production)

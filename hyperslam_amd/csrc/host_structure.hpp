@@ -139,9 +139,15 @@ inline bool build_visual_structure(const VisualInput& in, VisualStructure* vs, s
     cl[lm[i]] = std::max(cl[lm[i]], first[i] + in.k - 1);
   }
   // device order: observed landmarks by first control point (stable), unobserved last
-  vs->table_of_dev.resize(in.n_lm);
-  std::iota(vs->table_of_dev.begin(), vs->table_of_dev.end(), 0);
-  std::stable_sort(vs->table_of_dev.begin(), vs->table_of_dev.end(), [&](int a, int b) { return cf[a] < cf[b]; });
+  // (all orderings below are stable counting sorts: the keys are small integers and this runs once per optimize())
+  auto counting_sort = [](int n_items, int n_keys, auto key_of, std::vector<int>* out) {
+    std::vector<int> start(n_keys + 1, 0);
+    for (int i = 0; i < n_items; ++i) start[key_of(i) + 1]++;
+    for (int kk = 0; kk < n_keys; ++kk) start[kk + 1] += start[kk];
+    out->resize(n_items);
+    for (int i = 0; i < n_items; ++i) (*out)[start[key_of(i)]++] = i;
+  };
+  counting_sort(in.n_lm, in.n_cp + 1, [&](int t) { return std::min(cf[t], in.n_cp); }, &vs->table_of_dev);
   vs->dev_of_table.resize(in.n_lm);
   for (int d = 0; d < in.n_lm; ++d) vs->dev_of_table[vs->table_of_dev[d]] = d;
   vs->lm_cfirst.assign(in.n_lm, 0), vs->lm_ncp.assign(in.n_lm, 0), vs->lm_yoff.assign(in.n_lm + 1, 0);
@@ -165,9 +171,8 @@ inline bool build_visual_structure(const VisualInput& in, VisualStructure* vs, s
     vs->cf_ptr[c] = d;
   }
   // landmark-major residual order (stable: table order within a landmark, pixel before bearing)
-  std::vector<int> order(n);
-  std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return vs->dev_of_table[lm[a]] < vs->dev_of_table[lm[b]]; });
+  std::vector<int> order;
+  counting_sort(n, in.n_lm, [&](int i) { return vs->dev_of_table[lm[i]]; }, &order);
   vs->table_type.resize(n), vs->table_idx.resize(n), vs->lm_dev.resize(n), vs->first.resize(n), vs->pos.resize(n);
   vs->lm_ptr.assign(in.n_lm + 1, 0);
   for (int q = 0; q < n; ++q) {
@@ -177,9 +182,8 @@ inline bool build_visual_structure(const VisualInput& in, VisualStructure* vs, s
   }
   for (int d = 0; d < in.n_lm; ++d) vs->lm_ptr[d + 1] += vs->lm_ptr[d];
   // segment-major record slots (stable over the landmark-major order)
-  std::vector<int> by_seg(n);
-  std::iota(by_seg.begin(), by_seg.end(), 0);
-  std::stable_sort(by_seg.begin(), by_seg.end(), [&](int a, int b) { return vs->first[a] < vs->first[b]; });
+  std::vector<int> by_seg;
+  counting_sort(n, n_seg, [&](int q) { return vs->first[q]; }, &by_seg);
   vs->seg_ptr.assign(n_seg + 1, 0);
   for (int p = 0; p < n; ++p) {
     vs->pos[by_seg[p]] = p;

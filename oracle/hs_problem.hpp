@@ -229,6 +229,10 @@ struct NormalEquations {
   std::vector<int> w_first, w_count;  // per landmark: first cp and number of cps touched
   std::vector<std::vector<double>> W;  // per landmark: (6*count) x 3 row-major  (H_pl rows of its cp range)
   double cost = 0;
+  // The linearised blocks themselves, in evaluation order (Ceres keeps the Jacobian of the current point and reuses it for
+  // the model cost change of every candidate step, trust_region_minimizer.cc).
+  std::vector<FactorType> block_type;
+  std::vector<Linearized> blocks;
 };
 
 struct Solver {
@@ -308,12 +312,18 @@ struct Solver {
         ne->w_count[l] = w_last[l] - ne->w_first[l] + 1;
         ne->W[l].assign(size_t(6) * ne->w_count[l] * 3, 0.0);
       }
-    Linearized lin;
     std::vector<int> cols;
     std::vector<double> vals;
+    size_t n_blocks = 0;
+    for (int ti = 0; ti < 4; ++ti) n_blocks += size_t(P.n_res(types()[ti]));
+    ne->block_type.resize(n_blocks);
+    ne->blocks.resize(n_blocks);
+    size_t bi = 0;
     for (int ti = 0; ti < 4; ++ti) {
       const FactorType t = types()[ti];
-      for (int i = 0; i < P.n_res(t); ++i) {
+      for (int i = 0; i < P.n_res(t); ++i, ++bi) {
+        Linearized& lin = ne->blocks[bi];
+        ne->block_type[bi] = t;
         ev.evaluate(t, i, true, &lin);
         ne->cost += lin.cost;
         pose_columns(lin, t, &cols, &vals);
@@ -347,33 +357,48 @@ struct Solver {
   }
 };
 
-// Dense Cholesky (lower) in place; returns false if not positive definite.
-inline bool cholesky_lower(std::vector<double>& A, int n) {
+// Row envelope of a symmetric matrix stored dense: first[i] = first column of row i (lower triangle) holding a non-zero.
+// The Cholesky factor fills only inside the envelope, so the products skipped below are exact zeros and the results are
+// those of the plain dense algorithm; the reduced system is block-banded (plus border rows for bias splines / gravity),
+// which is what the reference's sparse Cholesky exploits (optimizer.cpp:42-43).
+inline std::vector<int> row_envelope(const std::vector<double>& A, int n) {
+  std::vector<int> first(n);
+  for (int i = 0; i < n; ++i) {
+    int f = 0;
+    while (f < i && A[size_t(i) * n + f] == 0.0) ++f;
+    first[i] = f;
+  }
+  return first;
+}
+// Cholesky (lower) in place inside the envelope; returns false if not positive definite.
+inline bool cholesky_lower(std::vector<double>& A, int n, const std::vector<int>& first) {
   for (int j = 0; j < n; ++j) {
-    double d = A[size_t(j) * n + j];
-    for (int k = 0; k < j; ++k) d -= A[size_t(j) * n + k] * A[size_t(j) * n + k];
+    const double* rj = &A[size_t(j) * n];
+    double d = rj[j];
+    for (int k = first[j]; k < j; ++k) d -= rj[k] * rj[k];
     if (!(d > 0.0)) return false;
     d = std::sqrt(d);
     A[size_t(j) * n + j] = d;
     for (int i = j + 1; i < n; ++i) {
-      double s = A[size_t(i) * n + j];
+      if (first[i] > j) continue;
       const double* ri = &A[size_t(i) * n];
-      const double* rj = &A[size_t(j) * n];
-      for (int k = 0; k < j; ++k) s -= ri[k] * rj[k];
+      double s = ri[j];
+      for (int k = std::max(first[i], first[j]); k < j; ++k) s -= ri[k] * rj[k];
       A[size_t(i) * n + j] = s / d;
     }
   }
   return true;
 }
-inline void cholesky_solve(const std::vector<double>& L, int n, std::vector<double>& b) {
+inline void cholesky_solve(const std::vector<double>& L, int n, const std::vector<int>& first, std::vector<double>& b) {
   for (int i = 0; i < n; ++i) {
     double s = b[i];
-    for (int k = 0; k < i; ++k) s -= L[size_t(i) * n + k] * b[k];
+    for (int k = first[i]; k < i; ++k) s -= L[size_t(i) * n + k] * b[k];
     b[i] = s / L[size_t(i) * n + i];
   }
   for (int i = n - 1; i >= 0; --i) {
     double s = b[i];
-    for (int k = i + 1; k < n; ++k) s -= L[size_t(k) * n + i] * b[k];
+    for (int k = i + 1; k < n; ++k)
+      if (first[k] <= i) s -= L[size_t(k) * n + i] * b[k];
     b[i] = s / L[size_t(i) * n + i];
   }
 }
@@ -516,8 +541,9 @@ struct LM {
       *rs_out = rs;
       rs_out->S = S, rs_out->g = y;
     }
-    if (!cholesky_lower(S, np)) return false;
-    cholesky_solve(S, np, y);  // y = (J'J + D^2)^-1 J'r
+    const std::vector<int> env = row_envelope(S, np);
+    if (!cholesky_lower(S, np, env)) return false;
+    cholesky_solve(S, np, env, y);  // y = (J'J + D^2)^-1 J'r
     step_p->assign(np, 0.0);
     for (int i = 0; i < np; ++i) (*step_p)[i] = -y[i];
     step_l->assign(size_t(ne.nl) * 3, 0.0);
@@ -540,25 +566,20 @@ struct LM {
   }
 
   /// model_cost_change = -(J step) . (r + J step / 2) on the scaled Jacobian (TrustRegionMinimizer::ComputeTrustRegionStep).
-  double model_cost_change(const std::vector<double>& delta_p, const std::vector<double>& delta_l) const {
-    Evaluator ev(P);
-    Linearized lin;
+  double model_cost_change(const NormalEquations& ne, const std::vector<double>& delta_p, const std::vector<double>& delta_l) const {
     std::vector<int> cols;
     std::vector<double> vals;
     double acc = 0;
-    for (int ti = 0; ti < 4; ++ti) {
-      const FactorType t = Solver::types()[ti];
-      for (int i = 0; i < P.n_res(t); ++i) {
-        ev.evaluate(t, i, true, &lin);
-        solver.pose_columns(lin, t, &cols, &vals);
-        const int nc = int(cols.size());
-        for (int r = 0; r < lin.n_res; ++r) {
-          double m = 0;
-          for (int a = 0; a < nc; ++a) m += vals[size_t(r) * nc + a] * delta_p[cols[a]];
-          if (lin.lm >= 0)
-            for (int b = 0; b < 3; ++b) m += lin.J_lm[r * 3 + b] * delta_l[3 * lin.lm + b];
-          acc += m * (lin.r[r] + 0.5 * m);
-        }
+    for (size_t bi = 0; bi < ne.blocks.size(); ++bi) {
+      const Linearized& lin = ne.blocks[bi];
+      solver.pose_columns(lin, ne.block_type[bi], &cols, &vals);
+      const int nc = int(cols.size());
+      for (int r = 0; r < lin.n_res; ++r) {
+        double m = 0;
+        for (int a = 0; a < nc; ++a) m += vals[size_t(r) * nc + a] * delta_p[cols[a]];
+        if (lin.lm >= 0)
+          for (int b = 0; b < 3; ++b) m += lin.J_lm[r * 3 + b] * delta_l[3 * lin.lm + b];
+        acc += m * (lin.r[r] + 0.5 * m);
       }
     }
     return -acc;
@@ -657,7 +678,7 @@ struct LM {
         delta_p = step_p, delta_l = step_l;
         for (size_t i = 0; i < delta_p.size(); ++i) delta_p[i] *= scale_p[i];
         for (size_t i = 0; i < delta_l.size(); ++i) delta_l[i] *= scale_l[i];
-        std::vector<double> m1(1, model_cost_change(delta_p, delta_l));  // per-residual sum: additive across shards
+        std::vector<double> m1(1, model_cost_change(ne, delta_p, delta_l));  // per-residual sum: additive across shards
         this->sum(m1);
         mcc = m1[0];
         if (mcc < 0.0) valid = false;

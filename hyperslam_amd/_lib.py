@@ -13,6 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PRODUCT_LIB = os.path.join(_HERE, "libhyperslam_hip.so")
 
 HS_PIXEL, HS_BEARING, HS_PRIOR, HS_INERTIAL = 0, 1, 2, 3
+(HS_MANIFOLD_CONSTANT, HS_MANIFOLD_EUCLIDEAN, HS_MANIFOLD_CONTROL_POINT, HS_MANIFOLD_SE3, HS_MANIFOLD_SPHERE3,
+ HS_MANIFOLD_BIAS_POINT) = range(6)
 HS_NO_CONVERGENCE, HS_CONVERGENCE, HS_FAILURE = 0, 1, 2
 
 c_double_p = C.POINTER(C.c_double)
@@ -97,6 +99,9 @@ _SIGNATURES = {
     "get_gravity": (C.c_int, [C.c_void_p, c_double_p]),
     "sample_trajectory": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]),
     "process_tracks": (C.c_int, [C.c_void_p, C.c_double, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
+    "manifold_tangent_size": (C.c_int, [C.c_int, C.c_int]),
+    "manifold_plus": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p]),
+    "manifold_plus_jacobian": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p]),
     "set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
     "set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "band_blocks": (C.c_int, [C.c_void_p]),

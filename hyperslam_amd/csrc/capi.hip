@@ -1395,6 +1395,50 @@ int hs_process_tracks(hs_problem* p, double stamp, int n, const double* pixels0,
   return HS_OK;
 }
 
+int hs_manifold_tangent_size(int kind, int ambient) {
+  switch (kind) {
+    case HS_MANIFOLD_CONSTANT: return (ambient >= 1 && ambient <= 9) ? 0 : -1;
+    case HS_MANIFOLD_EUCLIDEAN: return (ambient >= 1 && ambient <= 9) ? ambient : -1;
+    case HS_MANIFOLD_CONTROL_POINT: return ambient == 8 ? 6 : -1;
+    case HS_MANIFOLD_SE3: return ambient == 7 ? 6 : -1;
+    case HS_MANIFOLD_SPHERE3: return ambient == 3 ? 2 : -1;
+    case HS_MANIFOLD_BIAS_POINT: return ambient == 4 ? 3 : -1;
+    default: return -1;
+  }
+}
+
+static int manifold_launch(hs_problem* p, int kind, int ambient, int n, const double* x, const double* delta, double* out, double* jac) {
+  if (!p || n < 0 || (n && !x)) return HS_ERR_INVALID;
+  const int tangent = hs_manifold_tangent_size(kind, ambient);
+  if (tangent < 0) HS_FAIL(HS_ERR_INVALID, "unknown manifold kind / ambient size");
+  if (out && tangent > 0 && !delta) HS_FAIL(HS_ERR_INVALID, "delta is null");
+  if (n == 0) return HS_OK;
+  HIP_TRY(hipSetDevice(p->device));
+  hipStream_t s = p->stream;
+  DBuf<double> d_x, d_d, d_o, d_j;
+  HIP_TRY(d_x.upload(std::vector<double>(x, x + size_t(n) * ambient), s));
+  if (out && tangent > 0) HIP_TRY(d_d.upload(std::vector<double>(delta, delta + size_t(n) * tangent), s));
+  if (out) HIP_TRY(d_o.reserve(size_t(n) * ambient));
+  if (jac && tangent > 0) HIP_TRY(d_j.reserve(size_t(n) * ambient * tangent));
+  k_manifold_plus<<<(n + kBlock - 1) / kBlock, kBlock, 0, s>>>(kind, ambient, tangent, n, d_x.p, d_d.p, out ? d_o.p : nullptr,
+                                                             (jac && tangent > 0) ? d_j.p : nullptr);
+  HIP_TRY(hipGetLastError());
+  if (out) HIP_TRY(hipMemcpyAsync(out, d_o.p, size_t(n) * ambient * 8, hipMemcpyDeviceToHost, s));
+  if (jac && tangent > 0) HIP_TRY(hipMemcpyAsync(jac, d_j.p, size_t(n) * ambient * tangent * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return HS_OK;
+}
+
+int hs_manifold_plus(hs_problem* p, int kind, int ambient, int n, const double* x, const double* delta, double* x_plus_delta) {
+  if (n > 0 && !x_plus_delta) return HS_ERR_INVALID;
+  return manifold_launch(p, kind, ambient, n, x, delta, x_plus_delta, nullptr);
+}
+
+int hs_manifold_plus_jacobian(hs_problem* p, int kind, int ambient, int n, const double* x, double* jacobian) {
+  if (n > 0 && !jacobian) return HS_ERR_INVALID;
+  return manifold_launch(p, kind, ambient, n, x, nullptr, nullptr, jacobian);
+}
+
 int hs_sample_trajectory(hs_problem* p, int n, const double* stamps, double* pose, double* velocity, double* acceleration) {
   if (!p || n < 0 || (n && (!stamps || !pose))) return HS_ERR_INVALID;
   if (n == 0) return HS_OK;

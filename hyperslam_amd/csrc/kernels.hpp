@@ -2654,4 +2654,59 @@ __global__ void k_reset_state(DevState* st, int max_iterations, double radius) {
   st->max_iterations = max_iterations, st->chol_failed = 0;
 }
 
+/// Batched Manifold::Plus / PlusJacobian of the variable classes on the path (hs_manifold_plus*): the same device
+/// functions k_retract and the local-coordinate Jacobians use. One element per lane. kind: HS_MANIFOLD_* of the C ABI.
+__global__ void __launch_bounds__(kBlock) k_manifold_plus(int kind, int ambient, int tangent, int n, const double* __restrict__ x,
+                                                          const double* __restrict__ d, double* __restrict__ out, double* __restrict__ jac) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* xi = x + size_t(i) * ambient;
+  if (out) {
+    const double* di = d + size_t(i) * tangent;
+    double* o = out + size_t(i) * ambient;
+    switch (kind) {
+      case 1:
+        for (int c = 0; c < ambient; ++c) o[c] = xi[c] + di[c];
+        break;
+      case 2:
+      case 3: {
+        const Quat q = quat_plus(Quat{xi[0], xi[1], xi[2], xi[3]}, V3{di[0], di[1], di[2]});
+        o[0] = q.x, o[1] = q.y, o[2] = q.z, o[3] = q.w;
+        o[4] = xi[4] + di[3], o[5] = xi[5] + di[4], o[6] = xi[6] + di[5];
+        if (kind == 2) o[7] = xi[7];
+        break;
+      }
+      case 4: sphere_plus(xi, di, o); break;
+      case 5:
+        o[0] = xi[0] + di[0], o[1] = xi[1] + di[1], o[2] = xi[2] + di[2], o[3] = xi[3];
+        break;
+      default:
+        for (int c = 0; c < ambient; ++c) o[c] = xi[c];
+    }
+  }
+  if (jac && tangent > 0) {
+    double* J = jac + size_t(i) * ambient * tangent;
+    for (int e = 0; e < ambient * tangent; ++e) J[e] = 0.0;
+    switch (kind) {
+      case 1:
+        for (int c = 0; c < ambient; ++c) J[c * tangent + c] = 1.0;
+        break;
+      case 2:
+      case 3: {
+        const Quat q = Quat{xi[0], xi[1], xi[2], xi[3]};
+        // column c = d/d delta_c of [delta ; 1] (x) q at delta = 0 = (e_c, 0) (x) q
+        const Quat c0 = qmul(Quat{1, 0, 0, 0}, q), c1 = qmul(Quat{0, 1, 0, 0}, q), c2 = qmul(Quat{0, 0, 1, 0}, q);
+        J[0 * 6 + 0] = c0.x, J[1 * 6 + 0] = c0.y, J[2 * 6 + 0] = c0.z, J[3 * 6 + 0] = c0.w;
+        J[0 * 6 + 1] = c1.x, J[1 * 6 + 1] = c1.y, J[2 * 6 + 1] = c1.z, J[3 * 6 + 1] = c1.w;
+        J[0 * 6 + 2] = c2.x, J[1 * 6 + 2] = c2.y, J[2 * 6 + 2] = c2.z, J[3 * 6 + 2] = c2.w;
+        J[4 * 6 + 3] = 1.0, J[5 * 6 + 4] = 1.0, J[6 * 6 + 5] = 1.0;
+        break;
+      }
+      case 4: sphere_plus_jacobian(xi, J); break;
+      case 5: J[0 * 3 + 0] = 1.0, J[1 * 3 + 1] = 1.0, J[2 * 3 + 2] = 1.0; break;
+      default: break;
+    }
+  }
+}
+
 }  // namespace hs

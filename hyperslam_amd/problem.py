@@ -294,6 +294,30 @@ class Problem:
         self._check(self.lib.process_tracks(self.h, float(stamp), n, _d(p0), _d(p1), _d(b0), _d(b1), _d(pw)), "process_tracks")
         return b0, b1, pw
 
+    def manifold_plus(self, kind, x, delta):
+        """Batched ceres::Manifold::Plus of variable class `kind` (HS_MANIFOLD_*): x (n, ambient), delta (n, tangent)."""
+        x = _arr(x, _f64)
+        x = x.reshape(-1, x.shape[-1])
+        n, ambient = x.shape
+        tangent = self.lib.manifold_tangent_size(int(kind), ambient)
+        d = _arr(delta, _f64).reshape(n, max(tangent, 0)) if tangent > 0 else np.zeros((n, 0))
+        out = np.zeros((n, ambient))
+        self._check(self.lib.manifold_plus(self.h, int(kind), ambient, n, _d(x), _d(d) if tangent > 0 else None, _d(out)), "manifold_plus")
+        return out
+
+    def manifold_plus_jacobian(self, kind, x):
+        """Batched ceres::Manifold::PlusJacobian: (n, ambient, tangent), row-major per element."""
+        x = _arr(x, _f64)
+        x = x.reshape(-1, x.shape[-1])
+        n, ambient = x.shape
+        tangent = self.lib.manifold_tangent_size(int(kind), ambient)
+        if tangent < 0:
+            raise ValueError("unknown manifold kind / ambient size")
+        jac = np.zeros((n, ambient, tangent))
+        if tangent > 0:
+            self._check(self.lib.manifold_plus_jacobian(self.h, int(kind), ambient, n, _d(x), _d(jac)), "manifold_plus_jacobian")
+        return jac
+
     def sample_trajectory(self, stamps, derivatives=False):
         st = _arr(stamps, _f64)
         pose = np.zeros((len(st), 7))

@@ -200,6 +200,23 @@ int hs_sample_trajectory(hs_problem* p, int n, const double* stamps, double* pos
 int hs_process_tracks(hs_problem* p, double stamp, int n, const double* pixels0, const double* pixels1, double* bearings0, double* bearings1,
                       double* positions_w);
 
+/* ---- manifolds -------------------------------------------------------------------- */
+/* The retractions the solve applies, exposed as the batched counterpart of ceres::Manifold::Plus / PlusJacobian as the reference
+ * forwards them (include/hyper/optimizers/ceres/manifolds/variables/wrapper.hpp:32-38; Minus / MinusJacobian, :44-50, are never
+ * called by Ceres' trust-region minimiser and are not part of the path). kind: */
+#define HS_MANIFOLD_CONSTANT 0       /* SubsetManifold, all fixed (manifolds/variables/euclidean.hpp:35-36,45-50): tangent 0        */
+#define HS_MANIFOLD_EUCLIDEAN 1      /* EuclideanManifold (euclidean.hpp:38), landmarks (optimizer.cpp:356): tangent = ambient     */
+#define HS_MANIFOLD_CONTROL_POINT 2  /* Stamped<SE3> [q(4) p(3) t] (stamped.hpp:35-36, se3.cpp:20-23, su2.cpp:21): 8 -> 6, t fixed */
+#define HS_MANIFOLD_SE3 3            /* [q(4) p(3)], sensor extrinsics (ceres/manifolds/sensors/sensor.cpp:26-29): 7 -> 6          */
+#define HS_MANIFOLD_SPHERE3 4        /* SphereManifold<3>, gravity / bearings (variables/bearing.cpp:15, gravity.hpp:11-17): 3 -> 2 */
+#define HS_MANIFOLD_BIAS_POINT 5     /* Stamped<R3> [b(3) t] bias control point (ceres/manifolds/sensors/imu.cpp:64-66): 4 -> 3    */
+/* Tangent size of `kind` for an ambient size (only HS_MANIFOLD_CONSTANT / _EUCLIDEAN use `ambient`, 1..9), -1 if invalid. */
+int hs_manifold_tangent_size(int kind, int ambient);
+/* x: n x ambient, delta: n x tangent, x_plus_delta: n x ambient (Manifold::Plus, wrapper.hpp:32-34). */
+int hs_manifold_plus(hs_problem* p, int kind, int ambient, int n, const double* x, const double* delta, double* x_plus_delta);
+/* jacobian: n x (ambient x tangent) row-major (Manifold::PlusJacobian, wrapper.hpp:36-38). */
+int hs_manifold_plus_jacobian(hs_problem* p, int kind, int ambient, int n, const double* x, double* jacobian);
+
 #ifdef __cplusplus
 }
 #endif

@@ -375,4 +375,25 @@ int hso_sample_trajectory(hso_problem* p, int n, const double* stamps, double* p
   return HS_OK;
 }
 
+// Manifold::Plus / PlusJacobian of the variable classes (wrapper.hpp:32-38): hs_factors.hpp manifold_plus / manifold_plus_jacobian.
+int hso_manifold_tangent_size(int kind, int ambient) {
+  const bool free_size = kind == HS_MANIFOLD_CONSTANT || kind == HS_MANIFOLD_EUCLIDEAN;
+  const int need[6] = {0, 0, 8, 7, 3, 4};
+  if (kind < 0 || kind > 5 || (free_size ? (ambient < 1 || ambient > 9) : ambient != need[kind])) return -1;
+  return manifold_local_size(ManifoldKind(kind), ambient);
+}
+int hso_manifold_plus(hso_problem* p, int kind, int ambient, int n, const double* x, const double* delta, double* x_plus_delta) {
+  const int tangent = hso_manifold_tangent_size(kind, ambient);
+  CHECK_ARG(tangent >= 0, "unknown manifold kind / ambient size");
+  for (int i = 0; i < n; ++i)
+    manifold_plus(ManifoldKind(kind), ambient, x + size_t(i) * ambient, delta ? delta + size_t(i) * tangent : nullptr, x_plus_delta + size_t(i) * ambient);
+  return HS_OK;
+}
+int hso_manifold_plus_jacobian(hso_problem* p, int kind, int ambient, int n, const double* x, double* jacobian) {
+  const int tangent = hso_manifold_tangent_size(kind, ambient);
+  CHECK_ARG(tangent >= 0, "unknown manifold kind / ambient size");
+  for (int i = 0; i < n; ++i) manifold_plus_jacobian(ManifoldKind(kind), ambient, x + size_t(i) * ambient, jacobian + size_t(i) * ambient * tangent);
+  return HS_OK;
+}
+
 }  // extern "C"

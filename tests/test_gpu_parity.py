@@ -189,3 +189,27 @@ def test_band_width_classes(hip):
     assert got["pixel_long_tracks_k4"][0] >= 23
     bw, n = got["pixel_two_ended_k4"]
     assert bw <= 14 and n >= 4 * bw, got
+
+
+def test_manifolds(hip, oracle):
+    """hs_manifold_plus / hs_manifold_plus_jacobian (the retractions k_retract applies) against the 100-digit vectors and,
+    on a larger random batch, against the oracle."""
+    from util import check_manifolds_against_golden
+    w = synthetic.small_visual()
+    with ha.Problem(w, lib=hip) as p, ha.Problem(w, lib=oracle) as o:
+        assert check_manifolds_against_golden(p, 1e-14) <= 1e-14
+        rng = np.random.default_rng(5)
+        n = 1000
+        q = rng.normal(size=(n, 4))
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        x = np.concatenate([q, rng.normal(size=(n, 3)), rng.uniform(0, 10, size=(n, 1))], axis=1)
+        d = rng.normal(size=(n, 6)) * rng.choice([0.0, 1e-8, 1e-2, 1.0], size=(n, 1))
+        for kind, xs in ((ha.HS_MANIFOLD_CONTROL_POINT, x), (ha.HS_MANIFOLD_SE3, x[:, :7])):
+            assert np.abs(p.manifold_plus(kind, xs, d) - o.manifold_plus(kind, xs, d)).max() <= 1e-14
+            assert np.abs(p.manifold_plus_jacobian(kind, xs) - o.manifold_plus_jacobian(kind, xs)).max() <= 1e-15
+        g = rng.normal(size=(n, 3)) * 9.8
+        d2 = rng.normal(size=(n, 2)) * rng.choice([0.0, 1e-8, 1e-2, 1.0], size=(n, 1))
+        assert np.abs(p.manifold_plus(ha.HS_MANIFOLD_SPHERE3, g, d2) - o.manifold_plus(ha.HS_MANIFOLD_SPHERE3, g, d2)).max() <= 1e-13
+        assert np.abs(p.manifold_plus_jacobian(ha.HS_MANIFOLD_SPHERE3, g) - o.manifold_plus_jacobian(ha.HS_MANIFOLD_SPHERE3, g)).max() <= 1e-13
+        with pytest.raises(ha.HsError):
+            p.manifold_plus(ha.HS_MANIFOLD_SPHERE3, np.zeros((1, 4)), np.zeros((1, 2)))

@@ -10,7 +10,7 @@ import pytest
 
 import hyperslam_amd as ha
 from hyperslam_amd import _lib, synthetic
-from util import check_against_golden, golden_cases, golden_window, rel
+from util import check_against_golden, check_manifolds_against_golden, golden_cases, golden_window, rel
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -141,3 +141,12 @@ def test_process_tracks_round_trip(oracle):
         pose = p.sample_trajectory([stamp])[0]
         Rwb = synthetic.quat_to_matrix(pose[None, :4])[0]
         assert np.abs(pw - (pb @ Rwb.T + pose[4:])).max() < 1e-6    # midpoint triangulation recovers the point
+
+
+def test_oracle_manifolds_match_golden(oracle):
+    """Manifold::Plus / PlusJacobian of every variable class (wrapper.hpp:32-38) against the 100-digit vectors, incl. the
+    delta = 0, |delta| > pi/2 and SphereManifold pivot branches (tests/golden/make_manifold_golden.py)."""
+    with ha.Problem(synthetic.small_visual(), lib=oracle) as p:
+        assert check_manifolds_against_golden(p, 1e-14) <= 1e-14
+        with pytest.raises(ha.HsError):
+            p.manifold_plus(ha.HS_MANIFOLD_SPHERE3, np.zeros((1, 4)), np.zeros((1, 2)))

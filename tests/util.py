@@ -61,3 +61,33 @@ def check_against_golden(problem, case, tol):
     bad = {k: v for k, v in errs.items() if not v < tol}
     assert not bad, (case["type"], case["inputs"]["k"], bad)
     return errs
+
+
+def manifold_cases():
+    with open(os.path.join(HERE, "golden", "manifolds.json")) as f:
+        return json.load(f)["cases"]
+
+
+def check_manifolds_against_golden(problem, tol):
+    """Manifold::Plus / PlusJacobian (hs_manifold_plus*) of a library against tests/golden/manifolds.json, batched per kind."""
+    cases = manifold_cases()
+    groups = {}
+    for c in cases:
+        groups.setdefault((c["kind"], c["ambient"]), []).append(c)
+    assert {k for k, _ in groups} == {0, 1, 2, 3, 4, 5}
+    worst = 0.0
+    for (kind, ambient), cs in groups.items():
+        x = np.array([c["x"] for c in cs], float)
+        d = np.array([c["delta"] for c in cs], float).reshape(len(cs), -1)
+        out = problem.manifold_plus(kind, x, d)
+        jac = problem.manifold_plus_jacobian(kind, x)
+        for i, c in enumerate(cs):
+            e = rel(out[i], c["plus"])
+            assert e <= tol, (kind, c["x"], c["delta"], e)
+            worst = max(worst, e)
+            if c["tangent"]:
+                e = rel(jac[i], c["jacobian"])
+                assert e <= tol, (kind, c["x"], e)
+                worst = max(worst, e)
+            assert jac[i].shape == (ambient, c["tangent"])
+    return worst

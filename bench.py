@@ -170,10 +170,14 @@ def main():
     from hyperslam_amd.distributed import attach_allreduce, attach_rccl
     problem = ha.Problem(window, device=local_rank)
     keep = None
+    exchange = "rccl"
     if world > 1:
         if dist.get_backend() == "nccl" and os.environ.get("HS_EXCHANGE", "rccl") == "rccl":
-            attach_rccl(problem, dist)          # ncclAllReduce enqueued by the library on its own stream
+            if not attach_rccl(problem, dist):  # ncclAllReduce enqueued by the library on its own stream
+                keep = attach_allreduce(problem, dist)  # agreed fallback: torch.distributed all_reduce on the library's stream
+                exchange = "hook"
         else:
+            exchange = "hook"
             keep = attach_allreduce(problem, dist)  # Python hook (gloo test path / HS_EXCHANGE=hook)
     problem.snapshot()
 
@@ -218,7 +222,8 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: order-4 SE3 B-spline, 128 control points, 50k pixel reprojection residual blocks "
                                    "+ 5k landmarks per GPU, Schur on landmarks",
                        "residual_blocks_per_gpu": n_blocks_local, "landmarks_per_gpu": int(len(window.landmarks) if world == 1 else 5000),
-                       "lm_iterations_per_step": LM_ITERATIONS, "parallelism": f"residual-sharded x{world}" if world > 1 else "single GPU"},
+                       "lm_iterations_per_step": LM_ITERATIONS, "parallelism": f"residual-sharded x{world}" if world > 1 else "single GPU",
+                       **({"exchange": exchange} if world > 1 else {})},
             "final_cost": s["final_cost"], "initial_cost": s["initial_cost"],
             "device_ms_per_iteration": {k: v / n_lin for k, v in stage.items()},
             # roofline of the kernel SURVEY.md §8(d)'s B_alg is defined for (linearisation: 480 B per pixel residual block); its

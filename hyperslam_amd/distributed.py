@@ -82,7 +82,8 @@ def attach_allreduce(problem, dist, group=None, device_memory=None):
 def attach_rccl(problem, dist, group=None):
     """RCCL directly on the data path (no Python in the solve loop): torch.distributed is used once, to agree on the band layout and
     to hand rank 0's ncclUniqueId to the other ranks; the library then owns its communicator and enqueues ncclAllReduce on its own
-    stream. Needs one GPU per rank."""
+    stream. Needs one GPU per rank. Returns True on every rank if every rank has a communicator, False on every rank otherwise
+    (the caller then registers the generic hook, attach_allreduce)."""
     import torch
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     backend = dist.get_backend(group)
@@ -91,10 +92,21 @@ def attach_rccl(problem, dist, group=None):
     bw = torch.tensor([problem.lib.band_blocks(problem.h)], dtype=torch.int64, device=comm_device)
     dist.all_reduce(bw, op=dist.ReduceOp.MAX, group=group)
     problem._check(problem.lib.set_shard(problem.h, rank, world, int(bw.item())), "set_shard")
+    # Every step is agreed on collectively so that a rank-local failure (librccl not loadable, communicator bootstrap refused)
+    # cannot leave the other ranks waiting: the function returns the same boolean on every rank.
     buf = C.create_string_buffer(128)
+    have_id = 1
     if rank == 0 and problem.lib.rccl_unique_id(buf) != 0:
-        raise RuntimeError("hs_rccl_unique_id failed (librccl.so not loadable?)")
-    uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).to(comm_device)
+        have_id = 0
+    uid = torch.frombuffer(bytearray(buf.raw) + bytearray([have_id]), dtype=torch.uint8).to(comm_device)
     dist.broadcast(uid, src=0, group=group)
     raw = bytes(uid.cpu().numpy().tobytes())
-    problem._check(problem.lib.rccl_init(problem.h, raw, rank, world), "rccl_init")
+    ok = 0
+    if raw[128] == 1:
+        ok = 1 if problem.lib.rccl_init(problem.h, raw[:128], rank, world) == 0 else 0
+        if not ok:
+            msg = problem.lib.last_error(problem.h)
+            print(f"hyperslam_amd: hs_rccl_init failed on rank {rank}: {msg.decode() if msg else ''}", file=sys.stderr)
+    flag = torch.tensor([ok], dtype=torch.int64, device=comm_device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(flag.item())

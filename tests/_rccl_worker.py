@@ -29,7 +29,7 @@ def main():
         cp1 = p.control_points()
     from hyperslam_amd.distributed import attach_rccl
     with ha.Problem(w) as p:
-        attach_rccl(p, dist)  # library-owned communicator, ncclAllReduce on the library's stream
+        assert attach_rccl(p, dist)  # library-owned communicator, ncclAllReduce on the library's stream
         s2 = p.solve(5)
         cp2 = p.control_points()
     np.savez(out, c0=[it["cost"] for it in s0["iterations"]], c1=[it["cost"] for it in s1["iterations"]], cp0=cp0, cp1=cp1,

@@ -89,7 +89,7 @@ struct hs_problem {
   DBuf<double> d_cp, d_cp_cand, d_cam, d_sensor, d_lm, d_lm_cand;
   DBuf<uint8_t> d_cp_const, d_lm_const;
   DBuf<int> d_lm_ptr, d_lm_cfirst, d_lm_ncp, d_lm_yoff, d_cf_ptr;
-  DBuf<double> d_lm_scale, d_lm_L, d_lm_yhat, d_lm_sb, d_lm_D2, d_lm_mcc, d_lm_gmax, d_gabs, d_Y;
+  DBuf<double> d_lm_scale, d_lm_L, d_lm_yhat, d_lm_sb, d_lm_D2, d_lm_part, d_lm_gmax, d_gabs, d_Y;
   DBuf<double> d_v_stamp, d_v_meas, d_v_rec;
   DBuf<int> d_v_lm, d_v_info, d_v_first, d_v_pos, d_v_seg_ptr, d_v_dbgpos;
   DBuf<double> d_p_stamp, d_p_meas, d_p_rec;
@@ -267,7 +267,7 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_lm_yhat.reserve(3 * nl));
   HIP_TRY(p->d_lm_sb.reserve(3 * nl));
   HIP_TRY(p->d_lm_D2.reserve(3 * nl));
-  HIP_TRY(p->d_lm_mcc.reserve(2 * nl));
+  HIP_TRY(p->d_lm_part.reserve(4 * size_t((nl + kBlock / 64 - 1) / (kBlock / 64)) + 4));
   HIP_TRY(p->d_lm_gmax.reserve(nl));
   HIP_TRY(p->d_Y.reserve(size_t(vs.y_total) + 1));
   HIP_TRY(p->d_v_stamp.upload(v_stamp, s));
@@ -325,8 +325,8 @@ int prepare(hs_problem* p) {
   p->nb_cp = std::max((p->n_cp + kBlock - 1) / kBlock, 1);
   HIP_TRY(p->d_cost_part.reserve(p->nb_vis + p->nb_pri + (n_ine + kBlock - 1) / kBlock + 1));
   HIP_TRY(p->d_cand_part.reserve(p->nb_vis + p->nb_pri + (n_ine + kBlock - 1) / kBlock + 1));
-  const int nb_norm = std::max(p->nb_cp, std::min(64, (p->n_lm + kBlock - 1) / kBlock));
-  HIP_TRY(p->d_norm_part.reserve(4 * size_t(nb_norm)));
+  const int nb_norm = p->nb_cp;
+  HIP_TRY(p->d_norm_part.reserve(2 * size_t(nb_norm)));
   const int nbd = p->has_imu ? 6 * p->n_bias + 2 : 0;
   if (nbd && size_t(np) * 8 * 8 > 150 * 1024) HS_FAIL(HS_ERR_INVALID, "window too long for the LDS-resident border forward sweep");
   const int x_count1 = np * (ncb + 3) + np * nbd + nbd * nbd + nbd + 1 + p->world;
@@ -404,7 +404,7 @@ int prepare(hs_problem* p) {
   T.n_lm = p->n_lm, T.lm = p->d_lm.p, T.lm_cand = p->d_lm_cand.p, T.lm_const = p->d_lm_const.p;
   T.lm_ptr = p->d_lm_ptr.p, T.lm_cfirst = p->d_lm_cfirst.p, T.lm_ncp = p->d_lm_ncp.p, T.lm_yoff = p->d_lm_yoff.p, T.cf_ptr = p->d_cf_ptr.p;
   T.lm_scale = p->d_lm_scale.p, T.lm_L = p->d_lm_L.p, T.lm_yhat = p->d_lm_yhat.p, T.lm_sb = p->d_lm_sb.p, T.lm_D2 = p->d_lm_D2.p;
-  T.lm_mcc = p->d_lm_mcc.p, T.lm_gmax = p->d_lm_gmax.p, T.Y = p->d_Y.p;
+  T.lm_part = p->d_lm_part.p, T.n_lm_part = (p->n_lm + kBlock / 64 - 1) / (kBlock / 64), T.lm_gmax = p->d_lm_gmax.p, T.Y = p->d_Y.p;
   {
     int n_obs = p->n_lm;
     while (n_obs > 0 && vs.lm_ptr[n_obs] == vs.lm_ptr[n_obs - 1]) --n_obs;
@@ -563,13 +563,14 @@ int launch_build(hs_problem* p) {
   }
   if (T.nb)
     k_reduce_partials<<<std::min(1024, (T.xo_bb - T.xo_pb + kBlock - 1) / kBlock), kBlock, 0, s>>>(T, p->n_split, T.xo_pb);
-  k_pack_exchange<<<1, kBlock, 0, s>>>(T);
+  const bool reduce_here = !p->allreduce && !p->rccl_comm && !T.nb && p->world == 1;  // nothing to exchange: bookkeeping in the packing kernel
+  k_pack_exchange<<<1, kBlock, 0, s>>>(T, reduce_here ? 1 : 0);
   HIP_TRY(hipGetLastError());
   const int rc = exchange(p, T.xbuf, T.x_count1);  // one RCCL all-reduce of [S | g | diag | cost] per linearisation
   if (rc) return rc;
   k_finalize_reduced<<<T.sp.n_cp, kBlock, 0, s>>>(T);
   if (T.nb) k_finalize_border<<<std::min(256, ((T.np + T.nb) * T.nb + kBlock - 1) / kBlock), kBlock, 0, s>>>(T);
-  k_cost_reduce<<<1, kBlock, 0, s>>>(T);
+  if (!reduce_here) k_cost_reduce<<<1, kBlock, 0, s>>>(T);
   HIP_TRY(hipGetLastError());
   return HS_OK;
 }
@@ -632,8 +633,7 @@ template <int K>
 int launch_update(hs_problem* p) {
   const Tables& T = p->T;
   hipStream_t s = p->stream;
-  if (T.n_lm) k_backsub_landmarks<<<(T.n_lm + kBlock / 64 - 1) / (kBlock / 64), kBlock, 0, s>>>(T);
-  k_retract<<<T.n_norm_part, kBlock, 0, s>>>(T);
+  k_backsub_retract<<<T.n_lm_part + T.n_norm_part, kBlock, 0, s>>>(T);
   if (T.n_vis) k_cost_visual<K><<<p->nb_vis, kBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.lm_cand, T.cand_part);
   if (T.n_pri) k_cost_prior<K><<<p->nb_pri, kBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.cand_part + p->nb_vis);
   if (T.n_ine)
@@ -645,7 +645,7 @@ int launch_update(hs_problem* p) {
   const int rc = exchange(p, T.xbuf + T.xo_dec, 5);  // candidate cost + norms + landmark-side model-cost terms
   if (rc) return rc;
   if (!local_decision) k_decide<<<1, 64, 0, s>>>(T);
-  const int nb_commit = std::max((8 * T.sp.n_cp + kBlock - 1) / kBlock, 1);
+  const int nb_commit = std::max((std::max(8 * T.sp.n_cp, 3 * T.n_lm) + kBlock - 1) / kBlock, 1);  // one element per lane
   k_commit<<<nb_commit, kBlock, 0, s>>>(T);
   HIP_TRY(hipGetLastError());
   return HS_OK;
@@ -981,7 +981,7 @@ int hs_cost(hs_problem* p, double* cost) {
   if (rc) return rc;
   rc = p->k == 4 ? launch_linearize<4>(p) : launch_linearize<6>(p);
   if (rc) return rc;
-  k_pack_exchange<<<1, kBlock, 0, p->stream>>>(p->T);
+  k_pack_exchange<<<1, kBlock, 0, p->stream>>>(p->T, 0);
   rc = exchange(p, p->T.xbuf + p->T.xo_cost, 1);
   if (rc) return rc;
   k_cost_reduce<<<1, kBlock, 0, p->stream>>>(p->T);
@@ -1069,7 +1069,7 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
   if (max_iterations == 0) {
     rc = p->k == 4 ? launch_linearize<4>(p) : launch_linearize<6>(p);
     if (rc) return rc;
-    k_pack_exchange<<<1, kBlock, 0, s>>>(p->T);
+    k_pack_exchange<<<1, kBlock, 0, s>>>(p->T, 0);
     rc = exchange(p, p->T.xbuf + p->T.xo_cost, 1);
     if (rc) return rc;
     k_cost_reduce<<<1, kBlock, 0, s>>>(p->T);

@@ -10,7 +10,7 @@
 //   k_band_factor_la (look-ahead, one or two ends) | k_band_factor (bw <= 22) | k_band_factor_wide (bw <= 42)   S = U'U, y
 //   k_border_forward / _schur / _solve / _apply                                         bordered part of the solve
 //   k_band_backward | k_band_backward2       U x = y, step outputs
-//   k_backsub_landmarks / k_retract          step for landmarks, candidate point = Plus(x, delta)
+//   k_backsub_retract                        step for landmarks, candidate point = Plus(x, delta), norm / model-cost partials
 //   k_cost_visual / _prior / _inertial       cost at the candidate point
 //   k_pack_decision -> [all-reduce] -> k_decide -> k_commit      trust-region logic and acceptance
 #pragma once
@@ -351,6 +351,8 @@ __global__ void __launch_bounds__(kBlock) k_landmark(Tables T) {
       }
     }
     const int cnt = min(64, q1 - base);
+    // (a predicated batch of 5 / 10 records per load round with lane broadcasts of the landmark-side Jacobian was measured slower,
+    // 21.9 / 23 us vs 17.5 us: its registers cost the fifth resident wave per SIMD that keeps all 5 000 landmarks in flight)
 #pragma unroll 4
     for (int t = 0; t < cnt; ++t) {
       const int ft = __builtin_amdgcn_readlane(my_first, t), pt = __builtin_amdgcn_readlane(my_pos, t);  // wave-uniform
@@ -708,14 +710,30 @@ __global__ void __launch_bounds__(kBlock) k_reduce_partials(Tables T, int nsp, i
   }
 }
 
+HSD void begin_iteration(const Tables& T, double cost, double gmax, bool set_scaling_ready);
+
 /// Local cost and landmark-side gradient max norm into the exchange buffer (slot per rank so that a SUM all-reduce
-/// delivers every rank's value to every rank).
-__global__ void __launch_bounds__(kBlock) k_pack_exchange(Tables T) {
+/// delivers every rank's value to every rank). reduce_here (single shard, no border unknowns): nothing is exchanged, so the
+/// iteration bookkeeping of k_cost_reduce is done right here (the pose-side gradient is already in the buffer).
+__global__ void __launch_bounds__(kBlock) k_pack_exchange(Tables T, int reduce_here) {
   __shared__ double red[kBlock / 64];
   DevState* st = T.st;
   if (st->done) return;
   double s = strided_sum(T.cost_part, T.n_cost_part);
   double gm = strided_max(T.lm_gmax, T.n_obs_lm);
+  if (reduce_here) {
+    const double* gp = T.xbuf + T.xo_g;
+    for (int i0 = threadIdx.x; i0 < T.np; i0 += 8 * blockDim.x) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * blockDim.x;
+        v[u] = i < T.np ? fabs(gp[i]) : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) gm = fmax(gm, v[u]);
+    }
+  }
   s = block_sum(s, red);
   if (threadIdx.x == 0) T.xbuf[T.xo_cost] = s;
 #pragma unroll
@@ -725,6 +743,7 @@ __global__ void __launch_bounds__(kBlock) k_pack_exchange(Tables T) {
   if (threadIdx.x == 0) {
     for (int i = 1; i < int(blockDim.x >> 6); ++i) gm = fmax(gm, red[i]);
     for (int r = 0; r < T.world; ++r) T.xbuf[T.xo_gmax + r] = (r == T.rank) ? gm : 0.0;
+    if (reduce_here) begin_iteration(T, s, gm, /*set_scaling_ready=*/false);  // k_finalize_reduced of this linearisation still needs the flag
   }
 }
 
@@ -2324,48 +2343,61 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward(Tables T) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Landmark back-substitution (one wave per landmark):
-//   y_l = L^-T (yh_l - Yh_l' (Sp o y_p)),  step_l = -y_l, with y_p = -step_p;   candidate = lm + S_l o step_l.
+// Candidate point of the step, one launch. Workgroups [0, n_lm_part): landmark back-substitution (one wave per landmark):
+//   y_l = L^-T (yh_l - Yh_l' (Sp o y_p)),  step_l = -y_l, with y_p = -step_p;   candidate = lm + S_l o step_l,
+// with the landmark-side terms of the decision (|x|^2, |x - x+|^2, g.step, step'D^2 step) summed per workgroup in a fixed
+// order. Workgroups [n_lm_part, n_lm_part + n_norm_part): candidate control points / bias points / gravity = Plus(x, delta) per
+// Ceres manifold (quaternion left-multiplicative, R^3 additive, stamp constant, sphere) and their norms.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_backsub_landmarks(Tables T) {
+__global__ void __launch_bounds__(kBlock) k_backsub_retract(Tables T) {
   if (T.st->done) return;
-  const int lane = threadIdx.x & 63;
-  const int dl = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (dl >= T.n_lm) return;
-  const int rows = 6 * T.lm_ncp[dl], r0 = 6 * T.lm_cfirst[dl];
-  const double* Y = T.Y + T.lm_yoff[dl];
-  double t0 = 0, t1 = 0, t2 = 0;
-  for (int rho = lane; rho < rows; rho += 64) {
-    const double yp = -T.step_p[r0 + rho] * T.scale_p[r0 + rho];
-    t0 = fma(Y[3 * rho], yp, t0), t1 = fma(Y[3 * rho + 1], yp, t1), t2 = fma(Y[3 * rho + 2], yp, t2);
-  }
-  t0 = wave_sum(t0), t1 = wave_sum(t1), t2 = wave_sum(t2);
-  if (lane == 0) {
-    const double* L = T.lm_L + 6 * dl;
-    const double* yh = T.lm_yhat + 3 * dl;
-    const bool active = (T.lm_ptr[dl + 1] > T.lm_ptr[dl]) && !T.lm_const[dl];
-    // L' y = z
-    const double z0 = yh[0] - t0, z1 = yh[1] - t1, z2 = yh[2] - t2;
-    const double y2 = z2 / L[5], y1 = (z1 - L[4] * y2) / L[2], y0 = (z0 - L[1] * y1 - L[3] * y2) / L[0];
-    const double s[3] = {active ? -y0 : 0.0, active ? -y1 : 0.0, active ? -y2 : 0.0};
-    double gd = 0, dd = 0;
+  __shared__ double red[kBlock / 64][4];
+  if (int(blockIdx.x) < T.n_lm_part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int dl = blockIdx.x * (kBlock / 64) + wave;
+    double xl = 0.0, sl = 0.0, gd = 0.0, dd = 0.0;
+    if (dl < T.n_lm) {
+      const int rows = 6 * T.lm_ncp[dl], r0 = 6 * T.lm_cfirst[dl];
+      const double* Y = T.Y + T.lm_yoff[dl];
+      double t0 = 0, t1 = 0, t2 = 0;
+      for (int rho = lane; rho < rows; rho += 64) {
+        const double yp = -T.step_p[r0 + rho] * T.scale_p[r0 + rho];
+        t0 = fma(Y[3 * rho], yp, t0), t1 = fma(Y[3 * rho + 1], yp, t1), t2 = fma(Y[3 * rho + 2], yp, t2);
+      }
+      t0 = wave_sum(t0), t1 = wave_sum(t1), t2 = wave_sum(t2);
+      if (lane == 0) {
+        const double* L = T.lm_L + 6 * dl;
+        const double* yh = T.lm_yhat + 3 * dl;
+        const bool active = (T.lm_ptr[dl + 1] > T.lm_ptr[dl]) && !T.lm_const[dl];
+        // L' y = z
+        const double z0 = yh[0] - t0, z1 = yh[1] - t1, z2 = yh[2] - t2;
+        const double y2 = z2 / L[5], y1 = (z1 - L[4] * y2) / L[2], y0 = (z0 - L[1] * y1 - L[3] * y2) / L[0];
+        const double s[3] = {active ? -y0 : 0.0, active ? -y1 : 0.0, active ? -y2 : 0.0};
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      T.lm_cand[3 * dl + a] = T.lm[3 * dl + a] + T.lm_scale[3 * dl + a] * s[a];
-      gd = fma(T.lm_sb[3 * dl + a], s[a], gd);
-      dd = fma(T.lm_D2[3 * dl + a] * s[a], s[a], dd);
+        for (int a = 0; a < 3; ++a) {
+          const double x = T.lm[3 * dl + a], y = x + T.lm_scale[3 * dl + a] * s[a];
+          T.lm_cand[3 * dl + a] = y;
+          if (active) {
+            xl = fma(x, x, xl), sl = fma(x - y, x - y, sl);
+            gd = fma(T.lm_sb[3 * dl + a], s[a], gd);
+            dd = fma(T.lm_D2[3 * dl + a] * s[a], s[a], dd);
+          }
+        }
+      }
     }
-    T.lm_mcc[2 * dl] = active ? gd : 0.0, T.lm_mcc[2 * dl + 1] = active ? dd : 0.0;
+    if (lane == 0) red[wave][0] = xl, red[wave][1] = sl, red[wave][2] = gd, red[wave][3] = dd;
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      double v = 0.0;
+#pragma unroll
+      for (int w = 0; w < kBlock / 64; ++w) v += red[w][threadIdx.x];
+      T.lm_part[4 * blockIdx.x + threadIdx.x] = v;
+    }
+    return;
   }
-}
-
-/// Candidate control points: Plus(x, delta) per Ceres manifold (quaternion left-multiplicative half-angle, R^3 additive,
-/// stamp constant). Also accumulates |x|^2 and |x - x+|^2 partials for the parameter-tolerance test.
-__global__ void __launch_bounds__(kBlock) k_retract(Tables T) {
-  if (T.st->done) return;
-  __shared__ double red[kBlock / 64];
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  double xs = 0.0, ss = 0.0, xl = 0.0, sl = 0.0;
+  const int blk = blockIdx.x - T.n_lm_part;
+  const int j = blk * blockDim.x + threadIdx.x;
+  double xs = 0.0, ss = 0.0;
   if (j < T.sp.n_cp) {
     const double* x = T.cp + 8 * j;
     double* y = T.cp_cand + 8 * j;
@@ -2382,19 +2414,9 @@ __global__ void __launch_bounds__(kBlock) k_retract(Tables T) {
       for (int c = 0; c < 8; ++c) xs = fma(x[c], x[c], xs), ss = fma(x[c] - y[c], x[c] - y[c], ss);
     }
   }
-  for (int l = j; l < T.n_lm; l += gridDim.x * blockDim.x) {
-    const bool active = (T.lm_ptr[l + 1] > T.lm_ptr[l]) && !T.lm_const[l];
-    if (active) {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const double x = T.lm[3 * l + a], y = T.lm_cand[3 * l + a];
-        xl = fma(x, x, xl), sl = fma(x - y, x - y, sl);
-      }
-    }
-  }
   // border unknowns (replicated like the control points): bias control points [x y z t] and gravity
   if (T.nb > 0) {
-    for (int b = j; b < 2 * T.n_bias; b += gridDim.x * blockDim.x) {
+    for (int b = j; b < 2 * T.n_bias; b += T.n_norm_part * blockDim.x) {
       const bool acc = b >= T.n_bias;
       const int bi = acc ? b - T.n_bias : b;
       const double* x = (acc ? T.bias_a : T.bias_g) + 4 * bi;
@@ -2419,11 +2441,9 @@ __global__ void __launch_bounds__(kBlock) k_retract(Tables T) {
       }
     }
   }
-  xs = block_sum(xs, red), ss = block_sum(ss, red), xl = block_sum(xl, red), sl = block_sum(sl, red);
-  if (threadIdx.x == 0) {
-    double* o = T.norm_part + 4 * blockIdx.x;
-    o[0] = xs, o[1] = ss, o[2] = xl, o[3] = sl;
-  }
+  double* lds = &red[0][0];
+  xs = block_sum(xs, lds), ss = block_sum(ss, lds);
+  if (threadIdx.x == 0) T.norm_part[2 * blk] = xs, T.norm_part[2 * blk + 1] = ss;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -2450,10 +2470,17 @@ __global__ void __launch_bounds__(kBlock) k_cost_reduce(Tables T) {
   for (int i = 1; i < int(blockDim.x >> 6); ++i) gm = fmax(gm, red[i]);
   const double c = T.xbuf[T.xo_cost];
   for (int r = 0; r < T.world; ++r) gm = fmax(gm, T.xbuf[T.xo_gmax + r]);
+  begin_iteration(T, c, gm, true);
+}
+
+/// (global) cost and gradient max norm of the current linearisation point -> state; iteration 0 record; termination tests
+/// that precede a step (single lane).
+HSD void begin_iteration(const Tables& T, double c, double gm, bool set_scaling_ready) {
+  DevState* st = T.st;
   st->cost = c;
   st->gmax = gm;
   st->chol_failed = 0;    // raised by the factorisation kernels of this iteration
-  st->scaling_ready = 1;  // Jacobi scaling is computed at iteration 0 only
+  if (set_scaling_ready) st->scaling_ready = 1;  // Jacobi scaling is computed at iteration 0 only (else: set by decide_step)
   if (st->iteration == 0) {
     hs_iteration& r = st->records[0];
     r.iteration = 0, r.step_is_valid = 1, r.step_is_successful = 1, r.cost = c, r.cost_change = 0, r.gradient_max_norm = gm;
@@ -2479,9 +2506,9 @@ __global__ void __launch_bounds__(kBlock) k_pack_decision(Tables T, int decide_h
   DevState* st = T.st;
   if (st->done) return;
   double cand = strided_sum(T.cand_part, T.n_cost_part);
-  double xs = strided_sum(T.norm_part, T.n_norm_part, 4, 2), ss = strided_sum(T.norm_part, T.n_norm_part, 4, 3);  // landmarks (local)
-  if (T.rank == 0) xs += strided_sum(T.norm_part, T.n_norm_part, 4, 0), ss += strided_sum(T.norm_part, T.n_norm_part, 4, 1);  // control points (replicated)
-  double gd = strided_sum(T.lm_mcc, T.n_lm, 2, 0), dd = strided_sum(T.lm_mcc, T.n_lm, 2, 1);
+  double xs = strided_sum(T.lm_part, T.n_lm_part, 4, 0), ss = strided_sum(T.lm_part, T.n_lm_part, 4, 1);  // landmarks (local)
+  if (T.rank == 0) xs += strided_sum(T.norm_part, T.n_norm_part, 2, 0), ss += strided_sum(T.norm_part, T.n_norm_part, 2, 1);  // control points (replicated)
+  double gd = strided_sum(T.lm_part, T.n_lm_part, 4, 2), dd = strided_sum(T.lm_part, T.n_lm_part, 4, 3);
   cand = block_sum(cand, red), xs = block_sum(xs, red), ss = block_sum(ss, red), gd = block_sum(gd, red), dd = block_sum(dd, red);
   if (threadIdx.x == 0) {
     double* D = T.xbuf + T.xo_dec;
@@ -2500,6 +2527,7 @@ HSD void decide_step(const Tables& T) {
   const double g_step = st->g_dot_step_pose + D[3], d_step = st->d2_step2_pose + D[4];
   const double mcc = -0.5 * g_step + 0.5 * d_step;
   st->model_cost_change = mcc;
+  st->scaling_ready = 1;  // a step was computed: the Jacobi scaling of this solve is fixed from here on
   st->step_valid = (isfinite(mcc) && !st->chol_failed && mcc >= 0.0) ? 1 : 0;
   const int it = st->iteration;
   hs_iteration& r = st->records[it];
@@ -2655,7 +2683,7 @@ __global__ void k_reset_state(DevState* st, int max_iterations, double radius) {
 }
 
 /// Batched Manifold::Plus / PlusJacobian of the variable classes on the path (hs_manifold_plus*): the same device
-/// functions k_retract and the local-coordinate Jacobians use. One element per lane. kind: HS_MANIFOLD_* of the C ABI.
+/// functions k_backsub_retract and the local-coordinate Jacobians use. One element per lane. kind: HS_MANIFOLD_* of the C ABI.
 __global__ void __launch_bounds__(kBlock) k_manifold_plus(int kind, int ambient, int tangent, int n, const double* __restrict__ x,
                                                           const double* __restrict__ d, double* __restrict__ out, double* __restrict__ jac) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

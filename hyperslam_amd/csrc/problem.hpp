@@ -94,7 +94,8 @@ struct Tables {
   double* lm_yhat;         // n_lm x 3  L^-1 (s_l o b_l)
   double* lm_sb;           // n_lm x 3  s_l o b_l
   double* lm_D2;           // n_lm x 3  LM diagonal
-  double* lm_mcc;          // n_lm x 2  per-landmark (g.step, step D2 step) terms
+  double* lm_part;         // n_lm_part x 4  per-workgroup (|x|^2, |x - x+|^2, g.step, step D2 step) landmark terms of the decision
+  int n_lm_part;
   double* lm_gmax;         // n_lm      per-landmark max |b_l| (gradient max norm)
   int n_obs_lm;            // observed landmarks (device order puts unobserved ones last)
   double* Y;               // concatenated Y-hat (6 n_l x 3 per landmark)
@@ -167,7 +168,7 @@ struct Tables {
   double* cost_part;       // per-block cost partial sums (current point)
   double* cand_part;       // per-block cost partial sums (candidate point)
   int n_cost_part;
-  double* norm_part;       // per-block (x_sqnorm, step_sqnorm) pairs
+  double* norm_part;       // per-block (x_sqnorm, step_sqnorm) pairs of the replicated unknowns
   int n_norm_part;
   // exchange buffer (additive across residual shards): [Sraw np*6bw | g_p np | g_schur np | diag np | H_pb np*nb | H_bb nb*nb | g_b nb | cost | gmax[world] | decision 5]
   double* xbuf;

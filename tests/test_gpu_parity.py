@@ -192,7 +192,7 @@ def test_band_width_classes(hip):
 
 
 def test_manifolds(hip, oracle):
-    """hs_manifold_plus / hs_manifold_plus_jacobian (the retractions k_retract applies) against the 100-digit vectors and,
+    """hs_manifold_plus / hs_manifold_plus_jacobian (the retractions k_backsub_retract applies) against the 100-digit vectors and,
     on a larger random batch, against the oracle."""
     from util import check_manifolds_against_golden
     w = synthetic.small_visual()

@@ -28,7 +28,7 @@ B_ALG_PIXEL_K4 = 480        # algorithmic bytes per pixel residual block lineari
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-def cpu_baseline(window, budget_s=20.0):
+def cpu_baseline(window, budget_s=20.0, world_is_one=True):
     """Oracle (CPU restatement, 1 thread like the reference's num_threads = 1) timed on the same workload, bounded."""
     import hyperslam_amd as ha
     from hyperslam_amd import _lib
@@ -45,7 +45,9 @@ def cpu_baseline(window, budget_s=20.0):
     kind_note = "-O3 -march=native build on this host"
     try:
         src = os.path.join(ROOT, "oracle", "capi.cpp")
-        if not os.path.exists(native) or os.path.getmtime(native) < os.path.getmtime(src):
+        import glob
+        newest = max(os.path.getmtime(f) for f in [src] + glob.glob(os.path.join(ROOT, "oracle", "*.hpp")))
+        if not os.path.exists(native) or os.path.getmtime(native) < newest:
             subprocess.check_call(["g++", "-std=c++17", "-O3", "-march=native", "-fPIC", "-shared", "-o", native, src],
                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
         lib = _lib.Library(native, "hso_")
@@ -64,41 +66,48 @@ def cpu_baseline(window, budget_s=20.0):
     out = {"value": n_blocks * iters / spent, "unit": "residual_blocks/s", "cores": 1, "kind": "port",
            "ms_per_iteration": 1e3 * spent / iters,
            "sample": f"{runs} x optimize() ({LM_ITERATIONS} LM iterations) of the full workload on 1 host thread; own C++ restatement, not Ceres; {kind_note}"}
-    out["all_cores"] = cpu_all_cores(window, lib, n_blocks)
+    if world_is_one:
+        out["all_cores"] = cpu_all_cores(lib.path, n_blocks)
     return out
 
 
-def cpu_all_cores(window, lib, n_blocks):
+def cpu_all_cores(lib_path, n_blocks):
     """SURVEY.md §8d's second CPU figure. The reference solves one window on one thread (optimizer.cpp:41), so the only way it fills
-    a host is with independent windows: the same workload once per hardware thread, all started together, TWO LM iterations each (keeps
-    the leg at tens of seconds: with every thread busy the dense restatement is DRAM-bound and runs several times slower per thread); value
-    = blocks linearised by all threads / wall time of the slowest (ctypes releases the GIL during the call)."""
-    import threading
-    import hyperslam_amd as ha
+    a host is with independent windows: one optimize() of the same workload per hardware thread, each in its own PROCESS (threads
+    of one process serialise on the address-space lock while they fault in their working sets), all started at the same wall-clock
+    instant; value = blocks linearised by all processes / (latest finish - common start)."""
+    import subprocess
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    problems = [ha.Problem(window, lib=lib) for _ in range(cores)]
-    iters = [0] * cores
-    gate = threading.Barrier(cores + 1)
+    start = time.time() + 8.0 + 0.04 * cores  # interpreter start-up + window generation of every worker
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", lib_path, repr(start)], stdout=subprocess.PIPE,
+                              stderr=subprocess.DEVNULL, text=True) for _ in range(cores)]
+    results = []
+    for pr in procs:
+        out, _ = pr.communicate(timeout=600)
+        if pr.returncode == 0 and out.strip():
+            results.append(json.loads(out.strip().splitlines()[-1]))
+    if not results:
+        return None
+    wall = max(r["end"] for r in results) - start
+    return {"value": n_blocks * sum(r["iters"] for r in results) / wall, "unit": "residual_blocks/s", "cores": len(results),
+            "sample": f"{len(results)} independent windows (one optimize() = {LM_ITERATIONS} LM iterations each, one process per hardware thread) "
+                      f"started together, {wall:.2f} s wall; {sum(r['late'] for r in results)} started late"}
 
-    def work(i):
-        gate.wait()
-        iters[i] = problems[i].solve(2)["num_iterations"]
 
-    threads = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
-    for t in threads:
-        t.start()
-    gate.wait()
-    t0 = time.perf_counter()
-    for t in threads:
-        t.join()
-    wall = time.perf_counter() - t0
-    for p in problems:
-        p.close()
-    return {"value": n_blocks * sum(iters) / wall, "unit": "residual_blocks/s", "cores": cores,
-            "sample": f"{cores} independent windows (2 LM iterations each, one per hardware thread) started together, {wall:.2f} s wall"}
+def cpu_worker(lib_path, start):
+    """One process of the all-cores CPU leg (bench.py --cpu-worker): the oracle on the configs[1] window, started at `start`."""
+    import hyperslam_amd as ha
+    from hyperslam_amd import _lib, synthetic
+    lib = _lib.Library(lib_path, "hso_")
+    problem = ha.Problem(synthetic.config1(n_cp=128, n_landmarks=5000, obs_pairs=5), lib=lib)
+    late = time.time() > start
+    while time.time() < start:
+        time.sleep(0.0005)
+    s = problem.solve(LM_ITERATIONS)
+    print(json.dumps({"end": time.time(), "iters": s["num_iterations"], "late": int(late)}), flush=True)
 
 
 def pmc_traffic(kernel):
@@ -136,7 +145,10 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-worker", nargs=2, metavar=("LIB", "START"), help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker:
+        return cpu_worker(args.cpu_worker[0], float(args.cpu_worker[1]))
 
     import numpy as np
     import torch
@@ -245,9 +257,10 @@ def main():
         out["roofline_iteration"] = {"bound": "hbm", "achieved": B_ALG_PIXEL_K4 * n_blocks_local / (it_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": B_ALG_PIXEL_K4 * n_blocks_local / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": it_ms}
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(full if world == 1 else window)
+            out["cpu_baseline"] = cpu_baseline(full if world == 1 else window, world_is_one=(world == 1))
             out["speedup_vs_cpu_1thread"] = out["value"] / world / out["cpu_baseline"]["value"]
-            out["speedup_vs_cpu_all_cores"] = out["value"] / world / out["cpu_baseline"]["all_cores"]["value"]
+            if out["cpu_baseline"].get("all_cores"):
+                out["speedup_vs_cpu_all_cores"] = out["value"] / world / out["cpu_baseline"]["all_cores"]["value"]
         print(json.dumps(out))
     problem.close()
     if dist:

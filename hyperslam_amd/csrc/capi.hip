@@ -564,11 +564,11 @@ int launch_build(hs_problem* p) {
   if (T.nb)
     k_reduce_partials<<<std::min(1024, (T.xo_bb - T.xo_pb + kBlock - 1) / kBlock), kBlock, 0, s>>>(T, p->n_split, T.xo_pb);
   const bool reduce_here = !p->allreduce && !p->rccl_comm && !T.nb && p->world == 1;  // nothing to exchange: bookkeeping in the packing kernel
-  k_pack_exchange<<<1, kBlock, 0, s>>>(T, reduce_here ? 1 : 0);
+  if (!reduce_here) k_pack_exchange<<<1, kBlock, 0, s>>>(T, 0);
   HIP_TRY(hipGetLastError());
   const int rc = exchange(p, T.xbuf, T.x_count1);  // one RCCL all-reduce of [S | g | diag | cost] per linearisation
   if (rc) return rc;
-  k_finalize_reduced<<<T.sp.n_cp, kBlock, 0, s>>>(T);
+  k_finalize_reduced<<<T.sp.n_cp + (reduce_here ? 1 : 0), kBlock, 0, s>>>(T);  // + 1: packing / bookkeeping workgroup
   if (T.nb) k_finalize_border<<<std::min(256, ((T.np + T.nb) * T.nb + kBlock - 1) / kBlock), kBlock, 0, s>>>(T);
   if (!reduce_here) k_cost_reduce<<<1, kBlock, 0, s>>>(T);
   HIP_TRY(hipGetLastError());

@@ -61,17 +61,18 @@ HSD double strided_sum(const double* __restrict__ p, int n, int stride = 1, int 
   }
   return s;
 }
-HSD double strided_max(const double* __restrict__ p, int n) {  // entries >= 0
+template <int U = 8>
+HSD double strided_max(const double* __restrict__ p, int n) {  // entries >= 0; U independent loads in flight per lane
   double m = 0.0;
-  for (int i0 = threadIdx.x; i0 < n; i0 += 8 * blockDim.x) {
-    double v[8];
+  for (int i0 = threadIdx.x; i0 < n; i0 += U * blockDim.x) {
+    double v[U];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int i = i0 + u * blockDim.x;
       v[u] = i < n ? p[i] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) m = fmax(m, v[u]);
+    for (int u = 0; u < U; ++u) m = fmax(m, v[u]);
   }
   return m;
 }
@@ -715,12 +716,12 @@ HSD void begin_iteration(const Tables& T, double cost, double gmax, bool set_sca
 /// Local cost and landmark-side gradient max norm into the exchange buffer (slot per rank so that a SUM all-reduce
 /// delivers every rank's value to every rank). reduce_here (single shard, no border unknowns): nothing is exchanged, so the
 /// iteration bookkeeping of k_cost_reduce is done right here (the pose-side gradient is already in the buffer).
-__global__ void __launch_bounds__(kBlock) k_pack_exchange(Tables T, int reduce_here) {
+HSD void pack_exchange_body(const Tables& T, int reduce_here) {
   __shared__ double red[kBlock / 64];
   DevState* st = T.st;
   if (st->done) return;
   double s = strided_sum(T.cost_part, T.n_cost_part);
-  double gm = strided_max(T.lm_gmax, T.n_obs_lm);
+  double gm = strided_max<24>(T.lm_gmax, T.n_obs_lm);  // one value per landmark: a single round of loads at 5 000 landmarks
   if (reduce_here) {
     const double* gp = T.xbuf + T.xo_g;
     for (int i0 = threadIdx.x; i0 < T.np; i0 += 8 * blockDim.x) {
@@ -746,6 +747,7 @@ __global__ void __launch_bounds__(kBlock) k_pack_exchange(Tables T, int reduce_h
     if (reduce_here) begin_iteration(T, s, gm, /*set_scaling_ready=*/false);  // k_finalize_reduced of this linearisation still needs the flag
   }
 }
+__global__ void __launch_bounds__(kBlock) k_pack_exchange(Tables T, int reduce_here) { pack_exchange_body(T, reduce_here); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Border unknowns (IMU bias-spline control points + gravity; SURVEY a-4): the inertial factor couples every control point of
@@ -1118,8 +1120,15 @@ __global__ void __launch_bounds__(kBlock) k_border_apply(Tables T) {
 
 /// After the (optional) all-reduce: Jacobi scaling (fixed at iteration 0), LM diagonal, inactive coordinates.
 ///   S = Sp Sraw Sp + D_p^2,  g = Sp (g_p + g_schur),  g_full = Sp g_p,  D_p^2 = clamp(Sp^2 diag(J'J), 1e-6, 1e32) / radius.
+/// A workgroup past the last block row (single shard without border unknowns: gridDim.x = n_cp + 1) does the work of
+/// k_pack_exchange + k_cost_reduce concurrently: with nothing exchanged, neither side reads what the other writes (the block
+/// rows use the radius and the scaling flag, which the bookkeeping leaves alone; `done` only makes them skip unused work).
 __global__ void __launch_bounds__(kBlock) k_finalize_reduced(Tables T) {
   DevState* st = T.st;
+  if (int(blockIdx.x) >= T.sp.n_cp) {
+    pack_exchange_body(T, 1);
+    return;
+  }
   if (st->done) return;
   const int i = blockIdx.x, tid = threadIdx.x;
   const int ncb = 6 * T.bw;
@@ -2359,28 +2368,47 @@ __global__ void __launch_bounds__(kBlock) k_backsub_retract(Tables T) {
     if (dl < T.n_lm) {
       const int rows = 6 * T.lm_ncp[dl], r0 = 6 * T.lm_cfirst[dl];
       const double* Y = T.Y + T.lm_yoff[dl];
+      // lane 0's operands of the 3x3 solve are requested before the dot products (one memory round trip less on the chain)
+      double L[6] = {1, 0, 1, 0, 0, 1}, yh[3] = {0, 0, 0}, x[3] = {0, 0, 0}, sc[3] = {0, 0, 0}, sb[3] = {0, 0, 0}, d2[3] = {0, 0, 0};
+      bool active = false;
+      if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) L[a] = T.lm_L[6 * dl + a];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          yh[a] = T.lm_yhat[3 * dl + a], x[a] = T.lm[3 * dl + a], sc[a] = T.lm_scale[3 * dl + a];
+          sb[a] = T.lm_sb[3 * dl + a], d2[a] = T.lm_D2[3 * dl + a];
+        }
+        active = (T.lm_ptr[dl + 1] > T.lm_ptr[dl]) && !T.lm_const[dl];
+      }
       double t0 = 0, t1 = 0, t2 = 0;
-      for (int rho = lane; rho < rows; rho += 64) {
-        const double yp = -T.step_p[r0 + rho] * T.scale_p[r0 + rho];
-        t0 = fma(Y[3 * rho], yp, t0), t1 = fma(Y[3 * rho + 1], yp, t1), t2 = fma(Y[3 * rho + 2], yp, t2);
+      for (int rho0 = lane; rho0 < rows; rho0 += 128) {  // two 64-row passes per round of loads (a track of <= 21 control points: one round)
+        double yv[2][3], yp[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int rho = rho0 + 64 * u;
+          const bool ok = rho < rows;
+          yp[u] = ok ? -T.step_p[r0 + rho] * T.scale_p[r0 + rho] : 0.0;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) yv[u][c] = ok ? Y[3 * rho + c] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) t0 = fma(yv[u][0], yp[u], t0), t1 = fma(yv[u][1], yp[u], t1), t2 = fma(yv[u][2], yp[u], t2);
       }
       t0 = wave_sum(t0), t1 = wave_sum(t1), t2 = wave_sum(t2);
       if (lane == 0) {
-        const double* L = T.lm_L + 6 * dl;
-        const double* yh = T.lm_yhat + 3 * dl;
-        const bool active = (T.lm_ptr[dl + 1] > T.lm_ptr[dl]) && !T.lm_const[dl];
         // L' y = z
         const double z0 = yh[0] - t0, z1 = yh[1] - t1, z2 = yh[2] - t2;
         const double y2 = z2 / L[5], y1 = (z1 - L[4] * y2) / L[2], y0 = (z0 - L[1] * y1 - L[3] * y2) / L[0];
         const double s[3] = {active ? -y0 : 0.0, active ? -y1 : 0.0, active ? -y2 : 0.0};
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-          const double x = T.lm[3 * dl + a], y = x + T.lm_scale[3 * dl + a] * s[a];
+          const double y = x[a] + sc[a] * s[a];
           T.lm_cand[3 * dl + a] = y;
           if (active) {
-            xl = fma(x, x, xl), sl = fma(x - y, x - y, sl);
-            gd = fma(T.lm_sb[3 * dl + a], s[a], gd);
-            dd = fma(T.lm_D2[3 * dl + a] * s[a], s[a], dd);
+            xl = fma(x[a], x[a], xl), sl = fma(x[a] - y, x[a] - y, sl);
+            gd = fma(sb[a], s[a], gd);
+            dd = fma(d2[a] * s[a], s[a], dd);
           }
         }
       }
@@ -2505,10 +2533,30 @@ __global__ void __launch_bounds__(kBlock) k_pack_decision(Tables T, int decide_h
   __shared__ double red[kBlock / 64];
   DevState* st = T.st;
   if (st->done) return;
-  double cand = strided_sum(T.cand_part, T.n_cost_part);
-  double xs = strided_sum(T.lm_part, T.n_lm_part, 4, 0), ss = strided_sum(T.lm_part, T.n_lm_part, 4, 1);  // landmarks (local)
-  if (T.rank == 0) xs += strided_sum(T.norm_part, T.n_norm_part, 2, 0), ss += strided_sum(T.norm_part, T.n_norm_part, 2, 1);  // control points (replicated)
-  double gd = strided_sum(T.lm_part, T.n_lm_part, 4, 2), dd = strided_sum(T.lm_part, T.n_lm_part, 4, 3);
+  // The partial arrays are short (one entry per workgroup of the producing kernels): one combined pass with every load of a round
+  // issued before the first use (six separate strided sums cost six memory round trips, 8 us). Fixed order: bit-reproducible.
+  double cand = 0.0, xs = 0.0, ss = 0.0, gd = 0.0, dd = 0.0;
+  const int n_max = max(T.n_cost_part, max(T.n_lm_part, T.n_norm_part));
+  const bool with_replicated = T.rank == 0;  // control points / bias points / gravity are counted once
+  for (int i0 = threadIdx.x; i0 < n_max; i0 += 4 * kBlock) {
+    double c[4];
+    double2 la[4], lb[4], nr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * kBlock;
+      c[u] = i < T.n_cost_part ? T.cand_part[i] : 0.0;
+      const double2* lp = reinterpret_cast<const double2*>(T.lm_part) + 2 * size_t(i);
+      la[u] = i < T.n_lm_part ? lp[0] : make_double2(0.0, 0.0);  // (|x|^2, |x - x+|^2)
+      lb[u] = i < T.n_lm_part ? lp[1] : make_double2(0.0, 0.0);  // (g.step, step'D^2 step)
+      nr[u] = (with_replicated && i < T.n_norm_part) ? reinterpret_cast<const double2*>(T.norm_part)[i] : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      cand += c[u];
+      xs += la[u].x, ss += la[u].y, gd += lb[u].x, dd += lb[u].y;
+      xs += nr[u].x, ss += nr[u].y;
+    }
+  }
   cand = block_sum(cand, red), xs = block_sum(xs, red), ss = block_sum(ss, red), gd = block_sum(gd, red), dd = block_sum(dd, red);
   if (threadIdx.x == 0) {
     double* D = T.xbuf + T.xo_dec;

@@ -329,6 +329,7 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_norm_part.reserve(2 * size_t(nb_norm)));
   const int nbd = p->has_imu ? 6 * p->n_bias + 2 : 0;
   if (nbd && size_t(np) * 8 * 8 > 150 * 1024) HS_FAIL(HS_ERR_INVALID, "window too long for the LDS-resident border forward sweep");
+  if (size_t(np) * 2 * 8 > 100 * 1024) HS_FAIL(HS_ERR_INVALID, "window too long for the LDS-resident backward sweep (more than 1066 control points)");
   const int x_count1 = np * (ncb + 3) + np * nbd + nbd * nbd + nbd + 1 + p->world;
   HIP_TRY(p->d_ybuf.reserve(np));
   HIP_TRY(p->d_scale_b.reserve(nbd + 1));
@@ -596,7 +597,8 @@ int launch_factor(hs_problem* p) {
     Tables T3 = T2;
     T3.join_epoch = ++p->join_epoch;
     const BackJob j0{T.Ub, T.Ubk, T.ybuf, m + w_mid, 0, 0}, j1{p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, mB, w_mid, 1};
-    k_band_backward2<<<2, kCholThreads, 2 * size_t(T.np) * sizeof(double), s>>>(T3, j0, j1, m);
+    const size_t g_lds = size_t(6 * (T.bw - 1)) * (6 * (T.bw - 1) | 1) * sizeof(double);  // given-column block of the far sweep
+    k_band_backward2<<<2, kCholThreads, 2 * size_t(T.np) * sizeof(double) + g_lds, s>>>(T3, j0, j1, m);
     HIP_TRY(hipGetLastError());
     return HS_OK;
   }
@@ -664,6 +666,8 @@ int set_func_attributes(hs_problem* p) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_visual<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_visual<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_forward), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_backward2), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_backward), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   return HS_OK;
 }

@@ -1976,11 +1976,32 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward2(Tables T, BackJ
   double* xs = smem;          // n_all : pending rows (own) / given solution
   double* xout = smem + n_all;  // n_own : solution of the own rows (flushed to T.xsol at the end / when the middle is complete)
   __shared__ double Wl[2][24];
-  if (J.given) {  // wait for the middle solution
-    while (__hip_atomic_load(T.join_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < T.join_epoch) __builtin_amdgcn_s_sleep(8);
-  }
-  for (int rho = tid; rho < n_all; rho += nthr) xs[rho] = rho < n_own ? J.ybuf[rho] : T.xsol[J.reversed ? np - 1 - rho : rho];
   const int n_above = 6 * (bw - 1);
+  // The given block rows have no dependencies among themselves: their whole contribution to the pending rows is one
+  // (n_above x n_above) matrix-vector product. The matrix block G = U(own rows n_own - n_above .., given columns) does not depend on
+  // the other sweep, so it is brought into LDS (transposed: G[c][r], odd leading dimension) BEFORE waiting for the flag; once the
+  // middle solution is there, one pass replaces `given` sequential steps of the sweep.
+  const bool merged = J.given > 0 && 6 * J.given == n_above && n_own >= n_above;
+  const int ldg = n_above | 1;
+  double* G = smem + 2 * np;
+  for (int rho = tid; rho < n_own; rho += nthr) xs[rho] = J.ybuf[rho];
+  if (merged) {
+    const int n_g = n_above * n_above;
+    for (int e0 = tid; e0 < n_g; e0 += 8 * nthr) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * nthr, r = e / n_above, c = e - r * n_above;
+        const int rho = n_own - n_above + r, off = n_own + c - 6 * (rho / 6);  // band offset of column n_own + c in row rho
+        v[u] = (e < n_g && off < ncb) ? J.Ub[size_t(rho) * ncb + off] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * nthr, r = e / n_above, c = e - r * n_above;
+        if (e < n_g) G[c * ldg + r] = v[u];
+      }
+    }
+  }
   auto load_u = [&](int j, double* u) {
     const int rho = 6 * j - 1 - tid;
     const bool ok = j >= 0 && tid < n_above && rho >= 0 && rho < n_own;
@@ -1989,11 +2010,23 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward2(Tables T, BackJ
     for (int a = 0; a < 6; ++a) u[a] = ok ? src[a] : 0.0;
   };
   auto load_w = [&](int j) -> double { return (j >= 0 && j < J.n_rows && tid < 21) ? J.Ubk[size_t(j) * 24 + tid] : 0.0; };
-  __syncthreads();
-  const int jtop = J.n_rows + J.given - 1;
+  const int jtop = merged ? J.n_rows - 1 : J.n_rows + J.given - 1;
   double u0[6], u1[6], u2[6], u3[6], w0, w1, w2, w3;
   load_u(jtop, u0), load_u(jtop - 1, u1), load_u(jtop - 2, u2);
   w0 = load_w(jtop), w1 = load_w(jtop - 1), w2 = load_w(jtop - 2);
+  if (J.given) {  // wait for the middle solution
+    while (__hip_atomic_load(T.join_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < T.join_epoch) __builtin_amdgcn_s_sleep(8);
+    for (int rho = n_own + tid; rho < n_all; rho += nthr) xs[rho] = T.xsol[J.reversed ? np - 1 - rho : rho];
+  }
+  __syncthreads();
+  if (merged) {
+    if (tid < n_above) {
+      double acc = 0.0;
+      for (int c = 0; c < n_above; ++c) acc = fma(G[c * ldg + tid], xs[n_own + c], acc);
+      xs[n_own - n_above + tid] -= acc;
+    }
+    __syncthreads();
+  }
   // one block row of the sweep; `own` is a compile-time tag so that the hot loops below carry no extra control flow
   auto step = [&](int j, auto own_tag) {
     constexpr bool own = decltype(own_tag)::value;
@@ -2029,7 +2062,7 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward2(Tables T, BackJ
     for (int a = 0; a < 6; ++a) u0[a] = u1[a], u1[a] = u2[a], u2[a] = u3[a];
     w0 = w1, w1 = w2, w2 = w3;
   };
-  for (int j = jtop; j >= J.n_rows; --j) step(j, std::false_type{});
+  for (int j = jtop; j >= J.n_rows; --j) step(j, std::false_type{});  // (not merged: given rows one by one)
   const int j_pub = (blockIdx.x == 0 && m_mid >= 0) ? m_mid : 0;  // block 0 publishes the middle solution after block row m_mid
   for (int j = J.n_rows - 1; j >= j_pub; --j) step(j, std::true_type{});
   if (blockIdx.x == 0 && m_mid >= 0) {

@@ -163,3 +163,23 @@ def test_band_width_limits(hip, oracle):
     with ha.Problem(w, lib=hip) as g:
         with pytest.raises(RuntimeError, match="span too many control points"):
             g.solve(2)
+
+
+def test_long_window(hip, monkeypatch):
+    """900 control points: the backward sweeps keep the right-hand side in LDS (> 64 KiB here). The two-ended and the one-ended
+    factorisation / sweep must agree; windows beyond the LDS budget (> 1066 control points) are rejected with a message."""
+    w = synthetic.small_visual(order=4, n_cp=900, n_landmarks=2700, obs_pairs=2, seed=43, with_priors=900)
+    sols = []
+    for flags in ("0", "2048"):  # 2048: one-ended (measurement switch of the library)
+        monkeypatch.setenv("HS_DEBUG_FLAGS", flags)
+        with ha.Problem(w, lib=hip) as g:
+            s = g.solve(3)
+            assert s["num_iterations"] == 3 and np.isfinite(s["final_cost"]) and s["final_cost"] < 0.5 * s["initial_cost"]
+            sols.append((s["final_cost"], g.control_points(), g.landmarks()))
+    assert abs(sols[0][0] - sols[1][0]) <= 1e-8 * sols[1][0]
+    assert rel(sols[0][1], sols[1][1]) < 1e-7 and rel(sols[0][2], sols[1][2]) < 1e-7
+    monkeypatch.setenv("HS_DEBUG_FLAGS", "0")
+    w = synthetic.small_visual(order=4, n_cp=1100, n_landmarks=200, obs_pairs=2, seed=44)
+    with ha.Problem(w, lib=hip) as g:
+        with pytest.raises(RuntimeError, match="window too long"):
+            g.solve(1)

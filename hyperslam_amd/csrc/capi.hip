@@ -158,8 +158,10 @@ int prepare(hs_problem* p) {
   if (!build_visual_structure(in, &p->vs, &p->err)) return HS_ERR_INVALID;
   p->vs.bw = std::max(p->vs.bw, p->min_bw);
   const VisualStructure& vs = p->vs;
-  if (6 * vs.bw > kBlock || (size_t(36) * (6 * vs.bw + 2) + size_t(6) * p->n_cp + 48) * 8 > size_t(p->chol_lds_max) || size_t(12) * p->n_cp * 8 > 60 * 1024)
+  if (6 * vs.bw > kBlock || (size_t(36) * (6 * vs.bw + 2) + size_t(6) * p->n_cp + 48) * 8 > size_t(p->chol_lds_max))
     HS_FAIL(HS_ERR_INVALID, "landmark tracks span too many control points for the LDS-resident banded factorisation");
+  if (p->n_cp > 1024)  // 64 KiB of control points staged per workgroup; 96 KiB right-hand side + 49 KiB junction block in the backward sweep
+    HS_FAIL(HS_ERR_INVALID, "window too long for the LDS-resident control-point table and backward sweep (more than 1024 control points)");
   const int n_vis = n_px + n_br;
 
   // ---- visual tables (landmark-major) ----
@@ -329,7 +331,6 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_norm_part.reserve(2 * size_t(nb_norm)));
   const int nbd = p->has_imu ? 6 * p->n_bias + 2 : 0;
   if (nbd && size_t(np) * 8 * 8 > 150 * 1024) HS_FAIL(HS_ERR_INVALID, "window too long for the LDS-resident border forward sweep");
-  if (size_t(np) * 2 * 8 > 100 * 1024) HS_FAIL(HS_ERR_INVALID, "window too long for the LDS-resident backward sweep (more than 1066 control points)");
   const int x_count1 = np * (ncb + 3) + np * nbd + nbd * nbd + nbd + 1 + p->world;
   HIP_TRY(p->d_ybuf.reserve(np));
   HIP_TRY(p->d_scale_b.reserve(nbd + 1));

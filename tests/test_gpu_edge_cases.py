@@ -167,7 +167,7 @@ def test_band_width_limits(hip, oracle):
 
 def test_long_window(hip, monkeypatch):
     """900 control points: the backward sweeps keep the right-hand side in LDS (> 64 KiB here). The two-ended and the one-ended
-    factorisation / sweep must agree; windows beyond the LDS budget (> 1066 control points) are rejected with a message."""
+    factorisation / sweep must agree; windows beyond the LDS budget (> 1024 control points) are rejected with a message."""
     w = synthetic.small_visual(order=4, n_cp=900, n_landmarks=2700, obs_pairs=2, seed=43, with_priors=900)
     sols = []
     for flags in ("0", "2048"):  # 2048: one-ended (measurement switch of the library)

@@ -7,6 +7,7 @@
 //   k_seg_gram / k_group_gram / k_assemble   reduced system from per-segment J'J and per-landmark-group Y-hat Y-hat' partials
 //   k_border_pb / k_border_bb                border blocks of the inertial factors (bias splines, gravity)
 //   k_pack_exchange -> [all-reduce] -> k_finalize_reduced / _border -> k_cost_reduce     scaling, damping, gradient test
+//     (single shard without border unknowns: packing + bookkeeping are an extra workgroup of k_finalize_reduced, one launch)
 //   k_band_factor_la (look-ahead, one or two ends) | k_band_factor (bw <= 22) | k_band_factor_wide (bw <= 42)   S = U'U, y
 //   k_border_forward / _schur / _solve / _apply                                         bordered part of the solve
 //   k_band_backward | k_band_backward2       U x = y, step outputs

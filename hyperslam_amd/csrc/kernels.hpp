@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(kBlock) k_cost_prior(Tables T, const double* c
 /// this lane's W rows, forms V = S_l H_ll S_l + D_l^2 = L L', stores L, y-hat, the scaled gradient and the Y-hat rows.
 template <int PS>
 HSD void landmark_finish(const Tables& T, int dl, int lane, bool active, bool fresh, double radius, const double* sl_old, int yoff, int rows,
-                         const double* h, const double* b, double (*w)[3]) {
+                         const double* h, const double* b, double (*w)[3], double* y_lds = nullptr, double* yh_lds = nullptr, int rows_lds = 0) {
   double sl[3];
   if (fresh) {
     sl[0] = 1.0 / (1.0 + sqrt(h[0])), sl[1] = 1.0 / (1.0 + sqrt(h[3])), sl[2] = 1.0 / (1.0 + sqrt(h[5]));
@@ -302,18 +302,22 @@ HSD void landmark_finish(const Tables& T, int dl, int lane, bool active, bool fr
     // gradient max norm: per-landmark value, max-reduced by k_pack_exchange (thousands of atomics on one word would
     // serialise at ~12 ns each and dominate this pass)
     T.lm_gmax[dl] = active ? fmax(fabs(b[0]), fmax(fabs(b[1]), fabs(b[2]))) : 0.0;
+    if (yh_lds) yh_lds[0] = active ? y0 : 0.0, yh_lds[1] = active ? y1 : 0.0, yh_lds[2] = active ? y2 : 0.0;
   }
-  // W rows -> Y-hat rows
+  // W rows -> Y-hat rows (HBM copy for the back-substitution; optional LDS copy, zero past the landmark's rows, for a fused consumer)
   double* Y = T.Y + yoff;
 #pragma unroll
   for (int ps = 0; ps < PS; ++ps) {
     const int rho = lane + 64 * ps;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     if (rho < rows) {
       const double w0 = w[ps][0] * sl[0], w1 = w[ps][1] * sl[1], w2 = w[ps][2] * sl[2];
       // y L' = w  (forward substitution on the columns of L')
-      const double a0 = w0 / l00, a1 = (w1 - a0 * l10) / l11, a2 = (w2 - a0 * l20 - a1 * l21) / l22;
-      Y[3 * rho] = active ? a0 : 0.0, Y[3 * rho + 1] = active ? a1 : 0.0, Y[3 * rho + 2] = active ? a2 : 0.0;
+      a0 = w0 / l00, a1 = (w1 - a0 * l10) / l11, a2 = (w2 - a0 * l20 - a1 * l21) / l22;
+      if (!active) a0 = a1 = a2 = 0.0;
+      Y[3 * rho] = a0, Y[3 * rho + 1] = a1, Y[3 * rho + 2] = a2;
     }
+    if (y_lds && rho < rows_lds) y_lds[3 * rho] = a0, y_lds[3 * rho + 1] = a1, y_lds[3 * rho + 2] = a2;
   }
 }
 
@@ -324,12 +328,8 @@ HSD void landmark_finish(const Tables& T, int dl, int lane, bool active, bool fr
 // PS = 64-row passes a lane owns (rows of W = 6 * control points the landmark touches <= 64 * PS).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int K, int PS>
-__global__ void __launch_bounds__(kBlock) k_landmark(Tables T) {
-  if (T.st->done) return;
+HSD void landmark_eliminate(const Tables& T, int dl, int lane, double* y_lds = nullptr, double* yh_lds = nullptr, int rows_lds = 0) {
   constexpr int REC = 8 + 12 * K;
-  const int lane = threadIdx.x & 63;
-  const int dl = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (dl >= T.n_lm) return;
   const int q0 = T.lm_ptr[dl], q1 = T.lm_ptr[dl + 1];
   const int c_first = T.lm_cfirst[dl], rows = 6 * T.lm_ncp[dl];
   // One pass over the landmark's residuals: lane q of a 64-chunk fetches (first control point, record slot) of residual q
@@ -380,7 +380,15 @@ __global__ void __launch_bounds__(kBlock) k_landmark(Tables T) {
   const bool fresh = !T.st->scaling_ready;
   double sl_old[3] = {1.0, 1.0, 1.0};
   if (!fresh) sl_old[0] = T.lm_scale[3 * dl], sl_old[1] = T.lm_scale[3 * dl + 1], sl_old[2] = T.lm_scale[3 * dl + 2];
-  landmark_finish<PS>(T, dl, lane, (q1 > q0) && !T.lm_const[dl], fresh, T.st->radius, sl_old, T.lm_yoff[dl], rows, h, b, w);
+  landmark_finish<PS>(T, dl, lane, (q1 > q0) && !T.lm_const[dl], fresh, T.st->radius, sl_old, T.lm_yoff[dl], rows, h, b, w, y_lds, yh_lds, rows_lds);
+}
+
+template <int K, int PS>
+__global__ void __launch_bounds__(kBlock) k_landmark(Tables T) {
+  if (T.st->done) return;
+  const int dl = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (dl >= T.n_lm) return;
+  landmark_eliminate<K, PS>(T, dl, threadIdx.x & 63);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -504,7 +512,7 @@ HSD int group_tile_index(int rb, int cb, int bw) { return rb * bw - rb * (rb - 1
 constexpr int kGroupBatch = 16;  // landmarks staged in LDS per round (host caps it so that the stage fits 48 KB)
 
 template <int NT>  // tiles per thread: NT == 1: two landmark streams of 128 lanes (bw <= 15); NT > 1: one stream, bw (bw + 1) / 2 <= NT * kBlock
-__global__ void __launch_bounds__(kBlock) k_group_gram(Tables T, int batch) {
+__global__ void __launch_bounds__(kBlock, NT == 1 ? 3 : 1) k_group_gram(Tables T, int batch) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   __shared__ int m_ncp[kBlock], m_off[kBlock];
   if (T.st->done) return;
@@ -573,21 +581,30 @@ __global__ void __launch_bounds__(kBlock) k_group_gram(Tables T, int batch) {
 #pragma unroll
         for (int m = 0; m < NT; ++m) {
           if (!t_ok[m] || t_cb[m] >= ncp) continue;
-          double A[18], B[18];
+          double B[18];
 #pragma unroll
           for (int e = 0; e < 18; e += 2) {
-            const double2 va = *reinterpret_cast<const double2*>(Yb + 18 * t_rb[m] + e), vb = *reinterpret_cast<const double2*>(Yb + 18 * t_cb[m] + e);
-            A[e] = va.x, A[e + 1] = va.y, B[e] = vb.x, B[e + 1] = vb.y;
+            const double2 vb = *reinterpret_cast<const double2*>(Yb + 18 * t_cb[m] + e);
+            B[e] = vb.x, B[e + 1] = vb.y;
           }
+          const bool diag = t_rb[m] == t_cb[m];
+          const double y0 = yh[4 * b], y1 = yh[4 * b + 1], y2 = yh[4 * b + 2];
 #pragma unroll
-          for (int r = 0; r < 6; ++r)
+          for (int rp = 0; rp < 3; ++rp) {  // two rows of the A operand at a time: 148 instead of 190 registers, three workgroups per CU
+            double A[6];
 #pragma unroll
-            for (int c = 0; c < 6; ++c)
-              acc[m][6 * r + c] = fma(-A[3 * r + 2], B[3 * c + 2], fma(-A[3 * r + 1], B[3 * c + 1], fma(-A[3 * r], B[3 * c], acc[m][6 * r + c])));
-          if (t_rb[m] == t_cb[m]) {
-            const double y0 = yh[4 * b], y1 = yh[4 * b + 1], y2 = yh[4 * b + 2];
+            for (int e = 0; e < 6; e += 2) {
+              const double2 va = *reinterpret_cast<const double2*>(Yb + 18 * t_rb[m] + 6 * rp + e);
+              A[e] = va.x, A[e + 1] = va.y;
+            }
 #pragma unroll
-            for (int r = 0; r < 6; ++r) qacc[m][r] = fma(-A[3 * r + 2], y2, fma(-A[3 * r + 1], y1, fma(-A[3 * r], y0, qacc[m][r])));
+            for (int rr = 0; rr < 2; ++rr) {
+              const int r = 2 * rp + rr;
+#pragma unroll
+              for (int c = 0; c < 6; ++c)
+                acc[m][6 * r + c] = fma(-A[3 * rr + 2], B[3 * c + 2], fma(-A[3 * rr + 1], B[3 * c + 1], fma(-A[3 * rr], B[3 * c], acc[m][6 * r + c])));
+              if (diag) qacc[m][r] = fma(-A[3 * rr + 2], y2, fma(-A[3 * rr + 1], y1, fma(-A[3 * rr], y0, qacc[m][r])));
+            }
           }
         }
       }

@@ -539,9 +539,9 @@ int launch_build(hs_problem* p) {
   if (T.n_lm) {
     const int grid = (T.n_lm + kBlock / 64 - 1) / (kBlock / 64);
     if (6 * T.bw <= 128)
-      k_landmark<K, 2><<<grid, kBlock, 0, s>>>(T);
+      k_landmark<K, 2, 2><<<grid, kBlock, 0, s>>>(T);
     else  // long feature tracks (6 * bw <= kBlock is checked in prepare())
-      k_landmark<K, 4><<<grid, kBlock, 0, s>>>(T);
+      k_landmark<K, 4, 1><<<grid, kBlock, 0, s>>>(T);
   }
   if (T.n_lm && p->n_group_wg) {
     const int ntile = T.bw * (T.bw + 1) / 2;

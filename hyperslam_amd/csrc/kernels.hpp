@@ -327,68 +327,86 @@ HSD void landmark_finish(const Tables& T, int dl, int lane, bool active, bool fr
 // y-hat = L^-1 S_l b_l.  Jacobi scaling S_l is fixed at iteration 0 (TrustRegionMinimizer, jacobi_scaling = true).
 // PS = 64-row passes a lane owns (rows of W = 6 * control points the landmark touches <= 64 * PS).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int K, int PS>
+template <int K, int PS, int U>
 HSD void landmark_eliminate(const Tables& T, int dl, int lane, double* y_lds = nullptr, double* yh_lds = nullptr, int rows_lds = 0) {
   constexpr int REC = 8 + 12 * K;
   const int q0 = T.lm_ptr[dl], q1 = T.lm_ptr[dl + 1];
   const int c_first = T.lm_cfirst[dl], rows = 6 * T.lm_ncp[dl];
+  // operands of the finishing step: requested up front, they do not depend on the records
+  const bool fresh = !T.st->scaling_ready;
+  const double radius = T.st->radius;
+  const bool is_const = T.lm_const[dl];
+  const int yoff = T.lm_yoff[dl];
+  double sl_old[3] = {1.0, 1.0, 1.0};
+  if (!fresh) sl_old[0] = T.lm_scale[3 * dl], sl_old[1] = T.lm_scale[3 * dl + 1], sl_old[2] = T.lm_scale[3 * dl + 2];
   // One pass over the landmark's residuals: lane q of a 64-chunk fetches (first control point, record slot) of residual q
   // once; the chunk is then walked with register broadcasts, every lane accumulating its own W row(s) (rho = lane, lane + 64)
-  // and lane q the H_ll / b_l terms of residual q.
+  // and lane q the H_ll / b_l terms of residual q. All loads are unconditional on clamped indices and masked afterwards:
+  // straight-line code, so the loads of U records (all 64-row passes) are in flight together instead of one round trip per
+  // record and pass. (The kernel is nevertheless bound by instruction issue, not by this chain: U = 1, 2, 4 and the branchy
+  // original all take 17.3 us at 5 000 landmarks x 10 records — only 6K of 64 lanes carry a W row of a given record.)
   double h[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
   double w[PS][3];
 #pragma unroll
   for (int ps = 0; ps < PS; ++ps) w[ps][0] = w[ps][1] = w[ps][2] = 0.0;
   for (int base = q0; base < q1; base += 64) {
-    const int myq = base + lane;
-    const int my_first = myq < q1 ? T.v_first[myq] : 0, my_pos = myq < q1 ? T.v_pos[myq] : 0;
-    if (myq < q1) {
-      const double* rec = T.v_rec + size_t(my_pos) * REC;
+    const int myq = min(base + lane, q1 - 1);
+    const bool mine = base + lane < q1;
+    const int my_first = T.v_first[myq], my_pos = T.v_pos[myq];
+    const double* myrec = T.v_rec + size_t(my_pos) * REC;
+    double own[8];
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const double rr = rec[r], j0 = rec[2 + 3 * r], j1 = rec[3 + 3 * r], j2 = rec[4 + 3 * r];
-        h[0] = fma(j0, j0, h[0]), h[1] = fma(j0, j1, h[1]), h[2] = fma(j0, j2, h[2]);
-        h[3] = fma(j1, j1, h[3]), h[4] = fma(j1, j2, h[4]), h[5] = fma(j2, j2, h[5]);
-        b[0] = fma(j0, rr, b[0]), b[1] = fma(j1, rr, b[1]), b[2] = fma(j2, rr, b[2]);
-      }
-    }
+    for (int e = 0; e < 8; ++e) own[e] = myrec[e];
     const int cnt = min(64, q1 - base);
-    // (a predicated batch of 5 / 10 records per load round with lane broadcasts of the landmark-side Jacobian was measured slower,
-    // 21.9 / 23 us vs 17.5 us: its registers cost the fifth resident wave per SIMD that keeps all 5 000 landmarks in flight)
-#pragma unroll 4
-    for (int t = 0; t < cnt; ++t) {
-      const int ft = __builtin_amdgcn_readlane(my_first, t), pt = __builtin_amdgcn_readlane(my_pos, t);  // wave-uniform
-      const double* rec = T.v_rec + size_t(pt) * REC;
-      const int off = 6 * (ft - c_first);
+    for (int t0 = 0; t0 < cnt; t0 += U) {
+      double ja[U][PS], jb[U][PS], jl[U][6];
 #pragma unroll
-      for (int ps = 0; ps < PS; ++ps) {
-        const int c = lane + 64 * ps - off;
-        if (c >= 0 && c < 6 * K && lane + 64 * ps < rows) {
-          const double ja = rec[8 + c], jb = rec[8 + 6 * K + c];
-          w[ps][0] = fma(ja, rec[2], fma(jb, rec[5], w[ps][0]));
-          w[ps][1] = fma(ja, rec[3], fma(jb, rec[6], w[ps][1]));
-          w[ps][2] = fma(ja, rec[4], fma(jb, rec[7], w[ps][2]));
+      for (int u = 0; u < U; ++u) {
+        const int t = min(t0 + u, cnt - 1);
+        const int ft = __builtin_amdgcn_readlane(my_first, t), pt = __builtin_amdgcn_readlane(my_pos, t);  // wave-uniform
+        const double* rec = T.v_rec + size_t(pt) * REC;
+        const int off = 6 * (ft - c_first);
+#pragma unroll
+        for (int e = 0; e < 6; ++e) jl[u][e] = rec[2 + e];
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps) {
+          const int c = lane + 64 * ps - off;
+          const bool ok = t0 + u < cnt && c >= 0 && c < 6 * K && lane + 64 * ps < rows;
+          const int cc = ok ? c : 0;
+          const double va = rec[8 + cc], vb = rec[8 + 6 * K + cc];
+          ja[u][ps] = ok ? va : 0.0, jb[u][ps] = ok ? vb : 0.0;
         }
       }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int ps = 0; ps < PS; ++ps) {  // masked slots add exact zeros
+          w[ps][0] = fma(ja[u][ps], jl[u][0], fma(jb[u][ps], jl[u][3], w[ps][0]));
+          w[ps][1] = fma(ja[u][ps], jl[u][1], fma(jb[u][ps], jl[u][4], w[ps][1]));
+          w[ps][2] = fma(ja[u][ps], jl[u][2], fma(jb[u][ps], jl[u][5], w[ps][2]));
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const double rr = mine ? own[r] : 0.0, j0 = mine ? own[2 + 3 * r] : 0.0, j1 = mine ? own[3 + 3 * r] : 0.0, j2 = mine ? own[4 + 3 * r] : 0.0;
+      h[0] = fma(j0, j0, h[0]), h[1] = fma(j0, j1, h[1]), h[2] = fma(j0, j2, h[2]);
+      h[3] = fma(j1, j1, h[3]), h[4] = fma(j1, j2, h[4]), h[5] = fma(j2, j2, h[5]);
+      b[0] = fma(j0, rr, b[0]), b[1] = fma(j1, rr, b[1]), b[2] = fma(j2, rr, b[2]);
     }
   }
 #pragma unroll
   for (int i = 0; i < 6; ++i) h[i] = wave_sum(h[i]);
 #pragma unroll
   for (int i = 0; i < 3; ++i) b[i] = wave_sum(b[i]);
-
-  const bool fresh = !T.st->scaling_ready;
-  double sl_old[3] = {1.0, 1.0, 1.0};
-  if (!fresh) sl_old[0] = T.lm_scale[3 * dl], sl_old[1] = T.lm_scale[3 * dl + 1], sl_old[2] = T.lm_scale[3 * dl + 2];
-  landmark_finish<PS>(T, dl, lane, (q1 > q0) && !T.lm_const[dl], fresh, T.st->radius, sl_old, T.lm_yoff[dl], rows, h, b, w, y_lds, yh_lds, rows_lds);
+  landmark_finish<PS>(T, dl, lane, (q1 > q0) && !is_const, fresh, radius, sl_old, yoff, rows, h, b, w, y_lds, yh_lds, rows_lds);
 }
 
-template <int K, int PS>
+template <int K, int PS, int U>
 __global__ void __launch_bounds__(kBlock) k_landmark(Tables T) {
   if (T.st->done) return;
   const int dl = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (dl >= T.n_lm) return;
-  landmark_eliminate<K, PS>(T, dl, threadIdx.x & 63);
+  landmark_eliminate<K, PS, U>(T, dl, threadIdx.x & 63);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -663,43 +681,63 @@ __global__ void __launch_bounds__(kAsmThreads) k_assemble(Tables T) {
   double va = 0.0, vb = 0.0;  // J'J part / Schur part
   if (sl < nsl) {
     const int kk = c / 6, cc = c % 6;
-    // ---- segment partials: the workgroups of segments f0 .. f1 are contiguous in the work list
-    const bool a_live = c < ncb ? kk < K : c == ncb;
-    if (a_live && f1 >= f0) {
-      const int p_lo = T.sw_ptr[f0], np_ = T.sw_ptr[f1 + 1] - p_lo;
-      for (int p0 = sl; p0 < np_; p0 += kAsmU * nsl) {
-        double v[kAsmU];
-#pragma unroll
-        for (int u = 0; u < kAsmU; ++u) {
-          const int p = p0 + u * nsl;
-          const int w = p_lo + (p < np_ ? p : 0), bi = i - T.sw_seg[w];
-          const bool ok = p < np_ && (c == ncb || bi + kk < K);
-          const size_t off = size_t(w) * pstride + (c == ncb ? NCA * NCA + 6 * bi + a : (6 * bi + a) * NCA + 6 * bi + c);
-          v[u] = ok ? T.segP[off] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < kAsmU; ++u) va += v[u];
-      }
-    }
-    // ---- landmark-group partials: the workgroups of groups c0 .. i are contiguous in the work list
+    // segment partials: the workgroups of segments f0 .. f1 are contiguous in the work list; landmark-group partials: those of
+    // groups c0 .. i. A lane's sources are p = sl, sl + nsl, ... The first kAsmU segment sources and 2 kAsmU group sources are
+    // fetched in two rounds (all work-list entries, then all partial values: two memory round trips instead of one pair per
+    // batch); the sums run in the same fixed order as a plain loop over p.
+    const bool a_live = (c < ncb ? kk < K : c == ncb) && f1 >= f0;
     const bool b_live = T.n_lm > 0 && (c < ncb || c == ncb + 1);
-    if (b_live) {
-      const int q_lo = T.gw_ptr[c0], nq = T.gw_ptr[i + 1] - q_lo;
-      for (int q0 = sl; q0 < nq; q0 += kAsmU * nsl) {
-        double v[kAsmU];
+    const int p_lo = a_live ? T.sw_ptr[f0] : 0, np_ = a_live ? T.sw_ptr[f1 + 1] - p_lo : 0;
+    const int q_lo = b_live ? T.gw_ptr[c0] : 0, nq = b_live ? T.gw_ptr[i + 1] - q_lo : 0;
+    // (plain macros, not lambdas: a by-reference closure kept these operands in scratch memory)
+#define HS_SEG_VALUE(p, seg) \
+  ((p) < np_ && (c == ncb || i - (seg) + kk < K) \
+       ? T.segP[(p_lo + (p)) * int(pstride) + (c == ncb ? NCA * NCA + 6 * (i - (seg)) + a : (6 * (i - (seg)) + a) * NCA + 6 * (i - (seg)) + c)] \
+       : 0.0)
+#define HS_GRP_VALUE(q, cf) \
+  ((q) < nq && (c > ncb || i - (cf) + kk < bw) \
+       ? T.grpQ[(q_lo + (q)) * int(qstride) + \
+                (c > ncb ? ntile * 36 + 6 * (i - (cf)) + a : group_tile_index(i - (cf), i - (cf) + kk, bw) * 36 + 6 * a + cc)] \
+       : 0.0)
+    int si[kAsmU], gi[2 * kAsmU];
 #pragma unroll
-        for (int u = 0; u < kAsmU; ++u) {
-          const int q = q0 + u * nsl;
-          const int w = q_lo + (q < nq ? q : 0), rb = i - T.gw_cf[w];
-          const bool ok = q < nq && (c > ncb || rb + kk < bw);
-          const size_t off = size_t(w) * qstride +
-                             (c > ncb ? size_t(ntile) * 36 + 6 * rb + a : size_t(group_tile_index(rb, ok ? rb + kk : rb, bw)) * 36 + 6 * a + cc);
-          v[u] = ok ? T.grpQ[off] : 0.0;
-        }
+    for (int u = 0; u < kAsmU; ++u) si[u] = sl + u * nsl < np_ ? T.sw_seg[p_lo + sl + u * nsl] : 0;
 #pragma unroll
-        for (int u = 0; u < kAsmU; ++u) vb += v[u];
+    for (int u = 0; u < 2 * kAsmU; ++u) gi[u] = sl + u * nsl < nq ? T.gw_cf[q_lo + sl + u * nsl] : 0;
+    double sv[kAsmU], gv[2 * kAsmU];
+#pragma unroll
+    for (int u = 0; u < kAsmU; ++u) sv[u] = HS_SEG_VALUE(sl + u * nsl, si[u]);
+#pragma unroll
+    for (int u = 0; u < 2 * kAsmU; ++u) gv[u] = HS_GRP_VALUE(sl + u * nsl, gi[u]);
+#pragma unroll
+    for (int u = 0; u < kAsmU; ++u) va += sv[u];
+#pragma unroll
+    for (int u = 0; u < 2 * kAsmU; ++u) vb += gv[u];
+    // the rest (segments / groups split into unusually many workgroups)
+    for (int p0 = sl + kAsmU * nsl; p0 < np_; p0 += kAsmU * nsl) {
+      double v[kAsmU];
+#pragma unroll
+      for (int u = 0; u < kAsmU; ++u) {
+        const int p = p0 + u * nsl;
+        const int seg = p < np_ ? T.sw_seg[p_lo + p] : 0;
+        v[u] = HS_SEG_VALUE(p, seg);
       }
+#pragma unroll
+      for (int u = 0; u < kAsmU; ++u) va += v[u];
     }
+    for (int q0 = sl + 2 * kAsmU * nsl; q0 < nq; q0 += kAsmU * nsl) {
+      double v[kAsmU];
+#pragma unroll
+      for (int u = 0; u < kAsmU; ++u) {
+        const int q = q0 + u * nsl;
+        const int cf = q < nq ? T.gw_cf[q_lo + q] : 0;
+        v[u] = HS_GRP_VALUE(q, cf);
+      }
+#pragma unroll
+      for (int u = 0; u < kAsmU; ++u) vb += v[u];
+    }
+#undef HS_SEG_VALUE
+#undef HS_GRP_VALUE
   }
   part[0][tid] = va, part[1][tid] = vb;
   __syncthreads();

@@ -110,10 +110,16 @@ def cpu_worker(lib_path, start):
     print(json.dumps({"end": time.time(), "iters": s["num_iterations"], "late": int(late)}), flush=True)
 
 
+def _newest(pattern):
+    """Committed profile files in natural order (r01_v11 after r01_v7)."""
+    import glob
+    import re
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/), or None."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+    files = _newest("r*_pmc_hbm_traffic.json")
     try:
         with open(files[-1]) as f:
             k = json.load(f)["kernels"][kernel]
@@ -125,8 +131,7 @@ def pmc_traffic(kernel):
 def rocprof_kernel_ms(kernel_prefix):
     """Average duration of the kernel in the committed rocprofv3 --kernel-trace --stats summary of this command, or None."""
     import csv
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_stats.csv")))
+    files = _newest("r*_bench_kernel_stats.csv")
     if not files:
         return None
     try:

@@ -381,10 +381,12 @@ int prepare(hs_problem* p) {
     sw_seg.push_back(0);
     HIP_TRY(p->d_sw_ptr.upload(sw_ptr, s));
     HIP_TRY(p->d_sw_seg.upload(sw_seg, s));
-    // k_group_gram work list: ~8 landmarks per workgroup
+    // k_group_gram work list: <= 12 landmarks per workgroup (measured at configs[1]: 8 / 12 / 16 / 24 / 32 per workgroup give a
+    // Schur stage of 71.2 / 65.8 / 66.5 / 68.1 / 70.9 us: fewer, larger partials for k_assemble against less parallelism)
+    const int per_wg = 12;
     std::vector<int> gw_ptr(p->n_cp + 1, 0), gw_cf;
     for (int c = 0; c < p->n_cp; ++c) {
-      const int cnt = vs.cf_ptr[c + 1] - vs.cf_ptr[c], nw = (cnt + 7) / 8;
+      const int cnt = vs.cf_ptr[c + 1] - vs.cf_ptr[c], nw = (cnt + per_wg - 1) / per_wg;
       gw_ptr[c + 1] = gw_ptr[c] + nw;
       for (int w = 0; w < nw; ++w) gw_cf.push_back(c);
     }

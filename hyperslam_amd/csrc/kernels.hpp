@@ -285,14 +285,22 @@ HSD void landmark_finish(const Tables& T, int dl, int lane, bool active, bool fr
   // V = S H S + clamp(diag)/radius
   double v00 = sl[0] * sl[0] * h[0], v01 = sl[0] * sl[1] * h[1], v02 = sl[0] * sl[2] * h[2];
   double v11 = sl[1] * sl[1] * h[3], v12 = sl[1] * sl[2] * h[4], v22 = sl[2] * sl[2] * h[5];
-  const double d0 = fmin(fmax(v00, 1e-6), 1e32) / radius, d1 = fmin(fmax(v11, 1e-6), 1e32) / radius, d2 = fmin(fmax(v22, 1e-6), 1e32) / radius;
+  const double inv_radius = 1.0 / radius;
+  const double d0 = fmin(fmax(v00, 1e-6), 1e32) * inv_radius, d1 = fmin(fmax(v11, 1e-6), 1e32) * inv_radius, d2 = fmin(fmax(v22, 1e-6), 1e32) * inv_radius;
   v00 += d0, v11 += d1, v22 += d2;
-  // Cholesky V = L L'
-  const double l00 = sqrt(v00), l10 = v01 / l00, l20 = v02 / l00;
-  const double l11 = sqrt(v11 - l10 * l10), l21 = (v12 - l20 * l10) / l11;
-  const double l22 = sqrt(v22 - l20 * l20 - l21 * l21);
+  // Cholesky V = L L' with reciprocal pivots: every lane runs this redundantly, and a double-precision divide or square root
+  // costs ~35 instructions, so the 3x3 factor and the row solves below use 1 / l_ii from the hardware rsq estimate + one
+  // third-order correction (error ~ e^3, full double accuracy) and multiply.
+  auto rsqrt_refined = [](double d) {
+    const double y = __builtin_amdgcn_rsq(d);
+    const double e = fma(-d * y, y, 1.0);
+    return fma(y * e, fma(0.375, e, 0.5), y);
+  };
+  const double i00 = rsqrt_refined(v00), l00 = v00 * i00, l10 = v01 * i00, l20 = v02 * i00;
+  const double p11 = v11 - l10 * l10, i11 = rsqrt_refined(p11), l11 = p11 * i11, l21 = (v12 - l20 * l10) * i11;
+  const double p22 = v22 - l20 * l20 - l21 * l21, i22 = rsqrt_refined(p22), l22 = p22 * i22;
   const double sb0 = sl[0] * b[0], sb1 = sl[1] * b[1], sb2 = sl[2] * b[2];
-  const double y0 = sb0 / l00, y1 = (sb1 - l10 * y0) / l11, y2 = (sb2 - l20 * y0 - l21 * y1) / l22;
+  const double y0 = sb0 * i00, y1 = (sb1 - l10 * y0) * i11, y2 = (sb2 - l20 * y0 - l21 * y1) * i22;
   if (lane == 0) {
     double* L = T.lm_L + 6 * dl;
     L[0] = l00, L[1] = l10, L[2] = l11, L[3] = l20, L[4] = l21, L[5] = l22;
@@ -313,7 +321,7 @@ HSD void landmark_finish(const Tables& T, int dl, int lane, bool active, bool fr
     if (rho < rows) {
       const double w0 = w[ps][0] * sl[0], w1 = w[ps][1] * sl[1], w2 = w[ps][2] * sl[2];
       // y L' = w  (forward substitution on the columns of L')
-      a0 = w0 / l00, a1 = (w1 - a0 * l10) / l11, a2 = (w2 - a0 * l20 - a1 * l21) / l22;
+      a0 = w0 * i00, a1 = (w1 - a0 * l10) * i11, a2 = (w2 - a0 * l20 - a1 * l21) * i22;
       if (!active) a0 = a1 = a2 = 0.0;
       Y[3 * rho] = a0, Y[3 * rho + 1] = a1, Y[3 * rho + 2] = a2;
     }

@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(kBlock) k_cost_prior(Tables T, const double* c
 /// this lane's W rows, forms V = S_l H_ll S_l + D_l^2 = L L', stores L, y-hat, the scaled gradient and the Y-hat rows.
 template <int PS>
 HSD void landmark_finish(const Tables& T, int dl, int lane, bool active, bool fresh, double radius, const double* sl_old, int yoff, int rows,
-                         const double* h, const double* b, double (*w)[3], double* y_lds = nullptr, double* yh_lds = nullptr, int rows_lds = 0) {
+                         const double* h, const double* b, double (*w)[3]) {
   double sl[3];
   if (fresh) {
     sl[0] = 1.0 / (1.0 + sqrt(h[0])), sl[1] = 1.0 / (1.0 + sqrt(h[3])), sl[2] = 1.0 / (1.0 + sqrt(h[5]));
@@ -310,9 +310,8 @@ HSD void landmark_finish(const Tables& T, int dl, int lane, bool active, bool fr
     // gradient max norm: per-landmark value, max-reduced by k_pack_exchange (thousands of atomics on one word would
     // serialise at ~12 ns each and dominate this pass)
     T.lm_gmax[dl] = active ? fmax(fabs(b[0]), fmax(fabs(b[1]), fabs(b[2]))) : 0.0;
-    if (yh_lds) yh_lds[0] = active ? y0 : 0.0, yh_lds[1] = active ? y1 : 0.0, yh_lds[2] = active ? y2 : 0.0;
   }
-  // W rows -> Y-hat rows (HBM copy for the back-substitution; optional LDS copy, zero past the landmark's rows, for a fused consumer)
+  // W rows -> Y-hat rows
   double* Y = T.Y + yoff;
 #pragma unroll
   for (int ps = 0; ps < PS; ++ps) {
@@ -325,7 +324,6 @@ HSD void landmark_finish(const Tables& T, int dl, int lane, bool active, bool fr
       if (!active) a0 = a1 = a2 = 0.0;
       Y[3 * rho] = a0, Y[3 * rho + 1] = a1, Y[3 * rho + 2] = a2;
     }
-    if (y_lds && rho < rows_lds) y_lds[3 * rho] = a0, y_lds[3 * rho + 1] = a1, y_lds[3 * rho + 2] = a2;
   }
 }
 
@@ -336,7 +334,7 @@ HSD void landmark_finish(const Tables& T, int dl, int lane, bool active, bool fr
 // PS = 64-row passes a lane owns (rows of W = 6 * control points the landmark touches <= 64 * PS).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int K, int PS, int U>
-HSD void landmark_eliminate(const Tables& T, int dl, int lane, double* y_lds = nullptr, double* yh_lds = nullptr, int rows_lds = 0) {
+HSD void landmark_eliminate(const Tables& T, int dl, int lane) {
   constexpr int REC = 8 + 12 * K;
   const int q0 = T.lm_ptr[dl], q1 = T.lm_ptr[dl + 1];
   const int c_first = T.lm_cfirst[dl], rows = 6 * T.lm_ncp[dl];
@@ -406,7 +404,7 @@ HSD void landmark_eliminate(const Tables& T, int dl, int lane, double* y_lds = n
   for (int i = 0; i < 6; ++i) h[i] = wave_sum(h[i]);
 #pragma unroll
   for (int i = 0; i < 3; ++i) b[i] = wave_sum(b[i]);
-  landmark_finish<PS>(T, dl, lane, (q1 > q0) && !is_const, fresh, radius, sl_old, yoff, rows, h, b, w, y_lds, yh_lds, rows_lds);
+  landmark_finish<PS>(T, dl, lane, (q1 > q0) && !is_const, fresh, radius, sl_old, yoff, rows, h, b, w);
 }
 
 template <int K, int PS, int U>

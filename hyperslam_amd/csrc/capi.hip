@@ -226,7 +226,9 @@ int prepare(hs_problem* p) {
       if (fbt[i] < 0 || fbt[i] + p->kb > p->n_bias) HS_FAIL(HS_ERR_INVALID, "inertial residual stamp outside the valid range of the bias splines");
       p->in_order[i] = i;
     }
-    std::stable_sort(p->in_order.begin(), p->in_order.end(), [&](int a, int b) { return ft[a] < ft[b]; });
+    // segment-major, and bias-segment-major inside a segment: both first indices are monotone in time, so first_bias is
+    // non-decreasing over the whole table whatever the order of the caller's stamps (k_border_bb's i_bias_ptr ranges rely on it)
+    std::stable_sort(p->in_order.begin(), p->in_order.end(), [&](int a, int b) { return ft[a] != ft[b] ? ft[a] < ft[b] : fbt[a] < fbt[b]; });
     p->in_first.resize(n_ine), p->in_first_bias.resize(n_ine);
     p->in_seg_ptr.assign(n_seg + 1, 0);
     for (int d = 0; d < n_ine; ++d) {
@@ -236,7 +238,7 @@ int prepare(hs_problem* p) {
       p->in_seg_ptr[ft[t] + 1]++;
     }
     for (int sgm = 0; sgm < n_seg; ++sgm) p->in_seg_ptr[sgm + 1] += p->in_seg_ptr[sgm];
-    // records are time-sorted, so first_bias is non-decreasing: i_bias_ptr[f] = first record with first_bias >= f
+    // first_bias is non-decreasing (see the sort above): i_bias_ptr[f] = first record with first_bias >= f
     const int nbias = p->has_imu ? p->n_bias : 0;
     p->in_bias_ptr.assign(nbias + 2, n_ine);
     for (int f = 0, d = 0; f <= nbias + 1; ++f) {

@@ -213,3 +213,32 @@ def test_manifolds(hip, oracle):
         assert np.abs(p.manifold_plus_jacobian(ha.HS_MANIFOLD_SPHERE3, g) - o.manifold_plus_jacobian(ha.HS_MANIFOLD_SPHERE3, g)).max() <= 1e-13
         with pytest.raises(ha.HsError):
             p.manifold_plus(ha.HS_MANIFOLD_SPHERE3, np.zeros((1, 4)), np.zeros((1, 2)))
+
+
+@pytest.mark.parametrize("name", ["config0", "config1", "config2", "config3"])
+def test_baseline_configs_at_full_size(name, hip, oracle):
+    """BASELINE.json configs[0..3] at their FULL sizes (1 k priors / 50 k pixel blocks / 50 k pixel + 10 k inertial blocks on an
+    order-6 spline / 200 k blocks on 512 control points): cost, reduced normal equations and the whole 5-iteration LM trajectory
+    of the HIP path against the oracle (which needs 0.1 - 10 s for these), plus run-to-run bit reproducibility at that size."""
+    w = getattr(synthetic, name)()
+    with ha.Problem(w, lib=hip) as g, ha.Problem(w, lib=oracle) as c:
+        assert abs(g.cost() - c.cost()) <= 1e-11 * c.cost()
+        Sg, gg = g.reduced_system(1e4)
+        Sc, gc = c.reduced_system(1e4)
+        assert rel(Sg, Sc) < 1e-9 and rel(gg, gc) < 1e-9, (rel(Sg, Sc), rel(gg, gc))
+        assert np.array_equal(Sg, Sg.T)
+        sg, sc = g.solve(5), c.solve(5)
+        assert sg["num_iterations"] == sc["num_iterations"]
+        assert sg["num_successful_steps"] == sc["num_successful_steps"] and sg["termination"] == sc["termination"]
+        for ig, ic in zip(sg["iterations"], sc["iterations"]):
+            assert ig["step_is_successful"] == ic["step_is_successful"]
+            assert abs(ig["cost"] - ic["cost"]) <= 1e-6 * abs(ic["cost"]) + 1e-8 * sc["initial_cost"], (ig["iteration"], ig["cost"], ic["cost"])
+        assert rel(g.control_points(), c.control_points()) < 1e-6
+        if len(w.landmarks):
+            assert rel(g.landmarks(), c.landmarks()) < 1e-6
+        first = (g.control_points().copy(), g.landmarks().copy() if len(w.landmarks) else None)
+    with ha.Problem(w, lib=hip) as g:
+        g.solve(5)
+        assert np.array_equal(g.control_points(), first[0])
+        if first[1] is not None:
+            assert np.array_equal(g.landmarks(), first[1])

@@ -183,3 +183,46 @@ def test_long_window(hip, monkeypatch):
     with ha.Problem(w, lib=hip) as g:
         with pytest.raises(RuntimeError, match="window too long"):
             g.solve(1)
+
+
+def test_input_order_invariance(hip, oracle):
+    """The residual tables may arrive in any order (the library sorts them landmark- / segment- / bias-segment-major itself):
+    sorted by time, reversed and shuffled inputs give the oracle's normal equations and, among themselves, the same system up to
+    summation order; landmarks may be permuted too."""
+    base = synthetic.small_inertial(order=4, n_cp=24, n_landmarks=40, obs_pairs=3, n_inertial=900, seed=23, identity=False)
+    extra = synthetic.small_visual(order=4, n_cp=24, n_landmarks=8, obs_pairs=2, seed=23, with_priors=60)
+    lo, hi = base.valid_range()
+    base.sensor_T_bs = extra.sensor_T_bs
+    base.prior_stamps, base.prior_poses, base.prior_sensor = np.clip(extra.prior_stamps, lo, hi - 1e-9), extra.prior_poses, extra.prior_sensor
+    rng = np.random.default_rng(3)
+
+    def reordered(w, how):
+        v = copy.deepcopy(w)
+        for names in (("pixel_stamps", "pixels", "pixel_landmark", "pixel_camera"), ("prior_stamps", "prior_poses", "prior_sensor"),
+                      ("inertial_stamps", "inertial_measurements")):
+            n = len(getattr(v, names[0]))
+            order = {"sorted": np.argsort(getattr(v, names[0]), kind="stable"), "reversed": np.argsort(getattr(v, names[0]), kind="stable")[::-1],
+                     "shuffled": rng.permutation(n)}[how]
+            for f in names:
+                setattr(v, f, np.ascontiguousarray(getattr(v, f)[order]))
+        if how == "shuffled":  # relabel the landmarks as well
+            perm = rng.permutation(len(v.landmarks))  # new index of old landmark l is perm[l]
+            lm = np.empty_like(v.landmarks)
+            lm[perm] = v.landmarks
+            v.landmarks, v.pixel_landmark = lm, perm[v.pixel_landmark].astype(np.int32)
+        return v
+
+    systems = []
+    for how in ("sorted", "reversed", "shuffled"):
+        w = reordered(base, how)
+        with ha.Problem(w, lib=hip) as g, ha.Problem(w, lib=oracle) as c:
+            assert abs(g.cost() - c.cost()) <= 1e-11 * c.cost()
+            Sg, gg = g.reduced_system(1e4)
+            Sc, gc = c.reduced_system(1e4)
+            assert rel(Sg, Sc) < 1e-9 and rel(gg, gc) < 1e-9, (how, rel(Sg, Sc), rel(gg, gc))
+            systems.append((Sg, gg))
+            sg, sc = g.solve(4), c.solve(4)
+            assert sg["num_iterations"] == sc["num_iterations"]
+            assert abs(sg["final_cost"] - sc["final_cost"]) <= 1e-6 * abs(sc["final_cost"]) + 1e-8 * sc["initial_cost"]
+    for S, g_ in systems[1:]:  # the pose-side system does not depend on the order of the tables
+        assert rel(S, systems[0][0]) < 1e-11 and rel(g_, systems[0][1]) < 1e-11

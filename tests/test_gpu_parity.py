@@ -242,3 +242,9 @@ def test_baseline_configs_at_full_size(name, hip, oracle):
         assert np.array_equal(g.control_points(), first[0])
         if first[1] is not None:
             assert np.array_equal(g.landmarks(), first[1])
+
+
+def test_process_tracks_matches_golden(hip):
+    """hs_process_tracks against the 100-digit vectors of tests/golden/make_tracks_golden.py (same bar as the oracle's CPU test)."""
+    from util import check_tracks_against_golden
+    assert check_tracks_against_golden(hip, 1e-9) <= 1e-9

@@ -10,7 +10,7 @@ import pytest
 
 import hyperslam_amd as ha
 from hyperslam_amd import _lib, synthetic
-from util import check_against_golden, check_manifolds_against_golden, golden_cases, golden_window, rel
+from util import check_against_golden, check_manifolds_against_golden, check_tracks_against_golden, golden_cases, golden_window, rel
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -150,3 +150,8 @@ def test_oracle_manifolds_match_golden(oracle):
         assert check_manifolds_against_golden(p, 1e-14) <= 1e-14
         with pytest.raises(ha.HsError):
             p.manifold_plus(ha.HS_MANIFOLD_SPHERE3, np.zeros((1, 4)), np.zeros((1, 2)))
+
+
+def test_oracle_process_tracks_matches_golden(oracle):
+    """Pixel -> bearing (20 fixed-point undistortion steps vs the exact root) and stereo triangulation against 100-digit vectors."""
+    assert check_tracks_against_golden(oracle, 1e-10) <= 1e-10

@@ -91,3 +91,19 @@ def check_manifolds_against_golden(problem, tol):
                 worst = max(worst, e)
             assert jac[i].shape == (ambient, c["tangent"])
     return worst
+
+
+def check_tracks_against_golden(lib, tol):
+    """hs_process_tracks of a library against tests/golden/tracks.json (exact undistortion root, closest-point midpoint, spline
+    pose; tests/golden/make_tracks_golden.py). Returns the worst relative error."""
+    from hyperslam_amd import Problem
+    with open(os.path.join(HERE, "golden", "tracks.json")) as f:
+        d = json.load(f)
+    cps = np.array(d["cps"], float)
+    w = Window(order=d["k"], t0=float(cps[0, 7]), dt=0.1, control_points=cps, cam_T_bs=np.array(d["cam_T_bs"]),
+               cam_intrinsics=np.array(d["intrinsics"]), cam_distortion=np.array(d["distortion"]))
+    with Problem(w, lib=lib) as p:
+        b0, b1, pw = p.process_tracks(d["stamp"], d["pixels0"], d["pixels1"])
+    errs = (rel(b0, d["bearings0"]), rel(b1, d["bearings1"]), rel(pw, d["positions_w"]))
+    assert max(errs) <= tol, errs
+    return max(errs)

@@ -226,3 +226,34 @@ def test_input_order_invariance(hip, oracle):
             assert abs(sg["final_cost"] - sc["final_cost"]) <= 1e-6 * abs(sc["final_cost"]) + 1e-8 * sc["initial_cost"]
     for S, g_ in systems[1:]:  # the pose-side system does not depend on the order of the tables
         assert rel(S, systems[0][0]) < 1e-11 and rel(g_, systems[0][1]) < 1e-11
+
+
+def test_table_shapes(hip, oracle):
+    """Shapes the other windows do not cover: several prior sensors with mixed indices, bias splines whose knots are not aligned
+    with the pose knots (many bias control points, knots inside pose segments), windows one segment longer than the minimum,
+    landmarks with a single observation."""
+    # three prior sensors, mixed
+    w = synthetic.small_visual(order=4, n_cp=14, n_landmarks=20, obs_pairs=2, seed=51, with_priors=45)
+    rng = np.random.default_rng(51)
+    T = np.repeat(w.sensor_T_bs, 3, axis=0)
+    T[1, 4:] += [0.1, -0.05, 0.02]
+    T[2, :4] = synthetic.quat_mul(synthetic.quat_exp(np.array([[0.1, -0.2, 0.05]])), T[2:3, :4])[0]
+    w.sensor_T_bs, w.prior_sensor = T, rng.integers(0, 3, len(w.prior_stamps)).astype(np.int32)
+    compare(w, hip, oracle)
+    # bias knots every 0.25 s / 0.37 s on a 0.1 s pose spline
+    for bias_dt, order in ((0.25, 4), (0.37, 6)):
+        w, r = synthetic._visual_window(synthetic.SEED ^ (0x300 + order), order, 18, 30, 3)
+        w = synthetic.add_imu(w, r, 500, bias_dt=bias_dt, identity=False)
+        compare(w, hip, oracle, tol=1e-5)
+    # one segment more than the minimum
+    for k in (4, 6):
+        compare(synthetic.small_visual(order=k, n_cp=k + 1, n_landmarks=16, obs_pairs=2, seed=52), hip, oracle)
+    # landmarks seen once (one pixel observation: H_ll is rank 2, regularised only by the LM damping)
+    w = synthetic.small_visual(order=4, n_cp=16, n_landmarks=40, obs_pairs=3, seed=53)
+    keep = np.ones(len(w.pixel_stamps), bool)
+    for l in range(0, 40, 4):
+        idx = np.flatnonzero(w.pixel_landmark == l)
+        keep[idx[1:]] = False
+    for f in ("pixel_stamps", "pixels", "pixel_landmark", "pixel_camera"):
+        setattr(w, f, np.ascontiguousarray(getattr(w, f)[keep]))
+    compare(w, hip, oracle, tol=1e-5, check_lm=False)

@@ -1,0 +1,376 @@
+// kernels_border.hpp — border unknowns (bias splines, gravity): gathers, scaling, bordered solve (part of kernels.hpp; included once by capi.hip through it).
+#pragma once
+#include "kernels_common.hpp"
+
+namespace hs {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Border unknowns (IMU bias-spline control points + gravity; SURVEY a-4): the inertial factor couples every control point of
+// the window with a few *dense* unknowns, ordered last:  [gyro bias 3 n_bias | accel bias 3 n_bias | gravity 2] = nb.
+//   H_pb (np x nb), H_bb (nb x nb), g_b (nb) are gathered deterministically from the inertial records.
+// Record structure exploited: d r_ang / d b_g,j = wg[j] I_3, d r_lin / d b_a,j = wa[j] I_3 (only the weights are stored).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int K>
+__global__ void __launch_bounds__(128) k_border_pb(Tables T) {
+  // block (i, split): rows 6 i .. 6 i + 5 of H_pb, thread <-> border column
+  if (T.st->done) return;
+  const int i = blockIdx.x, sp = blockIdx.y, nsp = gridDim.y;
+  const int kb = T.kb, nbias = T.n_bias, nb = T.nb;
+  const int IREC = 18 + 36 * K + 2 * kb;
+  double* out = T.xpart + size_t(sp) * T.x_count1 + T.xo_pb;
+  for (int beta = threadIdx.x; beta < nb; beta += blockDim.x) {
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    // classify the column once
+    const int kind = beta < 3 * nbias ? 0 : (beta < 6 * nbias ? 1 : 2);
+    const int bb = kind == 2 ? 0 : (beta - 3 * nbias * kind) / 3, cc = kind == 2 ? beta - 6 * nbias : (beta - 3 * nbias * kind) % 3;
+    const int f0 = max(0, i - K + 1), f1 = min(i, T.n_seg - 1);
+    for (int first = f0; first <= f1; ++first) {
+      const int ao = 6 * (i - first);
+      if (kind == 2) {
+#pragma unroll 2
+        for (int pos = T.i_seg_ptr[first] + sp; pos < T.i_seg_ptr[first + 1]; pos += nsp) {
+          const double* rec = T.i_rec + size_t(pos) * IREC;
+          const double* jp = rec + 6;
+          const double* jg = rec + 6 + 36 * K + 2 * kb;
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+            const double g = jg[2 * r + cc];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) acc[a] = fma(jp[r * 6 * K + ao + a], g, acc[a]);
+          }
+        }
+      } else {
+        // branch-free body (clamped weight index, masked weight) so that the loads of four records are in flight together
+#pragma unroll 4
+        for (int pos = T.i_seg_ptr[first] + sp; pos < T.i_seg_ptr[first + 1]; pos += nsp) {
+          const double* rec = T.i_rec + size_t(pos) * IREC;
+          const int j = bb - T.i_first_bias[pos];
+          const bool ok = j >= 0 && j < kb;
+          const double wv = rec[6 + 36 * K + kind * kb + (ok ? j : 0)];
+          const double wgt = ok ? wv : 0.0;
+          const double* row = rec + 6 + (3 * kind + cc) * 6 * K + ao;
+#pragma unroll
+          for (int a = 0; a < 6; ++a) acc[a] = fma(row[a], wgt, acc[a]);
+        }
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) out[size_t(6 * i + a) * nb + beta] = acc[a];
+  }
+}
+
+/// H_bb and J_b' r. One workgroup per bias control point b (gyro and accel parts): the records whose bias window covers b are
+/// dealt to 256 lanes, sums are combined wave by wave in a fixed order; each entry of the exchange buffer has a single writer
+/// (the region is zero-filled first by k_border_zero). The gravity block is accumulated per b over the records that START at b
+/// (every record exactly once) into T.gravity_part[b][5] and summed by k_border_gravity.
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_border_bb(Tables T) {
+  constexpr int NV = 2 * hsd::kMaxOrder + 18 + 5;
+  __shared__ double red[kBlock / 64][NV];
+  if (T.st->done) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x;
+  const int kb = T.kb, nbias = T.n_bias, nb = T.nb;
+  const int IREC = 18 + 36 * K + 2 * kb;
+  double* Hbb = T.xbuf + T.xo_bb;
+  double* gb = T.xbuf + T.xo_gb;
+  const int og = 0, oa = 3 * nbias, ogr = 6 * nbias;
+  // records whose bias window covers b: first_bias in [b - kb + 1, b]
+  const int p0 = T.i_bias_ptr[max(0, b - kb + 1)], p1 = T.i_bias_ptr[b + 1], pown = T.i_bias_ptr[b];
+  double v[NV];  // [gg(kMaxOrder) | aa(kMaxOrder) | ggr 6 | agr 6 | rg 3 | ra 3 | gravity h00 h01 h11 g0 g1]
+#pragma unroll
+  for (int e = 0; e < NV; ++e) v[e] = 0.0;
+  double* gg = v, *aa = v + hsd::kMaxOrder, *ggr = v + 2 * hsd::kMaxOrder, *agr = ggr + 6, *rg = agr + 6, *ra = rg + 3, *hg = ra + 3;
+  for (int pos = p0 + tid; pos < p1; pos += kBlock) {
+    const double* rec = T.i_rec + size_t(pos) * IREC;
+    const int j = b - T.i_first_bias[pos];
+    const double* wgp = rec + 6 + 36 * K;
+    const double* wap = wgp + kb;
+    const double* jg = wap + kb;
+    const double wgb = wgp[j], wab = wap[j];
+#pragma unroll
+    for (int d = 0; d < hsd::kMaxOrder; ++d)
+      if (d < kb && j + d < kb) gg[d] = fma(wgb, wgp[j + d], gg[d]), aa[d] = fma(wab, wap[j + d], aa[d]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      ggr[2 * c] = fma(wgb, jg[2 * c], ggr[2 * c]), ggr[2 * c + 1] = fma(wgb, jg[2 * c + 1], ggr[2 * c + 1]);
+      agr[2 * c] = fma(wab, jg[2 * (3 + c)], agr[2 * c]), agr[2 * c + 1] = fma(wab, jg[2 * (3 + c) + 1], agr[2 * c + 1]);
+      rg[c] = fma(wgb, rec[c], rg[c]), ra[c] = fma(wab, rec[3 + c], ra[c]);
+    }
+    if (pos >= pown) {  // j == 0: this record starts at b -> its gravity terms are counted here
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        hg[0] = fma(jg[2 * r], jg[2 * r], hg[0]), hg[1] = fma(jg[2 * r], jg[2 * r + 1], hg[1]), hg[2] = fma(jg[2 * r + 1], jg[2 * r + 1], hg[2]);
+        hg[3] = fma(jg[2 * r], rec[r], hg[3]), hg[4] = fma(jg[2 * r + 1], rec[r], hg[4]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < NV; ++e) v[e] = wave_sum(v[e]);
+  if (lane == 0)
+#pragma unroll
+    for (int e = 0; e < NV; ++e) red[wave][e] = v[e];
+  __syncthreads();
+  if (tid != 0) return;
+#pragma unroll
+  for (int e = 0; e < NV; ++e) {
+    double t = 0.0;
+    for (int w = 0; w < kBlock / 64; ++w) t += red[w][e];
+    v[e] = t;
+  }
+  for (int d = 0; d < kb && b + d < nbias; ++d)
+    for (int c = 0; c < 3; ++c) {
+      const int r0 = og + 3 * b + c, c0 = og + 3 * (b + d) + c;
+      Hbb[size_t(r0) * nb + c0] = gg[d], Hbb[size_t(c0) * nb + r0] = gg[d];
+      const int r1 = oa + 3 * b + c, c1 = oa + 3 * (b + d) + c;
+      Hbb[size_t(r1) * nb + c1] = aa[d], Hbb[size_t(c1) * nb + r1] = aa[d];
+    }
+  for (int c = 0; c < 3; ++c)
+    for (int e = 0; e < 2; ++e) {
+      Hbb[size_t(og + 3 * b + c) * nb + ogr + e] = ggr[2 * c + e], Hbb[size_t(ogr + e) * nb + og + 3 * b + c] = ggr[2 * c + e];
+      Hbb[size_t(oa + 3 * b + c) * nb + ogr + e] = agr[2 * c + e], Hbb[size_t(ogr + e) * nb + oa + 3 * b + c] = agr[2 * c + e];
+    }
+  for (int c = 0; c < 3; ++c) gb[og + 3 * b + c] = rg[c], gb[oa + 3 * b + c] = ra[c];
+  for (int e = 0; e < 5; ++e) T.gravity_part[5 * b + e] = hg[e];
+}
+
+/// Gravity-gravity block and J_g' r: sum of the per-bias-point partials in index order.
+__global__ void k_border_gravity(Tables T) {
+  if (T.st->done || threadIdx.x != 0) return;
+  double h[5] = {0, 0, 0, 0, 0};
+  for (int b = 0; b < T.n_bias; ++b)
+    for (int e = 0; e < 5; ++e) h[e] += T.gravity_part[5 * b + e];
+  const int nb = T.nb, ogr = 6 * T.n_bias;
+  double* Hbb = T.xbuf + T.xo_bb;
+  Hbb[size_t(ogr) * nb + ogr] = h[0], Hbb[size_t(ogr) * nb + ogr + 1] = h[1];
+  Hbb[size_t(ogr + 1) * nb + ogr] = h[1], Hbb[size_t(ogr + 1) * nb + ogr + 1] = h[2];
+  T.xbuf[T.xo_gb + ogr] = h[3], T.xbuf[T.xo_gb + ogr + 1] = h[4];
+}
+
+__global__ void __launch_bounds__(kBlock) k_border_zero(Tables T) {
+  if (T.st->done) return;
+  const int n = T.nb * T.nb + T.nb;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) T.xbuf[T.xo_bb + e] = 0.0;
+}
+
+/// Scaling / damping of the border blocks after the exchange:  S_pb = Sp H_pb Sb,  S_bb = Sb H_bb Sb + D_b^2,  g_b = Sb g_b.
+__global__ void __launch_bounds__(kBlock) k_finalize_border(Tables T) {
+  DevState* st = T.st;
+  if (st->done) return;
+  const int nb = T.nb, np = T.np;
+  const double* X = T.xbuf;
+  const bool fresh = !st->scaling_ready;
+  const double radius = st->radius;
+  auto sb_of = [&](int b) { return fresh ? 1.0 / (1.0 + sqrt(X[T.xo_bb + size_t(b) * nb + b])) : T.scale_b[b]; };
+  auto sp_of = [&](int rho) { return fresh ? 1.0 / (1.0 + sqrt(X[T.xo_dj + rho])) : T.scale_p[rho]; };
+  const int total = (np + nb) * nb;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int row = e / nb, c = e % nb;
+    if (row < np) {
+      T.Spb[e] = sp_of(row) * X[T.xo_pb + e] * sb_of(c);
+    } else {
+      const int b = row - np;
+      const double sr = sb_of(b), sc = sb_of(c);
+      double out = sr * sc * X[T.xo_bb + size_t(b) * nb + c];
+      if (b == c) {
+        const double d = X[T.xo_bb + size_t(b) * nb + b];
+        if (d > 0.0) {
+          const double d2 = fmin(fmax(sr * sr * d, 1e-6), 1e32) / radius;
+          out += d2;
+          T.D2b[b] = d2;
+        } else {
+          out = 1.0;
+          T.D2b[b] = 0.0;
+        }
+        const double g = X[T.xo_gb + b];
+        T.gb_s[b] = sr * g;
+        if (fresh) T.scale_b[b] = sr;
+        T.gabs[T.np + b] = fabs(g);
+      }
+      T.Sbb[size_t(b) * nb + c] = out;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Bordered solve:  [S_pp S_pb; S_bp S_bb][x_p; x_b] = [g_p; g_b] with S_pp = U'U banded.
+//   Z = U^-T S_pb  (k_border_forward: one workgroup per group of border columns, column-oriented forward sweep)
+//   C = S_bb - Z'Z, h = g_b - Z'y  (k_border_schur, one workgroup per border row)
+//   C x_b = h (dense Cholesky in LDS), y' = y - Z x_b  (k_border_solve, one workgroup)   then the banded backward sweep on y'.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kBorderCols = 8;  // right-hand sides per workgroup in the forward sweep
+
+__global__ void __launch_bounds__(kBlock) k_border_forward(Tables T) {  // blockDim = 64 x waves covering the 6 (bw - 1) pending rows (>= 128)
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (T.st->done) return;
+  const int tid = threadIdx.x;
+  const int bw = T.bw, ncb = 6 * bw, nb = T.nb, np = T.np, n_blk = np / 6;
+  const int c0 = blockIdx.x * kBorderCols, ncols = min(kBorderCols, nb - c0);
+  double* z = smem;  // np x kBorderCols: pending right-hand side rows, overwritten by the solution
+  for (int e = tid; e < np * kBorderCols; e += blockDim.x) {
+    const int rho = e / kBorderCols, c = e % kBorderCols;
+    z[e] = c < ncols ? T.Spb[size_t(rho) * nb + c0 + c] : 0.0;
+  }
+  __syncthreads();
+  __shared__ double zi[6 * kBorderCols];
+  const int n_pend = 6 * (bw - 1);
+  // Operands of step m are requested D steps ahead (the sweep is a dependency chain over the block rows: a load issued inside
+  // the step would put a full L2 round trip on it). Thread t < n_pend: the six factor entries U[6m + a][6 + t]; thread
+  // (a, c) < 6 x kBorderCols: column a of W_m = U_mm^-1.
+  constexpr int D = 4;
+  const bool pend = tid < n_pend, diag = tid < 6 * kBorderCols;
+  const int da = diag ? tid / kBorderCols : 0, dc = diag ? tid % kBorderCols : 0;
+  double ur[D][6], wr[D][6];
+  auto request = [&](int m, double* u, double* w) {
+    const int mm = m < n_blk ? m : 0;
+    const double* src = T.Ub + size_t(6 * mm) * ncb + 6 + (pend ? tid : 0);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) u[a] = src[size_t(a) * ncb];
+    // (W')[a][k] = W[k][a], k <= a ; packed index of (k, a) = k*6 - k(k-1)/2 + (a - k)
+    const double* W = T.Ubk + size_t(mm) * 24;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) w[k] = W[k <= da ? k * 6 - k * (k - 1) / 2 + (da - k) : 0];
+  };
+#pragma unroll
+  for (int d = 0; d < D; ++d) request(d, ur[d], wr[d]);
+  for (int mb = 0; mb < n_blk; mb += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int m = mb + d;
+      if (m >= n_blk) break;
+      // z_m = U_mm^-T s_m = W' s_m
+      if (diag) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v = fma(k <= da ? wr[d][k] : 0.0, z[(6 * m + k) * kBorderCols + dc], v);
+        zi[tid] = v;
+      }
+      __syncthreads();
+      if (diag) z[(6 * m + da) * kBorderCols + dc] = zi[tid];
+      // pending rows of blocks m+1 .. m+bw-1: s_(i,c') -= sum_a U[6m+a][6(i-m)+c'] z_m[a]
+      if (pend) {
+        const int rho = 6 * (m + 1) + tid;
+        if (rho < np) {
+#pragma unroll
+          for (int c = 0; c < kBorderCols; ++c) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) sacc = fma(ur[d][a], zi[a * kBorderCols + c], sacc);
+            z[rho * kBorderCols + c] -= sacc;
+          }
+        }
+      }
+      request(m + D, ur[d], wr[d]);
+      __syncthreads();
+    }
+  }
+  for (int e = tid; e < np * kBorderCols; e += blockDim.x) {
+    const int rho = e / kBorderCols, c = e % kBorderCols;
+    if (c < ncols) T.Zb[size_t(rho) * nb + c0 + c] = z[e];
+  }
+}
+
+/// C = S_bb - Z'Z (16 x 16 tile per workgroup, upper tile triangle mirrored) and h = g_b - Z'y. Z rows are staged through LDS
+/// in chunks (coalesced, eight loads in flight per lane), the tile is accumulated from LDS.
+constexpr int kSchurTile = 16, kSchurRows = 128;
+
+__global__ void __launch_bounds__(kBlock) k_border_schur(Tables T) {
+  __shared__ double za[kSchurRows][kSchurTile + 1], zc[kSchurRows][kSchurTile + 1], ys[kSchurRows];
+  if (T.st->done) return;
+  const int nb = T.nb, np = T.np, tid = threadIdx.x;
+  const int bt = blockIdx.x, ct = blockIdx.y;
+  if (ct < bt) return;  // lower tiles are written by their mirror
+  const int ti = tid / kSchurTile, tj = tid % kSchurTile;
+  const int b = bt * kSchurTile + ti, c = ct * kSchurTile + tj;
+  double acc = 0.0, hacc = 0.0;
+  for (int r0 = 0; r0 < np; r0 += kSchurRows) {
+    const int nr = min(kSchurRows, np - r0);
+    __syncthreads();
+    // 2 x (kSchurRows x 16) operand entries + y: 16 + 1 loads per lane, issued together
+    double va[8], vc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = tid + u * kBlock, r = e / kSchurTile, k = e % kSchurTile;
+      const bool ok = r < nr;
+      va[u] = ok && bt * kSchurTile + k < nb ? T.Zb[size_t(r0 + r) * nb + bt * kSchurTile + k] : 0.0;
+      vc[u] = ok && ct * kSchurTile + k < nb ? T.Zb[size_t(r0 + r) * nb + ct * kSchurTile + k] : 0.0;
+    }
+    const double yv = tid < nr ? T.ybuf[r0 + tid] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = tid + u * kBlock, r = e / kSchurTile, k = e % kSchurTile;
+      za[r][k] = va[u], zc[r][k] = vc[u];
+    }
+    if (tid < kSchurRows) ys[tid] = yv;
+    __syncthreads();
+#pragma unroll 8
+    for (int r = 0; r < kSchurRows; ++r) {
+      const double a = za[r][ti];
+      acc = fma(a, zc[r][tj], acc);
+      if (ct == bt && tj == 0) hacc = fma(a, ys[r], hacc);
+    }
+  }
+  if (b < nb && c < nb) {
+    const double v = T.Sbb[size_t(b) * nb + c] - acc;
+    T.Cb[size_t(b) * nb + c] = v;
+    if (ct != bt) T.Cb[size_t(c) * nb + b] = v;
+  }
+  if (ct == bt && tj == 0 && b < nb) T.hb[b] = T.gb_s[b] - hacc;
+}
+
+/// Dense Cholesky of the border Schur complement C (nb x nb, in LDS, augmented with h as an extra row so that the forward
+/// solve comes out of the elimination), column-oriented backward solve, x_b. One barrier per column in both sweeps.
+__global__ void __launch_bounds__(kBlock) k_border_solve(Tables T) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  DevState* st = T.st;
+  if (st->done) return;
+  const int nb = T.nb, tid = threadIdx.x;
+  const int ld = nb + 1, n1 = nb + 1;  // rows 0 .. nb-1: C (lower), row nb: h'
+  double* C = smem;                    // (nb + 1) x ld
+  for (int e = tid; e < nb * nb; e += blockDim.x) C[(e / nb) * ld + e % nb] = T.Cb[e];
+  for (int e = tid; e < nb; e += blockDim.x) C[nb * ld + e] = T.hb[e];
+  __shared__ int bad;
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  const int ti = tid / 16, tj = tid % 16;  // 16 x 16 lanes over the trailing (i, c) entries
+  for (int j = 0; j < nb; ++j) {           // right-looking on the lower triangle; column j is scaled on the fly
+    const double d = C[j * ld + j];
+    if (tid == 0 && !(d > 0.0)) bad = 1;
+    const double inv = 1.0 / (d > 0.0 ? d : 1.0);  // 1 / l_jj^2
+    for (int i = j + 1 + ti; i < n1; i += 16) {
+      const double lij = C[i * ld + j];
+      for (int c = j + 1 + tj; c <= i && c < nb; c += 16) C[i * ld + c] = fma(-lij * inv, C[c * ld + j], C[i * ld + c]);
+    }
+    lds_barrier();
+    // scale column j (not read again by later columns' updates except through these scaled values in the backward sweep)
+    const double rs = sqrt(inv);
+    for (int i = j + tid; i < n1; i += blockDim.x) C[i * ld + j] = i == j ? d * rs : C[i * ld + j] * rs;
+    // (no barrier needed here: column j is not touched by the update of column j + 1, which reads columns > j only ... except
+    //  C[c][j+1] entries, which were finalised by the update above and published by the barrier)
+  }
+  lds_barrier();
+  // backward: L' x = y, y = row nb; column oriented, one barrier per column (x goes to its own array)
+  double* y = C + nb * ld;
+  double* x = C + n1 * ld;
+  for (int j = nb - 1; j >= 0; --j) {
+    const double xj = y[j] / C[j * ld + j];
+    if (tid == 0) x[j] = xj;
+    for (int i = tid; i < j; i += blockDim.x) y[i] = fma(-C[j * ld + i], xj, y[i]);
+    lds_barrier();
+  }
+  if (tid == 0 && bad) st->chol_failed = 1;
+  for (int bq = tid; bq < nb; bq += blockDim.x) T.xb[bq] = x[bq];
+}
+
+/// y' = y - Z x_b (one wave per row of Z, lanes over the border columns).
+__global__ void __launch_bounds__(kBlock) k_border_apply(Tables T) {
+  if (T.st->done) return;
+  const int lane = threadIdx.x & 63, rho = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (rho >= T.np) return;
+  double v = 0.0;
+  for (int bq = lane; bq < T.nb; bq += 64) v = fma(T.Zb[size_t(rho) * T.nb + bq], T.xb[bq], v);
+  v = wave_sum(v);
+  if (lane == 0) T.ybuf[rho] -= v;
+}
+
+}  // namespace hs

@@ -1,0 +1,87 @@
+// kernels_common.hpp — shared device helpers: wave / workgroup reductions, batched strided loads, control-point staging (part of kernels.hpp; included once by capi.hip through it).
+#pragma once
+#include <type_traits>
+#include "factors.hpp"
+
+namespace hs {
+
+constexpr int kBlock = 256;
+
+HSD double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+/// Workgroup barrier that only drains LDS traffic: global loads / stores stay in flight across it (the factorisation
+/// prefetches the next band row while the current step runs; __syncthreads() would wait for vmcnt(0) every step).
+HSD void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+/// Deterministic block sum (fixed butterfly inside each wave, waves combined in index order). Result valid on thread 0.
+HSD double block_sum(double v, double* lds /* >= blockDim/64 */) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) lds[w] = v;
+  __syncthreads();
+  double s = 0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < int(blockDim.x >> 6); ++i) s += lds[i];
+  __syncthreads();
+  return s;
+}
+
+/// Per-lane partial sum / max of a strided array with eight independent loads in flight (a plain `s += p[i]` loop keeps one
+/// load in flight per lane and pays the full memory latency per element). Fixed order: bit-reproducible.
+HSD double strided_sum(const double* __restrict__ p, int n, int stride = 1, int offset = 0) {
+  double s = 0.0;
+  for (int i0 = threadIdx.x; i0 < n; i0 += 8 * blockDim.x) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * blockDim.x;
+      v[u] = i < n ? p[size_t(i) * stride + offset] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  return s;
+}
+template <int U = 8>
+HSD double strided_max(const double* __restrict__ p, int n) {  // entries >= 0; U independent loads in flight per lane
+  double m = 0.0;
+  for (int i0 = threadIdx.x; i0 < n; i0 += U * blockDim.x) {
+    double v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * blockDim.x;
+      v[u] = i < n ? p[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) m = fmax(m, v[u]);
+  }
+  return m;
+}
+
+HSD void stage_cps(const double* __restrict__ src, double* dst, int n_doubles) {
+  // control points are n x 8 doubles: 16-byte pieces, four loads in flight per lane (one round trip for up to 128 control points
+  // per 256 lanes instead of one per piece)
+  const double2* s2 = reinterpret_cast<const double2*>(src);
+  double2* d2 = reinterpret_cast<double2*>(dst);
+  const int n2 = n_doubles / 2;
+  for (int i0 = threadIdx.x; i0 < n2; i0 += 4 * blockDim.x) {
+    double2 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * blockDim.x;
+      v[u] = i < n2 ? s2[i] : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * blockDim.x;
+      if (i < n2) d2[i] = v[u];
+    }
+  }
+  __syncthreads();
+}
+
+}  // namespace hs

@@ -1,0 +1,177 @@
+// kernels_linearize.hpp — linearisation and candidate-cost kernels (one residual block per lane) (part of kernels.hpp; included once by capi.hip through it).
+#pragma once
+#include "kernels_common.hpp"
+
+namespace hs {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Linearisation
+// ---------------------------------------------------------------------------------------------------------------------
+/// out_rec/out_pos: where the record of residual q goes (solver: T.v_rec at T.v_pos[q]; debug export: table order).
+/// Records are transposed through a per-wave LDS slab so that the scattered 448-byte (k = 4) records leave the CU as full
+/// 16-byte-per-lane stores (7 cache lines per record instead of 56 partial-line writes).
+template <int K>
+constexpr int lin_block() { return K <= 4 ? 256 : 128; }  // 2 waves at k = 6: the record slab is 42 KB per wave
+
+template <int K>
+__global__ void __launch_bounds__(lin_block<K>()) k_linearize_visual(Tables T, double* out_rec, const int* out_pos, int robustify,
+                                                                     double* cost_part, double* cost_each) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (T.st->done) return;
+  constexpr int REC = 8 + 12 * K, LREC = REC + 2, NCH = REC / 2;  // LDS record stride (16-byte aligned, bank-spread), 16-B chunks
+  constexpr int NW = lin_block<K>() / 64;
+  // control points: LDS copy when it fits next to the record slabs, otherwise straight from L2 (long windows)
+  const bool cps_in_lds = size_t(8) * T.sp.n_cp * sizeof(double) <= 24 * 1024;
+  const double* cps = cps_in_lds ? smem : T.cp;
+  double* slab = smem + (cps_in_lds ? 8 * T.sp.n_cp : 0) + (threadIdx.x >> 6) * 64 * LREC;  // this wave's 64 records
+  const bool lprof = (T.debug_flags & 32) && threadIdx.x == 0 && blockIdx.x < 256;
+  long long* llog = reinterpret_cast<long long*>(T.xpart) + 32 * 1024 + 4 * blockIdx.x;
+  if (lprof) llog[0] = wall_clock64();
+  if (cps_in_lds) stage_cps(T.cp, smem, 8 * T.sp.n_cp);
+  if (lprof) llog[1] = wall_clock64();
+  __shared__ double red[NW];
+  __shared__ int slots[NW * 64];
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  double cost = 0.0;
+  int slot = -1;
+  if (q < T.n_vis) {
+    VisualOut<K> o;
+    visual_linearize<K>(T, cps, q, robustify != 0, &o);
+    cost = o.cost;
+    slot = out_pos[q];
+    double* rec = slab + lane * LREC;
+    *reinterpret_cast<double2*>(rec) = make_double2(o.r[0], o.r[1]);
+#pragma unroll
+    for (int i = 0; i < 6; i += 2) *reinterpret_cast<double2*>(rec + 2 + i) = make_double2(o.Jl[i], o.Jl[i + 1]);
+#pragma unroll
+    for (int i = 0; i < 12 * K; i += 2) *reinterpret_cast<double2*>(rec + 8 + i) = make_double2(o.Jp[i], o.Jp[i + 1]);
+    if (cost_each) cost_each[slot] = cost;
+  }
+  if (lprof) llog[2] = wall_clock64();
+  slots[threadIdx.x] = slot;
+  __builtin_amdgcn_wave_barrier();  // LDS is in-order within a wave: the slab written above is visible to the reads below
+  const int* wslots = slots + (threadIdx.x & ~63);
+  // 64 records x NCH 16-byte chunks per wave; eight chunks per lane are read from LDS before any is stored (the plain loop paid
+  // one LDS round trip per chunk: 3.8 us of the kernel's 14)
+  constexpr int SU = 8;
+  for (int g0 = lane; g0 < 64 * NCH; g0 += SU * 64) {
+    double2 v[SU];
+    int sl[SU], cc[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int g = g0 + u * 64, gg = g < 64 * NCH ? g : 0;
+      const int r = gg / NCH, c = gg % NCH;
+      sl[u] = g < 64 * NCH ? wslots[r] : -1, cc[u] = c;
+      v[u] = *reinterpret_cast<const double2*>(slab + r * LREC + 2 * c);
+    }
+#pragma unroll
+    for (int u = 0; u < SU; ++u)
+      if (sl[u] >= 0) *reinterpret_cast<double2*>(out_rec + size_t(sl[u]) * REC + 2 * cc[u]) = v[u];
+  }
+  if (lprof) llog[3] = wall_clock64();
+  const double s = block_sum(cost, red);
+  if (threadIdx.x == 0 && cost_part) cost_part[blockIdx.x] = s;
+}
+
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_linearize_prior(Tables T, double* out_rec, double* cost_part, double* cost_each) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (T.st->done) return;
+  double* cps = smem;
+  stage_cps(T.cp, cps, 8 * T.sp.n_cp);
+  __shared__ double red[kBlock / 64];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double cost = 0.0;
+  if (i < T.n_pri) {
+    PriorOut<K> o;
+    prior_linearize<K>(T, cps, i, &o);
+    cost = o.cost;
+    constexpr int REC = 6 + 36 * K;
+    double* rec = out_rec + size_t(i) * REC;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) rec[c] = o.r[c];
+#pragma unroll
+    for (int c = 0; c < 36 * K; ++c) rec[6 + c] = o.Jp[c];
+    if (cost_each) cost_each[i] = cost;
+  }
+  const double s = block_sum(cost, red);
+  if (threadIdx.x == 0 && cost_part) cost_part[blockIdx.x] = s;
+}
+
+/// Inertial residual blocks (inertial.cpp:13-205): record = [r(6) | J_state(6 x 6K) | wg(KB) | wa(KB) | J_gravity(6 x 2)].
+template <int K, int KB>
+__global__ void __launch_bounds__(kBlock) k_linearize_inertial(Tables T, double* out_rec, int robustify, double* cost_part, double* cost_each) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (T.st->done) return;
+  double* cps = smem;
+  stage_cps(T.cp, cps, 8 * T.sp.n_cp);
+  __shared__ double red[kBlock / 64];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double cost = 0.0;
+  if (i < T.n_ine) {
+    InertialOut<K, KB> o;
+    inertial_evaluate<K, KB, true>(T, cps, T.bias_g, T.bias_a, T.gravity, i, robustify != 0, &o);
+    cost = o.cost;
+    constexpr int REC = 18 + 36 * K + 2 * KB;
+    double* rec = out_rec + size_t(i) * REC;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) rec[c] = o.r[c];
+#pragma unroll
+    for (int c = 0; c < 36 * K; ++c) rec[6 + c] = o.Jp[c];
+#pragma unroll
+    for (int c = 0; c < KB; ++c) rec[6 + 36 * K + c] = o.wg[c], rec[6 + 36 * K + KB + c] = o.wa[c];
+#pragma unroll
+    for (int c = 0; c < 12; ++c) rec[6 + 36 * K + 2 * KB + c] = o.Jg[c];
+    if (cost_each) cost_each[i] = cost;
+  }
+  const double s = block_sum(cost, red);
+  if (threadIdx.x == 0 && cost_part) cost_part[blockIdx.x] = s;
+}
+
+template <int K, int KB>
+__global__ void __launch_bounds__(kBlock) k_cost_inertial(Tables T, const double* cp_src, const double* bg, const double* ba, const double* grav,
+                                                         double* cost_part) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (T.st->done) return;
+  double* cps = smem;
+  stage_cps(cp_src, cps, 8 * T.sp.n_cp);
+  __shared__ double red[kBlock / 64];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double cost = 0.0;
+  if (i < T.n_ine) {
+    InertialOut<K, KB> o;
+    inertial_evaluate<K, KB, false>(T, cps, bg, ba, grav, i, false, &o);
+    cost = o.cost;
+  }
+  const double s = block_sum(cost, red);
+  if (threadIdx.x == 0) cost_part[blockIdx.x] = s;
+}
+
+/// Cost at the candidate point (residual-only branch).
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_cost_visual(Tables T, const double* cp_src, const double* lm_src, double* cost_part) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (T.st->done) return;
+  double* cps = smem;
+  stage_cps(cp_src, cps, 8 * T.sp.n_cp);
+  __shared__ double red[kBlock / 64];
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  const double cost = (q < T.n_vis) ? visual_cost<K>(T, cps, lm_src, q) : 0.0;
+  const double s = block_sum(cost, red);
+  if (threadIdx.x == 0) cost_part[blockIdx.x] = s;
+}
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_cost_prior(Tables T, const double* cp_src, double* cost_part) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (T.st->done) return;
+  double* cps = smem;
+  stage_cps(cp_src, cps, 8 * T.sp.n_cp);
+  __shared__ double red[kBlock / 64];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const double cost = (i < T.n_pri) ? prior_cost<K>(T, cps, i) : 0.0;
+  const double s = block_sum(cost, red);
+  if (threadIdx.x == 0) cost_part[blockIdx.x] = s;
+}
+
+}  // namespace hs

@@ -1,0 +1,302 @@
+// kernels_update.hpp — candidate point, trust-region state machine, acceptance (part of kernels.hpp; included once by capi.hip through it).
+#pragma once
+#include "kernels_common.hpp"
+
+namespace hs {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Candidate point of the step, one launch. Workgroups [0, n_lm_part): landmark back-substitution (one wave per landmark):
+//   y_l = L^-T (yh_l - Yh_l' (Sp o y_p)),  step_l = -y_l, with y_p = -step_p;   candidate = lm + S_l o step_l,
+// with the landmark-side terms of the decision (|x|^2, |x - x+|^2, g.step, step'D^2 step) summed per workgroup in a fixed
+// order. Workgroups [n_lm_part, n_lm_part + n_norm_part): candidate control points / bias points / gravity = Plus(x, delta) per
+// Ceres manifold (quaternion left-multiplicative, R^3 additive, stamp constant, sphere) and their norms.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_backsub_retract(Tables T) {
+  if (T.st->done) return;
+  __shared__ double red[kBlock / 64][4];
+  if (int(blockIdx.x) < T.n_lm_part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int dl = blockIdx.x * (kBlock / 64) + wave;
+    double xl = 0.0, sl = 0.0, gd = 0.0, dd = 0.0;
+    if (dl < T.n_lm) {
+      const int rows = 6 * T.lm_ncp[dl], r0 = 6 * T.lm_cfirst[dl];
+      const double* Y = T.Y + T.lm_yoff[dl];
+      // lane 0's operands of the 3x3 solve are requested before the dot products (one memory round trip less on the chain)
+      double L[6] = {1, 0, 1, 0, 0, 1}, yh[3] = {0, 0, 0}, x[3] = {0, 0, 0}, sc[3] = {0, 0, 0}, sb[3] = {0, 0, 0}, d2[3] = {0, 0, 0};
+      bool active = false;
+      if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) L[a] = T.lm_L[6 * dl + a];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          yh[a] = T.lm_yhat[3 * dl + a], x[a] = T.lm[3 * dl + a], sc[a] = T.lm_scale[3 * dl + a];
+          sb[a] = T.lm_sb[3 * dl + a], d2[a] = T.lm_D2[3 * dl + a];
+        }
+        active = (T.lm_ptr[dl + 1] > T.lm_ptr[dl]) && !T.lm_const[dl];
+      }
+      double t0 = 0, t1 = 0, t2 = 0;
+      for (int rho0 = lane; rho0 < rows; rho0 += 128) {  // two 64-row passes per round of loads (a track of <= 21 control points: one round)
+        double yv[2][3], yp[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int rho = rho0 + 64 * u;
+          const bool ok = rho < rows;
+          yp[u] = ok ? -T.step_p[r0 + rho] * T.scale_p[r0 + rho] : 0.0;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) yv[u][c] = ok ? Y[3 * rho + c] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) t0 = fma(yv[u][0], yp[u], t0), t1 = fma(yv[u][1], yp[u], t1), t2 = fma(yv[u][2], yp[u], t2);
+      }
+      t0 = wave_sum(t0), t1 = wave_sum(t1), t2 = wave_sum(t2);
+      if (lane == 0) {
+        // L' y = z
+        const double z0 = yh[0] - t0, z1 = yh[1] - t1, z2 = yh[2] - t2;
+        const double y2 = z2 / L[5], y1 = (z1 - L[4] * y2) / L[2], y0 = (z0 - L[1] * y1 - L[3] * y2) / L[0];
+        const double s[3] = {active ? -y0 : 0.0, active ? -y1 : 0.0, active ? -y2 : 0.0};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const double y = x[a] + sc[a] * s[a];
+          T.lm_cand[3 * dl + a] = y;
+          if (active) {
+            xl = fma(x[a], x[a], xl), sl = fma(x[a] - y, x[a] - y, sl);
+            gd = fma(sb[a], s[a], gd);
+            dd = fma(d2[a] * s[a], s[a], dd);
+          }
+        }
+      }
+    }
+    if (lane == 0) red[wave][0] = xl, red[wave][1] = sl, red[wave][2] = gd, red[wave][3] = dd;
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      double v = 0.0;
+#pragma unroll
+      for (int w = 0; w < kBlock / 64; ++w) v += red[w][threadIdx.x];
+      T.lm_part[4 * blockIdx.x + threadIdx.x] = v;
+    }
+    return;
+  }
+  const int blk = blockIdx.x - T.n_lm_part;
+  const int j = blk * blockDim.x + threadIdx.x;
+  double xs = 0.0, ss = 0.0;
+  if (j < T.sp.n_cp) {
+    const double* x = T.cp + 8 * j;
+    double* y = T.cp_cand + 8 * j;
+    const double* d = T.delta_p + 6 * j;
+    bool any = false;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) any |= (T.D2p[6 * j + c] != 0.0);
+    const Quat q = quat_plus(Quat{x[0], x[1], x[2], x[3]}, V3{d[0], d[1], d[2]});
+    y[0] = q.x, y[1] = q.y, y[2] = q.z, y[3] = q.w;
+    y[4] = x[4] + d[3], y[5] = x[5] + d[4], y[6] = x[6] + d[5];
+    y[7] = x[7];
+    if (any) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) xs = fma(x[c], x[c], xs), ss = fma(x[c] - y[c], x[c] - y[c], ss);
+    }
+  }
+  // border unknowns (replicated like the control points): bias control points [x y z t] and gravity
+  if (T.nb > 0) {
+    for (int b = j; b < 2 * T.n_bias; b += T.n_norm_part * blockDim.x) {
+      const bool acc = b >= T.n_bias;
+      const int bi = acc ? b - T.n_bias : b;
+      const double* x = (acc ? T.bias_a : T.bias_g) + 4 * bi;
+      double* y = (acc ? T.bias_a_cand : T.bias_g_cand) + 4 * bi;
+      const double* d = T.delta_b + 3 * b;
+      const bool any = T.D2b[3 * b] != 0.0 || T.D2b[3 * b + 1] != 0.0 || T.D2b[3 * b + 2] != 0.0;
+      y[0] = x[0] + d[0], y[1] = x[1] + d[1], y[2] = x[2] + d[2], y[3] = x[3];
+      if (any) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xs = fma(x[c], x[c], xs), ss = fma(x[c] - y[c], x[c] - y[c], ss);
+      }
+    }
+    if (j == 0) {
+      const double* d = T.delta_b + 6 * T.n_bias;
+      double y[3];
+      sphere_plus(T.gravity, d, y);
+      const bool any = T.D2b[6 * T.n_bias] != 0.0 || T.D2b[6 * T.n_bias + 1] != 0.0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        T.gravity_cand[c] = y[c];
+        if (any) xs = fma(T.gravity[c], T.gravity[c], xs), ss = fma(T.gravity[c] - y[c], T.gravity[c] - y[c], ss);
+      }
+    }
+  }
+  double* lds = &red[0][0];
+  xs = block_sum(xs, lds), ss = block_sum(ss, lds);
+  if (threadIdx.x == 0) T.norm_part[2 * blk] = xs, T.norm_part[2 * blk + 1] = ss;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Trust-region state machine (one workgroup). Restates TrustRegionMinimizer::Minimize + LevenbergMarquardtStrategy
+// (Ceres) with the in-tree options of optimizer.cpp:38-54.
+//   phase 0: after the first linearisation — record iteration 0.
+//   phase 1: after the candidate cost — accept / reject, radius update, termination tests.
+// ---------------------------------------------------------------------------------------------------------------------
+HSD double ordered_sum(const double* p, int n, double* lds) {
+  return block_sum(strided_sum(p, n), lds);
+}
+
+__global__ void __launch_bounds__(kBlock) k_cost_reduce(Tables T) {
+  // (global) cost of the current linearisation point -> st->cost, gradient max norm -> st->gmax; iteration bookkeeping
+  __shared__ double red[kBlock / 64];
+  DevState* st = T.st;
+  if (st->done) return;
+  double gm = strided_max(T.gabs, T.np + T.nb);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) gm = fmax(gm, __shfl_xor(gm, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gm;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  for (int i = 1; i < int(blockDim.x >> 6); ++i) gm = fmax(gm, red[i]);
+  const double c = T.xbuf[T.xo_cost];
+  for (int r = 0; r < T.world; ++r) gm = fmax(gm, T.xbuf[T.xo_gmax + r]);
+  begin_iteration(T, c, gm, true);
+}
+
+/// (global) cost and gradient max norm of the current linearisation point -> state; iteration 0 record; termination tests
+/// that precede a step (single lane).
+HSD void begin_iteration(const Tables& T, double c, double gm, bool set_scaling_ready) {
+  DevState* st = T.st;
+  st->cost = c;
+  st->gmax = gm;
+  st->chol_failed = 0;    // raised by the factorisation kernels of this iteration
+  if (set_scaling_ready) st->scaling_ready = 1;  // Jacobi scaling is computed at iteration 0 only (else: set by decide_step)
+  if (st->iteration == 0) {
+    hs_iteration& r = st->records[0];
+    r.iteration = 0, r.step_is_valid = 1, r.step_is_successful = 1, r.cost = c, r.cost_change = 0, r.gradient_max_norm = gm;
+    r.step_norm = 0, r.relative_decrease = 0, r.radius = st->radius;
+    st->iteration = 1;
+  }
+  // FinalizeIterationAndCheckIfMinimizerCanContinue
+  if (st->iteration - 1 >= st->max_iterations) {
+    st->done = 1, st->termination = HS_NO_CONVERGENCE;
+  } else if (gm <= 1e-10) {
+    st->done = 1, st->termination = HS_CONVERGENCE;
+  } else if (st->radius <= 1e-32) {
+    st->done = 1, st->termination = HS_CONVERGENCE;
+  }
+}
+
+HSD void decide_step(const Tables& T);
+
+/// Second exchange buffer (5 doubles, additive across shards): candidate cost, |x|^2, |x - x+|^2 and the landmark-side
+/// terms of the model cost change. The replicated control-point part of the norms is contributed by rank 0 only.
+__global__ void __launch_bounds__(kBlock) k_pack_decision(Tables T, int decide_here /* no exchange between packing and deciding */) {
+  __shared__ double red[kBlock / 64];
+  DevState* st = T.st;
+  if (st->done) return;
+  // The partial arrays are short (one entry per workgroup of the producing kernels): one combined pass with every load of a round
+  // issued before the first use (six separate strided sums cost six memory round trips, 8 us). Fixed order: bit-reproducible.
+  double cand = 0.0, xs = 0.0, ss = 0.0, gd = 0.0, dd = 0.0;
+  const int n_max = max(T.n_cost_part, max(T.n_lm_part, T.n_norm_part));
+  const bool with_replicated = T.rank == 0;  // control points / bias points / gravity are counted once
+  for (int i0 = threadIdx.x; i0 < n_max; i0 += 4 * kBlock) {
+    double c[4];
+    double2 la[4], lb[4], nr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * kBlock;
+      c[u] = i < T.n_cost_part ? T.cand_part[i] : 0.0;
+      const double2* lp = reinterpret_cast<const double2*>(T.lm_part) + 2 * size_t(i);
+      la[u] = i < T.n_lm_part ? lp[0] : make_double2(0.0, 0.0);  // (|x|^2, |x - x+|^2)
+      lb[u] = i < T.n_lm_part ? lp[1] : make_double2(0.0, 0.0);  // (g.step, step'D^2 step)
+      nr[u] = (with_replicated && i < T.n_norm_part) ? reinterpret_cast<const double2*>(T.norm_part)[i] : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      cand += c[u];
+      xs += la[u].x, ss += la[u].y, gd += lb[u].x, dd += lb[u].y;
+      xs += nr[u].x, ss += nr[u].y;
+    }
+  }
+  cand = block_sum(cand, red), xs = block_sum(xs, red), ss = block_sum(ss, red), gd = block_sum(gd, red), dd = block_sum(dd, red);
+  if (threadIdx.x == 0) {
+    double* D = T.xbuf + T.xo_dec;
+    D[0] = cand, D[1] = xs, D[2] = ss, D[3] = gd, D[4] = dd;
+    if (decide_here) decide_step(T);
+  }
+}
+
+/// Trust-region decision of one LM iteration (single lane): step quality, acceptance, radius update, termination tests.
+HSD void decide_step(const Tables& T) {
+  DevState* st = T.st;
+  const double* D = T.xbuf + T.xo_dec;
+  const double cand = D[0], xs = D[1], ss = D[2];
+  // model_cost_change = -g.step/2 + step'D^2 step/2 (exact for the solved system; TrustRegionMinimizer evaluates
+  // -(J step).(r + J step/2), identical algebraically)
+  const double g_step = st->g_dot_step_pose + D[3], d_step = st->d2_step2_pose + D[4];
+  const double mcc = -0.5 * g_step + 0.5 * d_step;
+  st->model_cost_change = mcc;
+  st->scaling_ready = 1;  // a step was computed: the Jacobi scaling of this solve is fixed from here on
+  st->step_valid = (isfinite(mcc) && !st->chol_failed && mcc >= 0.0) ? 1 : 0;
+  const int it = st->iteration;
+  hs_iteration& r = st->records[it];
+  r.iteration = it, r.cost = st->cost, r.cost_change = 0, r.gradient_max_norm = st->gmax, r.step_norm = 0, r.relative_decrease = 0;
+  r.step_is_valid = st->step_valid, r.step_is_successful = 0;
+  st->num_iterations = it;
+  st->accepted = 0;
+  st->gmax_bits = 0ull, st->gmax_pose_bits = 0ull;  // the next linearisation re-accumulates them
+  if (!st->step_valid) {  // HandleInvalidStep
+    if (++st->invalid_streak >= 5) {
+      st->done = 1, st->termination = HS_FAILURE;
+    } else {
+      st->radius *= 0.5;
+    }
+    r.radius = st->radius;
+    st->iteration = it + 1;
+    return;
+  }
+  st->invalid_streak = 0;
+  st->cand_cost = cand;
+  r.step_norm = sqrt(ss);
+  // ParameterToleranceReached
+  if (r.step_norm <= 1e-8 * (sqrt(xs) + 1e-8)) {
+    st->done = 1, st->termination = HS_CONVERGENCE;
+    r.radius = st->radius;
+    return;
+  }
+  // FunctionToleranceReached
+  r.cost_change = st->cost - cand;
+  if (fabs(r.cost_change) <= 1e-6 * st->cost) {
+    st->done = 1, st->termination = HS_CONVERGENCE;
+    r.radius = st->radius;
+    return;
+  }
+  r.relative_decrease = (st->cost - cand) / st->model_cost_change;
+  if (r.relative_decrease > 1e-3) {  // HandleSuccessfulStep
+    r.step_is_successful = 1;
+    st->accepted = 1;
+    st->num_successful++;
+    st->cost = cand;
+    r.cost = cand;
+    const double q = 2.0 * r.relative_decrease - 1.0;
+    st->radius = fmin(1e16, st->radius / fmax(1.0 / 3.0, 1.0 - q * q * q));
+    st->decrease_factor = 2.0;
+  } else {
+    st->radius = st->radius / st->decrease_factor;
+    st->decrease_factor *= 2.0;
+  }
+  r.radius = st->radius;
+  st->iteration = it + 1;
+}
+
+__global__ void __launch_bounds__(kBlock) k_decide(Tables T) {
+  if (T.st->done || threadIdx.x != 0) return;
+  decide_step(T);
+}
+
+/// x <- candidate when the step was accepted.
+__global__ void __launch_bounds__(kBlock) k_commit(Tables T) {
+  // note: reads `accepted` even when `done` was just set by a convergence test (those leave accepted = 0)
+  if (!T.st->accepted) return;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < 8 * T.sp.n_cp) T.cp[idx] = T.cp_cand[idx];
+  for (int l = idx; l < 3 * T.n_lm; l += gridDim.x * blockDim.x) T.lm[l] = T.lm_cand[l];
+  if (T.nb > 0) {
+    for (int e = idx; e < 4 * T.n_bias; e += gridDim.x * blockDim.x) T.bias_g[e] = T.bias_g_cand[e], T.bias_a[e] = T.bias_a_cand[e];
+    if (idx < 3) T.gravity[idx] = T.gravity_cand[idx];
+  }
+}
+
+}  // namespace hs

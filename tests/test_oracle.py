@@ -155,3 +155,22 @@ def test_oracle_manifolds_match_golden(oracle):
 def test_oracle_process_tracks_matches_golden(oracle):
     """Pixel -> bearing (20 fixed-point undistortion steps vs the exact root) and stereo triangulation against 100-digit vectors."""
     assert check_tracks_against_golden(oracle, 1e-10) <= 1e-10
+
+
+def test_bench_helpers(tmp_path):
+    """bench.py plumbing that runs without a GPU: natural ordering of the committed profile files (r01_v12 after r01_v7) and the
+    all-cores CPU leg's worker process (one oracle optimize() started at a common wall-clock instant, result as one JSON line)."""
+    import json
+    import sys
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    names = [os.path.basename(f) for f in bench._newest("r*_bench_kernel_stats.csv")]
+    keys = [[int(x) for x in re.findall(r"\d+", n)] for n in names]
+    assert keys == sorted(keys) and len(names) >= 2
+    assert bench.rocprof_kernel_ms("void hs::k_linearize_visual<4>") > 0 and bench.pmc_traffic("hs::k_linearize_visual<4>") > 1e6
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-worker", os.path.join(ROOT, "oracle", "liboracle.so"), repr(time.time() + 1.0)],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["iters"] == bench.LM_ITERATIONS and rec["late"] in (0, 1) and rec["end"] > time.time() - 300

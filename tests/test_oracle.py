@@ -174,3 +174,66 @@ def test_bench_helpers(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec["iters"] == bench.LM_ITERATIONS and rec["late"] in (0, 1) and rec["end"] > time.time() - 300
+
+
+def _mixed_window():
+    w = synthetic.small_inertial(order=4, n_cp=16, n_landmarks=30, obs_pairs=3, n_inertial=200, seed=61, identity=False)
+    e = synthetic.small_visual(order=4, n_cp=16, n_landmarks=4, obs_pairs=2, seed=61, with_priors=30)
+    lo, hi = w.valid_range()
+    w.sensor_T_bs, w.prior_stamps, w.prior_poses, w.prior_sensor = e.sensor_T_bs, np.clip(e.prior_stamps, lo, hi - 1e-9), e.prior_poses, e.prior_sensor
+    return w
+
+
+def test_oracle_world_frame_invariance(oracle):
+    """Physics check that needs no reference values: moving the whole world by a rigid transform G (control points, landmarks,
+    gravity, pose-prior measurements) leaves every pixel / inertial residual and the total cost unchanged (the cumulative SU2 x R^3
+    spline is left-equivariant); pose-prior residuals are expressed in the world frame, so they rotate but keep their norms."""
+    import copy
+    w = _mixed_window()
+    qg = synthetic.quat_exp(np.array([[0.7, -0.4, 1.1]]))[0]
+    Rg, tg = synthetic.quat_to_matrix(qg[None])[0], np.array([3.0, -2.0, 0.5])
+    v = copy.deepcopy(w)
+    for tab in ("control_points", "prior_poses"):
+        a = getattr(v, tab).copy()
+        a[:, :4] = synthetic.quat_mul(np.broadcast_to(qg, (len(a), 4)), a[:, :4])
+        a[:, 4:7] = a[:, 4:7] @ Rg.T + tg
+        setattr(v, tab, a)
+    v.landmarks, v.gravity = w.landmarks @ Rg.T + tg, Rg @ w.gravity
+    with ha.Problem(w, lib=oracle) as a, ha.Problem(v, lib=oracle) as b:
+        assert abs(a.cost() - b.cost()) <= 1e-12 * a.cost()
+        for t in (ha.HS_PIXEL, ha.HS_INERTIAL):
+            ra, rb = a.linearize(t, robustify=False)["r"], b.linearize(t, robustify=False)["r"]
+            assert np.abs(ra - rb).max() <= 1e-11 * np.abs(ra).max()
+        ra, rb = a.linearize(ha.HS_PRIOR, robustify=False)["r"], b.linearize(ha.HS_PRIOR, robustify=False)["r"]
+        assert np.abs(np.linalg.norm(ra, axis=1) - np.linalg.norm(rb, axis=1)).max() <= 1e-11
+
+
+def test_oracle_time_shift_invariance(oracle):
+    """Shifting every stamp (control points, bias control points, residuals) by the same amount changes nothing."""
+    import copy
+    w = _mixed_window()
+    lo, hi = w.valid_range()
+    for f in ("pixel_stamps", "prior_stamps", "inertial_stamps"):  # keep clear of the window ends: (t - t0) / dt at a knot is not
+        setattr(w, f, np.clip(getattr(w, f), lo + 1e-6, hi - 1e-6))  # shift-invariant in floating point (0.1 is not a binary fraction)
+    v, shift = copy.deepcopy(w), 8.0
+    v.t0 = w.t0 + shift
+    cp = v.control_points.copy()
+    cp[:, 7] += shift
+    v.control_points = cp
+    for f in ("pixel_stamps", "prior_stamps", "inertial_stamps"):
+        setattr(v, f, getattr(w, f) + shift)
+    v.imu = dict(w.imu)
+    v.imu["bias_t0"] = w.imu["bias_t0"] + shift
+    for key in ("bias_g", "bias_a"):
+        bb = np.array(w.imu[key], float).copy()
+        bb[:, 3] += shift
+        v.imu[key] = bb
+    with ha.Problem(w, lib=oracle) as a, ha.Problem(v, lib=oracle) as b:
+        assert abs(a.cost() - b.cost()) <= 1e-9 * a.cost()
+        for t in (ha.HS_PIXEL, ha.HS_PRIOR, ha.HS_INERTIAL):
+            la, lb = a.linearize(t, robustify=True), b.linearize(t, robustify=True)
+            assert np.array_equal(la["first_cp"], lb["first_cp"])
+            for key in ("r", "J_state"):
+                assert rel(la[key], lb[key]) < 1e-8, (t, key, rel(la[key], lb[key]))
+        sa, sb = a.solve(3), b.solve(3)
+        assert abs(sa["final_cost"] - sb["final_cost"]) <= 1e-6 * sa["final_cost"]

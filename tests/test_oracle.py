@@ -157,7 +157,7 @@ def test_oracle_process_tracks_matches_golden(oracle):
     assert check_tracks_against_golden(oracle, 1e-10) <= 1e-10
 
 
-def test_bench_helpers(tmp_path):
+def test_bench_helpers(oracle):
     """bench.py plumbing that runs without a GPU: natural ordering of the committed profile files (r01_v12 after r01_v7) and the
     all-cores CPU leg's worker process (one oracle optimize() started at a common wall-clock instant, result as one JSON line)."""
     import json
@@ -169,7 +169,7 @@ def test_bench_helpers(tmp_path):
     keys = [[int(x) for x in re.findall(r"\d+", n)] for n in names]
     assert keys == sorted(keys) and len(names) >= 2
     assert bench.rocprof_kernel_ms("void hs::k_linearize_visual<4>") > 0 and bench.pmc_traffic("hs::k_linearize_visual<4>") > 1e6
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-worker", os.path.join(ROOT, "oracle", "liboracle.so"), repr(time.time() + 1.0)],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-worker", oracle.path, repr(time.time() + 1.0)],
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads(out.stdout.strip().splitlines()[-1])

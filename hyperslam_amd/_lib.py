@@ -113,9 +113,10 @@ _PRODUCT_ONLY = {
     "arch": (C.c_char_p, []),
     "rccl_unique_id": (C.c_int, [C.c_char_p]),
     "rccl_init": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
+    "rccl_shutdown": (C.c_int, [C.c_void_p]),
 }
 
-# every symbol include/hyperslam_hip.h declares (checked by tests/test_abi.py)
+# every symbol include/hyperslam_hip.h declares (checked by tests/test_oracle.py::test_abi_exports)
 ABI_SYMBOLS = ["hs_" + n for n in list(_SIGNATURES) + list(_PRODUCT_ONLY)]
 
 

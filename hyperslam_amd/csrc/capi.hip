@@ -452,6 +452,7 @@ int prepare(hs_problem* p) {
   //    4 one-ended pre-look-ahead factorisation kernel                16 phase timestamps of the factorisation -> hs_debug_read
   //   32 per-workgroup timestamps of the linearise / gram kernels   1024 no side stream for the segment partials
   // 2048 one-ended factorisation (no second workgroup)              8192 generalised backward sweep on the one-ended factor
+  // 65536 four-wave LDS backward sweeps of round 1 instead of the single-wave register sweep
   T.debug_flags = std::getenv("HS_DEBUG_FLAGS") ? std::atoi(std::getenv("HS_DEBUG_FLAGS")) : 0;
   T.st = p->d_state.p;
   HIP_TRY(hipStreamSynchronize(s));  // host staging vectors go out of scope
@@ -602,8 +603,14 @@ int launch_factor(hs_problem* p) {
     Tables T3 = T2;
     T3.join_epoch = ++p->join_epoch;
     const BackJob j0{T.Ub, T.Ubk, T.ybuf, m + w_mid, 0, 0}, j1{p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, mB, w_mid, 1};
-    const size_t g_lds = size_t(6 * (T.bw - 1)) * (6 * (T.bw - 1) | 1) * sizeof(double);  // given-column block of the far sweep
-    k_band_backward2<<<2, kCholThreads, 2 * size_t(T.np) * sizeof(double) + g_lds, s>>>(T3, j0, j1, m);
+    if (T.debug_flags & 65536) {  // A/B: the four-wave LDS sweep of round 1
+      const size_t g_lds = size_t(6 * (T.bw - 1)) * (6 * (T.bw - 1) | 1) * sizeof(double);  // given-column block of the far sweep
+      k_band_backward2<<<2, kCholThreads, 2 * size_t(T.np) * sizeof(double) + g_lds, s>>>(T3, j0, j1, m);
+    } else if (6 * T.bw <= 128) {
+      k_band_backward_w<2><<<2, 64, 0, s>>>(T3, j0, j1, m);
+    } else {
+      k_band_backward_w<4><<<2, 64, 0, s>>>(T3, j0, j1, m);
+    }
     HIP_TRY(hipGetLastError());
     return HS_OK;
   }
@@ -613,8 +620,9 @@ int launch_factor(hs_problem* p) {
   //  kernel spills in its update loop - wider bands stay on the kernel below)
   else if (T.bw * T.bw <= kCholThreads)
     k_band_factor<1><<<1, kCholThreads + kCholIo, chol_lds, s>>>(T);
-  else if (T.bw * T.bw <= 2 * kCholThreads)  // bw = 21, 22: too many tiles for the look-ahead kernel's 192 compute lanes
-    k_band_factor<2><<<1, kCholThreads + kCholIo, chol_lds, s>>>(T);
+  else if (T.bw <= 21)  // two tiles per lane; the IO wave moves 12 x 64 entries per block row: 6 (6 bw + 1) <= 768 <=> bw <= 21
+    k_band_factor<2><<<1, kCholThreads + kCholIo, chol_lds, s>>>(T);  // (bw = 22 dropped entries of every block row in round 1:
+                                                                      //  found by the lock-step replay, tests/test_host_driver.py)
   else  // long feature tracks: trailing window in L2 instead of registers
     k_band_factor_wide<<<1, kWideThreads, size_t(12) * (ncb + 2) * sizeof(double), s>>>(T);
   if (T.nb) {  // bordered system (bias splines + gravity)
@@ -629,8 +637,14 @@ int launch_factor(hs_problem* p) {
     const BackJob j0{T.Ub, T.Ubk, T.ybuf, T.np / 6, 0, 0};
     k_band_backward2<<<1, kCholThreads, 2 * size_t(T.np) * sizeof(double), s>>>(T, j0, j0, -1);
     k_step_outputs<<<1, kBlock, 0, s>>>(T);
-  } else {
+  } else if (T.debug_flags & 65536) {  // A/B: the four-wave LDS sweep of round 1
     k_band_backward<<<1, kCholThreads, 2 * size_t(T.np) * sizeof(double), s>>>(T);
+  } else {
+    const BackJob j0{T.Ub, T.Ubk, T.ybuf, T.np / 6, 0, 0};
+    if (6 * T.bw <= 128)
+      k_band_backward_w<2><<<1, 64, 0, s>>>(T, j0, j0, -1);
+    else
+      k_band_backward_w<4><<<1, 64, 0, s>>>(T, j0, j0, -1);
   }
   HIP_TRY(hipGetLastError());
   return HS_OK;
@@ -1168,12 +1182,26 @@ int hs_rccl_init(hs_problem* p, const char id[128], int rank, int world) {
   RcclApi* api = rccl_api();
   if (!api) HS_FAIL(HS_ERR_DEVICE, "librccl.so could not be loaded");
   HIP_TRY(hipSetDevice(p->device));
+  if (p->rccl_comm) {  // a second initialisation replaces the communicator instead of leaking it
+    (void)api->CommDestroy(static_cast<ncclComm_t>(p->rccl_comm));
+    p->rccl_comm = nullptr;
+  }
   ncclUniqueId u;
   std::memcpy(&u, id, 128);
   ncclComm_t comm = nullptr;
   const ncclResult_t r = api->CommInitRank(&comm, world, u, rank);
   if (r != ncclSuccess) HS_FAIL(HS_ERR_DEVICE, std::string("ncclCommInitRank failed: ") + (api->GetErrorString ? api->GetErrorString(r) : "?"));
   p->rccl_comm = comm;
+  return HS_OK;
+}
+
+int hs_rccl_shutdown(hs_problem* p) {
+  if (!p) return HS_ERR_INVALID;
+  if (p->rccl_comm && rccl_api()) {
+    (void)hipStreamSynchronize(p->stream);
+    (void)rccl_api()->CommDestroy(static_cast<ncclComm_t>(p->rccl_comm));
+  }
+  p->rccl_comm = nullptr;
   return HS_OK;
 }
 

@@ -20,5 +20,6 @@
 #include "kernels_schur.hpp"
 #include "kernels_border.hpp"
 #include "kernels_factor.hpp"
+#include "kernels_backward.hpp"
 #include "kernels_update.hpp"
 #include "kernels_aux.hpp"

@@ -229,7 +229,7 @@ HSD void decide_step(const Tables& T) {
   const double mcc = -0.5 * g_step + 0.5 * d_step;
   st->model_cost_change = mcc;
   st->scaling_ready = 1;  // a step was computed: the Jacobi scaling of this solve is fixed from here on
-  st->step_valid = (isfinite(mcc) && !st->chol_failed && mcc >= 0.0) ? 1 : 0;
+  st->step_valid = (isfinite(mcc) && !st->chol_failed && mcc > 0.0) ? 1 : 0;  // TrustRegionMinimizer: step_is_valid = model_cost_change > 0
   const int it = st->iteration;
   hs_iteration& r = st->records[it];
   r.iteration = it, r.cost = st->cost, r.cost_change = 0, r.gradient_max_norm = st->gmax, r.step_norm = 0, r.relative_decrease = 0;
@@ -274,6 +274,7 @@ HSD void decide_step(const Tables& T) {
     st->radius = fmin(1e16, st->radius / fmax(1.0 / 3.0, 1.0 - q * q * q));
     st->decrease_factor = 2.0;
   } else {
+    r.cost = cand;  // TrustRegionMinimizer reports the candidate's cost for an unsuccessful step (the point itself is unchanged)
     st->radius = st->radius / st->decrease_factor;
     st->decrease_factor *= 2.0;
   }

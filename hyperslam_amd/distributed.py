@@ -109,4 +109,7 @@ def attach_rccl(problem, dist, group=None):
             print(f"hyperslam_amd: hs_rccl_init failed on rank {rank}: {msg.decode() if msg else ''}", file=sys.stderr)
     flag = torch.tensor([ok], dtype=torch.int64, device=comm_device)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    return bool(flag.item())
+    agreed = bool(flag.item())
+    if not agreed:  # a rank that did get a communicator must not keep it: every rank has to issue the same collectives
+        problem.lib.rccl_shutdown(problem.h)
+    return agreed

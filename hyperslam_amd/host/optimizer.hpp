@@ -17,6 +17,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <fstream>
+#include <functional>
 #include <iomanip>
 #include <map>
 #include <memory>
@@ -40,6 +41,7 @@ int HSF(destroy)(hs_problem*);
 const char* HSF(last_error)(const hs_problem*);
 int HSF(set_spline)(hs_problem*, int, double, double, int, const double*, const uint8_t*, int, int);
 int HSF(set_cameras)(hs_problem*, int, const double*, const double*, const double*);
+int HSF(set_sensors)(hs_problem*, int, const double*);
 int HSF(set_landmarks)(hs_problem*, int, const double*, const uint8_t*);
 int HSF(set_imu)(hs_problem*, const double*, const double*, const double*, const double*, const double*, int, double, double, int, const double*,
                  const double*, int);
@@ -160,8 +162,80 @@ struct Options {  // backend YAML keys actually read: separation
   int max_num_iterations = 5;  // optimizer.cpp:40
 };
 
+/// Everything optimize() hands to the library for one solve, as flat arrays in the C ABI's table layouts.
+struct WindowTables {
+  int order = 4;
+  double t0 = 0, dt = 0.1;
+  int rotation_constant = 0, translation_constant = 0;
+  std::vector<double> cp;              // n_cp x 8
+  std::vector<uint8_t> cp_constant;    // n_cp
+  std::vector<double> cam_T, cam_I, cam_D;
+  std::vector<double> landmarks;       // n x 3
+  std::vector<double> br_stamp, br_bearing;
+  std::vector<int32_t> br_lm, br_cam;
+  std::vector<double> pr_stamp, pr_pose;  // pose priors against the identity sensor (ManifoldMeasurement)
+  bool has_imu = false;
+  double imu_T[7] = {0, 0, 0, 1, 0, 0, 0}, imu_i_g[6] = {1, 1, 1, 0, 0, 0}, imu_i_a[6] = {1, 1, 1, 0, 0, 0}, imu_S_g[9] = {0}, imu_X_a[9] = {0};
+  int bias_order = 4;
+  double bias_t0 = 0, bias_dt = 1;
+  std::vector<double> bias_g, bias_a;  // n_bias x 4
+  double gravity[3] = {0, 0, -9.80665};
+  int gravity_constant = 1;
+  std::vector<double> in_stamp, in_meas;
+
+  int numControlPoints() const { return int(cp.size() / 8); }
+  int numFrozen() const { return int(std::count_if(cp_constant.begin(), cp_constant.end(), [](uint8_t c) { return c != 0; })); }
+  int numResidualBlocks() const { return int(br_stamp.size() + pr_stamp.size() + in_stamp.size()); }
+
+  /// Hands the tables to a library through its C ABI entry points (template arguments: the library's functions).
+  template <auto SetSpline, auto SetCameras, auto SetSensors, auto SetLandmarks, auto SetImu, auto SetGravity, auto SetBearing, auto SetPixel, auto SetPrior,
+            auto SetInertial, class Check>
+  void upload(hs_problem* h, Check&& check) const {
+    uploadWith(h, SetSpline, SetCameras, SetSensors, SetLandmarks, SetImu, SetGravity, SetBearing, SetPixel, SetPrior, SetInertial, check);
+  }
+  /// Same with run-time function pointers (a library resolved with dlsym).
+  template <class F1, class F2, class F3, class F4, class F5, class F6, class F7, class F8, class F9, class F10, class Check>
+  void uploadWith(hs_problem* h, F1 set_spline, F2 set_cameras, F3 set_sensors, F4 set_landmarks, F5 set_imu, F6 set_gravity, F7 set_bearing, F8 set_pixel,
+                  F9 set_prior, F10 set_inertial, Check&& check) const {
+    check(set_spline(h, order, t0, dt, numControlPoints(), cp.data(), cp_constant.data(), rotation_constant, translation_constant), "set_spline");
+    check(set_cameras(h, int(cam_T.size() / 7), cam_T.data(), cam_I.data(), cam_D.data()), "set_cameras");
+    static const double identity[7] = {0, 0, 0, 1, 0, 0, 0};
+    check(set_sensors(h, 1, identity), "set_sensors");
+    check(set_landmarks(h, int(landmarks.size() / 3), landmarks.data(), nullptr), "set_landmarks");
+    check(set_bearing(h, int(br_stamp.size()), br_stamp.data(), br_bearing.data(), br_lm.data(), br_cam.data()), "set_bearing_residuals");
+    check(set_pixel(h, 0, nullptr, nullptr, nullptr, nullptr), "set_pixel_residuals");
+    const std::vector<int32_t> sensor(pr_stamp.size(), 0);
+    check(set_prior(h, int(pr_stamp.size()), pr_stamp.data(), pr_pose.data(), sensor.data()), "set_prior_residuals");
+    if (has_imu) {
+      check(set_imu(h, imu_T, imu_i_g, imu_i_a, imu_S_g, imu_X_a, bias_order, bias_t0, bias_dt, int(bias_g.size() / 4), bias_g.data(), bias_a.data(), 0), "set_imu");
+      check(set_gravity(h, gravity, gravity_constant), "set_gravity");
+    }
+    check(set_inertial(h, int(in_stamp.size()), in_stamp.data(), in_meas.data()), "set_inertial_residuals");
+  }
+};
+
 /// Mirror of `Optimizer<OptimizerSuite::CERES>` + the non-virtual logic of `AbstractOptimizer` behind the C ABI.
 class Optimizer {
+  struct ControlPoint {
+    Stamp stamp;
+    SE3 T;
+    uint8_t constant = 0;
+  };
+  struct Observation {
+    Stamp stamp;
+    int32_t camera;
+    Vec3 bearing;
+  };
+  struct Landmark {
+    Vec3 position{0, 0, 0};
+    std::vector<Observation> observations;
+    Stamp lower = 0, upper = 0;  // AbstractLandmark::range() (landmarks/abstract.cpp:62-99)
+  };
+  struct BiasPoint {
+    Stamp stamp;
+    Vec3 g{0, 0, 0}, a{0, 0, 0};
+  };
+
  public:
   Optimizer(const Options& options, const std::vector<Camera>& cameras, const IMU* imu = nullptr, int device = 0)
       : opt_(options), cameras_(cameras), has_imu_(imu != nullptr) {
@@ -181,10 +255,13 @@ class Optimizer {
   size_t numLandmarks() const { return landmarks_.size(); }
   size_t numControlPoints() const { return cp_.size(); }
 
-  /// State range = stamps for which all k control points exist (EXTERNAL AbstractState::range()).
+  /// State range = stamps for which all k control points exist (EXTERNAL AbstractState::range()): with the uniform basis of
+  /// order k the segment [t_i, t_i+1) uses control points i - (k-1)/2 .. i - (k-1)/2 + k - 1, so the range runs from the stamp of
+  /// control point (k-1)/2 to the stamp of control point n - k/2 (the same bound as the library's own validity check,
+  /// host_structure.hpp n_seg, and as the bootstrap window [0, separation) of k control points, abstract.cpp:76-96).
   Range stateRange() const {
     const int k = opt_.order;
-    return {cp_[(k - 1) / 2].stamp, cp_[cp_.size() - 1 - k / 2].stamp};
+    return {cp_[(k - 1) / 2].stamp, cp_[cp_.size() - k / 2].stamp};
   }
 
   // ---- AbstractOptimizer::submit (abstract.cpp:74-147) ----
@@ -194,95 +271,111 @@ class Optimizer {
 
   // ---- AbstractOptimizer::setWindow (abstract.cpp:40-62) ----
   void setWindow(const Range& window) {
+    // abstract.cpp:42 reads state().range() before anything is pruned, and upstream never removes elements from the state itself
+    // (updateState only removes ceres parameter blocks, optimizer.cpp:331-341): the range keeps its original lower bound. This
+    // mirror drops unreachable control points from cp_, so the unpruned lower bound is remembered separately.
+    const Range range{unpruned_lower_, stateRange().upper};
     window_ = window;
     updateLandmarks(window_);
     updateState(window_);
-    const Range r = stateRange();
-    gravity_constant_ = window_.size() < r.size();  // abstract.cpp:57-61
+    gravity_constant_ = window_.size() < range.size();  // abstract.cpp:57-61
+  }
+
+  /// Builds the flat tables of the current window: the content upstream keeps in ceres::Problem (parameter blocks + residual
+  /// blocks of the window, optimizer.cpp:189-382). `order` receives the landmark behind every row of the landmark table.
+  WindowTables buildTables(std::vector<Landmark*>* order = nullptr) {
+    WindowTables t;
+    const int n_cp = int(cp_.size());
+    t.order = opt_.order, t.t0 = cp_.front().stamp, t.dt = opt_.separation;
+    t.rotation_constant = opt_.rotation_constant, t.translation_constant = opt_.translation_constant;
+    t.cp.resize(size_t(8) * n_cp), t.cp_constant.resize(n_cp);
+    for (int j = 0; j < n_cp; ++j) {
+      const ControlPoint& c = cp_[j];
+      double* o = &t.cp[8 * j];
+      o[0] = c.T.q.x, o[1] = c.T.q.y, o[2] = c.T.q.z, o[3] = c.T.q.w, o[4] = c.T.p[0], o[5] = c.T.p[1], o[6] = c.T.p[2], o[7] = c.stamp;
+      t.cp_constant[j] = c.constant;
+    }
+    t.cam_T.resize(7 * cameras_.size()), t.cam_I.resize(4 * cameras_.size()), t.cam_D.resize(4 * cameras_.size());
+    for (size_t c = 0; c < cameras_.size(); ++c) {
+      const SE3& x = cameras_[c].transformation;
+      const double v[7] = {x.q.x, x.q.y, x.q.z, x.q.w, x.p[0], x.p[1], x.p[2]};
+      std::copy(v, v + 7, &t.cam_T[7 * c]);
+      std::copy(cameras_[c].intrinsics.begin(), cameras_[c].intrinsics.end(), &t.cam_I[4 * c]);
+      std::copy(cameras_[c].distortion.begin(), cameras_[c].distortion.end(), &t.cam_D[4 * c]);
+    }
+    // landmarks + bearing residuals (the runtime uses bearing factors, abstract.cpp:243-260)
+    int32_t li = 0;
+    for (auto& [id, lm] : landmarks_) {
+      if (order) order->push_back(&lm);
+      t.landmarks.insert(t.landmarks.end(), lm.position.begin(), lm.position.end());
+      for (const Observation& ob : lm.observations) {
+        t.br_stamp.push_back(ob.stamp), t.br_lm.push_back(li), t.br_cam.push_back(ob.camera);
+        t.br_bearing.insert(t.br_bearing.end(), ob.bearing.begin(), ob.bearing.end());
+      }
+      ++li;
+    }
+    for (const ManifoldMeasurement& m : priors_) t.pr_stamp.push_back(m.stamp), t.pr_pose.insert(t.pr_pose.end(), m.value.begin(), m.value.end());
+    t.has_imu = has_imu_;
+    if (has_imu_) {
+      for (const InertialMeasurement& m : inertials_) t.in_stamp.push_back(m.stamp), t.in_meas.insert(t.in_meas.end(), m.value.begin(), m.value.end());
+      const SE3& x = imu_.transformation;
+      const double Tb[7] = {x.q.x, x.q.y, x.q.z, x.q.w, x.p[0], x.p[1], x.p[2]};
+      std::copy(Tb, Tb + 7, t.imu_T);
+      std::copy(imu_.gyroscope_intrinsics.begin(), imu_.gyroscope_intrinsics.end(), t.imu_i_g);
+      std::copy(imu_.accelerometer_intrinsics.begin(), imu_.accelerometer_intrinsics.end(), t.imu_i_a);
+      std::copy(imu_.gyroscope_sensitivity.begin(), imu_.gyroscope_sensitivity.end(), t.imu_S_g);
+      std::copy(imu_.accelerometer_axes_offsets.begin(), imu_.accelerometer_axes_offsets.end(), t.imu_X_a);
+      t.bias_order = imu_.bias_order, t.bias_t0 = bias_.front().stamp, t.bias_dt = imu_.bias_separation;
+      t.bias_g.resize(4 * bias_.size()), t.bias_a.resize(4 * bias_.size());
+      for (size_t j = 0; j < bias_.size(); ++j)
+        for (int c = 0; c < 4; ++c) t.bias_g[4 * j + c] = c < 3 ? bias_[j].g[c] : bias_[j].stamp, t.bias_a[4 * j + c] = c < 3 ? bias_[j].a[c] : bias_[j].stamp;
+      std::copy(gravity_.begin(), gravity_.end(), t.gravity);
+      t.gravity_constant = gravity_constant_;
+    }
+    return t;
   }
 
   /// CeresOptimizer::optimize (optimizer.cpp:276-280): flat tables -> hs_solve -> write back in place.
   void optimize() {
     const auto wall0 = std::chrono::steady_clock::now();
-    const int k = opt_.order, n_cp = int(cp_.size());
-    std::vector<double> cp(size_t(8) * n_cp);
-    std::vector<uint8_t> frozen(n_cp);
-    for (int j = 0; j < n_cp; ++j) {
-      const ControlPoint& c = cp_[j];
-      double* o = &cp[8 * j];
-      o[0] = c.T.q.x, o[1] = c.T.q.y, o[2] = c.T.q.z, o[3] = c.T.q.w, o[4] = c.T.p[0], o[5] = c.T.p[1], o[6] = c.T.p[2], o[7] = c.stamp;
-      frozen[j] = c.constant;
-    }
-    check(HSF(set_spline)(handle_, k, cp_.front().stamp, opt_.separation, n_cp, cp.data(), frozen.data(), opt_.rotation_constant, opt_.translation_constant),
-          "set_spline");
-    std::vector<double> T(7 * cameras_.size()), I(4 * cameras_.size()), D(4 * cameras_.size());
-    for (size_t c = 0; c < cameras_.size(); ++c) {
-      const SE3& t = cameras_[c].transformation;
-      const double v[7] = {t.q.x, t.q.y, t.q.z, t.q.w, t.p[0], t.p[1], t.p[2]};
-      std::copy(v, v + 7, &T[7 * c]);
-      std::copy(cameras_[c].intrinsics.begin(), cameras_[c].intrinsics.end(), &I[4 * c]);
-      std::copy(cameras_[c].distortion.begin(), cameras_[c].distortion.end(), &D[4 * c]);
-    }
-    check(HSF(set_cameras)(handle_, int(cameras_.size()), T.data(), I.data(), D.data()), "set_cameras");
-    // landmarks + bearing residuals (the runtime uses bearing factors, abstract.cpp:243-260)
-    std::vector<double> xyz, st, b;
-    std::vector<int32_t> lmi, cam;
     std::vector<Landmark*> order;
-    for (auto& [id, lm] : landmarks_) {
-      const int32_t li = int32_t(order.size());
-      order.push_back(&lm);
-      xyz.insert(xyz.end(), lm.position.begin(), lm.position.end());
-      for (const Observation& ob : lm.observations) {
-        st.push_back(ob.stamp), lmi.push_back(li), cam.push_back(ob.camera);
-        b.insert(b.end(), ob.bearing.begin(), ob.bearing.end());
-      }
-    }
-    check(HSF(set_landmarks)(handle_, int(order.size()), xyz.data(), nullptr), "set_landmarks");
-    check(HSF(set_bearing_residuals)(handle_, int(st.size()), st.data(), b.data(), lmi.data(), cam.data()), "set_bearing_residuals");
-    check(HSF(set_pixel_residuals)(handle_, 0, nullptr, nullptr, nullptr, nullptr), "set_pixel_residuals");
-    std::vector<double> pst, pval;
-    std::vector<int32_t> psen;
-    (void)psen;
-    check(HSF(set_prior_residuals)(handle_, 0, nullptr, nullptr, nullptr), "set_prior_residuals");
-    std::vector<double> ist, ival;
-    if (has_imu_) {
-      for (const InertialMeasurement& m : inertials_) ist.push_back(m.stamp), ival.insert(ival.end(), m.value.begin(), m.value.end());
-      const SE3& t = imu_.transformation;
-      const double Tb[7] = {t.q.x, t.q.y, t.q.z, t.q.w, t.p[0], t.p[1], t.p[2]};
-      std::vector<double> bg(4 * bias_.size()), ba(4 * bias_.size());
-      for (size_t j = 0; j < bias_.size(); ++j)
-        for (int c = 0; c < 4; ++c) bg[4 * j + c] = c < 3 ? bias_[j].g[c] : bias_[j].stamp, ba[4 * j + c] = c < 3 ? bias_[j].a[c] : bias_[j].stamp;
-      check(HSF(set_imu)(handle_, Tb, imu_.gyroscope_intrinsics.data(), imu_.accelerometer_intrinsics.data(), imu_.gyroscope_sensitivity.data(),
-                         imu_.accelerometer_axes_offsets.data(), imu_.bias_order, bias_.front().stamp, imu_.bias_separation, int(bias_.size()), bg.data(),
-                         ba.data(), 0),
-            "set_imu");
-      check(HSF(set_gravity)(handle_, gravity_.data(), gravity_constant_), "set_gravity");
-    }
-    check(HSF(set_inertial_residuals)(handle_, int(ist.size()), ist.data(), ival.data()), "set_inertial_residuals");
-    if (st.empty() && ist.empty()) return;  // nothing to optimise yet
+    const WindowTables t = buildTables(&order);
+    t.upload<&HSF(set_spline), &HSF(set_cameras), &HSF(set_sensors), &HSF(set_landmarks), &HSF(set_imu), &HSF(set_gravity), &HSF(set_bearing_residuals),
+             &HSF(set_pixel_residuals), &HSF(set_prior_residuals), &HSF(set_inertial_residuals)>(handle_, [&](int rc, const char* what) { check(rc, what); });
+    if (t.br_stamp.empty() && t.in_stamp.empty() && t.pr_stamp.empty()) return;  // nothing to optimise yet
+    if (before_solve) before_solve(t, num_optimizations_);
     const auto wall1 = std::chrono::steady_clock::now();
-    check(HSF(solve)(handle_, opt_.max_num_iterations, &last_summary_, nullptr), "solve");
+    last_iterations_.assign(size_t(opt_.max_num_iterations) + 1, hs_iteration{});
+    check(HSF(solve)(handle_, opt_.max_num_iterations, &last_summary_, last_iterations_.data()), "solve");
     const auto wall2 = std::chrono::steady_clock::now();
     ++num_optimizations_;
     // write back in place (the reference's solver mutates the variables through raw double*, optimizer.cpp:299-305,354-356)
-    check(HSF(get_control_points)(handle_, cp.data()), "get_control_points");
+    WindowTables r = t;  // result tables: the same window at the solver's final point
+    const int n_cp = int(cp_.size());
+    check(HSF(get_control_points)(handle_, r.cp.data()), "get_control_points");
     for (int j = 0; j < n_cp; ++j) {
-      const double* o = &cp[8 * j];
+      const double* o = &r.cp[8 * j];
       cp_[j].T = SE3{Quat{o[0], o[1], o[2], o[3]}, {o[4], o[5], o[6]}};
     }
-    check(HSF(get_landmarks)(handle_, xyz.data()), "get_landmarks");
-    for (size_t l = 0; l < order.size(); ++l) order[l]->position = {xyz[3 * l], xyz[3 * l + 1], xyz[3 * l + 2]};
+    if (!order.empty()) check(HSF(get_landmarks)(handle_, r.landmarks.data()), "get_landmarks");
+    for (size_t l = 0; l < order.size(); ++l) order[l]->position = {r.landmarks[3 * l], r.landmarks[3 * l + 1], r.landmarks[3 * l + 2]};
     if (has_imu_) {
-      std::vector<double> bg(4 * bias_.size()), ba(4 * bias_.size());
-      check(HSF(get_bias)(handle_, bg.data(), ba.data()), "get_bias");
+      check(HSF(get_bias)(handle_, r.bias_g.data(), r.bias_a.data()), "get_bias");
       for (size_t j = 0; j < bias_.size(); ++j)
-        for (int c = 0; c < 3; ++c) bias_[j].g[c] = bg[4 * j + c], bias_[j].a[c] = ba[4 * j + c];
-      check(HSF(get_gravity)(handle_, gravity_.data()), "get_gravity");
+        for (int c = 0; c < 3; ++c) bias_[j].g[c] = r.bias_g[4 * j + c], bias_[j].a[c] = r.bias_a[4 * j + c];
+      check(HSF(get_gravity)(handle_, r.gravity), "get_gravity");
+      std::copy(r.gravity, r.gravity + 3, gravity_.begin());
     }
     const auto wall3 = std::chrono::steady_clock::now();
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     wall_tables_ms_ += ms(wall0, wall1), wall_solve_ms_ += ms(wall1, wall2), wall_readback_ms_ += ms(wall2, wall3);
+    if (after_solve) after_solve(t, r, last_summary_, last_iterations_, num_optimizations_ - 1);
   }
+  /// Observers of optimize() (test harnesses only): `before_solve` sees the tables of the window right after they were handed to
+  /// the library, `after_solve` additionally the same tables at the solver's final point with its summary and iteration records.
+  std::function<void(const WindowTables&, int)> before_solve;
+  std::function<void(const WindowTables&, const WindowTables&, const hs_summary&, const std::vector<hs_iteration>&, int)> after_solve;
+  hs_problem* handle() const { return handle_; }
   /// Host wall-clock split of all optimize() calls so far: building + uploading the tables, hs_solve (structure, launches, sync), read-back.
   std::array<double, 3> wallSplitMs() const { return {wall_tables_ms_, wall_solve_ms_, wall_readback_ms_}; }
 
@@ -344,25 +437,6 @@ class Optimizer {
   }
 
  private:
-  struct ControlPoint {
-    Stamp stamp;
-    SE3 T;
-    uint8_t constant = 0;
-  };
-  struct Observation {
-    Stamp stamp;
-    int32_t camera;
-    Vec3 bearing;
-  };
-  struct Landmark {
-    Vec3 position{0, 0, 0};
-    std::vector<Observation> observations;
-    Stamp lower = 0, upper = 0;  // AbstractLandmark::range() (landmarks/abstract.cpp:62-99)
-  };
-  struct BiasPoint {
-    Stamp stamp;
-    Vec3 g{0, 0, 0}, a{0, 0, 0};
-  };
 
   void check(int rc, const char* what) const {
     if (rc != HS_OK) throw std::runtime_error(std::string(what) + " failed: " + HSF(last_error)(handle_));
@@ -398,21 +472,36 @@ class Optimizer {
       root_stamp_ = raw_stamp;
       const int k = opt_.order;
       for (int i = 0; i < k; ++i) cp_.push_back({0.0 + (i - (k - 1) / 2) * opt_.separation, SE3{}, 0});
+      unpruned_lower_ = stateRange().lower;
       if (has_imu_) extendBias(Range{0, opt_.separation});
       setWindow(Range{0, opt_.separation});
     }
     const Stamp stamp = raw_stamp - root_stamp_;
     const Range state_range = stateRange();
-    if (state_range.contains(stamp)) {
-      if (window_.contains(stamp)) do_process(stamp);
-      else throw std::runtime_error("message inside the state but outside the window: not implemented (abstract.cpp:109-112)");
+    // state_range.contains(stamp), evaluated with the library's own segment arithmetic (uniform knots t0 + j * separation,
+    // host_structure.hpp h_segment_first): the control-point stamps are accumulated sums (abstract.cpp:128) and differ from
+    // t0 + j * separation in the last bits, so comparing against them could admit a stamp the spline lookup then rejects.
+    const int seg = int(std::floor((stamp - cp_.front().stamp) / opt_.separation)) - (opt_.order - 1) / 2;
+    if (seg >= 0 && seg < int(cp_.size()) - opt_.order + 1) {
+      // window_.contains(stamp): the window's upper bound coincides with the state's by construction (both advance together,
+      // abstract.cpp:139-144), so inside the state only the lower bound remains to be checked
+      if (stamp >= window_.lower) do_process(stamp);
+      else throw std::runtime_error("message inside the state but before the window: not implemented (abstract.cpp:109-112)");
       return;
     }
-    if (stamp < state_range.lower) return;  // "Discarding out-of-scope message." (abstract.cpp:116)
+    if (seg < 0) return;  // "Discarding out-of-scope message." (abstract.cpp:116)
+    (void)state_range;
     optimize();                             // abstract.cpp:119
     const Stamp delta = stamp - window_.upper;
-    const int n = std::max(1, int(std::ceil(delta)));  // abstract.cpp:124 (in seconds, as written upstream)
+    // abstract.cpp:124: n = ceil(delta), delta in seconds as written upstream (one new control point for any gap up to 1 s).
+    // delta == 0 (a stamp exactly on the end of the state) gives n = 0 upstream, after which process() evaluates the state outside
+    // its range (undefined upstream); here that single case extends by one control point instead.
+    const int n_upstream = int(std::ceil(delta));
+    const int n = n_upstream < 1 ? 1 : n_upstream;
     for (int i = 1; i <= n; ++i) {                       // abstract.cpp:127-137: hold the second-to-last pose
+      // abstract.cpp:128 writes rbegin()->stamp() + i * separation with rbegin() re-read after every insertion: for n > 1 that
+      // spaces the new stamps by 1, 2, 3 ... separations, which a uniform basis cannot represent; the knots stay uniform here
+      // (identical for n = 1, the only case the 10 Hz cadence of the front-ends produces).
       const Stamp new_stamp = cp_.back().stamp + opt_.separation;
       const SE3 held = cp_[cp_.size() - 2].T;
       cp_.back().T = held;
@@ -474,7 +563,13 @@ class Optimizer {
     c.stamp = stamp;
     inertials_.push_back(c);
   }
-  void process(const ManifoldMeasurement&, Stamp) { throw std::runtime_error("pose priors are not fed by the runtime front-ends"); }
+  /// abstract.cpp:266-270: a pose measurement becomes a ManifoldObservation of the (identity-extrinsics) sensor -> pose-prior
+  /// residual block (optimizer.cpp:234-251).
+  void process(const ManifoldMeasurement& m, Stamp stamp) {
+    ManifoldMeasurement c = m;
+    c.stamp = stamp;
+    priors_.push_back(c);
+  }
 
   // ---- CeresOptimizer::updateLandmarks (optimizer.cpp:360-382): retire landmarks whose observation range left the window ----
   void updateLandmarks(const Range& range) {
@@ -495,6 +590,7 @@ class Optimizer {
       inertials_.erase(std::remove_if(inertials_.begin(), inertials_.end(), [&](const InertialMeasurement& m) { return m.stamp < oldest; }),
                        inertials_.end());
     }
+    priors_.erase(std::remove_if(priors_.begin(), priors_.end(), [&](const ManifoldMeasurement& m) { return m.stamp < oldest; }), priors_.end());
     const int k = opt_.order;
     size_t drop = 0;  // control points entirely before the segment of `oldest` (optimizer.cpp:331-341); the margin keeps a stamp that
                       // sits exactly on a knot inside the valid range whatever the rounding of (stamp - t0) / separation
@@ -523,13 +619,16 @@ class Optimizer {
   hs_problem* handle_ = nullptr;
   Stamp root_stamp_ = 0;
   Range window_;
+  Stamp unpruned_lower_ = 0;  // lower bound of state().range() upstream (elements are never removed from the state there)
   bool gravity_constant_ = false;
   Vec3 gravity_{0, 0, -9.80665};
   std::vector<ControlPoint> cp_;
   std::map<int64_t, Landmark> landmarks_;
   std::vector<InertialMeasurement> inertials_;
+  std::vector<ManifoldMeasurement> priors_;
   std::vector<BiasPoint> bias_;
   hs_summary last_summary_{};
+  std::vector<hs_iteration> last_iterations_;
   int num_optimizations_ = 0;
   double wall_tables_ms_ = 0, wall_solve_ms_ = 0, wall_readback_ms_ = 0;
 };

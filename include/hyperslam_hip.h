@@ -169,6 +169,9 @@ int hs_set_allreduce(hs_problem* p, hs_allreduce_fn fn, void* user);
  * hook of hs_set_allreduce, if any, is ignored. librccl.so is loaded on first use (no link-time dependency). */
 int hs_rccl_unique_id(char id[128]);
 int hs_rccl_init(hs_problem* p, const char id[128], int rank, int world);
+/* Destroys the communicator of hs_rccl_init (no-op without one): the exchanges fall back to the hs_set_allreduce hook. Every rank
+ * must call it when the collective initialisation did not succeed everywhere, so that all ranks issue the same collectives. */
+int hs_rccl_shutdown(hs_problem* p);
 /* Residual-sharded operation: this handle holds shard `rank` of `world` (all observations of a landmark on one rank,
  * control points / sensors replicated). min_band_blocks = max over ranks of hs_band_blocks() so that every rank uses the
  * same band layout for the exchanged reduced system. */

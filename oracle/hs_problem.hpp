@@ -681,7 +681,7 @@ struct LM {
         std::vector<double> m1(1, model_cost_change(ne, delta_p, delta_l));  // per-residual sum: additive across shards
         this->sum(m1);
         mcc = m1[0];
-        if (mcc < 0.0) valid = false;
+        if (!(mcc > 0.0)) valid = false;  // TrustRegionMinimizer: step_is_valid = model_cost_change > 0
       }
       if (!valid) {  // HandleInvalidStep
         if (++invalid_streak >= 5) { sum.termination = 2; sum.iterations.push_back(rec); break; }
@@ -734,6 +734,7 @@ struct LM {
         radius = std::min(kMaxRadius, radius);
         decrease_factor = 2.0;
       } else {
+        rec.cost = cand_cost;  // TrustRegionMinimizer reports the candidate's cost for an unsuccessful step
         radius = radius / decrease_factor;
         decrease_factor *= 2.0;
       }

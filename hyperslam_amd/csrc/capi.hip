@@ -103,6 +103,7 @@ struct hs_problem {
   DBuf<double> d_cost_part, d_cand_part, d_norm_part, d_dbg, d_dbg_cost;
   DBuf<DevState> d_state;
   DBuf<double> d_xbuf, d_xpart, d_segP, d_grpQ, d_gravity_part;
+  DBuf<double> d_Vb, d_Vb2, d_yt, d_yt2;  // block-row-scaled factors diag(U_jj^-1) U and right-hand sides for the register sweep
   DBuf<double> d_Sb2, d_g2, d_Ub2, d_Ubk2, d_ybuf2, d_win, d_xsol;  // two-ended factorisation: reversed system, its factor, junction window
   DBuf<unsigned> d_join;
   unsigned join_epoch = 0;
@@ -141,6 +142,8 @@ struct hs_problem {
   } while (0)
 
 namespace {
+
+int mfma_window_tiles(int bw);
 
 int prepare(hs_problem* p) {
   if (!p->dirty) return HS_OK;
@@ -355,6 +358,17 @@ int prepare(hs_problem* p) {
     HIP_TRY(hipMemsetAsync(p->d_Sb2.p, 0, p->d_Sb2.cap * sizeof(double), s));
   }
   HIP_TRY(p->d_g2.reserve(np));
+  {  // + a zero pad behind each array (operands of rows that do not exist, k_band_backward_w)
+    const size_t nv = size_t(np) * ncb, pad = 64;
+    for (DBuf<double>* b : {&p->d_Vb, &p->d_Vb2}) {
+      HIP_TRY(b->reserve(nv + pad));
+      HIP_TRY(hipMemsetAsync(b->p + nv, 0, pad * sizeof(double), s));
+    }
+    for (DBuf<double>* b : {&p->d_yt, &p->d_yt2}) {
+      HIP_TRY(b->reserve(size_t(np) + pad));
+      HIP_TRY(hipMemsetAsync(b->p + np, 0, pad * sizeof(double), s));
+    }
+  }
   HIP_TRY(p->d_Ub2.reserve(size_t(np) * ncb));
   HIP_TRY(p->d_Ubk2.reserve(size_t(p->n_cp) * 24));
   HIP_TRY(p->d_ybuf2.reserve(np));
@@ -439,9 +453,10 @@ int prepare(hs_problem* p) {
   T.fj[0] = FactorJob{T.Sb, T.g_s, T.Ub, T.Ubk, T.ybuf, nullptr, np / 6, -1};
   T.fj[1] = FactorJob{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, -1};
   T.xsol = p->d_xsol.p, T.join_flag = p->d_join.p, T.join_epoch = 0;
-  {
+  {  // the reversed copy feeds the far end of a two-ended factorisation and, as the lower band, every MFMA factorisation
     const bool la_ok = vs.bw * (vs.bw - 2) <= kLaCompute, two_ended = la_ok && nbd == 0 && np / 6 >= 4 * vs.bw;
-    T.Sb2 = two_ended ? p->d_Sb2.p : nullptr, T.g2 = two_ended ? p->d_g2.p : nullptr;
+    const bool need = two_ended || mfma_window_tiles(vs.bw) > 0;
+    T.Sb2 = need ? p->d_Sb2.p : nullptr, T.g2 = need ? p->d_g2.p : nullptr;
   }
   T.scale_b = p->d_scale_b.p, T.Spb = p->d_Spb.p, T.Sbb = p->d_Sbb.p, T.gb_s = p->d_gb_s.p, T.D2b = p->d_D2b.p;
   T.Zb = p->d_Zb.p, T.Cb = p->d_Cb.p, T.hb = p->d_hb.p, T.xb = p->d_xb.p, T.delta_b = p->d_delta_b.p, T.i_bias_ptr = p->d_i_bias_ptr.p;
@@ -452,7 +467,8 @@ int prepare(hs_problem* p) {
   //    4 one-ended pre-look-ahead factorisation kernel                16 phase timestamps of the factorisation -> hs_debug_read
   //   32 per-workgroup timestamps of the linearise / gram kernels   1024 no side stream for the segment partials
   // 2048 one-ended factorisation (no second workgroup)              8192 generalised backward sweep on the one-ended factor
-  // 65536 four-wave LDS backward sweeps of round 1 instead of the single-wave register sweep
+  // 131072 k_band_factor_mfma (trailing window in f64 MFMA tiles) instead of the VALU factorisation kernels
+  // 65536 single-wave register backward sweep (k_band_backward_w) instead of the four-wave LDS sweeps
   T.debug_flags = std::getenv("HS_DEBUG_FLAGS") ? std::atoi(std::getenv("HS_DEBUG_FLAGS")) : 0;
   T.st = p->d_state.p;
   HIP_TRY(hipStreamSynchronize(s));  // host staging vectors go out of scope
@@ -582,6 +598,37 @@ int launch_build(hs_problem* p) {
   return HS_OK;
 }
 
+/// Window size (in 16 x 16 tiles) of the MFMA factorisation for a band of bw blocks: 16 NT >= 6 bw + 12; 0: not supported.
+int mfma_window_tiles(int bw) {
+  for (int nt : {6, 9}) {
+    if (6 * bw + 12 <= 16 * nt) return nt;
+  }
+  return 0;
+}
+
+template <int NT, int NC>
+hipError_t launch_mfma(const Tables& T, int grid, hipStream_t s) {
+  static bool attr = false;
+  const size_t lds = size_t(MfmaGeom<NT>::kTotal) * sizeof(double);
+  if (!attr) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_mfma<NT, NC>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  k_band_factor_mfma<NT, NC><<<grid, 64 * (NC + 3), lds, s>>>(T);
+  return hipGetLastError();
+}
+
+void launch_backward_w(const Tables& T, const BackJob& j0, const BackJob& j1, int m_mid, int grid, hipStream_t s) {
+  const size_t lds = size_t(T.np) * sizeof(double);
+  if (T.bw <= 2 * kBackBlocks)
+    k_band_backward_w<2><<<grid, 64, lds, s>>>(T, j0, j1, m_mid);
+  else if (T.bw <= 4 * kBackBlocks)
+    k_band_backward_w<4><<<grid, 64, lds, s>>>(T, j0, j1, m_mid);
+  else
+    k_band_backward_w<5><<<grid, 64, lds, s>>>(T, j0, j1, m_mid);
+}
+
 int launch_factor(hs_problem* p) {
   const Tables& T = p->T;
   hipStream_t s = p->stream;
@@ -592,29 +639,46 @@ int launch_factor(hs_problem* p) {
   // Factoring from both ends at once (visual-only systems, look-ahead kernel, window long enough to pay for the junction)
   const int n_blk = T.np / 6, w_mid = T.bw - 1;
   const bool la_ok = !legacy && T.bw * (T.bw - 2) <= kLaCompute;
-  const bool two_ended = la_ok && T.nb == 0 && n_blk >= 4 * T.bw && T.Sb2 && !(T.debug_flags & 2048);
+  const int nt = (T.debug_flags & 131072) ? mfma_window_tiles(T.bw) : 0;  // A/B switch 131072: k_band_factor_mfma instead of the VALU kernels
+  const bool two_ended = (la_ok || nt) && T.nb == 0 && n_blk >= 4 * T.bw && T.Sb2 && !(T.debug_flags & 2048);
+  auto run_mfma = [&](const Tables& TT, int grid) -> hipError_t {
+    switch (nt) {
+      case 6: return launch_mfma<6, 3>(TT, grid, s);
+      default: return launch_mfma<9, 3>(TT, grid, s);
+    }
+  };
   if (two_ended) {
     const int m = (n_blk - w_mid) / 2, mB = n_blk - w_mid - m;
     Tables T2 = T;
     T2.fj[0] = FactorJob{T.Sb, T.g_s, T.Ub, T.Ubk, T.ybuf, p->d_win.p, m + w_mid, m};
     T2.fj[1] = FactorJob{p->d_Sb2.p, p->d_g2.p, p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, p->d_win.p, mB, -1};
+    T2.mj[0] = MfmaJob{p->d_Sb2.p, T.g_s, T.Ub, T.Ubk, T.ybuf, p->d_win.p, m + w_mid, m, m + w_mid, INT_MAX, 0};
+    T2.mj[1] = MfmaJob{T.Sb, p->d_g2.p, p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, p->d_win.p, mB, -1, mB + w_mid, mB, 1};
     T2.join_epoch = ++p->join_epoch;
-    k_band_factor_la<1><<<2, kLaThreads, la_lds, s>>>(T2);
+    if (nt)
+      HIP_TRY(run_mfma(T2, 2));
+    else
+      k_band_factor_la<1><<<2, kLaThreads, la_lds, s>>>(T2);
     Tables T3 = T2;
     T3.join_epoch = ++p->join_epoch;
-    const BackJob j0{T.Ub, T.Ubk, T.ybuf, m + w_mid, 0, 0}, j1{p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, mB, w_mid, 1};
-    if (T.debug_flags & 65536) {  // A/B: the four-wave LDS sweep of round 1
+    const BackJob j0{T.Ub, T.Ubk, T.ybuf, p->d_Vb.p, p->d_yt.p, m + w_mid, 0, 0};
+    const BackJob j1{p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, p->d_Vb2.p, p->d_yt2.p, mB, w_mid, 1};
+    if (T.debug_flags & 65536) k_premultiply<<<m + w_mid + mB, 128, 0, s>>>(T3, j0, j1, m + w_mid);
+    if (!(T.debug_flags & 65536)) {  // the four-wave LDS sweep (A/B switch 65536: single-wave register sweep)
       const size_t g_lds = size_t(6 * (T.bw - 1)) * (6 * (T.bw - 1) | 1) * sizeof(double);  // given-column block of the far sweep
       k_band_backward2<<<2, kCholThreads, 2 * size_t(T.np) * sizeof(double) + g_lds, s>>>(T3, j0, j1, m);
-    } else if (6 * T.bw <= 128) {
-      k_band_backward_w<2><<<2, 64, 0, s>>>(T3, j0, j1, m);
     } else {
-      k_band_backward_w<4><<<2, 64, 0, s>>>(T3, j0, j1, m);
+      launch_backward_w(T3, j0, j1, m, 2, s);
     }
     HIP_TRY(hipGetLastError());
     return HS_OK;
   }
-  if (la_ok)
+  if (nt) {
+    Tables T1 = T;
+    T1.mj[0] = MfmaJob{p->d_Sb2.p, T.g_s, T.Ub, T.Ubk, T.ybuf, nullptr, n_blk, -1, n_blk, INT_MAX, 0};
+    T1.mj[1] = T1.mj[0];
+    HIP_TRY(run_mfma(T1, 1));
+  } else if (la_ok)
     k_band_factor_la<1><<<1, kLaThreads, la_lds, s>>>(T);
   // (two tiles per lane need 168 accumulator registers: with six waves per workgroup the budget is 256 and the look-ahead
   //  kernel spills in its update loop - wider bands stay on the kernel below)
@@ -634,17 +698,15 @@ int launch_factor(hs_problem* p) {
     k_border_apply<<<(T.np + kBlock / 64 - 1) / (kBlock / 64), kBlock, 0, s>>>(T);
   }
   if ((T.debug_flags & 8192) && !T.nb) {  // A/B: the generalised sweep on the whole system
-    const BackJob j0{T.Ub, T.Ubk, T.ybuf, T.np / 6, 0, 0};
+    const BackJob j0{T.Ub, T.Ubk, T.ybuf, nullptr, nullptr, T.np / 6, 0, 0};
     k_band_backward2<<<1, kCholThreads, 2 * size_t(T.np) * sizeof(double), s>>>(T, j0, j0, -1);
     k_step_outputs<<<1, kBlock, 0, s>>>(T);
-  } else if (T.debug_flags & 65536) {  // A/B: the four-wave LDS sweep of round 1
+  } else if (!(T.debug_flags & 65536)) {  // the four-wave LDS sweep (A/B switch 65536: single-wave register sweep)
     k_band_backward<<<1, kCholThreads, 2 * size_t(T.np) * sizeof(double), s>>>(T);
   } else {
-    const BackJob j0{T.Ub, T.Ubk, T.ybuf, T.np / 6, 0, 0};
-    if (6 * T.bw <= 128)
-      k_band_backward_w<2><<<1, 64, 0, s>>>(T, j0, j0, -1);
-    else
-      k_band_backward_w<4><<<1, 64, 0, s>>>(T, j0, j0, -1);
+    const BackJob j0{T.Ub, T.Ubk, T.ybuf, p->d_Vb.p, p->d_yt.p, T.np / 6, 0, 0};
+    k_premultiply<<<T.np / 6, 128, 0, s>>>(T, j0, j0, T.np / 6);
+    launch_backward_w(T, j0, j0, -1, 1, s);
   }
   HIP_TRY(hipGetLastError());
   return HS_OK;

@@ -21,5 +21,6 @@
 #include "kernels_border.hpp"
 #include "kernels_factor.hpp"
 #include "kernels_backward.hpp"
+#include "kernels_factor_mfma.hpp"
 #include "kernels_update.hpp"
 #include "kernels_aux.hpp"

@@ -12,12 +12,14 @@ namespace hs {
 // Here a pending row keeps its running right-hand side in a REGISTER for its whole lifetime:
 //   * row rho lives in slot z = rho mod (6 bw) = lane + 64 s of the wave (s < NS): rows 6 bw apart never overlap in time, because a
 //     row is pending only while the sweep is inside its band (bw block rows);
-//   * step j: the six finished entries of block row j are broadcast with v_readlane (wave-uniform lane / slot), x_j = U_jj^-1 a_j
-//     is formed redundantly in every lane (21 FMAs, U_jj^-1 from Ubk), every pending row subtracts U[rho][cols of j] . x_j (6 FMAs
-//     per slot), the slots of block row j are re-initialised with y of block row j - bw;
-//   * the operands of step j - D (six factor entries per slot, the 21 entries of U_jj^-1, the y of the rows that start their
-//     life) are requested D steps ahead into rotating register sets: no memory latency on the chain.
-// Chain per block row: 12 readlanes + ~6 dependent FMAs + ~6 dependent FMAs. Two-ended systems run one wave per end (grid = 2):
+//   * the sweep runs on the block-row-scaled factor V = diag(U_jj^-1) U (unit diagonal blocks) and yt = diag(U_jj^-1) y, written
+//     by the factorisation (k_premultiply for the kernels that only produce U): x_j = yt_j - sum_{m > j} V_jm x_m, so the finished
+//     running sums of block row j ARE x_j — no triangular solve on the chain;
+//   * step j: the six entries of x_j are broadcast with v_readlane (wave-uniform lane / slot), every pending row subtracts
+//     V[rho][cols of j] . x_j (6 FMAs per slot), the slots of block row j are re-initialised with yt of block row j - bw;
+//   * the operands of step j - D (six factor entries per slot, the yt of the rows that start their life) are requested D steps
+//     ahead into rotating register sets: no memory latency on the chain.
+// Chain per block row: 12 readlanes + ~4 dependent FMAs. Two-ended systems run one wave per end (grid = 2):
 // block 0 solves the top system, publishes the middle solution (agent-scope release + flag), block 1 solves the reversed bottom
 // system whose first `given` block rows (in sweep order) are that middle solution. The block that finishes last turns the
 // solution into the step outputs.
@@ -29,67 +31,96 @@ HSD double readlane_f64(double v, int lane) {
 
 constexpr int kBackDepth = 4;  // prefetch distance in block rows
 
-template <int NS>  // slots per lane: 6 bw <= 64 NS
+/// V = diag(U_jj^-1) U and yt = diag(U_jj^-1) y for factorisation kernels that only write U, U_jj^-1 and y (one workgroup per
+/// block row; blocks [0, n0) serve job 0, the rest job 1). Runs after the border correction of y, if any.
+__global__ void __launch_bounds__(128) k_premultiply(Tables T, BackJob j0, BackJob j1, int n0) {
+  if (T.st->done) return;
+  const bool first = int(blockIdx.x) < n0;
+  const BackJob J = first ? j0 : j1;
+  const int r = first ? blockIdx.x : blockIdx.x - n0, ncb = 6 * T.bw;
+  double W[21];
+#pragma unroll
+  for (int e = 0; e < 21; ++e) W[e] = J.Ubk[size_t(r) * 24 + e];
+  double* V = const_cast<double*>(J.Vb);
+  for (int c = threadIdx.x; c <= ncb; c += blockDim.x) {
+    double u[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) u[k] = c < ncb ? J.Ub[size_t(6 * r + k) * ncb + c] : J.ybuf[6 * r + k];
+    int p = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = a; k < 6; ++k) v = fma(W[p++], u[k], v);
+      if (c < ncb)
+        V[size_t(6 * r + a) * ncb + c] = v;
+      else
+        const_cast<double*>(J.yt)[6 * r + a] = v;
+    }
+  }
+}
+
+constexpr int kBackBlocks = 10;  // block rows per slot: 60 of the 64 lanes carry a row, a block row never straddles two slots
+
+template <int NS>  // slots per lane: bw <= 10 NS
 __global__ void __launch_bounds__(64) k_band_backward_w(Tables T, BackJob j0, BackJob j1, int m_mid) {
+  extern __shared__ __attribute__((aligned(16))) double xs[];  // solution of the own block rows (own order), flushed to HBM in bulk
   DevState* st = T.st;
   if (st->done) return;
   const BackJob J = blockIdx.x == 0 ? j0 : j1;
   const int lane = threadIdx.x;
-  const int bw = T.bw, ncb = 6 * bw, R = 6 * bw, np = T.np;
+  const int bw = T.bw, ncb = 6 * bw, np = T.np;
   const int n_rows = J.n_rows, jtop = J.n_rows + J.given - 1;
   constexpr int D = kBackDepth;
-  // slot constants
-  int bz[NS], cz[NS];
+  const bool prof = (T.debug_flags & 16) && lane == 0;  // HS_DEBUG_FLAGS: phase timestamps (100 MHz clock) -> hs_debug_read
+  long long* tlog = reinterpret_cast<long long*>(T.xpart) + 64 * 1024 + 2048 * blockIdx.x;
+  if (prof) tlog[0] = wall_clock64();
+  // Slot s of lane l carries the row (ring block 10 s + l / 6, component l % 6): block row beta lives in ring block beta mod bw.
+  const int cz = lane % 6, lb = lane / 6;
   bool sok[NS];
 #pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const int z = lane + 64 * s;
-    sok[s] = z < R;
-    bz[s] = sok[s] ? z / 6 : 0, cz[s] = sok[s] ? z % 6 : 0;
-  }
-  // Operand sets of the next D steps. For step j and slot s: d = (j - bz) mod bw is how far the slot's live block row lies below
-  // j (d = 0: the slot belongs to block row j itself and is read out / re-initialised at this step).
-  double ub[D][NS][6], wb[D][21], yb[D][NS];
-  int dq[NS];  // d of the step being requested (runs D steps ahead of the sweep)
-  auto request = [&](int jr, double (*u)[6], double* w, double* y) {
-    // jr: block row of the step the operands are for (may be negative past the end: nothing to load)
+  for (int s = 0; s < NS; ++s) sok[s] = lane < 60 && kBackBlocks * s + lb < bw;
+  // Request stream (runs D block rows ahead of the sweep). Per slot: dq = how far the live block row lies below the requested
+  // step (0: the slot belongs to that block row itself), bq = that live block row, oq = offset (in doubles) of its six factor
+  // entries for the requested step inside Vb. Rows that do not exist read the zero pad behind Vb / yt (np * ncb, np): selecting
+  // the ADDRESS keeps the loads free of consumers until the step that uses them.
+  const int zero_v = np * ncb, zero_y = np;
+  int dq[NS], bq[NS], oq[NS];
+  double ub[D][NS][6], yb[D][NS];
+  auto request = [&](int jr, double (*u)[6], double* y) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      const int d = dq[s];
-      const int beta = jr - d;  // live block row of the slot at step jr
-      const bool upd = sok[s] && jr >= 0 && d != 0 && beta >= 0 && beta < n_rows;
-      const double2* src = reinterpret_cast<const double2*>(J.Ub + (upd ? size_t(6 * beta + cz[s]) * ncb + 6 * d : 0));
-      const double2 a0 = src[0], a1 = src[1], a2 = src[2];  // rows are 48 bw bytes apart, 6 d doubles = 48 d bytes: 16-byte aligned
-      u[s][0] = upd ? a0.x : 0.0, u[s][1] = upd ? a0.y : 0.0, u[s][2] = upd ? a1.x : 0.0;
-      u[s][3] = upd ? a1.y : 0.0, u[s][4] = upd ? a2.x : 0.0, u[s][5] = upd ? a2.y : 0.0;
-      // the slot of block row jr is re-initialised at step jr with y of block row jr - bw
+      const bool own_step = dq[s] == 0;  // the slot's row is block row jr itself: re-initialised with yt of block row jr - bw
+      const bool upd = sok[s] && !own_step && jr >= 0 && bq[s] >= 0 && bq[s] < n_rows;
+      const double2* src = reinterpret_cast<const double2*>(J.Vb + (upd ? oq[s] : zero_v));
+      const double2 a0 = src[0], a1 = src[1], a2 = src[2];  // 16-byte aligned: rows are 48 bw bytes apart, 6 d doubles = 48 d bytes
+      u[s][0] = a0.x, u[s][1] = a0.y, u[s][2] = a1.x, u[s][3] = a1.y, u[s][4] = a2.x, u[s][5] = a2.y;
       const int bn = jr - bw;
-      const bool ini = sok[s] && jr >= 0 && d == 0 && bn >= 0 && bn < n_rows;
-      const double yv = J.ybuf[ini ? 6 * bn + cz[s] : 0];
-      y[s] = ini ? yv : 0.0;
-      dq[s] = d == 0 ? bw - 1 : d - 1;  // next request: one block row further down
+      const bool ini = sok[s] && own_step && bn >= 0 && bn < n_rows;
+      y[s] = J.yt[ini ? 6 * bn + cz : zero_y];
+      // next request: one block row further down
+      bq[s] = own_step ? bq[s] - bw : bq[s];
+      oq[s] = own_step ? oq[s] - (6 * bw * ncb - 6 * (bw - 1)) : oq[s] - 6;
+      dq[s] = own_step ? bw - 1 : dq[s] - 1;
     }
-    const bool own = jr >= 0 && jr < n_rows;
-    const double* W = J.Ubk + size_t(own ? jr : 0) * 24;  // wave-uniform address: one cache line serves the whole wave
-#pragma unroll
-    for (int e = 0; e < 21; ++e) w[e] = W[e];
   };
   double acc[NS];
+  const int jm_top = ((jtop % bw) + bw) % bw;  // ring block of the first step
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    const int d0 = sok[s] ? ((jtop - bz[s]) % bw + bw) % bw : 0;
-    dq[s] = d0;
-    const int beta = jtop - d0;  // initial live block row of the slot
-    const bool live = sok[s] && beta >= 0 && beta < n_rows;
-    const double yv = J.ybuf[live ? 6 * beta + cz[s] : 0];
-    acc[s] = live ? yv : 0.0;
+    const int rb = kBackBlocks * s + lb;
+    const int d0 = sok[s] ? (jm_top - rb + bw) % bw : 0;
+    dq[s] = d0, bq[s] = jtop - d0, oq[s] = (6 * bq[s] + cz) * ncb + 6 * d0;
+    const bool live = sok[s] && bq[s] >= 0 && bq[s] < n_rows;
+    acc[s] = J.yt[live ? 6 * bq[s] + cz : zero_y];
   }
 #pragma unroll
-  for (int b = 0; b < D; ++b) request(jtop - b, ub[b], wb[b], yb[b]);
+  for (int b = 0; b < D; ++b) request(jtop - b, ub[b], yb[b]);
+  if (prof) tlog[1] = wall_clock64();
   // given block rows (solution of the other sweep): lane t holds entry t of the given part (up to 6 (bw - 1) <= 64 NS entries)
-  double xg[NS];
+  double xg[NS > 4 ? NS : 4];
 #pragma unroll
-  for (int s = 0; s < NS; ++s) xg[s] = 0.0;
+  for (int s = 0; s < (NS > 4 ? NS : 4); ++s) xg[s] = 0.0;
   if (J.given) {  // wait for the middle solution (bounded: a missing partner becomes a reported failure instead of a hang)
     const long long t0 = wall_clock64();
     bool ok = true;
@@ -105,81 +136,74 @@ __global__ void __launch_bounds__(64) k_band_backward_w(Tables T, BackJob j0, Ba
       return;
     }
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
+    for (int s = 0; s < (NS > 4 ? NS : 4); ++s) {
       const int e = lane + 64 * s;  // entry e of the given part = own-order row 6 n_rows + e
       const int rho = 6 * n_rows + e;
       if (e < 6 * J.given) xg[s] = __builtin_nontemporal_load(T.xsol + (J.reversed ? np - 1 - rho : rho));
     }
   }
-  int jm = ((jtop % bw) + bw) % bw;  // j mod bw
-  auto step = [&](int j, double (*u)[6], double* w, double* y) {
+  if (prof) tlog[2] = wall_clock64();
+  int jm = jm_top;  // j mod bw
+  auto step = [&](int j, double (*u)[6], double* y) {
     double x[6];
-    if (j >= n_rows) {  // given by the other sweep
+    if (j >= n_rows) {  // given by the other sweep (uniform branch, no memory operation inside)
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
         const int e = 6 * (j - n_rows) + c;
-        double v = 0.0;
+        double v = readlane_f64(xg[0], e & 63);
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
-          if ((e >> 6) == s) v = readlane_f64(xg[s], e & 63);
+        for (int s = 1; s < (NS > 4 ? NS : 4); ++s) {
+          const double t = readlane_f64(xg[s], e & 63);
+          v = (e >> 6) == s ? t : v;
+        }
         x[c] = v;
       }
     } else {
-      double a[6];
+      // unit diagonal blocks: the finished running sums of block row j are x_j. Its six rows sit in one slot (wave-uniform index)
+      const int sj = jm / kBackBlocks, l0 = 6 * (jm - kBackBlocks * sj);
+      double av = acc[0];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        const int z = 6 * jm + c;
-        double v = 0.0;
+      for (int s = 1; s < NS; ++s) av = sj == s ? acc[s] : av;
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
-          if ((z >> 6) == s) v = readlane_f64(acc[s], z & 63);
-        a[c] = v;
-      }
-      int p = 0;
-#pragma unroll
-      for (int r = 0; r < 6; ++r) {  // x = U_jj^-1 a (packed upper)
-        double v = 0.0;
-#pragma unroll
-        for (int c = r; c < 6; ++c) v = fma(w[p++], a[c], v);
-        x[r] = v;
-      }
-      if (lane < 6) {
-        const int rho = 6 * j + lane;
-        double xv = x[0];
-#pragma unroll
-        for (int c = 1; c < 6; ++c) xv = lane == c ? x[c] : xv;
-        T.xsol[J.reversed ? np - 1 - rho : rho] = xv;
-      }
+      for (int c = 0; c < 6; ++c) x[c] = readlane_f64(av, l0 + c);
+      // the owners keep their entry of the solution in LDS: a global store per block row would sit in the same in-order vmcnt
+      // queue as the operand prefetches and make every counted wait as slow as a store acknowledgement (~2 us)
+      if (lane >= l0 && lane < l0 + 6 && j >= 0) xs[6 * j + lane - l0] = av;
     }
+    const int sj = jm / kBackBlocks, l0 = 6 * (jm - kBackBlocks * sj);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const double t0 = fma(u[s][0], x[0], fma(u[s][1], x[1], u[s][2] * x[2]));
       const double t1 = fma(u[s][3], x[3], fma(u[s][4], x[4], u[s][5] * x[5]));
-      acc[s] -= t0 + t1;
-      const int z = lane + 64 * s;
-      if (z >= 6 * jm && z < 6 * jm + 6) acc[s] = y[s];  // block row j is done: its slots start the life of block row j - bw
+      const bool mine = sj == s && lane >= l0 && lane < l0 + 6;
+      acc[s] = mine ? y[s] : acc[s] - (t0 + t1);  // block row j is done: its slots start the life of block row j - bw
     }
     jm = jm == 0 ? bw - 1 : jm - 1;
-    request(j - D, u, w, y);
+    request(j - D, u, y);
   };
   const int j_pub = (blockIdx.x == 0 && m_mid >= 0 && gridDim.x == 2) ? m_mid : -1;  // block 0 publishes the middle solution after block row m_mid
-  int j = jtop;
+  auto flush = [&](int lo, int hi) {  // own-order rows [lo, hi) of the solution: LDS -> HBM (natural order)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int rho = lo + lane; rho < hi; rho += 64) T.xsol[J.reversed ? np - 1 - rho : rho] = xs[rho];
+  };
   auto publish = [&]() {
-    // rows [6 m_mid, 6 n_rows) of the solution were stored by lanes 0..5 of this wave: release them at agent scope, raise the flag
+    // rows [6 m_mid, 6 n_rows) of the solution: store them, release them at agent scope, raise the flag
+    flush(6 * m_mid, 6 * n_rows);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_store(T.join_flag, T.join_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  while (j >= 0) {
+  // Rounds of D block rows; the last round may run past block row 0 (steps with j < 0 find nothing alive and store nothing).
+  for (int j = jtop; j >= 0; j -= D) {
 #pragma unroll
     for (int b = 0; b < D; ++b) {
-      if (j >= 0) {
-        step(j, ub[b], wb[b], yb[b]);
-        if (j == j_pub) publish();
-        --j;
-      }
+      step(j - b, ub[b], yb[b]);
+      if (prof && j - b >= 0 && (T.debug_flags & 32)) tlog[16 + j - b] = wall_clock64();
+      if (j - b == j_pub) publish();
     }
   }
+  flush(0, j_pub >= 0 ? 6 * j_pub : 6 * n_rows);
+  if (prof) tlog[3] = wall_clock64();
   // ---- the block that finishes last turns the solution into the step outputs (join_flag[1] advances by gridDim.x per launch) ----
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -189,6 +213,7 @@ __global__ void __launch_bounds__(64) k_band_backward_w(Tables T, BackJob j0, Ba
     if (lane == 0) prev = atomicAdd(T.join_flag + 1, 1u);
     last = (__builtin_amdgcn_readfirstlane(int(prev)) & 1) == 1;
   }
+  if (prof) tlog[4] = wall_clock64();
   if (!last) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   double gd = 0.0, dd = 0.0;
@@ -210,6 +235,7 @@ __global__ void __launch_bounds__(64) k_band_backward_w(Tables T, BackJob j0, Ba
     st->g_dot_step_pose = gd;
     st->d2_step2_pose = dd;
   }
+  if (prof) tlog[5] = wall_clock64();
 }
 
 }  // namespace hs

@@ -790,6 +790,8 @@ struct BackJob {
   const double* Ub;
   const double* Ubk;
   const double* ybuf;
+  const double* Vb;   // block-row-scaled factor diag(U_jj^-1) U (k_band_backward_w)
+  const double* yt;   // diag(U_jj^-1) y
   int n_rows;   // block rows of this factor
   int given;    // block rows above them in sweep order whose solution comes from the other job
   int reversed; // solution index = np - 1 - rho

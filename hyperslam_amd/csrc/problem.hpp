@@ -69,6 +69,21 @@ struct FactorJob {
   int merge_at;       // job 0, two-ended mode: first block row of the middle part (-1: none)
 };
 
+/// One job of k_band_factor_mfma (kernels_factor_mfma.hpp).
+struct MfmaJob {
+  const double* L;   // lower-band rows in this job's ordering: row np-1-sigma of the OTHER ordering's upper band array, columns reversed
+  const double* g;   // right-hand side (own order)
+  double* Ub;        // factor rows out (own order, band storage)
+  double* Ubk;       // inverted diagonal blocks out
+  double* ybuf;      // forward-solved right-hand side out
+  double* win;       // two-ended: junction buffer dm x (dm + 1) (dm = 6 (bw - 1)), natural middle-local coordinates of job 0
+  int n_steps;       // block rows to eliminate
+  int merge_at;      // job 0, two-ended: first middle block row (-1: none)
+  int enter_limit;   // block rows >= enter_limit never enter (other end's territory / past the matrix): zeros
+  int zero_from;     // job 1, two-ended: pairs with both block rows >= zero_from enter as zeros (INT_MAX: none)
+  int dump;          // job 1, two-ended: hand the trailing window over at the end
+};
+
 struct Tables {
   Spline sp;
   hsd::BasisCoef basis;
@@ -175,6 +190,7 @@ struct Tables {
   const int* sw_ptr;  // n_seg + 1: workgroups of k_seg_gram serving segment f (splits ~ record count)
   const int* sw_seg;  // segment of workgroup w
   FactorJob fj[2];       // k_band_factor_la jobs (blockIdx.x)
+  MfmaJob mj[2];         // k_band_factor_mfma jobs (blockIdx.x)
   double* Sb2;           // reversed copy of Sb / g_s (nullptr unless the two-ended factorisation will run)
   double* g2;
   double* xsol;          // np: solution of the reduced system in natural order (two-ended path)

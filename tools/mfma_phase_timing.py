@@ -1,0 +1,23 @@
+"""Phase timestamps of k_band_factor_mfma (HS_DEBUG_FLAGS=16, 100 MHz clock): python tools/mfma_phase_timing.py [config]"""
+import os, sys, ctypes as C; sys.path.insert(0, ".")
+os.environ["HS_DEBUG_FLAGS"] = str(16 | int(os.environ.get("HS_DEBUG_FLAGS", "0")))
+import numpy as np
+import hyperslam_amd as ha
+from hyperslam_amd import synthetic, _lib
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+w = {1: synthetic.config1, 2: synthetic.config2, 3: synthetic.config3}[cfg]()
+p = ha.Problem(w); p.snapshot()
+for i in range(2): p.restore(); s = p.solve(1)
+lib = _lib.load().cdll
+n = 8 * 1024 + 8 * 600
+buf = np.zeros(n, np.int64)
+lib.hs_debug_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+lib.hs_debug_read(p.h, buf.ctypes.data, n)
+t = buf[:8 * 600].reshape(-1, 8); q = buf[8 * 1024:].reshape(-1, 8)
+r = slice(5, 50)
+print("units of 10 ns. step:", np.median(np.diff(t[r, 0])), " update", np.median(t[r, 1] - t[r, 0]), " enter", np.median(t[r, 2] - t[r, 1]),
+      " extract", np.median(t[r, 3] - t[r, 2]), " compute total", np.median(t[r, 3] - t[r, 0]))
+print("panel:", np.median(t[r, 5] - t[r, 4]), " panel start after step start", np.median(t[r, 4] - t[r, 0]), " storer done after step start",
+      np.median(t[r, 6] - t[r, 0]), " loader (even steps)", np.median(t[6:50:2, 7] - t[6:50:2, 0]))
+print("panel phases: load+update", np.median(q[r, 1] - q[r, 0]), " exchange+chol", np.median(q[r, 2] - q[r, 1]), " solve+write", np.median(q[r, 3] - q[r, 2]))
+print("solve_ms", s["solve_ms"])

@@ -453,9 +453,10 @@ int prepare(hs_problem* p) {
   T.fj[0] = FactorJob{T.Sb, T.g_s, T.Ub, T.Ubk, T.ybuf, nullptr, np / 6, -1};
   T.fj[1] = FactorJob{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, -1};
   T.xsol = p->d_xsol.p, T.join_flag = p->d_join.p, T.join_epoch = 0;
+  T.debug_flags = std::getenv("HS_DEBUG_FLAGS") ? std::atoi(std::getenv("HS_DEBUG_FLAGS")) : 0;
   {  // the reversed copy feeds the far end of a two-ended factorisation and, as the lower band, every MFMA factorisation
     const bool la_ok = vs.bw * (vs.bw - 2) <= kLaCompute, two_ended = la_ok && nbd == 0 && np / 6 >= 4 * vs.bw;
-    const bool need = two_ended || mfma_window_tiles(vs.bw) > 0;
+    const bool need = two_ended || ((T.debug_flags & 131072) && mfma_window_tiles(vs.bw) > 0);
     T.Sb2 = need ? p->d_Sb2.p : nullptr, T.g2 = need ? p->d_g2.p : nullptr;
   }
   T.scale_b = p->d_scale_b.p, T.Spb = p->d_Spb.p, T.Sbb = p->d_Sbb.p, T.gb_s = p->d_gb_s.p, T.D2b = p->d_D2b.p;
@@ -469,7 +470,6 @@ int prepare(hs_problem* p) {
   // 2048 one-ended factorisation (no second workgroup)              8192 generalised backward sweep on the one-ended factor
   // 131072 k_band_factor_mfma (trailing window in f64 MFMA tiles) instead of the VALU factorisation kernels
   // 65536 single-wave register backward sweep (k_band_backward_w) instead of the four-wave LDS sweeps
-  T.debug_flags = std::getenv("HS_DEBUG_FLAGS") ? std::atoi(std::getenv("HS_DEBUG_FLAGS")) : 0;
   T.st = p->d_state.p;
   HIP_TRY(hipStreamSynchronize(s));  // host staging vectors go out of scope
   p->dirty = false;
@@ -600,7 +600,7 @@ int launch_build(hs_problem* p) {
 
 /// Window size (in 16 x 16 tiles) of the MFMA factorisation for a band of bw blocks: 16 NT >= 6 bw + 12; 0: not supported.
 int mfma_window_tiles(int bw) {
-  for (int nt : {6, 9}) {
+  for (int nt : {6, 9}) {  // (NT = 10 would cover bw <= 24: 256 VGPRs + scratch, and wrong results on gfx950 — not instantiated)
     if (6 * bw + 12 <= 16 * nt) return nt;
   }
   return 0;
@@ -652,8 +652,8 @@ int launch_factor(hs_problem* p) {
     Tables T2 = T;
     T2.fj[0] = FactorJob{T.Sb, T.g_s, T.Ub, T.Ubk, T.ybuf, p->d_win.p, m + w_mid, m};
     T2.fj[1] = FactorJob{p->d_Sb2.p, p->d_g2.p, p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, p->d_win.p, mB, -1};
-    T2.mj[0] = MfmaJob{p->d_Sb2.p, T.g_s, T.Ub, T.Ubk, T.ybuf, p->d_win.p, m + w_mid, m, m + w_mid, INT_MAX, 0};
-    T2.mj[1] = MfmaJob{T.Sb, p->d_g2.p, p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, p->d_win.p, mB, -1, mB + w_mid, mB, 1};
+    T2.mj[0] = MfmaJob{p->d_Sb2.p, T.g_s, T.Ub, T.Ubk, T.ybuf, p->d_win.p, m + w_mid, m, m + w_mid, INT_MAX, 0, p->d_Vb.p + size_t(T.np) * (6 * T.bw)};
+    T2.mj[1] = MfmaJob{T.Sb, p->d_g2.p, p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, p->d_win.p, mB, -1, mB + w_mid, mB, 1, p->d_Vb.p + size_t(T.np) * (6 * T.bw)};
     T2.join_epoch = ++p->join_epoch;
     if (nt)
       HIP_TRY(run_mfma(T2, 2));
@@ -675,7 +675,7 @@ int launch_factor(hs_problem* p) {
   }
   if (nt) {
     Tables T1 = T;
-    T1.mj[0] = MfmaJob{p->d_Sb2.p, T.g_s, T.Ub, T.Ubk, T.ybuf, nullptr, n_blk, -1, n_blk, INT_MAX, 0};
+    T1.mj[0] = MfmaJob{p->d_Sb2.p, T.g_s, T.Ub, T.Ubk, T.ybuf, nullptr, n_blk, -1, n_blk, INT_MAX, 0, p->d_Vb.p + size_t(T.np) * (6 * T.bw)};
     T1.mj[1] = T1.mj[0];
     HIP_TRY(run_mfma(T1, 1));
   } else if (la_ok)

@@ -82,6 +82,7 @@ struct MfmaJob {
   int enter_limit;   // block rows >= enter_limit never enter (other end's territory / past the matrix): zeros
   int zero_from;     // job 1, two-ended: pairs with both block rows >= zero_from enter as zeros (INT_MAX: none)
   int dump;          // job 1, two-ended: hand the trailing window over at the end
+  const double* zero;  // a double 0.0 in device memory: source of entries that enter as zeros (no select on loaded values)
 };
 
 struct Tables {

@@ -14,10 +14,12 @@ buf = np.zeros(n, np.int64)
 lib.hs_debug_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 lib.hs_debug_read(p.h, buf.ctypes.data, n)
 t = buf[:8 * 600].reshape(-1, 8); q = buf[8 * 1024:].reshape(-1, 8)
-r = slice(5, 50)
-print("units of 10 ns. step:", np.median(np.diff(t[r, 0])), " update", np.median(t[r, 1] - t[r, 0]), " enter", np.median(t[r, 2] - t[r, 1]),
-      " extract", np.median(t[r, 3] - t[r, 2]), " compute total", np.median(t[r, 3] - t[r, 0]))
-print("panel:", np.median(t[r, 5] - t[r, 4]), " panel start after step start", np.median(t[r, 4] - t[r, 0]), " storer done after step start",
-      np.median(t[r, 6] - t[r, 0]), " loader (even steps)", np.median(t[6:50:2, 7] - t[6:50:2, 0]))
-print("panel phases: load+update", np.median(q[r, 1] - q[r, 0]), " exchange+chol", np.median(q[r, 2] - q[r, 1]), " solve+write", np.median(q[r, 3] - q[r, 2]))
+r = slice(6, 50, 2)
+print("units of 10 ns. step:", np.median(np.diff(t[5:50, 0])), " tile update", np.median(t[r, 1] - t[r, 0]))
+print("loader (even steps), relative to the start of phase B of the same step: put start", np.median(t[r, 4] - t[r, 0]), " put done",
+      np.median(t[r, 5] - t[r, 0]), " fetch issued", np.median(t[r, 6] - t[r, 0]))
+r = slice(6, 50)
+print("panel row r, relative to the start of phase B of step r - 1: read start", np.median(q[r, 0] - t[5:49, 0]), " read done",
+      np.median(q[r, 4] - t[5:49, 0]), " phase B start", np.median(q[r, 1] - t[5:49, 0]), " factor done", np.median(q[r, 2] - t[5:49, 0]),
+      " row written", np.median(q[r, 3] - t[5:49, 0]))
 print("solve_ms", s["solve_ms"])

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PRODUCT_LIB = os.path.join(_HERE, "libhyperslam_hip.so")
 
 HS_PIXEL, HS_BEARING, HS_PRIOR, HS_INERTIAL = 0, 1, 2, 3
+HS_INERTIAL_AS_REFERENCE, HS_INERTIAL_EXACT = 0, 1  # hs_set_inertial_jacobian
 (HS_MANIFOLD_CONSTANT, HS_MANIFOLD_EUCLIDEAN, HS_MANIFOLD_CONTROL_POINT, HS_MANIFOLD_SE3, HS_MANIFOLD_SPHERE3,
  HS_MANIFOLD_BIAS_POINT) = range(6)
 HS_NO_CONVERGENCE, HS_CONVERGENCE, HS_FAILURE = 0, 1, 2
@@ -64,6 +65,14 @@ class Linearization(C.Structure):
         ("first_cp", c_int32_p),
         ("first_bias", c_int32_p),
         ("cost", c_double_p),
+        # sensor parameter blocks (optional; constant in the solver)
+        ("J_extrinsics", c_double_p),
+        ("J_intrinsics", c_double_p),
+        ("J_distortion", c_double_p),
+        ("J_gyro_intrinsics", c_double_p),
+        ("J_acc_intrinsics", c_double_p),
+        ("J_gyro_sensitivity", c_double_p),
+        ("J_acc_offsets", c_double_p),
     ]
 
 
@@ -81,6 +90,7 @@ _SIGNATURES = {
     "set_imu": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int, C.c_double, C.c_double,
                           C.c_int, c_double_p, c_double_p, C.c_int]),
     "set_gravity": (C.c_int, [C.c_void_p, c_double_p, C.c_int]),
+    "set_inertial_jacobian": (C.c_int, [C.c_void_p, C.c_int]),
     "set_pixel_residuals": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_int32_p, c_int32_p]),
     "set_bearing_residuals": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_int32_p, c_int32_p]),
     "set_prior_residuals": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_int32_p]),

@@ -79,6 +79,8 @@ struct hs_problem {
   int bias_const = 0;
   double gravity[3] = {0, 0, -9.80665};
   int gravity_const = 1;
+  int inertial_mode = HS_INERTIAL_AS_REFERENCE;  // hs_set_inertial_jacobian
+  hs_problem* scratch = nullptr;                 // one-residual handle of hs_cost_function_evaluate (created on first use)
 
   // structure
   VisualStructure vs;
@@ -439,6 +441,7 @@ int prepare(hs_problem* p) {
   T.bias_basis = make_basis_coef(p->kb), T.kb = p->kb, T.n_bias = p->has_imu ? p->n_bias : 0, T.bias_t0 = p->bias_t0, T.bias_dt = p->bias_dt;
   T.bias_g = p->d_bias_g.p, T.bias_a = p->d_bias_a.p, T.bias_g_cand = p->d_bias_g_cand.p, T.bias_a_cand = p->d_bias_a_cand.p;
   T.gravity = p->d_gravity.p, T.gravity_cand = p->d_gravity_cand.p, T.bias_const = p->bias_const, T.gravity_const = p->gravity_const;
+  T.inertial_literal = p->inertial_mode == HS_INERTIAL_AS_REFERENCE;
   T.nb = p->has_imu ? 6 * p->n_bias + 2 : 0;
   T.n_seg = n_seg, T.bw = vs.bw, T.np = np;
   T.scale_p = p->d_scale_p.p, T.Sb = p->d_Sb.p, T.Ub = p->d_Ub.p, T.Ubk = p->d_Ubk.p, T.g_s = p->d_g_s.p, T.g_full = p->d_g_full.p, T.D2p = p->d_D2p.p, T.gabs = p->d_gabs.p;
@@ -767,6 +770,7 @@ int hs_create(int device, void* stream, hs_problem** out) {
   if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return HS_ERR_DEVICE;
   hs_problem* p = new hs_problem();
   p->device = device;
+  if (const char* e = std::getenv("HS_REFERENCE_LITERAL")) p->inertial_mode = std::atoi(e) ? HS_INERTIAL_AS_REFERENCE : HS_INERTIAL_EXACT;
   if (hipSetDevice(device) != hipSuccess) {
     delete p;
     return HS_ERR_DEVICE;
@@ -796,6 +800,7 @@ int hs_create(int device, void* stream, hs_problem** out) {
 
 int hs_destroy(hs_problem* p) {
   if (!p) return HS_OK;
+  if (p->scratch) hs_destroy(p->scratch), p->scratch = nullptr;
   (void)hipSetDevice(p->device);
   (void)hipStreamSynchronize(p->stream);
   for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
@@ -870,6 +875,13 @@ int hs_set_imu(hs_problem* p, const double* T_bs, const double* i_g, const doubl
   p->bias_g.assign(bias_g, bias_g + size_t(4) * n_bias), p->bias_a.assign(bias_a, bias_a + size_t(4) * n_bias);
   p->bias_const = bias_constant != 0;
   p->dirty = true;
+  return HS_OK;
+}
+
+int hs_set_inertial_jacobian(hs_problem* p, int mode) {
+  if (!p) return HS_ERR_INVALID;
+  if (mode != HS_INERTIAL_AS_REFERENCE && mode != HS_INERTIAL_EXACT) HS_FAIL(HS_ERR_INVALID, "unknown inertial Jacobian mode");
+  if (mode != p->inertial_mode) p->inertial_mode = mode, p->dirty = true;
   return HS_OK;
 }
 
@@ -957,11 +969,76 @@ int hs_residual_layout(hs_problem* p, int type, int idx, int32_t* num_blocks, in
   return HS_OK;
 }
 
+/// Optional sensor-block outputs of hs_linearize (kernels_sensor.hpp): a pass of its own, the solver's kernels do not carry these columns.
+static int linearize_sensor_blocks(hs_problem* p, int type, int robustify, const hs_linearization* out) {
+  if (!out->J_extrinsics && !out->J_intrinsics && !out->J_distortion && !out->J_gyro_intrinsics && !out->J_acc_intrinsics && !out->J_gyro_sensitivity &&
+      !out->J_acc_offsets)
+    return HS_OK;
+  const Tables& T = p->T;
+  hipStream_t s = p->stream;
+  const int k = p->k;
+  const bool visual = type == HS_PIXEL || type == HS_BEARING;
+  const int n = visual ? T.n_vis : (type == HS_PRIOR ? T.n_pri : T.n_ine);
+  const int REC = visual ? kSensorRecVisual : (type == HS_PRIOR ? kSensorRecPrior : kSensorRecInertial);
+  if (n == 0) return HS_OK;
+  HIP_TRY(p->d_dbg.reserve(size_t(n) * REC));
+  const int nb = (n + kBlock - 1) / kBlock;
+  if (visual) {
+    if (k == 4)
+      k_sensor_visual<4><<<nb, kBlock, 0, s>>>(T, p->d_dbg.p, p->d_v_dbgpos.p, robustify);
+    else
+      k_sensor_visual<6><<<nb, kBlock, 0, s>>>(T, p->d_dbg.p, p->d_v_dbgpos.p, robustify);
+  } else if (type == HS_PRIOR) {
+    if (k == 4)
+      k_sensor_prior<4><<<nb, kBlock, 0, s>>>(T, p->d_dbg.p);
+    else
+      k_sensor_prior<6><<<nb, kBlock, 0, s>>>(T, p->d_dbg.p);
+  } else {
+    if (k == 4)
+      k_sensor_inertial<4, 4><<<nb, kBlock, 0, s>>>(T, p->d_dbg.p, robustify);
+    else
+      k_sensor_inertial<6, 4><<<nb, kBlock, 0, s>>>(T, p->d_dbg.p, robustify);
+  }
+  HIP_TRY(hipGetLastError());
+  std::vector<double> rec(size_t(n) * REC);
+  HIP_TRY(hipMemcpyAsync(rec.data(), p->d_dbg.p, rec.size() * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (visual) {
+    const int n_px = int(p->px_stamp.size()), n_br = int(p->br_stamp.size());
+    const int base = type == HS_PIXEL ? 0 : n_px, cnt = type == HS_PIXEL ? n_px : n_br, nres = type == HS_PIXEL ? 2 : 1;
+    for (int i = 0; i < cnt; ++i) {
+      const double* r = &rec[size_t(base + i) * REC];
+      if (out->J_extrinsics) std::memcpy(out->J_extrinsics + size_t(i) * nres * 6, r, sizeof(double) * nres * 6);
+      if (type == HS_PIXEL) {
+        if (out->J_intrinsics) std::memcpy(out->J_intrinsics + size_t(i) * 8, r + 12, 64);
+        if (out->J_distortion) std::memcpy(out->J_distortion + size_t(i) * 8, r + 20, 64);
+      }
+    }
+  } else if (type == HS_PRIOR) {
+    for (int d = 0; d < n; ++d)
+      if (out->J_extrinsics) std::memcpy(out->J_extrinsics + size_t(p->pr_order[d]) * 36, &rec[size_t(d) * REC], 36 * 8);
+  } else {
+    for (int d = 0; d < n; ++d) {
+      const size_t i = size_t(p->in_order[d]);
+      const double* r = &rec[size_t(d) * REC];
+      if (out->J_extrinsics) std::memcpy(out->J_extrinsics + i * 36, r, 36 * 8);
+      if (out->J_gyro_intrinsics) std::memcpy(out->J_gyro_intrinsics + i * 36, r + 36, 36 * 8);
+      if (out->J_acc_intrinsics) std::memcpy(out->J_acc_intrinsics + i * 36, r + 72, 36 * 8);
+      if (out->J_gyro_sensitivity) std::memcpy(out->J_gyro_sensitivity + i * 54, r + 108, 54 * 8);
+      if (out->J_acc_offsets) std::memcpy(out->J_acc_offsets + i * 54, r + 162, 54 * 8);
+    }
+  }
+  return HS_OK;
+}
+
 int hs_linearize(hs_problem* p, int type, int robustify, const hs_linearization* out) {
   if (!p || !out) return HS_ERR_INVALID;
   int rc = prepare(p);
   if (rc) return rc;
   rc = reset_state(p, 0, 1e4);
+  if (rc) return rc;
+  if (type < HS_PIXEL || type > HS_INERTIAL) HS_FAIL(HS_ERR_INVALID, "unknown factor type");
+  rc = linearize_sensor_blocks(p, type, robustify, out);
   if (rc) return rc;
   const Tables& T = p->T;
   hipStream_t s = p->stream;
@@ -1347,21 +1424,19 @@ int hs_cost_function_evaluate(hs_problem* p, int type, int idx, const double* co
   if (type < 0 || type > 3 || idx < 0 || idx >= hs_num_residuals(p, type)) HS_FAIL(HS_ERR_INVALID, "residual index out of range");
   const int k = p->k, kb = p->kb;
   const BlockLayout L = make_block_layout(type, k, kb);
-  // Jacobians w.r.t. sensor blocks are not produced: those blocks are constant in the reference (camera.hpp:18, imu.hpp:18,
-  // optimizer.cpp:59-64) and Ceres passes nullptr for constant blocks.
-  if (jacobians) {
-    const int s0 = L.indices[1], s1 = (type == HS_INERTIAL) ? L.indices[1] + 5 : L.indices[3];
-    for (int b = s0; b < s1; ++b)
-      if (jacobians[b]) HS_FAIL(HS_ERR_INVALID, "Jacobians w.r.t. sensor parameter blocks are not available (constant blocks in the reference)");
+  // one-residual window at the given parameter values, on a scratch handle that lives as long as p (same device, same stream)
+  if (!p->scratch) {
+    const int rc0 = hs_create(p->device, p->stream, &p->scratch);
+    if (rc0) HS_FAIL(rc0, "hs_cost_function_evaluate: scratch handle");
   }
-  // one-residual window at the given parameter values
-  hs_problem* q = nullptr;
-  int rc = hs_create(p->device, p->stream, &q);
-  if (rc) HS_FAIL(rc, "temporary handle");
-  struct Guard {
-    hs_problem* q;
-    ~Guard() { hs_destroy(q); }
-  } guard{q};
+  hs_problem* q = p->scratch;
+  q->inertial_mode = p->inertial_mode;
+  // tables of the previous call (possibly another factor type)
+  q->px_stamp.clear(), q->px_meas.clear(), q->px_lm.clear(), q->px_cam.clear(), q->br_stamp.clear(), q->br_meas.clear(), q->br_lm.clear(), q->br_cam.clear();
+  q->pr_stamp.clear(), q->pr_meas.clear(), q->pr_sensor.clear(), q->in_stamp.clear(), q->in_meas.clear();
+  q->has_imu = false, q->n_bias = 0, q->bias_g.clear(), q->bias_a.clear(), q->n_lm = 0, q->lm.clear(), q->lm_const.clear();
+  q->dirty = true;
+  int rc = HS_OK;
   std::vector<double> cps(size_t(8) * k);
   for (int j = 0; j < k; ++j) std::memcpy(&cps[8 * j], parameters[j], 64);
   const double t0 = cps[7], dt = cps[15] - cps[7];
@@ -1390,9 +1465,23 @@ int hs_cost_function_evaluate(hs_problem* p, int type, int idx, const double* co
   }
   if (rc) HS_FAIL(rc, std::string("hs_cost_function_evaluate: ") + hs_last_error(q));
   std::vector<double> r(6), Js(size_t(6) * 6 * k), Jl(18), Jbg(size_t(18) * kb), Jba(size_t(18) * kb), Jg(12);
+  double Jext[36], Jintr[8], Jdist[8], Jig[36], Jia[36], JSg[54], JXa[54];
   hs_linearization lin;
   std::memset(&lin, 0, sizeof(lin));
   lin.r = r.data(), lin.J_state = Js.data(), lin.J_landmark = Jl.data(), lin.J_bias_g = Jbg.data(), lin.J_bias_a = Jba.data(), lin.J_gravity = Jg.data();
+  if (jacobians) {  // sensor blocks (static_sensor_idx ..): only when asked for — a pass of their own
+    const int s0 = L.indices[1];
+    if (jacobians[s0]) lin.J_extrinsics = Jext;
+    if (type == HS_PIXEL) {
+      if (jacobians[s0 + 1]) lin.J_intrinsics = Jintr;
+      if (jacobians[s0 + 2]) lin.J_distortion = Jdist;
+    } else if (type == HS_INERTIAL) {
+      if (jacobians[s0 + 1]) lin.J_gyro_intrinsics = Jig;
+      if (jacobians[s0 + 2]) lin.J_acc_intrinsics = Jia;
+      if (jacobians[s0 + 3]) lin.J_gyro_sensitivity = JSg;
+      if (jacobians[s0 + 4]) lin.J_acc_offsets = JXa;
+    }
+  }
   rc = hs_linearize(q, type, /*robustify=*/0, &lin);
   if (rc) HS_FAIL(rc, std::string("hs_cost_function_evaluate: ") + hs_last_error(q));
   for (int i = 0; i < nres; ++i) residuals[i] = r[i];
@@ -1408,10 +1497,28 @@ int hs_cost_function_evaluate(hs_problem* p, int type, int idx, const double* co
       out[4] = jl[3], out[5] = jl[4], out[6] = jl[5], out[7] = 0.0;
     }
   }
+  if (double* out = jacobians[k]) {  // sensor extrinsics SE3 [q(4) p(3)]: ambient = local * P^T as for the control points
+    double PT[12];
+    quat_plus_jacobian_T(parameters[k], PT);
+    for (int row = 0; row < nres; ++row) {
+      const double* jl = &Jext[6 * row];
+      for (int c = 0; c < 4; ++c) out[7 * row + c] = jl[0] * PT[c] + jl[1] * PT[4 + c] + jl[2] * PT[8 + c];
+      out[7 * row + 4] = jl[3], out[7 * row + 5] = jl[4], out[7 * row + 6] = jl[5];
+    }
+  }
   if (type == HS_PIXEL || type == HS_BEARING) {
+    // intrinsics / distortion: Euclidean blocks; the bearing evaluator leaves them zero (bearing.cpp:58-77)
+    if (jacobians[k + 1])
+      for (int e = 0; e < nres * 4; ++e) jacobians[k + 1][e] = type == HS_PIXEL ? Jintr[e] : 0.0;
+    if (jacobians[k + 2])
+      for (int e = 0; e < nres * 4; ++e) jacobians[k + 2][e] = type == HS_PIXEL ? Jdist[e] : 0.0;
     if (jacobians[k + 3])
       for (int e = 0; e < nres * 3; ++e) jacobians[k + 3][e] = Jl[e];
   } else if (type == HS_INERTIAL) {
+    if (jacobians[k + 1]) std::memcpy(jacobians[k + 1], Jig, sizeof(Jig));
+    if (jacobians[k + 2]) std::memcpy(jacobians[k + 2], Jia, sizeof(Jia));
+    if (jacobians[k + 3]) std::memcpy(jacobians[k + 3], JSg, sizeof(JSg));
+    if (jacobians[k + 4]) std::memcpy(jacobians[k + 4], JXa, sizeof(JXa));
     for (int j = 0; j < kb; ++j)
       for (int part = 0; part < 2; ++part) {
         double* out = jacobians[k + 5 + part * kb + j];

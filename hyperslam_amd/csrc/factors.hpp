@@ -250,8 +250,12 @@ namespace hs {
 
 // ---- inertial factor (inertial.cpp:13-205; CartesianMetric<6>; ScaledLoss(1.6e-5), optimizer.cpp:267-268) ---------------
 // prediction = [ I_g R_sb w_b + S_g a_m + b_g ;  I_a R_sb a_m + b_a ],   a_m[i] = a_i[i] + F_a.row(i) (X_a.col(i) + t_bs),
-// a_i = R_bw (p'' - g),  F_a = hat(w)^2 + hat(alpha).  Linear rows use I_a and the S_g / X_a terms are kept in every
-// Jacobian block (the in-tree text uses I_g and drops them; identical wherever the reference is exercised).
+// a_i = R_bw (p'' - g),  F_a = hat(w)^2 + hat(alpha).
+// Jacobian, two forms selected by Tables::inertial_literal (hs_set_inertial_jacobian):
+//   as written upstream (default): linear rows of the rotational state columns carry I_g (inertial.cpp:136,142,148), their lever arm
+//     is t_bs alone, and the S_g terms of the state and gravity columns are absent (:134-153,198);
+//   exact: the derivative of the prediction (I_a, per-row lever arms X_a.col(i) + t_bs, S_g terms kept).
+// Identical for I_g = I_a, S_g = 0, X_a = 0 — wherever the reference is exercised (settings.yaml:87-96).
 struct ImuParams {
   double T_bs[7], i_g[6], i_a[6], S_g[9], X_a[9];
 };
@@ -332,10 +336,13 @@ HSD void inertial_evaluate(const Tables& T, const double* cps, const double* bia
   if (!JAC) return;
 
   // d a_m / d w (L_w) and d a_m / d alpha (L_al) with per-row lever arms
+  const bool lit = T.inertial_literal != 0;
+  const M3 S_gJ = lit ? zero3() : S_g;        // S_g as it enters the state / gravity columns
+  const M3 IxRsb = lit ? IgRsb : IaRsb;       // (:136,142,148) vs the matrix of the prediction
   M3 L_w, L_al;
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
-    const M3 lx = hat(lever[r]);
+    const M3 lx = hat(lit ? t_bs : lever[r]);
     const M3 mw = sub(mul(lx, wx), scale(2.0, mul(wx, lx)));  // -(2 wx lx - lx wx)
 #pragma unroll
     for (int c = 0; c < 3; ++c) L_w.m[3 * r + c] = mw.m[3 * r + c], L_al.m[3 * r + c] = -lx.m[3 * r + c];
@@ -349,9 +356,9 @@ HSD void inertial_evaluate(const Tables& T, const double* cps, const double* bia
     // d a_m / d phi_j, d a_m / d dp_j
     const M3 dam_rot = add(mul(HaRt, S.dth[j]), add(mul(L_w, S.dw[j]), mul(L_al, S.dal[j])));
     const M3 dam_tr = scale(S.Bdd[j], Rt);
-    const M3 ang_rot = add(mul(IgRsb, S.dw[j]), mul(S_g, dam_rot));
-    const M3 ang_tr = mul(S_g, dam_tr);
-    const M3 lin_rot = mul(IaRsb, dam_rot);
+    const M3 ang_rot = add(mul(IgRsb, S.dw[j]), mul(S_gJ, dam_rot));
+    const M3 ang_tr = mul(S_gJ, dam_tr);
+    const M3 lin_rot = mul(IxRsb, dam_rot);
     const M3 lin_tr = mul(IaRsb, dam_tr);
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -370,7 +377,7 @@ HSD void inertial_evaluate(const Tables& T, const double* cps, const double* bia
   double Pg[6];
   sphere_plus_jacobian(gravity, Pg);
   const M3 nRt = scale(-1.0, Rt);
-  const M3 ang_g = mul(S_g, nRt), lin_g = mul(IaRsb, nRt);
+  const M3 ang_g = mul(S_gJ, nRt), lin_g = mul(IaRsb, nRt);
   const double gs = T.gravity_const ? 0.0 : sr;
 #pragma unroll
   for (int r = 0; r < 3; ++r)

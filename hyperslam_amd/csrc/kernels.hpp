@@ -17,6 +17,7 @@
 #pragma once
 #include "kernels_common.hpp"
 #include "kernels_linearize.hpp"
+#include "kernels_sensor.hpp"
 #include "kernels_schur.hpp"
 #include "kernels_border.hpp"
 #include "kernels_factor.hpp"

@@ -153,6 +153,7 @@ struct Tables {
   double* gravity;         // 3
   double* gravity_cand;
   int bias_const, gravity_const;
+  int inertial_literal;  // Jacobian of the inertial factor as written upstream (inertial.cpp:131-198) | 0: derivative of the prediction
   int nb;                  // border unknowns: 6 n_bias + 2 (0 without an IMU)
   // reduced system
   int bw;                  // band width in blocks

@@ -179,8 +179,13 @@ class Problem:
                     num_parameters=npar.value, num_residuals=nres.value)
 
     # -- evaluation --------------------------------------------------------------------------------------------
-    def linearize(self, ftype, robustify=True):
-        """Residuals + Ceres-local Jacobians of every residual block of one factor type (table order)."""
+    def set_inertial_jacobian(self, mode):
+        """HS_INERTIAL_AS_REFERENCE (0, default: inertial.cpp:131-198 as written) | HS_INERTIAL_EXACT (1: derivative of the prediction)."""
+        self._check(self.lib.set_inertial_jacobian(self.h, int(mode)), "set_inertial_jacobian")
+
+    def linearize(self, ftype, robustify=True, sensor_blocks=False):
+        """Residuals + Ceres-local Jacobians of every residual block of one factor type (table order). sensor_blocks adds the
+        Jacobians w.r.t. the sensor parameter blocks (extrinsics; pixel: intrinsics, distortion; inertial: i_g, i_a, S_g, X_a)."""
         w = self.window
         n = self.num_residuals(ftype)
         k = w.order
@@ -196,6 +201,16 @@ class Problem:
             out["J_bias_g"], out["J_bias_a"] = np.zeros((n, 6, 3 * kb)), np.zeros((n, 6, 3 * kb))
             out["J_gravity"], out["first_bias"] = np.zeros((n, 6, 2)), np.zeros(n, np.int32)
             lin.J_bias_g, lin.J_bias_a, lin.J_gravity, lin.first_bias = _d(out["J_bias_g"]), _d(out["J_bias_a"]), _d(out["J_gravity"]), _i(out["first_bias"])
+        if sensor_blocks:
+            out["J_extrinsics"] = np.zeros((n, nres, 6))
+            lin.J_extrinsics = _d(out["J_extrinsics"])
+            if ftype == HS_PIXEL:
+                out["J_intrinsics"], out["J_distortion"] = np.zeros((n, 2, 4)), np.zeros((n, 2, 4))
+                lin.J_intrinsics, lin.J_distortion = _d(out["J_intrinsics"]), _d(out["J_distortion"])
+            if ftype == HS_INERTIAL:
+                for name, cols in (("J_gyro_intrinsics", 6), ("J_acc_intrinsics", 6), ("J_gyro_sensitivity", 9), ("J_acc_offsets", 9)):
+                    out[name] = np.zeros((n, 6, cols))
+                    setattr(lin, name, _d(out[name]))
         self._check(self.lib.linearize(self.h, ftype, int(robustify), C.byref(lin)), "linearize")
         return out
 

@@ -87,6 +87,18 @@ typedef struct hs_linearization {
   int32_t* first_cp;    /* n   index of the first of the k control points used                  */
   int32_t* first_bias;  /* n   (inertial)                                                       */
   double* cost;         /* n   0.5 * rho(|r|^2)                                                 */
+  /* Sensor parameter blocks (static_sensor_idx .. dynamic_sensor_idx of exteroceptive.cpp:25-99). The solver keeps them constant
+   * (camera.hpp:18, imu.hpp:18, optimizer.cpp:59-64: Ceres passes nullptr); the evaluators fill them whenever the pointer is
+   * non-null (bearing.cpp:74, pixel.cpp:91-135,141, manifold.cpp:57, inertial.cpp:155-194), which is what the reference's own
+   * tests exercise (tests/.../evaluators/evaluator.hpp:38-65). Produced by a kernel of their own: the solver's kernels do not
+   * carry them. Ceres-local like the others (extrinsics: Product(EigenQuaternion, R3) manifold, sensors/sensor.cpp:26-29). */
+  double* J_extrinsics;        /* n x n_res x 6   T_bs [d_rot(3) d_trans(3)]            (all four factors) */
+  double* J_intrinsics;        /* n x 2 x 4       [cx cy fx fy]                          (pixel)            */
+  double* J_distortion;        /* n x 2 x 4       radtan [k1 k2 p1 p2]                   (pixel)            */
+  double* J_gyro_intrinsics;   /* n x 6 x 6       i_g [c00 c11 c22 c10 c20 c21]          (inertial)         */
+  double* J_acc_intrinsics;    /* n x 6 x 6       i_a                                    (inertial)         */
+  double* J_gyro_sensitivity;  /* n x 6 x 9       S_g, column-major                      (inertial)         */
+  double* J_acc_offsets;       /* n x 6 x 9       X_a, column-major                      (inertial)         */
 } hs_linearization;
 
 /* Exchange hook for the multi-GPU path: called once per linearisation with a device buffer of
@@ -122,6 +134,14 @@ int hs_set_landmarks(hs_problem* p, int n, const double* xyz, const uint8_t* con
  * bias splines: uniform R^3 splines of order bias_order, control point j at bias_t0 + j*bias_dt, n_bias x 4 [x y z t]. */
 int hs_set_imu(hs_problem* p, const double* T_bs, const double* i_g, const double* i_a, const double* S_g, const double* X_a,
                int bias_order, double bias_t0, double bias_dt, int n_bias, const double* bias_g, const double* bias_a, int bias_constant);
+/* Jacobian of the inertial factor. HS_INERTIAL_AS_REFERENCE (default; also HS_REFERENCE_LITERAL=1 in the environment at hs_create)
+ * reproduces inertial.cpp:131-198 as written: the linear rows of the state / extrinsic-rotation columns carry I_g where the
+ * prediction has I_a (:136,142,148,158), and the S_g / X_a terms of the state, extrinsic and gravity columns are absent (:134-153,
+ * 155-162,198). HS_INERTIAL_EXACT (HS_REFERENCE_LITERAL=0) is the derivative of the prediction (:200-203). The two coincide for
+ * I_g = I_a, S_g = 0, X_a = 0, i.e. everywhere the reference is exercised (settings.yaml:87-96). */
+#define HS_INERTIAL_AS_REFERENCE 0
+#define HS_INERTIAL_EXACT 1
+int hs_set_inertial_jacobian(hs_problem* p, int mode);
 /* Replaces swapEnvironment gravity block + setGravityConstant (optimizer.cpp:84-108, 130-141; rule abstract.cpp:57-61). */
 int hs_set_gravity(hs_problem* p, const double* g, int constant);
 

@@ -2,6 +2,7 @@
 // C entry points of the CPU restatement, mirroring include/hyperslam_hip.h one-to-one with the prefix `hso_`
 // so the parity tests drive both sides with the same tables.
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -61,6 +62,7 @@ extern "C" {
 
 int hso_create(int, void*, hso_problem** out) {
   *out = new hso_problem();
+  if (const char* e = std::getenv("HS_REFERENCE_LITERAL")) (*out)->P.inertial_mode = std::atoi(e) ? HS_INERTIAL_AS_REFERENCE : HS_INERTIAL_EXACT;
   return HS_OK;
 }
 int hso_destroy(hso_problem* p) {
@@ -109,6 +111,11 @@ int hso_set_imu(hso_problem* p, const double* T, const double* ig, const double*
   P.kb = kb, P.bias_t0 = bt0, P.bias_dt = bdt, P.n_bias = nb;
   P.bias_g.assign(bg, bg + 4 * nb), P.bias_a.assign(ba, ba + 4 * nb);
   P.bias_const = bias_constant != 0;
+  return HS_OK;
+}
+int hso_set_inertial_jacobian(hso_problem* p, int mode) {
+  CHECK_ARG(mode == HS_INERTIAL_AS_REFERENCE || mode == HS_INERTIAL_EXACT, "unknown inertial Jacobian mode");
+  p->P.inertial_mode = mode;
   return HS_OK;
 }
 int hso_set_gravity(hso_problem* p, const double* g, int constant) {
@@ -182,9 +189,22 @@ int hso_linearize(hso_problem* p, int type, int robustify, const hs_linearizatio
   const int n = P.n_res(t), k = P.k, kb = P.kb;
   Evaluator ev(P);
   Linearized lin;
+  const bool want_sensor = out->J_extrinsics || out->J_intrinsics || out->J_distortion || out->J_gyro_intrinsics || out->J_acc_intrinsics ||
+                           out->J_gyro_sensitivity || out->J_acc_offsets;
   for (int i = 0; i < n; ++i) {
-    ev.evaluate(t, i, robustify != 0, &lin);
+    ev.evaluate(t, i, robustify != 0, &lin, nullptr, nullptr, true, want_sensor);
     const int nr = lin.n_res;
+    if (out->J_extrinsics) std::memcpy(out->J_extrinsics + size_t(i) * nr * 6, lin.J_ext, sizeof(double) * nr * 6);
+    if (t == kPixel) {
+      if (out->J_intrinsics) std::memcpy(out->J_intrinsics + size_t(i) * 8, lin.J_intr, sizeof(double) * 8);
+      if (out->J_distortion) std::memcpy(out->J_distortion + size_t(i) * 8, lin.J_dist, sizeof(double) * 8);
+    }
+    if (t == kInertial) {
+      if (out->J_gyro_intrinsics) std::memcpy(out->J_gyro_intrinsics + size_t(i) * 36, lin.J_ig, sizeof(double) * 36);
+      if (out->J_acc_intrinsics) std::memcpy(out->J_acc_intrinsics + size_t(i) * 36, lin.J_ia, sizeof(double) * 36);
+      if (out->J_gyro_sensitivity) std::memcpy(out->J_gyro_sensitivity + size_t(i) * 54, lin.J_Sg, sizeof(double) * 54);
+      if (out->J_acc_offsets) std::memcpy(out->J_acc_offsets + size_t(i) * 54, lin.J_Xa, sizeof(double) * 54);
+    }
     if (out->r)
       for (int r = 0; r < nr; ++r) out->r[size_t(i) * nr + r] = lin.r[r];
     if (out->J_state) std::memcpy(out->J_state + size_t(i) * nr * 6 * k, lin.J_state.data(), sizeof(double) * nr * 6 * k);
@@ -215,7 +235,7 @@ int hso_cost_function_evaluate(hso_problem* p, int type, int idx, const double* 
     case kPrior: stamp = P.pr_stamp[idx], meas = &P.pr_meas[7 * idx]; break;
     case kInertial: stamp = P.in_stamp[idx], meas = &P.in_meas[6 * idx]; break;
   }
-  const CostContext ctx = {t, &basis, &bias_basis, stamp, meas};
+  const CostContext ctx = {t, &basis, &bias_basis, stamp, meas, P.inertial_mode == 0};
   cost_evaluate(ctx, L, parameters, residuals, jacobians);
   return HS_OK;
 }

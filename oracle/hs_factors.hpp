@@ -481,11 +481,15 @@ inline Mat<3, 6> align_param_jacobian(const V3& v) {
   return J;
 }
 
-/// inertial.cpp:13-205.  Deviations from the in-tree text (both invisible wherever the reference is exercised,
-/// SURVEY.md §8a "Latent reference bug"): linear rows use I_a (in-tree :136,142,148,158 use I_g); the S_g / X_a
-/// contributions to the state, extrinsic and gravity columns (omitted in-tree, zero by default) are included.
+/// inertial.cpp:13-205. Two forms of the Jacobian (the prediction :200-203 is the same):
+///   literal (default, HS_INERTIAL_AS_REFERENCE): the in-tree text — the linear rows of the state and extrinsic-rotation columns carry
+///     I_g where the prediction has I_a (:136,142,148,158), the lever arm of those columns is t_bs alone, and the S_g / X_a
+///     contributions to the state, extrinsic and gravity columns are absent (:134-153,155-162,198);
+///   exact (HS_INERTIAL_EXACT): the derivative of the prediction (I_a in the linear rows, per-row lever arms X_a.col(i) + t_bs,
+///     S_g terms in the angular rows).
+/// They coincide for I_g = I_a, S_g = 0, X_a = 0, i.e. wherever the reference is exercised (SURVEY.md §8a "Latent reference bug").
 inline Prediction evaluate_inertial(const Basis& basis, const Basis& bias_basis, double stamp, const double* const* p_ps, const Layout& L,
-                                    DMat* p_J_e, const double* const* p_js) {
+                                    DMat* p_J_e, const double* const* p_js, bool literal) {
   const int k = basis.k, kb = bias_basis.k;
   const int o_T_bs = L.static_sensor_idx + 0, o_i_g = L.static_sensor_idx + 1, o_i_a = L.static_sensor_idx + 2;
   const int o_S_g = L.static_sensor_idx + 3, o_X_a = L.static_sensor_idx + 4;
@@ -538,8 +542,11 @@ inline Prediction evaluate_inertial(const Basis& basis, const Basis& bias_basis,
   p_J_e->set_zero(6, L.num_parameters);
   // d a_m / d w and d a_m / d alpha with per-row lever arms l_i = X_a.col(i) + t_bs.
   M3 L_w, L_al;
+  const M3 S_gJ = literal ? M3::zero() : S_g;             // S_g as it enters the state / extrinsic / gravity columns
+  const M3 I_x_R_sb = literal ? I_g_R_sb : I_a_R_sb;      // (:136,142,148) vs the matrix of the prediction
+  const M3 I_x = literal ? I_g : I_a;                     // (:158)
   for (int i = 0; i < 3; ++i) {
-    const M3 lx = hat(lever[i]);
+    const M3 lx = hat(literal ? T_bs.p : lever[i]);
     const M3 mw = -1.0 * (2.0 * (w_b_x * lx) - lx * w_b_x);  // (:142) generalised to per-row lever arms
     const M3 ma = -1.0 * lx;                                  // (:148)
     for (int j = 0; j < 3; ++j) L_w(i, j) = mw(i, j), L_al(i, j) = ma(i, j);
@@ -551,13 +558,13 @@ inline Prediction evaluate_inertial(const Basis& basis, const Basis& bias_basis,
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) Ja_value(i, j) = hv(i, j), Ja_vel(i, j) = L_w(i, j), Ja_acc(i, j) = L_al(i, j), Ja_acc(i, 3 + j) = (i == j);
     Mat<6, 6> J_value = Mat<6, 6>::zero(), J_velocity = Mat<6, 6>::zero(), J_acceleration = Mat<6, 6>::zero();
-    const Mat<3, 6> gv = S_g * Ja_value, gw = S_g * Ja_vel, ga = S_g * Ja_acc;
-    const Mat<3, 6> lv = I_a_R_sb * Ja_value, lw = I_a_R_sb * Ja_vel, la = I_a_R_sb * Ja_acc;
+    const Mat<3, 6> gv = S_gJ * Ja_value, gw = S_gJ * Ja_vel, ga = S_gJ * Ja_acc;
+    const Mat<3, 6> lv = I_x_R_sb * Ja_value, lw = I_x_R_sb * Ja_vel, la = I_x_R_sb * Ja_acc, la_lin = I_a_R_sb * Ja_acc;
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 6; ++j) {
         J_value(i, j) = gv(i, j), J_value(3 + i, j) = lv(i, j);
         J_velocity(i, j) = gw(i, j) + (j < 3 ? I_g_R_sb(i, j) : 0.0), J_velocity(3 + i, j) = lw(i, j);
-        J_acceleration(i, j) = ga(i, j), J_acceleration(3 + i, j) = la(i, j);
+        J_acceleration(i, j) = ga(i, j), J_acceleration(3 + i, j) = j < 3 ? la(i, j) : la_lin(i, j);  // (:148 | :150)
       }
     DMat Jv, Jw, Ja;
     Jv.set_zero(6, 6), Jw.set_zero(6, 6), Ja.set_zero(6, 6);
@@ -569,9 +576,9 @@ inline Prediction evaluate_inertial(const Basis& basis, const Basis& bias_basis,
   }
   if (p_js[o_T_bs]) {  // (:155-162) right/additive tangent of T_bs
     const M3 amt = F_a;  // d a_m / d t_bs
-    const M3 ang_ang = I_g * hat(w_s) + S_g * M3::zero();
-    const M3 lin_ang = I_a * hat(a_s);
-    const M3 ang_lin = S_g * amt;
+    const M3 ang_ang = I_g * hat(w_s);
+    const M3 lin_ang = I_x * hat(a_s);
+    const M3 ang_lin = S_gJ * amt;
     const M3 lin_lin = I_a_R_sb * amt;
     DMat A;
     A.set_zero(6, 6);
@@ -589,7 +596,7 @@ inline Prediction evaluate_inertial(const Basis& basis, const Basis& bias_basis,
       for (int r = 0; r < 3; ++r)
         for (int row = 0; row < 3; ++row) {
           (*p_J_e)(3 + row, L.offsets[o_X_a] + 3 * i + r) = I_a_R_sb(row, i) * F_a(i, r);
-          (*p_J_e)(row, L.offsets[o_X_a] + 3 * i + r) = S_g(row, i) * F_a(i, r);
+          (*p_J_e)(row, L.offsets[o_X_a] + 3 * i + r) = S_gJ(row, i) * F_a(i, r);
         }
   }
   for (int j = 0; j < kb; ++j) {  // (:196-197)
@@ -598,7 +605,7 @@ inline Prediction evaluate_inertial(const Basis& basis, const Basis& bias_basis,
   }
   if (p_js[o_g_w]) {  // (:198)
     p_J_e->set_block(3, L.offsets[o_g_w], -1.0 * (I_a_R_sb * R_bw));
-    p_J_e->set_block(0, L.offsets[o_g_w], -1.0 * (S_g * R_bw));
+    p_J_e->set_block(0, L.offsets[o_g_w], -1.0 * (S_gJ * R_bw));
   }
   return out;
 }
@@ -645,6 +652,7 @@ struct CostContext {
   const Basis* bias_basis;
   double stamp;
   const double* measurement;  // pixel 2 | bearing 3 | pose 7 | [w; a] 6
+  bool inertial_literal = true;  // HS_INERTIAL_AS_REFERENCE
 };
 
 inline bool cost_evaluate(const CostContext& ctx, const Layout& L, const double* const* parameters, double* residuals, double** jacobians) {
@@ -655,7 +663,7 @@ inline bool cost_evaluate(const CostContext& ctx, const Layout& L, const double*
     case kPixel: pred = evaluate_pixel(*ctx.basis, ctx.stamp, parameters, L, p_J_e, jacobians); break;
     case kBearing: pred = evaluate_bearing(*ctx.basis, ctx.stamp, parameters, L, p_J_e, jacobians); break;
     case kPrior: pred = evaluate_manifold(*ctx.basis, ctx.stamp, parameters, L, p_J_e, jacobians); break;
-    case kInertial: pred = evaluate_inertial(*ctx.basis, *ctx.bias_basis, ctx.stamp, parameters, L, p_J_e, jacobians); break;
+    case kInertial: pred = evaluate_inertial(*ctx.basis, *ctx.bias_basis, ctx.stamp, parameters, L, p_J_e, jacobians, ctx.inertial_literal); break;
   }
   DMat J_m;
   DMat* p_J_m = jacobians ? &J_m : nullptr;

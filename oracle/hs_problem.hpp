@@ -59,6 +59,7 @@ struct Problem {
   std::vector<double> pr_stamp, pr_meas;
   std::vector<int32_t> pr_sensor;
   std::vector<double> in_stamp, in_meas;
+  int inertial_mode = 0;  // HS_INERTIAL_AS_REFERENCE (inertial.cpp as written) | 1 HS_INERTIAL_EXACT
 
   int n_res(FactorType t) const {
     switch (t) {
@@ -89,6 +90,10 @@ struct Linearized {
   int first_bias = 0;
   std::vector<double> J_bias_g, J_bias_a;  // n_res x 3kb
   double J_grav[6 * 2];
+  // sensor parameter blocks (only with want_sensor; constant in the solver): local Jacobians, n_res x local size
+  double J_ext[6 * 6];                         // T_bs  [d_rot d_trans]
+  double J_intr[2 * 4], J_dist[2 * 4];         // pixel
+  double J_ig[6 * 6], J_ia[6 * 6], J_Sg[6 * 9], J_Xa[6 * 9];  // inertial
 };
 
 struct Evaluator {
@@ -100,7 +105,7 @@ struct Evaluator {
   /// `type`. If `lin` is null only the (uncorrected) residual and cost are produced.
   /// raw_r (optional) receives the un-robustified residual.
   void evaluate(FactorType type, int idx, bool robustify, Linearized* lin, double* raw_r = nullptr, double* cost = nullptr,
-                bool want_jac = true) const {
+                bool want_jac = true, bool want_sensor = false) const {
     const int k = P.k;
     const Layout L = make_layout(type, k, P.kb);
     std::vector<const double*> params(L.sizes.size());
@@ -140,7 +145,12 @@ struct Evaluator {
       params[k + 5 + 2 * P.kb] = P.gravity;
       kinds[k + 5 + 2 * P.kb] = P.gravity_const ? kManifoldConstant : kManifoldSphere3;
     }
-    const CostContext ctx = {type, &basis, &bias_basis, stamp, meas};
+    if (want_sensor) {  // as if the sensor blocks were variable (sensors/sensor.cpp:26-29 manifolds)
+      const int n_static = type == kInertial ? 5 : (type == kPrior ? 1 : 3);
+      kinds[k] = kManifoldSE3;
+      for (int b = 1; b < n_static; ++b) kinds[k + b] = kManifoldEuclidean;
+    }
+    const CostContext ctx = {type, &basis, &bias_basis, stamp, meas, P.inertial_mode == 0};
     const Loss loss = loss_for(type);
     double r[6];
     if (!lin || !want_jac) {
@@ -188,6 +198,18 @@ struct Evaluator {
           const bool frozen = (c < 3) ? P.rot_const : P.trans_const;
           lin->J_state[size_t(rr) * 6 * k + 6 * j + c] = frozen ? 0.0 : scale * Jl[rr * 6 + c];
         }
+    }
+    if (want_sensor) {
+      auto local = [&](int b, ManifoldKind kind, int ambient, double* dst) {
+        to_local(kind, ambient, n, params[b], jac[b], dst);
+        for (int i = 0; i < n * manifold_local_size(kind, ambient); ++i) dst[i] *= scale;
+      };
+      local(k, kManifoldSE3, 7, lin->J_ext);
+      if (type == kPixel) local(k + 1, kManifoldEuclidean, 4, lin->J_intr), local(k + 2, kManifoldEuclidean, 4, lin->J_dist);
+      if (type == kInertial) {
+        local(k + 1, kManifoldEuclidean, 6, lin->J_ig), local(k + 2, kManifoldEuclidean, 6, lin->J_ia);
+        local(k + 3, kManifoldEuclidean, 9, lin->J_Sg), local(k + 4, kManifoldEuclidean, 9, lin->J_Xa);
+      }
     }
     for (int i = 0; i < 18; ++i) lin->J_lm[i] = 0;
     if (lm >= 0 && jac[k + 3]) {

@@ -18,7 +18,7 @@ static void rand_quat(double* q) {
   for (int i = 0; i < 4; ++i) q[i] /= n;
 }
 
-static int probe(FactorType type, int k, int kb, bool smooth) {
+static int probe(FactorType type, int k, int kb, bool smooth, bool literal = false) {
   const Basis basis = make_basis(k), bias_basis = make_basis(kb);
   const Layout L = make_layout(type, k, kb);
   const int nb = int(L.sizes.size());
@@ -91,10 +91,13 @@ static int probe(FactorType type, int k, int kb, bool smooth) {
     for (int i = 0; i < 3; ++i) T[4 + i] = urand(-1, 1);
     double* ig = add(6, kManifoldEuclidean);
     double* ia = add(6, kManifoldEuclidean);
-    for (int i = 0; i < 6; ++i) ig[i] = (i < 3 ? 1.0 : 0.0) + urand(-0.1, 0.1), ia[i] = (i < 3 ? 1.0 : 0.0) + urand(-0.1, 0.1);
+    // literal: the in-tree Jacobian (inertial.cpp:131-198) at the reference's own test point — Mock<IMU>::Create(), tests/include/tests/
+    // sensors/imu.hpp:20-26: random T_bs, identity intrinsics, S_g = X_a = 0 — where it is exact; otherwise the exact form at random values
+    const double spread = literal ? 0.0 : 1.0;
+    for (int i = 0; i < 6; ++i) ig[i] = (i < 3 ? 1.0 : 0.0) + spread * urand(-0.1, 0.1), ia[i] = (i < 3 ? 1.0 : 0.0) + spread * urand(-0.1, 0.1);
     double* sg = add(9, kManifoldEuclidean);
     double* xa = add(9, kManifoldEuclidean);
-    for (int i = 0; i < 9; ++i) sg[i] = urand(-0.01, 0.01), xa[i] = urand(-0.05, 0.05);
+    for (int i = 0; i < 9; ++i) sg[i] = spread * urand(-0.01, 0.01), xa[i] = spread * urand(-0.05, 0.05);
     const double bdt = 10.0, bt0 = stamp - bdt * ((kb - 1) / 2) - urand(0.1, 9.9);
     for (int j = 0; j < 2 * kb; ++j) {
       double* bc = add(4, kManifoldBiasPoint);
@@ -116,7 +119,7 @@ static int probe(FactorType type, int k, int kb, bool smooth) {
     jb[i].assign(size_t(L.num_residuals) * L.sizes[i], 0.0);
     jac[i] = jb[i].data();
   }
-  const CostContext ctx = {type, &basis, &bias_basis, stamp, meas.data()};
+  const CostContext ctx = {type, &basis, &bias_basis, stamp, meas.data(), literal};
   double r0[6];
   cost_evaluate(ctx, L, ps.data(), r0, jac.data());
   int fails = 0;
@@ -163,6 +166,7 @@ int main() {
       for (int t = 0; t < 4; ++t) {
         fails += probe(FactorType(t), k, 4, true);
         fails += probe(FactorType(t), k, 4, false);
+        if (t == kInertial) fails += probe(FactorType(t), k, 4, true, /*literal=*/true);
       }
   // basis sanity (SURVEY.md A.1 verified values)
   const Basis b4 = make_basis(4);

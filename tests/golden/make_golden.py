@@ -8,7 +8,7 @@ oracle and the HIP path against an implementation that shares NO code and NO der
   * angular velocity / acceleration by numerical time differentiation of R(t) (not the recursive formulas),
   * every Jacobian by central differences through the Ceres retractions with step 1e-20 at 100 digits
     (truncation error ~1e-40) — no analytic Jacobian formula appears in this file.
-Run:  python tests/golden/make_golden.py   (rewrites factors.json deterministically; ~1 minute)
+Run:  python tests/golden/make_golden.py   (rewrites factors.json deterministically; ~15 minutes: 232 cases, every block's Jacobian)
 """
 import json
 import os
@@ -260,6 +260,13 @@ def perturbed(P, block, col, h):
         dd = [mp.mpf(0)] * 2
         dd[col] = h
         Q["gravity"] = plus_sphere(P["gravity"], dd)
+    elif kind == "T_bs_rot":  # sensor extrinsics: Product(EigenQuaternion, R3) manifold (sensors/sensor.cpp:26-29)
+        d[col] = h
+        Q["T_bs"][:4] = plus_quat(P["T_bs"][:4], d)
+    elif kind == "T_bs_trans":
+        Q["T_bs"][4 + col] += h
+    elif kind in ("intrinsics", "distortion", "i_g", "i_a", "S_g", "X_a"):  # Euclidean sensor blocks
+        Q[kind][col] += h
     return Q
 
 
@@ -277,7 +284,18 @@ def rand_quat(rng):
     return qnorm([mp.mpf(rng.uniform(lo=-1.0, hi=1.0)) for _ in range(4)])
 
 
-def make_case(ftype, k, rng):
+def perp_unit(v, rng):
+    """A unit vector orthogonal to v."""
+    a = [mp.mpf(rng.uniform(lo=-1.0, hi=1.0)) for _ in range(3)]
+    c = cross(v, a)
+    n = mp.sqrt(sum(x * x for x in c))
+    return [x / n for x in c]
+
+
+def make_case(ftype, k, rng, variant=None):
+    """variant: None | "u0" / "u1" (stamp at the very start / end of its segment) | "near_pi" (prior: relative rotation pi - 1e-3)
+    | "small_angle" (bearing: 1e-5 rad off the measurement) | "axis" / "wide" (pixel: on the optical axis / strong distortion)
+    | "identity" (inertial: I_g = I_a = I, S_g = X_a = 0, where the in-tree Jacobian is exact)."""
     dt = mp.mpf("0.1")
     P = {"k": k}
     q = rand_quat(rng)
@@ -288,6 +306,10 @@ def make_case(ftype, k, rng):
         cps.append(q + [mp.mpf(rng.uniform(lo=-1.0, hi=1.0)) for _ in range(3)] + [t_first + dt * j])
     P["cps"] = cps
     P["stamp"] = cps[(k - 1) // 2][7] + dt * mp.mpf(rng.uniform(lo=0.05, hi=0.95))
+    if variant == "u0":
+        P["stamp"] = cps[(k - 1) // 2][7] + dt * mp.mpf("1e-9")
+    if variant == "u1":
+        P["stamp"] = cps[(k - 1) // 2][7] + dt * (1 - mp.mpf("1e-9"))
     P["T_bs"] = rand_quat(rng) + [mp.mpf(rng.uniform(lo=-0.3, hi=0.3)) for _ in range(3)]
     if ftype in ("pixel", "bearing"):
         P["intrinsics"] = [mp.mpf("367.215"), mp.mpf("248.375"), mp.mpf("458.654"), mp.mpf("457.296")]
@@ -296,15 +318,28 @@ def make_case(ftype, k, rng):
         q_ws = qmul(qw, P["T_bs"][:4])
         p_ws = [a + b for a, b in zip(qrot(qw, P["T_bs"][4:7]), pw)]
         ps = [mp.mpf(rng.uniform(lo=-1.5, hi=1.5)), mp.mpf(rng.uniform(lo=-1.0, hi=1.0)), mp.mpf(rng.uniform(lo=2.0, hi=8.0))]
+        if variant == "axis":
+            ps = [mp.mpf("1e-9"), mp.mpf("-2e-9"), ps[2]]
+        if variant == "wide":
+            ps = [mp.mpf("0.9") * ps[2], mp.mpf("-0.55") * ps[2], ps[2]]
         P["landmark"] = [a + b for a, b in zip(qrot(q_ws, ps), p_ws)]
         if ftype == "pixel":
             P["meas"] = [mp.mpf(rng.uniform(lo=0.0, hi=752.0)), mp.mpf(rng.uniform(lo=0.0, hi=480.0))]
         else:
             b = [ps[i] + mp.mpf(rng.uniform(lo=-0.2, hi=0.2)) for i in range(3)]
+            if variant == "small_angle":
+                e = perp_unit(ps, rng)
+                npz = mp.sqrt(sum(x * x for x in ps))
+                b = [ps[i] + mp.mpf("1e-5") * npz * e[i] for i in range(3)]
             n = mp.sqrt(sum(x * x for x in b))
             P["meas"] = [x / n for x in b]
     elif ftype == "prior":
         P["meas"] = rand_quat(rng) + [mp.mpf(rng.uniform(lo=-1.0, hi=1.0)) for _ in range(3)]
+        if variant == "near_pi":  # R_m = R_ws Exp(-(pi - 1e-3) axis): Log(R_m^T R_ws) has angle pi - 1e-3
+            qw, _ = spline_pose(cps, k, P["stamp"])
+            axis = perp_unit([mp.mpf(1), mp.mpf(2), mp.mpf(3)], rng)
+            ang = mp.pi - mp.mpf("1e-3")
+            P["meas"][:4] = qmul(qmul(qw, P["T_bs"][:4]), qexp([-ang * x for x in axis]))
     else:
         kb = 4
         P["kb"] = kb
@@ -312,6 +347,10 @@ def make_case(ftype, k, rng):
         P["i_a"] = [mp.mpf(1) + mp.mpf(rng.uniform(lo=-0.1, hi=0.1)) for _ in range(3)] + [mp.mpf(rng.uniform(lo=-0.1, hi=0.1)) for _ in range(3)]
         P["S_g"] = [mp.mpf(rng.uniform(lo=-0.01, hi=0.01)) for _ in range(9)]
         P["X_a"] = [mp.mpf(rng.uniform(lo=-0.05, hi=0.05)) for _ in range(9)]
+        if variant == "identity":
+            P["i_g"] = [mp.mpf(1)] * 3 + [mp.mpf(0)] * 3
+            P["i_a"] = [mp.mpf(1)] * 3 + [mp.mpf(0)] * 3
+            P["S_g"], P["X_a"] = [mp.mpf(0)] * 9, [mp.mpf(0)] * 9
         bdt = mp.mpf(1)
         bt0 = P["stamp"] - bdt * ((kb - 1) // 2) - mp.mpf(rng.uniform(lo=0.05, hi=0.95))
         for name in ("bias_g", "bias_a"):
@@ -333,10 +372,18 @@ def tofloat(x):
 def main():
     rng = SplitMix64(0x48595045 ^ 0x601DE)
     cases = []
+    # random cases + targeted edge cases per factor (SURVEY.md §8c asks for O(256) blocks)
+    plan = []
     for ftype in ("pixel", "bearing", "prior", "inertial"):
         for k in (4, 6):
-            for rep in range(4 if ftype != "inertial" else 3):
-                P = make_case(ftype, k, rng)
+            plan += [(ftype, k, None)] * (24 if ftype != "inertial" else 12)
+            edge = {"pixel": ["u0", "u1", "axis", "wide"], "bearing": ["u0", "u1", "small_angle", "small_angle"],
+                    "prior": ["u0", "u1", "near_pi", "near_pi"], "inertial": ["u0", "u1", "identity", "identity"]}[ftype]
+            plan += [(ftype, k, v) for v in edge]
+    for rep, (ftype, k, variant) in enumerate(plan):
+        if True:
+            if True:
+                P = make_case(ftype, k, rng, variant)
                 # inputs are rounded to doubles FIRST, so that the golden outputs belong to exactly representable inputs
                 P = {key: (tofloat(v) if not isinstance(v, int) else v) for key, v in P.items()}
                 Pm = {key: ([[mp.mpf(x) for x in r] for r in v] if isinstance(v, list) and isinstance(v[0], list)
@@ -350,9 +397,20 @@ def main():
                     for r in range(len(out["r"])):
                         Js[r] += tofloat(Jr[r]) + tofloat(Jt[r])
                 out["J_state"] = Js
+                # sensor parameter blocks (constant in the solver; probed by the reference's tests, evaluator.hpp:38-65)
+                Jr = jacobian(ftype, Pm, ("T_bs_rot", 0), 3)
+                Jt = jacobian(ftype, Pm, ("T_bs_trans", 0), 3)
+                out["J_extrinsics"] = [tofloat(Jr[r]) + tofloat(Jt[r]) for r in range(len(out["r"]))]
+                if ftype == "pixel":
+                    out["J_intrinsics"] = tofloat(jacobian(ftype, Pm, ("intrinsics", 0), 4))
+                    out["J_distortion"] = tofloat(jacobian(ftype, Pm, ("distortion", 0), 4))
                 if ftype in ("pixel", "bearing"):
                     out["J_landmark"] = tofloat(jacobian(ftype, Pm, ("landmark", 0), 3))
                 if ftype == "inertial":
+                    out["J_gyro_intrinsics"] = tofloat(jacobian(ftype, Pm, ("i_g", 0), 6))
+                    out["J_acc_intrinsics"] = tofloat(jacobian(ftype, Pm, ("i_a", 0), 6))
+                    out["J_gyro_sensitivity"] = tofloat(jacobian(ftype, Pm, ("S_g", 0), 9))
+                    out["J_acc_offsets"] = tofloat(jacobian(ftype, Pm, ("X_a", 0), 9))
                     kb = P["kb"]
                     Jg, Ja = [[] for _ in range(6)], [[] for _ in range(6)]
                     for j in range(kb):
@@ -367,8 +425,8 @@ def main():
                     out["w_b"], out["alpha_b"], out["v_w"], out["a_w"] = tofloat(w), tofloat(al), tofloat(v), tofloat(a)
                 q, p = spline_pose(Pm["cps"], k, Pm["stamp"])
                 out["pose"] = tofloat(q + p)
-                cases.append({"type": ftype, "inputs": P, "outputs": out})
-                print(ftype, k, rep, "ok", flush=True)
+                cases.append({"type": ftype, "variant": variant, "inputs": P, "outputs": out})
+                print(ftype, k, rep, variant, "ok", flush=True)
     with open(os.path.join(HERE, "factors.json"), "w") as f:
         json.dump({"generator": "tests/golden/make_golden.py (mpmath, 100 digits)", "cases": cases}, f, indent=None, separators=(",", ":"))
     print("wrote", len(cases), "cases")

@@ -4,7 +4,7 @@ import os
 
 import numpy as np
 
-from hyperslam_amd import HS_BEARING, HS_INERTIAL, HS_PIXEL, HS_PRIOR, Window
+from hyperslam_amd import HS_BEARING, HS_INERTIAL, HS_INERTIAL_AS_REFERENCE, HS_INERTIAL_EXACT, HS_PIXEL, HS_PRIOR, Window
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 TYPE_ID = {"pixel": HS_PIXEL, "bearing": HS_BEARING, "prior": HS_PRIOR, "inertial": HS_INERTIAL}
@@ -50,16 +50,35 @@ def golden_window(case) -> Window:
     return w
 
 
+SENSOR_KEYS = ("J_extrinsics", "J_intrinsics", "J_distortion", "J_gyro_intrinsics", "J_acc_intrinsics", "J_gyro_sensitivity", "J_acc_offsets")
+
+
 def check_against_golden(problem, case, tol):
-    """Compares an un-robustified linearisation (oracle or HIP) of a golden window with the 50-digit vectors."""
+    """Compares an un-robustified linearisation (oracle or HIP) of a golden window with the 100-digit vectors: residual, state /
+    landmark / bias / gravity columns and every sensor-block column. The vectors are derivatives of the prediction, i.e. the EXACT form
+    of the inertial Jacobian; the `identity` inertial cases (I_g = I_a = I, S_g = X_a = 0) are also checked in the default
+    as-written-upstream form, which coincides there."""
     out = case["outputs"]
-    lin = problem.linearize(TYPE_ID[case["type"]], robustify=False)
-    errs = {"r": rel(lin["r"][0], out["r"]), "J_state": rel(lin["J_state"][0], out["J_state"])}
-    for key in ("J_landmark", "J_bias_g", "J_bias_a", "J_gravity"):
-        if key in out:
-            errs[key] = rel(lin[key][0], out[key])
-    bad = {k: v for k, v in errs.items() if not v < tol}
-    assert not bad, (case["type"], case["inputs"]["k"], bad)
+    modes = [None]
+    if case["type"] == "inertial":
+        modes = [HS_INERTIAL_EXACT] + ([HS_INERTIAL_AS_REFERENCE] if case.get("variant") == "identity" else [])
+    # a bearing 1e-5 rad off its measurement: the direction of the Jacobian is conditioned like 1 / angle
+    tol = tol * 1e3 if case.get("variant") == "small_angle" else tol
+    errs = {}
+    for mode in modes:
+        if mode is not None:
+            problem.set_inertial_jacobian(mode)
+        lin = problem.linearize(TYPE_ID[case["type"]], robustify=False, sensor_blocks=True)
+        errs = {"r": rel(lin["r"][0], out["r"]), "J_state": rel(lin["J_state"][0], out["J_state"])}
+        for key in ("J_landmark", "J_bias_g", "J_bias_a", "J_gravity") + SENSOR_KEYS:
+            if key in out:
+                ref = np.asarray(out[key], float)
+                # columns that are structurally zero (e.g. d r_rot / d t_bs) compare absolutely against the block's scale
+                errs[key] = float(np.abs(np.asarray(lin[key][0]) - ref).max() / max(1e-300, np.abs(ref).max(), np.abs(np.asarray(out["J_state"])).max() * 1e-3))
+        bad = {k: v for k, v in errs.items() if not v < tol}
+        assert not bad, (case["type"], case.get("variant"), case["inputs"]["k"], mode, bad)
+    if case["type"] == "inertial":
+        problem.set_inertial_jacobian(HS_INERTIAL_AS_REFERENCE)
     return errs
 
 

@@ -1,0 +1,324 @@
+/// Optimizer<OptimizerSuite::HIP> — the reference-side plugin that puts libhyperslam_hip.so behind HyperSLAM's optimizer interface.
+///
+/// WHERE THIS FILE LIVES. It is written against the HyperSLAM tree (Eigen, glog, yaml-cpp, HyperVariables / HyperSensors / HyperState),
+/// none of which exist in this repository's image: it is shipped for the maintainer who adds the backend, it is NOT compiled by this
+/// repository's build and no test here can compile it. What this repository does test is everything underneath it — the C ABI it calls
+/// (include/hyperslam_hip.h: syntax, exported symbol set, behaviour) — and the same window logic restated without the external
+/// dependencies (hyperslam_amd/host/optimizer.hpp, tests/test_host_driver.py).
+///
+/// What a maintainer changes upstream (three places, everything else — front-end, Backend::spin, AbstractOptimizer::submit / setWindow /
+/// process, the YAML — stays as it is):
+///   1. include/hyper/optimizers/forward.hpp:14-17        enum class OptimizerSuite { CERES, HIP, DEFAULT = CERES };
+///   2. internal/hyper/system/components/backend.cpp:37    `} else if (suite == "hip") {` branch, see make_hip_optimizer() at the end
+///   3. settings.yaml:137                                  suite: hip
+/// and adds this header + include/hyperslam_hip.h to the include path and -lhyperslam_hip to the link line.
+///
+/// How it maps onto the Ceres backend it replaces (internal/hyper/optimizers/ceres/optimizer.cpp, "cc" below):
+///   Ceres keeps the problem structure incrementally (AddParameterBlock / AddResidualBlock / RemoveParameterBlock, cc:286-382) and
+///   mutates the variables in place through the registered double* (cc:299-305,354-356). The HIP library takes flat tables. The plugin
+///   therefore RECORDS what the virtuals are told (observations, landmarks, sensors, constancy), BUILDS the tables from the live
+///   variables at optimize() and WRITES the result back into the same variables, so that every caller above (abstract.cpp:74-147)
+///   observes exactly the side effects it observes with Ceres.
+///     parameter blocks   state elements in variables_ (cc:296-306)      -> hs_set_spline rows [q(4) p(3) t], constancy mask (cc:319-328)
+///                        sensor.parameters() (cc:143-155)               -> hs_set_cameras / hs_set_sensors / hs_set_imu (all constant, camera.hpp:18, imu.hpp:18)
+///                        imu bias elements (imu.cpp:64-81)              -> hs_set_imu bias tables (variable, cc:65-66)
+///                        landmarks_ (cc:347-358)                        -> hs_set_landmarks, dense id = position in the table
+///                        gravity (cc:84-108,130-141)                    -> hs_set_gravity
+///     residual blocks    add(VisualBearingObservation&) cc:189-210      -> hs_set_bearing_residuals  (AngularMetric, Huber 1.6e-3)
+///                        add(VisualPixelObservation&)   cc:212-232      -> hs_set_pixel_residuals    (CartesianMetric, Huber 0.5)
+///                        add(ManifoldObservation&)      cc:234-251      -> hs_set_prior_residuals    (ManifoldMetric, no loss)
+///                        add(InertialObservation&)      cc:253-274      -> hs_set_inertial_residuals (CartesianMetric<6>, Scaled 1.6e-5)
+///     removal            RemoveParameterBlock(landmark) drops its residual blocks (cc:365-371, enable_fast_removal) -> observation lists are
+///                        pruned with the landmark; state elements without residuals leave variables_ (cc:330-341)
+///     solve              ceres::Solve(kDefaultSolverOptions) cc:38-54,276-280 -> hs_solve(handle, 5, ...)
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <unordered_map>
+#include <vector>
+
+#include <glog/logging.h>
+#include <yaml-cpp/yaml.h>
+
+#include "hyper/environment/observations/inertial.hpp"
+#include "hyper/environment/observations/manifold.hpp"
+#include "hyper/environment/observations/visual.hpp"
+#include "hyper/optimizers/abstract.hpp"
+#include "hyper/sensors/camera.hpp"
+#include "hyper/sensors/imu.hpp"
+#include "hyper/state/interpolators/abstract.hpp"
+#include "hyper/yaml/yaml.hpp"
+
+#include "hyperslam_hip.h"
+
+namespace hyper {
+
+template <>
+class Optimizer<OptimizerSuite::HIP> final : public AbstractOptimizer {
+ public:
+  /// Same signature as Optimizer<CERES> (ceres/optimizer.hpp:28; backend.cpp:46). `device` / the in-tree solver options of cc:38-54
+  /// (max_num_iterations = 5) are fixed here as they are fixed there.
+  explicit Optimizer(const YAML::Node& yaml_node = {}, const std::vector<Sensor*>& sensors = {}) : AbstractOptimizer{yaml_node} {
+    CHECK_EQ(hs_create(/*device=*/0, /*stream=*/nullptr, &handle_), HS_OK) << "no usable gfx950 device";
+    if (!yaml_node.IsNull())
+      for (auto* sensor : sensors) {  // cc:76-83 setSensorManifold(createSensorManifold(...))
+        DCHECK(sensor != nullptr);
+        addSensor(*sensor);
+      }
+  }
+  ~Optimizer() final { hs_destroy(handle_); }
+
+  /// cc:84-108. The gravity block is read from the environment at optimize(); nothing to register.
+  auto swapEnvironment(std::unique_ptr<Environment<Manifold>>& environment) -> void final { std::swap(environment_, environment); }
+
+  /// cc:110-128.
+  auto swapState(std::unique_ptr<AbstractState>& state) -> void final {
+    variables_.clear();
+    std::swap(state_, state);
+    updateState(window_);
+  }
+
+  /// Constancy flags of Manifold<Stamped<SE3>, CERES>{time_constant, rotation_constant, translation_constant} (backend.cpp:52-55,
+  /// setStateManifold cc:168-182). Time is always constant in the library (stamped.hpp:35-36 with time_constant = true, settings.yaml).
+  auto setStateConstancy(const bool rotation_constant, const bool translation_constant) -> void {
+    rotation_constant_ = rotation_constant;
+    translation_constant_ = translation_constant;
+  }
+
+  auto add(VisualBearingObservation& observation) -> void final { bearings_.push_back(&observation); }  // cc:189-210
+  auto add(VisualPixelObservation& observation) -> void final { pixels_.push_back(&observation); }      // cc:212-232
+  auto add(ManifoldObservation<Manifold>& observation) -> void final { priors_.push_back(&observation); }     // cc:234-251
+  auto add(InertialObservation<Manifold>& observation) -> void final { inertials_.push_back(&observation); }  // cc:253-274
+
+  [[nodiscard]] auto hasSensor(const Sensor& sensor) const -> bool final {  // cc:157-159
+    return camera_index_.contains(&sensor) || pose_sensor_index_.contains(&sensor) || imu_ == &sensor;
+  }
+
+  auto setGravityConstant(const bool set_constant) -> void final { gravity_constant_ = set_constant; }  // cc:130-141
+
+  /// Inertial Jacobian: HS_INERTIAL_AS_REFERENCE reproduces evaluators/inertial.cpp:131-198 as written (default), HS_INERTIAL_EXACT the
+  /// derivative of the prediction (see include/hyperslam_hip.h).
+  auto setInertialJacobian(const int mode) -> void { CHECK_EQ(hs_set_inertial_jacobian(handle_, mode), HS_OK) << hs_last_error(handle_); }
+
+  /// cc:276-280. Tables from the live variables -> hs_solve -> write-back in place.
+  auto optimize() -> void final {
+    if (bearings_.empty() && pixels_.empty() && priors_.empty() && inertials_.empty()) return;
+    const auto order = state().interpolator()->layout().outer.size;  // control points per segment (k)
+
+    // ---- control points: the state elements Ceres holds parameter blocks for (variables_, cc:296-306), in stamp order ----
+    std::vector<StampedManifold*> cps;
+    for (auto* variable : variables_) cps.push_back(static_cast<StampedManifold*>(variable));
+    std::sort(cps.begin(), cps.end(), [](const auto* a, const auto* b) { return a->stamp() < b->stamp(); });
+    CHECK_GE(cps.size(), static_cast<std::size_t>(order));
+    std::vector<double> cp(8 * cps.size());
+    std::vector<std::uint8_t> cp_constant(cps.size());
+    const auto stamp_n = cps.back()->stamp();
+    for (std::size_t j = 0; j < cps.size(); ++j) {
+      const auto vector = cps[j]->asVector();  // [q(4) p(3) t], stamped.hpp:35-36
+      std::copy_n(vector.data(), 8, &cp[8 * j]);
+      const auto stamp = cps[j]->stamp();
+      cp_constant[j] = (stamp <= window_.lowerBound() || stamp_n < stamp) ? 1 : 0;  // cc:319-328
+    }
+    check(hs_set_spline(handle_, order, cps.front()->stamp(), separation_, static_cast<int>(cps.size()), cp.data(), cp_constant.data(), rotation_constant_,
+                        translation_constant_));
+
+    // ---- sensors: sensor.parameters() in Traits order (cc:143-155); constant blocks (camera.hpp:18, imu.hpp:18) ----
+    std::vector<double> cam_T(7 * cameras_.size()), cam_i(4 * cameras_.size()), cam_d(4 * cameras_.size());
+    for (std::size_t c = 0; c < cameras_.size(); ++c) {
+      const auto parameters = cameras_[c]->parameters();  // {transformation, intrinsics [cx cy fx fy], distortion [k1 k2 p1 p2]}
+      std::copy_n(parameters[Traits<Camera>::kTransformationOffset]->asVector().data(), 7, &cam_T[7 * c]);
+      std::copy_n(parameters[Traits<Camera>::kIntrinsicsOffset]->asVector().data(), 4, &cam_i[4 * c]);
+      std::copy_n(parameters[Traits<Camera>::kDistortionOffset]->asVector().data(), 4, &cam_d[4 * c]);
+    }
+    check(hs_set_cameras(handle_, static_cast<int>(cameras_.size()), cam_T.data(), cam_i.data(), cam_d.data()));
+    std::vector<double> sensor_T(7 * pose_sensors_.size());
+    for (std::size_t s = 0; s < pose_sensors_.size(); ++s) std::copy_n(pose_sensors_[s]->parameters()[0]->asVector().data(), 7, &sensor_T[7 * s]);
+    check(hs_set_sensors(handle_, static_cast<int>(pose_sensors_.size()), sensor_T.data()));
+
+    // ---- landmarks: pointer -> dense id = position in the table (landmarks_ is the active set, cc:347-382) ----
+    std::unordered_map<const AbstractLandmark*, std::int32_t> landmark_id;
+    std::vector<Landmark<Position<Scalar>>*> landmark_table;
+    std::vector<double> lm;
+    for (auto* abstract_landmark : landmarks_) {
+      auto* landmark = static_cast<Landmark<Position<Scalar>>*>(abstract_landmark);
+      landmark_id.emplace(landmark, static_cast<std::int32_t>(landmark_table.size()));
+      landmark_table.push_back(landmark);
+      const auto& p = landmark->variable();
+      lm.insert(lm.end(), {p.x(), p.y(), p.z()});
+    }
+    check(hs_set_landmarks(handle_, static_cast<int>(landmark_table.size()), lm.data(), /*constant=*/nullptr));
+
+    // ---- residual tables. A residual block whose landmark left the active set was removed with it (cc:365-371): prune. ----
+    const auto retired = [&](const auto* observation) { return !landmark_id.contains(&observation->landmark()); };
+    std::erase_if(bearings_, retired);
+    std::erase_if(pixels_, retired);
+    {
+      std::vector<double> stamps, values;
+      std::vector<std::int32_t> ids, cams;
+      for (const auto* o : bearings_) {
+        const auto& m = o->measurement();
+        stamps.push_back(m.stamp()), ids.push_back(landmark_id.at(&o->landmark())), cams.push_back(camera_index_.at(&m.sensor()));
+        const auto v = m.variable().asVector();
+        values.insert(values.end(), v.data(), v.data() + 3);
+      }
+      check(hs_set_bearing_residuals(handle_, static_cast<int>(stamps.size()), stamps.data(), values.data(), ids.data(), cams.data()));
+      stamps.clear(), values.clear(), ids.clear(), cams.clear();
+      for (const auto* o : pixels_) {
+        const auto& m = o->measurement();
+        stamps.push_back(m.stamp()), ids.push_back(landmark_id.at(&o->landmark())), cams.push_back(camera_index_.at(&m.sensor()));
+        const auto v = m.variable().asVector();
+        values.insert(values.end(), v.data(), v.data() + 2);
+      }
+      check(hs_set_pixel_residuals(handle_, static_cast<int>(stamps.size()), stamps.data(), values.data(), ids.data(), cams.data()));
+      stamps.clear(), values.clear(), ids.clear();
+      for (const auto* o : priors_) {
+        const auto& m = o->measurement();
+        stamps.push_back(m.stamp()), ids.push_back(pose_sensor_index_.at(&m.sensor()));
+        const auto v = m.variable().asVector();  // SE3 [q(4) p(3)]
+        values.insert(values.end(), v.data(), v.data() + 7);
+      }
+      check(hs_set_prior_residuals(handle_, static_cast<int>(stamps.size()), stamps.data(), values.data(), ids.data()));
+    }
+
+    // ---- IMU: static blocks {T_bs, i_g, i_a, S_g, X_a} (inertial.cpp:36-49) + the two R^3 bias splines (imu.cpp:64-81) + gravity ----
+    std::vector<Traits<IMU>::GyroscopeBias*> bias_g_elements;
+    std::vector<Traits<IMU>::AccelerometerBias*> bias_a_elements;
+    if (imu_ != nullptr && !inertials_.empty()) {
+      const auto parameters = imu_->parameters();
+      for (const auto& element : imu_->gyroscopeBias().elements()) bias_g_elements.push_back(static_cast<Traits<IMU>::GyroscopeBias*>(element.get()));
+      for (const auto& element : imu_->accelerometerBias().elements()) bias_a_elements.push_back(static_cast<Traits<IMU>::AccelerometerBias*>(element.get()));
+      CHECK_EQ(bias_g_elements.size(), bias_a_elements.size());  // both splines are extended together (abstract.cpp:278-290)
+      const auto n_bias = bias_g_elements.size();
+      std::vector<double> bias_g(4 * n_bias), bias_a(4 * n_bias);
+      for (std::size_t j = 0; j < n_bias; ++j) {
+        std::copy_n(bias_g_elements[j]->asVector().data(), 4, &bias_g[4 * j]);  // Stamped<R3> [b(3) t]
+        std::copy_n(bias_a_elements[j]->asVector().data(), 4, &bias_a[4 * j]);
+      }
+      const auto bias_order = imu_->gyroscopeBias().interpolator()->layout().outer.size;
+      const auto bias_dt = n_bias > 1 ? bias_g[7] - bias_g[3] : 1.0;
+      check(hs_set_imu(handle_, parameters[0]->asVector().data(), parameters[1]->asVector().data(), parameters[2]->asVector().data(),
+                       parameters[3]->asVector().data(), parameters[4]->asVector().data(), bias_order, bias_g[3], bias_dt, static_cast<int>(n_bias), bias_g.data(),
+                       bias_a.data(), /*bias_constant=*/0));  // cc:65-66 set*BiasConstant(false)
+      check(hs_set_gravity(handle_, mutableEnvironment().gravity().data(), gravity_constant_ ? 1 : 0));
+      std::vector<double> stamps, values;
+      for (const auto* o : inertials_) {
+        const auto& m = o->measurement();
+        stamps.push_back(m.stamp());
+        const auto v = m.variable().asVector();  // Tangent<SE3> [angular(3) linear(3)]
+        values.insert(values.end(), v.data(), v.data() + 6);
+      }
+      check(hs_set_inertial_residuals(handle_, static_cast<int>(stamps.size()), stamps.data(), values.data()));
+    }
+
+    // ---- solve (cc:38-54: trust-region LM, 5 iterations, monotonic steps) ----
+    hs_summary summary;
+    check(hs_solve(handle_, /*max_iterations=*/5, &summary, nullptr));
+    LOG(INFO) << "hip: " << summary.num_iterations << " iterations, cost " << summary.initial_cost << " -> " << summary.final_cost;  // cc:279
+
+    // ---- write back in place: the variables own the memory, the solver's result must be visible through them (cc:299-305,354-356) ----
+    check(hs_get_control_points(handle_, cp.data()));
+    for (std::size_t j = 0; j < cps.size(); ++j)
+      if (!cp_constant[j]) std::copy_n(&cp[8 * j], 7, cps[j]->asVector().data());  // stamp untouched (time is constant)
+    if (!landmark_table.empty()) {
+      check(hs_get_landmarks(handle_, lm.data()));
+      for (std::size_t l = 0; l < landmark_table.size(); ++l) landmark_table[l]->variable() = Position<Scalar>{lm[3 * l], lm[3 * l + 1], lm[3 * l + 2]};
+    }
+    if (!bias_g_elements.empty()) {
+      std::vector<double> bias_g(4 * bias_g_elements.size()), bias_a(4 * bias_a_elements.size());
+      check(hs_get_bias(handle_, bias_g.data(), bias_a.data()));
+      for (std::size_t j = 0; j < bias_g_elements.size(); ++j) {
+        std::copy_n(&bias_g[4 * j], 3, bias_g_elements[j]->asVector().data());
+        std::copy_n(&bias_a[4 * j], 3, bias_a_elements[j]->asVector().data());
+      }
+      check(hs_get_gravity(handle_, mutableEnvironment().gravity().data()));
+    }
+  }
+
+ private:
+  auto check(const int rc) const -> void { CHECK_EQ(rc, HS_OK) << hs_last_error(handle_); }  // the reference aborts through glog CHECK
+
+  /// createSensorManifold + setSensorManifold (cc:56-71,143-155): cameras by pointer -> index into the camera table, the IMU, and
+  /// any other pose sensor (ManifoldObservation's sensor) -> index into the extrinsics table.
+  auto addSensor(Sensor& sensor) -> void {
+    const auto type = std::type_index{typeid(sensor)};
+    if (type == std::type_index{typeid(Camera)}) {
+      camera_index_.emplace(&sensor, static_cast<std::int32_t>(cameras_.size()));
+      cameras_.push_back(&sensor.as<Camera>());
+    } else if (type == std::type_index{typeid(IMU)}) {
+      CHECK(imu_ == nullptr) << "one IMU (the inertial factor reads a single bias spline pair)";
+      imu_ = &sensor.as<IMU>();
+    } else {
+      pose_sensor_index_.emplace(&sensor, static_cast<std::int32_t>(pose_sensors_.size()));
+      pose_sensors_.push_back(&sensor);
+    }
+  }
+
+  /// cc:286-345 without the Ceres calls: variables_ is the set of state elements that are parameter blocks. New elements of the padded
+  /// range join; elements outside it leave once no residual block touches them (cc:330-341). Constancy is decided at optimize().
+  auto updateState(const Range& range) -> void final {
+    const auto& elements = state().elements();
+    const auto [left_padding, right_padding] = state().interpolator()->layout().outerPadding();
+    const auto begin = std::prev(elements.upper_bound(range.lowerBound()), left_padding);
+    const auto end = std::next(elements.upper_bound(range.upperBound()), right_padding);
+    const auto stamp_0 = (*begin)->stamp();
+    const auto stamp_n = (*std::prev(end))->stamp();
+    for (auto itr = begin; itr != end; ++itr) variables_.insert(itr->get());
+    // residual stamps still present, sorted: a control point is in use if a residual's k-neighbourhood contains it
+    std::vector<Stamp> stamps;
+    for (const auto* o : bearings_) stamps.push_back(o->measurement().stamp());
+    for (const auto* o : pixels_) stamps.push_back(o->measurement().stamp());
+    for (const auto* o : priors_) stamps.push_back(o->measurement().stamp());
+    for (const auto* o : inertials_) stamps.push_back(o->measurement().stamp());
+    std::sort(stamps.begin(), stamps.end());
+    const auto order = state().interpolator()->layout().outer.size;
+    const auto reach = separation_ * (order / 2);  // a residual at t touches control points within (t - reach - dt, t + reach]
+    std::erase_if(variables_, [&](const auto* variable) {
+      const auto stamp = variable->stamp();
+      if (!(stamp < stamp_0 || stamp_n < stamp)) return false;
+      const auto itr = std::lower_bound(stamps.begin(), stamps.end(), stamp - reach);
+      return itr == stamps.end() || *itr >= stamp + reach + separation_;  // no residual block left on it
+    });
+  }
+
+  auto addLandmark(Landmark<Position<Scalar>>& landmark) -> void final {  // cc:347-358
+    DCHECK(!landmarks_.contains(&landmark));
+    landmarks_.insert(&landmark);
+  }
+
+  auto updateLandmarks(const Range& range) -> void final {  // cc:360-382 (the residual blocks go at the next optimize())
+    std::erase_if(landmarks_, [&](const auto* landmark) { return !landmark->range().intersects(range); });
+  }
+
+  /// CHECK(false) upstream (cc:384-386): the bias splines are extended by AbstractOptimizer::process(InertialMeasurement)
+  /// (abstract.cpp:278-290), their elements are read at optimize(). Nothing to register.
+  auto updateSensor(IMU& /* imu */, const Range& /* range */) -> void final {}
+
+  hs_problem* handle_{nullptr};
+  std::vector<const Camera*> cameras_;
+  std::vector<const Sensor*> pose_sensors_;
+  std::unordered_map<const Sensor*, std::int32_t> camera_index_, pose_sensor_index_;
+  IMU* imu_{nullptr};
+  std::vector<VisualBearingObservation*> bearings_;
+  std::vector<VisualPixelObservation*> pixels_;
+  std::vector<ManifoldObservation<Manifold>*> priors_;
+  std::vector<InertialObservation<Manifold>*> inertials_;
+  bool rotation_constant_{false}, translation_constant_{false}, gravity_constant_{true};
+};
+
+using HipOptimizer = Optimizer<OptimizerSuite::HIP>;
+
+/// The branch of Backend::Backend (backend.cpp:37-60) for `suite: hip`: same sequence as the Ceres branch — optimizer, environment,
+/// state constancy from the YAML — minus the Ceres manifold objects (the library applies the same retractions).
+inline auto make_hip_optimizer(const YAML::Node& node, const std::vector<Sensor*>& sensors) -> std::unique_ptr<AbstractOptimizer> {
+  auto optimizer = std::make_unique<HipOptimizer>(node, sensors);
+  auto environment = std::make_unique<Environment<SE3<Scalar>>>();
+  optimizer->swapEnvironment(environment);
+  CHECK(yaml::ReadAs<bool>(node, "time_constant")) << "the HIP backend keeps control-point stamps fixed";
+  optimizer->setStateConstancy(yaml::ReadAs<bool>(node, "rotation_constant"), yaml::ReadAs<bool>(node, "translation_constant"));
+  return optimizer;
+}
+
+}  // namespace hyper

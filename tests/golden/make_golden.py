@@ -8,7 +8,7 @@ oracle and the HIP path against an implementation that shares NO code and NO der
   * angular velocity / acceleration by numerical time differentiation of R(t) (not the recursive formulas),
   * every Jacobian by central differences through the Ceres retractions with step 1e-20 at 100 digits
     (truncation error ~1e-40) — no analytic Jacobian formula appears in this file.
-Run:  python tests/golden/make_golden.py   (rewrites factors.json deterministically; ~15 minutes: 232 cases, every block's Jacobian)
+Run:  python tests/golden/make_golden.py   (rewrites factors.json deterministically; ~12 minutes: 230 cases, every block's Jacobian)
 """
 import json
 import os
@@ -295,14 +295,19 @@ def perp_unit(v, rng):
 def make_case(ftype, k, rng, variant=None):
     """variant: None | "u0" / "u1" (stamp at the very start / end of its segment) | "near_pi" (prior: relative rotation pi - 1e-3)
     | "small_angle" (bearing: 1e-5 rad off the measurement) | "axis" / "wide" (pixel: on the optical axis / strong distortion)
-    | "identity" (inertial: I_g = I_a = I, S_g = X_a = 0, where the in-tree Jacobian is exact)."""
+    | "identity" (inertial: I_g = I_a = I, S_g = X_a = 0, where the in-tree Jacobian is exact) | "cp_near_pi" (two consecutive control
+    points pi - 1e-2 apart: Log branch of the cumulative spline) | "gravity_pivot[_neg]" (gravity on the SphereManifold pivot axis)."""
     dt = mp.mpf("0.1")
     P = {"k": k}
     q = rand_quat(rng)
     cps = []
     t_first = mp.mpf(rng.uniform(lo=0.0, hi=5.0))
     for j in range(k):
-        q = qmul(q, qexp([mp.mpf(rng.uniform(lo=-0.2, hi=0.2)) for _ in range(3)]))
+        step = [mp.mpf(rng.uniform(lo=-0.2, hi=0.2)) for _ in range(3)]
+        if variant == "cp_near_pi" and j == (k - 1) // 2 + 1:  # Log branch: consecutive control points pi - 1e-2 apart
+            axis = perp_unit([mp.mpf(3), mp.mpf(-1), mp.mpf(2)], rng)
+            step = [(mp.pi - mp.mpf("1e-2")) * x for x in axis]
+        q = qmul(q, qexp(step))
         cps.append(q + [mp.mpf(rng.uniform(lo=-1.0, hi=1.0)) for _ in range(3)] + [t_first + dt * j])
     P["cps"] = cps
     P["stamp"] = cps[(k - 1) // 2][7] + dt * mp.mpf(rng.uniform(lo=0.05, hi=0.95))
@@ -357,6 +362,8 @@ def make_case(ftype, k, rng, variant=None):
             P[name] = [[mp.mpf(rng.uniform(lo=-0.5, hi=0.5)) for _ in range(3)] + [bt0 + bdt * j] for j in range(kb)]
         gq = rand_quat(rng)
         P["gravity"] = [mp.mpf("9.80665") * x for x in qrot(gq, [mp.mpf(1), mp.mpf(0), mp.mpf(0)])]
+        if variant in ("gravity_pivot", "gravity_pivot_neg"):  # SphereManifold<3> Householder pivot: x = (0, 0, +-|g|)
+            P["gravity"] = [mp.mpf(0), mp.mpf(0), mp.mpf("9.80665") * (1 if variant == "gravity_pivot" else -1)]
         P["meas"] = [mp.mpf(rng.uniform(lo=-1.0, hi=1.0)) for _ in range(6)]
     return P
 
@@ -376,9 +383,10 @@ def main():
     plan = []
     for ftype in ("pixel", "bearing", "prior", "inertial"):
         for k in (4, 6):
-            plan += [(ftype, k, None)] * (24 if ftype != "inertial" else 12)
-            edge = {"pixel": ["u0", "u1", "axis", "wide"], "bearing": ["u0", "u1", "small_angle", "small_angle"],
-                    "prior": ["u0", "u1", "near_pi", "near_pi"], "inertial": ["u0", "u1", "identity", "identity"]}[ftype]
+            plan += [(ftype, k, None)] * (27 if ftype != "inertial" else 12)
+            edge = {"pixel": ["u0", "u1", "axis", "wide", "cp_near_pi"], "bearing": ["u0", "u1", "small_angle", "small_angle", "cp_near_pi"],
+                    "prior": ["u0", "u1", "near_pi", "near_pi", "cp_near_pi"],
+                    "inertial": ["u0", "u1", "identity", "identity", "cp_near_pi", "gravity_pivot", "gravity_pivot_neg"]}[ftype]
             plan += [(ftype, k, v) for v in edge]
     for rep, (ftype, k, variant) in enumerate(plan):
         if True:

@@ -106,6 +106,37 @@ def test_product_library_exports_every_declared_symbol():
     assert lib.hs_arch() == b"gfx950"
 
 
+def test_c_header_is_plain_c99():
+    """The drop-in boundary is a C ABI: the header must be consumable by a C compiler (cgo / JNI / ctypes generators), not only by C++."""
+    header = os.path.join(ROOT, "include", "hyperslam_hip.h")
+    for std, cc in (("-std=c99", "gcc"), ("-std=c++17", "g++")):
+        out = subprocess.run([cc, std, "-fsyntax-only", "-Wall", "-Wextra", "-pedantic", "-x", "c" if cc == "gcc" else "c++", header], capture_output=True, text=True)
+        assert out.returncode == 0 and not out.stderr.strip(), out.stderr
+
+
+def test_reference_side_plugin_header_uses_only_the_declared_abi():
+    """include/hyper/optimizers/hip/optimizer.hpp (Optimizer<OptimizerSuite::HIP>, compiled inside the HyperSLAM tree, not here) may call
+    only functions the C header declares and the library exports, and must override every pure virtual of AbstractOptimizer
+    (/root/reference/include/hyper/optimizers/abstract.hpp:53-139)."""
+    shim = open(os.path.join(ROOT, "include", "hyper", "optimizers", "hip", "optimizer.hpp")).read()
+    code = "\n".join(line.split("//")[0] for line in shim.splitlines())  # comments stripped
+    called = set(re.findall(r"\b(hs_[a-z_]+)\s*\(", code))
+    header = open(os.path.join(ROOT, "include", "hyperslam_hip.h")).read()
+    declared = set(re.findall(r"\b(hs_[a-z_]+)\s*\(", header))
+    assert called and called <= declared, called - declared
+    lib = ctypes.CDLL(_lib.PRODUCT_LIB)
+    for sym in called:
+        assert hasattr(lib, sym), sym
+    for virtual in ("swapEnvironment", "swapState", "add(VisualBearingObservation&", "add(VisualPixelObservation&", "add(ManifoldObservation<Manifold>&",
+                    "add(InertialObservation<Manifold>&", "hasSensor", "setGravityConstant", "optimize()", "updateState", "addLandmark", "updateLandmarks",
+                    "updateSensor"):
+        assert re.search(r"auto\s+" + re.escape(virtual) + r"[^;{]*\bfinal\b", code), virtual
+    for needed in ("hs_create", "hs_destroy", "hs_set_spline", "hs_set_cameras", "hs_set_landmarks", "hs_set_bearing_residuals", "hs_set_pixel_residuals",
+                   "hs_set_prior_residuals", "hs_set_inertial_residuals", "hs_set_imu", "hs_set_gravity", "hs_solve", "hs_get_control_points", "hs_get_landmarks",
+                   "hs_get_bias", "hs_get_gravity"):
+        assert needed in called, needed
+
+
 def test_product_path_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():

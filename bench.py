@@ -13,6 +13,10 @@ N > 1 (torchrun, one rank per GPU): residual blocks are sharded by landmark (SUR
 replicated control points, eliminates its own landmarks and the reduced normal equations are summed with one RCCL
 all-reduce per iteration. Weak scaling: each rank gets a full configs[1]-sized shard (global = N x 50k residual blocks
 observing N x 5k landmarks on the same 128 control points).
+
+--config 3: BASELINE.json configs[3] (512 control points, 200 k residual blocks, 20 k landmarks) sharded by landmark over the N ranks,
+STRONG scaling (total work fixed). --config 2: configs[2] (stereo-inertial, order 6) on one GPU. The default (configs[1]) is the
+configuration the metric is quoted on.
 """
 import argparse
 import json
@@ -26,6 +30,7 @@ sys.path.insert(0, ROOT)
 LM_ITERATIONS = 5           # optimizer.cpp:40
 B_ALG_PIXEL_K4 = 480        # algorithmic bytes per pixel residual block linearised, SURVEY.md §8(d)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_PEAK_TFLOPS = 78.6     # MI355X_MICROARCH.md: vector fp64 = half the 157.3 TFLOP/s fp32 rate (the f64 MFMA runs at the same rate, tools/microbench)
 
 
 def cpu_baseline(window, budget_s=20.0):
@@ -65,6 +70,8 @@ def cpu_baseline(window, budget_s=20.0):
         runs += 1
     out = {"value": n_blocks * iters / spent, "unit": "residual_blocks/s", "cores": 1, "kind": "port",
            "ms_per_iteration": 1e3 * spent / iters,
+           # SURVEY.md §8d per-stage CPU times (last run): linearise / Schur build / reduced solve / retract + cost re-evaluation
+           "stage_ms_per_iteration": {k: s[k] / max(1, s["num_iterations"]) for k in ("linearize_ms", "schur_ms", "solve_ms", "update_ms")},
            "sample": f"{runs} x optimize() ({LM_ITERATIONS} LM iterations) of the full workload on 1 host thread; own C++ restatement, not Ceres; {kind_note}"}
     out["all_cores"] = cpu_all_cores(lib.path, n_blocks)
     return out
@@ -143,8 +150,63 @@ def rocprof_kernel_ms(kernel_prefix):
     return None
 
 
+def dominant_kernel(np_rows, bw, two_ended):
+    """The kernel with the largest share of device time in the newest committed rocprofv3 kernel-trace summary of this command
+    (profiles/r*_bench_kernel_stats.csv), priced against both rooflines with an algorithmic model of the banded factorisation:
+      bytes  = band of S read + band of U written + right-hand side in/out          (8 B x (2 np ncb + 2 np), ncb = 6 bw)
+      flops  = per block row: 6x6 Cholesky + 6 x ncb panel solve + symmetric rank-6 update of the trailing band  ~ 6 ncb^2 + 72 ncb
+    Both fractions are tiny by construction: the factorisation is ONE dependency chain of np / 6 block rows on one or two workgroups
+    (DESIGN.md §6); the entry exists so that the share of the iteration it takes is not hidden behind the linearisation's roofline."""
+    import csv
+    files = _newest("r*_bench_kernel_stats.csv")
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            rows = [r for r in csv.DictReader(f) if "hs::" in r["Name"]]
+        total = sum(float(r["TotalDurationNs"]) for r in rows)
+        top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+    except Exception:
+        return None
+    avg_s = float(top["AverageNs"]) * 1e-9
+    out = {"kernel": top["Name"].replace("void ", "").split("(")[0], "share_of_device_time": float(top["TotalDurationNs"]) / total,
+           "avg_kernel_ms": avg_s * 1e3, "calls": int(top["Calls"]), "source": os.path.relpath(files[-1], ROOT)}
+    if "k_band_factor" in top["Name"]:
+        ncb, n_blk = 6 * bw, np_rows // 6
+        nbytes = 8.0 * (2 * np_rows * ncb + 2 * np_rows)
+        flops = n_blk * (6.0 * ncb * ncb + 72.0 * ncb)
+        wgs = 2 if two_ended else 1
+        threads = 6 * 64 if "_la<" in top["Name"] else (6 * 64 if "mfma" in top["Name"] else 256)
+        out.update({"algorithmic_bytes_per_launch": nbytes, "algorithmic_flops_per_launch": flops,
+                    "hbm": {"achieved": nbytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBS},
+                    "fp64": {"achieved": flops / avg_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / avg_s / 1e12 / FP64_PEAK_TFLOPS},
+                    "workgroups": wgs, "waves_launched": wgs * threads // 64, "waves_available": 256 * 4 * 8,
+                    "bound": "latency (single dependency chain: block rows x ~2 us, DESIGN.md §6)"})
+    return out
+
+
+def bearing_variant(ha, synthetic, device, steps=10):
+    """configs[1] with bearing (AngularMetric) instead of pixel residuals — not part of `value`."""
+    import torch
+    w = synthetic.config1(n_cp=128, n_landmarks=5000, obs_pairs=5, bearing=True)
+    with ha.Problem(w, device=device) as p:
+        p.snapshot()
+        for _ in range(3):
+            p.restore(), p.solve(LM_ITERATIONS)
+        torch.cuda.synchronize()
+        t0, iters = time.perf_counter(), 0
+        for _ in range(steps):
+            p.restore()
+            iters += p.solve(LM_ITERATIONS)["num_iterations"]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return {"workload": "configs[1] with bearing residual blocks (VisualBearingEvaluator + AngularMetric, Huber 1.6e-3)", "steps": steps,
+            "ms_per_gn_iteration": 1e3 * dt / iters, "value": w.num_residual_blocks() * iters / dt, "unit": "residual_blocks/s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3], help="BASELINE.json configs[i]; 1 = the metric's configuration (default)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
@@ -178,8 +240,19 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    # weak scaling: world x configs[1]; landmarks l with l % world == rank live on this rank
-    full = synthetic.config1(n_cp=128, n_landmarks=5000 * world, obs_pairs=5)
+    if args.config == 1:  # weak scaling: world x configs[1]; landmarks l with l % world == rank live on this rank
+        full = synthetic.config1(n_cp=128, n_landmarks=5000 * world, obs_pairs=5)
+        scaling, workload = "weak", ("BASELINE.json configs[1]: order-4 SE3 B-spline, 128 control points, 50k pixel reprojection residual blocks "
+                                     "+ 5k landmarks per GPU, Schur on landmarks")
+    elif args.config == 3:  # strong scaling: the one configs[3] window, its landmarks dealt over the ranks
+        full = synthetic.config3()
+        scaling, workload = "strong", ("BASELINE.json configs[3]: order-4 SE3 B-spline, 512 control points, 200k pixel residual blocks + 20k landmarks "
+                                       "in total, sharded by landmark over the ranks")
+    else:
+        if world > 1:
+            raise SystemExit("--config 2 (stereo-inertial) is a single-GPU configuration")
+        full = synthetic.config2()
+        scaling, workload = "weak", "BASELINE.json configs[2]: order-6 SE3 B-spline, 128 control points, 50k pixel + 10k inertial residual blocks, bias splines + gravity"
     window = synthetic.shard_by_landmark(full, rank, world) if world > 1 else full
     n_blocks_local = window.num_residual_blocks()
     n_blocks_global = full.num_residual_blocks()
@@ -227,7 +300,25 @@ def main():
     if rank == 0:
         n_lin = args.steps * LM_ITERATIONS  # launches of the linearise kernel in the timed region
         lin_ms = stage["linearize_ms"] / n_lin
-        achieved = B_ALG_PIXEL_K4 * n_blocks_local / (lin_ms * 1e-3) / 1e9
+        order = int(window.order)
+        b_alg = 32 + 8 * (8 + 12 * order)  # 32 B in + one record [r(2) J_l(6) J_state(12 k)] out = 480 B at k = 4
+        n_visual = len(window.pixel_stamps) + len(window.bearing_stamps)
+        lin_kernel = f"hs::k_linearize_visual<{order}>"
+        live = b_alg * n_visual / (lin_ms * 1e-3) / 1e9
+        # the duration in the committed rocprofv3 kernel trace of this command excludes the ~6 us of dispatch latency the HIP events around
+        # the launch include: it prices the kernel, the events price the launch. frac uses the trace when one is committed for this kernel.
+        prof_ms = rocprof_kernel_ms(f"void {lin_kernel}") if args.config == 1 and world == 1 else None
+        achieved = b_alg * n_visual / (prof_ms * 1e-3) / 1e9 if prof_ms else live
+        roofline = {"kernel": lin_kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": pmc_traffic(lin_kernel) if args.config == 1 and world == 1 else None,
+                    "algorithmic_bytes_per_launch": b_alg * n_visual, "avg_launch_ms": lin_ms, "achieved_live": live, "frac_live": live / HBM_PEAK_GBS,
+                    "rocprof_avg_kernel_ms": prof_ms, "timing_source": "rocprofv3 kernel trace (profiles/)" if prof_ms else "HIP events (live)",
+                    "note": "avg_launch_ms / achieved_live / frac_live = HIP events around the launch on the library's stream, measured in this run "
+                            "(includes dispatch latency); rocprof_avg_kernel_ms = committed rocprofv3 --kernel-trace --stats average of this command; "
+                            "traffic = FETCH_SIZE + WRITE_SIZE of the newest profiles/r*_pmc_hbm_traffic.json (separate rocprofv3 --pmc passes, tools/pmc_traffic.sh)"}
+        n_cp_total = int(window.control_points.shape[0])
+        bw_blocks = problem.lib.band_blocks(problem.h)
+        two_ended = (not len(window.inertial_stamps)) and n_cp_total >= 4 * bw_blocks and bw_blocks * (bw_blocks - 2) <= 192
         out = {
             "metric": "residual blocks linearised per second (LM iteration = linearise + Schur + solve + update), 128-control-point window",
             "value": n_blocks_global * LM_ITERATIONS * args.steps / elapsed,
@@ -235,10 +326,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "ms_per_gn_iteration": 1e3 * elapsed / (args.steps * LM_ITERATIONS),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: order-4 SE3 B-spline, 128 control points, 50k pixel reprojection residual blocks "
-                                   "+ 5k landmarks per GPU, Schur on landmarks",
-                       "residual_blocks_per_gpu": n_blocks_local, "landmarks_per_gpu": int(len(window.landmarks) if world == 1 else 5000),
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload,
+                       "residual_blocks_per_gpu": n_blocks_local, "residual_blocks_total": n_blocks_global, "landmarks_per_gpu": int(len(np.unique(np.concatenate([window.pixel_landmark, window.bearing_landmark])))),
                        "lm_iterations_per_step": LM_ITERATIONS, "parallelism": f"residual-sharded x{world}" if world > 1 else "single GPU",
                        **({"exchange": exchange} if world > 1 else {})},
             "final_cost": s["final_cost"], "initial_cost": s["initial_cost"],
@@ -247,19 +337,19 @@ def main():
             # launch time is measured with HIP events on the launch stream inside hs_solve. The factorisation kernel that
             # dominates the iteration time is a single-workgroup dependency chain (latency-bound, no meaningful roofline); its
             # share is visible in device_ms_per_iteration["solve_ms"].
-            "roofline": {"kernel": "hs::k_linearize_visual<4>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("hs::k_linearize_visual<4>"),
-                         "algorithmic_bytes_per_launch": B_ALG_PIXEL_K4 * n_blocks_local, "avg_launch_ms": lin_ms,
-                         "rocprof_avg_kernel_ms": rocprof_kernel_ms("void hs::k_linearize_visual<4>"),
-                         "note": "avg_launch_ms = HIP events around the launch on the library's stream (includes ~6 us dispatch latency); "
-                                 "rocprof_avg_kernel_ms = committed rocprofv3 kernel-trace average of this command (profiles/); "
-                                 "traffic = FETCH_SIZE + WRITE_SIZE of the newest profiles/r*_pmc_hbm_traffic.json (separate rocprofv3 --pmc passes, tools/pmc_traffic.sh)"},
+            "roofline": roofline,
         }
+        # (the committed kernel trace belongs to the default command: configs[1] on one GPU)
+        dom = dominant_kernel(6 * n_cp_total, bw_blocks, two_ended) if args.config == 1 and world == 1 else None
+        if dom:
+            out["roofline_dominant"] = dom
         # the same algorithmic bytes against the whole LM iteration (linearise + Schur + solve + update): the path is a latency-bound
         # dependency chain after the linearisation, so this fraction is low by construction
         it_ms = out["ms_per_gn_iteration"]
-        out["roofline_iteration"] = {"bound": "hbm", "achieved": B_ALG_PIXEL_K4 * n_blocks_local / (it_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": B_ALG_PIXEL_K4 * n_blocks_local / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": it_ms}
+        out["roofline_iteration"] = {"bound": "hbm", "achieved": b_alg * n_visual / (it_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": b_alg * n_visual / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": it_ms}
+        if args.config == 1 and world == 1:  # the factor the runtime actually instantiates (abstract.cpp:243-260): same window, bearing residuals
+            out["bearing_variant"] = bearing_variant(ha, synthetic, local_rank)
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only (the other ranks would idle behind rank 0's CPU run)
             out["cpu_baseline"] = cpu_baseline(full)
             out["speedup_vs_cpu_1thread"] = out["value"] / out["cpu_baseline"]["value"]

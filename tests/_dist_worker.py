@@ -19,6 +19,8 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     if which.endswith("inertial"):
         full = synthetic.small_inertial(order=4, n_cp=18, n_landmarks=40)
+    elif which.endswith("config3"):  # the shape of BASELINE.json configs[3] (long window, 10 blocks per landmark), scaled to CPU size
+        full = synthetic.config3(n_cp=64, n_landmarks=600, obs_pairs=5)
     else:
         full = synthetic.small_visual(order=4, n_cp=18, n_landmarks=64, obs_pairs=3, with_priors=21)
     shard = synthetic.shard_by_landmark(full, rank, world)

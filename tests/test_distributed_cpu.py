@@ -1,4 +1,4 @@
-"""world_size-2 test of the residual-sharded path on CPU (gloo): shard_by_landmark + the all-reduce hook protocol of
+"""world_size-2 / world_size-4 tests of the residual-sharded path on CPU (gloo): shard_by_landmark + the all-reduce hook protocol of
 hyperslam_amd.distributed drive the oracle; the sharded solve must reproduce the single-process solve."""
 import os
 import subprocess
@@ -42,3 +42,27 @@ def test_sharded_oracle_matches_single_process(which, tmp_path, oracle):
     for r in ranks:  # each rank owns the landmarks it observes
         ids = r["lm_ids"]
         assert rel(r["lm"][ids], lm[ids]) < 1e-7
+
+
+def test_strong_scaling_shape_world4(tmp_path, oracle):
+    """bench.py --config 3 --gpus 4 in miniature: ONE window of the configs[3] shape dealt by landmark over four ranks (strong scaling,
+    total work fixed). Every rank must end with the single-process trajectory; the shards partition the residual blocks."""
+    full = synthetic.config3(n_cp=64, n_landmarks=600, obs_pairs=5)
+    shards = [synthetic.shard_by_landmark(full, r, 4) for r in range(4)]
+    assert sum(s.num_residual_blocks() for s in shards) == full.num_residual_blocks() == 6000
+    assert all(abs(s.num_residual_blocks() - 1500) <= 10 for s in shards)
+    with ha.Problem(full, lib=oracle) as p:
+        S, g = p.reduced_system(1e4)
+        s = p.solve(5)
+        cp, lm = p.control_points(), p.landmarks()
+    ranks = run_workers("oracle_config3", tmp_path, world=4)
+    for r in ranks:
+        assert rel(r["S"], S) < 1e-10 and rel(r["g"], g) < 1e-10
+        assert int(r["iters"]) == s["num_iterations"]
+        assert np.allclose(r["costs"], [it["cost"] for it in s["iterations"]], rtol=1e-7, atol=0)
+        assert rel(r["cp"], cp) < 1e-7
+        assert np.array_equal(r["cp"], ranks[0]["cp"])
+        ids = r["lm_ids"]
+        assert rel(r["lm"][ids], lm[ids]) < 1e-7
+    owned = np.concatenate([r["lm_ids"] for r in ranks])
+    assert len(owned) == len(np.unique(owned)) == 600  # every landmark eliminated on exactly one rank

@@ -308,3 +308,52 @@ def test_table_shapes(hip, oracle):
     for f in ("pixel_stamps", "pixels", "pixel_landmark", "pixel_camera"):
         setattr(w, f, np.ascontiguousarray(getattr(w, f)[keep]))
     compare(w, hip, oracle, tol=1e-5, check_lm=False)
+
+
+@pytest.mark.parametrize("bearing", [False, True])
+def test_huber_at_the_threshold(bearing, hip, oracle):
+    """Residual norms ON the Huber threshold (pixel 0.5, optimizer.cpp:226; bearing 1.6e-3, :204) and one ulp-scale step either side:
+    rho' switches from 1 to a / |r| there; both libraries must take the same branch's value (the two agree at the threshold) and the
+    corrector-scaled residual / Jacobian must match."""
+    w = synthetic.small_visual(order=4, n_cp=16, n_landmarks=24, obs_pairs=2, bearing=bearing, seed=31)
+    a = 1.6e-3 if bearing else 0.5
+    ftype = ha.HS_BEARING if bearing else ha.HS_PIXEL
+    with ha.Problem(w, lib=oracle) as c:
+        r0 = c.linearize(ftype, robustify=False)["r"]
+    n = len(r0)
+    factors = np.array([1.0, 1.0 - 1e-13, 1.0 + 1e-13, 0.999, 1.001, 2.0, 0.5, 1.0 + 1e-9])[np.arange(n) % 8]
+    if bearing:
+        # move every measured bearing along the sphere until the angular residual atan2(|p x b|, p . b) equals a * factor: a few
+        # Gauss-Newton steps on the oracle with a numerical tangent gradient (tiny problem)
+        w2 = copy.copy(w)
+        br = np.array(w.bearings, float)
+        target = a * factors
+
+        def angles(b):
+            w2.bearings = b
+            with ha.Problem(w2, lib=oracle) as c:
+                return c.linearize(ftype, robustify=False)["r"][:, 0]
+        for _ in range(8):
+            r = angles(br)
+            g = np.zeros_like(br)
+            for ax in range(3):
+                d = np.zeros(3)
+                d[ax] = 1e-7
+                g[:, ax] = (angles(br + d) - r) / 1e-7
+            g -= (g * br).sum(1, keepdims=True) * br
+            br = br - ((r - target) / np.maximum((g * g).sum(1), 1e-30))[:, None] * g
+            br /= np.linalg.norm(br, axis=1, keepdims=True)
+        w2.bearings = br
+    else:
+        target = np.zeros_like(r0)
+        target[:, 0], target[:, 1] = 0.6 * a * factors, 0.8 * a * factors  # |target| = a * factor (3-4-5: exact in binary up to rounding)
+        w2 = copy.copy(w)
+        w2.pixels = np.array(w.pixels, float) + (r0 - target)
+    with ha.Problem(w2, lib=hip) as g, ha.Problem(w2, lib=oracle) as c:
+        raw = c.linearize(ftype, robustify=False)["r"]
+        norms = np.linalg.norm(raw, axis=1)
+        assert np.abs(norms / a - factors).max() < (1e-6 if bearing else 1e-12)  # the construction hit the threshold neighbourhood
+        lg, lc = g.linearize(ftype, robustify=True), c.linearize(ftype, robustify=True)
+        for key in ("r", "J_state", "J_landmark", "cost"):
+            assert rel(lg[key], lc[key]) < 1e-9, key
+        assert abs(g.cost() - c.cost()) <= 1e-12 * c.cost()

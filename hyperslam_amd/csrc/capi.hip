@@ -81,6 +81,7 @@ struct hs_problem {
   int gravity_const = 1;
   int inertial_mode = HS_INERTIAL_AS_REFERENCE;  // hs_set_inertial_jacobian
   hs_problem* scratch = nullptr;                 // one-residual handle of hs_cost_function_evaluate (created on first use)
+  int frozen_prefix = 0;                         // leading constant control points: decoupled block rows of the reduced system
 
   // structure
   VisualStructure vs;
@@ -256,6 +257,8 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_cp.upload(p->cp, s));
   HIP_TRY(p->d_cp_cand.reserve(p->cp.size()));
   HIP_TRY(p->d_cp_const.upload(p->cp_const, s));
+  p->frozen_prefix = 0;
+  while (p->frozen_prefix < p->n_cp && p->cp_const[p->frozen_prefix]) ++p->frozen_prefix;
   HIP_TRY(p->d_cam.upload(p->cam, s));
   HIP_TRY(p->d_sensor.upload(p->sensor, s));
   HIP_TRY(p->d_lm.upload(lm_dev, s));
@@ -676,22 +679,32 @@ int launch_factor(hs_problem* p) {
     HIP_TRY(hipGetLastError());
     return HS_OK;
   }
+  // One-ended. Block rows of the leading constant control points are decoupled (k_factor_decoupled_rows): the dependency chain of the
+  // factorisation starts behind them — the same kernels on the trailing sub-matrix (the band storage is row relative: pointer offsets).
+  const int f0 = (T.debug_flags & 262144) ? 0 : std::min(p->frozen_prefix, n_blk - 1);  // A/B switch 262144: eliminate every block row
+  Tables Tf = T;
+  if (f0 > 0) {
+    k_factor_decoupled_rows<<<(f0 + 63) / 64, 64, 0, s>>>(T, f0);
+    Tf.Sb += size_t(6 * f0) * ncb, Tf.g_s += 6 * f0, Tf.Ub += size_t(6 * f0) * ncb, Tf.Ubk += size_t(24) * f0, Tf.ybuf += 6 * f0, Tf.np -= 6 * f0;
+    Tf.fj[0] = FactorJob{Tf.Sb, Tf.g_s, Tf.Ub, Tf.Ubk, Tf.ybuf, nullptr, Tf.np / 6, -1};
+  }
   if (nt) {
-    Tables T1 = T;
-    T1.mj[0] = MfmaJob{p->d_Sb2.p, T.g_s, T.Ub, T.Ubk, T.ybuf, nullptr, n_blk, -1, n_blk, INT_MAX, 0, p->d_Vb.p + size_t(T.np) * (6 * T.bw)};
+    Tables T1 = Tf;
+    // (the lower-band rows come from the reversed copy, whose rows are counted from the END of the matrix: no offset)
+    T1.mj[0] = MfmaJob{p->d_Sb2.p, Tf.g_s, Tf.Ub, Tf.Ubk, Tf.ybuf, nullptr, n_blk - f0, -1, n_blk - f0, INT_MAX, 0, p->d_Vb.p + size_t(T.np) * (6 * T.bw)};
     T1.mj[1] = T1.mj[0];
     HIP_TRY(run_mfma(T1, 1));
   } else if (la_ok)
-    k_band_factor_la<1><<<1, kLaThreads, la_lds, s>>>(T);
+    k_band_factor_la<1><<<1, kLaThreads, la_lds, s>>>(Tf);
   // (two tiles per lane need 168 accumulator registers: with six waves per workgroup the budget is 256 and the look-ahead
   //  kernel spills in its update loop - wider bands stay on the kernel below)
   else if (T.bw * T.bw <= kCholThreads)
-    k_band_factor<1><<<1, kCholThreads + kCholIo, chol_lds, s>>>(T);
+    k_band_factor<1><<<1, kCholThreads + kCholIo, chol_lds, s>>>(Tf);
   else if (T.bw <= 21)  // two tiles per lane; the IO wave moves 12 x 64 entries per block row: 6 (6 bw + 1) <= 768 <=> bw <= 21
-    k_band_factor<2><<<1, kCholThreads + kCholIo, chol_lds, s>>>(T);  // (bw = 22 dropped entries of every block row in round 1:
-                                                                      //  found by the lock-step replay, tests/test_host_driver.py)
+    k_band_factor<2><<<1, kCholThreads + kCholIo, chol_lds, s>>>(Tf);  // (bw = 22 dropped entries of every block row in round 1:
+                                                                       //  found by the lock-step replay, tests/test_host_driver.py)
   else  // long feature tracks: trailing window in L2 instead of registers
-    k_band_factor_wide<<<1, kWideThreads, size_t(12) * (ncb + 2) * sizeof(double), s>>>(T);
+    k_band_factor_wide<<<1, kWideThreads, size_t(12) * (ncb + 2) * sizeof(double), s>>>(Tf);
   if (T.nb) {  // bordered system (bias splines + gravity)
     const int fwd_threads = std::max(128, 64 * ((6 * (T.bw - 1) + 63) / 64));  // one lane per pending row
     k_border_forward<<<(T.nb + kBorderCols - 1) / kBorderCols, fwd_threads, size_t(T.np) * kBorderCols * sizeof(double), s>>>(T);

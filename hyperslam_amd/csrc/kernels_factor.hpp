@@ -1217,4 +1217,63 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward(Tables T) {
   }
 }
 
+
+/// Leading block rows of CONSTANT control points (the sliding window freezes every control point at or before its lower bound,
+/// optimizer.cpp:319-328, and keeps them while residuals still reach them): their Jacobian columns are zero, so the block rows are
+/// decoupled from everything — S_i,: = [D_i | 0] with the damping on the diagonal, g_i = 0. The factorisation kernels start behind
+/// them (pointer offsets at launch, the band storage is row relative); this kernel writes their part of the factor, one lane per block
+/// row: U_ii = chol(S_ii), the rest of the row zero, U_ii^-1, y_i = U_ii^-T g_i.
+__global__ void __launch_bounds__(64) k_factor_decoupled_rows(Tables T, int n_rows) {
+  if (T.st->done) return;
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n_rows) return;
+  const int ncb = 6 * T.bw;
+  double U[6][6], y[6];
+  bool ok = true;
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) U[a][c] = c >= a ? T.Sb[size_t(6 * i + a) * ncb + c] : 0.0;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    double d = U[a][a];
+#pragma unroll
+    for (int k = 0; k < a; ++k) d = fma(-U[k][a], U[k][a], d);
+    ok = ok && d > 0.0;
+    const double u = sqrt(d), r = 1.0 / u;
+    U[a][a] = u;
+#pragma unroll
+    for (int c = a + 1; c < 6; ++c) {
+      double t = U[a][c];
+#pragma unroll
+      for (int k = 0; k < a; ++k) t = fma(-U[k][a], U[k][c], t);
+      U[a][c] = t * r;
+    }
+    double t = T.g_s[6 * i + a];
+#pragma unroll
+    for (int k = 0; k < a; ++k) t = fma(-U[k][a], y[k], t);
+    y[a] = t * r;
+    T.ybuf[6 * i + a] = y[a];
+  }
+  if (!ok) T.st->chol_failed = 1;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    double* row = T.Ub + size_t(6 * i + a) * ncb;
+    for (int c = 0; c < ncb; ++c) row[c] = (c >= a && c < 6) ? U[a][c < 6 ? c : 0] : 0.0;
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {  // W = U_ii^-1, upper, packed like the factorisation kernels do
+    double w[6];
+#pragma unroll
+    for (int a = 5; a >= 0; --a) {
+      double t = a == c ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = a + 1; k < 6; ++k) t = fma(-U[a][k], w[k], t);
+      w[a] = a <= c ? t / U[a][a] : 0.0;
+    }
+#pragma unroll
+    for (int a = 0; a <= c; ++a) T.Ubk[size_t(i) * 24 + (a * 6 - a * (a - 1) / 2 + (c - a))] = w[a];
+  }
+}
+
 }  // namespace hs

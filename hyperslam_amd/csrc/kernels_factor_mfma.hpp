@@ -81,8 +81,8 @@ struct MfmaGeom {
   static constexpr int TS = 16 * 17;                          // doubles per tile (row stride 17)
   static constexpr int PC = (W + 1 + 63) / 64;                // panel columns per lane
   static constexpr int PW = (W + 63) / 64;                    // ring positions per lane (right-hand-side update)
-  // LDS (doubles): window NTILE x TS | gring W | xring 2 x 6 x LDX (column W of a row = y) | stage 6 x LDX | rowbuf 6 x LDX | dscr 36
-  static constexpr int kWin = 0, kG = kWin + NTILE * TS, kX = kG + W, kS = kX + 12 * LDX, kR = kS + 6 * LDX, kD = kR + 6 * LDX,
+  // LDS (doubles): window NTILE x TS | gring W | xring 2 x 6 x LDX (column W of a row = y) | stage 6 x LDX | rowbuf 2 x 6 x LDX | dscr 36
+  static constexpr int kWin = 0, kG = kWin + NTILE * TS, kX = kG + W, kS = kX + 12 * LDX, kR = kS + 6 * LDX, kD = kR + 12 * LDX,
                        kTotal = kD + 36;
   __host__ __device__ static constexpr int tile_row_base(int I) { return I * NT - I * (I - 1) / 2; }  // index of tile (I, I)
 };
@@ -109,9 +109,11 @@ HSD double mfma_job_value(const MfmaJob& J, int np, int ncb, int rho, int sigma)
   return ok ? v : 0.0;
 }
 
-/// Phase B of a compute wave: its tiles C -= X_i[:, I]' X_i[:, J].
+/// Phase B of a compute wave: its tiles C -= X_i[:, I]' X_i[:, J]. By-product: the entries of block row i + 2 (ring position p_row), final
+/// for the panel after this update (it applies X_(i+1) itself), go from the accumulator registers to rowbuf in band order — the panel
+/// never reads the tiled window in the steady state. rowbuf[k][c]: row p_row + k, band column c (ring position p_row + c).
 template <int NT, int NC, int WV>
-HSD void mfma_update_tiles(double* win, const double* x, int l, int p_i) {
+HSD void mfma_update_tiles(double* win, const double* x, int l, int p_i, int p_row, int ncb, double* rowbuf) {
   using G = MfmaGeom<NT>;
   constexpr int LDX = G::LDX, TW = (G::NTILE - WV + NC - 1) / NC;
   const int l15 = l & 15, g4 = l >> 4;
@@ -147,6 +149,30 @@ HSD void mfma_update_tiles(double* win, const double* x, int l, int p_i) {
       double* c = win + (G::tile_row_base(I) + Jt - I) * G::TS + el;
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) c[rr * 4 * 17] = acc[m - 1][rr];
+      // does the tile hold entries of rows p_row .. p_row + 5? (ring interval test, wave uniform)
+      constexpr int W = G::W;
+      int sr = 16 * I - p_row + 15, sc = 16 * Jt - p_row + 15;
+      sr += sr < 0 ? W : 0, sc += sc < 0 ? W : 0;
+      if (sr <= 20) {  // as rows of the tile: element (16 I + r, 16 Jt + l15) -> rowbuf[row - p_row][column - p_row]
+        int cc = 16 * Jt + l15 - p_row;
+        cc += cc < 0 ? W : 0;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          int k = 16 * I + g4 + 4 * rr - p_row;
+          k += k < 0 ? W : 0;
+          if (k < 6 && cc < ncb) rowbuf[k * LDX + cc] = acc[m - 1][rr];
+        }
+      }
+      if (I != Jt && sc <= 20) {  // as columns (the stored element also is the pair the other way round); a diagonal tile has both already
+        int k = 16 * Jt + l15 - p_row;
+        k += k < 0 ? W : 0;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          int cc = 16 * I + g4 + 4 * rr - p_row;
+          cc += cc < 0 ? W : 0;
+          if (k < 6 && cc < ncb) rowbuf[k * LDX + cc] = acc[m - 1][rr];
+        }
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   });
@@ -200,45 +226,27 @@ __global__ void __launch_bounds__(64 * (NC + 3)) k_band_factor_mfma(Tables T) {
     }
     for (int da = tid; da < dm; da += nthreads) gring[ring_add<W>(p_m, da)] += D[size_t(da) * (dm + 1) + dm];
   };
-  // Phase A of step i, shared by the five waves that have nothing else to do in it (compute 0-2, loader, storer: hx = 0 .. 4), one
-  // row each (+ a sixth for hx 0 / 4): GATHER the next pivot row (block row i + 1, ring position p_next) from the window into rowbuf
-  // in band order, SCATTER the staged entering block row (i + bw + 1) into the window. One element of each pair is wave uniform, so
-  // the tile address (mfma_pair_addr) splits into a uniform and a lane part.
-  auto helper_phase_a = [&](int hx, int p_next, bool gather) {
+  // Phase A of step i (all six waves, one row of the entering block row i + bw + 1 each): SCATTER the staged row q (stage[q][t]: pairs
+  // (ring position p_lo + t, p_e + q), t < ncb; t == ncb: right-hand side) into the tiled window. The second element of each pair is wave
+  // uniform, so the tile address (mfma_pair_addr) splits into a uniform and a lane part. This is the only work of phase A: nobody
+  // updates tiles in it, so the plain stores cannot race with a read-modify-write of a compute wave.
+  auto scatter_row = [&](int q, int p_next) {
     const int p_lo = ring_add<W>(p_next, 6), p_e = ring_add<W>(p_lo, 6 * (bw - 1));
-    int Ib[PC], cb[PC], tb[PC], Ia[PC], ca[PC], ta[PC];
+    const int b = p_e + q, Iu = b >> 4, cu = b & 15, tu = Iu * NT - ((Iu * (Iu - 1)) >> 1);
+    const int u1 = Iu * G::TS + cu, u2 = (tu - Iu) * G::TS + cu * 17, um = tu * G::TS + cu * 17;
+    double val[PC];
+#pragma unroll
+    for (int m = 0; m < PC; ++m) val[m] = stage[q * LDX + (l + 64 * m <= ncb ? l + 64 * m : 0)];
 #pragma unroll
     for (int m = 0; m < PC; ++m) {
-      const int c = l + 64 * m;
-      const int b = c < W ? ring_add<W>(p_next, c) : 0, a = c < W ? ring_add<W>(p_lo, c) : 0;
-      Ib[m] = b >> 4, cb[m] = b & 15, tb[m] = Ib[m] * NT - ((Ib[m] * (Ib[m] - 1)) >> 1);
-      Ia[m] = a >> 4, ca[m] = a & 15, ta[m] = Ia[m] * NT - ((Ia[m] * (Ia[m] - 1)) >> 1);
-    }
-    if (gather) {
-      for (int k = hx; k < 6; k += 5) {  // (hx 0 takes row 5 too)
-        const int a = p_next + k, Iu = a >> 4, cu = a & 15, tu = Iu * NT - ((Iu * (Iu - 1)) >> 1);
-        const int u1 = (tu - Iu) * G::TS + cu * 17, u2 = Iu * G::TS + cu;
-#pragma unroll
-        for (int m = 0; m < PC; ++m) {
-          const int c = l + 64 * m;
-          if (c < ncb) rowbuf[k * LDX + c] = win[Iu <= Ib[m] ? u1 + Ib[m] * G::TS + cb[m] : u2 + (tb[m] - Ib[m]) * G::TS + cb[m] * 17];
-          else if (c == ncb) rowbuf[k * LDX + W] = gring[a];
-        }
-      }
-    }
-    for (int q = hx; q < 6; q += (hx == 4 ? 1 : 6)) {  // (hx 4 takes row 5 too)
-      const int b = p_e + q, Iu = b >> 4, cu = b & 15, tu = Iu * NT - ((Iu * (Iu - 1)) >> 1);
-      const int u1 = Iu * G::TS + cu, u2 = (tu - Iu) * G::TS + cu * 17, um = tu * G::TS + cu * 17;
-#pragma unroll
-      for (int m = 0; m < PC; ++m) {
-        const int t = l + 64 * m;
-        if (t < ncb) {
-          const double val = stage[q * LDX + t];
-          win[Ia[m] <= Iu ? (ta[m] - Ia[m]) * G::TS + ca[m] * 17 + u1 : Ia[m] * G::TS + ca[m] + u2] = val;
-          if (Ia[m] == Iu) win[um + ca[m]] = val;  // diagonal tile: the mirrored element too
-        } else if (t == ncb) {
-          gring[b] = stage[q * LDX + t];
-        }
+      const int t = l + 64 * m;
+      const int a = t < W ? ring_add<W>(p_lo, t) : 0;
+      const int Ia = a >> 4, ca = a & 15, ta = __mul24(Ia, NT) - (__mul24(Ia, Ia - 1) >> 1);
+      if (t < ncb) {
+        win[Ia <= Iu ? __mul24(ta - Ia, G::TS) + ca * 17 + u1 : __mul24(Ia, G::TS) + ca + u2] = val[m];
+        if (Ia == Iu) win[um + ca] = val[m];  // diagonal tile: the mirrored element too
+      } else if (t == ncb) {
+        gring[b] = val[m];
       }
     }
   };
@@ -250,14 +258,16 @@ __global__ void __launch_bounds__(64 * (NC + 3)) k_band_factor_mfma(Tables T) {
     int p_i = 0;
     for (int i = 0; i < n_steps; ++i) {
       if (prof && hw == 0) tlog[8 * i + 4] = wall_clock64();
-      helper_phase_a(hw, ring_add<W>(p_i, 6), i + 1 < n_steps && !(m_at >= 0 && i + 1 == m_at));
+      scatter_row(hw, ring_add<W>(p_i, 6));
       if (prof && hw == 0) tlog[8 * i + 5] = wall_clock64();
       lds_barrier();  // A -> B
       if (prof && hw == 0) tlog[8 * i + 0] = wall_clock64();
       const double* x = xring + (i & 1) * 6 * LDX;
-      if (hw == 0) mfma_update_tiles<NT, NC, 0>(win, x, l, p_i);
-      if (hw == 1) mfma_update_tiles<NT, NC, 1>(win, x, l, p_i);
-      if (hw == 2) mfma_update_tiles<NT, NC, 2>(win, x, l, p_i);
+      double* rb = rowbuf + (i & 1) * 6 * LDX;  // block row i + 2 for the panel of the next step
+      const int p_row = ring_add<W>(p_i, 12);
+      if (hw == 0) mfma_update_tiles<NT, NC, 0>(win, x, l, p_i, p_row, ncb, rb);
+      if (hw == 1) mfma_update_tiles<NT, NC, 1>(win, x, l, p_i, p_row, ncb, rb);
+      if (hw == 2) mfma_update_tiles<NT, NC, 2>(win, x, l, p_i, p_row, ncb, rb);
       if (prof && hw == 0) tlog[8 * i + 1] = wall_clock64();
       p_i = ring_add<W>(p_i, 6);
       lds_barrier();  // B -> A
@@ -311,7 +321,7 @@ __global__ void __launch_bounds__(64 * (NC + 3)) k_band_factor_mfma(Tables T) {
     lds_barrier();  // P1
     int p_i = 0;
     auto step = [&](double (*v)[6], int i) {  // v holds block row i + bw + 2 (fetched two steps ago)
-      helper_phase_a(3, ring_add<W>(p_i, 6), i + 1 < n_steps && !(m_at >= 0 && i + 1 == m_at));
+      scatter_row(4, ring_add<W>(p_i, 6));
       lds_barrier();           // A -> B
       stage_write(v);          // scattered in phase A of step i + 1
       fetch(v, i + bw + 4);
@@ -328,7 +338,7 @@ __global__ void __launch_bounds__(64 * (NC + 3)) k_band_factor_mfma(Tables T) {
     lds_barrier();  // P1: X_0 complete
     int p_i = 0;
     for (int i = 0; i < n_steps; ++i) {
-      helper_phase_a(4, ring_add<W>(p_i, 6), i + 1 < n_steps && !(m_at >= 0 && i + 1 == m_at));
+      scatter_row(5, ring_add<W>(p_i, 6));
       lds_barrier();  // A -> B
       const double* x = xring + (i & 1) * 6 * LDX;
 #pragma unroll
@@ -361,6 +371,8 @@ __global__ void __launch_bounds__(64 * (NC + 3)) k_band_factor_mfma(Tables T) {
           gring[pos] = acc;
         }
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (same wave: the stores above are visible to the loads below)
+      if (l < 6) rowbuf[(i & 1) * 6 * LDX + l * LDX + W] = gring[ring_add<W>(p_i, 12) + l];  // right-hand side of block row i + 2 -> panel
       {  // W = U_ii^-1 (upper triangular, packed): lane c < 6 solves U w = e_c. U_ii sits at the pivot's own positions of X (upper part)
         const int c = l < 6 ? l : 0;
         double w[6];
@@ -434,15 +446,18 @@ __global__ void __launch_bounds__(64 * (NC + 3)) k_band_factor_mfma(Tables T) {
         pos[m] = is_rhs[m] ? W : (c < W ? ring_add<W>(pr, c) : 0);
       }
     };
-    auto panel_compute = [&](int r, int pr, bool update) {  // phase B
+    // update: the row still lacks X_(r-1) (look-ahead); direct: v was read from the window by panel_read (first rows, junction),
+    // otherwise the compute waves left the row in rowbuf[r & 1] one step ago (by-product of their update with X_(r-2))
+    auto panel_compute = [&](int r, int pr, bool update, bool direct) {  // phase B
       if (prof) plog[8 * r + 1] = wall_clock64();
-      if (update) {  // the row was gathered into rowbuf by the helper waves (phase A)
+      if (update && !direct) {
         panel_slots(pr);
+        const double* rb = rowbuf + (r & 1) * 6 * LDX;
 #pragma unroll
         for (int m = 0; m < PC; ++m) {
           const int c = l + 64 * m, cc = is_rhs[m] ? W : (c < W ? c : 0);
 #pragma unroll
-          for (int k = 0; k < 6; ++k) v[m][k] = rowbuf[k * LDX + cc];
+          for (int k = 0; k < 6; ++k) v[m][k] = rb[k * LDX + cc];
         }
       }
       const double* xp = xring + ((r - 1) & 1) * 6 * LDX;
@@ -527,20 +542,24 @@ __global__ void __launch_bounds__(64 * (NC + 3)) k_band_factor_mfma(Tables T) {
       if (prof) plog[8 * r + 3] = wall_clock64();
     };
     panel_read(0, 0);
-    panel_compute(0, 0, false);
+    panel_compute(0, 0, false, true);
+    bool direct = true;  // the row after a freshly factored one is read from the window itself: nobody has gathered it
+    if (n_steps > 1) panel_read(1, 6);
     lds_barrier();  // P1: X_0 published
     int p_next = 6;  // ring position of block row i + 1
     for (int i = 0; i < n_steps; ++i) {
       const bool junction = m_at >= 0 && i + 1 == m_at;  // no look-ahead across the junction: row m changes there
       const bool ahead = i + 1 < n_steps && !junction;
-      lds_barrier();  // A -> B (the helper waves gather row i + 1)
-      if (ahead) panel_compute(i + 1, p_next, true);
+      scatter_row(3, p_next);
+      lds_barrier();  // A -> B
+      if (ahead) panel_compute(i + 1, p_next, true, direct), direct = false;
       lds_barrier();  // B -> A
       if (junction) {
         junction_merge(p_next);
         lds_barrier();  // J1: window merged
         panel_read(m_at, p_next);
-        panel_compute(m_at, p_next, false);
+        panel_compute(m_at, p_next, false, true);
+        if (m_at + 1 < n_steps) panel_read(m_at + 1, ring_add<W>(p_next, 6)), direct = true;
         lds_barrier();  // J2: X_m published
       }
       p_next = ring_add<W>(p_next, 6);

@@ -21,6 +21,54 @@ using namespace hs;
 
 namespace {
 
+/// Table uploads of one prepare() collected into ONE pinned staging arena: a sliding window re-uploads ~45 small tables at every
+/// optimize(), and 45 hipMemcpyAsync calls from pageable memory cost more host time than the solve's launches. add() copies the
+/// source into the arena and records (destination, offset, bytes); flush() sends the arena with one asynchronous copy and lets one
+/// kernel scatter the segments to their destinations. The arena stays alive, so no host synchronisation is needed afterwards.
+struct UploadBatch {
+  struct Seg {
+    unsigned long long dst, off, bytes;
+  };
+  std::vector<Seg> segs;
+  char* host = nullptr;  // pinned
+  char* dev = nullptr;
+  size_t host_cap = 0, dev_cap = 0, used = 0;
+  hipEvent_t sent = nullptr;  // the previous arena content has left the host
+  bool in_flight = false;
+  ~UploadBatch() {
+    if (host) (void)hipHostFree(host);
+    if (dev) (void)hipFree(dev);
+    if (sent) (void)hipEventDestroy(sent);
+  }
+  hipError_t grow_host(size_t need) {
+    if (need <= host_cap) return hipSuccess;
+    const size_t want = std::max<size_t>(std::max<size_t>(need, size_t(1) << 20), 2 * host_cap);
+    char* fresh = nullptr;
+    const hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&fresh), want, hipHostMallocDefault);
+    if (e != hipSuccess) return e;
+    if (used) std::memcpy(fresh, host, used);
+    if (host) (void)hipHostFree(host);
+    host = fresh, host_cap = want;
+    return hipSuccess;
+  }
+  hipError_t add(void* dst, const void* src, size_t bytes) {
+    if (in_flight) {  // (only if two prepare() calls follow each other without a synchronising entry point in between)
+      const hipError_t e = hipEventSynchronize(sent);
+      if (e != hipSuccess) return e;
+      in_flight = false;
+    }
+    const size_t off = (used + 15) & ~size_t(15);
+    const hipError_t e = grow_host(off + bytes + 16);
+    if (e != hipSuccess) return e;
+    std::memcpy(host + off, src, bytes);
+    segs.push_back(Seg{reinterpret_cast<unsigned long long>(dst), off, bytes});
+    used = off + bytes;
+    return hipSuccess;
+  }
+  hipError_t flush(hipStream_t s);
+};
+thread_local UploadBatch* tl_upload_batch = nullptr;  // set by prepare() around its uploads
+
 template <class T>
 struct DBuf {
   T* p = nullptr;
@@ -43,9 +91,47 @@ struct DBuf {
   hipError_t upload(const std::vector<T>& h, hipStream_t s) {
     hipError_t e = reserve(h.size());
     if (e != hipSuccess || h.empty()) return e;
+    if (tl_upload_batch) return tl_upload_batch->add(p, h.data(), h.size() * sizeof(T));
     return hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s);
   }
 };
+
+__global__ void __launch_bounds__(256) k_scatter_uploads(const char* arena, const UploadBatch::Seg* segs) {
+  const UploadBatch::Seg sg = segs[blockIdx.x];
+  const char* src = arena + sg.off;
+  char* dst = reinterpret_cast<char*>(sg.dst);
+  const size_t n16 = sg.bytes / 16;  // destinations are hipMalloc'ed (256-byte aligned), arena offsets 16-byte aligned
+  for (size_t i = threadIdx.x; i < n16; i += 256) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+  for (size_t i = 16 * n16 + threadIdx.x; i < sg.bytes; i += 256) dst[i] = src[i];
+}
+
+hipError_t UploadBatch::flush(hipStream_t s) {
+  if (segs.empty()) return hipSuccess;
+  const size_t table = (used + 15) & ~size_t(15), total = table + segs.size() * sizeof(Seg);
+  hipError_t e = grow_host(total);
+  if (e != hipSuccess) return e;
+  std::memcpy(host + table, segs.data(), segs.size() * sizeof(Seg));
+  if (total > dev_cap) {
+    if (dev) (void)hipFree(dev);
+    dev = nullptr, dev_cap = 0;
+    const size_t want = std::max<size_t>(2 * total, size_t(1) << 20);
+    e = hipMalloc(reinterpret_cast<void**>(&dev), want);
+    if (e != hipSuccess) return e;
+    dev_cap = want;
+  }
+  e = hipMemcpyAsync(dev, host, total, hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) return e;
+  if (!sent) {
+    e = hipEventCreateWithFlags(&sent, hipEventDisableTiming);
+    if (e != hipSuccess) return e;
+  }
+  e = hipEventRecord(sent, s);
+  if (e != hipSuccess) return e;
+  in_flight = true;
+  k_scatter_uploads<<<int(segs.size()), 256, 0, s>>>(dev, reinterpret_cast<const Seg*>(dev + table));
+  segs.clear(), used = 0;
+  return hipGetLastError();
+}
 
 }  // namespace
 
@@ -82,6 +168,7 @@ struct hs_problem {
   int inertial_mode = HS_INERTIAL_AS_REFERENCE;  // hs_set_inertial_jacobian
   hs_problem* scratch = nullptr;                 // one-residual handle of hs_cost_function_evaluate (created on first use)
   int frozen_prefix = 0;                         // leading constant control points: decoupled block rows of the reduced system
+  UploadBatch batch;                             // table uploads of prepare()
 
   // structure
   VisualStructure vs;
@@ -150,6 +237,14 @@ int mfma_window_tiles(int bw);
 
 int prepare(hs_problem* p) {
   if (!p->dirty) return HS_OK;
+  struct BatchScope {  // every DBuf::upload below goes through the staging arena; sent in one piece at the end
+    UploadBatch* b;
+    explicit BatchScope(UploadBatch* x) : b(x) { tl_upload_batch = b; }
+    ~BatchScope() {
+      tl_upload_batch = nullptr;
+      b->segs.clear(), b->used = 0;  // (no-op after a flush; drops the pending segments of a failed prepare)
+    }
+  } batch_scope(&p->batch);
   if (p->n_cp == 0) HS_FAIL(HS_ERR_STATE, "hs_set_spline has not been called");
   if (p->k != 4 && p->k != 6) HS_FAIL(HS_ERR_INVALID, "device kernels are instantiated for spline order 4 and 6");
   HIP_TRY(hipSetDevice(p->device));
@@ -477,7 +572,7 @@ int prepare(hs_problem* p) {
   // 131072 k_band_factor_mfma (trailing window in f64 MFMA tiles) instead of the VALU factorisation kernels
   // 65536 single-wave register backward sweep (k_band_backward_w) instead of the four-wave LDS sweeps
   T.st = p->d_state.p;
-  HIP_TRY(hipStreamSynchronize(s));  // host staging vectors go out of scope
+  HIP_TRY(p->batch.flush(s));  // (the staging arena outlives this call: no host synchronisation)
   p->dirty = false;
   return HS_OK;
 }

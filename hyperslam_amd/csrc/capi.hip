@@ -1369,7 +1369,8 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
     const int n = std::min(st.num_iterations, max_iterations);
     for (int i = 0; i <= n; ++i) iterations[i] = st.records[i];
   }
-  if (st.chol_failed && st.termination == HS_FAILURE) p->err = "reduced system not positive definite";
+  if (st.chol_failed && st.termination == HS_FAILURE)
+    p->err = st.chol_failed == 2 ? "two-ended solve: the partner workgroup did not arrive within 2 s" : "reduced system not positive definite";
   return HS_OK;
 }
 

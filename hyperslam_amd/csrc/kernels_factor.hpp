@@ -297,6 +297,21 @@ __global__ void __launch_bounds__(kCholThreads + kCholIo) k_band_factor(Tables T
 // factor of the system in which the far end has been eliminated. k_band_backward2 solves the top part normally and the bottom
 // part in reversed coordinates once the middle solution is known.
 // ---------------------------------------------------------------------------------------------------------------------
+/// Waits until the partner workgroup of a two-ended kernel has published its half (join_flag >= join_epoch). Both workgroups of the
+/// launch are resident together on every gfx950 configuration this library runs on, but a wait on another workgroup must not be able
+/// to hang the device: after 2 s (100 MHz constant clock) the wait gives up and marks the factorisation as failed — the step is then
+/// rejected as invalid (k_decide) and hs_solve reports the reason — and the caller carries on so that no barrier is left waiting.
+HSD void wait_for_partner(const Tables& T) {
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(T.join_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < T.join_epoch) {
+    __builtin_amdgcn_s_sleep(8);
+    if (wall_clock64() - t0 > 200000000ll) {
+      T.st->chol_failed = 2;
+      break;
+    }
+  }
+}
+
 constexpr int kLaCompute = 192;
 constexpr int kLaThreads = kLaCompute + 3 * 64;
 
@@ -322,7 +337,7 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
     if (cl / 6 == r / 6) J.win[size_t(cl) * wl + (r - rb)] = value_minus_original;  // mirrored entry of the diagonal block
   };
   auto junction_wait = [&]() {                                  // job 0: the other end has published its window
-    while (__hip_atomic_load(T.join_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < T.join_epoch) __builtin_amdgcn_s_sleep(8);
+    wait_for_partner(T);
   };
   const int tid = threadIdx.x;
   constexpr int nthr = kLaCompute;
@@ -848,7 +863,7 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward2(Tables T, BackJ
   load_u(jtop, u0), load_u(jtop - 1, u1), load_u(jtop - 2, u2);
   w0 = load_w(jtop), w1 = load_w(jtop - 1), w2 = load_w(jtop - 2);
   if (J.given) {  // wait for the middle solution
-    while (__hip_atomic_load(T.join_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < T.join_epoch) __builtin_amdgcn_s_sleep(8);
+    wait_for_partner(T);
     for (int rho = n_own + tid; rho < n_all; rho += nthr) xs[rho] = T.xsol[J.reversed ? np - 1 - rho : rho];
   }
   __syncthreads();

@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(64 * (NC + 3)) k_band_factor_mfma(Tables T) {
   // Junction (job 0, every wave): add the other end's Schur correction of the middle block rows to the window (p_m = ring position of
   // block row m). D is dm x (dm + 1) in middle-local coordinates, last column = right-hand side.
   auto junction_merge = [&](int p_m) {
-    while (__hip_atomic_load(T.join_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < T.join_epoch) __builtin_amdgcn_s_sleep(8);
+    wait_for_partner(T);
     const int dm = 6 * (bw - 1);
     const double* D = J.win;
     for (int e = tid; e < dm * dm; e += nthreads) {

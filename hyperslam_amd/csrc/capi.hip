@@ -645,18 +645,22 @@ template <int K>
 int launch_build(hs_problem* p) {
   const Tables& T = p->T;
   hipStream_t s = p->stream;
-  // k_seg_gram only needs the records, k_landmark -> k_group_gram only records and landmarks: fork / join on a side stream
-  if (!p->side) {
-    HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
-  }
-  const bool fork = T.n_lm > 0 && !(T.debug_flags & 1024);
+  // k_seg_gram only needs the records, k_landmark -> k_group_gram records and landmarks: the two gram kernels share one launch
+  // (k_gram_pair). A/B switch 1024: the previous arrangement, k_seg_gram on a side stream next to k_landmark -> k_group_gram.
+  // (only while every workgroup of the pair is resident at once — two per CU at 80 KB of LDS each; larger grids keep the two streams,
+  //  where k_group_gram alone fits three workgroups per CU: configs[3] measured 0.165 ms vs 0.181 ms for the Schur stage)
+  const bool pair = T.n_lm > 0 && p->n_group_wg > 0 && p->n_group_wg + p->n_seg_wg <= 512 && !(T.debug_flags & 1024);
+  const bool fork = T.n_lm > 0 && !pair;
   if (fork) {
+    if (!p->side) {
+      HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+    }
     HIP_TRY(hipEventRecord(p->ev_fork, s));
     HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0));
   }
-  k_seg_gram<K><<<p->n_seg_wg, kBlock, kSegStage * sizeof(double), fork ? p->side : s>>>(T);
+  if (!pair) k_seg_gram<K><<<p->n_seg_wg, kBlock, kSegStage * sizeof(double), fork ? p->side : s>>>(T);
   if (fork) HIP_TRY(hipEventRecord(p->ev_join, p->side));
   if (T.n_lm) {
     const int grid = (T.n_lm + kBlock / 64 - 1) / (kBlock / 64);
@@ -670,7 +674,16 @@ int launch_build(hs_problem* p) {
     const int batch = std::max(2, std::min(kGroupBatch, int(48 * 1024 / (size_t(18) * T.bw * sizeof(double)))));
     const size_t lds = std::max((size_t(batch) * 18 * T.bw + 4 * batch) * sizeof(double), size_t(128) * 42 * sizeof(double));
     const dim3 grid(p->n_group_wg);
-    if (ntile <= kBlock)
+    if (pair) {
+      const size_t lds2 = std::max(lds, kSegStage * sizeof(double));
+      const dim3 grid2(p->n_group_wg + p->n_seg_wg);
+      if (ntile <= kBlock)
+        k_gram_pair<K, 1><<<grid2, kBlock, lds2, s>>>(T, batch, p->n_group_wg);
+      else if (ntile <= 2 * kBlock)
+        k_gram_pair<K, 2><<<grid2, kBlock, lds2, s>>>(T, batch, p->n_group_wg);
+      else
+        k_gram_pair<K, 4><<<grid2, kBlock, lds2, s>>>(T, batch, p->n_group_wg);
+    } else if (ntile <= kBlock)
       k_group_gram<1><<<grid, kBlock, lds, s>>>(T, batch);
     else if (ntile <= 2 * kBlock)
       k_group_gram<2><<<grid, kBlock, lds, s>>>(T, batch);
@@ -722,7 +735,9 @@ hipError_t launch_mfma(const Tables& T, int grid, hipStream_t s) {
 
 void launch_backward_w(const Tables& T, const BackJob& j0, const BackJob& j1, int m_mid, int grid, hipStream_t s) {
   const size_t lds = size_t(T.np) * sizeof(double);
-  if (T.bw <= 2 * kBackBlocks)
+  if (T.bw <= kBackBlocks)
+    k_band_backward_w<1><<<grid, 64, lds, s>>>(T, j0, j1, m_mid);
+  else if (T.bw <= 2 * kBackBlocks)
     k_band_backward_w<2><<<grid, 64, lds, s>>>(T, j0, j1, m_mid);
   else if (T.bw <= 4 * kBackBlocks)
     k_band_backward_w<4><<<grid, 64, lds, s>>>(T, j0, j1, m_mid);
@@ -855,6 +870,12 @@ int set_func_attributes(hs_problem* p) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_la<1>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seg_gram<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seg_gram<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<6, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<6, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<6, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_visual<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_visual<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_forward), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));

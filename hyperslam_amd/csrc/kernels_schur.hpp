@@ -161,8 +161,9 @@ __global__ void __launch_bounds__(kBlock) k_landmark(Tables T) {
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kSegStage = 6144;  // doubles of record data staged in LDS per round (48 KB)
 
+/// (body shared by k_seg_gram and the combined launch k_gram_pair; bid = workgroup index in the segment work list)
 template <int K>
-__global__ void __launch_bounds__(kBlock) k_seg_gram(Tables T) {
+HSD void seg_gram_body(const Tables& T, const int bid) {
   extern __shared__ __attribute__((aligned(16))) double stage[];  // kSegStage doubles: a contiguous run of records
   __shared__ __attribute__((aligned(16))) double red[kBlock * 12 + kBlock * 3];
   if (T.st->done) return;
@@ -170,7 +171,7 @@ __global__ void __launch_bounds__(kBlock) k_seg_gram(Tables T) {
   constexpr int VREC = 8 + 12 * K, PREC = 6 + 36 * K;
   // work list: workgroup w serves segment sw_seg[w] as split sp of nsp (splits proportional to the segment's record count: the
   // first and last segment of a window collect the clamped stamps)
-  const int first = T.sw_seg[blockIdx.x], sp = blockIdx.x - T.sw_ptr[first], nsp = T.sw_ptr[first + 1] - T.sw_ptr[first];
+  const int first = T.sw_seg[bid], sp = bid - T.sw_ptr[first], nsp = T.sw_ptr[first + 1] - T.sw_ptr[first];
   const int tid = threadIdx.x;
   const int stream = tid / TPS, tb = tid % TPS, rg = tb / CG, cg = tb % CG;
   const bool sprof = (T.debug_flags & 32) && tid == 0 && sp == 0 && first < 128;
@@ -244,7 +245,7 @@ __global__ void __launch_bounds__(kBlock) k_seg_gram(Tables T) {
       for (int r = 0; r < 3; ++r) rg3[(stream * RG + rg) * 3 + r] = gacc[r];
   }
   __syncthreads();
-  double* P = T.segP + size_t(blockIdx.x) * (NCA * NCA + NCA);
+  double* P = T.segP + size_t(bid) * (NCA * NCA + NCA);
   for (int e = tid; e < NCA * NCA; e += kBlock) {
     const int a = e / NCA, c = e % NCA;
     const int t = (a / 3) * CG + c / 4, in = 4 * (a % 3) + c % 4;
@@ -262,6 +263,11 @@ __global__ void __launch_bounds__(kBlock) k_seg_gram(Tables T) {
   if (sprof) slog[3] = wall_clock64();
 }
 
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_seg_gram(Tables T) {
+  seg_gram_body<K>(T, blockIdx.x);
+}
+
 HSD int ok_index(int b, int nb) { return b < nb ? b : 0; }
 
 /// Upper 6x6 tiles of the 6 bw x 6 bw window of a landmark group: tile index of (rb, cb), rb <= cb < bw.
@@ -270,13 +276,13 @@ HSD int group_tile_index(int rb, int cb, int bw) { return rb * bw - rb * (rb - 1
 constexpr int kGroupBatch = 16;  // landmarks staged in LDS per round (host caps it so that the stage fits 48 KB)
 
 template <int NT>  // tiles per thread: NT == 1: two landmark streams of 128 lanes (bw <= 15); NT > 1: one stream, bw (bw + 1) / 2 <= NT * kBlock
-__global__ void __launch_bounds__(kBlock, NT == 1 ? 3 : 1) k_group_gram(Tables T, int batch) {
+HSD void group_gram_body(const Tables& T, const int batch, const int bid) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   __shared__ int m_ncp[kBlock], m_off[kBlock];
   if (T.st->done) return;
   // work list: workgroup w serves group cf = gw_cf[w] as split sp of nsp (splits proportional to the group's landmark count:
   // the first control point of a window collects every track that started before it)
-  const int cf = T.gw_cf[blockIdx.x], sp = blockIdx.x - T.gw_ptr[cf], nsp = T.gw_ptr[cf + 1] - T.gw_ptr[cf];
+  const int cf = T.gw_cf[bid], sp = bid - T.gw_ptr[cf], nsp = T.gw_ptr[cf + 1] - T.gw_ptr[cf];
   const int tid = threadIdx.x;
   const int bw = T.bw, R = 6 * bw, ntile = bw * (bw + 1) / 2;
   double* ybuf = smem;                          // batch x (R x 3): Y-hat rows (zero past the landmark's rows)
@@ -369,7 +375,7 @@ __global__ void __launch_bounds__(kBlock, NT == 1 ? 3 : 1) k_group_gram(Tables T
     }
   }
   if (gprof) glog[3] = wall_clock64(), glog[5] = n_mine;
-  double* Q = T.grpQ + size_t(blockIdx.x) * (size_t(ntile) * 36 + R);
+  double* Q = T.grpQ + size_t(bid) * (size_t(ntile) * 36 + R);
   if (two) {  // stream 1 hands its partial to stream 0 through LDS (fixed order: stream 0 + stream 1)
     __syncthreads();
     double* xch = smem;  // 128 x 42 doubles <= the stage
@@ -399,6 +405,22 @@ __global__ void __launch_bounds__(kBlock, NT == 1 ? 3 : 1) k_group_gram(Tables T
       for (int r = 0; r < 6; ++r) Q[size_t(ntile) * 36 + 6 * t_rb[m] + r] = qacc[m][r];
   }
   if (gprof) glog[4] = wall_clock64();
+}
+
+template <int NT>
+__global__ void __launch_bounds__(kBlock, NT == 1 ? 3 : 1) k_group_gram(Tables T, int batch) {
+  group_gram_body<NT>(T, batch, blockIdx.x);
+}
+
+/// k_group_gram and k_seg_gram in ONE launch (workgroups [0, n_group) serve the landmark groups, the rest the segments): the two are
+/// independent and each fills only part of the chip; as two launches they ran on two streams with an event fork / join, whose barrier
+/// packets cost more (~6 us each on the critical path, rocprofv3 kernel trace) than the overlap was worth.
+template <int K, int NT>
+__global__ void __launch_bounds__(kBlock) k_gram_pair(Tables T, int batch, int n_group) {
+  if (int(blockIdx.x) < n_group)
+    group_gram_body<NT>(T, batch, blockIdx.x);
+  else
+    seg_gram_body<K>(T, blockIdx.x - n_group);
 }
 
 constexpr int kAsmThreads = 512, kAsmU = 8;  // lanes per scalar row, loads in flight per lane

@@ -271,23 +271,33 @@ def main():
             keep = attach_allreduce(problem, dist)  # Python hook (gloo test path / HS_EXCHANGE=hook)
     problem.snapshot()
 
-    def step():
+    # Per-stage HIP events (4 per LM iteration, each a barrier packet worth ~5.7 us of idle device) are off in the library by default.
+    # One step in STAGE_EVERY of the timed region runs with them on: the live launch duration of the linearisation kernel (roofline) and
+    # the stage breakdown come from those launches, inside the timed region, at a quarter of the events' cost to `value`.
+    STAGE_EVERY = 4
+
+    def step(i=0):
+        staged = i % STAGE_EVERY == 0
+        problem.set_stage_timing(staged)
         problem.restore()
         s = problem.solve(LM_ITERATIONS)
         assert s["num_iterations"] == LM_ITERATIONS, s
-        return s
+        return s, staged
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     stage = {"linearize_ms": 0.0, "schur_ms": 0.0, "solve_ms": 0.0, "update_ms": 0.0, "total_ms": 0.0}
+    n_staged = 0
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        s = step()
-        for k in stage:
-            stage[k] += s[k]
+    for i in range(args.steps):
+        s, staged = step(i)
+        if staged:
+            n_staged += 1
+            for k in stage:
+                stage[k] += s[k]
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -298,7 +308,7 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        n_lin = args.steps * LM_ITERATIONS  # launches of the linearise kernel in the timed region
+        n_lin = n_staged * LM_ITERATIONS  # launches of the linearise kernel bracketed by HIP events (every STAGE_EVERY-th step of the timed region)
         lin_ms = stage["linearize_ms"] / n_lin
         order = int(window.order)
         b_alg = 32 + 8 * (8 + 12 * order)  # 32 B in + one record [r(2) J_l(6) J_state(12 k)] out = 480 B at k = 4
@@ -333,6 +343,8 @@ def main():
                        **({"exchange": exchange} if world > 1 else {})},
             "final_cost": s["final_cost"], "initial_cost": s["initial_cost"],
             "device_ms_per_iteration": {k: v / n_lin for k, v in stage.items()},
+            "stage_events": f"HIP events around the four stages on every {STAGE_EVERY}th step of the timed region ({n_staged} of {args.steps} steps); "
+                            "those steps carry ~23 us of event barriers per iteration, the others none",
             # roofline of the kernel SURVEY.md §8(d)'s B_alg is defined for (linearisation: 480 B per pixel residual block); its
             # launch time is measured with HIP events on the launch stream inside hs_solve. The factorisation kernel that
             # dominates the iteration time is a single-workgroup dependency chain (latency-bound, no meaningful roofline); its

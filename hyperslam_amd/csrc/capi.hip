@@ -168,6 +168,7 @@ struct hs_problem {
   int inertial_mode = HS_INERTIAL_AS_REFERENCE;  // hs_set_inertial_jacobian
   hs_problem* scratch = nullptr;                 // one-residual handle of hs_cost_function_evaluate (created on first use)
   int frozen_prefix = 0;                         // leading constant control points: decoupled block rows of the reduced system
+  bool stage_timing = false;                     // hs_set_stage_timing
   UploadBatch batch;                             // table uploads of prepare()
 
   // structure
@@ -647,9 +648,9 @@ int launch_build(hs_problem* p) {
   hipStream_t s = p->stream;
   // k_seg_gram only needs the records, k_landmark -> k_group_gram records and landmarks: the two gram kernels share one launch
   // (k_gram_pair). A/B switch 1024: the previous arrangement, k_seg_gram on a side stream next to k_landmark -> k_group_gram.
-  // (only while every workgroup of the pair is resident at once — two per CU at 80 KB of LDS each; larger grids keep the two streams,
-  //  where k_group_gram alone fits three workgroups per CU: configs[3] measured 0.165 ms vs 0.181 ms for the Schur stage)
-  const bool pair = T.n_lm > 0 && p->n_group_wg > 0 && p->n_group_wg + p->n_seg_wg <= 512 && !(T.debug_flags & 1024);
+  // (for small grids only — configs[1]: ~940 workgroups, Schur stage 66 -> 62 us. The pair holds 80 KB of LDS per workgroup, two per
+  //  CU, where k_group_gram alone fits three: at configs[3], ~3 750 workgroups, the two streams are faster, 0.165 vs 0.181 ms)
+  const bool pair = T.n_lm > 0 && p->n_group_wg > 0 && p->n_group_wg + p->n_seg_wg <= 2048 && !(T.debug_flags & 1024);
   const bool fork = T.n_lm > 0 && !pair;
   if (fork) {
     if (!p->side) {
@@ -900,6 +901,7 @@ int hs_create(int device, void* stream, hs_problem** out) {
   hs_problem* p = new hs_problem();
   p->device = device;
   if (const char* e = std::getenv("HS_REFERENCE_LITERAL")) p->inertial_mode = std::atoi(e) ? HS_INERTIAL_AS_REFERENCE : HS_INERTIAL_EXACT;
+  if (const char* e = std::getenv("HS_STAGE_TIMING")) p->stage_timing = std::atoi(e) != 0;
   if (hipSetDevice(device) != hipSuccess) {
     delete p;
     return HS_ERR_DEVICE;
@@ -1326,6 +1328,12 @@ int hs_reduced_system(hs_problem* p, double radius, double* S, double* g) {
   return HS_OK;
 }
 
+int hs_set_stage_timing(hs_problem* p, int enabled) {
+  if (!p) return HS_ERR_INVALID;
+  p->stage_timing = enabled != 0;
+  return HS_OK;
+}
+
 int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteration* iterations) {
   if (!p || !summary) return HS_ERR_INVALID;
   if (max_iterations < 0 || max_iterations > kMaxIterations) HS_FAIL(HS_ERR_INVALID, "max_iterations out of range");
@@ -1334,7 +1342,9 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
   rc = reset_state(p, max_iterations, 1e4);
   if (rc) return rc;
   hipStream_t s = p->stream;
-  // stage timing: 4 stages per iteration bracketed by HIP events on the launch stream
+  // stage timing (optional, hs_set_stage_timing): 4 stages per iteration bracketed by HIP events on the launch stream; every event is a
+  // barrier packet (~5.7 us of idle device each, rocprofv3 kernel trace), so by default only the two ends of the solve are stamped
+  const bool stages = p->stage_timing;
   const size_t n_ev = size_t(4) * max_iterations + 1;
   while (p->events.size() < n_ev) {
     hipEvent_t e;
@@ -1346,16 +1356,16 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
   for (int it = 0; it < max_iterations; ++it) {
     rc = p->k == 4 ? launch_linearize<4>(p) : launch_linearize<6>(p);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(ev[4 * it + 1], s));
+    if (stages) HIP_TRY(hipEventRecord(ev[4 * it + 1], s));
     rc = p->k == 4 ? launch_build<4>(p) : launch_build<6>(p);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(ev[4 * it + 2], s));
+    if (stages) HIP_TRY(hipEventRecord(ev[4 * it + 2], s));
     rc = launch_factor(p);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(ev[4 * it + 3], s));
+    if (stages) HIP_TRY(hipEventRecord(ev[4 * it + 3], s));
     rc = p->k == 4 ? launch_update<4>(p) : launch_update<6>(p);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(ev[4 * it + 4], s));
+    if (stages || it + 1 == max_iterations) HIP_TRY(hipEventRecord(ev[4 * it + 4], s));
   }
   if (max_iterations == 0) {
     rc = p->k == 4 ? launch_linearize<4>(p) : launch_linearize<6>(p);
@@ -1375,7 +1385,7 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
   summary->num_successful_steps = st.num_successful;
   summary->termination = st.termination;
   summary->num_residual_blocks = p->T.n_vis + p->T.n_pri + p->T.n_ine;
-  for (int it = 0; it < max_iterations; ++it) {
+  for (int it = 0; stages && it < max_iterations; ++it) {
     float t[4] = {0, 0, 0, 0};
     for (int k = 0; k < 4; ++k) (void)hipEventElapsedTime(&t[k], ev[4 * it + k], ev[4 * it + k + 1]);
     summary->linearize_ms += t[0], summary->schur_ms += t[1], summary->solve_ms += t[2], summary->update_ms += t[3];

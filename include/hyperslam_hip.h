@@ -182,6 +182,11 @@ int hs_reduced_system(hs_problem* p, double radius, double* S, double* g);
 /* Replaces CeresOptimizer::optimize (optimizer.cpp:276-280) with the options of optimizer.cpp:38-54 (trust-region LM,
  * Jacobi scaling, monotonic steps). iterations (nullable) receives max_iterations + 1 records (record 0 = initial point). */
 int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteration* iterations);
+/* Per-stage device times in the summary: linearize_ms / schur_ms / solve_ms / update_ms. Off by default — the four HIP events per
+ * iteration that bracket the stages are barrier packets on the launch stream and cost ~5.7 us each on gfx950 (7 % of a configs[1]
+ * iteration). total_ms is always measured. enabled != 0 turns the stage events on for the following hs_solve calls
+ * (HS_STAGE_TIMING=1 in the environment at hs_create does the same). */
+int hs_set_stage_timing(hs_problem* p, int enabled);
 int hs_set_allreduce(hs_problem* p, hs_allreduce_fn fn, void* user);
 /* RCCL on the data path without a host hook: rank 0 obtains a 128-byte unique id (ncclGetUniqueId), the caller distributes it
  * by any means (torch.distributed in bench.py), every rank then creates its communicator (ncclCommInitRank on the handle's

@@ -113,6 +113,7 @@ int hso_set_imu(hso_problem* p, const double* T, const double* ig, const double*
   P.bias_const = bias_constant != 0;
   return HS_OK;
 }
+int hso_set_stage_timing(hso_problem*, int) { return HS_OK; }  // (the oracle's stage times are host clocks: always on)
 int hso_set_inertial_jacobian(hso_problem* p, int mode) {
   CHECK_ARG(mode == HS_INERTIAL_AS_REFERENCE || mode == HS_INERTIAL_EXACT, "unknown inertial Jacobian mode");
   p->P.inertial_mode = mode;

@@ -1,5 +1,7 @@
+import os
 import sys, ctypes as C; sys.path.insert(0,".")
 import numpy as np
+os.environ.setdefault("HS_STAGE_TIMING", "1")
 import hyperslam_amd as ha
 from hyperslam_amd import synthetic, _lib
 w=synthetic.config1()

@@ -2,6 +2,7 @@
 import os, sys, ctypes as C; sys.path.insert(0, ".")
 os.environ["HS_DEBUG_FLAGS"] = str(16 | int(os.environ.get("HS_DEBUG_FLAGS", "0")))
 import numpy as np
+os.environ.setdefault("HS_STAGE_TIMING", "1")
 import hyperslam_amd as ha
 from hyperslam_amd import synthetic, _lib
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 1

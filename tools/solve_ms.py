@@ -8,6 +8,7 @@ if len(sys.argv) > 2:
     sys.exit(0)
 sys.path.insert(0, ".")
 import numpy as np
+os.environ.setdefault("HS_STAGE_TIMING", "1")
 import hyperslam_amd as ha
 from hyperslam_amd import synthetic
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 1

@@ -1,6 +1,8 @@
+import os
 """Times optimize() on a BASELINE.json config (device stage times from hs_summary). usage: python tools/time_config.py 1|2|3"""
 import sys, time
 sys.path.insert(0, ".")
+os.environ.setdefault("HS_STAGE_TIMING", "1")
 import hyperslam_amd as ha
 from hyperslam_amd import synthetic
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 1

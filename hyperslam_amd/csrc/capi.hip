@@ -415,7 +415,7 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_bias_a.upload(p->bias_a, s));
   HIP_TRY(p->d_bias_g_cand.reserve(p->bias_g.size() + 1));
   HIP_TRY(p->d_bias_a_cand.reserve(p->bias_a.size() + 1));
-  p->nb_ine = (n_ine + kBlock - 1) / kBlock;
+  p->nb_ine = (n_ine + kInertialBlock - 1) / kInertialBlock;
   const int np = 6 * p->n_cp, ncb = 6 * vs.bw;
   HIP_TRY(p->d_scale_p.reserve(np));
   HIP_TRY(p->d_Sb.reserve(size_t(np) * ncb));
@@ -596,7 +596,7 @@ int launch_linearize(hs_problem* p) {
   hipStream_t s = p->stream;
   if (T.n_vis) k_linearize_visual<K><<<p->nb_vis, lin_block<K>(), lin_lds_bytes<K>(p), s>>>(T, T.v_rec, T.v_pos, 1, T.cost_part, nullptr);
   if (T.n_pri) k_linearize_prior<K><<<p->nb_pri, kBlock, cp_lds_bytes(p), s>>>(T, T.p_rec, T.cost_part + p->nb_vis, nullptr);
-  if (T.n_ine) k_linearize_inertial<K, 4><<<p->nb_ine, kBlock, cp_lds_bytes(p), s>>>(T, T.i_rec, 1, T.cost_part + p->nb_vis + p->nb_pri, nullptr);
+  if (T.n_ine) k_linearize_inertial<K, 4><<<p->nb_ine, kInertialBlock, cp_lds_bytes(p), s>>>(T, T.i_rec, 1, T.cost_part + p->nb_vis + p->nb_pri, nullptr);
   HIP_TRY(hipGetLastError());
   return HS_OK;
 }
@@ -818,10 +818,22 @@ int launch_factor(hs_problem* p) {
     k_band_factor_wide<<<1, kWideThreads, size_t(12) * (ncb + 2) * sizeof(double), s>>>(Tf);
   if (T.nb) {  // bordered system (bias splines + gravity)
     const int fwd_threads = std::max(128, 64 * ((6 * (T.bw - 1) + 63) / 64));  // one lane per pending row
-    k_border_forward<<<(T.nb + kBorderCols - 1) / kBorderCols, fwd_threads, size_t(T.np) * kBorderCols * sizeof(double), s>>>(T);
+    k_border_forward<<<(T.nb + kBorderCols - 1) / kBorderCols, fwd_threads, size_t(T.np) * kBorderLd * sizeof(double), s>>>(T);
     const int nt = (T.nb + kSchurTile - 1) / kSchurTile;
     k_border_schur<<<dim3(nt, nt), kBlock, 0, s>>>(T);
-    k_border_solve<<<1, kBlock, (size_t(T.nb + 1) * (T.nb + 1) + T.nb) * sizeof(double), s>>>(T);
+    if (T.nb + 1 <= 128 && !(T.debug_flags & 524288)) {  // trailing matrix in registers (A/B switch 524288: the LDS version)
+      const int R = std::max(4, (T.nb + 1 + 15) / 16), N = 16 * R;
+      const size_t lds = (size_t(2) * N + size_t(T.nb) * (N + 1) + T.nb) * sizeof(double);
+      switch (R) {
+        case 4: k_border_solve_reg<4><<<1, kBlock, lds, s>>>(T); break;
+        case 5: k_border_solve_reg<5><<<1, kBlock, lds, s>>>(T); break;
+        case 6: k_border_solve_reg<6><<<1, kBlock, lds, s>>>(T); break;
+        case 7: k_border_solve_reg<7><<<1, kBlock, lds, s>>>(T); break;
+        default: k_border_solve_reg<8><<<1, kBlock, lds, s>>>(T); break;
+      }
+    } else {
+      k_border_solve<<<1, kBlock, (size_t(T.nb + 1) * (T.nb + 1) + T.nb) * sizeof(double), s>>>(T);
+    }
     k_border_apply<<<(T.np + kBlock / 64 - 1) / (kBlock / 64), kBlock, 0, s>>>(T);
   }
   if ((T.debug_flags & 8192) && !T.nb) {  // A/B: the generalised sweep on the whole system
@@ -847,7 +859,7 @@ int launch_update(hs_problem* p) {
   if (T.n_vis) k_cost_visual<K><<<p->nb_vis, kBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.lm_cand, T.cand_part);
   if (T.n_pri) k_cost_prior<K><<<p->nb_pri, kBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.cand_part + p->nb_vis);
   if (T.n_ine)
-    k_cost_inertial<K, 4><<<p->nb_ine, kBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.bias_g_cand, T.bias_a_cand, T.gravity_cand,
+    k_cost_inertial<K, 4><<<p->nb_ine, kInertialBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.bias_g_cand, T.bias_a_cand, T.gravity_cand,
                                                                         T.cand_part + p->nb_vis + p->nb_pri);
   const bool local_decision = !p->allreduce && !p->rccl_comm;  // single shard: decide in the packing kernel
   k_pack_decision<<<1, kBlock, 0, s>>>(T, local_decision ? 1 : 0);
@@ -871,6 +883,10 @@ int set_func_attributes(hs_problem* p) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_la<1>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seg_gram<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seg_gram<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_solve_reg<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_solve_reg<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_solve_reg<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_solve_reg<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -1234,9 +1250,9 @@ int hs_linearize(hs_problem* p, int type, int robustify, const hs_linearization*
     HIP_TRY(p->d_dbg.reserve(size_t(n) * REC));
     HIP_TRY(p->d_dbg_cost.reserve(n));
     if (k == 4)
-      k_linearize_inertial<4, 4><<<p->nb_ine, kBlock, cp_lds_bytes(p), s>>>(T, p->d_dbg.p, robustify, nullptr, p->d_dbg_cost.p);
+      k_linearize_inertial<4, 4><<<p->nb_ine, kInertialBlock, cp_lds_bytes(p), s>>>(T, p->d_dbg.p, robustify, nullptr, p->d_dbg_cost.p);
     else
-      k_linearize_inertial<6, 4><<<p->nb_ine, kBlock, cp_lds_bytes(p), s>>>(T, p->d_dbg.p, robustify, nullptr, p->d_dbg_cost.p);
+      k_linearize_inertial<6, 4><<<p->nb_ine, kInertialBlock, cp_lds_bytes(p), s>>>(T, p->d_dbg.p, robustify, nullptr, p->d_dbg_cost.p);
     HIP_TRY(hipGetLastError());
     std::vector<double> rec(size_t(n) * REC), cost(n);
     HIP_TRY(hipMemcpyAsync(rec.data(), p->d_dbg.p, rec.size() * 8, hipMemcpyDeviceToHost, s));

@@ -263,7 +263,8 @@ struct ImuParams {
 template <int K, int KB>
 struct InertialOut {
   double r[6];
-  double Jp[6 * 6 * K];  // 6 x 6K local state Jacobian
+  double* Jp;            // 6 x 6K local state Jacobian, written as it is produced: the caller points it at the record in memory (held
+                         // in registers, its 36 K doubles alone exceed the register file at K = 6)
   double wg[KB], wa[KB]; // bias-spline weights (d r_ang / d b_g,j = wg[j] I, d r_lin / d b_a,j = wa[j] I)
   double Jg[12];         // 6 x 2 gravity (SphereManifold<3> tangent)
   double cost;

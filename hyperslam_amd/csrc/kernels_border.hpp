@@ -199,6 +199,8 @@ __global__ void __launch_bounds__(kBlock) k_finalize_border(Tables T) {
 //   C x_b = h (dense Cholesky in LDS), y' = y - Z x_b  (k_border_solve, one workgroup)   then the banded backward sweep on y'.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kBorderCols = 8;  // right-hand sides per workgroup in the forward sweep
+constexpr int kBorderLd = 10;   // LDS row stride of the pending rows (doubles): 64-byte rows put every fourth lane on the same banks (16-way
+                                // conflict on the row read-modify-write of every step); 80 bytes keeps 16-byte alignment and spreads them
 
 __global__ void __launch_bounds__(kBlock) k_border_forward(Tables T) {  // blockDim = 64 x waves covering the 6 (bw - 1) pending rows (>= 128)
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -206,59 +208,80 @@ __global__ void __launch_bounds__(kBlock) k_border_forward(Tables T) {  // block
   const int tid = threadIdx.x;
   const int bw = T.bw, ncb = 6 * bw, nb = T.nb, np = T.np, n_blk = np / 6;
   const int c0 = blockIdx.x * kBorderCols, ncols = min(kBorderCols, nb - c0);
-  double* z = smem;  // np x kBorderCols: pending right-hand side rows, overwritten by the solution
+  double* z = smem;  // np x kBorderLd: pending right-hand side rows, overwritten by the solution
   for (int e = tid; e < np * kBorderCols; e += blockDim.x) {
     const int rho = e / kBorderCols, c = e % kBorderCols;
-    z[e] = c < ncols ? T.Spb[size_t(rho) * nb + c0 + c] : 0.0;
+    z[rho * kBorderLd + c] = c < ncols ? T.Spb[size_t(rho) * nb + c0 + c] : 0.0;
   }
   __syncthreads();
-  __shared__ double zi[6 * kBorderCols];
+  __shared__ __attribute__((aligned(16))) double zi[2][6 * kBorderCols];  // z_m, double buffered: ONE workgroup barrier per block row
   const int n_pend = 6 * (bw - 1);
   // Operands of step m are requested D steps ahead (the sweep is a dependency chain over the block rows: a load issued inside
   // the step would put a full L2 round trip on it). Thread t < n_pend: the six factor entries U[6m + a][6 + t]; thread
-  // (a, c) < 6 x kBorderCols: column a of W_m = U_mm^-1.
+  // (a, c) < 6 x kBorderCols (all in wave 0): column a of W_(m+1) = U_(m+1,m+1)^-1 — the diagonal solve of block row m + 1 is done by
+  // wave 0 right after its own part of update m (the six rows of block row m + 1 are pending rows 0 .. 5: lanes of wave 0), so that
+  // z_(m+1) is published by the same barrier that ends step m.
   constexpr int D = 4;
   const bool pend = tid < n_pend, diag = tid < 6 * kBorderCols;
   const int da = diag ? tid / kBorderCols : 0, dc = diag ? tid % kBorderCols : 0;
   double ur[D][6], wr[D][6];
   auto request = [&](int m, double* u, double* w) {
-    const int mm = m < n_blk ? m : 0;
+    const int mm = m < n_blk ? m : 0, mw = m + 1 < n_blk ? m + 1 : 0;
     const double* src = T.Ub + size_t(6 * mm) * ncb + 6 + (pend ? tid : 0);
 #pragma unroll
     for (int a = 0; a < 6; ++a) u[a] = src[size_t(a) * ncb];
     // (W')[a][k] = W[k][a], k <= a ; packed index of (k, a) = k*6 - k(k-1)/2 + (a - k)
-    const double* W = T.Ubk + size_t(mm) * 24;
+    const double* W = T.Ubk + size_t(mw) * 24;
 #pragma unroll
     for (int k = 0; k < 6; ++k) w[k] = W[k <= da ? k * 6 - k * (k - 1) / 2 + (da - k) : 0];
   };
+  auto diag_solve = [&](int m, const double* w) {  // wave 0: z_m = U_mm^-T s_m = W' s_m, into zi[m & 1] and over s_m
+    if (diag) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) v = fma(k <= da ? w[k] : 0.0, z[(6 * m + k) * kBorderLd + dc], v);
+      zi[m & 1][tid] = v;
+      z[(6 * m + da) * kBorderLd + dc] = v;  // (LDS operations of a wave are in order: every lane has read s_m before this store)
+    }
+  };
+  {  // z_0
+    double w0[6];
+    const double* W = T.Ubk;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) w0[k] = W[k <= da ? k * 6 - k * (k - 1) / 2 + (da - k) : 0];
+    if (tid < 64) diag_solve(0, w0);
+  }
 #pragma unroll
   for (int d = 0; d < D; ++d) request(d, ur[d], wr[d]);
+  __syncthreads();
   for (int mb = 0; mb < n_blk; mb += D) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       const int m = mb + d;
       if (m >= n_blk) break;
-      // z_m = U_mm^-T s_m = W' s_m
-      if (diag) {
-        double v = 0.0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) v = fma(k <= da ? wr[d][k] : 0.0, z[(6 * m + k) * kBorderCols + dc], v);
-        zi[tid] = v;
-      }
-      __syncthreads();
-      if (diag) z[(6 * m + da) * kBorderCols + dc] = zi[tid];
       // pending rows of blocks m+1 .. m+bw-1: s_(i,c') -= sum_a U[6m+a][6(i-m)+c'] z_m[a]
       if (pend) {
         const int rho = 6 * (m + 1) + tid;
-        if (rho < np) {
+        if (rho < np) {  // 16-byte LDS operations: 24 reads of z_m, 4 + 4 for the row (the scalar form issued 112 per step)
+          double2* zr = reinterpret_cast<double2*>(z + rho * kBorderLd);
+          const double2* zm = reinterpret_cast<const double2*>(zi[m & 1]);
+          double2 acc[kBorderCols / 2];
 #pragma unroll
-          for (int c = 0; c < kBorderCols; ++c) {
-            double sacc = 0.0;
+          for (int c = 0; c < kBorderCols / 2; ++c) acc[c] = zr[c];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) sacc = fma(ur[d][a], zi[a * kBorderCols + c], sacc);
-            z[rho * kBorderCols + c] -= sacc;
-          }
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int c = 0; c < kBorderCols / 2; ++c) {
+              const double2 t = zm[a * (kBorderCols / 2) + c];
+              acc[c].x = fma(-ur[d][a], t.x, acc[c].x), acc[c].y = fma(-ur[d][a], t.y, acc[c].y);
+            }
+#pragma unroll
+          for (int c = 0; c < kBorderCols / 2; ++c) zr[c] = acc[c];
         }
+      }
+      if (tid < 64 && m + 1 < n_blk) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave 0: its rows of block row m + 1 are final
+        diag_solve(m + 1, wr[d]);
       }
       request(m + D, ur[d], wr[d]);
       __syncthreads();
@@ -266,7 +289,7 @@ __global__ void __launch_bounds__(kBlock) k_border_forward(Tables T) {  // block
   }
   for (int e = tid; e < np * kBorderCols; e += blockDim.x) {
     const int rho = e / kBorderCols, c = e % kBorderCols;
-    if (c < ncols) T.Zb[size_t(rho) * nb + c0 + c] = z[e];
+    if (c < ncols) T.Zb[size_t(rho) * nb + c0 + c] = z[rho * kBorderLd + c];
   }
 }
 
@@ -360,6 +383,100 @@ __global__ void __launch_bounds__(kBlock) k_border_solve(Tables T) {
   }
   if (tid == 0 && bad) st->chol_failed = 1;
   for (int bq = tid; bq < nb; bq += blockDim.x) T.xb[bq] = x[bq];
+}
+
+/// The same solve with the trailing matrix in REGISTERS (nb + 1 <= 16 R): lane (ti, tj) of the 16 x 16 arrangement owns the entries
+/// (i, c) = (ti + 16 r, tj + 16 q), r, q < R, of the augmented lower triangle (row nb = h'). Per column j its owners publish the
+/// column through a double-buffered LDS vector (ONE barrier per column, no LDS read-modify-write: the version above spent 1.6 us
+/// per column — 160 us at the 98 border unknowns of configs[2] — on three LDS operations per updated entry and two loops per
+/// barrier), everybody updates its registers with a[r][q] -= l_ij l_cj / d_j. The scaled columns are kept in LDS for the backward
+/// sweep L' x = y, which ONE wave runs without barriers: lane i carries y_i (two per lane), x_j is broadcast with v_readlane.
+template <int R>
+__global__ void __launch_bounds__(kBlock) k_border_solve_reg(Tables T) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  DevState* st = T.st;
+  if (st->done) return;
+  const int nb = T.nb, tid = threadIdx.x, n1 = nb + 1;
+  constexpr int N = 16 * R;
+  const int ld = N + 1;                // odd: a lane-strided walk down a column of Lc is conflict free
+  double* col = smem;                  // 2 x N : column j as its owners hold it (unscaled), double buffered
+  double* Lc = smem + 2 * N;           // nb x ld : Lc[j][i] = l_ij, i >= j (i = nb: forward-solved right-hand side y_j)
+  double* invd = Lc + size_t(nb) * ld; // nb : 1 / l_jj
+  const int ti = tid / 16, tj = tid % 16;
+  double a[R][R];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const int i = ti + 16 * r, c = tj + 16 * q;
+      a[r][q] = (i < n1 && c < nb && c <= i) ? (i < nb ? T.Cb[size_t(i) * nb + c] : T.hb[c]) : 0.0;
+    }
+  __shared__ int bad;
+  if (tid == 0) bad = 0;
+  for (int j = 0; j < nb; ++j) {
+    double* cj = col + (j & 1) * N;
+    const int qj = j >> 4;
+    if (tj == (j & 15)) {  // owners of column j (the compile-time q loop keeps a[][] in registers)
+#pragma unroll
+      for (int q = 0; q < R; ++q)
+        if (q == qj) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) cj[ti + 16 * r] = a[r][q];
+        }
+    }
+    lds_barrier();
+    const double d = cj[j];
+    if (tid == 0 && !(d > 0.0)) bad = 1;
+    // 1 / l_jj by the hardware estimate + one Newton-Halley step (as in the 6 x 6 panels): the division + square root of the plain
+    // formula were a third of the instructions of a column
+    const double dd = d > 0.0 ? d : 1.0, y0r = __builtin_amdgcn_rsq(dd), er = fma(-dd * y0r, y0r, 1.0);
+    const double rs = fma(y0r * er, fma(0.375, er, 0.5), y0r), inv = rs * rs;
+    double li[R], lc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = ti + 16 * r, c = tj + 16 * r;
+      li[r] = i > j ? cj[i] * inv : 0.0;  // rows / columns <= j are finished: zero operands leave them alone
+      lc[r] = c > j ? cj[c] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int q = 0; q < R; ++q) a[r][q] = fma(-li[r], lc[q], a[r][q]);
+    // the scaled column for the backward sweep (any 64 lanes; not read before the end of the elimination)
+    if (tid < N && tid >= j && tid < n1) Lc[size_t(j) * ld + tid] = tid == j ? d * rs : cj[tid] * rs;
+    if (tid == 0) invd[j] = rs;
+  }
+  lds_barrier();
+  if (tid == 0 && bad) st->chol_failed = 1;
+  if (tid >= 64) return;
+  // ---- backward sweep, one wave: y_i in lanes i and i + 64, column j of L' = row j of L: l_ji = Lc[i][j], i < j ----
+  const int lane = tid;
+  double y0 = lane < nb ? Lc[size_t(lane) * ld + nb] : 0.0, y1 = lane + 64 < nb ? Lc[size_t(lane + 64) * ld + nb] : 0.0;
+  double x0 = 0.0, x1 = 0.0;
+  constexpr int U = 4;  // columns whose operands are in flight
+  for (int j0 = nb - 1; j0 >= 0; j0 -= U) {
+    double l0[U], l1[U], iv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 - u;
+      l0[u] = (j >= 0 && lane < j) ? Lc[size_t(lane) * ld + j] : 0.0;
+      l1[u] = (j >= 0 && lane + 64 < j) ? Lc[size_t(lane + 64) * ld + j] : 0.0;
+      iv[u] = j >= 0 ? invd[j] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 - u;
+      if (j < 0) break;
+      const double ysel = j < 64 ? y0 : y1;  // (wave-uniform choice)
+      const int jl = j & 63;
+      const double yj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ysel), jl), __builtin_amdgcn_readlane(__double2loint(ysel), jl));
+      const double xj = yj * iv[u];
+      y0 = fma(-l0[u], xj, y0), y1 = fma(-l1[u], xj, y1);
+      x0 = lane == j ? xj : x0, x1 = lane + 64 == j ? xj : x1;
+    }
+  }
+  if (lane < nb) T.xb[lane] = x0;
+  if (lane + 64 < nb) T.xb[lane + 64] = x1;
 }
 
 /// y' = y - Z x_b (one wave per row of Z, lanes over the border columns).

@@ -99,9 +99,14 @@ __global__ void __launch_bounds__(kBlock) k_linearize_prior(Tables T, double* ou
   if (threadIdx.x == 0 && cost_part) cost_part[blockIdx.x] = s;
 }
 
+/// One wave per workgroup for the inertial kernels: the order-6 linearisation holds three derivative levels of the spline with their
+/// Jacobians and needed 256 VGPRs + 1.7 KB of scratch per lane under a 256-thread launch bound; a window has ~1e4 inertial residual
+/// blocks (157 waves on 1024 SIMDs), so occupancy buys nothing and the 512-register budget of a lone wave removes the spills.
+constexpr int kInertialBlock = 64;
+
 /// Inertial residual blocks (inertial.cpp:13-205): record = [r(6) | J_state(6 x 6K) | wg(KB) | wa(KB) | J_gravity(6 x 2)].
 template <int K, int KB>
-__global__ void __launch_bounds__(kBlock) k_linearize_inertial(Tables T, double* out_rec, int robustify, double* cost_part, double* cost_each) {
+__global__ void __launch_bounds__(kInertialBlock) k_linearize_inertial(Tables T, double* out_rec, int robustify, double* cost_part, double* cost_each) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (T.st->done) return;
   double* cps = smem;
@@ -110,15 +115,14 @@ __global__ void __launch_bounds__(kBlock) k_linearize_inertial(Tables T, double*
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   double cost = 0.0;
   if (i < T.n_ine) {
-    InertialOut<K, KB> o;
-    inertial_evaluate<K, KB, true>(T, cps, T.bias_g, T.bias_a, T.gravity, i, robustify != 0, &o);
-    cost = o.cost;
     constexpr int REC = 18 + 36 * K + 2 * KB;
     double* rec = out_rec + size_t(i) * REC;
+    InertialOut<K, KB> o;
+    o.Jp = rec + 6;
+    inertial_evaluate<K, KB, true>(T, cps, T.bias_g, T.bias_a, T.gravity, i, robustify != 0, &o);
+    cost = o.cost;
 #pragma unroll
     for (int c = 0; c < 6; ++c) rec[c] = o.r[c];
-#pragma unroll
-    for (int c = 0; c < 36 * K; ++c) rec[6 + c] = o.Jp[c];
 #pragma unroll
     for (int c = 0; c < KB; ++c) rec[6 + 36 * K + c] = o.wg[c], rec[6 + 36 * K + KB + c] = o.wa[c];
 #pragma unroll
@@ -130,7 +134,7 @@ __global__ void __launch_bounds__(kBlock) k_linearize_inertial(Tables T, double*
 }
 
 template <int K, int KB>
-__global__ void __launch_bounds__(kBlock) k_cost_inertial(Tables T, const double* cp_src, const double* bg, const double* ba, const double* grav,
+__global__ void __launch_bounds__(kInertialBlock) k_cost_inertial(Tables T, const double* cp_src, const double* bg, const double* ba, const double* grav,
                                                          double* cost_part) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (T.st->done) return;
@@ -141,6 +145,7 @@ __global__ void __launch_bounds__(kBlock) k_cost_inertial(Tables T, const double
   double cost = 0.0;
   if (i < T.n_ine) {
     InertialOut<K, KB> o;
+    o.Jp = nullptr;  // (value-only branch)
     inertial_evaluate<K, KB, false>(T, cps, bg, ba, grav, i, false, &o);
     cost = o.cost;
   }

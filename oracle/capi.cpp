@@ -290,6 +290,7 @@ int hso_solve(hso_problem* p, int max_iterations, hs_summary* summary, hs_iterat
   summary->termination = s.termination;
   summary->num_residual_blocks = p->P.n_res(kPixel) + p->P.n_res(kBearing) + p->P.n_res(kPrior) + p->P.n_res(kInertial);
   summary->total_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+  summary->linearize_ms = s.linearize_ms, summary->schur_ms = s.schur_ms, summary->solve_ms = s.solve_ms, summary->update_ms = s.update_ms;
   if (iterations) {
     std::memset(iterations, 0, sizeof(hs_iteration) * (max_iterations + 1));
     for (size_t i = 0; i < s.iterations.size() && int(i) <= max_iterations; ++i) {

@@ -7,6 +7,7 @@
 //   max_num_iterations = 5.  The linear solve eliminates landmarks by Schur complement and factors the reduced
 //   system densely (algebraically identical to SPARSE_NORMAL_CHOLESKY on the full J'J).
 #pragma once
+#include <chrono>
 #include <algorithm>
 #include <cstdio>
 #include <functional>
@@ -447,6 +448,10 @@ struct Summary {
   int num_successful_steps = 0;
   int termination = 0;          // 0 NO_CONVERGENCE (max iterations), 1 CONVERGENCE, 2 FAILURE
   std::vector<IterationRecord> iterations;
+  // host clocks per stage, summed over the iterations (SURVEY.md §8d per-stage CPU times): linearise (residuals, Jacobians and the
+  // accumulation of J'J / J'r, one pass as in Ceres' evaluator), Schur complement (reduced system), factor + solves, update
+  // (retraction, cost at the candidate, step decision)
+  double linearize_ms = 0, schur_ms = 0, solve_ms = 0, update_ms = 0;
 };
 
 /// Scaled + damped reduced system at the current point (what one LM iteration factors):
@@ -546,7 +551,18 @@ struct LM {
   }
 
   /// Solves the LM system; outputs the *scaled* step (trust_region_step) for pose-side and landmark unknowns.
+  mutable double t_schur_ms = 0, t_solve_ms = 0;  // stage clocks of solve_step
+  static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
   bool solve_step(const NormalEquations& ne, std::vector<double>* step_p, std::vector<double>* step_l, ReducedSystem* rs_out = nullptr) const {
+    const double ts0 = now_ms();
+    struct StageClock {
+      const LM* lm;
+      double t0, t_mid = -1;
+      ~StageClock() {
+        const double t1 = now_ms();
+        lm->t_schur_ms += (t_mid < 0 ? t1 : t_mid) - t0, lm->t_solve_ms += t_mid < 0 ? 0.0 : t1 - t_mid;
+      }
+    } clock{this, ts0};
     ReducedSystem rs;
     reduce(ne, &rs);
     const int np = ne.np;
@@ -563,6 +579,7 @@ struct LM {
       *rs_out = rs;
       rs_out->S = S, rs_out->g = y;
     }
+    clock.t_mid = now_ms();
     const std::vector<int> env = row_envelope(S, np);
     if (!cholesky_lower(S, np, env)) return false;
     cholesky_solve(S, np, env, y);  // y = (J'J + D^2)^-1 J'r
@@ -676,7 +693,10 @@ struct LM {
     constexpr double kMinRelativeDecrease = 1e-3, kMaxRadius = 1e16, kMinRadius = 1e-32;
     Summary sum;
     NormalEquations ne;
+    double tl = now_ms();
     solver.build(&ne);
+    sum.linearize_ms += now_ms() - tl;
+    t_schur_ms = t_solve_ms = 0;
     globalize(&ne);
     compute_scaling(ne);
     double cost = ne.cost;
@@ -714,6 +734,7 @@ struct LM {
       }
       invalid_streak = 0;
       rec.step_is_valid = 1;
+      const double tu = now_ms();
       Problem cand;
       apply(delta_p, delta_l, &cand);
       // candidate cost and norms: replicated unknowns (control points, biases, gravity) are counted by rank 0 only
@@ -728,6 +749,7 @@ struct LM {
       std::vector<double> dec = {Solver(cand).total_cost(), sn + (rank == 0 ? sn_rep : 0.0), xs_lm + (rank == 0 ? xs_rep : 0.0)};
       this->sum(dec);
       const double cand_cost = dec[0];
+      sum.update_ms += now_ms() - tu;
       rec.step_norm = std::sqrt(dec[1]);
       const double x_norm = std::sqrt(dec[2]);
       if (rec.step_norm <= kParameterTolerance * (x_norm + kParameterTolerance)) {
@@ -747,7 +769,9 @@ struct LM {
         rec.step_is_successful = 1;
         sum.num_successful_steps++;
         P = cand;
+        tl = now_ms();
         solver.build(&ne);
+        sum.linearize_ms += now_ms() - tl;
         globalize(&ne);
         cost = ne.cost;
         gmax = gradient_max_norm(ne, P);
@@ -764,6 +788,7 @@ struct LM {
       sum.iterations.push_back(rec);
     }
     sum.final_cost = cost;
+    sum.schur_ms = t_schur_ms, sum.solve_ms = t_solve_ms;
     return sum;
   }
 };

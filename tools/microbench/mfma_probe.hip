@@ -108,7 +108,7 @@ template <int B>
 __device__ __forceinline__ int uidx(int a, int c) { return a * B - a * (a - 1) / 2 + (c - a); }
 
 template <int B, int MODE>
-__global__ void k_panel(double* out, long long* t, int n) {
+__global__ void __launch_bounds__(64) k_panel(double* out, long long* t, int n) {
   __shared__ double lds[B * B + 2 * B * 64];
   for (int e = threadIdx.x; e < B * B; e += 64) lds[e] = (e / B == e % B ? 8.0 : 0.0) + 0.3 / (1 + e / B + e % B);
   for (int e = threadIdx.x; e < 2 * B * 64; e += 64) lds[B * B + e] = 0.01 * (e % 13);

@@ -1,0 +1,23 @@
+#!/bin/bash
+# usage (on the GPU box): bash tools/round_measurements.sh <tag>    e.g. r02_v2  -> gpurun_out/<tag>_*
+# Everything DESIGN.md quotes for a round: smoke, the bench line (with the CPU baseline), kernel traces, PMC passes, replays, lock-step logs.
+tag=${1:-rXX}
+out=gpurun_out
+mkdir -p $out
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/${tag}_smoke.log 2>&1
+python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+B="python bench.py --steps 40 --warmup 5 --no-cpu-baseline"
+bash tools/kernel_stats.sh $out/${tag}_bench_kernel_stats.csv $B > $out/${tag}_kernel_stats.txt 2>&1
+bash tools/kernel_stats.sh $out/${tag}_config2_kernel_stats.csv python bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline >> $out/${tag}_kernel_stats.txt 2>&1
+bash tools/kernel_stats.sh $out/${tag}_replay_kernel_stats.csv hyperslam_amd/host/replay 6.0 1 4 >> $out/${tag}_kernel_stats.txt 2>&1
+bash tools/pmc_traffic.sh $out/${tag}_pmc_hbm_traffic.json $B > $out/${tag}_pmc.txt 2>&1
+bash tools/pmc_sq.sh $out/${tag}_pmc_sq.json $B >> $out/${tag}_pmc.txt 2>&1
+bash tools/pmc_sq.sh $out/${tag}_config2_pmc_sq.json python bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline >> $out/${tag}_pmc.txt 2>&1
+for c in 0 1 2 3; do HS_STAGE_TIMING=0 python tools/time_config.py $c; HS_STAGE_TIMING=1 python tools/time_config.py $c; done > $out/${tag}_configs.txt 2>&1
+python bench.py --config 3 --steps 20 --warmup 3 --no-cpu-baseline > $out/${tag}_bench_config3.json 2>/dev/null
+python bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline > $out/${tag}_bench_config2.json 2>/dev/null
+( cd hyperslam_amd/host
+  for a in "6.0 1 4" "6.0 0 4" "6.0 1 6" "8.0 1 4"; do ./replay $a 2>/dev/null | tail -1; HS_STAGE_TIMING=1 ./replay $a 2>/dev/null | tail -1; done
+  ./replay_oracle 6.0 1 4 2>/dev/null | tail -1 ) > $out/${tag}_replay.txt 2>&1
+for a in "3.6 0 4" "3.6 1 4" "6.0 1 6"; do hyperslam_amd/host/replay_lockstep hyperslam_amd/libhyperslam_hip.so $a > $out/${tag}_lockstep_$(echo $a | tr ' .' '__').jsonl 2>&1; done
+echo done

@@ -795,7 +795,7 @@ int launch_factor(hs_problem* p) {
   const int f0 = (T.debug_flags & 262144) ? 0 : std::min(p->frozen_prefix, n_blk - 1);  // A/B switch 262144: eliminate every block row
   Tables Tf = T;
   if (f0 > 0) {
-    k_factor_decoupled_rows<<<(f0 + 63) / 64, 64, 0, s>>>(T, f0);
+    k_factor_decoupled_rows<<<f0, 64, 0, s>>>(T, f0);
     Tf.Sb += size_t(6 * f0) * ncb, Tf.g_s += 6 * f0, Tf.Ub += size_t(6 * f0) * ncb, Tf.Ubk += size_t(24) * f0, Tf.ybuf += 6 * f0, Tf.np -= 6 * f0;
     Tf.fj[0] = FactorJob{Tf.Sb, Tf.g_s, Tf.Ub, Tf.Ubk, Tf.ybuf, nullptr, Tf.np / 6, -1};
   }

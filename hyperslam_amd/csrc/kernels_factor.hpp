@@ -1236,13 +1236,16 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward(Tables T) {
 /// Leading block rows of CONSTANT control points (the sliding window freezes every control point at or before its lower bound,
 /// optimizer.cpp:319-328, and keeps them while residuals still reach them): their Jacobian columns are zero, so the block rows are
 /// decoupled from everything — S_i,: = [D_i | 0] with the damping on the diagonal, g_i = 0. The factorisation kernels start behind
-/// them (pointer offsets at launch, the band storage is row relative); this kernel writes their part of the factor, one lane per block
+/// them (pointer offsets at launch, the band storage is row relative); this kernel writes their part of the factor, one wave per block
 /// row: U_ii = chol(S_ii), the rest of the row zero, U_ii^-1, y_i = U_ii^-T g_i.
 __global__ void __launch_bounds__(64) k_factor_decoupled_rows(Tables T, int n_rows) {
   if (T.st->done) return;
-  const int i = blockIdx.x * 64 + threadIdx.x;
+  const int i = blockIdx.x, lane = threadIdx.x;  // one wave per block row: the lanes clear the row, lane 0 factors the 6 x 6 block
   if (i >= n_rows) return;
   const int ncb = 6 * T.bw;
+  for (int e = lane; e < 6 * ncb; e += 64)
+    if (e % ncb >= 6) T.Ub[size_t(6 * i) * ncb + e] = 0.0;
+  if (lane != 0) return;
   double U[6][6], y[6];
   bool ok = true;
 #pragma unroll
@@ -1272,10 +1275,9 @@ __global__ void __launch_bounds__(64) k_factor_decoupled_rows(Tables T, int n_ro
   }
   if (!ok) T.st->chol_failed = 1;
 #pragma unroll
-  for (int a = 0; a < 6; ++a) {
-    double* row = T.Ub + size_t(6 * i + a) * ncb;
-    for (int c = 0; c < ncb; ++c) row[c] = (c >= a && c < 6) ? U[a][c < 6 ? c : 0] : 0.0;
-  }
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) T.Ub[size_t(6 * i + a) * ncb + c] = U[a][c];  // (zero below the diagonal)
 #pragma unroll
   for (int c = 0; c < 6; ++c) {  // W = U_ii^-1, upper, packed like the factorisation kernels do
     double w[6];

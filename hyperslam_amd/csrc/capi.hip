@@ -209,7 +209,8 @@ struct hs_problem {
   DevState* h_state = nullptr;  // pinned
   std::vector<hipEvent_t> events;
   hipStream_t side = nullptr;           // second stream: the segment partials run next to the landmark pass (independent inputs)
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_irec = nullptr;
+  bool side_imu = false;  // this iteration's inertial linearisation + border gathers run on the side stream
   Tables T;
   int nb_vis = 0, nb_pri = 0, nb_cp = 0;
   int chol_lds_max = 64 * 1024;
@@ -590,13 +591,37 @@ size_t lin_lds_bytes(const hs_problem* p) {  // control points + one record slab
   return (cp_lds_bytes(p) <= 24 * 1024 ? cp_lds_bytes(p) : 0) + size_t(lin_block<K>()) * (8 + 12 * K + 2) * sizeof(double);
 }
 
+static int ensure_side_stream(hs_problem* p) {
+  if (!p->side) {
+    HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&p->ev_irec, hipEventDisableTiming));
+  }
+  return HS_OK;
+}
+
+/// `inertial_on_side` (the solve loop of bordered systems): the inertial branch of an iteration — k_linearize_inertial, then the border
+/// gathers k_border_pb / _zero / _bb / _gravity in launch_build — only meets the visual branch (k_linearize_visual -> k_landmark -> Gram
+/// kernels -> k_assemble) at the segment Gram kernel (reads the inertial records) and at k_reduce_partials, and each branch fills a
+/// fraction of the chip: they run on two streams. configs[2]: 293 us of kernels back to back -> 175 us on the critical path.
 template <int K>
-int launch_linearize(hs_problem* p) {
+int launch_linearize(hs_problem* p, bool inertial_on_side = false) {
   const Tables& T = p->T;
   hipStream_t s = p->stream;
+  p->side_imu = inertial_on_side && T.n_ine > 0 && T.nb > 0 && !(T.debug_flags & 1048576);  // A/B switch 1048576: one stream
+  if (p->side_imu) {
+    const int rc = ensure_side_stream(p);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(p->ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+  }
   if (T.n_vis) k_linearize_visual<K><<<p->nb_vis, lin_block<K>(), lin_lds_bytes<K>(p), s>>>(T, T.v_rec, T.v_pos, 1, T.cost_part, nullptr);
   if (T.n_pri) k_linearize_prior<K><<<p->nb_pri, kBlock, cp_lds_bytes(p), s>>>(T, T.p_rec, T.cost_part + p->nb_vis, nullptr);
-  if (T.n_ine) k_linearize_inertial<K, 4><<<p->nb_ine, kInertialBlock, cp_lds_bytes(p), s>>>(T, T.i_rec, 1, T.cost_part + p->nb_vis + p->nb_pri, nullptr);
+  if (T.n_ine)
+    k_linearize_inertial<K, 4><<<p->nb_ine, kInertialBlock, cp_lds_bytes(p), p->side_imu ? p->side : s>>>(T, T.i_rec, 1, T.cost_part + p->nb_vis + p->nb_pri,
+                                                                                                        nullptr);
+  if (p->side_imu) HIP_TRY(hipEventRecord(p->ev_irec, p->side));
   HIP_TRY(hipGetLastError());
   return HS_OK;
 }
@@ -651,17 +676,32 @@ int launch_build(hs_problem* p) {
   // (for small grids only — configs[1]: ~940 workgroups, Schur stage 66 -> 62 us. The pair holds 80 KB of LDS per workgroup, two per
   //  CU, where k_group_gram alone fits three: at configs[3], ~3 750 workgroups, the two streams are faster, 0.165 vs 0.181 ms)
   const bool pair = T.n_lm > 0 && p->n_group_wg > 0 && p->n_group_wg + p->n_seg_wg <= 2048 && !(T.debug_flags & 1024);
-  const bool fork = T.n_lm > 0 && !pair;
+  const bool side_imu = p->side_imu;       // (set by launch_linearize: the side stream is busy with the inertial branch)
+  const bool fork = T.n_lm > 0 && !pair && !side_imu;
   if (fork) {
-    if (!p->side) {
-      HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
-      HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-      HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
-    }
+    const int rc = ensure_side_stream(p);
+    if (rc) return rc;
     HIP_TRY(hipEventRecord(p->ev_fork, s));
     HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0));
   }
-  if (!pair) k_seg_gram<K><<<p->n_seg_wg, kBlock, kSegStage * sizeof(double), fork ? p->side : s>>>(T);
+  hipStream_t sb = side_imu ? p->side : s;  // stream of the border gathers
+  if (side_imu && T.nb) {  // behind k_linearize_inertial on the side stream, next to k_landmark / the Gram kernels
+    k_border_pb<K><<<dim3(T.sp.n_cp, p->n_split), 128, 0, sb>>>(T);
+    k_border_zero<<<std::min(64, (T.nb * T.nb + T.nb + kBlock - 1) / kBlock), kBlock, 0, sb>>>(T);
+    k_border_bb<K><<<T.n_bias, kBlock, 0, sb>>>(T);
+    k_border_gravity<<<1, 64, 0, sb>>>(T);
+    HIP_TRY(hipEventRecord(p->ev_join, p->side));
+  }
+  bool irec_ready = !side_imu;  // the segment Gram kernel reads the inertial records: wait for the side stream's linearisation once
+  auto need_irec = [&]() -> hipError_t {
+    if (irec_ready) return hipSuccess;
+    irec_ready = true;
+    return hipStreamWaitEvent(s, p->ev_irec, 0);
+  };
+  if (!pair && !(side_imu && T.n_lm)) {
+    HIP_TRY(need_irec());
+    k_seg_gram<K><<<p->n_seg_wg, kBlock, kSegStage * sizeof(double), fork ? p->side : s>>>(T);
+  }
   if (fork) HIP_TRY(hipEventRecord(p->ev_join, p->side));
   if (T.n_lm) {
     const int grid = (T.n_lm + kBlock / 64 - 1) / (kBlock / 64);
@@ -676,6 +716,7 @@ int launch_build(hs_problem* p) {
     const size_t lds = std::max((size_t(batch) * 18 * T.bw + 4 * batch) * sizeof(double), size_t(128) * 42 * sizeof(double));
     const dim3 grid(p->n_group_wg);
     if (pair) {
+      HIP_TRY(need_irec());
       const size_t lds2 = std::max(lds, kSegStage * sizeof(double));
       const dim3 grid2(p->n_group_wg + p->n_seg_wg);
       if (ntile <= kBlock)
@@ -691,14 +732,19 @@ int launch_build(hs_problem* p) {
     else
       k_group_gram<4><<<grid, kBlock, lds, s>>>(T, batch);
   }
+  if (side_imu && T.n_lm && !pair) {  // (large grids with an IMU: the segment Gram kernel after the landmark chain, same stream)
+    HIP_TRY(need_irec());
+    k_seg_gram<K><<<p->n_seg_wg, kBlock, kSegStage * sizeof(double), s>>>(T);
+  }
   if (fork) HIP_TRY(hipStreamWaitEvent(s, p->ev_join, 0));
   k_assemble<K><<<dim3(T.sp.n_cp, 6), kAsmThreads, 0, s>>>(T);
-  if (T.nb) {
+  if (T.nb && !side_imu) {
     k_border_pb<K><<<dim3(T.sp.n_cp, p->n_split), 128, 0, s>>>(T);
     k_border_zero<<<std::min(64, (T.nb * T.nb + T.nb + kBlock - 1) / kBlock), kBlock, 0, s>>>(T);
     k_border_bb<K><<<T.n_bias, kBlock, 0, s>>>(T);
     k_border_gravity<<<1, 64, 0, s>>>(T);
   }
+  if (side_imu) HIP_TRY(hipStreamWaitEvent(s, p->ev_join, 0));  // border gathers done
   if (T.nb)
     k_reduce_partials<<<std::min(1024, (T.xo_bb - T.xo_pb + kBlock - 1) / kBlock), kBlock, 0, s>>>(T, p->n_split, T.xo_pb);
   const bool reduce_here = !p->allreduce && !p->rccl_comm && !T.nb && p->world == 1;  // nothing to exchange: bookkeeping in the packing kernel
@@ -953,6 +999,7 @@ int hs_destroy(hs_problem* p) {
   for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+  if (p->ev_irec) (void)hipEventDestroy(p->ev_irec);
   if (p->side) (void)hipStreamDestroy(p->side);
   if (p->h_state) (void)hipHostFree(p->h_state);
   if (p->rccl_comm && rccl_api()) (void)rccl_api()->CommDestroy(static_cast<ncclComm_t>(p->rccl_comm));
@@ -1370,7 +1417,7 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
   std::vector<hipEvent_t>& ev = p->events;
   HIP_TRY(hipEventRecord(ev[0], s));
   for (int it = 0; it < max_iterations; ++it) {
-    rc = p->k == 4 ? launch_linearize<4>(p) : launch_linearize<6>(p);
+    rc = p->k == 4 ? launch_linearize<4>(p, true) : launch_linearize<6>(p, true);
     if (rc) return rc;
     if (stages) HIP_TRY(hipEventRecord(ev[4 * it + 1], s));
     rc = p->k == 4 ? launch_build<4>(p) : launch_build<6>(p);

@@ -127,7 +127,7 @@ _PRODUCT_ONLY = {
     "rccl_shutdown": (C.c_int, [C.c_void_p]),
 }
 
-# every symbol include/hyperslam_hip.h declares (checked by tests/test_oracle.py::test_abi_exports)
+# every symbol include/hyperslam_hip.h declares (checked by tests/test_oracle.py::test_product_library_exports_every_declared_symbol)
 ABI_SYMBOLS = ["hs_" + n for n in list(_SIGNATURES) + list(_PRODUCT_ONLY)]
 
 

@@ -845,7 +845,13 @@ int launch_factor(hs_problem* p) {
     Tf.Sb += size_t(6 * f0) * ncb, Tf.g_s += 6 * f0, Tf.Ub += size_t(6 * f0) * ncb, Tf.Ubk += size_t(24) * f0, Tf.ybuf += 6 * f0, Tf.np -= 6 * f0;
     Tf.fj[0] = FactorJob{Tf.Sb, Tf.g_s, Tf.Ub, Tf.Ubk, Tf.ybuf, nullptr, Tf.np / 6, -1};
   }
-  if (nt) {
+  // short systems with window-wide bands (the sliding-window replay): every band tile in a register for the whole factorisation
+  const int n_eff = n_blk - f0;
+  const bool dense = !nt && !(T.debug_flags & 2097152) && T.bw > 14 && n_eff <= 2 * T.bw &&
+                     dense_factor_tiles(n_eff, std::min(T.bw, n_eff)) <= kDenseThreads * kDenseTiles;  // A/B switch 2097152: banded kernels
+  if (dense) {
+    k_dense_factor<<<1, kDenseThreads, (size_t(12) * (ncb + 8) + 64) * sizeof(double), s>>>(Tf);
+  } else if (nt) {
     Tables T1 = Tf;
     // (the lower-band rows come from the reversed copy, whose rows are counted from the END of the matrix: no offset)
     T1.mj[0] = MfmaJob{p->d_Sb2.p, Tf.g_s, Tf.Ub, Tf.Ubk, Tf.ybuf, nullptr, n_blk - f0, -1, n_blk - f0, INT_MAX, 0, p->d_Vb.p + size_t(T.np) * (6 * T.bw)};

@@ -1233,6 +1233,208 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward(Tables T) {
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Factorisation of SHORT systems with window-wide bands (the sliding-window replay: ~33 free block rows, every landmark track as long
+// as the window, so the "band" is the whole matrix and nothing slides): every 6x6 tile of the upper block triangle inside the band
+// lives in the registers of ONE lane for the whole factorisation — no trailing window in L2 (k_band_factor_wide: two global round
+// trips per step, 6.4 us per block row), no loader, no tile ownership that moves. 512 lanes x 2 tiles; the right-hand side is an extra
+// tile column. Per block row k:
+//   A1 the owner of the diagonal tile (k, k) factors it in place (6x6 Cholesky, one lane) and publishes U_kk, 1 / diag — at the end of its
+//      part of update k - 1, in the shadow of the other lanes' updates (X rows and U_kk are double buffered)
+//   A2 the other owners of row k (one contiguous run of <= bw lanes) solve their tile in place, X(k, j) = U_kk^-T S(k, j) (U_kk read
+//      from LDS with uniform addresses), write it to LDS (operand of the update) and to the factor (band storage)     --- barrier ---
+//   B  every lane: tile (i, j) -= X(k, i)' X(k, j) for its tiles with k < i <= k + bw - 1 (216 FMAs, 36 ds_read_b128) --- barrier ---
+// (A redundant register Cholesky in every row owner, as in the panel of k_band_factor_la, needs 60 more live registers next to the two
+//  resident tiles and spilled: 6.5 us per block row, parked 83 % of the time.)
+// Same outputs as the other factorisation kernels (Ub in band storage, U_ii^-1 packed, y = U^-T g).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kDenseThreads = 512, kDenseTiles = 2;
+
+/// Number of tile slots the dense kernel needs for n block rows of band width bw (band tiles + one right-hand-side tile per row).
+__host__ __device__ constexpr int dense_factor_tiles(int n, int bw) {
+  int t = 0;
+  for (int i = 0; i < n; ++i) t += (n - i < bw ? n - i : bw) + 1;
+  return t;
+}
+
+__global__ void __launch_bounds__(kDenseThreads) k_dense_factor(Tables T) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  DevState* st = T.st;
+  if (st->done) return;
+  const int tid = threadIdx.x;
+  const int bw = T.bw, ncb = 6 * bw, n = T.np / 6;
+  const int ldx = ncb + 8;           // row stride of the X row in LDS: [6 x (bw tiles) | y]
+  double* xrow = smem;               // 2 x 6 x ldx : X_k in band order (column 6 (j - k) + c), right-hand side at column ncb
+  double* dscr = smem + 12 * ldx;    // 2 x 32 : U_kk (upper, packed, 21) and 1 / diag (6), published by the owner of the diagonal tile
+  __shared__ int fail;
+  if (tid == 0) fail = 0;
+  // ---- static tile ownership: slot t = tid + 512 m -> (i, j), row major over rows i with columns j = i .. min(i + bw, n) - 1 and
+  //      the right-hand-side column (encoded as j = n) ----
+  int ti[kDenseTiles], tj[kDenseTiles];
+  double acc[kDenseTiles][36];
+#pragma unroll
+  for (int m = 0; m < kDenseTiles; ++m) {
+    ti[m] = -1, tj[m] = -1;
+    int rem = tid + m * kDenseThreads;
+    for (int i = 0; i < n; ++i) {
+      const int cnt = (n - i < bw ? n - i : bw) + 1;
+      if (rem < cnt) {
+        ti[m] = i, tj[m] = rem == cnt - 1 ? n : i + rem;
+        break;
+      }
+      rem -= cnt;
+    }
+#pragma unroll
+    for (int e = 0; e < 36; ++e) acc[m][e] = 0.0;
+    if (ti[m] >= 0) {
+      if (tj[m] == n) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) acc[m][6 * a] = T.g_s[6 * ti[m] + a];  // right-hand side: column 0 of the tile
+      } else {
+        const double* src = T.Sb + size_t(6 * ti[m]) * ncb + 6 * (tj[m] - ti[m]);
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int c = 0; c < 6; ++c) acc[m][6 * a + c] = (tj[m] > ti[m] || c >= a) ? src[size_t(a) * ncb + c] : 0.0;
+      }
+    }
+  }
+  __syncthreads();
+#define UIDX(a, c) ((a) * 6 - (a) * ((a)-1) / 2 + ((c) - (a)))
+  // X rows and the published U_kk are double buffered by k & 1: the owner of (k + 1, k + 1) factors its tile at the end of its part of
+  // update k (nothing else depends on that lane), while the other lanes still read X_k
+  auto factor_diagonal = [&](double (&t)[36], int k) {  // in place; publishes U_kk, 1 / diag, the diagonal tile of X_k, U_kk^-1
+    double* ub = dscr + 32 * (k & 1);
+    double* xr = xrow + (k & 1) * 6 * ldx;
+    double dmin = 1.0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      double d = t[6 * a + a];
+#pragma unroll
+      for (int q = 0; q < a; ++q) d = fma(-t[6 * q + a], t[6 * q + a], d);
+      dmin = a == 0 ? d : fmin(dmin, d);
+      const double y = __builtin_amdgcn_rsq(d);
+      const double e = fma(-d * y, y, 1.0);
+      const double rs = fma(y * e, fma(0.375, e, 0.5), y);
+      ub[21 + a] = rs;
+      t[6 * a + a] = d * rs;  // u_aa
+#pragma unroll
+      for (int c = a + 1; c < 6; ++c) {
+        double v = t[6 * a + c];
+#pragma unroll
+        for (int q = 0; q < a; ++q) v = fma(-t[6 * q + a], t[6 * q + c], v);
+        t[6 * a + c] = v * rs;
+      }
+    }
+    if (!(dmin > 0.0)) fail = 1;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const double v = c >= a ? t[6 * a + c] : 0.0;
+        if (c >= a) ub[UIDX(a, c)] = v;
+        xr[a * ldx + c] = v;
+        T.Ub[size_t(6 * k + a) * ncb + c] = v;
+      }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {  // W = U_kk^-1 (upper, packed)
+      double w[6];
+#pragma unroll
+      for (int a = 5; a >= 0; --a) {
+        double v = a == c ? 1.0 : 0.0;
+#pragma unroll
+        for (int q = a + 1; q < 6; ++q) v = fma(-t[6 * a + q], w[q], v);
+        w[a] = v * ub[21 + a];  // (own LDS stores: in order within the wave)
+      }
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+        if (a <= c) T.Ubk[size_t(k) * 24 + UIDX(a, c)] = w[a];
+    }
+  };
+#pragma unroll
+  for (int m = 0; m < kDenseTiles; ++m)
+    if (ti[m] == 0 && tj[m] == 0) factor_diagonal(acc[m], 0);
+  lds_barrier();
+  for (int k = 0; k < n; ++k) {
+    const double* ubuf = dscr + 32 * (k & 1);
+    double* xk = xrow + (k & 1) * 6 * ldx;
+    // ---- A: the owners of row k other than the diagonal one solve their tile in place, X(k, j) = U_kk^-T S(k, j); U_kk is read from
+    //      LDS (uniform addresses: broadcast), so the only registers involved are the tile's own ----
+#pragma unroll
+    for (int m = 0; m < kDenseTiles; ++m) {
+      if (ti[m] != k || tj[m] == k) continue;
+      const bool rhs = tj[m] == n;
+      const int col0 = rhs ? ncb : 6 * (tj[m] - k);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        const double ia = ubuf[21 + a];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          double t = acc[m][6 * a + c];
+#pragma unroll
+          for (int q = 0; q < a; ++q) t = fma(-ubuf[UIDX(q, a)], acc[m][6 * q + c], t);
+          acc[m][6 * a + c] = t * ia;
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        if (rhs) {
+          xk[a * ldx + ncb] = acc[m][6 * a];
+          T.ybuf[6 * k + a] = acc[m][6 * a];
+        } else {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) {
+            xk[a * ldx + col0 + c] = acc[m][6 * a + c];
+            T.Ub[size_t(6 * k + a) * ncb + col0 + c] = acc[m][6 * a + c];
+          }
+        }
+      }
+    }
+    lds_barrier();
+    // ---- B: trailing update ----
+    {  // band columns past the end of the matrix: zero in the factor row (the sweeps read whole rows); all lanes share the stores
+      const int used = 6 * (n - k < bw ? n - k : bw), nz = ncb - used;
+      for (int e = tid; e < 6 * nz; e += kDenseThreads) T.Ub[size_t(6 * k + e / nz) * ncb + used + e % nz] = 0.0;
+    }
+#pragma unroll
+    for (int m = 0; m < kDenseTiles; ++m) {
+      const int i = ti[m], j = tj[m];
+      if (i <= k || i - k >= bw) continue;      // finished rows; rows X_k does not reach
+      if (j != n && j - k >= bw) continue;      // (inside the band of row i but beyond the band of row k: untouched by X_k)
+      const double* A = xk + 6 * (i - k);
+      const double* B = xk + (j == n ? ncb : 6 * (j - k));
+#pragma unroll 2  // (fully unrolled, the scheduler hoists all 36 operand loads above the FMAs: 144 more live registers -> scratch)
+      for (int q = 0; q < 6; ++q) {
+        double av[6], bv[6];
+#pragma unroll
+        for (int a = 0; a < 6; a += 2) {
+          const double2 t = *reinterpret_cast<const double2*>(A + q * ldx + a);
+          av[a] = t.x, av[a + 1] = t.y;
+        }
+        if (j == n) {
+          bv[0] = B[q * ldx];
+#pragma unroll
+          for (int c = 1; c < 6; ++c) bv[c] = 0.0;
+        } else {
+#pragma unroll
+          for (int c = 0; c < 6; c += 2) {
+            const double2 t = *reinterpret_cast<const double2*>(B + q * ldx + c);
+            bv[c] = t.x, bv[c + 1] = t.y;
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int c = 0; c < 6; ++c) acc[m][6 * a + c] = fma(-av[a], bv[c], acc[m][6 * a + c]);
+      }
+      if (i == k + 1 && j == k + 1) factor_diagonal(acc[m], k + 1);  // (the next pivot: its tile is final now)
+    }
+    lds_barrier();
+  }
+#undef UIDX
+  if (tid == 0 && fail) st->chol_failed = 1;
+}
+
 /// Leading block rows of CONSTANT control points (the sliding window freezes every control point at or before its lower bound,
 /// optimizer.cpp:319-328, and keeps them while residuals still reach them): their Jacobian columns are zero, so the block rows are
 /// decoupled from everything — S_i,: = [D_i | 0] with the damping on the diagonal, g_i = 0. The factorisation kernels start behind

@@ -357,3 +357,21 @@ def test_huber_at_the_threshold(bearing, hip, oracle):
         for key in ("r", "J_state", "J_landmark", "cost"):
             assert rel(lg[key], lc[key]) < 1e-9, key
         assert abs(g.cost() - c.cost()) <= 1e-12 * c.cost()
+
+
+@pytest.mark.parametrize("order,bw,n_cp,imu", [(4, 15, 30, False), (4, 16, 24, False), (4, 22, 30, False), (4, 30, 36, True), (6, 33, 41, True), (4, 33, 47, False)])
+def test_short_windows_with_window_wide_bands(order, bw, n_cp, imu, hip, oracle, monkeypatch):
+    """The shape of the sliding-window replay: a few dozen free control points and tracks as long as the window. These systems take the
+    register-resident k_dense_factor (n - frozen <= 2 bw, bw > 14, <= 1024 tile slots); the banded kernels (HS_DEBUG_FLAGS=2097152) must
+    give the same step."""
+    w = window_with_band(order, bw, n_cp=n_cp, imu=imu)
+    compare(w, hip, oracle)
+    with ha.Problem(w, lib=hip) as g:
+        s1 = g.solve(3)
+        cp1 = g.control_points()
+    monkeypatch.setenv("HS_DEBUG_FLAGS", "2097152")
+    with ha.Problem(w, lib=hip) as g:
+        s2 = g.solve(3)
+        cp2 = g.control_points()
+    assert s1["num_successful_steps"] == s2["num_successful_steps"] and rel(cp1, cp2) < 1e-9
+    assert abs(s1["final_cost"] - s2["final_cost"]) <= 1e-9 * s2["final_cost"]

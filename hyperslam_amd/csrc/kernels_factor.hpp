@@ -1174,12 +1174,17 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward(Tables T) {
   };
   auto load_w = [&](int j) -> double { return (j >= 0 && tid < 21) ? T.Ubk[size_t(j) * 24 + tid] : 0.0; };
   __syncthreads();
-  double u0[6], u1[6], u2[6], u3[6], w0, w1, w2, w3;
-  load_u(n_blk - 1, u0), load_u(n_blk - 2, u1), load_u(n_blk - 3, u2);
-  w0 = load_w(n_blk - 1), w1 = load_w(n_blk - 2), w2 = load_w(n_blk - 3);
-  for (int j = n_blk - 1; j >= 0; --j) {
-    if (tid < 21) Wl[j & 1][tid] = w0;
-    load_u(j - 3, u3), w3 = load_w(j - 3);
+  // Four register sets, renamed by unrolling (a rotating set costs ~40 v_mov per block row: 0.08 us of the 0.5 us step). Ablation at
+  // configs[2] (128 rows, 69 us): the bare loop (barrier, y, x store) 34 us, W y 15 us, operand loads 14 us, pending-row update 6 us —
+  // the step is instruction-issue bound, not a latency chain: neither two block rows per barrier (81 us), nor a deeper prefetch, nor one
+  // wave instead of four changed it.
+  double ua[6], ub[6], uc[6], ud[6], wa, wb, wc, wd;
+  load_u(n_blk - 1, ua), load_u(n_blk - 2, ub), load_u(n_blk - 3, uc);
+  wa = load_w(n_blk - 1), wb = load_w(n_blk - 2), wc = load_w(n_blk - 3);
+  auto body = [&](int j, const double* u, double w, double* u_next, double* w_next) {
+    if (j < 0) return;
+    if (tid < 21) Wl[j & 1][tid] = w;
+    load_u(j - 3, u_next), *w_next = load_w(j - 3);
     lds_barrier();  // publishes Wl and the pending-row updates of the previous step
     const double* W = Wl[j & 1];
     double y[6], x[6];
@@ -1199,12 +1204,15 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward(Tables T) {
     if (tid < n_above && 6 * j - 1 - tid >= 0) {
       double sacc = 0.0;
 #pragma unroll
-      for (int a = 0; a < 6; ++a) sacc = fma(u0[a], x[a], sacc);
+      for (int a = 0; a < 6; ++a) sacc = fma(u[a], x[a], sacc);
       xs[6 * j - 1 - tid] -= sacc;
     }
-#pragma unroll
-    for (int a = 0; a < 6; ++a) u0[a] = u1[a], u1[a] = u2[a], u2[a] = u3[a];
-    w0 = w1, w1 = w2, w2 = w3;
+  };
+  for (int j = n_blk - 1; j >= 0; j -= 4) {
+    body(j, ua, wa, ud, &wd);
+    body(j - 1, ub, wb, ua, &wa);
+    body(j - 2, uc, wc, ub, &wb);
+    body(j - 3, ud, wd, uc, &wc);
   }
   __syncthreads();
 

@@ -181,7 +181,7 @@ def dominant_kernel(np_rows, bw, two_ended):
                     "hbm": {"achieved": nbytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBS},
                     "fp64": {"achieved": flops / avg_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / avg_s / 1e12 / FP64_PEAK_TFLOPS},
                     "workgroups": wgs, "waves_launched": wgs * threads // 64, "waves_available": 256 * 4 * 8,
-                    "bound": "latency (single dependency chain: block rows x ~2 us, DESIGN.md §6)"})
+                    "bound": "latency (single dependency chain: block rows x ~2 us, DESIGN.md §5)"})
     return out
 
 

@@ -92,6 +92,7 @@ _SIGNATURES = {
     "set_gravity": (C.c_int, [C.c_void_p, c_double_p, C.c_int]),
     "set_inertial_jacobian": (C.c_int, [C.c_void_p, C.c_int]),
     "set_stage_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "set_weights": (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
     "set_pixel_residuals": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_int32_p, c_int32_p]),
     "set_bearing_residuals": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_int32_p, c_int32_p]),
     "set_prior_residuals": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_int32_p]),

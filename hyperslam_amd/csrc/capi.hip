@@ -169,6 +169,8 @@ struct hs_problem {
   hs_problem* scratch = nullptr;                 // one-residual handle of hs_cost_function_evaluate (created on first use)
   int frozen_prefix = 0;                         // leading constant control points: decoupled block rows of the reduced system
   bool stage_timing = false;                     // hs_set_stage_timing
+  std::vector<double> weights[4];                // hs_set_weights: CostConfiguration::weights per factor type (empty: none)
+  bool has_weights() const { return !weights[0].empty() || !weights[1].empty() || !weights[2].empty() || !weights[3].empty(); }
   UploadBatch batch;                             // table uploads of prepare()
 
   // structure
@@ -218,6 +220,10 @@ struct hs_problem {
   void* allreduce_user = nullptr;
   void* rccl_comm = nullptr;  // ncclComm_t when hs_rccl_init was called
 };
+
+static const char* kWeightsMessage =
+    "a weight matrix is set (hs_set_weights): weights are applied by hs_linearize / hs_cost_function_evaluate; the solver runs the "
+    "reference's production configuration, weights = nullptr (optimizer.cpp:191,214,236,255)";
 
 #define HS_FAIL(code, msg) \
   do {                     \
@@ -1231,7 +1237,70 @@ static int linearize_sensor_blocks(hs_problem* p, int type, int robustify, const
   return HS_OK;
 }
 
+static int linearize_impl(hs_problem* p, int type, int robustify, const hs_linearization* out);
+
+/// hs_linearize with CostConfiguration::weights (exteroceptive.cpp:129-147): output = W * distance, J_w = W * J_m * J_e, then Ceres' loss
+/// corrector on the weighted residual. The device produces the unweighted, uncorrected rows (linearize_impl, robustify = 0); W (n_res x
+/// n_res) and the corrector are applied per residual block while the rows are handed out.
 int hs_linearize(hs_problem* p, int type, int robustify, const hs_linearization* out) {
+  if (!p || !out) return HS_ERR_INVALID;
+  if (type < HS_PIXEL || type > HS_INERTIAL) HS_FAIL(HS_ERR_INVALID, "unknown factor type");
+  const std::vector<double>& W = p->weights[type];
+  if (W.empty()) return linearize_impl(p, type, robustify, out);
+  const int n = hs_num_residuals(p, type), nr = type == HS_PIXEL ? 2 : (type == HS_BEARING ? 1 : 6);
+  hs_linearization o = *out;
+  std::vector<double> r_tmp, c_tmp;
+  if (!o.r) r_tmp.resize(size_t(n) * nr), o.r = r_tmp.data();
+  if (!o.cost) c_tmp.resize(n), o.cost = c_tmp.data();
+  const int rc = linearize_impl(p, type, 0, &o);
+  if (rc) return rc;
+  struct Block {
+    double* J;
+    int cols;
+  };
+  const Block blocks[] = {{o.J_state, 6 * p->k},       {o.J_landmark, 3},        {o.J_bias_g, 3 * p->kb},      {o.J_bias_a, 3 * p->kb},
+                          {o.J_gravity, 2},            {o.J_extrinsics, 6},      {o.J_intrinsics, 4},          {o.J_distortion, 4},
+                          {o.J_gyro_intrinsics, 6},    {o.J_acc_intrinsics, 6},  {o.J_gyro_sensitivity, 9},    {o.J_acc_offsets, 9}};
+  const bool visual = type == HS_PIXEL || type == HS_BEARING;
+  std::vector<double> tmp;
+  for (int i = 0; i < n; ++i) {
+    double rw[6], s2 = 0.0;
+    for (int a = 0; a < nr; ++a) {
+      rw[a] = 0.0;
+      for (int c = 0; c < nr; ++c) rw[a] += W[a * nr + c] * o.r[size_t(i) * nr + c];
+      s2 += rw[a] * rw[a];
+    }
+    double rho = s2, sr = 1.0;  // loss of the factor type on the weighted residual (optimizer.cpp:204,226,250,267)
+    if (visual) {
+      const double a = type == HS_PIXEL ? kHuberPixel : kHuberBearing;
+      if (s2 > a * a) rho = 2.0 * a * std::sqrt(s2) - a * a, sr = std::sqrt(a / std::sqrt(s2));
+    } else if (type == HS_INERTIAL) {
+      rho = kScaleInertial * s2, sr = std::sqrt(kScaleInertial);
+    }
+    if (!robustify) sr = 1.0;
+    o.cost[i] = 0.5 * rho;
+    for (int a = 0; a < nr; ++a) o.r[size_t(i) * nr + a] = sr * rw[a];
+    for (const Block& b : blocks) {
+      if (!b.J) continue;
+      if ((b.J == o.J_landmark || b.J == o.J_intrinsics || b.J == o.J_distortion) && !visual) continue;
+      if ((b.J == o.J_intrinsics || b.J == o.J_distortion) && type != HS_PIXEL) continue;
+      if ((b.J == o.J_bias_g || b.J == o.J_bias_a || b.J == o.J_gravity || b.J == o.J_gyro_intrinsics || b.J == o.J_acc_intrinsics ||
+           b.J == o.J_gyro_sensitivity || b.J == o.J_acc_offsets) && type != HS_INERTIAL)
+        continue;
+      double* J = b.J + size_t(i) * nr * b.cols;
+      tmp.assign(J, J + size_t(nr) * b.cols);
+      for (int a = 0; a < nr; ++a)
+        for (int c = 0; c < b.cols; ++c) {
+          double v = 0.0;
+          for (int m = 0; m < nr; ++m) v += W[a * nr + m] * tmp[size_t(m) * b.cols + c];
+          J[size_t(a) * b.cols + c] = sr * v;
+        }
+    }
+  }
+  return HS_OK;
+}
+
+static int linearize_impl(hs_problem* p, int type, int robustify, const hs_linearization* out) {
   if (!p || !out) return HS_ERR_INVALID;
   int rc = prepare(p);
   if (rc) return rc;
@@ -1337,6 +1406,7 @@ int hs_linearize(hs_problem* p, int type, int robustify, const hs_linearization*
 
 int hs_cost(hs_problem* p, double* cost) {
   if (!p || !cost) return HS_ERR_INVALID;
+  if (p->has_weights()) HS_FAIL(HS_ERR_INVALID, kWeightsMessage);
   int rc = prepare(p);
   if (rc) return rc;
   rc = reset_state(p, 0, 1e4);
@@ -1357,6 +1427,7 @@ int hs_cost(hs_problem* p, double* cost) {
 
 int hs_reduced_system(hs_problem* p, double radius, double* S, double* g) {
   if (!p || !S || !g) return HS_ERR_INVALID;
+  if (p->has_weights()) HS_FAIL(HS_ERR_INVALID, kWeightsMessage);
   int rc = prepare(p);
   if (rc) return rc;
   rc = reset_state(p, 1, radius);
@@ -1397,6 +1468,17 @@ int hs_reduced_system(hs_problem* p, double radius, double* S, double* g) {
   return HS_OK;
 }
 
+int hs_set_weights(hs_problem* p, int type, const double* weights) {
+  if (!p) return HS_ERR_INVALID;
+  if (type < HS_PIXEL || type > HS_INERTIAL) HS_FAIL(HS_ERR_INVALID, "unknown factor type");
+  const int nr = type == HS_PIXEL ? 2 : (type == HS_BEARING ? 1 : 6);
+  if (weights)
+    p->weights[type].assign(weights, weights + nr * nr);
+  else
+    p->weights[type].clear();
+  return HS_OK;
+}
+
 int hs_set_stage_timing(hs_problem* p, int enabled) {
   if (!p) return HS_ERR_INVALID;
   p->stage_timing = enabled != 0;
@@ -1405,6 +1487,7 @@ int hs_set_stage_timing(hs_problem* p, int enabled) {
 
 int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteration* iterations) {
   if (!p || !summary) return HS_ERR_INVALID;
+  if (p->has_weights()) HS_FAIL(HS_ERR_INVALID, kWeightsMessage);
   if (max_iterations < 0 || max_iterations > kMaxIterations) HS_FAIL(HS_ERR_INVALID, "max_iterations out of range");
   int rc = prepare(p);
   if (rc) return rc;
@@ -1640,6 +1723,7 @@ int hs_cost_function_evaluate(hs_problem* p, int type, int idx, const double* co
   }
   hs_problem* q = p->scratch;
   q->inertial_mode = p->inertial_mode;
+  for (int t = 0; t < 4; ++t) q->weights[t] = p->weights[t];
   // tables of the previous call (possibly another factor type)
   q->px_stamp.clear(), q->px_meas.clear(), q->px_lm.clear(), q->px_cam.clear(), q->br_stamp.clear(), q->br_meas.clear(), q->br_lm.clear(), q->br_cam.clear();
   q->pr_stamp.clear(), q->pr_meas.clear(), q->pr_sensor.clear(), q->in_stamp.clear(), q->in_meas.clear();

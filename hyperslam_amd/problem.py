@@ -179,6 +179,11 @@ class Problem:
                     num_parameters=npar.value, num_residuals=nres.value)
 
     # -- evaluation --------------------------------------------------------------------------------------------
+    def set_weights(self, ftype, weights):
+        """CostConfiguration::weights of one factor type (n_res x n_res; None clears): honoured by linearize / cost_function_evaluate."""
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=_f64)
+        self._check(self.lib.set_weights(self.h, int(ftype), None if w is None else _d(w)), "set_weights")
+
     def set_stage_timing(self, enabled=True):
         """Per-stage device times in the summary of solve() (four HIP events per iteration, ~5.7 us of idle device each): off by default."""
         self._check(self.lib.set_stage_timing(self.h, int(bool(enabled))), "set_stage_timing")

@@ -172,6 +172,13 @@ int hs_linearize(hs_problem* p, int type, int robustify, const hs_linearization*
  * (exteroceptive.hpp:31): parameters in update() block order, jacobians[i] row-major num_residuals x size_i, nullable
  * individually or as a whole. Evaluated on the GPU at the *given* parameter values. */
 int hs_cost_function_evaluate(hs_problem* p, int type, int idx, const double* const* parameters, double* residuals, double** jacobians);
+/* CostConfiguration::weights (forward.hpp:30-41; exteroceptive.cpp:109-121,129-147): an n_res x n_res matrix W per factor type
+ * (row-major; pixel 2, bearing 1, prior 6, inertial 6; NULL clears) with residual = W * distance(..) and J_w = W * J_m * J_e.
+ * Every production call site of the reference passes weights = nullptr (optimizer.cpp:191,214,236,255), and so does the solver here:
+ * the weights are honoured by the EVALUATION entry points (hs_linearize, hs_cost_function_evaluate: device rows, weighted and
+ * loss-corrected per residual block on the way out); hs_solve / hs_cost / hs_reduced_system return HS_ERR_INVALID while a weight
+ * matrix is set. */
+int hs_set_weights(hs_problem* p, int type, const double* weights);
 /* Total cost 0.5*sum rho(|r|^2) at the current point. */
 int hs_cost(hs_problem* p, double* cost);
 /* Reduced (landmark-eliminated), Jacobi-scaled, LM-damped system of the first iteration at the current point:

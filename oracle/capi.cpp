@@ -113,6 +113,15 @@ int hso_set_imu(hso_problem* p, const double* T, const double* ig, const double*
   P.bias_const = bias_constant != 0;
   return HS_OK;
 }
+int hso_set_weights(hso_problem* p, int type, const double* w) {
+  CHECK_ARG(type >= 0 && type <= 3, "unknown factor type");
+  const int nr = type == HS_PIXEL ? 2 : (type == HS_BEARING ? 1 : 6);
+  if (w)
+    p->P.weights[type].assign(w, w + nr * nr);
+  else
+    p->P.weights[type].clear();
+  return HS_OK;
+}
 int hso_set_stage_timing(hso_problem*, int) { return HS_OK; }  // (the oracle's stage times are host clocks: always on)
 int hso_set_inertial_jacobian(hso_problem* p, int mode) {
   CHECK_ARG(mode == HS_INERTIAL_AS_REFERENCE || mode == HS_INERTIAL_EXACT, "unknown inertial Jacobian mode");
@@ -236,7 +245,7 @@ int hso_cost_function_evaluate(hso_problem* p, int type, int idx, const double* 
     case kPrior: stamp = P.pr_stamp[idx], meas = &P.pr_meas[7 * idx]; break;
     case kInertial: stamp = P.in_stamp[idx], meas = &P.in_meas[6 * idx]; break;
   }
-  const CostContext ctx = {t, &basis, &bias_basis, stamp, meas, P.inertial_mode == 0};
+  const CostContext ctx = {t, &basis, &bias_basis, stamp, meas, P.inertial_mode == 0, P.weights[t].empty() ? nullptr : P.weights[t].data()};
   cost_evaluate(ctx, L, parameters, residuals, jacobians);
   return HS_OK;
 }

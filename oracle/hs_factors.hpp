@@ -653,6 +653,7 @@ struct CostContext {
   double stamp;
   const double* measurement;  // pixel 2 | bearing 3 | pose 7 | [w; a] 6
   bool inertial_literal = true;  // HS_INERTIAL_AS_REFERENCE
+  const double* weights = nullptr;  // CostConfiguration::weights: n_res x n_res, row-major (exteroceptive.cpp:109-121,129-147)
 };
 
 inline bool cost_evaluate(const CostContext& ctx, const Layout& L, const double* const* parameters, double* residuals, double** jacobians) {
@@ -677,8 +678,24 @@ inline bool cost_evaluate(const CostContext& ctx, const Layout& L, const double*
     case kBearing: metric_angular(pred.v, ctx.measurement, residuals, p_J_m); break;
     case kPrior: metric_se3(pred.v, ctx.measurement, residuals, p_J_m); break;
   }
+  const int nr = L.num_residuals;
+  if (ctx.weights) {  // output = weights * distance(..)
+    double t[6];
+    for (int r = 0; r < nr; ++r) {
+      t[r] = 0;
+      for (int c = 0; c < nr; ++c) t[r] += ctx.weights[r * nr + c] * residuals[c];
+    }
+    for (int r = 0; r < nr; ++r) residuals[r] = t[r];
+  }
   if (!jacobians) return true;
-  const DMat J_w = (ctx.type == kBearing || ctx.type == kPrior) ? dmul(J_m, J_e) : J_e;  // Cartesian metric: J_m = I
+  DMat J_w = (ctx.type == kBearing || ctx.type == kPrior) ? dmul(J_m, J_e) : J_e;  // Cartesian metric: J_m = I
+  if (ctx.weights) {  // J_w = weights * J_m * J_e
+    DMat W;
+    W.set_zero(nr, nr);
+    for (int r = 0; r < nr; ++r)
+      for (int c = 0; c < nr; ++c) W(r, c) = ctx.weights[r * nr + c];
+    J_w = dmul(W, J_w);
+  }
   for (size_t i = 0; i < L.sizes.size(); ++i) {
     if (!jacobians[i]) continue;
     const int size = L.sizes[i];

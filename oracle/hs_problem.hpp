@@ -61,6 +61,7 @@ struct Problem {
   std::vector<int32_t> pr_sensor;
   std::vector<double> in_stamp, in_meas;
   int inertial_mode = 0;  // HS_INERTIAL_AS_REFERENCE (inertial.cpp as written) | 1 HS_INERTIAL_EXACT
+  std::vector<double> weights[4];  // CostConfiguration::weights per factor type (empty: none)
 
   int n_res(FactorType t) const {
     switch (t) {
@@ -151,7 +152,7 @@ struct Evaluator {
       kinds[k] = kManifoldSE3;
       for (int b = 1; b < n_static; ++b) kinds[k + b] = kManifoldEuclidean;
     }
-    const CostContext ctx = {type, &basis, &bias_basis, stamp, meas, P.inertial_mode == 0};
+    const CostContext ctx = {type, &basis, &bias_basis, stamp, meas, P.inertial_mode == 0, P.weights[type].empty() ? nullptr : P.weights[type].data()};
     const Loss loss = loss_for(type);
     double r[6];
     if (!lin || !want_jac) {

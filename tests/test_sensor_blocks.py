@@ -151,3 +151,71 @@ def test_sensor_blocks_hip_vs_oracle(ftype, order, mode, robustify, hip, oracle)
             for bi, kind in enumerate(kinds):
                 P = c.manifold_plus_jacobian(kind, blocks[bi][None, :])[0]
                 assert np.abs(Jg[bi] @ P - Jc[bi] @ P).max() <= 1e-9 * scale, (bi, kind)
+
+
+# ---- CostConfiguration::weights (exteroceptive.cpp:109-121,129-147): output = W * distance(..), J_w = W * J_m * J_e ------------------
+def weight_matrix(ftype, seed=5):
+    nr = {ha.HS_PIXEL: 2, ha.HS_BEARING: 1, ha.HS_PRIOR: 6, ha.HS_INERTIAL: 6}[ftype]
+    rng = np.random.default_rng(seed + ftype)
+    return np.eye(nr) * rng.uniform(0.5, 2.0, size=nr) + 0.2 * rng.normal(size=(nr, nr))
+
+
+WEIGHT_CASES = [(ha.HS_PIXEL, 4), (ha.HS_BEARING, 6), (ha.HS_PRIOR, 4), (ha.HS_INERTIAL, 6)]
+
+
+@pytest.mark.parametrize("ftype,order", WEIGHT_CASES)
+def test_weights_oracle(ftype, order, oracle):
+    """With W set the entry point returns W r and W J (checked against the unweighted call), and the gradient probe still holds."""
+    w = probe_window(ftype, order)
+    W = weight_matrix(ftype)
+    with ha.Problem(w, lib=oracle) as p:
+        if ftype == ha.HS_INERTIAL:
+            p.set_inertial_jacobian(ha.HS_INERTIAL_EXACT)
+        blocks = p.parameter_blocks(ftype, 2)
+        r0, J0 = p.cost_function_evaluate(ftype, 2, blocks, [True] * len(blocks))
+        p.set_weights(ftype, W)
+        r1, J1 = p.cost_function_evaluate(ftype, 2, blocks, [True] * len(blocks))
+        assert np.allclose(r1, W @ r0, rtol=1e-13, atol=1e-15)
+        for a, b in zip(J0, J1):
+            assert np.allclose(b, W @ a, rtol=1e-12, atol=1e-13 * max(1.0, np.abs(a).max()))
+        assert probe(p, ftype, 2, blocks) < TOL
+        p.set_weights(ftype, None)
+        r2, _ = p.cost_function_evaluate(ftype, 2, blocks)
+        assert np.array_equal(r2, r0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ftype,order", WEIGHT_CASES)
+@pytest.mark.parametrize("robustify", [False, True])
+def test_weights_hip_vs_oracle(ftype, order, robustify, hip, oracle):
+    """hs_set_weights through the HIP evaluation entry points (whole tables and the Ceres-style single block) against the oracle; the
+    solver refuses to run with weights (the reference never passes any: optimizer.cpp:191,214,236,255)."""
+    w = probe_window(ftype, order)
+    W = weight_matrix(ftype)
+    with ha.Problem(w, lib=hip) as g, ha.Problem(w, lib=oracle) as c:
+        if ftype == ha.HS_INERTIAL:  # (the gradient probe below needs the derivative of the residual: I_g != I_a in this window)
+            g.set_inertial_jacobian(ha.HS_INERTIAL_EXACT), c.set_inertial_jacobian(ha.HS_INERTIAL_EXACT)
+        g.set_weights(ftype, W), c.set_weights(ftype, W)
+        a, b = g.linearize(ftype, robustify, sensor_blocks=True), c.linearize(ftype, robustify, sensor_blocks=True)
+        keys = ("r", "J_state", "cost") + SENSOR_KEYS[ftype] + (("J_landmark",) if ftype in (ha.HS_PIXEL, ha.HS_BEARING) else ()) + \
+            (("J_bias_g", "J_bias_a", "J_gravity") if ftype == ha.HS_INERTIAL else ())
+        scale = np.abs(b["J_state"]).max()
+        for key in keys:
+            assert np.abs(a[key] - b[key]).max() <= 1e-9 * max(np.abs(b[key]).max(), 1e-3 * scale if key.startswith("J") else 0.0), key
+        if robustify and ftype in (ha.HS_PIXEL, ha.HS_BEARING):  # the corrector acts on the WEIGHTED residual
+            u = g.linearize(ftype, False)
+            assert rel(a["r"], u["r"]) > 1e-6
+        blocks = g.parameter_blocks(ftype, 1)
+        rg, Jg = g.cost_function_evaluate(ftype, 1, blocks, [True] * len(blocks))
+        rc, Jc = c.cost_function_evaluate(ftype, 1, blocks, [True] * len(blocks))
+        assert rel(rg, rc) < 1e-9
+        kb = int(w.imu["bias_order"]) if ftype == ha.HS_INERTIAL else 0
+        sc = max(np.abs(J).max() for J in Jc)
+        for bi, kind in enumerate(block_kinds(ftype, w.order, kb)):
+            P = c.manifold_plus_jacobian(kind, blocks[bi][None, :])[0]
+            assert np.abs(Jg[bi] @ P - Jc[bi] @ P).max() <= 1e-9 * sc, bi
+        assert probe(g, ftype, 1, blocks) < TOL
+        with pytest.raises(ha.HsError, match="weight"):
+            g.solve(1)
+        g.set_weights(ftype, None)
+        assert g.solve(1)["num_iterations"] == 1

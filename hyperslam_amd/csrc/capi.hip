@@ -820,7 +820,10 @@ int launch_factor(hs_problem* p) {
     }
   };
   if (two_ended) {
-    const int m = (n_blk - w_mid) / 2, mB = n_blk - w_mid - m;
+    // The near end takes a few block rows more than the far end: the far end still has to hand its trailing window over (~7 us,
+    // i.e. ~4 steps: window through HBM + agent-scope release) before the near end can pass the junction. With an even split
+    // workgroup 0 waited 13 us there (tools/chol_phase_timing.py).
+    const int m = std::min((n_blk - w_mid) / 2 + 3, n_blk - w_mid - w_mid), mB = n_blk - w_mid - m;  // (+2 / +3 / +4: 132.0 / 130.5 / 132.1 us)
     Tables T2 = T;
     T2.fj[0] = FactorJob{T.Sb, T.g_s, T.Ub, T.Ubk, T.ybuf, p->d_win.p, m + w_mid, m};
     T2.fj[1] = FactorJob{p->d_Sb2.p, p->d_g2.p, p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, p->d_win.p, mB, -1};

@@ -634,6 +634,16 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
       for (int ap = 0; ap < 6; ++ap)
 #pragma unroll
         for (int a = 0; a < 6; ++a) B[ap][a] = xp[ap * ld + 6 + a];
+      double o0[PC][6], o1[PC][6];  // the originals of both rows first (the stores below may alias them as far as the compiler knows)
+#pragma unroll
+      for (int m = 0; m < PC; ++m) {
+        const int c = l + 64 * m;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          o0[m][a] = c > ncb ? 0.0 : (c == ncb ? J.g_s[6 * r + a] : J.Sb[size_t(6 * r + a) * ncb + c]);
+          o1[m][a] = c > ncb ? 0.0 : (c == ncb ? J.g_s[6 * (r + 1) + a] : J.Sb[size_t(6 * (r + 1) + a) * ncb + c]);
+        }
+      }
 #pragma unroll
       for (int m = 0; m < PC; ++m) {
         const int c = l + 64 * m;
@@ -647,11 +657,11 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
 #pragma unroll
           for (int ap = 0; ap < 6; ++ap) v = fma(-B[ap][a], xc[ap], v);
           if (c == ncb) {  // right-hand side: row vr of the reversed middle block is row dm - 1 - vr of the natural one
-            J.win[size_t(6 * w_mid - 1 - a) * (ncb + 1) + ncb] = v - J.g_s[6 * r + a];
-            J.win[size_t(6 * w_mid - 1 - (6 + a)) * (ncb + 1) + ncb] = row1[a * ld + c] - J.g_s[6 * (r + 1) + a];
+            J.win[size_t(6 * w_mid - 1 - a) * (ncb + 1) + ncb] = v - o0[m][a];
+            J.win[size_t(6 * w_mid - 1 - (6 + a)) * (ncb + 1) + ncb] = row1[a * ld + c] - o1[m][a];
           } else {
-            hand_over(a, c, v - J.Sb[size_t(6 * r + a) * ncb + c]);
-            hand_over(6 + a, c, row1[a * ld + c] - J.Sb[size_t(6 * (r + 1) + a) * ncb + c]);
+            hand_over(a, c, v - o0[m][a]);
+            hand_over(6 + a, c, row1[a * ld + c] - o1[m][a]);
           }
         }
       }
@@ -690,10 +700,15 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
       rhs[m][a] = (in && t_kk[m] == 0) ? J.g_s[6 * r + a] : 0.0;
     }
   }
+  const bool cprof = (T.debug_flags & 16) && tid == 0;  // coarse phases of this workgroup -> tlog[8 (200 + 10 job) + ..]
+  long long* clog = reinterpret_cast<long long*>(T.xpart) + 8 * (200 + 10 * blockIdx.x);
+  if (cprof) clog[0] = wall_clock64();  // tiles requested
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (cprof) clog[1] = wall_clock64();  // tiles loaded
   lds_barrier();  // init
   lds_barrier();  // prologue: X_0 complete
-  const bool prof = (T.debug_flags & 16) && tid == 0;
+  if (cprof) clog[2] = wall_clock64();
+  const bool prof = (T.debug_flags & 16) && tid == 0 && blockIdx.x == 0;
   long long* tlog = reinterpret_cast<long long*>(T.xpart);
   for (int i = 0; i < n_steps; ++i) {
     if (prof) tlog[8 * i + 0] = wall_clock64();
@@ -752,15 +767,44 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
     if (prof) tlog[8 * i + 1] = wall_clock64();
     lds_barrier();
     if (m_at >= 0 && i + 1 == m_at) {  // ---- junction: add the other end's Schur contribution to the middle rows ----
+      if (cprof) clog[3] = wall_clock64();
       junction_wait();
+      if (cprof) clog[4] = wall_clock64();
       const int dm = 6 * w_mid, wl = ncb + 1;
       const double* WD = J.win;  // correction in this job's own band layout, local to the middle rows (see hand_over)
+      // The window was written by a workgroup on another XCD: every load misses this L2 (~2 us). All operands are requested first —
+      // the two LDS rows (up to six entries per lane) and the register tiles — so that the merge costs one round trip, not seven.
+      constexpr int RU = 6;  // 2 * 6 * (ncb + 1) <= RU * nthr  (ncb <= 95)
+      double wrow[RU];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const int e = tid + u * nthr;
+        const bool ok = e < 2 * 6 * (ncb + 1);
+        const int jr = ok ? e / (6 * (ncb + 1)) : 0, rem = ok ? e % (6 * (ncb + 1)) : 0, a = rem / (ncb + 1), c = rem % (ncb + 1);
+        wrow[u] = WD[size_t(6 * jr + a) * wl + c];
+      }
+      double wt[TPT][36], wh[TPT][6];
+#pragma unroll
+      for (int m = 0; m < TPT; ++m) {
+        const int jr = t_row[m] - m_at;
+        const bool ok = t_ok[m] && jr >= 2 && jr < w_mid;
+        const double* src = WD + (ok ? size_t(6 * jr) * wl + 6 * t_kk[m] : 0);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) wt[m][6 * a + c] = src[size_t(a) * wl + c];
+          wh[m][a] = WD[(ok ? size_t(6 * jr + a) * wl : 0) + ncb];
+        }
+      }
       // rows m and m + 1 sit in LDS
-      for (int e = tid; e < 2 * 6 * (ncb + 1); e += nthr) {
-        const int jr = e / (6 * (ncb + 1)), rem = e % (6 * (ncb + 1)), a = rem / (ncb + 1), c = rem % (ncb + 1);
-        double* dst = rowbuf + ((m_at + jr) & 1) * 6 * ld + a * ld + c;
-        const double d = WD[size_t(6 * jr + a) * wl + c];
-        *dst = (c == ncb || 6 * jr + c < dm) ? *dst + d : 0.0;  // columns beyond the middle couple to the eliminated end
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const int e = tid + u * nthr;
+        if (e < 2 * 6 * (ncb + 1)) {
+          const int jr = e / (6 * (ncb + 1)), rem = e % (6 * (ncb + 1)), a = rem / (ncb + 1), c = rem % (ncb + 1);
+          double* dst = rowbuf + ((m_at + jr) & 1) * 6 * ld + a * ld + c;
+          *dst = (c == ncb || 6 * jr + c < dm) ? *dst + wrow[u] : 0.0;  // columns beyond the middle couple to the eliminated end
+        }
       }
 #pragma unroll
       for (int m = 0; m < TPT; ++m) {
@@ -770,30 +814,41 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
 #pragma unroll
-          for (int c = 0; c < 6; ++c) acc[m][6 * a + c] = inside ? acc[m][6 * a + c] + WD[size_t(6 * jr + a) * wl + 6 * t_kk[m] + c] : 0.0;
-          if (t_kk[m] == 0) rhs[m][a] += WD[size_t(6 * jr + a) * wl + ncb];
+          for (int c = 0; c < 6; ++c) acc[m][6 * a + c] = inside ? acc[m][6 * a + c] + wt[m][6 * a + c] : 0.0;
+          if (t_kk[m] == 0) rhs[m][a] += wh[m][a];
         }
       }
+      if (cprof) clog[5] = wall_clock64();
       lds_barrier();  // merge done
       lds_barrier();  // panel(m) done
+      if (cprof) clog[6] = wall_clock64();
     }
   }
   lds_barrier();
+  if (cprof) clog[7] = wall_clock64();  // last block row done
   if (dump) {  // rows n_steps + 2 .. n_steps + w - 1 of the trailing window live in the register tiles
 #pragma unroll
     for (int m = 0; m < TPT; ++m) {
       const int jr = t_row[m] - n_steps;
       if (!t_ok[m] || jr < 2 || jr >= w_mid) continue;
+      double so[36], go[6];  // the originals first: the stores below may alias them as far as the compiler knows, which serialised
+                             // 36 load -> subtract -> store round trips
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
 #pragma unroll
-        for (int c = 0; c < 6; ++c)
-          hand_over(6 * jr + a, 6 * t_kk[m] + c, acc[m][6 * a + c] - J.Sb[size_t(6 * t_row[m] + a) * ncb + 6 * t_kk[m] + c]);
-        if (t_kk[m] == 0) J.win[size_t(6 * w_mid - 1 - (6 * jr + a)) * (ncb + 1) + ncb] = rhs[m][a] - J.g_s[6 * t_row[m] + a];
+        for (int c = 0; c < 6; ++c) so[6 * a + c] = J.Sb[size_t(6 * t_row[m] + a) * ncb + 6 * t_kk[m] + c];
+        go[a] = t_kk[m] == 0 ? J.g_s[6 * t_row[m] + a] : 0.0;
+      }
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) hand_over(6 * jr + a, 6 * t_kk[m] + c, acc[m][6 * a + c] - so[6 * a + c]);
+        if (t_kk[m] == 0) J.win[size_t(6 * w_mid - 1 - (6 * jr + a)) * (ncb + 1) + ncb] = rhs[m][a] - go[a];
       }
     }
     __threadfence();
     lds_barrier();
+    if (cprof) clog[8] = wall_clock64();  // window handed over
   }
 }
 

@@ -8,10 +8,10 @@ w=synthetic.config1()
 p=ha.Problem(w); p.snapshot()
 for i in range(2): p.restore(); s=p.solve(1)
 lib=_lib.load().cdll
-buf=np.zeros(16*1024+8*128, np.int64)
+buf=np.zeros(16*1024+8*256, np.int64)
 lib.hs_debug_read.argtypes=[C.c_void_p, C.c_void_p, C.c_int]
 lib.hs_debug_read(p.h, buf.ctypes.data, len(buf))
-t=buf[:8*128].reshape(128,8); t2=buf[8*1024:8*1024+8*128].reshape(128,8); t3=buf[16*1024:].reshape(128,8)
+t=buf[:8*128].reshape(128,8); t2=buf[8*1024:8*1024+8*128].reshape(128,8); t3=buf[16*1024:16*1024+8*128].reshape(128,8)
 # compute wave 0: [0] step start, [1] rank-6 update + publish done; panel wave (row r): [2] start, [3] row updated, [4] factored, [5] X written
 r = slice(10, 110)
 print("units of 10 ns. step:", np.median(np.diff(t[r, 0])), " compute P2+publish:", np.median(t[r, 1] - t[r, 0]))
@@ -21,3 +21,10 @@ ev = slice(10, 110, 2)
 print("arrival at the step barrier relative to step start: compute", np.median(t[ev, 1] - t[ev, 0]), " panel(row r+1)", np.median(t[11:111:2, 5] - t[ev, 0]),
       " storer", np.median(t[ev, 6] - t[ev, 0]), " loader", np.median(t[ev, 7] - t[ev, 0]))
 print("solve_ms", s["solve_ms"])
+
+for job in (0, 1):
+    c = buf[8 * (200 + 10 * job): 8 * (200 + 10 * job) + 9]
+    b = buf[8 * 200]
+    print("job", job, "relative to job 0's start [10 ns]: tiles requested", c[0] - b, " loaded", c[1] - b, " prologue done", c[2] - b,
+          " junction reached", c[3] - b, " partner arrived", c[4] - b, " merged", c[5] - b, " X_m published", c[6] - b, " last row", c[7] - b,
+          " window handed over", c[8] - b)

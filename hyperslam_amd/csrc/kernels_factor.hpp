@@ -875,6 +875,9 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward2(Tables T, BackJ
   const int tid = threadIdx.x;
   constexpr int nthr = kCholThreads;
   const int bw = T.bw, ncb = 6 * bw, np = T.np;
+  const bool cprof = (T.debug_flags & 16) && tid == 0;  // coarse phases -> xpart[8 (230 + 10 block) + ..] (tools/chol_phase_timing.py)
+  long long* clog = reinterpret_cast<long long*>(T.xpart) + 8 * (230 + 10 * blockIdx.x);
+  if (cprof) clog[0] = wall_clock64();
   const int n_own = 6 * J.n_rows, n_all = 6 * (J.n_rows + J.given);
   double* xs = smem;          // n_all : pending rows (own) / given solution
   double* xout = smem + n_all;  // n_own : solution of the own rows (flushed to T.xsol at the end / when the middle is complete)
@@ -917,8 +920,10 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward2(Tables T, BackJ
   double u0[6], u1[6], u2[6], u3[6], w0, w1, w2, w3;
   load_u(jtop, u0), load_u(jtop - 1, u1), load_u(jtop - 2, u2);
   w0 = load_w(jtop), w1 = load_w(jtop - 1), w2 = load_w(jtop - 2);
+  if (cprof) clog[1] = wall_clock64();  // operands staged
   if (J.given) {  // wait for the middle solution
     wait_for_partner(T);
+    if (cprof) clog[2] = wall_clock64();  // middle solution arrived
     for (int rho = n_own + tid; rho < n_all; rho += nthr) xs[rho] = T.xsol[J.reversed ? np - 1 - rho : rho];
   }
   __syncthreads();
@@ -965,11 +970,13 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward2(Tables T, BackJ
     for (int a = 0; a < 6; ++a) u0[a] = u1[a], u1[a] = u2[a], u2[a] = u3[a];
     w0 = w1, w1 = w2, w2 = w3;
   };
+  if (cprof) clog[3] = wall_clock64();  // sweep starts
   for (int j = jtop; j >= J.n_rows; --j) step(j, std::false_type{});  // (not merged: given rows one by one)
   const int j_pub = (blockIdx.x == 0 && m_mid >= 0) ? m_mid : 0;  // block 0 publishes the middle solution after block row m_mid
   for (int j = J.n_rows - 1; j >= j_pub; --j) step(j, std::true_type{});
   if (blockIdx.x == 0 && m_mid >= 0) {
     lds_barrier();
+    if (cprof) clog[4] = wall_clock64();  // middle rows solved
     for (int rho = 6 * m_mid + tid; rho < n_own; rho += nthr) T.xsol[rho] = xout[rho];
     __threadfence();
     lds_barrier();
@@ -977,9 +984,11 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward2(Tables T, BackJ
       __threadfence();
       __hip_atomic_store(T.join_flag, T.join_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (cprof) clog[5] = wall_clock64();  // middle solution published
     for (int j = m_mid - 1; j >= 0; --j) step(j, std::true_type{});
   }
   __syncthreads();
+  if (cprof) clog[6] = wall_clock64();  // sweep done
   const int flush_to = (blockIdx.x == 0 && m_mid >= 0) ? 6 * m_mid : n_own;  // (the middle rows of block 0 are already out)
   for (int rho = tid; rho < flush_to; rho += nthr) T.xsol[J.reversed ? np - 1 - rho : rho] = xout[rho];
   if (gridDim.x == 1) return;  // (A/B runs on the whole system: k_step_outputs follows)
@@ -993,12 +1002,26 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward2(Tables T, BackJ
   __threadfence();
   __shared__ double red[kCholThreads / 64];
   double gd = 0.0, dd = 0.0;
-  for (int rho = tid; rho < np; rho += nthr) {
-    const double step = -__builtin_nontemporal_load(T.xsol + rho);
-    T.step_p[rho] = step;
-    T.delta_p[rho] = T.scale_p[rho] * step;
-    gd = fma(T.g_full[rho], step, gd);
-    dd = fma(T.D2p[rho] * step, step, dd);
+  // (four rows per lane in flight: the other block's half of the solution comes through HBM, a plain loop paid that latency per pass:
+  //  5.6 us for 768 rows)
+  for (int rho0 = tid; rho0 < np; rho0 += 4 * nthr) {
+    double xv[4], sc[4], gf[4], d2[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rho = rho0 + u * nthr, rr = rho < np ? rho : 0;
+      xv[u] = __builtin_nontemporal_load(T.xsol + rr), sc[u] = T.scale_p[rr], gf[u] = T.g_full[rr], d2[u] = T.D2p[rr];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rho = rho0 + u * nthr;
+      if (rho < np) {
+        const double step = -xv[u];
+        T.step_p[rho] = step;
+        T.delta_p[rho] = sc[u] * step;
+        gd = fma(gf[u], step, gd);
+        dd = fma(d2[u] * step, step, dd);
+      }
+    }
   }
   gd = block_sum(gd, red);
   dd = block_sum(dd, red);
@@ -1006,6 +1029,7 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward2(Tables T, BackJ
     st->g_dot_step_pose = gd;
     st->d2_step2_pose = dd;
   }
+  if (cprof) clog[7] = wall_clock64();  // step outputs written (the block that finished last)
 }
 
 

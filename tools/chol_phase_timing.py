@@ -28,3 +28,9 @@ for job in (0, 1):
     print("job", job, "relative to job 0's start [10 ns]: tiles requested", c[0] - b, " loaded", c[1] - b, " prologue done", c[2] - b,
           " junction reached", c[3] - b, " partner arrived", c[4] - b, " merged", c[5] - b, " X_m published", c[6] - b, " last row", c[7] - b,
           " window handed over", c[8] - b)
+
+for blk in (0, 1):
+    c = buf[8 * (230 + 10 * blk): 8 * (230 + 10 * blk) + 8]
+    b = buf[8 * 230]
+    print("backward block", blk, "[10 ns after block 0's start]: operands staged", c[1] - b, " middle arrived", c[2] - b, " sweep starts", c[3] - b,
+          " middle solved", c[4] - b, " published", c[5] - b, " sweep done", c[6] - b, " outputs", c[7] - b)

@@ -716,8 +716,10 @@ int launch_build(hs_problem* p) {
     const int grid = (T.n_lm + kBlock / 64 - 1) / (kBlock / 64);
     if (6 * T.bw <= 128)
       k_landmark<K, 2, 2><<<grid, kBlock, 0, s>>>(T);
-    else  // long feature tracks (6 * bw <= kBlock is checked in prepare())
+    else if (T.debug_flags & 4194304)  // A/B switch 4194304: one wave per landmark with four passes
       k_landmark<K, 4, 1><<<grid, kBlock, 0, s>>>(T);
+    else  // long feature tracks (6 * bw <= kBlock is checked in prepare()): one workgroup per landmark, one wave per 64 rows of W
+      k_landmark_rows<K, 4><<<T.n_lm, kBlock, 0, s>>>(T);
   }
   if (T.n_lm && p->n_group_wg) {
     const int ntile = T.bw * (T.bw + 1) / 2;
@@ -754,15 +756,19 @@ int launch_build(hs_problem* p) {
     k_border_gravity<<<1, 64, 0, s>>>(T);
   }
   if (side_imu) HIP_TRY(hipStreamWaitEvent(s, p->ev_join, 0));  // border gathers done
-  if (T.nb)
+  // Nothing to exchange (single shard): packing + bookkeeping are an extra workgroup of k_finalize_reduced, the border blocks further
+  // ones that sum the accumulation splits themselves — one launch where the exchanging path has five (~5 us each on the chain).
+  // A/B switch 8388608: the five launches.
+  const bool reduce_here = !p->allreduce && !p->rccl_comm && p->world == 1 && !(T.nb && (T.debug_flags & 8388608));
+  const int nb_wg = T.nb ? std::min(256, ((T.np + T.nb) * T.nb + kBlock - 1) / kBlock) : 0;
+  if (T.nb && !reduce_here)
     k_reduce_partials<<<std::min(1024, (T.xo_bb - T.xo_pb + kBlock - 1) / kBlock), kBlock, 0, s>>>(T, p->n_split, T.xo_pb);
-  const bool reduce_here = !p->allreduce && !p->rccl_comm && !T.nb && p->world == 1;  // nothing to exchange: bookkeeping in the packing kernel
   if (!reduce_here) k_pack_exchange<<<1, kBlock, 0, s>>>(T, 0);
   HIP_TRY(hipGetLastError());
   const int rc = exchange(p, T.xbuf, T.x_count1);  // one RCCL all-reduce of [S | g | diag | cost] per linearisation
   if (rc) return rc;
-  k_finalize_reduced<<<T.sp.n_cp + (reduce_here ? 1 : 0), kBlock, 0, s>>>(T);  // + 1: packing / bookkeeping workgroup
-  if (T.nb) k_finalize_border<<<std::min(256, ((T.np + T.nb) * T.nb + kBlock - 1) / kBlock), kBlock, 0, s>>>(T);
+  k_finalize_reduced<<<T.sp.n_cp + (reduce_here ? 1 + nb_wg : 0), kBlock, 0, s>>>(T, p->n_split);  // + 1: packing / bookkeeping workgroup, + border
+  if (T.nb && !reduce_here) k_finalize_border<<<nb_wg, kBlock, 0, s>>>(T);
   if (!reduce_here) k_cost_reduce<<<1, kBlock, 0, s>>>(T);
   HIP_TRY(hipGetLastError());
   return HS_OK;
@@ -852,17 +858,17 @@ int launch_factor(hs_problem* p) {
   // factorisation starts behind them — the same kernels on the trailing sub-matrix (the band storage is row relative: pointer offsets).
   const int f0 = (T.debug_flags & 262144) ? 0 : std::min(p->frozen_prefix, n_blk - 1);  // A/B switch 262144: eliminate every block row
   Tables Tf = T;
+  const int n_eff = n_blk - f0;
+  const bool dense = !nt && !(T.debug_flags & 2097152) && T.bw > 14 && n_eff <= 2 * T.bw &&
+                     dense_factor_tiles(n_eff, std::min(T.bw, n_eff)) <= kDenseThreads * kDenseTiles;  // A/B switch 2097152: banded kernels
   if (f0 > 0) {
-    k_factor_decoupled_rows<<<f0, 64, 0, s>>>(T, f0);
+    if (!dense) k_factor_decoupled_rows<<<f0, 64, 0, s>>>(T, f0);  // (the dense kernel writes them with extra workgroups of its own launch)
     Tf.Sb += size_t(6 * f0) * ncb, Tf.g_s += 6 * f0, Tf.Ub += size_t(6 * f0) * ncb, Tf.Ubk += size_t(24) * f0, Tf.ybuf += 6 * f0, Tf.np -= 6 * f0;
     Tf.fj[0] = FactorJob{Tf.Sb, Tf.g_s, Tf.Ub, Tf.Ubk, Tf.ybuf, nullptr, Tf.np / 6, -1};
   }
   // short systems with window-wide bands (the sliding-window replay): every band tile in a register for the whole factorisation
-  const int n_eff = n_blk - f0;
-  const bool dense = !nt && !(T.debug_flags & 2097152) && T.bw > 14 && n_eff <= 2 * T.bw &&
-                     dense_factor_tiles(n_eff, std::min(T.bw, n_eff)) <= kDenseThreads * kDenseTiles;  // A/B switch 2097152: banded kernels
   if (dense) {
-    k_dense_factor<<<1, kDenseThreads, (size_t(12) * (ncb + 8) + 64) * sizeof(double), s>>>(Tf);
+    k_dense_factor<<<1 + f0, kDenseThreads, (size_t(12) * (ncb + 8) + 64) * sizeof(double), s>>>(Tf, f0);
   } else if (nt) {
     Tables T1 = Tf;
     // (the lower-band rows come from the reversed copy, whose rows are counted from the END of the matrix: no offset)
@@ -905,7 +911,7 @@ int launch_factor(hs_problem* p) {
     k_band_backward2<<<1, kCholThreads, 2 * size_t(T.np) * sizeof(double), s>>>(T, j0, j0, -1);
     k_step_outputs<<<1, kBlock, 0, s>>>(T);
   } else if (!(T.debug_flags & 65536)) {  // the four-wave LDS sweep (A/B switch 65536: single-wave register sweep)
-    k_band_backward<<<1, kCholThreads, 2 * size_t(T.np) * sizeof(double), s>>>(T);
+    k_band_backward<<<1, kCholThreads, 2 * size_t(T.np) * sizeof(double), s>>>(T, f0);
   } else {
     const BackJob j0{T.Ub, T.Ubk, T.ybuf, p->d_Vb.p, p->d_yt.p, T.np / 6, 0, 0};
     k_premultiply<<<T.np / 6, 128, 0, s>>>(T, j0, j0, T.np / 6);
@@ -926,13 +932,14 @@ int launch_update(hs_problem* p) {
     k_cost_inertial<K, 4><<<p->nb_ine, kInertialBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.bias_g_cand, T.bias_a_cand, T.gravity_cand,
                                                                         T.cand_part + p->nb_vis + p->nb_pri);
   const bool local_decision = !p->allreduce && !p->rccl_comm;  // single shard: decide in the packing kernel
-  k_pack_decision<<<1, kBlock, 0, s>>>(T, local_decision ? 1 : 0);
+  const bool inline_commit = local_decision && 8 * T.sp.n_cp + 3 * T.n_lm + 8 * T.n_bias <= kCommitInline && !(T.debug_flags & 16777216);  // A/B switch 16777216
+  k_pack_decision<<<1, kBlock, 0, s>>>(T, inline_commit ? 2 : local_decision ? 1 : 0);
   HIP_TRY(hipGetLastError());
   const int rc = exchange(p, T.xbuf + T.xo_dec, 5);  // candidate cost + norms + landmark-side model-cost terms
   if (rc) return rc;
   if (!local_decision) k_decide<<<1, 64, 0, s>>>(T);
   const int nb_commit = std::max((std::max(8 * T.sp.n_cp, 3 * T.n_lm) + kBlock - 1) / kBlock, 1);  // one element per lane
-  k_commit<<<nb_commit, kBlock, 0, s>>>(T);
+  if (!inline_commit) k_commit<<<nb_commit, kBlock, 0, s>>>(T);
   HIP_TRY(hipGetLastError());
   return HS_OK;
 }

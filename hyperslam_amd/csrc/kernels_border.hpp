@@ -154,7 +154,8 @@ __global__ void __launch_bounds__(kBlock) k_border_zero(Tables T) {
 }
 
 /// Scaling / damping of the border blocks after the exchange:  S_pb = Sp H_pb Sb,  S_bb = Sb H_bb Sb + D_b^2,  g_b = Sb g_b.
-__global__ void __launch_bounds__(kBlock) k_finalize_border(Tables T) {
+/// (n_splits = 0: H_pb was reduced into the exchange buffer by k_reduce_partials; > 0: summed here over the accumulation splits, same order)
+HSD void finalize_border_body(const Tables& T, const int wg, const int n_wg, const int n_splits) {
   DevState* st = T.st;
   if (st->done) return;
   const int nb = T.nb, np = T.np;
@@ -164,10 +165,16 @@ __global__ void __launch_bounds__(kBlock) k_finalize_border(Tables T) {
   auto sb_of = [&](int b) { return fresh ? 1.0 / (1.0 + sqrt(X[T.xo_bb + size_t(b) * nb + b])) : T.scale_b[b]; };
   auto sp_of = [&](int rho) { return fresh ? 1.0 / (1.0 + sqrt(X[T.xo_dj + rho])) : T.scale_p[rho]; };
   const int total = (np + nb) * nb;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+  for (int e = wg * blockDim.x + threadIdx.x; e < total; e += n_wg * blockDim.x) {
     const int row = e / nb, c = e % nb;
     if (row < np) {
-      T.Spb[e] = sp_of(row) * X[T.xo_pb + e] * sb_of(c);
+      double hpb = 0.0;
+      if (n_splits > 0) {
+        for (int k = 0; k < n_splits; ++k) hpb += T.xpart[size_t(k) * T.x_count1 + T.xo_pb + e];
+      } else {
+        hpb = X[T.xo_pb + e];
+      }
+      T.Spb[e] = sp_of(row) * hpb * sb_of(c);
     } else {
       const int b = row - np;
       const double sr = sb_of(b), sc = sb_of(c);
@@ -191,6 +198,8 @@ __global__ void __launch_bounds__(kBlock) k_finalize_border(Tables T) {
     }
   }
 }
+
+__global__ void __launch_bounds__(kBlock) k_finalize_border(Tables T) { finalize_border_body(T, blockIdx.x, gridDim.x, 0); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Bordered solve:  [S_pp S_pb; S_bp S_bb][x_p; x_b] = [g_p; g_b] with S_pp = U'U banded.

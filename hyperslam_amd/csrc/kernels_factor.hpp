@@ -1226,7 +1226,9 @@ __global__ void __launch_bounds__(kWideThreads) k_band_factor_wide(Tables T) {
 }
 
 /// Backward sweep U x = y (y in T.ybuf, possibly corrected by the border solve) + step outputs and model-cost reductions.
-__global__ void __launch_bounds__(kCholThreads) k_band_backward(Tables T) {
+/// The sweep stops above block row j_lo: the leading block rows of constant control points are decoupled with a zero right-hand side
+/// (k_factor_decoupled_rows), their part of the solution is zero (half of the block rows of a full sliding window).
+__global__ void __launch_bounds__(kCholThreads) k_band_backward(Tables T, int j_lo) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   DevState* st = T.st;
   if (st->done) return;
@@ -1237,7 +1239,7 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward(Tables T) {
   double* xs = smem;         // np : pending rows
   double* xout = xs + T.np;  // np : final x
   __shared__ double Wl[2][24];
-  for (int rho = tid; rho < T.np; rho += nthr) xs[rho] = T.ybuf[rho];
+  for (int rho = tid; rho < T.np; rho += nthr) xs[rho] = T.ybuf[rho], xout[rho] = 0.0;
   if (T.debug_flags & 1) return;  // timing experiments only (HS_DEBUG_FLAGS)
 
   // ---- backward solve U x = y, column oriented: once x_j is final every pending row above subtracts U[rho][x_j] ----
@@ -1261,7 +1263,7 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward(Tables T) {
   load_u(n_blk - 1, ua), load_u(n_blk - 2, ub), load_u(n_blk - 3, uc);
   wa = load_w(n_blk - 1), wb = load_w(n_blk - 2), wc = load_w(n_blk - 3);
   auto body = [&](int j, const double* u, double w, double* u_next, double* w_next) {
-    if (j < 0) return;
+    if (j < j_lo) return;
     if (tid < 21) Wl[j & 1][tid] = w;
     load_u(j - 3, u_next), *w_next = load_w(j - 3);
     lds_barrier();  // publishes Wl and the pending-row updates of the previous step
@@ -1287,7 +1289,7 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward(Tables T) {
       xs[6 * j - 1 - tid] -= sacc;
     }
   };
-  for (int j = n_blk - 1; j >= 0; j -= 4) {
+  for (int j = n_blk - 1; j >= j_lo; j -= 4) {
     body(j, ua, wa, ud, &wd);
     body(j - 1, ub, wb, ua, &wa);
     body(j - 2, uc, wc, ub, &wb);
@@ -1337,6 +1339,8 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward(Tables T) {
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kDenseThreads = 512, kDenseTiles = 2;
 
+HSD void factor_decoupled_row(const Tables& T, int i, int lane);
+
 /// Number of tile slots the dense kernel needs for n block rows of band width bw (band tiles + one right-hand-side tile per row).
 __host__ __device__ constexpr int dense_factor_tiles(int n, int bw) {
   int t = 0;
@@ -1344,11 +1348,17 @@ __host__ __device__ constexpr int dense_factor_tiles(int n, int bw) {
   return t;
 }
 
-__global__ void __launch_bounds__(kDenseThreads) k_dense_factor(Tables T) {
+/// Workgroups 1 .. n_decoupled (first wave only) write the decoupled leading block rows -n_decoupled .. -1 (factor_decoupled_row): their
+/// own launch in front of this kernel cost 6 us on the chain.
+__global__ void __launch_bounds__(kDenseThreads) k_dense_factor(Tables T, int n_decoupled) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   DevState* st = T.st;
   if (st->done) return;
   const int tid = threadIdx.x;
+  if (blockIdx.x > 0) {
+    if (tid < 64) factor_decoupled_row(T, int(blockIdx.x) - 1 - n_decoupled, tid);
+    return;
+  }
   const int bw = T.bw, ncb = 6 * bw, n = T.np / 6;
   const int ldx = ncb + 8;           // row stride of the X row in LDS: [6 x (bw tiles) | y]
   double* xrow = smem;               // 2 x 6 x ldx : X_k in band order (column 6 (j - k) + c), right-hand side at column ncb
@@ -1527,20 +1537,19 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense_factor(Tables T) {
 /// decoupled from everything — S_i,: = [D_i | 0] with the damping on the diagonal, g_i = 0. The factorisation kernels start behind
 /// them (pointer offsets at launch, the band storage is row relative); this kernel writes their part of the factor, one wave per block
 /// row: U_ii = chol(S_ii), the rest of the row zero, U_ii^-1, y_i = U_ii^-T g_i.
-__global__ void __launch_bounds__(64) k_factor_decoupled_rows(Tables T, int n_rows) {
-  if (T.st->done) return;
-  const int i = blockIdx.x, lane = threadIdx.x;  // one wave per block row: the lanes clear the row, lane 0 factors the 6 x 6 block
-  if (i >= n_rows) return;
-  const int ncb = 6 * T.bw;
+/// (one wave: the lanes clear block row i, lane 0 factors the 6 x 6 block. `i` may be negative: k_dense_factor runs on pointers that
+///  were moved past the decoupled rows and reaches back)
+HSD void factor_decoupled_row(const Tables& T, const int i, const int lane) {
+  const ptrdiff_t ncb = 6 * T.bw;
   for (int e = lane; e < 6 * ncb; e += 64)
-    if (e % ncb >= 6) T.Ub[size_t(6 * i) * ncb + e] = 0.0;
+    if (e % ncb >= 6) T.Ub[ptrdiff_t(6 * i) * ncb + e] = 0.0;
   if (lane != 0) return;
   double U[6][6], y[6];
   bool ok = true;
 #pragma unroll
   for (int a = 0; a < 6; ++a)
 #pragma unroll
-    for (int c = 0; c < 6; ++c) U[a][c] = c >= a ? T.Sb[size_t(6 * i + a) * ncb + c] : 0.0;
+    for (int c = 0; c < 6; ++c) U[a][c] = c >= a ? T.Sb[ptrdiff_t(6 * i + a) * ncb + c] : 0.0;
 #pragma unroll
   for (int a = 0; a < 6; ++a) {
     double d = U[a][a];
@@ -1566,7 +1575,7 @@ __global__ void __launch_bounds__(64) k_factor_decoupled_rows(Tables T, int n_ro
 #pragma unroll
   for (int a = 0; a < 6; ++a)
 #pragma unroll
-    for (int c = 0; c < 6; ++c) T.Ub[size_t(6 * i + a) * ncb + c] = U[a][c];  // (zero below the diagonal)
+    for (int c = 0; c < 6; ++c) T.Ub[ptrdiff_t(6 * i + a) * ncb + c] = U[a][c];  // (zero below the diagonal)
 #pragma unroll
   for (int c = 0; c < 6; ++c) {  // W = U_ii^-1, upper, packed like the factorisation kernels do
     double w[6];
@@ -1578,8 +1587,13 @@ __global__ void __launch_bounds__(64) k_factor_decoupled_rows(Tables T, int n_ro
       w[a] = a <= c ? t / U[a][a] : 0.0;
     }
 #pragma unroll
-    for (int a = 0; a <= c; ++a) T.Ubk[size_t(i) * 24 + (a * 6 - a * (a - 1) / 2 + (c - a))] = w[a];
+    for (int a = 0; a <= c; ++a) T.Ubk[ptrdiff_t(i) * 24 + (a * 6 - a * (a - 1) / 2 + (c - a))] = w[a];
   }
+}
+
+__global__ void __launch_bounds__(64) k_factor_decoupled_rows(Tables T, int n_rows) {
+  if (T.st->done) return;
+  if (int(blockIdx.x) < n_rows) factor_decoupled_row(T, blockIdx.x, threadIdx.x);
 }
 
 }  // namespace hs

@@ -8,11 +8,11 @@ namespace hs {
 /// this lane's W rows, forms V = S_l H_ll S_l + D_l^2 = L L', stores L, y-hat, the scaled gradient and the Y-hat rows.
 template <int PS>
 HSD void landmark_finish(const Tables& T, int dl, int lane, bool active, bool fresh, double radius, const double* sl_old, int yoff, int rows,
-                         const double* h, const double* b, double (*w)[3]) {
+                         const double* h, const double* b, double (*w)[3], bool lead = true) {
   double sl[3];
   if (fresh) {
     sl[0] = 1.0 / (1.0 + sqrt(h[0])), sl[1] = 1.0 / (1.0 + sqrt(h[3])), sl[2] = 1.0 / (1.0 + sqrt(h[5]));
-    if (lane < 3) T.lm_scale[3 * dl + lane] = sl[lane];
+    if (lane < 3 && lead) T.lm_scale[3 * dl + lane] = sl[lane];
   } else {
     sl[0] = sl_old[0], sl[1] = sl_old[1], sl[2] = sl_old[2];
   }
@@ -35,7 +35,7 @@ HSD void landmark_finish(const Tables& T, int dl, int lane, bool active, bool fr
   const double p22 = v22 - l20 * l20 - l21 * l21, i22 = rsqrt_refined(p22), l22 = p22 * i22;
   const double sb0 = sl[0] * b[0], sb1 = sl[1] * b[1], sb2 = sl[2] * b[2];
   const double y0 = sb0 * i00, y1 = (sb1 - l10 * y0) * i11, y2 = (sb2 - l20 * y0 - l21 * y1) * i22;
-  if (lane == 0) {
+  if (lane == 0 && lead) {  // (lead = false: a wave that only owns further rows of W, k_landmark_rows)
     double* L = T.lm_L + 6 * dl;
     L[0] = l00, L[1] = l10, L[2] = l11, L[3] = l20, L[4] = l21, L[5] = l22;
     T.lm_yhat[3 * dl] = active ? y0 : 0.0, T.lm_yhat[3 * dl + 1] = active ? y1 : 0.0, T.lm_yhat[3 * dl + 2] = active ? y2 : 0.0;
@@ -147,6 +147,79 @@ __global__ void __launch_bounds__(kBlock) k_landmark(Tables T) {
   const int dl = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (dl >= T.n_lm) return;
   landmark_eliminate<K, PS, U>(T, dl, threadIdx.x & 63);
+}
+
+/// Long feature tracks (sliding-window replay: a landmark is seen for up to 3 s, ~120 records, and couples up to ~33 control points):
+/// one WORKGROUP per landmark, wave p owns rows [64 p, 64 p + 64) of W. A record touches 6 K consecutive rows, i.e. one pass (two when
+/// it straddles a boundary): each wave walks only the records that touch its rows (ballot over the chunk), where k_landmark<K,4,1>
+/// walks every record in all four passes on one wave — the longest track sets the kernel time (60 us in the replay). The
+/// accumulation order per row is the same as there (records in table order), so the results are bit-identical. H_ll and b_l are
+/// accumulated by every wave (15 FMAs per 64 records); wave 0 stores the per-landmark outputs.
+template <int K, int U>
+__global__ void __launch_bounds__(kBlock) k_landmark_rows(Tables T) {
+  constexpr int REC = 8 + 12 * K;
+  if (T.st->done) return;
+  const int dl = blockIdx.x, lane = threadIdx.x & 63, pass = threadIdx.x >> 6;
+  const int q0 = T.lm_ptr[dl], q1 = T.lm_ptr[dl + 1];
+  const int c_first = T.lm_cfirst[dl], rows = 6 * T.lm_ncp[dl];
+  const int r0 = 64 * pass;
+  if (pass > 0 && r0 >= rows) return;
+  const bool fresh = !T.st->scaling_ready;
+  const double radius = T.st->radius;
+  const bool is_const = T.lm_const[dl];
+  const int yoff = T.lm_yoff[dl];
+  double sl_old[3] = {1.0, 1.0, 1.0};
+  if (!fresh) sl_old[0] = T.lm_scale[3 * dl], sl_old[1] = T.lm_scale[3 * dl + 1], sl_old[2] = T.lm_scale[3 * dl + 2];
+  double h[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+  double w[1][3] = {{0.0, 0.0, 0.0}};
+  const int rho = r0 + lane;
+  for (int base = q0; base < q1; base += 64) {
+    const int myq = min(base + lane, q1 - 1);
+    const bool mine = base + lane < q1;
+    const int my_first = T.v_first[myq], my_pos = T.v_pos[myq];
+    const double* myrec = T.v_rec + size_t(my_pos) * REC;
+    double own[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) own[e] = myrec[e];
+    const int my_off = 6 * (my_first - c_first);
+    unsigned long long todo = __ballot(mine && my_off < r0 + 64 && my_off + 6 * K > r0);  // records of this chunk that touch the wave's rows
+    while (todo) {
+      double ja[U], jb[U], jl[U][6];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool have = todo != 0;
+        const int t = have ? __builtin_ctzll(todo) : 0;
+        todo = have ? todo & (todo - 1) : 0;
+        const int ft = __builtin_amdgcn_readlane(my_first, t), pt = __builtin_amdgcn_readlane(my_pos, t);  // wave-uniform
+        const double* rec = T.v_rec + size_t(pt) * REC;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) jl[u][e] = rec[2 + e];
+        const int c = rho - 6 * (ft - c_first);
+        const bool ok = have && c >= 0 && c < 6 * K && rho < rows;
+        const int cc = ok ? c : 0;
+        const double va = rec[8 + cc], vb = rec[8 + 6 * K + cc];
+        ja[u] = ok ? va : 0.0, jb[u] = ok ? vb : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {  // masked slots add exact zeros
+        w[0][0] = fma(ja[u], jl[u][0], fma(jb[u], jl[u][3], w[0][0]));
+        w[0][1] = fma(ja[u], jl[u][1], fma(jb[u], jl[u][4], w[0][1]));
+        w[0][2] = fma(ja[u], jl[u][2], fma(jb[u], jl[u][5], w[0][2]));
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const double rr = mine ? own[r] : 0.0, j0 = mine ? own[2 + 3 * r] : 0.0, j1 = mine ? own[3 + 3 * r] : 0.0, j2 = mine ? own[4 + 3 * r] : 0.0;
+      h[0] = fma(j0, j0, h[0]), h[1] = fma(j0, j1, h[1]), h[2] = fma(j0, j2, h[2]);
+      h[3] = fma(j1, j1, h[3]), h[4] = fma(j1, j2, h[4]), h[5] = fma(j2, j2, h[5]);
+      b[0] = fma(j0, rr, b[0]), b[1] = fma(j1, rr, b[1]), b[2] = fma(j2, rr, b[2]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) h[i] = wave_sum(h[i]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) b[i] = wave_sum(b[i]);
+  landmark_finish<1>(T, dl, lane, (q1 > q0) && !is_const, fresh, radius, sl_old, yoff + 3 * r0, rows - r0, h, b, w, pass == 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -530,6 +603,7 @@ __global__ void __launch_bounds__(kBlock) k_reduce_partials(Tables T, int nsp, i
 }
 
 HSD void begin_iteration(const Tables& T, double cost, double gmax, bool set_scaling_ready);
+HSD void finalize_border_body(const Tables& T, int wg, int n_wg, int n_splits);  // kernels_border.hpp
 
 /// Local cost and landmark-side gradient max norm into the exchange buffer (slot per rank so that a SUM all-reduce
 /// delivers every rank's value to every rank). reduce_here (single shard, no border unknowns): nothing is exchanged, so the
@@ -552,6 +626,7 @@ HSD void pack_exchange_body(const Tables& T, int reduce_here) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) gm = fmax(gm, v[u]);
     }
+    for (int b = threadIdx.x; b < T.nb; b += blockDim.x) gm = fmax(gm, fabs(T.xbuf[T.xo_gb + b]));  // border unknowns (bias points, gravity)
   }
   s = block_sum(s, red);
   if (threadIdx.x == 0) T.xbuf[T.xo_cost] = s;
@@ -569,13 +644,17 @@ __global__ void __launch_bounds__(kBlock) k_pack_exchange(Tables T, int reduce_h
 
 /// After the (optional) all-reduce: Jacobi scaling (fixed at iteration 0), LM diagonal, inactive coordinates.
 ///   S = Sp Sraw Sp + D_p^2,  g = Sp (g_p + g_schur),  g_full = Sp g_p,  D_p^2 = clamp(Sp^2 diag(J'J), 1e-6, 1e32) / radius.
-/// A workgroup past the last block row (single shard without border unknowns: gridDim.x = n_cp + 1) does the work of
+/// A workgroup past the last block row (single shard: gridDim.x = n_cp + 1 [+ border workgroups]) does the work of
 /// k_pack_exchange + k_cost_reduce concurrently: with nothing exchanged, neither side reads what the other writes (the block
 /// rows use the radius and the scaling flag, which the bookkeeping leaves alone; `done` only makes them skip unused work).
-__global__ void __launch_bounds__(kBlock) k_finalize_reduced(Tables T) {
+__global__ void __launch_bounds__(kBlock) k_finalize_reduced(Tables T, int n_splits) {
   DevState* st = T.st;
   if (int(blockIdx.x) >= T.sp.n_cp) {
-    pack_exchange_body(T, 1);
+    const int extra = int(blockIdx.x) - T.sp.n_cp;
+    if (extra == 0)
+      pack_exchange_body(T, 1);
+    else  // border blocks of a single shard: H_pb straight from the accumulation splits (no k_reduce_partials in front)
+      finalize_border_body(T, extra - 1, int(gridDim.x) - T.sp.n_cp - 1, n_splits);
     return;
   }
   if (st->done) return;

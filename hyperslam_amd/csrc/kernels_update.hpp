@@ -179,6 +179,7 @@ HSD void begin_iteration(const Tables& T, double c, double gm, bool set_scaling_
 }
 
 HSD void decide_step(const Tables& T);
+HSD void commit_body(const Tables& T, int idx, int stride);
 
 /// Second exchange buffer (5 doubles, additive across shards): candidate cost, |x|^2, |x - x+|^2 and the landmark-side
 /// terms of the model cost change. The replicated control-point part of the norms is contributed by rank 0 only.
@@ -215,6 +216,12 @@ __global__ void __launch_bounds__(kBlock) k_pack_decision(Tables T, int decide_h
     double* D = T.xbuf + T.xo_dec;
     D[0] = cand, D[1] = xs, D[2] = ss, D[3] = gd, D[4] = dd;
     if (decide_here) decide_step(T);
+  }
+  if (decide_here == 2) {  // small problems: x <- candidate right here instead of a k_commit launch behind this one
+    __shared__ int accepted;  // (handed over in LDS: the other waves may hold the state's cache line from their `done` test)
+    if (threadIdx.x == 0) accepted = st->accepted;
+    __syncthreads();
+    if (accepted) commit_body(T, threadIdx.x, blockDim.x);
   }
 }
 
@@ -288,16 +295,20 @@ __global__ void __launch_bounds__(kBlock) k_decide(Tables T) {
 }
 
 /// x <- candidate when the step was accepted.
-__global__ void __launch_bounds__(kBlock) k_commit(Tables T) {
-  // note: reads `accepted` even when `done` was just set by a convergence test (those leave accepted = 0)
-  if (!T.st->accepted) return;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < 8 * T.sp.n_cp) T.cp[idx] = T.cp_cand[idx];
-  for (int l = idx; l < 3 * T.n_lm; l += gridDim.x * blockDim.x) T.lm[l] = T.lm_cand[l];
+HSD void commit_body(const Tables& T, const int idx, const int stride) {
+  for (int e = idx; e < 8 * T.sp.n_cp; e += stride) T.cp[e] = T.cp_cand[e];
+  for (int l = idx; l < 3 * T.n_lm; l += stride) T.lm[l] = T.lm_cand[l];
   if (T.nb > 0) {
-    for (int e = idx; e < 4 * T.n_bias; e += gridDim.x * blockDim.x) T.bias_g[e] = T.bias_g_cand[e], T.bias_a[e] = T.bias_a_cand[e];
+    for (int e = idx; e < 4 * T.n_bias; e += stride) T.bias_g[e] = T.bias_g_cand[e], T.bias_a[e] = T.bias_a_cand[e];
     if (idx < 3) T.gravity[idx] = T.gravity_cand[idx];
   }
+}
+
+constexpr int kCommitInline = 4096;  // elements copied by the decision kernel itself (16 per lane); larger problems launch k_commit
+
+__global__ void __launch_bounds__(kBlock) k_commit(Tables T) {
+  // note: reads `accepted` even when `done` was just set by a convergence test (those leave accepted = 0)
+  if (T.st->accepted) commit_body(T, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 }  // namespace hs

@@ -206,7 +206,7 @@ struct hs_problem {
   DBuf<int> d_gw_ptr, d_gw_cf, d_sw_ptr, d_sw_seg;
   int n_seg_wg = 0, n_group_wg = 0;
   DBuf<double> d_ybuf, d_scale_b, d_Spb, d_Sbb, d_gb_s, d_D2b, d_Zb, d_Cb, d_hb, d_xb, d_delta_b, d_bias_g_snap, d_bias_a_snap, d_gravity_snap;
-  DBuf<int> d_i_bias_ptr;
+  DBuf<int> d_i_bias_ptr, d_bfwd_start;
   int n_split = 1;
   int rank = 0, world = 1, min_bw = 0;
   DBuf<double> d_cp_snap, d_lm_snap;
@@ -409,6 +409,24 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_i_first_bias.upload(p->in_first_bias, s));
   HIP_TRY(p->d_i_seg_ptr.upload(p->in_seg_ptr, s));
   HIP_TRY(p->d_i_bias_ptr.upload(p->in_bias_ptr, s));
+  {  // k_border_forward: column b of S_pb is zero above the first pose block row its bias point (or gravity) meets a residual in
+    const int nbias = p->has_imu ? p->n_bias : 0, nbd_ = nbias ? 6 * nbias + 2 : 0;
+    const int n_wg = (nbd_ + kBorderCols - 1) / kBorderCols;
+    std::vector<int> start(std::max(n_wg, 1), 0);
+    for (int w = 0; w < n_wg; ++w) {
+      int first = p->n_cp;
+      for (int c = w * kBorderCols; c < std::min(nbd_, (w + 1) * kBorderCols); ++c) {
+        int rec = 0;  // gravity columns: the first inertial record
+        if (c < 6 * nbias) {
+          const int beta = (c < 3 * nbias ? c : c - 3 * nbias) / 3;
+          rec = p->in_bias_ptr[std::max(beta - p->kb + 1, 0)];  // first record whose bias segment reaches bias point beta
+        }
+        if (rec < n_ine) first = std::min(first, p->in_first[rec]);  // (records are segment-major: the earliest control point)
+      }
+      start[w] = first;
+    }
+    HIP_TRY(p->d_bfwd_start.upload(start, s));
+  }
   HIP_TRY(p->d_i_rec.reserve(size_t(n_ine) * (18 + 36 * k + 2 * p->kb) + 1));
   {
     std::vector<ImuParams> ip(1);
@@ -572,7 +590,7 @@ int prepare(hs_problem* p) {
     T.Sb2 = need ? p->d_Sb2.p : nullptr, T.g2 = need ? p->d_g2.p : nullptr;
   }
   T.scale_b = p->d_scale_b.p, T.Spb = p->d_Spb.p, T.Sbb = p->d_Sbb.p, T.gb_s = p->d_gb_s.p, T.D2b = p->d_D2b.p;
-  T.Zb = p->d_Zb.p, T.Cb = p->d_Cb.p, T.hb = p->d_hb.p, T.xb = p->d_xb.p, T.delta_b = p->d_delta_b.p, T.i_bias_ptr = p->d_i_bias_ptr.p;
+  T.Zb = p->d_Zb.p, T.Cb = p->d_Cb.p, T.hb = p->d_hb.p, T.xb = p->d_xb.p, T.delta_b = p->d_delta_b.p, T.i_bias_ptr = p->d_i_bias_ptr.p, T.bfwd_start = p->d_bfwd_start.p;
   T.x_count1 = x_count1, T.xo_dec = x_count1;
   T.rank = p->rank, T.world = p->world;
   // HS_DEBUG_FLAGS (measurement switches only, never needed for correct operation):
@@ -868,7 +886,7 @@ int launch_factor(hs_problem* p) {
   }
   // short systems with window-wide bands (the sliding-window replay): every band tile in a register for the whole factorisation
   if (dense) {
-    k_dense_factor<<<1 + f0, kDenseThreads, (size_t(12) * (ncb + 8) + 64) * sizeof(double), s>>>(Tf, f0);
+    k_dense_factor<<<1 + f0, kDenseThreads, (size_t(12) * (ncb + 8) + size_t(32) * n_eff) * sizeof(double), s>>>(Tf, f0);
   } else if (nt) {
     Tables T1 = Tf;
     // (the lower-band rows come from the reversed copy, whose rows are counted from the END of the matrix: no offset)
@@ -888,7 +906,7 @@ int launch_factor(hs_problem* p) {
     k_band_factor_wide<<<1, kWideThreads, size_t(12) * (ncb + 2) * sizeof(double), s>>>(Tf);
   if (T.nb) {  // bordered system (bias splines + gravity)
     const int fwd_threads = std::max(128, 64 * ((6 * (T.bw - 1) + 63) / 64));  // one lane per pending row
-    k_border_forward<<<(T.nb + kBorderCols - 1) / kBorderCols, fwd_threads, size_t(T.np) * kBorderLd * sizeof(double), s>>>(T);
+    k_border_forward<<<(T.nb + kBorderCols - 1) / kBorderCols, fwd_threads, size_t(T.np) * kBorderLd * sizeof(double), s>>>(T, f0);
     const int nt = (T.nb + kSchurTile - 1) / kSchurTile;
     k_border_schur<<<dim3(nt, nt), kBlock, 0, s>>>(T);
     if (T.nb + 1 <= 128 && !(T.debug_flags & 524288)) {  // trailing matrix in registers (A/B switch 524288: the LDS version)

@@ -211,12 +211,16 @@ constexpr int kBorderCols = 8;  // right-hand sides per workgroup in the forward
 constexpr int kBorderLd = 10;   // LDS row stride of the pending rows (doubles): 64-byte rows put every fourth lane on the same banks (16-way
                                 // conflict on the row read-modify-write of every step); 80 bytes keeps 16-byte alignment and spreads them
 
-__global__ void __launch_bounds__(kBlock) k_border_forward(Tables T) {  // blockDim = 64 x waves covering the 6 (bw - 1) pending rows (>= 128)
+/// The sweep of a workgroup starts at block row m0: rows above it are zero in its columns of S_pb, hence in Z — the rows of the leading
+/// constant control points (j_lo, decoupled: k_factor_decoupled_rows) and the rows before the first residual that involves the
+/// workgroup's bias points (T.bfwd_start: a bias point meets the pose rows of its own few seconds only).
+__global__ void __launch_bounds__(kBlock) k_border_forward(Tables T, int j_lo) {  // blockDim = 64 x waves covering the 6 (bw - 1) pending rows (>= 128)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (T.st->done) return;
   const int tid = threadIdx.x;
   const int bw = T.bw, ncb = 6 * bw, nb = T.nb, np = T.np, n_blk = np / 6;
   const int c0 = blockIdx.x * kBorderCols, ncols = min(kBorderCols, nb - c0);
+  const int m0 = min(max(j_lo, T.bfwd_start[blockIdx.x]), n_blk - 1);
   double* z = smem;  // np x kBorderLd: pending right-hand side rows, overwritten by the solution
   for (int e = tid; e < np * kBorderCols; e += blockDim.x) {
     const int rho = e / kBorderCols, c = e % kBorderCols;
@@ -253,17 +257,17 @@ __global__ void __launch_bounds__(kBlock) k_border_forward(Tables T) {  // block
       z[(6 * m + da) * kBorderLd + dc] = v;  // (LDS operations of a wave are in order: every lane has read s_m before this store)
     }
   };
-  {  // z_0
+  {  // z_m0
     double w0[6];
-    const double* W = T.Ubk;
+    const double* W = T.Ubk + size_t(m0) * 24;
 #pragma unroll
     for (int k = 0; k < 6; ++k) w0[k] = W[k <= da ? k * 6 - k * (k - 1) / 2 + (da - k) : 0];
-    if (tid < 64) diag_solve(0, w0);
+    if (tid < 64) diag_solve(m0, w0);
   }
 #pragma unroll
-  for (int d = 0; d < D; ++d) request(d, ur[d], wr[d]);
+  for (int d = 0; d < D; ++d) request(m0 + d, ur[d], wr[d]);
   __syncthreads();
-  for (int mb = 0; mb < n_blk; mb += D) {
+  for (int mb = m0; mb < n_blk; mb += D) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       const int m = mb + d;

@@ -1362,9 +1362,15 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense_factor(Tables T, int n_
   const int bw = T.bw, ncb = 6 * bw, n = T.np / 6;
   const int ldx = ncb + 8;           // row stride of the X row in LDS: [6 x (bw tiles) | y]
   double* xrow = smem;               // 2 x 6 x ldx : X_k in band order (column 6 (j - k) + c), right-hand side at column ncb
-  double* dscr = smem + 12 * ldx;    // 2 x 32 : U_kk (upper, packed, 21) and 1 / diag (6), published by the owner of the diagonal tile
+  double* dscr = smem + 12 * ldx;    // n x 32 : U_kk (upper, packed, 21) and 1 / diag (6), published by the owner of the diagonal tile
   __shared__ int fail;
   if (tid == 0) fail = 0;
+  // HS_DEBUG_FLAGS 16: phase timestamps (100 MHz clock) -> hs_debug_read, tools/dense_phase_timing.py. Per block row k (8 slots):
+  // [0] barrier after A, [1] barrier after B (thread 0); [2] row owner (k, k + 1): solve done, [3] stores issued; diagonal owner
+  // (k + 1, k + 1): [4] update done, [5] factorised and published
+  const bool prof = T.debug_flags & 16;
+  long long* tlog = reinterpret_cast<long long*>(T.xpart) + 8 * 300;
+  if (prof && tid == 0) tlog[-1] = wall_clock64();
   // ---- static tile ownership: slot t = tid + 512 m -> (i, j), row major over rows i with columns j = i .. min(i + bw, n) - 1 and
   //      the right-hand-side column (encoded as j = n) ----
   int ti[kDenseTiles], tj[kDenseTiles];
@@ -1396,12 +1402,14 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense_factor(Tables T, int n_
       }
     }
   }
+  for (int e = tid; e < 12 * ldx; e += kDenseThreads) xrow[e] = 0.0;  // (the pad columns behind y stay zero: a right-hand-side tile is
+                                                                      //  an ordinary tile whose columns 1 .. 5 are zero)
   __syncthreads();
 #define UIDX(a, c) ((a) * 6 - (a) * ((a)-1) / 2 + ((c) - (a)))
   // X rows and the published U_kk are double buffered by k & 1: the owner of (k + 1, k + 1) factors its tile at the end of its part of
   // update k (nothing else depends on that lane), while the other lanes still read X_k
-  auto factor_diagonal = [&](double (&t)[36], int k) {  // in place; publishes U_kk, 1 / diag, the diagonal tile of X_k, U_kk^-1
-    double* ub = dscr + 32 * (k & 1);
+  auto factor_diagonal = [&](double (&t)[36], int k) {  // in place; publishes U_kk, 1 / diag and the diagonal tile of X_k
+    double* ub = dscr + 32 * k;
     double* xr = xrow + (k & 1) * 6 * ldx;
     double dmin = 1.0;
 #pragma unroll
@@ -1425,27 +1433,16 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense_factor(Tables T, int n_
     }
     if (!(dmin > 0.0)) fail = 1;
 #pragma unroll
-    for (int a = 0; a < 6; ++a)
+    for (int a = 0; a < 6; ++a) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
-        const double v = c >= a ? t[6 * a + c] : 0.0;
-        if (c >= a) ub[UIDX(a, c)] = v;
-        xr[a * ldx + c] = v;
-        T.Ub[size_t(6 * k + a) * ncb + c] = v;
+        if (c < a) t[6 * a + c] = 0.0;
+        if (c >= a) ub[UIDX(a, c)] = t[6 * a + c];
       }
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {  // W = U_kk^-1 (upper, packed)
-      double w[6];
-#pragma unroll
-      for (int a = 5; a >= 0; --a) {
-        double v = a == c ? 1.0 : 0.0;
-#pragma unroll
-        for (int q = a + 1; q < 6; ++q) v = fma(-t[6 * a + q], w[q], v);
-        w[a] = v * ub[21 + a];  // (own LDS stores: in order within the wave)
+      for (int c = 0; c < 6; c += 2) {  // (rows are 16-byte aligned: ldx and ncb are even)
+        *reinterpret_cast<double2*>(xr + a * ldx + c) = make_double2(t[6 * a + c], t[6 * a + c + 1]);
       }
-#pragma unroll
-      for (int a = 0; a < 6; ++a)
-        if (a <= c) T.Ubk[size_t(k) * 24 + UIDX(a, c)] = w[a];
     }
   };
 #pragma unroll
@@ -1453,15 +1450,14 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense_factor(Tables T, int n_
     if (ti[m] == 0 && tj[m] == 0) factor_diagonal(acc[m], 0);
   lds_barrier();
   for (int k = 0; k < n; ++k) {
-    const double* ubuf = dscr + 32 * (k & 1);
+    const double* ubuf = dscr + 32 * k;
     double* xk = xrow + (k & 1) * 6 * ldx;
     // ---- A: the owners of row k other than the diagonal one solve their tile in place, X(k, j) = U_kk^-T S(k, j); U_kk is read from
     //      LDS (uniform addresses: broadcast), so the only registers involved are the tile's own ----
 #pragma unroll
     for (int m = 0; m < kDenseTiles; ++m) {
       if (ti[m] != k || tj[m] == k) continue;
-      const bool rhs = tj[m] == n;
-      const int col0 = rhs ? ncb : 6 * (tj[m] - k);
+      const int col0 = tj[m] == n ? ncb : 6 * (tj[m] - k);  // (right-hand side: column ncb, its zero columns land in the pad)
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
         const double ia = ubuf[21 + a];
@@ -1473,21 +1469,16 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense_factor(Tables T, int n_
           acc[m][6 * a + c] = t * ia;
         }
       }
+      if (prof && tj[m] == k + 1) tlog[8 * k + 2] = wall_clock64();
 #pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        if (rhs) {
-          xk[a * ldx + ncb] = acc[m][6 * a];
-          T.ybuf[6 * k + a] = acc[m][6 * a];
-        } else {
+      for (int a = 0; a < 6; ++a)
 #pragma unroll
-          for (int c = 0; c < 6; ++c) {
-            xk[a * ldx + col0 + c] = acc[m][6 * a + c];
-            T.Ub[size_t(6 * k + a) * ncb + col0 + c] = acc[m][6 * a + c];
-          }
-        }
-      }
+        for (int c = 0; c < 6; c += 2)
+          *reinterpret_cast<double2*>(xk + a * ldx + col0 + c) = make_double2(acc[m][6 * a + c], acc[m][6 * a + c + 1]);
+      if (prof && tj[m] == k + 1) tlog[8 * k + 3] = wall_clock64();
     }
     lds_barrier();
+    if (prof && tid == 0) tlog[8 * k] = wall_clock64();
     // ---- B: trailing update ----
     {  // band columns past the end of the matrix: zero in the factor row (the sweeps read whole rows); all lanes share the stores
       const int used = 6 * (n - k < bw ? n - k : bw), nz = ncb - used;
@@ -1500,33 +1491,69 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense_factor(Tables T, int n_
       if (j != n && j - k >= bw) continue;      // (inside the band of row i but beyond the band of row k: untouched by X_k)
       const double* A = xk + 6 * (i - k);
       const double* B = xk + (j == n ? ncb : 6 * (j - k));
+      // (one code path for band, diagonal and right-hand-side tiles: lanes of a wave that own different kinds would otherwise run the
+      //  216 FMAs once per kind — measured 1.76 us for this loop with three kinds, tools/dense_phase_timing.py)
 #pragma unroll 2  // (fully unrolled, the scheduler hoists all 36 operand loads above the FMAs: 144 more live registers -> scratch)
       for (int q = 0; q < 6; ++q) {
         double av[6], bv[6];
 #pragma unroll
         for (int a = 0; a < 6; a += 2) {
-          const double2 t = *reinterpret_cast<const double2*>(A + q * ldx + a);
-          av[a] = t.x, av[a + 1] = t.y;
-        }
-        if (j == n) {
-          bv[0] = B[q * ldx];
-#pragma unroll
-          for (int c = 1; c < 6; ++c) bv[c] = 0.0;
-        } else {
-#pragma unroll
-          for (int c = 0; c < 6; c += 2) {
-            const double2 t = *reinterpret_cast<const double2*>(B + q * ldx + c);
-            bv[c] = t.x, bv[c + 1] = t.y;
-          }
+          const double2 ta = *reinterpret_cast<const double2*>(A + q * ldx + a);
+          const double2 tb = *reinterpret_cast<const double2*>(B + q * ldx + a);
+          av[a] = ta.x, av[a + 1] = ta.y, bv[a] = tb.x, bv[a + 1] = tb.y;
         }
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
           for (int c = 0; c < 6; ++c) acc[m][6 * a + c] = fma(-av[a], bv[c], acc[m][6 * a + c]);
       }
-      if (i == k + 1 && j == k + 1) factor_diagonal(acc[m], k + 1);  // (the next pivot: its tile is final now)
+      if (i == k + 1 && j == k + 1) {  // (the next pivot: its tile is final now)
+        if (prof) tlog[8 * k + 4] = wall_clock64();
+        factor_diagonal(acc[m], k + 1);
+        if (prof) tlog[8 * k + 5] = wall_clock64();
+      }
     }
     lds_barrier();
+    if (prof && tid == 0) tlog[8 * k + 1] = wall_clock64();
+  }
+  // ---- the factor: every tile is still in the registers of its owner (X(i, j), U_ii with a zero lower triangle, y_i in column 0 of the
+  //      right-hand-side tiles). Stored here, off the chain: inside the steps the 18 + 18 stores of a row owner took 0.8 us ----
+#pragma unroll
+  for (int m = 0; m < kDenseTiles; ++m) {
+    const int i = ti[m], j = tj[m];
+    if (i < 0) continue;
+    if (j == n) {
+#pragma unroll
+      for (int a = 0; a < 6; ++a) T.ybuf[6 * i + a] = acc[m][6 * a];
+    } else {
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c = 0; c < 6; c += 2)
+          *reinterpret_cast<double2*>(T.Ub + size_t(6 * i + a) * ncb + 6 * (j - i) + c) = make_double2(acc[m][6 * a + c], acc[m][6 * a + c + 1]);
+    }
+  }
+  // ---- U_kk^-1 (upper, packed; operand of the backward sweep) for every block row at once, one lane each: on the chain it cost
+  //      ~0.3 us per block row in the lane that owns the next pivot ----
+  for (int k = tid; k < n; k += kDenseThreads) {
+    const double* ub = dscr + 32 * k;
+    double u[21];
+#pragma unroll
+    for (int e = 0; e < 21; ++e) u[e] = ub[e];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      double w[6];
+#pragma unroll
+      for (int a = 5; a >= 0; --a) {
+        double v = a == c ? 1.0 : 0.0;
+#pragma unroll
+        for (int q = a + 1; q < 6; ++q) v = fma(-u[UIDX(a, q)], w[q], v);
+        w[a] = a <= c ? v * ub[21 + a] : 0.0;
+      }
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+        if (a <= c) T.Ubk[size_t(k) * 24 + UIDX(a, c)] = w[a];
+    }
   }
 #undef UIDX
   if (tid == 0 && fail) st->chol_failed = 1;

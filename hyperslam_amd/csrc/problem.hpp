@@ -181,6 +181,7 @@ struct Tables {
   double* xb;              // nb        border solution
   double* delta_b;         // nb        unscaled border step
   const int* i_bias_ptr;   // n_bias + 1: first inertial record with first_bias >= f
+  const int* bfwd_start;   // per workgroup of k_border_forward: first block row in which one of its border columns is non-zero
   // reductions
   double* cost_part;       // per-block cost partial sums (current point)
   double* cand_part;       // per-block cost partial sums (candidate point)

@@ -5,6 +5,7 @@
 // at 20 Hz through the EuRoC cameras (settings.yaml:20-72), optional IMU at 200 Hz, one optimize() per separation of data exactly
 // as AbstractOptimizer::submit drives it (abstract.cpp:74-147).  Prints one JSON line.
 //   usage: replay [seconds=6] [imu=0|1] [order=4] [estimation.hyper]   (4th argument: write the 100 Hz trajectory dump of main.cpp:52-80)
+#include <algorithm>
 #include <chrono>
 #include <cstring>
 
@@ -23,12 +24,14 @@ int main(int argc, char** argv) {
   double total_solve_ms = 0, max_solve_ms = 0, stage_ms[4] = {0, 0, 0, 0};
   long total_blocks = 0;
   int solves_seen = 0;
+  std::vector<double> solve_ms;  // per optimize(): the median and the full-window mean do not see the one-off first-launch cost
   const auto wall0 = std::chrono::steady_clock::now();
   feed_stream(optimizer, cams, seconds, with_imu, [&] {
     if (optimizer.numOptimizations() > solves_seen) {
       solves_seen = optimizer.numOptimizations();
       const hs_summary& s = optimizer.lastSummary();
       total_solve_ms += s.total_ms, max_solve_ms = std::max(max_solve_ms, s.total_ms);
+      solve_ms.push_back(s.total_ms);
       total_blocks += long(s.num_residual_blocks) * s.num_iterations;
       stage_ms[0] += s.linearize_ms, stage_ms[1] += s.schur_ms, stage_ms[2] += s.solve_ms, stage_ms[3] += s.update_ms;
       if (std::getenv("HS_REPLAY_TRACE"))
@@ -50,13 +53,22 @@ int main(int argc, char** argv) {
     se += (e[0] - g[0]) * (e[0] - g[0]) + (e[1] - g[1]) * (e[1] - g[1]) + (e[2] - g[2]) * (e[2] - g[2]);
     ++n;
   }
+  // steady state: the second half of the calls (full 3 s windows, everything loaded)
+  double steady = 0, median = 0;
+  if (!solve_ms.empty()) {
+    const size_t h = solve_ms.size() / 2;
+    for (size_t i = h; i < solve_ms.size(); ++i) steady += solve_ms[i] / double(solve_ms.size() - h);
+    std::vector<double> sorted = solve_ms;
+    std::sort(sorted.begin(), sorted.end());
+    median = sorted[sorted.size() / 2];
+  }
   std::printf("{\"replay_seconds\": %.2f, \"imu\": %d, \"order\": %d, \"optimizations\": %d, \"control_points\": %zu, \"landmarks\": %zu, "
-              "\"mean_solve_ms\": %.4f, \"max_solve_ms\": %.4f, \"residual_blocks_per_s_in_solve\": %.1f, \"wall_ms\": %.1f, "
+              "\"mean_solve_ms\": %.4f, \"median_solve_ms\": %.4f, \"full_window_mean_solve_ms\": %.4f, \"max_solve_ms\": %.4f, \"residual_blocks_per_s_in_solve\": %.1f, \"wall_ms\": %.1f, "
               "\"window\": [%.2f, %.2f], \"state_range\": [%.6f, %.6f], \"position_rmse_m\": %.4f, \"last_cost\": [%.6g, %.6g], "
               "\"mean_stage_ms\": {\"linearize\": %.4f, \"schur\": %.4f, \"solve\": %.4f, \"update\": %.4f}, "
               "\"mean_host_wall_ms\": {\"tables\": %.4f, \"hs_solve\": %.4f, \"readback\": %.4f}}\n",
               seconds, int(with_imu), opt.order, optimizer.numOptimizations(), optimizer.numControlPoints(), optimizer.numLandmarks(),
-              total_solve_ms / std::max(1, solves_seen), max_solve_ms, total_solve_ms > 0 ? 1e3 * total_blocks / total_solve_ms : 0.0, wall_ms,
+              total_solve_ms / std::max(1, solves_seen), median, steady, max_solve_ms, total_solve_ms > 0 ? 1e3 * total_blocks / total_solve_ms : 0.0, wall_ms,
               optimizer.window().lower, optimizer.window().upper, optimizer.stateRange().lower, optimizer.stateRange().upper, std::sqrt(se / std::max(1, n)), optimizer.lastSummary().initial_cost,
               optimizer.lastSummary().final_cost, stage_ms[0] / std::max(1, solves_seen), stage_ms[1] / std::max(1, solves_seen),
               stage_ms[2] / std::max(1, solves_seen), stage_ms[3] / std::max(1, solves_seen), optimizer.wallSplitMs()[0] / std::max(1, solves_seen),

@@ -878,7 +878,7 @@ int launch_factor(hs_problem* p) {
   Tables Tf = T;
   const int n_eff = n_blk - f0;
   const bool dense = !nt && !(T.debug_flags & 2097152) && T.bw > 14 && n_eff <= 2 * T.bw &&
-                     dense_factor_tiles(n_eff, std::min(T.bw, n_eff)) <= kDenseThreads * kDenseTiles;  // A/B switch 2097152: banded kernels
+                     dense_factor_fits(n_eff, std::min(T.bw, n_eff));  // A/B switch 2097152: banded kernels
   if (f0 > 0) {
     if (!dense) k_factor_decoupled_rows<<<f0, 64, 0, s>>>(T, f0);  // (the dense kernel writes them with extra workgroups of its own launch)
     Tf.Sb += size_t(6 * f0) * ncb, Tf.g_s += 6 * f0, Tf.Ub += size_t(6 * f0) * ncb, Tf.Ubk += size_t(24) * f0, Tf.ybuf += 6 * f0, Tf.np -= 6 * f0;

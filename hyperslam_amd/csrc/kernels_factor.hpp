@@ -1338,14 +1338,19 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward(Tables T, int j_
 // Same outputs as the other factorisation kernels (Ub in band storage, U_ii^-1 packed, y = U^-T g).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kDenseThreads = 512, kDenseTiles = 2;
+constexpr int kDenseBand = kDenseThreads - 64;  // lanes that own band / right-hand-side tiles; the last wave owns the diagonal tiles
 
 HSD void factor_decoupled_row(const Tables& T, int i, int lane);
 
-/// Number of tile slots the dense kernel needs for n block rows of band width bw (band tiles + one right-hand-side tile per row).
+/// Number of tile slots the dense kernel needs in its band lanes for n block rows of band width bw (off-diagonal band tiles + one
+/// right-hand-side tile per row; the n diagonal tiles live in the last wave).
 __host__ __device__ constexpr int dense_factor_tiles(int n, int bw) {
   int t = 0;
-  for (int i = 0; i < n; ++i) t += (n - i < bw ? n - i : bw) + 1;
+  for (int i = 0; i < n; ++i) t += (n - i < bw ? n - i : bw);
   return t;
+}
+__host__ __device__ constexpr bool dense_factor_fits(int n, int bw) {
+  return n <= 64 * kDenseTiles && dense_factor_tiles(n, bw) <= kDenseBand * kDenseTiles;
 }
 
 /// Workgroups 1 .. n_decoupled (first wave only) write the decoupled leading block rows -n_decoupled .. -1 (factor_decoupled_row): their
@@ -1378,14 +1383,19 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense_factor(Tables T, int n_
 #pragma unroll
   for (int m = 0; m < kDenseTiles; ++m) {
     ti[m] = -1, tj[m] = -1;
-    int rem = tid + m * kDenseThreads;
-    for (int i = 0; i < n; ++i) {
-      const int cnt = (n - i < bw ? n - i : bw) + 1;
-      if (rem < cnt) {
-        ti[m] = i, tj[m] = rem == cnt - 1 ? n : i + rem;
-        break;
+    if (tid >= kDenseBand) {  // diagonal tiles: one wave of their own (its code path is the next pivot's: half the operands, no other kind)
+      const int i = tid - kDenseBand + 64 * m;
+      if (i < n) ti[m] = tj[m] = i;
+    } else {
+      int rem = tid + m * kDenseBand;
+      for (int i = 0; i < n; ++i) {
+        const int cnt = n - i < bw ? n - i : bw;  // columns i + 1 .. i + cnt - 1 and the right-hand side
+        if (rem < cnt) {
+          ti[m] = i, tj[m] = rem == cnt - 1 ? n : i + 1 + rem;
+          break;
+        }
+        rem -= cnt;
       }
-      rem -= cnt;
     }
 #pragma unroll
     for (int e = 0; e < 36; ++e) acc[m][e] = 0.0;
@@ -1480,14 +1490,40 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense_factor(Tables T, int n_
     lds_barrier();
     if (prof && tid == 0) tlog[8 * k] = wall_clock64();
     // ---- B: trailing update ----
-    {  // band columns past the end of the matrix: zero in the factor row (the sweeps read whole rows); all lanes share the stores
+    if (tid >= kDenseBand) {
+      // diagonal tiles: S(i, i) -= X(k, i)' X(k, i), upper triangle (18 operand loads, 126 FMAs); the owner of the next pivot factors it
+#pragma unroll
+      for (int m = 0; m < kDenseTiles; ++m) {
+        const int i = ti[m];
+        if (i <= k || i - k >= bw) continue;
+        const double* A = xk + 6 * (i - k);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          double av[6];
+#pragma unroll
+          for (int a = 0; a < 6; a += 2) {
+            const double2 ta = *reinterpret_cast<const double2*>(A + q * ldx + a);
+            av[a] = ta.x, av[a + 1] = ta.y;
+          }
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int c = a; c < 6; ++c) acc[m][6 * a + c] = fma(-av[a], av[c], acc[m][6 * a + c]);
+        }
+        if (i == k + 1) {  // (the next pivot: its tile is final now)
+          if (prof) tlog[8 * k + 4] = wall_clock64();
+          factor_diagonal(acc[m], k + 1);
+          if (prof) tlog[8 * k + 5] = wall_clock64();
+        }
+      }
+    } else {  // band columns past the end of the matrix: zero in the factor row (the sweeps read whole rows); the band lanes share the stores
       const int used = 6 * (n - k < bw ? n - k : bw), nz = ncb - used;
-      for (int e = tid; e < 6 * nz; e += kDenseThreads) T.Ub[size_t(6 * k + e / nz) * ncb + used + e % nz] = 0.0;
+      for (int e = tid; e < 6 * nz; e += kDenseBand) T.Ub[size_t(6 * k + e / nz) * ncb + used + e % nz] = 0.0;
     }
 #pragma unroll
     for (int m = 0; m < kDenseTiles; ++m) {
       const int i = ti[m], j = tj[m];
-      if (i <= k || i - k >= bw) continue;      // finished rows; rows X_k does not reach
+      if (tid >= kDenseBand || i <= k || i - k >= bw) continue;  // diagonal wave; finished rows; rows X_k does not reach
       if (j != n && j - k >= bw) continue;      // (inside the band of row i but beyond the band of row k: untouched by X_k)
       const double* A = xk + 6 * (i - k);
       const double* B = xk + (j == n ? ncb : 6 * (j - k));
@@ -1506,11 +1542,6 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense_factor(Tables T, int n_
         for (int a = 0; a < 6; ++a)
 #pragma unroll
           for (int c = 0; c < 6; ++c) acc[m][6 * a + c] = fma(-av[a], bv[c], acc[m][6 * a + c]);
-      }
-      if (i == k + 1 && j == k + 1) {  // (the next pivot: its tile is final now)
-        if (prof) tlog[8 * k + 4] = wall_clock64();
-        factor_diagonal(acc[m], k + 1);
-        if (prof) tlog[8 * k + 5] = wall_clock64();
       }
     }
     lds_barrier();

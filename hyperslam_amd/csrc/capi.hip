@@ -10,6 +10,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -175,6 +176,13 @@ struct hs_problem {
   std::vector<double> weights[4];                // hs_set_weights: CostConfiguration::weights per factor type (empty: none)
   bool has_weights() const { return !weights[0].empty() || !weights[1].empty() || !weights[2].empty() || !weights[3].empty(); }
   UploadBatch batch;                             // table uploads of prepare()
+  bool host_timing = false;                      // HS_HOST_TIMING=1: host wall-clock split of prepare() / hs_solve, printed by hs_destroy
+  double host_ms[5] = {0, 0, 0, 0, 0};           // structure + table assembly, uploads, launches, wait for the device, (spare)
+  int host_calls = 0;
+  std::vector<double> host_log;                  // the same four numbers per call
+  double host_prepare[2] = {0, 0};               // (prepare() of the running call)
+  int zeroed_np = -1, zeroed_ncb = -1;           // layout / allocations for which the never-written parts of Sb2, Vb, yt were zeroed
+  const void* zeroed_ptr[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 
   // structure
   VisualStructure vs;
@@ -256,6 +264,7 @@ int prepare(hs_problem* p) {
       b->segs.clear(), b->used = 0;  // (no-op after a flush; drops the pending segments of a failed prepare)
     }
   } batch_scope(&p->batch);
+  const auto host_t0 = std::chrono::steady_clock::now();
   if (p->n_cp == 0) HS_FAIL(HS_ERR_STATE, "hs_set_spline has not been called");
   if (p->k != 4 && p->k != 6) HS_FAIL(HS_ERR_INVALID, "device kernels are instantiated for spline order 4 and 6");
   HIP_TRY(hipSetDevice(p->device));
@@ -360,6 +369,7 @@ int prepare(hs_problem* p) {
   }
 
   // ---- upload ----
+  const auto host_t1 = std::chrono::steady_clock::now();
   HIP_TRY(p->d_cp.upload(p->cp, s));
   HIP_TRY(p->d_cp_cand.reserve(p->cp.size()));
   HIP_TRY(p->d_cp_const.upload(p->cp_const, s));
@@ -378,8 +388,7 @@ int prepare(hs_problem* p) {
   const size_t nl = size_t(std::max(p->n_lm, 1));
   {
     std::vector<double> ones(3 * nl, 1.0);  // unobserved landmarks keep scale 1 (never visited by the landmark pass)
-    HIP_TRY(p->d_lm_scale.upload(ones, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(p->d_lm_scale.upload(ones, s));  // (copied into the staging arena right here: the vector may go)
   }
   HIP_TRY(p->d_lm_L.reserve(6 * nl));
   HIP_TRY(p->d_lm_yhat.reserve(3 * nl));
@@ -433,10 +442,8 @@ int prepare(hs_problem* p) {
     std::memcpy(ip[0].T_bs, p->imu_T_bs, 56), std::memcpy(ip[0].i_g, p->imu_i_g, 48), std::memcpy(ip[0].i_a, p->imu_i_a, 48);
     std::memcpy(ip[0].S_g, p->imu_S_g, 72), std::memcpy(ip[0].X_a, p->imu_X_a, 72);
     HIP_TRY(p->d_imu.upload(ip, s));
-    HIP_TRY(hipStreamSynchronize(s));
     std::vector<double> grav(p->gravity, p->gravity + 3);
     HIP_TRY(p->d_gravity.upload(grav, s));
-    HIP_TRY(hipStreamSynchronize(s));
   }
   HIP_TRY(p->d_gravity_cand.reserve(3));
   HIP_TRY(p->d_bias_g.upload(p->bias_g, s));
@@ -480,24 +487,22 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_xbuf.reserve(size_t(x_count1) + 8));
   HIP_TRY(p->d_gravity_part.reserve(size_t(5) * std::max(p->n_bias, 1)));
   {
-    const size_t cap0 = p->d_Sb2.cap;
-    HIP_TRY(p->d_Sb2.reserve(size_t(np) * ncb));
-    // entries past the end of the matrix are never written: zero once per allocation / layout
-    (void)cap0;
-    HIP_TRY(hipMemsetAsync(p->d_Sb2.p, 0, p->d_Sb2.cap * sizeof(double), s));
+    // Entries of the reversed copy past the end of the matrix are never written, the pads behind Vb / yt (operands of rows that do not
+    // exist, k_band_backward_w) neither: they are zeroed once per allocation and layout — a sliding window keeps both from one
+    // optimize() to the next, and five memsets per prepare() cost more host time than the structure tables.
+    const size_t nv = size_t(np) * ncb, pad = 64;
+    HIP_TRY(p->d_Sb2.reserve(nv));
+    for (DBuf<double>* b : {&p->d_Vb, &p->d_Vb2}) HIP_TRY(b->reserve(nv + pad));
+    for (DBuf<double>* b : {&p->d_yt, &p->d_yt2}) HIP_TRY(b->reserve(size_t(np) + pad));
+    const void* now[5] = {p->d_Sb2.p, p->d_Vb.p, p->d_Vb2.p, p->d_yt.p, p->d_yt2.p};
+    if (p->zeroed_np != np || p->zeroed_ncb != ncb || std::memcmp(now, p->zeroed_ptr, sizeof(now)) != 0) {
+      HIP_TRY(hipMemsetAsync(p->d_Sb2.p, 0, p->d_Sb2.cap * sizeof(double), s));
+      for (DBuf<double>* b : {&p->d_Vb, &p->d_Vb2}) HIP_TRY(hipMemsetAsync(b->p + nv, 0, pad * sizeof(double), s));
+      for (DBuf<double>* b : {&p->d_yt, &p->d_yt2}) HIP_TRY(hipMemsetAsync(b->p + np, 0, pad * sizeof(double), s));
+      p->zeroed_np = np, p->zeroed_ncb = ncb, std::memcpy(p->zeroed_ptr, now, sizeof(now));
+    }
   }
   HIP_TRY(p->d_g2.reserve(np));
-  {  // + a zero pad behind each array (operands of rows that do not exist, k_band_backward_w)
-    const size_t nv = size_t(np) * ncb, pad = 64;
-    for (DBuf<double>* b : {&p->d_Vb, &p->d_Vb2}) {
-      HIP_TRY(b->reserve(nv + pad));
-      HIP_TRY(hipMemsetAsync(b->p + nv, 0, pad * sizeof(double), s));
-    }
-    for (DBuf<double>* b : {&p->d_yt, &p->d_yt2}) {
-      HIP_TRY(b->reserve(size_t(np) + pad));
-      HIP_TRY(hipMemsetAsync(b->p + np, 0, pad * sizeof(double), s));
-    }
-  }
   HIP_TRY(p->d_Ub2.reserve(size_t(np) * ncb));
   HIP_TRY(p->d_Ubk2.reserve(size_t(p->n_cp) * 24));
   HIP_TRY(p->d_ybuf2.reserve(np));
@@ -603,6 +608,12 @@ int prepare(hs_problem* p) {
   T.st = p->d_state.p;
   HIP_TRY(p->batch.flush(s));  // (the staging arena outlives this call: no host synchronisation)
   p->dirty = false;
+  if (p->host_timing) {
+    const auto host_t2 = std::chrono::steady_clock::now();
+    p->host_prepare[0] = std::chrono::duration<double, std::milli>(host_t1 - host_t0).count();
+    p->host_prepare[1] = std::chrono::duration<double, std::milli>(host_t2 - host_t1).count();
+    p->host_ms[0] += p->host_prepare[0], p->host_ms[1] += p->host_prepare[1];
+  }
   return HS_OK;
 }
 
@@ -911,7 +922,7 @@ int launch_factor(hs_problem* p) {
     k_border_schur<<<dim3(nt, nt), kBlock, 0, s>>>(T);
     if (T.nb + 1 <= 128 && !(T.debug_flags & 524288)) {  // trailing matrix in registers (A/B switch 524288: the LDS version)
       const int R = std::max(4, (T.nb + 1 + 15) / 16), N = 16 * R;
-      const size_t lds = (size_t(2) * N + size_t(T.nb) * (N + 1) + T.nb) * sizeof(double);
+      const size_t lds = (size_t(4) * N + size_t(T.nb) * (N + 1) + T.nb) * sizeof(double);
       switch (R) {
         case 4: k_border_solve_reg<4><<<1, kBlock, lds, s>>>(T); break;
         case 5: k_border_solve_reg<5><<<1, kBlock, lds, s>>>(T); break;
@@ -1007,6 +1018,7 @@ int hs_create(int device, void* stream, hs_problem** out) {
   p->device = device;
   if (const char* e = std::getenv("HS_REFERENCE_LITERAL")) p->inertial_mode = std::atoi(e) ? HS_INERTIAL_AS_REFERENCE : HS_INERTIAL_EXACT;
   if (const char* e = std::getenv("HS_STAGE_TIMING")) p->stage_timing = std::atoi(e) != 0;
+  if (const char* e = std::getenv("HS_HOST_TIMING")) p->host_timing = std::atoi(e) != 0;
   if (hipSetDevice(device) != hipSuccess) {
     delete p;
     return HS_ERR_DEVICE;
@@ -1036,6 +1048,15 @@ int hs_create(int device, void* stream, hs_problem** out) {
 
 int hs_destroy(hs_problem* p) {
   if (!p) return HS_OK;
+  if (p->host_timing && p->host_calls) {
+    std::fprintf(stderr, "hs host timing over %d hs_solve calls [ms per call]: structure + tables %.4f, uploads %.4f, launches %.4f, wait %.4f\n", p->host_calls,
+                 p->host_ms[0] / p->host_calls, p->host_ms[1] / p->host_calls, p->host_ms[2] / p->host_calls, p->host_ms[3] / p->host_calls);
+    const size_t n = p->host_log.size() / 4, h = n / 2;  // second half of the calls: buffers have reached their size, nothing is allocated
+    double m[4] = {0, 0, 0, 0};
+    for (size_t i = h; i < n; ++i)
+      for (int c = 0; c < 4; ++c) m[c] += p->host_log[4 * i + c] / double(n - h);
+    std::fprintf(stderr, "hs host timing, second half of the calls: structure + tables %.4f, uploads %.4f, launches %.4f, wait %.4f\n", m[0], m[1], m[2], m[3]);
+  }
   if (p->scratch) hs_destroy(p->scratch), p->scratch = nullptr;
   (void)hipSetDevice(p->device);
   (void)hipStreamSynchronize(p->stream);
@@ -1525,6 +1546,7 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
   rc = reset_state(p, max_iterations, 1e4);
   if (rc) return rc;
   hipStream_t s = p->stream;
+  const auto host_t3 = std::chrono::steady_clock::now();
   // stage timing (optional, hs_set_stage_timing): 4 stages per iteration bracketed by HIP events on the launch stream; every event is a
   // barrier packet (~5.7 us of idle device each, rocprofv3 kernel trace), so by default only the two ends of the solve are stamped
   const bool stages = p->stage_timing;
@@ -1559,8 +1581,17 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
     k_cost_reduce<<<1, kBlock, 0, s>>>(p->T);
   }
   DevState& st = *p->h_state;
+  const auto host_t4 = std::chrono::steady_clock::now();
   HIP_TRY(hipMemcpyAsync(&st, p->d_state.p, sizeof(st), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  if (p->host_timing) {
+    const auto host_t5 = std::chrono::steady_clock::now();
+    const double tl = std::chrono::duration<double, std::milli>(host_t4 - host_t3).count(), tw = std::chrono::duration<double, std::milli>(host_t5 - host_t4).count();
+    p->host_ms[2] += tl, p->host_ms[3] += tw;
+    p->host_log.insert(p->host_log.end(), {p->host_prepare[0], p->host_prepare[1], tl, tw});
+    p->host_prepare[0] = p->host_prepare[1] = 0;
+    ++p->host_calls;
+  }
   std::memset(summary, 0, sizeof(*summary));
   summary->initial_cost = st.records[0].cost;
   summary->final_cost = st.cost;

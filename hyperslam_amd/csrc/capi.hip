@@ -181,6 +181,12 @@ struct hs_problem {
   int host_calls = 0;
   std::vector<double> host_log;                  // the same four numbers per call
   double host_prepare[2] = {0, 0};               // (prepare() of the running call)
+  // Result read-back: a caller that fetches the state after every solve (the sliding-window driver: control points, landmarks, bias
+  // points, gravity = four synchronous copies of ~30 us each) gets it copied into pinned host memory at the end of hs_solve, in the stream,
+  // before the solve's own synchronisation; the getters then read host memory. Enabled by the first getter call that had to go to the device.
+  double* h_result = nullptr;
+  size_t h_result_cap = 0;
+  bool want_results = false, results_cached = false;
   int zeroed_np = -1, zeroed_ncb = -1;           // layout / allocations for which the never-written parts of Sb2, Vb, yt were zeroed
   const void* zeroed_ptr[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 
@@ -705,6 +711,8 @@ int exchange(hs_problem* p, double* buf, int64_t count) {
   return HS_OK;
 }
 
+static int border_zero_wgs(const Tables& T) { return std::min(64, (T.nb * T.nb + T.nb + 127) / 128); }
+
 template <int K>
 int launch_build(hs_problem* p) {
   const Tables& T = p->T;
@@ -724,8 +732,7 @@ int launch_build(hs_problem* p) {
   }
   hipStream_t sb = side_imu ? p->side : s;  // stream of the border gathers
   if (side_imu && T.nb) {  // behind k_linearize_inertial on the side stream, next to k_landmark / the Gram kernels
-    k_border_pb<K><<<dim3(T.sp.n_cp, p->n_split), 128, 0, sb>>>(T);
-    k_border_zero<<<std::min(64, (T.nb * T.nb + T.nb + kBlock - 1) / kBlock), kBlock, 0, sb>>>(T);
+    k_border_pb<K><<<dim3(T.sp.n_cp + border_zero_wgs(T), p->n_split), 128, 0, sb>>>(T);  // (+ zero-fill of the border-border block)
     k_border_bb<K><<<T.n_bias, kBlock, 0, sb>>>(T);
     k_border_gravity<<<1, 64, 0, sb>>>(T);
     HIP_TRY(hipEventRecord(p->ev_join, p->side));
@@ -779,8 +786,7 @@ int launch_build(hs_problem* p) {
   if (fork) HIP_TRY(hipStreamWaitEvent(s, p->ev_join, 0));
   k_assemble<K><<<dim3(T.sp.n_cp, 6), kAsmThreads, 0, s>>>(T);
   if (T.nb && !side_imu) {
-    k_border_pb<K><<<dim3(T.sp.n_cp, p->n_split), 128, 0, s>>>(T);
-    k_border_zero<<<std::min(64, (T.nb * T.nb + T.nb + kBlock - 1) / kBlock), kBlock, 0, s>>>(T);
+    k_border_pb<K><<<dim3(T.sp.n_cp + border_zero_wgs(T), p->n_split), 128, 0, s>>>(T);
     k_border_bb<K><<<T.n_bias, kBlock, 0, s>>>(T);
     k_border_gravity<<<1, 64, 0, s>>>(T);
   }
@@ -955,11 +961,16 @@ int launch_update(hs_problem* p) {
   const Tables& T = p->T;
   hipStream_t s = p->stream;
   k_backsub_retract<<<T.n_lm_part + T.n_norm_part, kBlock, 0, s>>>(T);
-  if (T.n_vis) k_cost_visual<K><<<p->nb_vis, kBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.lm_cand, T.cand_part);
-  if (T.n_pri) k_cost_prior<K><<<p->nb_pri, kBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.cand_part + p->nb_vis);
-  if (T.n_ine)
-    k_cost_inertial<K, 4><<<p->nb_ine, kInertialBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.bias_g_cand, T.bias_a_cand, T.gravity_cand,
-                                                                        T.cand_part + p->nb_vis + p->nb_pri);
+  if ((T.n_ine || T.n_pri) && !(T.debug_flags & 33554432)) {  // one launch for all factor types (A/B switch 33554432: one per type)
+    k_cost_all<K, 4><<<p->nb_vis + p->nb_pri + p->nb_ine, kBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.lm_cand, T.bias_g_cand, T.bias_a_cand, T.gravity_cand,
+                                                                                       T.cand_part, p->nb_vis, p->nb_pri);
+  } else {
+    if (T.n_vis) k_cost_visual<K><<<p->nb_vis, kBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.lm_cand, T.cand_part);
+    if (T.n_pri) k_cost_prior<K><<<p->nb_pri, kBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.cand_part + p->nb_vis);
+    if (T.n_ine)
+      k_cost_inertial<K, 4><<<p->nb_ine, kInertialBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.bias_g_cand, T.bias_a_cand, T.gravity_cand,
+                                                                          T.cand_part + p->nb_vis + p->nb_pri);
+  }
   const bool local_decision = !p->allreduce && !p->rccl_comm;  // single shard: decide in the packing kernel
   const bool inline_commit = local_decision && 8 * T.sp.n_cp + 3 * T.n_lm + 8 * T.n_bias <= kCommitInline && !(T.debug_flags & 16777216);  // A/B switch 16777216
   k_pack_decision<<<1, kBlock, 0, s>>>(T, inline_commit ? 2 : local_decision ? 1 : 0);
@@ -1066,6 +1077,7 @@ int hs_destroy(hs_problem* p) {
   if (p->ev_irec) (void)hipEventDestroy(p->ev_irec);
   if (p->side) (void)hipStreamDestroy(p->side);
   if (p->h_state) (void)hipHostFree(p->h_state);
+  if (p->h_result) (void)hipHostFree(p->h_result);
   if (p->rccl_comm && rccl_api()) (void)rccl_api()->CommDestroy(static_cast<ncclComm_t>(p->rccl_comm));
   if (p->own_stream) (void)hipStreamDestroy(p->stream);
   delete p;
@@ -1541,6 +1553,7 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
   if (!p || !summary) return HS_ERR_INVALID;
   if (p->has_weights()) HS_FAIL(HS_ERR_INVALID, kWeightsMessage);
   if (max_iterations < 0 || max_iterations > kMaxIterations) HS_FAIL(HS_ERR_INVALID, "max_iterations out of range");
+  p->results_cached = false;
   int rc = prepare(p);
   if (rc) return rc;
   rc = reset_state(p, max_iterations, 1e4);
@@ -1582,6 +1595,24 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
   }
   DevState& st = *p->h_state;
   const auto host_t4 = std::chrono::steady_clock::now();
+  if (p->want_results) {  // [cp | lm (device order) | bias_g | bias_a | gravity] -> pinned host memory, behind the last kernel
+    const size_t n_cp8 = p->cp.size(), n_lm3 = p->lm.size(), n_b = p->has_imu ? p->bias_g.size() : 0, total = n_cp8 + n_lm3 + 2 * n_b + 3;
+    if (total > p->h_result_cap) {
+      if (p->h_result) (void)hipHostFree(p->h_result);
+      p->h_result = nullptr, p->h_result_cap = 0;
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->h_result), 2 * total * sizeof(double), hipHostMallocDefault));
+      p->h_result_cap = 2 * total;
+    }
+    double* h = p->h_result;
+    HIP_TRY(hipMemcpyAsync(h, p->d_cp.p, n_cp8 * 8, hipMemcpyDeviceToHost, s));
+    if (n_lm3) HIP_TRY(hipMemcpyAsync(h + n_cp8, p->d_lm.p, n_lm3 * 8, hipMemcpyDeviceToHost, s));
+    if (n_b) {
+      HIP_TRY(hipMemcpyAsync(h + n_cp8 + n_lm3, p->d_bias_g.p, n_b * 8, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(h + n_cp8 + n_lm3 + n_b, p->d_bias_a.p, n_b * 8, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(h + n_cp8 + n_lm3 + 2 * n_b, p->d_gravity.p, 24, hipMemcpyDeviceToHost, s));
+    }
+    p->results_cached = true;  // (valid once the synchronisation below has returned)
+  }
   HIP_TRY(hipMemcpyAsync(&st, p->d_state.p, sizeof(st), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   if (p->host_timing) {
@@ -1649,6 +1680,7 @@ int hs_snapshot(hs_problem* p) {
 int hs_restore(hs_problem* p) {
   if (!p) return HS_ERR_INVALID;
   if (!p->has_snapshot || p->dirty) HS_FAIL(HS_ERR_STATE, "hs_restore without a valid hs_snapshot");
+  p->results_cached = false;
   HIP_TRY(hipMemcpyAsync(p->d_cp.p, p->d_cp_snap.p, p->cp.size() * 8, hipMemcpyDeviceToDevice, p->stream));
   if (p->n_lm) HIP_TRY(hipMemcpyAsync(p->d_lm.p, p->d_lm_snap.p, p->lm.size() * 8, hipMemcpyDeviceToDevice, p->stream));
   if (p->has_imu) {
@@ -1724,8 +1756,13 @@ int hs_get_control_points(hs_problem* p, double* cp) {
     std::memcpy(cp, p->cp.data(), p->cp.size() * 8);
     return HS_OK;
   }
-  HIP_TRY(hipMemcpyAsync(cp, p->d_cp.p, size_t(8) * p->n_cp * 8, hipMemcpyDeviceToHost, p->stream));
-  HIP_TRY(hipStreamSynchronize(p->stream));
+  if (p->results_cached) {
+    std::memcpy(cp, p->h_result, p->cp.size() * 8);
+  } else {
+    p->want_results = true;
+    HIP_TRY(hipMemcpyAsync(cp, p->d_cp.p, size_t(8) * p->n_cp * 8, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+  }
   std::memcpy(p->cp.data(), cp, p->cp.size() * 8);
   return HS_OK;
 }
@@ -1735,9 +1772,15 @@ int hs_get_landmarks(hs_problem* p, double* xyz) {
     std::memcpy(xyz, p->lm.data(), p->lm.size() * 8);
     return HS_OK;
   }
-  std::vector<double> dev(size_t(3) * p->n_lm);
-  HIP_TRY(hipMemcpyAsync(dev.data(), p->d_lm.p, dev.size() * 8, hipMemcpyDeviceToHost, p->stream));
-  HIP_TRY(hipStreamSynchronize(p->stream));
+  std::vector<double> fetched;
+  const double* dev = p->h_result + p->cp.size();
+  if (!p->results_cached) {
+    p->want_results = true;
+    fetched.resize(size_t(3) * p->n_lm);
+    HIP_TRY(hipMemcpyAsync(fetched.data(), p->d_lm.p, fetched.size() * 8, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    dev = fetched.data();
+  }
   for (int d = 0; d < p->n_lm; ++d) {
     const int t = p->vs.table_of_dev[d];
     for (int c = 0; c < 3; ++c) xyz[3 * t + c] = p->lm[3 * t + c] = dev[3 * d + c];
@@ -1747,9 +1790,15 @@ int hs_get_landmarks(hs_problem* p, double* xyz) {
 int hs_get_bias(hs_problem* p, double* bg, double* ba) {
   if (!p || !bg || !ba) return HS_ERR_INVALID;
   if (!p->dirty && p->has_imu && !p->bias_g.empty()) {
-    HIP_TRY(hipMemcpyAsync(p->bias_g.data(), p->d_bias_g.p, p->bias_g.size() * 8, hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipMemcpyAsync(p->bias_a.data(), p->d_bias_a.p, p->bias_a.size() * 8, hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (p->results_cached) {
+      const double* h = p->h_result + p->cp.size() + p->lm.size();
+      std::memcpy(p->bias_g.data(), h, p->bias_g.size() * 8), std::memcpy(p->bias_a.data(), h + p->bias_g.size(), p->bias_a.size() * 8);
+    } else {
+      p->want_results = true;
+      HIP_TRY(hipMemcpyAsync(p->bias_g.data(), p->d_bias_g.p, p->bias_g.size() * 8, hipMemcpyDeviceToHost, p->stream));
+      HIP_TRY(hipMemcpyAsync(p->bias_a.data(), p->d_bias_a.p, p->bias_a.size() * 8, hipMemcpyDeviceToHost, p->stream));
+      HIP_TRY(hipStreamSynchronize(p->stream));
+    }
   }
   std::memcpy(bg, p->bias_g.data(), p->bias_g.size() * 8), std::memcpy(ba, p->bias_a.data(), p->bias_a.size() * 8);
   return HS_OK;
@@ -1757,8 +1806,13 @@ int hs_get_bias(hs_problem* p, double* bg, double* ba) {
 int hs_get_gravity(hs_problem* p, double* g) {
   if (!p || !g) return HS_ERR_INVALID;
   if (!p->dirty && p->has_imu) {
-    HIP_TRY(hipMemcpyAsync(p->gravity, p->d_gravity.p, 24, hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (p->results_cached) {
+      std::memcpy(p->gravity, p->h_result + p->cp.size() + p->lm.size() + 2 * p->bias_g.size(), 24);
+    } else {
+      p->want_results = true;
+      HIP_TRY(hipMemcpyAsync(p->gravity, p->d_gravity.p, 24, hipMemcpyDeviceToHost, p->stream));
+      HIP_TRY(hipStreamSynchronize(p->stream));
+    }
   }
   std::memcpy(g, p->gravity, 24);
   return HS_OK;

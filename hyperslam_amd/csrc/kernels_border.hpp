@@ -12,8 +12,15 @@ namespace hs {
 // ---------------------------------------------------------------------------------------------------------------------
 template <int K>
 __global__ void __launch_bounds__(128) k_border_pb(Tables T) {
-  // block (i, split): rows 6 i .. 6 i + 5 of H_pb, thread <-> border column
+  // block (i, split): rows 6 i .. 6 i + 5 of H_pb, thread <-> border column. Blocks i >= n_cp (split 0 only) zero the border-border block and
+  // its gradient in the exchange buffer for k_border_bb, which follows on the same stream (a launch of its own cost 6 us on the side-stream chain)
   if (T.st->done) return;
+  if (int(blockIdx.x) >= T.sp.n_cp) {
+    if (blockIdx.y != 0) return;
+    const int n = T.nb * T.nb + T.nb, nz = int(gridDim.x) - T.sp.n_cp;
+    for (int e = (int(blockIdx.x) - T.sp.n_cp) * blockDim.x + threadIdx.x; e < n; e += nz * blockDim.x) T.xbuf[T.xo_bb + e] = 0.0;
+    return;
+  }
   const int i = blockIdx.x, sp = blockIdx.y, nsp = gridDim.y;
   const int kb = T.kb, nbias = T.n_bias, nb = T.nb;
   const int IREC = 18 + 36 * K + 2 * kb;
@@ -61,7 +68,7 @@ __global__ void __launch_bounds__(128) k_border_pb(Tables T) {
 
 /// H_bb and J_b' r. One workgroup per bias control point b (gyro and accel parts): the records whose bias window covers b are
 /// dealt to 256 lanes, sums are combined wave by wave in a fixed order; each entry of the exchange buffer has a single writer
-/// (the region is zero-filled first by k_border_zero). The gravity block is accumulated per b over the records that START at b
+/// (the region is zero-filled first by the extra workgroups of k_border_pb). The gravity block is accumulated per b over the records that START at b
 /// (every record exactly once) into T.gravity_part[b][5] and summed by k_border_gravity.
 template <int K>
 __global__ void __launch_bounds__(kBlock) k_border_bb(Tables T) {
@@ -145,12 +152,6 @@ __global__ void k_border_gravity(Tables T) {
   Hbb[size_t(ogr) * nb + ogr] = h[0], Hbb[size_t(ogr) * nb + ogr + 1] = h[1];
   Hbb[size_t(ogr + 1) * nb + ogr] = h[1], Hbb[size_t(ogr + 1) * nb + ogr + 1] = h[2];
   T.xbuf[T.xo_gb + ogr] = h[3], T.xbuf[T.xo_gb + ogr + 1] = h[4];
-}
-
-__global__ void __launch_bounds__(kBlock) k_border_zero(Tables T) {
-  if (T.st->done) return;
-  const int n = T.nb * T.nb + T.nb;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) T.xbuf[T.xo_bb + e] = 0.0;
 }
 
 /// Scaling / damping of the border blocks after the exchange:  S_pb = Sp H_pb Sb,  S_bb = Sb H_bb Sb + D_b^2,  g_b = Sb g_b.

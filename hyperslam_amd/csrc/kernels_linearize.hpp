@@ -179,4 +179,36 @@ __global__ void __launch_bounds__(kBlock) k_cost_prior(Tables T, const double* c
   if (threadIdx.x == 0) cost_part[blockIdx.x] = s;
 }
 
+/// Cost at the candidate point of every factor type in ONE launch (windows with inertial or prior factors: three dependent launches of
+/// ~8 us each otherwise, almost all of it launch + first-load latency). Workgroups [0, nb_vis) visual, [nb_vis, nb_vis + nb_pri) prior, the
+/// rest inertial (kInertialBlock residuals per workgroup, first wave). Same partial sums, same slots of cost_part as the three kernels.
+template <int K, int KB>
+__global__ void __launch_bounds__(kBlock) k_cost_all(Tables T, const double* cp_src, const double* lm_src, const double* bg, const double* ba, const double* grav,
+                                                     double* cost_part, int nb_vis, int nb_pri) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (T.st->done) return;
+  double* cps = smem;
+  stage_cps(cp_src, cps, 8 * T.sp.n_cp);
+  __shared__ double red[kBlock / 64];
+  const int b = blockIdx.x;
+  double cost = 0.0;
+  if (b < nb_vis) {
+    const int q = b * kBlock + threadIdx.x;
+    if (q < T.n_vis) cost = visual_cost<K>(T, cps, lm_src, q);
+  } else if (b < nb_vis + nb_pri) {
+    const int i = (b - nb_vis) * kBlock + threadIdx.x;
+    if (i < T.n_pri) cost = prior_cost<K>(T, cps, i);
+  } else {
+    const int i = (b - nb_vis - nb_pri) * kInertialBlock + threadIdx.x;
+    if (threadIdx.x < kInertialBlock && i < T.n_ine) {
+      InertialOut<K, KB> o;
+      o.Jp = nullptr;  // (value-only branch)
+      inertial_evaluate<K, KB, false>(T, cps, bg, ba, grav, i, false, &o);
+      cost = o.cost;
+    }
+  }
+  const double s = block_sum(cost, red);
+  if (threadIdx.x == 0) cost_part[b] = s;
+}
+
 }  // namespace hs

@@ -375,3 +375,58 @@ def test_short_windows_with_window_wide_bands(order, bw, n_cp, imu, hip, oracle,
         cp2 = g.control_points()
     assert s1["num_successful_steps"] == s2["num_successful_steps"] and rel(cp1, cp2) < 1e-9
     assert abs(s1["final_cost"] - s2["final_cost"]) <= 1e-9 * s2["final_cost"]
+
+
+@pytest.mark.parametrize("flags,what", [(4194304, "k_landmark<K,4,1> instead of k_landmark_rows"), (8388608, "five finalisation launches instead of one"),
+                                         (16777216, "k_commit launch instead of the inline copy"), (262144, "no frozen-prefix shortcuts")])
+@pytest.mark.parametrize("imu", [False, True])
+def test_replay_shape_launch_variants_agree(flags, what, imu, hip, monkeypatch):
+    """The launch arrangements added for the sliding-window shape (long tracks, frozen prefix, bordered single shard, small state) against
+    the arrangements they replaced (measurement switches of the library): the first three reorder no floating-point operation, so the
+    iteration records must be identical; eliminating the frozen prefix instead of skipping it changes rounding only."""
+    w = window_with_band(4, 33, n_cp=47, imu=imu)
+    w.cp_constant = np.r_[np.ones(12, np.uint8), np.zeros(47 - 12, np.uint8)]  # a frozen prefix as in a slid window
+    runs = []
+    for f in ("0", str(flags)):
+        monkeypatch.setenv("HS_DEBUG_FLAGS", f)
+        with ha.Problem(w, lib=hip) as g:
+            s = g.solve(4)
+            runs.append((s, g.control_points(), g.landmarks()))
+    monkeypatch.setenv("HS_DEBUG_FLAGS", "0")
+    (s0, cp0, lm0), (s1, cp1, lm1) = runs
+    assert s0["num_iterations"] == s1["num_iterations"] and s0["num_successful_steps"] == s1["num_successful_steps"], what
+    if flags == 262144:
+        assert rel(cp0, cp1) < 1e-9 and rel(lm0, lm1) < 1e-9 and abs(s0["final_cost"] - s1["final_cost"]) <= 1e-9 * s1["final_cost"], what
+    else:
+        assert np.array_equal(cp0, cp1) and np.array_equal(lm0, lm1) and s0["final_cost"] == s1["final_cost"], what
+
+
+@pytest.mark.parametrize("imu", [False, True])
+def test_result_readback_through_the_pinned_cache(imu, hip):
+    """A caller that reads the state after a solve gets the next solve's result copied into pinned host memory inside hs_solve; the getters
+    must return exactly what a direct device read returns (also after hs_restore, which invalidates the cache)."""
+    w = synthetic.small_inertial(order=4, n_cp=20, seed=5) if imu else synthetic.small_visual(order=4, n_cp=20, seed=5)
+
+    def state(g):
+        out = [g.control_points(), g.landmarks()]
+        if imu:
+            out += list(g.bias()) + [g.gravity()]
+        return out
+
+    with ha.Problem(w, lib=hip) as a, ha.Problem(w, lib=hip) as b:
+        a.snapshot()
+        a.solve(2)
+        state(a)            # device path; switches the read-back cache on
+        a.solve(2)
+        cached = state(a)   # served from the cache
+        b.solve(2)
+        b.solve(2)
+        direct = state(b)   # never cached: device path
+        for x, y in zip(cached, direct):
+            assert np.array_equal(x, y)
+        a.restore()
+        restored = state(a)
+        with ha.Problem(w, lib=hip) as c:
+            initial = state(c)
+        for x, y in zip(restored, initial):
+            assert np.array_equal(x, y)

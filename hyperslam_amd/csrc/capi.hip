@@ -925,7 +925,7 @@ int launch_factor(hs_problem* p) {
     const int fwd_threads = std::max(128, 64 * ((6 * (T.bw - 1) + 63) / 64));  // one lane per pending row
     k_border_forward<<<(T.nb + kBorderCols - 1) / kBorderCols, fwd_threads, size_t(T.np) * kBorderLd * sizeof(double), s>>>(T, f0);
     const int nt = (T.nb + kSchurTile - 1) / kSchurTile;
-    k_border_schur<<<dim3(nt, nt), kBlock, 0, s>>>(T);
+    k_border_schur<<<dim3(nt, nt), kBlock, 0, s>>>(T, f0);
     if (T.nb + 1 <= 128 && !(T.debug_flags & 524288)) {  // trailing matrix in registers (A/B switch 524288: the LDS version)
       const int R = std::max(4, (T.nb + 1 + 15) / 16), N = 16 * R;
       const size_t lds = (size_t(4) * N + size_t(T.nb) * (N + 1) + T.nb) * sizeof(double);

@@ -208,9 +208,9 @@ __global__ void __launch_bounds__(kBlock) k_finalize_border(Tables T) { finalize
 //   C = S_bb - Z'Z, h = g_b - Z'y  (k_border_schur, one workgroup per border row)
 //   C x_b = h (dense Cholesky in LDS), y' = y - Z x_b  (k_border_solve, one workgroup)   then the banded backward sweep on y'.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kBorderCols = 8;  // right-hand sides per workgroup in the forward sweep
-constexpr int kBorderLd = 10;   // LDS row stride of the pending rows (doubles): 64-byte rows put every fourth lane on the same banks (16-way
-                                // conflict on the row read-modify-write of every step); 80 bytes keeps 16-byte alignment and spreads them
+constexpr int kBorderCols = 4;  // right-hand sides per workgroup in the forward sweep
+constexpr int kBorderLd = 6;    // LDS row stride of the pending rows (doubles): rows of a power-of-two size put every fourth lane on the same banks
+                                // (16-way conflict on the row read-modify-write of every step); + 16 bytes keeps the alignment and spreads them
 
 /// The sweep of a workgroup starts at block row m0: rows above it are zero in its columns of S_pb, hence in Z — the rows of the leading
 /// constant control points (j_lo, decoupled: k_factor_decoupled_rows) and the rows before the first residual that involves the
@@ -311,7 +311,8 @@ __global__ void __launch_bounds__(kBlock) k_border_forward(Tables T, int j_lo) {
 /// in chunks (coalesced, eight loads in flight per lane), the tile is accumulated from LDS.
 constexpr int kSchurTile = 16, kSchurRows = 128;
 
-__global__ void __launch_bounds__(kBlock) k_border_schur(Tables T) {
+/// (rows of Z above the first non-zero row of either column group are zero — j_lo / T.bfwd_start as in k_border_forward — and are skipped)
+__global__ void __launch_bounds__(kBlock) k_border_schur(Tables T, int j_lo) {
   __shared__ double za[kSchurRows][kSchurTile + 1], zc[kSchurRows][kSchurTile + 1], ys[kSchurRows];
   if (T.st->done) return;
   const int nb = T.nb, np = T.np, tid = threadIdx.x;
@@ -319,8 +320,17 @@ __global__ void __launch_bounds__(kBlock) k_border_schur(Tables T) {
   if (ct < bt) return;  // lower tiles are written by their mirror
   const int ti = tid / kSchurTile, tj = tid % kSchurTile;
   const int b = bt * kSchurTile + ti, c = ct * kSchurTile + tj;
+  static_assert(kSchurTile % kBorderCols == 0, "a Schur tile covers whole column groups of the forward sweep");
+  constexpr int G = kSchurTile / kBorderCols;
+  const int n_groups = (nb + kBorderCols - 1) / kBorderCols;
+  int sb = np / 6, sc = np / 6;  // first block row with a non-zero entry in the tile's row / column groups
+  for (int g = 0; g < G; ++g) {
+    if (bt * G + g < n_groups) sb = min(sb, T.bfwd_start[bt * G + g]);
+    if (ct * G + g < n_groups) sc = min(sc, T.bfwd_start[ct * G + g]);
+  }
+  const int row0 = 6 * min(max(j_lo, max(sb, sc)), np / 6);
   double acc = 0.0, hacc = 0.0;
-  for (int r0 = 0; r0 < np; r0 += kSchurRows) {
+  for (int r0 = row0; r0 < np; r0 += kSchurRows) {
     const int nr = min(kSchurRows, np - r0);
     __syncthreads();
     // 2 x (kSchurRows x 16) operand entries + y: 16 + 1 loads per lane, issued together

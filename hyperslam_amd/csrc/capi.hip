@@ -711,7 +711,7 @@ int exchange(hs_problem* p, double* buf, int64_t count) {
   return HS_OK;
 }
 
-static int border_zero_wgs(const Tables& T) { return std::min(64, (T.nb * T.nb + T.nb + 127) / 128); }
+static int border_zero_wgs(const Tables& T) { return std::min(64, (T.nb * T.nb + T.nb + kPbThreads - 1) / kPbThreads); }
 
 template <int K>
 int launch_build(hs_problem* p) {
@@ -732,7 +732,7 @@ int launch_build(hs_problem* p) {
   }
   hipStream_t sb = side_imu ? p->side : s;  // stream of the border gathers
   if (side_imu && T.nb) {  // behind k_linearize_inertial on the side stream, next to k_landmark / the Gram kernels
-    k_border_pb<K><<<dim3(T.sp.n_cp + border_zero_wgs(T), p->n_split), 128, 0, sb>>>(T);  // (+ zero-fill of the border-border block)
+    k_border_pb<K><<<dim3(T.sp.n_cp + border_zero_wgs(T), p->n_split), kPbThreads, 0, sb>>>(T);  // (+ zero-fill of the border-border block)
     k_border_bb<K><<<T.n_bias, kBlock, 0, sb>>>(T);
     k_border_gravity<<<1, 64, 0, sb>>>(T);
     HIP_TRY(hipEventRecord(p->ev_join, p->side));
@@ -786,7 +786,7 @@ int launch_build(hs_problem* p) {
   if (fork) HIP_TRY(hipStreamWaitEvent(s, p->ev_join, 0));
   k_assemble<K><<<dim3(T.sp.n_cp, 6), kAsmThreads, 0, s>>>(T);
   if (T.nb && !side_imu) {
-    k_border_pb<K><<<dim3(T.sp.n_cp + border_zero_wgs(T), p->n_split), 128, 0, s>>>(T);
+    k_border_pb<K><<<dim3(T.sp.n_cp + border_zero_wgs(T), p->n_split), kPbThreads, 0, s>>>(T);
     k_border_bb<K><<<T.n_bias, kBlock, 0, s>>>(T);
     k_border_gravity<<<1, 64, 0, s>>>(T);
   }

@@ -10,10 +10,16 @@ namespace hs {
 //   H_pb (np x nb), H_bb (nb x nb), g_b (nb) are gathered deterministically from the inertial records.
 // Record structure exploited: d r_ang / d b_g,j = wg[j] I_3, d r_lin / d b_a,j = wa[j] I_3 (only the weights are stored).
 // ---------------------------------------------------------------------------------------------------------------------
+constexpr int kPbThreads = 192;  // two waves of bias columns + one wave for the two gravity columns
+
 template <int K>
-__global__ void __launch_bounds__(128) k_border_pb(Tables T) {
-  // block (i, split): rows 6 i .. 6 i + 5 of H_pb, thread <-> border column. Blocks i >= n_cp (split 0 only) zero the border-border block and
-  // its gradient in the exchange buffer for k_border_bb, which follows on the same stream (a launch of its own cost 6 us on the side-stream chain)
+__global__ void __launch_bounds__(kPbThreads) k_border_pb(Tables T) {
+  // block (i, split): rows 6 i .. 6 i + 5 of H_pb. Waves 0-1: thread <-> bias column, one flat loop over the records of the <= K
+  // segments that reach control point i (they are contiguous in the segment-major table; eight records in flight per lane). Wave 2: the
+  // two gravity columns — every record contributes (42 loads each), so the LANES take records and the sums are combined across the wave;
+  // as two more columns of the loop above they kept one wave busy for ~60 of the kernel's 89 us at configs[2].
+  // Blocks i >= n_cp (split 0 only) zero the border-border block and its gradient in the exchange buffer for k_border_bb, which
+  // follows on the same stream (a launch of its own cost 6 us on the side-stream chain)
   if (T.st->done) return;
   if (int(blockIdx.x) >= T.sp.n_cp) {
     if (blockIdx.y != 0) return;
@@ -25,41 +31,62 @@ __global__ void __launch_bounds__(128) k_border_pb(Tables T) {
   const int kb = T.kb, nbias = T.n_bias, nb = T.nb;
   const int IREC = 18 + 36 * K + 2 * kb;
   double* out = T.xpart + size_t(sp) * T.x_count1 + T.xo_pb;
-  for (int beta = threadIdx.x; beta < nb; beta += blockDim.x) {
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    // classify the column once
-    const int kind = beta < 3 * nbias ? 0 : (beta < 6 * nbias ? 1 : 2);
-    const int bb = kind == 2 ? 0 : (beta - 3 * nbias * kind) / 3, cc = kind == 2 ? beta - 6 * nbias : (beta - 3 * nbias * kind) % 3;
-    const int f0 = max(0, i - K + 1), f1 = min(i, T.n_seg - 1);
-    for (int first = f0; first <= f1; ++first) {
-      const int ao = 6 * (i - first);
-      if (kind == 2) {
-#pragma unroll 2
-        for (int pos = T.i_seg_ptr[first] + sp; pos < T.i_seg_ptr[first + 1]; pos += nsp) {
-          const double* rec = T.i_rec + size_t(pos) * IREC;
-          const double* jp = rec + 6;
-          const double* jg = rec + 6 + 36 * K + 2 * kb;
+  const int f0 = max(0, i - K + 1), f1 = min(i, T.n_seg - 1);
+  const int p0 = T.i_seg_ptr[f0], p1 = T.i_seg_ptr[f1 + 1];
+  int seg_end[K];  // end of segment f0 + j in the record table: first control point of record pos = f0 + #{j : pos >= seg_end[j]}
 #pragma unroll
-          for (int r = 0; r < 6; ++r) {
-            const double g = jg[2 * r + cc];
+  for (int j = 0; j < K; ++j) seg_end[j] = T.i_seg_ptr[min(f0 + j + 1, T.n_seg)];
+  auto first_of = [&](int pos) {
+    int f = f0;
 #pragma unroll
-            for (int a = 0; a < 6; ++a) acc[a] = fma(jp[r * 6 * K + ao + a], g, acc[a]);
-          }
-        }
-      } else {
-        // branch-free body (clamped weight index, masked weight) so that the loads of four records are in flight together
-#pragma unroll 4
-        for (int pos = T.i_seg_ptr[first] + sp; pos < T.i_seg_ptr[first + 1]; pos += nsp) {
-          const double* rec = T.i_rec + size_t(pos) * IREC;
-          const int j = bb - T.i_first_bias[pos];
-          const bool ok = j >= 0 && j < kb;
-          const double wv = rec[6 + 36 * K + kind * kb + (ok ? j : 0)];
-          const double wgt = ok ? wv : 0.0;
-          const double* row = rec + 6 + (3 * kind + cc) * 6 * K + ao;
+    for (int j = 0; j < K - 1; ++j) f += pos >= seg_end[j] ? 1 : 0;
+    return min(f, f1);
+  };
+  if (threadIdx.x >= 128) {  // ---- gravity columns ----
+    const int lane = threadIdx.x - 128;
+    double acc[2][6];
 #pragma unroll
-          for (int a = 0; a < 6; ++a) acc[a] = fma(row[a], wgt, acc[a]);
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int a = 0; a < 6; ++a) acc[c][a] = 0.0;
+    for (int pos = p0 + sp + lane * nsp; pos < p1; pos += 64 * nsp) {
+      const double* rec = T.i_rec + size_t(pos) * IREC;
+      const double* jp = rec + 6 + 6 * (i - first_of(pos));
+      const double* jg = rec + 6 + 36 * K + 2 * kb;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const double g0 = jg[2 * r], g1 = jg[2 * r + 1];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          const double v = jp[r * 6 * K + a];
+          acc[0][a] = fma(v, g0, acc[0][a]), acc[1][a] = fma(v, g1, acc[1][a]);
         }
       }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        const double v = wave_sum(acc[c][a]);
+        if (lane == 0) out[size_t(6 * i + a) * nb + 6 * nbias + c] = v;
+      }
+    return;
+  }
+  for (int beta = threadIdx.x; beta < 6 * nbias; beta += 128) {  // ---- bias columns ----
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    const int kind = beta < 3 * nbias ? 0 : 1;
+    const int bb = (beta - 3 * nbias * kind) / 3, cc = (beta - 3 * nbias * kind) % 3;
+    // branch-free body (clamped weight index, masked weight) so that the loads of eight records are in flight together
+#pragma unroll 8
+    for (int pos = p0 + sp; pos < p1; pos += nsp) {
+      const double* rec = T.i_rec + size_t(pos) * IREC;
+      const int j = bb - T.i_first_bias[pos];
+      const bool ok = j >= 0 && j < kb;
+      const double wv = rec[6 + 36 * K + kind * kb + (ok ? j : 0)];
+      const double wgt = ok ? wv : 0.0;
+      const double* row = rec + 6 + (3 * kind + cc) * 6 * K + 6 * (i - first_of(pos));
+#pragma unroll
+      for (int a = 0; a < 6; ++a) acc[a] = fma(row[a], wgt, acc[a]);
     }
 #pragma unroll
     for (int a = 0; a < 6; ++a) out[size_t(6 * i + a) * nb + beta] = acc[a];
@@ -208,7 +235,7 @@ __global__ void __launch_bounds__(kBlock) k_finalize_border(Tables T) { finalize
 //   C = S_bb - Z'Z, h = g_b - Z'y  (k_border_schur, one workgroup per border row)
 //   C x_b = h (dense Cholesky in LDS), y' = y - Z x_b  (k_border_solve, one workgroup)   then the banded backward sweep on y'.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kBorderCols = 4;  // right-hand sides per workgroup in the forward sweep
+constexpr int kBorderCols = 2;  // right-hand sides per workgroup in the forward sweep
 constexpr int kBorderLd = 6;    // LDS row stride of the pending rows (doubles): rows of a power-of-two size put every fourth lane on the same banks
                                 // (16-way conflict on the row read-modify-write of every step); + 16 bytes keeps the alignment and spreads them
 

@@ -357,11 +357,12 @@ __global__ void __launch_bounds__(kBlock) k_border_schur(Tables T, int j_lo) {
   }
   const int row0 = 6 * min(max(j_lo, max(sb, sc)), np / 6);
   double acc = 0.0, hacc = 0.0;
-  for (int r0 = row0; r0 < np; r0 += kSchurRows) {
+  // 2 x (kSchurRows x 16) operand entries + y per chunk: 16 + 1 loads per lane, issued together — and one chunk AHEAD of the products, so
+  // that the memory round trip of chunk r + 1 runs under the 128 FMAs of chunk r (the slowest tile sets the kernel time: six chunks at
+  // configs[2], each a full round trip + the products before)
+  double va[8], vc[8], yv;
+  auto request = [&](int r0) {
     const int nr = min(kSchurRows, np - r0);
-    __syncthreads();
-    // 2 x (kSchurRows x 16) operand entries + y: 16 + 1 loads per lane, issued together
-    double va[8], vc[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int e = tid + u * kBlock, r = e / kSchurTile, k = e % kSchurTile;
@@ -369,7 +370,11 @@ __global__ void __launch_bounds__(kBlock) k_border_schur(Tables T, int j_lo) {
       va[u] = ok && bt * kSchurTile + k < nb ? T.Zb[size_t(r0 + r) * nb + bt * kSchurTile + k] : 0.0;
       vc[u] = ok && ct * kSchurTile + k < nb ? T.Zb[size_t(r0 + r) * nb + ct * kSchurTile + k] : 0.0;
     }
-    const double yv = tid < nr ? T.ybuf[r0 + tid] : 0.0;
+    yv = tid < nr ? T.ybuf[r0 + tid] : 0.0;
+  };
+  if (row0 < np) request(row0);
+  for (int r0 = row0; r0 < np; r0 += kSchurRows) {
+    __syncthreads();  // the products of the previous chunk are done with the LDS operands
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int e = tid + u * kBlock, r = e / kSchurTile, k = e % kSchurTile;
@@ -377,11 +382,18 @@ __global__ void __launch_bounds__(kBlock) k_border_schur(Tables T, int j_lo) {
     }
     if (tid < kSchurRows) ys[tid] = yv;
     __syncthreads();
+    if (r0 + kSchurRows < np) request(r0 + kSchurRows);
+    if (ct == bt) {  // diagonal tiles also form Z'y: by every lane (only column 0 keeps it) — a per-lane condition inside the loop made it a
+                     // divergent branch per row, and the diagonal tiles set the kernel time
 #pragma unroll 8
-    for (int r = 0; r < kSchurRows; ++r) {
-      const double a = za[r][ti];
-      acc = fma(a, zc[r][tj], acc);
-      if (ct == bt && tj == 0) hacc = fma(a, ys[r], hacc);
+      for (int r = 0; r < kSchurRows; ++r) {
+        const double a = za[r][ti];
+        acc = fma(a, zc[r][tj], acc);
+        hacc = fma(a, ys[r], hacc);
+      }
+    } else {
+#pragma unroll 8
+      for (int r = 0; r < kSchurRows; ++r) acc = fma(za[r][ti], zc[r][tj], acc);
     }
   }
   if (b < nb && c < nb) {

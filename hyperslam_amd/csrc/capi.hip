@@ -515,8 +515,8 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_xsol.reserve(np));
   HIP_TRY(p->d_win.reserve(size_t(6) * vs.bw * (ncb + 1)));
   if (!p->d_join.p) {
-    HIP_TRY(p->d_join.reserve(2));
-    HIP_TRY(hipMemsetAsync(p->d_join.p, 0, 2 * sizeof(unsigned), s));
+    HIP_TRY(p->d_join.reserve(4));  // [0] two-ended factor / sweep hand-over, [1] last-block ticket of k_band_backward2, [2] of k_border_bb
+    HIP_TRY(hipMemsetAsync(p->d_join.p, 0, 4 * sizeof(unsigned), s));
     p->join_epoch = 0;
   }
   // split the accumulation over enough workgroups to fill the chip (256 CUs x a few workgroups)
@@ -646,7 +646,7 @@ static int ensure_side_stream(hs_problem* p) {
 }
 
 /// `inertial_on_side` (the solve loop of bordered systems): the inertial branch of an iteration — k_linearize_inertial, then the border
-/// gathers k_border_pb / _zero / _bb / _gravity in launch_build — only meets the visual branch (k_linearize_visual -> k_landmark -> Gram
+/// gathers k_border_pb / _bb in launch_build — only meets the visual branch (k_linearize_visual -> k_landmark -> Gram
 /// kernels -> k_assemble) at the segment Gram kernel (reads the inertial records) and at k_reduce_partials, and each branch fills a
 /// fraction of the chip: they run on two streams. configs[2]: 293 us of kernels back to back -> 175 us on the critical path.
 template <int K>
@@ -734,7 +734,6 @@ int launch_build(hs_problem* p) {
   if (side_imu && T.nb) {  // behind k_linearize_inertial on the side stream, next to k_landmark / the Gram kernels
     k_border_pb<K><<<dim3(T.sp.n_cp + border_zero_wgs(T), p->n_split), kPbThreads, 0, sb>>>(T);  // (+ zero-fill of the border-border block)
     k_border_bb<K><<<T.n_bias, kBlock, 0, sb>>>(T);
-    k_border_gravity<<<1, 64, 0, sb>>>(T);
     HIP_TRY(hipEventRecord(p->ev_join, p->side));
   }
   bool irec_ready = !side_imu;  // the segment Gram kernel reads the inertial records: wait for the side stream's linearisation once
@@ -788,7 +787,6 @@ int launch_build(hs_problem* p) {
   if (T.nb && !side_imu) {
     k_border_pb<K><<<dim3(T.sp.n_cp + border_zero_wgs(T), p->n_split), kPbThreads, 0, s>>>(T);
     k_border_bb<K><<<T.n_bias, kBlock, 0, s>>>(T);
-    k_border_gravity<<<1, 64, 0, s>>>(T);
   }
   if (side_imu) HIP_TRY(hipStreamWaitEvent(s, p->ev_join, 0));  // border gathers done
   // Nothing to exchange (single shard): packing + bookkeeping are an extra workgroup of k_finalize_reduced, the border blocks further
@@ -923,9 +921,12 @@ int launch_factor(hs_problem* p) {
     k_band_factor_wide<<<1, kWideThreads, size_t(12) * (ncb + 2) * sizeof(double), s>>>(Tf);
   if (T.nb) {  // bordered system (bias splines + gravity)
     const int fwd_threads = std::max(128, 64 * ((6 * (T.bw - 1) + 63) / 64));  // one lane per pending row
-    k_border_forward<<<(T.nb + kBorderCols - 1) / kBorderCols, fwd_threads, size_t(T.np) * kBorderLd * sizeof(double), s>>>(T, f0);
+    // the first non-zero row of a border column follows from the inertial record table — of ALL shards: a shard of a distributed solve
+    // only skips the rows of the constant control points (which every shard agrees on)
+    const int local_rows = (!p->allreduce && !p->rccl_comm && p->world == 1) ? 1 : 0;
+    k_border_forward<<<(T.nb + kBorderCols - 1) / kBorderCols, fwd_threads, size_t(T.np) * kBorderLd * sizeof(double), s>>>(T, f0, local_rows);
     const int nt = (T.nb + kSchurTile - 1) / kSchurTile;
-    k_border_schur<<<dim3(nt, nt), kBlock, 0, s>>>(T, f0);
+    k_border_schur<<<dim3(nt, nt), kBlock, 0, s>>>(T, f0, local_rows);
     if (T.nb + 1 <= 128 && !(T.debug_flags & 524288)) {  // trailing matrix in registers (A/B switch 524288: the LDS version)
       const int R = std::max(4, (T.nb + 1 + 15) / 16), N = 16 * R;
       const size_t lds = (size_t(4) * N + size_t(T.nb) * (N + 1) + T.nb) * sizeof(double);

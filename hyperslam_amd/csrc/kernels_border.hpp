@@ -25,6 +25,7 @@ __global__ void __launch_bounds__(kPbThreads) k_border_pb(Tables T) {
     if (blockIdx.y != 0) return;
     const int n = T.nb * T.nb + T.nb, nz = int(gridDim.x) - T.sp.n_cp;
     for (int e = (int(blockIdx.x) - T.sp.n_cp) * blockDim.x + threadIdx.x; e < n; e += nz * blockDim.x) T.xbuf[T.xo_bb + e] = 0.0;
+    if (int(blockIdx.x) == T.sp.n_cp && threadIdx.x == 0) T.join_flag[2] = 0u;  // arrival counter of k_border_bb's workgroups
     return;
   }
   const int i = blockIdx.x, sp = blockIdx.y, nsp = gridDim.y;
@@ -96,7 +97,7 @@ __global__ void __launch_bounds__(kPbThreads) k_border_pb(Tables T) {
 /// H_bb and J_b' r. One workgroup per bias control point b (gyro and accel parts): the records whose bias window covers b are
 /// dealt to 256 lanes, sums are combined wave by wave in a fixed order; each entry of the exchange buffer has a single writer
 /// (the region is zero-filled first by the extra workgroups of k_border_pb). The gravity block is accumulated per b over the records that START at b
-/// (every record exactly once) into T.gravity_part[b][5] and summed by k_border_gravity.
+/// (every record exactly once) into T.gravity_part[b][5] and summed by the workgroup that finishes last.
 template <int K>
 __global__ void __launch_bounds__(kBlock) k_border_bb(Tables T) {
   constexpr int NV = 2 * hsd::kMaxOrder + 18 + 5;
@@ -166,19 +167,19 @@ __global__ void __launch_bounds__(kBlock) k_border_bb(Tables T) {
     }
   for (int c = 0; c < 3; ++c) gb[og + 3 * b + c] = rg[c], gb[oa + 3 * b + c] = ra[c];
   for (int e = 0; e < 5; ++e) T.gravity_part[5 * b + e] = hg[e];
-}
-
-/// Gravity-gravity block and J_g' r: sum of the per-bias-point partials in index order.
-__global__ void k_border_gravity(Tables T) {
-  if (T.st->done || threadIdx.x != 0) return;
+  // Gravity-gravity block and J_g' r = sum of the per-bias-point partials in index order, by the workgroup that arrives last (the counter is
+  // reset by the zero-fill workgroups of k_border_pb, in front of this kernel on the same stream): a launch of its own ended the side-stream
+  // chain with 4.6 us of latency
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (atomicAdd(T.join_flag + 2, 1u) != gridDim.x - 1) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   double h[5] = {0, 0, 0, 0, 0};
-  for (int b = 0; b < T.n_bias; ++b)
-    for (int e = 0; e < 5; ++e) h[e] += T.gravity_part[5 * b + e];
-  const int nb = T.nb, ogr = 6 * T.n_bias;
-  double* Hbb = T.xbuf + T.xo_bb;
+  for (int bb = 0; bb < nbias; ++bb)
+    for (int e = 0; e < 5; ++e) h[e] += __builtin_nontemporal_load(T.gravity_part + 5 * bb + e);
   Hbb[size_t(ogr) * nb + ogr] = h[0], Hbb[size_t(ogr) * nb + ogr + 1] = h[1];
   Hbb[size_t(ogr + 1) * nb + ogr] = h[1], Hbb[size_t(ogr + 1) * nb + ogr + 1] = h[2];
-  T.xbuf[T.xo_gb + ogr] = h[3], T.xbuf[T.xo_gb + ogr + 1] = h[4];
+  gb[ogr] = h[3], gb[ogr + 1] = h[4];
 }
 
 /// Scaling / damping of the border blocks after the exchange:  S_pb = Sp H_pb Sb,  S_bb = Sb H_bb Sb + D_b^2,  g_b = Sb g_b.
@@ -242,13 +243,14 @@ constexpr int kBorderLd = 6;    // LDS row stride of the pending rows (doubles):
 /// The sweep of a workgroup starts at block row m0: rows above it are zero in its columns of S_pb, hence in Z — the rows of the leading
 /// constant control points (j_lo, decoupled: k_factor_decoupled_rows) and the rows before the first residual that involves the
 /// workgroup's bias points (T.bfwd_start: a bias point meets the pose rows of its own few seconds only).
-__global__ void __launch_bounds__(kBlock) k_border_forward(Tables T, int j_lo) {  // blockDim = 64 x waves covering the 6 (bw - 1) pending rows (>= 128)
+/// (local_rows = 0 on a shard of a distributed solve: the record table of one shard says nothing about the rows the other shards fill)
+__global__ void __launch_bounds__(kBlock) k_border_forward(Tables T, int j_lo, int local_rows) {  // blockDim = 64 x waves covering the 6 (bw - 1) pending rows (>= 128)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (T.st->done) return;
   const int tid = threadIdx.x;
   const int bw = T.bw, ncb = 6 * bw, nb = T.nb, np = T.np, n_blk = np / 6;
   const int c0 = blockIdx.x * kBorderCols, ncols = min(kBorderCols, nb - c0);
-  const int m0 = min(max(j_lo, T.bfwd_start[blockIdx.x]), n_blk - 1);
+  const int m0 = min(local_rows ? max(j_lo, T.bfwd_start[blockIdx.x]) : j_lo, n_blk - 1);
   double* z = smem;  // np x kBorderLd: pending right-hand side rows, overwritten by the solution
   for (int e = tid; e < np * kBorderCols; e += blockDim.x) {
     const int rho = e / kBorderCols, c = e % kBorderCols;
@@ -339,7 +341,7 @@ __global__ void __launch_bounds__(kBlock) k_border_forward(Tables T, int j_lo) {
 constexpr int kSchurTile = 16, kSchurRows = 128;
 
 /// (rows of Z above the first non-zero row of either column group are zero — j_lo / T.bfwd_start as in k_border_forward — and are skipped)
-__global__ void __launch_bounds__(kBlock) k_border_schur(Tables T, int j_lo) {
+__global__ void __launch_bounds__(kBlock) k_border_schur(Tables T, int j_lo, int local_rows) {
   __shared__ double za[kSchurRows][kSchurTile + 1], zc[kSchurRows][kSchurTile + 1], ys[kSchurRows];
   if (T.st->done) return;
   const int nb = T.nb, np = T.np, tid = threadIdx.x;
@@ -355,6 +357,7 @@ __global__ void __launch_bounds__(kBlock) k_border_schur(Tables T, int j_lo) {
     if (bt * G + g < n_groups) sb = min(sb, T.bfwd_start[bt * G + g]);
     if (ct * G + g < n_groups) sc = min(sc, T.bfwd_start[ct * G + g]);
   }
+  if (!local_rows) sb = sc = 0;
   const int row0 = 6 * min(max(j_lo, max(sb, sc)), np / 6);
   double acc = 0.0, hacc = 0.0;
   // 2 x (kSchurRows x 16) operand entries + y per chunk: 16 + 1 loads per lane, issued together — and one chunk AHEAD of the products, so

@@ -611,6 +611,9 @@ int prepare(hs_problem* p) {
   // 2048 one-ended factorisation (no second workgroup)              8192 generalised backward sweep on the one-ended factor
   // 131072 k_band_factor_mfma (trailing window in f64 MFMA tiles) instead of the VALU factorisation kernels
   // 65536 single-wave register backward sweep (k_band_backward_w) instead of the four-wave LDS sweeps
+  // 262144 eliminate / sweep the decoupled block rows of leading constant control points like any other     524288 border Cholesky in LDS
+  // 1048576 inertial branch on the main stream    2097152 banded kernels instead of k_dense_factor    4194304 k_landmark<K,4,1> instead of k_landmark_rows
+  // 8388608 five finalisation launches for a bordered single shard    16777216 k_commit launch for small windows    33554432 one cost launch per factor type
   T.st = p->d_state.p;
   HIP_TRY(p->batch.flush(s));  // (the staging arena outlives this call: no host synchronisation)
   p->dirty = false;

@@ -1326,15 +1326,20 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward(Tables T, int j_
 // Factorisation of SHORT systems with window-wide bands (the sliding-window replay: ~33 free block rows, every landmark track as long
 // as the window, so the "band" is the whole matrix and nothing slides): every 6x6 tile of the upper block triangle inside the band
 // lives in the registers of ONE lane for the whole factorisation — no trailing window in L2 (k_band_factor_wide: two global round
-// trips per step, 6.4 us per block row), no loader, no tile ownership that moves. 512 lanes x 2 tiles; the right-hand side is an extra
-// tile column. Per block row k:
-//   A1 the owner of the diagonal tile (k, k) factors it in place (6x6 Cholesky, one lane) and publishes U_kk, 1 / diag — at the end of its
-//      part of update k - 1, in the shadow of the other lanes' updates (X rows and U_kk are double buffered)
-//   A2 the other owners of row k (one contiguous run of <= bw lanes) solve their tile in place, X(k, j) = U_kk^-T S(k, j) (U_kk read
-//      from LDS with uniform addresses), write it to LDS (operand of the update) and to the factor (band storage)     --- barrier ---
-//   B  every lane: tile (i, j) -= X(k, i)' X(k, j) for its tiles with k < i <= k + bw - 1 (216 FMAs, 36 ds_read_b128) --- barrier ---
+// trips per step, 6.4 us per block row), no loader, no tile ownership that moves. Seven waves x 2 tiles own the off-diagonal band tiles and
+// the right-hand side (an extra tile column whose columns 1 .. 5 are zero), the eighth wave owns the diagonal tiles. Per block row k:
+//   A  the owners of row k (one contiguous run of <= bw lanes) solve their tile in place, X(k, j) = U_kk^-T S(k, j) (U_kk read from LDS
+//      with uniform addresses) and write it to LDS, the operand of the update                                          --- barrier ---
+//   B  band lanes: tile (i, j) -= X(k, i)' X(k, j) for their tiles with k < i <= k + bw - 1 (216 FMAs, 36 ds_read_b128; ONE code path for
+//      band and right-hand-side tiles). Diagonal wave: S(i, i) -= X(k, i)' X(k, i), upper triangle (18 reads, 126 FMAs); the owner of
+//      (k + 1, k + 1) then factors it in place (6x6 Cholesky, one lane) and publishes U, 1 / diag, the diagonal tile of X_(k+1) — in the
+//      shadow of the band lanes' updates (X rows double buffered, U_kk per block row)                                   --- barrier ---
+// Every tile stays in the registers of its owner to the end: the factor (band storage), y and U_kk^-1 are written after the last step.
+// Chain per block row (tools/dense_phase_timing.py): A 0.64 us, diagonal update 0.56 us, pivot 0.68 us, barriers: 2.1 us — 3.5 us while
+// lanes of one wave owned tiles of three kinds (the update ran once per kind) and the stores and U_kk^-1 were inside the steps.
 // (A redundant register Cholesky in every row owner, as in the panel of k_band_factor_la, needs 60 more live registers next to the two
-//  resident tiles and spilled: 6.5 us per block row, parked 83 % of the time.)
+//  resident tiles and spilled: 6.5 us per block row, parked 83 % of the time. A right-looking pivot with U_kk read from the X row: pivot
+//  0.56 us, A 0.88 us — no gain.)
 // Same outputs as the other factorisation kernels (Ub in band storage, U_ii^-1 packed, y = U^-T g).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kDenseThreads = 512, kDenseTiles = 2;

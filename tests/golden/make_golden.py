@@ -388,10 +388,22 @@ def main():
                     "prior": ["u0", "u1", "near_pi", "near_pi", "cp_near_pi"],
                     "inertial": ["u0", "u1", "identity", "identity", "cp_near_pi", "gravity_pivot", "gravity_pivot_neg"]}[ftype]
             plan += [(ftype, k, v) for v in edge]
+    # second block (own random stream, appended behind the first so that the cases above keep their values): the inertial factor has the
+    # most parameter blocks and gets as many random cases per order as the other factors, 32 with its edge cases
+    n_first = len(plan)
+    plan += [("inertial", k, None) for k in (4, 6) for _ in range(13)]
+    rng2 = SplitMix64(0x48595045 ^ 0x1E127)
+    only_second = "--second-block-only" in sys.argv  # (re-uses the first block of an existing factors.json: minutes instead of an hour)
+    if only_second:
+        with open(os.path.join(HERE, "factors.json")) as f:
+            cases = json.load(f)["cases"][:n_first]
+        assert len(cases) == n_first
     for rep, (ftype, k, variant) in enumerate(plan):
+        if only_second and rep < n_first:
+            continue
         if True:
             if True:
-                P = make_case(ftype, k, rng, variant)
+                P = make_case(ftype, k, rng if rep < n_first else rng2, variant)
                 # inputs are rounded to doubles FIRST, so that the golden outputs belong to exactly representable inputs
                 P = {key: (tofloat(v) if not isinstance(v, int) else v) for key, v in P.items()}
                 Pm = {key: ([[mp.mpf(x) for x in r] for r in v] if isinstance(v, list) and isinstance(v[0], list)

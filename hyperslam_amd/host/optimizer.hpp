@@ -586,11 +586,22 @@ class Optimizer {
     Stamp oldest = range.lower;
     for (const auto& [id, lm] : landmarks_) oldest = std::min(oldest, lm.lower);
     if (has_imu_) {
-      // inertial residuals older than every retained visual residual and the window only touch frozen control points: drop them
+      // Ceres never removes inertial / prior residual blocks (only landmark removal takes residual blocks along, optimizer.cpp:365-371),
+      // so upstream the problem grows for as long as the IMU runs. Retirement rule here: residuals older than the window and than every
+      // retained landmark go — the same kind of information loss as landmark retirement — which keeps the tables bounded.
       inertials_.erase(std::remove_if(inertials_.begin(), inertials_.end(), [&](const InertialMeasurement& m) { return m.stamp < oldest; }),
                        inertials_.end());
     }
     priors_.erase(std::remove_if(priors_.begin(), priors_.end(), [&](const ManifoldMeasurement& m) { return m.stamp < oldest; }), priors_.end());
+    if (has_imu_ && !inertials_.empty() && !bias_.empty()) {
+      // bias points no retained inertial residual reads are not part of the problem (Ceres only holds parameter blocks some residual
+      // block refers to, exteroceptive.cpp:64-76): drop them from the front so that the border of the reduced system stays as wide
+      // as the window, not as long as the run. Same arithmetic as the library's segment lookup (floor((t - t0) / dt) - (kb - 1) / 2).
+      Stamp t_min = inertials_.front().stamp;
+      for (const InertialMeasurement& m : inertials_) t_min = std::min(t_min, m.stamp);
+      const int kb = imu_.bias_order;
+      while (int(bias_.size()) > kb && int(std::floor((t_min - bias_[1].stamp) / imu_.bias_separation)) - (kb - 1) / 2 >= 0) bias_.erase(bias_.begin());
+    }
     const int k = opt_.order;
     size_t drop = 0;  // control points entirely before the segment of `oldest` (optimizer.cpp:331-341); the margin keeps a stamp that
                       // sits exactly on a knot inside the valid range whatever the rounding of (stamp - t0) / separation

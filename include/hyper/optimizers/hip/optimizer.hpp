@@ -1,17 +1,20 @@
-/// Optimizer<OptimizerSuite::HIP> — the reference-side plugin that puts libhyperslam_hip.so behind HyperSLAM's optimizer interface.
+/// Optimizer<kOptimizerSuiteHIP> ("suite: hip") — the reference-side plugin that puts libhyperslam_hip.so behind HyperSLAM's optimizer interface.
 ///
 /// WHERE THIS FILE LIVES. It is written against the HyperSLAM tree (Eigen, glog, yaml-cpp, HyperVariables / HyperSensors / HyperState),
-/// none of which exist in this repository's image: it is shipped for the maintainer who adds the backend, it is NOT compiled by this
-/// repository's build and no test here can compile it. What this repository does test is everything underneath it — the C ABI it calls
-/// (include/hyperslam_hip.h: syntax, exported symbol set, behaviour) — and the same window logic restated without the external
-/// dependencies (hyperslam_amd/host/optimizer.hpp, tests/test_host_driver.py).
+/// none of which exist in this repository's image: it is shipped for the maintainer who adds the backend and is not part of this
+/// repository's build. What this repository tests: (i) the header is type-checked (`g++ -std=c++20 -fsyntax-only`) against the
+/// reference's own in-tree headers (AbstractOptimizer, Environment, observations, landmarks) with hand-written declaration-only
+/// stand-ins for the EXTERNAL ones (tests/stubs/, tests/test_plugin_header.py; build container only), so every override, signature and
+/// include is checked by a compiler; (ii) everything underneath it — the C ABI it calls (include/hyperslam_hip.h: syntax, exported
+/// symbol set, behaviour); (iii) the same window logic restated without the external dependencies (hyperslam_amd/host/optimizer.hpp,
+/// tests/test_host_driver.py), which runs against both libraries.
 ///
-/// What a maintainer changes upstream (three places, everything else — front-end, Backend::spin, AbstractOptimizer::submit / setWindow /
-/// process, the YAML — stays as it is):
-///   1. include/hyper/optimizers/forward.hpp:14-17        enum class OptimizerSuite { CERES, HIP, DEFAULT = CERES };
-///   2. internal/hyper/system/components/backend.cpp:37    `} else if (suite == "hip") {` branch, see make_hip_optimizer() at the end
-///   3. settings.yaml:137                                  suite: hip
-/// and adds this header + include/hyperslam_hip.h to the include path and -lhyperslam_hip to the link line.
+/// What a maintainer changes upstream (two places, everything else — front-end, Backend::spin, AbstractOptimizer::submit / setWindow /
+/// process, the YAML keys — stays as it is):
+///   1. internal/hyper/system/components/backend.cpp:37    `} else if (suite == "hip") {` branch, see make_hip_optimizer() at the end
+///   2. settings.yaml:137                                  suite: hip
+/// and adds this header + include/hyperslam_hip.h to the include path and -lhyperslam_hip to the link line. The enum of
+/// include/hyper/optimizers/forward.hpp:14-17 needs no edit: see kOptimizerSuiteHIP below.
 ///
 /// How it maps onto the Ceres backend it replaces (internal/hyper/optimizers/ceres/optimizer.cpp, "cc" below):
 ///   Ceres keeps the problem structure incrementally (AddParameterBlock / AddResidualBlock / RemoveParameterBlock, cc:286-382) and
@@ -29,15 +32,26 @@
 ///                        add(ManifoldObservation&)      cc:234-251      -> hs_set_prior_residuals    (ManifoldMetric, no loss)
 ///                        add(InertialObservation&)      cc:253-274      -> hs_set_inertial_residuals (CartesianMetric<6>, Scaled 1.6e-5)
 ///     removal            RemoveParameterBlock(landmark) drops its residual blocks (cc:365-371, enable_fast_removal) -> observation lists are
-///                        pruned with the landmark; state elements without residuals leave variables_ (cc:330-341)
+///                        pruned with the landmark in updateLandmarks(); state elements without residuals leave variables_ (cc:330-341)
+///     bias splines       updateSensor(imu, range) — CHECK(false) upstream (cc:384-386) although abstract.cpp:278-286 relies on it to create
+///                        and extend imu.gyroscopeBias() / accelerometerBias() — is implemented here (extendBias)
+///     bounded window     Ceres never removes inertial / prior residual blocks, so upstream every control point an IMU sample ever touched
+///                        stays a (constant) parameter block for ever; here residuals older than the window and every retained landmark are
+///                        retired in updateLandmarks() (the same kind of information loss as landmark retirement, cc:365-371), which keeps
+///                        variables_ and the tables bounded (the library holds at most 1024 control points)
 ///     solve              ceres::Solve(kDefaultSolverOptions) cc:38-54,276-280 -> hs_solve(handle, 5, ...)
 #pragma once
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
-#include <map>
+#include <iterator>
+#include <limits>
 #include <memory>
+#include <typeindex>
+#include <typeinfo>
 #include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include <glog/logging.h>
@@ -56,8 +70,13 @@
 
 namespace hyper {
 
+/// Key of the specialisation. The reference's `enum class OptimizerSuite { CERES, DEFAULT = CERES }` (forward.hpp:14-17) has no HIP
+/// enumerator; a scoped enum admits every value of its underlying type, so the key is a constant of the enum type and forward.hpp
+/// stays untouched (a tree that adds `HIP = 1` to the enum names the same specialisation).
+inline constexpr auto kOptimizerSuiteHIP = static_cast<OptimizerSuite>(1);
+
 template <>
-class Optimizer<OptimizerSuite::HIP> final : public AbstractOptimizer {
+class Optimizer<kOptimizerSuiteHIP> final : public AbstractOptimizer {
  public:
   /// Same signature as Optimizer<CERES> (ceres/optimizer.hpp:28; backend.cpp:46). `device` / the in-tree solver options of cc:38-54
   /// (max_num_iterations = 5) are fixed here as they are fixed there.
@@ -102,6 +121,13 @@ class Optimizer<OptimizerSuite::HIP> final : public AbstractOptimizer {
   /// Inertial Jacobian: HS_INERTIAL_AS_REFERENCE reproduces evaluators/inertial.cpp:131-198 as written (default), HS_INERTIAL_EXACT the
   /// derivative of the prediction (see include/hyperslam_hip.h).
   auto setInertialJacobian(const int mode) -> void { CHECK_EQ(hs_set_inertial_jacobian(handle_, mode), HS_OK) << hs_last_error(handle_); }
+
+  /// Knot spacing of the two bias splines updateSensor() creates (the reference has no YAML key for it; its test uses 10 state
+  /// separations, tests/internal/tests/optimizers/evaluators/inertial.cpp:48-49). Takes effect for splines that are still empty.
+  auto setBiasSeparation(const Stamp separation) -> void {
+    CHECK_GT(separation, 0);
+    bias_separation_ = separation;
+  }
 
   /// cc:276-280. Tables from the live variables -> hs_solve -> write-back in place.
   auto optimize() -> void final {
@@ -151,10 +177,7 @@ class Optimizer<OptimizerSuite::HIP> final : public AbstractOptimizer {
     }
     check(hs_set_landmarks(handle_, static_cast<int>(landmark_table.size()), lm.data(), /*constant=*/nullptr));
 
-    // ---- residual tables. A residual block whose landmark left the active set was removed with it (cc:365-371): prune. ----
-    const auto retired = [&](const auto* observation) { return !landmark_id.contains(&observation->landmark()); };
-    std::erase_if(bearings_, retired);
-    std::erase_if(pixels_, retired);
+    // ---- residual tables. Residual blocks of retired landmarks went with them in updateLandmarks() (cc:365-371). ----
     {
       std::vector<double> stamps, values;
       std::vector<std::int32_t> ids, cams;
@@ -183,25 +206,42 @@ class Optimizer<OptimizerSuite::HIP> final : public AbstractOptimizer {
       check(hs_set_prior_residuals(handle_, static_cast<int>(stamps.size()), stamps.data(), values.data(), ids.data()));
     }
 
-    // ---- IMU: static blocks {T_bs, i_g, i_a, S_g, X_a} (inertial.cpp:36-49) + the two R^3 bias splines (imu.cpp:64-81) + gravity ----
+    // ---- IMU: static blocks {T_bs, i_g, i_a, S_g, X_a} (inertial.cpp:36-49) + the two R^3 bias splines (imu.cpp:64-81) + gravity.
+    //      Ceres only sees the bias elements some residual block refers to (exteroceptive.cpp:64-76); the table holds exactly that range:
+    //      elements [bias_first, bias_first + n_bias) of both splines. ----
     std::vector<Traits<IMU>::GyroscopeBias*> bias_g_elements;
     std::vector<Traits<IMU>::AccelerometerBias*> bias_a_elements;
     if (imu_ != nullptr && !inertials_.empty()) {
       const auto parameters = imu_->parameters();
       for (const auto& element : imu_->gyroscopeBias().elements()) bias_g_elements.push_back(static_cast<Traits<IMU>::GyroscopeBias*>(element.get()));
       for (const auto& element : imu_->accelerometerBias().elements()) bias_a_elements.push_back(static_cast<Traits<IMU>::AccelerometerBias*>(element.get()));
-      CHECK_EQ(bias_g_elements.size(), bias_a_elements.size());  // both splines are extended together (abstract.cpp:278-290)
+      CHECK_EQ(bias_g_elements.size(), bias_a_elements.size());  // both splines are created and extended together (updateSensor)
+      const auto bias_layout = imu_->gyroscopeBias().interpolator()->layout();
+      const auto bias_order = bias_layout.outer.size;
+      CHECK_GE(bias_g_elements.size(), static_cast<std::size_t>(bias_order));
+      const auto bias_dt = bias_g_elements[1]->stamp() - bias_g_elements[0]->stamp();
+      auto [oldest, newest] = std::minmax_element(inertials_.begin(), inertials_.end(),
+                                                  [](const auto* a, const auto* b) { return a->measurement().stamp() < b->measurement().stamp(); });
+      // first element a residual at `stamp` reads, counted from element `from`, with the library's own arithmetic (hyperslam_hip.h:
+      // control point j at bias_t0 + j * bias_dt, segment floor((stamp - t0) / dt), elements segment - (order - 1) / 2 ... + order - 1)
+      const auto first_read = [&](const Stamp stamp, const std::size_t from) {
+        return static_cast<std::ptrdiff_t>(std::floor((stamp - bias_g_elements[from]->stamp()) / bias_dt)) - (bias_order - 1) / 2;
+      };
+      auto bias_first = static_cast<std::size_t>(std::max<std::ptrdiff_t>(0, first_read((*oldest)->measurement().stamp(), 0)));
+      while (bias_first > 0 && first_read((*oldest)->measurement().stamp(), bias_first) < 0) --bias_first;  // a stamp within rounding of a knot
+      const auto bias_end = std::min<std::ptrdiff_t>(static_cast<std::ptrdiff_t>(bias_g_elements.size()),
+                                                     static_cast<std::ptrdiff_t>(bias_first) + first_read((*newest)->measurement().stamp(), bias_first) + bias_order + 1);
+      bias_g_elements = {bias_g_elements.begin() + static_cast<std::ptrdiff_t>(bias_first), bias_g_elements.begin() + bias_end};
+      bias_a_elements = {bias_a_elements.begin() + static_cast<std::ptrdiff_t>(bias_first), bias_a_elements.begin() + bias_end};
       const auto n_bias = bias_g_elements.size();
       std::vector<double> bias_g(4 * n_bias), bias_a(4 * n_bias);
       for (std::size_t j = 0; j < n_bias; ++j) {
         std::copy_n(bias_g_elements[j]->asVector().data(), 4, &bias_g[4 * j]);  // Stamped<R3> [b(3) t]
         std::copy_n(bias_a_elements[j]->asVector().data(), 4, &bias_a[4 * j]);
       }
-      const auto bias_order = imu_->gyroscopeBias().interpolator()->layout().outer.size;
-      const auto bias_dt = n_bias > 1 ? bias_g[7] - bias_g[3] : 1.0;
       check(hs_set_imu(handle_, parameters[0]->asVector().data(), parameters[1]->asVector().data(), parameters[2]->asVector().data(),
                        parameters[3]->asVector().data(), parameters[4]->asVector().data(), bias_order, bias_g[3], bias_dt, static_cast<int>(n_bias), bias_g.data(),
-                       bias_a.data(), /*bias_constant=*/0));  // cc:65-66 set*BiasConstant(false)
+                       bias_a.data(), /*bias_constant=*/0));  // cc:62-63 set*BiasConstant(false)
       check(hs_set_gravity(handle_, mutableEnvironment().gravity().data(), gravity_constant_ ? 1 : 0));
       std::vector<double> stamps, values;
       for (const auto* o : inertials_) {
@@ -258,6 +298,7 @@ class Optimizer<OptimizerSuite::HIP> final : public AbstractOptimizer {
 
   /// cc:286-345 without the Ceres calls: variables_ is the set of state elements that are parameter blocks. New elements of the padded
   /// range join; elements outside it leave once no residual block touches them (cc:330-341). Constancy is decided at optimize().
+  /// AbstractOptimizer::setWindow runs updateLandmarks() first (abstract.cpp:52-56), so the observation lists are already pruned.
   auto updateState(const Range& range) -> void final {
     const auto& elements = state().elements();
     const auto [left_padding, right_padding] = state().interpolator()->layout().outerPadding();
@@ -273,13 +314,16 @@ class Optimizer<OptimizerSuite::HIP> final : public AbstractOptimizer {
     for (const auto* o : priors_) stamps.push_back(o->measurement().stamp());
     for (const auto* o : inertials_) stamps.push_back(o->measurement().stamp());
     std::sort(stamps.begin(), stamps.end());
-    const auto order = state().interpolator()->layout().outer.size;
-    const auto reach = separation_ * (order / 2);  // a residual at t touches control points within (t - reach - dt, t + reach]
+    // A residual at t in [t_i, t_i+1) reads the control points i - left_padding ... i + right_padding, i.e. those with stamps in
+    // (t - (left_padding + 1) dt, t + right_padding dt]. One separation of slack on the old side: a control point that stays one window
+    // longer is a constant block without residuals (harmless), one that leaves too early would fail the library's range check.
+    const auto ahead = separation_ * right_padding;
+    const auto behind = separation_ * (left_padding + 2);
     std::erase_if(variables_, [&](const auto* variable) {
       const auto stamp = variable->stamp();
       if (!(stamp < stamp_0 || stamp_n < stamp)) return false;
-      const auto itr = std::lower_bound(stamps.begin(), stamps.end(), stamp - reach);
-      return itr == stamps.end() || *itr >= stamp + reach + separation_;  // no residual block left on it
+      const auto itr = std::lower_bound(stamps.begin(), stamps.end(), stamp - ahead);
+      return itr == stamps.end() || *itr >= stamp + behind;  // no residual block left on it (cc:331-341)
     });
   }
 
@@ -288,13 +332,59 @@ class Optimizer<OptimizerSuite::HIP> final : public AbstractOptimizer {
     landmarks_.insert(&landmark);
   }
 
-  auto updateLandmarks(const Range& range) -> void final {  // cc:360-382 (the residual blocks go at the next optimize())
+  /// cc:360-382: landmarks whose observation range left the window are retired, and RemoveParameterBlock takes their residual blocks
+  /// along (enable_fast_removal, cc:365-371) — before updateState() looks for state elements without residuals (abstract.cpp:52-56).
+  /// Then the retirement rule for the residual kinds Ceres never removes (inertial, pose prior): everything older than the window and
+  /// than every retained landmark goes, so the tables (and variables_) stay bounded while the IMU runs.
+  auto updateLandmarks(const Range& range) -> void final {
     std::erase_if(landmarks_, [&](const auto* landmark) { return !landmark->range().intersects(range); });
+    const auto retired = [&](const auto* observation) { return !landmarks_.contains(&observation->landmark()); };
+    std::erase_if(bearings_, retired);
+    std::erase_if(pixels_, retired);
+    auto oldest = range.lowerBound();
+    for (const auto* landmark : landmarks_) oldest = std::min(oldest, landmark->range().lowerBound());
+    const auto expired = [&](const auto* observation) { return observation->measurement().stamp() < oldest; };
+    std::erase_if(inertials_, expired);
+    std::erase_if(priors_, expired);
   }
 
-  /// CHECK(false) upstream (cc:384-386): the bias splines are extended by AbstractOptimizer::process(InertialMeasurement)
-  /// (abstract.cpp:278-290), their elements are read at optimize(). Nothing to register.
-  auto updateSensor(IMU& /* imu */, const Range& /* range */) -> void final {}
+  /// CHECK(false) upstream (cc:384-386), yet AbstractOptimizer::process(InertialMeasurement) calls it whenever a bias spline is empty
+  /// or does not contain the stamp and then DCHECKs that it does (abstract.cpp:278-289): this override is the only place the bias
+  /// elements can come from. Both splines get the same knots: created at the first call, extended past the range afterwards.
+  auto updateSensor(IMU& imu, const Range& range) -> void final {
+    DCHECK(imu_ == &imu);
+    extendBias<Traits<IMU>::GyroscopeBias>(imu.gyroscopeBias(), range);
+    extendBias<Traits<IMU>::AccelerometerBias>(imu.accelerometerBias(), range);
+  }
+
+  /// Uniform knots at multiples of bias_separation_ (shifted by the left padding of the interpolator, like the state's bootstrap at
+  /// abstract.cpp:87-93); a new element starts from the value of the last one (the bias random walk's best guess), zero for the first.
+  /// The spline is kept valid one state separation beyond the range, so that a sample on the upper boundary of the window — and the
+  /// extrapolated control point abstract.cpp:127-137 adds next — stay inside. Same rule as Optimizer::extendBias of the host mirror
+  /// (hyperslam_amd/host/optimizer.hpp), which the replay tests run.
+  template <typename TElement>
+  auto extendBias(AbstractState& bias, const Range& range) -> void {
+    auto& elements = bias.elements();
+    const auto layout = bias.interpolator()->layout();
+    const auto [left_padding, right_padding] = layout.outerPadding();
+    if (elements.empty()) {
+      const auto first = std::floor(range.lowerBound() / bias_separation_) * bias_separation_ - left_padding * bias_separation_;
+      for (auto i = 0; i < layout.outer.size; ++i) {
+        auto element = std::make_unique<TElement>();
+        element->stamp() = first + i * bias_separation_;
+        element->variable().setZero();
+        elements.insert(std::move(element));
+      }
+    }
+    // range() of the spline ends at the stamp of its right_padding-th element from the end
+    while ((*std::prev(elements.end(), 1 + right_padding))->stamp() <= range.upperBound() + separation_) {
+      const auto& last = static_cast<const TElement&>(**elements.rbegin());
+      auto element = std::make_unique<TElement>();
+      element->stamp() = last.stamp() + bias_separation_;
+      element->variable() = last.variable();
+      elements.insert(std::move(element));
+    }
+  }
 
   hs_problem* handle_{nullptr};
   std::vector<const Camera*> cameras_;
@@ -306,9 +396,10 @@ class Optimizer<OptimizerSuite::HIP> final : public AbstractOptimizer {
   std::vector<ManifoldObservation<Manifold>*> priors_;
   std::vector<InertialObservation<Manifold>*> inertials_;
   bool rotation_constant_{false}, translation_constant_{false}, gravity_constant_{true};
+  Stamp bias_separation_{1.0};
 };
 
-using HipOptimizer = Optimizer<OptimizerSuite::HIP>;
+using HipOptimizer = Optimizer<kOptimizerSuiteHIP>;
 
 /// The branch of Backend::Backend (backend.cpp:37-60) for `suite: hip`: same sequence as the Ceres branch — optimizer, environment,
 /// state constancy from the YAML — minus the Ceres manifold objects (the library applies the same retractions).

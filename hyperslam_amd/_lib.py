@@ -114,6 +114,8 @@ _SIGNATURES = {
     "manifold_tangent_size": (C.c_int, [C.c_int, C.c_int]),
     "manifold_plus": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p]),
     "manifold_plus_jacobian": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p]),
+    "manifold_minus": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p]),
+    "manifold_minus_jacobian": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p]),
     "set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
     "set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "band_blocks": (C.c_int, [C.c_void_p]),

@@ -1613,12 +1613,12 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
     if (n_b) {
       HIP_TRY(hipMemcpyAsync(h + n_cp8 + n_lm3, p->d_bias_g.p, n_b * 8, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipMemcpyAsync(h + n_cp8 + n_lm3 + n_b, p->d_bias_a.p, n_b * 8, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipMemcpyAsync(h + n_cp8 + n_lm3 + 2 * n_b, p->d_gravity.p, 24, hipMemcpyDeviceToHost, s));
     }
-    p->results_cached = true;  // (valid once the synchronisation below has returned)
+    if (p->has_imu) HIP_TRY(hipMemcpyAsync(h + n_cp8 + n_lm3 + 2 * n_b, p->d_gravity.p, 24, hipMemcpyDeviceToHost, s));  // also with an empty bias table
   }
   HIP_TRY(hipMemcpyAsync(&st, p->d_state.p, sizeof(st), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  p->results_cached = p->want_results;  // only once every copy above has completed: a failed copy or synchronisation leaves the getters on the device path
   if (p->host_timing) {
     const auto host_t5 = std::chrono::steady_clock::now();
     const double tl = std::chrono::duration<double, std::milli>(host_t4 - host_t3).count(), tw = std::chrono::duration<double, std::milli>(host_t5 - host_t4).count();
@@ -1634,6 +1634,7 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
   summary->num_successful_steps = st.num_successful;
   summary->termination = st.termination;
   summary->num_residual_blocks = p->T.n_vis + p->T.n_pri + p->T.n_ine;
+  if (!stages) summary->linearize_ms = summary->schur_ms = summary->solve_ms = summary->update_ms = -1.0;  // not measured (hs_set_stage_timing)
   for (int it = 0; stages && it < max_iterations; ++it) {
     float t[4] = {0, 0, 0, 0};
     for (int k = 0; k < 4; ++k) (void)hipEventElapsedTime(&t[k], ev[4 * it + k], ev[4 * it + k + 1]);
@@ -1654,12 +1655,16 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
   return HS_OK;
 }
 
-int hs_debug_read(hs_problem* p, double* dst, int n) {
+#if HS_PROFILE_HOOKS
+/// Profiling builds only (hipcc -DHS_PROFILE_HOOKS=1, tools/build_profiling_lib.sh): the phase timestamps the kernels wrote under
+/// HS_DEBUG_FLAGS 16 / 32. Not part of the C ABI: the product library neither contains the hooks nor exports this function.
+extern "C" int hs_debug_read(hs_problem* p, double* dst, int n) {
   if (!p || !dst) return HS_ERR_INVALID;
   HIP_TRY(hipMemcpyAsync(dst, p->d_xpart.p, size_t(n) * 8, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   return HS_OK;
 }
+#endif
 
 int hs_snapshot(hs_problem* p) {
   if (!p) return HS_ERR_INVALID;
@@ -2056,6 +2061,37 @@ int hs_manifold_plus(hs_problem* p, int kind, int ambient, int n, const double* 
 int hs_manifold_plus_jacobian(hs_problem* p, int kind, int ambient, int n, const double* x, double* jacobian) {
   if (n > 0 && !jacobian) return HS_ERR_INVALID;
   return manifold_launch(p, kind, ambient, n, x, nullptr, nullptr, jacobian);
+}
+
+static int manifold_minus_launch(hs_problem* p, int kind, int ambient, int n, const double* y, const double* x, double* out, double* jac) {
+  if (!p || n < 0 || (n && !x)) return HS_ERR_INVALID;
+  const int tangent = hs_manifold_tangent_size(kind, ambient);
+  if (tangent < 0) HS_FAIL(HS_ERR_INVALID, "unknown manifold kind / ambient size");
+  if (out && !y) HS_FAIL(HS_ERR_INVALID, "y is null");
+  if (n == 0 || tangent == 0) return HS_OK;
+  HIP_TRY(hipSetDevice(p->device));
+  hipStream_t s = p->stream;
+  DBuf<double> d_x, d_y, d_o, d_j;
+  HIP_TRY(d_x.upload(std::vector<double>(x, x + size_t(n) * ambient), s));
+  if (out) HIP_TRY(d_y.upload(std::vector<double>(y, y + size_t(n) * ambient), s));
+  if (out) HIP_TRY(d_o.reserve(size_t(n) * tangent));
+  if (jac) HIP_TRY(d_j.reserve(size_t(n) * ambient * tangent));
+  k_manifold_minus<<<(n + kBlock - 1) / kBlock, kBlock, 0, s>>>(kind, ambient, tangent, n, out ? d_y.p : nullptr, d_x.p, out ? d_o.p : nullptr, jac ? d_j.p : nullptr);
+  HIP_TRY(hipGetLastError());
+  if (out) HIP_TRY(hipMemcpyAsync(out, d_o.p, size_t(n) * tangent * 8, hipMemcpyDeviceToHost, s));
+  if (jac) HIP_TRY(hipMemcpyAsync(jac, d_j.p, size_t(n) * ambient * tangent * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return HS_OK;
+}
+
+int hs_manifold_minus(hs_problem* p, int kind, int ambient, int n, const double* y, const double* x, double* y_minus_x) {
+  if (n > 0 && hs_manifold_tangent_size(kind, ambient) > 0 && !y_minus_x) return HS_ERR_INVALID;
+  return manifold_minus_launch(p, kind, ambient, n, y, x, y_minus_x, nullptr);
+}
+
+int hs_manifold_minus_jacobian(hs_problem* p, int kind, int ambient, int n, const double* x, double* jacobian) {
+  if (n > 0 && hs_manifold_tangent_size(kind, ambient) > 0 && !jacobian) return HS_ERR_INVALID;
+  return manifold_minus_launch(p, kind, ambient, n, nullptr, x, nullptr, jacobian);
 }
 
 int hs_sample_trajectory(hs_problem* p, int n, const double* stamps, double* pose, double* velocity, double* acceleration) {

@@ -205,6 +205,14 @@ HSD Quat quat_plus(Quat x, V3 d) {
   s /= n;
   return qmul(Quat{s * d.x, s * d.y, s * d.z, c}, x);
 }
+/// EigenQuaternionManifold::Minus: [v ; w] = y (x) conj(x), delta = atan2(|v|, w) / |v| * v (zero for v = 0).
+HSD V3 quat_minus(Quat y, Quat x) {
+  const Quat r = qmul(y, qconj(x));
+  const double n = sqrt(r.x * r.x + r.y * r.y + r.z * r.z);
+  if (n == 0.0) return V3{0.0, 0.0, 0.0};
+  const double s = atan2(n, r.w) / n;
+  return V3{s * r.x, s * r.y, s * r.z};
+}
 /// Householder vector of Ceres' SphereManifold<3> (manifolds/variables/bearing.cpp:15, gravity.hpp:11-17).
 HSD void sphere_householder(const double* x, double* v, double* beta) {
   const double sigma = x[0] * x[0] + x[1] * x[1];
@@ -246,6 +254,31 @@ HSD void sphere_plus_jacobian(const double* x, double* J) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int r = 0; r < 3; ++r) J[r * 2 + i] = nx * ((r == i ? 1.0 : 0.0) - beta * v[r] * v[i]);
+}
+/// SphereManifold<3>::Minus: h = H y / |x|, delta = atan2(|h_t|, h_last) / |h_t| * h_t over the two tangent entries of h.
+HSD void sphere_minus(const double* y, const double* x, double* out) {
+  double v[3], beta;
+  sphere_householder(x, v, &beta);
+  const double nx = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+  const double vy = beta * (v[0] * y[0] + v[1] * y[1] + v[2] * y[2]);
+  const double h0 = (y[0] - v[0] * vy) / nx, h1 = (y[1] - v[1] * vy) / nx, h2 = (y[2] - v[2] * vy) / nx;
+  const double n = sqrt(h0 * h0 + h1 * h1);
+  if (n == 0.0) {
+    out[0] = out[1] = 0.0;
+    return;
+  }
+  const double s = atan2(n, h2) / n;
+  out[0] = s * h0, out[1] = s * h1;
+}
+/// 2x3 MinusJacobian of SphereManifold<3> (row-major): the first two rows of H / |x|.
+HSD void sphere_minus_jacobian(const double* x, double* J) {
+  double v[3], beta;
+  sphere_householder(x, v, &beta);
+  const double nx = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) J[i * 3 + c] = ((c == i ? 1.0 : 0.0) - beta * v[i] * v[c]) / nx;
 }
 
 // ---- losses (Ceres semantics; constants optimizer.cpp:204,226,250,267-268) -----------------------

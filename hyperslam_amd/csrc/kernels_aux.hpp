@@ -143,4 +143,53 @@ __global__ void __launch_bounds__(kBlock) k_manifold_plus(int kind, int ambient,
   }
 }
 
+/// Batched Manifold::Minus / MinusJacobian (hs_manifold_minus*, wrapper.hpp:44-50). One element per lane; jac is tangent x ambient.
+__global__ void __launch_bounds__(kBlock) k_manifold_minus(int kind, int ambient, int tangent, int n, const double* __restrict__ y,
+                                                           const double* __restrict__ x, double* __restrict__ out, double* __restrict__ jac) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* xi = x + size_t(i) * ambient;
+  if (out) {
+    const double* yi = y + size_t(i) * ambient;
+    double* o = out + size_t(i) * tangent;
+    switch (kind) {
+      case 1:
+        for (int c = 0; c < ambient; ++c) o[c] = yi[c] - xi[c];
+        break;
+      case 2:
+      case 3: {
+        const V3 d = quat_minus(Quat{yi[0], yi[1], yi[2], yi[3]}, Quat{xi[0], xi[1], xi[2], xi[3]});
+        o[0] = d.x, o[1] = d.y, o[2] = d.z;
+        o[3] = yi[4] - xi[4], o[4] = yi[5] - xi[5], o[5] = yi[6] - xi[6];
+        break;
+      }
+      case 4: sphere_minus(yi, xi, o); break;
+      case 5: o[0] = yi[0] - xi[0], o[1] = yi[1] - xi[1], o[2] = yi[2] - xi[2]; break;
+      default: break;
+    }
+  }
+  if (jac) {
+    double* J = jac + size_t(i) * ambient * tangent;
+    for (int e = 0; e < ambient * tangent; ++e) J[e] = 0.0;
+    switch (kind) {
+      case 1:
+        for (int c = 0; c < ambient; ++c) J[c * ambient + c] = 1.0;
+        break;
+      case 2:
+      case 3: {
+        // row c = d/dy of the vector part of y (x) conj(x), entry c
+        const double qx = xi[0], qy = xi[1], qz = xi[2], qw = xi[3];
+        J[0 * ambient + 0] = qw, J[0 * ambient + 1] = qz, J[0 * ambient + 2] = -qy, J[0 * ambient + 3] = -qx;
+        J[1 * ambient + 0] = -qz, J[1 * ambient + 1] = qw, J[1 * ambient + 2] = qx, J[1 * ambient + 3] = -qy;
+        J[2 * ambient + 0] = qy, J[2 * ambient + 1] = -qx, J[2 * ambient + 2] = qw, J[2 * ambient + 3] = -qz;
+        J[3 * ambient + 4] = 1.0, J[4 * ambient + 5] = 1.0, J[5 * ambient + 6] = 1.0;
+        break;
+      }
+      case 4: sphere_minus_jacobian(xi, J); break;
+      case 5: J[0 * 4 + 0] = 1.0, J[1 * 4 + 1] = 1.0, J[2 * 4 + 2] = 1.0; break;
+      default: break;
+    }
+  }
+}
+
 }  // namespace hs

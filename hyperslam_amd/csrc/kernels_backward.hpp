@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(64) k_band_backward_w(Tables T, BackJob j0, Ba
   const int bw = T.bw, ncb = 6 * bw, np = T.np;
   const int n_rows = J.n_rows, jtop = J.n_rows + J.given - 1;
   constexpr int D = kBackDepth;
-  const bool prof = (T.debug_flags & 16) && lane == 0;  // HS_DEBUG_FLAGS: phase timestamps (100 MHz clock) -> hs_debug_read
+  const bool prof = prof_enabled(T.debug_flags, 16) && lane == 0;  // HS_DEBUG_FLAGS: phase timestamps (100 MHz clock) -> hs_debug_read
   long long* tlog = reinterpret_cast<long long*>(T.xpart) + 64 * 1024 + 2048 * blockIdx.x;
   if (prof) tlog[0] = wall_clock64();
   // Slot s of lane l carries the row (ring block 10 s + l / 6, component l % 6): block row beta lives in ring block beta mod bw.
@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(64) k_band_backward_w(Tables T, BackJob j0, Ba
 #pragma unroll
     for (int b = 0; b < D; ++b) {
       step(j - b, ub[b], yb[b]);
-      if (prof && j - b >= 0 && (T.debug_flags & 32)) tlog[16 + j - b] = wall_clock64();
+      if (prof && j - b >= 0 && prof_enabled(T.debug_flags, 32)) tlog[16 + j - b] = wall_clock64();
       if (j - b == j_pub) publish();
     }
   }

@@ -7,6 +7,14 @@ namespace hs {
 
 constexpr int kBlock = 256;
 
+/// Phase-timestamp hooks (wall_clock64 writes behind HS_DEBUG_FLAGS 16 / 32, read by tools/*_phase_timing.py) exist only in
+/// profiling builds: with the default HS_PROFILE_HOOKS = 0 every `prof` predicate below is a compile-time false and the product
+/// kernels carry no timing code.
+#ifndef HS_PROFILE_HOOKS
+#define HS_PROFILE_HOOKS 0
+#endif
+HSD bool prof_enabled(int debug_flags, int bit) { return HS_PROFILE_HOOKS && (debug_flags & bit); }
+
 HSD double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(kCholThreads + kCholIo) k_band_factor(Tables T
       }
       lds_barrier();
       for (int rho = l; rho < T.np; rho += 64) T.ybuf[rho] = xs[rho];  // y = U^-T g
-      if (l == 0) st->chol_failed = fail;
+      if (l == 0 && fail) st->chol_failed = 1;  // never cleared here: k_factor_decoupled_rows may have raised it earlier in this iteration
     }
     return;
   }
@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(kCholThreads + kCholIo) k_band_factor(Tables T
     }
   };
   lds_barrier();  // initial window loaded / staged
-  const bool prof = (T.debug_flags & 16) && tid == 0;
+  const bool prof = prof_enabled(T.debug_flags, 16) && tid == 0;
   long long* tlog = reinterpret_cast<long long*>(T.xpart);
 
 #define UIDX(a, c) ((a) * 6 - (a) * ((a)-1) / 2 + ((c) - (a)))
@@ -430,7 +430,7 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
         tput(tb, rowbuf + (i & 1) * 6 * ld, i + 2);
         fetch(vb, i + 5 + bw);
         tfetch(tb, i + 4);
-        if ((T.debug_flags & 16) && l == 0) reinterpret_cast<long long*>(T.xpart)[8 * i + 7] = wall_clock64();
+        if (prof_enabled(T.debug_flags, 16) && l == 0) reinterpret_cast<long long*>(T.xpart)[8 * i + 7] = wall_clock64();
         lds_barrier();
         junction_io(i);
         if (i + 1 < n_steps) {
@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
               if (a <= c) J.Ubk[size_t(i) * 24 + (a * 6 - a * (a - 1) / 2 + (c - a))] = w[a];
           }
         }
-        if ((T.debug_flags & 16) && l == 0) reinterpret_cast<long long*>(T.xpart)[8 * i + 6] = wall_clock64();
+        if (prof_enabled(T.debug_flags, 16) && l == 0) reinterpret_cast<long long*>(T.xpart)[8 * i + 6] = wall_clock64();
         lds_barrier();
         if (m_at >= 0 && i + 1 == m_at) {
           junction_wait();
@@ -501,7 +501,7 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
 
   if (wave == 3) {  // ================================ panel wave (alone on SIMD 3) ================================
 #define UIDX(a, c) ((a) * 6 - (a) * ((a)-1) / 2 + ((c) - (a)))
-    const bool pprof = (T.debug_flags & 16) && l == 0;
+    const bool pprof = prof_enabled(T.debug_flags, 16) && l == 0;
     long long* plog = reinterpret_cast<long long*>(T.xpart);
     // column bookkeeping of this lane (loop invariant): c = l + 64 m; lanes past the row write to the pad column ncb + 1
     int c_rd[PC], c_src[PC], c_wr[PC];
@@ -700,7 +700,7 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
       rhs[m][a] = (in && t_kk[m] == 0) ? J.g_s[6 * r + a] : 0.0;
     }
   }
-  const bool cprof = (T.debug_flags & 16) && tid == 0;  // coarse phases of this workgroup -> tlog[8 (200 + 10 job) + ..]
+  const bool cprof = prof_enabled(T.debug_flags, 16) && tid == 0;  // coarse phases of this workgroup -> tlog[8 (200 + 10 job) + ..]
   long long* clog = reinterpret_cast<long long*>(T.xpart) + 8 * (200 + 10 * blockIdx.x);
   if (cprof) clog[0] = wall_clock64();  // tiles requested
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -708,7 +708,7 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
   lds_barrier();  // init
   lds_barrier();  // prologue: X_0 complete
   if (cprof) clog[2] = wall_clock64();
-  const bool prof = (T.debug_flags & 16) && tid == 0 && blockIdx.x == 0;
+  const bool prof = prof_enabled(T.debug_flags, 16) && tid == 0 && blockIdx.x == 0;
   long long* tlog = reinterpret_cast<long long*>(T.xpart);
   for (int i = 0; i < n_steps; ++i) {
     if (prof) tlog[8 * i + 0] = wall_clock64();
@@ -875,7 +875,7 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward2(Tables T, BackJ
   const int tid = threadIdx.x;
   constexpr int nthr = kCholThreads;
   const int bw = T.bw, ncb = 6 * bw, np = T.np;
-  const bool cprof = (T.debug_flags & 16) && tid == 0;  // coarse phases -> xpart[8 (230 + 10 block) + ..] (tools/chol_phase_timing.py)
+  const bool cprof = prof_enabled(T.debug_flags, 16) && tid == 0;  // coarse phases -> xpart[8 (230 + 10 block) + ..] (tools/chol_phase_timing.py)
   long long* clog = reinterpret_cast<long long*>(T.xpart) + 8 * (230 + 10 * blockIdx.x);
   if (cprof) clog[0] = wall_clock64();
   const int n_own = 6 * J.n_rows, n_all = 6 * (J.n_rows + J.given);
@@ -1222,7 +1222,7 @@ __global__ void __launch_bounds__(kWideThreads) k_band_factor_wide(Tables T) {
     __syncthreads();
   }
 #undef UIDX
-  if (tid == 0) st->chol_failed = fail;
+  if (tid == 0 && fail) st->chol_failed = 1;  // (reset by begin_iteration; an earlier kernel of this iteration may have raised it)
 }
 
 /// Backward sweep U x = y (y in T.ybuf, possibly corrected by the border solve) + step outputs and model-cost reductions.
@@ -1378,7 +1378,7 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense_factor(Tables T, int n_
   // HS_DEBUG_FLAGS 16: phase timestamps (100 MHz clock) -> hs_debug_read, tools/dense_phase_timing.py. Per block row k (8 slots):
   // [0] barrier after A, [1] barrier after B (thread 0); [2] row owner (k, k + 1): solve done, [3] stores issued; diagonal owner
   // (k + 1, k + 1): [4] update done, [5] factorised and published
-  const bool prof = T.debug_flags & 16;
+  const bool prof = prof_enabled(T.debug_flags, 16);
   long long* tlog = reinterpret_cast<long long*>(T.xpart) + 8 * 300;
   if (prof && tid == 0) tlog[-1] = wall_clock64();
   // ---- static tile ownership: slot t = tid + 512 m -> (i, j), row major over rows i with columns j = i .. min(i + bw, n) - 1 and

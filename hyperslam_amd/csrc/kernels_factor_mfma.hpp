@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(64 * (NC + 3)) k_band_factor_mfma(Tables T) {
       }
     }
   };
-  const bool prof = (T.debug_flags & 16) && l == 0 && blockIdx.x == 0;  // HS_DEBUG_FLAGS: phase timestamps -> hs_debug_read
+  const bool prof = prof_enabled(T.debug_flags, 16) && l == 0 && blockIdx.x == 0;  // HS_DEBUG_FLAGS: phase timestamps -> hs_debug_read
   long long* tlog = reinterpret_cast<long long*>(T.xpart);
 
   if (hw < 3) {  // ================================ compute waves ================================

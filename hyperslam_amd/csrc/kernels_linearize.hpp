@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(lin_block<K>()) k_linearize_visual(Tables T, d
   const bool cps_in_lds = size_t(8) * T.sp.n_cp * sizeof(double) <= 24 * 1024;
   const double* cps = cps_in_lds ? smem : T.cp;
   double* slab = smem + (cps_in_lds ? 8 * T.sp.n_cp : 0) + (threadIdx.x >> 6) * 64 * LREC;  // this wave's 64 records
-  const bool lprof = (T.debug_flags & 32) && threadIdx.x == 0 && blockIdx.x < 256;
+  const bool lprof = prof_enabled(T.debug_flags, 32) && threadIdx.x == 0 && blockIdx.x < 256;
   long long* llog = reinterpret_cast<long long*>(T.xpart) + 32 * 1024 + 4 * blockIdx.x;
   if (lprof) llog[0] = wall_clock64();
   if (cps_in_lds) stage_cps(T.cp, smem, 8 * T.sp.n_cp);

@@ -247,7 +247,7 @@ HSD void seg_gram_body(const Tables& T, const int bid) {
   const int first = T.sw_seg[bid], sp = bid - T.sw_ptr[first], nsp = T.sw_ptr[first + 1] - T.sw_ptr[first];
   const int tid = threadIdx.x;
   const int stream = tid / TPS, tb = tid % TPS, rg = tb / CG, cg = tb % CG;
-  const bool sprof = (T.debug_flags & 32) && tid == 0 && sp == 0 && first < 128;
+  const bool sprof = prof_enabled(T.debug_flags, 32) && tid == 0 && sp == 0 && first < 128;
   long long* slog = reinterpret_cast<long long*>(T.xpart) + 8 * 1024 + 8 * first;
   if (sprof) slog[0] = wall_clock64();
   // a tile is needed if some column block >= the row block (upper block triangle); column group 0 also carries J'r
@@ -378,7 +378,7 @@ HSD void group_gram_body(const Tables& T, const int batch, const int bid) {
 #pragma unroll
     for (int e = 0; e < 6; ++e) qacc[m][e] = 0.0;
   }
-  const bool gprof = (T.debug_flags & 32) && tid == 0 && sp == 0 && cf < 128;
+  const bool gprof = prof_enabled(T.debug_flags, 32) && tid == 0 && sp == 0 && cf < 128;
   long long* glog = reinterpret_cast<long long*>(T.xpart) + 8 * cf;
   if (gprof) glog[0] = wall_clock64();
   const int dl0 = T.cf_ptr[cf], dl1 = T.cf_ptr[cf + 1];

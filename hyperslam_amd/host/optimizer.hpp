@@ -57,6 +57,7 @@ int HSF(get_bias)(hs_problem*, double*, double*);
 int HSF(get_gravity)(hs_problem*, double*);
 int HSF(sample_trajectory)(hs_problem*, int, const double*, double*, double*, double*);
 int HSF(process_tracks)(hs_problem*, double, int, const double*, const double*, double*, double*, double*);
+int HSF(set_stage_timing)(hs_problem*, int);
 }
 
 namespace hyper_hip {

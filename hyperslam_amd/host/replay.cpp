@@ -21,6 +21,9 @@ int main(int argc, char** argv) {
   const std::vector<Camera> cams = euroc_cameras();
   IMU imu;
   Optimizer optimizer(opt, cams, with_imu ? &imu : nullptr);
+  // the per-stage split printed below needs the stage events (four barrier packets per iteration, off by default): HS_REPLAY_STAGES=1
+  const bool stages = std::getenv("HS_REPLAY_STAGES") && std::atoi(std::getenv("HS_REPLAY_STAGES")) != 0;
+  if (stages && HSF(set_stage_timing)(optimizer.handle(), 1) != HS_OK) return 1;
   double total_solve_ms = 0, max_solve_ms = 0, stage_ms[4] = {0, 0, 0, 0};
   long total_blocks = 0;
   int solves_seen = 0;
@@ -33,7 +36,7 @@ int main(int argc, char** argv) {
       total_solve_ms += s.total_ms, max_solve_ms = std::max(max_solve_ms, s.total_ms);
       solve_ms.push_back(s.total_ms);
       total_blocks += long(s.num_residual_blocks) * s.num_iterations;
-      stage_ms[0] += s.linearize_ms, stage_ms[1] += s.schur_ms, stage_ms[2] += s.solve_ms, stage_ms[3] += s.update_ms;
+      if (stages) stage_ms[0] += s.linearize_ms, stage_ms[1] += s.schur_ms, stage_ms[2] += s.solve_ms, stage_ms[3] += s.update_ms;
       if (std::getenv("HS_REPLAY_TRACE"))
         std::fprintf(stderr, "opt %3d  cps %3zu  lms %4zu  blocks %6d  iters %d  ok %d  term %d  cost %.12g -> %.12g\n", solves_seen, optimizer.numControlPoints(),
                      optimizer.numLandmarks(), s.num_residual_blocks, s.num_iterations, s.num_successful_steps, s.termination, s.initial_cost, s.final_cost);
@@ -70,8 +73,8 @@ int main(int argc, char** argv) {
               seconds, int(with_imu), opt.order, optimizer.numOptimizations(), optimizer.numControlPoints(), optimizer.numLandmarks(),
               total_solve_ms / std::max(1, solves_seen), median, steady, max_solve_ms, total_solve_ms > 0 ? 1e3 * total_blocks / total_solve_ms : 0.0, wall_ms,
               optimizer.window().lower, optimizer.window().upper, optimizer.stateRange().lower, optimizer.stateRange().upper, std::sqrt(se / std::max(1, n)), optimizer.lastSummary().initial_cost,
-              optimizer.lastSummary().final_cost, stage_ms[0] / std::max(1, solves_seen), stage_ms[1] / std::max(1, solves_seen),
-              stage_ms[2] / std::max(1, solves_seen), stage_ms[3] / std::max(1, solves_seen), optimizer.wallSplitMs()[0] / std::max(1, solves_seen),
+              optimizer.lastSummary().final_cost, stages ? stage_ms[0] / std::max(1, solves_seen) : -1.0, stages ? stage_ms[1] / std::max(1, solves_seen) : -1.0,
+              stages ? stage_ms[2] / std::max(1, solves_seen) : -1.0, stages ? stage_ms[3] / std::max(1, solves_seen) : -1.0, optimizer.wallSplitMs()[0] / std::max(1, solves_seen),
               optimizer.wallSplitMs()[1] / std::max(1, solves_seen), optimizer.wallSplitMs()[2] / std::max(1, solves_seen));
   return 0;
 }

@@ -342,6 +342,33 @@ class Problem:
             self._check(self.lib.manifold_plus_jacobian(self.h, int(kind), ambient, n, _d(x), _d(jac)), "manifold_plus_jacobian")
         return jac
 
+    def manifold_minus(self, kind, y, x):
+        """Batched ceres::Manifold::Minus: y, x (n, ambient) -> (n, tangent), the tangent vector with Plus(x, .) = y."""
+        x = _arr(x, _f64)
+        x = x.reshape(-1, x.shape[-1])
+        n, ambient = x.shape
+        y = _arr(y, _f64).reshape(n, ambient)
+        tangent = self.lib.manifold_tangent_size(int(kind), ambient)
+        if tangent < 0:
+            raise ValueError("unknown manifold kind / ambient size")
+        out = np.zeros((n, tangent))
+        if tangent > 0:
+            self._check(self.lib.manifold_minus(self.h, int(kind), ambient, n, _d(y), _d(x), _d(out)), "manifold_minus")
+        return out
+
+    def manifold_minus_jacobian(self, kind, x):
+        """Batched ceres::Manifold::MinusJacobian: (n, tangent, ambient), row-major per element."""
+        x = _arr(x, _f64)
+        x = x.reshape(-1, x.shape[-1])
+        n, ambient = x.shape
+        tangent = self.lib.manifold_tangent_size(int(kind), ambient)
+        if tangent < 0:
+            raise ValueError("unknown manifold kind / ambient size")
+        jac = np.zeros((n, tangent, ambient))
+        if tangent > 0:
+            self._check(self.lib.manifold_minus_jacobian(self.h, int(kind), ambient, n, _d(x), _d(jac)), "manifold_minus_jacobian")
+        return jac
+
     def sample_trajectory(self, stamps, derivatives=False):
         st = _arr(stamps, _f64)
         pose = np.zeros((len(st), 7))

@@ -67,7 +67,7 @@ typedef struct hs_summary {
   int32_t num_successful_steps;
   int32_t termination;           /* HS_NO_CONVERGENCE | HS_CONVERGENCE | HS_FAILURE */
   int32_t num_residual_blocks;   /* residual blocks evaluated per linearisation on this handle */
-  double linearize_ms;           /* accumulated device time per stage over the solve (HIP events) */
+  double linearize_ms;           /* accumulated device time per stage over the solve (HIP events); the four stage fields are -1 unless hs_set_stage_timing is on */
   double schur_ms;
   double solve_ms;
   double update_ms;
@@ -237,8 +237,8 @@ int hs_process_tracks(hs_problem* p, double stamp, int n, const double* pixels0,
 
 /* ---- manifolds -------------------------------------------------------------------- */
 /* The retractions the solve applies, exposed as the batched counterpart of ceres::Manifold::Plus / PlusJacobian as the reference
- * forwards them (include/hyper/optimizers/ceres/manifolds/variables/wrapper.hpp:32-38; Minus / MinusJacobian, :44-50, are never
- * called by Ceres' trust-region minimiser and are not part of the path). kind: */
+ * forwards them (include/hyper/optimizers/ceres/manifolds/variables/wrapper.hpp:32-38), and Minus / MinusJacobian (:44-50; never
+ * called by Ceres' trust-region minimiser, provided for completeness of the Manifold interface). kind: */
 #define HS_MANIFOLD_CONSTANT 0       /* SubsetManifold, all fixed (manifolds/variables/euclidean.hpp:35-36,45-50): tangent 0        */
 #define HS_MANIFOLD_EUCLIDEAN 1      /* EuclideanManifold (euclidean.hpp:38), landmarks (optimizer.cpp:356): tangent = ambient     */
 #define HS_MANIFOLD_CONTROL_POINT 2  /* Stamped<SE3> [q(4) p(3) t] (stamped.hpp:35-36, se3.cpp:20-23, su2.cpp:21): 8 -> 6, t fixed */
@@ -251,6 +251,10 @@ int hs_manifold_tangent_size(int kind, int ambient);
 int hs_manifold_plus(hs_problem* p, int kind, int ambient, int n, const double* x, const double* delta, double* x_plus_delta);
 /* jacobian: n x (ambient x tangent) row-major (Manifold::PlusJacobian, wrapper.hpp:36-38). */
 int hs_manifold_plus_jacobian(hs_problem* p, int kind, int ambient, int n, const double* x, double* jacobian);
+/* y, x: n x ambient, y_minus_x: n x tangent (Manifold::Minus, wrapper.hpp:44-46): the tangent vector with Plus(x, .) = y. */
+int hs_manifold_minus(hs_problem* p, int kind, int ambient, int n, const double* y, const double* x, double* y_minus_x);
+/* jacobian: n x (tangent x ambient) row-major, d Minus(y, x) / dy at y = x (Manifold::MinusJacobian, wrapper.hpp:48-50). */
+int hs_manifold_minus_jacobian(hs_problem* p, int kind, int ambient, int n, const double* x, double* jacobian);
 
 #ifdef __cplusplus
 }

@@ -426,5 +426,18 @@ int hso_manifold_plus_jacobian(hso_problem* p, int kind, int ambient, int n, con
   for (int i = 0; i < n; ++i) manifold_plus_jacobian(ManifoldKind(kind), ambient, x + size_t(i) * ambient, jacobian + size_t(i) * ambient * tangent);
   return HS_OK;
 }
+int hso_manifold_minus(hso_problem* p, int kind, int ambient, int n, const double* y, const double* x, double* y_minus_x) {
+  const int tangent = hso_manifold_tangent_size(kind, ambient);
+  CHECK_ARG(tangent >= 0, "unknown manifold kind / ambient size");
+  for (int i = 0; i < n && tangent > 0; ++i)
+    manifold_minus(ManifoldKind(kind), ambient, y + size_t(i) * ambient, x + size_t(i) * ambient, y_minus_x + size_t(i) * tangent);
+  return HS_OK;
+}
+int hso_manifold_minus_jacobian(hso_problem* p, int kind, int ambient, int n, const double* x, double* jacobian) {
+  const int tangent = hso_manifold_tangent_size(kind, ambient);
+  CHECK_ARG(tangent >= 0, "unknown manifold kind / ambient size");
+  for (int i = 0; i < n && tangent > 0; ++i) manifold_minus_jacobian(ManifoldKind(kind), ambient, x + size_t(i) * ambient, jacobian + size_t(i) * ambient * tangent);
+  return HS_OK;
+}
 
 }  // extern "C"

@@ -841,6 +841,78 @@ inline void manifold_plus_jacobian(ManifoldKind m, int ambient, const double* x,
   }
 }
 
+/// ceres::Manifold::Minus of the variable classes (wrapper.hpp:44-46), restated from Ceres' public definitions (third party, 2.1):
+/// quaternion: [v ; w] = y (x) conj(x), delta = atan2(|v|, w) / |v| v; sphere: h = H y / |x|, delta = atan2(|h_t|, h_last) / |h_t| h_t;
+/// Euclidean: y - x; products: block-wise; constant blocks have no tangent.
+inline void manifold_minus(ManifoldKind m, int ambient, const double* y, const double* x, double* out) {
+  auto quat = [&](double* o) {
+    // r = y (x) conj(x), Hamilton, storage (x, y, z, w)
+    const double ax = y[0], ay = y[1], az = y[2], aw = y[3], bx = -x[0], by = -x[1], bz = -x[2], bw = x[3];
+    const double rx = aw * bx + ax * bw + ay * bz - az * by, ry = aw * by - ax * bz + ay * bw + az * bx, rz = aw * bz + ax * by - ay * bx + az * bw,
+                 rw = aw * bw - ax * bx - ay * by - az * bz;
+    const double n = std::sqrt(rx * rx + ry * ry + rz * rz);
+    const double s = n == 0.0 ? 0.0 : std::atan2(n, rw) / n;
+    o[0] = s * rx, o[1] = s * ry, o[2] = s * rz;
+  };
+  switch (m) {
+    case kManifoldConstant: break;
+    case kManifoldEuclidean:
+      for (int i = 0; i < ambient; ++i) out[i] = y[i] - x[i];
+      break;
+    case kManifoldControlPoint:
+    case kManifoldSE3:
+      quat(out);
+      for (int i = 0; i < 3; ++i) out[3 + i] = y[4 + i] - x[4 + i];
+      break;
+    case kManifoldSphere3: {
+      double v[3], beta;
+      sphere_householder(x, v, &beta);
+      const double nx = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+      const double vy = beta * (v[0] * y[0] + v[1] * y[1] + v[2] * y[2]);
+      double h[3];
+      for (int i = 0; i < 3; ++i) h[i] = (y[i] - v[i] * vy) / nx;
+      const double n = std::sqrt(h[0] * h[0] + h[1] * h[1]);
+      const double s = n == 0.0 ? 0.0 : std::atan2(n, h[2]) / n;
+      out[0] = s * h[0], out[1] = s * h[1];
+      break;
+    }
+    case kManifoldBiasPoint:
+      for (int i = 0; i < 3; ++i) out[i] = y[i] - x[i];
+      break;
+  }
+}
+/// local x ambient row-major MinusJacobian (wrapper.hpp:48-50): d Minus(y, x) / dy at y = x.
+inline void manifold_minus_jacobian(ManifoldKind m, int ambient, const double* x, double* J) {
+  const int local = manifold_local_size(m, ambient);
+  for (int i = 0; i < ambient * local; ++i) J[i] = 0.0;
+  switch (m) {
+    case kManifoldConstant: break;
+    case kManifoldEuclidean:
+      for (int i = 0; i < ambient; ++i) J[i * ambient + i] = 1.0;
+      break;
+    case kManifoldControlPoint:
+    case kManifoldSE3: {
+      double P[12];  // PlusJacobian of the quaternion (4 x 3): MinusJacobian is its transpose
+      quat_plus_jacobian(x, P);
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) J[r * ambient + c] = P[c * 3 + r];
+      for (int i = 0; i < 3; ++i) J[(3 + i) * ambient + 4 + i] = 1.0;
+      break;
+    }
+    case kManifoldSphere3: {
+      double v[3], beta;
+      sphere_householder(x, v, &beta);
+      const double nx = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+      for (int i = 0; i < 2; ++i)
+        for (int c = 0; c < 3; ++c) J[i * 3 + c] = ((c == i ? 1.0 : 0.0) - beta * v[i] * v[c]) / nx;
+      break;
+    }
+    case kManifoldBiasPoint:
+      for (int i = 0; i < 3; ++i) J[i * ambient + i] = 1.0;
+      break;
+  }
+}
+
 /// Local Jacobian of one block: J_local (n_res x local) = J_block (n_res x ambient, row-major) * PlusJacobian.
 inline void to_local(ManifoldKind m, int ambient, int n_res, const double* x, const double* J_block, double* J_local) {
   const int local = manifold_local_size(m, ambient);

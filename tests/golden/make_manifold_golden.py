@@ -1,10 +1,14 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/manifolds.json — 100-digit golden vectors for ceres::Manifold::Plus / PlusJacobian of the
+"""Generates tests/golden/manifolds.json — 100-digit golden vectors for ceres::Manifold::Plus / PlusJacobian / Minus / MinusJacobian of the
 variable classes on the path: quaternion (left-multiplicative, full-angle exponential), R^n,
 SphereManifold<3> (Householder construction), and the products used for control points, extrinsics and bias points.
 
 Plus is evaluated with the mpmath retractions of make_golden.py (which share no code with the oracle or the kernels);
 PlusJacobian = d Plus(x, delta) / d delta at delta = 0 by central differences with step 1e-20 at 100 digits.
+Minus(y, x) with y = the double-rounded Plus(x, delta) is computed from the geometric definition — the tangent vector of the geodesic from
+x to y in the coordinates of the tangent basis PlusJacobian(x) spans (quaternion: angle-axis of y x^-1; sphere: angle between x and y along the
+normalised rejection of y from x) — and then CHECKED against the retraction: Plus(x, Minus(y, x)) must reproduce the direction of y to 1e-60 (on the sphere the geometric value is the first guess of a root search for exactly that property, see minus()).
+MinusJacobian = d Minus(y, x) / dy at y = x by central differences in the ambient coordinates of y.
 Inputs are rounded to doubles first, so the expected values belong to exactly representable inputs.
 Run:  python tests/golden/make_manifold_golden.py   (seconds)
 """
@@ -16,7 +20,7 @@ import mpmath as mp
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-from make_golden import H, SplitMix64, plus_quat, plus_sphere, tofloat  # noqa: E402  (sets mp.dps = 100)
+from make_golden import H, SplitMix64, plus_quat, plus_sphere, qconj, qmul, tofloat  # noqa: E402  (sets mp.dps = 100)
 
 # kind ids of include/hyperslam_hip.h
 CONSTANT, EUCLIDEAN, CONTROL_POINT, SE3, SPHERE3, BIAS_POINT = range(6)
@@ -47,6 +51,73 @@ def plus_jacobian(kind, x, tangent):
     return [[cols[c][r] for c in range(tangent)] for r in range(len(x))]  # ambient x tangent
 
 
+def minus(kind, y, x):
+    """Geometric definition of Manifold::Minus (not Ceres' formulas): see the module docstring."""
+    def quat(yq, xq):
+        n2 = sum(c * c for c in xq)
+        r = qmul(yq, [c / n2 for c in qconj(xq)])  # y x^-1
+        nv = mp.sqrt(r[0] ** 2 + r[1] ** 2 + r[2] ** 2)
+        if nv == 0:
+            return [mp.mpf(0)] * 3
+        theta = mp.atan2(nv, r[3])  # rotation half-angle of the left factor: Plus uses [sin|d| d/|d| ; cos|d|] (x) x
+        return [theta * c / nv for c in r[:3]]
+    if kind == CONSTANT:
+        return []
+    if kind == EUCLIDEAN:
+        return [a - b for a, b in zip(y, x)]
+    if kind in (CONTROL_POINT, SE3):
+        return quat(y[:4], x[:4]) + [y[4 + i] - x[4 + i] for i in range(3)]
+    if kind == BIAS_POINT:
+        return [y[i] - x[i] for i in range(3)]
+    # sphere: geometric first guess (angle between x and y along the normalised rejection of y from x, in the coordinates of the
+    # tangent basis PlusJacobian(x) / |x|), then refined so that Plus(x, delta) points exactly at y: Ceres' retraction is built on a
+    # Householder reflection whose sigma <= eps branch (x within 1e-8 of the z axis) is not exactly orthogonal — there Plus(x, 0) is
+    # 4e-9 away from x and "the inverse of Plus", which is what Minus is, differs from the geodesic definition by that much.
+    nx = mp.sqrt(sum(c * c for c in x))
+    J = plus_jacobian(SPHERE3, x, 2)
+    basis = [[J[r][c] / nx for r in range(3)] for c in range(2)]
+    xh = [c / nx for c in x]
+    ny = mp.sqrt(sum(c * c for c in y))
+    yh = [c / ny for c in y]
+    along = sum(a * b for a, b in zip(yh, xh))
+    rej = [a - along * b for a, b in zip(yh, xh)]
+    nr = mp.sqrt(sum(c * c for c in rej))
+    theta = mp.atan2(nr, along)
+    guess = [theta * sum(rej[r] * basis[c][r] for r in range(3)) / nr if nr != 0 else mp.mpf(0) for c in range(2)]
+
+    def miss(d0, d1):
+        p = plus_sphere(x, [d0, d1])
+        n = mp.sqrt(sum(c * c for c in p))
+        return [sum((p[r] / n - yh[r]) * basis[c][r] for r in range(3)) for c in range(2)]
+    if max(abs(m) for m in miss(*guess)) < mp.mpf(10) ** -80:
+        return guess
+    root = mp.findroot(miss, guess, tol=mp.mpf(10) ** -85, maxsteps=60)
+    return [root[0], root[1]]
+
+
+def minus_jacobian(kind, x, tangent):
+    rows = [[mp.mpf(0)] * len(x) for _ in range(tangent)]
+    for c in range(len(x)):
+        yp, ym = list(x), list(x)
+        yp[c] += H
+        ym[c] -= H
+        a, b = minus(kind, yp, x), minus(kind, ym, x)
+        for r in range(tangent):
+            rows[r][c] = (a[r] - b[r]) / (2 * H)
+    return rows  # tangent x ambient
+
+
+def direction(kind, v):
+    """The part of an ambient point the manifold constrains up to scale, normalised (quaternion / sphere), the rest as is."""
+    if kind in (CONTROL_POINT, SE3):
+        n = mp.sqrt(sum(c * c for c in v[:4]))
+        return [c / n for c in v[:4]] + list(v[4:])
+    if kind == SPHERE3:
+        n = mp.sqrt(sum(c * c for c in v))
+        return [c / n for c in v]
+    return list(v)
+
+
 def main():
     rng = SplitMix64(0x4D414E49)
 
@@ -63,8 +134,15 @@ def main():
     def add(kind, x, d):
         xm, dm = [mp.mpf(v) for v in x], [mp.mpf(v) for v in d]
         tangent = len(d)
+        y = tofloat(plus(kind, xm, dm))  # Minus is evaluated at the representable point y
+        ym = [mp.mpf(v) for v in y]
+        back = minus(kind, ym, xm)
+        # definitional check: the retraction of x by Minus(y, x) points at y (norms of x and y differ by double rounding only)
+        a, b = direction(kind, plus(kind, xm, back)), direction(kind, ym)
+        assert max([abs(u - v) for u, v in zip(a, b)] + [mp.mpf(0)]) < mp.mpf(10) ** -60, (kind, x, d, max([abs(u - v) for u, v in zip(a, b)]))
         cases.append({"kind": kind, "ambient": len(x), "tangent": tangent, "x": x, "delta": d,
-                      "plus": tofloat(plus(kind, xm, dm)), "jacobian": tofloat(plus_jacobian(kind, xm, tangent))})
+                      "plus": y, "jacobian": tofloat(plus_jacobian(kind, xm, tangent)),
+                      "minus": tofloat(back), "minus_jacobian": tofloat(minus_jacobian(kind, xm, tangent))})
 
     for scale in (0.0, 1e-9, 1e-3, 0.3, 2.5):  # |delta| from exactly zero to beyond pi/2
         for _ in range(2):

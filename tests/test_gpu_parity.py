@@ -193,7 +193,7 @@ def test_band_width_classes(hip):
 
 
 def test_manifolds(hip, oracle):
-    """hs_manifold_plus / hs_manifold_plus_jacobian (the retractions k_backsub_retract applies) against the 100-digit vectors and,
+    """hs_manifold_plus / _plus_jacobian (the retractions k_backsub_retract applies) and hs_manifold_minus / _minus_jacobian against the 100-digit vectors and,
     on a larger random batch, against the oracle."""
     from util import check_manifolds_against_golden
     w = synthetic.small_visual()
@@ -208,10 +208,18 @@ def test_manifolds(hip, oracle):
         for kind, xs in ((ha.HS_MANIFOLD_CONTROL_POINT, x), (ha.HS_MANIFOLD_SE3, x[:, :7])):
             assert np.abs(p.manifold_plus(kind, xs, d) - o.manifold_plus(kind, xs, d)).max() <= 1e-14
             assert np.abs(p.manifold_plus_jacobian(kind, xs) - o.manifold_plus_jacobian(kind, xs)).max() <= 1e-15
+            y = o.manifold_plus(kind, xs, d)
+            assert np.abs(p.manifold_minus(kind, y, xs) - o.manifold_minus(kind, y, xs)).max() <= 1e-13
+            assert np.abs(p.manifold_minus_jacobian(kind, xs) - o.manifold_minus_jacobian(kind, xs)).max() <= 1e-15
+            small = np.abs(d[:, :3]).max(axis=1) < 1.5  # |delta| < pi: Minus inverts Plus
+            assert np.abs(p.manifold_minus(kind, y, xs)[small] - d[small]).max() <= 1e-7  # (deltas of 1e-8 come back through acos-like conditioning)
         g = rng.normal(size=(n, 3)) * 9.8
         d2 = rng.normal(size=(n, 2)) * rng.choice([0.0, 1e-8, 1e-2, 1.0], size=(n, 1))
         assert np.abs(p.manifold_plus(ha.HS_MANIFOLD_SPHERE3, g, d2) - o.manifold_plus(ha.HS_MANIFOLD_SPHERE3, g, d2)).max() <= 1e-13
         assert np.abs(p.manifold_plus_jacobian(ha.HS_MANIFOLD_SPHERE3, g) - o.manifold_plus_jacobian(ha.HS_MANIFOLD_SPHERE3, g)).max() <= 1e-13
+        y = o.manifold_plus(ha.HS_MANIFOLD_SPHERE3, g, d2)
+        assert np.abs(p.manifold_minus(ha.HS_MANIFOLD_SPHERE3, y, g) - o.manifold_minus(ha.HS_MANIFOLD_SPHERE3, y, g)).max() <= 1e-12
+        assert np.abs(p.manifold_minus_jacobian(ha.HS_MANIFOLD_SPHERE3, g) - o.manifold_minus_jacobian(ha.HS_MANIFOLD_SPHERE3, g)).max() <= 1e-13
         with pytest.raises(ha.HsError):
             p.manifold_plus(ha.HS_MANIFOLD_SPHERE3, np.zeros((1, 4)), np.zeros((1, 2)))
 

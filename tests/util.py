@@ -88,7 +88,7 @@ def manifold_cases():
 
 
 def check_manifolds_against_golden(problem, tol):
-    """Manifold::Plus / PlusJacobian (hs_manifold_plus*) of a library against tests/golden/manifolds.json, batched per kind."""
+    """Manifold::Plus / PlusJacobian / Minus / MinusJacobian (hs_manifold_*) of a library against tests/golden/manifolds.json, batched per kind."""
     cases = manifold_cases()
     groups = {}
     for c in cases:
@@ -100,7 +100,24 @@ def check_manifolds_against_golden(problem, tol):
         d = np.array([c["delta"] for c in cs], float).reshape(len(cs), -1)
         out = problem.manifold_plus(kind, x, d)
         jac = problem.manifold_plus_jacobian(kind, x)
+        y = np.array([c["plus"] for c in cs], float)
+        back = problem.manifold_minus(kind, y, x)
+        mjac = problem.manifold_minus_jacobian(kind, x)
         for i, c in enumerate(cs):
+            if c["tangent"]:
+                # Minus: absolute error against max(1, |delta|) (a delta of 1e-9 is recovered from a y that carries 1e-16 of rounding)
+                e = float(np.abs(back[i] - np.array(c["minus"])).max()) / max(1.0, float(np.abs(np.array(c["minus"])).max()))
+                assert e <= 4 * tol, (kind, "minus", c["x"], c["delta"], e)
+                e = rel(mjac[i], c["minus_jacobian"])
+                # SphereManifold, sigma = x0^2 + x1^2 <= eps but not zero: Ceres' Householder reflection is only approximately orthogonal
+                # there, Plus(x, 0) sits 2 sqrt(sigma) / |x| away from x, and Ceres' closed-form MinusJacobian (rows of H / |x|, what the
+                # libraries return) differs from the derivative of the inverse of Plus (what the vectors hold) by that amount (4e-9 here).
+                degenerate = kind == 4 and 0.0 < c["x"][0] ** 2 + c["x"][1] ** 2 <= 2.220446049250313e-16
+                assert e <= (1e-8 if degenerate else tol), (kind, "minus_jacobian", c["x"], e)
+                worst = max(worst, 0.0 if degenerate else e)
+                # the two Jacobians are inverse to each other on the tangent space (Ceres' own manifold test): MinusJacobian * PlusJacobian = I
+                assert np.abs(mjac[i] @ jac[i] - np.eye(c["tangent"])).max() <= 1e-13, (kind, c["x"])
+            assert mjac[i].shape == (c["tangent"], ambient)
             e = rel(out[i], c["plus"])
             assert e <= tol, (kind, c["x"], c["delta"], e)
             worst = max(worst, e)

@@ -5,6 +5,8 @@ import numpy as np
 os.environ.setdefault("HS_STAGE_TIMING", "1")
 import hyperslam_amd as ha
 from hyperslam_amd import synthetic, _lib
+_lib.PRODUCT_LIB = os.path.join("tools", "libhyperslam_hip_prof.so")  # profiling build (tools/build_profiling_lib.sh): the product library has no timing hooks
+os.environ.setdefault("HS_DEBUG_FLAGS", "16")
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 w = {1: synthetic.config1, 2: synthetic.config2, 3: synthetic.config3}[cfg]()
 p = ha.Problem(w); p.snapshot()

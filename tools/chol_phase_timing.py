@@ -4,6 +4,8 @@ import numpy as np
 os.environ.setdefault("HS_STAGE_TIMING", "1")
 import hyperslam_amd as ha
 from hyperslam_amd import synthetic, _lib
+_lib.PRODUCT_LIB = os.path.join("tools", "libhyperslam_hip_prof.so")  # profiling build (tools/build_profiling_lib.sh): the product library has no timing hooks
+os.environ.setdefault("HS_DEBUG_FLAGS", "16")
 w=synthetic.config1()
 p=ha.Problem(w); p.snapshot()
 for i in range(2): p.restore(); s=p.solve(1)

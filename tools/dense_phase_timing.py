@@ -7,6 +7,8 @@ os.environ.setdefault("HS_STAGE_TIMING", "1")
 import numpy as np
 import hyperslam_amd as ha
 from hyperslam_amd import _lib
+_lib.PRODUCT_LIB = os.path.join("tools", "libhyperslam_hip_prof.so")  # profiling build (tools/build_profiling_lib.sh): the product library has no timing hooks
+os.environ.setdefault("HS_DEBUG_FLAGS", "16")
 from test_gpu_edge_cases import window_with_band
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 33

@@ -177,11 +177,11 @@ __global__ void __launch_bounds__(kBlock) k_manifold_minus(int kind, int ambient
         break;
       case 2:
       case 3: {
-        // row c = d/dy of the vector part of y (x) conj(x), entry c
+        // row c = d/dy of entry c of the vector part of y (x) conj(x) (= the transpose of the quaternion's PlusJacobian)
         const double qx = xi[0], qy = xi[1], qz = xi[2], qw = xi[3];
-        J[0 * ambient + 0] = qw, J[0 * ambient + 1] = qz, J[0 * ambient + 2] = -qy, J[0 * ambient + 3] = -qx;
-        J[1 * ambient + 0] = -qz, J[1 * ambient + 1] = qw, J[1 * ambient + 2] = qx, J[1 * ambient + 3] = -qy;
-        J[2 * ambient + 0] = qy, J[2 * ambient + 1] = -qx, J[2 * ambient + 2] = qw, J[2 * ambient + 3] = -qz;
+        J[0 * ambient + 0] = qw, J[0 * ambient + 1] = -qz, J[0 * ambient + 2] = qy, J[0 * ambient + 3] = -qx;
+        J[1 * ambient + 0] = qz, J[1 * ambient + 1] = qw, J[1 * ambient + 2] = -qx, J[1 * ambient + 3] = -qy;
+        J[2 * ambient + 0] = -qy, J[2 * ambient + 1] = qx, J[2 * ambient + 2] = qw, J[2 * ambient + 3] = -qz;
         J[3 * ambient + 4] = 1.0, J[4 * ambient + 5] = 1.0, J[5 * ambient + 6] = 1.0;
         break;
       }

@@ -3,6 +3,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 
 from hyperslam_amd import HS_BEARING, HS_INERTIAL, HS_INERTIAL_AS_REFERENCE, HS_INERTIAL_EXACT, HS_PIXEL, HS_PRIOR, Window
 
@@ -143,3 +144,83 @@ def check_tracks_against_golden(lib, tol):
     errs = (rel(b0, d["bearings0"]), rel(b1, d["bearings1"]), rel(pw, d["positions_w"]))
     assert max(errs) <= tol, errs
     return max(errs)
+
+
+def solve_golden():
+    """tests/golden/solve.json (tests/golden/make_solve_golden.py): the window and, per LM iteration, the 100-digit solver quantities."""
+    with open(os.path.join(HERE, "golden", "solve.json")) as f:
+        d = json.load(f)
+    blocks = d["blocks"]
+
+    def table(ftype, key, width=None):
+        rows = [b[key] for b in blocks if b["type"] == ftype]
+        a = np.array(rows, float if key in ("stamp", "meas") else np.int32)
+        return a.reshape(len(rows), width) if width else a
+
+    ini = d["initial"]
+    imu = dict(d["imu"])
+    imu.update(bias_order=d["bias_order"], bias_t0=d["bias_t0"], bias_dt=d["bias_dt"], bias_g=np.array(ini["bias_g"]), bias_a=np.array(ini["bias_a"]),
+               bias_constant=False)
+    w = Window(order=d["order"], t0=d["t0"], dt=d["dt"], control_points=np.array(ini["control_points"]), cp_constant=np.array(d["cp_constant"], np.uint8),
+               cam_T_bs=np.array([c["T_bs"] for c in d["cameras"]]), cam_intrinsics=np.array([c["intrinsics"] for c in d["cameras"]]),
+               cam_distortion=np.array([c["distortion"] for c in d["cameras"]]), sensor_T_bs=np.array([d["sensor_T_bs"]]),
+               landmarks=np.array(ini["landmarks"]),
+               pixel_stamps=table("pixel", "stamp"), pixels=table("pixel", "meas", 2), pixel_landmark=table("pixel", "landmark"), pixel_camera=table("pixel", "camera"),
+               bearing_stamps=table("bearing", "stamp"), bearings=table("bearing", "meas", 3), bearing_landmark=table("bearing", "landmark"),
+               bearing_camera=table("bearing", "camera"),
+               prior_stamps=table("prior", "stamp"), prior_poses=table("prior", "meas", 7), prior_sensor=np.zeros(len(table("prior", "stamp")), np.int32),
+               inertial_stamps=table("inertial", "stamp"), inertial_measurements=table("inertial", "meas", 6),
+               imu=imu, gravity=np.array(ini["gravity"]), gravity_constant=False)
+    return d, w
+
+
+def check_solver_against_golden(lib, tol_forward, tol_state):
+    """The solver level of a library (a-11: cost, reduced normal equations, LM step, step quality, accept / reject, radius, and the state
+    after every iteration) against tests/golden/solve.json. `tol_forward`: quantities that are evaluated (cost, reduced system, gradient);
+    `tol_state`: quantities that went through the linear solve (steps, step quality, the state). Returns the worst errors seen."""
+    from hyperslam_amd import HS_INERTIAL_EXACT, Problem
+    d, w = solve_golden()
+    its = d["iterations"]
+    worst = {"forward": 0.0, "state": 0.0}
+
+    def fwd(a, b, what):
+        e = rel(a, b)
+        assert e <= tol_forward, (what, e)
+        worst["forward"] = max(worst["forward"], e)
+
+    def sta(a, b, what, scale=1.0):
+        e = float(np.abs(np.asarray(a, float) - np.asarray(b, float)).max()) / max(scale, float(np.abs(np.asarray(b, float)).max()))
+        assert e <= tol_state, (what, e)
+        worst["state"] = max(worst["state"], e)
+
+    with Problem(w, lib=lib) as p:
+        p.set_inertial_jacobian(HS_INERTIAL_EXACT)  # every golden Jacobian is a derivative; the IMU parameters are not at the identity point
+        fwd(p.cost(), d["initial_cost"], "initial cost")
+        S, g = p.reduced_system(its[0]["radius_before"])
+        fwd(S, its[0]["reduced_S"], "reduced system, first iteration")
+        fwd(g, its[0]["reduced_g"], "reduced gradient, first iteration")
+        for n in range(1, len(its) + 1):  # the state after n iterations, from the same starting point every time
+            p.upload(w)
+            p.set_inertial_jacobian(HS_INERTIAL_EXACT)
+            s = p.solve(n)
+            assert s["num_iterations"] == n
+            golden_state = its[n - 1]["state"]
+            sta(p.control_points(), golden_state["control_points"], f"control points after {n}")
+            sta(p.landmarks(), golden_state["landmarks"], f"landmarks after {n}")
+            bg, ba = p.bias()
+            # the bias points carry the weakest blocks of the window (inertial loss scale 1.6e-5): absolute scale = the step they took
+            bias_scale = max(1.0, float(np.abs(np.array(its[n - 1]["step"])).max()))
+            sta(bg, golden_state["bias_g"], f"gyroscope bias after {n}", bias_scale)
+            sta(ba, golden_state["bias_a"], f"accelerometer bias after {n}", bias_scale)
+            sta(p.gravity(), golden_state["gravity"], f"gravity after {n}")
+        assert s["initial_cost"] == pytest.approx(d["initial_cost"], rel=tol_forward)
+        assert s["num_successful_steps"] == sum(r["step_is_successful"] for r in its)
+        for rec, gold in zip(s["iterations"][1:], its):
+            assert rec["step_is_valid"] == 1 and rec["step_is_successful"] == gold["step_is_successful"], (gold["iteration"], rec)
+            sta(rec["cost"], gold["cost"], "cost after the step")
+            sta(rec["cost_change"], gold["cost_change"], "cost change", scale=abs(gold["cost"]))
+            sta(rec["relative_decrease"], gold["relative_decrease"], "step quality")
+            sta(rec["radius"], gold["radius"], "trust-region radius")
+            sta(rec["step_norm"], gold["step_norm"], "step norm")
+            sta(rec["gradient_max_norm"], gold["gradient_max_norm"], "gradient max norm (local coordinates)")
+    return worst

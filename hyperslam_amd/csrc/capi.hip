@@ -285,7 +285,7 @@ int prepare(hs_problem* p) {
   if (!build_visual_structure(in, &p->vs, &p->err)) return HS_ERR_INVALID;
   p->vs.bw = std::max(p->vs.bw, p->min_bw);
   const VisualStructure& vs = p->vs;
-  if (6 * vs.bw > kBlock || (size_t(36) * (6 * vs.bw + 2) + size_t(6) * p->n_cp + 48) * 8 > size_t(p->chol_lds_max))
+  if (6 * vs.bw > kBlock || (size_t(42) * (6 * vs.bw + 2) + size_t(6) * p->n_cp + 48) * 8 > size_t(p->chol_lds_max))
     HS_FAIL(HS_ERR_INVALID, "landmark tracks span too many control points for the LDS-resident banded factorisation");
   if (p->n_cp > 1024)  // 64 KiB of control points staged per workgroup; 96 KiB right-hand side + 49 KiB junction block in the backward sweep
     HS_FAIL(HS_ERR_INVALID, "window too long for the LDS-resident control-point table and backward sweep (more than 1024 control points)");
@@ -848,7 +848,7 @@ int launch_factor(hs_problem* p) {
   hipStream_t s = p->stream;
   const int ncb = 6 * T.bw;
   const size_t chol_lds = (size_t(24) * (ncb + 2) + size_t(T.np)) * sizeof(double);
-  const size_t la_lds = (size_t(36) * (ncb + 2) + size_t(T.np) + 48) * sizeof(double);
+  const size_t la_lds = (size_t(42) * (ncb + 2) + size_t(T.np) + 48) * sizeof(double);
   const bool legacy = T.debug_flags & 4;  // A/B switch: pre-look-ahead kernel
   // Factoring from both ends at once (visual-only systems, look-ahead kernel, window long enough to pay for the junction)
   const int n_blk = T.np / 6, w_mid = T.bw - 1;

@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(kCholThreads + kCholIo) k_band_factor(Tables T
 //   wave  4    loader  : streams block rows from HBM into the LDS stage two steps ahead (+ the tail blocks of row i + 2)
 //   wave  5    storer  : streams X_i (the factor row) to HBM, keeps y in LDS, inverts U_ii for the backward sweep
 // One LDS-only barrier per block row; critical path per step = max(panel chain, rank-6 update) instead of their sum.
-// LDS (doubles): rowbuf 2 x 6 x ld | xbuf 2 x 6 x ld | stage 2 x 6 x ld | y np | diagonal scratch 36.
+// LDS (doubles): rowbuf 2 x 6 x ld | xbuf 2 x 6 x ld | stage 3 x 6 x ld | y np | diagonal scratch 36.
 //
 // Two-ended mode (grid = 2, visual-only systems): the chain over the block rows is halved by eliminating from both ends at once.
 // Workgroup 1 factors the REVERSED system (written by k_finalize_reduced next to the natural one) for the last n - m - w block rows (w = bw - 1), dumps its trailing
@@ -346,8 +346,9 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
   const int n_blk = T.np / 6;
   double* rowbuf = smem;            // row r (published by its owners, updated through X_(r-2)) in rowbuf[r & 1]
   double* xbuf = smem + 12 * ld;    // [U_rr | X_r | y_r] in xbuf[r & 1]
-  double* stage = smem + 24 * ld;   // block row r staged by the loader in stage[r & 1]
-  double* xs = smem + 36 * ld;      // np : y (forward solve)
+  double* stage = smem + 24 * ld;   // block row r staged by the loader in stage[r % 3] (three buffers: a row is read by its new owners
+                                    // one step after it was staged for them, see the compute waves)
+  double* xs = smem + 42 * ld;      // np : y (forward solve)
   double* dscr = xs + T.np;         // 36 : updated diagonal block of the panel row
   double* dinv = dscr + 36;         // 2 x 6 : 1 / diag(U_rr) in dinv[r & 1]
   __shared__ int fail;
@@ -421,12 +422,12 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
       put(va, rowbuf), put(vb, rowbuf + 6 * ld);
       fetch(va, bw + 2), fetch(vb, bw + 3);
       tfetch(tb, 2), tfetch(ta, 3);
-      put(va, stage + ((bw + 2) & 1) * 6 * ld);
+      put(va, stage + ((bw + 2) % 3) * 6 * ld);
       fetch(va, bw + 4);
       lds_barrier();  // init
       lds_barrier();  // prologue
       for (int i = 0; i < n_steps; i += 2) {
-        put(vb, stage + ((i + 3 + bw) & 1) * 6 * ld);
+        put(vb, stage + ((i + 3 + bw) % 3) * 6 * ld);
         tput(tb, rowbuf + (i & 1) * 6 * ld, i + 2);
         fetch(vb, i + 5 + bw);
         tfetch(tb, i + 4);
@@ -434,7 +435,7 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
         lds_barrier();
         junction_io(i);
         if (i + 1 < n_steps) {
-          put(va, stage + ((i + 4 + bw) & 1) * 6 * ld);
+          put(va, stage + ((i + 4 + bw) % 3) * 6 * ld);
           tput(ta, rowbuf + ((i + 1) & 1) * 6 * ld, i + 3);
           fetch(va, i + 6 + bw);
           tfetch(ta, i + 5);
@@ -677,16 +678,20 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
   }
 
   // ================================ compute waves: static tile ownership ================================
+  // Ring slot s (block rows s, s + bw, s + 2 bw, ...) lives in wave s % 3, lanes (s / 3) (bw - 2) + kk: consecutive block rows sit in
+  // different waves. The wave that owns block row i + 2 is the last one at the step barrier (it publishes the row on top of its update
+  // pass); with consecutive rows in one wave it also had to refill the slot it published the step before.
+  static_assert(TPT == 1, "one tile per lane");
   int t_kk[TPT], t_row[TPT];
-  bool t_ok[TPT];
+  bool t_ok[TPT], t_refill[TPT];  // t_refill: the slot was published in the previous step and takes its next block row from the stage
   double acc[TPT][36], rhs[TPT][6];
 #pragma unroll
   for (int m = 0; m < TPT; ++m) {
-    const int tl = tid + m * nthr;
-    t_ok[m] = tl < bw * (bw - 2);
-    const int slot = t_ok[m] ? tl / (bw - 2) : 0;
-    t_kk[m] = t_ok[m] ? tl % (bw - 2) : 0;
+    const int slot = wave + 3 * (l / (bw - 2));
+    t_ok[m] = slot < bw;
+    t_kk[m] = l % (bw - 2);
     t_row[m] = slot < 2 ? slot + bw : slot;  // rows 0 and 1 start in LDS (loader); their slots prefetch rows bw, bw + 1
+    t_refill[m] = false;
   }
 #pragma unroll
   for (int m = 0; m < TPT; ++m) {
@@ -709,18 +714,40 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
   lds_barrier();  // prologue: X_0 complete
   if (cprof) clog[2] = wall_clock64();
   const bool prof = prof_enabled(T.debug_flags, 16) && tid == 0 && blockIdx.x == 0;
+  const bool prof12 = prof_enabled(T.debug_flags, 16) && (tid == 64 || tid == 128) && blockIdx.x == 0;  // compute waves 1, 2 -> tlog[8 (512 + i) + 2 wave ..]
   long long* tlog = reinterpret_cast<long long*>(T.xpart);
   for (int i = 0; i < n_steps; ++i) {
     if (prof) tlog[8 * i + 0] = wall_clock64();
+    if (prof12) tlog[8 * (512 + i) + 2 * (tid >> 6)] = wall_clock64();
     const double* xb = xbuf + (i & 1) * 6 * ld;
 #pragma unroll
     for (int m = 0; m < TPT; ++m) {
       const int j = t_row[m] - i;
+      if (t_refill[m]) {  // published in the previous step: the next block row of this slot (first update three steps from now)
+        const int r = t_row[m];
+        const double* src = stage + (r % 3) * 6 * ld + 6 * t_kk[m];
+        const double first = t_kk[m] == 0 ? 1.0 : 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+          for (int c = 0; c < 6; c += 2) {
+            const double2 t = *reinterpret_cast<const double2*>(&src[a * ld + c]);
+            acc[m][6 * a + c] = t.x, acc[m][6 * a + c + 1] = t.y;
+          }
+          rhs[m][a] = first * stage[(r % 3) * 6 * ld + a * ld + ncb];
+        }
+        t_refill[m] = false;
+      }
       if (!t_ok[m] || j < 2 || j > bw - 1) continue;
       if (j + t_kk[m] <= bw - 1 && !(T.debug_flags & 2)) {  // rank-6 update  S_(i+j),kk -= X_j' X_(j+kk)
         const int ca = 6 * j, cb = 6 * (j + t_kk[m]);
-        // software pipelined over the six rows of X: the operands of row a + 1 are requested before the 36 FMAs of row a, and
-        // the scheduler may not hoist more than that (all 72 operands in flight at once spills the register tiles at TPT = 2)
+        // The right-hand side rides along as a seventh column in EVERY lane (only the lanes with kk = 0 ever use theirs): as a branch
+        // around six loads and FMAs per row of X it cost a full drain of the LDS queue per row (s_waitcnt lgkmcnt(0) inside the
+        // predicated block), ~0.3 us per step in every compute wave.
+        double y[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) y[a] = xb[a * ld + ncb];
+        // software pipelined over the six rows of X: the operands of row a + 1 are requested before the 36 FMAs of row a
         double xa[2][6], xc[2][6];
         auto fetch_x = [&](int a, int b) {
 #pragma unroll
@@ -736,35 +763,30 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
           const int b = a & 1;
           if (a < 5) fetch_x(a + 1, b ^ 1);
 #pragma unroll
-          for (int r = 0; r < 6; ++r)
+          for (int r = 0; r < 6; ++r) {
 #pragma unroll
             for (int c = 0; c < 6; ++c) acc[m][6 * r + c] = fma(-xa[b][r], xc[b][c], acc[m][6 * r + c]);
-          if (t_kk[m] == 0) {
-            const double y = xb[a * ld + ncb];
-#pragma unroll
-            for (int r = 0; r < 6; ++r) rhs[m][r] = fma(-xa[b][r], y, rhs[m][r]);
+            rhs[m][r] = fma(-xa[b][r], y[a], rhs[m][r]);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      if (j == 2) {  // row i + 2 becomes the panel row of the next step: publish, then prefetch row i + 2 + bw into the registers
+      if (j == 2) {  // row i + 2 becomes the panel row of the next step: publish; the slot is refilled in the next step
         double* dst = rowbuf + (i & 1) * 6 * ld;
-        const double* src = stage + ((i + 2 + bw) & 1) * 6 * ld;
+        const int c_rhs = t_kk[m] == 0 ? ncb : ncb + 1;  // lanes without a right-hand side write theirs to the pad column
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
 #pragma unroll
-          for (int c = 0; c < 6; c += 2) {
+          for (int c = 0; c < 6; c += 2)
             *reinterpret_cast<double2*>(&dst[a * ld + 6 * t_kk[m] + c]) = make_double2(acc[m][6 * a + c], acc[m][6 * a + c + 1]);
-            const double2 t = *reinterpret_cast<const double2*>(&src[a * ld + 6 * t_kk[m] + c]);
-            acc[m][6 * a + c] = t.x, acc[m][6 * a + c + 1] = t.y;
-          }
-          if (t_kk[m] == 0) dst[a * ld + ncb] = rhs[m][a];
-          rhs[m][a] = t_kk[m] == 0 ? src[a * ld + ncb] : 0.0;
+          dst[a * ld + c_rhs] = rhs[m][a];
         }
         t_row[m] = i + 2 + bw;
+        t_refill[m] = true;
       }
     }
     if (prof) tlog[8 * i + 1] = wall_clock64();
+    if (prof12) tlog[8 * (512 + i) + 2 * (tid >> 6) + 1] = wall_clock64();
     lds_barrier();
     if (m_at >= 0 && i + 1 == m_at) {  // ---- junction: add the other end's Schur contribution to the middle rows ----
       if (cprof) clog[3] = wall_clock64();

@@ -167,6 +167,12 @@ HSD void begin_iteration(const Tables& T, double c, double gm, bool set_scaling_
     r.iteration = 0, r.step_is_valid = 1, r.step_is_successful = 1, r.cost = c, r.cost_change = 0, r.gradient_max_norm = gm;
     r.step_norm = 0, r.relative_decrease = 0, r.radius = st->radius;
     st->iteration = 1;
+  } else {
+    // TrustRegionMinimizer reports, with iteration i, the gradient at the point AFTER its step (it re-evaluates the Jacobian inside
+    // HandleSuccessfulStep). Here that gradient only exists once the next iteration has linearised: patch the previous record. The
+    // record of the LAST iteration of a solve keeps the gradient from before its step (no linearisation at the final point: that
+    // would be a sixth linearise + build per optimize() whose only consumer is this field).
+    st->records[st->iteration - 1].gradient_max_norm = gm;
   }
   // FinalizeIterationAndCheckIfMinimizerCanContinue
   if (st->iteration - 1 >= st->max_iterations) {

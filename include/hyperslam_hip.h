@@ -54,7 +54,7 @@ typedef struct hs_iteration {
   int32_t reserved;
   double cost;              /* cost after this iteration (0.5 * sum rho(|r|^2)) */
   double cost_change;
-  double gradient_max_norm;
+  double gradient_max_norm; /* max |gradient| in local coordinates after this iteration's step; for the LAST executed iteration: before it */
   double step_norm;
   double relative_decrease;
   double radius;            /* trust-region radius after this iteration */

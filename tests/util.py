@@ -222,5 +222,9 @@ def check_solver_against_golden(lib, tol_forward, tol_state):
             sta(rec["relative_decrease"], gold["relative_decrease"], "step quality")
             sta(rec["radius"], gold["radius"], "trust-region radius")
             sta(rec["step_norm"], gold["step_norm"], "step norm")
-            sta(rec["gradient_max_norm"], gold["gradient_max_norm"], "gradient max norm (local coordinates)")
+            # the last record of a solve keeps the gradient from before its step (include/hyperslam_hip.h): the product library does not
+            # linearise at the final point; the oracle, like Ceres, does
+            last = gold is its[-1]
+            sta(rec["gradient_max_norm"], gold["gradient_max_norm_before"] if (last and lib.prefix == "hs_") else gold["gradient_max_norm"],
+                "gradient max norm (local coordinates)")
     return worst

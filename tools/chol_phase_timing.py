@@ -22,6 +22,13 @@ print("panel: update", np.median(t[r, 3] - t[r, 2]), " factor", np.median(t[r, 4
 ev = slice(10, 110, 2)
 print("arrival at the step barrier relative to step start: compute", np.median(t[ev, 1] - t[ev, 0]), " panel(row r+1)", np.median(t[11:111:2, 5] - t[ev, 0]),
       " storer", np.median(t[ev, 6] - t[ev, 0]), " loader", np.median(t[ev, 7] - t[ev, 0]))
+print("after the barrier: next step start - compute arrival", np.median(t[11:111, 0] - t[10:110, 1]), " next step start - panel(r+1) end", np.median(t[11:111, 0] - t[11:111, 5]),
+      " next step start - storer arrival", np.median(t[11:111, 0] - t[10:110, 6]), " - loader arrival", np.median(t[12:110:2, 0] - t[11:109:2, 7]),
+      " panel(r+1) start - step r start", np.median(t[11:111, 2] - t[10:110, 0]))
+print("raw, steps 20..31, relative to the start of step 20 [10 ns]: columns = step start, compute done, panel(r) start, row updated, factored, X written, storer arrival, loader arrival (even steps)")
+tw = buf[8 * 512:8 * 512 + 8 * 128].reshape(128, 8)
+for r in range(20, 32):
+    print(r, [int(v - t[20, 0]) if v else None for v in t[r]], " compute waves 1, 2 (start, done):", [int(v - t[20, 0]) for v in tw[r, 2:6]])
 print("solve_ms", s["solve_ms"])
 
 for job in (0, 1):

@@ -515,8 +515,9 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_xsol.reserve(np));
   HIP_TRY(p->d_win.reserve(size_t(6) * vs.bw * (ncb + 1)));
   if (!p->d_join.p) {
-    HIP_TRY(p->d_join.reserve(4));  // [0] two-ended factor / sweep hand-over, [1] last-block ticket of k_band_backward2, [2] of k_border_bb
-    HIP_TRY(hipMemsetAsync(p->d_join.p, 0, 4 * sizeof(unsigned), s));
+    // [0] two-ended factor / sweep hand-over, [1] last-block ticket of the backward sweeps, [2] of k_border_bb, [4 ..] super-block inverses
+    HIP_TRY(p->d_join.reserve(kSbFlagBase + 2 * kSbMaxBlocks));
+    HIP_TRY(hipMemsetAsync(p->d_join.p, 0, (kSbFlagBase + 2 * kSbMaxBlocks) * sizeof(unsigned), s));
     p->join_epoch = 0;
   }
   // split the accumulation over enough workgroups to fill the chip (256 CUs x a few workgroups)
@@ -881,9 +882,13 @@ int launch_factor(hs_problem* p) {
     const BackJob j0{T.Ub, T.Ubk, T.ybuf, p->d_Vb.p, p->d_yt.p, m + w_mid, 0, 0};
     const BackJob j1{p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, p->d_Vb2.p, p->d_yt2.p, mB, w_mid, 1};
     if (T.debug_flags & 65536) k_premultiply<<<m + w_mid + mB, 128, 0, s>>>(T3, j0, j1, m + w_mid);
-    if (!(T.debug_flags & 65536)) {  // the four-wave LDS sweep (A/B switch 65536: single-wave register sweep)
+    if (!(T.debug_flags & 65536)) {  // (A/B switch 65536: single-wave register sweep)
       const size_t g_lds = size_t(6 * (T.bw - 1)) * (6 * (T.bw - 1) | 1) * sizeof(double);  // given-column block of the far sweep
-      k_band_backward2<<<2, kCholThreads, 2 * size_t(T.np) * sizeof(double) + g_lds, s>>>(T3, j0, j1, m);
+      if (T.debug_flags & 268435456)  // A/B switch 268435456: one block row per step
+        k_band_backward2<<<2, kCholThreads, 2 * size_t(T.np) * sizeof(double) + g_lds, s>>>(T3, j0, j1, m);
+      else  // super-blocks of four block rows; the inverses of the diagonal super-blocks come from extra workgroups of the launch
+        k_band_backward_sb<<<2 + (m + w_mid + kSb - 1) / kSb + (mB + kSb - 1) / kSb, kCholThreads,
+                             std::max((2 * size_t(T.np) + 32) * sizeof(double) + g_lds, size_t(3 * kSbN * (kSbN + 1)) * sizeof(double)), s>>>(T3, j0, j1, m);
     } else {
       launch_backward_w(T3, j0, j1, m, 2, s);
     }
@@ -1012,6 +1017,7 @@ int set_func_attributes(hs_problem* p) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_visual<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_forward), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_backward2), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_backward_sb), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_backward), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   return HS_OK;

@@ -10,7 +10,7 @@
 //     (single shard without border unknowns: packing + bookkeeping are an extra workgroup of k_finalize_reduced, one launch)
 //   k_band_factor_la (look-ahead, one or two ends) | k_band_factor (bw <= 22) | k_band_factor_wide (bw <= 42)   S = U'U, y
 //   k_border_forward / _schur / _solve / _apply                                         bordered part of the solve
-//   k_band_backward | k_band_backward2       U x = y, step outputs
+//   k_band_backward | k_band_backward_sb     U x = y (two-ended: super-blocks of four block rows, inverses built by extra workgroups), step outputs
 //   k_backsub_retract                        step for landmarks, candidate point = Plus(x, delta), norm / model-cost partials
 //   k_cost_visual / _prior / _inertial       cost at the candidate point
 //   k_pack_decision -> [all-reduce] -> k_decide -> k_commit      trust-region logic and acceptance
@@ -22,6 +22,7 @@
 #include "kernels_border.hpp"
 #include "kernels_factor.hpp"
 #include "kernels_backward.hpp"
+#include "kernels_backward_sb.hpp"
 #include "kernels_factor_mfma.hpp"
 #include "kernels_update.hpp"
 #include "kernels_aux.hpp"

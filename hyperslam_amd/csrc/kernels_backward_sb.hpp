@@ -1,0 +1,346 @@
+// kernels_backward_sb.hpp — backward sweep U x = y of the two-ended factorisation in SUPER-BLOCKS of four block rows (part of kernels.hpp).
+//
+// The sweep is a dependency chain over the rows of the factor. One block row per step (k_band_backward2) costs 0.55 us per step —
+// barrier, operands through LDS, a 6 x 6 triangular product, one update pass — whatever the arithmetic, and a window of 128 control
+// points has 57 such steps on the chain of each end. Here a step solves 24 scalar rows at once:
+//     x_J = Winv_J y_J,            Winv_J = (U_JJ)^-1, the inverse of the 24 x 24 upper-triangular diagonal super-block,
+//     y_rho -= U[rho, J] x_J       for the 6 (bw - 1) pending rows above,
+// so the chain has a quarter of the steps, and each step is two short dot products per lane (12 multiply-adds + one cross-lane add)
+// with two barriers. The inverses do not depend on one another: extra workgroups of the same launch (one per super-block, one wave
+// each) compute them concurrently while the sweep workgroups stage their operands, and publish them through agent-scope flags; the
+// sweeps consume them from the bottom row up, four steps after requesting them.
+//
+// Launch: grid = 2 + n_sb(job 0) + n_sb(job 1), 256 lanes. Workgroups 0, 1 are the two sweeps (roles and hand-over exactly as in
+// k_band_backward2: block 0 solves the top system and publishes the middle solution, block 1 takes it as given and solves the reversed
+// bottom system); the remaining workgroups are the inverse builders (first wave only).
+#pragma once
+#include "kernels_factor.hpp"
+
+namespace hs {
+
+constexpr int kSb = 4;            // block rows per super-block
+constexpr int kSbN = 6 * kSb;     // scalar rows per super-block
+constexpr int kSbPrefetch = 5;    // super-steps between requesting the operands of a step from HBM / MALL and using them (~2 us)
+constexpr int kSbFlagBase = 4;    // T.join_flag[kSbFlagBase + 512 job + s] = epoch once Winv of super-block s of that job is in memory
+constexpr int kSbMaxBlocks = 512; // super-blocks per job the flag table has room for (n_cp <= 1024 control points)
+
+HSD int sb_count(int n_rows) { return (n_rows + kSb - 1) / kSb; }
+
+/// Entry (rho, col) of a factor in band storage (row rho holds columns 6 floor(rho / 6) .. + 6 bw - 1), zero outside the band / matrix.
+HSD double band_entry(const double* __restrict__ Ub, int ncb, int n_own, int rho, int col) {
+  const int off = col - 6 * (rho / 6);
+  return (rho >= 0 && rho < n_own && col < n_own && off >= 0 && off < ncb) ? Ub[size_t(rho) * ncb + off] : 0.0;
+}
+
+/// Sum of a value over a lane pair (lanes 2 i, 2 i + 1) through the DPP cross bar (quad_perm [1 0 3 2]): two moves and an add instead
+/// of the ~150 cycles of an LDS permute on the chain of the sweep.
+HSD double pair_sum(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xF, 0xF, false);
+  return v + __hiloint2double(hi, lo);
+}
+
+/// Winv of super-block s of job J -> J.Vb + 576 s (row-major 24 x 24, zeros below the diagonal and in the rows / columns of a partial
+/// last super-block), then the flag. One wave. The 6 x 6 inverses W_j = U_jj^-1 of the diagonal blocks come from the factorisation
+/// (J.Ubk); the blocks above the diagonal follow by block back substitution, one block diagonal per level:
+///     V_jj = W_j,     V_ij = -W_i sum_(k = i + 1 .. j) U_ik V_kj     (i < j, level j - i),
+/// so the dependent chain is three levels of two 6 x 6 products instead of 24 scalar rows.
+HSD void sb_inverse(const Tables& T, const BackJob& J, int job, int s, double* lds /* 3 x 24 x 25 */) {
+  const int l = threadIdx.x;
+  if (l >= 64) return;
+  constexpr int LD = kSbN + 1;
+  double* U = lds;
+  double* V = lds + kSbN * LD;
+  double* Tm = lds + 2 * kSbN * LD;
+  const int ncb = 6 * T.bw, n_own = 6 * J.n_rows, r0 = kSbN * s;
+  const int nr = min(kSbN, n_own - r0);
+  {  // every load first (nine + five per lane), then the stores: a load -> store loop pays the memory latency once per trip
+    constexpr int NU = (kSbN * kSbN + 63) / 64;
+    double v[NU], w[2];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int e = l + 64 * u, a = e / kSbN, c = e % kSbN;
+      v[u] = (e < kSbN * kSbN && a < nr && c < nr && c >= a) ? band_entry(J.Ub, ncb, n_own, r0 + a, r0 + c) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {  // W_j: 21 packed entries per block row (upper triangle, row-major)
+      const int e = l + 64 * u, jb = e / 21;
+      w[u] = (e < kSb * 21 && 6 * jb < nr) ? J.Ubk[size_t(kSb * s + jb) * 24 + e % 21] : 0.0;
+    }
+    for (int e = l; e < 2 * kSbN * LD; e += 64) lds[e] = 0.0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wave: LDS is in order; only the compiler must keep the order
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int e = l + 64 * u;
+      if (e < kSbN * kSbN) U[(e / kSbN) * LD + e % kSbN] = v[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = l + 64 * u, jb = e / 21, t = e % 21;
+      if (e < kSb * 21) {
+        int a = 0, rem = t;  // packed index -> (a, c): row a holds 6 - a entries
+        while (rem >= 6 - a) rem -= 6 - a, ++a;
+        V[(6 * jb + a) * LD + 6 * jb + a + rem] = w[u];
+      }
+    }
+  }
+  __syncthreads();  // (the workgroup's other waves have left: a barrier of one wave)
+  for (int d = 1; d < kSb; ++d) {
+    const int n_e = (kSb - d) * 36;
+    for (int e = l; e < n_e; e += 64) {  // Tm_ij = sum_k U_ik V_kj
+      const int i = e / 36, r = (e % 36) / 6, c = e % 6, j = i + d;
+      double t = 0.0;
+      for (int k = i + 1; k <= j; ++k)
+#pragma unroll
+        for (int m = 0; m < 6; ++m) t = fma(U[(6 * i + r) * LD + 6 * k + m], V[(6 * k + m) * LD + 6 * j + c], t);
+      Tm[(6 * i + r) * LD + 6 * j + c] = t;
+    }
+    __syncthreads();
+    for (int e = l; e < n_e; e += 64) {  // V_ij = -W_i Tm_ij
+      const int i = e / 36, r = (e % 36) / 6, c = e % 6, j = i + d;
+      double v = 0.0;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) v = fma(V[(6 * i + r) * LD + 6 * i + m], Tm[(6 * i + m) * LD + 6 * j + c], v);  // (W_i is upper triangular: zeros below)
+      V[(6 * i + r) * LD + 6 * j + c] = -v;
+    }
+    __syncthreads();
+  }
+  double* dst = const_cast<double*>(J.Vb) + size_t(s) * (kSbN * kSbN);
+  for (int e = l; e < kSbN * kSbN; e += 64) {
+    const int a = e / kSbN, c = e % kSbN;
+    dst[e] = (a < nr && c < nr) ? V[a * LD + c] : 0.0;
+  }
+  __threadfence();
+  __syncthreads();
+  if (l == 0) {
+    __threadfence();
+    __hip_atomic_store(T.join_flag + kSbFlagBase + kSbMaxBlocks * job + s, T.join_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+/// Bounded wait for a flag word (see wait_for_partner): 2 s, then the factorisation is marked as failed and the caller carries on.
+HSD void sb_wait(const Tables& T, const unsigned* flag) {
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < T.join_epoch) {
+    __builtin_amdgcn_s_sleep(2);
+    if (wall_clock64() - t0 > 200000000ll) {
+      T.st->chol_failed = 2;
+      break;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kCholThreads) k_band_backward_sb(Tables T, BackJob j0, BackJob j1, int m_mid) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  DevState* st = T.st;
+  if (st->done) return;
+  const int tid = threadIdx.x;
+  if (blockIdx.x >= 2) {  // ---------------- inverse builders ----------------
+    const int s0 = int(blockIdx.x) - 2, n0 = sb_count(j0.n_rows);
+    if (s0 < n0)
+      sb_inverse(T, j0, 0, s0, smem);
+    else
+      sb_inverse(T, j1, 1, s0 - n0, smem);
+    return;
+  }
+  const int job = blockIdx.x;
+  const BackJob J = job == 0 ? j0 : j1;
+  constexpr int nthr = kCholThreads;
+  const int bw = T.bw, ncb = 6 * bw, np = T.np;
+  const bool cprof = prof_enabled(T.debug_flags, 16) && tid == 0;  // coarse phases -> xpart[8 (230 + 10 block) + ..] (tools/chol_phase_timing.py)
+  long long* clog = reinterpret_cast<long long*>(T.xpart) + 8 * (230 + 10 * blockIdx.x);
+  if (cprof) clog[0] = wall_clock64();
+  const int n_own = 6 * J.n_rows, n_all = 6 * (J.n_rows + J.given);
+  double* xs = smem;              // n_all : pending rows (own) / given solution
+  double* xout = smem + n_all;    // n_own : solution of the own rows
+  double* xj = smem + 2 * np;     // 24 (+ pad 8) : solution of the super-block of the current step
+  double* G = smem + 2 * np + 32; // given-column block of the far sweep, see k_band_backward2
+  const int n_above = 6 * (bw - 1);
+  const bool merged = J.given > 0;  // (the two-ended launch always has 6 given = n_above <= n_own)
+  const int ldg = n_above | 1;
+  for (int rho = tid; rho < n_own; rho += nthr) xs[rho] = J.ybuf[rho];
+  if (tid < kSbN && J.given == 0) smem[n_all + tid] = 0.0;  // a partial last super-block reads 24 entries from its first row on
+  if (merged) {
+    const int n_g = n_above * n_above;
+    for (int e0 = tid; e0 < n_g; e0 += 8 * nthr) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * nthr, r = e / n_above, c = e - r * n_above;
+        const int rho = n_own - n_above + r, off = n_own + c - 6 * (rho / 6);  // band offset of column n_own + c in row rho
+        v[u] = (e < n_g && off < ncb) ? J.Ub[size_t(rho) * ncb + off] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * nthr, r = e / n_above, c = e - r * n_above;
+        if (e < n_g) G[c * ldg + r] = v[u];
+      }
+    }
+  }
+  // ---- lane roles ----
+  // waves 0 .. 2 (192 lanes), lane (p, q) = (tid / 2, tid & 1): pending row rho = r0 - 1 - p of the step (p < n_above), columns
+  //   r0 + 12 q .. + 11 of the super-block: 12 multiply-adds, the two halves are added across the lane pair;
+  // wave 3, lane (r, q) = (l / 2, l & 1), r < 24: row r of Winv_J, columns 12 q .. + 11.
+  const int wave = tid >> 6, l = tid & 63;
+  const bool solver = wave == 3;
+  const int q = tid & 1;
+  const int p_row = solver ? (l >> 1) : (tid >> 1);
+  const int n_sb = sb_count(J.n_rows);
+  const unsigned* flags = T.join_flag + kSbFlagBase + kSbMaxBlocks * job;
+  double ring[kSbPrefetch][12];  // operands of the next kSbPrefetch steps, oldest first (register renaming by full unrolling below)
+  auto request = [&](int s, double* dst) {
+    if (s < 0) {
+#pragma unroll
+      for (int c = 0; c < 12; ++c) dst[c] = 0.0;
+      return;
+    }
+    const int r0 = kSbN * s;
+    if (solver) {
+      const bool ok = p_row < kSbN;
+      // (16-byte loads: rows of Winv are 192 bytes, rows of the band 8 * 6 bw bytes and every offset below is even)
+      const double2* src = reinterpret_cast<const double2*>(J.Vb + size_t(s) * (kSbN * kSbN) + (ok ? p_row : 0) * kSbN + 12 * q);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const double2 t = ok ? src[c] : make_double2(0.0, 0.0);
+        dst[2 * c] = t.x, dst[2 * c + 1] = t.y;
+      }
+    } else {
+      const int rho = r0 - 1 - p_row;
+      const bool ok = p_row < n_above && rho >= 0;
+      const int base = r0 + 12 * q - 6 * ((ok ? rho : 0) / 6);  // band offset of the first of the 12 columns (even)
+      const double* src = J.Ub + size_t(ok ? rho : 0) * ncb;
+#pragma unroll
+      for (int c = 0; c < 12; c += 2) {
+        const int off = base + c;
+        const double2 t = (ok && off < ncb && r0 + 12 * q + c < n_own) ? *reinterpret_cast<const double2*>(src + off) : make_double2(0.0, 0.0);
+        dst[c] = t.x, dst[c + 1] = t.y;
+      }
+    }
+  };
+  // The solver wave needs the inverses in memory before it requests them. All builders run concurrently and finish within a few
+  // microseconds of the launch, so the wave waits for ALL of its job's flags once, lane i polling flag i (an agent-scope acquire load
+  // costs ~1 us: one per step on the chain doubled the step, five in a row delayed the first step by 8 us).
+  auto request_checked = [&](int s, double* dst) { request(s, dst); };
+  if (solver) {
+    for (int i = l; i < n_sb; i += 64) sb_wait(T, flags + i);
+    __threadfence();
+  }
+  const int s_top = n_sb - 1;
+#pragma unroll
+  for (int d = 0; d < kSbPrefetch; ++d) request_checked(s_top - d, ring[d]);
+  if (cprof) clog[1] = wall_clock64();  // operands staged
+  if (J.given) {  // wait for the middle solution
+    wait_for_partner(T);
+    if (cprof) clog[2] = wall_clock64();  // middle solution arrived
+    for (int rho = n_own + tid; rho < n_all; rho += nthr) xs[rho] = T.xsol[J.reversed ? np - 1 - rho : rho];
+  }
+  __syncthreads();
+  if (merged) {
+    if (tid < n_above) {
+      double acc = 0.0;
+      for (int c = 0; c < n_above; ++c) acc = fma(G[c * ldg + tid], xs[n_own + c], acc);
+      xs[n_own - n_above + tid] -= acc;
+    }
+    __syncthreads();
+  }
+  if (cprof) clog[3] = wall_clock64();  // sweep starts
+  // one super-step; `slot` is the ring entry that holds its operands (compile-time after unrolling)
+  auto step = [&](int s, double* op) {
+    const int r0 = kSbN * s;
+    if (solver) {
+      // x_J[r] = sum_c Winv[r][c] y[c]
+      double acc = 0.0, acc1 = 0.0;
+#pragma unroll
+      for (int c = 0; c < 12; c += 2) {
+        const double2 y = *reinterpret_cast<const double2*>(&xs[r0 + 12 * q + c]);
+        acc = fma(op[c], y.x, acc);
+        acc1 = fma(op[c + 1], y.y, acc1);
+      }
+      acc = pair_sum(acc + acc1);
+      if (q == 0 && p_row < kSbN) {
+        xj[p_row] = acc;
+        if (r0 + p_row < n_own) xout[r0 + p_row] = acc;
+      }
+    }
+    lds_barrier();
+    if (!solver) {
+      const int rho = r0 - 1 - p_row;
+      double acc = 0.0, acc1 = 0.0;
+#pragma unroll
+      for (int c = 0; c < 12; c += 2) {
+        const double2 x = *reinterpret_cast<const double2*>(&xj[12 * q + c]);
+        acc = fma(op[c], x.x, acc);
+        acc1 = fma(op[c + 1], x.y, acc1);
+      }
+      acc = pair_sum(acc + acc1);
+      if (q == 0 && p_row < n_above && rho >= 0) xs[rho] -= acc;
+    }
+    lds_barrier();
+  };
+  const int s_pub = (job == 0 && m_mid >= 0) ? m_mid / kSb : 0;  // block 0 publishes the middle solution once block row m_mid is solved
+  int s = s_top;
+  bool published = !(job == 0 && m_mid >= 0);
+  while (s >= 0) {
+#pragma unroll
+    for (int d = 0; d < kSbPrefetch; ++d) {  // ring entry d holds the operands of super-block s (rotation by unrolling: no register moves)
+      if (s < 0) break;
+      step(s, ring[d]);
+      request_checked(s - kSbPrefetch, ring[d]);
+      if (!published && s == s_pub) {
+        if (cprof) clog[4] = wall_clock64();  // middle rows solved
+        for (int rho = 6 * m_mid + tid; rho < n_own; rho += nthr) T.xsol[rho] = xout[rho];
+        __threadfence();
+        lds_barrier();
+        if (tid == 0) {
+          __threadfence();
+          __hip_atomic_store(T.join_flag, T.join_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (cprof) clog[5] = wall_clock64();  // middle solution published
+        published = true;
+      }
+      --s;
+    }
+  }
+  __syncthreads();
+  if (cprof) clog[6] = wall_clock64();  // sweep done
+  const int flush_to = (job == 0 && m_mid >= 0) ? 6 * m_mid : n_own;  // (the middle rows of block 0 are already out)
+  for (int rho = tid; rho < flush_to; rho += nthr) T.xsol[J.reversed ? np - 1 - rho : rho] = xout[rho];
+  // the sweep that finishes last turns the solution into the step outputs (saves a launch); join_flag[1] advances by two per launch
+  __shared__ int is_last;
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) is_last = (atomicAdd(T.join_flag + 1, 1u) & 1u) == 1u;
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  __shared__ double red[kCholThreads / 64];
+  double gd = 0.0, dd = 0.0;
+  for (int rho0 = tid; rho0 < np; rho0 += 4 * nthr) {
+    double xv[4], sc[4], gf[4], d2[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rho = rho0 + u * nthr, rr = rho < np ? rho : 0;
+      xv[u] = __builtin_nontemporal_load(T.xsol + rr), sc[u] = T.scale_p[rr], gf[u] = T.g_full[rr], d2[u] = T.D2p[rr];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rho = rho0 + u * nthr;
+      if (rho < np) {
+        const double step_v = -xv[u];
+        T.step_p[rho] = step_v;
+        T.delta_p[rho] = sc[u] * step_v;
+        gd = fma(gf[u], step_v, gd);
+        dd = fma(d2[u] * step_v, step_v, dd);
+      }
+    }
+  }
+  gd = block_sum(gd, red);
+  dd = block_sum(dd, red);
+  if (tid == 0) {
+    st->g_dot_step_pose = gd;
+    st->d2_step2_pose = dd;
+  }
+  if (cprof) clog[7] = wall_clock64();  // step outputs written (the block that finished last)
+}
+
+}  // namespace hs

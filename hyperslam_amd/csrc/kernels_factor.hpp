@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(kCholThreads + kCholIo) k_band_factor(Tables T
         const double2 v = *reinterpret_cast<const double2*>(&src[a * ld + 6 * t_kk[m] + c]);
         acc[m][6 * a + c] = v.x, acc[m][6 * a + c + 1] = v.y;
       }
-      rhs[m][a] = t_kk[m] == 0 ? src[a * ld + ncb] : 0.0;
+      rhs[m][a] = (t_kk[m] == 0 ? 1.0 : 0.0) * src[a * ld + ncb];
     }
   };
   lds_barrier();  // initial window loaded / staged
@@ -154,12 +154,13 @@ __global__ void __launch_bounds__(kCholThreads + kCholIo) k_band_factor(Tables T
 #pragma unroll
     for (int m = 0; m < TPT; ++m)
       if (t_ok[m] && t_slot[m] == si) {
+        const int c_rhs = t_kk[m] == 0 ? ncb : ncb + 1;  // lanes without a right-hand side write theirs to the pad column (no branch)
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
 #pragma unroll
           for (int c = 0; c < 6; c += 2)
             *reinterpret_cast<double2*>(&rowbuf[a * ld + 6 * t_kk[m] + c]) = make_double2(acc[m][6 * a + c], acc[m][6 * a + c + 1]);
-          if (t_kk[m] == 0) rowbuf[a * ld + ncb] = rhs[m][a];
+          rowbuf[a * ld + c_rhs] = rhs[m][a];
         }
         refill_tile(m, i + bw);
       }
@@ -247,6 +248,11 @@ __global__ void __launch_bounds__(kCholThreads + kCholIo) k_band_factor(Tables T
       if (j < 0) j += bw;
       if (!t_ok[m] || j == 0 || j + t_kk[m] > bw - 1 || (T.debug_flags & 2)) continue;
       const int ca = 6 * j, cb = 6 * (j + t_kk[m]);
+      // the right-hand side rides along in every lane (only the lanes with kk = 0 use theirs): as a branch around its loads and FMAs it
+      // drained the LDS queue once per row of X (see k_band_factor_la)
+      double yv[6];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) yv[a] = xbuf[a * ld + ncb];
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
         double xa[6], xb[6];
@@ -257,13 +263,10 @@ __global__ void __launch_bounds__(kCholThreads + kCholIo) k_band_factor(Tables T
           xa[c] = va.x, xa[c + 1] = va.y, xb[c] = vb.x, xb[c + 1] = vb.y;
         }
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
+        for (int r = 0; r < 6; ++r) {
 #pragma unroll
           for (int c = 0; c < 6; ++c) acc[m][6 * r + c] = fma(-xa[r], xb[c], acc[m][6 * r + c]);
-        if (t_kk[m] == 0) {
-          const double y = xbuf[a * ld + ncb];
-#pragma unroll
-          for (int r = 0; r < 6; ++r) rhs[m][r] = fma(-xa[r], y, rhs[m][r]);
+          rhs[m][r] = fma(-xa[r], yv[a], rhs[m][r]);
         }
       }
     }

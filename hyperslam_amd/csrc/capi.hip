@@ -888,7 +888,7 @@ int launch_factor(hs_problem* p) {
         k_band_backward2<<<2, kCholThreads, 2 * size_t(T.np) * sizeof(double) + g_lds, s>>>(T3, j0, j1, m);
       else  // super-blocks of four block rows; the inverses of the diagonal super-blocks come from extra workgroups of the launch
         k_band_backward_sb<<<2 + (m + w_mid + kSb - 1) / kSb + (mB + kSb - 1) / kSb, kCholThreads,
-                             std::max((2 * size_t(T.np) + 32) * sizeof(double) + g_lds, size_t(3 * kSbN * (kSbN + 1)) * sizeof(double)), s>>>(T3, j0, j1, m);
+                             std::max((2 * size_t(T.np) + 32) * sizeof(double) + g_lds, size_t(3 * kSbN * (kSbN + 1)) * sizeof(double)), s>>>(T3, j0, j1, m, 2, 0);
     } else {
       launch_backward_w(T3, j0, j1, m, 2, s);
     }
@@ -954,8 +954,16 @@ int launch_factor(hs_problem* p) {
     const BackJob j0{T.Ub, T.Ubk, T.ybuf, nullptr, nullptr, T.np / 6, 0, 0};
     k_band_backward2<<<1, kCholThreads, 2 * size_t(T.np) * sizeof(double), s>>>(T, j0, j0, -1);
     k_step_outputs<<<1, kBlock, 0, s>>>(T);
-  } else if (!(T.debug_flags & 65536)) {  // the four-wave LDS sweep (A/B switch 65536: single-wave register sweep)
-    k_band_backward<<<1, kCholThreads, 2 * size_t(T.np) * sizeof(double), s>>>(T, f0);
+  } else if (!(T.debug_flags & 65536)) {  // (A/B switch 65536: single-wave register sweep)
+    if (6 * (T.bw - 1) <= 96 && !(T.debug_flags & 268435456)) {  // super-blocks of four block rows: one lane pair per pending row, 96 pairs
+      Tables T3 = T;
+      T3.join_epoch = ++p->join_epoch;
+      const BackJob j0{T.Ub, T.Ubk, T.ybuf, p->d_Vb.p, p->d_yt.p, T.np / 6, 0, 0};
+      k_band_backward_sb<<<1 + (T.np / 6 + kSb - 1) / kSb, kCholThreads,
+                           std::max((2 * size_t(T.np) + 32) * sizeof(double), size_t(3 * kSbN * (kSbN + 1)) * sizeof(double)), s>>>(T3, j0, j0, -1, 1, f0);
+    } else {  // wide bands (long feature tracks): one block row per step, one lane per pending row
+      k_band_backward<<<1, kCholThreads, 2 * size_t(T.np) * sizeof(double), s>>>(T, f0);
+    }
   } else {
     const BackJob j0{T.Ub, T.Ubk, T.ybuf, p->d_Vb.p, p->d_yt.p, T.np / 6, 0, 0};
     k_premultiply<<<T.np / 6, 128, 0, s>>>(T, j0, j0, T.np / 6);

@@ -13,6 +13,9 @@
 // Launch: grid = 2 + n_sb(job 0) + n_sb(job 1), 256 lanes. Workgroups 0, 1 are the two sweeps (roles and hand-over exactly as in
 // k_band_backward2: block 0 solves the top system and publishes the middle solution, block 1 takes it as given and solves the reversed
 // bottom system); the remaining workgroups are the inverse builders (first wave only).
+// One-ended systems (bordered: bias splines + gravity; n_jobs = 1): grid = 1 + n_sb, workgroup 0 sweeps the whole factor from the last
+// block row up to block row j_lo (the block rows of leading constant control points above it are decoupled with a zero right-hand
+// side) and writes the step outputs itself, including those of the border unknowns, like k_band_backward.
 #pragma once
 #include "kernels_factor.hpp"
 
@@ -130,13 +133,13 @@ HSD void sb_wait(const Tables& T, const unsigned* flag) {
   }
 }
 
-__global__ void __launch_bounds__(kCholThreads) k_band_backward_sb(Tables T, BackJob j0, BackJob j1, int m_mid) {
+__global__ void __launch_bounds__(kCholThreads) k_band_backward_sb(Tables T, BackJob j0, BackJob j1, int m_mid, int n_jobs, int j_lo) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   DevState* st = T.st;
   if (st->done) return;
   const int tid = threadIdx.x;
-  if (blockIdx.x >= 2) {  // ---------------- inverse builders ----------------
-    const int s0 = int(blockIdx.x) - 2, n0 = sb_count(j0.n_rows);
+  if (int(blockIdx.x) >= n_jobs) {  // ---------------- inverse builders ----------------
+    const int s0 = int(blockIdx.x) - n_jobs, n0 = sb_count(j0.n_rows);
     if (s0 < n0)
       sb_inverse(T, j0, 0, s0, smem);
     else
@@ -159,6 +162,8 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward_sb(Tables T, Bac
   const bool merged = J.given > 0;  // (the two-ended launch always has 6 given = n_above <= n_own)
   const int ldg = n_above | 1;
   for (int rho = tid; rho < n_own; rho += nthr) xs[rho] = J.ybuf[rho];
+  if (n_jobs == 1)
+    for (int rho = tid; rho < n_own; rho += nthr) xout[rho] = 0.0;  // (rows above j_lo are not swept)
   if (tid < kSbN && J.given == 0) smem[n_all + tid] = 0.0;  // a partial last super-block reads 24 entries from its first row on
   if (merged) {
     const int n_g = n_above * n_above;
@@ -280,10 +285,11 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward_sb(Tables T, Bac
   const int s_pub = (job == 0 && m_mid >= 0) ? m_mid / kSb : 0;  // block 0 publishes the middle solution once block row m_mid is solved
   int s = s_top;
   bool published = !(job == 0 && m_mid >= 0);
-  while (s >= 0) {
+  const int s_lo = n_jobs == 1 ? j_lo / kSb : 0;
+  while (s >= s_lo) {
 #pragma unroll
     for (int d = 0; d < kSbPrefetch; ++d) {  // ring entry d holds the operands of super-block s (rotation by unrolling: no register moves)
-      if (s < 0) break;
+      if (s < s_lo) break;
       step(s, ring[d]);
       request_checked(s - kSbPrefetch, ring[d]);
       if (!published && s == s_pub) {
@@ -303,6 +309,30 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward_sb(Tables T, Bac
   }
   __syncthreads();
   if (cprof) clog[6] = wall_clock64();  // sweep done
+  __shared__ double red[kCholThreads / 64];
+  if (n_jobs == 1) {  // one-ended: the solution is in LDS; step = -x, delta = scale o step, reductions of the model cost change
+    double gd = 0.0, dd = 0.0;
+    for (int rho = tid; rho < np; rho += nthr) {
+      const double step_v = -xout[rho];
+      T.step_p[rho] = step_v;
+      T.delta_p[rho] = T.scale_p[rho] * step_v;
+      gd = fma(T.g_full[rho], step_v, gd);
+      dd = fma(T.D2p[rho] * step_v, step_v, dd);
+    }
+    for (int b = tid; b < T.nb; b += nthr) {
+      const double step_v = -T.xb[b];
+      T.delta_b[b] = T.scale_b[b] * step_v;
+      gd = fma(T.gb_s[b], step_v, gd);
+      dd = fma(T.D2b[b] * step_v, step_v, dd);
+    }
+    gd = block_sum(gd, red);
+    dd = block_sum(dd, red);
+    if (tid == 0) {
+      st->g_dot_step_pose = gd;
+      st->d2_step2_pose = dd;
+    }
+    return;
+  }
   const int flush_to = (job == 0 && m_mid >= 0) ? 6 * m_mid : n_own;  // (the middle rows of block 0 are already out)
   for (int rho = tid; rho < flush_to; rho += nthr) T.xsol[J.reversed ? np - 1 - rho : rho] = xout[rho];
   // the sweep that finishes last turns the solution into the step outputs (saves a launch); join_flag[1] advances by two per launch
@@ -313,7 +343,6 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward_sb(Tables T, Bac
   __syncthreads();
   if (!is_last) return;
   __threadfence();
-  __shared__ double red[kCholThreads / 64];
   double gd = 0.0, dd = 0.0;
   for (int rho0 = tid; rho0 < np; rho0 += 4 * nthr) {
     double xv[4], sc[4], gf[4], d2[4];

@@ -597,7 +597,7 @@ int prepare(hs_problem* p) {
   T.xsol = p->d_xsol.p, T.join_flag = p->d_join.p, T.join_epoch = 0;
   T.debug_flags = std::getenv("HS_DEBUG_FLAGS") ? std::atoi(std::getenv("HS_DEBUG_FLAGS")) : 0;
   {  // the reversed copy feeds the far end of a two-ended factorisation and, as the lower band, every MFMA factorisation
-    const bool la_ok = vs.bw * (vs.bw - 2) <= kLaCompute, two_ended = la_ok && nbd == 0 && np / 6 >= 4 * vs.bw;
+    const bool la_ok = la_compute_waves(vs.bw) > 0, two_ended = la_ok && nbd == 0 && np / 6 >= 4 * vs.bw;
     const bool need = two_ended || ((T.debug_flags & 131072) && mfma_window_tiles(vs.bw) > 0);
     T.Sb2 = need ? p->d_Sb2.p : nullptr, T.g2 = need ? p->d_g2.p : nullptr;
   }
@@ -853,7 +853,8 @@ int launch_factor(hs_problem* p) {
   const bool legacy = T.debug_flags & 4;  // A/B switch: pre-look-ahead kernel
   // Factoring from both ends at once (visual-only systems, look-ahead kernel, window long enough to pay for the junction)
   const int n_blk = T.np / 6, w_mid = T.bw - 1;
-  const bool la_ok = !legacy && T.bw * (T.bw - 2) <= kLaCompute;
+  const bool la_ok = !legacy && la_compute_waves(T.bw) > 0;
+  const int la_ncw = la_compute_waves(T.bw);
   const int nt = (T.debug_flags & 131072) ? mfma_window_tiles(T.bw) : 0;  // A/B switch 131072: k_band_factor_mfma instead of the VALU kernels
   const bool two_ended = (la_ok || nt) && T.nb == 0 && n_blk >= 4 * T.bw && T.Sb2 && !(T.debug_flags & 2048);
   auto run_mfma = [&](const Tables& TT, int grid) -> hipError_t {
@@ -876,7 +877,10 @@ int launch_factor(hs_problem* p) {
     if (nt)
       HIP_TRY(run_mfma(T2, 2));
     else
-      k_band_factor_la<1><<<2, kLaThreads, la_lds, s>>>(T2);
+      if (la_ncw == 3)
+        k_band_factor_la<1, 3><<<2, la_threads(3), la_lds, s>>>(T2);
+      else
+        k_band_factor_la<1, 4><<<2, la_threads(4), la_lds, s>>>(T2);
     Tables T3 = T2;
     T3.join_epoch = ++p->join_epoch;
     const BackJob j0{T.Ub, T.Ubk, T.ybuf, p->d_Vb.p, p->d_yt.p, m + w_mid, 0, 0};
@@ -916,8 +920,10 @@ int launch_factor(hs_problem* p) {
     T1.mj[0] = MfmaJob{p->d_Sb2.p, Tf.g_s, Tf.Ub, Tf.Ubk, Tf.ybuf, nullptr, n_blk - f0, -1, n_blk - f0, INT_MAX, 0, p->d_Vb.p + size_t(T.np) * (6 * T.bw)};
     T1.mj[1] = T1.mj[0];
     HIP_TRY(run_mfma(T1, 1));
-  } else if (la_ok)
-    k_band_factor_la<1><<<1, kLaThreads, la_lds, s>>>(Tf);
+  } else if (la_ok && la_ncw == 3)
+    k_band_factor_la<1, 3><<<1, la_threads(3), la_lds, s>>>(Tf);
+  else if (la_ok)
+    k_band_factor_la<1, 4><<<1, la_threads(4), la_lds, s>>>(Tf);
   // (two tiles per lane need 168 accumulator registers: with six waves per workgroup the budget is 256 and the look-ahead
   //  kernel spills in its update loop - wider bands stay on the kernel below)
   else if (T.bw * T.bw <= kCholThreads)
@@ -1008,7 +1014,8 @@ int set_func_attributes(hs_problem* p) {
   p->chol_lds_max = 160 * 1024 - int(fa.sharedSizeBytes);
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor<1>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor<2>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_la<1>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_la<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_la<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seg_gram<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seg_gram<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_solve_reg<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));

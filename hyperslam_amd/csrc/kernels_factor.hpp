@@ -315,11 +315,15 @@ HSD void wait_for_partner(const Tables& T) {
   }
 }
 
-constexpr int kLaCompute = 192;
-constexpr int kLaThreads = kLaCompute + 3 * 64;
+/// Compute waves of the look-ahead kernel for a band of bw control points: ring slot s lives in compute wave s % NCW, so a wave holds
+/// ceil(bw / NCW) slots of bw - 2 tiles, one tile per lane. 0 = the band does not fit (one-ended kernels below).
+constexpr int la_compute_waves(int bw) { return ((bw + 2) / 3) * (bw - 2) <= 64 ? 3 : ((bw + 3) / 4) * (bw - 2) <= 64 ? 4 : 0; }
+/// Waves of the workgroup: three compute waves on SIMDs 0 - 2, the panel wave alone on SIMD 3, loader and storer (waves 4, 5: SIMDs 0, 1);
+/// a fourth compute wave (bands of 15 and 16 control points: order-6 splines) is wave 6 and shares SIMD 2 with compute wave 2.
+constexpr int la_threads(int ncw) { return ncw == 3 ? 6 * 64 : 7 * 64; }
 
-template <int TPT>  // tiles per compute thread: bw * (bw - 2) <= TPT * kLaCompute
-__global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
+template <int TPT, int NCW>  // one tile per compute lane; NCW compute waves
+__global__ void __launch_bounds__(la_threads(NCW)) k_band_factor_la(Tables T) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   DevState* st = T.st;
   if (st->done) return;
@@ -342,8 +346,10 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
   auto junction_wait = [&]() {                                  // job 0: the other end has published its window
     wait_for_partner(T);
   };
-  const int tid = threadIdx.x;
-  constexpr int nthr = kLaCompute;
+  constexpr int nthr = 64 * NCW;
+  const int wave = int(threadIdx.x) >> 6, l = int(threadIdx.x) & 63;
+  const int cwave = wave < 3 ? wave : 3;        // compute wave index of waves 0, 1, 2 (and 6)
+  const int tid = wave < 3 ? int(threadIdx.x) : wave == 6 ? 192 + l : int(threadIdx.x);  // compute lanes: 0 .. nthr - 1, contiguous
   constexpr int PC = 2;  // columns of the pivot row per panel lane: 6 * bw + 1 <= 128 (bw <= 20)
   const int bw = T.bw, ncb = 6 * bw, ld = ncb + 2;
   const int n_blk = T.np / 6;
@@ -355,8 +361,7 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
   double* dscr = xs + T.np;         // 36 : updated diagonal block of the panel row
   double* dinv = dscr + 36;         // 2 x 6 : 1 / diag(U_rr) in dinv[r & 1]
   __shared__ int fail;
-  if (tid == 0) fail = 0;
-  const int wave = tid >> 6, l = tid & 63;
+  if (threadIdx.x == 0) fail = 0;
   if (wave == 4 || wave == 5) {  // ================================ IO waves ================================
     // lane l owns columns l and l + 64 of a block row ([band | rhs], 6 * bw + 1 <= 128 columns), all six rows: no index tables
     int c_col[2];
@@ -681,7 +686,7 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
   }
 
   // ================================ compute waves: static tile ownership ================================
-  // Ring slot s (block rows s, s + bw, s + 2 bw, ...) lives in wave s % 3, lanes (s / 3) (bw - 2) + kk: consecutive block rows sit in
+  // Ring slot s (block rows s, s + bw, s + 2 bw, ...) lives in compute wave s % NCW, lanes (s / NCW) (bw - 2) + kk: consecutive block rows sit in
   // different waves. The wave that owns block row i + 2 is the last one at the step barrier (it publishes the row on top of its update
   // pass); with consecutive rows in one wave it also had to refill the slot it published the step before.
   static_assert(TPT == 1, "one tile per lane");
@@ -690,7 +695,7 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
   double acc[TPT][36], rhs[TPT][6];
 #pragma unroll
   for (int m = 0; m < TPT; ++m) {
-    const int slot = wave + 3 * (l / (bw - 2));
+    const int slot = cwave + NCW * (l / (bw - 2));
     t_ok[m] = slot < bw;
     t_kk[m] = l % (bw - 2);
     t_row[m] = slot < 2 ? slot + bw : slot;  // rows 0 and 1 start in LDS (loader); their slots prefetch rows bw, bw + 1
@@ -799,7 +804,7 @@ __global__ void __launch_bounds__(kLaThreads) k_band_factor_la(Tables T) {
       const double* WD = J.win;  // correction in this job's own band layout, local to the middle rows (see hand_over)
       // The window was written by a workgroup on another XCD: every load misses this L2 (~2 us). All operands are requested first —
       // the two LDS rows (up to six entries per lane) and the register tiles — so that the merge costs one round trip, not seven.
-      constexpr int RU = 6;  // 2 * 6 * (ncb + 1) <= RU * nthr  (ncb <= 95)
+      constexpr int RU = 7;  // 2 * 6 * (ncb + 1) <= RU * nthr  (ncb <= 96)
       double wrow[RU];
 #pragma unroll
       for (int u = 0; u < RU; ++u) {

@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "host_structure.hpp"
@@ -639,12 +640,21 @@ size_t lin_lds_bytes(const hs_problem* p) {  // control points + one record slab
   return (cp_lds_bytes(p) <= 24 * 1024 ? cp_lds_bytes(p) : 0) + size_t(lin_block<K>()) * (8 + 12 * K + 2) * sizeof(double);
 }
 
+__global__ void k_noop() {}
+
+/// The side stream of the inertial branch and its three events. Created by hs_create and used once there: a stream gets its hardware
+/// queue at its first submission, which — together with the first allocations — made the first optimize() with an IMU 10 ms long.
 static int ensure_side_stream(hs_problem* p) {
   if (!p->side) {
     HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&p->ev_irec, hipEventDisableTiming));
+    k_noop<<<1, 64, 0, p->side>>>();
+    HIP_TRY(hipEventRecord(p->ev_join, p->side));
+    HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_join, 0));
+    k_noop<<<1, 64, 0, p->stream>>>();
+    HIP_TRY(hipStreamSynchronize(p->stream));
   }
   return HS_OK;
 }
@@ -1007,6 +1017,47 @@ int launch_update(hs_problem* p) {
   return HS_OK;
 }
 
+/// First use of a kernel costs ~0.35 ms of host time (the runtime builds its kernel object lazily); a solve touches ~25 different kernels,
+/// which showed up as a 9 ms hs_solve on the first optimize() of a process (HS_HOST_TIMING=2: "launches" of call 0). hs_create resolves
+/// the kernels of the solve path up front, once per process and device; what remains on the first call is the allocation of the tables.
+template <int K>
+static void warm_kernels_of_order() {
+  hipFuncAttributes fa;
+  const void* kernels[] = {
+      reinterpret_cast<const void*>(&k_linearize_visual<K>), reinterpret_cast<const void*>(&k_linearize_prior<K>),
+      reinterpret_cast<const void*>(&k_linearize_inertial<K, 4>), reinterpret_cast<const void*>(&k_landmark<K, 2, 2>),
+      reinterpret_cast<const void*>(&k_landmark<K, 4, 1>), reinterpret_cast<const void*>(&k_landmark_rows<K, 4>),
+      reinterpret_cast<const void*>(&k_gram_pair<K, 1>), reinterpret_cast<const void*>(&k_gram_pair<K, 2>), reinterpret_cast<const void*>(&k_gram_pair<K, 4>),
+      reinterpret_cast<const void*>(&k_seg_gram<K>), reinterpret_cast<const void*>(&k_assemble<K>), reinterpret_cast<const void*>(&k_border_pb<K>),
+      reinterpret_cast<const void*>(&k_border_bb<K>), reinterpret_cast<const void*>(&k_cost_visual<K>), reinterpret_cast<const void*>(&k_cost_prior<K>),
+      reinterpret_cast<const void*>(&k_cost_inertial<K, 4>), reinterpret_cast<const void*>(&k_cost_all<K, 4>),
+      reinterpret_cast<const void*>(&k_process_tracks<K>), reinterpret_cast<const void*>(&k_sample_trajectory<K>)};
+  for (const void* k : kernels) (void)hipFuncGetAttributes(&fa, k);
+}
+static void warm_kernels(int device) {
+  static std::mutex mu;
+  static std::vector<int> done;
+  std::lock_guard<std::mutex> lock(mu);
+  if (std::find(done.begin(), done.end(), device) != done.end()) return;
+  done.push_back(device);
+  hipFuncAttributes fa;
+  const void* kernels[] = {
+      reinterpret_cast<const void*>(&k_group_gram<1>), reinterpret_cast<const void*>(&k_group_gram<2>), reinterpret_cast<const void*>(&k_group_gram<4>),
+      reinterpret_cast<const void*>(&k_pack_exchange), reinterpret_cast<const void*>(&k_cost_reduce), reinterpret_cast<const void*>(&k_finalize_reduced),
+      reinterpret_cast<const void*>(&k_finalize_border), reinterpret_cast<const void*>(&k_reduce_partials), reinterpret_cast<const void*>(&k_factor_decoupled_rows),
+      reinterpret_cast<const void*>(&k_dense_factor), reinterpret_cast<const void*>(&k_band_factor_wide), reinterpret_cast<const void*>(&k_band_factor<1>),
+      reinterpret_cast<const void*>(&k_band_factor<2>), reinterpret_cast<const void*>(&k_band_factor_la<1, 3>), reinterpret_cast<const void*>(&k_band_factor_la<1, 4>),
+      reinterpret_cast<const void*>(&k_band_backward), reinterpret_cast<const void*>(&k_band_backward_sb), reinterpret_cast<const void*>(&k_border_forward),
+      reinterpret_cast<const void*>(&k_border_schur), reinterpret_cast<const void*>(&k_border_solve), reinterpret_cast<const void*>(&k_border_solve_reg<4>),
+      reinterpret_cast<const void*>(&k_border_solve_reg<5>), reinterpret_cast<const void*>(&k_border_solve_reg<6>), reinterpret_cast<const void*>(&k_border_solve_reg<7>),
+      reinterpret_cast<const void*>(&k_border_solve_reg<8>), reinterpret_cast<const void*>(&k_border_apply), reinterpret_cast<const void*>(&k_backsub_retract),
+      reinterpret_cast<const void*>(&k_pack_decision), reinterpret_cast<const void*>(&k_decide), reinterpret_cast<const void*>(&k_commit),
+      reinterpret_cast<const void*>(&k_reset_state), reinterpret_cast<const void*>(&k_scatter_uploads)};
+  for (const void* k : kernels) (void)hipFuncGetAttributes(&fa, k);
+  warm_kernels_of_order<4>();
+  warm_kernels_of_order<6>();
+}
+
 int set_func_attributes(hs_problem* p) {
   // opt in to > 64 KiB dynamic LDS for the factorisation
   hipFuncAttributes fa;
@@ -1072,7 +1123,8 @@ int hs_create(int device, void* stream, hs_problem** out) {
     delete p;
     return HS_ERR_DEVICE;
   }
-  if (set_func_attributes(p) != HS_OK) {
+  warm_kernels(device);
+  if (set_func_attributes(p) != HS_OK || ensure_side_stream(p) != HS_OK) {
     const std::string e = p->err;
     std::fprintf(stderr, "hyperslam_hip: %s\n", e.c_str());
     delete p;
@@ -1092,6 +1144,10 @@ int hs_destroy(hs_problem* p) {
     for (size_t i = h; i < n; ++i)
       for (int c = 0; c < 4; ++c) m[c] += p->host_log[4 * i + c] / double(n - h);
     std::fprintf(stderr, "hs host timing, second half of the calls: structure + tables %.4f, uploads %.4f, launches %.4f, wait %.4f\n", m[0], m[1], m[2], m[3]);
+    if (const char* e = std::getenv("HS_HOST_TIMING"); e && std::atoi(e) >= 2)  // HS_HOST_TIMING=2: every call (where a one-off cost sits)
+      for (size_t i = 0; i < n; ++i)
+        std::fprintf(stderr, "hs host timing call %zu: structure + tables %.4f, uploads %.4f, launches %.4f, wait %.4f\n", i, p->host_log[4 * i],
+                     p->host_log[4 * i + 1], p->host_log[4 * i + 2], p->host_log[4 * i + 3]);
   }
   if (p->scratch) hs_destroy(p->scratch), p->scratch = nullptr;
   (void)hipSetDevice(p->device);

@@ -43,3 +43,35 @@ def test_rccl_hook_single_rank(tmp_path):
     d = np.load(out)
     assert np.array_equal(d["c0"], d["c1"]) and np.array_equal(d["cp0"], d["cp1"])
     assert np.array_equal(d["c0"], d["c2"]) and np.array_equal(d["cp0"], d["cp2"])   # hs_rccl_init path (no Python hook)
+
+
+def test_rccl_two_ranks_on_two_gpus(tmp_path, hip):
+    """hs_rccl_init with world > 1: one process per GPU, the library-owned RCCL communicator sums the reduced normal equations of the two
+    landmark shards on the library's stream (xGMI between the GPUs); both ranks must end with the single-GPU trajectory. Needs two
+    visible GPUs (the test box of this repository has one: skipped there, run on every multi-GPU node)."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    full = synthetic.config3(n_cp=64, n_landmarks=600, obs_pairs=5)
+    with ha.Problem(full, lib=hip) as p:
+        S, g = p.reduced_system(1e4)
+        s = p.solve(5)
+        cp, lm = p.control_points(), p.landmarks()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    worker = os.path.join(os.path.dirname(__file__), "_rccl_world_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(tmp_path)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [q.communicate(timeout=600)[0].decode() for q in procs]
+    assert all(q.returncode == 0 for q in procs), "\n".join(outs)
+    ranks = [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(2)]
+    for r in ranks:
+        assert rel(r["S"], S) < 1e-10 and rel(r["g"], g) < 1e-10
+        assert int(r["iters"]) == s["num_iterations"]
+        assert np.allclose(r["costs"], [it["cost"] for it in s["iterations"]], rtol=1e-7, atol=0)
+        assert rel(r["cp"], cp) < 1e-7
+        ids = r["lm_ids"]
+        assert rel(r["lm"][ids], lm[ids]) < 1e-7
+    assert np.array_equal(ranks[0]["S"], ranks[1]["S"]) and np.array_equal(ranks[0]["cp"], ranks[1]["cp"])

@@ -217,6 +217,7 @@ struct hs_problem {
   DBuf<double> d_Vb, d_Vb2, d_yt, d_yt2;  // block-row-scaled factors diag(U_jj^-1) U and right-hand sides for the register sweep
   DBuf<double> d_Sb2, d_g2, d_Ub2, d_Ubk2, d_ybuf2, d_win, d_xsol;  // two-ended factorisation: reversed system, its factor, junction window
   DBuf<unsigned> d_join;
+  DBuf<double> d_bf_handover;  // k_border_forward2: what the far end's sweep leaves on the middle rows, per column group
   unsigned join_epoch = 0;
   DBuf<int> d_gw_ptr, d_gw_cf, d_sw_ptr, d_sw_seg;
   int n_seg_wg = 0, n_group_wg = 0;
@@ -517,8 +518,8 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_win.reserve(size_t(6) * vs.bw * (ncb + 1)));
   if (!p->d_join.p) {
     // [0] two-ended factor / sweep hand-over, [1] last-block ticket of the backward sweeps, [2] of k_border_bb, [4 ..] super-block inverses
-    HIP_TRY(p->d_join.reserve(kSbFlagBase + 2 * kSbMaxBlocks));
-    HIP_TRY(hipMemsetAsync(p->d_join.p, 0, (kSbFlagBase + 2 * kSbMaxBlocks) * sizeof(unsigned), s));
+    HIP_TRY(p->d_join.reserve(kBfFlagBase + 512));  // (+ one flag per column group of k_border_forward2)
+    HIP_TRY(hipMemsetAsync(p->d_join.p, 0, (kBfFlagBase + 512) * sizeof(unsigned), s));
     p->join_epoch = 0;
   }
   // split the accumulation over enough workgroups to fill the chip (256 CUs x a few workgroups)
@@ -592,13 +593,13 @@ int prepare(hs_problem* p) {
   T.xpart = p->d_xpart.p, T.gravity_part = p->d_gravity_part.p, T.segP = p->d_segP.p, T.grpQ = p->d_grpQ.p, T.gw_ptr = p->d_gw_ptr.p, T.gw_cf = p->d_gw_cf.p, T.sw_ptr = p->d_sw_ptr.p, T.sw_seg = p->d_sw_seg.p;
   T.xo_g = np * ncb, T.xo_gs = T.xo_g + np, T.xo_dj = T.xo_gs + np, T.xo_pb = T.xo_dj + np, T.xo_bb = T.xo_pb + np * nbd;
   T.xo_gb = T.xo_bb + nbd * nbd, T.xo_cost = T.xo_gb + nbd, T.xo_gmax = T.xo_cost + 1;
-  T.ybuf = p->d_ybuf.p;
+  T.ybuf = p->d_ybuf.p, T.ybuf2 = nullptr, T.y_split = np;
   T.fj[0] = FactorJob{T.Sb, T.g_s, T.Ub, T.Ubk, T.ybuf, nullptr, np / 6, -1};
   T.fj[1] = FactorJob{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, -1};
   T.xsol = p->d_xsol.p, T.join_flag = p->d_join.p, T.join_epoch = 0;
   T.debug_flags = std::getenv("HS_DEBUG_FLAGS") ? std::atoi(std::getenv("HS_DEBUG_FLAGS")) : 0;
   {  // the reversed copy feeds the far end of a two-ended factorisation and, as the lower band, every MFMA factorisation
-    const bool la_ok = la_compute_waves(vs.bw) > 0, two_ended = la_ok && nbd == 0 && np / 6 >= 4 * vs.bw;
+    const bool la_ok = la_compute_waves(vs.bw) > 0, two_ended = la_ok && np / 6 >= 4 * vs.bw;
     const bool need = two_ended || ((T.debug_flags & 131072) && mfma_window_tiles(vs.bw) > 0);
     T.Sb2 = need ? p->d_Sb2.p : nullptr, T.g2 = need ? p->d_g2.p : nullptr;
   }
@@ -854,6 +855,24 @@ void launch_backward_w(const Tables& T, const BackJob& j0, const BackJob& j1, in
     k_band_backward_w<5><<<grid, 64, lds, s>>>(T, j0, j1, m_mid);
 }
 
+/// Dense Cholesky of the border Schur complement + solve for the border unknowns (one workgroup).
+static hipError_t launch_border_solve(const Tables& T, hipStream_t s) {
+  if (T.nb + 1 <= 128 && !(T.debug_flags & 524288)) {  // trailing matrix in registers (A/B switch 524288: the LDS version)
+    const int R = std::max(4, (T.nb + 1 + 15) / 16), N = 16 * R;
+    const size_t lds = (size_t(4) * N + size_t(T.nb) * (N + 1) + T.nb) * sizeof(double);
+    switch (R) {
+      case 4: k_border_solve_reg<4><<<1, kBlock, lds, s>>>(T); break;
+      case 5: k_border_solve_reg<5><<<1, kBlock, lds, s>>>(T); break;
+      case 6: k_border_solve_reg<6><<<1, kBlock, lds, s>>>(T); break;
+      case 7: k_border_solve_reg<7><<<1, kBlock, lds, s>>>(T); break;
+      default: k_border_solve_reg<8><<<1, kBlock, lds, s>>>(T); break;
+    }
+  } else {
+    k_border_solve<<<1, kBlock, (size_t(T.nb + 1) * (T.nb + 1) + T.nb) * sizeof(double), s>>>(T);
+  }
+  return hipGetLastError();
+}
+
 int launch_factor(hs_problem* p) {
   const Tables& T = p->T;
   hipStream_t s = p->stream;
@@ -866,7 +885,9 @@ int launch_factor(hs_problem* p) {
   const bool la_ok = !legacy && la_compute_waves(T.bw) > 0;
   const int la_ncw = la_compute_waves(T.bw);
   const int nt = (T.debug_flags & 131072) ? mfma_window_tiles(T.bw) : 0;  // A/B switch 131072: k_band_factor_mfma instead of the VALU kernels
-  const bool two_ended = (la_ok || nt) && T.nb == 0 && n_blk >= 4 * T.bw && T.Sb2 && !(T.debug_flags & 2048);
+  // (bordered systems — bias splines + gravity — too: the forward sweep of the border columns follows the two-ended elimination order,
+  //  k_border_forward2; A/B switch 536870912: bordered systems one-ended)
+  const bool two_ended = (la_ok || nt) && (T.nb == 0 || (!nt && !(T.debug_flags & 536870912))) && n_blk >= 4 * T.bw && T.Sb2 && !(T.debug_flags & 2048);
   auto run_mfma = [&](const Tables& TT, int grid) -> hipError_t {
     switch (nt) {
       case 6: return launch_mfma<6, 3>(TT, grid, s);
@@ -891,6 +912,21 @@ int launch_factor(hs_problem* p) {
         k_band_factor_la<1, 3><<<2, la_threads(3), la_lds, s>>>(T2);
       else
         k_band_factor_la<1, 4><<<2, la_threads(4), la_lds, s>>>(T2);
+    if (T.nb) {  // bordered system: Z = U^-T S_pb in the two-ended elimination order, border Schur complement and solve, y' = y - Z x_b
+      Tables Tb = T2;
+      Tb.ybuf2 = p->d_ybuf2.p, Tb.y_split = 6 * (m + w_mid);
+      Tb.join_epoch = ++p->join_epoch;
+      const int n_groups = (T.nb + kBorderCols - 1) / kBorderCols;
+      HIP_TRY(p->d_bf_handover.reserve(size_t(n_groups) * 6 * w_mid * kBorderCols + 1));
+      const int fwd_threads = std::max(128, 64 * ((6 * w_mid + 63) / 64));  // one lane per pending row
+      const int local_rows = (!p->allreduce && !p->rccl_comm && p->world == 1) ? 1 : 0;
+      k_border_forward2<<<dim3(n_groups, 2), fwd_threads, size_t(T.np) * kBorderLd * sizeof(double), s>>>(
+          Tb, BfJob{T.Ub, T.Ubk, m + w_mid, 0}, BfJob{p->d_Ub2.p, p->d_Ubk2.p, mB, 1}, m, 0, local_rows, p->d_bf_handover.p);
+      const int n_tiles = (T.nb + kSchurTile - 1) / kSchurTile;
+      k_border_schur<<<dim3(n_tiles, n_tiles), kBlock, 0, s>>>(Tb, 0, local_rows);
+      HIP_TRY(launch_border_solve(Tb, s));
+      k_border_apply<<<(T.np + kBlock / 64 - 1) / (kBlock / 64), kBlock, 0, s>>>(Tb);
+    }
     Tables T3 = T2;
     T3.join_epoch = ++p->join_epoch;
     const BackJob j0{T.Ub, T.Ubk, T.ybuf, p->d_Vb.p, p->d_yt.p, m + w_mid, 0, 0};
@@ -951,19 +987,7 @@ int launch_factor(hs_problem* p) {
     k_border_forward<<<(T.nb + kBorderCols - 1) / kBorderCols, fwd_threads, size_t(T.np) * kBorderLd * sizeof(double), s>>>(T, f0, local_rows);
     const int nt = (T.nb + kSchurTile - 1) / kSchurTile;
     k_border_schur<<<dim3(nt, nt), kBlock, 0, s>>>(T, f0, local_rows);
-    if (T.nb + 1 <= 128 && !(T.debug_flags & 524288)) {  // trailing matrix in registers (A/B switch 524288: the LDS version)
-      const int R = std::max(4, (T.nb + 1 + 15) / 16), N = 16 * R;
-      const size_t lds = (size_t(4) * N + size_t(T.nb) * (N + 1) + T.nb) * sizeof(double);
-      switch (R) {
-        case 4: k_border_solve_reg<4><<<1, kBlock, lds, s>>>(T); break;
-        case 5: k_border_solve_reg<5><<<1, kBlock, lds, s>>>(T); break;
-        case 6: k_border_solve_reg<6><<<1, kBlock, lds, s>>>(T); break;
-        case 7: k_border_solve_reg<7><<<1, kBlock, lds, s>>>(T); break;
-        default: k_border_solve_reg<8><<<1, kBlock, lds, s>>>(T); break;
-      }
-    } else {
-      k_border_solve<<<1, kBlock, (size_t(T.nb + 1) * (T.nb + 1) + T.nb) * sizeof(double), s>>>(T);
-    }
+    HIP_TRY(launch_border_solve(T, s));
     k_border_apply<<<(T.np + kBlock / 64 - 1) / (kBlock / 64), kBlock, 0, s>>>(T);
   }
   if ((T.debug_flags & 8192) && !T.nb) {  // A/B: the generalised sweep on the whole system

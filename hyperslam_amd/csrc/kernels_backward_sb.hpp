@@ -363,6 +363,12 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward_sb(Tables T, Bac
       }
     }
   }
+  for (int b = tid; b < T.nb; b += nthr) {  // border unknowns of a bordered system (bias points, gravity)
+    const double step_v = -T.xb[b];
+    T.delta_b[b] = T.scale_b[b] * step_v;
+    gd = fma(T.gb_s[b], step_v, gd);
+    dd = fma(T.D2b[b] * step_v, step_v, dd);
+  }
   gd = block_sum(gd, red);
   dd = block_sum(dd, red);
   if (tid == 0) {

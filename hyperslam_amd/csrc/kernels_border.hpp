@@ -236,6 +236,10 @@ __global__ void __launch_bounds__(kBlock) k_finalize_border(Tables T) { finalize
 //   C = S_bb - Z'Z, h = g_b - Z'y  (k_border_schur, one workgroup per border row)
 //   C x_b = h (dense Cholesky in LDS), y' = y - Z x_b  (k_border_solve, one workgroup)   then the banded backward sweep on y'.
 // ---------------------------------------------------------------------------------------------------------------------
+/// Row rho of the forward-solved right-hand side y. One-ended factorisation: T.ybuf. Two-ended: the near end's rows (top and middle,
+/// rho < T.y_split) are in T.ybuf, the far end's in T.ybuf2 in reversed order.
+HSD double* y_slot(const Tables& T, int rho) { return rho < T.y_split ? T.ybuf + rho : T.ybuf2 + (T.np - 1 - rho); }
+
 constexpr int kBorderCols = 2;  // right-hand sides per workgroup in the forward sweep
 constexpr int kBorderLd = 6;    // LDS row stride of the pending rows (doubles): rows of a power-of-two size put every fourth lane on the same banks
                                 // (16-way conflict on the row read-modify-write of every step); + 16 bytes keeps the alignment and spreads them
@@ -336,6 +340,139 @@ __global__ void __launch_bounds__(kBlock) k_border_forward(Tables T, int j_lo, i
   }
 }
 
+/// Forward sweep Z = U^-T S_pb for a factorisation from BOTH ENDS (k_band_factor_la, grid 2): the elimination order is top rows and
+/// (reversed) bottom rows side by side, then the middle rows, and the sweep of the border columns has to follow it. grid = (column
+/// groups, 2): workgroup (g, 1) sweeps the far end's own block rows in reversed coordinates with the far end's factor and hands the
+/// updates that its last rows leave on the middle rows over (T.join_flag[kBfFlagBase + g], agent scope); workgroup (g, 0) sweeps the
+/// top rows, adds the hand-over in front of the first middle block row and carries on through the middle rows with the near end's
+/// factor — the same recurrence as k_border_forward, one block row per step.
+struct BfJob {
+  const double* Ub;
+  const double* Ubk;
+  int n_rows;    // block rows this job eliminates (near end: top + middle)
+  int reversed;  // row rho of this job is row np - 1 - rho of the system
+};
+constexpr int kBfFlagBase = 4 + 2 * 512;  // behind the super-block flags of the backward sweep (kernels_backward_sb.hpp)
+
+__global__ void __launch_bounds__(kBlock) k_border_forward2(Tables T, BfJob j0, BfJob j1, int m_junction, int j_lo, int local_rows, double* handover) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (T.st->done) return;
+  const int tid = threadIdx.x, grp = blockIdx.x, far = blockIdx.y;
+  const BfJob J = far ? j1 : j0;
+  const int bw = T.bw, ncb = 6 * bw, nb = T.nb, np = T.np, w_mid = bw - 1;
+  const int n_rows = J.n_rows, nz = 6 * (n_rows + (far ? w_mid : 0));  // rows of z: own rows (+ the middle rows the far end leaves updates on)
+  const int c0 = grp * kBorderCols, ncols = min(kBorderCols, nb - c0);
+  const int m0 = far ? 0 : min(min(local_rows ? max(j_lo, T.bfwd_start[grp]) : j_lo, n_rows - 1), m_junction - 1);
+  double* z = smem;
+  for (int e = tid; e < nz * kBorderCols; e += blockDim.x) {
+    const int rho = e / kBorderCols, c = e % kBorderCols;
+    const bool own = rho < 6 * n_rows;
+    const int row = far ? np - 1 - rho : rho;
+    z[rho * kBorderLd + c] = (c < ncols && own) ? T.Spb[size_t(row) * nb + c0 + c] : 0.0;
+  }
+  __syncthreads();
+  __shared__ __attribute__((aligned(16))) double zi[2][6 * kBorderCols];
+  const int n_pend = 6 * w_mid;
+  constexpr int D = 4;
+  const bool pend = tid < n_pend, diag = tid < 6 * kBorderCols;
+  const int da = diag ? tid / kBorderCols : 0, dc = diag ? tid % kBorderCols : 0;
+  double ur[D][6], wr[D][6];
+  auto request = [&](int m, double* u, double* w) {
+    const int mm = m < n_rows ? m : 0, mw = m + 1 < n_rows ? m + 1 : 0;
+    const double* src = J.Ub + size_t(6 * mm) * ncb + 6 + (pend ? tid : 0);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) u[a] = src[size_t(a) * ncb];
+    const double* W = J.Ubk + size_t(mw) * 24;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) w[k] = W[k <= da ? k * 6 - k * (k - 1) / 2 + (da - k) : 0];
+  };
+  auto diag_solve = [&](int m, const double* w) {
+    if (diag) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) v = fma(k <= da ? w[k] : 0.0, z[(6 * m + k) * kBorderLd + dc], v);
+      zi[m & 1][tid] = v;
+      z[(6 * m + da) * kBorderLd + dc] = v;
+    }
+  };
+  {
+    double w0[6];
+    const double* W = J.Ubk + size_t(m0) * 24;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) w0[k] = W[k <= da ? k * 6 - k * (k - 1) / 2 + (da - k) : 0];
+    if (tid < 64) diag_solve(m0, w0);
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) request(m0 + d, ur[d], wr[d]);
+  __syncthreads();
+  double* ho = handover + size_t(grp) * (6 * w_mid * kBorderCols);
+  const unsigned* flag = T.join_flag + kBfFlagBase + grp;
+  for (int mb = m0; mb < n_rows; mb += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int m = mb + d;
+      if (m >= n_rows) break;
+      if (pend) {
+        const int rho = 6 * (m + 1) + tid;
+        if (rho < nz) {
+          double2* zr = reinterpret_cast<double2*>(z + rho * kBorderLd);
+          const double2* zm = reinterpret_cast<const double2*>(zi[m & 1]);
+          double2 acc[kBorderCols / 2];
+#pragma unroll
+          for (int c = 0; c < kBorderCols / 2; ++c) acc[c] = zr[c];
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int c = 0; c < kBorderCols / 2; ++c) {
+              const double2 t = zm[a * (kBorderCols / 2) + c];
+              acc[c].x = fma(-ur[d][a], t.x, acc[c].x), acc[c].y = fma(-ur[d][a], t.y, acc[c].y);
+            }
+#pragma unroll
+          for (int c = 0; c < kBorderCols / 2; ++c) zr[c] = acc[c];
+        }
+      }
+      if (!far && m + 1 == m_junction) {  // ---- junction: what the far end's sweep left on the middle rows (reversed order) ----
+        __syncthreads();
+        if (tid == 0) {
+          const long long t0 = wall_clock64();
+          while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < T.join_epoch) {
+            __builtin_amdgcn_s_sleep(4);
+            if (wall_clock64() - t0 > 200000000ll) {
+              T.st->chol_failed = 2;
+              break;
+            }
+          }
+        }
+        __syncthreads();
+        for (int e = tid; e < 6 * w_mid * kBorderCols; e += blockDim.x) {
+          const int r = e / kBorderCols, c = e % kBorderCols;
+          z[(6 * (m_junction + w_mid) - 1 - r) * kBorderLd + c] += __builtin_nontemporal_load(ho + e);
+        }
+        __syncthreads();
+      }
+      if (tid < 64 && m + 1 < n_rows) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        diag_solve(m + 1, wr[d]);
+      }
+      request(m + D, ur[d], wr[d]);
+      __syncthreads();
+    }
+  }
+  for (int e = tid; e < 6 * n_rows * kBorderCols; e += blockDim.x) {
+    const int rho = e / kBorderCols, c = e % kBorderCols;
+    if (c < ncols) T.Zb[size_t(far ? np - 1 - rho : rho) * nb + c0 + c] = z[rho * kBorderLd + c];
+  }
+  if (far) {
+    for (int e = tid; e < 6 * w_mid * kBorderCols; e += blockDim.x) ho[e] = z[(6 * n_rows + e / kBorderCols) * kBorderLd + e % kBorderCols];
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence();
+      __hip_atomic_store(const_cast<unsigned*>(flag), T.join_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 /// C = S_bb - Z'Z (16 x 16 tile per workgroup, upper tile triangle mirrored) and h = g_b - Z'y. Z rows are staged through LDS
 /// in chunks (coalesced, eight loads in flight per lane), the tile is accumulated from LDS.
 constexpr int kSchurTile = 16, kSchurRows = 128;
@@ -373,7 +510,7 @@ __global__ void __launch_bounds__(kBlock) k_border_schur(Tables T, int j_lo, int
       va[u] = ok && bt * kSchurTile + k < nb ? T.Zb[size_t(r0 + r) * nb + bt * kSchurTile + k] : 0.0;
       vc[u] = ok && ct * kSchurTile + k < nb ? T.Zb[size_t(r0 + r) * nb + ct * kSchurTile + k] : 0.0;
     }
-    yv = tid < nr ? T.ybuf[r0 + tid] : 0.0;
+    yv = tid < nr ? *y_slot(T, r0 + tid) : 0.0;
   };
   if (row0 < np) request(row0);
   for (int r0 = row0; r0 < np; r0 += kSchurRows) {
@@ -595,7 +732,7 @@ __global__ void __launch_bounds__(kBlock) k_border_apply(Tables T) {
   double v = 0.0;
   for (int bq = lane; bq < T.nb; bq += 64) v = fma(T.Zb[size_t(rho) * T.nb + bq], T.xb[bq], v);
   v = wave_sum(v);
-  if (lane == 0) T.ybuf[rho] -= v;
+  if (lane == 0) *y_slot(T, rho) -= v;
 }
 
 }  // namespace hs

@@ -169,6 +169,8 @@ struct Tables {
   double* step_p;          // np  scaled step
   double* delta_p;         // np  unscaled step (tangent update)
   double* ybuf;            // np  y = U^-T g (forward-solved right-hand side)
+  double* ybuf2;           // two-ended factorisation: the far end's part of y, reversed order (kernels_border.hpp y_slot)
+  int y_split;             // rows below y_split are in ybuf (np unless the factorisation runs from both ends)
   // border blocks (scaled + damped) and the bordered solve
   double* scale_b;         // nb
   double* Spb;             // np x nb

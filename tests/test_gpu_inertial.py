@@ -60,3 +60,32 @@ def test_bordered_solve_trajectory(order, identity, grav_const, hip, oracle):
         assert rel(bg, cg) < 1e-6 and rel(ba, ca) < 1e-6
         if grav_const:
             assert np.array_equal(g.gravity(), w.gravity)
+
+
+@pytest.mark.parametrize("order,n_cp", [(4, 72), (6, 80)])
+def test_two_ended_bordered_solve(order, n_cp, hip, oracle, monkeypatch):
+    """Windows long enough (n_cp >= 4 band widths) for the bordered system to be factored from both ends (k_border_forward2, the y view over
+    both ends, border outputs of the two-ended backward sweep): the 5-iteration trajectory against the oracle and, bias points and gravity
+    included, against the one-ended path of the same library (A/B switch 536870912)."""
+    w = synthetic.small_inertial(order=order, n_cp=n_cp, n_landmarks=300, obs_pairs=3, n_inertial=600, seed=33)
+    w.cp_constant = np.r_[np.ones(order, np.uint8), np.zeros(n_cp - order, np.uint8)]
+
+    def run(lib):
+        with ha.Problem(w, lib=lib) as p:
+            bw = p.lib.band_blocks(p.h)
+            s = p.solve(5)
+            bg, ba = p.bias()
+            return bw, s, p.control_points(), p.landmarks(), p.gravity(), bg, ba
+
+    bw, sg, cpg, lmg, gg, bgg, bag = run(hip)
+    assert n_cp >= 4 * bw and bw <= 16, (bw, "the window must take the two-ended look-ahead path")
+    _, sc, cpc, lmc, gc, bgc, bac = run(oracle)
+    assert sg["num_iterations"] == sc["num_iterations"] and sg["num_successful_steps"] == sc["num_successful_steps"]
+    for ig, ic in zip(sg["iterations"], sc["iterations"]):
+        assert ig["step_is_successful"] == ic["step_is_successful"]
+        assert abs(ig["cost"] - ic["cost"]) <= 1e-6 * abs(ic["cost"]) + 1e-8 * sc["initial_cost"]
+    assert rel(cpg, cpc) < 1e-6 and rel(lmg, lmc) < 1e-6 and rel(gg, gc) < 1e-6 and rel(bgg, bgc) < 1e-6 and rel(bag, bac) < 1e-6
+    monkeypatch.setenv("HS_DEBUG_FLAGS", str(536870912))  # the same window through the one-ended bordered path
+    _, s1, cp1, lm1, g1, bg1, ba1 = run(hip)
+    assert [it["step_is_successful"] for it in s1["iterations"]] == [it["step_is_successful"] for it in sg["iterations"]]
+    assert rel(cpg, cp1) < 1e-8 and rel(lmg, lm1) < 1e-8 and rel(gg, g1) < 1e-8 and rel(bgg, bg1) < 1e-7 and rel(bag, ba1) < 1e-7

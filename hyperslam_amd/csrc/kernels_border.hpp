@@ -636,38 +636,60 @@ __global__ void __launch_bounds__(kBlock) k_border_solve_reg(Tables T) {
   // updated column j + 1 itself (c1'[i] = c1[i] - l_ij c0[j + 1], the very FMA its owners would have done) and applies both updates.
   // The chain per column is publish -> barrier -> 1 / d -> operands -> update (0.63 us at 57 unknowns, 1.04 us at 99): half the barriers.
   int j = 0;
-  for (; j + 1 < nb; j += 2) {
-    double* c0 = col + ((j >> 1) & 1) * 2 * N;
-    double* c1 = c0 + N;
-    HS_PUBLISH_COLUMN(j, c0)
-    HS_PUBLISH_COLUMN(j + 1, c1)
-    lds_barrier();
-    const double d0 = c0[j];
-    const double rs0 = rsqrt_refined(d0), inv0 = rs0 * rs0;
-    const double m01 = c0[j + 1];                                // entry (j + 1, j), unscaled
-    const double d1 = fma(-(m01 * inv0), m01, c1[j + 1]);        // pivot of column j + 1 after the update by column j
-    const double rs1 = rsqrt_refined(d1), inv1 = rs1 * rs1;
-    if (tid == 0 && (!(d0 > 0.0) || !(d1 > 0.0))) bad = 1;
-    double li0[R], lc0[R], li1[R], lc1[R];
+  const bool bprof = prof_enabled(T.debug_flags, 16) && tid == 0;  // phase stamps -> xpart[8 (700 + j / 2) + ..] (tools/border_phase_timing.py)
+  long long* blog = reinterpret_cast<long long*>(T.xpart) + 8 * 700;
+  // The loop over the pairs is split by the 16-column block Q the pair lies in (compile time): its owners publish a[.][Q] without a
+  // run-time choice of the register column — as a chain of `if (q == j >> 4)` around the stores that choice cost 14 branches per pair,
+  // 0.4 us of the 1.5 us a pair took — and tiles left of / above block Q are finished and take no part in the update.
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int i = ti + 16 * r, c = tj + 16 * r;
-      const double ci0 = cj_or_zero(c0, i, N), cc0 = cj_or_zero(c0, c, N);
-      li0[r] = i > j ? ci0 * inv0 : 0.0;  // rows / columns <= j are finished: zero operands leave them alone
-      lc0[r] = c > j ? cc0 : 0.0;
-      const double ci1 = fma(-li0[r], m01, cj_or_zero(c1, i, N)), cc1 = fma(-(cc0 * inv0), m01, cj_or_zero(c1, c, N));
-      li1[r] = i > j + 1 ? ci1 * inv1 : 0.0;
-      lc1[r] = c > j + 1 ? cc1 : 0.0;
+  for (int Q = 0; Q < R; ++Q) {
+    const int j_end = min(16 * (Q + 1), nb);
+    for (j = 16 * Q; j + 1 < j_end; j += 2) {
+      double* c0 = col + ((j >> 1) & 1) * 2 * N;
+      double* c1 = c0 + N;
+      if (bprof) blog[8 * (j >> 1) + 0] = wall_clock64();
+      if (tj == (j & 15)) {
+#pragma unroll
+        for (int r = Q; r < R; ++r) c0[ti + 16 * r] = a[r][Q];  // (rows above block Q are finished and never read)
+      }
+      if (tj == ((j + 1) & 15)) {
+#pragma unroll
+        for (int r = Q; r < R; ++r) c1[ti + 16 * r] = a[r][Q];
+      }
+      if (bprof) blog[8 * (j >> 1) + 1] = wall_clock64();
+      lds_barrier();
+      if (bprof) blog[8 * (j >> 1) + 2] = wall_clock64();
+      const double d0 = c0[j];
+      const double rs0 = rsqrt_refined(d0), inv0 = rs0 * rs0;
+      const double m01 = c0[j + 1];                                // entry (j + 1, j), unscaled
+      const double d1 = fma(-(m01 * inv0), m01, c1[j + 1]);        // pivot of column j + 1 after the update by column j
+      const double rs1 = rsqrt_refined(d1), inv1 = rs1 * rs1;
+      if (tid == 0 && (!(d0 > 0.0) || !(d1 > 0.0))) bad = 1;
+      double li0[R], lc0[R], li1[R], lc1[R];
+#pragma unroll
+      for (int r = Q; r < R; ++r) {
+        const int i = ti + 16 * r, c = tj + 16 * r;
+        const double ci0 = cj_or_zero(c0, i, N), cc0 = cj_or_zero(c0, c, N);
+        li0[r] = i > j ? ci0 * inv0 : 0.0;  // rows / columns <= j are finished: zero operands leave them alone
+        lc0[r] = c > j ? cc0 : 0.0;
+        const double ci1 = fma(-li0[r], m01, cj_or_zero(c1, i, N)), cc1 = fma(-(cc0 * inv0), m01, cj_or_zero(c1, c, N));
+        li1[r] = i > j + 1 ? ci1 * inv1 : 0.0;
+        lc1[r] = c > j + 1 ? cc1 : 0.0;
+      }
+      if (bprof) blog[8 * (j >> 1) + 3] = wall_clock64();
+#pragma unroll
+      for (int r = Q; r < R; ++r)
+#pragma unroll
+        for (int q = Q; q < R; ++q) a[r][q] = fma(-li1[r], lc1[q], fma(-li0[r], lc0[q], a[r][q]));
+      if (bprof) blog[8 * (j >> 1) + 4] = wall_clock64();
+      // the scaled columns for the backward sweep (any lanes; not read before the end of the elimination)
+      if (tid < N && tid >= j && tid < n1) Lc[size_t(j) * ld + tid] = tid == j ? d0 * rs0 : c0[tid] * rs0;
+      if (tid < N && tid >= j + 1 && tid < n1)
+        Lc[size_t(j + 1) * ld + tid] = tid == j + 1 ? d1 * rs1 : fma(-(c0[tid] * inv0), m01, c1[tid]) * rs1;
+      if (tid == 0) invd[j] = rs0, invd[j + 1] = rs1;
+      if (bprof) blog[8 * (j >> 1) + 5] = wall_clock64();
     }
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-      for (int q = 0; q < R; ++q) a[r][q] = fma(-li1[r], lc1[q], fma(-li0[r], lc0[q], a[r][q]));
-    // the scaled columns for the backward sweep (any lanes; not read before the end of the elimination)
-    if (tid < N && tid >= j && tid < n1) Lc[size_t(j) * ld + tid] = tid == j ? d0 * rs0 : c0[tid] * rs0;
-    if (tid < N && tid >= j + 1 && tid < n1)
-      Lc[size_t(j + 1) * ld + tid] = tid == j + 1 ? d1 * rs1 : fma(-(c0[tid] * inv0), m01, c1[tid]) * rs1;
-    if (tid == 0) invd[j] = rs0, invd[j + 1] = rs1;
+    if (j_end == nb) break;  // (an odd last column is handled below)
   }
   for (; j < nb; ++j) {  // (odd number of unknowns: the last column on its own)
     double* cj = col + ((j >> 1) & 1) * 2 * N;

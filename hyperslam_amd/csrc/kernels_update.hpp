@@ -302,15 +302,32 @@ __global__ void __launch_bounds__(kBlock) k_decide(Tables T) {
 
 /// x <- candidate when the step was accepted.
 HSD void commit_body(const Tables& T, const int idx, const int stride) {
-  for (int e = idx; e < 8 * T.sp.n_cp; e += stride) T.cp[e] = T.cp_cand[e];
-  for (int l = idx; l < 3 * T.n_lm; l += stride) T.lm[l] = T.lm_cand[l];
+  // eight loads in flight per lane (a plain copy loop pays one memory round trip per element and lane)
+  auto copy = [&](double* __restrict__ dst, const double* __restrict__ src, int n) {
+    for (int e0 = idx; e0 < n; e0 += 8 * stride) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * stride;
+        v[u] = e < n ? src[e] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * stride;
+        if (e < n) dst[e] = v[u];
+      }
+    }
+  };
+  copy(T.cp, T.cp_cand, 8 * T.sp.n_cp);
+  copy(T.lm, T.lm_cand, 3 * T.n_lm);
   if (T.nb > 0) {
     for (int e = idx; e < 4 * T.n_bias; e += stride) T.bias_g[e] = T.bias_g_cand[e], T.bias_a[e] = T.bias_a_cand[e];
     if (idx < 3) T.gravity[idx] = T.gravity_cand[idx];
   }
 }
 
-constexpr int kCommitInline = 4096;  // elements copied by the decision kernel itself (16 per lane); larger problems launch k_commit
+constexpr int kCommitInline = 4096;  // elements copied by the decision kernel itself (16 per lane); larger problems launch k_commit (16 000 elements in the
+                                     // decision kernel's single workgroup took as long as the launch it saves: measured, configs[1])
 
 __global__ void __launch_bounds__(kBlock) k_commit(Tables T) {
   // note: reads `accepted` even when `done` was just set by a convergence test (those leave accepted = 0)

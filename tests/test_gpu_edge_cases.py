@@ -209,6 +209,17 @@ def test_every_band_width(bw, hip, oracle):
     compare(w, hip, oracle)
 
 
+@pytest.mark.parametrize("bw,imu", [(13, False), (14, False), (15, False), (16, False), (14, True), (16, True)])
+def test_band_widths_from_both_ends(bw, imu, hip, oracle):
+    """Windows of 72 control points (>= 4 band widths): the factorisation runs from both ends — three compute waves up to 14 band blocks,
+    four for 15 and 16 — visual-only and bordered; super-block sweeps, border forward sweep in the two-ended elimination order."""
+    w = window_with_band(4, bw, n_cp=72, imu=imu)
+    with ha.Problem(w, lib=hip) as g:
+        g.cost()
+        assert g.lib.band_blocks(g.h) == bw and w.n_cp >= 4 * bw
+    compare(w, hip, oracle)
+
+
 @pytest.mark.parametrize("bw", [14, 15, 16, 22, 23, 24, 34])
 def test_band_widths_order6_bordered(bw, hip, oracle):
     """The same with an order-6 spline and the bordered (inertial) system."""

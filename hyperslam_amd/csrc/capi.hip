@@ -887,7 +887,8 @@ int launch_factor(hs_problem* p) {
   const int nt = (T.debug_flags & 131072) ? mfma_window_tiles(T.bw) : 0;  // A/B switch 131072: k_band_factor_mfma instead of the VALU kernels
   // (bordered systems — bias splines + gravity — too: the forward sweep of the border columns follows the two-ended elimination order,
   //  k_border_forward2; A/B switch 536870912: bordered systems one-ended)
-  const bool two_ended = (la_ok || nt) && (T.nb == 0 || (!nt && !(T.debug_flags & 536870912))) && n_blk >= 4 * T.bw && T.Sb2 && !(T.debug_flags & 2048);
+  const bool two_ended = (la_ok || nt) && (T.nb == 0 || (!nt && !(T.debug_flags & 536870912) && (T.nb + kBorderCols - 1) / kBorderCols <= 512)) &&
+                         n_blk >= 4 * T.bw && T.Sb2 && !(T.debug_flags & 2048);  // (512: flag words of k_border_forward2's column groups)
   auto run_mfma = [&](const Tables& TT, int grid) -> hipError_t {
     switch (nt) {
       case 6: return launch_mfma<6, 3>(TT, grid, s);

@@ -57,6 +57,9 @@ HSD void sb_inverse(const Tables& T, const BackJob& J, int job, int s, double* l
   double* Tm = lds + 2 * kSbN * LD;
   const int ncb = 6 * T.bw, n_own = 6 * J.n_rows, r0 = kSbN * s;
   const int nr = min(kSbN, n_own - r0);
+  const bool iprof = prof_enabled(T.debug_flags, 16) && l == 0 && job == 0 && s == sb_count(J.n_rows) - 1;  // -> xpart[8 * 260 ..]
+  long long* ilog = reinterpret_cast<long long*>(T.xpart) + 8 * 260;
+  if (iprof) ilog[0] = wall_clock64();
   {  // every load first (nine + five per lane), then the stores: a load -> store loop pays the memory latency once per trip
     constexpr int NU = (kSbN * kSbN + 63) / 64;
     double v[NU], w[2];
@@ -88,6 +91,7 @@ HSD void sb_inverse(const Tables& T, const BackJob& J, int job, int s, double* l
     }
   }
   __syncthreads();  // (the workgroup's other waves have left: a barrier of one wave)
+  if (iprof) ilog[1] = wall_clock64();  // block in LDS
   for (int d = 1; d < kSb; ++d) {
     const int n_e = (kSb - d) * 36;
     for (int e = l; e < n_e; e += 64) {  // Tm_ij = sum_k U_ik V_kj
@@ -108,6 +112,7 @@ HSD void sb_inverse(const Tables& T, const BackJob& J, int job, int s, double* l
     }
     __syncthreads();
   }
+  if (iprof) ilog[2] = wall_clock64();  // inverse in LDS
   double* dst = const_cast<double*>(J.Vb) + size_t(s) * (kSbN * kSbN);
   for (int e = l; e < kSbN * kSbN; e += 64) {
     const int a = e / kSbN, c = e % kSbN;
@@ -118,6 +123,7 @@ HSD void sb_inverse(const Tables& T, const BackJob& J, int job, int s, double* l
   if (l == 0) {
     __threadfence();
     __hip_atomic_store(T.join_flag + kSbFlagBase + kSbMaxBlocks * job + s, T.join_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (iprof) ilog[3] = wall_clock64();  // flag raised
   }
 }
 

@@ -43,3 +43,6 @@ for blk in (0, 1):
     b = buf[8 * 230]
     print("backward block", blk, "[10 ns after block 0's start]: operands staged", c[1] - b, " middle arrived", c[2] - b, " sweep starts", c[3] - b,
           " middle solved", c[4] - b, " published", c[5] - b, " sweep done", c[6] - b, " outputs", c[7] - b)
+
+c = buf[8 * 260:8 * 260 + 4]; b = buf[8 * 230]
+print("builder of the last super-block of job 0 [10 ns after sweep block 0's start]: start", c[0] - b, " block in LDS", c[1] - b, " inverse done", c[2] - b, " flag raised", c[3] - b)

@@ -604,8 +604,8 @@ __global__ void __launch_bounds__(kBlock) k_border_solve_reg(Tables T) {
   const int nb = T.nb, tid = threadIdx.x, n1 = nb + 1;
   constexpr int N = 16 * R;
   const int ld = N + 1;                // odd: a lane-strided walk down a column of Lc is conflict free
-  double* col = smem;                  // 2 x 2 x N : columns j, j + 1 as their owners hold them (unscaled), double buffered
-  double* Lc = smem + 4 * N;           // nb x ld : Lc[j][i] = l_ij, i >= j (i = nb: forward-solved right-hand side y_j)
+  double* Lc = smem + 4 * N;           // nb x ld : Lc[j][i] = l_ij, i >= j (i = nb: forward-solved right-hand side y_j); during the elimination:
+                                       // the columns as their owners published them (unscaled) — a scaled copy inside the loop cost 0.24 us per pair
   double* invd = Lc + size_t(nb) * ld; // nb : 1 / l_jj
   const int ti = tid / 16, tj = tid % 16;
   double a[R][R];
@@ -645,8 +645,8 @@ __global__ void __launch_bounds__(kBlock) k_border_solve_reg(Tables T) {
   for (int Q = 0; Q < R; ++Q) {
     const int j_end = min(16 * (Q + 1), nb);
     for (j = 16 * Q; j + 1 < j_end; j += 2) {
-      double* c0 = col + ((j >> 1) & 1) * 2 * N;
-      double* c1 = c0 + N;
+      double* c0 = Lc + size_t(j) * ld;  // the columns are published straight into their rows of Lc (UNSCALED, column j + 1 as it is
+      double* c1 = c0 + ld;              // before the update by column j); the scaling pass behind the elimination finishes them
       if (bprof) blog[8 * (j >> 1) + 0] = wall_clock64();
       if (tj == (j & 15)) {
 #pragma unroll
@@ -682,17 +682,13 @@ __global__ void __launch_bounds__(kBlock) k_border_solve_reg(Tables T) {
 #pragma unroll
         for (int q = Q; q < R; ++q) a[r][q] = fma(-li1[r], lc1[q], fma(-li0[r], lc0[q], a[r][q]));
       if (bprof) blog[8 * (j >> 1) + 4] = wall_clock64();
-      // the scaled columns for the backward sweep (any lanes; not read before the end of the elimination)
-      if (tid < N && tid >= j && tid < n1) Lc[size_t(j) * ld + tid] = tid == j ? d0 * rs0 : c0[tid] * rs0;
-      if (tid < N && tid >= j + 1 && tid < n1)
-        Lc[size_t(j + 1) * ld + tid] = tid == j + 1 ? d1 * rs1 : fma(-(c0[tid] * inv0), m01, c1[tid]) * rs1;
-      if (tid == 0) invd[j] = rs0, invd[j + 1] = rs1;
+      if (tid == 0) invd[j] = rs0, invd[j + 1] = rs1, smem[j >> 1] = m01;  // (smem[0 .. 4 N): scalars of the pairs for the scaling pass)
       if (bprof) blog[8 * (j >> 1) + 5] = wall_clock64();
     }
     if (j_end == nb) break;  // (an odd last column is handled below)
   }
   for (; j < nb; ++j) {  // (odd number of unknowns: the last column on its own)
-    double* cj = col + ((j >> 1) & 1) * 2 * N;
+    double* cj = Lc + size_t(j) * ld;
     HS_PUBLISH_COLUMN(j, cj)
     lds_barrier();
     const double d = cj[j];
@@ -709,10 +705,22 @@ __global__ void __launch_bounds__(kBlock) k_border_solve_reg(Tables T) {
     for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int q = 0; q < R; ++q) a[r][q] = fma(-li[r], lc[q], a[r][q]);
-    if (tid < N && tid >= j && tid < n1) Lc[size_t(j) * ld + tid] = tid == j ? d * rs : cj[tid] * rs;
     if (tid == 0) invd[j] = rs;
   }
 #undef HS_PUBLISH_COLUMN
+  lds_barrier();
+  // ---- scaling pass: l_ij = c_ij / l_jj; the second column of a pair was published before the update by the first:
+  //      c'_(i, j+1) = c_(i, j+1) - c_(i, j) c_(j+1, j) / d_j ----
+  for (int e = tid; e < ((nb + 1) / 2) * N; e += kBlock) {
+    const int pj = 2 * (e / N), i = e % N;
+    if (i >= n1 || i < pj) continue;
+    const double rs0 = invd[pj], v0 = Lc[size_t(pj) * ld + i];
+    if (pj + 1 < nb) {
+      const double m01 = smem[pj >> 1], rs1 = invd[pj + 1], v1 = Lc[size_t(pj + 1) * ld + i];  // (entry (j + 1, j) as published: its slot in Lc is being scaled)
+      if (i >= pj + 1) Lc[size_t(pj + 1) * ld + i] = fma(-(v0 * (rs0 * rs0)), m01, v1) * rs1;  // (i = pj + 1: d1 rs1 = l_(j+1, j+1))
+    }
+    Lc[size_t(pj) * ld + i] = v0 * rs0;  // (i = pj: d0 rs0 = l_jj)
+  }
   lds_barrier();
   if (tid == 0 && bad) st->chol_failed = 1;
   if (tid >= 64) return;

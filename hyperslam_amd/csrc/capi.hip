@@ -201,7 +201,7 @@ struct hs_problem {
   DBuf<uint8_t> d_cp_const, d_lm_const;
   DBuf<int> d_lm_ptr, d_lm_cfirst, d_lm_ncp, d_lm_yoff, d_cf_ptr;
   DBuf<double> d_lm_scale, d_lm_L, d_lm_yhat, d_lm_sb, d_lm_D2, d_lm_part, d_lm_gmax, d_gabs, d_Y;
-  DBuf<double> d_v_stamp, d_v_meas, d_v_rec;
+  DBuf<double> d_v_stamp, d_v_meas, d_v_rec, d_v_rec_alt;
   DBuf<int> d_v_lm, d_v_info, d_v_first, d_v_pos, d_v_seg_ptr, d_v_dbgpos;
   DBuf<double> d_p_stamp, d_p_meas, d_p_rec;
   DBuf<double> d_i_stamp, d_i_meas, d_i_rec, d_bias_g, d_bias_a, d_bias_g_cand, d_bias_a_cand, d_gravity, d_gravity_cand;
@@ -414,6 +414,7 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_v_dbgpos.upload(v_dbgpos, s));
   HIP_TRY(p->d_v_seg_ptr.upload(vs.seg_ptr, s));
   HIP_TRY(p->d_v_rec.reserve(size_t(n_vis) * (8 + 12 * k) + 1));
+  HIP_TRY(p->d_v_rec_alt.reserve(size_t(n_vis) * (8 + 12 * k) + 1));
   HIP_TRY(p->d_p_stamp.upload(p_stamp, s));
   HIP_TRY(p->d_p_meas.upload(p_meas, s));
   HIP_TRY(p->d_p_sensor.upload(p_sensor, s));
@@ -574,7 +575,7 @@ int prepare(hs_problem* p) {
     T.n_obs_lm = n_obs;
   }
   T.n_vis = n_vis, T.v_stamp = p->d_v_stamp.p, T.v_meas = p->d_v_meas.p, T.v_lm = p->d_v_lm.p, T.v_info = p->d_v_info.p;
-  T.v_first = p->d_v_first.p, T.v_pos = p->d_v_pos.p, T.v_rec = p->d_v_rec.p, T.v_seg_ptr = p->d_v_seg_ptr.p;
+  T.v_first = p->d_v_first.p, T.v_pos = p->d_v_pos.p, T.v_rec = p->d_v_rec.p, T.v_rec_alt = p->d_v_rec_alt.p, T.v_seg_ptr = p->d_v_seg_ptr.p;
   T.n_pri = n_pri, T.p_stamp = p->d_p_stamp.p, T.p_meas = p->d_p_meas.p, T.p_sensor = p->d_p_sensor.p, T.p_first = p->d_p_first.p;
   T.p_rec = p->d_p_rec.p, T.p_seg_ptr = p->d_p_seg_ptr.p;
   T.n_ine = n_ine, T.i_stamp = p->d_i_stamp.p, T.i_meas = p->d_i_meas.p, T.i_first = p->d_i_first.p, T.i_first_bias = p->d_i_first_bias.p;
@@ -617,6 +618,7 @@ int prepare(hs_problem* p) {
   // 262144 eliminate / sweep the decoupled block rows of leading constant control points like any other     524288 border Cholesky in LDS
   // 1048576 inertial branch on the main stream    2097152 banded kernels instead of k_dense_factor    4194304 k_landmark<K,4,1> instead of k_landmark_rows
   // 8388608 five finalisation launches for a bordered single shard    16777216 k_commit launch for small windows    33554432 one cost launch per factor type
+  // 268435456 backward sweeps one block row per step    536870912 bordered systems one-ended    1073741824 no speculative linearisation at the candidate
   T.st = p->d_state.p;
   HIP_TRY(p->batch.flush(s));  // (the staging arena outlives this call: no host synchronisation)
   p->dirty = false;
@@ -629,8 +631,8 @@ int prepare(hs_problem* p) {
   return HS_OK;
 }
 
-int reset_state(hs_problem* p, int max_iterations, double radius) {
-  k_reset_state<<<1, 64, 0, p->stream>>>(p->d_state.p, max_iterations, radius);
+int reset_state(hs_problem* p, int max_iterations, double radius, int spec = 0) {
+  k_reset_state<<<1, 64, 0, p->stream>>>(p->d_state.p, max_iterations, radius, spec);
   HIP_TRY(hipGetLastError());
   return HS_OK;
 }
@@ -1014,12 +1016,24 @@ int launch_factor(hs_problem* p) {
   return HS_OK;
 }
 
+/// Speculative solves (visual-only windows on one shard): the candidate is LINEARISED instead of only costed, unless this is the last
+/// iteration of the solve: its records land in the record buffer that does not hold the current point and become the current
+/// linearisation if the step is accepted (decide_step flips DevState::rec_sel), so that the next iteration starts at k_landmark — after an
+/// accepted step and after a rejected one (the records of the unchanged current point are still there: today's path linearises again).
+/// One linearise launch (16 us at configs[1]) replaces a cost launch (7.7 us) + a linearise launch per iteration.
+static bool speculative_solve(const hs_problem* p) {
+  const Tables& T = p->T;
+  return T.n_vis > 0 && !T.n_pri && !T.n_ine && !T.nb && !p->allreduce && !p->rccl_comm && p->world == 1 && !(T.debug_flags & 1073741824);  // A/B switch
+}
+
 template <int K>
-int launch_update(hs_problem* p) {
+int launch_update(hs_problem* p, bool linearize_candidate = false) {
   const Tables& T = p->T;
   hipStream_t s = p->stream;
   k_backsub_retract<<<T.n_lm_part + T.n_norm_part, kBlock, 0, s>>>(T);
-  if ((T.n_ine || T.n_pri) && !(T.debug_flags & 33554432)) {  // one launch for all factor types (A/B switch 33554432: one per type)
+  if (linearize_candidate) {
+    k_linearize_visual<K><<<p->nb_vis, lin_block<K>(), lin_lds_bytes<K>(p), s>>>(T, nullptr, T.v_pos, 1, T.cand_part, nullptr, T.cp_cand, T.lm_cand);
+  } else if ((T.n_ine || T.n_pri) && !(T.debug_flags & 33554432)) {  // one launch for all factor types (A/B switch 33554432: one per type)
     k_cost_all<K, 4><<<p->nb_vis + p->nb_pri + p->nb_ine, kBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.lm_cand, T.bias_g_cand, T.bias_a_cand, T.gravity_cand,
                                                                                        T.cand_part, p->nb_vis, p->nb_pri);
   } else {
@@ -1662,7 +1676,8 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
   p->results_cached = false;
   int rc = prepare(p);
   if (rc) return rc;
-  rc = reset_state(p, max_iterations, 1e4);
+  const bool spec = speculative_solve(p);
+  rc = reset_state(p, max_iterations, 1e4, spec ? 1 : 0);
   if (rc) return rc;
   hipStream_t s = p->stream;
   const auto host_t3 = std::chrono::steady_clock::now();
@@ -1678,8 +1693,10 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
   std::vector<hipEvent_t>& ev = p->events;
   HIP_TRY(hipEventRecord(ev[0], s));
   for (int it = 0; it < max_iterations; ++it) {
-    rc = p->k == 4 ? launch_linearize<4>(p, true) : launch_linearize<6>(p, true);
-    if (rc) return rc;
+    if (it == 0 || !spec) {  // (speculative solves: the linearisation of the current point came with the previous iteration's candidate)
+      rc = p->k == 4 ? launch_linearize<4>(p, true) : launch_linearize<6>(p, true);
+      if (rc) return rc;
+    }
     if (stages) HIP_TRY(hipEventRecord(ev[4 * it + 1], s));
     rc = p->k == 4 ? launch_build<4>(p) : launch_build<6>(p);
     if (rc) return rc;
@@ -1687,7 +1704,8 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
     rc = launch_factor(p);
     if (rc) return rc;
     if (stages) HIP_TRY(hipEventRecord(ev[4 * it + 3], s));
-    rc = p->k == 4 ? launch_update<4>(p) : launch_update<6>(p);
+    const bool lin_cand = spec && it + 1 < max_iterations;
+    rc = p->k == 4 ? launch_update<4>(p, lin_cand) : launch_update<6>(p, lin_cand);
     if (rc) return rc;
     if (stages || it + 1 == max_iterations) HIP_TRY(hipEventRecord(ev[4 * it + 4], s));
   }

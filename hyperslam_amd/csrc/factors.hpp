@@ -109,7 +109,7 @@ HSD double visual_cost(const Tables& T, const double* cps, const double* lms, in
 
 /// Full linearisation of visual residual q (landmark-major index) in Ceres-local coordinates.
 template <int K>
-HSD void visual_linearize(const Tables& T, const double* cps, int q, bool robustify, VisualOut<K>* o) {
+HSD void visual_linearize(const Tables& T, const double* cps, int q, bool robustify, VisualOut<K>* o, const double* lms = nullptr) {
   const int info = T.v_info[q];
   const int type = info >> 16, camid = info & 0xffff;
   const double* cam = T.cam + kCamStride * camid;
@@ -123,7 +123,7 @@ HSD void visual_linearize(const Tables& T, const double* cps, int q, bool robust
   M3 G[K];
   spline_pose_jac<K>(cps + 8 * first, lam, &qw, &pw, G);
   const int lmid = T.v_lm[q];
-  const double* l = T.lm + 3 * lmid;
+  const double* l = (lms ? lms : T.lm) + 3 * lmid;
   M3 R_sw;
   V3 v;
   const V3 ps = to_sensor(qw, pw, cam, V3{l[0], l[1], l[2]}, &R_sw, &v);

@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(kBlock) k_process_tracks(Tables T, double stam
 }
 
 /// Fresh trust-region state (LevenbergMarquardtStrategy: initial radius 1e4, decrease factor 2).
-__global__ void k_reset_state(DevState* st, int max_iterations, double radius) {
+__global__ void k_reset_state(DevState* st, int max_iterations, double radius, int spec) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   st->radius = radius, st->decrease_factor = 2.0;
   st->cost = st->cand_cost = st->model_cost_change = 0.0;
@@ -86,6 +86,7 @@ __global__ void k_reset_state(DevState* st, int max_iterations, double radius) {
   st->iteration = 0, st->done = 0, st->termination = HS_NO_CONVERGENCE, st->accepted = 0, st->step_valid = 0;
   st->invalid_streak = 0, st->num_successful = 0, st->num_iterations = 0, st->scaling_ready = 0;
   st->max_iterations = max_iterations, st->chol_failed = 0;
+  st->spec = spec, st->rec_sel = 0, st->rec_pending = 0;
 }
 
 /// Batched Manifold::Plus / PlusJacobian of the variable classes on the path (hs_manifold_plus*): the same device

@@ -13,21 +13,32 @@ namespace hs {
 template <int K>
 constexpr int lin_block() { return K <= 4 ? 256 : 128; }  // 2 waves at k = 6: the record slab is 42 KB per wave
 
+/// Speculative use (cp_src / lm_src = the candidate point, out_rec = nullptr): the records go to the visual record buffer that does NOT hold
+/// the linearisation of the current point, the cost partials are the candidate's — if the step is accepted, the next iteration starts
+/// from these records without linearising again (launch_update, decide_step).
+HSD const double* current_visual_records(const Tables& T) { return T.st->rec_sel ? T.v_rec_alt : T.v_rec; }
+
 template <int K>
 __global__ void __launch_bounds__(lin_block<K>()) k_linearize_visual(Tables T, double* out_rec, const int* out_pos, int robustify,
-                                                                     double* cost_part, double* cost_each) {
+                                                                     double* cost_part, double* cost_each, const double* cp_src = nullptr,
+                                                                     const double* lm_src = nullptr) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (T.st->done) return;
+  if (!out_rec) {
+    out_rec = T.st->rec_sel ? T.v_rec : T.v_rec_alt;
+    if (blockIdx.x == 0 && threadIdx.x == 0) T.st->rec_pending = 1;
+  }
+  if (!cp_src) cp_src = T.cp;
   constexpr int REC = 8 + 12 * K, LREC = REC + 2, NCH = REC / 2;  // LDS record stride (16-byte aligned, bank-spread), 16-B chunks
   constexpr int NW = lin_block<K>() / 64;
   // control points: LDS copy when it fits next to the record slabs, otherwise straight from L2 (long windows)
   const bool cps_in_lds = size_t(8) * T.sp.n_cp * sizeof(double) <= 24 * 1024;
-  const double* cps = cps_in_lds ? smem : T.cp;
+  const double* cps = cps_in_lds ? smem : cp_src;
   double* slab = smem + (cps_in_lds ? 8 * T.sp.n_cp : 0) + (threadIdx.x >> 6) * 64 * LREC;  // this wave's 64 records
   const bool lprof = prof_enabled(T.debug_flags, 32) && threadIdx.x == 0 && blockIdx.x < 256;
   long long* llog = reinterpret_cast<long long*>(T.xpart) + 32 * 1024 + 4 * blockIdx.x;
   if (lprof) llog[0] = wall_clock64();
-  if (cps_in_lds) stage_cps(T.cp, smem, 8 * T.sp.n_cp);
+  if (cps_in_lds) stage_cps(cp_src, smem, 8 * T.sp.n_cp);
   if (lprof) llog[1] = wall_clock64();
   __shared__ double red[NW];
   __shared__ int slots[NW * 64];
@@ -37,7 +48,7 @@ __global__ void __launch_bounds__(lin_block<K>()) k_linearize_visual(Tables T, d
   int slot = -1;
   if (q < T.n_vis) {
     VisualOut<K> o;
-    visual_linearize<K>(T, cps, q, robustify != 0, &o);
+    visual_linearize<K>(T, cps, q, robustify != 0, &o, lm_src);
     cost = o.cost;
     slot = out_pos[q];
     double* rec = slab + lane * LREC;

@@ -93,7 +93,7 @@ HSD void landmark_eliminate(const Tables& T, int dl, int lane) {
     const int myq = min(base + lane, q1 - 1);
     const bool mine = base + lane < q1;
     const int my_first = T.v_first[myq], my_pos = T.v_pos[myq];
-    const double* myrec = T.v_rec + size_t(my_pos) * REC;
+    const double* myrec = current_visual_records(T) + size_t(my_pos) * REC;
     double own[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) own[e] = myrec[e];
@@ -104,7 +104,7 @@ HSD void landmark_eliminate(const Tables& T, int dl, int lane) {
       for (int u = 0; u < U; ++u) {
         const int t = min(t0 + u, cnt - 1);
         const int ft = __builtin_amdgcn_readlane(my_first, t), pt = __builtin_amdgcn_readlane(my_pos, t);  // wave-uniform
-        const double* rec = T.v_rec + size_t(pt) * REC;
+        const double* rec = current_visual_records(T) + size_t(pt) * REC;
         const int off = 6 * (ft - c_first);
 #pragma unroll
         for (int e = 0; e < 6; ++e) jl[u][e] = rec[2 + e];
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(kBlock) k_landmark_rows(Tables T) {
     const int myq = min(base + lane, q1 - 1);
     const bool mine = base + lane < q1;
     const int my_first = T.v_first[myq], my_pos = T.v_pos[myq];
-    const double* myrec = T.v_rec + size_t(my_pos) * REC;
+    const double* myrec = current_visual_records(T) + size_t(my_pos) * REC;
     double own[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) own[e] = myrec[e];
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(kBlock) k_landmark_rows(Tables T) {
         const int t = have ? __builtin_ctzll(todo) : 0;
         todo = have ? todo & (todo - 1) : 0;
         const int ft = __builtin_amdgcn_readlane(my_first, t), pt = __builtin_amdgcn_readlane(my_pos, t);  // wave-uniform
-        const double* rec = T.v_rec + size_t(pt) * REC;
+        const double* rec = current_visual_records(T) + size_t(pt) * REC;
 #pragma unroll
         for (int e = 0; e < 6; ++e) jl[u][e] = rec[2 + e];
         const int c = rho - 6 * (ft - c_first);
@@ -301,7 +301,7 @@ HSD void seg_gram_body(const Tables& T, const int bid) {
         }
     }
   };
-  run(T.v_rec, T.v_seg_ptr[first], T.v_seg_ptr[first + 1], VREC, 2, 8);
+  run(current_visual_records(T), T.v_seg_ptr[first], T.v_seg_ptr[first + 1], VREC, 2, 8);
   if (T.n_pri) run(T.p_rec, T.p_seg_ptr[first], T.p_seg_ptr[first + 1], PREC, 6, 6);
   if (T.n_ine) run(T.i_rec, T.i_seg_ptr[first], T.i_seg_ptr[first + 1], 18 + 36 * K + 2 * T.kb, 6, 6);
   if (sprof) slog[2] = wall_clock64();

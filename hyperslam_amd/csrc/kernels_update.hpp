@@ -158,7 +158,9 @@ __global__ void __launch_bounds__(kBlock) k_cost_reduce(Tables T) {
 /// that precede a step (single lane).
 HSD void begin_iteration(const Tables& T, double c, double gm, bool set_scaling_ready) {
   DevState* st = T.st;
-  st->cost = c;
+  // (speculative solves linearise at the candidate point: from the second iteration on, the cost partials of the current point are not
+  //  recomputed — the cost of an accepted candidate was taken over by decide_step, a rejected one left it alone)
+  if (!(st->spec && st->iteration > 0)) st->cost = c;
   st->gmax = gm;
   st->chol_failed = 0;    // raised by the factorisation kernels of this iteration
   if (set_scaling_ready) st->scaling_ready = 1;  // Jacobi scaling is computed at iteration 0 only (else: set by decide_step)
@@ -249,6 +251,8 @@ HSD void decide_step(const Tables& T) {
   r.step_is_valid = st->step_valid, r.step_is_successful = 0;
   st->num_iterations = it;
   st->accepted = 0;
+  const int rec_pending = st->rec_pending;  // the candidate was linearised into the other record buffer (k_linearize_visual)
+  st->rec_pending = 0;
   st->gmax_bits = 0ull, st->gmax_pose_bits = 0ull;  // the next linearisation re-accumulates them
   if (!st->step_valid) {  // HandleInvalidStep
     if (++st->invalid_streak >= 5) {
@@ -282,6 +286,7 @@ HSD void decide_step(const Tables& T) {
     st->accepted = 1;
     st->num_successful++;
     st->cost = cand;
+    if (rec_pending) st->rec_sel ^= 1;  // its records are the linearisation of the new current point
     r.cost = cand;
     const double q = 2.0 * r.relative_decrease - 1.0;
     st->radius = fmin(1e16, st->radius / fmax(1.0 / 3.0, 1.0 - q * q * q));

@@ -52,7 +52,9 @@ struct DevState {
   int scaling_ready;      // Jacobi scaling computed (iteration 0 only)
   int max_iterations;
   int chol_failed;
-  int pad;
+  int spec;               // this solve linearises at the CANDIDATE point (visual-only single shard): see launch_update
+  int rec_sel;            // which visual record buffer holds the linearisation of the current point (0: v_rec, 1: v_rec_alt)
+  int rec_pending;        // the other buffer holds the linearisation of the candidate awaiting its decision
   hs_iteration records[kMaxIterations + 1];
 };
 
@@ -124,6 +126,7 @@ struct Tables {
   const int* v_first;
   const int* v_pos;        // record slot (segment-major)
   double* v_rec;           // n x (8 + 12k)
+  double* v_rec_alt;       // second buffer of the same size (speculative linearisation at the candidate point)
   const int* v_seg_ptr;    // n_seg + 1 over record slots
   // prior residuals (segment-major == record order)
   int n_pri;

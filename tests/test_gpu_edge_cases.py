@@ -441,3 +441,45 @@ def test_result_readback_through_the_pinned_cache(imu, hip):
             initial = state(c)
         for x, y in zip(restored, initial):
             assert np.array_equal(x, y)
+
+
+def perturbed_visual(seed, lm_noise, cp_noise, order=4, bearing=False):
+    w, _ = synthetic._visual_window(seed, order, 20, 120, 3, bearing=bearing, lm_noise=lm_noise, span=1.0)
+    rng = np.random.default_rng(seed)
+    w.control_points = w.control_points.copy()
+    w.control_points[:, 4:7] += cp_noise * rng.standard_normal((w.control_points.shape[0], 3))
+    return w
+
+
+@pytest.mark.parametrize("seed,lm_noise,cp_noise,order,bearing", [(1, 0.5, 0.3, 4, False), (4, 0.5, 0.3, 4, False), (1, 2.0, 0.0, 4, False),
+                                                                (3, 2.0, 0.3, 6, False), (1, 0.5, 0.6, 4, True)])
+def test_rejected_steps_on_visual_windows(seed, lm_noise, cp_noise, order, bearing, hip, oracle, monkeypatch):
+    """Visual-only solves linearise at the candidate point and keep the records of the current point across a rejected step
+    (capi.hip: speculative_solve). Starts far enough from the optimum that steps are rejected: the accept / reject sequence, every recorded
+    quantity and the final state must match the oracle's (which linearises the current point at the top of every iteration), and the
+    path that does the same on the device (HS_DEBUG_FLAGS=1073741824)."""
+    w = perturbed_visual(seed, lm_noise, cp_noise, order, bearing)
+    n_it = 6
+    with ha.Problem(w, lib=oracle) as c:
+        sc = c.solve(n_it)
+        cp_c, lm_c = c.control_points(), c.landmarks()
+    flags_seen = [it["step_is_successful"] for it in sc["iterations"]]
+    assert 0 in flags_seen[1:] and 1 in flags_seen[1:], flags_seen  # the case exercises both branches
+    outs = []
+    for flags in ("0", "1073741824"):
+        monkeypatch.setenv("HS_DEBUG_FLAGS", flags)
+        with ha.Problem(w, lib=hip) as g:
+            sg = g.solve(n_it)
+            outs.append((sg, g.control_points(), g.landmarks()))
+        assert [it["step_is_successful"] for it in sg["iterations"]] == flags_seen, flags
+        assert sg["termination"] == sc["termination"] and sg["num_successful_steps"] == sc["num_successful_steps"]
+        for ig, ic in zip(sg["iterations"], sc["iterations"]):
+            assert abs(ig["cost"] - ic["cost"]) <= 1e-6 * abs(ic["cost"]) + 1e-8 * sc["initial_cost"], (flags, ig["iteration"], ig["cost"], ic["cost"])
+            for k in ("radius", "step_norm", "relative_decrease"):
+                assert abs(ig[k] - ic[k]) <= 1e-5 * max(abs(ic[k]), 1e-12), (flags, ig["iteration"], k, ig[k], ic[k])
+        assert abs(sg["final_cost"] - sc["final_cost"]) <= 1e-6 * sc["final_cost"]
+        assert rel(outs[-1][1], cp_c) < 1e-6 and rel(outs[-1][2], lm_c) < 1e-6
+    # the two device paths evaluate the same expressions at the same points
+    assert rel(outs[0][1], outs[1][1]) < 1e-9 and rel(outs[0][2], outs[1][2]) < 1e-9
+    for a, b in zip(outs[0][0]["iterations"], outs[1][0]["iterations"]):
+        assert abs(a["cost"] - b["cost"]) <= 1e-12 * abs(b["cost"])

@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(la_threads(NCW)) k_band_factor_la(Tables T) {
   double* stage = smem + 24 * ld;   // block row r staged by the loader in stage[r % 3] (three buffers: a row is read by its new owners
                                     // one step after it was staged for them, see the compute waves)
   double* xs = smem + 42 * ld;      // np : y (forward solve)
-  double* dscr = xs + T.np;         // 36 : updated diagonal block of the panel row
+  double* dscr = xs + T.np;         // 36 : (unused: the panel broadcasts its diagonal block with v_readlane)
   double* dinv = dscr + 36;         // 2 x 6 : 1 / diag(U_rr) in dinv[r & 1]
   __shared__ int fail;
   if (threadIdx.x == 0) fail = 0;
@@ -559,18 +559,17 @@ __global__ void __launch_bounds__(la_threads(NCW)) k_band_factor_la(Tables T) {
         }
       }
       if (pprof) plog[8 * r + 3] = wall_clock64();
-      if (l < 6) {
-#pragma unroll
-        for (int a = 0; a < 6; ++a) dscr[6 * a + l] = v[0][a];
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave: LDS is in order, only the compiler must not reorder
+      // The updated diagonal block sits in lanes 0 - 5 (lane c: column c). Every lane factors it redundantly: the 21 entries are
+      // broadcast with v_readlane (wave-uniform values in SGPRs, each the addend of one FMA chain below) instead of a round trip
+      // through LDS (6 stores, wait, 21 loads behind the compute waves' traffic: 0.08 us of the chain per block row).
       double U[21], inv[6], dmin;
       {
         int pidx = 0;
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
-          for (int c = a; c < 6; ++c) U[pidx++] = dscr[6 * a + c];
+          for (int c = a; c < 6; ++c)
+            U[pidx++] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v[0][a]), c), __builtin_amdgcn_readlane(__double2loint(v[0][a]), c));
       }
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
@@ -596,7 +595,7 @@ __global__ void __launch_bounds__(la_threads(NCW)) k_band_factor_la(Tables T) {
         }
       }
 #pragma unroll
-      for (int a = 0; a < 6; ++a) dinv[(r & 1) * 6 + a] = inv[a];  // every lane, same value
+      for (int a = 0; a < 6; a += 2) *reinterpret_cast<double2*>(&dinv[(r & 1) * 6 + a]) = make_double2(inv[a], inv[a + 1]);  // every lane, same value
       if (!(dmin > 0.0) && l == 0) fail = 1;
       if (pprof) plog[8 * r + 4] = wall_clock64();
 #pragma unroll

@@ -618,7 +618,7 @@ int prepare(hs_problem* p) {
   // 262144 eliminate / sweep the decoupled block rows of leading constant control points like any other     524288 border Cholesky in LDS
   // 1048576 inertial branch on the main stream    2097152 banded kernels instead of k_dense_factor    4194304 k_landmark<K,4,1> instead of k_landmark_rows
   // 8388608 five finalisation launches for a bordered single shard    16777216 k_commit launch for small windows    33554432 one cost launch per factor type
-  // 268435456 backward sweeps one block row per step    536870912 bordered systems one-ended    1073741824 no speculative linearisation at the candidate
+  // 268435456 backward sweeps one block row per step    536870912 bordered systems one-ended    1073741824 no speculative linearisation at the candidate    67108864 k_commit in every iteration of a speculative solve
   T.st = p->d_state.p;
   HIP_TRY(p->batch.flush(s));  // (the staging arena outlives this call: no host synchronisation)
   p->dirty = false;
@@ -1026,8 +1026,14 @@ static bool speculative_solve(const hs_problem* p) {
   return T.n_vis > 0 && !T.n_pri && !T.n_ine && !T.nb && !p->allreduce && !p->rccl_comm && p->world == 1 && !(T.debug_flags & 1073741824);  // A/B switch
 }
 
+/// Small problems: the decision kernel copies the accepted candidate to x itself (single shard). A/B switch 16777216: always k_commit.
+static bool commit_inline(const hs_problem* p) {
+  const Tables& T = p->T;
+  return !p->allreduce && !p->rccl_comm && 8 * T.sp.n_cp + 3 * T.n_lm + 8 * T.n_bias <= kCommitInline && !(T.debug_flags & 16777216);
+}
+
 template <int K>
-int launch_update(hs_problem* p, bool linearize_candidate = false) {
+int launch_update(hs_problem* p, bool linearize_candidate = false, bool deferred_commit = false) {
   const Tables& T = p->T;
   hipStream_t s = p->stream;
   k_backsub_retract<<<T.n_lm_part + T.n_norm_part, kBlock, 0, s>>>(T);
@@ -1044,16 +1050,24 @@ int launch_update(hs_problem* p, bool linearize_candidate = false) {
                                                                           T.cand_part + p->nb_vis + p->nb_pri);
   }
   const bool local_decision = !p->allreduce && !p->rccl_comm;  // single shard: decide in the packing kernel
-  const bool inline_commit = local_decision && 8 * T.sp.n_cp + 3 * T.n_lm + 8 * T.n_bias <= kCommitInline && !(T.debug_flags & 16777216);  // A/B switch 16777216
+  const bool inline_commit = commit_inline(p);
   k_pack_decision<<<1, kBlock, 0, s>>>(T, inline_commit ? 2 : local_decision ? 1 : 0);
   HIP_TRY(hipGetLastError());
   const int rc = exchange(p, T.xbuf + T.xo_dec, 5);  // candidate cost + norms + landmark-side model-cost terms
   if (rc) return rc;
   if (!local_decision) k_decide<<<1, 64, 0, s>>>(T);
   const int nb_commit = std::max((std::max(8 * T.sp.n_cp, 3 * T.n_lm) + kBlock - 1) / kBlock, 1);  // one element per lane
-  if (!inline_commit) k_commit<<<nb_commit, kBlock, 0, s>>>(T);
+  // (deferred: speculative solves of larger problems — the next iteration's k_backsub_retract copies the accepted candidate to x on its way,
+  //  hs_solve launches k_commit once behind the last iteration)
+  if (!inline_commit && !deferred_commit) k_commit<<<nb_commit, kBlock, 0, s>>>(T);
   HIP_TRY(hipGetLastError());
   return HS_OK;
+}
+
+static void launch_commit(hs_problem* p) {
+  const Tables& T = p->T;
+  const int nb_commit = std::max((std::max(8 * T.sp.n_cp, 3 * T.n_lm) + kBlock - 1) / kBlock, 1);
+  k_commit<<<nb_commit, kBlock, 0, p->stream>>>(T);
 }
 
 /// First use of a kernel costs ~0.35 ms of host time (the runtime builds its kernel object lazily); a solve touches ~25 different kernels,
@@ -1677,7 +1691,8 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
   int rc = prepare(p);
   if (rc) return rc;
   const bool spec = speculative_solve(p);
-  rc = reset_state(p, max_iterations, 1e4, spec ? 1 : 0);
+  const bool deferred = spec && !commit_inline(p) && !(p->T.debug_flags & 67108864);  // A/B switch 67108864: k_commit in every iteration
+  rc = reset_state(p, max_iterations, 1e4, spec ? (deferred ? 2 : 1) : 0);
   if (rc) return rc;
   hipStream_t s = p->stream;
   const auto host_t3 = std::chrono::steady_clock::now();
@@ -1705,8 +1720,9 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
     if (rc) return rc;
     if (stages) HIP_TRY(hipEventRecord(ev[4 * it + 3], s));
     const bool lin_cand = spec && it + 1 < max_iterations;
-    rc = p->k == 4 ? launch_update<4>(p, lin_cand) : launch_update<6>(p, lin_cand);
+    rc = p->k == 4 ? launch_update<4>(p, lin_cand, deferred) : launch_update<6>(p, lin_cand, deferred);
     if (rc) return rc;
+    if (deferred && it + 1 == max_iterations) launch_commit(p);  // the last accepted candidate (also when a convergence test ended the solve early)
     if (stages || it + 1 == max_iterations) HIP_TRY(hipEventRecord(ev[4 * it + 4], s));
   }
   if (max_iterations == 0) {

@@ -14,6 +14,10 @@ namespace hs {
 __global__ void __launch_bounds__(kBlock) k_backsub_retract(Tables T) {
   if (T.st->done) return;
   __shared__ double red[kBlock / 64][4];
+  // Speculative solves with a deferred commit (DevState::spec == 2): the candidate accepted by the previous iteration is still only in
+  // the candidate buffers — it is the current point here, and it is copied to x on the way (every element of x passes through this
+  // kernel once per iteration), which replaces one k_commit launch per iteration. hs_solve launches k_commit once behind the last iteration.
+  const bool pend = T.st->spec == 2 && T.st->accepted;
   if (int(blockIdx.x) < T.n_lm_part) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int dl = blockIdx.x * (kBlock / 64) + wave;
@@ -29,7 +33,7 @@ __global__ void __launch_bounds__(kBlock) k_backsub_retract(Tables T) {
         for (int a = 0; a < 6; ++a) L[a] = T.lm_L[6 * dl + a];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-          yh[a] = T.lm_yhat[3 * dl + a], x[a] = T.lm[3 * dl + a], sc[a] = T.lm_scale[3 * dl + a];
+          yh[a] = T.lm_yhat[3 * dl + a], x[a] = (pend ? T.lm_cand : T.lm)[3 * dl + a], sc[a] = T.lm_scale[3 * dl + a];
           sb[a] = T.lm_sb[3 * dl + a], d2[a] = T.lm_D2[3 * dl + a];
         }
         active = (T.lm_ptr[dl + 1] > T.lm_ptr[dl]) && !T.lm_const[dl];
@@ -58,6 +62,7 @@ __global__ void __launch_bounds__(kBlock) k_backsub_retract(Tables T) {
         for (int a = 0; a < 3; ++a) {
           const double y = x[a] + sc[a] * s[a];
           T.lm_cand[3 * dl + a] = y;
+          if (pend) T.lm[3 * dl + a] = x[a];
           if (active) {
             xl = fma(x[a], x[a], xl), sl = fma(x[a] - y, x[a] - y, sl);
             gd = fma(sb[a], s[a], gd);
@@ -80,7 +85,13 @@ __global__ void __launch_bounds__(kBlock) k_backsub_retract(Tables T) {
   const int j = blk * blockDim.x + threadIdx.x;
   double xs = 0.0, ss = 0.0;
   if (j < T.sp.n_cp) {
-    const double* x = T.cp + 8 * j;
+    double x[8];  // (a copy: with a pending commit the current point is read from the buffer the candidate is written to)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) x[c] = (pend ? T.cp_cand : T.cp)[8 * j + c];
+    if (pend) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) T.cp[8 * j + c] = x[c];
+    }
     double* y = T.cp_cand + 8 * j;
     const double* d = T.delta_p + 6 * j;
     bool any = false;

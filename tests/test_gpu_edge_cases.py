@@ -443,22 +443,25 @@ def test_result_readback_through_the_pinned_cache(imu, hip):
             assert np.array_equal(x, y)
 
 
-def perturbed_visual(seed, lm_noise, cp_noise, order=4, bearing=False):
-    w, _ = synthetic._visual_window(seed, order, 20, 120, 3, bearing=bearing, lm_noise=lm_noise, span=1.0)
+def perturbed_visual(seed, lm_noise, cp_noise, order=4, bearing=False, n_lm=120):
+    w, _ = synthetic._visual_window(seed, order, 20, n_lm, 3, bearing=bearing, lm_noise=lm_noise, span=1.0)
     rng = np.random.default_rng(seed)
     w.control_points = w.control_points.copy()
     w.control_points[:, 4:7] += cp_noise * rng.standard_normal((w.control_points.shape[0], 3))
     return w
 
 
-@pytest.mark.parametrize("seed,lm_noise,cp_noise,order,bearing", [(1, 0.5, 0.3, 4, False), (4, 0.5, 0.3, 4, False), (1, 2.0, 0.0, 4, False),
-                                                                (3, 2.0, 0.3, 6, False), (1, 0.5, 0.6, 4, True)])
-def test_rejected_steps_on_visual_windows(seed, lm_noise, cp_noise, order, bearing, hip, oracle, monkeypatch):
+@pytest.mark.parametrize("seed,lm_noise,cp_noise,order,bearing,n_lm", [(1, 0.5, 0.3, 4, False, 120), (4, 0.5, 0.3, 4, False, 120), (1, 2.0, 0.0, 4, False, 120),
+                                                                     (3, 2.0, 0.3, 6, False, 120), (1, 0.5, 0.6, 4, True, 120),
+                                                                     (1, 0.5, 0.3, 4, False, 1500), (4, 0.5, 0.3, 4, False, 1500)])
+def test_rejected_steps_on_visual_windows(seed, lm_noise, cp_noise, order, bearing, n_lm, hip, oracle, monkeypatch):
     """Visual-only solves linearise at the candidate point and keep the records of the current point across a rejected step
-    (capi.hip: speculative_solve). Starts far enough from the optimum that steps are rejected: the accept / reject sequence, every recorded
-    quantity and the final state must match the oracle's (which linearises the current point at the top of every iteration), and the
-    path that does the same on the device (HS_DEBUG_FLAGS=1073741824)."""
-    w = perturbed_visual(seed, lm_noise, cp_noise, order, bearing)
+    (capi.hip: speculative_solve); above 4096 state scalars (the 1500-landmark cases) the accepted candidate is copied to x by the next
+    iteration's k_backsub_retract instead of a k_commit launch. Starts far enough from the optimum that steps are rejected: the accept /
+    reject sequence, every recorded quantity and the final state must match the oracle's (which linearises the current point at the top of
+    every iteration), the path with a commit per iteration (HS_DEBUG_FLAGS=67108864) and the one that does everything the oracle's way
+    on the device (1073741824)."""
+    w = perturbed_visual(seed, lm_noise, cp_noise, order, bearing, n_lm)
     n_it = 6
     with ha.Problem(w, lib=oracle) as c:
         sc = c.solve(n_it)
@@ -466,7 +469,7 @@ def test_rejected_steps_on_visual_windows(seed, lm_noise, cp_noise, order, beari
     flags_seen = [it["step_is_successful"] for it in sc["iterations"]]
     assert 0 in flags_seen[1:] and 1 in flags_seen[1:], flags_seen  # the case exercises both branches
     outs = []
-    for flags in ("0", "1073741824"):
+    for flags in ("0", "67108864", "1073741824"):
         monkeypatch.setenv("HS_DEBUG_FLAGS", flags)
         with ha.Problem(w, lib=hip) as g:
             sg = g.solve(n_it)
@@ -483,3 +486,15 @@ def test_rejected_steps_on_visual_windows(seed, lm_noise, cp_noise, order, beari
     assert rel(outs[0][1], outs[1][1]) < 1e-9 and rel(outs[0][2], outs[1][2]) < 1e-9
     for a, b in zip(outs[0][0]["iterations"], outs[1][0]["iterations"]):
         assert abs(a["cost"] - b["cost"]) <= 1e-12 * abs(b["cost"])
+
+
+def test_deferred_commit_when_a_solve_converges_early(hip, oracle):
+    """A speculative solve that stops on a convergence test before max_iterations: the last accepted candidate must be in x (the commit of
+    an accepted step is deferred to the next iteration's k_backsub_retract, which a finished solve no longer runs)."""
+    w = perturbed_visual(7, 0.05, 0.02, 4, False, 1500)
+    with ha.Problem(w, lib=oracle) as c, ha.Problem(w, lib=hip) as g:
+        sc, sg = c.solve(25), g.solve(25)
+        assert sc["num_iterations"] < 25 and sg["num_iterations"] == sc["num_iterations"] and sg["termination"] == sc["termination"]
+        assert abs(sg["final_cost"] - sc["final_cost"]) <= 1e-9 * sc["final_cost"]
+        assert rel(g.control_points(), c.control_points()) < 1e-7 and rel(g.landmarks(), c.landmarks()) < 1e-7
+        assert abs(g.cost() - sg["final_cost"]) <= 1e-12 * sg["final_cost"]  # x is the point the summary reports

@@ -77,9 +77,14 @@ __global__ void __launch_bounds__(kPbThreads) k_border_pb(Tables T) {
     double acc[6] = {0, 0, 0, 0, 0, 0};
     const int kind = beta < 3 * nbias ? 0 : 1;
     const int bb = (beta - 3 * nbias * kind) / 3, cc = (beta - 3 * nbias * kind) % 3;
+    // Only the records whose bias window covers point bb contribute (first_bias in [bb - kb + 1, bb]: one contiguous range of the table,
+    // T.i_bias_ptr); a control point meets the records of K segments, i.e. one or two of the n_bias bias intervals, so most columns
+    // of a row block have nothing to add. Same members of the split (pos = p0 + sp mod nsp) in the same order: the skipped terms were exact zeros.
+    const int r_lo = max(p0, T.i_bias_ptr[max(0, bb - kb + 1)]), r_hi = min(p1, T.i_bias_ptr[bb + 1]);
+    const int start = r_lo + ((p0 + sp - r_lo) % nsp + nsp) % nsp;
     // branch-free body (clamped weight index, masked weight) so that the loads of eight records are in flight together
 #pragma unroll 8
-    for (int pos = p0 + sp; pos < p1; pos += nsp) {
+    for (int pos = start; pos < r_hi; pos += nsp) {
       const double* rec = T.i_rec + size_t(pos) * IREC;
       const int j = bb - T.i_first_bias[pos];
       const bool ok = j >= 0 && j < kb;
@@ -116,6 +121,7 @@ __global__ void __launch_bounds__(kBlock) k_border_bb(Tables T) {
 #pragma unroll
   for (int e = 0; e < NV; ++e) v[e] = 0.0;
   double* gg = v, *aa = v + hsd::kMaxOrder, *ggr = v + 2 * hsd::kMaxOrder, *agr = ggr + 6, *rg = agr + 6, *ra = rg + 3, *hg = ra + 3;
+#pragma unroll 2
   for (int pos = p0 + tid; pos < p1; pos += kBlock) {
     const double* rec = T.i_rec + size_t(pos) * IREC;
     const int j = b - T.i_first_bias[pos];
@@ -175,8 +181,17 @@ __global__ void __launch_bounds__(kBlock) k_border_bb(Tables T) {
   if (atomicAdd(T.join_flag + 2, 1u) != gridDim.x - 1) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   double h[5] = {0, 0, 0, 0, 0};
-  for (int bb = 0; bb < nbias; ++bb)
-    for (int e = 0; e < 5; ++e) h[e] += __builtin_nontemporal_load(T.gravity_part + 5 * bb + e);
+  for (int bb0 = 0; bb0 < nbias; bb0 += 8) {  // the loads of eight bias points in flight together (one dependent load per term cost ~1 us each)
+    double t[8][5];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int e = 0; e < 5; ++e) t[u][e] = bb0 + u < nbias ? __builtin_nontemporal_load(T.gravity_part + 5 * (bb0 + u) + e) : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int e = 0; e < 5; ++e) h[e] += t[u][e];
+  }
   Hbb[size_t(ogr) * nb + ogr] = h[0], Hbb[size_t(ogr) * nb + ogr + 1] = h[1];
   Hbb[size_t(ogr + 1) * nb + ogr] = h[1], Hbb[size_t(ogr + 1) * nb + ogr + 1] = h[2];
   gb[ogr] = h[3], gb[ogr + 1] = h[4];

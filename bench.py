@@ -308,7 +308,10 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        n_lin = n_staged * LM_ITERATIONS  # launches of the linearise kernel bracketed by HIP events (every STAGE_EVERY-th step of the timed region)
+        # launches of the linearise kernel bracketed by HIP events (every STAGE_EVERY-th step of the timed region). A solve of N iterations
+        # launches it N times: the start point + the candidates of iterations 0 .. N - 2 on the speculative path (the last iteration only
+        # costs its candidate), one per iteration otherwise; the library books all of them under linearize_ms (hyperslam_hip.h).
+        n_lin = n_staged * LM_ITERATIONS
         lin_ms = stage["linearize_ms"] / n_lin
         order = int(window.order)
         b_alg = 32 + 8 * (8 + 12 * order)  # 32 B in + one record [r(2) J_l(6) J_state(12 k)] out = 480 B at k = 4

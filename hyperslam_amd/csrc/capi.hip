@@ -1033,12 +1033,14 @@ static bool commit_inline(const hs_problem* p) {
 }
 
 template <int K>
-int launch_update(hs_problem* p, bool linearize_candidate = false, bool deferred_commit = false) {
+int launch_update(hs_problem* p, bool linearize_candidate = false, bool deferred_commit = false, hipEvent_t* lin_events = nullptr) {
   const Tables& T = p->T;
   hipStream_t s = p->stream;
   k_backsub_retract<<<T.n_lm_part + T.n_norm_part, kBlock, 0, s>>>(T);
   if (linearize_candidate) {
+    if (lin_events) HIP_TRY(hipEventRecord(lin_events[0], s));  // stage timing: this launch is booked under "linearise", not "update"
     k_linearize_visual<K><<<p->nb_vis, lin_block<K>(), lin_lds_bytes<K>(p), s>>>(T, nullptr, T.v_pos, 1, T.cand_part, nullptr, T.cp_cand, T.lm_cand);
+    if (lin_events) HIP_TRY(hipEventRecord(lin_events[1], s));
   } else if ((T.n_ine || T.n_pri) && !(T.debug_flags & 33554432)) {  // one launch for all factor types (A/B switch 33554432: one per type)
     k_cost_all<K, 4><<<p->nb_vis + p->nb_pri + p->nb_ine, kBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.lm_cand, T.bias_g_cand, T.bias_a_cand, T.gravity_cand,
                                                                                        T.cand_part, p->nb_vis, p->nb_pri);
@@ -1699,7 +1701,8 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
   // stage timing (optional, hs_set_stage_timing): 4 stages per iteration bracketed by HIP events on the launch stream; every event is a
   // barrier packet (~5.7 us of idle device each, rocprofv3 kernel trace), so by default only the two ends of the solve are stamped
   const bool stages = p->stage_timing;
-  const size_t n_ev = size_t(4) * max_iterations + 1;
+  const size_t n_ev = size_t(6) * max_iterations + 1;  // (+ two per iteration around the candidate's linearisation of a speculative solve)
+  const size_t ev_cand = size_t(4) * max_iterations + 1;
   while (p->events.size() < n_ev) {
     hipEvent_t e;
     HIP_TRY(hipEventCreate(&e));
@@ -1720,7 +1723,8 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
     if (rc) return rc;
     if (stages) HIP_TRY(hipEventRecord(ev[4 * it + 3], s));
     const bool lin_cand = spec && it + 1 < max_iterations;
-    rc = p->k == 4 ? launch_update<4>(p, lin_cand, deferred) : launch_update<6>(p, lin_cand, deferred);
+    hipEvent_t* lin_ev = stages && lin_cand ? &ev[ev_cand + 2 * it] : nullptr;
+    rc = p->k == 4 ? launch_update<4>(p, lin_cand, deferred, lin_ev) : launch_update<6>(p, lin_cand, deferred, lin_ev);
     if (rc) return rc;
     if (deferred && it + 1 == max_iterations) launch_commit(p);  // the last accepted candidate (also when a convergence test ended the solve early)
     if (stages || it + 1 == max_iterations) HIP_TRY(hipEventRecord(ev[4 * it + 4], s));
@@ -1775,6 +1779,11 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
     float t[4] = {0, 0, 0, 0};
     for (int k = 0; k < 4; ++k) (void)hipEventElapsedTime(&t[k], ev[4 * it + k], ev[4 * it + k + 1]);
     summary->linearize_ms += t[0], summary->schur_ms += t[1], summary->solve_ms += t[2], summary->update_ms += t[3];
+    if (spec && it + 1 < max_iterations) {  // the linearisation of this iteration's candidate = the next iteration's linearisation when accepted
+      float tc = 0;
+      (void)hipEventElapsedTime(&tc, ev[ev_cand + 2 * it], ev[ev_cand + 2 * it + 1]);
+      summary->linearize_ms += tc, summary->update_ms -= tc;
+    }
   }
   if (max_iterations > 0) {
     float t = 0;

@@ -53,7 +53,11 @@ struct UploadBatch {
     host = fresh, host_cap = want;
     return hipSuccess;
   }
-  hipError_t add(void* dst, const void* src, size_t bytes) {
+  /// Room for `bytes` more without moving the arena: pointers handed out by alloc() stay valid until then.
+  hipError_t reserve_more(size_t bytes) { return grow_host(((used + 15) & ~size_t(15)) + bytes + 16); }
+  /// add() without the copy: *out points at the segment's place in the arena, the caller fills it before flush().
+  hipError_t alloc(void* dst, size_t bytes, void** out) { return add(dst, nullptr, bytes, out); }
+  hipError_t add(void* dst, const void* src, size_t bytes, void** out = nullptr) {
     if (in_flight) {  // (only if two prepare() calls follow each other without a synchronising entry point in between)
       const hipError_t e = hipEventSynchronize(sent);
       if (e != hipSuccess) return e;
@@ -62,7 +66,8 @@ struct UploadBatch {
     const size_t off = (used + 15) & ~size_t(15);
     const hipError_t e = grow_host(off + bytes + 16);
     if (e != hipSuccess) return e;
-    std::memcpy(host + off, src, bytes);
+    if (src) std::memcpy(host + off, src, bytes);
+    if (out) *out = host + off;
     // one workgroup of the scatter kernel per 16 KB: a 0.8 MB residual table copied by a single workgroup took 46 us
     constexpr size_t kChunk = 16 * 1024;
     for (size_t o = 0; o < bytes; o += kChunk)
@@ -293,23 +298,7 @@ int prepare(hs_problem* p) {
     HS_FAIL(HS_ERR_INVALID, "window too long for the LDS-resident control-point table and backward sweep (more than 1024 control points)");
   const int n_vis = n_px + n_br;
 
-  // ---- visual tables (landmark-major) ----
-  std::vector<double> v_stamp(n_vis), v_meas(size_t(3) * n_vis, 0.0);
-  std::vector<int> v_info(n_vis), v_dbgpos(n_vis);
-  for (int q = 0; q < n_vis; ++q) {
-    const int ti = vs.table_idx[q];
-    if (vs.table_type[q] == HS_PIXEL) {
-      v_stamp[q] = p->px_stamp[ti];
-      v_meas[3 * q] = p->px_meas[2 * ti], v_meas[3 * q + 1] = p->px_meas[2 * ti + 1];
-      v_info[q] = p->px_cam[ti];
-      v_dbgpos[q] = ti;
-    } else {
-      v_stamp[q] = p->br_stamp[ti];
-      for (int c = 0; c < 3; ++c) v_meas[3 * q + c] = p->br_meas[3 * ti + c];
-      v_info[q] = p->br_cam[ti] | (1 << 16);
-      v_dbgpos[q] = n_px + ti;
-    }
-  }
+  // ---- visual tables (landmark-major): written straight into the staging arena in the upload phase below ----
   // landmarks in device order
   std::vector<double> lm_dev(size_t(3) * p->n_lm);
   std::vector<uint8_t> lmc_dev(p->n_lm);
@@ -405,13 +394,39 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_lm_part.reserve(4 * size_t((nl + kBlock / 64 - 1) / (kBlock / 64)) + 4));
   HIP_TRY(p->d_lm_gmax.reserve(nl));
   HIP_TRY(p->d_Y.reserve(size_t(vs.y_total) + 1));
-  HIP_TRY(p->d_v_stamp.upload(v_stamp, s));
-  HIP_TRY(p->d_v_meas.upload(v_meas, s));
+  if (n_vis) {
+    // [stamp | measurement (3: a pixel leaves the third entry zero) | camera | type << 16 | position in the caller's tables] per residual, gathered in
+    // landmark-major order right where the staging copy will pick them up (as vectors first they cost an allocation, a zero fill and a copy of 1 MB per call)
+    HIP_TRY(p->d_v_stamp.reserve(n_vis));
+    HIP_TRY(p->d_v_meas.reserve(size_t(3) * n_vis));
+    HIP_TRY(p->d_v_info.reserve(n_vis));
+    HIP_TRY(p->d_v_dbgpos.reserve(n_vis));
+    HIP_TRY(p->batch.reserve_more(size_t(n_vis) * (8 + 24 + 4 + 4) + 4 * 32));
+    void *a0, *a1, *a2, *a3;
+    HIP_TRY(p->batch.alloc(p->d_v_stamp.p, size_t(n_vis) * 8, &a0));
+    HIP_TRY(p->batch.alloc(p->d_v_meas.p, size_t(n_vis) * 24, &a1));
+    HIP_TRY(p->batch.alloc(p->d_v_info.p, size_t(n_vis) * 4, &a2));
+    HIP_TRY(p->batch.alloc(p->d_v_dbgpos.p, size_t(n_vis) * 4, &a3));
+    double *v_stamp = static_cast<double*>(a0), *v_meas = static_cast<double*>(a1);
+    int *v_info = static_cast<int*>(a2), *v_dbgpos = static_cast<int*>(a3);
+    for (int q = 0; q < n_vis; ++q) {
+      const int ti = vs.table_idx[q];
+      if (vs.table_type[q] == HS_PIXEL) {
+        v_stamp[q] = p->px_stamp[ti];
+        v_meas[3 * q] = p->px_meas[2 * ti], v_meas[3 * q + 1] = p->px_meas[2 * ti + 1], v_meas[3 * q + 2] = 0.0;
+        v_info[q] = p->px_cam[ti];
+        v_dbgpos[q] = ti;
+      } else {
+        v_stamp[q] = p->br_stamp[ti];
+        for (int c = 0; c < 3; ++c) v_meas[3 * q + c] = p->br_meas[3 * ti + c];
+        v_info[q] = p->br_cam[ti] | (1 << 16);
+        v_dbgpos[q] = n_px + ti;
+      }
+    }
+  }
   HIP_TRY(p->d_v_lm.upload(vs.lm_dev, s));
-  HIP_TRY(p->d_v_info.upload(v_info, s));
   HIP_TRY(p->d_v_first.upload(vs.first, s));
   HIP_TRY(p->d_v_pos.upload(vs.pos, s));
-  HIP_TRY(p->d_v_dbgpos.upload(v_dbgpos, s));
   HIP_TRY(p->d_v_seg_ptr.upload(vs.seg_ptr, s));
   HIP_TRY(p->d_v_rec.reserve(size_t(n_vis) * (8 + 12 * k) + 1));
   HIP_TRY(p->d_v_rec_alt.reserve(size_t(n_vis) * (8 + 12 * k) + 1));

@@ -103,6 +103,7 @@ struct VisualStructure {
   std::vector<int> lm_ptr, lm_cfirst, lm_ncp, lm_yoff, cf_ptr;
   int bw = 0;
   int y_total = 0;
+  std::vector<int> scratch_first, scratch_cf, scratch_cl, scratch_cnt, scratch_start;  // work arrays of build_visual_structure (kept: no allocation per call)
 };
 
 struct VisualInput {
@@ -114,43 +115,51 @@ struct VisualInput {
 };
 
 inline bool build_visual_structure(const VisualInput& in, VisualStructure* vs, std::string* err) {
+  // Three passes over the residual tables (this runs on the host in front of every optimize() of a sliding window: ~2 ns per residual
+  // and pass): (A) first control point, landmark ranges and the two histograms, (B) stable scatter into landmark-major order,
+  // (C) stable scatter of the record slots into segment-major order. All orderings are stable counting sorts on small integer keys.
   const int n = in.n_px + in.n_br, n_seg = in.n_cp - in.k + 1;
-  std::vector<int> type(n), idx(n), lm(n), first(n);
-  for (int i = 0; i < n; ++i) {
-    const bool px = i < in.n_px;
-    type[i] = px ? HS_PIXEL : HS_BEARING;
-    idx[i] = px ? i : i - in.n_px;
-    lm[i] = px ? in.px_lm[idx[i]] : in.br_lm[idx[i]];
-    const double st = px ? in.px_stamp[idx[i]] : in.br_stamp[idx[i]];
-    first[i] = h_segment_first(st, in.t0, in.dt, in.k);
-    if (lm[i] < 0 || lm[i] >= in.n_lm) {
-      *err = "visual residual references a landmark outside the landmark table";
-      return false;
+  vs->scratch_first.resize(n);
+  std::vector<int>& first = vs->scratch_first;
+  std::vector<int>& cf = vs->scratch_cf;
+  std::vector<int>& cl = vs->scratch_cl;
+  std::vector<int>& cnt = vs->scratch_cnt;  // residuals per table landmark, then the write cursor of its run
+  cf.assign(in.n_lm, 1 << 30), cl.assign(in.n_lm, -1), cnt.assign(in.n_lm, 0);
+  vs->seg_ptr.assign(n_seg + 1, 0);
+  auto pass_a = [&](const double* stamp, const int32_t* lm, int count, int offset) {
+    for (int j = 0; j < count; ++j) {
+      const int l = lm[j], f = h_segment_first(stamp[j], in.t0, in.dt, in.k);
+      if (l < 0 || l >= in.n_lm) {
+        *err = "visual residual references a landmark outside the landmark table";
+        return false;
+      }
+      if (f < 0 || f >= n_seg) {
+        *err = "visual residual stamp outside the valid range of the spline";
+        return false;
+      }
+      first[offset + j] = f;
+      cf[l] = std::min(cf[l], f), cl[l] = std::max(cl[l], f + in.k - 1);
+      cnt[l]++;
+      vs->seg_ptr[f + 1]++;
     }
-    if (first[i] < 0 || first[i] >= n_seg) {
-      *err = "visual residual stamp outside the valid range of the spline";
-      return false;
-    }
-  }
-  // landmark cp ranges
-  std::vector<int> cf(in.n_lm, 1 << 30), cl(in.n_lm, -1);
-  for (int i = 0; i < n; ++i) {
-    cf[lm[i]] = std::min(cf[lm[i]], first[i]);
-    cl[lm[i]] = std::max(cl[lm[i]], first[i] + in.k - 1);
-  }
-  // device order: observed landmarks by first control point (stable), unobserved last
-  // (all orderings below are stable counting sorts: the keys are small integers and this runs once per optimize())
-  auto counting_sort = [](int n_items, int n_keys, auto key_of, std::vector<int>* out) {
-    std::vector<int> start(n_keys + 1, 0);
-    for (int i = 0; i < n_items; ++i) start[key_of(i) + 1]++;
-    for (int kk = 0; kk < n_keys; ++kk) start[kk + 1] += start[kk];
-    out->resize(n_items);
-    for (int i = 0; i < n_items; ++i) (*out)[start[key_of(i)]++] = i;
+    return true;
   };
-  counting_sort(in.n_lm, in.n_cp + 1, [&](int t) { return std::min(cf[t], in.n_cp); }, &vs->table_of_dev);
-  vs->dev_of_table.resize(in.n_lm);
-  for (int d = 0; d < in.n_lm; ++d) vs->dev_of_table[vs->table_of_dev[d]] = d;
-  vs->lm_cfirst.assign(in.n_lm, 0), vs->lm_ncp.assign(in.n_lm, 0), vs->lm_yoff.assign(in.n_lm + 1, 0);
+  if (!pass_a(in.px_stamp, in.px_lm, in.n_px, 0) || !pass_a(in.br_stamp, in.br_lm, in.n_br, in.n_px)) return false;
+  for (int s = 0; s < n_seg; ++s) vs->seg_ptr[s + 1] += vs->seg_ptr[s];
+  // device order of the landmarks: observed ones by first control point (stable), unobserved last
+  {
+    std::vector<int>& start = vs->scratch_start;
+    start.assign(in.n_cp + 2, 0);
+    for (int t = 0; t < in.n_lm; ++t) start[std::min(cf[t], in.n_cp) + 1]++;
+    for (int c = 0; c <= in.n_cp; ++c) start[c + 1] += start[c];
+    vs->table_of_dev.resize(in.n_lm), vs->dev_of_table.resize(in.n_lm);
+    for (int t = 0; t < in.n_lm; ++t) {
+      const int d = start[std::min(cf[t], in.n_cp)]++;
+      vs->table_of_dev[d] = t, vs->dev_of_table[t] = d;
+    }
+  }
+  vs->lm_cfirst.resize(in.n_lm), vs->lm_ncp.resize(in.n_lm), vs->lm_yoff.resize(in.n_lm + 1), vs->lm_ptr.resize(in.n_lm + 1);
+  vs->lm_yoff[0] = 0, vs->lm_ptr[0] = 0;
   vs->bw = in.k;
   for (int d = 0; d < in.n_lm; ++d) {
     const int t = vs->table_of_dev[d];
@@ -163,6 +172,8 @@ inline bool build_visual_structure(const VisualInput& in, VisualStructure* vs, s
       vs->lm_ncp[d] = 0;
     }
     vs->lm_yoff[d + 1] = vs->lm_yoff[d] + 18 * vs->lm_ncp[d];
+    vs->lm_ptr[d + 1] = vs->lm_ptr[d] + cnt[t];
+    cnt[t] = vs->lm_ptr[d];  // from here on: where the next residual of table landmark t goes
   }
   vs->y_total = vs->lm_yoff[in.n_lm];
   vs->cf_ptr.assign(in.n_cp + 2, 0);
@@ -170,26 +181,21 @@ inline bool build_visual_structure(const VisualInput& in, VisualStructure* vs, s
     while (d < in.n_lm && vs->lm_cfirst[d] < c) ++d;
     vs->cf_ptr[c] = d;
   }
-  // landmark-major residual order (stable: table order within a landmark, pixel before bearing)
-  std::vector<int> order;
-  counting_sort(n, in.n_lm, [&](int i) { return vs->dev_of_table[lm[i]]; }, &order);
+  // (B) landmark-major residual order (stable: table order within a landmark, pixel before bearing)
   vs->table_type.resize(n), vs->table_idx.resize(n), vs->lm_dev.resize(n), vs->first.resize(n), vs->pos.resize(n);
-  vs->lm_ptr.assign(in.n_lm + 1, 0);
-  for (int q = 0; q < n; ++q) {
-    const int i = order[q];
-    vs->table_type[q] = type[i], vs->table_idx[q] = idx[i], vs->lm_dev[q] = vs->dev_of_table[lm[i]], vs->first[q] = first[i];
-    vs->lm_ptr[vs->lm_dev[q] + 1]++;
+  auto pass_b = [&](const int32_t* lm, int count, int offset, int type) {
+    for (int j = 0; j < count; ++j) {
+      const int t = lm[j], q = cnt[t]++;
+      vs->table_type[q] = type, vs->table_idx[q] = j, vs->lm_dev[q] = vs->dev_of_table[t], vs->first[q] = first[offset + j];
+    }
+  };
+  pass_b(in.px_lm, in.n_px, 0, HS_PIXEL), pass_b(in.br_lm, in.n_br, in.n_px, HS_BEARING);
+  // (C) segment-major record slots (stable over the landmark-major order)
+  {
+    std::vector<int>& cur = vs->scratch_start;
+    cur.assign(vs->seg_ptr.begin(), vs->seg_ptr.end() - 1);
+    for (int q = 0; q < n; ++q) vs->pos[q] = cur[vs->first[q]]++;
   }
-  for (int d = 0; d < in.n_lm; ++d) vs->lm_ptr[d + 1] += vs->lm_ptr[d];
-  // segment-major record slots (stable over the landmark-major order)
-  std::vector<int> by_seg;
-  counting_sort(n, n_seg, [&](int q) { return vs->first[q]; }, &by_seg);
-  vs->seg_ptr.assign(n_seg + 1, 0);
-  for (int p = 0; p < n; ++p) {
-    vs->pos[by_seg[p]] = p;
-    vs->seg_ptr[vs->first[by_seg[p]] + 1]++;
-  }
-  for (int s = 0; s < n_seg; ++s) vs->seg_ptr[s + 1] += vs->seg_ptr[s];
   return true;
 }
 

@@ -1031,14 +1031,14 @@ int launch_factor(hs_problem* p) {
   return HS_OK;
 }
 
-/// Speculative solves (visual-only windows on one shard): the candidate is LINEARISED instead of only costed, unless this is the last
+/// Speculative solves (visual-only windows, on one shard or on every shard of a distributed solve): the candidate is LINEARISED instead of only costed, unless this is the last
 /// iteration of the solve: its records land in the record buffer that does not hold the current point and become the current
 /// linearisation if the step is accepted (decide_step flips DevState::rec_sel), so that the next iteration starts at k_landmark — after an
 /// accepted step and after a rejected one (the records of the unchanged current point are still there: today's path linearises again).
 /// One linearise launch (16 us at configs[1]) replaces a cost launch (7.7 us) + a linearise launch per iteration.
 static bool speculative_solve(const hs_problem* p) {
   const Tables& T = p->T;
-  return T.n_vis > 0 && !T.n_pri && !T.n_ine && !T.nb && !p->allreduce && !p->rccl_comm && p->world == 1 && !(T.debug_flags & 1073741824);  // A/B switch
+  return T.n_vis > 0 && !T.n_pri && !T.n_ine && !T.nb && !(T.debug_flags & 1073741824);  // A/B switch (shards of a distributed solve too: the decision is replicated)
 }
 
 /// Small problems: the decision kernel copies the accepted candidate to x itself (single shard). A/B switch 16777216: always k_commit.

@@ -612,7 +612,11 @@ HSD void pack_exchange_body(const Tables& T, int reduce_here) {
   __shared__ double red[kBlock / 64];
   DevState* st = T.st;
   if (st->done) return;
-  double s = strided_sum(T.cost_part, T.n_cost_part);
+  // Speculative solves linearise at the candidate: from their second iteration on the cost partials of the CURRENT point are not
+  // recomputed — this shard's part of its cost is what decide_step took over when the candidate was accepted (st->local_cost). The
+  // exchanged sum is then right on every shard, whichever way the shard linearises (a shard that holds the priors does it the plain way).
+  const bool kept_cost = st->spec && st->iteration > 0;
+  double s = kept_cost ? (threadIdx.x == 0 ? st->local_cost : 0.0) : strided_sum(T.cost_part, T.n_cost_part);
   double gm = strided_max<24>(T.lm_gmax, T.n_obs_lm);  // one value per landmark: a single round of loads at 5 000 landmarks
   if (reduce_here) {
     const double* gp = T.xbuf + T.xo_g;
@@ -629,7 +633,10 @@ HSD void pack_exchange_body(const Tables& T, int reduce_here) {
     for (int b = threadIdx.x; b < T.nb; b += blockDim.x) gm = fmax(gm, fabs(T.xbuf[T.xo_gb + b]));  // border unknowns (bias points, gravity)
   }
   s = block_sum(s, red);
-  if (threadIdx.x == 0) T.xbuf[T.xo_cost] = s;
+  if (threadIdx.x == 0) {
+    T.xbuf[T.xo_cost] = s;
+    if (!kept_cost) st->local_cost = s;
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) gm = fmax(gm, __shfl_xor(gm, o));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = gm;

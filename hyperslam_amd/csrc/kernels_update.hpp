@@ -169,9 +169,7 @@ __global__ void __launch_bounds__(kBlock) k_cost_reduce(Tables T) {
 /// that precede a step (single lane).
 HSD void begin_iteration(const Tables& T, double c, double gm, bool set_scaling_ready) {
   DevState* st = T.st;
-  // (speculative solves linearise at the candidate point: from the second iteration on, the cost partials of the current point are not
-  //  recomputed — the cost of an accepted candidate was taken over by decide_step, a rejected one left it alone)
-  if (!(st->spec && st->iteration > 0)) st->cost = c;
+  st->cost = c;  // (speculative solves: the sum of the shards' kept costs, pack_exchange_body — equal to what decide_step took over)
   st->gmax = gm;
   st->chol_failed = 0;    // raised by the factorisation kernels of this iteration
   if (set_scaling_ready) st->scaling_ready = 1;  // Jacobi scaling is computed at iteration 0 only (else: set by decide_step)
@@ -234,6 +232,7 @@ __global__ void __launch_bounds__(kBlock) k_pack_decision(Tables T, int decide_h
   if (threadIdx.x == 0) {
     double* D = T.xbuf + T.xo_dec;
     D[0] = cand, D[1] = xs, D[2] = ss, D[3] = gd, D[4] = dd;
+    st->local_cand = cand;  // this shard's part (the exchange sums D over the shards)
     if (decide_here) decide_step(T);
   }
   if (decide_here == 2) {  // small problems: x <- candidate right here instead of a k_commit launch behind this one
@@ -297,6 +296,7 @@ HSD void decide_step(const Tables& T) {
     st->accepted = 1;
     st->num_successful++;
     st->cost = cand;
+    st->local_cost = st->local_cand;
     if (rec_pending) st->rec_sel ^= 1;  // its records are the linearisation of the new current point
     r.cost = cand;
     const double q = 2.0 * r.relative_decrease - 1.0;

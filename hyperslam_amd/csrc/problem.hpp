@@ -34,6 +34,8 @@ struct DevState {
   double radius, decrease_factor;
   double cost;            // cost at the current point
   double cand_cost;       // cost at the candidate point
+  double local_cost;      // this shard's part of `cost` (speculative solves: the cost partials of the current point are not recomputed)
+  double local_cand;      // this shard's part of the candidate's cost (k_pack_decision, before the exchange)
   double model_cost_change;
   unsigned long long gmax_bits;       // landmark-side max |gradient| as raw bits (atomicMax on non-negative doubles)
   unsigned long long gmax_pose_bits;  // pose-side max |gradient| (after the exchange)

@@ -192,7 +192,7 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
 /* Per-stage device times in the summary: linearize_ms / schur_ms / solve_ms / update_ms. Off by default — the four HIP events per
  * iteration that bracket the stages are barrier packets on the launch stream and cost ~5.7 us each on gfx950 (7 % of a configs[1]
  * iteration). total_ms is always measured. enabled != 0 turns the stage events on for the following hs_solve calls
- * (HS_STAGE_TIMING=1 in the environment at hs_create does the same). Visual-only single-shard solves linearise each iteration's
+ * (HS_STAGE_TIMING=1 in the environment at hs_create does the same). Visual-only solves linearise each iteration's
  * CANDIDATE (its records become the next iteration's linearisation when the step is accepted): that launch is booked under
  * linearize_ms, so that linearize_ms covers max_iterations launches of the linearisation kernel as on every other path. */
 int hs_set_stage_timing(hs_problem* p, int enabled);

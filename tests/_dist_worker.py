@@ -21,6 +21,14 @@ def main():
         full = synthetic.small_inertial(order=4, n_cp=18, n_landmarks=40)
     elif which.endswith("config3"):  # the shape of BASELINE.json configs[3] (long window, 10 blocks per landmark), scaled to CPU size
         full = synthetic.config3(n_cp=64, n_landmarks=600, obs_pairs=5)
+    elif which.endswith("visual_only") or which.endswith("one_prior"):
+        # visual-only shards linearise at the candidate point (capi.hip: speculative_solve); with ONE prior in the window, the shard that
+        # holds it does not, the other one does — started far from the optimum so that steps are rejected on the way
+        full = synthetic.small_visual(order=4, n_cp=18, n_landmarks=64, obs_pairs=3, with_priors=1 if which.endswith("one_prior") else 0, seed=3)
+        rng = np.random.default_rng(5)
+        full.control_points, full.landmarks = full.control_points.copy(), full.landmarks.copy()
+        full.control_points[:, 4:7] += 0.3 * rng.standard_normal((full.control_points.shape[0], 3))
+        full.landmarks += 1.0 * rng.standard_normal(full.landmarks.shape)
     else:
         full = synthetic.small_visual(order=4, n_cp=18, n_landmarks=64, obs_pairs=3, with_priors=21)
     shard = synthetic.shard_by_landmark(full, rank, world)

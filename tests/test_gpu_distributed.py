@@ -11,10 +11,24 @@ from util import rel
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("which", ["hip_visual", "hip_inertial"])
+def full_window(which):
+    if which.endswith("inertial"):
+        return synthetic.small_inertial(order=4, n_cp=18, n_landmarks=40)
+    if which.endswith("visual_only") or which.endswith("one_prior"):  # (the same construction as tests/_dist_worker.py)
+        full = synthetic.small_visual(order=4, n_cp=18, n_landmarks=64, obs_pairs=3, with_priors=1 if which.endswith("one_prior") else 0, seed=3)
+        rng = np.random.default_rng(5)
+        full.control_points, full.landmarks = full.control_points.copy(), full.landmarks.copy()
+        full.control_points[:, 4:7] += 0.3 * rng.standard_normal((full.control_points.shape[0], 3))
+        full.landmarks += 1.0 * rng.standard_normal(full.landmarks.shape)
+        return full
+    return synthetic.small_visual(order=4, n_cp=18, n_landmarks=64, obs_pairs=3, with_priors=21)
+
+
+@pytest.mark.parametrize("which", ["hip_visual", "hip_inertial", "hip_visual_only", "hip_one_prior"])
 def test_sharded_hip_matches_single_process(which, tmp_path, hip):
-    full = synthetic.small_inertial(order=4, n_cp=18, n_landmarks=40) if which.endswith("inertial") else \
-        synthetic.small_visual(order=4, n_cp=18, n_landmarks=64, obs_pairs=3, with_priors=21)
+    """hip_visual_only: both shards linearise at the candidate point; hip_one_prior: only the shard without the prior does — the exchanged
+    cost of the current point has to be right on both (DevState::local_cost)."""
+    full = full_window(which)
     with ha.Problem(full, lib=hip) as p:
         S, g = p.reduced_system(1e4)
         s = p.solve(5)

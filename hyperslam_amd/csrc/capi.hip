@@ -949,10 +949,13 @@ int launch_factor(hs_problem* p) {
     T3.join_epoch = ++p->join_epoch;
     const BackJob j0{T.Ub, T.Ubk, T.ybuf, p->d_Vb.p, p->d_yt.p, m + w_mid, 0, 0};
     const BackJob j1{p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, p->d_Vb2.p, p->d_yt2.p, mB, w_mid, 1};
-    if (T.debug_flags & 65536) k_premultiply<<<m + w_mid + mB, 128, 0, s>>>(T3, j0, j1, m + w_mid);
-    if (!(T.debug_flags & 65536)) {  // (A/B switch 65536: single-wave register sweep)
+    // (the two older sweeps are kept as measurement switches for visual-only systems, the shape they were measured on; they do not write
+    //  the border's step outputs)
+    const bool sweep_w = (T.debug_flags & 65536) && !T.nb, sweep_rows = (T.debug_flags & 268435456) && !T.nb;
+    if (sweep_w) k_premultiply<<<m + w_mid + mB, 128, 0, s>>>(T3, j0, j1, m + w_mid);
+    if (!sweep_w) {  // (A/B switch 65536: single-wave register sweep)
       const size_t g_lds = size_t(6 * (T.bw - 1)) * (6 * (T.bw - 1) | 1) * sizeof(double);  // given-column block of the far sweep
-      if (T.debug_flags & 268435456)  // A/B switch 268435456: one block row per step
+      if (sweep_rows)  // A/B switch 268435456: one block row per step
         k_band_backward2<<<2, kCholThreads, 2 * size_t(T.np) * sizeof(double) + g_lds, s>>>(T3, j0, j1, m);
       else  // super-blocks of four block rows; the inverses of the diagonal super-blocks come from extra workgroups of the launch
         k_band_backward_sb<<<2 + (m + w_mid + kSb - 1) / kSb + (mB + kSb - 1) / kSb, kCholThreads,
@@ -1012,7 +1015,7 @@ int launch_factor(hs_problem* p) {
     const BackJob j0{T.Ub, T.Ubk, T.ybuf, nullptr, nullptr, T.np / 6, 0, 0};
     k_band_backward2<<<1, kCholThreads, 2 * size_t(T.np) * sizeof(double), s>>>(T, j0, j0, -1);
     k_step_outputs<<<1, kBlock, 0, s>>>(T);
-  } else if (!(T.debug_flags & 65536)) {  // (A/B switch 65536: single-wave register sweep)
+  } else if (!(T.debug_flags & 65536) || T.nb) {  // (A/B switch 65536: single-wave register sweep — visual-only systems, the shape it was measured on)
     if (6 * (T.bw - 1) <= 96 && !(T.debug_flags & 268435456)) {  // super-blocks of four block rows: one lane pair per pending row, 96 pairs
       Tables T3 = T;
       T3.join_epoch = ++p->join_epoch;

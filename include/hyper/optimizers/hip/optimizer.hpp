@@ -251,6 +251,11 @@ class Optimizer<kOptimizerSuiteHIP> final : public AbstractOptimizer {
         values.insert(values.end(), v.data(), v.data() + 6);
       }
       check(hs_set_inertial_residuals(handle_, static_cast<int>(stamps.size()), stamps.data(), values.data()));
+    } else if (imu_ != nullptr) {
+      // every sample has left the window (or none has arrived yet): the table of the previous call must not stay behind. The bias
+      // and gravity tables the handle may still hold are unknowns without residuals then and come back untouched
+      // (tests/test_gpu_inertial.py::test_imu_tables_without_inertial_residuals).
+      check(hs_set_inertial_residuals(handle_, 0, nullptr, nullptr));
     }
 
     // ---- solve (cc:38-54: trust-region LM, 5 iterations, monotonic steps) ----

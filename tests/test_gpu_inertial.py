@@ -89,3 +89,26 @@ def test_two_ended_bordered_solve(order, n_cp, hip, oracle, monkeypatch):
     _, s1, cp1, lm1, g1, bg1, ba1 = run(hip)
     assert [it["step_is_successful"] for it in s1["iterations"]] == [it["step_is_successful"] for it in sg["iterations"]]
     assert rel(cpg, cp1) < 1e-8 and rel(lmg, lm1) < 1e-8 and rel(gg, g1) < 1e-8 and rel(bgg, bg1) < 1e-7 and rel(bag, ba1) < 1e-7
+
+
+@pytest.mark.parametrize("gravity_constant", [True, False])
+def test_imu_tables_without_inertial_residuals(gravity_constant, hip, oracle):
+    """An IMU whose samples have all left the window (or have not arrived yet): the bias splines and gravity are unknowns without
+    residuals — structurally zero columns of the border. The solve must be the visual-only solve, biases and gravity must come back
+    untouched (the reference-side plugin relies on it: it hands the empty inertial table over, include/hyper/optimizers/hip/optimizer.hpp)."""
+    import copy
+    w = synthetic.small_inertial(order=4, n_cp=18, n_landmarks=40, seed=23)
+    w.gravity_constant = gravity_constant
+    empty = copy.copy(w)
+    empty.inertial_stamps, empty.inertial_measurements = w.inertial_stamps[:0], w.inertial_measurements[:0]
+    visual = copy.copy(empty)
+    visual.imu = None
+    with ha.Problem(empty, lib=hip) as g, ha.Problem(visual, lib=hip) as v, ha.Problem(visual, lib=oracle) as c:
+        sg, sv, sc = g.solve(5), v.solve(5), c.solve(5)
+        assert sg["num_iterations"] == sv["num_iterations"] == sc["num_iterations"]
+        assert [it["step_is_successful"] for it in sg["iterations"]] == [it["step_is_successful"] for it in sc["iterations"]]
+        assert abs(sg["final_cost"] - sc["final_cost"]) <= 1e-8 * sc["final_cost"] and abs(sg["final_cost"] - sv["final_cost"]) <= 1e-10 * sv["final_cost"]
+        assert rel(g.control_points(), c.control_points()) < 1e-6 and rel(g.landmarks(), c.landmarks()) < 1e-6
+        bg, ba = g.bias()
+        assert np.array_equal(bg, np.asarray(w.imu["bias_g"]).reshape(-1, 4)) and np.array_equal(ba, np.asarray(w.imu["bias_a"]).reshape(-1, 4))
+        assert np.array_equal(g.gravity(), np.asarray(w.gravity, dtype=np.float64))

@@ -107,8 +107,17 @@ class Optimizer<kOptimizerSuiteHIP> final : public AbstractOptimizer {
     translation_constant_ = translation_constant;
   }
 
-  auto add(VisualBearingObservation& observation) -> void final { bearings_.push_back(&observation); }  // cc:189-210
-  auto add(VisualPixelObservation& observation) -> void final { pixels_.push_back(&observation); }      // cc:212-232
+  /// cc:189-232. A residual block keeps its landmark's parameter block alive in Ceres (AddResidualBlock registers an unknown block): an
+  /// observation of a landmark that was retired earlier (addLandmark is only called for NEW landmarks, abstract.cpp:252-257) makes
+  /// it active again, like there.
+  auto add(VisualBearingObservation& observation) -> void final {
+    landmarks_.insert(&observation.landmark());
+    bearings_.push_back(&observation);
+  }
+  auto add(VisualPixelObservation& observation) -> void final {
+    landmarks_.insert(&observation.landmark());
+    pixels_.push_back(&observation);
+  }
   auto add(ManifoldObservation<Manifold>& observation) -> void final { priors_.push_back(&observation); }     // cc:234-251
   auto add(InertialObservation<Manifold>& observation) -> void final { inertials_.push_back(&observation); }  // cc:253-274
 

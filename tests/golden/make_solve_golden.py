@@ -15,6 +15,11 @@ into HS_INERTIAL_EXACT mode: every Jacobian here is a derivative). Per LM iterat
 Unknown order of the pose side (what hs_reduced_system returns): 6 per control point (constant ones: unit diagonal, zero rhs),
 3 per gyroscope bias point, 3 per accelerometer bias point, 2 for gravity.
 Run:  python tests/golden/make_solve_golden.py   (about 10 minutes)
+
+Second window (`python tests/golden/make_solve_golden.py visual` -> solve_visual.json): order 6, 12 control points (the first six constant:
+the gauge is fixed), 6 landmarks far from their true positions, 24 pixel + 24 bearing blocks, no priors, no IMU — the kind of window on
+which the HIP library linearises at the candidate point and keeps the records of the current point across a rejected step; the recorded
+iterations contain rejected steps.
 """
 import json
 import os
@@ -28,16 +33,20 @@ sys.path.insert(0, HERE)
 from make_golden import (H, RES, SplitMix64, perturbed, plus_quat, plus_sphere, qconj, qexp, qmul, qnorm, qrot, spline_pose,  # noqa: E402
                          tofloat)
 
-K, N_CP, DT, T0 = 4, 9, mp.mpf("0.1"), mp.mpf(0)
-KB, N_BIAS, BIAS_DT, BIAS_T0 = 4, 4, mp.mpf("1.0"), mp.mpf("-1.0")  # one bias segment [0, 1) over the window: four points, all observed
+VISUAL = len(sys.argv) > 1 and sys.argv[1] == "visual"
+K, N_CP, DT, T0 = (6, 12, mp.mpf("0.1"), mp.mpf(0)) if VISUAL else (4, 9, mp.mpf("0.1"), mp.mpf(0))
+KB, N_BIAS, BIAS_DT, BIAS_T0 = 4, 0 if VISUAL else 4, mp.mpf("1.0"), mp.mpf("-1.0")  # one bias segment [0, 1) over the window: four points, all observed
 N_LM = 6
-N_ITER = 4
+N_ITER = 6 if VISUAL else 4
+N_CONST = 6 if VISUAL else 2   # leading constant control points (frozen prefix)
+LM_NOISE = float(os.environ.get("HS_GOLDEN_LM_NOISE", "1.0"))  # visual window: how far the landmarks start from their true positions [m]
+OUT_NAME = "solve_visual.json" if VISUAL else "solve.json"
 HUBER = {"pixel": mp.mpf("0.5"), "bearing": mp.mpf("1.6e-3")}  # optimizer.cpp:204,226
 INERTIAL_SCALE = mp.mpf("1.6e-5")                               # optimizer.cpp:267
 OFF_BG = 6 * N_CP
 OFF_BA = OFF_BG + 3 * N_BIAS
 OFF_G = OFF_BA + 3 * N_BIAS
-NP = OFF_G + 2
+NP = OFF_G + (0 if VISUAL else 2)
 NT = NP + 3 * N_LM
 
 
@@ -84,7 +93,7 @@ def build_window():
         return lo + (hi - lo) * u(0.02, 0.98)
 
     # landmarks: a point in front of camera 0 at a stamp in the middle of the window
-    qm, pm = spline_pose(truth[2:2 + K], K, truth[3][7] + DT / 2)
+    qm, pm = spline_pose(truth[2:2 + K], K, T0 + DT * (2 + (K - 1) // 2) + DT / 2)  # (the segment of control points 2 .. 2 + K - 1)
     lms_true = []
     for _ in range(N_LM):
         ps = [u(-1.2, 1.2), u(-0.8, 0.8), u(3.0, 7.0)]
@@ -131,17 +140,26 @@ def build_window():
                 b["meas"] = [f(x + u(-noise, noise)) for x in pred]
         W["blocks"].append(b)
 
+    pairs = 4 if VISUAL else 2
     for lm in range(3):           # pixel factors on landmarks 0..2
-        for _ in range(2):
+        for _ in range(pairs):
             t = stamp()
             add("pixel", t, lm=lm, cam=0)
             add("pixel", t, lm=lm, cam=1)
     W["blocks"][3]["meas"][0] = f(W["blocks"][3]["meas"][0] + 25)  # one gross outlier (Huber stays active at the solution)
     for lm in range(3, 6):        # bearing factors on landmarks 3..5
-        for _ in range(2):
+        for _ in range(pairs):
             t = stamp()
             add("bearing", t, lm=lm, cam=0)
             add("bearing", t, lm=lm, cam=1)
+    if VISUAL:  # starting point: free control points moved a little, landmarks moved a lot (the first steps overshoot and are rejected)
+        for j in range(N_CONST, N_CP):
+            W["cps"][j][:4] = [f(x) for x in qnorm(plus_quat(W["cps"][j][:4], [u(-0.01, 0.01) for _ in range(3)]))]
+            for c in range(3):
+                W["cps"][j][4 + c] = f(W["cps"][j][4 + c] + u(-0.05, 0.05))
+        W["lms"] = [[f(x + u(-LM_NOISE, LM_NOISE)) for x in lm] for lm in W["lms"]]
+        W["cp_constant"] = [1] * N_CONST + [0] * (N_CP - N_CONST)
+        return W
     # pose priors (unit weight), two of them late in the last segment: the newest control point only carries the basis weight u^3 / 6 of
     # the residuals of that segment, and without them its block is conditioned like 1e-10 (it still is the weakest block, as in every
     # sliding window; the LM diagonal is what keeps the newest control point in place)
@@ -238,7 +256,7 @@ def retract(W, delta):
     Q["lms"] = [[W["lms"][l][c] + delta[NP + 3 * l + c] for c in range(3)] for l in range(N_LM)]
     Q["bias_g"] = [[W["bias_g"][j][c] + delta[OFF_BG + 3 * j + c] for c in range(3)] + [W["bias_g"][j][3]] for j in range(N_BIAS)]
     Q["bias_a"] = [[W["bias_a"][j][c] + delta[OFF_BA + 3 * j + c] for c in range(3)] + [W["bias_a"][j][3]] for j in range(N_BIAS)]
-    Q["gravity"] = plus_sphere(W["gravity"], delta[OFF_G:OFF_G + 2])
+    Q["gravity"] = W["gravity"] if VISUAL else plus_sphere(W["gravity"], delta[OFF_G:OFF_G + 2])
     return Q
 
 
@@ -261,10 +279,14 @@ def main():
     t_start = time.time()
     W = build_window()
     out = {"generator": "tests/golden/make_solve_golden.py (mpmath, 100 digits)", "order": K, "t0": float(T0), "dt": float(DT),
-           "cp_constant": W["cp_constant"], "cameras": to_json(W["cams"]), "sensor_T_bs": to_json(W["sensor_T"]), "imu": to_json(W["imu"]),
+           "cp_constant": W["cp_constant"], "cameras": to_json(W["cams"]), "sensor_T_bs": to_json(W["sensor_T"]), "imu": None if VISUAL else to_json(W["imu"]),
            "bias_order": KB, "bias_t0": float(BIAS_T0), "bias_dt": float(BIAS_DT),
            "blocks": [{"type": b["type"], "stamp": float(b["stamp"]), "landmark": b["lm"], "camera": b["cam"], "meas": tofloat(b["meas"])} for b in W["blocks"]],
            "initial": state_json(W), "iterations": []}
+    if os.environ.get("HS_GOLDEN_DUMP_ONLY"):  # (tuning the starting point: the window alone, for a look at it through a library)
+        with open(os.environ["HS_GOLDEN_DUMP_ONLY"], "w") as fh:
+            json.dump(out, fh, separators=(",", ":"))
+        return
     radius, decrease = mp.mpf(10) ** 4, mp.mpf(2)
     cost, rows = evaluate(W)
     out["initial_cost"] = float(cost)
@@ -356,6 +378,8 @@ def main():
                "relative_decrease": float(quality), "step_norm": float(step_norm), "gradient_max_norm_before": float(gradient_max),
                "candidate": state_json(cand)}
         assert model_change > 0
+        if os.environ.get("HS_GOLDEN_PROBE"):  # (tuning the starting point: print the decisions only)
+            print("probe: iteration", it, "rho", mp.nstr(quality, 6), flush=True)
         # the convergence tests TrustRegionMinimizer runs before it looks at the step quality (parameter, then function tolerance)
         x_norm = mp.sqrt(sum(v * v for v in ambient_free(W)))
         rec["x_norm"] = float(x_norm)
@@ -385,9 +409,9 @@ def main():
         rec["state"] = state_json(W)
         out["iterations"].append(rec)
         print("iteration", it, "cost", mp.nstr(cost, 12), "rho", mp.nstr(quality, 8), "radius", mp.nstr(radius, 8), "%.0f s" % (time.time() - t_start), flush=True)
-    with open(os.path.join(HERE, "solve.json"), "w") as fh:
+    with open(os.path.join(HERE, OUT_NAME), "w") as fh:
         json.dump(out, fh, separators=(",", ":"))
-    print("wrote solve.json")
+    print("wrote", OUT_NAME)
 
 
 if __name__ == "__main__":

@@ -146,9 +146,10 @@ def check_tracks_against_golden(lib, tol):
     return max(errs)
 
 
-def solve_golden():
-    """tests/golden/solve.json (tests/golden/make_solve_golden.py): the window and, per LM iteration, the 100-digit solver quantities."""
-    with open(os.path.join(HERE, "golden", "solve.json")) as f:
+def solve_golden(name="solve.json"):
+    """tests/golden/solve.json / solve_visual.json (tests/golden/make_solve_golden.py): the window and, per LM iteration, the 100-digit
+    solver quantities. `name` may be a path."""
+    with open(name if os.path.isabs(name) else os.path.join(HERE, "golden", name)) as f:
         d = json.load(f)
     blocks = d["blocks"]
 
@@ -158,9 +159,11 @@ def solve_golden():
         return a.reshape(len(rows), width) if width else a
 
     ini = d["initial"]
-    imu = dict(d["imu"])
-    imu.update(bias_order=d["bias_order"], bias_t0=d["bias_t0"], bias_dt=d["bias_dt"], bias_g=np.array(ini["bias_g"]), bias_a=np.array(ini["bias_a"]),
-               bias_constant=False)
+    imu = None
+    if d["imu"] is not None:
+        imu = dict(d["imu"])
+        imu.update(bias_order=d["bias_order"], bias_t0=d["bias_t0"], bias_dt=d["bias_dt"], bias_g=np.array(ini["bias_g"]), bias_a=np.array(ini["bias_a"]),
+                   bias_constant=False)
     w = Window(order=d["order"], t0=d["t0"], dt=d["dt"], control_points=np.array(ini["control_points"]), cp_constant=np.array(d["cp_constant"], np.uint8),
                cam_T_bs=np.array([c["T_bs"] for c in d["cameras"]]), cam_intrinsics=np.array([c["intrinsics"] for c in d["cameras"]]),
                cam_distortion=np.array([c["distortion"] for c in d["cameras"]]), sensor_T_bs=np.array([d["sensor_T_bs"]]),
@@ -174,13 +177,14 @@ def solve_golden():
     return d, w
 
 
-def check_solver_against_golden(lib, tol_forward, tol_state):
+def check_solver_against_golden(lib, tol_forward, tol_state, name="solve.json"):
     """The solver level of a library (a-11: cost, reduced normal equations, LM step, step quality, accept / reject, radius, and the state
     after every iteration) against tests/golden/solve.json. `tol_forward`: quantities that are evaluated (cost, reduced system, gradient);
     `tol_state`: quantities that went through the linear solve (steps, step quality, the state). Returns the worst errors seen."""
     from hyperslam_amd import HS_INERTIAL_EXACT, Problem
-    d, w = solve_golden()
+    d, w = solve_golden(name)
     its = d["iterations"]
+    has_imu = w.imu is not None
     worst = {"forward": 0.0, "state": 0.0}
 
     def fwd(a, b, what):
@@ -194,19 +198,23 @@ def check_solver_against_golden(lib, tol_forward, tol_state):
         worst["state"] = max(worst["state"], e)
 
     with Problem(w, lib=lib) as p:
-        p.set_inertial_jacobian(HS_INERTIAL_EXACT)  # every golden Jacobian is a derivative; the IMU parameters are not at the identity point
+        if has_imu:
+            p.set_inertial_jacobian(HS_INERTIAL_EXACT)  # every golden Jacobian is a derivative; the IMU parameters are not at the identity point
         fwd(p.cost(), d["initial_cost"], "initial cost")
         S, g = p.reduced_system(its[0]["radius_before"])
         fwd(S, its[0]["reduced_S"], "reduced system, first iteration")
         fwd(g, its[0]["reduced_g"], "reduced gradient, first iteration")
         for n in range(1, len(its) + 1):  # the state after n iterations, from the same starting point every time
             p.upload(w)
-            p.set_inertial_jacobian(HS_INERTIAL_EXACT)
+            if has_imu:
+                p.set_inertial_jacobian(HS_INERTIAL_EXACT)
             s = p.solve(n)
             assert s["num_iterations"] == n
             golden_state = its[n - 1]["state"]
             sta(p.control_points(), golden_state["control_points"], f"control points after {n}")
             sta(p.landmarks(), golden_state["landmarks"], f"landmarks after {n}")
+            if not has_imu:
+                continue
             bg, ba = p.bias()
             # the bias points carry the weakest blocks of the window (inertial loss scale 1.6e-5): absolute scale = the step they took
             bias_scale = max(1.0, float(np.abs(np.array(its[n - 1]["step"])).max()))

@@ -28,7 +28,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 LM_ITERATIONS = 5           # optimizer.cpp:40
-B_ALG_PIXEL_K4 = 480        # algorithmic bytes per pixel residual block linearised, SURVEY.md §8(d)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_PEAK_TFLOPS = 78.6     # MI355X_MICROARCH.md: vector fp64 = half the 157.3 TFLOP/s fp32 rate (the f64 MFMA runs at the same rate, tools/microbench)
 
@@ -314,27 +313,53 @@ def main():
         n_lin = n_staged * LM_ITERATIONS
         lin_ms = stage["linearize_ms"] / n_lin
         order = int(window.order)
-        b_alg = 32 + 8 * (8 + 12 * order)  # 32 B in + one record [r(2) J_l(6) J_state(12 k)] out = 480 B at k = 4
         n_visual = len(window.pixel_stamps) + len(window.bearing_stamps)
-        lin_kernel = f"hs::k_linearize_visual<{order}>"
-        live = b_alg * n_visual / (lin_ms * 1e-3) / 1e9
+        bw_blocks = problem.lib.band_blocks(problem.h)
+        # Default path (round 4): the FUSED BUILD — k_build_visual linearises a landmark group's residual blocks into LDS, eliminates its landmarks and
+        # accumulates J_p'J_p - Yh Yh' in the same pass; the 448-byte record of SURVEY.md 8(d) (B_out at k = 4) is never written. Its
+        # algorithmic bytes are what the kernel's contract makes it move: 32 B of inputs per residual block, the Y-hat rows (3 x 6 doubles
+        # per control point a landmark touches: k_backsub_retract needs them), 25 doubles of per-landmark factors and one window partial
+        # [bw (bw + 1) / 2 tiles of 36 + 3 x 6 bw doubles] per chunk of <= 24 landmarks. The record path (HS_BUILD_PATH=records, long feature
+        # tracks) keeps the round-3 kernel and SURVEY's B_alg = 480 B per block.
+        fused = os.environ.get("HS_BUILD_PATH") != "records" and bw_blocks * (bw_blocks + 1) // 2 <= 256 and n_visual > 0
+        if fused:
+            lin_kernel = f"hs::k_build_visual<{order}>"
+            lm_ids = np.concatenate([window.pixel_landmark, window.bearing_landmark])
+            st_all = np.concatenate([window.pixel_stamps, window.bearing_stamps])
+            seg = np.floor((st_all - window.t0) / window.dt).astype(np.int64) - (order - 1) // 2
+            lo = np.full(len(window.landmarks), 1 << 30, np.int64)
+            hi = np.full(len(window.landmarks), -1, np.int64)
+            np.minimum.at(lo, lm_ids, seg), np.maximum.at(hi, lm_ids, seg + order - 1)
+            ncp_l = (hi - lo + 1)[hi >= 0]
+            n_chunks = max(1, int(np.ceil(len(ncp_l) / 24.0)))  # lower bound of the chunk count (the library splits per landmark group)
+            alg_bytes = 32 * n_visual + 8 * (18 * int(ncp_l.sum()) + 25 * len(ncp_l)) + 8 * n_chunks * (36 * bw_blocks * (bw_blocks + 1) // 2 + 18 * bw_blocks)
+            alg_note = ("32 B in per residual block + Y-hat rows + per-landmark factors + one window partial per chunk (lower bound: ceil(landmarks / 24) chunks); "
+                        "the 448-byte record of SURVEY.md 8(d) is not materialised on this path")
+        else:
+            lin_kernel = f"hs::k_linearize_visual<{order}>"
+            alg_bytes = (32 + 8 * (8 + 12 * order)) * n_visual  # 32 B in + one record [r(2) J_l(6) J_state(12 k)] out = 480 B at k = 4
+            alg_note = "SURVEY.md 8(d): B_alg = 32 B in + 8 (8 + 12 k) B record out per residual block"
+        b_alg = alg_bytes / max(1, n_visual)
+        live = alg_bytes / (lin_ms * 1e-3) / 1e9
         # the duration in the committed rocprofv3 kernel trace of this command excludes the ~6 us of dispatch latency the HIP events around
         # the launch include: it prices the kernel, the events price the launch. frac uses the trace when one is committed for this kernel.
         prof_ms = rocprof_kernel_ms(f"void {lin_kernel}") if args.config == 1 and world == 1 else None
-        profiled = b_alg * n_visual / (prof_ms * 1e-3) / 1e9 if prof_ms else None
+        profiled = alg_bytes / (prof_ms * 1e-3) / 1e9 if prof_ms else None
         # `achieved` / `frac` are the numbers measured in THIS run (HIP events around the launch on the library's stream, inside the timed
         # region); the figures derived from the committed rocprofv3 trace of the same command stand beside them (`*_profile`).
         roofline = {"kernel": lin_kernel, "bound": "hbm", "achieved": live, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": live / HBM_PEAK_GBS,
                     "traffic": pmc_traffic(lin_kernel) if args.config == 1 and world == 1 else None,
-                    "algorithmic_bytes_per_launch": b_alg * n_visual, "avg_launch_ms": lin_ms, "timing_source": "HIP events (live, this run)",
+                    "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_residual_block": b_alg, "algorithmic_bytes_model": alg_note,
+                    "avg_launch_ms": lin_ms, "timing_source": "HIP events (live, this run)",
                     "rocprof_avg_kernel_ms": prof_ms, "achieved_profile": profiled, "frac_profile": profiled / HBM_PEAK_GBS if profiled else None,
                     "note": "avg_launch_ms / achieved / frac = HIP events around the launch on the library's stream, measured in this run (they include "
                             "~4 us of dispatch latency); rocprof_avg_kernel_ms / achieved_profile / frac_profile = committed rocprofv3 --kernel-trace "
                             "--stats average of this command (the kernel alone); traffic = FETCH_SIZE + WRITE_SIZE of the newest "
                             "profiles/r*_pmc_hbm_traffic.json (separate rocprofv3 --pmc passes, tools/pmc_traffic.sh)"}
         n_cp_total = int(window.control_points.shape[0])
-        bw_blocks = problem.lib.band_blocks(problem.h)
-        two_ended = (not len(window.inertial_stamps)) and n_cp_total >= 4 * bw_blocks and bw_blocks <= 16
+        # (launch_factor's rule: look-ahead kernel, window of >= 4 bw block rows; bordered systems too unless HS_DEBUG_FLAGS 536870912 / 2048)
+        flags = int(os.environ.get("HS_DEBUG_FLAGS", "0"))
+        two_ended = n_cp_total >= 4 * bw_blocks and bw_blocks <= 16 and not (flags & 2048) and not (len(window.inertial_stamps) and (flags & 536870912))
         out = {
             "metric": "residual blocks linearised per second (LM iteration = linearise + Schur + solve + update), 128-control-point window",
             "value": n_blocks_global * LM_ITERATIONS * args.steps / elapsed,
@@ -364,8 +389,8 @@ def main():
         # the same algorithmic bytes against the whole LM iteration (linearise + Schur + solve + update): the path is a latency-bound
         # dependency chain after the linearisation, so this fraction is low by construction
         it_ms = out["ms_per_gn_iteration"]
-        out["roofline_iteration"] = {"bound": "hbm", "achieved": b_alg * n_visual / (it_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                     "frac": b_alg * n_visual / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": it_ms}
+        out["roofline_iteration"] = {"bound": "hbm", "achieved": alg_bytes / (it_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": alg_bytes / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": it_ms}
         if args.config == 1 and world == 1:  # the factor the runtime actually instantiates (abstract.cpp:243-260): same window, bearing residuals
             out["bearing_variant"] = bearing_variant(ha, synthetic, local_rank)
         if not args.no_cpu_baseline and world == 1:  # reported at N = 1 only (the other ranks would idle behind rank 0's CPU run)

@@ -226,6 +226,12 @@ struct hs_problem {
   unsigned join_epoch = 0;
   DBuf<int> d_gw_ptr, d_gw_cf, d_sw_ptr, d_sw_seg;
   int n_seg_wg = 0, n_group_wg = 0;
+  // fused build of the visual factors (kernels_build.hpp)
+  bool fused = false;
+  int build_R = 0, build_L = 0;     // records per pass, landmarks per chunk
+  size_t build_lds = 0;
+  DBuf<int> d_ch_ptr;
+  std::vector<int> h_ch_ptr, h_gw_ptr, h_gw_cf;
   DBuf<double> d_ybuf, d_scale_b, d_Spb, d_Sbb, d_gb_s, d_D2b, d_Zb, d_Cb, d_hb, d_xb, d_delta_b, d_bias_g_snap, d_bias_a_snap, d_gravity_snap;
   DBuf<int> d_i_bias_ptr, d_bfwd_start;
   int n_split = 1;
@@ -428,8 +434,31 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_v_first.upload(vs.first, s));
   HIP_TRY(p->d_v_pos.upload(vs.pos, s));
   HIP_TRY(p->d_v_seg_ptr.upload(vs.seg_ptr, s));
-  HIP_TRY(p->d_v_rec.reserve(size_t(n_vis) * (8 + 12 * k) + 1));
-  HIP_TRY(p->d_v_rec_alt.reserve(size_t(n_vis) * (8 + 12 * k) + 1));
+  // ---- fused build (kernels_build.hpp) or the record path (long feature tracks: more than 256 window tiles; A/B switch 2147483648... see below) ----
+  {
+    const int ntile_ = vs.bw * (vs.bw + 1) / 2, nband_ = k * vs.bw - k * (k - 1) / 2;
+    const char* env = std::getenv("HS_BUILD_PATH");  // "records": the record path everywhere (measurement switch, like HS_DEBUG_FLAGS)
+    p->fused = n_vis > 0 && ntile_ <= kBlock && nband_ <= kBlock && !(env && std::strcmp(env, "records") == 0);
+  }
+  if (p->fused) {
+    // chunk geometry: records per pass R (<= 256 lanes), landmarks per chunk L — as large as the LDS allows (fewer, larger partials for
+    // k_assemble; one workgroup per CU either way). HS_BUILD_R / HS_BUILD_L: tuning overrides.
+    int R = k == 4 ? 256 : 192, L = k == 4 ? 24 : 18;
+    if (const char* e = std::getenv("HS_BUILD_R")) R = std::max(32, std::min(kBlock, std::atoi(e)));
+    if (const char* e = std::getenv("HS_BUILD_L")) L = std::max(1, std::min(kBlock - 1, std::atoi(e)));
+    const size_t lds_cap = 156 * 1024;
+    while (size_t(build_lds_layout(k, vs.bw, R, L).total_doubles) * 8 > lds_cap && L > 4) --L;
+    while (size_t(build_lds_layout(k, vs.bw, R, L).total_doubles) * 8 > lds_cap && R > 64) R -= 32;
+    if (size_t(build_lds_layout(k, vs.bw, R, L).total_doubles) * 8 > lds_cap) p->fused = false;
+    p->build_R = R, p->build_L = L, p->build_lds = size_t(build_lds_layout(k, vs.bw, R, L).total_doubles) * 8;
+  }
+  if (p->fused) {
+    build_chunks(vs, p->n_cp, p->build_R, p->build_L, &p->h_ch_ptr, &p->h_gw_ptr, &p->h_gw_cf);
+  }
+  if (!p->fused) {
+    HIP_TRY(p->d_v_rec.reserve(size_t(n_vis) * (8 + 12 * k) + 1));
+    HIP_TRY(p->d_v_rec_alt.reserve(size_t(n_vis) * (8 + 12 * k) + 1));
+  }
   HIP_TRY(p->d_p_stamp.upload(p_stamp, s));
   HIP_TRY(p->d_p_meas.upload(p_meas, s));
   HIP_TRY(p->d_p_sensor.upload(p_sensor, s));
@@ -488,6 +517,7 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_delta_p.reserve(np));
   const int vis_block = k == 4 ? lin_block<4>() : lin_block<6>();
   p->nb_vis = (n_vis + vis_block - 1) / vis_block;
+  if (p->fused) p->nb_vis = std::max((n_vis + kBlock - 1) / kBlock, int(p->h_ch_ptr.size()) - 1);  // one cost partial per chunk / per workgroup of k_cost_visual
   p->nb_pri = (n_pri + kBlock - 1) / kBlock;
   p->nb_cp = std::max((p->n_cp + kBlock - 1) / kBlock, 1);
   HIP_TRY(p->d_cost_part.reserve(p->nb_vis + p->nb_pri + (n_ine + kBlock - 1) / kBlock + 1));
@@ -546,9 +576,9 @@ int prepare(hs_problem* p) {
     // k_seg_gram work list: ~96 visual-record equivalents per workgroup (one LDS stage)
     std::vector<int> sw_ptr(n_seg_ + 1, 0), sw_seg;
     for (int f = 0; f < n_seg_; ++f) {
-      const int load = (vs.seg_ptr[f + 1] - vs.seg_ptr[f]) + 3 * (p->pr_seg_ptr[f + 1] - p->pr_seg_ptr[f]) +
+      const int load = (p->fused ? 0 : vs.seg_ptr[f + 1] - vs.seg_ptr[f]) + 3 * (p->pr_seg_ptr[f + 1] - p->pr_seg_ptr[f]) +
                        (p->in_seg_ptr.empty() ? 0 : 3 * (p->in_seg_ptr[f + 1] - p->in_seg_ptr[f]));
-      const int nw = std::max(1, (load + 95) / 96);
+      const int nw = p->fused ? (load + 95) / 96 : std::max(1, (load + 95) / 96);  // (fused build: segments without prior / inertial records have no workgroup)
       sw_ptr[f + 1] = sw_ptr[f] + nw;
       for (int w = 0; w < nw; ++w) sw_seg.push_back(f);
     }
@@ -560,17 +590,24 @@ int prepare(hs_problem* p) {
     // Schur stage of 71.2 / 65.8 / 66.5 / 68.1 / 70.9 us: fewer, larger partials for k_assemble against less parallelism)
     const int per_wg = 12;
     std::vector<int> gw_ptr(p->n_cp + 1, 0), gw_cf;
-    for (int c = 0; c < p->n_cp; ++c) {
-      const int cnt = vs.cf_ptr[c + 1] - vs.cf_ptr[c], nw = (cnt + per_wg - 1) / per_wg;
-      gw_ptr[c + 1] = gw_ptr[c] + nw;
-      for (int w = 0; w < nw; ++w) gw_cf.push_back(c);
+    if (p->fused) {  // the chunks of the fused build take the place of the k_group_gram workgroups
+      HIP_TRY(p->d_gw_ptr.upload(p->h_gw_ptr, s));
+      HIP_TRY(p->d_gw_cf.upload(p->h_gw_cf, s));
+      HIP_TRY(p->d_ch_ptr.upload(p->h_ch_ptr, s));
+      p->n_group_wg = int(p->h_ch_ptr.size()) - 1;
+    } else {
+      for (int c = 0; c < p->n_cp; ++c) {
+        const int cnt = vs.cf_ptr[c + 1] - vs.cf_ptr[c], nw = (cnt + per_wg - 1) / per_wg;
+        gw_ptr[c + 1] = gw_ptr[c] + nw;
+        for (int w = 0; w < nw; ++w) gw_cf.push_back(c);
+      }
+      p->n_group_wg = gw_ptr[p->n_cp];
+      gw_cf.push_back(0);
+      HIP_TRY(p->d_gw_ptr.upload(gw_ptr, s));
+      HIP_TRY(p->d_gw_cf.upload(gw_cf, s));
     }
-    p->n_group_wg = gw_ptr[p->n_cp];
-    gw_cf.push_back(0);
-    HIP_TRY(p->d_gw_ptr.upload(gw_ptr, s));
-    HIP_TRY(p->d_gw_cf.upload(gw_cf, s));
-    HIP_TRY(p->d_segP.reserve(size_t(p->n_seg_wg) * (size_t(nca) * nca + nca)));
-    HIP_TRY(p->d_grpQ.reserve(size_t(p->n_group_wg) * (size_t(ntile) * 36 + 6 * vs.bw) + 1));
+    HIP_TRY(p->d_segP.reserve(size_t(p->n_seg_wg) * (size_t(nca) * nca + nca) + 1));
+    HIP_TRY(p->d_grpQ.reserve(size_t(p->n_group_wg) * (size_t(ntile) * 36 + (p->fused ? 3 : 1) * 6 * vs.bw) + 1));
   }
   HIP_TRY(p->d_state.reserve(1));
 
@@ -622,6 +659,7 @@ int prepare(hs_problem* p) {
   T.scale_b = p->d_scale_b.p, T.Spb = p->d_Spb.p, T.Sbb = p->d_Sbb.p, T.gb_s = p->d_gb_s.p, T.D2b = p->d_D2b.p;
   T.Zb = p->d_Zb.p, T.Cb = p->d_Cb.p, T.hb = p->d_hb.p, T.xb = p->d_xb.p, T.delta_b = p->d_delta_b.p, T.i_bias_ptr = p->d_i_bias_ptr.p, T.bfwd_start = p->d_bfwd_start.p;
   T.x_count1 = x_count1, T.xo_dec = x_count1;
+  T.fused = p->fused ? 1 : 0, T.n_chunk = p->fused ? p->n_group_wg : 0, T.ch_ptr = p->d_ch_ptr.p;
   T.rank = p->rank, T.world = p->world;
   // HS_DEBUG_FLAGS (measurement switches only, never needed for correct operation):
   //    1 skip the backward sweep          2 skip the rank-6 updates (timing of the panel chain alone; results are garbage)
@@ -681,8 +719,10 @@ static int ensure_side_stream(hs_problem* p) {
 /// gathers k_border_pb / _bb in launch_build — only meets the visual branch (k_linearize_visual -> k_landmark -> Gram
 /// kernels -> k_assemble) at the segment Gram kernel (reads the inertial records) and at k_reduce_partials, and each branch fills a
 /// fraction of the chip: they run on two streams. configs[2]: 293 us of kernels back to back -> 175 us on the critical path.
+/// Fused build (p->fused): the visual factors are linearised by k_build_visual inside launch_build — nothing to do for them here, unless only
+/// the cost is wanted (`visual_cost_only`: hs_cost, hs_solve with zero iterations), which the value-only kernel delivers.
 template <int K>
-int launch_linearize(hs_problem* p, bool inertial_on_side = false) {
+int launch_linearize(hs_problem* p, bool inertial_on_side = false, bool visual_cost_only = false) {
   const Tables& T = p->T;
   hipStream_t s = p->stream;
   p->side_imu = inertial_on_side && T.n_ine > 0 && T.nb > 0 && !(T.debug_flags & 1048576);  // A/B switch 1048576: one stream
@@ -692,7 +732,8 @@ int launch_linearize(hs_problem* p, bool inertial_on_side = false) {
     HIP_TRY(hipEventRecord(p->ev_fork, s));
     HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0));
   }
-  if (T.n_vis) k_linearize_visual<K><<<p->nb_vis, lin_block<K>(), lin_lds_bytes<K>(p), s>>>(T, T.v_rec, T.v_pos, 1, T.cost_part, nullptr);
+  if (T.n_vis && !p->fused) k_linearize_visual<K><<<p->nb_vis, lin_block<K>(), lin_lds_bytes<K>(p), s>>>(T, T.v_rec, T.v_pos, 1, T.cost_part, nullptr);
+  if (T.n_vis && p->fused && visual_cost_only) k_cost_visual<K><<<p->nb_vis, kBlock, cp_lds_bytes(p), s>>>(T, T.cp, T.lm, T.cost_part);
   if (T.n_pri) k_linearize_prior<K><<<p->nb_pri, kBlock, cp_lds_bytes(p), s>>>(T, T.p_rec, T.cost_part + p->nb_vis, nullptr);
   if (T.n_ine)
     k_linearize_inertial<K, 4><<<p->nb_ine, kInertialBlock, cp_lds_bytes(p), p->side_imu ? p->side : s>>>(T, T.i_rec, 1, T.cost_part + p->nb_vis + p->nb_pri,
@@ -745,17 +786,24 @@ int exchange(hs_problem* p, double* buf, int64_t count) {
 
 static int border_zero_wgs(const Tables& T) { return std::min(64, (T.nb * T.nb + T.nb + kPbThreads - 1) / kPbThreads); }
 
+/// `after_build` (stage timing of a fused build): recorded behind k_build_visual — the launch that linearises the visual factors belongs to
+/// the "linearise" stage of hs_summary, what follows it (segment Gram of the prior / inertial records, assembly, finalisation) to "schur".
 template <int K>
-int launch_build(hs_problem* p) {
+int launch_build(hs_problem* p, hipEvent_t after_build = nullptr) {
   const Tables& T = p->T;
   hipStream_t s = p->stream;
   // k_seg_gram only needs the records, k_landmark -> k_group_gram records and landmarks: the two gram kernels share one launch
   // (k_gram_pair). A/B switch 1024: the previous arrangement, k_seg_gram on a side stream next to k_landmark -> k_group_gram.
   // (for small grids only — configs[1]: ~940 workgroups, Schur stage 66 -> 62 us. The pair holds 80 KB of LDS per workgroup, two per
   //  CU, where k_group_gram alone fits three: at configs[3], ~3 750 workgroups, the two streams are faster, 0.165 vs 0.181 ms)
-  const bool pair = T.n_lm > 0 && p->n_group_wg > 0 && p->n_group_wg + p->n_seg_wg <= 2048 && !(T.debug_flags & 1024);
+  const bool fused = p->fused;
+  const bool pair = !fused && T.n_lm > 0 && p->n_group_wg > 0 && p->n_group_wg + p->n_seg_wg <= 2048 && !(T.debug_flags & 1024);
   const bool side_imu = p->side_imu;       // (set by launch_linearize: the side stream is busy with the inertial branch)
-  const bool fork = T.n_lm > 0 && !pair && !side_imu;
+  const bool fork = !fused && T.n_lm > 0 && !pair && !side_imu;
+  // Fused build: linearisation, landmark elimination and both Gram terms of the visual factors in one launch; what remains for the segment
+  // Gram kernel are the prior / inertial records (none on visual-only windows: no launch)
+  if (fused) k_build_visual<K><<<p->nb_vis, kBlock, p->build_lds, s>>>(T, p->build_R, p->build_L, 1);
+  if (fused && after_build) HIP_TRY(hipEventRecord(after_build, s));
   if (fork) {
     const int rc = ensure_side_stream(p);
     if (rc) return rc;
@@ -774,12 +822,12 @@ int launch_build(hs_problem* p) {
     irec_ready = true;
     return hipStreamWaitEvent(s, p->ev_irec, 0);
   };
-  if (!pair && !(side_imu && T.n_lm)) {
+  if (!pair && !(side_imu && T.n_lm) && p->n_seg_wg) {
     HIP_TRY(need_irec());
     k_seg_gram<K><<<p->n_seg_wg, kBlock, kSegStage * sizeof(double), fork ? p->side : s>>>(T);
   }
   if (fork) HIP_TRY(hipEventRecord(p->ev_join, p->side));
-  if (T.n_lm) {
+  if (T.n_lm && !fused) {
     const int grid = (T.n_lm + kBlock / 64 - 1) / (kBlock / 64);
     if (6 * T.bw <= 128)
       k_landmark<K, 2, 2><<<grid, kBlock, 0, s>>>(T);
@@ -788,7 +836,7 @@ int launch_build(hs_problem* p) {
     else  // long feature tracks (6 * bw <= kBlock is checked in prepare()): one workgroup per landmark, one wave per 64 rows of W
       k_landmark_rows<K, 4><<<T.n_lm, kBlock, 0, s>>>(T);
   }
-  if (T.n_lm && p->n_group_wg) {
+  if (T.n_lm && p->n_group_wg && !fused) {
     const int ntile = T.bw * (T.bw + 1) / 2;
     const int batch = std::max(2, std::min(kGroupBatch, int(48 * 1024 / (size_t(18) * T.bw * sizeof(double)))));
     const size_t lds = std::max((size_t(batch) * 18 * T.bw + 4 * batch) * sizeof(double), size_t(128) * 42 * sizeof(double));
@@ -810,7 +858,7 @@ int launch_build(hs_problem* p) {
     else
       k_group_gram<4><<<grid, kBlock, lds, s>>>(T, batch);
   }
-  if (side_imu && T.n_lm && !pair) {  // (large grids with an IMU: the segment Gram kernel after the landmark chain, same stream)
+  if (side_imu && T.n_lm && !pair && p->n_seg_wg) {  // (large grids with an IMU: the segment Gram kernel after the landmark chain, same stream)
     HIP_TRY(need_irec());
     k_seg_gram<K><<<p->n_seg_wg, kBlock, kSegStage * sizeof(double), s>>>(T);
   }
@@ -941,7 +989,7 @@ int launch_factor(hs_problem* p) {
       k_border_forward2<<<dim3(n_groups, 2), fwd_threads, size_t(T.np) * kBorderLd * sizeof(double), s>>>(
           Tb, BfJob{T.Ub, T.Ubk, m + w_mid, 0}, BfJob{p->d_Ub2.p, p->d_Ubk2.p, mB, 1}, m, 0, local_rows, p->d_bf_handover.p);
       const int n_tiles = (T.nb + kSchurTile - 1) / kSchurTile;
-      k_border_schur<<<dim3(n_tiles, n_tiles), kBlock, 0, s>>>(Tb, 0, local_rows);
+      k_border_schur<<<dim3(n_tiles, n_tiles), kBlock, 0, s>>>(Tb, 0, local_rows, m);  // (rows from the junction on are never skipped)
       HIP_TRY(launch_border_solve(Tb, s));
       k_border_apply<<<(T.np + kBlock / 64 - 1) / (kBlock / 64), kBlock, 0, s>>>(Tb);
     }
@@ -1007,7 +1055,7 @@ int launch_factor(hs_problem* p) {
     const int local_rows = (!p->allreduce && !p->rccl_comm && p->world == 1) ? 1 : 0;
     k_border_forward<<<(T.nb + kBorderCols - 1) / kBorderCols, fwd_threads, size_t(T.np) * kBorderLd * sizeof(double), s>>>(T, f0, local_rows);
     const int nt = (T.nb + kSchurTile - 1) / kSchurTile;
-    k_border_schur<<<dim3(nt, nt), kBlock, 0, s>>>(T, f0, local_rows);
+    k_border_schur<<<dim3(nt, nt), kBlock, 0, s>>>(T, f0, local_rows, n_blk);
     HIP_TRY(launch_border_solve(T, s));
     k_border_apply<<<(T.np + kBlock / 64 - 1) / (kBlock / 64), kBlock, 0, s>>>(T);
   }
@@ -1041,7 +1089,13 @@ int launch_factor(hs_problem* p) {
 /// One linearise launch (16 us at configs[1]) replaces a cost launch (7.7 us) + a linearise launch per iteration.
 static bool speculative_solve(const hs_problem* p) {
   const Tables& T = p->T;
-  return T.n_vis > 0 && !T.n_pri && !T.n_ine && !T.nb && !(T.debug_flags & 1073741824);  // A/B switch (shards of a distributed solve too: the decision is replicated)
+  return !p->fused && T.n_vis > 0 && !T.n_pri && !T.n_ine && !T.nb && !(T.debug_flags & 1073741824);  // A/B switch (shards of a distributed solve too: the decision is replicated)
+}
+/// Fused build: a visual-only window keeps an accepted candidate in the candidate buffers (k_build_visual reads it from there, the next
+/// k_backsub_retract copies it to x on its way): no k_commit launch per iteration. Other windows commit (their prior / inertial kernels read x).
+static bool fused_visual_only(const hs_problem* p) {
+  const Tables& T = p->T;
+  return p->fused && !T.n_pri && !T.n_ine && !T.nb;
 }
 
 /// Small problems: the decision kernel copies the accepted candidate to x itself (single shard). A/B switch 16777216: always k_commit.
@@ -1097,7 +1151,7 @@ template <int K>
 static void warm_kernels_of_order() {
   hipFuncAttributes fa;
   const void* kernels[] = {
-      reinterpret_cast<const void*>(&k_linearize_visual<K>), reinterpret_cast<const void*>(&k_linearize_prior<K>),
+      reinterpret_cast<const void*>(&k_build_visual<K>), reinterpret_cast<const void*>(&k_linearize_visual<K>), reinterpret_cast<const void*>(&k_linearize_prior<K>),
       reinterpret_cast<const void*>(&k_linearize_inertial<K, 4>), reinterpret_cast<const void*>(&k_landmark<K, 2, 2>),
       reinterpret_cast<const void*>(&k_landmark<K, 4, 1>), reinterpret_cast<const void*>(&k_landmark_rows<K, 4>),
       reinterpret_cast<const void*>(&k_gram_pair<K, 1>), reinterpret_cast<const void*>(&k_gram_pair<K, 2>), reinterpret_cast<const void*>(&k_gram_pair<K, 4>),
@@ -1121,6 +1175,7 @@ static void warm_kernels(int device) {
       reinterpret_cast<const void*>(&k_dense_factor), reinterpret_cast<const void*>(&k_band_factor_wide), reinterpret_cast<const void*>(&k_band_factor<1>),
       reinterpret_cast<const void*>(&k_band_factor<2>), reinterpret_cast<const void*>(&k_band_factor_la<1, 3>), reinterpret_cast<const void*>(&k_band_factor_la<1, 4>),
       reinterpret_cast<const void*>(&k_band_backward), reinterpret_cast<const void*>(&k_band_backward_sb), reinterpret_cast<const void*>(&k_border_forward),
+      reinterpret_cast<const void*>(&k_border_forward2),
       reinterpret_cast<const void*>(&k_border_schur), reinterpret_cast<const void*>(&k_border_solve), reinterpret_cast<const void*>(&k_border_solve_reg<4>),
       reinterpret_cast<const void*>(&k_border_solve_reg<5>), reinterpret_cast<const void*>(&k_border_solve_reg<6>), reinterpret_cast<const void*>(&k_border_solve_reg<7>),
       reinterpret_cast<const void*>(&k_border_solve_reg<8>), reinterpret_cast<const void*>(&k_border_apply), reinterpret_cast<const void*>(&k_backsub_retract),
@@ -1152,9 +1207,12 @@ int set_func_attributes(hs_problem* p) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<6, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<6, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<6, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_visual<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_visual<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_visual<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_visual<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_forward), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_forward2), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_backward2), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_backward_sb), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_backward), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -1537,9 +1595,9 @@ static int linearize_impl(hs_problem* p, int type, int robustify, const hs_linea
     HIP_TRY(p->d_dbg.reserve(size_t(n) * REC));
     HIP_TRY(p->d_dbg_cost.reserve(n));
     if (k == 4)
-      k_linearize_visual<4><<<p->nb_vis, lin_block<4>(), lin_lds_bytes<4>(p), s>>>(T, p->d_dbg.p, p->d_v_dbgpos.p, robustify, nullptr, p->d_dbg_cost.p);
+      k_linearize_visual<4><<<(n + lin_block<4>() - 1) / lin_block<4>(), lin_block<4>(), lin_lds_bytes<4>(p), s>>>(T, p->d_dbg.p, p->d_v_dbgpos.p, robustify, nullptr, p->d_dbg_cost.p);
     else
-      k_linearize_visual<6><<<p->nb_vis, lin_block<6>(), lin_lds_bytes<6>(p), s>>>(T, p->d_dbg.p, p->d_v_dbgpos.p, robustify, nullptr, p->d_dbg_cost.p);
+      k_linearize_visual<6><<<(n + lin_block<6>() - 1) / lin_block<6>(), lin_block<6>(), lin_lds_bytes<6>(p), s>>>(T, p->d_dbg.p, p->d_v_dbgpos.p, robustify, nullptr, p->d_dbg_cost.p);
     HIP_TRY(hipGetLastError());
     std::vector<double> rec(size_t(n) * REC), cost(n);
     HIP_TRY(hipMemcpyAsync(rec.data(), p->d_dbg.p, rec.size() * 8, hipMemcpyDeviceToHost, s));
@@ -1629,7 +1687,7 @@ int hs_cost(hs_problem* p, double* cost) {
   if (rc) return rc;
   rc = reset_state(p, 0, 1e4);
   if (rc) return rc;
-  rc = p->k == 4 ? launch_linearize<4>(p) : launch_linearize<6>(p);
+  rc = p->k == 4 ? launch_linearize<4>(p, false, true) : launch_linearize<6>(p, false, true);
   if (rc) return rc;
   k_pack_exchange<<<1, kBlock, 0, p->stream>>>(p->T, 0);
   rc = exchange(p, p->T.xbuf + p->T.xo_cost, 1);
@@ -1711,8 +1769,8 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
   int rc = prepare(p);
   if (rc) return rc;
   const bool spec = speculative_solve(p);
-  const bool deferred = spec && !commit_inline(p) && !(p->T.debug_flags & 67108864);  // A/B switch 67108864: k_commit in every iteration
-  rc = reset_state(p, max_iterations, 1e4, spec ? (deferred ? 2 : 1) : 0);
+  const bool deferred = (spec || fused_visual_only(p)) && !commit_inline(p) && !(p->T.debug_flags & 67108864);  // A/B switch 67108864: k_commit in every iteration
+  rc = reset_state(p, max_iterations, 1e4, spec ? (deferred ? 2 : 1) : (deferred ? 4 : 0));
   if (rc) return rc;
   hipStream_t s = p->stream;
   const auto host_t3 = std::chrono::steady_clock::now();
@@ -1733,8 +1791,9 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
       rc = p->k == 4 ? launch_linearize<4>(p, true) : launch_linearize<6>(p, true);
       if (rc) return rc;
     }
-    if (stages) HIP_TRY(hipEventRecord(ev[4 * it + 1], s));
-    rc = p->k == 4 ? launch_build<4>(p) : launch_build<6>(p);
+    if (stages && !p->fused) HIP_TRY(hipEventRecord(ev[4 * it + 1], s));
+    hipEvent_t after_build = stages && p->fused ? ev[4 * it + 1] : nullptr;  // fused build: the linearise stage ends behind k_build_visual
+    rc = p->k == 4 ? launch_build<4>(p, after_build) : launch_build<6>(p, after_build);
     if (rc) return rc;
     if (stages) HIP_TRY(hipEventRecord(ev[4 * it + 2], s));
     rc = launch_factor(p);
@@ -1748,7 +1807,7 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
     if (stages || it + 1 == max_iterations) HIP_TRY(hipEventRecord(ev[4 * it + 4], s));
   }
   if (max_iterations == 0) {
-    rc = p->k == 4 ? launch_linearize<4>(p) : launch_linearize<6>(p);
+    rc = p->k == 4 ? launch_linearize<4>(p, false, true) : launch_linearize<6>(p, false, true);
     if (rc) return rc;
     k_pack_exchange<<<1, kBlock, 0, s>>>(p->T, 0);
     rc = exchange(p, p->T.xbuf + p->T.xo_cost, 1);

@@ -107,23 +107,33 @@ HSD double visual_cost(const Tables& T, const double* cps, const double* lms, in
   return 0.5 * loss_huber(s, type == 0 ? kHuberPixel : kHuberBearing, &sr);
 }
 
-/// Full linearisation of visual residual q (landmark-major index) in Ceres-local coordinates.
+/// Shared front half of the visual linearisation: spline pose + rotation Jacobian blocks, projection chain, loss corrector.
+///   A = sr * J_proj * R_sw (2 x 3) = d r / d p_w,   Mh = A * hat(p_w - p_wb) (2 x 3).
 template <int K>
-HSD void visual_linearize(const Tables& T, const double* cps, int q, bool robustify, VisualOut<K>* o, const double* lms = nullptr) {
+struct VisualCore {
+  double r[2];     // corrected residual rows
+  double A[6], Mh[6];
+  M3 G[K];         // d theta / d phi_j
+  double lam[K];   // cumulative basis weights
+  int first, lmid;
+  double cost;
+};
+
+template <int K>
+HSD void visual_core(const Tables& T, const double* cps, int q, bool robustify, const double* lms, VisualCore<K>* o) {
   const int info = T.v_info[q];
   const int type = info >> 16, camid = info & 0xffff;
   const double* cam = T.cam + kCamStride * camid;
-  const int first = T.v_first[q];
+  o->first = T.v_first[q];
   double u;
   segment_of(T.v_stamp[q], T.sp.t0, T.sp.dt, K, &u);
-  double lam[K], dl[1], ddl[1];
-  basis_weights<K>(T.basis, u, T.sp.inv_dt, lam, dl, ddl, 0);
+  double dl[1], ddl[1];
+  basis_weights<K>(T.basis, u, T.sp.inv_dt, o->lam, dl, ddl, 0);
   Quat qw;
   V3 pw;
-  M3 G[K];
-  spline_pose_jac<K>(cps + 8 * first, lam, &qw, &pw, G);
-  const int lmid = T.v_lm[q];
-  const double* l = (lms ? lms : T.lm) + 3 * lmid;
+  spline_pose_jac<K>(cps + 8 * o->first, o->lam, &qw, &pw, o->G);
+  o->lmid = T.v_lm[q];
+  const double* l = (lms ? lms : T.lm) + 3 * o->lmid;
   M3 R_sw;
   V3 v;
   const V3 ps = to_sensor(qw, pw, cam, V3{l[0], l[1], l[2]}, &R_sw, &v);
@@ -135,34 +145,77 @@ HSD void visual_linearize(const Tables& T, const double* cps, int q, bool robust
   if (!robustify) sr = 1.0;
   o->r[0] *= sr, o->r[1] *= sr;
   // A = sr * Jps * R_sw (2x3);  M = A * hat(v)
-  double A[6], Mh[6];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) A[3 * i + j] = sr * (Jps[3 * i] * R_sw.m[j] + Jps[3 * i + 1] * R_sw.m[3 + j] + Jps[3 * i + 2] * R_sw.m[6 + j]);
+    for (int j = 0; j < 3; ++j) o->A[3 * i + j] = sr * (Jps[3 * i] * R_sw.m[j] + Jps[3 * i + 1] * R_sw.m[3 + j] + Jps[3 * i + 2] * R_sw.m[6 + j]);
     // row * hat(v) = (row x v)^T ... (a^T hat(v))_j : a x v with sign: a^T hat(v) = (hat(v)^T a)^T = -(v x a)^T = (a x v)^T
-    const V3 a = V3{A[3 * i], A[3 * i + 1], A[3 * i + 2]};
+    const V3 a = V3{o->A[3 * i], o->A[3 * i + 1], o->A[3 * i + 2]};
     const V3 axv = cross(a, v);
-    Mh[3 * i] = axv.x, Mh[3 * i + 1] = axv.y, Mh[3 * i + 2] = axv.z;
+    o->Mh[3 * i] = axv.x, o->Mh[3 * i + 1] = axv.y, o->Mh[3 * i + 2] = axv.z;
   }
-  const bool lm_free = !T.lm_const[lmid];
+}
+
+/// Full linearisation of visual residual q (landmark-major index) in Ceres-local coordinates.
+template <int K>
+HSD void visual_linearize(const Tables& T, const double* cps, int q, bool robustify, VisualOut<K>* o, const double* lms = nullptr) {
+  VisualCore<K> c;
+  visual_core<K>(T, cps, q, robustify, lms, &c);
+  o->r[0] = c.r[0], o->r[1] = c.r[1], o->cost = c.cost;
+  const bool lm_free = !T.lm_const[c.lmid];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) o->Jl[i] = lm_free ? A[i] : 0.0;
+  for (int i = 0; i < 6; ++i) o->Jl[i] = lm_free ? c.A[i] : 0.0;
 #pragma unroll
   for (int j = 0; j < K; ++j) {
-    const bool frozen = T.cp_const[first + j] != 0;
-    const double Bj = lam[j] - (j + 1 < K ? lam[j + 1] : 0.0);
+    const bool frozen = T.cp_const[c.first + j] != 0;
+    const double Bj = c.lam[j] - (j + 1 < K ? c.lam[j + 1] : 0.0);
     const bool rot_free = !frozen && !T.sp.rot_const, tr_free = !frozen && !T.sp.trans_const;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const double jr = 2.0 * (Mh[3 * i] * G[j].m[c] + Mh[3 * i + 1] * G[j].m[3 + c] + Mh[3 * i + 2] * G[j].m[6 + c]);
-        o->Jp[i * 6 * K + 6 * j + c] = rot_free ? jr : 0.0;
-        o->Jp[i * 6 * K + 6 * j + 3 + c] = tr_free ? -Bj * A[3 * i + c] : 0.0;
+      for (int cc = 0; cc < 3; ++cc) {
+        const double jr = 2.0 * (c.Mh[3 * i] * c.G[j].m[cc] + c.Mh[3 * i + 1] * c.G[j].m[3 + cc] + c.Mh[3 * i + 2] * c.G[j].m[6 + cc]);
+        o->Jp[i * 6 * K + 6 * j + cc] = rot_free ? jr : 0.0;
+        o->Jp[i * 6 * K + 6 * j + 3 + cc] = tr_free ? -Bj * c.A[3 * i + cc] : 0.0;
       }
     }
   }
+}
+
+/// Compact record of a visual residual (the fused build keeps a workgroup's records in LDS, kernels_build.hpp). The translation columns of
+/// the state Jacobian are -B_j A and the landmark Jacobian is A itself, so the 2 x 6K state block is stored as its rotation half plus K
+/// scalars:   [r(2) | A(2 x 3) | B_eff(K) | J_rot row 0 (3K) | J_rot row 1 (3K)]  = 8 + 7K doubles   (full record: 8 + 12K).
+/// B_eff_j = 0 for a constant control point / constant translations, the rotation columns of such a point are stored as zeros. A is
+/// stored unmasked: a constant landmark's flag is applied by the consumers (its W, H_ll and b_l are zero, its translation columns are not).
+template <int K>
+constexpr int compact_record() { return 8 + 7 * K; }
+
+template <int K>
+HSD double visual_linearize_compact(const Tables& T, const double* cps, int q, bool robustify, const double* lms, double* rec, int* first) {
+  VisualCore<K> c;
+  visual_core<K>(T, cps, q, robustify, lms, &c);
+  *first = c.first;
+  *reinterpret_cast<double2*>(rec) = make_double2(c.r[0], c.r[1]);
+#pragma unroll
+  for (int i = 0; i < 6; i += 2) *reinterpret_cast<double2*>(rec + 2 + i) = make_double2(c.A[i], c.A[i + 1]);
+  double jrot[6 * K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const bool frozen = T.cp_const[c.first + j] != 0;
+    const double Bj = c.lam[j] - (j + 1 < K ? c.lam[j + 1] : 0.0);
+    const bool rot_free = !frozen && !T.sp.rot_const, tr_free = !frozen && !T.sp.trans_const;
+    rec[8 + j] = tr_free ? Bj : 0.0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        const double jr = 2.0 * (c.Mh[3 * i] * c.G[j].m[cc] + c.Mh[3 * i + 1] * c.G[j].m[3 + cc] + c.Mh[3 * i + 2] * c.G[j].m[6 + cc]);
+        jrot[i * 3 * K + 3 * j + cc] = rot_free ? jr : 0.0;
+      }
+  }
+#pragma unroll
+  for (int e = 0; e < 6 * K; e += 2) *reinterpret_cast<double2*>(rec + 8 + K + e) = make_double2(jrot[e], jrot[e + 1]);
+  return c.cost;
 }
 
 // ---- pose prior (manifold.cpp:12-61 + ManifoldMetric<SE3>: r = [Log(R_m^T R_ws) ; p_ws - p_m]) ------------------

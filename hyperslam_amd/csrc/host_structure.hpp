@@ -199,4 +199,32 @@ inline bool build_visual_structure(const VisualInput& in, VisualStructure* vs, s
   return true;
 }
 
+/// Work list of the fused build (kernels_build.hpp). Chunk = consecutive device landmarks of one landmark group (same first control point),
+/// at most L landmarks, about R residuals (a landmark with more than R residuals is a chunk of its own and takes several passes).
+/// ch_ptr[w] .. ch_ptr[w + 1]: landmarks of chunk w;  gw_ptr[c] .. gw_ptr[c + 1]: chunks of group c;  gw_cf[w]: group of chunk w.
+inline void build_chunks(const VisualStructure& vs, int n_cp, int R, int L, std::vector<int>* ch_ptr, std::vector<int>* gw_ptr, std::vector<int>* gw_cf) {
+  int n_obs = int(vs.lm_ptr.size()) - 1;
+  while (n_obs > 0 && vs.lm_ptr[n_obs] == vs.lm_ptr[n_obs - 1]) --n_obs;  // unobserved landmarks are last in device order
+  ch_ptr->clear(), gw_cf->clear();
+  gw_ptr->assign(n_cp + 1, 0);
+  for (int c = 0; c < n_cp; ++c) {
+    const int d0 = std::min(vs.cf_ptr[c], n_obs), d1 = std::min(vs.cf_ptr[c + 1], n_obs);
+    (*gw_ptr)[c] = int(gw_cf->size());
+    if (d1 <= d0) continue;
+    const int nres = vs.lm_ptr[d1] - vs.lm_ptr[d0], nl = d1 - d0;
+    const int nch = std::max((nl + L - 1) / L, (nres + R - 1) / R);
+    const int target = std::max((nres + nch - 1) / nch, 1);  // residuals per chunk, evenly
+    int d = d0;
+    while (d < d1) {
+      ch_ptr->push_back(d), gw_cf->push_back(c);
+      int cnt = 0, e = d;
+      while (e < d1 && e - d < L && (e == d || cnt + (vs.lm_ptr[e + 1] - vs.lm_ptr[e]) <= target)) cnt += vs.lm_ptr[e + 1] - vs.lm_ptr[e], ++e;
+      d = e;
+    }
+  }
+  (*gw_ptr)[n_cp] = int(gw_cf->size());
+  ch_ptr->push_back(n_obs);
+  gw_cf->push_back(0);
+}
+
 }  // namespace hs

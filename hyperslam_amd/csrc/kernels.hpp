@@ -19,6 +19,7 @@
 #include "kernels_linearize.hpp"
 #include "kernels_sensor.hpp"
 #include "kernels_schur.hpp"
+#include "kernels_build.hpp"
 #include "kernels_border.hpp"
 #include "kernels_factor.hpp"
 #include "kernels_backward.hpp"

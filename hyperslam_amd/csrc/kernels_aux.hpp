@@ -8,7 +8,7 @@ namespace hs {
 /// pose n x 7, velocity / acceleration n x 6 [angular (body) ; linear (world)], nullable.
 template <int K>
 __global__ void __launch_bounds__(kBlock) k_sample_trajectory(Tables T, int n, const double* stamps, double* pose, double* vel, double* acc) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+  HS_DYNAMIC_LDS(smem);
   double* cps = smem;
   stage_cps(T.cp, cps, 8 * T.sp.n_cp);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -43,7 +43,7 @@ HSD V3 pixel_to_bearing(const double* cam, double u, double v) {
 template <int K>
 __global__ void __launch_bounds__(kBlock) k_process_tracks(Tables T, double stamp, int n, const double* px0, const double* px1, double* b0o, double* b1o,
                                                            double* pwo) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+  HS_DYNAMIC_LDS(smem);
   double* cps = smem;
   stage_cps(T.cp, cps, 8 * T.sp.n_cp);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -64,7 +64,7 @@ constexpr int kBackBlocks = 10;  // block rows per slot: 60 of the 64 lanes carr
 
 template <int NS>  // slots per lane: bw <= 10 NS
 __global__ void __launch_bounds__(64) k_band_backward_w(Tables T, BackJob j0, BackJob j1, int m_mid) {
-  extern __shared__ __attribute__((aligned(16))) double xs[];  // solution of the own block rows (own order), flushed to HBM in bulk
+  HS_DYNAMIC_LDS(xs);  // solution of the own block rows (own order), flushed to HBM in bulk
   DevState* st = T.st;
   if (st->done) return;
   const BackJob J = blockIdx.x == 0 ? j0 : j1;

@@ -140,7 +140,7 @@ HSD void sb_wait(const Tables& T, const unsigned* flag) {
 }
 
 __global__ void __launch_bounds__(kCholThreads) k_band_backward_sb(Tables T, BackJob j0, BackJob j1, int m_mid, int n_jobs, int j_lo) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+  HS_DYNAMIC_LDS(smem);
   DevState* st = T.st;
   if (st->done) return;
   const int tid = threadIdx.x;

@@ -264,7 +264,7 @@ constexpr int kBorderLd = 6;    // LDS row stride of the pending rows (doubles):
 /// workgroup's bias points (T.bfwd_start: a bias point meets the pose rows of its own few seconds only).
 /// (local_rows = 0 on a shard of a distributed solve: the record table of one shard says nothing about the rows the other shards fill)
 __global__ void __launch_bounds__(kBlock) k_border_forward(Tables T, int j_lo, int local_rows) {  // blockDim = 64 x waves covering the 6 (bw - 1) pending rows (>= 128)
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+  HS_DYNAMIC_LDS(smem);
   if (T.st->done) return;
   const int tid = threadIdx.x;
   const int bw = T.bw, ncb = 6 * bw, nb = T.nb, np = T.np, n_blk = np / 6;
@@ -370,9 +370,11 @@ struct BfJob {
 constexpr int kBfFlagBase = 4 + 2 * 512;  // behind the super-block flags of the backward sweep (kernels_backward_sb.hpp)
 
 __global__ void __launch_bounds__(kBlock) k_border_forward2(Tables T, BfJob j0, BfJob j1, int m_junction, int j_lo, int local_rows, double* handover) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+  HS_DYNAMIC_LDS(smem);
   if (T.st->done) return;
-  const int tid = threadIdx.x, grp = blockIdx.x, far = blockIdx.y;
+  // The far-end (producer) jobs are the LOWER-numbered workgroups of the grid (x runs fastest in dispatch order): every consumer that spins
+  // on a hand-over flag is dispatched behind its producer, so the spin cannot starve the producers of workgroup slots.
+  const int tid = threadIdx.x, grp = blockIdx.x, far = 1 - int(blockIdx.y);
   const BfJob J = far ? j1 : j0;
   const int bw = T.bw, ncb = 6 * bw, nb = T.nb, np = T.np, w_mid = bw - 1;
   const int n_rows = J.n_rows, nz = 6 * (n_rows + (far ? w_mid : 0));  // rows of z: own rows (+ the middle rows the far end leaves updates on)
@@ -492,8 +494,11 @@ __global__ void __launch_bounds__(kBlock) k_border_forward2(Tables T, BfJob j0, 
 /// in chunks (coalesced, eight loads in flight per lane), the tile is accumulated from LDS.
 constexpr int kSchurTile = 16, kSchurRows = 128;
 
-/// (rows of Z above the first non-zero row of either column group are zero — j_lo / T.bfwd_start as in k_border_forward — and are skipped)
-__global__ void __launch_bounds__(kBlock) k_border_schur(Tables T, int j_lo, int local_rows) {
+/// (rows of Z above the first non-zero row of either column group are zero — j_lo / T.bfwd_start as in k_border_forward — and are skipped.
+///  row_cap: block rows from row_cap on are never skipped. Two-ended elimination: the far end eliminates from the last row upwards, so a
+///  column of Z fills every far and middle row ABOVE its first non-zero row of S_pb as well; only rows of the near end's top section,
+///  row_cap = the first middle block row, stay zero above it.)
+__global__ void __launch_bounds__(kBlock) k_border_schur(Tables T, int j_lo, int local_rows, int row_cap) {
   __shared__ double za[kSchurRows][kSchurTile + 1], zc[kSchurRows][kSchurTile + 1], ys[kSchurRows];
   if (T.st->done) return;
   const int nb = T.nb, np = T.np, tid = threadIdx.x;
@@ -510,7 +515,7 @@ __global__ void __launch_bounds__(kBlock) k_border_schur(Tables T, int j_lo, int
     if (ct * G + g < n_groups) sc = min(sc, T.bfwd_start[ct * G + g]);
   }
   if (!local_rows) sb = sc = 0;
-  const int row0 = 6 * min(max(j_lo, max(sb, sc)), np / 6);
+  const int row0 = 6 * min(min(max(j_lo, max(sb, sc)), row_cap), np / 6);
   double acc = 0.0, hacc = 0.0;
   // 2 x (kSchurRows x 16) operand entries + y per chunk: 16 + 1 loads per lane, issued together — and one chunk AHEAD of the products, so
   // that the memory round trip of chunk r + 1 runs under the 128 FMAs of chunk r (the slowest tile sets the kernel time: six chunks at
@@ -562,7 +567,7 @@ __global__ void __launch_bounds__(kBlock) k_border_schur(Tables T, int j_lo, int
 /// Dense Cholesky of the border Schur complement C (nb x nb, in LDS, augmented with h as an extra row so that the forward
 /// solve comes out of the elimination), column-oriented backward solve, x_b. One barrier per column in both sweeps.
 __global__ void __launch_bounds__(kBlock) k_border_solve(Tables T) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+  HS_DYNAMIC_LDS(smem);
   DevState* st = T.st;
   if (st->done) return;
   const int nb = T.nb, tid = threadIdx.x;
@@ -613,7 +618,7 @@ HSD double cj_or_zero(const double* col, int i, int n) { return col[i < n ? i : 
 
 template <int R>
 __global__ void __launch_bounds__(kBlock) k_border_solve_reg(Tables T) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+  HS_DYNAMIC_LDS(smem);
   DevState* st = T.st;
   if (st->done) return;
   const int nb = T.nb, tid = threadIdx.x, n1 = nb + 1;

@@ -15,6 +15,12 @@ constexpr int kBlock = 256;
 #endif
 HSD bool prof_enabled(int debug_flags, int bit) { return HS_PROFILE_HOOKS && (debug_flags & bit); }
 
+/// Dynamic LDS of a kernel (sized at launch). One spelling for every kernel; the CPU emulation harness of the tests (tests/emul/: the
+/// kernel sources compiled for the host with one thread per lane) supplies its own definition.
+#ifndef HS_DYNAMIC_LDS
+#define HS_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) double name[]
+#endif
+
 HSD double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -28,7 +28,7 @@ constexpr int kCholIo = 128;  // two extra waves that own all global traffic of 
 
 template <int TPT>  // tiles per thread: bw * bw <= TPT * kCholThreads
 __global__ void __launch_bounds__(kCholThreads + kCholIo) k_band_factor(Tables T) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+  HS_DYNAMIC_LDS(smem);
   DevState* st = T.st;
   if (st->done) return;
   const int tid = threadIdx.x;
@@ -324,7 +324,7 @@ constexpr int la_threads(int ncw) { return ncw == 3 ? 6 * 64 : 7 * 64; }
 
 template <int TPT, int NCW>  // one tile per compute lane; NCW compute waves
 __global__ void __launch_bounds__(la_threads(NCW)) k_band_factor_la(Tables T) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+  HS_DYNAMIC_LDS(smem);
   DevState* st = T.st;
   if (st->done) return;
   const FactorJob J = T.fj[blockIdx.x];
@@ -897,7 +897,7 @@ struct BackJob {
 };
 
 __global__ void __launch_bounds__(kCholThreads) k_band_backward2(Tables T, BackJob j0, BackJob j1, int m_mid) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+  HS_DYNAMIC_LDS(smem);
   DevState* st = T.st;
   if (st->done) return;
   const BackJob J = blockIdx.x == 0 ? j0 : j1;
@@ -1094,7 +1094,7 @@ __global__ void __launch_bounds__(kBlock) k_step_outputs(Tables T) {
 constexpr int kWideThreads = 512, kWideTiles = 2;
 
 __global__ void __launch_bounds__(kWideThreads) k_band_factor_wide(Tables T) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+  HS_DYNAMIC_LDS(smem);
   DevState* st = T.st;
   if (st->done) return;
   const int tid = threadIdx.x;
@@ -1258,7 +1258,7 @@ __global__ void __launch_bounds__(kWideThreads) k_band_factor_wide(Tables T) {
 /// The sweep stops above block row j_lo: the leading block rows of constant control points are decoupled with a zero right-hand side
 /// (k_factor_decoupled_rows), their part of the solution is zero (half of the block rows of a full sliding window).
 __global__ void __launch_bounds__(kCholThreads) k_band_backward(Tables T, int j_lo) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+  HS_DYNAMIC_LDS(smem);
   DevState* st = T.st;
   if (st->done) return;
   const int tid = threadIdx.x;
@@ -1390,7 +1390,7 @@ __host__ __device__ constexpr bool dense_factor_fits(int n, int bw) {
 /// Workgroups 1 .. n_decoupled (first wave only) write the decoupled leading block rows -n_decoupled .. -1 (factor_decoupled_row): their
 /// own launch in front of this kernel cost 6 us on the chain.
 __global__ void __launch_bounds__(kDenseThreads) k_dense_factor(Tables T, int n_decoupled) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+  HS_DYNAMIC_LDS(smem);
   DevState* st = T.st;
   if (st->done) return;
   const int tid = threadIdx.x;

@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(64 * (NC + 3)) k_band_factor_mfma(Tables T) {
   constexpr int W = G::W, LDX = G::LDX, PC = G::PC, PW = G::PW;
   static_assert(G::LDX >= G::W + 1, "column W of an X row carries y");
   static_assert(NC == 3, "wave roles below assume three compute waves");
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+  HS_DYNAMIC_LDS(smem);
   DevState* st = T.st;
   if (st->done) return;
   const MfmaJob J = T.mj[blockIdx.x];

@@ -22,7 +22,7 @@ template <int K>
 __global__ void __launch_bounds__(lin_block<K>()) k_linearize_visual(Tables T, double* out_rec, const int* out_pos, int robustify,
                                                                      double* cost_part, double* cost_each, const double* cp_src = nullptr,
                                                                      const double* lm_src = nullptr) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+  HS_DYNAMIC_LDS(smem);
   if (T.st->done) return;
   if (!out_rec) {
     out_rec = T.st->rec_sel ? T.v_rec : T.v_rec_alt;
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(lin_block<K>()) k_linearize_visual(Tables T, d
 
 template <int K>
 __global__ void __launch_bounds__(kBlock) k_linearize_prior(Tables T, double* out_rec, double* cost_part, double* cost_each) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+  HS_DYNAMIC_LDS(smem);
   if (T.st->done) return;
   double* cps = smem;
   stage_cps(T.cp, cps, 8 * T.sp.n_cp);
@@ -118,7 +118,7 @@ constexpr int kInertialBlock = 64;
 /// Inertial residual blocks (inertial.cpp:13-205): record = [r(6) | J_state(6 x 6K) | wg(KB) | wa(KB) | J_gravity(6 x 2)].
 template <int K, int KB>
 __global__ void __launch_bounds__(kInertialBlock) k_linearize_inertial(Tables T, double* out_rec, int robustify, double* cost_part, double* cost_each) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+  HS_DYNAMIC_LDS(smem);
   if (T.st->done) return;
   double* cps = smem;
   stage_cps(T.cp, cps, 8 * T.sp.n_cp);
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(kInertialBlock) k_linearize_inertial(Tables T,
 template <int K, int KB>
 __global__ void __launch_bounds__(kInertialBlock) k_cost_inertial(Tables T, const double* cp_src, const double* bg, const double* ba, const double* grav,
                                                          double* cost_part) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+  HS_DYNAMIC_LDS(smem);
   if (T.st->done) return;
   double* cps = smem;
   stage_cps(cp_src, cps, 8 * T.sp.n_cp);
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(kInertialBlock) k_cost_inertial(Tables T, cons
 /// Cost at the candidate point (residual-only branch).
 template <int K>
 __global__ void __launch_bounds__(kBlock) k_cost_visual(Tables T, const double* cp_src, const double* lm_src, double* cost_part) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+  HS_DYNAMIC_LDS(smem);
   if (T.st->done) return;
   double* cps = smem;
   stage_cps(cp_src, cps, 8 * T.sp.n_cp);
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(kBlock) k_cost_visual(Tables T, const double* 
 }
 template <int K>
 __global__ void __launch_bounds__(kBlock) k_cost_prior(Tables T, const double* cp_src, double* cost_part) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+  HS_DYNAMIC_LDS(smem);
   if (T.st->done) return;
   double* cps = smem;
   stage_cps(cp_src, cps, 8 * T.sp.n_cp);
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(kBlock) k_cost_prior(Tables T, const double* c
 template <int K, int KB>
 __global__ void __launch_bounds__(kBlock) k_cost_all(Tables T, const double* cp_src, const double* lm_src, const double* bg, const double* ba, const double* grav,
                                                      double* cost_part, int nb_vis, int nb_pri) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+  HS_DYNAMIC_LDS(smem);
   if (T.st->done) return;
   double* cps = smem;
   stage_cps(cp_src, cps, 8 * T.sp.n_cp);

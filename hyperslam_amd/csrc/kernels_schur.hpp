@@ -237,7 +237,7 @@ constexpr int kSegStage = 6144;  // doubles of record data staged in LDS per rou
 /// (body shared by k_seg_gram and the combined launch k_gram_pair; bid = workgroup index in the segment work list)
 template <int K>
 HSD void seg_gram_body(const Tables& T, const int bid) {
-  extern __shared__ __attribute__((aligned(16))) double stage[];  // kSegStage doubles: a contiguous run of records
+  HS_DYNAMIC_LDS(stage);  // kSegStage doubles: a contiguous run of records
   __shared__ __attribute__((aligned(16))) double red[kBlock * 12 + kBlock * 3];
   if (T.st->done) return;
   constexpr int NCA = 6 * K, RG = NCA / 3, CG = NCA / 4, TPS = RG * CG, NS = kBlock / TPS;  // 3x4 register tiles, NS record streams
@@ -301,7 +301,7 @@ HSD void seg_gram_body(const Tables& T, const int bid) {
         }
     }
   };
-  run(current_visual_records(T), T.v_seg_ptr[first], T.v_seg_ptr[first + 1], VREC, 2, 8);
+  if (!T.fused) run(current_visual_records(T), T.v_seg_ptr[first], T.v_seg_ptr[first + 1], VREC, 2, 8);  // (fused build: J_p'J_p of the visual factors comes with the chunk partials)
   if (T.n_pri) run(T.p_rec, T.p_seg_ptr[first], T.p_seg_ptr[first + 1], PREC, 6, 6);
   if (T.n_ine) run(T.i_rec, T.i_seg_ptr[first], T.i_seg_ptr[first + 1], 18 + 36 * K + 2 * T.kb, 6, 6);
   if (sprof) slog[2] = wall_clock64();
@@ -350,7 +350,7 @@ constexpr int kGroupBatch = 16;  // landmarks staged in LDS per round (host caps
 
 template <int NT>  // tiles per thread: NT == 1: two landmark streams of 128 lanes (bw <= 15); NT > 1: one stream, bw (bw + 1) / 2 <= NT * kBlock
 HSD void group_gram_body(const Tables& T, const int batch, const int bid) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+  HS_DYNAMIC_LDS(smem);
   __shared__ int m_ncp[kBlock], m_off[kBlock];
   if (T.st->done) return;
   // work list: workgroup w serves group cf = gw_cf[w] as split sp of nsp (splits proportional to the group's landmark count:
@@ -503,17 +503,18 @@ constexpr int kAsmThreads = 512, kAsmU = 8;  // lanes per scalar row, loads in f
 /// issued kAsmU at a time), the slices are combined through LDS in index order: fixed summation order, bit-reproducible.
 template <int K>
 __global__ void __launch_bounds__(kAsmThreads) k_assemble(Tables T) {
-  __shared__ double part[2][kAsmThreads];
+  __shared__ double part[3][kAsmThreads];
   if (T.st->done) return;
   constexpr int NCA = 6 * K;
   const int i = blockIdx.x, a = blockIdx.y, tid = threadIdx.x;
   const int bw = T.bw, ncb = 6 * bw, R = 6 * bw, ntile = bw * (bw + 1) / 2;
-  const size_t pstride = NCA * NCA + NCA, qstride = size_t(ntile) * 36 + R;
+  const size_t pstride = NCA * NCA + NCA, qstride = size_t(ntile) * 36 + (T.fused ? 3 : 1) * R;
   const int f0 = max(0, i - K + 1), f1 = min(i, T.n_seg - 1);
   const int c0 = max(0, i - bw + 1);
   const int nent = ncb + 2;  // band entries + [J'r | Y-hat y-hat] of this row
   const int nsl = max(1, kAsmThreads / nent), sl = tid / nent, c = tid % nent;
   double va = 0.0, vb = 0.0;  // J'J part / Schur part
+  double vp = 0.0;            // fused build: the chunk partials carry J_p'J_p inside their tiles; J_p'r (lane ncb) and diag J_p'J_p (lane a) ride along
   if (sl < nsl) {
     const int kk = c / 6, cc = c % 6;
     // segment partials: the workgroups of segments f0 .. f1 are contiguous in the work list; landmark-group partials: those of
@@ -521,7 +522,8 @@ __global__ void __launch_bounds__(kAsmThreads) k_assemble(Tables T) {
     // fetched in two rounds (all work-list entries, then all partial values: two memory round trips instead of one pair per
     // batch); the sums run in the same fixed order as a plain loop over p.
     const bool a_live = (c < ncb ? kk < K : c == ncb) && f1 >= f0;
-    const bool b_live = T.n_lm > 0 && (c < ncb || c == ncb + 1);
+    const bool x_live = T.fused && (c == ncb || c == a);  // lanes that also collect J_p'r / diag J_p'J_p of the chunk partials
+    const bool b_live = T.n_lm > 0 && (c < ncb || c == ncb + 1 || x_live);
     const int p_lo = a_live ? T.sw_ptr[f0] : 0, np_ = a_live ? T.sw_ptr[f1 + 1] - p_lo : 0;
     const int q_lo = b_live ? T.gw_ptr[c0] : 0, nq = b_live ? T.gw_ptr[i + 1] - q_lo : 0;
     // (plain macros, not lambdas: a by-reference closure kept these operands in scratch memory)
@@ -534,6 +536,7 @@ __global__ void __launch_bounds__(kAsmThreads) k_assemble(Tables T) {
        ? T.grpQ[(q_lo + (q)) * int(qstride) + \
                 (c > ncb ? ntile * 36 + 6 * (i - (cf)) + a : group_tile_index(i - (cf), i - (cf) + kk, bw) * 36 + 6 * a + cc)] \
        : 0.0)
+#define HS_GRP_EXTRA(q, cf) ((q) < nq ? T.grpQ[(q_lo + (q)) * int(qstride) + ntile * 36 + (c == ncb ? 1 : 2) * R + 6 * (i - (cf)) + a] : 0.0)
     int si[kAsmU], gi[2 * kAsmU];
 #pragma unroll
     for (int u = 0; u < kAsmU; ++u) si[u] = sl + u * nsl < np_ ? T.sw_seg[p_lo + sl + u * nsl] : 0;
@@ -543,7 +546,14 @@ __global__ void __launch_bounds__(kAsmThreads) k_assemble(Tables T) {
 #pragma unroll
     for (int u = 0; u < kAsmU; ++u) sv[u] = HS_SEG_VALUE(sl + u * nsl, si[u]);
 #pragma unroll
-    for (int u = 0; u < 2 * kAsmU; ++u) gv[u] = HS_GRP_VALUE(sl + u * nsl, gi[u]);
+    for (int u = 0; u < 2 * kAsmU; ++u) gv[u] = c == ncb && T.fused ? 0.0 : HS_GRP_VALUE(sl + u * nsl, gi[u]);
+    if (x_live) {
+      double xv[2 * kAsmU];
+#pragma unroll
+      for (int u = 0; u < 2 * kAsmU; ++u) xv[u] = HS_GRP_EXTRA(sl + u * nsl, gi[u]);
+#pragma unroll
+      for (int u = 0; u < 2 * kAsmU; ++u) vp += xv[u];
+    }
 #pragma unroll
     for (int u = 0; u < kAsmU; ++u) va += sv[u];
 #pragma unroll
@@ -566,25 +576,27 @@ __global__ void __launch_bounds__(kAsmThreads) k_assemble(Tables T) {
       for (int u = 0; u < kAsmU; ++u) {
         const int q = q0 + u * nsl;
         const int cf = q < nq ? T.gw_cf[q_lo + q] : 0;
-        v[u] = HS_GRP_VALUE(q, cf);
+        v[u] = c == ncb && T.fused ? 0.0 : HS_GRP_VALUE(q, cf);
+        if (x_live) vp += HS_GRP_EXTRA(q, cf);
       }
 #pragma unroll
       for (int u = 0; u < kAsmU; ++u) vb += v[u];
     }
 #undef HS_SEG_VALUE
 #undef HS_GRP_VALUE
+#undef HS_GRP_EXTRA
   }
-  part[0][tid] = va, part[1][tid] = vb;
+  part[0][tid] = va, part[1][tid] = vb, part[2][tid] = vp;
   __syncthreads();
   if (tid < nent) {
-    double sa = 0.0, sb = 0.0;
-    for (int q = 0; q < nsl; ++q) sa += part[0][q * nent + tid], sb += part[1][q * nent + tid];
+    double sa = 0.0, sb = 0.0, sx = 0.0;
+    for (int q = 0; q < nsl; ++q) sa += part[0][q * nent + tid], sb += part[1][q * nent + tid], sx += part[2][q * nent + tid];
     const int rho = 6 * i + a;
     if (tid < ncb) {
       T.xbuf[size_t(rho) * ncb + tid] = sa + sb;
-      if (tid == a) T.xbuf[T.xo_dj + rho] = sa;
+      if (tid == a) T.xbuf[T.xo_dj + rho] = sa + sx;  // diag J'J: segment partials (priors, inertial; records path: visual too) + chunk partials
     } else if (tid == ncb) {
-      T.xbuf[T.xo_g + rho] = sa;
+      T.xbuf[T.xo_g + rho] = sa + sx;
     } else {
       T.xbuf[T.xo_gs + rho] = sb;
     }
@@ -615,7 +627,7 @@ HSD void pack_exchange_body(const Tables& T, int reduce_here) {
   // Speculative solves linearise at the candidate: from their second iteration on the cost partials of the CURRENT point are not
   // recomputed — this shard's part of its cost is what decide_step took over when the candidate was accepted (st->local_cost). The
   // exchanged sum is then right on every shard, whichever way the shard linearises (a shard that holds the priors does it the plain way).
-  const bool kept_cost = st->spec && st->iteration > 0;
+  const bool kept_cost = (st->spec == 1 || st->spec == 2) && st->iteration > 0;
   double s = kept_cost ? (threadIdx.x == 0 ? st->local_cost : 0.0) : strided_sum(T.cost_part, T.n_cost_part);
   double gm = strided_max<24>(T.lm_gmax, T.n_obs_lm);  // one value per landmark: a single round of loads at 5 000 landmarks
   if (reduce_here) {

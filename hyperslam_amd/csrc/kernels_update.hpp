@@ -17,7 +17,7 @@ __global__ void __launch_bounds__(kBlock) k_backsub_retract(Tables T) {
   // Speculative solves with a deferred commit (DevState::spec == 2): the candidate accepted by the previous iteration is still only in
   // the candidate buffers — it is the current point here, and it is copied to x on the way (every element of x passes through this
   // kernel once per iteration), which replaces one k_commit launch per iteration. hs_solve launches k_commit once behind the last iteration.
-  const bool pend = T.st->spec == 2 && T.st->accepted;
+  const bool pend = (T.st->spec == 2 || T.st->spec == 4) && T.st->accepted;
   if (int(blockIdx.x) < T.n_lm_part) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int dl = blockIdx.x * (kBlock / 64) + wave;

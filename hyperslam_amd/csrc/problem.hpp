@@ -54,7 +54,8 @@ struct DevState {
   int scaling_ready;      // Jacobi scaling computed (iteration 0 only)
   int max_iterations;
   int chol_failed;
-  int spec;               // this solve linearises at the CANDIDATE point (visual-only single shard): see launch_update
+  int spec;               // 1, 2: this solve linearises at the CANDIDATE point (visual-only windows, record path): see launch_update; 2, 4: the accepted
+                          // candidate stays in the candidate buffers until the next k_backsub_retract copies it on its way (deferred commit)
   int rec_sel;            // which visual record buffer holds the linearisation of the current point (0: v_rec, 1: v_rec_alt)
   int rec_pending;        // the other buffer holds the linearisation of the candidate awaiting its decision
   hs_iteration records[kMaxIterations + 1];
@@ -213,6 +214,10 @@ struct Tables {
   double* grpQ;   // per k_group_gram workgroup: [upper 6x6 tiles of -sum Yh Yh' | -sum Yh yh (6 bw)]
   double* xpart;  // per-split partial copies of the H_pb part of the exchange buffer (stride x_count1); scratch for timestamps
   int xo_g, xo_gs, xo_dj, xo_pb, xo_bb, xo_gb, xo_cost, xo_gmax, xo_dec, x_count1;
+  // fused build of the visual factors (kernels_build.hpp): chunk w = device landmarks [ch_ptr[w], ch_ptr[w + 1]) of one landmark group;
+  // gw_ptr / gw_cf then list the chunks of a group and grpQ holds one partial [tiles | -Yh yh | J_p'r | diag J_p'J_p] per chunk
+  int fused, n_chunk;
+  const int* ch_ptr;
   int rank, world;
   int debug_flags;  // HS_DEBUG_FLAGS env (timing experiments; 0 in production)
   DevState* st;

@@ -1,0 +1,173 @@
+// build_harness.cpp — TEST INFRASTRUCTURE (tests/test_emulated_build.py): the fused build of the visual factors, compiled FROM THE PRODUCT'S
+// KERNEL SOURCES for the host (tests/emul/hip/hip_runtime.h: one std::thread per lane) and run on a window a Python test hands over.
+//   k_build_visual<K> -> k_assemble<K> -> k_finalize_reduced     (hyperslam_amd/csrc/kernels_build.hpp, kernels_schur.hpp)
+// with the tables laid out the way prepare() of capi.hip lays them out (host_structure.hpp is shared). Output: the scaled, damped band
+// system, its right-hand side, the cost and the Y-hat rows — compared by the test with the oracle's reduced system of the same window.
+// Usage: build_harness <window.bin> <out.bin>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "hip/hip_runtime.h"
+
+thread_local dim3 threadIdx;
+dim3 blockIdx, blockDim, gridDim;
+
+#include "../../hyperslam_amd/csrc/host_structure.hpp"
+#include "../../hyperslam_amd/csrc/kernels_common.hpp"
+#include "../../hyperslam_amd/csrc/kernels_linearize.hpp"
+#include "../../hyperslam_amd/csrc/kernels_schur.hpp"
+#include "../../hyperslam_amd/csrc/kernels_build.hpp"
+#include "../../hyperslam_amd/csrc/kernels_update.hpp"
+
+namespace hs {
+HSD void finalize_border_body(const Tables&, int, int, int) {}  // (no border unknowns in the harness: never reached)
+}  // namespace hs
+
+using namespace hs;
+
+struct Reader {
+  FILE* f;
+  template <class T>
+  std::vector<T> vec(size_t n) {
+    std::vector<T> v(n);
+    if (n && fread(v.data(), sizeof(T), n, f) != n) {
+      fprintf(stderr, "short read\n");
+      exit(2);
+    }
+    return v;
+  }
+};
+
+template <int K>
+static void run(Tables& T, int nb_vis, int R, int L, size_t lds) {
+  hs_emul::launch(dim3(nb_vis), dim3(kBlock), lds, [&] { k_build_visual<K>(T, R, L, 1); });
+  hs_emul::launch(dim3(T.sp.n_cp, 6), dim3(kAsmThreads), 0, [&] { k_assemble<K>(T); });
+  hs_emul::launch(dim3(T.sp.n_cp + 1), dim3(kBlock), 0, [&] { k_finalize_reduced(T, 1); });
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) return 1;
+  Reader rd{fopen(argv[1], "rb")};
+  if (!rd.f) return 1;
+  const std::vector<int> hdr = rd.vec<int>(12);
+  const int k = hdr[0], n_cp = hdr[1], n_lm = hdr[2], n_px = hdr[3], n_br = hdr[4], n_cam = hdr[5], rot_c = hdr[6], tr_c = hdr[7];
+  int R = hdr[8], L = hdr[9];
+  const int scaling_ready = hdr[10];
+  const std::vector<double> par = rd.vec<double>(3);
+  const double t0 = par[0], dt = par[1], radius = par[2];
+  std::vector<double> cp = rd.vec<double>(size_t(8) * n_cp);
+  const std::vector<int> cpc_i = rd.vec<int>(n_cp);
+  std::vector<double> cam = rd.vec<double>(size_t(16) * n_cam);
+  const std::vector<double> lm_tab = rd.vec<double>(size_t(3) * n_lm);
+  const std::vector<int> lmc_i = rd.vec<int>(n_lm);
+  const std::vector<double> px_stamp = rd.vec<double>(n_px), px_meas = rd.vec<double>(size_t(2) * n_px);
+  const std::vector<int> px_lm = rd.vec<int>(n_px), px_cam = rd.vec<int>(n_px);
+  const std::vector<double> br_stamp = rd.vec<double>(n_br), br_meas = rd.vec<double>(size_t(3) * n_br);
+  const std::vector<int> br_lm = rd.vec<int>(n_br), br_cam = rd.vec<int>(n_br);
+  const std::vector<double> lm_scale_in = rd.vec<double>(scaling_ready ? size_t(3) * n_lm : 0);  // table order
+  const std::vector<double> scale_p_in = rd.vec<double>(scaling_ready ? size_t(6) * n_cp : 0);
+  fclose(rd.f);
+
+  VisualStructure vs;
+  std::string err;
+  VisualInput in = {k, n_cp, n_lm, t0, dt, n_px, n_br, px_stamp.data(), br_stamp.data(), px_lm.data(), br_lm.data()};
+  if (!build_visual_structure(in, &vs, &err)) {
+    fprintf(stderr, "%s\n", err.c_str());
+    return 3;
+  }
+  const int n_vis = n_px + n_br, bw = vs.bw, np = 6 * n_cp, ncb = 6 * bw, ntile = bw * (bw + 1) / 2;
+  if (!R) R = k == 4 ? 256 : 192;
+  if (!L) L = k == 4 ? 24 : 18;
+  while (size_t(build_lds_layout(k, bw, R, L).total_doubles) * 8 > 156 * 1024 && L > 4) --L;
+  std::vector<int> ch_ptr, gw_ptr, gw_cf;
+  build_chunks(vs, n_cp, R, L, &ch_ptr, &gw_ptr, &gw_cf);
+  const int n_chunk = int(ch_ptr.size()) - 1;
+
+  // device-order tables (prepare() of capi.hip)
+  std::vector<double> lm_dev(size_t(3) * n_lm), lm_scale(size_t(3) * std::max(n_lm, 1), 1.0);
+  std::vector<uint8_t> lmc_dev(n_lm), cpc(n_cp);
+  for (int i = 0; i < n_cp; ++i) cpc[i] = uint8_t(cpc_i[i]);
+  for (int d = 0; d < n_lm; ++d) {
+    const int t = vs.table_of_dev[d];
+    for (int c = 0; c < 3; ++c) lm_dev[3 * d + c] = lm_tab[3 * t + c];
+    if (scaling_ready)
+      for (int c = 0; c < 3; ++c) lm_scale[3 * d + c] = lm_scale_in[3 * t + c];
+    lmc_dev[d] = uint8_t(lmc_i[t]);
+  }
+  std::vector<double> v_stamp(n_vis), v_meas(size_t(3) * n_vis);
+  std::vector<int> v_info(n_vis);
+  for (int q = 0; q < n_vis; ++q) {
+    const int ti = vs.table_idx[q];
+    if (vs.table_type[q] == HS_PIXEL) {
+      v_stamp[q] = px_stamp[ti], v_meas[3 * q] = px_meas[2 * ti], v_meas[3 * q + 1] = px_meas[2 * ti + 1], v_meas[3 * q + 2] = 0.0;
+      v_info[q] = px_cam[ti];
+    } else {
+      v_stamp[q] = br_stamp[ti];
+      for (int c = 0; c < 3; ++c) v_meas[3 * q + c] = br_meas[3 * ti + c];
+      v_info[q] = br_cam[ti] | (1 << 16);
+    }
+  }
+  const size_t nl = size_t(std::max(n_lm, 1));
+  std::vector<double> lm_L(6 * nl), lm_yhat(3 * nl), lm_sb(3 * nl), lm_D2(3 * nl), lm_gmax(nl), Y(size_t(vs.y_total) + 1);
+  const int nb_vis = std::max((n_vis + kBlock - 1) / kBlock, n_chunk);
+  std::vector<double> cost_part(nb_vis + 1, -1.0), grpQ(size_t(n_chunk) * (size_t(ntile) * 36 + 3 * ncb) + 1, 1e300), segP(1);
+  std::vector<int> sw_ptr(n_cp - k + 2, 0), sw_seg(1, 0);
+  const int x_count1 = np * (ncb + 3) + 2;
+  std::vector<double> xbuf(size_t(x_count1) + 8, 1e300), scale_p(np, 1.0), Sb(size_t(np) * ncb, 0.0), g_s(np), g_full(np), D2p(np), gabs(np + 1);
+  if (scaling_ready) scale_p = scale_p_in;
+  DevState st;
+  std::memset(&st, 0, sizeof(st));
+  st.radius = radius, st.decrease_factor = 2.0, st.max_iterations = 1, st.scaling_ready = scaling_ready;
+
+  Tables T;
+  std::memset(&T, 0, sizeof(T));
+  T.sp = Spline{k, n_cp, t0, dt, 1.0 / dt, rot_c, tr_c};
+  T.basis = make_basis_coef(k);
+  T.cp = cp.data(), T.cp_cand = cp.data(), T.cp_const = cpc.data(), T.cam = cam.data();
+  T.n_lm = n_lm, T.lm = lm_dev.data(), T.lm_cand = lm_dev.data(), T.lm_const = lmc_dev.data();
+  T.lm_ptr = vs.lm_ptr.data(), T.lm_cfirst = vs.lm_cfirst.data(), T.lm_ncp = vs.lm_ncp.data(), T.lm_yoff = vs.lm_yoff.data(), T.cf_ptr = vs.cf_ptr.data();
+  T.lm_scale = lm_scale.data(), T.lm_L = lm_L.data(), T.lm_yhat = lm_yhat.data(), T.lm_sb = lm_sb.data(), T.lm_D2 = lm_D2.data();
+  T.lm_gmax = lm_gmax.data(), T.Y = Y.data();
+  {
+    int n_obs = n_lm;
+    while (n_obs > 0 && vs.lm_ptr[n_obs] == vs.lm_ptr[n_obs - 1]) --n_obs;
+    T.n_obs_lm = n_obs;
+  }
+  T.n_vis = n_vis, T.v_stamp = v_stamp.data(), T.v_meas = v_meas.data(), T.v_lm = vs.lm_dev.data(), T.v_info = v_info.data();
+  T.v_first = vs.first.data(), T.v_pos = vs.pos.data(), T.v_seg_ptr = vs.seg_ptr.data();
+  T.n_seg = n_cp - k + 1, T.bw = bw, T.np = np;
+  T.scale_p = scale_p.data(), T.Sb = Sb.data(), T.g_s = g_s.data(), T.g_full = g_full.data(), T.D2p = D2p.data(), T.gabs = gabs.data();
+  T.cost_part = cost_part.data(), T.n_cost_part = nb_vis;
+  T.xbuf = xbuf.data(), T.segP = segP.data(), T.grpQ = grpQ.data();
+  T.gw_ptr = gw_ptr.data(), T.gw_cf = gw_cf.data(), T.sw_ptr = sw_ptr.data(), T.sw_seg = sw_seg.data();
+  T.xo_g = np * ncb, T.xo_gs = T.xo_g + np, T.xo_dj = T.xo_gs + np, T.xo_pb = T.xo_dj + np, T.xo_bb = T.xo_pb, T.xo_gb = T.xo_bb, T.xo_cost = T.xo_gb, T.xo_gmax = T.xo_cost + 1;
+  T.x_count1 = x_count1, T.xo_dec = x_count1;
+  T.fused = 1, T.n_chunk = n_chunk, T.ch_ptr = ch_ptr.data();
+  T.rank = 0, T.world = 1, T.st = &st;
+
+  const size_t lds = size_t(build_lds_layout(k, bw, R, L).total_doubles) * 8;
+  if (k == 4)
+    run<4>(T, nb_vis, R, L, lds);
+  else if (k == 6)
+    run<6>(T, nb_vis, R, L, lds);
+  else
+    return 4;
+
+  FILE* out = fopen(argv[2], "wb");
+  const int ohdr[8] = {bw, np, n_chunk, R, L, vs.y_total, int(lds), 0};
+  fwrite(ohdr, sizeof(int), 8, out);
+  const double cost = st.cost;
+  fwrite(&cost, 8, 1, out);
+  fwrite(Sb.data(), 8, Sb.size(), out);
+  fwrite(g_s.data(), 8, g_s.size(), out);
+  fwrite(Y.data(), 8, size_t(vs.y_total), out);
+  // landmark scaling back in table order, pose scaling (so that a second call can run with the scaling fixed)
+  std::vector<double> ls_tab(size_t(3) * n_lm);
+  for (int d = 0; d < n_lm; ++d)
+    for (int c = 0; c < 3; ++c) ls_tab[3 * vs.table_of_dev[d] + c] = lm_scale[3 * d + c];
+  fwrite(ls_tab.data(), 8, ls_tab.size(), out);
+  fwrite(scale_p.data(), 8, scale_p.size(), out);
+  fclose(out);
+  return 0;
+}

@@ -1,0 +1,165 @@
+// hip/hip_runtime.h — TEST INFRASTRUCTURE: a CPU stand-in for the HIP device environment, written for this repository's tests.
+//
+// tests/emul/ compiles the product's kernel SOURCES (hyperslam_amd/csrc/kernels_*.hpp) for the host with g++ and runs a workgroup as
+// one std::thread per lane: __syncthreads() is a barrier over the workgroup's live threads, the wave intrinsics the kernels use
+// (__shfl_xor, __ballot, readlane) exchange values through a per-wave buffer. That makes the index arithmetic, LDS layouts and
+// summation orders of a kernel checkable against the oracle in the `-m "not gpu"` suite, before a GPU is involved. It says nothing about
+// timing, occupancy or memory-model subtleties (x86 is sequentially consistent enough for barrier-synchronised code); the `-m gpu` tests
+// remain the parity tests proper. Nothing in the product includes or links this directory.
+#pragma once
+#include <cmath>
+#include <condition_variable>
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+#define HS_DYNAMIC_LDS(name) double* name = hs_emul::dynamic_lds()
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
+};
+struct double2 {
+  double x, y;
+};
+inline double2 make_double2(double a, double b) { return double2{a, b}; }
+
+namespace hs_emul {
+
+/// Barrier over the threads that have not left the kernel yet (a wave that returned early does not take part on the GPU either).
+class LiveBarrier {
+ public:
+  void reset(int n) { live_ = n, waiting_ = 0, phase_ = 0; }
+  void arrive_and_wait() {
+    std::unique_lock<std::mutex> lk(m_);
+    const unsigned ph = phase_;
+    if (++waiting_ == live_) {
+      waiting_ = 0, ++phase_;
+      cv_.notify_all();
+    } else {
+      cv_.wait(lk, [&] { return phase_ != ph; });
+    }
+  }
+  void leave() {
+    std::unique_lock<std::mutex> lk(m_);
+    --live_;
+    if (live_ > 0 && waiting_ == live_) {
+      waiting_ = 0, ++phase_;
+      cv_.notify_all();
+    }
+  }
+
+ private:
+  std::mutex m_;
+  std::condition_variable cv_;
+  int live_ = 0, waiting_ = 0;
+  unsigned phase_ = 0;
+};
+
+struct Block {
+  LiveBarrier barrier;
+  LiveBarrier wave_barrier[16];
+  unsigned long long wave_bits[16][64];  // value exchange of the wave intrinsics (doubles travel as bits)
+  std::vector<double> lds;
+};
+inline Block& block() {
+  static Block b;
+  return b;
+}
+inline double* dynamic_lds() { return block().lds.data(); }
+
+}  // namespace hs_emul
+
+extern thread_local dim3 threadIdx;
+extern dim3 blockIdx, blockDim, gridDim;
+
+inline void __syncthreads() { hs_emul::block().barrier.arrive_and_wait(); }
+
+namespace hs_emul {
+template <class T>
+inline T wave_exchange(T v, int src_lane) {
+  static_assert(sizeof(T) <= 8, "value exchange through 64-bit slots");
+  Block& b = block();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned long long bits = 0;
+  std::memcpy(&bits, &v, sizeof(T));
+  b.wave_bits[wave][lane] = bits;
+  b.wave_barrier[wave].arrive_and_wait();
+  const unsigned long long got = b.wave_bits[wave][src_lane & 63];
+  b.wave_barrier[wave].arrive_and_wait();
+  T out;
+  std::memcpy(&out, &got, sizeof(T));
+  return out;
+}
+}  // namespace hs_emul
+
+template <class T>
+inline T __shfl_xor(T v, int mask) { return hs_emul::wave_exchange(v, (threadIdx.x & 63) ^ mask); }
+inline int __builtin_amdgcn_readlane(int v, int lane) { return hs_emul::wave_exchange(v, lane); }
+inline unsigned long long __ballot(bool pred) {
+  hs_emul::Block& b = hs_emul::block();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  b.wave_bits[wave][lane] = pred ? 1ull : 0ull;
+  b.wave_barrier[wave].arrive_and_wait();
+  unsigned long long m = 0;
+  const int n_lanes = int(blockDim.x) - 64 * wave < 64 ? int(blockDim.x) - 64 * wave : 64;
+  for (int l = 0; l < n_lanes; ++l) m |= b.wave_bits[wave][l] << l;
+  b.wave_barrier[wave].arrive_and_wait();
+  return m;
+}
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline void __builtin_amdgcn_wave_barrier() {}
+inline double __builtin_amdgcn_rsq(double d) { return 1.0 / std::sqrt(d); }
+inline long long wall_clock64() { return 0; }
+inline double rsqrt(double d) { return 1.0 / std::sqrt(d); }
+
+template <class T>
+inline T min(T a, T b) { return b < a ? b : a; }
+template <class T>
+inline T max(T a, T b) { return a < b ? b : a; }
+using std::atan2;
+using std::fabs;
+using std::fma;
+using std::fmax;
+using std::fmin;
+using std::isfinite;
+using std::sqrt;
+
+namespace hs_emul {
+
+/// Runs `kernel` for every workgroup of the grid, one after the other; one thread per lane.
+inline void launch(dim3 grid, dim3 block_dim, size_t lds_bytes, const std::function<void()>& kernel) {
+  Block& b = block();
+  b.lds.assign(lds_bytes / 8 + 64, 0.0);
+  gridDim = grid, blockDim = block_dim;
+  const int n = int(block_dim.x);
+  for (unsigned by = 0; by < grid.y; ++by)
+    for (unsigned bx = 0; bx < grid.x; ++bx) {
+      blockIdx = dim3(bx, by, 0);
+      b.barrier.reset(n);
+      for (int w = 0; w < (n + 63) / 64; ++w) b.wave_barrier[w].reset(n - 64 * w < 64 ? n - 64 * w : 64);
+      std::vector<std::thread> threads;
+      threads.reserve(n);
+      for (int t = 0; t < n; ++t)
+        threads.emplace_back([&, t] {
+          threadIdx = dim3(unsigned(t), 0, 0);
+          kernel();
+          b.wave_barrier[t >> 6].leave();
+          b.barrier.leave();
+        });
+      for (std::thread& th : threads) th.join();
+    }
+}
+
+}  // namespace hs_emul

@@ -1,0 +1,122 @@
+"""CPU tests (no GPU): the fused build kernel — linearisation, landmark elimination and both Gram terms in one pass
+(hyperslam_amd/csrc/kernels_build.hpp) followed by k_assemble and k_finalize_reduced — compiled from the product's kernel SOURCES for the
+host (tests/emul/: one thread per lane, barriers and wave exchanges emulated) and compared with the oracle's reduced normal equations of
+the same window. This pins the kernel's index arithmetic, LDS layout and summation structure before a GPU is involved; the `-m gpu`
+tests run the same comparison on the real device through the C ABI."""
+import os
+import struct
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import hyperslam_amd as ha
+from hyperslam_amd import synthetic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMUL = os.path.join(ROOT, "tests", "emul")
+
+
+@pytest.fixture(scope="session")
+def harness():
+    exe = os.path.join(EMUL, "build_harness")
+    srcs = [os.path.join(EMUL, "build_harness.cpp"), os.path.join(EMUL, "hip", "hip_runtime.h")]
+    csrc = os.path.join(ROOT, "hyperslam_amd", "csrc")
+    srcs += [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp")]
+    if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in srcs):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-I", EMUL, "-o", exe, os.path.join(EMUL, "build_harness.cpp")])
+    return exe
+
+
+def _pack_cameras(w):
+    n = len(w.cam_T_bs)
+    cam = np.zeros((n, 16))
+    cam[:, :7], cam[:, 7:11], cam[:, 11:15] = w.cam_T_bs, w.cam_intrinsics, w.cam_distortion
+    return cam
+
+
+def run_emulated_build(exe, w, radius=1e4, R=0, L=0, scaling=None):
+    """Returns dict(S, g, cost, bw, n_chunk, Y, lm_scale, scale_p) of the emulated fused build on window `w`."""
+    n_cp, n_lm = w.n_cp, len(w.landmarks)
+    n_px, n_br = len(w.pixel_stamps), len(w.bearing_stamps)
+    f64, i32 = np.float64, np.int32
+    cpc = np.zeros(n_cp, i32) if w.cp_constant is None else np.asarray(w.cp_constant, i32)
+    lmc = np.zeros(n_lm, i32) if w.landmark_constant is None else np.asarray(w.landmark_constant, i32)
+    hdr = np.array([w.order, n_cp, n_lm, n_px, n_br, len(w.cam_T_bs), int(w.rotation_constant), int(w.translation_constant), R, L,
+                    1 if scaling is not None else 0, 0], i32)
+    parts = [hdr, np.array([w.t0, w.dt, radius], f64), np.asarray(w.control_points, f64), cpc, _pack_cameras(w), np.asarray(w.landmarks, f64), lmc,
+             np.asarray(w.pixel_stamps, f64), np.asarray(w.pixels, f64), np.asarray(w.pixel_landmark, i32), np.asarray(w.pixel_camera, i32),
+             np.asarray(w.bearing_stamps, f64), np.asarray(w.bearings, f64), np.asarray(w.bearing_landmark, i32), np.asarray(w.bearing_camera, i32)]
+    if scaling is not None:
+        parts += [np.asarray(scaling[0], f64), np.asarray(scaling[1], f64)]
+    with tempfile.TemporaryDirectory() as tmp:
+        fin, fout = os.path.join(tmp, "w.bin"), os.path.join(tmp, "o.bin")
+        with open(fin, "wb") as f:
+            for a in parts:
+                f.write(np.ascontiguousarray(a).tobytes())
+        subprocess.check_call([exe, fin, fout], timeout=600)
+        raw = open(fout, "rb").read()
+    bw, np_, n_chunk, R_, L_, y_total, lds, _ = struct.unpack("8i", raw[:32])
+    off = 32
+    cost = struct.unpack("d", raw[off:off + 8])[0]
+    off += 8
+    ncb = 6 * bw
+
+    def take(n):
+        nonlocal off
+        a = np.frombuffer(raw, np.float64, n, off).copy()
+        off += 8 * n
+        return a
+
+    Sb, g, Y = take(np_ * ncb).reshape(np_, ncb), take(np_), take(y_total)
+    lm_scale, scale_p = take(3 * n_lm), take(np_)
+    S = np.zeros((np_, np_))
+    for rho in range(np_):
+        c0 = 6 * (rho // 6)
+        for c in range(min(ncb, np_ - c0)):
+            if c0 + c >= rho:
+                S[rho, c0 + c] = S[c0 + c, rho] = Sb[rho, c]
+    return dict(S=S, g=g, cost=cost, bw=bw, n_chunk=n_chunk, R=R_, L=L_, Y=Y, lm_scale=lm_scale, scale_p=scale_p, lds=lds)
+
+
+def _check(exe, oracle, w, radius=1e4, tol=1e-9, **kw):
+    out = run_emulated_build(exe, w, radius, **kw)
+    with ha.Problem(w, lib=oracle) as p:
+        S, g = p.reduced_system(radius)
+        cost = p.cost()
+    n = out["S"].shape[0]
+    scale = np.abs(S[:n, :n]).max()
+    assert np.abs(out["S"] - S[:n, :n]).max() <= tol * scale, (np.abs(out["S"] - S[:n, :n]).max() / scale, out["n_chunk"])
+    assert np.abs(out["g"] - g[:n]).max() <= tol * max(1.0, np.abs(g).max())
+    assert abs(out["cost"] - cost) <= 1e-11 * cost
+    return out
+
+
+@pytest.mark.parametrize("order,bearing", [(4, False), (4, True), (6, False)])
+def test_emulated_fused_build_matches_oracle(harness, oracle, order, bearing):
+    w = synthetic.small_visual(order=order, n_cp=14 if order == 4 else 16, n_landmarks=40, obs_pairs=3, bearing=bearing)
+    out = _check(harness, oracle, w)
+    assert out["n_chunk"] >= 2
+
+
+def test_emulated_fused_build_small_chunks_and_passes(harness, oracle):
+    """Forced tiny geometry: chunks of <= 3 landmarks, 32 records per pass — landmarks with 40 residuals take two passes (the W rows and
+    H_ll / b_l accumulate across passes in LDS, the J_p'J_p tiles in registers)."""
+    w = synthetic.small_visual(order=4, n_cp=16, n_landmarks=12, obs_pairs=20, span=0.6)
+    out = _check(harness, oracle, w, R=32, L=3)
+    assert out["R"] == 32 and out["n_chunk"] >= 4
+
+
+def test_emulated_fused_build_constants_and_radius(harness, oracle):
+    """Constant control points (zero columns), constant landmarks (no elimination, translation columns intact), another radius."""
+    w = synthetic.small_visual(order=4, n_cp=14, n_landmarks=30, obs_pairs=3)
+    w.cp_constant = np.r_[np.ones(4, np.uint8), np.zeros(10, np.uint8)]
+    w.landmark_constant = (np.arange(30) % 5 == 0).astype(np.uint8)
+    _check(harness, oracle, w, radius=37.0)
+
+
+def test_emulated_fused_build_is_reproducible(harness):
+    w = synthetic.small_visual(order=4, n_cp=14, n_landmarks=40, obs_pairs=3)
+    a, b = run_emulated_build(harness, w), run_emulated_build(harness, w)
+    assert np.array_equal(a["S"], b["S"]) and np.array_equal(a["g"], b["g"]) and np.array_equal(a["Y"], b["Y"]) and a["cost"] == b["cost"]

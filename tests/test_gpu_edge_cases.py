@@ -455,12 +455,14 @@ def perturbed_visual(seed, lm_noise, cp_noise, order=4, bearing=False, n_lm=120)
                                                                      (3, 2.0, 0.3, 6, False, 120), (1, 0.5, 0.6, 4, True, 120),
                                                                      (1, 0.5, 0.3, 4, False, 1500), (4, 0.5, 0.3, 4, False, 1500)])
 def test_rejected_steps_on_visual_windows(seed, lm_noise, cp_noise, order, bearing, n_lm, hip, oracle, monkeypatch):
-    """Visual-only solves linearise at the candidate point and keep the records of the current point across a rejected step
-    (capi.hip: speculative_solve); above 4096 state scalars (the 1500-landmark cases) the accepted candidate is copied to x by the next
-    iteration's k_backsub_retract instead of a k_commit launch. Starts far enough from the optimum that steps are rejected: the accept /
+    """Rejected steps on visual-only windows, on both build paths of the library. Fused build (default): the current point is linearised,
+    eliminated and accumulated by k_build_visual at the top of every iteration, with the radius the decision left behind. Record path
+    (HS_BUILD_PATH=records): solves linearise at the candidate point and keep the records of the current point across a rejected step
+    (capi.hip: speculative_solve). On both, above 4096 state scalars (the 1500-landmark cases) the accepted candidate is copied to x by the
+    next iteration's k_backsub_retract instead of a k_commit launch. Starts far enough from the optimum that steps are rejected: the accept /
     reject sequence, every recorded quantity and the final state must match the oracle's (which linearises the current point at the top of
-    every iteration), the path with a commit per iteration (HS_DEBUG_FLAGS=67108864) and the one that does everything the oracle's way
-    on the device (1073741824)."""
+    every iteration), the path with a commit per iteration (HS_DEBUG_FLAGS=67108864) and, on the record path, the one that does
+    everything the oracle's way on the device (1073741824)."""
     w = perturbed_visual(seed, lm_noise, cp_noise, order, bearing, n_lm)
     n_it = 6
     with ha.Problem(w, lib=oracle) as c:
@@ -469,11 +471,13 @@ def test_rejected_steps_on_visual_windows(seed, lm_noise, cp_noise, order, beari
     flags_seen = [it["step_is_successful"] for it in sc["iterations"]]
     assert 0 in flags_seen[1:] and 1 in flags_seen[1:], flags_seen  # the case exercises both branches
     outs = []
-    for flags in ("0", "67108864", "1073741824"):
+    for path, flags in (("fused", "0"), ("fused", "67108864"), ("records", "0"), ("records", "67108864"), ("records", "1073741824")):
         monkeypatch.setenv("HS_DEBUG_FLAGS", flags)
+        monkeypatch.setenv("HS_BUILD_PATH", path)
         with ha.Problem(w, lib=hip) as g:
             sg = g.solve(n_it)
             outs.append((sg, g.control_points(), g.landmarks()))
+        flags = (path, flags)
         assert [it["step_is_successful"] for it in sg["iterations"]] == flags_seen, flags
         assert sg["termination"] == sc["termination"] and sg["num_successful_steps"] == sc["num_successful_steps"]
         for ig, ic in zip(sg["iterations"], sc["iterations"]):
@@ -482,10 +486,13 @@ def test_rejected_steps_on_visual_windows(seed, lm_noise, cp_noise, order, beari
                 assert abs(ig[k] - ic[k]) <= 1e-5 * max(abs(ic[k]), 1e-12), (flags, ig["iteration"], k, ig[k], ic[k])
         assert abs(sg["final_cost"] - sc["final_cost"]) <= 1e-6 * sc["final_cost"]
         assert rel(outs[-1][1], cp_c) < 1e-6 and rel(outs[-1][2], lm_c) < 1e-6
-    # the two device paths evaluate the same expressions at the same points
-    assert rel(outs[0][1], outs[1][1]) < 1e-9 and rel(outs[0][2], outs[1][2]) < 1e-9
-    for a, b in zip(outs[0][0]["iterations"], outs[1][0]["iterations"]):
-        assert abs(a["cost"] - b["cost"]) <= 1e-12 * abs(b["cost"])
+    monkeypatch.delenv("HS_BUILD_PATH")
+    monkeypatch.setenv("HS_DEBUG_FLAGS", "0")
+    # with and without the deferred commit a path evaluates the same expressions at the same points
+    for i, j in ((0, 1), (2, 3)):
+        assert rel(outs[i][1], outs[j][1]) < 1e-9 and rel(outs[i][2], outs[j][2]) < 1e-9
+        for a, b in zip(outs[i][0]["iterations"], outs[j][0]["iterations"]):
+            assert abs(a["cost"] - b["cost"]) <= 1e-12 * abs(b["cost"])
 
 
 def test_deferred_commit_when_a_solve_converges_early(hip, oracle):

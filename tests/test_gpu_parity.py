@@ -61,8 +61,16 @@ def test_linearization(name, w, robustify, hip, oracle):
         assert abs(g.cost() - c.cost()) <= 1e-12 * c.cost()
 
 
+@pytest.fixture(params=["fused", "records"])
+def build_path(request, monkeypatch):
+    """Both normal-equation builds of the library: the fused build (k_build_visual, default wherever a landmark's window has <= 256 tiles)
+    and the record path (HS_BUILD_PATH=records: k_linearize_visual -> k_landmark -> Gram kernels; what long feature tracks always take)."""
+    monkeypatch.setenv("HS_BUILD_PATH", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("name,w", list(windows()), ids=[n for n, _ in windows()])
-def test_reduced_system(name, w, hip, oracle):
+def test_reduced_system(name, w, hip, oracle, build_path):
     with ha.Problem(w, lib=hip) as g, ha.Problem(w, lib=oracle) as c:
         Sg, gg = g.reduced_system(1e4)
         Sc, gc = c.reduced_system(1e4)
@@ -72,7 +80,7 @@ def test_reduced_system(name, w, hip, oracle):
 
 
 @pytest.mark.parametrize("name,w", list(windows()), ids=[n for n, _ in windows()])
-def test_solve_trajectory(name, w, hip, oracle):
+def test_solve_trajectory(name, w, hip, oracle, build_path):
     with ha.Problem(w, lib=hip) as g, ha.Problem(w, lib=oracle) as c:
         sg, sc = g.solve(5), c.solve(5)
         assert sg["num_iterations"] == sc["num_iterations"]
@@ -90,7 +98,7 @@ def test_solve_trajectory(name, w, hip, oracle):
             assert rel(g.landmarks(), c.landmarks()) < 1e-6
 
 
-def test_run_to_run_bit_reproducible(hip):
+def test_run_to_run_bit_reproducible(hip, build_path):
     w = synthetic.small_visual(order=4, n_cp=24, n_landmarks=300, obs_pairs=4, seed=11)
     outs = []
     for _ in range(3):
@@ -251,6 +259,25 @@ def test_baseline_configs_at_full_size(name, hip, oracle):
         assert np.array_equal(g.control_points(), first[0])
         if first[1] is not None:
             assert np.array_equal(g.landmarks(), first[1])
+
+
+@pytest.mark.parametrize("name", ["config1", "config2", "config3"])
+def test_build_paths_agree_at_full_size(name, hip, monkeypatch):
+    """The fused build (default) and the record path (HS_BUILD_PATH=records) of the same library on BASELINE.json configs[1..3] at full size:
+    the same reduced normal equations to round-off, the same accept / reject decisions and the same 5-iteration result."""
+    w = getattr(synthetic, name)()
+    outs = []
+    for path in ("fused", "records"):
+        monkeypatch.setenv("HS_BUILD_PATH", path)
+        with ha.Problem(w, lib=hip) as g:
+            S, gr = g.reduced_system(1e4)
+            s = g.solve(5)
+            outs.append((S, gr, s, g.control_points().copy(), g.landmarks().copy()))
+    (S0, g0, s0, cp0, lm0), (S1, g1, s1, cp1, lm1) = outs
+    assert rel(S0, S1) < 1e-11 and rel(g0, g1) < 1e-11, (rel(S0, S1), rel(g0, g1))
+    assert [it["step_is_successful"] for it in s0["iterations"]] == [it["step_is_successful"] for it in s1["iterations"]]
+    assert abs(s0["final_cost"] - s1["final_cost"]) <= 1e-8 * s1["final_cost"]
+    assert rel(cp0, cp1) < 1e-7 and rel(lm0, lm1) < 1e-7
 
 
 def test_process_tracks_matches_golden(hip):

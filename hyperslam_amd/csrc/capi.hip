@@ -230,8 +230,8 @@ struct hs_problem {
   bool fused = false;
   int build_R = 0, build_L = 0;     // records per pass, landmarks per chunk
   size_t build_lds = 0;
-  DBuf<int> d_ch_ptr;
-  std::vector<int> h_ch_ptr, h_gw_ptr, h_gw_cf;
+  DBuf<int> d_ch_ptr, d_ch_desc;
+  std::vector<int> h_ch_ptr, h_gw_ptr, h_gw_cf, h_ch_desc;
   DBuf<double> d_ybuf, d_scale_b, d_Spb, d_Sbb, d_gb_s, d_D2b, d_Zb, d_Cb, d_hb, d_xb, d_delta_b, d_bias_g_snap, d_bias_a_snap, d_gravity_snap;
   DBuf<int> d_i_bias_ptr, d_bfwd_start;
   int n_split = 1;
@@ -441,19 +441,16 @@ int prepare(hs_problem* p) {
     p->fused = n_vis > 0 && ntile_ <= kBlock && nband_ <= kBlock && !(env && std::strcmp(env, "records") == 0);
   }
   if (p->fused) {
-    // chunk geometry: records per pass R (<= 256 lanes), landmarks per chunk L — as large as the LDS allows (fewer, larger partials for
-    // k_assemble; one workgroup per CU either way). HS_BUILD_R / HS_BUILD_L: tuning overrides.
-    int R = k == 4 ? 256 : 192, L = k == 4 ? 24 : 18;
-    if (const char* e = std::getenv("HS_BUILD_R")) R = std::max(32, std::min(kBlock, std::atoi(e)));
-    if (const char* e = std::getenv("HS_BUILD_L")) L = std::max(1, std::min(kBlock - 1, std::atoi(e)));
-    const size_t lds_cap = 156 * 1024;
-    while (size_t(build_lds_layout(k, vs.bw, R, L).total_doubles) * 8 > lds_cap && L > 4) --L;
-    while (size_t(build_lds_layout(k, vs.bw, R, L).total_doubles) * 8 > lds_cap && R > 64) R -= 32;
-    if (size_t(build_lds_layout(k, vs.bw, R, L).total_doubles) * 8 > lds_cap) p->fused = false;
-    p->build_R = R, p->build_L = L, p->build_lds = size_t(build_lds_layout(k, vs.bw, R, L).total_doubles) * 8;
-  }
-  if (p->fused) {
-    build_chunks(vs, p->n_cp, p->build_R, p->build_L, &p->h_ch_ptr, &p->h_gw_ptr, &p->h_gw_cf);
+    // chunk geometry: R residuals (lanes) and L landmarks per chunk, sized for two workgroups per CU (every phase of the kernel is an LDS
+    // gather: latency bound on a lone wave per SIMD). HS_BUILD_R / HS_BUILD_L: tuning overrides.
+    int R0 = k == 4 ? 128 : 96, L0 = k == 4 ? 12 : 10;
+    if (const char* e = std::getenv("HS_BUILD_R")) R0 = std::max(32, std::min(kBlock, std::atoi(e)));
+    if (const char* e = std::getenv("HS_BUILD_L")) L0 = std::max(1, std::min(24, std::atoi(e)));  // (<= 24: 9 L + 8 lanes of phase 2a, L lanes of one wave in 4a)
+    auto lds_bytes = [&](int r, int l) { return size_t(build_lds_layout(k, vs.bw, r, l).total_doubles) * 8; };
+    const bool overridden = std::getenv("HS_BUILD_R") || std::getenv("HS_BUILD_L");  // (a tuning run asks for exactly this geometry, one workgroup per CU if need be)
+    p->fused = choose_build_geometry(k, R0, L0, size_t(overridden ? 156 : 79) * 1024, size_t(156) * 1024, lds_bytes, &p->build_R, &p->build_L) &&
+               build_chunks(vs, p->n_cp, p->build_R, p->build_L, &p->h_ch_ptr, &p->h_gw_ptr, &p->h_gw_cf, &p->h_ch_desc);
+    p->build_lds = p->fused ? lds_bytes(p->build_R, p->build_L) : 0;
   }
   if (!p->fused) {
     HIP_TRY(p->d_v_rec.reserve(size_t(n_vis) * (8 + 12 * k) + 1));
@@ -517,7 +514,10 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_delta_p.reserve(np));
   const int vis_block = k == 4 ? lin_block<4>() : lin_block<6>();
   p->nb_vis = (n_vis + vis_block - 1) / vis_block;
-  if (p->fused) p->nb_vis = std::max((n_vis + kBlock - 1) / kBlock, int(p->h_ch_ptr.size()) - 1);  // one cost partial per chunk / per workgroup of k_cost_visual
+  if (p->fused) {
+    p->nb_vis = std::max((n_vis + kBlock - 1) / kBlock, int(p->h_ch_ptr.size()) - 1);  // one cost partial per chunk / per workgroup of k_cost_visual
+    p->h_ch_desc.resize(size_t(8) * p->nb_vis, 0);                                        // (k_build_visual reads its descriptor before it knows whether it is a padding workgroup)
+  }
   p->nb_pri = (n_pri + kBlock - 1) / kBlock;
   p->nb_cp = std::max((p->n_cp + kBlock - 1) / kBlock, 1);
   HIP_TRY(p->d_cost_part.reserve(p->nb_vis + p->nb_pri + (n_ine + kBlock - 1) / kBlock + 1));
@@ -594,6 +594,7 @@ int prepare(hs_problem* p) {
       HIP_TRY(p->d_gw_ptr.upload(p->h_gw_ptr, s));
       HIP_TRY(p->d_gw_cf.upload(p->h_gw_cf, s));
       HIP_TRY(p->d_ch_ptr.upload(p->h_ch_ptr, s));
+      HIP_TRY(p->d_ch_desc.upload(p->h_ch_desc, s));
       p->n_group_wg = int(p->h_ch_ptr.size()) - 1;
     } else {
       for (int c = 0; c < p->n_cp; ++c) {
@@ -616,7 +617,7 @@ int prepare(hs_problem* p) {
   T.sp = Spline{k, p->n_cp, p->t0, p->dt, 1.0 / p->dt, p->rot_const, p->trans_const};
   T.basis = make_basis_coef(k);
   T.cp = p->d_cp.p, T.cp_cand = p->d_cp_cand.p, T.cp_const = p->d_cp_const.p;
-  T.cam = p->d_cam.p, T.sensor = p->d_sensor.p;
+  T.cam = p->d_cam.p, T.n_cam = p->n_cam, T.sensor = p->d_sensor.p;
   T.n_lm = p->n_lm, T.lm = p->d_lm.p, T.lm_cand = p->d_lm_cand.p, T.lm_const = p->d_lm_const.p;
   T.lm_ptr = p->d_lm_ptr.p, T.lm_cfirst = p->d_lm_cfirst.p, T.lm_ncp = p->d_lm_ncp.p, T.lm_yoff = p->d_lm_yoff.p, T.cf_ptr = p->d_cf_ptr.p;
   T.lm_scale = p->d_lm_scale.p, T.lm_L = p->d_lm_L.p, T.lm_yhat = p->d_lm_yhat.p, T.lm_sb = p->d_lm_sb.p, T.lm_D2 = p->d_lm_D2.p;
@@ -659,7 +660,7 @@ int prepare(hs_problem* p) {
   T.scale_b = p->d_scale_b.p, T.Spb = p->d_Spb.p, T.Sbb = p->d_Sbb.p, T.gb_s = p->d_gb_s.p, T.D2b = p->d_D2b.p;
   T.Zb = p->d_Zb.p, T.Cb = p->d_Cb.p, T.hb = p->d_hb.p, T.xb = p->d_xb.p, T.delta_b = p->d_delta_b.p, T.i_bias_ptr = p->d_i_bias_ptr.p, T.bfwd_start = p->d_bfwd_start.p;
   T.x_count1 = x_count1, T.xo_dec = x_count1;
-  T.fused = p->fused ? 1 : 0, T.n_chunk = p->fused ? p->n_group_wg : 0, T.ch_ptr = p->d_ch_ptr.p;
+  T.fused = p->fused ? 1 : 0, T.n_chunk = p->fused ? p->n_group_wg : 0, T.ch_ptr = p->d_ch_ptr.p, T.ch_desc = p->d_ch_desc.p;
   T.rank = p->rank, T.world = p->world;
   // HS_DEBUG_FLAGS (measurement switches only, never needed for correct operation):
   //    1 skip the backward sweep          2 skip the rank-6 updates (timing of the panel chain alone; results are garbage)
@@ -1302,6 +1303,12 @@ int hs_set_spline(hs_problem* p, int order, double t0, double dt, int n_cp, cons
   if (!p) return HS_ERR_INVALID;
   if (order < 2 || order > hsd::kMaxOrder) HS_FAIL(HS_ERR_INVALID, "spline order out of range");
   if (n_cp < order || !(dt > 0) || !cp) HS_FAIL(HS_ERR_INVALID, "need n_cp >= order, dt > 0 and a control-point table");
+  // The basis is uniform: control point j is taken to sit at t0 + j dt, whatever its row says. A table with a hole (upstream prunes state
+  // elements one by one, ceres/optimizer.cpp:330-341) or non-uniform knots would silently re-index every later control point: refused.
+  // (Stamps accumulated as t += dt differ from t0 + j dt in the last bits only: 1e-9 dt is far above that and far below a knot.)
+  for (int j = 0; j < n_cp; ++j)
+    if (!(std::fabs(cp[8 * j + 7] - (t0 + j * dt)) <= 1e-9 * dt))
+      HS_FAIL(HS_ERR_INVALID, "control-point stamps are not t0 + j dt (row " + std::to_string(j) + "): the spline basis is uniform, a table with a hole or non-uniform knots is refused");
   p->k = order, p->t0 = t0, p->dt = dt, p->n_cp = n_cp;
   p->cp.assign(cp, cp + size_t(8) * n_cp);
   p->cp_const.assign(n_cp, 0);

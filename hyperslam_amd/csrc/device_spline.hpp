@@ -133,6 +133,51 @@ HSD void spline_pose_jac(const double* cp, const double* lam, Quat* q_out, V3* p
   *p_out = p;
 }
 
+/// The part of spline_pose_jac that depends on the control points alone: relative rotation j -> j + 1 of two consecutive control points
+/// (its Log with the trigonometry of the angle, the J_r^-1 coefficient). A workgroup whose residuals share a window of control points
+/// computes these once per pair instead of once per residual and pair (one atan2, one quaternion product, three divisions each).
+struct RelPre {
+  RelRot rr;
+  double D;
+  double pad;  // (8 doubles: 16-byte rows in LDS)
+};
+HSD RelPre rel_precompute(const double* cp_prev, const double* cp_next) {
+  RelPre p;
+  p.rr = rel_log(load_quat(cp_prev), load_quat(cp_next));
+  p.D = jr_inv_coef(p.rr);
+  p.pad = 0.0;
+  return p;
+}
+
+/// spline_pose_jac with the relative rotations handed in: rel[j - 1] = rel_precompute(cp + 8 (j - 1), cp + 8 j). Same arithmetic, same result.
+template <int K>
+HSD void spline_pose_jac_pre(const double* cp, const RelPre* rel, const double* lam, Quat* q_out, V3* p_out, M3* G) {
+  Quat q = load_quat(cp);
+  V3 p = V3{cp[4], cp[5], cp[6]};
+  V3 pprev = p;
+  G[0] = eye();
+#pragma unroll
+  for (int j = 1; j < K; ++j) {
+    const double* c = cp + 8 * j;
+    const RelRot rr = rel[j - 1].rr;
+    double b, cc;
+    q = qmul(q, exp_scaled(rr, lam[j], &b, &cc));
+    const double D = rel[j - 1].D;
+    const double alpha = 0.5 - b + rr.t2 * (b * D - 0.5 * cc);
+    const double beta = D - 0.5 * b + cc - rr.t2 * cc * D;
+    M3 X = rodrigues_poly(rr.d, alpha, beta);
+    X = scale(lam[j], X);
+    const M3 Tj = mul_nt(mul(qmat(q), X), qmat(load_quat(c)));
+    G[j - 1] = sub(G[j - 1], Tj);
+    G[j] = Tj;
+    const V3 pj = V3{c[4], c[5], c[6]};
+    p = p + lam[j] * (pj - pprev);
+    pprev = pj;
+  }
+  *q_out = qnormalized(q);
+  *p_out = p;
+}
+
 /// Full evaluation for the inertial factor (right-perturbation recursion of SURVEY.md A.2b, converted to world-frame
 /// perturbations at the end): outputs body-frame w, alpha, world-frame v, a and the 3x3 Jacobian blocks of theta, w, alpha.
 template <int K>

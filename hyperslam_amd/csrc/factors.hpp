@@ -107,6 +107,25 @@ HSD double visual_cost(const Tables& T, const double* cps, const double* lms, in
   return 0.5 * loss_huber(s, type == 0 ? kHuberPixel : kHuberBearing, &sr);
 }
 
+/// Inputs of one visual residual block (whoever calls visual_core decides where they come from: the tables in HBM, or LDS copies
+/// a workgroup staged for its chunk).
+struct VisualIn {
+  double stamp, meas[3];
+  int type, first;
+  const double* cam;  // 16 doubles: T_bs(7) | cx cy fx fy | k1 k2 p1 p2
+  double lm[3];       // landmark position
+};
+HSD VisualIn visual_input(const Tables& T, int q, const double* lms) {
+  VisualIn in;
+  const int info = T.v_info[q];
+  in.type = info >> 16, in.cam = T.cam + kCamStride * (info & 0xffff);
+  in.first = T.v_first[q], in.stamp = T.v_stamp[q];
+  in.meas[0] = T.v_meas[3 * q], in.meas[1] = T.v_meas[3 * q + 1], in.meas[2] = T.v_meas[3 * q + 2];
+  const double* l = (lms ? lms : T.lm) + 3 * T.v_lm[q];
+  in.lm[0] = l[0], in.lm[1] = l[1], in.lm[2] = l[2];
+  return in;
+}
+
 /// Shared front half of the visual linearisation: spline pose + rotation Jacobian blocks, projection chain, loss corrector.
 ///   A = sr * J_proj * R_sw (2 x 3) = d r / d p_w,   Mh = A * hat(p_w - p_wb) (2 x 3).
 template <int K>
@@ -115,33 +134,30 @@ struct VisualCore {
   double A[6], Mh[6];
   M3 G[K];         // d theta / d phi_j
   double lam[K];   // cumulative basis weights
-  int first, lmid;
   double cost;
 };
 
+/// rel (optional): relative rotations of consecutive control points, indexed like `cps` (rel[j] = pair j -> j + 1, device_spline.hpp RelPre).
 template <int K>
-HSD void visual_core(const Tables& T, const double* cps, int q, bool robustify, const double* lms, VisualCore<K>* o) {
-  const int info = T.v_info[q];
-  const int type = info >> 16, camid = info & 0xffff;
-  const double* cam = T.cam + kCamStride * camid;
-  o->first = T.v_first[q];
+HSD void visual_core(const Tables& T, const double* cps, const VisualIn& in, bool robustify, VisualCore<K>* o, const RelPre* rel = nullptr) {
   double u;
-  segment_of(T.v_stamp[q], T.sp.t0, T.sp.dt, K, &u);
+  segment_of(in.stamp, T.sp.t0, T.sp.dt, K, &u);
   double dl[1], ddl[1];
   basis_weights<K>(T.basis, u, T.sp.inv_dt, o->lam, dl, ddl, 0);
   Quat qw;
   V3 pw;
-  spline_pose_jac<K>(cps + 8 * o->first, o->lam, &qw, &pw, o->G);
-  o->lmid = T.v_lm[q];
-  const double* l = (lms ? lms : T.lm) + 3 * o->lmid;
+  if (rel)
+    spline_pose_jac_pre<K>(cps + 8 * in.first, rel + in.first, o->lam, &qw, &pw, o->G);
+  else
+    spline_pose_jac<K>(cps + 8 * in.first, o->lam, &qw, &pw, o->G);
   M3 R_sw;
   V3 v;
-  const V3 ps = to_sensor(qw, pw, cam, V3{l[0], l[1], l[2]}, &R_sw, &v);
+  const V3 ps = to_sensor(qw, pw, in.cam, V3{in.lm[0], in.lm[1], in.lm[2]}, &R_sw, &v);
   double Jps[6];
-  visual_measure(type, ps, cam, T.v_meas + 3 * q, true, o->r, Jps);
+  visual_measure(in.type, ps, in.cam, in.meas, true, o->r, Jps);
   const double s = o->r[0] * o->r[0] + o->r[1] * o->r[1];
   double sr;
-  o->cost = 0.5 * loss_huber(s, type == 0 ? kHuberPixel : kHuberBearing, &sr);
+  o->cost = 0.5 * loss_huber(s, in.type == 0 ? kHuberPixel : kHuberBearing, &sr);
   if (!robustify) sr = 1.0;
   o->r[0] *= sr, o->r[1] *= sr;
   // A = sr * Jps * R_sw (2x3);  M = A * hat(v)
@@ -159,15 +175,16 @@ HSD void visual_core(const Tables& T, const double* cps, int q, bool robustify, 
 /// Full linearisation of visual residual q (landmark-major index) in Ceres-local coordinates.
 template <int K>
 HSD void visual_linearize(const Tables& T, const double* cps, int q, bool robustify, VisualOut<K>* o, const double* lms = nullptr) {
+  const VisualIn in = visual_input(T, q, lms);
   VisualCore<K> c;
-  visual_core<K>(T, cps, q, robustify, lms, &c);
+  visual_core<K>(T, cps, in, robustify, &c);
   o->r[0] = c.r[0], o->r[1] = c.r[1], o->cost = c.cost;
-  const bool lm_free = !T.lm_const[c.lmid];
+  const bool lm_free = !T.lm_const[T.v_lm[q]];
 #pragma unroll
   for (int i = 0; i < 6; ++i) o->Jl[i] = lm_free ? c.A[i] : 0.0;
 #pragma unroll
   for (int j = 0; j < K; ++j) {
-    const bool frozen = T.cp_const[c.first + j] != 0;
+    const bool frozen = T.cp_const[in.first + j] != 0;
     const double Bj = c.lam[j] - (j + 1 < K ? c.lam[j + 1] : 0.0);
     const bool rot_free = !frozen && !T.sp.rot_const, tr_free = !frozen && !T.sp.trans_const;
 #pragma unroll
@@ -183,38 +200,42 @@ HSD void visual_linearize(const Tables& T, const double* cps, int q, bool robust
 }
 
 /// Compact record of a visual residual (the fused build keeps a workgroup's records in LDS, kernels_build.hpp). The translation columns of
-/// the state Jacobian are -B_j A and the landmark Jacobian is A itself, so the 2 x 6K state block is stored as its rotation half plus K
-/// scalars:   [r(2) | A(2 x 3) | B_eff(K) | J_rot row 0 (3K) | J_rot row 1 (3K)]  = 8 + 7K doubles   (full record: 8 + 12K).
+/// the state Jacobian are -B_j A and the landmark Jacobian is A itself, so the 2 x 6K state block is stored as its rotation half plus the
+/// K scalars B_j, laid out for 16-byte LDS accesses:
+///   [r(2) | A(2 x 3) | per control point j: J_rot row 0 (3), B_eff_j, J_rot row 1 (3), B_eff_j]  = 8 + 8K doubles   (full record: 8 + 12K).
 /// B_eff_j = 0 for a constant control point / constant translations, the rotation columns of such a point are stored as zeros. A is
 /// stored unmasked: a constant landmark's flag is applied by the consumers (its W, H_ll and b_l are zero, its translation columns are not).
+/// cp_frozen: constancy flags of the control points, indexed like `cps` (absolute index).
 template <int K>
-constexpr int compact_record() { return 8 + 7 * K; }
+constexpr int compact_record() { return 8 + 8 * K; }
 
 template <int K>
-HSD double visual_linearize_compact(const Tables& T, const double* cps, int q, bool robustify, const double* lms, double* rec, int* first) {
+HSD double visual_linearize_compact(const Tables& T, const double* cps, const RelPre* rel, const uint8_t* cp_frozen, const VisualIn& in, bool robustify,
+                                    double* rec) {
   VisualCore<K> c;
-  visual_core<K>(T, cps, q, robustify, lms, &c);
-  *first = c.first;
+  visual_core<K>(T, cps, in, robustify, &c, rel);
   *reinterpret_cast<double2*>(rec) = make_double2(c.r[0], c.r[1]);
 #pragma unroll
   for (int i = 0; i < 6; i += 2) *reinterpret_cast<double2*>(rec + 2 + i) = make_double2(c.A[i], c.A[i + 1]);
-  double jrot[6 * K];
 #pragma unroll
   for (int j = 0; j < K; ++j) {
-    const bool frozen = T.cp_const[c.first + j] != 0;
+    const bool frozen = cp_frozen[in.first + j] != 0;
     const double Bj = c.lam[j] - (j + 1 < K ? c.lam[j + 1] : 0.0);
     const bool rot_free = !frozen && !T.sp.rot_const, tr_free = !frozen && !T.sp.trans_const;
-    rec[8 + j] = tr_free ? Bj : 0.0;
+    const double be = tr_free ? Bj : 0.0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+      double jr[3];
 #pragma unroll
       for (int cc = 0; cc < 3; ++cc) {
-        const double jr = 2.0 * (c.Mh[3 * i] * c.G[j].m[cc] + c.Mh[3 * i + 1] * c.G[j].m[3 + cc] + c.Mh[3 * i + 2] * c.G[j].m[6 + cc]);
-        jrot[i * 3 * K + 3 * j + cc] = rot_free ? jr : 0.0;
+        const double v = 2.0 * (c.Mh[3 * i] * c.G[j].m[cc] + c.Mh[3 * i + 1] * c.G[j].m[3 + cc] + c.Mh[3 * i + 2] * c.G[j].m[6 + cc]);
+        jr[cc] = rot_free ? v : 0.0;
       }
+      double* blk = rec + 8 + 8 * j + 4 * i;
+      *reinterpret_cast<double2*>(blk) = make_double2(jr[0], jr[1]);
+      *reinterpret_cast<double2*>(blk + 2) = make_double2(jr[2], be);
+    }
   }
-#pragma unroll
-  for (int e = 0; e < 6 * K; e += 2) *reinterpret_cast<double2*>(rec + 8 + K + e) = make_double2(jrot[e], jrot[e + 1]);
   return c.cost;
 }
 

@@ -200,9 +200,11 @@ inline bool build_visual_structure(const VisualInput& in, VisualStructure* vs, s
 }
 
 /// Work list of the fused build (kernels_build.hpp). Chunk = consecutive device landmarks of one landmark group (same first control point),
-/// at most L landmarks, about R residuals (a landmark with more than R residuals is a chunk of its own and takes several passes).
+/// at most L landmarks and at most R residuals (one lane each). Returns false when a single landmark has more than R residuals (the caller
+/// takes the record path then).
 /// ch_ptr[w] .. ch_ptr[w + 1]: landmarks of chunk w;  gw_ptr[c] .. gw_ptr[c + 1]: chunks of group c;  gw_cf[w]: group of chunk w.
-inline void build_chunks(const VisualStructure& vs, int n_cp, int R, int L, std::vector<int>* ch_ptr, std::vector<int>* gw_ptr, std::vector<int>* gw_cf) {
+inline bool build_chunks(const VisualStructure& vs, int n_cp, int R, int L, std::vector<int>* ch_ptr, std::vector<int>* gw_ptr, std::vector<int>* gw_cf,
+                         std::vector<int>* ch_desc = nullptr) {
   int n_obs = int(vs.lm_ptr.size()) - 1;
   while (n_obs > 0 && vs.lm_ptr[n_obs] == vs.lm_ptr[n_obs - 1]) --n_obs;  // unobserved landmarks are last in device order
   ch_ptr->clear(), gw_cf->clear();
@@ -211,20 +213,45 @@ inline void build_chunks(const VisualStructure& vs, int n_cp, int R, int L, std:
     const int d0 = std::min(vs.cf_ptr[c], n_obs), d1 = std::min(vs.cf_ptr[c + 1], n_obs);
     (*gw_ptr)[c] = int(gw_cf->size());
     if (d1 <= d0) continue;
-    const int nres = vs.lm_ptr[d1] - vs.lm_ptr[d0], nl = d1 - d0;
-    const int nch = std::max((nl + L - 1) / L, (nres + R - 1) / R);
-    const int target = std::max((nres + nch - 1) / nch, 1);  // residuals per chunk, evenly
     int d = d0;
-    while (d < d1) {
+    while (d < d1) {  // greedy fill: as many landmarks as the two limits admit (fewest chunks; an even split of a group costs chunks)
+      if (vs.lm_ptr[d + 1] - vs.lm_ptr[d] > R) return false;
       ch_ptr->push_back(d), gw_cf->push_back(c);
       int cnt = 0, e = d;
-      while (e < d1 && e - d < L && (e == d || cnt + (vs.lm_ptr[e + 1] - vs.lm_ptr[e]) <= target)) cnt += vs.lm_ptr[e + 1] - vs.lm_ptr[e], ++e;
+      while (e < d1 && e - d < L && cnt + (vs.lm_ptr[e + 1] - vs.lm_ptr[e]) <= R) cnt += vs.lm_ptr[e + 1] - vs.lm_ptr[e], ++e;
       d = e;
     }
   }
   (*gw_ptr)[n_cp] = int(gw_cf->size());
   ch_ptr->push_back(n_obs);
   gw_cf->push_back(0);
+  if (ch_desc) {  // [first landmark, landmarks, first control point, first residual, residuals, 0, 0, 0] per chunk
+    const int n = int(ch_ptr->size()) - 1;
+    ch_desc->assign(size_t(8) * std::max(n, 1), 0);
+    for (int w = 0; w < n; ++w) {
+      const int lo = (*ch_ptr)[w], hi = (*ch_ptr)[w + 1];
+      int* d = ch_desc->data() + 8 * w;
+      d[0] = lo, d[1] = hi - lo, d[2] = vs.lm_cfirst[lo], d[3] = vs.lm_ptr[lo], d[4] = vs.lm_ptr[hi] - vs.lm_ptr[lo];
+    }
+  }
+  return true;
+}
+
+/// Chunk geometry of the fused build: records (= lanes) per chunk R and landmarks per chunk L such that TWO workgroups share a CU
+/// (lds_two bytes each); bands too wide for that get one workgroup per CU (lds_one); false: no geometry fits (record path).
+template <class LdsBytes>
+inline bool choose_build_geometry(int k, int R0, int L0, size_t lds_two, size_t lds_one, LdsBytes lds_bytes, int* R, int* L) {
+  for (const size_t cap : {lds_two, lds_one}) {
+    int r = R0, l = L0;
+    while (lds_bytes(r, l) > cap && l > 4) --l;
+    while (lds_bytes(r, l) > cap && r > 64) r -= 32;
+    if (lds_bytes(r, l) <= cap) {
+      *R = r, *L = l;
+      return true;
+    }
+  }
+  (void)k;
+  return false;
 }
 
 }  // namespace hs

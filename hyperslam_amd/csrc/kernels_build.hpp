@@ -9,17 +9,22 @@
 // landmark-group-major by the workgroup that linearised the residual; no segment-major pass, no record ever leaves the CU.
 //
 // Work unit = CHUNK: a run of consecutive device landmarks that share their first control point cf (device order sorts landmarks by cf),
-// at most L_max landmarks (W / Y-hat rows in LDS) and about R residuals (one pass; a landmark with more residuals takes several passes).
-// Per workgroup (256 lanes):
-//   1  lane t linearises residual t of the pass into a COMPACT record in LDS (factors.hpp: 8 + 7K doubles, the translation columns
-//      -B_j A are rebuilt by the consumers)
-//   2  lane <-> (landmark, row of W): W_l += J_p' J_l over the landmark's records;  9 more lanes per landmark: H_ll, b_l
-//   3  lane <-> (record stream s, band tile (rb, cb), cb - rb < K): P += J_p' J_p of the records whose segment covers both blocks —
-//      the pass's records are counting-sorted by segment (stable, ballot based: fixed summation order), so a tile's records are one run
-//   4  lane <-> (landmark, row): damped 3 x 3 Cholesky (redundant per lane), Y-hat row -> LDS and HBM (k_backsub_retract needs it)
-//   5  lane <-> (landmark stream, window tile (rb, cb)): Q -= Yh Yh', q -= Yh yh  (as k_group_gram)
-//   6  streams combined through LDS in index order; the chunk's partial [tiles of P + Q | -Yh yh | J_p'r | diag J_p'J_p] -> HBM, summed
-//      over the chunks of the overlapping groups by k_assemble in a fixed order: bit-reproducible, no floating-point atomics.
+// at most L_max landmarks (W / Y-hat rows in LDS) and at most R residuals (one lane each). Sized so that TWO workgroups share a CU
+// (<= 79 KB of LDS, <= 256 registers): every phase below is a gather through LDS, i.e. latency bound on a lone wave per SIMD (the first
+// version ran one 133 KB workgroup per CU: 51 us per chunk, of which 16 us in phase 2 at ~630 clk per record visited).
+// The unit of every gather is (landmark, control-point block) or (tile, record stream), and a record is stored where its consumers
+// find it without searching: LDS slot = rank in the order (segment, landmark, table order), with the table pos[segment][landmark].
+//   0  segment offset o = first control point - cf and landmark of every residual -> stable counting sort (ballots + a wave scan)
+//   1  lane t linearises residual t into a COMPACT record at its sorted slot (factors.hpp: 8 + 7K doubles, the translation columns
+//      -B_j A are rebuilt by the consumers);  H_t = A'A, b_t = A'r per record in landmark-major order
+//   2  lane <-> (landmark, control point j'): the 6 x 3 block of W_l = sum J_p' J_l from the records of segments j' - K + 1 .. j' of that
+//      landmark (pos table: only records that contribute are visited);  lane <-> (landmark, entry): H_ll, b_l
+//   3  lane <-> (band tile (rb, cb), cb - rb < K; record stream s): P += J_p' J_p over the runs of the segments that cover both
+//      blocks; the streams of a tile sit in adjacent lanes and are combined with butterfly steps (fixed order, no LDS)
+//   4  lane <-> landmark: damped 3 x 3 Cholesky;  lane <-> (landmark, control point): Y-hat block -> LDS and HBM (k_backsub_retract)
+//   5  lane <-> (window tile, landmark stream): Q -= Yh Yh', q -= Yh yh (two streams in adjacent lanes)
+//   6  the chunk's partial [tiles of P + Q | -Yh yh | J_p'r | diag J_p'J_p] -> HBM, summed over the chunks of the overlapping groups
+//      by k_assemble in a fixed order: bit-reproducible, no floating-point atomics.
 // HBM traffic per residual: 32 B of inputs + its share of Y-hat and of the chunk partial; the 448-byte record (k = 4) is never written.
 #pragma once
 #include "kernels_common.hpp"
@@ -30,227 +35,363 @@ template <int K>
 constexpr int build_rec_stride() { return compact_record<K>() + 2; }  // LDS record stride (16-byte aligned, bank-spread)
 
 /// Band tiles of the chunk window that J_p'J_p touches: (rb, d = cb - rb), d < K, rb + d < bw; index = tiles of smaller d first.
-HSD int band_tile_count(int bw, int k) { return k * bw - k * (k - 1) / 2; }
+__host__ __device__ inline int band_tile_count(int bw, int k) { return k * bw - k * (k - 1) / 2; }
 HSD int band_tile_index(int rb, int d, int bw) { return d * bw - d * (d - 1) / 2 + rb; }
+/// Record streams per band tile (adjacent lanes, combined by butterflies).
+__host__ __device__ inline int build_streams(int n_tiles) { return 4 * n_tiles <= kBlock ? 4 : (2 * n_tiles <= kBlock ? 2 : 1); }
 
-/// LDS layout of k_build_visual (doubles unless noted) — the host sizes the launch with the same function.
+constexpr int kLinv = 14;  // per landmark: 1/l00 l10 1/l11 l20 l21 1/l22 | s_l (3) | free flag | y-hat (3) | pad
+constexpr int kBuildCams = 4;  // cameras staged in LDS (a residual of a later camera reads the table in HBM)
+
+/// LDS layout of k_build_visual (offsets in doubles) — the host sizes the launch with the same function.
 struct BuildLds {
-  int rec, wy, cps, hb, yh, slo, ints, total_doubles;
+  int rec, wy, cps, relp, lmp, cam, hb, linv, cpart, ints, total_doubles;
 };
 __host__ __device__ inline BuildLds build_lds_layout(int K, int bw, int R, int Lmax) {
-  const int cs = 8 + 7 * K + 2, nband = K * bw - K * (K - 1) / 2, ns = kBlock / nband, ntile = bw * (bw + 1) / 2;
-  const bool two = ntile <= kBlock / 2;
+  const int cs = 8 + 8 * K + 2, nband = band_tile_count(bw, K), nseg = bw - K + 1;
   BuildLds o;
   int off = 0;
-  o.rec = off;  // records of the pass | per-stream P tiles [ns][nband][42] at the end
-  off += (R * cs > ns * nband * 42 ? R * cs : ns * nband * 42);
-  o.wy = off;   // W rows, then Y-hat rows [Lmax][6 bw][3] | stream 1's Q tiles at the end
-  {
-    int n = Lmax * 6 * bw * 3;
-    if (two && ntile * 42 > n) n = ntile * 42;
-    off += n;
-  }
-  o.cps = off, off += 8 * bw;     // the window's control points
-  o.hb = off, off += Lmax * 10;   // H_ll (6), b_l (3) per landmark
-  o.yh = off, off += Lmax * 4;    // y-hat per landmark
-  o.slo = off, off += Lmax * 4;   // Jacobi scaling of the landmark (previous iterations) + its constant flag
+  o.rec = off, off += (R * cs > nband * 42 ? R * cs : nband * 42);  // records | combined P tiles [nband][36 + 6] once phase 3 is over
+  // W rows, then Y-hat rows [Lmax][6 bw][3]; before them (phase 2a): A'A (6), A'r (3), cost per record, landmark-major
+  o.wy = off, off += (Lmax * 6 * bw * 3 > R * 10 ? Lmax * 6 * bw * 3 : R * 10);
+  o.cps = off, off += 8 * bw;                // the window's control points
+  o.relp = off, off += 8 * bw;               // relative rotations of consecutive control points (device_spline.hpp RelPre)
+  o.lmp = off, off += 4 * Lmax;              // the chunk's landmark positions
+  o.cam = off, off += 16 * kBuildCams;       // cameras
+  o.hb = off, off += Lmax * 10;              // H_ll (6), b_l (3) per landmark
+  o.linv = off, off += Lmax * kLinv;
+  o.cpart = off, off += 8;                   // cost partials
   off += off & 1;
-  o.ints = off;                   // int tables (two per double): lp[Lmax + 1] ncp[Lmax] yoff[Lmax] segoff[R] sorted[R] seg_start[bw + 2] wave_cnt[4][bw]
-  off += (3 * Lmax + 1 + 2 * R + (bw + 2) + 4 * bw + 1) / 2 + 1;
+  o.ints = off;  // int tables (two per double): lp[Lmax + 1] ncp[Lmax] yoff[Lmax] seg_start[bw + 2] wave_cnt[4][bw] slot_lm[R] pos[nseg][Lmax + 1] frozen[bw]
+  off += (3 * Lmax + 1 + (bw + 2) + 4 * bw + R + nseg * (Lmax + 1) + bw + 1) / 2 + 1;
   o.total_doubles = off;
   return o;
 }
 
+/// Operands of one record for a J_p'J_p band tile (blocks a, b of its state Jacobian) / for a W block (block jj): loaded as a unit so that
+/// the loads of the NEXT record can be issued before the products of the current one (a lone wave per SIMD pays the full LDS latency per
+/// record otherwise).
+struct TileOps {
+  double2 r, A0, A1, A2, a00, a01, a10, a11, b00, b01, b10, b11;
+};
+HSD TileOps tile_ops_load(const double* rec, int a, int b) {
+  TileOps x;
+  const double2* p = reinterpret_cast<const double2*>(rec);
+  x.r = p[0], x.A0 = p[1], x.A1 = p[2], x.A2 = p[3];
+  const double2* pa = reinterpret_cast<const double2*>(rec + 8 + 8 * a);
+  const double2* pb = reinterpret_cast<const double2*>(rec + 8 + 8 * b);
+  x.a00 = pa[0], x.a01 = pa[1], x.a10 = pa[2], x.a11 = pa[3];
+  x.b00 = pb[0], x.b01 = pb[1], x.b10 = pb[2], x.b11 = pb[3];
+  return x;
+}
+HSD void tile_ops_apply(const TileOps& x, bool diag, double* pacc, double* pg) {
+  const double A[6] = {x.A0.x, x.A0.y, x.A1.x, x.A1.y, x.A2.x, x.A2.y};
+  double ja[2][6], jb[2][6];
+  ja[0][0] = x.a00.x, ja[0][1] = x.a00.y, ja[0][2] = x.a01.x, ja[1][0] = x.a10.x, ja[1][1] = x.a10.y, ja[1][2] = x.a11.x;
+  jb[0][0] = x.b00.x, jb[0][1] = x.b00.y, jb[0][2] = x.b01.x, jb[1][0] = x.b10.x, jb[1][1] = x.b10.y, jb[1][2] = x.b11.x;
+  const double na = -x.a01.y, nb = -x.b01.y;  // (both rows of a block carry the same B_eff)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ja[i][3 + c] = na * A[3 * i + c], jb[i][3 + c] = nb * A[3 * i + c];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) pacc[6 * r + c] = fma(ja[0][r], jb[0][c], fma(ja[1][r], jb[1][c], pacc[6 * r + c]));
+  if (diag) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) pg[r] = fma(ja[0][r], x.r.x, fma(ja[1][r], x.r.y, pg[r]));
+  }
+}
+struct WOps {
+  double2 A0, A1, A2, j00, j01, j10, j11;
+};
+HSD WOps w_ops_load(const double* rec, int jj) {
+  WOps x;
+  const double2* p = reinterpret_cast<const double2*>(rec);
+  x.A0 = p[1], x.A1 = p[2], x.A2 = p[3];
+  const double2* pj = reinterpret_cast<const double2*>(rec + 8 + 8 * jj);
+  x.j00 = pj[0], x.j01 = pj[1], x.j10 = pj[2], x.j11 = pj[3];
+  return x;
+}
+HSD void w_ops_apply(const WOps& x, double* wacc) {
+  const double A[6] = {x.A0.x, x.A0.y, x.A1.x, x.A1.y, x.A2.x, x.A2.y};
+  double jp[2][6];
+  jp[0][0] = x.j00.x, jp[0][1] = x.j00.y, jp[0][2] = x.j01.x, jp[1][0] = x.j10.x, jp[1][1] = x.j10.y, jp[1][2] = x.j11.x;
+  const double nb = -x.j01.y;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) jp[i][3 + c] = nb * A[3 * i + c];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) wacc[3 * r + c] = fma(jp[0][r], A[c], fma(jp[1][r], A[3 + c], wacc[3 * r + c]));
+}
+
 template <int K>
-__global__ void __launch_bounds__(kBlock) k_build_visual(Tables T, int R, int Lmax, int robustify) {
+__global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int Lmax, int robustify) {
   HS_DYNAMIC_LDS(smem);
-  __shared__ double red[kBlock / 64];
   const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   DevState* st = T.st;
-  if (st->done) return;
+  // the chunk descriptor and the solver state are requested together (the descriptor table is padded to the grid: always in bounds)
+  const int4 d0 = *reinterpret_cast<const int4*>(T.ch_desc + 8 * w);
+  const int nres = T.ch_desc[8 * w + 4];  // <= R (host: build_chunks)
+  const int st_done = st->done, st_spec = st->spec, st_accepted = st->accepted, st_ready = st->scaling_ready;
+  const double radius = st->radius;
+  if (st_done) return;
   if (w >= T.n_chunk) {  // padding workgroups of the visual section of the cost-partial table
     if (tid == 0) T.cost_part[w] = 0.0;
     return;
   }
   constexpr int CS = build_rec_stride<K>();
-  const int bw = T.bw, R6 = 6 * bw, ntile = bw * (bw + 1) / 2, nband = band_tile_count(bw, K), NS = kBlock / nband, nseg = bw - K + 1;
+  const int bw = T.bw, R6 = 6 * bw, ntile = bw * (bw + 1) / 2, nband = band_tile_count(bw, K), nseg = bw - K + 1;
+  const unsigned bw_magic = ((1u << 20) + bw - 1) / bw;  // tau / bw = (tau * magic) >> 20 for tau < 2^20 / bw (tasks: <= Lmax * bw)
   const BuildLds lay = build_lds_layout(K, bw, R, Lmax);
   double* recs = smem + lay.rec;
   double* Wy = smem + lay.wy;
+  double* hbr = Wy;  // (phase 2a only)
+  double* cps_l = smem + lay.cps;
+  RelPre* relp = reinterpret_cast<RelPre*>(smem + lay.relp);
+  double* lmp = smem + lay.lmp;
+  double* cams = smem + lay.cam;
   double* Hb = smem + lay.hb;
-  double* yhs = smem + lay.yh;
-  double* slo = smem + lay.slo;
+  double* Linv = smem + lay.linv;
+  double* cpart = smem + lay.cpart;
   int* lp = reinterpret_cast<int*>(smem + lay.ints);
   int* l_ncp = lp + Lmax + 1;
   int* l_yoff = l_ncp + Lmax;
-  int* segoff = l_yoff + Lmax;
-  int* sorted = segoff + R;
-  int* seg_start = sorted + R;       // nseg + 1
+  int* seg_start = l_yoff + Lmax;      // nseg + 1
   int* wave_cnt = seg_start + bw + 2;  // [4][bw]
+  int* slot_lm = wave_cnt + 4 * bw;    // landmark of the record in sorted slot s
+  int* pos = slot_lm + R;              // [nseg][Lmax + 1]: first slot of segment o whose landmark is >= l
+  uint8_t* frozen = reinterpret_cast<uint8_t*>(pos + nseg * (Lmax + 1));  // constancy flags of the window's control points
 
-  // Deferred commit (DevState::spec & 2 or 4): the candidate accepted by the previous iteration is still only in the candidate buffers
-  const bool pend = (st->spec == 2 || st->spec == 4) && st->accepted;
+  // phase timestamps (profiling builds only, HS_DEBUG_FLAGS 32; tools/build_phase_timing.py): lane 0 of every wave of the first 1024 chunks
+  const bool bprof = prof_enabled(T.debug_flags, 32) && lane == 0 && w < 1024;
+  long long* blog = reinterpret_cast<long long*>(T.xpart) + 48 * 1024 + 64 * w + 16 * wave;
+#define HS_BSTAMP(i) \
+  if (bprof) blog[i] = wall_clock64()
+  HS_BSTAMP(0);
+
+  // Deferred commit (DevState::spec 2 or 4): the candidate accepted by the previous iteration is still only in the candidate buffers
+  const bool pend = (st_spec == 2 || st_spec == 4) && st_accepted;
   const double* cp_src = pend ? T.cp_cand : T.cp;
   const double* lm_src = pend ? T.lm_cand : T.lm;
-  const bool fresh = !st->scaling_ready;
-  const double radius = st->radius;
+  const bool fresh = !st_ready;
 
-  const int lo = T.ch_ptr[w], hi = T.ch_ptr[w + 1], nl = hi - lo;
-  const int cf = T.lm_cfirst[lo];
-  const int q0 = T.lm_ptr[lo], nres = T.lm_ptr[hi] - q0;
-  // ---- chunk tables + the window's control points ----
-  double* cps_l = smem + lay.cps;
+  // ---- 0: every table of the chunk and every input of its residuals in ONE round of independent loads ----
+  const int lo = d0.x, nl = d0.y, cf = d0.z, q0 = d0.w;
+  const bool has_rec = tid < nres;
+  int my_o = -1, my_l = 0;
+  VisualIn in;
+  int camid = 0;
+  if (has_rec) {
+    const int q = q0 + tid;
+    in.first = T.v_first[q], my_l = T.v_lm[q] - lo;
+    my_o = in.first - cf;
+    const int info = T.v_info[q];
+    in.type = info >> 16, camid = info & 0xffff;
+    in.stamp = T.v_stamp[q];
+    in.meas[0] = T.v_meas[3 * q], in.meas[1] = T.v_meas[3 * q + 1], in.meas[2] = T.v_meas[3 * q + 2];
+  }
   {
     const int ncp_w = min(bw, T.sp.n_cp - cf);
     const double2* s2 = reinterpret_cast<const double2*>(cp_src + 8 * cf);
     for (int e = tid; e < 4 * ncp_w; e += kBlock) reinterpret_cast<double2*>(cps_l)[e] = s2[e];
+    if (tid < ncp_w) frozen[tid] = T.cp_const[cf + tid];
+    for (int e = tid; e < 16 * min(T.n_cam, kBuildCams); e += kBlock) cams[e] = T.cam[e];
     if (tid <= nl) lp[tid] = T.lm_ptr[lo + tid] - q0;
     if (tid < nl) {
       const int dl = lo + tid;
       l_ncp[tid] = T.lm_ncp[dl], l_yoff[tid] = T.lm_yoff[dl];
-      slo[4 * tid] = fresh ? 1.0 : T.lm_scale[3 * dl], slo[4 * tid + 1] = fresh ? 1.0 : T.lm_scale[3 * dl + 1];
-      slo[4 * tid + 2] = fresh ? 1.0 : T.lm_scale[3 * dl + 2], slo[4 * tid + 3] = T.lm_const[dl] ? 0.0 : 1.0;
+      double* li = Linv + kLinv * tid;
+      li[6] = fresh ? 1.0 : T.lm_scale[3 * dl], li[7] = fresh ? 1.0 : T.lm_scale[3 * dl + 1], li[8] = fresh ? 1.0 : T.lm_scale[3 * dl + 2];
+      li[9] = T.lm_const[dl] ? 0.0 : 1.0;
+      lmp[4 * tid] = lm_src[3 * dl], lmp[4 * tid + 1] = lm_src[3 * dl + 1], lmp[4 * tid + 2] = lm_src[3 * dl + 2];
     }
   }
+  // stable counting sort of the record slots by (segment offset, landmark-major index): rank inside the wave from ballots
+  int my_rank = 0;
+  for (int o = 0; o < nseg; ++o) {
+    const unsigned long long m = __ballot(my_o == o);
+    if (my_o == o) my_rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wave * bw + o] = __popcll(m);
+  }
   __syncthreads();
-  const double* cps_v = cps_l - 8 * cf;  // indexed by absolute control point
-
-  // ---- lane roles of the J_p'J_p accumulation (phase 3) ----
-  const bool p_lane = tid < NS * nband;
-  const int p_s = p_lane ? tid / nband : 0, p_tb = p_lane ? tid % nband : 0;
-  int p_d = 0, p_rb = p_tb;
+  HS_BSTAMP(1);
+  if (wave == 1) {  // relative rotations of the window's consecutive control points: once per pair, not once per residual and pair
+    const int ncp_w = min(bw, T.sp.n_cp - cf);
+    if (lane + 1 < ncp_w) relp[lane] = rel_precompute(cps_l + 8 * lane, cps_l + 8 * lane + 8);
+  }
+  if (wave == 0) {  // seg_start[o] = records with a smaller segment offset: inclusive scan over the lanes of wave 0
+    const int tot = lane < nseg ? wave_cnt[lane] + wave_cnt[bw + lane] + wave_cnt[2 * bw + lane] + wave_cnt[3 * bw + lane] : 0;
+    int inc = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(inc, d);
+      if (lane >= d) inc += up;
+    }
+    if (lane < nseg) seg_start[lane + 1] = inc;
+    if (lane == 0) seg_start[0] = 0;
+  }
+  __syncthreads();
+  int my_slot = 0;
+  if (has_rec) {
+    my_slot = seg_start[my_o] + my_rank;
+    for (int ww = 0; ww < wave; ++ww) my_slot += wave_cnt[ww * bw + my_o];
+    slot_lm[my_slot] = my_l;
+  }
+  for (int e = tid; e < nseg * (Lmax + 1); e += kBlock) pos[e] = seg_start[e / (Lmax + 1) + 1];  // default: the end of the segment's run
+  __syncthreads();
+  HS_BSTAMP(2);
+  // ---- 1: linearise into the sorted slot (no global loads from here to phase 4); pos[o][l'] = my slot for the landmarks l' between my
+  //         predecessor's (exclusive) and mine ----
+  if (has_rec) {
+    const int l_prev = my_slot > seg_start[my_o] ? slot_lm[my_slot - 1] : -1;
+    for (int l = l_prev + 1; l <= my_l; ++l) pos[my_o * (Lmax + 1) + l] = my_slot;
+    double* rec = recs + my_slot * CS;
+    in.cam = camid < kBuildCams ? cams + 16 * camid : T.cam + kCamStride * camid;
+    in.lm[0] = lmp[4 * my_l], in.lm[1] = lmp[4 * my_l + 1], in.lm[2] = lmp[4 * my_l + 2];
+    // (cps_l / frozen are indexed by absolute control point)
+    const double cost = visual_linearize_compact<K>(T, cps_l - 8 * cf, relp - cf, frozen - cf, in, robustify != 0, rec);
+    // A'A, A'r and the cost of this record (the landmark's H_ll and b_l are their sums in table order)
+    const double a0 = rec[2], a1 = rec[3], a2 = rec[4], a3 = rec[5], a4 = rec[6], a5 = rec[7], r0 = rec[0], r1 = rec[1];
+    double* h = hbr + 10 * tid;
+    h[0] = fma(a0, a0, a3 * a3), h[1] = fma(a0, a1, a3 * a4), h[2] = fma(a0, a2, a3 * a5);
+    h[3] = fma(a1, a1, a4 * a4), h[4] = fma(a1, a2, a4 * a5), h[5] = fma(a2, a2, a5 * a5);
+    h[6] = fma(a0, r0, a3 * r1), h[7] = fma(a1, r0, a4 * r1), h[8] = fma(a2, r0, a5 * r1);
+    h[9] = cost;
+  }
+  HS_BSTAMP(3);
+  __syncthreads();
+  HS_BSTAMP(4);
+  // ---- 2a: H_ll / b_l (lane <-> landmark, entry); cost partials (8 lanes, fixed order) ----
+  if (tid < 9 * nl) {
+    const int l = tid / 9, e = tid - 9 * l;
+    double acc = 0.0;
+    for (int t = lp[l]; t < lp[l + 1]; ++t) acc += hbr[10 * t + e];
+    Hb[10 * l + e] = acc;
+  } else if (tid >= kBlock - 8) {
+    const int g = tid - (kBlock - 8), per = (nres + 7) / 8;
+    double acc = 0.0;
+    for (int t = g * per; t < min(nres, (g + 1) * per); ++t) acc += hbr[10 * t + 9];
+    cpart[g] = acc;
+  }
+  __syncthreads();  // the W rows take the place of the per-record sums
+  // ---- 2b: W_l blocks, lane <-> (landmark, control point): ONE loop over the records that contribute (runs of K segments) ----
+  const int n_task_w = nl * bw;
+  for (int tau = tid; tau < n_task_w; tau += kBlock) {
+    const int l = int((unsigned(tau) * bw_magic) >> 20), jb = tau - l * bw;
+    double wacc[18];
+#pragma unroll
+    for (int e = 0; e < 18; ++e) wacc[e] = 0.0;
+    // run of (segment jb - jj, landmark l), requested for all K segments at once; cum[jj] = records in the runs 0 .. jj
+    // (a block beyond the landmark's control points has no records: its rows are written as zeros, which is what lets phase 5 walk every
+    //  landmark without masking its operands)
+    int run_lo[K], cum[K];
+    int total = 0;
+    const bool in_rows = jb < l_ncp[l];
+#pragma unroll
+    for (int jj = 0; jj < K; ++jj) {
+      const int o = jb - jj;
+      const bool ok = in_rows && o >= 0 && o < nseg;
+      const int* pp = pos + (ok ? o : 0) * (Lmax + 1) + l;
+      const int a = pp[0], b = pp[1];
+      run_lo[jj] = a, total += ok ? b - a : 0, cum[jj] = total;
+    }
+    // h-th contributing record: run jj, slot s. Two operand sets alternate: the loads of record h + 1 are in flight during the products
+    // of record h, and nothing is copied between them.
+#define HS_W_LOAD(h_, dst)                                                   \
+  {                                                                          \
+    int jj_ = 0, s_ = run_lo[0] + (h_);                                      \
+    _Pragma("unroll") for (int x = 1; x < K; ++x) if ((h_) >= cum[x - 1]) jj_ = x, s_ = run_lo[x] + (h_)-cum[x - 1]; \
+    dst = w_ops_load(recs + s_ * CS, jj_);                                   \
+  }
+    WOps opa, opb;
+    if (total > 0) HS_W_LOAD(0, opa);
+    for (int h = 0; h < total; h += 2) {
+      if (h + 1 < total) HS_W_LOAD(h + 1, opb);
+      w_ops_apply(opa, wacc);
+      if (h + 1 < total) {
+        if (h + 2 < total) HS_W_LOAD(h + 2, opa);
+        w_ops_apply(opb, wacc);
+      }
+    }
+#undef HS_W_LOAD
+    double* wr = Wy + (size_t(l) * R6 + 6 * jb) * 3;
+#pragma unroll
+    for (int e = 0; e < 18; e += 2) *reinterpret_cast<double2*>(wr + e) = make_double2(wacc[e], wacc[e + 1]);
+  }
+  HS_BSTAMP(5);
+  // ---- 3: J_p'J_p band tiles: lane group g = tid / NS serves tile (g mod 16) * 4 + g / 16 (NS = 4: every wave gets tiles of every
+  //         diagonal offset — the diagonal tiles see K segments, the outermost one), stream = tid mod NS ----
+  const int NS = build_streams(nband);
+  const int p_g = tid / NS, p_s = tid - p_g * NS;
+  const int p_tb = NS == 4 ? (p_g & 15) * 4 + (p_g >> 4) : p_g;
+  const bool p_lane = p_tb < nband;
+  int p_d = 0, p_rb = p_lane ? p_tb : 0;
   while (p_rb >= bw - p_d) p_rb -= bw - p_d, ++p_d;  // tiles of offset d: bw - d
   double pacc[36], pg[6];
 #pragma unroll
   for (int e = 0; e < 36; ++e) pacc[e] = 0.0;
 #pragma unroll
   for (int e = 0; e < 6; ++e) pg[e] = 0.0;
-
-  double cost = 0.0;
-  const int n_task_w = nl * R6, n_task = n_task_w + 9 * nl;
-  for (int p0 = 0; p0 < nres; p0 += R) {
-    const int n_p = min(R, nres - p0);
-    // ---- 1: linearise ----
-    int my_o = -1;
-    if (tid < n_p) {
-      int first;
-      cost += visual_linearize_compact<K>(T, cps_v, q0 + p0 + tid, robustify != 0, lm_src, recs + tid * CS, &first);
-      my_o = first - cf;
-      segoff[tid] = my_o;
-    }
-    // stable counting sort of the pass's record slots by segment offset: rank inside the wave from ballots, wave totals through LDS
-    int my_rank = 0;
-    for (int o = 0; o < nseg; ++o) {
-      const unsigned long long m = __ballot(my_o == o);
-      if (my_o == o) my_rank = __popcll(m & ((1ull << lane) - 1ull));
-      if (lane == 0) wave_cnt[wave * bw + o] = __popcll(m);
-    }
-    __syncthreads();  // records, segoff, wave_cnt visible; (pass > 0) the previous pass's consumers are done — see the barrier at the loop end
-    if (tid <= nseg) {  // seg_start[o] = records with a smaller segment offset
-      int s = 0;
-      for (int o = 0; o < tid; ++o) s += wave_cnt[o] + wave_cnt[bw + o] + wave_cnt[2 * bw + o] + wave_cnt[3 * bw + o];
-      seg_start[tid] = s;
-    }
-    __syncthreads();
-    if (my_o >= 0) {
-      int pos = seg_start[my_o] + my_rank;
-      for (int ww = 0; ww < wave; ++ww) pos += wave_cnt[ww * bw + my_o];
-      sorted[pos] = tid;
-    }
-    // (phase 2 below reads the records and segoff only; `sorted` is first read behind the next barrier)
-    // ---- 2: W_l rows (lane <-> landmark, row), H_ll / b_l entries (lane <-> landmark, entry) ----
-    for (int tau = tid; tau < n_task; tau += kBlock) {
-      if (tau < n_task_w) {
-        const int l = tau / R6, rho = tau - l * R6;
-        if (rho >= 6 * l_ncp[l]) continue;
-        const int jb = rho / 6, c = rho - 6 * jb;
-        const int t_lo = max(lp[l], p0) - p0, t_hi = min(lp[l + 1], p0 + R) - p0;
-        double* wr = Wy + (size_t(l) * R6 + rho) * 3;
-        double w0 = p0 ? wr[0] : 0.0, w1 = p0 ? wr[1] : 0.0, w2 = p0 ? wr[2] : 0.0;
-        for (int t = t_lo; t < t_hi; ++t) {
-          const int jj = jb - segoff[t];
-          if (jj < 0 || jj >= K) continue;
-          const double* rec = recs + t * CS;
-          double j0, j1;
-          if (c < 3) {
-            j0 = rec[8 + K + 3 * jj + c], j1 = rec[8 + 4 * K + 3 * jj + c];
-          } else {
-            const double nb = -rec[8 + jj];
-            j0 = nb * rec[2 + c - 3], j1 = nb * rec[5 + c - 3];
-          }
-          w0 = fma(j0, rec[2], fma(j1, rec[5], w0));
-          w1 = fma(j0, rec[3], fma(j1, rec[6], w1));
-          w2 = fma(j0, rec[4], fma(j1, rec[7], w2));
-        }
-        wr[0] = w0, wr[1] = w1, wr[2] = w2;
-      } else {
-        const int tl = tau - n_task_w, l = tl / 9, e = tl - 9 * l;
-        const int t_lo = max(lp[l], p0) - p0, t_hi = min(lp[l + 1], p0 + R) - p0;
-        // e: 0..5 = H00 H01 H02 H11 H12 H22, 6..8 = b0 b1 b2  (x = row index of the first factor, y = second factor / residual)
-        const int x = e < 3 ? 0 : (e < 5 ? 1 : (e < 6 ? 2 : e - 6));
-        const int y = e < 3 ? e : (e < 5 ? e - 2 : 2);
-        double acc = p0 ? Hb[10 * l + e] : 0.0;
-        for (int t = t_lo; t < t_hi; ++t) {
-          const double* rec = recs + t * CS;
-          if (e < 6)
-            acc = fma(rec[2 + x], rec[2 + y], fma(rec[5 + x], rec[5 + y], acc));
-          else
-            acc = fma(rec[2 + x], rec[0], fma(rec[5 + x], rec[1], acc));
-        }
-        Hb[10 * l + e] = acc;
-      }
-    }
-    __syncthreads();  // `sorted` complete
-    // ---- 3: J_p'J_p band tiles ----
-    if (p_lane) {
-      const int o_lo = max(0, p_rb + p_d - K + 1), o_hi = min(p_rb, nseg - 1);
-      if (o_lo <= o_hi) {
-        const int i_hi = seg_start[o_hi + 1];
-        for (int idx = seg_start[o_lo] + p_s; idx < i_hi; idx += NS) {
-          const int t = sorted[idx];
-          const double* rec = recs + t * CS;
-          const int o = segoff[t], a = p_rb - o, b = a + p_d;
-          const double na = -rec[8 + a], nb = -rec[8 + b];
-          double ja[2][6], jb[2][6];
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              const double Ai = rec[2 + 3 * i + c];
-              ja[i][c] = rec[8 + K + 3 * K * i + 3 * a + c], ja[i][3 + c] = na * Ai;
-              jb[i][c] = rec[8 + K + 3 * K * i + 3 * b + c], jb[i][3 + c] = nb * Ai;
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = 0; c < 6; ++c) pacc[6 * r + c] = fma(ja[0][r], jb[0][c], fma(ja[1][r], jb[1][c], pacc[6 * r + c]));
-          if (p_d == 0) {
-            const double r0 = rec[0], r1 = rec[1];
-#pragma unroll
-            for (int r = 0; r < 6; ++r) pg[r] = fma(ja[0][r], r0, fma(ja[1][r], r1, pg[r]));
-          }
-        }
-      }
-    }
-    __syncthreads();  // the next pass overwrites the records / the stream tiles below alias them
-  }
-  // per-stream P tiles -> LDS (aliases the records: everybody is past the barrier above)
-  double* Ps = recs;  // [NS][nband][42]
   if (p_lane) {
-    double* dst = Ps + (size_t(p_s) * nband + p_tb) * 42;
+    // the runs of the <= K segments that cover both blocks of the tile, this stream's share of each; one loop over all of them
+    const int o_hi = min(p_rb, nseg - 1);
+    int run_lo[K], cum[K];
+    int total = 0;
+#pragma unroll
+    for (int x = 0; x < K; ++x) {
+      const int o = o_hi - x;  // block a = p_rb - o = (p_rb - o_hi) + x
+      const bool ok = o >= 0 && o >= p_rb + p_d - K + 1;
+      const int a0 = seg_start[ok ? o : 0], a1 = seg_start[(ok ? o : 0) + 1];
+      run_lo[x] = a0 + p_s;
+      total += ok && a1 > a0 + p_s ? (a1 - a0 - p_s + NS - 1) / NS : 0, cum[x] = total;
+    }
+    const int a_base = p_rb - o_hi;
+#define HS_T_LOAD(h_, dst)                                                   \
+  {                                                                          \
+    int x_ = 0, s_ = run_lo[0] + NS * (h_);                                  \
+    _Pragma("unroll") for (int x = 1; x < K; ++x) if ((h_) >= cum[x - 1]) x_ = x, s_ = run_lo[x] + NS * ((h_)-cum[x - 1]); \
+    dst = tile_ops_load(recs + s_ * CS, a_base + x_, a_base + x_ + p_d);     \
+  }
+    TileOps opa, opb;  // two operand sets alternate (no copies): record h + 1 is in flight during the products of record h
+    if (total > 0) HS_T_LOAD(0, opa);
+    for (int h = 0; h < total; h += 2) {
+      if (h + 1 < total) HS_T_LOAD(h + 1, opb);
+      tile_ops_apply(opa, p_d == 0, pacc, pg);
+      if (h + 1 < total) {
+        if (h + 2 < total) HS_T_LOAD(h + 2, opa);
+        tile_ops_apply(opb, p_d == 0, pacc, pg);
+      }
+    }
+#undef HS_T_LOAD
+  }
+  // the streams of a tile are adjacent lanes: butterfly sums, (s0 + s1) + (s2 + s3) on every lane of the group
+  for (int m = 1; m < NS; m <<= 1) {
+#pragma unroll
+    for (int e = 0; e < 36; ++e) pacc[e] += __shfl_xor(pacc[e], m);
+#pragma unroll
+    for (int e = 0; e < 6; ++e) pg[e] += __shfl_xor(pg[e], m);
+  }
+  HS_BSTAMP(6);
+  __syncthreads();  // everybody is done with the records: the combined P tiles take their place
+  HS_BSTAMP(7);
+  double* Pc = recs;  // [nband][42]
+  if (p_lane && p_s == 0) {
+    double* dst = Pc + size_t(p_tb) * 42;
 #pragma unroll
     for (int e = 0; e < 36; e += 2) *reinterpret_cast<double2*>(dst + e) = make_double2(pacc[e], pacc[e + 1]);
 #pragma unroll
     for (int e = 0; e < 6; e += 2) *reinterpret_cast<double2*>(dst + 36 + e) = make_double2(pg[e], pg[e + 1]);
   }
-  // ---- 4: landmark elimination: V = S_l H_ll S_l + D_l^2 = L L', Y-hat = W S_l L^-T (landmark_finish of k_landmark, per row lane) ----
-  const double inv_radius = 1.0 / radius;
-  for (int tau = tid; tau < n_task_w; tau += kBlock) {
-    const int l = tau / R6, rho = tau - l * R6;
-    if (rho >= 6 * l_ncp[l]) continue;
-    const int dl = lo + l;
-    const double lmf = slo[4 * l + 3];  // 0: constant landmark (J_l = 0)
+  // ---- 4a: V = S_l H_ll S_l + D_l^2 = L L' per landmark (landmark_finish of k_landmark); the last wave, which holds the fewest tiles ----
+  if (tid >= kBlock - 64 && tid - (kBlock - 64) < nl) {
+    const int l = tid - (kBlock - 64), dl = lo + l;
+    double* li = Linv + kLinv * l;
+    const double lmf = li[9];  // 0: constant landmark (J_l = 0)
     const double* h = Hb + 10 * l;
     const double h0 = lmf * h[0], h1 = lmf * h[1], h2 = lmf * h[2], h3 = lmf * h[3], h4 = lmf * h[4], h5 = lmf * h[5];
     const double b0 = lmf * h[6], b1 = lmf * h[7], b2 = lmf * h[8];
@@ -258,9 +399,10 @@ __global__ void __launch_bounds__(kBlock) k_build_visual(Tables T, int R, int Lm
     if (fresh)
       sl0 = 1.0 / (1.0 + sqrt(h0)), sl1 = 1.0 / (1.0 + sqrt(h3)), sl2 = 1.0 / (1.0 + sqrt(h5));
     else
-      sl0 = slo[4 * l], sl1 = slo[4 * l + 1], sl2 = slo[4 * l + 2];
+      sl0 = li[6], sl1 = li[7], sl2 = li[8];
     double v00 = sl0 * sl0 * h0, v01 = sl0 * sl1 * h1, v02 = sl0 * sl2 * h2;
     double v11 = sl1 * sl1 * h3, v12 = sl1 * sl2 * h4, v22 = sl2 * sl2 * h5;
+    const double inv_radius = 1.0 / radius;
     const double d0 = fmin(fmax(v00, 1e-6), 1e32) * inv_radius, d1 = fmin(fmax(v11, 1e-6), 1e32) * inv_radius, d2 = fmin(fmax(v22, 1e-6), 1e32) * inv_radius;
     v00 += d0, v11 += d1, v22 += d2;
     auto rsqrt_refined = [](double d) {  // hardware estimate + one third-order correction: full double accuracy, no divide / sqrt sequence
@@ -272,31 +414,55 @@ __global__ void __launch_bounds__(kBlock) k_build_visual(Tables T, int R, int Lm
     const double p11 = v11 - l10 * l10, i11 = rsqrt_refined(p11), l11 = p11 * i11, l21 = (v12 - l20 * l10) * i11;
     const double p22 = v22 - l20 * l20 - l21 * l21, i22 = rsqrt_refined(p22), l22 = p22 * i22;
     const bool active = lmf != 0.0;
-    double* wr = Wy + (size_t(l) * R6 + rho) * 3;
-    const double w0 = lmf * wr[0] * sl0, w1 = lmf * wr[1] * sl1, w2 = lmf * wr[2] * sl2;
-    double a0 = w0 * i00, a1 = (w1 - a0 * l10) * i11, a2 = (w2 - a0 * l20 - a1 * l21) * i22;
-    if (!active) a0 = a1 = a2 = 0.0;
-    wr[0] = a0, wr[1] = a1, wr[2] = a2;
-    double* Y = T.Y + l_yoff[l] + 3 * rho;
-    Y[0] = a0, Y[1] = a1, Y[2] = a2;
-    if (rho == 0) {
-      const double sb0 = sl0 * b0, sb1 = sl1 * b1, sb2 = sl2 * b2;
-      const double y0 = sb0 * i00, y1 = (sb1 - l10 * y0) * i11, y2 = (sb2 - l20 * y0 - l21 * y1) * i22;
-      double* L = T.lm_L + 6 * dl;
-      L[0] = l00, L[1] = l10, L[2] = l11, L[3] = l20, L[4] = l21, L[5] = l22;
-      const double yy0 = active ? y0 : 0.0, yy1 = active ? y1 : 0.0, yy2 = active ? y2 : 0.0;
-      T.lm_yhat[3 * dl] = yy0, T.lm_yhat[3 * dl + 1] = yy1, T.lm_yhat[3 * dl + 2] = yy2;
-      yhs[4 * l] = yy0, yhs[4 * l + 1] = yy1, yhs[4 * l + 2] = yy2;
-      T.lm_sb[3 * dl] = sb0, T.lm_sb[3 * dl + 1] = sb1, T.lm_sb[3 * dl + 2] = sb2;
-      T.lm_D2[3 * dl] = d0, T.lm_D2[3 * dl + 1] = d1, T.lm_D2[3 * dl + 2] = d2;
-      T.lm_gmax[dl] = active ? fmax(fabs(b0), fmax(fabs(b1), fabs(b2))) : 0.0;
-      if (fresh) T.lm_scale[3 * dl] = sl0, T.lm_scale[3 * dl + 1] = sl1, T.lm_scale[3 * dl + 2] = sl2;
+    const double sb0 = sl0 * b0, sb1 = sl1 * b1, sb2 = sl2 * b2;
+    const double y0 = sb0 * i00, y1 = (sb1 - l10 * y0) * i11, y2 = (sb2 - l20 * y0 - l21 * y1) * i22;
+    const double yy0 = active ? y0 : 0.0, yy1 = active ? y1 : 0.0, yy2 = active ? y2 : 0.0;
+    li[0] = i00, li[1] = l10, li[2] = i11, li[3] = l20, li[4] = l21, li[5] = i22;
+    li[6] = sl0, li[7] = sl1, li[8] = sl2;
+    li[10] = yy0, li[11] = yy1, li[12] = yy2;
+    double* L = T.lm_L + 6 * dl;
+    L[0] = l00, L[1] = l10, L[2] = l11, L[3] = l20, L[4] = l21, L[5] = l22;
+    T.lm_yhat[3 * dl] = yy0, T.lm_yhat[3 * dl + 1] = yy1, T.lm_yhat[3 * dl + 2] = yy2;
+    T.lm_sb[3 * dl] = sb0, T.lm_sb[3 * dl + 1] = sb1, T.lm_sb[3 * dl + 2] = sb2;
+    T.lm_D2[3 * dl] = d0, T.lm_D2[3 * dl + 1] = d1, T.lm_D2[3 * dl + 2] = d2;
+    T.lm_gmax[dl] = active ? fmax(fabs(b0), fmax(fabs(b1), fabs(b2))) : 0.0;
+    if (fresh) T.lm_scale[3 * dl] = sl0, T.lm_scale[3 * dl + 1] = sl1, T.lm_scale[3 * dl + 2] = sl2;
+  }
+  __syncthreads();
+  HS_BSTAMP(8);
+  // ---- 4b: Y-hat = W S_l L^-T, one 6 x 3 block per lane ----
+  for (int tau = tid; tau < n_task_w; tau += kBlock) {
+    const int l = int((unsigned(tau) * bw_magic) >> 20), jb = tau - l * bw;
+    if (jb >= l_ncp[l]) continue;
+    const double* li = Linv + kLinv * l;
+    const double i00 = li[0], l10 = li[1], i11 = li[2], l20 = li[3], l21 = li[4], i22 = li[5];
+    const double s0 = li[6] * li[9], s1 = li[7] * li[9], s2 = li[8] * li[9];  // (constant landmark: zero rows)
+    double* wr = Wy + (size_t(l) * R6 + 6 * jb) * 3;
+    double y[18];
+#pragma unroll
+    for (int e = 0; e < 18; e += 2) {
+      const double2 v = *reinterpret_cast<const double2*>(wr + e);
+      y[e] = v.x, y[e + 1] = v.y;
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const double w0 = y[3 * r] * s0, w1 = y[3 * r + 1] * s1, w2 = y[3 * r + 2] * s2;
+      const double a0 = w0 * i00, a1 = (w1 - a0 * l10) * i11, a2 = (w2 - a0 * l20 - a1 * l21) * i22;
+      y[3 * r] = a0, y[3 * r + 1] = a1, y[3 * r + 2] = a2;
+    }
+    double* Y = T.Y + l_yoff[l] + 18 * jb;
+#pragma unroll
+    for (int e = 0; e < 18; e += 2) {
+      *reinterpret_cast<double2*>(wr + e) = make_double2(y[e], y[e + 1]);
+      *reinterpret_cast<double2*>(Y + e) = make_double2(y[e], y[e + 1]);
     }
   }
   __syncthreads();
-  // ---- 5: Q = - sum_l Yh_l Yh_l' over the window tiles, q = - sum_l Yh_l yh_l (diagonal tiles) ----
-  const bool two = ntile <= kBlock / 2;
-  const int q_s = two ? tid / (kBlock / 2) : 0, q_ns = two ? 2 : 1, q_t = two ? tid % (kBlock / 2) : tid;
+  HS_BSTAMP(9);
+  // ---- 5: Q = - sum_l Yh_l Yh_l' over the window tiles, q = - sum_l Yh_l yh_l (diagonal tiles): lane = QS * tile + stream.
+  //         Branch-free over the landmarks (a tile outside a landmark's rows reads zero rows), two landmarks in flight. ----
+  const int QS = ntile <= kBlock / 2 ? 2 : 1;
+  const int q_t = tid / QS, q_s = tid - q_t * QS;
   const bool q_ok = q_t < ntile;
   int q_rb = 0, q_cb = 0;
   {
@@ -311,85 +477,66 @@ __global__ void __launch_bounds__(kBlock) k_build_visual(Tables T, int R, int Lm
   for (int e = 0; e < 6; ++e) qacc[e] = 0.0;
   if (q_ok) {
     const bool diag = q_rb == q_cb;
-    for (int l = q_s; l < nl; l += q_ns) {
-      if (q_cb >= l_ncp[l]) continue;
-      const double* Yb = Wy + size_t(l) * R6 * 3;
-      double B[18];
+#pragma unroll 2
+    for (int l = q_s; l < nl; l += QS) {
+      const double* Yb = Wy + size_t(l) * R6 * 3;  // (rows beyond the landmark's control points are zeros: phase 2b)
+      double A[18], B[18];
 #pragma unroll
       for (int e = 0; e < 18; e += 2) {
-        const double2 vb = *reinterpret_cast<const double2*>(Yb + 18 * q_cb + e);
-        B[e] = vb.x, B[e + 1] = vb.y;
+        const double2 va = *reinterpret_cast<const double2*>(Yb + 18 * q_rb + e), vb = *reinterpret_cast<const double2*>(Yb + 18 * q_cb + e);
+        A[e] = va.x, A[e + 1] = va.y, B[e] = vb.x, B[e + 1] = vb.y;
       }
-      const double y0 = yhs[4 * l], y1 = yhs[4 * l + 1], y2 = yhs[4 * l + 2];
+      const double* li = Linv + kLinv * l;
+      const double y0 = li[10], y1 = li[11], y2 = li[12];
 #pragma unroll
-      for (int rp = 0; rp < 3; ++rp) {
-        double A[6];
+      for (int r = 0; r < 6; ++r) {
 #pragma unroll
-        for (int e = 0; e < 6; e += 2) {
-          const double2 va = *reinterpret_cast<const double2*>(Yb + 18 * q_rb + 6 * rp + e);
-          A[e] = va.x, A[e + 1] = va.y;
-        }
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-          const int r = 2 * rp + rr;
-#pragma unroll
-          for (int c = 0; c < 6; ++c)
-            acc[6 * r + c] = fma(-A[3 * rr + 2], B[3 * c + 2], fma(-A[3 * rr + 1], B[3 * c + 1], fma(-A[3 * rr], B[3 * c], acc[6 * r + c])));
-          if (diag) qacc[r] = fma(-A[3 * rr + 2], y2, fma(-A[3 * rr + 1], y1, fma(-A[3 * rr], y0, qacc[r])));
-        }
+        for (int c = 0; c < 6; ++c)
+          acc[6 * r + c] = fma(-A[3 * r + 2], B[3 * c + 2], fma(-A[3 * r + 1], B[3 * c + 1], fma(-A[3 * r], B[3 * c], acc[6 * r + c])));
+        if (diag) qacc[r] = fma(-A[3 * r + 2], y2, fma(-A[3 * r + 1], y1, fma(-A[3 * r], y0, qacc[r])));
       }
     }
   }
-  __syncthreads();  // everybody is done with the Y-hat rows: stream 1 hands its tiles over through the same area
-  double* xch = Wy;
-  if (two && q_s == 1 && q_ok) {
+  if (QS == 2) {  // stream 0 + stream 1 (adjacent lanes)
 #pragma unroll
-    for (int e = 0; e < 36; e += 2) *reinterpret_cast<double2*>(xch + q_t * 42 + e) = make_double2(acc[e], acc[e + 1]);
+    for (int e = 0; e < 36; ++e) acc[e] += __shfl_xor(acc[e], 1);
 #pragma unroll
-    for (int e = 0; e < 6; e += 2) *reinterpret_cast<double2*>(xch + q_t * 42 + 36 + e) = make_double2(qacc[e], qacc[e + 1]);
+    for (int e = 0; e < 6; ++e) qacc[e] += __shfl_xor(qacc[e], 1);
   }
-  __syncthreads();
-  // ---- 6: combine (fixed order: Q stream 0 + stream 1, then the P streams in index order) and write the chunk partial ----
+  HS_BSTAMP(10);
+  // ---- 6: P + Q and the three vectors of the chunk partial -> HBM ----
   double* G = T.grpQ + size_t(w) * (size_t(ntile) * 36 + 3 * R6);
   if (q_s == 0 && q_ok) {
-    if (two) {
-#pragma unroll
-      for (int e = 0; e < 36; ++e) acc[e] += xch[q_t * 42 + e];
-#pragma unroll
-      for (int e = 0; e < 6; ++e) qacc[e] += xch[q_t * 42 + 36 + e];
-    }
     const int d = q_cb - q_rb;
     if (d < K) {
-      const int bi = band_tile_index(q_rb, d, bw);
-      double pt[36], gp[6];
-#pragma unroll
-      for (int e = 0; e < 36; ++e) pt[e] = 0.0;
-#pragma unroll
-      for (int e = 0; e < 6; ++e) gp[e] = 0.0;
-      for (int s = 0; s < NS; ++s) {
-        const double* src = Ps + (size_t(s) * nband + bi) * 42;
-#pragma unroll
-        for (int e = 0; e < 36; ++e) pt[e] += src[e];
-        if (d == 0)
-#pragma unroll
-          for (int e = 0; e < 6; ++e) gp[e] += src[36 + e];
-      }
+      const double* src = Pc + size_t(band_tile_index(q_rb, d, bw)) * 42;
       if (d == 0) {
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
           G[size_t(ntile) * 36 + 6 * q_rb + r] = qacc[r];
-          G[size_t(ntile) * 36 + R6 + 6 * q_rb + r] = gp[r];
-          G[size_t(ntile) * 36 + 2 * R6 + 6 * q_rb + r] = pt[7 * r];
+          G[size_t(ntile) * 36 + R6 + 6 * q_rb + r] = src[36 + r];
+          G[size_t(ntile) * 36 + 2 * R6 + 6 * q_rb + r] = src[7 * r];
         }
       }
 #pragma unroll
-      for (int e = 0; e < 36; ++e) acc[e] += pt[e];
+      for (int e = 0; e < 36; e += 2) {
+        const double2 v = *reinterpret_cast<const double2*>(src + e);
+        acc[e] += v.x, acc[e + 1] += v.y;
+      }
     }
 #pragma unroll
     for (int e = 0; e < 36; e += 2) *reinterpret_cast<double2*>(G + size_t(q_t) * 36 + e) = make_double2(acc[e], acc[e + 1]);
   }
-  const double s = block_sum(cost, red);
-  if (tid == 0) T.cost_part[w] = s;
+  HS_BSTAMP(11);
+  if (tid == 0) {
+    double s = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) s += cpart[g];
+    T.cost_part[w] = s;
+  }
+  HS_BSTAMP(12);
+  if (bprof) blog[13] = nres, blog[14] = nl, blog[15] = (long long)(__builtin_amdgcn_s_getreg(63492)) | ((long long)(__builtin_amdgcn_s_getreg(63508)) << 32);  // HW_ID | XCC_ID
+#undef HS_BSTAMP
 }
 
 }  // namespace hs

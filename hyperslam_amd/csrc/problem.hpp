@@ -99,6 +99,7 @@ struct Tables {
   const uint8_t* cp_const;
   // cameras / plain sensors
   const double* cam;       // n_cam x 16
+  int n_cam;
   const double* sensor;    // n_sensor x 8 (T_bs 7 + pad)
   // landmarks (device order)
   int n_lm;
@@ -218,6 +219,7 @@ struct Tables {
   // gw_ptr / gw_cf then list the chunks of a group and grpQ holds one partial [tiles | -Yh yh | J_p'r | diag J_p'J_p] per chunk
   int fused, n_chunk;
   const int* ch_ptr;
+  const int* ch_desc;  // n_chunk x 8: first landmark, landmarks, first control point, first residual, residuals (one 32-byte load per workgroup)
   int rank, world;
   int debug_flags;  // HS_DEBUG_FLAGS env (timing experiments; 0 in production)
   DevState* st;

@@ -131,6 +131,12 @@ class Optimizer<kOptimizerSuiteHIP> final : public AbstractOptimizer {
   /// derivative of the prediction (see include/hyperslam_hip.h).
   auto setInertialJacobian(const int mode) -> void { CHECK_EQ(hs_set_inertial_jacobian(handle_, mode), HS_OK) << hs_last_error(handle_); }
 
+  /// Retirement of inertial / pose-prior observations older than the window and every retained landmark (updateLandmarks). DEVIATION from
+  /// the Ceres backend, which never removes those residual blocks (and so never lets their control points go): default on, because the
+  /// library holds a bounded window (<= 1024 control points); off reproduces upstream's unbounded growth for as long as the tables fit.
+  /// Pose priors on control points that are still free are kept either way (they may be what fixes the gauge).
+  auto setRetireOldObservations(const bool retire) -> void { retire_old_observations_ = retire; }
+
   /// Knot spacing of the two bias splines updateSensor() creates (the reference has no YAML key for it; its test uses 10 state
   /// separations, tests/internal/tests/optimizers/evaluators/inertial.cpp:48-49). Takes effect for splines that are still empty.
   auto setBiasSeparation(const Stamp separation) -> void {
@@ -143,22 +149,38 @@ class Optimizer<kOptimizerSuiteHIP> final : public AbstractOptimizer {
     if (bearings_.empty() && pixels_.empty() && priors_.empty() && inertials_.empty()) return;
     const auto order = state().interpolator()->layout().outer.size;  // control points per segment (k)
 
-    // ---- control points: the state elements Ceres holds parameter blocks for (variables_, cc:296-306), in stamp order ----
+    // ---- control points: the state elements Ceres holds parameter blocks for (variables_, cc:296-306), in stamp order. The library's
+    //      basis is uniform — control point j sits at t0 + j * separation and hs_set_spline rejects a table whose stamps say otherwise —
+    //      so the table is the CONTIGUOUS run of state elements between the oldest and the newest parameter block. updateState() only
+    //      ever drops a prefix / suffix of that run; should an element in between not be a parameter block (it is not in variables_), it
+    //      rides along as a constant row instead of silently re-indexing every later control point. ----
+    CHECK(!variables_.empty());
+    auto oldest_stamp = std::numeric_limits<Stamp>::max(), newest_stamp = std::numeric_limits<Stamp>::lowest();
+    for (const auto* variable : variables_) oldest_stamp = std::min(oldest_stamp, variable->stamp()), newest_stamp = std::max(newest_stamp, variable->stamp());
     std::vector<StampedManifold*> cps;
-    for (auto* variable : variables_) cps.push_back(static_cast<StampedManifold*>(variable));
-    std::sort(cps.begin(), cps.end(), [](const auto* a, const auto* b) { return a->stamp() < b->stamp(); });
+    std::vector<std::uint8_t> cp_constant;
+    const auto& elements = state().elements();
+    for (auto itr = elements.lower_bound(oldest_stamp); itr != elements.end() && (*itr)->stamp() <= newest_stamp; ++itr) {
+      cps.push_back(static_cast<StampedManifold*>(itr->get()));
+      const auto stamp = (*itr)->stamp();
+      cp_constant.push_back((!variables_.contains(itr->get()) || stamp <= window_.lowerBound() || newest_stamp < stamp) ? 1 : 0);  // cc:319-328
+    }
     CHECK_GE(cps.size(), static_cast<std::size_t>(order));
     std::vector<double> cp(8 * cps.size());
-    std::vector<std::uint8_t> cp_constant(cps.size());
-    const auto stamp_n = cps.back()->stamp();
-    for (std::size_t j = 0; j < cps.size(); ++j) {
-      const auto vector = cps[j]->asVector();  // [q(4) p(3) t], stamped.hpp:35-36
-      std::copy_n(vector.data(), 8, &cp[8 * j]);
-      const auto stamp = cps[j]->stamp();
-      cp_constant[j] = (stamp <= window_.lowerBound() || stamp_n < stamp) ? 1 : 0;  // cc:319-328
-    }
-    check(hs_set_spline(handle_, order, cps.front()->stamp(), separation_, static_cast<int>(cps.size()), cp.data(), cp_constant.data(), rotation_constant_,
-                        translation_constant_));
+    for (std::size_t j = 0; j < cps.size(); ++j) std::copy_n(cps[j]->asVector().data(), 8, &cp[8 * j]);  // [q(4) p(3) t], stamped.hpp:35-36
+    const auto t0 = cps.front()->stamp();
+    check(hs_set_spline(handle_, order, t0, separation_, static_cast<int>(cps.size()), cp.data(), cp_constant.data(), rotation_constant_, translation_constant_));
+    // Upstream admits a message with state().range().contains(stamp) on the elements' ACCUMULATED stamps (abstract.cpp:103-106, 127-137);
+    // the library derives the segment from t0 + j * separation. The two agree except in the last bits of a stamp on a knot: a stamp
+    // that upstream admitted and the uniform arithmetic puts one segment outside the table is moved by those last bits.
+    const auto n_segments = static_cast<std::ptrdiff_t>(cps.size()) - order + 1;
+    const auto admitted = [&](Stamp stamp) {
+      const auto segment = [&](const Stamp s) { return static_cast<std::ptrdiff_t>(std::floor((s - t0) / separation_)) - (order - 1) / 2; };
+      for (auto i = 0; i < 4 && segment(stamp) >= n_segments && stamp - newest_stamp < 1e-9 * separation_; ++i)
+        stamp = std::nextafter(stamp, std::numeric_limits<Stamp>::lowest());
+      for (auto i = 0; i < 4 && segment(stamp) < 0 && oldest_stamp - stamp < 1e-9 * separation_; ++i) stamp = std::nextafter(stamp, std::numeric_limits<Stamp>::max());
+      return stamp;
+    };
 
     // ---- sensors: sensor.parameters() in Traits order (cc:143-155); constant blocks (camera.hpp:18, imu.hpp:18) ----
     std::vector<double> cam_T(7 * cameras_.size()), cam_i(4 * cameras_.size()), cam_d(4 * cameras_.size());
@@ -192,7 +214,7 @@ class Optimizer<kOptimizerSuiteHIP> final : public AbstractOptimizer {
       std::vector<std::int32_t> ids, cams;
       for (const auto* o : bearings_) {
         const auto& m = o->measurement();
-        stamps.push_back(m.stamp()), ids.push_back(landmark_id.at(&o->landmark())), cams.push_back(camera_index_.at(&m.sensor()));
+        stamps.push_back(admitted(m.stamp())), ids.push_back(landmark_id.at(&o->landmark())), cams.push_back(camera_index_.at(&m.sensor()));
         const auto v = m.variable().asVector();
         values.insert(values.end(), v.data(), v.data() + 3);
       }
@@ -200,7 +222,7 @@ class Optimizer<kOptimizerSuiteHIP> final : public AbstractOptimizer {
       stamps.clear(), values.clear(), ids.clear(), cams.clear();
       for (const auto* o : pixels_) {
         const auto& m = o->measurement();
-        stamps.push_back(m.stamp()), ids.push_back(landmark_id.at(&o->landmark())), cams.push_back(camera_index_.at(&m.sensor()));
+        stamps.push_back(admitted(m.stamp())), ids.push_back(landmark_id.at(&o->landmark())), cams.push_back(camera_index_.at(&m.sensor()));
         const auto v = m.variable().asVector();
         values.insert(values.end(), v.data(), v.data() + 2);
       }
@@ -208,7 +230,7 @@ class Optimizer<kOptimizerSuiteHIP> final : public AbstractOptimizer {
       stamps.clear(), values.clear(), ids.clear();
       for (const auto* o : priors_) {
         const auto& m = o->measurement();
-        stamps.push_back(m.stamp()), ids.push_back(pose_sensor_index_.at(&m.sensor()));
+        stamps.push_back(admitted(m.stamp())), ids.push_back(pose_sensor_index_.at(&m.sensor()));
         const auto v = m.variable().asVector();  // SE3 [q(4) p(3)]
         values.insert(values.end(), v.data(), v.data() + 7);
       }
@@ -255,7 +277,7 @@ class Optimizer<kOptimizerSuiteHIP> final : public AbstractOptimizer {
       std::vector<double> stamps, values;
       for (const auto* o : inertials_) {
         const auto& m = o->measurement();
-        stamps.push_back(m.stamp());
+        stamps.push_back(admitted(m.stamp()));
         const auto v = m.variable().asVector();  // Tangent<SE3> [angular(3) linear(3)]
         values.insert(values.end(), v.data(), v.data() + 6);
       }
@@ -333,12 +355,22 @@ class Optimizer<kOptimizerSuiteHIP> final : public AbstractOptimizer {
     // longer is a constant block without residuals (harmless), one that leaves too early would fail the library's range check.
     const auto ahead = separation_ * right_padding;
     const auto behind = separation_ * (left_padding + 2);
-    std::erase_if(variables_, [&](const auto* variable) {
+    const auto unused = [&](const auto* variable) {
       const auto stamp = variable->stamp();
       if (!(stamp < stamp_0 || stamp_n < stamp)) return false;
       const auto itr = std::lower_bound(stamps.begin(), stamps.end(), stamp - ahead);
       return itr == stamps.end() || *itr >= stamp + behind;  // no residual block left on it (cc:331-341)
-    });
+    };
+    // CONTIGUITY RULE: only a prefix and a suffix (in stamp order) leave. Ceres removes any parameter block without residuals (cc:336-341);
+    // the library indexes control points uniformly, so an unused element between two used ones stays (optimize() hands it over as a
+    // constant row) and leaves once everything older than it has left.
+    std::vector<AbstractStamped<Scalar>*> by_stamp(variables_.begin(), variables_.end());
+    std::sort(by_stamp.begin(), by_stamp.end(), [](const auto* a, const auto* b) { return a->stamp() < b->stamp(); });
+    auto first_kept = by_stamp.begin(), last_kept = by_stamp.end();
+    while (first_kept != last_kept && unused(*first_kept)) ++first_kept;
+    while (last_kept != first_kept && unused(*std::prev(last_kept))) --last_kept;
+    for (auto itr = by_stamp.begin(); itr != first_kept; ++itr) variables_.erase(*itr);
+    for (auto itr = last_kept; itr != by_stamp.end(); ++itr) variables_.erase(*itr);
   }
 
   auto addLandmark(Landmark<Position<Scalar>>& landmark) -> void final {  // cc:347-358
@@ -355,11 +387,19 @@ class Optimizer<kOptimizerSuiteHIP> final : public AbstractOptimizer {
     const auto retired = [&](const auto* observation) { return !landmarks_.contains(&observation->landmark()); };
     std::erase_if(bearings_, retired);
     std::erase_if(pixels_, retired);
+    if (!retire_old_observations_) return;
     auto oldest = range.lowerBound();
     for (const auto* landmark : landmarks_) oldest = std::min(oldest, landmark->range().lowerBound());
     const auto expired = [&](const auto* observation) { return observation->measurement().stamp() < oldest; };
     std::erase_if(inertials_, expired);
-    std::erase_if(priors_, expired);
+    // a pose prior goes once every control point it constrains is constant (stamp <= window lower bound, cc:319-328): until then it may be
+    // what anchors the gauge of the free control points
+    const auto [left_padding, right_padding] = state().interpolator()->layout().outerPadding();
+    (void)left_padding;
+    const auto prior_expired = [&, reach = separation_ * (right_padding + 1)](const auto* observation) {
+      return expired(observation) && observation->measurement().stamp() + reach <= range.lowerBound();
+    };
+    std::erase_if(priors_, prior_expired);
   }
 
   /// CHECK(false) upstream (cc:384-386), yet AbstractOptimizer::process(InertialMeasurement) calls it whenever a bias spline is empty
@@ -409,7 +449,7 @@ class Optimizer<kOptimizerSuiteHIP> final : public AbstractOptimizer {
   std::vector<VisualPixelObservation*> pixels_;
   std::vector<ManifoldObservation<Manifold>*> priors_;
   std::vector<InertialObservation<Manifold>*> inertials_;
-  bool rotation_constant_{false}, translation_constant_{false}, gravity_constant_{true};
+  bool rotation_constant_{false}, translation_constant_{false}, gravity_constant_{true}, retire_old_observations_{true};
   Stamp bias_separation_{1.0};
 };
 

@@ -77,11 +77,12 @@ int main(int argc, char** argv) {
     return 3;
   }
   const int n_vis = n_px + n_br, bw = vs.bw, np = 6 * n_cp, ncb = 6 * bw, ntile = bw * (bw + 1) / 2;
-  if (!R) R = k == 4 ? 256 : 192;
-  if (!L) L = k == 4 ? 24 : 18;
-  while (size_t(build_lds_layout(k, bw, R, L).total_doubles) * 8 > 156 * 1024 && L > 4) --L;
-  std::vector<int> ch_ptr, gw_ptr, gw_cf;
-  build_chunks(vs, n_cp, R, L, &ch_ptr, &gw_ptr, &gw_cf);
+  {
+    auto lds_bytes = [&](int r, int l) { return size_t(build_lds_layout(k, bw, r, l).total_doubles) * 8; };
+    if (!choose_build_geometry(k, R ? R : (k == 4 ? 128 : 96), L ? L : (k == 4 ? 12 : 10), size_t(79) * 1024, size_t(156) * 1024, lds_bytes, &R, &L)) return 5;
+  }
+  std::vector<int> ch_ptr, gw_ptr, gw_cf, ch_desc;
+  if (!build_chunks(vs, n_cp, R, L, &ch_ptr, &gw_ptr, &gw_cf, &ch_desc)) return 6;  // a landmark with more than R residuals: record path in the library
   const int n_chunk = int(ch_ptr.size()) - 1;
 
   // device-order tables (prepare() of capi.hip)
@@ -111,6 +112,7 @@ int main(int argc, char** argv) {
   const size_t nl = size_t(std::max(n_lm, 1));
   std::vector<double> lm_L(6 * nl), lm_yhat(3 * nl), lm_sb(3 * nl), lm_D2(3 * nl), lm_gmax(nl), Y(size_t(vs.y_total) + 1);
   const int nb_vis = std::max((n_vis + kBlock - 1) / kBlock, n_chunk);
+  ch_desc.resize(size_t(8) * nb_vis, 0);
   std::vector<double> cost_part(nb_vis + 1, -1.0), grpQ(size_t(n_chunk) * (size_t(ntile) * 36 + 3 * ncb) + 1, 1e300), segP(1);
   std::vector<int> sw_ptr(n_cp - k + 2, 0), sw_seg(1, 0);
   const int x_count1 = np * (ncb + 3) + 2;
@@ -124,7 +126,7 @@ int main(int argc, char** argv) {
   std::memset(&T, 0, sizeof(T));
   T.sp = Spline{k, n_cp, t0, dt, 1.0 / dt, rot_c, tr_c};
   T.basis = make_basis_coef(k);
-  T.cp = cp.data(), T.cp_cand = cp.data(), T.cp_const = cpc.data(), T.cam = cam.data();
+  T.cp = cp.data(), T.cp_cand = cp.data(), T.cp_const = cpc.data(), T.cam = cam.data(), T.n_cam = n_cam;
   T.n_lm = n_lm, T.lm = lm_dev.data(), T.lm_cand = lm_dev.data(), T.lm_const = lmc_dev.data();
   T.lm_ptr = vs.lm_ptr.data(), T.lm_cfirst = vs.lm_cfirst.data(), T.lm_ncp = vs.lm_ncp.data(), T.lm_yoff = vs.lm_yoff.data(), T.cf_ptr = vs.cf_ptr.data();
   T.lm_scale = lm_scale.data(), T.lm_L = lm_L.data(), T.lm_yhat = lm_yhat.data(), T.lm_sb = lm_sb.data(), T.lm_D2 = lm_D2.data();
@@ -143,7 +145,7 @@ int main(int argc, char** argv) {
   T.gw_ptr = gw_ptr.data(), T.gw_cf = gw_cf.data(), T.sw_ptr = sw_ptr.data(), T.sw_seg = sw_seg.data();
   T.xo_g = np * ncb, T.xo_gs = T.xo_g + np, T.xo_dj = T.xo_gs + np, T.xo_pb = T.xo_dj + np, T.xo_bb = T.xo_pb, T.xo_gb = T.xo_bb, T.xo_cost = T.xo_gb, T.xo_gmax = T.xo_cost + 1;
   T.x_count1 = x_count1, T.xo_dec = x_count1;
-  T.fused = 1, T.n_chunk = n_chunk, T.ch_ptr = ch_ptr.data();
+  T.fused = 1, T.n_chunk = n_chunk, T.ch_ptr = ch_ptr.data(), T.ch_desc = ch_desc.data();
   T.rank = 0, T.world = 1, T.st = &st;
 
   const size_t lds = size_t(build_lds_layout(k, bw, R, L).total_doubles) * 8;

@@ -34,6 +34,9 @@ struct double2 {
   double x, y;
 };
 inline double2 make_double2(double a, double b) { return double2{a, b}; }
+struct int4 {
+  int x, y, z, w;
+};
 
 namespace hs_emul {
 
@@ -106,6 +109,12 @@ inline T wave_exchange(T v, int src_lane) {
 
 template <class T>
 inline T __shfl_xor(T v, int mask) { return hs_emul::wave_exchange(v, (threadIdx.x & 63) ^ mask); }
+template <class T>
+inline T __shfl_up(T v, unsigned delta) {
+  const int lane = threadIdx.x & 63;
+  const T got = hs_emul::wave_exchange(v, lane >= int(delta) ? lane - int(delta) : lane);
+  return got;
+}
 inline int __builtin_amdgcn_readlane(int v, int lane) { return hs_emul::wave_exchange(v, lane); }
 inline unsigned long long __ballot(bool pred) {
   hs_emul::Block& b = hs_emul::block();
@@ -122,6 +131,7 @@ inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline void __builtin_amdgcn_wave_barrier() {}
 inline double __builtin_amdgcn_rsq(double d) { return 1.0 / std::sqrt(d); }
 inline long long wall_clock64() { return 0; }
+inline unsigned __builtin_amdgcn_s_getreg(int) { return 0; }
 inline double rsqrt(double d) { return 1.0 / std::sqrt(d); }
 
 template <class T>

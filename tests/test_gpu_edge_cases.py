@@ -227,6 +227,13 @@ def test_band_widths_order6_bordered(bw, hip, oracle):
     compare(w, hip, oracle)
 
 
+def test_knot_uniformity_is_enforced(hip):
+    """hs_set_spline: a table with a hole or a shifted knot is refused, last-bit differences are not (tests/util.py; the oracle's CPU test
+    runs the same function)."""
+    from util import check_knot_uniformity_is_enforced
+    check_knot_uniformity_is_enforced(hip)
+
+
 def test_long_window(hip, monkeypatch):
     """900 control points: the backward sweeps keep the right-hand side in LDS (> 64 KiB here). The two-ended and the one-ended
     factorisation / sweep must agree; windows beyond the LDS budget (> 1024 control points) are rejected with a message."""

@@ -36,6 +36,11 @@ def test_oracle_gradient_probe():
     assert out.returncode == 0 and "SELFTEST OK" in out.stdout, out.stdout[-2000:]
 
 
+def test_knot_uniformity_is_enforced(oracle):
+    from util import check_knot_uniformity_is_enforced
+    check_knot_uniformity_is_enforced(oracle)
+
+
 def test_layout_matches_exteroceptive_update(oracle):
     """Block structure of ExteroceptiveCost::update (exteroceptive.cpp:25-99): sizes, offsets, indices, counts."""
     w = synthetic.small_visual(order=4, n_cp=12, n_landmarks=5, obs_pairs=2, with_priors=3)

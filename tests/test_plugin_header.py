@@ -61,3 +61,16 @@ def test_bias_splines_are_created_by_update_sensor():
     assert "imu.gyroscopeBias()" in body and "imu.accelerometerBias()" in body and "extendBias" in body
     extend = text[text.index("auto extendBias(AbstractState& bias, const Range& range) -> void"):]
     assert "elements.insert(std::move(element))" in extend and "elements.empty()" in extend
+
+
+def test_control_point_table_stays_contiguous():
+    """The library's basis is uniform (hs_set_spline refuses a table with a hole): updateState() may only drop a prefix / suffix of the
+    parameter blocks in stamp order — never `erase_if` single elements like Ceres does (ceres/optimizer.cpp:330-341) — and optimize()
+    builds the table from the contiguous run of state elements, handing an element that is not a parameter block over as a constant row."""
+    text = open(os.path.join(ROOT, "include", PLUGIN)).read()
+    body = text[text.index("auto updateState(const Range& range) -> void final"):]
+    body = body[:body.index("\n  }\n") + 5]
+    assert "erase_if(variables_" not in body and "first_kept" in body and "last_kept" in body
+    opt = text[text.index("auto optimize() -> void final"):text.index("// ---- sensors:")]
+    assert "elements.lower_bound(oldest_stamp)" in opt and "!variables_.contains(itr->get())" in opt
+    assert "admitted(m.stamp())" in text and text.count("admitted(m.stamp())") == 4  # bearing, pixel, prior, inertial tables

@@ -236,3 +236,40 @@ def check_solver_against_golden(lib, tol_forward, tol_state, name="solve.json"):
             sta(rec["gradient_max_norm"], gold["gradient_max_norm_before"] if (last and lib.prefix == "hs_") else gold["gradient_max_norm"],
                 "gradient max norm (local coordinates)")
     return worst
+
+
+def check_knot_uniformity_is_enforced(lib):
+    """hs_set_spline refuses a control-point table whose stamps are not t0 + j dt (a hole, a shifted knot) and accepts stamps that differ
+    from it in the last bits (accumulated sums, /root/reference/internal/hyper/optimizers/abstract.cpp:128). Same rule in both libraries."""
+    import numpy as np
+    import hyperslam_amd as ha
+    from hyperslam_amd import synthetic
+    w = synthetic.small_visual(order=4, n_cp=14, n_landmarks=20, obs_pairs=2)
+    with ha.Problem(w, lib=lib) as p:
+        c0 = p.cost()
+    # stamps accumulated the way upstream extends the state: t += dt (last-bit differences from t0 + j dt)
+    acc = w.control_points.copy()
+    t = acc[0, 7]
+    for j in range(1, len(acc)):
+        t = t + w.dt
+        acc[j, 7] = t
+    assert not np.array_equal(acc[:, 7], w.control_points[:, 7])
+    w2 = synthetic.small_visual(order=4, n_cp=14, n_landmarks=20, obs_pairs=2)
+    w2.control_points = acc
+    with ha.Problem(w2, lib=lib) as p:
+        assert p.cost() == c0
+    for what in ("hole", "shifted"):
+        bad = w.control_points.copy()
+        if what == "hole":  # element 6 pruned: every later row moves up, a fresh one is appended at the end
+            bad[6:-1] = w.control_points[7:]
+            bad[-1, 7] = bad[-2, 7] + w.dt
+        else:
+            bad[5, 7] += 1e-6 * w.dt
+        w3 = synthetic.small_visual(order=4, n_cp=14, n_landmarks=20, obs_pairs=2)
+        w3.control_points = bad
+        try:
+            ha.Problem(w3, lib=lib).close()
+        except ha.HsError as e:
+            assert "uniform" in str(e), e
+        else:
+            raise AssertionError(f"a control-point table with a {what} was accepted")

@@ -1,0 +1,52 @@
+"""Phase timestamps of k_build_visual (HS_DEBUG_FLAGS=32, profiling build: tools/build_profiling_lib.sh).
+usage (GPU box): python tools/build_phase_timing.py [config=1]"""
+import os
+import sys, ctypes as C; sys.path.insert(0, ".")
+import numpy as np
+os.environ["HS_DEBUG_FLAGS"] = str(32 | int(os.environ.get("HS_DEBUG_FLAGS", "0")))
+import hyperslam_amd as ha
+from hyperslam_amd import synthetic, _lib
+_lib.PRODUCT_LIB = os.path.join("tools", "libhyperslam_hip_prof.so")
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+w = {1: synthetic.config1, 2: synthetic.config2, 3: synthetic.config3}[cfg]()
+p = ha.Problem(w); p.snapshot()
+for i in range(3): p.restore(); s = p.solve(1)
+lib = _lib.load().cdll
+n = 48 * 1024 + 64 * 1024
+buf = np.zeros(n, np.int64)
+lib.hs_debug_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+lib.hs_debug_read(p.h, buf.ctypes.data, n)
+t = buf[48 * 1024:].reshape(1024, 4, 16)
+ok = t[:, 0, 0] > 0
+t = t[ok]
+print("chunks stamped:", len(t), " residuals / landmarks per chunk (median, max):", np.median(t[:, 0, 13]), t[:, 0, 13].max(), np.median(t[:, 0, 14]), t[:, 0, 14].max())
+names = ["start", "tables staged", "linearised", "sorted", "W/H rows done", "barrier", "J'J tiles done", "barrier", "eliminated", "barrier", "Yh Yh' done",
+         "written", "cost summed"]
+base = t[:, :, 0].min(axis=1)[:, None, None]
+rel = (t[:, :, :13] - base) * 0.01  # 100 MHz clock -> us
+print("median over chunks [us after the chunk's first wave started]; columns = wave 0..3")
+for i, nme in enumerate(names):
+    print(f"{i:2d} {nme:16s}", " ".join(f"{np.median(rel[:, wv, i]):7.2f}" for wv in range(4)), "   max over chunks/waves", f"{rel[:, :, i].max():7.2f}")
+t0 = t[:, :, 0].min()
+print("kernel span over the stamped chunks [us]: first start -> last end", (t[:, :, 12].max() - t0) * 0.01, " chunk starts (min, median, max)",
+      (np.min(t[:, 0, 0]) - t0) * 0.01, (np.median(t[:, 0, 0]) - t0) * 0.01, (np.max(t[:, 0, 0]) - t0) * 0.01)
+
+end = (t[:, :, 12].max(axis=1) - t0) * 0.01
+start = (t[:, :, 0].min(axis=1) - t0) * 0.01
+print("all chunks: start quantiles [us]", np.percentile(start, [0, 25, 50, 75, 100]).round(2), " end quantiles", np.percentile(end, [0, 25, 50, 75, 100]).round(2),
+      " duration quantiles", np.percentile(end - start, [0, 25, 50, 75, 100]).round(2))
+hw = t[:, 0, 15] & 0xffffffff
+xcc = (t[:, 0, 15] >> 32) & 0xf
+cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 0x1; se = (hw >> 13) & 0x7
+key = xcc * 10000 + se * 1000 + sh * 100 + cu
+uniq, cnt = np.unique(key, return_counts=True)
+print("distinct (xcc, se, sh, cu):", len(uniq), " chunks per CU: max", cnt.max(), " histogram", np.bincount(cnt))
+# overlap: for every CU the number of chunks alive at the median start of its second chunk
+over = 0
+for k_ in uniq:
+    idx = np.where(key == k_)[0]
+    if len(idx) >= 2:
+        o = np.argsort(start[idx])
+        a, b = idx[o[0]], idx[o[1]]
+        over += int(start[b] < end[a] - 1.0)
+print("CUs whose second chunk started more than 1 us before the first ended (co-resident workgroups):", over, "of", int((cnt >= 2).sum()))

@@ -306,6 +306,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # what the library itself says about the exchange: ranks of its RCCL communicator (ncclCommCount; 0 = hook / single shard) and the bytes
+    # every rank contributes per LM iteration (one all-reduce of the reduced normal equations + one of five doubles for the decision)
+    import ctypes
+    n_ranks, n_lin, n_dec = ctypes.c_int32(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    problem._check(problem.lib.exchange_info(problem.h, ctypes.byref(n_ranks), ctypes.byref(n_lin), ctypes.byref(n_dec)), "exchange_info")
+    exchange_info = {"rccl_ranks": int(n_ranks.value), "exchange_bytes_per_iteration_per_rank": 8 * int(n_lin.value + n_dec.value) if world > 1 else 0}
+    if world > 1 and exchange == "rccl":
+        assert n_ranks.value == world, (n_ranks.value, world)  # the library's communicator spans every rank of the job
     if rank == 0:
         # launches of the linearise kernel bracketed by HIP events (every STAGE_EVERY-th step of the timed region). A solve of N iterations
         # launches it N times: the start point + the candidates of iterations 0 .. N - 2 on the speculative path (the last iteration only
@@ -371,7 +379,7 @@ def main():
             "config": {"workload": workload,
                        "residual_blocks_per_gpu": n_blocks_local, "residual_blocks_total": n_blocks_global, "landmarks_per_gpu": int(len(np.unique(np.concatenate([window.pixel_landmark, window.bearing_landmark])))),
                        "lm_iterations_per_step": LM_ITERATIONS, "parallelism": f"residual-sharded x{world}" if world > 1 else "single GPU",
-                       **({"exchange": exchange} if world > 1 else {})},
+                       **({"exchange": exchange} if world > 1 else {}), **exchange_info},
             "final_cost": s["final_cost"], "initial_cost": s["initial_cost"],
             "device_ms_per_iteration": {k: v / n_lin for k, v in stage.items()},
             "stage_events": f"HIP events around the four stages on every {STAGE_EVERY}th step of the timed region ({n_staged} of {args.steps} steps); "

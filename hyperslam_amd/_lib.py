@@ -128,6 +128,7 @@ _PRODUCT_ONLY = {
     "rccl_unique_id": (C.c_int, [C.c_char_p]),
     "rccl_init": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
     "rccl_shutdown": (C.c_int, [C.c_void_p]),
+    "exchange_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
 }
 
 # every symbol include/hyperslam_hip.h declares (checked by tests/test_oracle.py::test_product_library_exports_every_declared_symbol)

@@ -397,7 +397,7 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_lm_yhat.reserve(3 * nl));
   HIP_TRY(p->d_lm_sb.reserve(3 * nl));
   HIP_TRY(p->d_lm_D2.reserve(3 * nl));
-  HIP_TRY(p->d_lm_part.reserve(4 * size_t((nl + kBlock / 64 - 1) / (kBlock / 64)) + 4));
+  HIP_TRY(p->d_lm_part.reserve(4 * (nl + size_t(n_vis) / kBlock + 2) + 4));  // (one entry per four landmarks; fused path: per chunk, <= landmarks, padded to the grid)
   HIP_TRY(p->d_lm_gmax.reserve(nl));
   HIP_TRY(p->d_Y.reserve(size_t(vs.y_total) + 1));
   if (n_vis) {
@@ -621,7 +621,7 @@ int prepare(hs_problem* p) {
   T.n_lm = p->n_lm, T.lm = p->d_lm.p, T.lm_cand = p->d_lm_cand.p, T.lm_const = p->d_lm_const.p;
   T.lm_ptr = p->d_lm_ptr.p, T.lm_cfirst = p->d_lm_cfirst.p, T.lm_ncp = p->d_lm_ncp.p, T.lm_yoff = p->d_lm_yoff.p, T.cf_ptr = p->d_cf_ptr.p;
   T.lm_scale = p->d_lm_scale.p, T.lm_L = p->d_lm_L.p, T.lm_yhat = p->d_lm_yhat.p, T.lm_sb = p->d_lm_sb.p, T.lm_D2 = p->d_lm_D2.p;
-  T.lm_part = p->d_lm_part.p, T.n_lm_part = (p->n_lm + kBlock / 64 - 1) / (kBlock / 64), T.lm_gmax = p->d_lm_gmax.p, T.Y = p->d_Y.p;
+  T.lm_part = p->d_lm_part.p, T.n_lm_part = p->fused ? p->nb_vis : (p->n_lm + kBlock / 64 - 1) / (kBlock / 64), T.lm_gmax = p->d_lm_gmax.p, T.Y = p->d_Y.p;
   {
     int n_obs = p->n_lm;
     while (n_obs > 0 && vs.lm_ptr[n_obs] == vs.lm_ptr[n_obs - 1]) --n_obs;
@@ -751,6 +751,7 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 static RcclApi* rccl_api() {
@@ -768,6 +769,7 @@ static RcclApi* rccl_api() {
       api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.lib, "ncclAllReduce"));
       api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.lib, "ncclCommDestroy"));
       api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.lib, "ncclGetErrorString"));
+      api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.lib, "ncclCommCount"));
       if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) api.lib = nullptr;
     }
   }
@@ -1109,8 +1111,16 @@ template <int K>
 int launch_update(hs_problem* p, bool linearize_candidate = false, bool deferred_commit = false, hipEvent_t* lin_events = nullptr) {
   const Tables& T = p->T;
   hipStream_t s = p->stream;
-  k_backsub_retract<<<T.n_lm_part + T.n_norm_part, kBlock, 0, s>>>(T);
-  if (linearize_candidate) {
+  if (p->fused) {  // candidate point, landmark back-substitution and the visual candidate cost per chunk, one launch
+    k_update_visual<K><<<p->nb_vis + T.n_norm_part, kBlock, size_t(update_lds_doubles(T.bw, p->build_R, p->build_L)) * 8, s>>>(T, p->build_R, p->build_L, p->nb_vis);
+    if (T.n_pri) k_cost_prior<K><<<p->nb_pri, kBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.cand_part + p->nb_vis);
+    if (T.n_ine)
+      k_cost_inertial<K, 4><<<p->nb_ine, kInertialBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.bias_g_cand, T.bias_a_cand, T.gravity_cand,
+                                                                          T.cand_part + p->nb_vis + p->nb_pri);
+  } else
+    k_backsub_retract<<<T.n_lm_part + T.n_norm_part, kBlock, 0, s>>>(T);
+  if (p->fused) {
+  } else if (linearize_candidate) {
     if (lin_events) HIP_TRY(hipEventRecord(lin_events[0], s));  // stage timing: this launch is booked under "linearise", not "update"
     k_linearize_visual<K><<<p->nb_vis, lin_block<K>(), lin_lds_bytes<K>(p), s>>>(T, nullptr, T.v_pos, 1, T.cand_part, nullptr, T.cp_cand, T.lm_cand);
     if (lin_events) HIP_TRY(hipEventRecord(lin_events[1], s));
@@ -1126,11 +1136,12 @@ int launch_update(hs_problem* p, bool linearize_candidate = false, bool deferred
   }
   const bool local_decision = !p->allreduce && !p->rccl_comm;  // single shard: decide in the packing kernel
   const bool inline_commit = commit_inline(p);
-  k_pack_decision<<<1, kBlock, 0, s>>>(T, inline_commit ? 2 : local_decision ? 1 : 0);
+  const bool cps_here = p->fused && deferred_commit;  // fused path: the decision kernel commits the control points, the landmarks stay deferred
+  k_pack_decision<<<1, kBlock, 0, s>>>(T, inline_commit ? 2 : local_decision ? (cps_here ? 3 : 1) : 0);
   HIP_TRY(hipGetLastError());
   const int rc = exchange(p, T.xbuf + T.xo_dec, 5);  // candidate cost + norms + landmark-side model-cost terms
   if (rc) return rc;
-  if (!local_decision) k_decide<<<1, 64, 0, s>>>(T);
+  if (!local_decision) k_decide<<<1, kBlock, 0, s>>>(T, cps_here ? 1 : 0);
   const int nb_commit = std::max((std::max(8 * T.sp.n_cp, 3 * T.n_lm) + kBlock - 1) / kBlock, 1);  // one element per lane
   // (deferred: speculative solves of larger problems — the next iteration's k_backsub_retract copies the accepted candidate to x on its way,
   //  hs_solve launches k_commit once behind the last iteration)
@@ -1152,7 +1163,7 @@ template <int K>
 static void warm_kernels_of_order() {
   hipFuncAttributes fa;
   const void* kernels[] = {
-      reinterpret_cast<const void*>(&k_build_visual<K>), reinterpret_cast<const void*>(&k_linearize_visual<K>), reinterpret_cast<const void*>(&k_linearize_prior<K>),
+      reinterpret_cast<const void*>(&k_build_visual<K>), reinterpret_cast<const void*>(&k_update_visual<K>), reinterpret_cast<const void*>(&k_linearize_visual<K>), reinterpret_cast<const void*>(&k_linearize_prior<K>),
       reinterpret_cast<const void*>(&k_linearize_inertial<K, 4>), reinterpret_cast<const void*>(&k_landmark<K, 2, 2>),
       reinterpret_cast<const void*>(&k_landmark<K, 4, 1>), reinterpret_cast<const void*>(&k_landmark_rows<K, 4>),
       reinterpret_cast<const void*>(&k_gram_pair<K, 1>), reinterpret_cast<const void*>(&k_gram_pair<K, 2>), reinterpret_cast<const void*>(&k_gram_pair<K, 4>),
@@ -1209,6 +1220,8 @@ int set_func_attributes(hs_problem* p) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<6, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<6, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_visual<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_visual<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_visual<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_visual<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_visual<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_visual<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -1965,6 +1978,21 @@ int hs_rccl_shutdown(hs_problem* p) {
     (void)rccl_api()->CommDestroy(static_cast<ncclComm_t>(p->rccl_comm));
   }
   p->rccl_comm = nullptr;
+  return HS_OK;
+}
+
+int hs_exchange_info(hs_problem* p, int32_t* rccl_ranks, int64_t* doubles_per_linearisation, int64_t* doubles_per_decision) {
+  if (!p) return HS_ERR_INVALID;
+  if (rccl_ranks) {
+    int n = 0;
+    if (p->rccl_comm && rccl_api() && rccl_api()->CommCount) {
+      const ncclResult_t r = rccl_api()->CommCount(static_cast<ncclComm_t>(p->rccl_comm), &n);
+      if (r != ncclSuccess) HS_FAIL(HS_ERR_DEVICE, "ncclCommCount failed");
+    }
+    *rccl_ranks = n;
+  }
+  if (doubles_per_linearisation) *doubles_per_linearisation = p->dirty ? 0 : p->T.x_count1;
+  if (doubles_per_decision) *doubles_per_decision = 5;
   return HS_OK;
 }
 

@@ -23,7 +23,7 @@
 //      blocks; the streams of a tile sit in adjacent lanes and are combined with butterfly steps (fixed order, no LDS)
 //   4  lane <-> landmark: damped 3 x 3 Cholesky;  lane <-> (landmark, control point): Y-hat block -> LDS and HBM (k_backsub_retract)
 //   5  lane <-> (window tile, landmark stream): Q -= Yh Yh', q -= Yh yh (two streams in adjacent lanes)
-//   6  the chunk's partial [tiles of P + Q | -Yh yh | J_p'r | diag J_p'J_p] -> HBM, summed over the chunks of the overlapping groups
+//   6  the chunk's partial [rows of P + Q | -Yh yh | J_p'r | diag J_p'J_p] -> HBM, summed over the chunks of the overlapping groups
 //      by k_assemble in a fixed order: bit-reproducible, no floating-point atomics.
 // HBM traffic per residual: 32 B of inputs + its share of Y-hat and of the chunk partial; the 448-byte record (k = 4) is never written.
 #pragma once
@@ -174,9 +174,10 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
   if (bprof) blog[i] = wall_clock64()
   HS_BSTAMP(0);
 
-  // Deferred commit (DevState::spec 2 or 4): the candidate accepted by the previous iteration is still only in the candidate buffers
-  const bool pend = (st_spec == 2 || st_spec == 4) && st_accepted;
-  const double* cp_src = pend ? T.cp_cand : T.cp;
+  // Deferred commit of the landmarks (DevState::spec == 4): the candidate accepted by the previous iteration is still only in lm_cand
+  // (k_update_visual copies it on its way); the control points are committed by the decision kernel and always current in T.cp
+  const bool pend = st_spec == 4 && st_accepted;
+  const double* cp_src = T.cp;
   const double* lm_src = pend ? T.lm_cand : T.lm;
   const bool fresh = !st_ready;
 
@@ -524,8 +525,14 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
         acc[e] += v.x, acc[e + 1] += v.y;
       }
     }
+    // rows of the window, not tiles: row (rb, r) holds its (bw - rb) blocks contiguously, so that k_assemble — one lane per band entry of a
+    // scalar row — reads a chunk partial with consecutive lanes on consecutive doubles
+    double* grow = G + 36 * group_tile_index(q_rb, q_rb, bw) + 6 * (q_cb - q_rb);
+    const int rstride = 6 * (bw - q_rb);
 #pragma unroll
-    for (int e = 0; e < 36; e += 2) *reinterpret_cast<double2*>(G + size_t(q_t) * 36 + e) = make_double2(acc[e], acc[e + 1]);
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int e = 0; e < 6; e += 2) *reinterpret_cast<double2*>(grow + r * rstride + e) = make_double2(acc[6 * r + e], acc[6 * r + e + 1]);
   }
   HS_BSTAMP(11);
   if (tid == 0) {
@@ -537,6 +544,209 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
   HS_BSTAMP(12);
   if (bprof) blog[13] = nres, blog[14] = nl, blog[15] = (long long)(__builtin_amdgcn_s_getreg(63492)) | ((long long)(__builtin_amdgcn_s_getreg(63508)) << 32);  // HW_ID | XCC_ID
 #undef HS_BSTAMP
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Candidate point and its cost, per chunk (the fused path's k_backsub_retract + k_cost_visual in one launch). Workgroups
+// [0, n_vis_parts): chunk w — the candidate control points of its window (Plus(x, delta), recomputed per workgroup: bw quaternion
+// products), the landmark back-substitution of its landmarks
+//   y_l = L^-T (yh_l - Yh_l' (Sp o y_p)),  step_l = -y_l,  candidate = lm + S_l o step_l        (lane <-> (landmark, control point) partial
+//   dot products, summed per landmark in a fixed order; the landmark-side terms of the decision per chunk),
+// and the value-only cost of its residual blocks at that candidate. Workgroups behind them: the candidate of every replicated unknown
+// (control points, bias points, gravity) and its norms — k_backsub_retract's second half — and the landmarks no chunk holds (unobserved).
+// The current control points are always in T.cp (the decision kernel commits them: 8 n_cp doubles); an accepted landmark candidate stays in
+// lm_cand until this kernel passes over it (DevState::spec == 4).
+// ---------------------------------------------------------------------------------------------------------------------
+__host__ __device__ inline int update_lds_doubles(int bw, int R, int Lmax) {
+  return 14 * bw + 4 * Lmax * bw + 8 * Lmax + 16 * kBuildCams + R + 8 + (Lmax + 1) / 2 + 8;
+}
+
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_update_visual(Tables T, int R, int Lmax, int n_vis_parts) {
+  HS_DYNAMIC_LDS(smem);
+  const int w = blockIdx.x, tid = threadIdx.x;
+  DevState* st = T.st;
+  if (int(blockIdx.x) >= n_vis_parts) {  // ---- replicated unknowns: candidate = Plus(x, delta), norms (k_backsub_retract) ----
+    if (st->done) return;
+    __shared__ double red[kBlock / 64];
+    const int blk = blockIdx.x - n_vis_parts;
+    const int j = blk * blockDim.x + tid;
+    double xs = 0.0, ss = 0.0;
+    if (j < T.sp.n_cp) {
+      const double* x = T.cp + 8 * j;
+      double* y = T.cp_cand + 8 * j;
+      const double* d = T.delta_p + 6 * j;
+      bool any = false;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) any |= (T.D2p[6 * j + c] != 0.0);
+      const Quat q = quat_plus(Quat{x[0], x[1], x[2], x[3]}, V3{d[0], d[1], d[2]});
+      y[0] = q.x, y[1] = q.y, y[2] = q.z, y[3] = q.w;
+      y[4] = x[4] + d[3], y[5] = x[5] + d[4], y[6] = x[6] + d[5];
+      y[7] = x[7];
+      if (any) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) xs = fma(x[c], x[c], xs), ss = fma(x[c] - y[c], x[c] - y[c], ss);
+      }
+    }
+    if (T.nb > 0) {  // border unknowns (replicated like the control points): bias control points [x y z t] and gravity
+      for (int b = j; b < 2 * T.n_bias; b += T.n_norm_part * blockDim.x) {
+        const bool acc = b >= T.n_bias;
+        const int bi = acc ? b - T.n_bias : b;
+        const double* x = (acc ? T.bias_a : T.bias_g) + 4 * bi;
+        double* y = (acc ? T.bias_a_cand : T.bias_g_cand) + 4 * bi;
+        const double* d = T.delta_b + 3 * b;
+        const bool any = T.D2b[3 * b] != 0.0 || T.D2b[3 * b + 1] != 0.0 || T.D2b[3 * b + 2] != 0.0;
+        y[0] = x[0] + d[0], y[1] = x[1] + d[1], y[2] = x[2] + d[2], y[3] = x[3];
+        if (any) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) xs = fma(x[c], x[c], xs), ss = fma(x[c] - y[c], x[c] - y[c], ss);
+        }
+      }
+      if (j == 0) {
+        const double* d = T.delta_b + 6 * T.n_bias;
+        double y[3];
+        sphere_plus(T.gravity, d, y);
+        const bool any = T.D2b[6 * T.n_bias] != 0.0 || T.D2b[6 * T.n_bias + 1] != 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          T.gravity_cand[c] = y[c];
+          if (any) xs = fma(T.gravity[c], T.gravity[c], xs), ss = fma(T.gravity[c] - y[c], T.gravity[c] - y[c], ss);
+        }
+      }
+    }
+    // landmarks without residuals are in no chunk: their candidate is the landmark itself
+    for (int e = 3 * T.n_obs_lm + j; e < 3 * T.n_lm; e += T.n_norm_part * blockDim.x) T.lm_cand[e] = T.lm[e];
+    xs = block_sum(xs, red), ss = block_sum(ss, red);
+    if (tid == 0) T.norm_part[2 * blk] = xs, T.norm_part[2 * blk + 1] = ss;
+    return;
+  }
+  // ---- chunk w ----
+  const int4 d0 = *reinterpret_cast<const int4*>(T.ch_desc + 8 * w);
+  const int nres = T.ch_desc[8 * w + 4];
+  const int st_done = st->done, st_spec = st->spec, st_accepted = st->accepted;
+  if (st_done) return;
+  if (w >= T.n_chunk) {  // padding workgroups of the partial tables
+    if (tid == 0) T.cand_part[w] = 0.0;
+    if (tid < 4) T.lm_part[4 * w + tid] = 0.0;
+    return;
+  }
+  const bool pend = st_spec == 4 && st_accepted;  // the landmarks' current point is still in lm_cand
+  const int lo = d0.x, nl = d0.y, cf = d0.z, q0 = d0.w;
+  const int bw = T.bw, R6 = 6 * bw;
+  const unsigned bw_magic = ((1u << 20) + bw - 1) / bw;
+  double* cps_c = smem;                       // candidate control points of the window [bw][8]
+  double* yp = cps_c + 8 * bw;                // Sp o y_p over the window rows [6 bw]
+  double* part = yp + 6 * bw;                 // [Lmax][bw][4]: partial Yh' (Sp o y_p) per (landmark, control point)
+  double* lmc = part + 4 * Lmax * bw;         // [Lmax][8]: candidate landmark (3), decision terms (4)
+  double* cams = lmc + 8 * Lmax;              // cameras
+  double* costs = cams + 16 * kBuildCams;     // [R]
+  double* cpart = costs + R;                  // [8]
+  int* l_ncp = reinterpret_cast<int*>(cpart + 8);
+  // residual inputs (independent of everything below: requested first)
+  const bool has_rec = tid < nres;
+  VisualIn in;
+  int camid = 0, my_l = 0;
+  if (has_rec) {
+    const int q = q0 + tid;
+    in.first = T.v_first[q], my_l = T.v_lm[q] - lo;
+    const int info = T.v_info[q];
+    in.type = info >> 16, camid = info & 0xffff;
+    in.stamp = T.v_stamp[q];
+    in.meas[0] = T.v_meas[3 * q], in.meas[1] = T.v_meas[3 * q + 1], in.meas[2] = T.v_meas[3 * q + 2];
+  }
+  const int ncp_w = min(bw, T.sp.n_cp - cf);
+  if (tid < ncp_w) {  // candidate control points of the window
+    const double* x = T.cp + 8 * (cf + tid);
+    const double* d = T.delta_p + 6 * (cf + tid);
+    const Quat q = quat_plus(Quat{x[0], x[1], x[2], x[3]}, V3{d[0], d[1], d[2]});
+    double* y = cps_c + 8 * tid;
+    y[0] = q.x, y[1] = q.y, y[2] = q.z, y[3] = q.w, y[4] = x[4] + d[3], y[5] = x[5] + d[4], y[6] = x[6] + d[5], y[7] = x[7];
+  }
+  for (int e = tid; e < 6 * ncp_w; e += kBlock) yp[e] = -T.step_p[6 * cf + e] * T.scale_p[6 * cf + e];
+  for (int e = tid; e < 16 * min(T.n_cam, kBuildCams); e += kBlock) cams[e] = T.cam[e];
+  if (tid < nl) l_ncp[tid] = T.lm_ncp[lo + tid];
+  __syncthreads();
+  // partial dot products, one (landmark, control point) block per lane: the 6 x 3 block of Y-hat is 18 consecutive doubles in HBM
+  const int n_task = nl * bw;
+  for (int tau = tid; tau < n_task; tau += kBlock) {
+    const int l = int((unsigned(tau) * bw_magic) >> 20), jb = tau - l * bw;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+    if (jb < l_ncp[l]) {
+      const double2* Y = reinterpret_cast<const double2*>(T.Y + T.lm_yoff[lo + l] + 18 * jb);
+      double y[18];
+#pragma unroll
+      for (int e = 0; e < 9; ++e) {
+        const double2 v = Y[e];
+        y[2 * e] = v.x, y[2 * e + 1] = v.y;
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const double p = yp[6 * jb + r];
+        t0 = fma(y[3 * r], p, t0), t1 = fma(y[3 * r + 1], p, t1), t2 = fma(y[3 * r + 2], p, t2);
+      }
+    }
+    double* dst = part + 4 * (l * bw + jb);
+    dst[0] = t0, dst[1] = t1, dst[2] = t2;
+  }
+  __syncthreads();
+  if (tid < nl) {  // 3 x 3 back-substitution per landmark
+    const int l = tid, dl = lo + l;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+    for (int jb = 0; jb < l_ncp[l]; ++jb) t0 += part[4 * (l * bw + jb)], t1 += part[4 * (l * bw + jb) + 1], t2 += part[4 * (l * bw + jb) + 2];
+    double L[6], yh[3], x[3], sc[3], sb[3], d2[3];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) L[a] = T.lm_L[6 * dl + a];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      yh[a] = T.lm_yhat[3 * dl + a], x[a] = (pend ? T.lm_cand : T.lm)[3 * dl + a], sc[a] = T.lm_scale[3 * dl + a];
+      sb[a] = T.lm_sb[3 * dl + a], d2[a] = T.lm_D2[3 * dl + a];
+    }
+    const bool active = !T.lm_const[dl];
+    const double z0 = yh[0] - t0, z1 = yh[1] - t1, z2 = yh[2] - t2;  // L' y = z
+    const double y2 = z2 / L[5], y1 = (z1 - L[4] * y2) / L[2], y0 = (z0 - L[1] * y1 - L[3] * y2) / L[0];
+    const double s[3] = {active ? -y0 : 0.0, active ? -y1 : 0.0, active ? -y2 : 0.0};
+    double xl = 0.0, sl = 0.0, gd = 0.0, dd = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double y = x[a] + sc[a] * s[a];
+      T.lm_cand[3 * dl + a] = y;
+      lmc[8 * l + a] = y;
+      if (pend) T.lm[3 * dl + a] = x[a];
+      if (active) {
+        xl = fma(x[a], x[a], xl), sl = fma(x[a] - y, x[a] - y, sl);
+        gd = fma(sb[a], s[a], gd);
+        dd = fma(d2[a] * s[a], s[a], dd);
+      }
+    }
+    lmc[8 * l + 4] = xl, lmc[8 * l + 5] = sl, lmc[8 * l + 6] = gd, lmc[8 * l + 7] = dd;
+  }
+  __syncthreads();
+  if (tid >= kBlock - 4) {  // landmark-side terms of the decision (|x|^2, |x - x+|^2, g.step, step'D^2 step), landmarks in order
+    const int e = tid - (kBlock - 4);
+    double v = 0.0;
+    for (int l = 0; l < nl; ++l) v += lmc[8 * l + 4 + e];
+    T.lm_part[4 * w + e] = v;
+  }
+  // value-only cost of the chunk's residual blocks at the candidate
+  if (has_rec) {
+    in.cam = camid < kBuildCams ? cams + 16 * camid : T.cam + kCamStride * camid;
+    in.lm[0] = lmc[8 * my_l], in.lm[1] = lmc[8 * my_l + 1], in.lm[2] = lmc[8 * my_l + 2];
+    costs[tid] = visual_cost_in<K>(T, cps_c - 8 * cf, in);
+  }
+  __syncthreads();
+  if (tid < 8) {  // fixed-order sum: eight strided partials, then their sum
+    const int per = (nres + 7) / 8;
+    double acc = 0.0;
+    for (int t = tid * per; t < min(nres, (tid + 1) * per); ++t) acc += costs[t];
+    cpart[tid] = acc;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0.0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) s += cpart[g];
+    T.cand_part[w] = s;
+  }
 }
 
 }  // namespace hs

@@ -534,7 +534,9 @@ __global__ void __launch_bounds__(kAsmThreads) k_assemble(Tables T) {
 #define HS_GRP_VALUE(q, cf) \
   ((q) < nq && (c > ncb || i - (cf) + kk < bw) \
        ? T.grpQ[(q_lo + (q)) * int(qstride) + \
-                (c > ncb ? ntile * 36 + 6 * (i - (cf)) + a : group_tile_index(i - (cf), i - (cf) + kk, bw) * 36 + 6 * a + cc)] \
+                (c > ncb ? ntile * 36 + 6 * (i - (cf)) + a                                                               \
+                 : T.fused ? group_tile_index(i - (cf), i - (cf), bw) * 36 + a * 6 * (bw - (i - (cf))) + c /* row-major rows: kernels_build.hpp */ \
+                           : group_tile_index(i - (cf), i - (cf) + kk, bw) * 36 + 6 * a + cc)] \
        : 0.0)
 #define HS_GRP_EXTRA(q, cf) ((q) < nq ? T.grpQ[(q_lo + (q)) * int(qstride) + ntile * 36 + (c == ncb ? 1 : 2) * R + 6 * (i - (cf)) + a] : 0.0)
     int si[kAsmU], gi[2 * kAsmU];

@@ -17,7 +17,7 @@ __global__ void __launch_bounds__(kBlock) k_backsub_retract(Tables T) {
   // Speculative solves with a deferred commit (DevState::spec == 2): the candidate accepted by the previous iteration is still only in
   // the candidate buffers — it is the current point here, and it is copied to x on the way (every element of x passes through this
   // kernel once per iteration), which replaces one k_commit launch per iteration. hs_solve launches k_commit once behind the last iteration.
-  const bool pend = (T.st->spec == 2 || T.st->spec == 4) && T.st->accepted;
+  const bool pend = T.st->spec == 2 && T.st->accepted;  // (spec == 4, the fused path: k_update_visual)
   if (int(blockIdx.x) < T.n_lm_part) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int dl = blockIdx.x * (kBlock / 64) + wave;
@@ -197,6 +197,7 @@ HSD void begin_iteration(const Tables& T, double c, double gm, bool set_scaling_
 
 HSD void decide_step(const Tables& T);
 HSD void commit_body(const Tables& T, int idx, int stride);
+HSD void commit_control_points(const Tables& T, int idx, int stride);
 
 /// Second exchange buffer (5 doubles, additive across shards): candidate cost, |x|^2, |x - x+|^2 and the landmark-side
 /// terms of the model cost change. The replicated control-point part of the norms is contributed by rank 0 only.
@@ -235,11 +236,13 @@ __global__ void __launch_bounds__(kBlock) k_pack_decision(Tables T, int decide_h
     st->local_cand = cand;  // this shard's part (the exchange sums D over the shards)
     if (decide_here) decide_step(T);
   }
-  if (decide_here == 2) {  // small problems: x <- candidate right here instead of a k_commit launch behind this one
+  if (decide_here >= 2) {  // 2, small problems: x <- candidate right here instead of a k_commit launch behind this one;
+                           // 3, fused path with deferred landmarks: the control points only (k_build_visual / k_update_visual read T.cp)
     __shared__ int accepted;  // (handed over in LDS: the other waves may hold the state's cache line from their `done` test)
     if (threadIdx.x == 0) accepted = st->accepted;
     __syncthreads();
-    if (accepted) commit_body(T, threadIdx.x, blockDim.x);
+    if (accepted && decide_here == 2) commit_body(T, threadIdx.x, blockDim.x);
+    if (accepted && decide_here == 3) commit_control_points(T, threadIdx.x, blockDim.x);
   }
 }
 
@@ -311,9 +314,16 @@ HSD void decide_step(const Tables& T) {
   st->iteration = it + 1;
 }
 
-__global__ void __launch_bounds__(kBlock) k_decide(Tables T) {
-  if (T.st->done || threadIdx.x != 0) return;
-  decide_step(T);
+/// (commit_cps: the fused path with deferred landmarks — the accepted control points go to T.cp right here)
+__global__ void __launch_bounds__(kBlock) k_decide(Tables T, int commit_cps) {
+  if (T.st->done) return;
+  __shared__ int accepted;
+  if (threadIdx.x == 0) {
+    decide_step(T);
+    accepted = T.st->accepted;
+  }
+  __syncthreads();
+  if (commit_cps && accepted) commit_control_points(T, threadIdx.x, blockDim.x);
 }
 
 /// x <- candidate when the step was accepted.
@@ -339,6 +349,17 @@ HSD void commit_body(const Tables& T, const int idx, const int stride) {
   if (T.nb > 0) {
     for (int e = idx; e < 4 * T.n_bias; e += stride) T.bias_g[e] = T.bias_g_cand[e], T.bias_a[e] = T.bias_a_cand[e];
     if (idx < 3) T.gravity[idx] = T.gravity_cand[idx];
+  }
+}
+
+HSD void commit_control_points(const Tables& T, const int idx, const int stride) {
+  for (int e0 = idx; e0 < 8 * T.sp.n_cp; e0 += 4 * stride) {
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = e0 + u * stride < 8 * T.sp.n_cp ? T.cp_cand[e0 + u * stride] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (e0 + u * stride < 8 * T.sp.n_cp) T.cp[e0 + u * stride] = v[u];
   }
 }
 

@@ -206,6 +206,12 @@ int hs_rccl_init(hs_problem* p, const char id[128], int rank, int world);
 /* Destroys the communicator of hs_rccl_init (no-op without one): the exchanges fall back to the hs_set_allreduce hook. Every rank
  * must call it when the collective initialisation did not succeed everywhere, so that all ranks issue the same collectives. */
 int hs_rccl_shutdown(hs_problem* p);
+/* What the shards exchange, read back from the library (a driver can see that RCCL really runs with N ranks): rccl_ranks = ncclCommCount
+ * of the communicator of hs_rccl_init (0: none, the hs_set_allreduce hook or a single shard); doubles_per_linearisation = length of the
+ * all-reduce behind every linearisation ([S | g | diag | border blocks | cost | gradient norms], valid after the first hs_solve /
+ * hs_reduced_system of the current tables); doubles_per_decision = length of the second all-reduce of an iteration (5). Any pointer may
+ * be NULL. */
+int hs_exchange_info(hs_problem* p, int32_t* rccl_ranks, int64_t* doubles_per_linearisation, int64_t* doubles_per_decision);
 /* Residual-sharded operation: this handle holds shard `rank` of `world` (all observations of a landmark on one rank,
  * control points / sensors replicated). min_band_blocks = max over ranks of hs_band_blocks() so that every rank uses the
  * same band layout for the exchanged reduced system. */

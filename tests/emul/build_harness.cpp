@@ -46,6 +46,36 @@ static void run(Tables& T, int nb_vis, int R, int L, size_t lds) {
   hs_emul::launch(dim3(T.sp.n_cp + 1), dim3(kBlock), 0, [&] { k_finalize_reduced(T, 1); });
 }
 
+/// The candidate point two ways: k_update_visual (per chunk) against k_backsub_retract + k_cost_visual (per landmark / per residual).
+template <int K>
+static void run_update(Tables& T, int nb_vis, int R, int L, std::vector<double>* out) {
+  const int n_lm = T.n_lm, n_cp = T.sp.n_cp;
+  std::vector<double> lm_cand_a(3 * size_t(std::max(n_lm, 1))), cp_cand_a(8 * size_t(n_cp)), cand_a(nb_vis + 1), norm_a(2 * size_t(T.n_norm_part));
+  std::vector<double> lm_part_a(4 * size_t((n_lm + 3) / 4) + 4);
+  Tables A = T;
+  A.lm_cand = lm_cand_a.data(), A.cp_cand = cp_cand_a.data(), A.cand_part = cand_a.data(), A.norm_part = norm_a.data(), A.lm_part = lm_part_a.data();
+  A.n_lm_part = (n_lm + 3) / 4;
+  hs_emul::launch(dim3(A.n_lm_part + A.n_norm_part), dim3(kBlock), 0, [&] { k_backsub_retract(A); });
+  hs_emul::launch(dim3(nb_vis), dim3(kBlock), size_t(8) * n_cp * 8, [&] { k_cost_visual<K>(A, A.cp_cand, A.lm_cand, A.cand_part); });
+  std::vector<double> lm_cand_b(3 * size_t(std::max(n_lm, 1))), cp_cand_b(8 * size_t(n_cp)), cand_b(nb_vis + 1), norm_b(2 * size_t(T.n_norm_part));
+  std::vector<double> lm_part_b(4 * size_t(nb_vis) + 4);
+  Tables B = T;
+  B.lm_cand = lm_cand_b.data(), B.cp_cand = cp_cand_b.data(), B.cand_part = cand_b.data(), B.norm_part = norm_b.data(), B.lm_part = lm_part_b.data();
+  B.n_lm_part = nb_vis;
+  hs_emul::launch(dim3(nb_vis + B.n_norm_part), dim3(kBlock), size_t(update_lds_doubles(T.bw, R, L)) * 8, [&] { k_update_visual<K>(B, R, L, nb_vis); });
+  auto sum = [](const std::vector<double>& v, size_t n, size_t stride = 1, size_t off = 0) {
+    double s = 0;
+    for (size_t i = 0; i < n; ++i) s += v[i * stride + off];
+    return s;
+  };
+  double dlm = 0, dcp = 0;
+  for (size_t i = 0; i < 3 * size_t(n_lm); ++i) dlm = std::max(dlm, std::fabs(lm_cand_a[i] - lm_cand_b[i]));
+  for (size_t i = 0; i < 8 * size_t(n_cp); ++i) dcp = std::max(dcp, std::fabs(cp_cand_a[i] - cp_cand_b[i]));
+  out->assign({dlm, dcp, sum(cand_a, nb_vis), sum(cand_b, nb_vis)});
+  for (int e = 0; e < 4; ++e) out->push_back(sum(lm_part_a, A.n_lm_part, 4, e)), out->push_back(sum(lm_part_b, B.n_lm_part, 4, e));
+  for (int e = 0; e < 2; ++e) out->push_back(sum(norm_a, T.n_norm_part, 2, e)), out->push_back(sum(norm_b, T.n_norm_part, 2, e));
+}
+
 int main(int argc, char** argv) {
   if (argc < 3) return 1;
   Reader rd{fopen(argv[1], "rb")};
@@ -156,8 +186,18 @@ int main(int argc, char** argv) {
   else
     return 4;
 
+  // a step to retract along (any vector will do for the comparison of the two update paths): step_p fabricated, delta_p = s_p o step_p
+  std::vector<double> step_p(np), delta_p(np), lm_sb_dummy;
+  for (int i = 0; i < np; ++i) step_p[i] = 1e-2 * std::sin(0.37 * i + 0.1) * (D2p[i] != 0.0 ? 1.0 : 0.0), delta_p[i] = -step_p[i] * scale_p[i];
+  std::vector<double> norm_part(2), upd;
+  T.step_p = step_p.data(), T.delta_p = delta_p.data(), T.n_norm_part = std::max((n_cp + kBlock - 1) / kBlock, 1), T.norm_part = norm_part.data();
+  if (k == 4)
+    run_update<4>(T, nb_vis, R, L, &upd);
+  else
+    run_update<6>(T, nb_vis, R, L, &upd);
+
   FILE* out = fopen(argv[2], "wb");
-  const int ohdr[8] = {bw, np, n_chunk, R, L, vs.y_total, int(lds), 0};
+  const int ohdr[8] = {bw, np, n_chunk, R, L, vs.y_total, int(lds), int(upd.size())};
   fwrite(ohdr, sizeof(int), 8, out);
   const double cost = st.cost;
   fwrite(&cost, 8, 1, out);
@@ -170,6 +210,7 @@ int main(int argc, char** argv) {
     for (int c = 0; c < 3; ++c) ls_tab[3 * vs.table_of_dev[d] + c] = lm_scale[3 * d + c];
   fwrite(ls_tab.data(), 8, ls_tab.size(), out);
   fwrite(scale_p.data(), 8, scale_p.size(), out);
+  fwrite(upd.data(), 8, upd.size(), out);
   fclose(out);
   return 0;
 }

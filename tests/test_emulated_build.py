@@ -57,7 +57,7 @@ def run_emulated_build(exe, w, radius=1e4, R=0, L=0, scaling=None):
                 f.write(np.ascontiguousarray(a).tobytes())
         subprocess.check_call([exe, fin, fout], timeout=600)
         raw = open(fout, "rb").read()
-    bw, np_, n_chunk, R_, L_, y_total, lds, _ = struct.unpack("8i", raw[:32])
+    bw, np_, n_chunk, R_, L_, y_total, lds, n_upd = struct.unpack("8i", raw[:32])
     off = 32
     cost = struct.unpack("d", raw[off:off + 8])[0]
     off += 8
@@ -71,13 +71,14 @@ def run_emulated_build(exe, w, radius=1e4, R=0, L=0, scaling=None):
 
     Sb, g, Y = take(np_ * ncb).reshape(np_, ncb), take(np_), take(y_total)
     lm_scale, scale_p = take(3 * n_lm), take(np_)
+    upd = take(n_upd)
     S = np.zeros((np_, np_))
     for rho in range(np_):
         c0 = 6 * (rho // 6)
         for c in range(min(ncb, np_ - c0)):
             if c0 + c >= rho:
                 S[rho, c0 + c] = S[c0 + c, rho] = Sb[rho, c]
-    return dict(S=S, g=g, cost=cost, bw=bw, n_chunk=n_chunk, R=R_, L=L_, Y=Y, lm_scale=lm_scale, scale_p=scale_p, lds=lds)
+    return dict(S=S, g=g, cost=cost, bw=bw, n_chunk=n_chunk, R=R_, L=L_, Y=Y, lm_scale=lm_scale, scale_p=scale_p, lds=lds, upd=upd)
 
 
 def _check(exe, oracle, w, radius=1e4, tol=1e-9, **kw):
@@ -90,6 +91,12 @@ def _check(exe, oracle, w, radius=1e4, tol=1e-9, **kw):
     assert np.abs(out["S"] - S[:n, :n]).max() <= tol * scale, (np.abs(out["S"] - S[:n, :n]).max() / scale, out["n_chunk"])
     assert np.abs(out["g"] - g[:n]).max() <= tol * max(1.0, np.abs(g).max())
     assert abs(out["cost"] - cost) <= 1e-11 * cost
+    # the candidate point of a (fabricated) step two ways: k_update_visual (per chunk: candidate control points of the window, landmark
+    # back-substitution, candidate cost) against k_backsub_retract + k_cost_visual — landmarks, control points, cost, decision terms, norms
+    u = out["upd"]
+    assert u[0] <= 1e-13 and u[1] == 0.0, u[:2]
+    for a, b in zip(u[2::2], u[3::2]):
+        assert abs(a - b) <= 1e-12 * max(abs(a), 1e-300), (a, b)
     return out
 
 

@@ -89,3 +89,31 @@ def test_rccl_two_ranks_on_two_gpus(tmp_path, hip):
         ids = r["lm_ids"]
         assert rel(r["lm"][ids], lm[ids]) < 1e-7
     assert np.array_equal(ranks[0]["S"], ranks[1]["S"]) and np.array_equal(ranks[0]["cp"], ranks[1]["cp"])
+
+
+@pytest.mark.parametrize("config", [1, 3])
+def test_bench_runs_with_two_ranks(config, tmp_path):
+    """bench.py's N > 1 branch exactly as the driver launches it (torch.distributed.run, one rank per process), with the two ranks sharing
+    the one GPU of the test box (HS_DIST_BACKEND=gloo: the library's exchange hook stages through the host). configs[1]: weak scaling
+    (2 x 50 k blocks on the same 128 control points); configs[3]: the one 200 k-block window dealt over the ranks. The JSON line must
+    parse, carry the whole-job aggregate and say what was exchanged."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(29700 + config + os.getpid() % 200), os.path.join(root, "bench.py"), "--config", str(config), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == ("weak" if config == 1 else "strong") and d["value"] > 0
+    total = 100000 if config == 1 else 200000
+    assert d["config"]["residual_blocks_total"] == total and d["config"]["residual_blocks_per_gpu"] == total // 2
+    assert d["config"]["exchange"] == "hook" and d["config"]["rccl_ranks"] == 0  # gloo on one GPU: the hook, no RCCL communicator
+    assert d["config"]["exchange_bytes_per_iteration_per_rank"] > 8 * 6 * (128 if config == 1 else 512) * 6 * 4
+    assert abs(d["ms_per_step"] - 5 * d["ms_per_gn_iteration"]) < 1e-9 * d["ms_per_step"]

@@ -112,3 +112,12 @@ def test_imu_tables_without_inertial_residuals(gravity_constant, hip, oracle):
         bg, ba = g.bias()
         assert np.array_equal(bg, np.asarray(w.imu["bias_g"]).reshape(-1, 4)) and np.array_equal(ba, np.asarray(w.imu["bias_a"]).reshape(-1, 4))
         assert np.array_equal(g.gravity(), np.asarray(w.gravity, dtype=np.float64))
+
+
+def test_hip_matches_literal_inertial_golden(hip):
+    """The library's DEFAULT inertial Jacobian (as written upstream, inertial.cpp:131-198) at non-identity IMU parameters against the
+    100-digit transcription of tests/golden/make_inertial_literal_golden.py: 32 cases, same bar as the oracle's CPU test."""
+    from util import check_against_literal_golden, golden_window, literal_inertial_cases
+    for case in literal_inertial_cases():
+        with ha.Problem(golden_window(case), lib=hip) as p:
+            check_against_literal_golden(p, case, 1e-9)

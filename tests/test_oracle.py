@@ -29,6 +29,19 @@ def test_oracle_matches_golden(idx, oracle):
         check_against_golden(p, case, 1e-9)
 
 
+def test_oracle_matches_literal_inertial_golden(oracle):
+    """The default inertial Jacobian (as written upstream) off the identity point: 32 cases, orders 4 and 6."""
+    from util import check_against_literal_golden, literal_inertial_cases
+    cases = literal_inertial_cases()
+    assert len(cases) == 32 and {c["inputs"]["k"] for c in cases} == {4, 6}
+    worst = {}
+    for case in cases:
+        with ha.Problem(golden_window(case), lib=oracle) as p:
+            for k, v in check_against_literal_golden(p, case, 1e-9).items():
+                worst[k] = max(worst.get(k, 0.0), v)
+    assert max(worst.values()) < 1e-9, worst
+
+
 def test_oracle_gradient_probe():
     """Mirror of the reference's four `Gradients` tests (tests/internal/tests/optimizers/evaluators/*.cpp)."""
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "selftest"], stdout=subprocess.DEVNULL)

@@ -83,6 +83,33 @@ def check_against_golden(problem, case, tol):
     return errs
 
 
+def literal_inertial_cases():
+    with open(os.path.join(HERE, "golden", "inertial_literal.json")) as f:
+        return json.load(f)["cases"]
+
+
+def check_against_literal_golden(problem, case, tol):
+    """The DEFAULT mode of the libraries (HS_INERTIAL_AS_REFERENCE: the inertial Jacobian as written upstream, inertial.cpp:131-198) against
+    the 100-digit transcription of that text at IMU parameters where it is not the derivative of the prediction
+    (tests/golden/make_inertial_literal_golden.py): residual and the four blocks in which the two forms differ — state, extrinsics, gravity,
+    accelerometer offsets. The same inputs in the exact mode must DIFFER from these vectors (the case is not vacuous)."""
+    out = case["outputs"]
+    problem.set_inertial_jacobian(HS_INERTIAL_AS_REFERENCE)
+    lin = problem.linearize(HS_INERTIAL, robustify=False, sensor_blocks=True)
+    scale = np.abs(np.asarray(out["J_state"])).max()
+    errs = {"r": rel(lin["r"][0], out["r"])}
+    for key in ("J_state", "J_extrinsics", "J_gravity", "J_acc_offsets"):
+        ref = np.asarray(out[key], float)
+        errs[key] = float(np.abs(np.asarray(lin[key][0]) - ref).max() / max(np.abs(ref).max(), 1e-3 * scale))
+    bad = {k: v for k, v in errs.items() if not v < tol}
+    assert not bad, (case["inputs"]["k"], case.get("variant"), bad)
+    problem.set_inertial_jacobian(HS_INERTIAL_EXACT)
+    exact = problem.linearize(HS_INERTIAL, robustify=False, sensor_blocks=True)
+    problem.set_inertial_jacobian(HS_INERTIAL_AS_REFERENCE)
+    assert rel(exact["J_state"][0], out["J_state"]) > 1e-4  # the two forms are different matrices at these parameters
+    return errs
+
+
 def manifold_cases():
     with open(os.path.join(HERE, "golden", "manifolds.json")) as f:
         return json.load(f)["cases"]

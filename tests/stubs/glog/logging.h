@@ -10,6 +10,9 @@ struct Voidify {
   auto operator&(const NullStream&) -> void {}
 };
 }  // namespace google_stub
+namespace google {
+inline void InitGoogleLogging(const char*) {}
+}  // namespace google
 #define HS_STUB_STREAM(condition) (condition) ? (void)0 : google_stub::Voidify{} & google_stub::NullStream{}
 #define LOG(severity) HS_STUB_STREAM(false)
 #define LOG_IF(severity, condition) HS_STUB_STREAM(!(condition))

@@ -21,6 +21,7 @@ namespace hyper {
 using Scalar = double;
 using Stamp = Scalar;
 using Identifier = std::size_t;
+using Index = std::ptrdiff_t;
 template <typename T>
 using Pointers = std::vector<T*>;
 template <typename>
@@ -83,6 +84,7 @@ class Stamped final : public AbstractStamped<Scalar> {
 };
 template <typename TVariable>
 struct Traits<Stamped<TVariable>> {
+  using Stamp = Cartesian<hyper::Stamp, 1>;  // (a variable type: ceres/manifolds/variables/stamped.hpp:32-33 builds Manifold<Stamp, CERES> from it)
   static constexpr auto kNumParameters = 0;
 };
 template <typename TScalar>
@@ -93,9 +95,22 @@ class CompositeVariable {
   auto setVariable(std::size_t, std::unique_ptr<AbstractVariable<TScalar>>&&) -> void;
 };
 template <typename TScalar>
-class AbstractMetric;
+class AbstractMetric {
+ public:
+  virtual ~AbstractMetric() = default;
+};
+template <typename TVariable>
+class AngularMetric final : public AbstractMetric<Scalar> {};    // optimizer.cpp:192
+template <typename TVariable>
+class CartesianMetric final : public AbstractMetric<Scalar> {};  // optimizer.cpp:215,256
+template <typename TVariable>
+class ManifoldMetric final : public AbstractMetric<Scalar> {};   // optimizer.cpp:237
 template <typename TScalar>
 using DynamicJacobian = Eigen::Matrix<TScalar, Eigen::Dynamic, Eigen::Dynamic>;
+template <typename TScalar>
+using DynamicVector = Eigen::Matrix<TScalar, Eigen::Dynamic, 1>;
+template <typename TOutput, typename TInput = TOutput>
+using Jacobian = Eigen::Matrix<Scalar, Eigen::Dynamic, Eigen::Dynamic>;
 
 // ---- hyper/state/** (abstract.cpp:80-96,127-136; optimizer.cpp:286-294; inertial.cpp:34; tests/.../inertial.cpp:55-75) ----
 struct StateQuery {
@@ -121,6 +136,12 @@ class AbstractPolicy {
  public:
   virtual ~AbstractPolicy() = default;
 };
+class BasisInterpolator final : public AbstractInterpolator {  // tests/internal/tests/optimizers/evaluators/bearing.cpp:52: (degree, uniform)
+ public:
+  explicit BasisInterpolator(int degree = 3, bool uniform = true);
+};
+template <typename TVariable>
+class ManifoldPolicy final : public AbstractPolicy {};  // tests/internal/tests/optimizers/evaluators/bearing.cpp:53
 class AbstractState {
  public:
   struct ElementCompare {
@@ -131,7 +152,9 @@ class AbstractState {
   };
   using Elements = std::set<std::unique_ptr<AbstractStamped<Scalar>>, ElementCompare>;
   using Range = hyper::Range<Stamp, BoundaryPolicy::LOWER_INCLUSIVE_ONLY>;
+  AbstractState();  // tests/include/tests/state/abstract.hpp:35
   AbstractState(std::unique_ptr<AbstractInterpolator>&&, std::unique_ptr<AbstractPolicy>&&);
+  auto policy() -> std::unique_ptr<AbstractPolicy>&;  // tests/internal/tests/optimizers/evaluators/bearing.cpp:53
   auto elements() const -> const Elements&;
   auto elements() -> Elements&;
   auto range() const -> Range;
@@ -150,7 +173,28 @@ class Sensor {
   template <typename TSensor>
   auto as() -> TSensor&;
 };
-class Camera final : public Sensor {};
+template <typename TScalar>
+class AbstractDistortion : public AbstractVariable<TScalar> {};
+template <typename TScalar, int TOrder>
+class RadialTangentialDistortion final : public AbstractDistortion<TScalar> {  // tests/include/tests/sensors/camera.hpp:31
+ public:
+  RadialTangentialDistortion(TScalar, TScalar, TScalar, TScalar);
+  auto perturb(TScalar) -> void;
+};
+template <typename TScalar>
+class Intrinsics final : public Cartesian<TScalar, 4> {  // tests/include/tests/sensors/camera.hpp:27
+ public:
+  Intrinsics(TScalar, TScalar, TScalar, TScalar);
+};
+class Camera final : public Sensor {
+ public:
+  struct SensorSize {
+    int width, height;
+  };
+  auto sensorSize() -> SensorSize&;                                                            // tests/include/tests/sensors/camera.hpp:25
+  auto intrinsics() -> Intrinsics<Scalar>&;                                                    // :27
+  auto setDistortion(std::unique_ptr<AbstractDistortion<Scalar>>&&) -> void;                   // :33
+};
 class IMU final : public Sensor {
  public:
   auto gyroscopeBias() const -> const AbstractState&;
@@ -202,9 +246,15 @@ class VariableMeasurement : public AbstractMeasurement {
 using PixelMeasurement = VariableMeasurement<Pixel<Scalar>, Camera>;
 using BearingMeasurement = VariableMeasurement<Bearing<Scalar>, Camera>;
 template <typename TManifold>
-class ManifoldMeasurement final : public VariableMeasurement<TManifold> {};
+class ManifoldMeasurement final : public VariableMeasurement<TManifold> {
+ public:
+  using VariableMeasurement<TManifold>::VariableMeasurement;
+};
 template <typename TManifold>
-class InertialMeasurement final : public VariableMeasurement<Tangent<TManifold>, IMU> {};
+class InertialMeasurement final : public VariableMeasurement<Tangent<TManifold>, IMU> {
+ public:
+  using VariableMeasurement<Tangent<TManifold>, IMU>::VariableMeasurement;
+};
 class VisualTracks;
 
 // ---- hyper/yaml/yaml.hpp (abstract.cpp:165-166; backend.cpp:52-55) ----

@@ -1,0 +1,3 @@
+// Stand-in for the EXTERNAL header of this name (tests/stubs/README.md).
+#pragma once
+#include "hyper/stub_external.hpp"

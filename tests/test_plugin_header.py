@@ -74,3 +74,18 @@ def test_control_point_table_stays_contiguous():
     opt = text[text.index("auto optimize() -> void final"):text.index("// ---- sensors:")]
     assert "elements.lower_bound(oldest_stamp)" in opt and "!variables_.contains(itr->get())" in opt
     assert "admitted(m.stamp())" in text and text.count("admitted(m.stamp())") == 4  # bearing, pixel, prior, inertial tables
+
+
+def test_reference_dump_compiles_against_the_reference_interface():
+    """tools/reference_dump.cpp — the reference side of the conformance kit: the reference's own evaluators (ExteroceptiveCost::update /
+    Evaluate over Evaluator<Observation, SE3>), manifolds (ceres/manifolds/**) and ceres::Solve on the inputs of tests/golden/*.json, written
+    out in the same schema (HS_REFERENCE_VECTORS=<dir> then points the golden tests at them, tests/util.py). It can only run where HyperSLAM
+    builds; here every call into the reference's API is type-checked exactly like the plugin."""
+    tool = os.path.join(ROOT, "tools", "reference_dump.cpp")
+    out = subprocess.run(["g++", "-std=c++20", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", REFERENCE,
+                          "-I", os.path.join(ROOT, "tests", "stubs"), tool], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    text = open(tool).read()
+    for needed in ("cost.update()", "cost.Evaluate(", "RightMultiplyByPlusJacobian", "ceres::Solve(", "MinusJacobian", "factors.json", "inertial_literal.json",
+                   "manifolds.json", "solve_visual.json"):
+        assert needed in text, needed

@@ -16,9 +16,38 @@ def rel(a, b):
     return float(np.abs(a - b).max() / max(1e-300, np.abs(b).max()))
 
 
+def reference_vectors(name):
+    """HS_REFERENCE_VECTORS=<dir>: outputs of the REAL reference on the inputs of tests/golden/<name> (written by tools/reference_dump.cpp where
+    HyperSLAM builds; same case order, same schema). None when the variable is unset: the suite then checks against the 100-digit restatements
+    of tests/golden/make_*.py — which is all this repository can do on its own ("parity unpinned")."""
+    d = os.environ.get("HS_REFERENCE_VECTORS")
+    if not d:
+        return None
+    with open(os.path.join(d, name)) as f:
+        return json.load(f)
+
+
+def _overlay_cases(cases, name, keys=None):
+    ref = reference_vectors(name)
+    if ref is None:
+        return cases
+    assert len(ref["cases"]) == len(cases), (name, len(ref["cases"]), len(cases))
+    for c, r in zip(cases, ref["cases"]):
+        if "outputs" in r:
+            assert r["type"] == c["type"]
+            c["outputs"], c["reference"] = r["outputs"], True
+        else:
+            assert r["kind"] == c["kind"] and r["ambient"] == c["ambient"] and r["tangent"] == c["tangent"]
+            for k in (keys or r):
+                if k in r:
+                    c[k] = r[k]
+            c["reference"] = True
+    return cases
+
+
 def golden_cases():
     with open(os.path.join(HERE, "golden", "factors.json")) as f:
-        return json.load(f)["cases"]
+        return _overlay_cases(json.load(f)["cases"], "factors.json")
 
 
 def golden_window(case) -> Window:
@@ -63,6 +92,8 @@ def check_against_golden(problem, case, tol):
     modes = [None]
     if case["type"] == "inertial":
         modes = [HS_INERTIAL_EXACT] + ([HS_INERTIAL_AS_REFERENCE] if case.get("variant") == "identity" else [])
+        if case.get("reference"):  # vectors of the reference itself (HS_REFERENCE_VECTORS): its Jacobian is the one written in inertial.cpp
+            modes = [HS_INERTIAL_AS_REFERENCE]
     # a bearing 1e-5 rad off its measurement: the direction of the Jacobian is conditioned like 1 / angle
     tol = tol * 1e3 if case.get("variant") == "small_angle" else tol
     errs = {}
@@ -85,7 +116,7 @@ def check_against_golden(problem, case, tol):
 
 def literal_inertial_cases():
     with open(os.path.join(HERE, "golden", "inertial_literal.json")) as f:
-        return json.load(f)["cases"]
+        return _overlay_cases(json.load(f)["cases"], "inertial_literal.json")
 
 
 def check_against_literal_golden(problem, case, tol):
@@ -112,7 +143,7 @@ def check_against_literal_golden(problem, case, tol):
 
 def manifold_cases():
     with open(os.path.join(HERE, "golden", "manifolds.json")) as f:
-        return json.load(f)["cases"]
+        return _overlay_cases(json.load(f)["cases"], "manifolds.json", keys=("plus", "jacobian", "minus", "minus_jacobian"))
 
 
 def check_manifolds_against_golden(problem, tol):
@@ -178,6 +209,14 @@ def solve_golden(name="solve.json"):
     solver quantities. `name` may be a path."""
     with open(name if os.path.isabs(name) else os.path.join(HERE, "golden", name)) as f:
         d = json.load(f)
+    ref = None if os.path.isabs(name) else reference_vectors(name)
+    if ref is not None:  # the reference's own ceres::Solve on this window (tools/reference_dump.cpp): its records and states replace the restatement's
+        assert len(ref["iterations"]) == len(d["iterations"])
+        d["initial_cost"], d["reference"] = ref["initial_cost"], True
+        for it, r in zip(d["iterations"], ref["iterations"]):
+            for k in ("reduced_S", "reduced_g", "radius_before", "gradient_max_norm_before"):
+                it.pop(k, None)  # quantities Ceres does not report
+            it.update(r)
     blocks = d["blocks"]
 
     def table(ftype, key, width=None):
@@ -224,17 +263,22 @@ def check_solver_against_golden(lib, tol_forward, tol_state, name="solve.json"):
         assert e <= tol_state, (what, e)
         worst["state"] = max(worst["state"], e)
 
+    from hyperslam_amd import HS_INERTIAL_AS_REFERENCE
+    # every vector of the restatement is a derivative (the IMU parameters are not at the identity point): exact mode; the reference's own
+    # solve (HS_REFERENCE_VECTORS) runs on the Jacobian written in inertial.cpp: the libraries' default mode
+    mode = HS_INERTIAL_AS_REFERENCE if d.get("reference") else HS_INERTIAL_EXACT
     with Problem(w, lib=lib) as p:
         if has_imu:
-            p.set_inertial_jacobian(HS_INERTIAL_EXACT)  # every golden Jacobian is a derivative; the IMU parameters are not at the identity point
+            p.set_inertial_jacobian(mode)
         fwd(p.cost(), d["initial_cost"], "initial cost")
-        S, g = p.reduced_system(its[0]["radius_before"])
-        fwd(S, its[0]["reduced_S"], "reduced system, first iteration")
-        fwd(g, its[0]["reduced_g"], "reduced gradient, first iteration")
+        if "reduced_S" in its[0]:
+            S, g = p.reduced_system(its[0]["radius_before"])
+            fwd(S, its[0]["reduced_S"], "reduced system, first iteration")
+            fwd(g, its[0]["reduced_g"], "reduced gradient, first iteration")
         for n in range(1, len(its) + 1):  # the state after n iterations, from the same starting point every time
             p.upload(w)
             if has_imu:
-                p.set_inertial_jacobian(HS_INERTIAL_EXACT)
+                p.set_inertial_jacobian(mode)
             s = p.solve(n)
             assert s["num_iterations"] == n
             golden_state = its[n - 1]["state"]
@@ -260,6 +304,8 @@ def check_solver_against_golden(lib, tol_forward, tol_state, name="solve.json"):
             # the last record of a solve keeps the gradient from before its step (include/hyperslam_hip.h): the product library does not
             # linearise at the final point; the oracle, like Ceres, does
             last = gold is its[-1]
+            if last and lib.prefix == "hs_" and "gradient_max_norm_before" not in gold:
+                continue  # (reference vectors: Ceres reports the gradient at the final point only, which the product library does not evaluate)
             sta(rec["gradient_max_norm"], gold["gradient_max_norm_before"] if (last and lib.prefix == "hs_") else gold["gradient_max_norm"],
                 "gradient max norm (local coordinates)")
     return worst
@@ -284,7 +330,7 @@ def check_knot_uniformity_is_enforced(lib):
     w2 = synthetic.small_visual(order=4, n_cp=14, n_landmarks=20, obs_pairs=2)
     w2.control_points = acc
     with ha.Problem(w2, lib=lib) as p:
-        assert p.cost() == c0
+        assert abs(p.cost() - c0) <= 1e-12 * c0  # (the oracle, like the reference, reads the knots from the rows; the product library derives them)
     for what in ("hole", "shifted"):
         bad = w.control_points.copy()
         if what == "hole":  # element 6 pruned: every later row moves up, a fresh one is appended at the end

@@ -1,0 +1,543 @@
+/// reference_dump.cpp — CONFORMANCE KIT, reference side. Runs the REAL HyperSLAM evaluators, manifolds and Ceres solve on the inputs of this
+/// repository's golden files and writes their outputs in the same schema, so that whoever can build HyperSLAM can close what this
+/// repository cannot ("parity unpinned"): the oracle and the HIP library are then checked against the reference itself,
+///     HS_REFERENCE_VECTORS=<out dir> python -m pytest tests/test_oracle.py tests/test_solve_golden.py            (CPU, oracle)
+///     HS_REFERENCE_VECTORS=<out dir> python -m pytest tests -m gpu -k "golden"                                    (MI355X, HIP path)
+/// instead of against the 100-digit restatements of tests/golden/make_*.py.
+///
+/// WHERE THIS FILE LIVES. Like include/hyper/optimizers/hip/optimizer.hpp it is written against the HyperSLAM tree (Eigen, Ceres, glog,
+/// yaml-cpp, HyperVariables / HyperState / HyperSensors), none of which exist in this repository's image: here it is only type-checked
+/// (`g++ -std=c++20 -fsyntax-only`) against the reference's in-tree headers with the declaration-only stand-ins of tests/stubs/
+/// (tests/test_plugin_header.py::test_reference_dump_compiles_against_the_reference_interface). A maintainer adds it to the reference's
+/// tests (it needs nothing beyond what tests/internal/tests/optimizers/evaluators/*.cpp link) and runs
+///     reference_dump <this repo>/tests/golden <out dir>
+///
+/// Every construction below follows an in-tree call site:
+///   state, sensors, bias splines   tests/include/tests/state/abstract.hpp:33-43, tests/include/tests/sensors/{camera,imu,sensor}.hpp,
+///                                  tests/internal/tests/optimizers/evaluators/inertial.cpp:62-90
+///   cost + manifolds per factor    tests/internal/tests/optimizers/evaluators/{bearing,pixel,manifold,inertial}.cpp (checkGradients)
+///   local Jacobian                 J_ambient * Manifold::PlusJacobian — the quantity ceres::GradientChecker compares,
+///                                  tests/include/tests/optimizers/evaluators/evaluator.hpp:38-65
+///   losses, problem / solver options   internal/hyper/optimizers/ceres/optimizer.cpp:28-54,189-274 (restated here: they are file-local there)
+/// Sensor parameter blocks are written through sensor.parameters()[Traits<...>::k...Offset]->asVector() (the access path of
+/// optimizer.cpp:143-155 and of the evaluators), so no accessor name of the EXTERNAL sensor classes is guessed.
+/// Golden files are read with yaml-cpp (JSON is YAML flow style).
+#include <cmath>
+#include <fstream>
+#include <iomanip>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include <ceres/ceres.h>
+#include <glog/logging.h>
+#include <yaml-cpp/yaml.h>
+
+#include "hyper/environment/observations/inertial.hpp"
+#include "hyper/environment/observations/manifold.hpp"
+#include "hyper/environment/observations/visual.hpp"
+#include "hyper/messages/measurements/inertial.hpp"
+#include "hyper/messages/measurements/variable.hpp"
+#include "hyper/messages/measurements/visual.hpp"
+#include "hyper/optimizers/ceres/costs/exteroceptive.hpp"
+#include "hyper/optimizers/ceres/manifolds/sensors/camera.hpp"
+#include "hyper/optimizers/ceres/manifolds/sensors/imu.hpp"
+#include "hyper/optimizers/ceres/manifolds/sensors/sensor.hpp"
+#include "hyper/optimizers/ceres/manifolds/variables/euclidean.hpp"
+#include "hyper/optimizers/ceres/manifolds/variables/gravity.hpp"
+#include "hyper/optimizers/ceres/manifolds/variables/se3.hpp"
+#include "hyper/optimizers/ceres/manifolds/variables/stamped.hpp"
+#include "hyper/optimizers/evaluators/evaluator.hpp"
+#include "hyper/sensors/camera.hpp"
+#include "hyper/sensors/imu.hpp"
+#include "hyper/state/abstract.hpp"
+#include "hyper/state/interpolators/basis.hpp"
+#include "hyper/state/policies/se3.hpp"
+#include "hyper/variables/distortions/radial_tangential.hpp"
+#include "hyper/variables/gravity.hpp"
+#include "hyper/variables/groups/se3.hpp"
+#include "hyper/variables/intrinsics.hpp"
+#include "hyper/variables/metrics/angular.hpp"
+#include "hyper/variables/metrics/cartesian.hpp"
+#include "hyper/variables/metrics/manifold.hpp"
+#include "hyper/variables/stamped.hpp"
+
+namespace hyper::conformance {
+
+using Space = SE3<Scalar>;
+using StampedSpace = Stamped<Space>;
+using Cost = ExteroceptiveCost<OptimizerSuite::CERES>;
+using Manifolds = Pointers<const ceres::Manifold>;
+using Values = std::vector<Scalar>;
+
+// ---- JSON out -----------------------------------------------------------------------------------------------------------------
+struct Json {
+  std::ostringstream os;
+  Json() { os << std::setprecision(17); }
+  auto key(const std::string& k) -> Json& {
+    os << '"' << k << "\":";
+    return *this;
+  }
+  auto vector(const Values& v) -> Json& {
+    os << '[';
+    for (std::size_t i = 0; i < v.size(); ++i) os << (i ? "," : "") << v[i];
+    os << ']';
+    return *this;
+  }
+  /// Row-major n_rows x n_cols matrix as a list of rows.
+  auto matrix(const Values& m, const int n_rows, const int n_cols) -> Json& {
+    os << '[';
+    for (int r = 0; r < n_rows; ++r) {
+      os << (r ? "," : "");
+      vector(Values(m.begin() + r * n_cols, m.begin() + (r + 1) * n_cols));
+    }
+    os << ']';
+    return *this;
+  }
+};
+
+auto values(const YAML::Node& node) -> Values {
+  Values v;
+  for (const auto& x : node) v.push_back(x.as<Scalar>());
+  return v;
+}
+
+template <typename TVariable>
+auto assign(TVariable& variable, const Values& v) -> void {
+  auto map = variable.asVector();
+  CHECK_EQ(static_cast<std::size_t>(map.size()), v.size());
+  for (std::size_t i = 0; i < v.size(); ++i) map[static_cast<Eigen::Index>(i)] = v[i];
+}
+
+// ---- the window of one golden case ---------------------------------------------------------------------------------------------
+/// State of k (or more) control points [q(4) p(3) t] with the uniform basis of order k (tests/.../bearing.cpp:51-53: degree k - 1, uniform).
+auto makeState(const YAML::Node& cps, const int order) -> std::unique_ptr<AbstractState> {
+  auto state = std::make_unique<AbstractState>();
+  for (const auto& cp : cps) {
+    const auto v = values(cp);
+    auto element = std::make_unique<StampedSpace>();
+    element->stamp() = v[7];
+    assign(element->variable(), Values(v.begin(), v.begin() + 7));
+    state->elements().insert(std::move(element));
+  }
+  state->interpolator() = std::make_unique<BasisInterpolator>(order - 1, true);
+  state->policy() = std::make_unique<ManifoldPolicy<StampedSpace>>();
+  return state;
+}
+
+auto makeCamera(const Values& T_bs, const Values& intrinsics, const Values& distortion) -> std::unique_ptr<Camera> {
+  auto camera = std::make_unique<Camera>();  // tests/include/tests/sensors/camera.hpp:24-36
+  camera->sensorSize() = {752, 480};
+  camera->setDistortion(std::make_unique<RadialTangentialDistortion<Scalar, 2>>(distortion[0], distortion[1], distortion[2], distortion[3]));
+  const auto parameters = camera->parameters();
+  assign(*parameters[Traits<Camera>::kTransformationOffset], T_bs);
+  assign(*parameters[Traits<Camera>::kIntrinsicsOffset], intrinsics);
+  assign(*parameters[Traits<Camera>::kDistortionOffset], distortion);
+  return camera;
+}
+
+auto makeIMU(const YAML::Node& in) -> std::unique_ptr<IMU> {
+  auto imu = std::make_unique<IMU>();  // tests/include/tests/sensors/imu.hpp:21-27
+  const auto parameters = imu->parameters();
+  assign(*parameters[Traits<IMU>::kTransformationOffset], values(in["T_bs"]));
+  assign(*parameters[Traits<IMU>::kGyroscopeIntrinsicsOffset], values(in["i_g"]));
+  assign(*parameters[Traits<IMU>::kAccelerometerIntrinsicsOffset], values(in["i_a"]));
+  assign(*parameters[Traits<IMU>::kGyroscopeSensitivityOffset], values(in["S_g"]));
+  assign(*parameters[Traits<IMU>::kAccelerometerAxesOffsetsOffset], values(in["X_a"]));
+  const auto fill = [](AbstractState& bias, const YAML::Node& points, auto make) {  // tests/.../inertial.cpp:68-90
+    for (const auto& point : points) {
+      const auto v = values(point);
+      auto element = make();
+      element->stamp() = v[3];
+      assign(element->variable(), Values(v.begin(), v.begin() + 3));
+      bias.elements().insert(std::move(element));
+    }
+  };
+  fill(imu->gyroscopeBias(), in["bias_g"], [] { return std::make_unique<Traits<IMU>::GyroscopeBias>(); });
+  fill(imu->accelerometerBias(), in["bias_a"], [] { return std::make_unique<Traits<IMU>::AccelerometerBias>(); });
+  return imu;
+}
+
+/// Evaluate + project: residuals and, per parameter block, J_ambient * PlusJacobian (row-major n_res x tangent size).
+struct Evaluation {
+  Values residuals;
+  std::vector<Values> local;  // per block
+  std::vector<int> tangent;
+};
+auto evaluate(Cost& cost, const Manifolds& manifolds) -> Evaluation {
+  const auto parameters = cost.update();
+  CHECK_EQ(parameters.size(), manifolds.size());
+  const auto& sizes = cost.parameter_block_sizes();
+  const auto n_res = cost.num_residuals();
+  Evaluation e;
+  e.residuals.resize(n_res);
+  std::vector<Values> ambient(sizes.size());
+  std::vector<Scalar*> pointers(sizes.size());
+  for (std::size_t b = 0; b < sizes.size(); ++b) ambient[b].resize(static_cast<std::size_t>(n_res) * sizes[b]), pointers[b] = ambient[b].data();
+  CHECK(cost.Evaluate(parameters.data(), e.residuals.data(), pointers.data()));
+  for (std::size_t b = 0; b < sizes.size(); ++b) {
+    const auto tangent = manifolds[b]->TangentSize();
+    Values local(static_cast<std::size_t>(n_res) * tangent);
+    CHECK(manifolds[b]->RightMultiplyByPlusJacobian(parameters[b], n_res, ambient[b].data(), local.data()));
+    e.local.push_back(std::move(local)), e.tangent.push_back(tangent);
+  }
+  return e;
+}
+
+/// Blocks [first, first + count) side by side: n_res x (sum of tangent sizes).
+auto concatenate(const Evaluation& e, const std::size_t first, const std::size_t count, const int n_res) -> std::pair<Values, int> {
+  int n_cols = 0;
+  for (std::size_t b = first; b < first + count; ++b) n_cols += e.tangent[b];
+  Values out(static_cast<std::size_t>(n_res) * n_cols);
+  int col = 0;
+  for (std::size_t b = first; b < first + count; ++b) {
+    for (int r = 0; r < n_res; ++r)
+      for (int c = 0; c < e.tangent[b]; ++c) out[static_cast<std::size_t>(r) * n_cols + col + c] = e.local[b][static_cast<std::size_t>(r) * e.tangent[b] + c];
+    col += e.tangent[b];
+  }
+  return {out, n_cols};
+}
+
+auto emitBlock(Json& json, const std::string& name, const Evaluation& e, const std::size_t first, const std::size_t count, const int n_res) -> void {
+  const auto [m, n_cols] = concatenate(e, first, count, n_res);
+  json.os << ',';
+  json.key(name).matrix(m, n_res, n_cols);
+}
+
+/// One case of factors.json / inertial_literal.json -> {"type", "variant", "outputs": {...}} (inputs are matched by position).
+auto factorCase(const YAML::Node& c) -> std::string {
+  const auto type = c["type"].as<std::string>();
+  const auto& in = c["inputs"];
+  const auto order = in["k"].as<int>();
+  const auto k = static_cast<std::size_t>(order);
+  const auto stamp = in["stamp"].as<Scalar>();
+  auto state = makeState(in["cps"], order);
+  const auto state_manifold = Manifold<StampedSpace, OptimizerSuite::CERES>{true, false, false};
+  Manifolds manifolds(k, &state_manifold);
+  Json json;
+  json.os << "{\"type\":\"" << type << "\",\"outputs\":{";
+  if (type == "pixel" || type == "bearing") {
+    const auto camera = makeCamera(values(in["T_bs"]), values(in["intrinsics"]), values(in["distortion"]));
+    const auto camera_manifold = Manifold<Camera, OptimizerSuite::CERES>{*camera, false};
+    const auto camera_manifolds = camera_manifold.manifolds(stamp);
+    manifolds.insert(manifolds.end(), camera_manifolds.begin(), camera_manifolds.end());
+    auto landmark = VisualBearingObservation::Landmark{};
+    assign(landmark.variable(), values(in["landmark"]));
+    const auto landmark_manifold = Manifold<Position<Scalar>, OptimizerSuite::CERES>{false};
+    manifolds.emplace_back(&landmark_manifold);
+    Evaluation e;
+    if (type == "pixel") {
+      Pixel<Scalar> pixel;
+      assign(pixel, values(in["meas"]));
+      auto measurement = PixelMeasurement{stamp, *camera, pixel};
+      auto observation = VisualPixelObservation{measurement, landmark};
+      const auto metric = CartesianMetric<Pixel<Scalar>>{};
+      const auto evaluator = Evaluator<VisualPixelObservation, Space>{};
+      const auto configuration = CostConfiguration<Scalar>{nullptr, &metric, &evaluator};
+      auto cost = Cost{configuration, CostContext{state.get(), &observation}};
+      e = evaluate(cost, manifolds);
+    } else {
+      Bearing<Scalar> bearing;
+      assign(bearing, values(in["meas"]));
+      auto measurement = BearingMeasurement{stamp, *camera, bearing};
+      auto observation = VisualBearingObservation{measurement, landmark};
+      const auto metric = AngularMetric<Bearing<Scalar>>{};
+      const auto evaluator = Evaluator<VisualBearingObservation, Space>{};
+      const auto configuration = CostConfiguration<Scalar>{nullptr, &metric, &evaluator};
+      auto cost = Cost{configuration, CostContext{state.get(), &observation}};
+      e = evaluate(cost, manifolds);
+    }
+    const auto n_res = static_cast<int>(e.residuals.size());
+    json.key("r").vector(e.residuals);
+    emitBlock(json, "J_state", e, 0, k, n_res);
+    emitBlock(json, "J_extrinsics", e, k + Traits<Camera>::kTransformationOffset, 1, n_res);
+    if (type == "pixel") {
+      emitBlock(json, "J_intrinsics", e, k + Traits<Camera>::kIntrinsicsOffset, 1, n_res);
+      emitBlock(json, "J_distortion", e, k + Traits<Camera>::kDistortionOffset, 1, n_res);
+    }
+    emitBlock(json, "J_landmark", e, manifolds.size() - 1, 1, n_res);
+  } else if (type == "prior") {
+    auto sensor = std::make_unique<Sensor>();  // tests/include/tests/sensors/sensor.hpp:20-24
+    assign(*sensor->parameters()[Traits<Sensor>::kTransformationOffset], values(in["T_bs"]));
+    const auto sensor_manifold = Manifold<Sensor, OptimizerSuite::CERES>{*sensor, false};
+    const auto sensor_manifolds = sensor_manifold.manifolds(stamp);
+    manifolds.insert(manifolds.end(), sensor_manifolds.begin(), sensor_manifolds.end());
+    Space pose;
+    assign(pose, values(in["meas"]));
+    auto measurement = ManifoldMeasurement<Space>{stamp, *sensor, pose};
+    auto observation = ManifoldObservation<Space>{measurement};
+    const auto metric = ManifoldMetric<Space>{};
+    const auto evaluator = Evaluator<ManifoldObservation<Space>, Space>{};
+    const auto configuration = CostConfiguration<Scalar>{nullptr, &metric, &evaluator};
+    auto cost = Cost{configuration, CostContext{state.get(), &observation}};
+    const auto e = evaluate(cost, manifolds);
+    json.key("r").vector(e.residuals);
+    emitBlock(json, "J_state", e, 0, k, 6);
+    emitBlock(json, "J_extrinsics", e, k, 1, 6);
+  } else {
+    const auto imu = makeIMU(in);
+    const auto kb = static_cast<std::size_t>(in["kb"].as<int>());
+    const auto imu_manifold = Manifold<IMU, OptimizerSuite::CERES>{*imu, false};
+    const auto imu_manifolds = imu_manifold.manifolds(stamp);  // static blocks, then the bias elements the stamp reads (tests/.../inertial.cpp)
+    manifolds.insert(manifolds.end(), imu_manifolds.begin(), imu_manifolds.end());
+    Gravity<Scalar> gravity;
+    assign(gravity, values(in["gravity"]));
+    const auto gravity_manifold = Manifold<Gravity<Scalar>, OptimizerSuite::CERES>{false};
+    manifolds.emplace_back(&gravity_manifold);
+    Tangent<Space> tangent;
+    assign(tangent, values(in["meas"]));
+    auto measurement = InertialMeasurement<Space>{stamp, *imu, tangent};
+    auto observation = InertialObservation<Space>{measurement, gravity};
+    const auto metric = CartesianMetric<Cartesian<Scalar, 6>>{};
+    const auto evaluator = Evaluator<InertialObservation<Space>, Space>{};
+    const auto configuration = CostConfiguration<Scalar>{nullptr, &metric, &evaluator};
+    auto cost = Cost{configuration, CostContext{state.get(), &observation}};
+    const auto e = evaluate(cost, manifolds);
+    json.key("r").vector(e.residuals);
+    emitBlock(json, "J_state", e, 0, k, 6);
+    emitBlock(json, "J_extrinsics", e, k + Traits<IMU>::kTransformationOffset, 1, 6);
+    emitBlock(json, "J_gyro_intrinsics", e, k + Traits<IMU>::kGyroscopeIntrinsicsOffset, 1, 6);
+    emitBlock(json, "J_acc_intrinsics", e, k + Traits<IMU>::kAccelerometerIntrinsicsOffset, 1, 6);
+    emitBlock(json, "J_gyro_sensitivity", e, k + Traits<IMU>::kGyroscopeSensitivityOffset, 1, 6);
+    emitBlock(json, "J_acc_offsets", e, k + Traits<IMU>::kAccelerometerAxesOffsetsOffset, 1, 6);
+    const auto first_bias = manifolds.size() - 1 - 2 * kb;
+    emitBlock(json, "J_bias_g", e, first_bias, kb, 6);
+    emitBlock(json, "J_bias_a", e, first_bias + kb, kb, 6);
+    emitBlock(json, "J_gravity", e, manifolds.size() - 1, 1, 6);
+  }
+  json.os << "}}";
+  return json.os.str();
+}
+
+/// Plus / PlusJacobian / Minus / MinusJacobian of the manifold classes of include/hyper/optimizers/ceres/manifolds/variables/
+/// (wrapper.hpp:24-50) for one case of manifolds.json; kinds as in include/hyperslam_hip.h (HS_MANIFOLD_*).
+auto manifoldCase(const YAML::Node& c) -> std::string {
+  const auto kind = c["kind"].as<int>();
+  const auto ambient = c["ambient"].as<int>();
+  std::unique_ptr<ceres::Manifold> manifold;
+  switch (kind) {
+    case 0: manifold = std::make_unique<Manifold<Cartesian<Scalar, Eigen::Dynamic>, OptimizerSuite::CERES>>(ambient, true); break;   // constant block
+    case 1: manifold = std::make_unique<Manifold<Cartesian<Scalar, Eigen::Dynamic>, OptimizerSuite::CERES>>(ambient, false); break;  // Euclidean
+    case 2: manifold = std::make_unique<Manifold<StampedSpace, OptimizerSuite::CERES>>(true, false, false); break;
+    case 3: manifold = std::make_unique<Manifold<Space, OptimizerSuite::CERES>>(false, false); break;
+    case 4: manifold = std::make_unique<Manifold<Gravity<Scalar>, OptimizerSuite::CERES>>(false); break;
+    default: manifold = std::make_unique<Manifold<Stamped<Cartesian<Scalar, 3>>, OptimizerSuite::CERES>>(true, false); break;
+  }
+  const auto tangent = manifold->TangentSize();
+  const auto x = values(c["x"]), delta = values(c["delta"]);
+  Values plus(ambient), jacobian(static_cast<std::size_t>(ambient) * tangent), minus(tangent), minus_jacobian(static_cast<std::size_t>(tangent) * ambient);
+  CHECK(manifold->Plus(x.data(), delta.data(), plus.data()));
+  Json json;
+  json.os << "{\"kind\":" << kind << ",\"ambient\":" << ambient << ",\"tangent\":" << tangent << ',';
+  json.key("plus").vector(plus);
+  if (tangent > 0) {
+    CHECK(manifold->PlusJacobian(x.data(), jacobian.data()));
+    CHECK(manifold->Minus(plus.data(), x.data(), minus.data()));
+    CHECK(manifold->MinusJacobian(x.data(), minus_jacobian.data()));
+    json.os << ',';
+    json.key("jacobian").matrix(jacobian, ambient, tangent);
+    json.os << ',';
+    json.key("minus").vector(minus);
+    json.os << ',';
+    json.key("minus_jacobian").matrix(minus_jacobian, tangent, ambient);
+  }
+  json.os << '}';
+  return json.os.str();
+}
+
+// ---- the solver level: ceres::Solve as CeresOptimizer::optimize() runs it (optimizer.cpp:28-54,189-280) -----------------------------
+/// Per-iteration records + the state after every iteration (update_state_every_iteration), for solve.json / solve_visual.json.
+class Recorder final : public ceres::IterationCallback {
+ public:
+  Recorder(std::vector<std::pair<std::string, std::vector<AbstractVariable<Scalar>*>>> groups) : groups_{std::move(groups)} {}
+  auto operator()(const ceres::IterationSummary& s) -> ceres::CallbackReturnType final {
+    if (s.iteration == 0) {
+      initial_cost = s.cost;
+      return ceres::SOLVER_CONTINUE;
+    }
+    Json json;
+    json.os << "{\"iteration\":" << s.iteration << ",\"cost\":" << s.cost << ",\"cost_change\":" << s.cost_change << ",\"gradient_max_norm\":" << s.gradient_max_norm
+            << ",\"step_norm\":" << s.step_norm << ",\"relative_decrease\":" << s.relative_decrease << ",\"radius\":" << s.trust_region_radius
+            << ",\"step_is_successful\":" << (s.step_is_successful ? 1 : 0) << ",\"state\":{";
+    bool first = true;
+    for (const auto& [name, variables] : groups_) {
+      json.os << (first ? "" : ",") << '"' << name << "\":[";
+      first = false;
+      for (std::size_t i = 0; i < variables.size(); ++i) {
+        const auto v = variables[i]->asVector();
+        json.os << (i ? "," : "");
+        json.vector(Values(v.data(), v.data() + v.size()));
+      }
+      json.os << ']';
+    }
+    json.os << "}}";
+    records.push_back(json.os.str());
+    return ceres::SOLVER_CONTINUE;
+  }
+  Scalar initial_cost{0};
+  std::vector<std::string> records;
+
+ private:
+  std::vector<std::pair<std::string, std::vector<AbstractVariable<Scalar>*>>> groups_;
+};
+
+auto solveWindow(const YAML::Node& d) -> std::string {
+  const auto order = d["order"].as<int>();
+  auto state = makeState(d["initial"]["control_points"], order);
+  const auto free_state = Manifold<StampedSpace, OptimizerSuite::CERES>{true, false, false};
+  // cameras / pose sensor / IMU
+  std::vector<std::unique_ptr<Camera>> cameras;
+  for (const auto& c : d["cameras"]) cameras.push_back(makeCamera(values(c["T_bs"]), values(c["intrinsics"]), values(c["distortion"])));
+  auto sensor = std::make_unique<Sensor>();
+  assign(*sensor->parameters()[Traits<Sensor>::kTransformationOffset], values(d["sensor_T_bs"]));
+  std::unique_ptr<IMU> imu;
+  Gravity<Scalar> gravity;
+  if (d["imu"] && !d["imu"].IsNull()) {
+    YAML::Node in = YAML::Clone(d["imu"]);
+    in["bias_g"] = d["initial"]["bias_g"], in["bias_a"] = d["initial"]["bias_a"];
+    imu = makeIMU(in);
+    assign(gravity, values(d["initial"]["gravity"]));
+  }
+  std::vector<VisualBearingObservation::Landmark> landmarks(d["initial"]["landmarks"].size());
+  for (std::size_t l = 0; l < landmarks.size(); ++l) assign(landmarks[l].variable(), values(d["initial"]["landmarks"][l]));
+
+  // problem (optimizer.cpp:28-36) — manifolds as createSensorManifold / setStateManifold configure them: sensors constant, bias + gravity free
+  ceres::Problem::Options problem_options;
+  problem_options.cost_function_ownership = ceres::TAKE_OWNERSHIP;
+  problem_options.loss_function_ownership = ceres::DO_NOT_TAKE_OWNERSHIP;
+  problem_options.manifold_ownership = ceres::DO_NOT_TAKE_OWNERSHIP;
+  problem_options.enable_fast_removal = true;
+  ceres::Problem problem{problem_options};
+  auto huber_bearing = ceres::HuberLoss{1.6e-3};                                   // optimizer.cpp:204
+  auto huber_pixel = ceres::HuberLoss{0.5};                                        // optimizer.cpp:226
+  auto scaled_inertial = ceres::ScaledLoss{nullptr, 1.6e-5, ceres::TAKE_OWNERSHIP};  // optimizer.cpp:267-268
+  const auto metric_bearing = AngularMetric<Bearing<Scalar>>{};
+  const auto metric_pixel = CartesianMetric<Pixel<Scalar>>{};
+  const auto metric_prior = ManifoldMetric<Space>{};
+  const auto metric_inertial = CartesianMetric<Cartesian<Scalar, 6>>{};
+  const auto evaluator_bearing = Evaluator<VisualBearingObservation, Space>{};
+  const auto evaluator_pixel = Evaluator<VisualPixelObservation, Space>{};
+  const auto evaluator_prior = Evaluator<ManifoldObservation<Space>, Space>{};
+  const auto evaluator_inertial = Evaluator<InertialObservation<Space>, Space>{};
+  // measurements and observations live as long as the problem
+  std::vector<std::unique_ptr<PixelMeasurement>> pixel_measurements;
+  std::vector<std::unique_ptr<BearingMeasurement>> bearing_measurements;
+  std::vector<std::unique_ptr<ManifoldMeasurement<Space>>> prior_measurements;
+  std::vector<std::unique_ptr<InertialMeasurement<Space>>> inertial_measurements;
+  std::vector<std::unique_ptr<VisualPixelObservation>> pixel_observations;
+  std::vector<std::unique_ptr<VisualBearingObservation>> bearing_observations;
+  std::vector<std::unique_ptr<ManifoldObservation<Space>>> prior_observations;
+  std::vector<std::unique_ptr<InertialObservation<Space>>> inertial_observations;
+  for (const auto& b : d["blocks"]) {
+    const auto type = b["type"].as<std::string>();
+    const auto stamp = b["stamp"].as<Scalar>();
+    Cost* cost = nullptr;
+    ceres::LossFunction* loss = nullptr;
+    if (type == "pixel") {
+      Pixel<Scalar> pixel;
+      assign(pixel, values(b["meas"]));
+      pixel_measurements.push_back(std::make_unique<PixelMeasurement>(stamp, *cameras[b["camera"].as<std::size_t>()], pixel));
+      pixel_observations.push_back(std::make_unique<VisualPixelObservation>(*pixel_measurements.back(), landmarks[b["landmark"].as<std::size_t>()]));
+      cost = new Cost{CostConfiguration<Scalar>{nullptr, &metric_pixel, &evaluator_pixel}, CostContext{state.get(), pixel_observations.back().get()}};
+      loss = &huber_pixel;
+    } else if (type == "bearing") {
+      Bearing<Scalar> bearing;
+      assign(bearing, values(b["meas"]));
+      bearing_measurements.push_back(std::make_unique<BearingMeasurement>(stamp, *cameras[b["camera"].as<std::size_t>()], bearing));
+      bearing_observations.push_back(std::make_unique<VisualBearingObservation>(*bearing_measurements.back(), landmarks[b["landmark"].as<std::size_t>()]));
+      cost = new Cost{CostConfiguration<Scalar>{nullptr, &metric_bearing, &evaluator_bearing}, CostContext{state.get(), bearing_observations.back().get()}};
+      loss = &huber_bearing;
+    } else if (type == "prior") {
+      Space pose;
+      assign(pose, values(b["meas"]));
+      prior_measurements.push_back(std::make_unique<ManifoldMeasurement<Space>>(stamp, *sensor, pose));
+      prior_observations.push_back(std::make_unique<ManifoldObservation<Space>>(*prior_measurements.back()));
+      cost = new Cost{CostConfiguration<Scalar>{nullptr, &metric_prior, &evaluator_prior}, CostContext{state.get(), prior_observations.back().get()}};
+    } else {
+      Tangent<Space> tangent;
+      assign(tangent, values(b["meas"]));
+      inertial_measurements.push_back(std::make_unique<InertialMeasurement<Space>>(stamp, *imu, tangent));
+      inertial_observations.push_back(std::make_unique<InertialObservation<Space>>(*inertial_measurements.back(), gravity));
+      cost = new Cost{CostConfiguration<Scalar>{nullptr, &metric_inertial, &evaluator_inertial}, CostContext{state.get(), inertial_observations.back().get()}};
+      loss = &scaled_inertial;
+    }
+    problem.AddResidualBlock(cost, loss, cost->update());
+  }
+  // manifolds and constancy: control points (golden cp_constant), sensors constant (camera.hpp:18, imu.hpp:18), landmarks Euclidean, gravity on the sphere
+  std::size_t j = 0;
+  std::vector<AbstractVariable<Scalar>*> cp_variables, lm_variables, bg_variables, ba_variables, g_variables;
+  for (const auto& element : state->elements()) {
+    auto* block = element->asVector().data();
+    if (problem.HasParameterBlock(block)) {
+      problem.SetManifold(block, const_cast<Manifold<StampedSpace, OptimizerSuite::CERES>*>(&free_state));
+      if (d["cp_constant"][j].as<int>()) problem.SetParameterBlockConstant(block);
+    }
+    cp_variables.push_back(element.get()), ++j;
+  }
+  const auto constant = [&](const Sensor& s) {
+    for (auto* parameter : s.parameters())
+      if (problem.HasParameterBlock(parameter->asVector().data())) problem.SetParameterBlockConstant(parameter->asVector().data());
+  };
+  for (const auto& camera : cameras) constant(*camera);
+  constant(*sensor);
+  const auto bias_manifold = Manifold<Stamped<Cartesian<Scalar, 3>>, OptimizerSuite::CERES>{true, false};
+  const auto gravity_manifold = Manifold<Gravity<Scalar>, OptimizerSuite::CERES>{false};
+  if (imu) {
+    constant(*imu);
+    for (auto* bias : {&imu->gyroscopeBias(), &imu->accelerometerBias()})
+      for (const auto& element : bias->elements()) {
+        auto* block = element->asVector().data();
+        if (problem.HasParameterBlock(block)) problem.SetManifold(block, const_cast<Manifold<Stamped<Cartesian<Scalar, 3>>, OptimizerSuite::CERES>*>(&bias_manifold));
+        (bias == &imu->gyroscopeBias() ? bg_variables : ba_variables).push_back(element.get());
+      }
+    problem.SetManifold(gravity.data(), const_cast<Manifold<Gravity<Scalar>, OptimizerSuite::CERES>*>(&gravity_manifold));
+    g_variables.push_back(&gravity);
+  }
+  for (auto& landmark : landmarks) lm_variables.push_back(&landmark.variable());
+
+  ceres::Solver::Options options;  // optimizer.cpp:38-54
+  options.max_num_iterations = static_cast<int>(d["iterations"].size());
+  options.num_threads = 1;
+  options.linear_solver_type = ceres::SPARSE_NORMAL_CHOLESKY;
+  options.sparse_linear_algebra_library_type = ceres::SUITE_SPARSE;
+  options.update_state_every_iteration = true;
+  Recorder recorder{{{"control_points", cp_variables}, {"landmarks", lm_variables}, {"bias_g", bg_variables}, {"bias_a", ba_variables}, {"gravity", g_variables}}};
+  options.callbacks.push_back(&recorder);
+  ceres::Solver::Summary summary;
+  ceres::Solve(options, &problem, &summary);
+  Json json;
+  json.os << "{\"initial_cost\":" << recorder.initial_cost << ",\"iterations\":[";
+  for (std::size_t i = 0; i < recorder.records.size(); ++i) json.os << (i ? "," : "") << recorder.records[i];
+  json.os << "]}";
+  return json.os.str();
+}
+
+auto dumpCases(const std::string& in, const std::string& out, auto one) -> void {
+  const auto root = YAML::LoadFile(in);
+  std::ofstream os{out};
+  os << "{\"generator\":\"tools/reference_dump.cpp (the reference's own evaluators / manifolds)\",\"cases\":[";
+  bool first = true;
+  for (const auto& c : root["cases"]) {
+    os << (first ? "" : ",") << one(c);
+    first = false;
+  }
+  os << "]}";
+}
+
+}  // namespace hyper::conformance
+
+auto main(int argc, char** argv) -> int {
+  google::InitGoogleLogging(argv[0]);
+  CHECK_EQ(argc, 3) << "usage: reference_dump <tests/golden directory of hyperslam_amd> <output directory>";
+  using namespace hyper::conformance;
+  const std::string in = argv[1], out = argv[2];
+  dumpCases(in + "/factors.json", out + "/factors.json", factorCase);
+  dumpCases(in + "/inertial_literal.json", out + "/inertial_literal.json", factorCase);
+  dumpCases(in + "/manifolds.json", out + "/manifolds.json", manifoldCase);
+  for (const auto* name : {"solve.json", "solve_visual.json"}) {
+    std::ofstream os{out + "/" + name};
+    os << solveWindow(YAML::LoadFile(in + "/" + name));
+  }
+  return 0;
+}

@@ -737,7 +737,7 @@ int launch_linearize(hs_problem* p, bool inertial_on_side = false, bool visual_c
   if (T.n_vis && p->fused && visual_cost_only) k_cost_visual<K><<<p->nb_vis, kBlock, cp_lds_bytes(p), s>>>(T, T.cp, T.lm, T.cost_part);
   if (T.n_pri) k_linearize_prior<K><<<p->nb_pri, kBlock, cp_lds_bytes(p), s>>>(T, T.p_rec, T.cost_part + p->nb_vis, nullptr);
   if (T.n_ine)
-    k_linearize_inertial<K, 4><<<p->nb_ine, kInertialBlock, cp_lds_bytes(p), p->side_imu ? p->side : s>>>(T, T.i_rec, 1, T.cost_part + p->nb_vis + p->nb_pri,
+    k_linearize_inertial<K, 4><<<p->nb_ine, kInertialBlock * K, cp_lds_bytes(p), p->side_imu ? p->side : s>>>(T, T.i_rec, 1, T.cost_part + p->nb_vis + p->nb_pri,
                                                                                                         nullptr);
   if (p->side_imu) HIP_TRY(hipEventRecord(p->ev_irec, p->side));
   HIP_TRY(hipGetLastError());
@@ -1668,9 +1668,9 @@ static int linearize_impl(hs_problem* p, int type, int robustify, const hs_linea
     HIP_TRY(p->d_dbg.reserve(size_t(n) * REC));
     HIP_TRY(p->d_dbg_cost.reserve(n));
     if (k == 4)
-      k_linearize_inertial<4, 4><<<p->nb_ine, kInertialBlock, cp_lds_bytes(p), s>>>(T, p->d_dbg.p, robustify, nullptr, p->d_dbg_cost.p);
+      k_linearize_inertial<4, 4><<<p->nb_ine, kInertialBlock * 4, cp_lds_bytes(p), s>>>(T, p->d_dbg.p, robustify, nullptr, p->d_dbg_cost.p);
     else
-      k_linearize_inertial<6, 4><<<p->nb_ine, kInertialBlock, cp_lds_bytes(p), s>>>(T, p->d_dbg.p, robustify, nullptr, p->d_dbg_cost.p);
+      k_linearize_inertial<6, 4><<<p->nb_ine, kInertialBlock * 6, cp_lds_bytes(p), s>>>(T, p->d_dbg.p, robustify, nullptr, p->d_dbg_cost.p);
     HIP_TRY(hipGetLastError());
     std::vector<double> rec(size_t(n) * REC), cost(n);
     HIP_TRY(hipMemcpyAsync(rec.data(), p->d_dbg.p, rec.size() * 8, hipMemcpyDeviceToHost, s));

@@ -263,4 +263,69 @@ HSD void spline_full(const double* cp, const double* lam, const double* dlam, co
   }
 }
 
+/// spline_full for ONE control point m of the segment (the Jacobian blocks of the other control points are not formed): the recursion
+/// over the K - 1 relative rotations is the same, but only E[m], W[m], Qm[m] are carried — 3 instead of 3 K 3 x 3 matrices, so that one
+/// residual can be spread over K lanes (one per control point) at a quarter of the registers. Same arithmetic per block as spline_full.
+template <int K>
+struct SplineCol {
+  Quat q;
+  V3 p, w, al, v, a;
+  M3 dth, dw, dal;  // blocks of control point m
+  double Bdd_m;     // second derivative of the (non-cumulative) basis weight of control point m
+};
+
+template <int K>
+HSD void spline_full_col(const double* cp, const double* lam, const double* dlam, const double* ddlam, const int m, SplineCol<K>* o) {
+  V3 p = V3{0, 0, 0}, v = p, a = p;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const double Bj = lam[j] - (j + 1 < K ? lam[j + 1] : 0.0);
+    const double Bdj = dlam[j] - (j + 1 < K ? dlam[j + 1] : 0.0);
+    const double Bddj = ddlam[j] - (j + 1 < K ? ddlam[j + 1] : 0.0);
+    if (j == m) o->Bdd_m = Bddj;  // (a select per j: indexing a register array with m would put it into scratch memory)
+    const V3 pj = V3{cp[8 * j + 4], cp[8 * j + 5], cp[8 * j + 6]};
+    p = p + Bj * pj, v = v + Bdj * pj, a = a + Bddj * pj;
+  }
+  o->p = p, o->v = v, o->a = a;
+
+  Quat qprev = load_quat(cp);
+  Quat q = qprev;
+  V3 w = V3{0, 0, 0}, al = w;
+  M3 E = m == 0 ? eye() : zero3(), W = zero3(), Qm = zero3();
+#pragma unroll
+  for (int j = 1; j < K; ++j) {
+    const Quat qj = load_quat(cp + 8 * j);
+    const RelRot rr = rel_log(qprev, qj);
+    double b, cc;
+    const Quat eq = exp_scaled(rr, lam[j], &b, &cc);
+    q = qmul(q, eq);
+    const M3 A = qmat(eq);
+    const V3 w_rot = mul_t(A, w), al_rot = mul_t(A, al);
+    const V3 w_new = w_rot + dlam[j] * rr.d;
+    const V3 al_new = al_rot + dlam[j] * cross(w_new, rr.d) + ddlam[j] * rr.d;
+    if (m <= j) {  // (blocks beyond j are still zero)
+      E = mul_tn(A, E), W = mul_tn(A, W), Qm = mul_tn(A, Qm);
+      if (m >= j - 1) {  // the two blocks this relative rotation depends on: m = j - 1 (through -J_l^-1) and m = j (through J_r^-1)
+        const double D = jr_inv_coef(rr);
+        const M3 Jri = rodrigues_poly(rr.d, 0.5, D);
+        const M3 JrL = rodrigues_poly(rr.d, -b, cc);
+        const M3 dd = m == j - 1 ? scale(-1.0, transpose(Jri)) : Jri;
+        const M3 eta = scale(lam[j], mul(JrL, dd));
+        E = add(E, eta);
+        W = add(W, add(mul(hat(w_rot), eta), scale(dlam[j], dd)));
+        Qm = add(Qm, add(mul(hat(al_rot), eta), add(scale(dlam[j], mul(hat(w_new), dd)), scale(ddlam[j], dd))));
+      }
+      Qm = sub(Qm, scale(dlam[j], mul(hat(rr.d), W)));
+    }
+    w = w_new, al = al_new, qprev = qj;
+  }
+  o->q = qnormalized(q);
+  o->w = w, o->al = al;
+  const M3 R = qmat(o->q);
+  const M3 Rm = qmat(load_quat(cp + 8 * m));
+  o->dth = mul_nt(mul(R, E), Rm);
+  o->dw = mul_nt(W, Rm);
+  o->dal = mul_nt(Qm, Rm);
+}
+
 }  // namespace hsd

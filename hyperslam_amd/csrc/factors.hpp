@@ -482,4 +482,107 @@ HSD void inertial_evaluate(const Tables& T, const double* cps, const double* bia
     }
 }
 
+/// The linearisation of inertial residual i for ONE control point m of its segment (wave-uniform m: k_linearize_inertial spreads a
+/// residual over K lanes of K different waves): the prediction and the residual — by every lane, they are cheap — and the 6 x 6 block of
+/// the local state Jacobian that belongs to control point m, written straight into the record. m == 0 also writes the residual, the bias
+/// weights and the gravity block and returns the cost (other lanes return 0). Same expressions as inertial_evaluate.
+template <int K, int KB>
+HSD double inertial_linearize_col(const Tables& T, const double* cps, const double* bias_g, const double* bias_a, const double* gravity, const int i,
+                                  const int m, const bool robustify, double* rec) {
+  const ImuParams& P = *T.imu;
+  const int first = T.i_first[i], fb = T.i_first_bias[i];
+  double u;
+  segment_of(T.i_stamp[i], T.sp.t0, T.sp.dt, K, &u);
+  double lam[K], dlam[K], ddlam[K];
+  basis_weights<K>(T.basis, u, T.sp.inv_dt, lam, dlam, ddlam, 2);
+  SplineCol<K> S;
+  spline_full_col<K>(cps + 8 * first, lam, dlam, ddlam, m, &S);
+  const M3 R = qmat(S.q);  // R_wb
+  const M3 R_bs = qmat(Quat{P.T_bs[0], P.T_bs[1], P.T_bs[2], P.T_bs[3]});
+  const V3 t_bs = V3{P.T_bs[4], P.T_bs[5], P.T_bs[6]};
+  const M3 I_g = lower_tri(P.i_g), I_a = lower_tri(P.i_a), S_g = colmajor3(P.S_g), X_a = colmajor3(P.X_a);
+  const V3 g = V3{gravity[0], gravity[1], gravity[2]};
+  const V3 a_i = mul_t(R, S.a - g);  // R_bw (p'' - g)
+  const M3 wx = hat(S.w);
+  const M3 F_a = add(mul(wx, wx), hat(S.al));
+  V3 lever[3];
+  double am[3];
+  const double ai[3] = {a_i.x, a_i.y, a_i.z};
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    lever[r] = V3{X_a.m[r] + t_bs.x, X_a.m[3 + r] + t_bs.y, X_a.m[6 + r] + t_bs.z};  // X_a.col(r) + t_bs
+    am[r] = ai[r] + F_a.m[3 * r] * lever[r].x + F_a.m[3 * r + 1] * lever[r].y + F_a.m[3 * r + 2] * lever[r].z;
+  }
+  const M3 IgRsb = mul_nt(I_g, R_bs), IaRsb = mul_nt(I_a, R_bs);  // I * R_sb = I * R_bs^T
+  const double sr = robustify ? sqrt(kScaleInertial) : 1.0;
+  const M3 Rt = transpose(R);
+  const bool lit = T.inertial_literal != 0;
+  const M3 S_gJ = lit ? zero3() : S_g;   // S_g as it enters the state / gravity columns
+  const M3 IxRsb = lit ? IgRsb : IaRsb;  // (:136,142,148) vs the matrix of the prediction
+  double cost = 0.0;
+  if (m == 0) {
+    const V3 a_m = V3{am[0], am[1], am[2]};
+    double ub, wg[KB], wa[KB];
+    segment_of(T.i_stamp[i], T.bias_t0, T.bias_dt, KB, &ub);
+    const V3 b_g = bias_value<KB>(T.bias_basis, bias_g + 4 * fb, ub, wg);
+    const V3 b_a = bias_value<KB>(T.bias_basis, bias_a + 4 * fb, ub, wa);
+    const V3 ang = mul(IgRsb, S.w) + mul(S_g, a_m) + b_g;
+    const V3 lin = mul(IaRsb, a_m) + b_a;
+    const double* ms = T.i_meas + 6 * i;
+    double r[6] = {ang.x - ms[0], ang.y - ms[1], ang.z - ms[2], lin.x - ms[3], lin.y - ms[4], lin.z - ms[5]};
+    double s = 0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) s += r[c] * r[c];
+    cost = 0.5 * kScaleInertial * s;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) rec[c] = r[c] * sr;
+    const double bscale = T.bias_const ? 0.0 : sr;
+#pragma unroll
+    for (int j = 0; j < KB; ++j) rec[6 + 36 * K + j] = wg[j] * bscale, rec[6 + 36 * K + KB + j] = wa[j] * bscale;
+    // gravity: d a_m / d g = -R_bw, through the SphereManifold<3> tangent basis
+    double Pg[6];
+    sphere_plus_jacobian(gravity, Pg);
+    const M3 nRt = scale(-1.0, Rt);
+    const M3 ang_g = mul(S_gJ, nRt), lin_g = mul(IaRsb, nRt);
+    const double gs = T.gravity_const ? 0.0 : sr;
+    double* Jg = rec + 6 + 36 * K + 2 * KB;
+#pragma unroll
+    for (int r2 = 0; r2 < 3; ++r2)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        Jg[2 * r2 + c] = gs * (ang_g.m[3 * r2] * Pg[c] + ang_g.m[3 * r2 + 1] * Pg[2 + c] + ang_g.m[3 * r2 + 2] * Pg[4 + c]);
+        Jg[2 * (3 + r2) + c] = gs * (lin_g.m[3 * r2] * Pg[c] + lin_g.m[3 * r2 + 1] * Pg[2 + c] + lin_g.m[3 * r2 + 2] * Pg[4 + c]);
+      }
+  }
+  // d a_m / d w (L_w) and d a_m / d alpha (L_al) with per-row lever arms
+  M3 L_w, L_al;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const M3 lx = hat(lit ? t_bs : lever[r]);
+    const M3 mw = sub(mul(lx, wx), scale(2.0, mul(wx, lx)));  // -(2 wx lx - lx wx)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) L_w.m[3 * r + c] = mw.m[3 * r + c], L_al.m[3 * r + c] = -lx.m[3 * r + c];
+  }
+  const M3 HaRt = mul(hat(a_i), Rt);  // hat(a_i) R_bw
+  const bool frozen = T.cp_const[first + m] != 0;
+  const bool rot_free = !frozen && !T.sp.rot_const, tr_free = !frozen && !T.sp.trans_const;
+  const M3 dam_rot = add(mul(HaRt, S.dth), add(mul(L_w, S.dw), mul(L_al, S.dal)));  // d a_m / d phi_m
+  const M3 dam_tr = scale(S.Bdd_m, Rt);                                               // d a_m / d dp_m
+  const M3 ang_rot = add(mul(IgRsb, S.dw), mul(S_gJ, dam_rot));
+  const M3 ang_tr = mul(S_gJ, dam_tr);
+  const M3 lin_rot = mul(IxRsb, dam_rot);
+  const M3 lin_tr = mul(IaRsb, dam_tr);
+  double* Jp = rec + 6;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      Jp[r * 6 * K + 6 * m + c] = rot_free ? 2.0 * sr * ang_rot.m[3 * r + c] : 0.0;
+      Jp[r * 6 * K + 6 * m + 3 + c] = tr_free ? sr * ang_tr.m[3 * r + c] : 0.0;
+      Jp[(3 + r) * 6 * K + 6 * m + c] = rot_free ? 2.0 * sr * lin_rot.m[3 * r + c] : 0.0;
+      Jp[(3 + r) * 6 * K + 6 * m + 3 + c] = tr_free ? sr * lin_tr.m[3 * r + c] : 0.0;
+    }
+  return cost;
+}
+
 }  // namespace hs

@@ -110,37 +110,30 @@ __global__ void __launch_bounds__(kBlock) k_linearize_prior(Tables T, double* ou
   if (threadIdx.x == 0 && cost_part) cost_part[blockIdx.x] = s;
 }
 
-/// One wave per workgroup for the inertial kernels: the order-6 linearisation holds three derivative levels of the spline with their
-/// Jacobians and needed 256 VGPRs + 1.7 KB of scratch per lane under a 256-thread launch bound; a window has ~1e4 inertial residual
-/// blocks (157 waves on 1024 SIMDs), so occupancy buys nothing and the 512-register budget of a lone wave removes the spills.
+/// Residuals per workgroup of the inertial kernels. The value-only kernels run one wave of 64 residuals per workgroup; the linearisation
+/// spreads each residual over K lanes — lane (wave m, lane t) forms the Jacobian block of control point m of residual t — so that a window's
+/// ~1e4 inertial residual blocks occupy K x 157 waves instead of 157 (one lane per residual held three derivative levels of the spline with
+/// all their K Jacobian blocks: 512 VGPRs + scratch, 56 us at configs[2] on 15 % of the SIMDs).
 constexpr int kInertialBlock = 64;
 
 /// Inertial residual blocks (inertial.cpp:13-205): record = [r(6) | J_state(6 x 6K) | wg(KB) | wa(KB) | J_gravity(6 x 2)].
+/// blockDim = 64 K: wave m handles control point m of the workgroup's 64 residuals (m is wave uniform: no divergence on it).
 template <int K, int KB>
-__global__ void __launch_bounds__(kInertialBlock) k_linearize_inertial(Tables T, double* out_rec, int robustify, double* cost_part, double* cost_each) {
+__global__ void __launch_bounds__(kInertialBlock * K) k_linearize_inertial(Tables T, double* out_rec, int robustify, double* cost_part, double* cost_each) {
   HS_DYNAMIC_LDS(smem);
   if (T.st->done) return;
   double* cps = smem;
   stage_cps(T.cp, cps, 8 * T.sp.n_cp);
-  __shared__ double red[kBlock / 64];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ double red[K];
+  const int lane = threadIdx.x & 63, m = threadIdx.x >> 6;
+  const int i = blockIdx.x * kInertialBlock + lane;
   double cost = 0.0;
   if (i < T.n_ine) {
     constexpr int REC = 18 + 36 * K + 2 * KB;
-    double* rec = out_rec + size_t(i) * REC;
-    InertialOut<K, KB> o;
-    o.Jp = rec + 6;
-    inertial_evaluate<K, KB, true>(T, cps, T.bias_g, T.bias_a, T.gravity, i, robustify != 0, &o);
-    cost = o.cost;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) rec[c] = o.r[c];
-#pragma unroll
-    for (int c = 0; c < KB; ++c) rec[6 + 36 * K + c] = o.wg[c], rec[6 + 36 * K + KB + c] = o.wa[c];
-#pragma unroll
-    for (int c = 0; c < 12; ++c) rec[6 + 36 * K + 2 * KB + c] = o.Jg[c];
-    if (cost_each) cost_each[i] = cost;
+    cost = inertial_linearize_col<K, KB>(T, cps, T.bias_g, T.bias_a, T.gravity, i, m, robustify != 0, out_rec + size_t(i) * REC);
+    if (cost_each && m == 0) cost_each[i] = cost;
   }
-  const double s = block_sum(cost, red);
+  const double s = block_sum(cost, red);  // (only wave 0 carries costs)
   if (threadIdx.x == 0 && cost_part) cost_part[blockIdx.x] = s;
 }
 

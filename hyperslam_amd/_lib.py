@@ -10,7 +10,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-PRODUCT_LIB = os.path.join(_HERE, "libhyperslam_hip.so")
+# HS_LIBRARY: another build of the SAME library (the profiling build tools/libhyperslam_hip_prof.so with the phase timestamps and the A/B
+# kernels compiled in) for the measurement tools; unset in production.
+PRODUCT_LIB = os.environ.get("HS_LIBRARY") or os.path.join(_HERE, "libhyperslam_hip.so")
 
 HS_PIXEL, HS_BEARING, HS_PRIOR, HS_INERTIAL = 0, 1, 2, 3
 HS_INERTIAL_AS_REFERENCE, HS_INERTIAL_EXACT = 0, 1  # hs_set_inertial_jacobian

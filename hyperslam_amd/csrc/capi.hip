@@ -255,6 +255,10 @@ static const char* kWeightsMessage =
     "a weight matrix is set (hs_set_weights): weights are applied by hs_linearize / hs_cost_function_evaluate; the solver runs the "
     "reference's production configuration, weights = nullptr (optimizer.cpp:191,214,236,255)";
 
+/// Measurement switches that select a kernel kept for A/B comparison only: compile-time false in the product library (HS_PROFILE_HOOKS = 0,
+/// the alternatives are not compiled in), HS_DEBUG_FLAGS bits in profiling builds (tools/build_profiling_lib.sh).
+#define HS_AB(flags, bit) (HS_PROFILE_HOOKS && ((flags) & (bit)))
+
 #define HS_FAIL(code, msg) \
   do {                     \
     p->err = (msg);        \
@@ -654,7 +658,7 @@ int prepare(hs_problem* p) {
   T.debug_flags = std::getenv("HS_DEBUG_FLAGS") ? std::atoi(std::getenv("HS_DEBUG_FLAGS")) : 0;
   {  // the reversed copy feeds the far end of a two-ended factorisation and, as the lower band, every MFMA factorisation
     const bool la_ok = la_compute_waves(vs.bw) > 0, two_ended = la_ok && np / 6 >= 4 * vs.bw;
-    const bool need = two_ended || ((T.debug_flags & 131072) && mfma_window_tiles(vs.bw) > 0);
+    const bool need = two_ended || (HS_AB(T.debug_flags, 131072) && mfma_window_tiles(vs.bw) > 0);
     T.Sb2 = need ? p->d_Sb2.p : nullptr, T.g2 = need ? p->d_g2.p : nullptr;
   }
   T.scale_b = p->d_scale_b.p, T.Spb = p->d_Spb.p, T.Sbb = p->d_Sbb.p, T.gb_s = p->d_gb_s.p, T.D2b = p->d_D2b.p;
@@ -898,6 +902,7 @@ int mfma_window_tiles(int bw) {
   return 0;
 }
 
+#if HS_PROFILE_HOOKS
 template <int NT, int NC>
 hipError_t launch_mfma(const Tables& T, int grid, hipStream_t s) {
   static bool attr = false;
@@ -922,6 +927,8 @@ void launch_backward_w(const Tables& T, const BackJob& j0, const BackJob& j1, in
   else
     k_band_backward_w<5><<<grid, 64, lds, s>>>(T, j0, j1, m_mid);
 }
+
+#endif  // HS_PROFILE_HOOKS
 
 /// Dense Cholesky of the border Schur complement + solve for the border unknowns (one workgroup).
 static hipError_t launch_border_solve(const Tables& T, hipStream_t s) {
@@ -952,17 +959,21 @@ int launch_factor(hs_problem* p) {
   const int n_blk = T.np / 6, w_mid = T.bw - 1;
   const bool la_ok = !legacy && la_compute_waves(T.bw) > 0;
   const int la_ncw = la_compute_waves(T.bw);
-  const int nt = (T.debug_flags & 131072) ? mfma_window_tiles(T.bw) : 0;  // A/B switch 131072: k_band_factor_mfma instead of the VALU kernels
+  const int nt = HS_AB(T.debug_flags, 131072) ? mfma_window_tiles(T.bw) : 0;  // A/B switch 131072 (profiling builds): k_band_factor_mfma instead of the VALU kernels
   // (bordered systems — bias splines + gravity — too: the forward sweep of the border columns follows the two-ended elimination order,
   //  k_border_forward2; A/B switch 536870912: bordered systems one-ended)
   const bool two_ended = (la_ok || nt) && (T.nb == 0 || (!nt && !(T.debug_flags & 536870912) && (T.nb + kBorderCols - 1) / kBorderCols <= 512)) &&
                          n_blk >= 4 * T.bw && T.Sb2 && !(T.debug_flags & 2048);  // (512: flag words of k_border_forward2's column groups)
+#if HS_PROFILE_HOOKS
   auto run_mfma = [&](const Tables& TT, int grid) -> hipError_t {
     switch (nt) {
       case 6: return launch_mfma<6, 3>(TT, grid, s);
       default: return launch_mfma<9, 3>(TT, grid, s);
     }
   };
+#else
+  auto run_mfma = [&](const Tables&, int) -> hipError_t { return hipErrorNotSupported; };  // (nt == 0: never reached)
+#endif
   if (two_ended) {
     // The near end takes a few block rows more than the far end: the far end still has to hand its trailing window over (~7 us,
     // i.e. ~4 steps: window through HBM + agent-scope release) before the near end can pass the junction. With an even split
@@ -1002,18 +1013,26 @@ int launch_factor(hs_problem* p) {
     const BackJob j1{p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, p->d_Vb2.p, p->d_yt2.p, mB, w_mid, 1};
     // (the two older sweeps are kept as measurement switches for visual-only systems, the shape they were measured on; they do not write
     //  the border's step outputs)
-    const bool sweep_w = (T.debug_flags & 65536) && !T.nb, sweep_rows = (T.debug_flags & 268435456) && !T.nb;
+    const bool sweep_w = HS_AB(T.debug_flags, 65536) && !T.nb, sweep_rows = HS_AB(T.debug_flags, 268435456) && !T.nb;
+#if HS_PROFILE_HOOKS
     if (sweep_w) k_premultiply<<<m + w_mid + mB, 128, 0, s>>>(T3, j0, j1, m + w_mid);
+#endif
     if (!sweep_w) {  // (A/B switch 65536: single-wave register sweep)
       const size_t g_lds = size_t(6 * (T.bw - 1)) * (6 * (T.bw - 1) | 1) * sizeof(double);  // given-column block of the far sweep
+#if HS_PROFILE_HOOKS
       if (sweep_rows)  // A/B switch 268435456: one block row per step
         k_band_backward2<<<2, kCholThreads, 2 * size_t(T.np) * sizeof(double) + g_lds, s>>>(T3, j0, j1, m);
-      else  // super-blocks of four block rows; the inverses of the diagonal super-blocks come from extra workgroups of the launch
+      else
+#endif
+        // super-blocks of four block rows; the inverses of the diagonal super-blocks come from extra workgroups of the launch
         k_band_backward_sb<<<2 + (m + w_mid + kSb - 1) / kSb + (mB + kSb - 1) / kSb, kCholThreads,
                              std::max((2 * size_t(T.np) + 32) * sizeof(double) + g_lds, size_t(3 * kSbN * (kSbN + 1)) * sizeof(double)), s>>>(T3, j0, j1, m, 2, 0);
     } else {
+#if HS_PROFILE_HOOKS
       launch_backward_w(T3, j0, j1, m, 2, s);
+#endif
     }
+    (void)sweep_rows;
     HIP_TRY(hipGetLastError());
     return HS_OK;
   }
@@ -1062,11 +1081,14 @@ int launch_factor(hs_problem* p) {
     HIP_TRY(launch_border_solve(T, s));
     k_border_apply<<<(T.np + kBlock / 64 - 1) / (kBlock / 64), kBlock, 0, s>>>(T);
   }
+#if HS_PROFILE_HOOKS
   if ((T.debug_flags & 8192) && !T.nb) {  // A/B: the generalised sweep on the whole system
     const BackJob j0{T.Ub, T.Ubk, T.ybuf, nullptr, nullptr, T.np / 6, 0, 0};
     k_band_backward2<<<1, kCholThreads, 2 * size_t(T.np) * sizeof(double), s>>>(T, j0, j0, -1);
     k_step_outputs<<<1, kBlock, 0, s>>>(T);
-  } else if (!(T.debug_flags & 65536) || T.nb) {  // (A/B switch 65536: single-wave register sweep — visual-only systems, the shape it was measured on)
+  } else
+#endif
+  if (!HS_AB(T.debug_flags, 65536) || T.nb) {  // (A/B switch 65536: single-wave register sweep — visual-only systems, the shape it was measured on)
     if (6 * (T.bw - 1) <= 96 && !(T.debug_flags & 268435456)) {  // super-blocks of four block rows: one lane pair per pending row, 96 pairs
       Tables T3 = T;
       T3.join_epoch = ++p->join_epoch;
@@ -1077,9 +1099,11 @@ int launch_factor(hs_problem* p) {
       k_band_backward<<<1, kCholThreads, 2 * size_t(T.np) * sizeof(double), s>>>(T, f0);
     }
   } else {
+#if HS_PROFILE_HOOKS
     const BackJob j0{T.Ub, T.Ubk, T.ybuf, p->d_Vb.p, p->d_yt.p, T.np / 6, 0, 0};
     k_premultiply<<<T.np / 6, 128, 0, s>>>(T, j0, j0, T.np / 6);
     launch_backward_w(T, j0, j0, -1, 1, s);
+#endif
   }
   HIP_TRY(hipGetLastError());
   return HS_OK;
@@ -1227,7 +1251,9 @@ int set_func_attributes(hs_problem* p) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_visual<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_forward), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_forward2), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+#if HS_PROFILE_HOOKS
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_backward2), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+#endif
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_backward_sb), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_backward), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));

@@ -896,6 +896,7 @@ struct BackJob {
   int reversed; // solution index = np - 1 - rho
 };
 
+#if HS_PROFILE_HOOKS  // (measured alternative of k_band_backward_sb, HS_DEBUG_FLAGS 268435456 / 8192: profiling builds only)
 __global__ void __launch_bounds__(kCholThreads) k_band_backward2(Tables T, BackJob j0, BackJob j1, int m_mid) {
   HS_DYNAMIC_LDS(smem);
   DevState* st = T.st;
@@ -1082,6 +1083,8 @@ __global__ void __launch_bounds__(kBlock) k_step_outputs(Tables T) {
     st->d2_step2_pose = dd;
   }
 }
+
+#endif  // HS_PROFILE_HOOKS
 
 /// Factorisation for wide bands (long feature tracks: more tiles than the register-resident kernels can hold): same algorithm and
 /// outputs (Ub, U_ii^-1, y). The trailing window stays in HBM / L2 (in place in Sb), one 6x6 tile per lane and step:

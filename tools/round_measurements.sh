@@ -15,9 +15,10 @@ bash tools/pmc_sq.sh $out/${tag}_pmc_sq.json $B >> $out/${tag}_pmc.txt 2>&1
 bash tools/pmc_sq.sh $out/${tag}_config2_pmc_sq.json python bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline >> $out/${tag}_pmc.txt 2>&1
 # matrix-core counters of the factorisation: the VALU look-ahead kernel (default) and the f64-MFMA kernel (A/B switch 131072)
 bash tools/pmc_mfma.sh $out/${tag}_pmc_mfma_valu_factor.json $B >> $out/${tag}_pmc.txt 2>&1
-HS_DEBUG_FLAGS=131072 bash tools/pmc_mfma.sh $out/${tag}_pmc_mfma_mfma_factor.json $B >> $out/${tag}_pmc.txt 2>&1
+HS_LIBRARY=$PWD/tools/libhyperslam_hip_prof.so HS_DEBUG_FLAGS=131072 bash tools/pmc_mfma.sh $out/${tag}_pmc_mfma_mfma_factor.json $B >> $out/${tag}_pmc.txt 2>&1
 bash tools/kernel_stats.sh $out/${tag}_config3_kernel_stats.csv python bench.py --config 3 --steps 10 --warmup 2 --no-cpu-baseline >> $out/${tag}_kernel_stats.txt 2>&1
 [ -f tools/libhyperslam_hip_prof.so ] && python tools/chol_phase_timing.py > $out/${tag}_chol_phase_timing.txt 2>&1
+[ -f tools/libhyperslam_hip_prof.so ] && python tools/build_phase_timing.py 1 > $out/${tag}_build_phase_timing.txt 2>&1
 for c in 0 1 2 3; do HS_STAGE_TIMING=0 python tools/time_config.py $c; HS_STAGE_TIMING=1 python tools/time_config.py $c; done > $out/${tag}_configs.txt 2>&1
 python bench.py --config 3 --steps 20 --warmup 3 --no-cpu-baseline > $out/${tag}_bench_config3.json 2>/dev/null
 python bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline > $out/${tag}_bench_config2.json 2>/dev/null

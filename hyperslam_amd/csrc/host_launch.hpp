@@ -1,0 +1,579 @@
+// host_launch.hpp — the launch sequence of one LM iteration (linearise / build / factor + solve / update), the RCCL exchange and the
+// one-time kernel set-up (part of capi.hip: included once, by it, behind host_tables.hpp).
+#pragma once
+#include "host_tables.hpp"
+
+namespace {
+
+int reset_state(hs_problem* p, int max_iterations, double radius, int spec = 0) {
+  k_reset_state<<<1, 64, 0, p->stream>>>(p->d_state.p, max_iterations, radius, spec);
+  HIP_TRY(hipGetLastError());
+  return HS_OK;
+}
+
+size_t cp_lds_bytes(const hs_problem* p) { return size_t(8) * p->n_cp * sizeof(double); }
+template <int K>
+size_t lin_lds_bytes(const hs_problem* p) {  // control points + one record slab per wave
+  return (cp_lds_bytes(p) <= 24 * 1024 ? cp_lds_bytes(p) : 0) + size_t(lin_block<K>()) * (8 + 12 * K + 2) * sizeof(double);
+}
+
+__global__ void k_noop() {}
+
+/// The side stream of the inertial branch and its three events. Created by hs_create and used once there: a stream gets its hardware
+/// queue at its first submission, which — together with the first allocations — made the first optimize() with an IMU 10 ms long.
+static int ensure_side_stream(hs_problem* p) {
+  if (!p->side) {
+    HIP_TRY(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&p->ev_irec, hipEventDisableTiming));
+    k_noop<<<1, 64, 0, p->side>>>();
+    HIP_TRY(hipEventRecord(p->ev_join, p->side));
+    HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_join, 0));
+    k_noop<<<1, 64, 0, p->stream>>>();
+    HIP_TRY(hipStreamSynchronize(p->stream));
+  }
+  return HS_OK;
+}
+
+/// `inertial_on_side` (the solve loop of bordered systems): the inertial branch of an iteration — k_linearize_inertial, then the border
+/// gathers k_border_pb / _bb in launch_build — only meets the visual branch (k_linearize_visual -> k_landmark -> Gram
+/// kernels -> k_assemble) at the segment Gram kernel (reads the inertial records) and at k_reduce_partials, and each branch fills a
+/// fraction of the chip: they run on two streams. configs[2]: 293 us of kernels back to back -> 175 us on the critical path.
+/// Fused build (p->fused): the visual factors are linearised by k_build_visual inside launch_build — nothing to do for them here, unless only
+/// the cost is wanted (`visual_cost_only`: hs_cost, hs_solve with zero iterations), which the value-only kernel delivers.
+template <int K>
+int launch_linearize(hs_problem* p, bool inertial_on_side = false, bool visual_cost_only = false) {
+  const Tables& T = p->T;
+  hipStream_t s = p->stream;
+  p->side_imu = inertial_on_side && T.n_ine > 0 && T.nb > 0 && !(T.debug_flags & 1048576);  // A/B switch 1048576: one stream
+  if (p->side_imu) {
+    const int rc = ensure_side_stream(p);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(p->ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+  }
+  if (T.n_vis && !p->fused) k_linearize_visual<K><<<p->nb_vis, lin_block<K>(), lin_lds_bytes<K>(p), s>>>(T, T.v_rec, T.v_pos, 1, T.cost_part, nullptr);
+  if (T.n_vis && p->fused && visual_cost_only) k_cost_visual<K><<<p->nb_vis, kBlock, cp_lds_bytes(p), s>>>(T, T.cp, T.lm, T.cost_part);
+  if (T.n_pri) k_linearize_prior<K><<<p->nb_pri, kBlock, cp_lds_bytes(p), s>>>(T, T.p_rec, T.cost_part + p->nb_vis, nullptr);
+  if (T.n_ine)
+    k_linearize_inertial<K, 4><<<p->nb_ine, kInertialBlock * K, cp_lds_bytes(p), p->side_imu ? p->side : s>>>(T, T.i_rec, 1, T.cost_part + p->nb_vis + p->nb_pri,
+                                                                                                        nullptr);
+  if (p->side_imu) HIP_TRY(hipEventRecord(p->ev_irec, p->side));
+  HIP_TRY(hipGetLastError());
+  return HS_OK;
+}
+
+// ---- RCCL, loaded on first use ---------------------------------------------------------------------------------------------------
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi* rccl_api() {
+  static RcclApi api;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (api.lib) break;
+    }
+    if (api.lib) {
+      api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(api.lib, "ncclGetUniqueId"));
+      api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(api.lib, "ncclCommInitRank"));
+      api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(api.lib, "ncclAllReduce"));
+      api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.lib, "ncclCommDestroy"));
+      api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.lib, "ncclGetErrorString"));
+      api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.lib, "ncclCommCount"));
+      if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) api.lib = nullptr;
+    }
+  }
+  return api.lib ? &api : nullptr;
+}
+
+int exchange(hs_problem* p, double* buf, int64_t count) {
+  if (p->rccl_comm) {  // one in-place sum all-reduce on the library's stream, no host involvement
+    const ncclResult_t r = rccl_api()->AllReduce(buf, buf, size_t(count), ncclDouble, ncclSum, static_cast<ncclComm_t>(p->rccl_comm), p->stream);
+    if (r != ncclSuccess) HS_FAIL(HS_ERR_DEVICE, std::string("ncclAllReduce failed: ") + (rccl_api()->GetErrorString ? rccl_api()->GetErrorString(r) : "?"));
+    return HS_OK;
+  }
+  if (!p->allreduce) return HS_OK;
+  if (p->allreduce(p->allreduce_user, buf, count, p->stream) != 0) HS_FAIL(HS_ERR_DEVICE, "all-reduce hook reported a failure");
+  return HS_OK;
+}
+
+static int border_zero_wgs(const Tables& T) { return std::min(64, (T.nb * T.nb + T.nb + kPbThreads - 1) / kPbThreads); }
+
+/// `after_build` (stage timing of a fused build): recorded behind k_build_visual — the launch that linearises the visual factors belongs to
+/// the "linearise" stage of hs_summary, what follows it (segment Gram of the prior / inertial records, assembly, finalisation) to "schur".
+template <int K>
+int launch_build(hs_problem* p, hipEvent_t after_build = nullptr) {
+  const Tables& T = p->T;
+  hipStream_t s = p->stream;
+  // k_seg_gram only needs the records, k_landmark -> k_group_gram records and landmarks: the two gram kernels share one launch
+  // (k_gram_pair). A/B switch 1024: the previous arrangement, k_seg_gram on a side stream next to k_landmark -> k_group_gram.
+  // (for small grids only — configs[1]: ~940 workgroups, Schur stage 66 -> 62 us. The pair holds 80 KB of LDS per workgroup, two per
+  //  CU, where k_group_gram alone fits three: at configs[3], ~3 750 workgroups, the two streams are faster, 0.165 vs 0.181 ms)
+  const bool fused = p->fused;
+  const bool pair = !fused && T.n_lm > 0 && p->n_group_wg > 0 && p->n_group_wg + p->n_seg_wg <= 2048 && !(T.debug_flags & 1024);
+  const bool side_imu = p->side_imu;       // (set by launch_linearize: the side stream is busy with the inertial branch)
+  const bool fork = !fused && T.n_lm > 0 && !pair && !side_imu;
+  // Fused build: linearisation, landmark elimination and both Gram terms of the visual factors in one launch; what remains for the segment
+  // Gram kernel are the prior / inertial records (none on visual-only windows: no launch)
+  if (fused) k_build_visual<K><<<p->nb_vis, kBlock, p->build_lds, s>>>(T, p->build_R, p->build_L, 1);
+  if (fused && after_build) HIP_TRY(hipEventRecord(after_build, s));
+  if (fork) {
+    const int rc = ensure_side_stream(p);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(p->ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+  }
+  hipStream_t sb = side_imu ? p->side : s;  // stream of the border gathers
+  if (side_imu && T.nb) {  // behind k_linearize_inertial on the side stream, next to k_landmark / the Gram kernels
+    k_border_pb<K><<<dim3(T.sp.n_cp + border_zero_wgs(T), p->n_split), kPbThreads, 0, sb>>>(T);  // (+ zero-fill of the border-border block)
+    k_border_bb<K><<<T.n_bias, kBlock, 0, sb>>>(T);
+    HIP_TRY(hipEventRecord(p->ev_join, p->side));
+  }
+  bool irec_ready = !side_imu;  // the segment Gram kernel reads the inertial records: wait for the side stream's linearisation once
+  auto need_irec = [&]() -> hipError_t {
+    if (irec_ready) return hipSuccess;
+    irec_ready = true;
+    return hipStreamWaitEvent(s, p->ev_irec, 0);
+  };
+  if (!pair && !(side_imu && T.n_lm) && p->n_seg_wg) {
+    HIP_TRY(need_irec());
+    k_seg_gram<K><<<p->n_seg_wg, kBlock, kSegStage * sizeof(double), fork ? p->side : s>>>(T);
+  }
+  if (fork) HIP_TRY(hipEventRecord(p->ev_join, p->side));
+  if (T.n_lm && !fused) {
+    const int grid = (T.n_lm + kBlock / 64 - 1) / (kBlock / 64);
+    if (6 * T.bw <= 128)
+      k_landmark<K, 2, 2><<<grid, kBlock, 0, s>>>(T);
+    else if (T.debug_flags & 4194304)  // A/B switch 4194304: one wave per landmark with four passes
+      k_landmark<K, 4, 1><<<grid, kBlock, 0, s>>>(T);
+    else  // long feature tracks (6 * bw <= kBlock is checked in prepare()): one workgroup per landmark, one wave per 64 rows of W
+      k_landmark_rows<K, 4><<<T.n_lm, kBlock, 0, s>>>(T);
+  }
+  if (T.n_lm && p->n_group_wg && !fused) {
+    const int ntile = T.bw * (T.bw + 1) / 2;
+    const int batch = std::max(2, std::min(kGroupBatch, int(48 * 1024 / (size_t(18) * T.bw * sizeof(double)))));
+    const size_t lds = std::max((size_t(batch) * 18 * T.bw + 4 * batch) * sizeof(double), size_t(128) * 42 * sizeof(double));
+    const dim3 grid(p->n_group_wg);
+    if (pair) {
+      HIP_TRY(need_irec());
+      const size_t lds2 = std::max(lds, kSegStage * sizeof(double));
+      const dim3 grid2(p->n_group_wg + p->n_seg_wg);
+      if (ntile <= kBlock)
+        k_gram_pair<K, 1><<<grid2, kBlock, lds2, s>>>(T, batch, p->n_group_wg);
+      else if (ntile <= 2 * kBlock)
+        k_gram_pair<K, 2><<<grid2, kBlock, lds2, s>>>(T, batch, p->n_group_wg);
+      else
+        k_gram_pair<K, 4><<<grid2, kBlock, lds2, s>>>(T, batch, p->n_group_wg);
+    } else if (ntile <= kBlock)
+      k_group_gram<1><<<grid, kBlock, lds, s>>>(T, batch);
+    else if (ntile <= 2 * kBlock)
+      k_group_gram<2><<<grid, kBlock, lds, s>>>(T, batch);
+    else
+      k_group_gram<4><<<grid, kBlock, lds, s>>>(T, batch);
+  }
+  if (side_imu && T.n_lm && !pair && p->n_seg_wg) {  // (large grids with an IMU: the segment Gram kernel after the landmark chain, same stream)
+    HIP_TRY(need_irec());
+    k_seg_gram<K><<<p->n_seg_wg, kBlock, kSegStage * sizeof(double), s>>>(T);
+  }
+  if (fork) HIP_TRY(hipStreamWaitEvent(s, p->ev_join, 0));
+  k_assemble<K><<<dim3(T.sp.n_cp, 6), kAsmThreads, 0, s>>>(T);
+  if (T.nb && !side_imu) {
+    k_border_pb<K><<<dim3(T.sp.n_cp + border_zero_wgs(T), p->n_split), kPbThreads, 0, s>>>(T);
+    k_border_bb<K><<<T.n_bias, kBlock, 0, s>>>(T);
+  }
+  if (side_imu) HIP_TRY(hipStreamWaitEvent(s, p->ev_join, 0));  // border gathers done
+  // Nothing to exchange (single shard): packing + bookkeeping are an extra workgroup of k_finalize_reduced, the border blocks further
+  // ones that sum the accumulation splits themselves — one launch where the exchanging path has five (~5 us each on the chain).
+  // A/B switch 8388608: the five launches.
+  const bool reduce_here = !p->allreduce && !p->rccl_comm && p->world == 1 && !(T.nb && (T.debug_flags & 8388608));
+  const int nb_wg = T.nb ? std::min(256, ((T.np + T.nb) * T.nb + kBlock - 1) / kBlock) : 0;
+  if (T.nb && !reduce_here)
+    k_reduce_partials<<<std::min(1024, (T.xo_bb - T.xo_pb + kBlock - 1) / kBlock), kBlock, 0, s>>>(T, p->n_split, T.xo_pb);
+  if (!reduce_here) k_pack_exchange<<<1, kBlock, 0, s>>>(T, 0);
+  HIP_TRY(hipGetLastError());
+  const int rc = exchange(p, T.xbuf, T.x_count1);  // one RCCL all-reduce of [S | g | diag | cost] per linearisation
+  if (rc) return rc;
+  k_finalize_reduced<<<T.sp.n_cp + (reduce_here ? 1 + nb_wg : 0), kBlock, 0, s>>>(T, p->n_split);  // + 1: packing / bookkeeping workgroup, + border
+  if (T.nb && !reduce_here) k_finalize_border<<<nb_wg, kBlock, 0, s>>>(T);
+  if (!reduce_here) k_cost_reduce<<<1, kBlock, 0, s>>>(T);
+  HIP_TRY(hipGetLastError());
+  return HS_OK;
+}
+
+/// Window size (in 16 x 16 tiles) of the MFMA factorisation for a band of bw blocks: 16 NT >= 6 bw + 12; 0: not supported.
+int mfma_window_tiles(int bw) {
+  for (int nt : {6, 9}) {  // (NT = 10 would cover bw <= 24: 256 VGPRs + scratch, and wrong results on gfx950 — not instantiated)
+    if (6 * bw + 12 <= 16 * nt) return nt;
+  }
+  return 0;
+}
+
+#if HS_PROFILE_HOOKS
+template <int NT, int NC>
+hipError_t launch_mfma(const Tables& T, int grid, hipStream_t s) {
+  static bool attr = false;
+  const size_t lds = size_t(MfmaGeom<NT>::kTotal) * sizeof(double);
+  if (!attr) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_mfma<NT, NC>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  k_band_factor_mfma<NT, NC><<<grid, 64 * (NC + 3), lds, s>>>(T);
+  return hipGetLastError();
+}
+
+void launch_backward_w(const Tables& T, const BackJob& j0, const BackJob& j1, int m_mid, int grid, hipStream_t s) {
+  const size_t lds = size_t(T.np) * sizeof(double);
+  if (T.bw <= kBackBlocks)
+    k_band_backward_w<1><<<grid, 64, lds, s>>>(T, j0, j1, m_mid);
+  else if (T.bw <= 2 * kBackBlocks)
+    k_band_backward_w<2><<<grid, 64, lds, s>>>(T, j0, j1, m_mid);
+  else if (T.bw <= 4 * kBackBlocks)
+    k_band_backward_w<4><<<grid, 64, lds, s>>>(T, j0, j1, m_mid);
+  else
+    k_band_backward_w<5><<<grid, 64, lds, s>>>(T, j0, j1, m_mid);
+}
+
+#endif  // HS_PROFILE_HOOKS
+
+/// Dense Cholesky of the border Schur complement + solve for the border unknowns (one workgroup).
+static hipError_t launch_border_solve(const Tables& T, hipStream_t s) {
+  if (T.nb + 1 <= 128 && !(T.debug_flags & 524288)) {  // trailing matrix in registers (A/B switch 524288: the LDS version)
+    const int R = std::max(4, (T.nb + 1 + 15) / 16), N = 16 * R;
+    const size_t lds = (size_t(4) * N + size_t(T.nb) * (N + 1) + T.nb) * sizeof(double);
+    switch (R) {
+      case 4: k_border_solve_reg<4><<<1, kBlock, lds, s>>>(T); break;
+      case 5: k_border_solve_reg<5><<<1, kBlock, lds, s>>>(T); break;
+      case 6: k_border_solve_reg<6><<<1, kBlock, lds, s>>>(T); break;
+      case 7: k_border_solve_reg<7><<<1, kBlock, lds, s>>>(T); break;
+      default: k_border_solve_reg<8><<<1, kBlock, lds, s>>>(T); break;
+    }
+  } else {
+    k_border_solve<<<1, kBlock, (size_t(T.nb + 1) * (T.nb + 1) + T.nb) * sizeof(double), s>>>(T);
+  }
+  return hipGetLastError();
+}
+
+int launch_factor(hs_problem* p) {
+  const Tables& T = p->T;
+  hipStream_t s = p->stream;
+  const int ncb = 6 * T.bw;
+  const size_t chol_lds = (size_t(24) * (ncb + 2) + size_t(T.np)) * sizeof(double);
+  const size_t la_lds = (size_t(42) * (ncb + 2) + size_t(T.np) + 48) * sizeof(double);
+  const bool legacy = T.debug_flags & 4;  // A/B switch: pre-look-ahead kernel
+  // Factoring from both ends at once (visual-only systems, look-ahead kernel, window long enough to pay for the junction)
+  const int n_blk = T.np / 6, w_mid = T.bw - 1;
+  const bool la_ok = !legacy && la_compute_waves(T.bw) > 0;
+  const int la_ncw = la_compute_waves(T.bw);
+  const int nt = HS_AB(T.debug_flags, 131072) ? mfma_window_tiles(T.bw) : 0;  // A/B switch 131072 (profiling builds): k_band_factor_mfma instead of the VALU kernels
+  // (bordered systems — bias splines + gravity — too: the forward sweep of the border columns follows the two-ended elimination order,
+  //  k_border_forward2; A/B switch 536870912: bordered systems one-ended)
+  const bool two_ended = (la_ok || nt) && (T.nb == 0 || (!nt && !(T.debug_flags & 536870912) && (T.nb + kBorderCols - 1) / kBorderCols <= 512)) &&
+                         n_blk >= 4 * T.bw && T.Sb2 && !(T.debug_flags & 2048);  // (512: flag words of k_border_forward2's column groups)
+#if HS_PROFILE_HOOKS
+  auto run_mfma = [&](const Tables& TT, int grid) -> hipError_t {
+    switch (nt) {
+      case 6: return launch_mfma<6, 3>(TT, grid, s);
+      default: return launch_mfma<9, 3>(TT, grid, s);
+    }
+  };
+#else
+  auto run_mfma = [&](const Tables&, int) -> hipError_t { return hipErrorNotSupported; };  // (nt == 0: never reached)
+#endif
+  if (two_ended) {
+    // The near end takes a few block rows more than the far end: the far end still has to hand its trailing window over (~7 us,
+    // i.e. ~4 steps: window through HBM + agent-scope release) before the near end can pass the junction. With an even split
+    // workgroup 0 waited 13 us there (tools/chol_phase_timing.py).
+    const int m = std::min((n_blk - w_mid) / 2 + 3, n_blk - w_mid - w_mid), mB = n_blk - w_mid - m;  // (+2 / +3 / +4: 132.0 / 130.5 / 132.1 us)
+    Tables T2 = T;
+    T2.fj[0] = FactorJob{T.Sb, T.g_s, T.Ub, T.Ubk, T.ybuf, p->d_win.p, m + w_mid, m};
+    T2.fj[1] = FactorJob{p->d_Sb2.p, p->d_g2.p, p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, p->d_win.p, mB, -1};
+    T2.mj[0] = MfmaJob{p->d_Sb2.p, T.g_s, T.Ub, T.Ubk, T.ybuf, p->d_win.p, m + w_mid, m, m + w_mid, INT_MAX, 0, p->d_Vb.p + size_t(T.np) * (6 * T.bw)};
+    T2.mj[1] = MfmaJob{T.Sb, p->d_g2.p, p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, p->d_win.p, mB, -1, mB + w_mid, mB, 1, p->d_Vb.p + size_t(T.np) * (6 * T.bw)};
+    T2.join_epoch = ++p->join_epoch;
+    if (nt)
+      HIP_TRY(run_mfma(T2, 2));
+    else
+      if (la_ncw == 3)
+        k_band_factor_la<1, 3><<<2, la_threads(3), la_lds, s>>>(T2);
+      else
+        k_band_factor_la<1, 4><<<2, la_threads(4), la_lds, s>>>(T2);
+    if (T.nb) {  // bordered system: Z = U^-T S_pb in the two-ended elimination order, border Schur complement and solve, y' = y - Z x_b
+      Tables Tb = T2;
+      Tb.ybuf2 = p->d_ybuf2.p, Tb.y_split = 6 * (m + w_mid);
+      Tb.join_epoch = ++p->join_epoch;
+      const int n_groups = (T.nb + kBorderCols - 1) / kBorderCols;
+      HIP_TRY(p->d_bf_handover.reserve(size_t(n_groups) * 6 * w_mid * kBorderCols + 1));
+      const int fwd_threads = std::max(128, 64 * ((6 * w_mid + 63) / 64));  // one lane per pending row
+      const int local_rows = (!p->allreduce && !p->rccl_comm && p->world == 1) ? 1 : 0;
+      k_border_forward2<<<dim3(n_groups, 2), fwd_threads, size_t(T.np) * kBorderLd * sizeof(double), s>>>(
+          Tb, BfJob{T.Ub, T.Ubk, m + w_mid, 0}, BfJob{p->d_Ub2.p, p->d_Ubk2.p, mB, 1}, m, 0, local_rows, p->d_bf_handover.p);
+      const int n_tiles = (T.nb + kSchurTile - 1) / kSchurTile;
+      k_border_schur<<<dim3(n_tiles, n_tiles), kBlock, 0, s>>>(Tb, 0, local_rows, m);  // (rows from the junction on are never skipped)
+      HIP_TRY(launch_border_solve(Tb, s));
+      k_border_apply<<<(T.np + kBlock / 64 - 1) / (kBlock / 64), kBlock, 0, s>>>(Tb);
+    }
+    Tables T3 = T2;
+    T3.join_epoch = ++p->join_epoch;
+    const BackJob j0{T.Ub, T.Ubk, T.ybuf, p->d_Vb.p, p->d_yt.p, m + w_mid, 0, 0};
+    const BackJob j1{p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, p->d_Vb2.p, p->d_yt2.p, mB, w_mid, 1};
+    // (the two older sweeps are kept as measurement switches for visual-only systems, the shape they were measured on; they do not write
+    //  the border's step outputs)
+    const bool sweep_w = HS_AB(T.debug_flags, 65536) && !T.nb, sweep_rows = HS_AB(T.debug_flags, 268435456) && !T.nb;
+#if HS_PROFILE_HOOKS
+    if (sweep_w) k_premultiply<<<m + w_mid + mB, 128, 0, s>>>(T3, j0, j1, m + w_mid);
+#endif
+    if (!sweep_w) {  // (A/B switch 65536: single-wave register sweep)
+      const size_t g_lds = size_t(6 * (T.bw - 1)) * (6 * (T.bw - 1) | 1) * sizeof(double);  // given-column block of the far sweep
+#if HS_PROFILE_HOOKS
+      if (sweep_rows)  // A/B switch 268435456: one block row per step
+        k_band_backward2<<<2, kCholThreads, 2 * size_t(T.np) * sizeof(double) + g_lds, s>>>(T3, j0, j1, m);
+      else
+#endif
+        // super-blocks of four block rows; the inverses of the diagonal super-blocks come from extra workgroups of the launch
+        k_band_backward_sb<<<2 + (m + w_mid + kSb - 1) / kSb + (mB + kSb - 1) / kSb, kCholThreads,
+                             std::max((2 * size_t(T.np) + 32) * sizeof(double) + g_lds, size_t(3 * kSbN * (kSbN + 1)) * sizeof(double)), s>>>(T3, j0, j1, m, 2, 0);
+    } else {
+#if HS_PROFILE_HOOKS
+      launch_backward_w(T3, j0, j1, m, 2, s);
+#endif
+    }
+    (void)sweep_rows;
+    HIP_TRY(hipGetLastError());
+    return HS_OK;
+  }
+  // One-ended. Block rows of the leading constant control points are decoupled (k_factor_decoupled_rows): the dependency chain of the
+  // factorisation starts behind them — the same kernels on the trailing sub-matrix (the band storage is row relative: pointer offsets).
+  const int f0 = (T.debug_flags & 262144) ? 0 : std::min(p->frozen_prefix, n_blk - 1);  // A/B switch 262144: eliminate every block row
+  Tables Tf = T;
+  const int n_eff = n_blk - f0;
+  const bool dense = !nt && !(T.debug_flags & 2097152) && T.bw > 14 && n_eff <= 2 * T.bw &&
+                     dense_factor_fits(n_eff, std::min(T.bw, n_eff));  // A/B switch 2097152: banded kernels
+  if (f0 > 0) {
+    if (!dense) k_factor_decoupled_rows<<<f0, 64, 0, s>>>(T, f0);  // (the dense kernel writes them with extra workgroups of its own launch)
+    Tf.Sb += size_t(6 * f0) * ncb, Tf.g_s += 6 * f0, Tf.Ub += size_t(6 * f0) * ncb, Tf.Ubk += size_t(24) * f0, Tf.ybuf += 6 * f0, Tf.np -= 6 * f0;
+    Tf.fj[0] = FactorJob{Tf.Sb, Tf.g_s, Tf.Ub, Tf.Ubk, Tf.ybuf, nullptr, Tf.np / 6, -1};
+  }
+  // short systems with window-wide bands (the sliding-window replay): every band tile in a register for the whole factorisation
+  if (dense) {
+    k_dense_factor<<<1 + f0, kDenseThreads, (size_t(12) * (ncb + 8) + size_t(32) * n_eff) * sizeof(double), s>>>(Tf, f0);
+  } else if (nt) {
+    Tables T1 = Tf;
+    // (the lower-band rows come from the reversed copy, whose rows are counted from the END of the matrix: no offset)
+    T1.mj[0] = MfmaJob{p->d_Sb2.p, Tf.g_s, Tf.Ub, Tf.Ubk, Tf.ybuf, nullptr, n_blk - f0, -1, n_blk - f0, INT_MAX, 0, p->d_Vb.p + size_t(T.np) * (6 * T.bw)};
+    T1.mj[1] = T1.mj[0];
+    HIP_TRY(run_mfma(T1, 1));
+  } else if (la_ok && la_ncw == 3)
+    k_band_factor_la<1, 3><<<1, la_threads(3), la_lds, s>>>(Tf);
+  else if (la_ok)
+    k_band_factor_la<1, 4><<<1, la_threads(4), la_lds, s>>>(Tf);
+  // (two tiles per lane need 168 accumulator registers: with six waves per workgroup the budget is 256 and the look-ahead
+  //  kernel spills in its update loop - wider bands stay on the kernel below)
+  else if (T.bw * T.bw <= kCholThreads)
+    k_band_factor<1><<<1, kCholThreads + kCholIo, chol_lds, s>>>(Tf);
+  else if (T.bw <= 21)  // two tiles per lane; the IO wave moves 12 x 64 entries per block row: 6 (6 bw + 1) <= 768 <=> bw <= 21
+    k_band_factor<2><<<1, kCholThreads + kCholIo, chol_lds, s>>>(Tf);  // (bw = 22 dropped entries of every block row in round 1:
+                                                                       //  found by the lock-step replay, tests/test_host_driver.py)
+  else  // long feature tracks: trailing window in L2 instead of registers
+    k_band_factor_wide<<<1, kWideThreads, size_t(12) * (ncb + 2) * sizeof(double), s>>>(Tf);
+  if (T.nb) {  // bordered system (bias splines + gravity)
+    const int fwd_threads = std::max(128, 64 * ((6 * (T.bw - 1) + 63) / 64));  // one lane per pending row
+    // the first non-zero row of a border column follows from the inertial record table — of ALL shards: a shard of a distributed solve
+    // only skips the rows of the constant control points (which every shard agrees on)
+    const int local_rows = (!p->allreduce && !p->rccl_comm && p->world == 1) ? 1 : 0;
+    k_border_forward<<<(T.nb + kBorderCols - 1) / kBorderCols, fwd_threads, size_t(T.np) * kBorderLd * sizeof(double), s>>>(T, f0, local_rows);
+    const int nt = (T.nb + kSchurTile - 1) / kSchurTile;
+    k_border_schur<<<dim3(nt, nt), kBlock, 0, s>>>(T, f0, local_rows, n_blk);
+    HIP_TRY(launch_border_solve(T, s));
+    k_border_apply<<<(T.np + kBlock / 64 - 1) / (kBlock / 64), kBlock, 0, s>>>(T);
+  }
+#if HS_PROFILE_HOOKS
+  if ((T.debug_flags & 8192) && !T.nb) {  // A/B: the generalised sweep on the whole system
+    const BackJob j0{T.Ub, T.Ubk, T.ybuf, nullptr, nullptr, T.np / 6, 0, 0};
+    k_band_backward2<<<1, kCholThreads, 2 * size_t(T.np) * sizeof(double), s>>>(T, j0, j0, -1);
+    k_step_outputs<<<1, kBlock, 0, s>>>(T);
+  } else
+#endif
+  if (!HS_AB(T.debug_flags, 65536) || T.nb) {  // (A/B switch 65536: single-wave register sweep — visual-only systems, the shape it was measured on)
+    if (6 * (T.bw - 1) <= 96 && !(T.debug_flags & 268435456)) {  // super-blocks of four block rows: one lane pair per pending row, 96 pairs
+      Tables T3 = T;
+      T3.join_epoch = ++p->join_epoch;
+      const BackJob j0{T.Ub, T.Ubk, T.ybuf, p->d_Vb.p, p->d_yt.p, T.np / 6, 0, 0};
+      k_band_backward_sb<<<1 + (T.np / 6 + kSb - 1) / kSb, kCholThreads,
+                           std::max((2 * size_t(T.np) + 32) * sizeof(double), size_t(3 * kSbN * (kSbN + 1)) * sizeof(double)), s>>>(T3, j0, j0, -1, 1, f0);
+    } else {  // wide bands (long feature tracks): one block row per step, one lane per pending row
+      k_band_backward<<<1, kCholThreads, 2 * size_t(T.np) * sizeof(double), s>>>(T, f0);
+    }
+  } else {
+#if HS_PROFILE_HOOKS
+    const BackJob j0{T.Ub, T.Ubk, T.ybuf, p->d_Vb.p, p->d_yt.p, T.np / 6, 0, 0};
+    k_premultiply<<<T.np / 6, 128, 0, s>>>(T, j0, j0, T.np / 6);
+    launch_backward_w(T, j0, j0, -1, 1, s);
+#endif
+  }
+  HIP_TRY(hipGetLastError());
+  return HS_OK;
+}
+
+/// Speculative solves (visual-only windows, on one shard or on every shard of a distributed solve): the candidate is LINEARISED instead of only costed, unless this is the last
+/// iteration of the solve: its records land in the record buffer that does not hold the current point and become the current
+/// linearisation if the step is accepted (decide_step flips DevState::rec_sel), so that the next iteration starts at k_landmark — after an
+/// accepted step and after a rejected one (the records of the unchanged current point are still there: today's path linearises again).
+/// One linearise launch (16 us at configs[1]) replaces a cost launch (7.7 us) + a linearise launch per iteration.
+static bool speculative_solve(const hs_problem* p) {
+  const Tables& T = p->T;
+  return !p->fused && T.n_vis > 0 && !T.n_pri && !T.n_ine && !T.nb && !(T.debug_flags & 1073741824);  // A/B switch (shards of a distributed solve too: the decision is replicated)
+}
+/// Fused build: a visual-only window keeps an accepted candidate in the candidate buffers (k_build_visual reads it from there, the next
+/// k_backsub_retract copies it to x on its way): no k_commit launch per iteration. Other windows commit (their prior / inertial kernels read x).
+static bool fused_visual_only(const hs_problem* p) {
+  const Tables& T = p->T;
+  return p->fused && !T.n_pri && !T.n_ine && !T.nb;
+}
+
+/// Small problems: the decision kernel copies the accepted candidate to x itself (single shard). A/B switch 16777216: always k_commit.
+static bool commit_inline(const hs_problem* p) {
+  const Tables& T = p->T;
+  return !p->allreduce && !p->rccl_comm && 8 * T.sp.n_cp + 3 * T.n_lm + 8 * T.n_bias <= kCommitInline && !(T.debug_flags & 16777216);
+}
+
+template <int K>
+int launch_update(hs_problem* p, bool linearize_candidate = false, bool deferred_commit = false, hipEvent_t* lin_events = nullptr) {
+  const Tables& T = p->T;
+  hipStream_t s = p->stream;
+  if (p->fused) {  // candidate point, landmark back-substitution and the visual candidate cost per chunk, one launch
+    k_update_visual<K><<<p->nb_vis + T.n_norm_part, kBlock, size_t(update_lds_doubles(T.bw, p->build_R, p->build_L)) * 8, s>>>(T, p->build_R, p->build_L, p->nb_vis);
+    if (T.n_pri) k_cost_prior<K><<<p->nb_pri, kBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.cand_part + p->nb_vis);
+    if (T.n_ine)
+      k_cost_inertial<K, 4><<<p->nb_ine, kInertialBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.bias_g_cand, T.bias_a_cand, T.gravity_cand,
+                                                                          T.cand_part + p->nb_vis + p->nb_pri);
+  } else
+    k_backsub_retract<<<T.n_lm_part + T.n_norm_part, kBlock, 0, s>>>(T);
+  if (p->fused) {
+  } else if (linearize_candidate) {
+    if (lin_events) HIP_TRY(hipEventRecord(lin_events[0], s));  // stage timing: this launch is booked under "linearise", not "update"
+    k_linearize_visual<K><<<p->nb_vis, lin_block<K>(), lin_lds_bytes<K>(p), s>>>(T, nullptr, T.v_pos, 1, T.cand_part, nullptr, T.cp_cand, T.lm_cand);
+    if (lin_events) HIP_TRY(hipEventRecord(lin_events[1], s));
+  } else if ((T.n_ine || T.n_pri) && !(T.debug_flags & 33554432)) {  // one launch for all factor types (A/B switch 33554432: one per type)
+    k_cost_all<K, 4><<<p->nb_vis + p->nb_pri + p->nb_ine, kBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.lm_cand, T.bias_g_cand, T.bias_a_cand, T.gravity_cand,
+                                                                                       T.cand_part, p->nb_vis, p->nb_pri);
+  } else {
+    if (T.n_vis) k_cost_visual<K><<<p->nb_vis, kBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.lm_cand, T.cand_part);
+    if (T.n_pri) k_cost_prior<K><<<p->nb_pri, kBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.cand_part + p->nb_vis);
+    if (T.n_ine)
+      k_cost_inertial<K, 4><<<p->nb_ine, kInertialBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.bias_g_cand, T.bias_a_cand, T.gravity_cand,
+                                                                          T.cand_part + p->nb_vis + p->nb_pri);
+  }
+  const bool local_decision = !p->allreduce && !p->rccl_comm;  // single shard: decide in the packing kernel
+  const bool inline_commit = commit_inline(p);
+  const bool cps_here = p->fused && deferred_commit;  // fused path: the decision kernel commits the control points, the landmarks stay deferred
+  k_pack_decision<<<1, kBlock, 0, s>>>(T, inline_commit ? 2 : local_decision ? (cps_here ? 3 : 1) : 0);
+  HIP_TRY(hipGetLastError());
+  const int rc = exchange(p, T.xbuf + T.xo_dec, 5);  // candidate cost + norms + landmark-side model-cost terms
+  if (rc) return rc;
+  if (!local_decision) k_decide<<<1, kBlock, 0, s>>>(T, cps_here ? 1 : 0);
+  const int nb_commit = std::max((std::max(8 * T.sp.n_cp, 3 * T.n_lm) + kBlock - 1) / kBlock, 1);  // one element per lane
+  // (deferred: speculative solves of larger problems — the next iteration's k_backsub_retract copies the accepted candidate to x on its way,
+  //  hs_solve launches k_commit once behind the last iteration)
+  if (!inline_commit && !deferred_commit) k_commit<<<nb_commit, kBlock, 0, s>>>(T);
+  HIP_TRY(hipGetLastError());
+  return HS_OK;
+}
+
+static void launch_commit(hs_problem* p) {
+  const Tables& T = p->T;
+  const int nb_commit = std::max((std::max(8 * T.sp.n_cp, 3 * T.n_lm) + kBlock - 1) / kBlock, 1);
+  k_commit<<<nb_commit, kBlock, 0, p->stream>>>(T);
+}
+
+/// First use of a kernel costs ~0.35 ms of host time (the runtime builds its kernel object lazily); a solve touches ~25 different kernels,
+/// which showed up as a 9 ms hs_solve on the first optimize() of a process (HS_HOST_TIMING=2: "launches" of call 0). hs_create resolves
+/// the kernels of the solve path up front, once per process and device; what remains on the first call is the allocation of the tables.
+template <int K>
+static void warm_kernels_of_order() {
+  hipFuncAttributes fa;
+  const void* kernels[] = {
+      reinterpret_cast<const void*>(&k_build_visual<K>), reinterpret_cast<const void*>(&k_update_visual<K>), reinterpret_cast<const void*>(&k_linearize_visual<K>), reinterpret_cast<const void*>(&k_linearize_prior<K>),
+      reinterpret_cast<const void*>(&k_linearize_inertial<K, 4>), reinterpret_cast<const void*>(&k_landmark<K, 2, 2>),
+      reinterpret_cast<const void*>(&k_landmark<K, 4, 1>), reinterpret_cast<const void*>(&k_landmark_rows<K, 4>),
+      reinterpret_cast<const void*>(&k_gram_pair<K, 1>), reinterpret_cast<const void*>(&k_gram_pair<K, 2>), reinterpret_cast<const void*>(&k_gram_pair<K, 4>),
+      reinterpret_cast<const void*>(&k_seg_gram<K>), reinterpret_cast<const void*>(&k_assemble<K>), reinterpret_cast<const void*>(&k_border_pb<K>),
+      reinterpret_cast<const void*>(&k_border_bb<K>), reinterpret_cast<const void*>(&k_cost_visual<K>), reinterpret_cast<const void*>(&k_cost_prior<K>),
+      reinterpret_cast<const void*>(&k_cost_inertial<K, 4>), reinterpret_cast<const void*>(&k_cost_all<K, 4>),
+      reinterpret_cast<const void*>(&k_process_tracks<K>), reinterpret_cast<const void*>(&k_sample_trajectory<K>)};
+  for (const void* k : kernels) (void)hipFuncGetAttributes(&fa, k);
+}
+static void warm_kernels(int device) {
+  static std::mutex mu;
+  static std::vector<int> done;
+  std::lock_guard<std::mutex> lock(mu);
+  if (std::find(done.begin(), done.end(), device) != done.end()) return;
+  done.push_back(device);
+  hipFuncAttributes fa;
+  const void* kernels[] = {
+      reinterpret_cast<const void*>(&k_group_gram<1>), reinterpret_cast<const void*>(&k_group_gram<2>), reinterpret_cast<const void*>(&k_group_gram<4>),
+      reinterpret_cast<const void*>(&k_pack_exchange), reinterpret_cast<const void*>(&k_cost_reduce), reinterpret_cast<const void*>(&k_finalize_reduced),
+      reinterpret_cast<const void*>(&k_finalize_border), reinterpret_cast<const void*>(&k_reduce_partials), reinterpret_cast<const void*>(&k_factor_decoupled_rows),
+      reinterpret_cast<const void*>(&k_dense_factor), reinterpret_cast<const void*>(&k_band_factor_wide), reinterpret_cast<const void*>(&k_band_factor<1>),
+      reinterpret_cast<const void*>(&k_band_factor<2>), reinterpret_cast<const void*>(&k_band_factor_la<1, 3>), reinterpret_cast<const void*>(&k_band_factor_la<1, 4>),
+      reinterpret_cast<const void*>(&k_band_backward), reinterpret_cast<const void*>(&k_band_backward_sb), reinterpret_cast<const void*>(&k_border_forward),
+      reinterpret_cast<const void*>(&k_border_forward2),
+      reinterpret_cast<const void*>(&k_border_schur), reinterpret_cast<const void*>(&k_border_solve), reinterpret_cast<const void*>(&k_border_solve_reg<4>),
+      reinterpret_cast<const void*>(&k_border_solve_reg<5>), reinterpret_cast<const void*>(&k_border_solve_reg<6>), reinterpret_cast<const void*>(&k_border_solve_reg<7>),
+      reinterpret_cast<const void*>(&k_border_solve_reg<8>), reinterpret_cast<const void*>(&k_border_apply), reinterpret_cast<const void*>(&k_backsub_retract),
+      reinterpret_cast<const void*>(&k_pack_decision), reinterpret_cast<const void*>(&k_decide), reinterpret_cast<const void*>(&k_commit),
+      reinterpret_cast<const void*>(&k_reset_state), reinterpret_cast<const void*>(&k_scatter_uploads)};
+  for (const void* k : kernels) (void)hipFuncGetAttributes(&fa, k);
+  warm_kernels_of_order<4>();
+  warm_kernels_of_order<6>();
+}
+
+int set_func_attributes(hs_problem* p) {
+  // opt in to > 64 KiB dynamic LDS for the factorisation
+  hipFuncAttributes fa;
+  HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_band_factor<2>)));
+  p->chol_lds_max = 160 * 1024 - int(fa.sharedSizeBytes);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor<1>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor<2>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_la<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_la<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seg_gram<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seg_gram<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_solve_reg<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_solve_reg<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_solve_reg<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_solve_reg<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<6, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<6, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<6, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_visual<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_visual<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_visual<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_visual<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_visual<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_visual<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_forward), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_forward2), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+#if HS_PROFILE_HOOKS
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_backward2), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+#endif
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_backward_sb), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_backward), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  return HS_OK;
+}
+
+}  // namespace

@@ -20,8 +20,8 @@ t = buf[48 * 1024:].reshape(1024, 4, 16)
 ok = t[:, 0, 0] > 0
 t = t[ok]
 print("chunks stamped:", len(t), " residuals / landmarks per chunk (median, max):", np.median(t[:, 0, 13]), t[:, 0, 13].max(), np.median(t[:, 0, 14]), t[:, 0, 14].max())
-names = ["start", "tables staged", "linearised", "sorted", "W/H rows done", "barrier", "J'J tiles done", "barrier", "eliminated", "barrier", "Yh Yh' done",
-         "written", "cost summed"]
+names = ["start", "inputs + keys (b)", "sorted, pos (b)", "linearised", "barrier", "H/b, W blocks", "J'J tiles done", "barrier", "Cholesky (b)", "Y-hat (b)",
+         "Yh Yh' done", "written", "cost summed"]  # (b): stamp taken behind the phase's barrier
 base = t[:, :, 0].min(axis=1)[:, None, None]
 rel = (t[:, :, :13] - base) * 0.01  # 100 MHz clock -> us
 print("median over chunks [us after the chunk's first wave started]; columns = wave 0..3")

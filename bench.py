@@ -341,9 +341,14 @@ def main():
             ncp_l = (hi - lo + 1)[hi >= 0]
             n_chunks = max(1, int(np.ceil(len(ncp_l) / 24.0)))  # lower bound of the chunk count (the library splits per landmark group)
             alg_bytes = 32 * n_visual + 8 * (18 * int(ncp_l.sum()) + 25 * len(ncp_l)) + 8 * n_chunks * (36 * bw_blocks * (bw_blocks + 1) // 2 + 18 * bw_blocks)
+            # fp64 work of the same launch (the kernel is instruction-issue bound, not HBM bound: DESIGN.md §5): per residual block the
+            # linearisation (~3.5 kFLOP: spline, factor, local Jacobian, loss), H_ll / b_l / the k W blocks (36 + 72 k) and k (k + 1) / 2
+            # J_p'J_p tiles of 2 x 36 FMAs; per landmark n (n + 1) / 2 window tiles of 3 x 36 FMAs, Y-hat (108 n) and the 3 x 3 factor
+            alg_flops = n_visual * (3500 + 36 + 72 * order + 144 * order * (order + 1) // 2) + int((ncp_l * (ncp_l + 1) // 2 * 216 + 108 * ncp_l + 100).sum())
             alg_note = ("32 B in per residual block + Y-hat rows + per-landmark factors + one window partial per chunk (lower bound: ceil(landmarks / 24) chunks); "
                         "the 448-byte record of SURVEY.md 8(d) is not materialised on this path")
         else:
+            alg_flops = None
             lin_kernel = f"hs::k_linearize_visual<{order}>"
             alg_bytes = (32 + 8 * (8 + 12 * order)) * n_visual  # 32 B in + one record [r(2) J_l(6) J_state(12 k)] out = 480 B at k = 4
             alg_note = "SURVEY.md 8(d): B_alg = 32 B in + 8 (8 + 12 k) B record out per residual block"
@@ -364,6 +369,11 @@ def main():
                             "~4 us of dispatch latency); rocprof_avg_kernel_ms / achieved_profile / frac_profile = committed rocprofv3 --kernel-trace "
                             "--stats average of this command (the kernel alone); traffic = FETCH_SIZE + WRITE_SIZE of the newest "
                             "profiles/r*_pmc_hbm_traffic.json (separate rocprofv3 --pmc passes, tools/pmc_traffic.sh)"}
+        if alg_flops:
+            t_ms = prof_ms or lin_ms
+            roofline["fp64_valu"] = {"achieved": alg_flops / (t_ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": alg_flops / (t_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "algorithmic_flops_per_launch": alg_flops,
+                                     "time_ms": t_ms, "note": "vector fp64 (no MFMA: 6-wide blocks, DESIGN.md §2); the kernel's binding resource"}
         n_cp_total = int(window.control_points.shape[0])
         # (launch_factor's rule: look-ahead kernel, window of >= 4 bw block rows; bordered systems too unless HS_DEBUG_FLAGS 536870912 / 2048)
         flags = int(os.environ.get("HS_DEBUG_FLAGS", "0"))

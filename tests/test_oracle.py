@@ -217,7 +217,7 @@ def test_bench_helpers(oracle):
     names = [os.path.basename(f) for f in bench._newest("r*_bench_kernel_stats.csv")]
     keys = [[int(x) for x in re.findall(r"\d+", n)] for n in names]
     assert keys == sorted(keys) and len(names) >= 2
-    assert bench.rocprof_kernel_ms("void hs::k_linearize_visual<4>") > 0 and bench.pmc_traffic("hs::k_linearize_visual<4>") > 1e6
+    assert bench.rocprof_kernel_ms("void hs::k_build_visual<4>") > 0 and bench.pmc_traffic("hs::k_build_visual<4>") > 1e6  # (newest committed profile: the fused build)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-worker", oracle.path, repr(time.time() + 1.0)],
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -286,3 +286,35 @@ def test_oracle_time_shift_invariance(oracle):
                 assert rel(la[key], lb[key]) < 1e-8, (t, key, rel(la[key], lb[key]))
         sa, sb = a.solve(3), b.solve(3)
         assert abs(sa["final_cost"] - sb["final_cost"]) <= 1e-6 * sa["final_cost"]
+
+
+def test_reference_vectors_overlay_is_what_the_golden_tests_compare_with(oracle, tmp_path, monkeypatch):
+    """HS_REFERENCE_VECTORS=<dir> (outputs of the real reference written by tools/reference_dump.cpp) replaces the outputs of the
+    golden cases: a faithful copy passes — inertial cases then in the as-written mode, which the as-written vectors of inertial_literal.json
+    stand in for here — and a copy with one residual changed fails, i.e. the overlay is what is compared."""
+    import json
+
+    import util
+
+    plain = util.golden_cases()
+    with open(os.path.join(util.HERE, "golden", "inertial_literal.json")) as f:
+        literal = json.load(f)["cases"]
+    ref = {"cases": [{"type": c["type"], "outputs": c["outputs"]} for c in plain]}
+    (tmp_path / "factors.json").write_text(json.dumps(ref))
+    (tmp_path / "inertial_literal.json").write_text(json.dumps({"cases": [{"type": c["type"], "outputs": c["outputs"]} for c in literal]}))
+    monkeypatch.setenv("HS_REFERENCE_VECTORS", str(tmp_path))
+    cases = util.golden_cases()
+    assert all(c.get("reference") for c in cases)
+    pixel = next(c for c in cases if c["type"] == "pixel")
+    with ha.Problem(golden_window(pixel), lib=oracle) as p:
+        check_against_golden(p, pixel, 1e-9)
+    lit = util.literal_inertial_cases()
+    assert lit[0].get("reference")
+    with ha.Problem(golden_window(lit[0]), lib=oracle) as p:  # a reference vector of an inertial factor is compared in the default mode only
+        lit[0]["variant"] = None
+        check_against_golden(p, {**lit[0], "outputs": {k: lit[0]["outputs"][k] for k in ("r", "J_state", "J_extrinsics", "J_gravity", "J_acc_offsets")}}, 1e-9)
+    ref["cases"][plain.index(next(c for c in plain if c["type"] == "pixel"))]["outputs"] = dict(pixel["outputs"], r=[x + 1e-6 for x in pixel["outputs"]["r"]])
+    (tmp_path / "factors.json").write_text(json.dumps(ref))
+    changed = next(c for c in util.golden_cases() if c["type"] == "pixel")
+    with ha.Problem(golden_window(changed), lib=oracle) as p, pytest.raises(AssertionError):
+        check_against_golden(p, changed, 1e-9)

@@ -558,7 +558,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
 // lm_cand until this kernel passes over it (DevState::spec == 4).
 // ---------------------------------------------------------------------------------------------------------------------
 __host__ __device__ inline int update_lds_doubles(int bw, int R, int Lmax) {
-  return 14 * bw + 4 * Lmax * bw + 8 * Lmax + 16 * kBuildCams + R + 8 + (Lmax + 1) / 2 + 8;
+  return 14 * bw + 4 * Lmax * bw + 8 * Lmax + 16 * kBuildCams + R + 8 + Lmax + 8;  // (.. + l_ncp, l_yoff: 2 Lmax ints)
 }
 
 template <int K>
@@ -642,6 +642,7 @@ __global__ void __launch_bounds__(kBlock) k_update_visual(Tables T, int R, int L
   double* costs = cams + 16 * kBuildCams;     // [R]
   double* cpart = costs + R;                  // [8]
   int* l_ncp = reinterpret_cast<int*>(cpart + 8);
+  int* l_yoff = l_ncp + Lmax;
   // residual inputs (independent of everything below: requested first)
   const bool has_rec = tid < nres;
   VisualIn in;
@@ -664,7 +665,22 @@ __global__ void __launch_bounds__(kBlock) k_update_visual(Tables T, int R, int L
   }
   for (int e = tid; e < 6 * ncp_w; e += kBlock) yp[e] = -T.step_p[6 * cf + e] * T.scale_p[6 * cf + e];
   for (int e = tid; e < 16 * min(T.n_cam, kBuildCams); e += kBlock) cams[e] = T.cam[e];
-  if (tid < nl) l_ncp[tid] = T.lm_ncp[lo + tid];
+  if (tid < nl) l_ncp[tid] = T.lm_ncp[lo + tid], l_yoff[tid] = T.lm_yoff[lo + tid];
+  // Everything the landmark lanes need behind the dot products is requested in this round too (the kernel is a chain of memory round
+  // trips: descriptor -> tables -> Y-hat; as a fourth and fifth round these loads cost ~3 us of its 12.8)
+  double L[6], yh[3], x[3], sc[3], sb[3], d2[3];
+  bool active = false;
+  if (tid < nl) {
+    const int dl = lo + tid;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) L[a] = T.lm_L[6 * dl + a];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      yh[a] = T.lm_yhat[3 * dl + a], x[a] = (pend ? T.lm_cand : T.lm)[3 * dl + a], sc[a] = T.lm_scale[3 * dl + a];
+      sb[a] = T.lm_sb[3 * dl + a], d2[a] = T.lm_D2[3 * dl + a];
+    }
+    active = !T.lm_const[dl];
+  }
   __syncthreads();
   // partial dot products, one (landmark, control point) block per lane: the 6 x 3 block of Y-hat is 18 consecutive doubles in HBM
   const int n_task = nl * bw;
@@ -672,7 +688,7 @@ __global__ void __launch_bounds__(kBlock) k_update_visual(Tables T, int R, int L
     const int l = int((unsigned(tau) * bw_magic) >> 20), jb = tau - l * bw;
     double t0 = 0.0, t1 = 0.0, t2 = 0.0;
     if (jb < l_ncp[l]) {
-      const double2* Y = reinterpret_cast<const double2*>(T.Y + T.lm_yoff[lo + l] + 18 * jb);
+      const double2* Y = reinterpret_cast<const double2*>(T.Y + l_yoff[l] + 18 * jb);
       double y[18];
 #pragma unroll
       for (int e = 0; e < 9; ++e) {
@@ -693,15 +709,6 @@ __global__ void __launch_bounds__(kBlock) k_update_visual(Tables T, int R, int L
     const int l = tid, dl = lo + l;
     double t0 = 0.0, t1 = 0.0, t2 = 0.0;
     for (int jb = 0; jb < l_ncp[l]; ++jb) t0 += part[4 * (l * bw + jb)], t1 += part[4 * (l * bw + jb) + 1], t2 += part[4 * (l * bw + jb) + 2];
-    double L[6], yh[3], x[3], sc[3], sb[3], d2[3];
-#pragma unroll
-    for (int a = 0; a < 6; ++a) L[a] = T.lm_L[6 * dl + a];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      yh[a] = T.lm_yhat[3 * dl + a], x[a] = (pend ? T.lm_cand : T.lm)[3 * dl + a], sc[a] = T.lm_scale[3 * dl + a];
-      sb[a] = T.lm_sb[3 * dl + a], d2[a] = T.lm_D2[3 * dl + a];
-    }
-    const bool active = !T.lm_const[dl];
     const double z0 = yh[0] - t0, z1 = yh[1] - t1, z2 = yh[2] - t2;  // L' y = z
     const double y2 = z2 / L[5], y1 = (z1 - L[4] * y2) / L[2], y0 = (z0 - L[1] * y1 - L[3] * y2) / L[0];
     const double s[3] = {active ? -y0 : 0.0, active ? -y1 : 0.0, active ? -y2 : 0.0};

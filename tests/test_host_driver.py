@@ -136,7 +136,10 @@ def test_estimation_dump_hip_matches_oracle(built, tmp_path):
     run("replay", 0.6, 1, 4, a), run("replay_oracle", 0.6, 1, 4, b)
     ra, rb = np.loadtxt(a, delimiter=","), np.loadtxt(b, delimiter=",")
     assert ra.shape == rb.shape and np.array_equal(ra[:, 0], rb[:, 0])
-    assert np.abs(ra[:, 5:] - rb[:, 5:]).max() < 1e-3   # same trajectory up to the solver-path differences discussed below
+    # Free-running: each library drives its own replay through six gauge-free windows (no frozen control point yet: rank deficient up to the LM
+    # damping), so the round-off of the two factorisations is amplified from call to call. Measured on the MI355X box (round 4): 9.6e-6 m on
+    # the positions, 9.0e-7 on the quaternions; the bars are 10x that. (The lock-step test below feeds both libraries identical windows and holds 1e-6.)
+    assert np.abs(ra[:, 5:] - rb[:, 5:]).max() < 1e-4 and np.abs(ra[:, 1:5] - rb[:, 1:5]).max() < 1e-5
 
 
 def check_lockstep(calls, summary, n_calls, slides):

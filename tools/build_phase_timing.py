@@ -50,3 +50,15 @@ for k_ in uniq:
         a, b = idx[o[0]], idx[o[1]]
         over += int(start[b] < end[a] - 1.0)
 print("CUs whose second chunk started more than 1 us before the first ended (co-resident workgroups):", over, "of", int((cnt >= 2).sum()))
+# which SIMD each wave of a workgroup runs on, and whether the two co-resident workgroups of a CU put wave k on the same SIMD
+simd = (t[:, :, 15] & 0xffffffff) >> 4 & 3
+print("SIMD of waves 0..3, first 6 chunks:", simd[:6].tolist())
+same = tot = 0
+pat = {}
+for k_ in uniq:
+    idx = np.where(key == k_)[0]
+    if len(idx) == 2:
+        tot += 1
+        same += int((simd[idx[0]] == simd[idx[1]]).all())
+        pat[tuple(simd[idx[0]].tolist() + simd[idx[1]].tolist())] = pat.get(tuple(simd[idx[0]].tolist() + simd[idx[1]].tolist()), 0) + 1
+print("CUs with two chunks:", tot, " wave k of both on the same SIMD:", same, " patterns (wg A waves | wg B waves):", sorted(pat.items(), key=lambda kv: -kv[1])[:6])

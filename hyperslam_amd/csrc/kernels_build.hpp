@@ -183,12 +183,17 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
 
   // ---- 0: every table of the chunk and every input of its residuals in ONE round of independent loads ----
   const int lo = d0.x, nl = d0.y, cf = d0.z, q0 = d0.w;
-  const bool has_rec = tid < nres;
+  // Record t of the chunk is linearised by lane t & 63 of wave 0 (t < 64) or wave 2: a chunk holds <= 128 records, and the hardware puts
+  // waves {0, 2} of the two workgroups that share a CU on disjoint SIMD pairs (measured: wave -> SIMD is (0 2 1 3), (2 1 3 0), (3 0 2 1) or
+  // (1 3 0 2), the co-resident workgroup one rotation on), where waves {0, 1} of both met on one SIMD and the linearisation — the phase in
+  // which only the record lanes work — ran at half speed. (Wider chunks, HS_BUILD_R > 128: lane t.)
+  const int rt = R > 128 ? tid : wave == 0 ? lane : wave == 2 ? 64 + lane : kBlock;
+  const bool has_rec = rt < nres;
   int my_o = -1, my_l = 0;
   VisualIn in;
   int camid = 0;
   if (has_rec) {
-    const int q = q0 + tid;
+    const int q = q0 + rt;
     in.first = T.v_first[q], my_l = T.v_lm[q] - lo;
     my_o = in.first - cf;
     const int info = T.v_info[q];
@@ -258,7 +263,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
     const double cost = visual_linearize_compact<K>(T, cps_l - 8 * cf, relp - cf, frozen - cf, in, robustify != 0, rec);
     // A'A, A'r and the cost of this record (the landmark's H_ll and b_l are their sums in table order)
     const double a0 = rec[2], a1 = rec[3], a2 = rec[4], a3 = rec[5], a4 = rec[6], a5 = rec[7], r0 = rec[0], r1 = rec[1];
-    double* h = hbr + 10 * tid;
+    double* h = hbr + 10 * rt;
     h[0] = fma(a0, a0, a3 * a3), h[1] = fma(a0, a1, a3 * a4), h[2] = fma(a0, a2, a3 * a5);
     h[3] = fma(a1, a1, a4 * a4), h[4] = fma(a1, a2, a4 * a5), h[5] = fma(a2, a2, a5 * a5);
     h[6] = fma(a0, r0, a3 * r1), h[7] = fma(a1, r0, a4 * r1), h[8] = fma(a2, r0, a5 * r1);
@@ -644,11 +649,12 @@ __global__ void __launch_bounds__(kBlock) k_update_visual(Tables T, int R, int L
   int* l_ncp = reinterpret_cast<int*>(cpart + 8);
   int* l_yoff = l_ncp + Lmax;
   // residual inputs (independent of everything below: requested first)
-  const bool has_rec = tid < nres;
+  const int rt = R > 128 ? tid : (tid >> 6) == 0 ? tid : (tid >> 6) == 2 ? tid - 64 : kBlock;  // (record <-> lane as in k_build_visual: waves 0 and 2)
+  const bool has_rec = rt < nres;
   VisualIn in;
   int camid = 0, my_l = 0;
   if (has_rec) {
-    const int q = q0 + tid;
+    const int q = q0 + rt;
     in.first = T.v_first[q], my_l = T.v_lm[q] - lo;
     const int info = T.v_info[q];
     in.type = info >> 16, camid = info & 0xffff;
@@ -738,7 +744,7 @@ __global__ void __launch_bounds__(kBlock) k_update_visual(Tables T, int R, int L
   if (has_rec) {
     in.cam = camid < kBuildCams ? cams + 16 * camid : T.cam + kCamStride * camid;
     in.lm[0] = lmc[8 * my_l], in.lm[1] = lmc[8 * my_l + 1], in.lm[2] = lmc[8 * my_l + 2];
-    costs[tid] = visual_cost_in<K>(T, cps_c - 8 * cf, in);
+    costs[rt] = visual_cost_in<K>(T, cps_c - 8 * cf, in);
   }
   __syncthreads();
   if (tid < 8) {  // fixed-order sum: eight strided partials, then their sum

@@ -82,7 +82,7 @@ __global__ void k_reset_state(DevState* st, int max_iterations, double radius, i
   st->radius = radius, st->decrease_factor = 2.0;
   st->cost = st->cand_cost = st->model_cost_change = 0.0;
   st->gmax_bits = 0ull, st->gmax_pose_bits = 0ull, st->gmax = 0.0, st->x_sqnorm = st->step_sqnorm = 0.0;
-  st->g_dot_step_pose = st->d2_step2_pose = 0.0;
+  st->g_dot_step_pose = st->d2_step2_pose = st->g_dot_step_far = st->d2_step2_far = 0.0;
   st->iteration = 0, st->done = 0, st->termination = HS_NO_CONVERGENCE, st->accepted = 0, st->step_valid = 0;
   st->invalid_streak = 0, st->num_successful = 0, st->num_iterations = 0, st->scaling_ready = 0;
   st->max_iterations = max_iterations, st->chol_failed = 0;

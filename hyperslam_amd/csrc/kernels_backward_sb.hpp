@@ -25,6 +25,7 @@ constexpr int kSb = 4;            // block rows per super-block
 constexpr int kSbN = 6 * kSb;     // scalar rows per super-block
 constexpr int kSbPrefetch = 5;    // super-steps between requesting the operands of a step from HBM / MALL and using them (~2 us)
 constexpr int kSbFlagBase = 4;    // T.join_flag[kSbFlagBase + 512 job + s] = epoch once Winv of super-block s of that job is in memory
+constexpr int kSbOut = 2;        // step-output operands a lane keeps from the start of the kernel (2 x 256 scalar rows per end: 170 control points per window)
 constexpr int kSbMaxBlocks = 512; // super-blocks per job the flag table has room for (n_cp <= 1024 control points)
 
 HSD int sb_count(int n_rows) { return (n_rows + kSb - 1) / kSb; }
@@ -168,6 +169,15 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward_sb(Tables T, Bac
   const bool merged = J.given > 0;  // (the two-ended launch always has 6 given = n_above <= n_own)
   const int ldg = n_above | 1;
   for (int rho = tid; rho < n_own; rho += nthr) xs[rho] = J.ybuf[rho];
+  // operands of the step outputs at the end of a two-ended sweep (the rows this block solves), requested now
+  double o_sc[kSbOut], o_gf[kSbOut], o_d2[kSbOut];
+#pragma unroll
+  for (int u = 0; u < kSbOut; ++u) {
+    const int rho = tid + u * nthr;
+    const bool ok = n_jobs == 2 && rho < n_own;
+    const int nat = ok ? (J.reversed ? np - 1 - rho : rho) : 0;
+    o_sc[u] = ok ? T.scale_p[nat] : 0.0, o_gf[u] = ok ? T.g_full[nat] : 0.0, o_d2[u] = ok ? T.D2p[nat] : 0.0;
+  }
   if (n_jobs == 1)
     for (int rho = tid; rho < n_own; rho += nthr) xout[rho] = 0.0;  // (rows above j_lo are not swept)
   if (tid < kSbN && J.given == 0) smem[n_all + tid] = 0.0;  // a partial last super-block reads 24 entries from its first row on
@@ -339,47 +349,47 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward_sb(Tables T, Bac
     }
     return;
   }
-  const int flush_to = (job == 0 && m_mid >= 0) ? 6 * m_mid : n_own;  // (the middle rows of block 0 are already out)
-  for (int rho = tid; rho < flush_to; rho += nthr) T.xsol[J.reversed ? np - 1 - rho : rho] = xout[rho];
-  // the sweep that finishes last turns the solution into the step outputs (saves a launch); join_flag[1] advances by two per launch
-  __shared__ int is_last;
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) is_last = (atomicAdd(T.join_flag + 1, 1u) & 1u) == 1u;
-  __syncthreads();
-  if (!is_last) return;
-  __threadfence();
+  // Two-ended: each sweep turns the rows it solved into the step outputs itself — step = -x, delta = scale o step and its share of the two
+  // sums of the model cost change (DevState: block 0 the near share + the border unknowns, block 1 the far share; decide_step adds them) —
+  // with the operands requested at the start of the kernel. (Until round 4 the block that finished last did it for all rows behind a
+  // ticket: a release, an acquire and a round of loads, ~4 us at the end of the iteration's chain.)
   double gd = 0.0, dd = 0.0;
-  for (int rho0 = tid; rho0 < np; rho0 += 4 * nthr) {
-    double xv[4], sc[4], gf[4], d2[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int rho = rho0 + u * nthr, rr = rho < np ? rho : 0;
-      xv[u] = __builtin_nontemporal_load(T.xsol + rr), sc[u] = T.scale_p[rr], gf[u] = T.g_full[rr], d2[u] = T.D2p[rr];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int rho = rho0 + u * nthr;
-      if (rho < np) {
-        const double step_v = -xv[u];
-        T.step_p[rho] = step_v;
-        T.delta_p[rho] = sc[u] * step_v;
-        gd = fma(gf[u], step_v, gd);
-        dd = fma(d2[u] * step_v, step_v, dd);
-      }
+  for (int u = 0; u < kSbOut; ++u) {
+    const int rho = tid + u * nthr;
+    if (rho < n_own) {
+      const int nat = J.reversed ? np - 1 - rho : rho;
+      const double step_v = -xout[rho];
+      T.xsol[nat] = -step_v;
+      T.step_p[nat] = step_v;
+      T.delta_p[nat] = o_sc[u] * step_v;
+      gd = fma(o_gf[u], step_v, gd);
+      dd = fma(o_d2[u] * step_v, step_v, dd);
     }
   }
-  for (int b = tid; b < T.nb; b += nthr) {  // border unknowns of a bordered system (bias points, gravity)
-    const double step_v = -T.xb[b];
-    T.delta_b[b] = T.scale_b[b] * step_v;
-    gd = fma(T.gb_s[b], step_v, gd);
-    dd = fma(T.D2b[b] * step_v, step_v, dd);
+  for (int rho = tid + kSbOut * nthr; rho < n_own; rho += nthr) {  // (windows beyond kSbOut * 256 scalar rows per end)
+    const int nat = J.reversed ? np - 1 - rho : rho;
+    const double step_v = -xout[rho];
+    T.xsol[nat] = -step_v;
+    T.step_p[nat] = step_v;
+    T.delta_p[nat] = T.scale_p[nat] * step_v;
+    gd = fma(T.g_full[nat], step_v, gd);
+    dd = fma(T.D2p[nat] * step_v, step_v, dd);
   }
+  if (job == 0)
+    for (int b = tid; b < T.nb; b += nthr) {  // border unknowns of a bordered system (bias points, gravity)
+      const double step_v = -T.xb[b];
+      T.delta_b[b] = T.scale_b[b] * step_v;
+      gd = fma(T.gb_s[b], step_v, gd);
+      dd = fma(T.D2b[b] * step_v, step_v, dd);
+    }
   gd = block_sum(gd, red);
   dd = block_sum(dd, red);
   if (tid == 0) {
-    st->g_dot_step_pose = gd;
-    st->d2_step2_pose = dd;
+    if (job == 0)
+      st->g_dot_step_pose = gd, st->d2_step2_pose = dd;
+    else
+      st->g_dot_step_far = gd, st->d2_step2_far = dd;
   }
   if (cprof) clog[7] = wall_clock64();  // step outputs written (the block that finished last)
 }

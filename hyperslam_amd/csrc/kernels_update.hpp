@@ -253,7 +253,7 @@ HSD void decide_step(const Tables& T) {
   const double cand = D[0], xs = D[1], ss = D[2];
   // model_cost_change = -g.step/2 + step'D^2 step/2 (exact for the solved system; TrustRegionMinimizer evaluates
   // -(J step).(r + J step/2), identical algebraically)
-  const double g_step = st->g_dot_step_pose + D[3], d_step = st->d2_step2_pose + D[4];
+  const double g_step = (st->g_dot_step_pose + st->g_dot_step_far) + D[3], d_step = (st->d2_step2_pose + st->d2_step2_far) + D[4];
   const double mcc = -0.5 * g_step + 0.5 * d_step;
   st->model_cost_change = mcc;
   st->scaling_ready = 1;  // a step was computed: the Jacobi scaling of this solve is fixed from here on

@@ -43,6 +43,7 @@ struct DevState {
   double x_sqnorm, step_sqnorm;
   // reduction scratch for the model cost change (scaled coordinates)
   double g_dot_step_pose, d2_step2_pose;
+  double g_dot_step_far, d2_step2_far;  // the far end's share of the two sums (two-ended super-block sweep: each end reduces its own rows); 0 on every other path
   int iteration;          // index of the LM iteration being executed (1-based; 0 = initial evaluation)
   int done;               // 1 once a termination criterion fired: all later kernels early-exit
   int termination;

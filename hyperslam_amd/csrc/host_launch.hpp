@@ -342,7 +342,8 @@ int launch_factor(hs_problem* p) {
 #endif
         // super-blocks of four block rows; the inverses of the diagonal super-blocks come from extra workgroups of the launch
         k_band_backward_sb<<<2 + (m + w_mid + kSb - 1) / kSb + (mB + kSb - 1) / kSb, kCholThreads,
-                             std::max((2 * size_t(T.np) + 32) * sizeof(double) + g_lds, size_t(3 * kSbN * (kSbN + 1)) * sizeof(double)), s>>>(T3, j0, j1, m, 2, 0);
+                             std::max((2 * size_t(T.np) + 32) * sizeof(double) + g_lds + sb_phase_a_doubles(T.bw) * sizeof(double),
+                                      size_t(3 * kSbN * (kSbN + 1)) * sizeof(double)), s>>>(T3, j0, j1, m, 2, 0);
     } else {
 #if HS_PROFILE_HOOKS
       launch_backward_w(T3, j0, j1, m, 2, s);

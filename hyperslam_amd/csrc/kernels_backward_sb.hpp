@@ -29,6 +29,9 @@ constexpr int kSbOut = 2;        // step-output operands a lane keeps from the s
 constexpr int kSbMaxBlocks = 512; // super-blocks per job the flag table has room for (n_cp <= 1024 control points)
 
 HSD int sb_count(int n_rows) { return (n_rows + kSb - 1) / kSb; }
+/// LDS of the far sweep's phase A (the near factor's top super-blocks solved again, k_band_backward_sb): pending rows + solution of at most
+/// kSbPrefetch super-blocks and the 6 (bw - 1) rows above them, + the zero tail a partial last super-block reads, + alignment.
+__host__ __device__ inline size_t sb_phase_a_doubles(int bw) { return size_t(2) * (kSbN * kSbPrefetch + 6 * (bw - 1)) + kSbN + 8; }
 
 /// Entry (rho, col) of a factor in band storage (row rho holds columns 6 floor(rho / 6) .. + 6 bw - 1), zero outside the band / matrix.
 HSD double band_entry(const double* __restrict__ Ub, int ncb, int n_own, int rho, int col) {
@@ -169,6 +172,19 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward_sb(Tables T, Bac
   const bool merged = J.given > 0;  // (the two-ended launch always has 6 given = n_above <= n_own)
   const int ldg = n_above | 1;
   for (int rho = tid; rho < n_own; rho += nthr) xs[rho] = J.ybuf[rho];
+  // Two-ended: the far sweep needs the solution of the middle rows, which are the top rows of the NEAR factor. It does not wait for the near
+  // sweep to publish them (flag + release / acquire + a round of loads: ~3 us on its chain) — it solves the near factor's top super-blocks
+  // itself first, the same steps on the same operands as block 0 (phase A: at most kSbPrefetch super-steps), in arrays of its own.
+  const int nA_own = 6 * j0.n_rows, sA_top = sb_count(j0.n_rows) - 1, sA_pub = m_mid >= 0 ? m_mid / kSb : 0;
+  const bool redo_mid = n_jobs == 2 && m_mid >= 0 && sA_top - sA_pub + 1 <= kSbPrefetch;
+  const bool phase_a = redo_mid && job == 1;
+  const int baseA = max(0, kSbN * sA_pub - n_above);  // first row phase A touches
+  double* xsA = G + n_above * ldg + 2;                // nA_own - baseA (+ 24 zeros: partial last super-block), indexed from baseA
+  double* xoutA = xsA + (nA_own - baseA) + kSbN;      // nA_own - baseA
+  if (phase_a) {
+    for (int rho = baseA + tid; rho < nA_own; rho += nthr) xsA[rho - baseA] = j0.ybuf[rho];
+    if (tid < kSbN) xsA[nA_own - baseA + tid] = 0.0;
+  }
   // operands of the step outputs at the end of a two-ended sweep (the rows this block solves), requested now
   double o_sc[kSbOut], o_gf[kSbOut], o_d2[kSbOut];
 #pragma unroll
@@ -183,16 +199,17 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward_sb(Tables T, Bac
   if (tid < kSbN && J.given == 0) smem[n_all + tid] = 0.0;  // a partial last super-block reads 24 entries from its first row on
   if (merged) {
     const int n_g = n_above * n_above;
-    for (int e0 = tid; e0 < n_g; e0 += 8 * nthr) {
-      double v[8];
+    constexpr int GU = 16;  // (loads in flight per lane: the far sweep's staging is on the chain since it no longer waits for the near one)
+    for (int e0 = tid; e0 < n_g; e0 += GU * nthr) {
+      double v[GU];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < GU; ++u) {
         const int e = e0 + u * nthr, r = e / n_above, c = e - r * n_above;
         const int rho = n_own - n_above + r, off = n_own + c - 6 * (rho / 6);  // band offset of column n_own + c in row rho
         v[u] = (e < n_g && off < ncb) ? J.Ub[size_t(rho) * ncb + off] : 0.0;
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < GU; ++u) {
         const int e = e0 + u * nthr, r = e / n_above, c = e - r * n_above;
         if (e < n_g) G[c * ldg + r] = v[u];
       }
@@ -209,7 +226,7 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward_sb(Tables T, Bac
   const int n_sb = sb_count(J.n_rows);
   const unsigned* flags = T.join_flag + kSbFlagBase + kSbMaxBlocks * job;
   double ring[kSbPrefetch][12];  // operands of the next kSbPrefetch steps, oldest first (register renaming by full unrolling below)
-  auto request = [&](int s, double* dst) {
+  auto request_of = [&](const double* Ub_, const double* Vb_, int n_own_, int s, double* dst) {
     if (s < 0) {
 #pragma unroll
       for (int c = 0; c < 12; ++c) dst[c] = 0.0;
@@ -219,7 +236,7 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward_sb(Tables T, Bac
     if (solver) {
       const bool ok = p_row < kSbN;
       // (16-byte loads: rows of Winv are 192 bytes, rows of the band 8 * 6 bw bytes and every offset below is even)
-      const double2* src = reinterpret_cast<const double2*>(J.Vb + size_t(s) * (kSbN * kSbN) + (ok ? p_row : 0) * kSbN + 12 * q);
+      const double2* src = reinterpret_cast<const double2*>(Vb_ + size_t(s) * (kSbN * kSbN) + (ok ? p_row : 0) * kSbN + 12 * q);
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
         const double2 t = ok ? src[c] : make_double2(0.0, 0.0);
@@ -229,44 +246,42 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward_sb(Tables T, Bac
       const int rho = r0 - 1 - p_row;
       const bool ok = p_row < n_above && rho >= 0;
       const int base = r0 + 12 * q - 6 * ((ok ? rho : 0) / 6);  // band offset of the first of the 12 columns (even)
-      const double* src = J.Ub + size_t(ok ? rho : 0) * ncb;
+      const double* src = Ub_ + size_t(ok ? rho : 0) * ncb;
 #pragma unroll
       for (int c = 0; c < 12; c += 2) {
         const int off = base + c;
-        const double2 t = (ok && off < ncb && r0 + 12 * q + c < n_own) ? *reinterpret_cast<const double2*>(src + off) : make_double2(0.0, 0.0);
+        const double2 t = (ok && off < ncb && r0 + 12 * q + c < n_own_) ? *reinterpret_cast<const double2*>(src + off) : make_double2(0.0, 0.0);
         dst[c] = t.x, dst[c + 1] = t.y;
       }
     }
   };
+  auto request = [&](int s, double* dst) { request_of(J.Ub, J.Vb, n_own, s, dst); };
   // The solver wave needs the inverses in memory before it requests them. All builders run concurrently and finish within a few
   // microseconds of the launch, so the wave waits for ALL of its job's flags once, lane i polling flag i (an agent-scope acquire load
   // costs ~1 us: one per step on the chain doubled the step, five in a row delayed the first step by 8 us).
   auto request_checked = [&](int s, double* dst) { request(s, dst); };
   if (solver) {
     for (int i = l; i < n_sb; i += 64) sb_wait(T, flags + i);
+    if (phase_a && l <= sA_top - sA_pub) sb_wait(T, T.join_flag + kSbFlagBase + sA_pub + l);  // the near job's top super-blocks
     __threadfence();
   }
   const int s_top = n_sb - 1;
+  double ringA[kSbPrefetch][12];  // phase A: operands of the near factor's top super-blocks, all requested at once
+  if (phase_a) {
+#pragma unroll
+    for (int d = 0; d < kSbPrefetch; ++d) request_of(j0.Ub, j0.Vb, nA_own, sA_top - d >= sA_pub ? sA_top - d : -1, ringA[d]);
+  }
 #pragma unroll
   for (int d = 0; d < kSbPrefetch; ++d) request_checked(s_top - d, ring[d]);
   if (cprof) clog[1] = wall_clock64();  // operands staged
-  if (J.given) {  // wait for the middle solution
+  if (J.given && !phase_a) {  // wait for the middle solution
     wait_for_partner(T);
     if (cprof) clog[2] = wall_clock64();  // middle solution arrived
     for (int rho = n_own + tid; rho < n_all; rho += nthr) xs[rho] = T.xsol[J.reversed ? np - 1 - rho : rho];
   }
   __syncthreads();
-  if (merged) {
-    if (tid < n_above) {
-      double acc = 0.0;
-      for (int c = 0; c < n_above; ++c) acc = fma(G[c * ldg + tid], xs[n_own + c], acc);
-      xs[n_own - n_above + tid] -= acc;
-    }
-    __syncthreads();
-  }
-  if (cprof) clog[3] = wall_clock64();  // sweep starts
   // one super-step; `slot` is the ring entry that holds its operands (compile-time after unrolling)
-  auto step = [&](int s, double* op) {
+  auto step_of = [&](double* xs, double* xout, int n_own, int rho_lo, int s, double* op) {  // (rows below rho_lo are not kept: phase A)
     const int r0 = kSbN * s;
     if (solver) {
       // x_J[r] = sum_c Winv[r][c] y[c]
@@ -294,13 +309,32 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward_sb(Tables T, Bac
         acc1 = fma(op[c + 1], x.y, acc1);
       }
       acc = pair_sum(acc + acc1);
-      if (q == 0 && p_row < n_above && rho >= 0) xs[rho] -= acc;
+      if (q == 0 && p_row < n_above && rho >= rho_lo) xs[rho] -= acc;
     }
     lds_barrier();
   };
+  auto step = [&](int s, double* op) { step_of(xs, xout, n_own, 0, s, op); };
+  if (phase_a) {  // the middle rows, solved here as block 0 solves them; then they are the given part of this sweep
+#pragma unroll
+    for (int d = 0; d < kSbPrefetch; ++d)
+      if (sA_top - d >= sA_pub) step_of(xsA - baseA, xoutA - baseA, nA_own, baseA, sA_top - d, ringA[d]);
+    for (int rho = n_own + tid; rho < n_all; rho += nthr) xs[rho] = xoutA[(np - 1 - rho) - baseA];
+    __syncthreads();
+    if (cprof) clog[2] = wall_clock64();  // middle solution ready
+  }
+  if (merged) {  // row r = tid / 2, the lane pair takes the even / odd columns (fixed order: even sum + odd sum)
+    const int r = tid >> 1;
+    double acc = 0.0;
+    if (r < n_above)
+      for (int c = tid & 1; c < n_above; c += 2) acc = fma(G[c * ldg + r], xs[n_own + c], acc);
+    acc = pair_sum(acc);
+    if ((tid & 1) == 0 && r < n_above) xs[n_own - n_above + r] -= acc;
+    __syncthreads();
+  }
+  if (cprof) clog[3] = wall_clock64();  // sweep starts
   const int s_pub = (job == 0 && m_mid >= 0) ? m_mid / kSb : 0;  // block 0 publishes the middle solution once block row m_mid is solved
   int s = s_top;
-  bool published = !(job == 0 && m_mid >= 0);
+  bool published = !(job == 0 && m_mid >= 0) || redo_mid;  // (redo_mid: block 1 solves the middle rows itself)
   const int s_lo = n_jobs == 1 ? j_lo / kSb : 0;
   while (s >= s_lo) {
 #pragma unroll

@@ -41,7 +41,7 @@ for job in (0, 1):
 for blk in (0, 1):
     c = buf[8 * (230 + 10 * blk): 8 * (230 + 10 * blk) + 8]
     b = buf[8 * 230]
-    print("backward block", blk, "[10 ns after block 0's start]: operands staged", c[1] - b, " middle arrived", c[2] - b, " sweep starts", c[3] - b,
+    print("backward block", blk, "[10 ns after block 0's start]: started", c[0] - b, " operands staged", c[1] - b, " middle arrived", c[2] - b, " sweep starts", c[3] - b,
           " middle solved", c[4] - b, " published", c[5] - b, " sweep done", c[6] - b, " outputs", c[7] - b)
 
 c = buf[8 * 260:8 * 260 + 4]; b = buf[8 * 230]

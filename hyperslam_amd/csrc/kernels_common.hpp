@@ -44,6 +44,27 @@ HSD double block_sum(double v, double* lds /* >= blockDim/64 */) {
   return s;
 }
 
+/// N block sums at once (same order of additions as N calls of block_sum, two barriers instead of 2 N). Results valid on thread 0.
+template <int N>
+HSD void block_sum_n(double (&v)[N], double* lds /* >= N * blockDim / 64 */) {
+  const int w = threadIdx.x >> 6, nw = int(blockDim.x >> 6);
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    v[e] = wave_sum(v[e]);
+    if ((threadIdx.x & 63) == 0) lds[e * nw + w] = v[e];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      double s = 0;
+      for (int i = 0; i < nw; ++i) s += lds[e * nw + i];
+      v[e] = s;
+    }
+  }
+  __syncthreads();
+}
+
 /// Per-lane partial sum / max of a strided array with eight independent loads in flight (a plain `s += p[i]` loop keeps one
 /// load in flight per lane and pays the full memory latency per element). Fixed order: bit-reproducible.
 HSD double strided_sum(const double* __restrict__ p, int n, int stride = 1, int offset = 0) {

@@ -496,15 +496,21 @@ __global__ void __launch_bounds__(kBlock) k_gram_pair(Tables T, int batch, int n
     seg_gram_body<K>(T, blockIdx.x - n_group);
 }
 
-constexpr int kAsmThreads = 512, kAsmU = 8;  // lanes per scalar row, loads in flight per lane
+constexpr int kAsmThreads = 512, kAsmU = 6;  // lanes per scalar row, loads in flight per lane (6, and at most 80 VGPRs: six waves per SIMD = three workgroups per CU —
+                                              // at 97 VGPRs a CU held two, and the 768 workgroups of a 128-control-point window ran in two rounds: 13.7 us)
 
 /// Scalar row rho = 6 i + a of the raw (unscaled, undamped) reduced system from the segment and group partials; writes xbuf
 /// directly. Grid (n_cp, 6). The sources of an entry are dealt round-robin to `nsl` thread slices (loads of a slice are
 /// issued kAsmU at a time), the slices are combined through LDS in index order: fixed summation order, bit-reproducible.
 template <int K>
-__global__ void __launch_bounds__(kAsmThreads) k_assemble(Tables T) {
+__global__ void __launch_bounds__(kAsmThreads, 6) k_assemble(Tables T) {  // (see kAsmThreads)
   __shared__ double part[3][kAsmThreads];
+  // phase timestamps (profiling builds, HS_DEBUG_FLAGS 64; tools/assemble_phase_timing.py): lane 0 of every workgroup
+  const bool aprof = prof_enabled(T.debug_flags, 64) && threadIdx.x == 0;
+  long long* alog = reinterpret_cast<long long*>(T.xpart) + 128 * 1024 + 8 * (blockIdx.y * gridDim.x + blockIdx.x);
+  if (aprof) alog[0] = wall_clock64();
   if (T.st->done) return;
+  if (aprof) alog[1] = wall_clock64();
   constexpr int NCA = 6 * K;
   const int i = blockIdx.x, a = blockIdx.y, tid = threadIdx.x;
   const int bw = T.bw, ncb = 6 * bw, R = 6 * bw, ntile = bw * (bw + 1) / 2;
@@ -539,11 +545,13 @@ __global__ void __launch_bounds__(kAsmThreads) k_assemble(Tables T) {
                            : group_tile_index(i - (cf), i - (cf) + kk, bw) * 36 + 6 * a + cc)] \
        : 0.0)
 #define HS_GRP_EXTRA(q, cf) ((q) < nq ? T.grpQ[(q_lo + (q)) * int(qstride) + ntile * 36 + (c == ncb ? 1 : 2) * R + 6 * (i - (cf)) + a] : 0.0)
+    if (aprof && np_ + nq >= 0) alog[2] = wall_clock64();  // ranges of the work lists here
     int si[kAsmU], gi[2 * kAsmU];
 #pragma unroll
     for (int u = 0; u < kAsmU; ++u) si[u] = sl + u * nsl < np_ ? T.sw_seg[p_lo + sl + u * nsl] : 0;
 #pragma unroll
     for (int u = 0; u < 2 * kAsmU; ++u) gi[u] = sl + u * nsl < nq ? T.gw_cf[q_lo + sl + u * nsl] : 0;
+    if (aprof && si[0] + gi[0] >= 0) alog[3] = wall_clock64();  // work-list entries here
     double sv[kAsmU], gv[2 * kAsmU];
 #pragma unroll
     for (int u = 0; u < kAsmU; ++u) sv[u] = HS_SEG_VALUE(sl + u * nsl, si[u]);
@@ -588,8 +596,10 @@ __global__ void __launch_bounds__(kAsmThreads) k_assemble(Tables T) {
 #undef HS_GRP_VALUE
 #undef HS_GRP_EXTRA
   }
+  if (aprof && va + vb + vp != 1e300) alog[4] = wall_clock64();  // values here
   part[0][tid] = va, part[1][tid] = vb, part[2][tid] = vp;
   __syncthreads();
+  if (aprof) alog[5] = wall_clock64();
   if (tid < nent) {
     double sa = 0.0, sb = 0.0, sx = 0.0;
     for (int q = 0; q < nsl; ++q) sa += part[0][q * nent + tid], sb += part[1][q * nent + tid], sx += part[2][q * nent + tid];
@@ -603,6 +613,7 @@ __global__ void __launch_bounds__(kAsmThreads) k_assemble(Tables T) {
       T.xbuf[T.xo_gs + rho] = sb;
     }
   }
+  if (aprof) alog[6] = wall_clock64();
 }
 
 /// xbuf[e] = sum over the accumulation splits (fixed order => bit-reproducible). The result is additive across residual shards.

@@ -195,14 +195,14 @@ HSD void begin_iteration(const Tables& T, double c, double gm, bool set_scaling_
   }
 }
 
-HSD void decide_step(const Tables& T);
+HSD void decide_step(const Tables& T, const double* D_known = nullptr);
 HSD void commit_body(const Tables& T, int idx, int stride);
 HSD void commit_control_points(const Tables& T, int idx, int stride);
 
 /// Second exchange buffer (5 doubles, additive across shards): candidate cost, |x|^2, |x - x+|^2 and the landmark-side
 /// terms of the model cost change. The replicated control-point part of the norms is contributed by rank 0 only.
 __global__ void __launch_bounds__(kBlock) k_pack_decision(Tables T, int decide_here /* no exchange between packing and deciding */) {
-  __shared__ double red[kBlock / 64];
+  __shared__ double red[5 * (kBlock / 64)];
   DevState* st = T.st;
   if (st->done) return;
   // The partial arrays are short (one entry per workgroup of the producing kernels): one combined pass with every load of a round
@@ -229,12 +229,14 @@ __global__ void __launch_bounds__(kBlock) k_pack_decision(Tables T, int decide_h
       xs += nr[u].x, ss += nr[u].y;
     }
   }
-  cand = block_sum(cand, red), xs = block_sum(xs, red), ss = block_sum(ss, red), gd = block_sum(gd, red), dd = block_sum(dd, red);
+  double v5[5] = {cand, xs, ss, gd, dd};
+  block_sum_n<5>(v5, red);  // (one pair of barriers for the five sums; the decision takes them from registers, not back from memory)
   if (threadIdx.x == 0) {
     double* D = T.xbuf + T.xo_dec;
-    D[0] = cand, D[1] = xs, D[2] = ss, D[3] = gd, D[4] = dd;
-    st->local_cand = cand;  // this shard's part (the exchange sums D over the shards)
-    if (decide_here) decide_step(T);
+#pragma unroll
+    for (int e = 0; e < 5; ++e) D[e] = v5[e];
+    st->local_cand = v5[0];  // this shard's part (the exchange sums D over the shards)
+    if (decide_here) decide_step(T, v5);
   }
   if (decide_here >= 2) {  // 2, small problems: x <- candidate right here instead of a k_commit launch behind this one;
                            // 3, fused path with deferred landmarks: the control points only (k_build_visual / k_update_visual read T.cp)
@@ -247,9 +249,9 @@ __global__ void __launch_bounds__(kBlock) k_pack_decision(Tables T, int decide_h
 }
 
 /// Trust-region decision of one LM iteration (single lane): step quality, acceptance, radius update, termination tests.
-HSD void decide_step(const Tables& T) {
+HSD void decide_step(const Tables& T, const double* D_known) {
   DevState* st = T.st;
-  const double* D = T.xbuf + T.xo_dec;
+  const double* D = D_known ? D_known : T.xbuf + T.xo_dec;  // (after an exchange: the summed terms from the buffer)
   const double cand = D[0], xs = D[1], ss = D[2];
   // model_cost_change = -g.step/2 + step'D^2 step/2 (exact for the solved system; TrustRegionMinimizer evaluates
   // -(J step).(r + J step/2), identical algebraically)

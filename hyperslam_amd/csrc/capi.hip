@@ -29,6 +29,10 @@ int hs_create(int device, void* stream, hs_problem** out) {
     delete p;
     return HS_ERR_DEVICE;
   }
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) p->n_cu = cus;
+  }
   if (stream) {
     p->stream = static_cast<hipStream_t>(stream);
   } else {

@@ -225,16 +225,55 @@ inline bool build_chunks(const VisualStructure& vs, int n_cp, int R, int L, std:
   (*gw_ptr)[n_cp] = int(gw_cf->size());
   ch_ptr->push_back(n_obs);
   gw_cf->push_back(0);
-  if (ch_desc) {  // [first landmark, landmarks, first control point, first residual, residuals, 0, 0, 0] per chunk
+  if (ch_desc) {  // [first landmark, landmarks, first control point, first residual, residuals, chunk id (= slot of its partial), 0, 0] per chunk
     const int n = int(ch_ptr->size()) - 1;
     ch_desc->assign(size_t(8) * std::max(n, 1), 0);
     for (int w = 0; w < n; ++w) {
       const int lo = (*ch_ptr)[w], hi = (*ch_ptr)[w + 1];
       int* d = ch_desc->data() + 8 * w;
-      d[0] = lo, d[1] = hi - lo, d[2] = vs.lm_cfirst[lo], d[3] = vs.lm_ptr[lo], d[4] = vs.lm_ptr[hi] - vs.lm_ptr[lo];
+      d[0] = lo, d[1] = hi - lo, d[2] = vs.lm_cfirst[lo], d[3] = vs.lm_ptr[lo], d[4] = vs.lm_ptr[hi] - vs.lm_ptr[lo], d[5] = w;
     }
   }
   return true;
+}
+
+/// Order in which the chunks are handed to the workgroups of k_build_visual / k_update_visual (descriptor w = the chunk workgroup w works on;
+/// a chunk's partial stays in the slot of its id, so k_assemble is not concerned). The kernels keep two workgroups per CU, and the hardware
+/// places workgroup w on CU w mod n_cu: with n_cu < n <= 2 n_cu chunks the workgroups n - n_cu .. n_cu - 1 have a CU to themselves (20 us
+/// per chunk instead of ~29) and w shares its CU with w + n_cu (measured: tools/build_phase_timing.py). A chunk whose records crowd into few
+/// segments — landmarks first seen near the end of the window — takes up to 40 % longer than the median one, and the slowest chunk is the
+/// kernel time: the heaviest chunks get the CUs of their own, the rest are paired heaviest with lightest. More than two rounds: heaviest first.
+/// Weight of a chunk = most records in k consecutive segments (what the longest lane of its J'J and W phases walks).
+inline void order_chunks_for_dispatch(const VisualStructure& vs, int k, int n_cu, std::vector<int>* ch_desc, int n) {
+  if (n <= 1 || n_cu <= 0) return;
+  std::vector<int> weight(n), order(n);
+  std::vector<int> cnt;
+  for (int c = 0; c < n; ++c) {
+    const int* d = ch_desc->data() + 8 * c;
+    cnt.assign(size_t(vs.bw) + k + 1, 0);
+    for (int q = d[3]; q < d[3] + d[4]; ++q) {
+      const int o = vs.first[q] - d[2];
+      if (o >= 0 && o < vs.bw) cnt[o]++;
+    }
+    int run = 0, best = 0;
+    for (int o = 0; o < vs.bw + k; ++o) {
+      run += (o < vs.bw ? cnt[o] : 0) - (o >= k ? cnt[o - k] : 0);
+      best = std::max(best, run);
+    }
+    weight[c] = best, order[c] = c;
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return weight[a] > weight[b]; });
+  std::vector<int> slot_chunk(n, -1);
+  if (n > n_cu && n <= 2 * n_cu) {
+    const int n_lone = 2 * n_cu - n, n_pair = n - n_cu;
+    for (int i = 0; i < n_lone; ++i) slot_chunk[n_pair + i] = order[i];                 // workgroups n - n_cu .. n_cu - 1: alone on their CU
+    for (int i = 0; i < n_pair; ++i) slot_chunk[i] = order[n_lone + i], slot_chunk[n_cu + i] = order[n - 1 - i];  // heavy w, light w + n_cu
+  } else {
+    for (int i = 0; i < n; ++i) slot_chunk[i] = order[i];
+  }
+  std::vector<int> out(ch_desc->size(), 0);
+  for (int w = 0; w < n; ++w) std::copy(ch_desc->begin() + 8 * slot_chunk[w], ch_desc->begin() + 8 * slot_chunk[w] + 8, out.begin() + 8 * w);
+  ch_desc->swap(out);
 }
 
 /// Chunk geometry of the fused build: records (= lanes) per chunk R and landmarks per chunk L such that TWO workgroups share a CU

@@ -144,6 +144,7 @@ hipError_t UploadBatch::flush(hipStream_t s) {
 
 struct hs_problem {
   int device = 0;
+  int n_cu = 256;  // compute units of the device (hs_create): the fused build orders its chunks by how the hardware places workgroups on them
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::string err;
@@ -452,6 +453,8 @@ int prepare(hs_problem* p) {
     p->fused = choose_build_geometry(k, R0, L0, size_t(overridden ? 156 : 79) * 1024, size_t(156) * 1024, lds_bytes, &p->build_R, &p->build_L) &&
                build_chunks(vs, p->n_cp, p->build_R, p->build_L, &p->h_ch_ptr, &p->h_gw_ptr, &p->h_gw_cf, &p->h_ch_desc);
     p->build_lds = p->fused ? lds_bytes(p->build_R, p->build_L) : 0;
+    if (p->fused && !std::getenv("HS_BUILD_ORDER"))  // (HS_BUILD_ORDER=table: chunks in table order, measurement switch)
+      order_chunks_for_dispatch(vs, k, p->n_cu, &p->h_ch_desc, int(p->h_ch_ptr.size()) - 1);
   }
   if (!p->fused) {
     HIP_TRY(p->d_v_rec.reserve(size_t(n_vis) * (8 + 12 * k) + 1));
@@ -662,6 +665,7 @@ int prepare(hs_problem* p) {
   T.Zb = p->d_Zb.p, T.Cb = p->d_Cb.p, T.hb = p->d_hb.p, T.xb = p->d_xb.p, T.delta_b = p->d_delta_b.p, T.i_bias_ptr = p->d_i_bias_ptr.p, T.bfwd_start = p->d_bfwd_start.p;
   T.x_count1 = x_count1, T.xo_dec = x_count1;
   T.fused = p->fused ? 1 : 0, T.n_chunk = p->fused ? p->n_group_wg : 0, T.ch_ptr = p->d_ch_ptr.p, T.ch_desc = p->d_ch_desc.p;
+  T.build_stream_lg = p->fused ? build_streams_packed(vs.bw, k) : 0;
   T.rank = p->rank, T.world = p->world;
   // HS_DEBUG_FLAGS (measurement switches only, never needed for correct operation):
   //    1 skip the backward sweep          2 skip the rank-6 updates (timing of the panel chain alone; results are garbage)

@@ -37,8 +37,48 @@ constexpr int build_rec_stride() { return compact_record<K>() + 2; }  // LDS rec
 /// Band tiles of the chunk window that J_p'J_p touches: (rb, d = cb - rb), d < K, rb + d < bw; index = tiles of smaller d first.
 __host__ __device__ inline int band_tile_count(int bw, int k) { return k * bw - k * (k - 1) / 2; }
 HSD int band_tile_index(int rb, int d, int bw) { return d * bw - d * (d - 1) / 2 + rb; }
-/// Record streams per band tile (adjacent lanes, combined by butterflies).
-__host__ __device__ inline int build_streams(int n_tiles) { return 4 * n_tiles <= kBlock ? 4 : (2 * n_tiles <= kBlock ? 2 : 1); }
+/// Record streams per band tile, by diagonal offset d (adjacent lanes of one wave, combined by butterflies). A tile of offset d sees the
+/// records of K - d segments, so the diagonals get streams in proportion: greedy doubling of the most loaded diagonal (load (K - d) / ns[d])
+/// while the lanes last, at most 8 streams, never more than the diagonal before it (so that groups stay aligned to their size when the
+/// diagonals are laid out one after the other). K = 4, bw = 14: {8, 4, 4, 2} = 234 lanes, 5.5 - 8.3 records per lane where four streams for
+/// every tile gave 2.8 - 11 — and the longest lane sets the phase.
+struct BuildStreams {
+  int ns[hsd::kMaxOrder], off[hsd::kMaxOrder + 1];  // streams per tile / first lane of diagonal d
+};
+__host__ __device__ inline BuildStreams build_streams(int bw, int k) {
+  BuildStreams b;
+  for (int d = 0; d < hsd::kMaxOrder; ++d) b.ns[d] = d < k ? 1 : 0;
+  int used = band_tile_count(bw, k);
+  bool stuck[hsd::kMaxOrder] = {false, false, false, false, false, false, false, false};
+  for (;;) {
+    int best = -1;
+    for (int d = 0; d < k; ++d)  // most loaded diagonal that may still grow: compare (k - d) / ns[d] as cross products
+      if (!stuck[d] && (best < 0 || (k - d) * b.ns[best] > (k - best) * b.ns[d])) best = d;
+    if (best < 0) break;
+    const bool fits = used + (bw - best) * b.ns[best] <= kBlock && 2 * b.ns[best] <= 8 && (best == 0 || 2 * b.ns[best] <= b.ns[best - 1]);
+    if (!fits) {
+      // the most loaded diagonal cannot grow any more: growing others would not shorten the phase
+      bool any_heavier = false;
+      for (int d = 0; d < k; ++d) any_heavier |= !stuck[d] && d != best && (k - d) * b.ns[best] >= (k - best) * b.ns[d];
+      stuck[best] = true;
+      if (!any_heavier) break;
+      continue;
+    }
+    used += (bw - best) * b.ns[best];
+    b.ns[best] *= 2;
+  }
+  b.off[0] = 0;
+  for (int d = 0; d < hsd::kMaxOrder; ++d) b.off[d + 1] = b.off[d] + (d < k ? (bw - d) * b.ns[d] : 0);
+  return b;
+}
+/// log2 of the stream counts, two bits per diagonal: what the kernel takes (Tables::build_stream_lg; computed by the host — as a table built
+/// inside the kernel it lived in scratch memory, and the dependent scratch accesses of the loop above cost 7 us per workgroup)
+inline int build_streams_packed(int bw, int k) {
+  const BuildStreams b = build_streams(bw, k);
+  int packed = 0;
+  for (int d = 0; d < k; ++d) packed |= (b.ns[d] == 8 ? 3 : b.ns[d] == 4 ? 2 : b.ns[d] == 2 ? 1 : 0) << (2 * d);
+  return packed;
+}
 
 constexpr int kLinv = 14;  // per landmark: 1/l00 l10 1/l11 l20 l21 1/l22 | s_l (3) | free flag | y-hat (3) | pad
 constexpr int kBuildCams = 4;  // cameras staged in LDS (a residual of a later camera reads the table in HBM)
@@ -136,7 +176,9 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
   DevState* st = T.st;
   // the chunk descriptor and the solver state are requested together (the descriptor table is padded to the grid: always in bounds)
   const int4 d0 = *reinterpret_cast<const int4*>(T.ch_desc + 8 * w);
-  const int nres = T.ch_desc[8 * w + 4];  // <= R (host: build_chunks)
+  const int4 d1 = *reinterpret_cast<const int4*>(T.ch_desc + 8 * w + 4);
+  const int nres = d1.x;      // <= R (host: build_chunks)
+  const int chunk_id = d1.y;  // slot of this chunk's partial (the descriptors are in dispatch order: order_chunks_for_dispatch)
   const int st_done = st->done, st_spec = st->spec, st_accepted = st->accepted, st_ready = st->scaling_ready;
   const double radius = st->radius;
   if (st_done) return;
@@ -332,12 +374,17 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
   HS_BSTAMP(5);
   // ---- 3: J_p'J_p band tiles: lane group g = tid / NS serves tile (g mod 16) * 4 + g / 16 (NS = 4: every wave gets tiles of every
   //         diagonal offset — the diagonal tiles see K segments, the outermost one), stream = tid mod NS ----
-  const int NS = build_streams(nband);
-  const int p_g = tid / NS, p_s = tid - p_g * NS;
-  const int p_tb = NS == 4 ? (p_g & 15) * 4 + (p_g >> 4) : p_g;
-  const bool p_lane = p_tb < nband;
-  int p_d = 0, p_rb = p_lane ? p_tb : 0;
-  while (p_rb >= bw - p_d) p_rb -= bw - p_d, ++p_d;  // tiles of offset d: bw - d
+  int p_d = 0, p_off = 0, ns_lg = 0, p_end = 0;  // diagonal of this lane's tile, first lane of that diagonal, log2 of its stream count
+#pragma unroll
+  for (int d = 0; d < K; ++d) {  // (no tables: registers only)
+    const int lg = (T.build_stream_lg >> (2 * d)) & 3, next = p_end + ((bw - d) << lg);
+    if (tid >= p_end && tid < next) p_d = d, p_off = p_end, ns_lg = lg;
+    p_end = next;
+  }
+  const bool p_lane = tid < p_end;
+  const int NS = 1 << ns_lg, ns0 = 1 << (T.build_stream_lg & 3);  // (ns0: the widest groups, diagonal 0)
+  const int p_rb = p_lane ? (tid - p_off) >> ns_lg : 0, p_s = (tid - p_off) & (NS - 1);
+  const int p_tb = band_tile_index(p_rb, p_d, bw);
   double pacc[36], pg[6];
 #pragma unroll
   for (int e = 0; e < 36; ++e) pacc[e] = 0.0;
@@ -354,13 +401,13 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
       const bool ok = o >= 0 && o >= p_rb + p_d - K + 1;
       const int a0 = seg_start[ok ? o : 0], a1 = seg_start[(ok ? o : 0) + 1];
       run_lo[x] = a0 + p_s;
-      total += ok && a1 > a0 + p_s ? (a1 - a0 - p_s + NS - 1) / NS : 0, cum[x] = total;
+      total += ok && a1 > a0 + p_s ? (a1 - a0 - p_s + NS - 1) >> ns_lg : 0, cum[x] = total;
     }
     const int a_base = p_rb - o_hi;
 #define HS_T_LOAD(h_, dst)                                                   \
   {                                                                          \
-    int x_ = 0, s_ = run_lo[0] + NS * (h_);                                  \
-    _Pragma("unroll") for (int x = 1; x < K; ++x) if ((h_) >= cum[x - 1]) x_ = x, s_ = run_lo[x] + NS * ((h_)-cum[x - 1]); \
+    int x_ = 0, s_ = run_lo[0] + ((h_) << ns_lg);                            \
+    _Pragma("unroll") for (int x = 1; x < K; ++x) if ((h_) >= cum[x - 1]) x_ = x, s_ = run_lo[x] + (((h_)-cum[x - 1]) << ns_lg); \
     dst = tile_ops_load(recs + s_ * CS, a_base + x_, a_base + x_ + p_d);     \
   }
     TileOps opa, opb;  // two operand sets alternate (no copies): record h + 1 is in flight during the products of record h
@@ -375,12 +422,44 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
     }
 #undef HS_T_LOAD
   }
-  // the streams of a tile are adjacent lanes: butterfly sums, (s0 + s1) + (s2 + s3) on every lane of the group
-  for (int m = 1; m < NS; m <<= 1) {
+  // the streams of a tile are adjacent lanes: butterfly sums, ((s0 + s1) + (s2 + s3)) + ... on every lane of the group; the groups of a wave
+  // have different sizes, so a level is exchanged by every lane and added by the lanes whose group reaches that far
+  {
+    const bool t1 = NS > 1, t2 = NS > 2, t4 = NS > 4;
 #pragma unroll
-    for (int e = 0; e < 36; ++e) pacc[e] += __shfl_xor(pacc[e], m);
+    for (int e = 0; e < 36; ++e) {
+      const double o = lane_xor1(pacc[e]);
+      pacc[e] += t1 ? o : 0.0;
+    }
 #pragma unroll
-    for (int e = 0; e < 6; ++e) pg[e] += __shfl_xor(pg[e], m);
+    for (int e = 0; e < 6; ++e) {
+      const double o = lane_xor1(pg[e]);
+      pg[e] += t1 ? o : 0.0;
+    }
+    if (ns0 > 2) {
+#pragma unroll
+      for (int e = 0; e < 36; ++e) {
+        const double o = lane_xor2(pacc[e]);
+        pacc[e] += t2 ? o : 0.0;
+      }
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        const double o = lane_xor2(pg[e]);
+        pg[e] += t2 ? o : 0.0;
+      }
+    }
+    if (ns0 > 4) {
+#pragma unroll
+      for (int e = 0; e < 36; ++e) {
+        const double o = lane_xor4(pacc[e]);
+        pacc[e] += t4 ? o : 0.0;
+      }
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        const double o = lane_xor4(pg[e]);
+        pg[e] += t4 ? o : 0.0;
+      }
+    }
   }
   HS_BSTAMP(6);
   __syncthreads();  // everybody is done with the records: the combined P tiles take their place
@@ -505,13 +584,13 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
   }
   if (QS == 2) {  // stream 0 + stream 1 (adjacent lanes)
 #pragma unroll
-    for (int e = 0; e < 36; ++e) acc[e] += __shfl_xor(acc[e], 1);
+    for (int e = 0; e < 36; ++e) acc[e] += lane_xor1(acc[e]);
 #pragma unroll
-    for (int e = 0; e < 6; ++e) qacc[e] += __shfl_xor(qacc[e], 1);
+    for (int e = 0; e < 6; ++e) qacc[e] += lane_xor1(qacc[e]);
   }
   HS_BSTAMP(10);
   // ---- 6: P + Q and the three vectors of the chunk partial -> HBM ----
-  double* G = T.grpQ + size_t(w) * (size_t(ntile) * 36 + 3 * R6);
+  double* G = T.grpQ + size_t(chunk_id) * (size_t(ntile) * 36 + 3 * R6);
   if (q_s == 0 && q_ok) {
     const int d = q_cb - q_rb;
     if (d < K) {
@@ -547,7 +626,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
     T.cost_part[w] = s;
   }
   HS_BSTAMP(12);
-  if (bprof) blog[13] = nres, blog[14] = nl, blog[15] = (long long)(__builtin_amdgcn_s_getreg(63492)) | ((long long)(__builtin_amdgcn_s_getreg(63508)) << 32);  // HW_ID | XCC_ID
+  if (bprof) blog[13] = nres, blog[14] = nl | (cf << 16), blog[15] = (long long)(__builtin_amdgcn_s_getreg(63492)) | ((long long)(__builtin_amdgcn_s_getreg(63508)) << 32);  // HW_ID | XCC_ID
 #undef HS_BSTAMP
 }
 

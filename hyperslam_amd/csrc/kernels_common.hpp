@@ -21,6 +21,21 @@ HSD bool prof_enabled(int debug_flags, int bit) { return HS_PROFILE_HOOKS && (de
 #define HS_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) double name[]
 #endif
 
+/// The value of lane ^ 1 / ^ 2 / ^ 4 through the DPP cross bar (vector moves; a general __shfl_xor is an LDS permute: ~80 cycles of issue per
+/// 32-bit half where these are 4). xor 4 = row_shl:4 for the lanes with bit 2 clear, row_shr:4 for the others.
+template <int CTRL>
+HSD double dpp_move(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+HSD double lane_xor1(double v) { return dpp_move<0xB1>(v); }  // quad_perm [1 0 3 2]
+HSD double lane_xor2(double v) { return dpp_move<0x4E>(v); }  // quad_perm [2 3 0 1]
+HSD double lane_xor4(double v) {
+  const double up = dpp_move<0x104>(v), down = dpp_move<0x114>(v);
+  return (threadIdx.x & 4) ? down : up;
+}
+
 HSD double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

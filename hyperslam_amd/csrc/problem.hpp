@@ -219,6 +219,7 @@ struct Tables {
   // fused build of the visual factors (kernels_build.hpp): chunk w = device landmarks [ch_ptr[w], ch_ptr[w + 1]) of one landmark group;
   // gw_ptr / gw_cf then list the chunks of a group and grpQ holds one partial [tiles | -Yh yh | J_p'r | diag J_p'J_p] per chunk
   int fused, n_chunk;
+  int build_stream_lg;   // fused build: log2 of the record streams per band tile, two bits per diagonal offset (kernels_build.hpp: build_streams)
   const int* ch_ptr;
   const int* ch_desc;  // n_chunk x 8: first landmark, landmarks, first control point, first residual, residuals (one 32-byte load per workgroup)
   int rank, world;

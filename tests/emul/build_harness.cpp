@@ -113,6 +113,8 @@ int main(int argc, char** argv) {
   }
   std::vector<int> ch_ptr, gw_ptr, gw_cf, ch_desc;
   if (!build_chunks(vs, n_cp, R, L, &ch_ptr, &gw_ptr, &gw_cf, &ch_desc)) return 6;  // a landmark with more than R residuals: record path in the library
+  // the dispatch order of the chunks (a permutation of the descriptors; partial slots by chunk id): "two rounds" rule of a device with 2/3 n CUs
+  order_chunks_for_dispatch(vs, k, std::max(1, 2 * (int(ch_ptr.size()) - 1) / 3), &ch_desc, int(ch_ptr.size()) - 1);
   const int n_chunk = int(ch_ptr.size()) - 1;
 
   // device-order tables (prepare() of capi.hip)
@@ -176,6 +178,7 @@ int main(int argc, char** argv) {
   T.xo_g = np * ncb, T.xo_gs = T.xo_g + np, T.xo_dj = T.xo_gs + np, T.xo_pb = T.xo_dj + np, T.xo_bb = T.xo_pb, T.xo_gb = T.xo_bb, T.xo_cost = T.xo_gb, T.xo_gmax = T.xo_cost + 1;
   T.x_count1 = x_count1, T.xo_dec = x_count1;
   T.fused = 1, T.n_chunk = n_chunk, T.ch_ptr = ch_ptr.data(), T.ch_desc = ch_desc.data();
+  T.build_stream_lg = hs::build_streams_packed(vs.bw, k);
   T.rank = 0, T.world = 1, T.st = &st;
 
   const size_t lds = size_t(build_lds_layout(k, bw, R, L).total_doubles) * 8;

@@ -116,6 +116,20 @@ inline T __shfl_up(T v, unsigned delta) {
   return got;
 }
 inline int __builtin_amdgcn_readlane(int v, int lane) { return hs_emul::wave_exchange(v, lane); }
+/// DPP move as the kernels use it (row_mask = bank_mask = 0xF, bound_ctrl off: a lane whose source is outside its row of 16 keeps `old`):
+/// quad_perm (ctrl < 0x100, two bits per lane of the quad), row_shl:n (0x100 + n: lane i reads lane i + n), row_shr:n (0x110 + n: lane i - n).
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool) {
+  const int lane = threadIdx.x & 63;
+  int from = -1;
+  if (ctrl < 0x100) from = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+  else if (ctrl > 0x100 && ctrl < 0x110) from = ((lane & 15) + (ctrl - 0x100) < 16) ? lane + (ctrl - 0x100) : -1;
+  else if (ctrl > 0x110 && ctrl < 0x120) from = ((lane & 15) - (ctrl - 0x110) >= 0) ? lane - (ctrl - 0x110) : -1;
+  const int got = hs_emul::wave_exchange(src, from < 0 ? lane : from);
+  return from < 0 ? old : got;
+}
+inline int __double2loint(double d) { unsigned long long b; std::memcpy(&b, &d, 8); return int(unsigned(b)); }
+inline int __double2hiint(double d) { unsigned long long b; std::memcpy(&b, &d, 8); return int(unsigned(b >> 32)); }
+inline double __hiloint2double(int hi, int lo) { const unsigned long long b = (static_cast<unsigned long long>(unsigned(hi)) << 32) | unsigned(lo); double d; std::memcpy(&d, &b, 8); return d; }
 inline unsigned long long __ballot(bool pred) {
   hs_emul::Block& b = hs_emul::block();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

@@ -19,7 +19,7 @@ lib.hs_debug_read(p.h, buf.ctypes.data, n)
 t = buf[48 * 1024:].reshape(1024, 4, 16)
 ok = t[:, 0, 0] > 0
 t = t[ok]
-print("chunks stamped:", len(t), " residuals / landmarks per chunk (median, max):", np.median(t[:, 0, 13]), t[:, 0, 13].max(), np.median(t[:, 0, 14]), t[:, 0, 14].max())
+print("chunks stamped:", len(t), " residuals / landmarks per chunk (median, max):", np.median(t[:, 0, 13]), t[:, 0, 13].max(), np.median(t[:, 0, 14] & 0xffff), (t[:, 0, 14] & 0xffff).max())
 names = ["start", "inputs + keys (b)", "sorted, pos (b)", "linearised", "barrier", "H/b, W blocks", "J'J tiles done", "barrier", "Cholesky (b)", "Y-hat (b)",
          "Yh Yh' done", "written", "cost summed"]  # (b): stamp taken behind the phase's barrier
 base = t[:, :, 0].min(axis=1)[:, None, None]
@@ -62,3 +62,21 @@ for k_ in uniq:
         same += int((simd[idx[0]] == simd[idx[1]]).all())
         pat[tuple(simd[idx[0]].tolist() + simd[idx[1]].tolist())] = pat.get(tuple(simd[idx[0]].tolist() + simd[idx[1]].tolist()), 0) + 1
 print("CUs with two chunks:", tot, " wave k of both on the same SIMD:", same, " patterns (wg A waves | wg B waves):", sorted(pat.items(), key=lambda kv: -kv[1])[:6])
+
+# the slowest chunks: first control point, records, landmarks, phase lengths (wave-max) — which phase makes the tail
+dur = (t[:, :, 12].max(axis=1) - t[:, :, 0].min(axis=1)) * 0.01
+ph = (t[:, :, 1:13].max(axis=1) - t[:, :, 0:12].max(axis=1)) * 0.01
+order = np.argsort(-dur)
+print("slowest chunks: duration | cf records landmarks | phase lengths (stamps 1..12)")
+for i in list(order[:8]) + list(order[len(order) // 2: len(order) // 2 + 3]):
+    print(f"  {dur[i]:6.2f} | cf {int(t[i, 0, 14]) >> 16:4d} n {int(t[i, 0, 13]):4d} l {int(t[i, 0, 14]) & 0xffff:3d} |", " ".join(f"{x:5.2f}" for x in ph[i]))
+cfs = t[:, 0, 14] >> 16
+for lo, hi in ((0, 2), (2, 10), (10, 100), (100, 120), (120, 200)):
+    m = (cfs >= lo) & (cfs < hi)
+    if m.any(): print(f"chunks with cf in [{lo}, {hi}): {int(m.sum()):4d}  median duration {np.median(dur[m]):6.2f}  max {dur[m].max():6.2f}")
+# which workgroup indices sit alone on their CU (dispatch order -> placement): the slots for the heaviest chunks
+lone = sorted(int(np.where(key == k_)[0][0]) for k_ in uniq[cnt == 1])
+print("workgroups alone on a CU:", len(lone), " indices", lone[:5], "...", lone[-5:], " contiguous:", lone == list(range(lone[0], lone[0] + len(lone))) if lone else None)
+pairs = [tuple(sorted(np.where(key == k_)[0].tolist())) for k_ in uniq[cnt == 2]]
+d = np.array([b - a for a, b in pairs])
+print("index distance of the two workgroups of a CU: min", d.min(), " median", np.median(d), " max", d.max(), " share == 256:", float((d == 256).mean()))

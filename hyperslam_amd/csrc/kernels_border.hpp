@@ -117,10 +117,18 @@ __global__ void __launch_bounds__(kBlock) k_border_bb(Tables T) {
   const int og = 0, oa = 3 * nbias, ogr = 6 * nbias;
   // records whose bias window covers b: first_bias in [b - kb + 1, b]
   const int p0 = T.i_bias_ptr[max(0, b - kb + 1)], p1 = T.i_bias_ptr[b + 1], pown = T.i_bias_ptr[b];
-  double v[NV];  // [gg(kMaxOrder) | aa(kMaxOrder) | ggr 6 | agr 6 | rg 3 | ra 3 | gravity h00 h01 h11 g0 g1]
+  // [gg(kMaxOrder) | aa(kMaxOrder) | ggr 6 | agr 6 | rg 3 | ra 3 | gravity h00 h01 h11 g0 g1] — separate register arrays: as slices of ONE array
+  // addressed through pointers the 39 sums lived in scratch memory (320 bytes per lane), a load and a store per multiply-add
+  constexpr int KM = hsd::kMaxOrder;
+  double gg[KM], aa[KM], ggr[6], agr[6], rg[3], ra[3], hg[5];
 #pragma unroll
-  for (int e = 0; e < NV; ++e) v[e] = 0.0;
-  double* gg = v, *aa = v + hsd::kMaxOrder, *ggr = v + 2 * hsd::kMaxOrder, *agr = ggr + 6, *rg = agr + 6, *ra = rg + 3, *hg = ra + 3;
+  for (int e = 0; e < KM; ++e) gg[e] = aa[e] = 0.0;
+#pragma unroll
+  for (int e = 0; e < 6; ++e) ggr[e] = agr[e] = 0.0;
+#pragma unroll
+  for (int e = 0; e < 3; ++e) rg[e] = ra[e] = 0.0;
+#pragma unroll
+  for (int e = 0; e < 5; ++e) hg[e] = 0.0;
 #pragma unroll 2
   for (int pos = p0 + tid; pos < p1; pos += kBlock) {
     const double* rec = T.i_rec + size_t(pos) * IREC;
@@ -130,7 +138,7 @@ __global__ void __launch_bounds__(kBlock) k_border_bb(Tables T) {
     const double* jg = wap + kb;
     const double wgb = wgp[j], wab = wap[j];
 #pragma unroll
-    for (int d = 0; d < hsd::kMaxOrder; ++d)
+    for (int d = 0; d < KM; ++d)
       if (d < kb && j + d < kb) gg[d] = fma(wgb, wgp[j + d], gg[d]), aa[d] = fma(wab, wap[j + d], aa[d]);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -146,32 +154,55 @@ __global__ void __launch_bounds__(kBlock) k_border_bb(Tables T) {
       }
     }
   }
-#pragma unroll
-  for (int e = 0; e < NV; ++e) v[e] = wave_sum(v[e]);
-  if (lane == 0)
-#pragma unroll
-    for (int e = 0; e < NV; ++e) red[wave][e] = v[e];
+  // wave sums, then the waves in index order (fixed order: bit-reproducible); slot e of red[wave] as in the layout above
+#define HS_BB_REDUCE(arr, n, base)                                   \
+  _Pragma("unroll") for (int e = 0; e < (n); ++e) {                  \
+    arr[e] = wave_sum(arr[e]);                                       \
+    if (lane == 0) red[wave][(base) + e] = arr[e];                   \
+  }
+  HS_BB_REDUCE(gg, KM, 0)
+  HS_BB_REDUCE(aa, KM, KM)
+  HS_BB_REDUCE(ggr, 6, 2 * KM)
+  HS_BB_REDUCE(agr, 6, 2 * KM + 6)
+  HS_BB_REDUCE(rg, 3, 2 * KM + 12)
+  HS_BB_REDUCE(ra, 3, 2 * KM + 15)
+  HS_BB_REDUCE(hg, 5, 2 * KM + 18)
+#undef HS_BB_REDUCE
   __syncthreads();
   if (tid != 0) return;
-#pragma unroll
-  for (int e = 0; e < NV; ++e) {
-    double t = 0.0;
-    for (int w = 0; w < kBlock / 64; ++w) t += red[w][e];
-    v[e] = t;
+#define HS_BB_TOTAL(arr, n, base)                                    \
+  _Pragma("unroll") for (int e = 0; e < (n); ++e) {                  \
+    double t = 0.0;                                                  \
+    for (int w = 0; w < kBlock / 64; ++w) t += red[w][(base) + e];   \
+    arr[e] = t;                                                      \
   }
-  for (int d = 0; d < kb && b + d < nbias; ++d)
+  HS_BB_TOTAL(gg, KM, 0)
+  HS_BB_TOTAL(aa, KM, KM)
+  HS_BB_TOTAL(ggr, 6, 2 * KM)
+  HS_BB_TOTAL(agr, 6, 2 * KM + 6)
+  HS_BB_TOTAL(rg, 3, 2 * KM + 12)
+  HS_BB_TOTAL(ra, 3, 2 * KM + 15)
+  HS_BB_TOTAL(hg, 5, 2 * KM + 18)
+#undef HS_BB_TOTAL
+#pragma unroll
+  for (int d = 0; d < KM; ++d)  // (compile-time d: a run-time index would put gg / aa back into scratch memory)
+    if (d < kb && b + d < nbias)
     for (int c = 0; c < 3; ++c) {
       const int r0 = og + 3 * b + c, c0 = og + 3 * (b + d) + c;
       Hbb[size_t(r0) * nb + c0] = gg[d], Hbb[size_t(c0) * nb + r0] = gg[d];
       const int r1 = oa + 3 * b + c, c1 = oa + 3 * (b + d) + c;
       Hbb[size_t(r1) * nb + c1] = aa[d], Hbb[size_t(c1) * nb + r1] = aa[d];
     }
+#pragma unroll
   for (int c = 0; c < 3; ++c)
+#pragma unroll
     for (int e = 0; e < 2; ++e) {
       Hbb[size_t(og + 3 * b + c) * nb + ogr + e] = ggr[2 * c + e], Hbb[size_t(ogr + e) * nb + og + 3 * b + c] = ggr[2 * c + e];
       Hbb[size_t(oa + 3 * b + c) * nb + ogr + e] = agr[2 * c + e], Hbb[size_t(ogr + e) * nb + oa + 3 * b + c] = agr[2 * c + e];
     }
+#pragma unroll
   for (int c = 0; c < 3; ++c) gb[og + 3 * b + c] = rg[c], gb[oa + 3 * b + c] = ra[c];
+#pragma unroll
   for (int e = 0; e < 5; ++e) T.gravity_part[5 * b + e] = hg[e];
   // Gravity-gravity block and J_g' r = sum of the per-bias-point partials in index order, by the workgroup that arrives last (the counter is
   // reset by the zero-fill workgroups of k_border_pb, in front of this kernel on the same stream): a launch of its own ended the side-stream

@@ -705,6 +705,9 @@ __global__ void __launch_bounds__(kBlock) k_update_visual(Tables T, int R, int L
     return;
   }
   // ---- chunk w ----
+  const bool uprof = prof_enabled(T.debug_flags, 128) && tid == 0 && w < 1024;  // phase stamps (profiling builds; tools/update_phase_timing.py)
+  long long* ulog = reinterpret_cast<long long*>(T.xpart) + 192 * 1024 + 16 * w;
+  if (uprof) ulog[0] = wall_clock64();
   const int4 d0 = *reinterpret_cast<const int4*>(T.ch_desc + 8 * w);
   const int nres = T.ch_desc[8 * w + 4];
   const int st_done = st->done, st_spec = st->spec, st_accepted = st->accepted;
@@ -716,6 +719,7 @@ __global__ void __launch_bounds__(kBlock) k_update_visual(Tables T, int R, int L
   }
   const bool pend = st_spec == 4 && st_accepted;  // the landmarks' current point is still in lm_cand
   const int lo = d0.x, nl = d0.y, cf = d0.z, q0 = d0.w;
+  if (uprof && lo + nl + cf + q0 >= 0) ulog[1] = wall_clock64();  // descriptor + state here
   const int bw = T.bw, R6 = 6 * bw;
   const unsigned bw_magic = ((1u << 20) + bw - 1) / bw;
   double* cps_c = smem;                       // candidate control points of the window [bw][8]
@@ -767,6 +771,7 @@ __global__ void __launch_bounds__(kBlock) k_update_visual(Tables T, int R, int L
     active = !T.lm_const[dl];
   }
   __syncthreads();
+  if (uprof) ulog[2] = wall_clock64();  // tables staged
   // partial dot products, one (landmark, control point) block per lane: the 6 x 3 block of Y-hat is 18 consecutive doubles in HBM
   const int n_task = nl * bw;
   for (int tau = tid; tau < n_task; tau += kBlock) {
@@ -790,6 +795,7 @@ __global__ void __launch_bounds__(kBlock) k_update_visual(Tables T, int R, int L
     dst[0] = t0, dst[1] = t1, dst[2] = t2;
   }
   __syncthreads();
+  if (uprof) ulog[3] = wall_clock64();  // Y-hat dot products done
   if (tid < nl) {  // 3 x 3 back-substitution per landmark
     const int l = tid, dl = lo + l;
     double t0 = 0.0, t1 = 0.0, t2 = 0.0;
@@ -813,6 +819,7 @@ __global__ void __launch_bounds__(kBlock) k_update_visual(Tables T, int R, int L
     lmc[8 * l + 4] = xl, lmc[8 * l + 5] = sl, lmc[8 * l + 6] = gd, lmc[8 * l + 7] = dd;
   }
   __syncthreads();
+  if (uprof) ulog[4] = wall_clock64();  // landmarks back-substituted
   if (tid >= kBlock - 4) {  // landmark-side terms of the decision (|x|^2, |x - x+|^2, g.step, step'D^2 step), landmarks in order
     const int e = tid - (kBlock - 4);
     double v = 0.0;
@@ -826,6 +833,7 @@ __global__ void __launch_bounds__(kBlock) k_update_visual(Tables T, int R, int L
     costs[rt] = visual_cost_in<K>(T, cps_c - 8 * cf, in);
   }
   __syncthreads();
+  if (uprof) ulog[5] = wall_clock64();  // candidate costs
   if (tid < 8) {  // fixed-order sum: eight strided partials, then their sum
     const int per = (nres + 7) / 8;
     double acc = 0.0;
@@ -839,6 +847,7 @@ __global__ void __launch_bounds__(kBlock) k_update_visual(Tables T, int R, int L
     for (int g = 0; g < 8; ++g) s += cpart[g];
     T.cand_part[w] = s;
   }
+  if (uprof) ulog[6] = wall_clock64();
 }
 
 }  // namespace hs

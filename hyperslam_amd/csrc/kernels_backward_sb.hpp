@@ -52,10 +52,12 @@ HSD double pair_sum(double v) {
 /// (J.Ubk); the blocks above the diagonal follow by block back substitution, one block diagonal per level:
 ///     V_jj = W_j,     V_ij = -W_i sum_(k = i + 1 .. j) U_ik V_kj     (i < j, level j - i),
 /// so the dependent chain is three levels of two 6 x 6 products instead of 24 scalar rows.
-HSD void sb_inverse(const Tables& T, const BackJob& J, int job, int s, double* lds /* 3 x 24 x 25 */) {
-  const int l = threadIdx.x;
-  if (l >= 64) return;
+/// (raise_flag = false: the wave belongs to a workgroup that uses the inverse itself — the fused factor + sweep kernel — and synchronises on its own)
+HSD void sb_inverse(const Tables& T, const BackJob& J, int job, int s, double* lds /* 3 x 24 x 25, this wave's */, bool raise_flag = true) {
+  const int l = threadIdx.x & 63;
   constexpr int LD = kSbN + 1;
+  // one wave: LDS operations complete in program order; only the compiler and the counters must keep it
+#define HS_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
   double* U = lds;
   double* V = lds + kSbN * LD;
   double* Tm = lds + 2 * kSbN * LD;
@@ -94,7 +96,7 @@ HSD void sb_inverse(const Tables& T, const BackJob& J, int job, int s, double* l
       }
     }
   }
-  __syncthreads();  // (the workgroup's other waves have left: a barrier of one wave)
+  HS_WAVE_SYNC();
   if (iprof) ilog[1] = wall_clock64();  // block in LDS
   for (int d = 1; d < kSb; ++d) {
     const int n_e = (kSb - d) * 36;
@@ -106,7 +108,7 @@ HSD void sb_inverse(const Tables& T, const BackJob& J, int job, int s, double* l
         for (int m = 0; m < 6; ++m) t = fma(U[(6 * i + r) * LD + 6 * k + m], V[(6 * k + m) * LD + 6 * j + c], t);
       Tm[(6 * i + r) * LD + 6 * j + c] = t;
     }
-    __syncthreads();
+    HS_WAVE_SYNC();
     for (int e = l; e < n_e; e += 64) {  // V_ij = -W_i Tm_ij
       const int i = e / 36, r = (e % 36) / 6, c = e % 6, j = i + d;
       double v = 0.0;
@@ -114,7 +116,7 @@ HSD void sb_inverse(const Tables& T, const BackJob& J, int job, int s, double* l
       for (int m = 0; m < 6; ++m) v = fma(V[(6 * i + r) * LD + 6 * i + m], Tm[(6 * i + m) * LD + 6 * j + c], v);  // (W_i is upper triangular: zeros below)
       V[(6 * i + r) * LD + 6 * j + c] = -v;
     }
-    __syncthreads();
+    HS_WAVE_SYNC();
   }
   if (iprof) ilog[2] = wall_clock64();  // inverse in LDS
   double* dst = const_cast<double*>(J.Vb) + size_t(s) * (kSbN * kSbN);
@@ -122,13 +124,13 @@ HSD void sb_inverse(const Tables& T, const BackJob& J, int job, int s, double* l
     const int a = e / kSbN, c = e % kSbN;
     dst[e] = (a < nr && c < nr) ? V[a * LD + c] : 0.0;
   }
-  __threadfence();
-  __syncthreads();
+  if (!raise_flag) return;
+  __threadfence();  // (the wave's stores: one instruction stream)
   if (l == 0) {
-    __threadfence();
     __hip_atomic_store(T.join_flag + kSbFlagBase + kSbMaxBlocks * job + s, T.join_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     if (iprof) ilog[3] = wall_clock64();  // flag raised
   }
+#undef HS_WAVE_SYNC
 }
 
 /// Bounded wait for a flag word (see wait_for_partner): 2 s, then the factorisation is marked as failed and the caller carries on.
@@ -143,25 +145,18 @@ HSD void sb_wait(const Tables& T, const unsigned* flag) {
   }
 }
 
-__global__ void __launch_bounds__(kCholThreads) k_band_backward_sb(Tables T, BackJob j0, BackJob j1, int m_mid, int n_jobs, int j_lo) {
-  HS_DYNAMIC_LDS(smem);
+/// The sweep of one job (the first kCholThreads lanes of the workgroup; the others must have left). prebuilt: the inverses of the super-blocks
+/// are in memory (fused factor + sweep kernel: built by the same workgroup) — no builder flags to wait for; near_ready: job 1 of the fused
+/// kernel waits on it before it touches the near job's factor (phase A).
+HSD void sb_sweep(const Tables& T, const BackJob& j0, const BackJob& j1, const int m_mid, const int n_jobs, const int j_lo, const int job, double* smem,
+                  const bool prebuilt, const unsigned* near_ready) {
   DevState* st = T.st;
-  if (st->done) return;
   const int tid = threadIdx.x;
-  if (int(blockIdx.x) >= n_jobs) {  // ---------------- inverse builders ----------------
-    const int s0 = int(blockIdx.x) - n_jobs, n0 = sb_count(j0.n_rows);
-    if (s0 < n0)
-      sb_inverse(T, j0, 0, s0, smem);
-    else
-      sb_inverse(T, j1, 1, s0 - n0, smem);
-    return;
-  }
-  const int job = blockIdx.x;
   const BackJob J = job == 0 ? j0 : j1;
   constexpr int nthr = kCholThreads;
   const int bw = T.bw, ncb = 6 * bw, np = T.np;
   const bool cprof = prof_enabled(T.debug_flags, 16) && tid == 0;  // coarse phases -> xpart[8 (230 + 10 block) + ..] (tools/chol_phase_timing.py)
-  long long* clog = reinterpret_cast<long long*>(T.xpart) + 8 * (230 + 10 * blockIdx.x);
+  long long* clog = reinterpret_cast<long long*>(T.xpart) + 8 * (230 + 10 * job);
   if (cprof) clog[0] = wall_clock64();
   const int n_own = 6 * J.n_rows, n_all = 6 * (J.n_rows + J.given);
   double* xs = smem;              // n_all : pending rows (own) / given solution
@@ -181,10 +176,6 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward_sb(Tables T, Bac
   const int baseA = max(0, kSbN * sA_pub - n_above);  // first row phase A touches
   double* xsA = G + n_above * ldg + 2;                // nA_own - baseA (+ 24 zeros: partial last super-block), indexed from baseA
   double* xoutA = xsA + (nA_own - baseA) + kSbN;      // nA_own - baseA
-  if (phase_a) {
-    for (int rho = baseA + tid; rho < nA_own; rho += nthr) xsA[rho - baseA] = j0.ybuf[rho];
-    if (tid < kSbN) xsA[nA_own - baseA + tid] = 0.0;
-  }
   // operands of the step outputs at the end of a two-ended sweep (the rows this block solves), requested now
   double o_sc[kSbOut], o_gf[kSbOut], o_d2[kSbOut];
 #pragma unroll
@@ -214,6 +205,14 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward_sb(Tables T, Bac
         if (e < n_g) G[c * ldg + r] = v[u];
       }
     }
+  }
+  if (phase_a && near_ready) {  // fused kernel: wait until the near workgroup has published its factor and its top inverses
+    sb_wait(T, near_ready);
+    __threadfence();
+  }
+  if (phase_a) {
+    for (int rho = baseA + tid; rho < nA_own; rho += nthr) xsA[rho - baseA] = j0.ybuf[rho];
+    if (tid < kSbN) xsA[nA_own - baseA + tid] = 0.0;
   }
   // ---- lane roles ----
   // waves 0 .. 2 (192 lanes), lane (p, q) = (tid / 2, tid & 1): pending row rho = r0 - 1 - p of the step (p < n_above), columns
@@ -260,7 +259,7 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward_sb(Tables T, Bac
   // microseconds of the launch, so the wave waits for ALL of its job's flags once, lane i polling flag i (an agent-scope acquire load
   // costs ~1 us: one per step on the chain doubled the step, five in a row delayed the first step by 8 us).
   auto request_checked = [&](int s, double* dst) { request(s, dst); };
-  if (solver) {
+  if (solver && !prebuilt) {
     for (int i = l; i < n_sb; i += 64) sb_wait(T, flags + i);
     if (phase_a && l <= sA_top - sA_pub) sb_wait(T, T.join_flag + kSbFlagBase + sA_pub + l);  // the near job's top super-blocks
     __threadfence();
@@ -426,6 +425,21 @@ __global__ void __launch_bounds__(kCholThreads) k_band_backward_sb(Tables T, Bac
       st->g_dot_step_far = gd, st->d2_step2_far = dd;
   }
   if (cprof) clog[7] = wall_clock64();  // step outputs written (the block that finished last)
+}
+
+__global__ void __launch_bounds__(kCholThreads) k_band_backward_sb(Tables T, BackJob j0, BackJob j1, int m_mid, int n_jobs, int j_lo) {
+  HS_DYNAMIC_LDS(smem);
+  if (T.st->done) return;
+  if (int(blockIdx.x) >= n_jobs) {  // ---------------- inverse builders (first wave) ----------------
+    if (threadIdx.x >= 64) return;
+    const int s0 = int(blockIdx.x) - n_jobs, n0 = sb_count(j0.n_rows);
+    if (s0 < n0)
+      sb_inverse(T, j0, 0, s0, smem);
+    else
+      sb_inverse(T, j1, 1, s0 - n0, smem);
+    return;
+  }
+  sb_sweep(T, j0, j1, m_mid, n_jobs, j_lo, blockIdx.x, smem, false, nullptr);
 }
 
 }  // namespace hs

@@ -264,20 +264,11 @@ static int linearize_sensor_blocks(hs_problem* p, int type, int robustify, const
   HIP_TRY(p->d_dbg.reserve(size_t(n) * REC));
   const int nb = (n + kBlock - 1) / kBlock;
   if (visual) {
-    if (k == 4)
-      k_sensor_visual<4><<<nb, kBlock, 0, s>>>(T, p->d_dbg.p, p->d_v_dbgpos.p, robustify);
-    else
-      k_sensor_visual<6><<<nb, kBlock, 0, s>>>(T, p->d_dbg.p, p->d_v_dbgpos.p, robustify);
+    HS_ORDER_SWITCH(k, k_sensor_visual<K><<<nb, kBlock, 0, s>>>(T, p->d_dbg.p, p->d_v_dbgpos.p, robustify));
   } else if (type == HS_PRIOR) {
-    if (k == 4)
-      k_sensor_prior<4><<<nb, kBlock, 0, s>>>(T, p->d_dbg.p);
-    else
-      k_sensor_prior<6><<<nb, kBlock, 0, s>>>(T, p->d_dbg.p);
+    HS_ORDER_SWITCH(k, k_sensor_prior<K><<<nb, kBlock, 0, s>>>(T, p->d_dbg.p));
   } else {
-    if (k == 4)
-      k_sensor_inertial<4, 4><<<nb, kBlock, 0, s>>>(T, p->d_dbg.p, robustify);
-    else
-      k_sensor_inertial<6, 4><<<nb, kBlock, 0, s>>>(T, p->d_dbg.p, robustify);
+    HS_ORDER_SWITCH(k, k_sensor_inertial<K, 4><<<nb, kBlock, 0, s>>>(T, p->d_dbg.p, robustify));
   }
   HIP_TRY(hipGetLastError());
   std::vector<double> rec(size_t(n) * REC);
@@ -392,10 +383,7 @@ static int linearize_impl(hs_problem* p, int type, int robustify, const hs_linea
     if (n == 0) return HS_OK;
     HIP_TRY(p->d_dbg.reserve(size_t(n) * REC));
     HIP_TRY(p->d_dbg_cost.reserve(n));
-    if (k == 4)
-      k_linearize_visual<4><<<(n + lin_block<4>() - 1) / lin_block<4>(), lin_block<4>(), lin_lds_bytes<4>(p), s>>>(T, p->d_dbg.p, p->d_v_dbgpos.p, robustify, nullptr, p->d_dbg_cost.p);
-    else
-      k_linearize_visual<6><<<(n + lin_block<6>() - 1) / lin_block<6>(), lin_block<6>(), lin_lds_bytes<6>(p), s>>>(T, p->d_dbg.p, p->d_v_dbgpos.p, robustify, nullptr, p->d_dbg_cost.p);
+    HS_ORDER_SWITCH(k, k_linearize_visual<K><<<(n + lin_block<K>() - 1) / lin_block<K>(), lin_block<K>(), lin_lds_bytes<K>(p), s>>>(T, p->d_dbg.p, p->d_v_dbgpos.p, robustify, nullptr, p->d_dbg_cost.p));
     HIP_TRY(hipGetLastError());
     std::vector<double> rec(size_t(n) * REC), cost(n);
     HIP_TRY(hipMemcpyAsync(rec.data(), p->d_dbg.p, rec.size() * 8, hipMemcpyDeviceToHost, s));
@@ -421,10 +409,7 @@ static int linearize_impl(hs_problem* p, int type, int robustify, const hs_linea
     if (n == 0) return HS_OK;
     HIP_TRY(p->d_dbg.reserve(size_t(n) * REC));
     HIP_TRY(p->d_dbg_cost.reserve(n));
-    if (k == 4)
-      k_linearize_prior<4><<<p->nb_pri, kBlock, cp_lds_bytes(p), s>>>(T, p->d_dbg.p, nullptr, p->d_dbg_cost.p);
-    else
-      k_linearize_prior<6><<<p->nb_pri, kBlock, cp_lds_bytes(p), s>>>(T, p->d_dbg.p, nullptr, p->d_dbg_cost.p);
+    HS_ORDER_SWITCH(k, k_linearize_prior<K><<<p->nb_pri, kBlock, cp_lds_bytes(p), s>>>(T, p->d_dbg.p, nullptr, p->d_dbg_cost.p));
     HIP_TRY(hipGetLastError());
     std::vector<double> rec(size_t(n) * REC), cost(n);
     HIP_TRY(hipMemcpyAsync(rec.data(), p->d_dbg.p, rec.size() * 8, hipMemcpyDeviceToHost, s));
@@ -445,10 +430,7 @@ static int linearize_impl(hs_problem* p, int type, int robustify, const hs_linea
     if (n == 0) return HS_OK;
     HIP_TRY(p->d_dbg.reserve(size_t(n) * REC));
     HIP_TRY(p->d_dbg_cost.reserve(n));
-    if (k == 4)
-      k_linearize_inertial<4, 4><<<p->nb_ine, kInertialBlock * 4, cp_lds_bytes(p), s>>>(T, p->d_dbg.p, robustify, nullptr, p->d_dbg_cost.p);
-    else
-      k_linearize_inertial<6, 4><<<p->nb_ine, kInertialBlock * 6, cp_lds_bytes(p), s>>>(T, p->d_dbg.p, robustify, nullptr, p->d_dbg_cost.p);
+    HS_ORDER_SWITCH(k, k_linearize_inertial<K, 4><<<p->nb_ine, kInertialBlock * K, cp_lds_bytes(p), s>>>(T, p->d_dbg.p, robustify, nullptr, p->d_dbg_cost.p));
     HIP_TRY(hipGetLastError());
     std::vector<double> rec(size_t(n) * REC), cost(n);
     HIP_TRY(hipMemcpyAsync(rec.data(), p->d_dbg.p, rec.size() * 8, hipMemcpyDeviceToHost, s));
@@ -485,7 +467,7 @@ int hs_cost(hs_problem* p, double* cost) {
   if (rc) return rc;
   rc = reset_state(p, 0, 1e4);
   if (rc) return rc;
-  rc = p->k == 4 ? launch_linearize<4>(p, false, true) : launch_linearize<6>(p, false, true);
+  HS_ORDER_SWITCH(p->k, rc = launch_linearize<K>(p, false, true));
   if (rc) return rc;
   k_pack_exchange<<<1, kBlock, 0, p->stream>>>(p->T, 0);
   rc = exchange(p, p->T.xbuf + p->T.xo_cost, 1);
@@ -506,9 +488,9 @@ int hs_reduced_system(hs_problem* p, double radius, double* S, double* g) {
   if (rc) return rc;
   rc = reset_state(p, 1, radius);
   if (rc) return rc;
-  rc = p->k == 4 ? launch_linearize<4>(p) : launch_linearize<6>(p);
+  HS_ORDER_SWITCH(p->k, rc = launch_linearize<K>(p));
   if (rc) return rc;
-  rc = p->k == 4 ? launch_build<4>(p) : launch_build<6>(p);
+  HS_ORDER_SWITCH(p->k, rc = launch_build<K>(p));
   if (rc) return rc;
   const int np = p->T.np, ncb = 6 * p->T.bw;
   std::vector<double> Sb(size_t(np) * ncb), gs(np);
@@ -586,12 +568,12 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
   HIP_TRY(hipEventRecord(ev[0], s));
   for (int it = 0; it < max_iterations; ++it) {
     if (it == 0 || !spec) {  // (speculative solves: the linearisation of the current point came with the previous iteration's candidate)
-      rc = p->k == 4 ? launch_linearize<4>(p, true) : launch_linearize<6>(p, true);
+      HS_ORDER_SWITCH(p->k, rc = launch_linearize<K>(p, true));
       if (rc) return rc;
     }
     if (stages && !p->fused) HIP_TRY(hipEventRecord(ev[4 * it + 1], s));
     hipEvent_t after_build = stages && p->fused ? ev[4 * it + 1] : nullptr;  // fused build: the linearise stage ends behind k_build_visual
-    rc = p->k == 4 ? launch_build<4>(p, after_build) : launch_build<6>(p, after_build);
+    HS_ORDER_SWITCH(p->k, rc = launch_build<K>(p, after_build));
     if (rc) return rc;
     if (stages) HIP_TRY(hipEventRecord(ev[4 * it + 2], s));
     rc = launch_factor(p);
@@ -599,13 +581,13 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
     if (stages) HIP_TRY(hipEventRecord(ev[4 * it + 3], s));
     const bool lin_cand = spec && it + 1 < max_iterations;
     hipEvent_t* lin_ev = stages && lin_cand ? &ev[ev_cand + 2 * it] : nullptr;
-    rc = p->k == 4 ? launch_update<4>(p, lin_cand, deferred, lin_ev) : launch_update<6>(p, lin_cand, deferred, lin_ev);
+    HS_ORDER_SWITCH(p->k, rc = launch_update<K>(p, lin_cand, deferred, lin_ev));
     if (rc) return rc;
     if (deferred && it + 1 == max_iterations) launch_commit(p);  // the last accepted candidate (also when a convergence test ended the solve early)
     if (stages || it + 1 == max_iterations) HIP_TRY(hipEventRecord(ev[4 * it + 4], s));
   }
   if (max_iterations == 0) {
-    rc = p->k == 4 ? launch_linearize<4>(p, false, true) : launch_linearize<6>(p, false, true);
+    HS_ORDER_SWITCH(p->k, rc = launch_linearize<K>(p, false, true));
     if (rc) return rc;
     k_pack_exchange<<<1, kBlock, 0, s>>>(p->T, 0);
     rc = exchange(p, p->T.xbuf + p->T.xo_cost, 1);
@@ -1040,12 +1022,8 @@ int hs_process_tracks(hs_problem* p, double stamp, int n, const double* pixels0,
   if (bearings1) HIP_TRY(d_b1.reserve(size_t(3) * n));
   if (positions_w) HIP_TRY(d_pw.reserve(size_t(3) * n));
   const int nb = (n + kBlock - 1) / kBlock;
-  if (k == 4)
-    k_process_tracks<4><<<nb, kBlock, cp_lds_bytes(p), s>>>(T, stamp, n, d_p0.p, d_p1.p, bearings0 ? d_b0.p : nullptr, bearings1 ? d_b1.p : nullptr,
-                                                           positions_w ? d_pw.p : nullptr);
-  else
-    k_process_tracks<6><<<nb, kBlock, cp_lds_bytes(p), s>>>(T, stamp, n, d_p0.p, d_p1.p, bearings0 ? d_b0.p : nullptr, bearings1 ? d_b1.p : nullptr,
-                                                           positions_w ? d_pw.p : nullptr);
+  HS_ORDER_SWITCH(k, k_process_tracks<K><<<nb, kBlock, cp_lds_bytes(p), s>>>(T, stamp, n, d_p0.p, d_p1.p, bearings0 ? d_b0.p : nullptr, bearings1 ? d_b1.p : nullptr,
+                                                           positions_w ? d_pw.p : nullptr));
   HIP_TRY(hipGetLastError());
   if (bearings0) HIP_TRY(hipMemcpyAsync(bearings0, d_b0.p, size_t(3) * n * 8, hipMemcpyDeviceToHost, s));
   if (bearings1) HIP_TRY(hipMemcpyAsync(bearings1, d_b1.p, size_t(3) * n * 8, hipMemcpyDeviceToHost, s));
@@ -1149,10 +1127,7 @@ int hs_sample_trajectory(hs_problem* p, int n, const double* stamps, double* pos
   if (velocity) HIP_TRY(d_vel.reserve(size_t(6) * n));
   if (acceleration) HIP_TRY(d_acc.reserve(size_t(6) * n));
   const int nb = (n + kBlock - 1) / kBlock;
-  if (k == 4)
-    k_sample_trajectory<4><<<nb, kBlock, cp_lds_bytes(p), s>>>(T, n, d_st.p, d_pose.p, velocity ? d_vel.p : nullptr, acceleration ? d_acc.p : nullptr);
-  else
-    k_sample_trajectory<6><<<nb, kBlock, cp_lds_bytes(p), s>>>(T, n, d_st.p, d_pose.p, velocity ? d_vel.p : nullptr, acceleration ? d_acc.p : nullptr);
+  HS_ORDER_SWITCH(k, k_sample_trajectory<K><<<nb, kBlock, cp_lds_bytes(p), s>>>(T, n, d_st.p, d_pose.p, velocity ? d_vel.p : nullptr, acceleration ? d_acc.p : nullptr));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(pose, d_pose.p, size_t(7) * n * 8, hipMemcpyDeviceToHost, s));
   if (velocity) HIP_TRY(hipMemcpyAsync(velocity, d_vel.p, size_t(6) * n * 8, hipMemcpyDeviceToHost, s));

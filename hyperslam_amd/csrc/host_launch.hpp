@@ -536,6 +536,7 @@ static void warm_kernels(int device) {
       reinterpret_cast<const void*>(&k_reset_state), reinterpret_cast<const void*>(&k_scatter_uploads)};
   for (const void* k : kernels) (void)hipFuncGetAttributes(&fa, k);
   warm_kernels_of_order<4>();
+  warm_kernels_of_order<5>();
   warm_kernels_of_order<6>();
 }
 
@@ -548,24 +549,19 @@ int set_func_attributes(hs_problem* p) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor<2>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_la<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_factor_la<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, p->chol_lds_max));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seg_gram<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seg_gram<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  for (int k = 4; k <= 6; ++k) HS_ORDER_SWITCH(k, {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seg_gram<K>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<K, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<K, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<K, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_visual<K>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_visual<K>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_visual<K>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+  });
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_solve_reg<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_solve_reg<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_solve_reg<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_solve_reg<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<6, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<6, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_pair<6, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_visual<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_visual<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_visual<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_build_visual<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_visual<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_visual<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_forward), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_forward2), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
 #if HS_PROFILE_HOOKS

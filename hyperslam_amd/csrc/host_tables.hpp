@@ -257,6 +257,21 @@ static const char* kWeightsMessage =
 /// the alternatives are not compiled in), HS_DEBUG_FLAGS bits in profiling builds (tools/build_profiling_lib.sh).
 #define HS_AB(flags, bit) (HS_PROFILE_HOOKS && ((flags) & (bit)))
 
+/// Spline orders the device kernels are instantiated for: 4, 5 and 6. Runs the statement(s) with the compile-time constant K = k.
+#define HS_ORDER_SWITCH(k, ...)    \
+  do {                             \
+    if ((k) == 4) {                \
+      constexpr int K = 4;         \
+      __VA_ARGS__;                 \
+    } else if ((k) == 5) {         \
+      constexpr int K = 5;         \
+      __VA_ARGS__;                 \
+    } else {                       \
+      constexpr int K = 6;         \
+      __VA_ARGS__;                 \
+    }                              \
+  } while (0)
+
 #define HS_FAIL(code, msg) \
   do {                     \
     p->err = (msg);        \
@@ -287,7 +302,7 @@ int prepare(hs_problem* p) {
   } batch_scope(&p->batch);
   const auto host_t0 = std::chrono::steady_clock::now();
   if (p->n_cp == 0) HS_FAIL(HS_ERR_STATE, "hs_set_spline has not been called");
-  if (p->k != 4 && p->k != 6) HS_FAIL(HS_ERR_INVALID, "device kernels are instantiated for spline order 4 and 6");
+  if (p->k < 4 || p->k > 6) HS_FAIL(HS_ERR_INVALID, "device kernels are instantiated for spline orders 4, 5 and 6");
   HIP_TRY(hipSetDevice(p->device));
   hipStream_t s = p->stream;
   const int k = p->k, n_seg = p->n_cp - k + 1;
@@ -445,7 +460,7 @@ int prepare(hs_problem* p) {
   if (p->fused) {
     // chunk geometry: R residuals (lanes) and L landmarks per chunk, sized for two workgroups per CU (every phase of the kernel is an LDS
     // gather: latency bound on a lone wave per SIMD). HS_BUILD_R / HS_BUILD_L: tuning overrides.
-    int R0 = k == 4 ? 128 : 96, L0 = k == 4 ? 12 : 10;
+    int R0 = k == 4 ? 128 : k == 5 ? 112 : 96, L0 = k == 4 ? 12 : k == 5 ? 11 : 10;
     if (const char* e = std::getenv("HS_BUILD_R")) R0 = std::max(32, std::min(kBlock, std::atoi(e)));
     if (const char* e = std::getenv("HS_BUILD_L")) L0 = std::max(1, std::min(24, std::atoi(e)));  // (<= 24: 9 L + 8 lanes of phase 2a, L lanes of one wave in 4a)
     auto lds_bytes = [&](int r, int l) { return size_t(build_lds_layout(k, vs.bw, r, l).total_doubles) * 8; };
@@ -516,7 +531,8 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_gabs.reserve(np + (p->has_imu ? 6 * p->n_bias + 2 : 0) + 1));
   HIP_TRY(p->d_step_p.reserve(np));
   HIP_TRY(p->d_delta_p.reserve(np));
-  const int vis_block = k == 4 ? lin_block<4>() : lin_block<6>();
+  int vis_block = 0;
+  HS_ORDER_SWITCH(k, vis_block = lin_block<K>());
   p->nb_vis = (n_vis + vis_block - 1) / vis_block;
   if (p->fused) {
     p->nb_vis = std::max((n_vis + kBlock - 1) / kBlock, int(p->h_ch_ptr.size()) - 1);  // one cost partial per chunk / per workgroup of k_cost_visual

@@ -240,7 +240,9 @@ HSD void seg_gram_body(const Tables& T, const int bid) {
   HS_DYNAMIC_LDS(stage);  // kSegStage doubles: a contiguous run of records
   __shared__ __attribute__((aligned(16))) double red[kBlock * 12 + kBlock * 3];
   if (T.st->done) return;
-  constexpr int NCA = 6 * K, RG = NCA / 3, CG = NCA / 4, TPS = RG * CG, NS = kBlock / TPS;  // 3x4 register tiles, NS record streams
+  // 3 x TC register tiles, NS record streams. TC = 4 where it divides 6 K (orders 4 and 6), 2 for order 5 (6 K = 30)
+  constexpr int NCA = 6 * K, TC = NCA % 4 == 0 ? 4 : 2, RG = NCA / 3, CG = NCA / TC, TPS = RG * CG, NS = kBlock / TPS;
+  static_assert(NCA % 3 == 0 && NCA % TC == 0 && TPS <= kBlock, "tile shape of the segment Gram kernel");
   constexpr int VREC = 8 + 12 * K, PREC = 6 + 36 * K;
   // work list: workgroup w serves segment sw_seg[w] as split sp of nsp (splits proportional to the segment's record count: the
   // first and last segment of a window collect the clamped stamps)
@@ -251,7 +253,7 @@ HSD void seg_gram_body(const Tables& T, const int bid) {
   long long* slog = reinterpret_cast<long long*>(T.xpart) + 8 * 1024 + 8 * first;
   if (sprof) slog[0] = wall_clock64();
   // a tile is needed if some column block >= the row block (upper block triangle); column group 0 also carries J'r
-  const bool live = stream < NS && (cg == 0 || (4 * cg + 3) / 6 >= (3 * rg) / 6);
+  const bool live = stream < NS && (cg == 0 || (TC * cg + TC - 1) / 6 >= (3 * rg) / 6);
   double acc[3][4], gacc[3] = {0, 0, 0};
 #pragma unroll
   for (int r = 0; r < 3; ++r)
@@ -289,10 +291,16 @@ HSD void seg_gram_body(const Tables& T, const int bid) {
           for (int r = 0; r < n_rows; ++r) {
             const double* j = rec + joff + r * NCA;
             const double a0 = j[3 * rg], a1 = j[3 * rg + 1], a2 = j[3 * rg + 2];
-            const double2 b01 = *reinterpret_cast<const double2*>(j + 4 * cg), b23 = *reinterpret_cast<const double2*>(j + 4 * cg + 2);
-            acc[0][0] = fma(a0, b01.x, acc[0][0]), acc[0][1] = fma(a0, b01.y, acc[0][1]), acc[0][2] = fma(a0, b23.x, acc[0][2]), acc[0][3] = fma(a0, b23.y, acc[0][3]);
-            acc[1][0] = fma(a1, b01.x, acc[1][0]), acc[1][1] = fma(a1, b01.y, acc[1][1]), acc[1][2] = fma(a1, b23.x, acc[1][2]), acc[1][3] = fma(a1, b23.y, acc[1][3]);
-            acc[2][0] = fma(a2, b01.x, acc[2][0]), acc[2][1] = fma(a2, b01.y, acc[2][1]), acc[2][2] = fma(a2, b23.x, acc[2][2]), acc[2][3] = fma(a2, b23.y, acc[2][3]);
+            const double2 b01 = *reinterpret_cast<const double2*>(j + TC * cg);
+            acc[0][0] = fma(a0, b01.x, acc[0][0]), acc[0][1] = fma(a0, b01.y, acc[0][1]);
+            acc[1][0] = fma(a1, b01.x, acc[1][0]), acc[1][1] = fma(a1, b01.y, acc[1][1]);
+            acc[2][0] = fma(a2, b01.x, acc[2][0]), acc[2][1] = fma(a2, b01.y, acc[2][1]);
+            if (TC == 4) {
+              const double2 b23 = *reinterpret_cast<const double2*>(j + TC * cg + 2);
+              acc[0][2] = fma(a0, b23.x, acc[0][2]), acc[0][3] = fma(a0, b23.y, acc[0][3]);
+              acc[1][2] = fma(a1, b23.x, acc[1][2]), acc[1][3] = fma(a1, b23.y, acc[1][3]);
+              acc[2][2] = fma(a2, b23.x, acc[2][2]), acc[2][3] = fma(a2, b23.y, acc[2][3]);
+            }
             if (cg == 0) {
               const double rr = rec[r];
               gacc[0] = fma(a0, rr, gacc[0]), gacc[1] = fma(a1, rr, gacc[1]), gacc[2] = fma(a2, rr, gacc[2]);
@@ -321,7 +329,7 @@ HSD void seg_gram_body(const Tables& T, const int bid) {
   double* P = T.segP + size_t(bid) * (NCA * NCA + NCA);
   for (int e = tid; e < NCA * NCA; e += kBlock) {
     const int a = e / NCA, c = e % NCA;
-    const int t = (a / 3) * CG + c / 4, in = 4 * (a % 3) + c % 4;
+    const int t = (a / 3) * CG + c / TC, in = 4 * (a % 3) + c % TC;
     double v = 0.0;
 #pragma unroll
     for (int st = 0; st < NS; ++st) v += racc[(st * TPS + t) * 12 + in];

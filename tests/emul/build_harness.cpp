@@ -109,7 +109,7 @@ int main(int argc, char** argv) {
   const int n_vis = n_px + n_br, bw = vs.bw, np = 6 * n_cp, ncb = 6 * bw, ntile = bw * (bw + 1) / 2;
   {
     auto lds_bytes = [&](int r, int l) { return size_t(build_lds_layout(k, bw, r, l).total_doubles) * 8; };
-    if (!choose_build_geometry(k, R ? R : (k == 4 ? 128 : 96), L ? L : (k == 4 ? 12 : 10), size_t(79) * 1024, size_t(156) * 1024, lds_bytes, &R, &L)) return 5;
+    if (!choose_build_geometry(k, R ? R : (k == 4 ? 128 : k == 5 ? 112 : 96), L ? L : (k == 4 ? 12 : k == 5 ? 11 : 10), size_t(79) * 1024, size_t(156) * 1024, lds_bytes, &R, &L)) return 5;
   }
   std::vector<int> ch_ptr, gw_ptr, gw_cf, ch_desc;
   if (!build_chunks(vs, n_cp, R, L, &ch_ptr, &gw_ptr, &gw_cf, &ch_desc)) return 6;  // a landmark with more than R residuals: record path in the library
@@ -184,6 +184,8 @@ int main(int argc, char** argv) {
   const size_t lds = size_t(build_lds_layout(k, bw, R, L).total_doubles) * 8;
   if (k == 4)
     run<4>(T, nb_vis, R, L, lds);
+  else if (k == 5)
+    run<5>(T, nb_vis, R, L, lds);
   else if (k == 6)
     run<6>(T, nb_vis, R, L, lds);
   else
@@ -196,6 +198,8 @@ int main(int argc, char** argv) {
   T.step_p = step_p.data(), T.delta_p = delta_p.data(), T.n_norm_part = std::max((n_cp + kBlock - 1) / kBlock, 1), T.norm_part = norm_part.data();
   if (k == 4)
     run_update<4>(T, nb_vis, R, L, &upd);
+  else if (k == 5)
+    run_update<5>(T, nb_vis, R, L, &upd);
   else
     run_update<6>(T, nb_vis, R, L, &upd);
 

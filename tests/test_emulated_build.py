@@ -100,7 +100,7 @@ def _check(exe, oracle, w, radius=1e4, tol=1e-9, **kw):
     return out
 
 
-@pytest.mark.parametrize("order,bearing", [(4, False), (4, True), (6, False)])
+@pytest.mark.parametrize("order,bearing", [(4, False), (4, True), (6, False), (5, False)])
 def test_emulated_fused_build_matches_oracle(harness, oracle, order, bearing):
     w = synthetic.small_visual(order=order, n_cp=14 if order == 4 else 16, n_landmarks=40, obs_pairs=3, bearing=bearing)
     out = _check(harness, oracle, w)

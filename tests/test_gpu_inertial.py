@@ -16,7 +16,7 @@ def test_hip_inertial_matches_golden(idx, hip):
         check_against_golden(p, case, 1e-9)
 
 
-@pytest.mark.parametrize("order,identity", [(4, False), (6, False), (4, True)])
+@pytest.mark.parametrize("order,identity", [(4, False), (6, False), (4, True), (5, False)])
 @pytest.mark.parametrize("robustify", [False, True])
 def test_inertial_linearization_vs_oracle(order, identity, robustify, hip, oracle):
     w = synthetic.small_inertial(order=order, n_cp=18, identity=identity)
@@ -31,7 +31,7 @@ def test_inertial_linearization_vs_oracle(order, identity, robustify, hip, oracl
             assert np.array_equal(L[k], Lc[k]), k
 
 
-@pytest.mark.parametrize("order,identity", [(4, False), (6, True)])
+@pytest.mark.parametrize("order,identity", [(4, False), (6, True), (5, False)])
 def test_bordered_reduced_system(order, identity, hip, oracle):
     w = synthetic.small_inertial(order=order, n_cp=18, identity=identity)
     with ha.Problem(w, lib=hip) as g, ha.Problem(w, lib=oracle) as c:
@@ -41,7 +41,7 @@ def test_bordered_reduced_system(order, identity, hip, oracle):
         assert rel(Sg, Sc) < 1e-9 and rel(gg, gc) < 1e-9, (rel(Sg, Sc), rel(gg, gc))
 
 
-@pytest.mark.parametrize("order,identity,grav_const", [(4, False, False), (6, True, False), (4, True, True)])
+@pytest.mark.parametrize("order,identity,grav_const", [(4, False, False), (6, True, False), (4, True, True), (5, False, False)])
 def test_bordered_solve_trajectory(order, identity, grav_const, hip, oracle):
     w = synthetic.small_inertial(order=order, n_cp=18, identity=identity)
     w.gravity_constant = grav_const
@@ -62,7 +62,7 @@ def test_bordered_solve_trajectory(order, identity, grav_const, hip, oracle):
             assert np.array_equal(g.gravity(), w.gravity)
 
 
-@pytest.mark.parametrize("order,n_cp", [(4, 72), (6, 80)])
+@pytest.mark.parametrize("order,n_cp", [(4, 72), (6, 80), (5, 76)])
 def test_two_ended_bordered_solve(order, n_cp, hip, oracle, monkeypatch):
     """Windows long enough (n_cp >= 4 band widths) for the bordered system to be factored from both ends (k_border_forward2, the y view over
     both ends, border outputs of the two-ended backward sweep): the 5-iteration trajectory against the oracle and, bias points and gravity

@@ -19,6 +19,11 @@ def rel(a, b):
 def windows():
     yield "pixel_k4", synthetic.small_visual(order=4, n_cp=16, n_landmarks=60, obs_pairs=3)
     yield "pixel_k6", synthetic.small_visual(order=6, n_cp=20, n_landmarks=50, obs_pairs=3, seed=8)
+    # order 5 (odd: the segment of a stamp starts (k - 1) / 2 = 2 control points before it, abstract.cpp:89 in integer arithmetic): instantiated since
+    # round 4; visual + priors, and a window long enough for the two-ended factorisation
+    yield "pixel_k5", synthetic.small_visual(order=5, n_cp=18, n_landmarks=50, obs_pairs=3, seed=21)
+    yield "pixel_prior_k5", synthetic.small_visual(order=5, n_cp=18, n_landmarks=40, obs_pairs=4, seed=22, with_priors=30)
+    yield "pixel_two_ended_k5", synthetic.small_visual(order=5, n_cp=66, n_landmarks=150, obs_pairs=3, seed=23, span=0.45)
     wb = synthetic.small_visual(order=4, n_cp=16, n_landmarks=60, obs_pairs=3, bearing=True, seed=9)
     wb.cp_constant = np.r_[np.ones(4, np.uint8), np.zeros(12, np.uint8)]  # frozen old control points fix the gauge (optimizer.cpp:323-328)
     yield "bearing_k4", wb
@@ -170,7 +175,7 @@ def test_sample_trajectory(hip, oracle):
             g.sample_trajectory([hi + 1.0])
 
 
-@pytest.mark.parametrize("order", [4, 6])
+@pytest.mark.parametrize("order", [4, 5, 6])
 def test_process_tracks(order, hip, oracle):
     """Pixel -> bearing conversion and stereo triangulation through the spline (abstract.cpp:197-223,250-255)."""
     w = synthetic.small_visual(order=order, n_cp=14, n_landmarks=10, obs_pairs=2, seed=5)

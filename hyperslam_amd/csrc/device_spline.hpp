@@ -149,6 +149,26 @@ HSD RelPre rel_precompute(const double* cp_prev, const double* cp_next) {
   return p;
 }
 
+/// spline_pose with the relative rotations handed in (rel[j - 1] = rel_precompute(cp + 8 (j - 1), cp + 8 j)): same arithmetic, same result —
+/// the logarithm of a pair (an atan2, two square roots) once per pair of the window instead of once per residual and pair.
+template <int K>
+HSD void spline_pose_pre(const double* cp, const RelPre* rel, const double* lam, Quat* q_out, V3* p_out) {
+  Quat q = load_quat(cp);
+  V3 p = V3{cp[4], cp[5], cp[6]};
+  V3 pprev = p;
+#pragma unroll
+  for (int j = 1; j < K; ++j) {
+    const double* c = cp + 8 * j;
+    double b, cc;
+    q = qmul(q, exp_scaled(rel[j - 1].rr, lam[j], &b, &cc));
+    const V3 pj = V3{c[4], c[5], c[6]};
+    p = p + lam[j] * (pj - pprev);
+    pprev = pj;
+  }
+  *q_out = qnormalized(q);
+  *p_out = p;
+}
+
 /// spline_pose_jac with the relative rotations handed in: rel[j - 1] = rel_precompute(cp + 8 (j - 1), cp + 8 j). Same arithmetic, same result.
 template <int K>
 HSD void spline_pose_jac_pre(const double* cp, const RelPre* rel, const double* lam, Quat* q_out, V3* p_out, M3* G) {

@@ -175,14 +175,17 @@ HSD void visual_core(const Tables& T, const double* cps, const VisualIn& in, boo
 /// Value-only cost 0.5 * rho(|r|^2) of a visual residual block from preloaded inputs (residual-only branch, exteroceptive.cpp:104-122):
 /// what visual_cost computes, for callers that staged the inputs themselves.
 template <int K>
-HSD double visual_cost_in(const Tables& T, const double* cps, const VisualIn& in) {
+HSD double visual_cost_in(const Tables& T, const double* cps, const VisualIn& in, const RelPre* rel = nullptr /* indexed like cps: pair (j, j + 1) at rel[j] */) {
   double u;
   segment_of(in.stamp, T.sp.t0, T.sp.dt, K, &u);
   double lam[K], dl[1], ddl[1];
   basis_weights<K>(T.basis, u, T.sp.inv_dt, lam, dl, ddl, 0);
   Quat qw;
   V3 pw;
-  spline_pose<K>(cps + 8 * in.first, lam, &qw, &pw);
+  if (rel)
+    spline_pose_pre<K>(cps + 8 * in.first, rel + in.first, lam, &qw, &pw);
+  else
+    spline_pose<K>(cps + 8 * in.first, lam, &qw, &pw);
   const V3 ps = to_sensor(qw, pw, in.cam, V3{in.lm[0], in.lm[1], in.lm[2]}, nullptr, nullptr);
   double r[2], dummy[6];
   visual_measure(in.type, ps, in.cam, in.meas, false, r, dummy);

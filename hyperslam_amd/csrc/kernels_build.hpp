@@ -642,7 +642,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
 // lm_cand until this kernel passes over it (DevState::spec == 4).
 // ---------------------------------------------------------------------------------------------------------------------
 __host__ __device__ inline int update_lds_doubles(int bw, int R, int Lmax) {
-  return 14 * bw + 4 * Lmax * bw + 8 * Lmax + 16 * kBuildCams + R + 8 + Lmax + 8;  // (.. + l_ncp, l_yoff: 2 Lmax ints)
+  return 14 * bw + 4 * Lmax * bw + 8 * Lmax + 16 * kBuildCams + R + 8 + Lmax + 8 + 8 * bw;  // (.. + l_ncp, l_yoff: 2 Lmax ints; + relative rotations of the candidate window)
 }
 
 template <int K>
@@ -731,6 +731,7 @@ __global__ void __launch_bounds__(kBlock) k_update_visual(Tables T, int R, int L
   double* cpart = costs + R;                  // [8]
   int* l_ncp = reinterpret_cast<int*>(cpart + 8);
   int* l_yoff = l_ncp + Lmax;
+  RelPre* relp = reinterpret_cast<RelPre*>(cpart + 8 + Lmax + 8);  // relative rotations of the window's consecutive CANDIDATE control points
   // residual inputs (independent of everything below: requested first)
   const int rt = R > 128 ? tid : (tid >> 6) == 0 ? tid : (tid >> 6) == 2 ? tid - 64 : kBlock;  // (record <-> lane as in k_build_visual: waves 0 and 2)
   const bool has_rec = rt < nres;
@@ -772,6 +773,7 @@ __global__ void __launch_bounds__(kBlock) k_update_visual(Tables T, int R, int L
   }
   __syncthreads();
   if (uprof) ulog[2] = wall_clock64();  // tables staged
+  if ((tid >> 6) == 3 && (tid & 63) + 1 < ncp_w) relp[tid & 63] = rel_precompute(cps_c + 8 * (tid & 63), cps_c + 8 * (tid & 63) + 8);  // (read behind the next barriers)
   // partial dot products, one (landmark, control point) block per lane: the 6 x 3 block of Y-hat is 18 consecutive doubles in HBM
   const int n_task = nl * bw;
   for (int tau = tid; tau < n_task; tau += kBlock) {
@@ -830,7 +832,7 @@ __global__ void __launch_bounds__(kBlock) k_update_visual(Tables T, int R, int L
   if (has_rec) {
     in.cam = camid < kBuildCams ? cams + 16 * camid : T.cam + kCamStride * camid;
     in.lm[0] = lmc[8 * my_l], in.lm[1] = lmc[8 * my_l + 1], in.lm[2] = lmc[8 * my_l + 2];
-    costs[rt] = visual_cost_in<K>(T, cps_c - 8 * cf, in);
+    costs[rt] = visual_cost_in<K>(T, cps_c - 8 * cf, in, relp - cf);
   }
   __syncthreads();
   if (uprof) ulog[5] = wall_clock64();  // candidate costs

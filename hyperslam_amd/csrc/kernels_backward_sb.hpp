@@ -125,7 +125,7 @@ HSD void sb_inverse(const Tables& T, const BackJob& J, int job, int s, double* l
     dst[e] = (a < nr && c < nr) ? V[a * LD + c] : 0.0;
   }
   if (!raise_flag) return;
-  __threadfence();  // (the wave's stores: one instruction stream)
+  // (the release store waits for every store of the wave — one instruction stream, one counter — and writes the L2 back: no fence of its own in front)
   if (l == 0) {
     __hip_atomic_store(T.join_flag + kSbFlagBase + kSbMaxBlocks * job + s, T.join_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     if (iprof) ilog[3] = wall_clock64();  // flag raised
@@ -262,7 +262,7 @@ HSD void sb_sweep(const Tables& T, const BackJob& j0, const BackJob& j1, const i
   if (solver && !prebuilt) {
     for (int i = l; i < n_sb; i += 64) sb_wait(T, flags + i);
     if (phase_a && l <= sA_top - sA_pub) sb_wait(T, T.join_flag + kSbFlagBase + sA_pub + l);  // the near job's top super-blocks
-    __threadfence();
+    // (every poll is an acquire load of the wave: the caches it must not read stale lines from were invalidated by the last of them)
   }
   const int s_top = n_sb - 1;
   double ringA[kSbPrefetch][12];  // phase A: operands of the near factor's top super-blocks, all requested at once

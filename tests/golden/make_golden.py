@@ -388,10 +388,19 @@ def main():
                     "prior": ["u0", "u1", "near_pi", "near_pi", "cp_near_pi"],
                     "inertial": ["u0", "u1", "identity", "identity", "cp_near_pi", "gravity_pivot", "gravity_pivot_neg"]}[ftype]
             plan += [(ftype, k, v) for v in edge]
+    # `--order5` (round 4): a file of its own, factors_k5.json — order 5 is instantiated on the device since then; 9 random + 3 targeted cases
+    # per factor (the segment of a stamp starts (k - 1) // 2 = 2 control points before it), own random stream
+    order5 = "--order5" in sys.argv
+    if order5:
+        plan = []
+        for ftype in ("pixel", "bearing", "prior", "inertial"):
+            plan += [(ftype, 5, None)] * 9 + [(ftype, 5, v) for v in ("u0", "u1", "cp_near_pi")]
+        rng = SplitMix64(0x48595045 ^ 0x0B5E5)
     # second block (own random stream, appended behind the first so that the cases above keep their values): the inertial factor has the
     # most parameter blocks and gets as many random cases per order as the other factors, 32 with its edge cases
     n_first = len(plan)
-    plan += [("inertial", k, None) for k in (4, 6) for _ in range(13)]
+    if not order5:
+        plan += [("inertial", k, None) for k in (4, 6) for _ in range(13)]
     rng2 = SplitMix64(0x48595045 ^ 0x1E127)
     only_second = "--second-block-only" in sys.argv  # (re-uses the first block of an existing factors.json: minutes instead of an hour)
     if only_second:
@@ -447,7 +456,7 @@ def main():
                 out["pose"] = tofloat(q + p)
                 cases.append({"type": ftype, "variant": variant, "inputs": P, "outputs": out})
                 print(ftype, k, rep, variant, "ok", flush=True)
-    with open(os.path.join(HERE, "factors.json"), "w") as f:
+    with open(os.path.join(HERE, "factors_k5.json" if order5 else "factors.json"), "w") as f:
         json.dump({"generator": "tests/golden/make_golden.py (mpmath, 100 digits)", "cases": cases}, f, indent=None, separators=(",", ":"))
     print("wrote", len(cases), "cases")
 

@@ -289,3 +289,11 @@ def test_process_tracks_matches_golden(hip):
     """hs_process_tracks against the 100-digit vectors of tests/golden/make_tracks_golden.py (same bar as the oracle's CPU test)."""
     from util import check_tracks_against_golden
     assert check_tracks_against_golden(hip, 1e-9) <= 1e-9
+
+
+def test_hip_matches_golden_order5(hip):
+    """Order 5 against its own 100-digit vectors (tests/golden/factors_k5.json): every factor incl. the inertial one, every parameter block."""
+    from util import golden_cases_k5
+    for case in golden_cases_k5():
+        with ha.Problem(golden_window(case), lib=hip) as p:
+            check_against_golden(p, case, 1e-9)

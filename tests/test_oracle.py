@@ -29,6 +29,16 @@ def test_oracle_matches_golden(idx, oracle):
         check_against_golden(p, case, 1e-9)
 
 
+def test_oracle_matches_golden_order5(oracle):
+    """Order 5 (instantiated on the device since round 4): 48 independent 100-digit cases, 12 per factor, every parameter block."""
+    from util import golden_cases_k5
+    cases = golden_cases_k5()
+    assert len(cases) == 48 and {c["inputs"]["k"] for c in cases} == {5}
+    for case in cases:
+        with ha.Problem(golden_window(case), lib=oracle) as p:
+            check_against_golden(p, case, 1e-9)
+
+
 def test_oracle_matches_literal_inertial_golden(oracle):
     """The default inertial Jacobian (as written upstream) off the identity point: 32 cases, orders 4 and 6."""
     from util import check_against_literal_golden, literal_inertial_cases

@@ -50,6 +50,12 @@ def golden_cases():
         return _overlay_cases(json.load(f)["cases"], "factors.json")
 
 
+def golden_cases_k5():
+    """Order 5 (tests/golden/make_golden.py --order5): 48 cases, 12 per factor."""
+    with open(os.path.join(HERE, "golden", "factors_k5.json")) as f:
+        return _overlay_cases(json.load(f)["cases"], "factors_k5.json")
+
+
 def golden_window(case) -> Window:
     """One-residual window reproducing a golden case (tests/golden/make_golden.py)."""
     P = case["inputs"]

@@ -534,6 +534,7 @@ auto main(int argc, char** argv) -> int {
   const std::string in = argv[1], out = argv[2];
   dumpCases(in + "/factors.json", out + "/factors.json", factorCase);
   dumpCases(in + "/inertial_literal.json", out + "/inertial_literal.json", factorCase);
+  dumpCases(in + "/factors_k5.json", out + "/factors_k5.json", factorCase);  // order 5 (instantiated on the device since round 4)
   dumpCases(in + "/manifolds.json", out + "/manifolds.json", manifoldCase);
   for (const auto* name : {"solve.json", "solve_visual.json"}) {
     std::ofstream os{out + "/" + name};

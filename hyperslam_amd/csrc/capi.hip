@@ -573,7 +573,7 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
     }
     if (stages && !p->fused) HIP_TRY(hipEventRecord(ev[4 * it + 1], s));
     hipEvent_t after_build = stages && p->fused ? ev[4 * it + 1] : nullptr;  // fused build: the linearise stage ends behind k_build_visual
-    HS_ORDER_SWITCH(p->k, rc = launch_build<K>(p, after_build));
+    HS_ORDER_SWITCH(p->k, rc = launch_build<K>(p, after_build, it > 0));
     if (rc) return rc;
     if (stages) HIP_TRY(hipEventRecord(ev[4 * it + 2], s));
     rc = launch_factor(p);

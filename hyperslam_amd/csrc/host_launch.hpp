@@ -111,10 +111,21 @@ static int border_zero_wgs(const Tables& T) { return std::min(64, (T.nb * T.nb +
 
 /// `after_build` (stage timing of a fused build): recorded behind k_build_visual — the launch that linearises the visual factors belongs to
 /// the "linearise" stage of hs_summary, what follows it (segment Gram of the prior / inertial records, assembly, finalisation) to "schur".
+/// launch_factor's rule for the two-ended look-ahead factorisation (k_band_factor_la, grid 2) of a system without border unknowns.
+static bool factor_two_ended_la(const hs_problem* p) {
+  const Tables& T = p->T;
+  const int n_blk = T.np / 6;
+  return T.nb == 0 && !(T.debug_flags & 4) && la_compute_waves(T.bw) > 0 && !HS_AB(T.debug_flags, 131072) && n_blk >= 4 * T.bw && T.Sb2 && !(T.debug_flags & 2048);
+}
+
+/// scaling_fixed: a step of this solve has been computed (every linearisation but the first): the Jacobi scaling is fixed, and on a single
+/// shard without border unknowns whose factorisation is the two-ended look-ahead kernel k_assemble writes the scaled, damped system itself
+/// (direct mode) — no k_finalize_reduced launch; the iteration bookkeeping moves into the factorisation's prologue (Tables::bookkeep).
 template <int K>
-int launch_build(hs_problem* p, hipEvent_t after_build = nullptr) {
+int launch_build(hs_problem* p, hipEvent_t after_build = nullptr, bool scaling_fixed = false) {
   const Tables& T = p->T;
   hipStream_t s = p->stream;
+  p->bookkeep = false;
   // k_seg_gram only needs the records, k_landmark -> k_group_gram records and landmarks: the two gram kernels share one launch
   // (k_gram_pair). A/B switch 1024: the previous arrangement, k_seg_gram on a side stream next to k_landmark -> k_group_gram.
   // (for small grids only — configs[1]: ~940 workgroups, Schur stage 66 -> 62 us. The pair holds 80 KB of LDS per workgroup, two per
@@ -186,7 +197,14 @@ int launch_build(hs_problem* p, hipEvent_t after_build = nullptr) {
     k_seg_gram<K><<<p->n_seg_wg, kBlock, kSegStage * sizeof(double), s>>>(T);
   }
   if (fork) HIP_TRY(hipStreamWaitEvent(s, p->ev_join, 0));
-  k_assemble<K><<<dim3(T.sp.n_cp, 6), kAsmThreads, 0, s>>>(T);
+  const bool direct = scaling_fixed && fused && !T.nb && !p->allreduce && !p->rccl_comm && p->world == 1 && factor_two_ended_la(p) &&
+                      !(T.debug_flags & 4096);  // A/B switch 4096: k_finalize_reduced in every iteration
+  k_assemble<K><<<dim3(T.sp.n_cp, 6), kAsmThreads, 0, s>>>(T, direct ? 1 : 0);
+  if (direct) {
+    p->bookkeep = true;
+    HIP_TRY(hipGetLastError());
+    return HS_OK;
+  }
   if (T.nb && !side_imu) {
     k_border_pb<K><<<dim3(T.sp.n_cp + border_zero_wgs(T), p->n_split), kPbThreads, 0, s>>>(T);
     k_border_bb<K><<<T.n_bias, kBlock, 0, s>>>(T);
@@ -301,6 +319,7 @@ int launch_factor(hs_problem* p) {
     T2.mj[0] = MfmaJob{p->d_Sb2.p, T.g_s, T.Ub, T.Ubk, T.ybuf, p->d_win.p, m + w_mid, m, m + w_mid, INT_MAX, 0, p->d_Vb.p + size_t(T.np) * (6 * T.bw)};
     T2.mj[1] = MfmaJob{T.Sb, p->d_g2.p, p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, p->d_win.p, mB, -1, mB + w_mid, mB, 1, p->d_Vb.p + size_t(T.np) * (6 * T.bw)};
     T2.join_epoch = ++p->join_epoch;
+    T2.bookkeep = p->bookkeep && !nt ? 1 : 0;
     if (nt)
       HIP_TRY(run_mfma(T2, 2));
     else

@@ -226,9 +226,11 @@ struct hs_problem {
   int n_seg_wg = 0, n_group_wg = 0;
   // fused build of the visual factors (kernels_build.hpp)
   bool fused = false;
+  bool bookkeep = false;            // this linearisation's rows were finalised by k_assemble: the factorisation does the iteration bookkeeping (launch_build)
   int build_R = 0, build_L = 0;     // records per pass, landmarks per chunk
   size_t build_lds = 0;
   DBuf<int> d_ch_ptr, d_ch_desc;
+  DBuf<double> d_ch_gmax;
   std::vector<int> h_ch_ptr, h_gw_ptr, h_gw_cf, h_ch_desc;
   DBuf<double> d_ybuf, d_scale_b, d_Spb, d_Sbb, d_gb_s, d_D2b, d_Zb, d_Cb, d_hb, d_xb, d_delta_b, d_bias_g_snap, d_bias_a_snap, d_gravity_snap;
   DBuf<int> d_i_bias_ptr, d_bfwd_start;
@@ -541,6 +543,7 @@ int prepare(hs_problem* p) {
   p->nb_pri = (n_pri + kBlock - 1) / kBlock;
   p->nb_cp = std::max((p->n_cp + kBlock - 1) / kBlock, 1);
   HIP_TRY(p->d_cost_part.reserve(p->nb_vis + p->nb_pri + (n_ine + kBlock - 1) / kBlock + 1));
+  HIP_TRY(p->d_ch_gmax.reserve(size_t(p->nb_vis) + 1));
   HIP_TRY(p->d_cand_part.reserve(p->nb_vis + p->nb_pri + (n_ine + kBlock - 1) / kBlock + 1));
   const int nb_norm = p->nb_cp;
   HIP_TRY(p->d_norm_part.reserve(2 * size_t(nb_norm)));
@@ -682,6 +685,7 @@ int prepare(hs_problem* p) {
   T.x_count1 = x_count1, T.xo_dec = x_count1;
   T.fused = p->fused ? 1 : 0, T.n_chunk = p->fused ? p->n_group_wg : 0, T.ch_ptr = p->d_ch_ptr.p, T.ch_desc = p->d_ch_desc.p;
   T.build_stream_lg = p->fused ? build_streams_packed(vs.bw, k) : 0;
+  T.ch_gmax = p->d_ch_gmax.p;
   T.rank = p->rank, T.world = p->world;
   // HS_DEBUG_FLAGS (measurement switches only, never needed for correct operation):
   //    1 skip the backward sweep          2 skip the rank-6 updates (timing of the panel chain alone; results are garbage)

@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
   const double radius = st->radius;
   if (st_done) return;
   if (w >= T.n_chunk) {  // padding workgroups of the visual section of the cost-partial table
-    if (tid == 0) T.cost_part[w] = 0.0;
+    if (tid == 0) T.cost_part[w] = 0.0, T.ch_gmax[w] = 0.0;
     return;
   }
   constexpr int CS = build_rec_stride<K>();
@@ -473,6 +473,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
     for (int e = 0; e < 6; e += 2) *reinterpret_cast<double2*>(dst + 36 + e) = make_double2(pg[e], pg[e + 1]);
   }
   // ---- 4a: V = S_l H_ll S_l + D_l^2 = L L' per landmark (landmark_finish of k_landmark); the last wave, which holds the fewest tiles ----
+  double lane_gmax = 0.0;  // (last wave: max |b_l| of this lane's landmark; reduced over the chunk below)
   if (tid >= kBlock - 64 && tid - (kBlock - 64) < nl) {
     const int l = tid - (kBlock - 64), dl = lo + l;
     double* li = Linv + kLinv * l;
@@ -510,8 +511,14 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
     T.lm_yhat[3 * dl] = yy0, T.lm_yhat[3 * dl + 1] = yy1, T.lm_yhat[3 * dl + 2] = yy2;
     T.lm_sb[3 * dl] = sb0, T.lm_sb[3 * dl + 1] = sb1, T.lm_sb[3 * dl + 2] = sb2;
     T.lm_D2[3 * dl] = d0, T.lm_D2[3 * dl + 1] = d1, T.lm_D2[3 * dl + 2] = d2;
-    T.lm_gmax[dl] = active ? fmax(fabs(b0), fmax(fabs(b1), fabs(b2))) : 0.0;
+    lane_gmax = active ? fmax(fabs(b0), fmax(fabs(b1), fabs(b2))) : 0.0;
+    T.lm_gmax[dl] = lane_gmax;
     if (fresh) T.lm_scale[3 * dl] = sl0, T.lm_scale[3 * dl + 1] = sl1, T.lm_scale[3 * dl + 2] = sl2;
+  }
+  if (tid >= kBlock - 64) {  // the chunk's landmark-side gradient max norm (one value per chunk for the bookkeeping of k_band_factor_la)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lane_gmax = fmax(lane_gmax, __shfl_xor(lane_gmax, o));
+    if (tid == kBlock - 64) T.ch_gmax[w] = lane_gmax;
   }
   __syncthreads();
   HS_BSTAMP(8);

@@ -510,9 +510,14 @@ constexpr int kAsmThreads = 512, kAsmU = 6;  // lanes per scalar row, loads in f
 /// Scalar row rho = 6 i + a of the raw (unscaled, undamped) reduced system from the segment and group partials; writes xbuf
 /// directly. Grid (n_cp, 6). The sources of an entry are dealt round-robin to `nsl` thread slices (loads of a slice are
 /// issued kAsmU at a time), the slices are combined through LDS in index order: fixed summation order, bit-reproducible.
+/// direct = 1 (single shard, no border unknowns, Jacobi scaling fixed — every linearisation of a solve but the first — and a factorisation that
+/// does the iteration bookkeeping itself, Tables::bookkeep): the row is scaled, damped and written in the factorisation's layout right here,
+///     S = Sp Sraw Sp + D_p^2,  g = Sp (g_p + g_schur),  g_full = Sp g_p,  D_p^2 = clamp(Sp^2 diag(J'J), 1e-6, 1e32) / radius
+/// (what k_finalize_reduced does with a launch of its own: ~6 us on the chain of an iteration, most of it launch latency).
 template <int K>
-__global__ void __launch_bounds__(kAsmThreads, 6) k_assemble(Tables T) {  // (see kAsmThreads)
+__global__ void __launch_bounds__(kAsmThreads, 6) k_assemble(Tables T, int direct) {  // (see kAsmThreads)
   __shared__ double part[3][kAsmThreads];
+  __shared__ double gpair[2];
   // phase timestamps (profiling builds, HS_DEBUG_FLAGS 64; tools/assemble_phase_timing.py): lane 0 of every workgroup
   const bool aprof = prof_enabled(T.debug_flags, 64) && threadIdx.x == 0;
   long long* alog = reinterpret_cast<long long*>(T.xpart) + 128 * 1024 + 8 * (blockIdx.y * gridDim.x + blockIdx.x);
@@ -527,6 +532,13 @@ __global__ void __launch_bounds__(kAsmThreads, 6) k_assemble(Tables T) {  // (se
   const int c0 = max(0, i - bw + 1);
   const int nent = ncb + 2;  // band entries + [J'r | Y-hat y-hat] of this row
   const int nsl = max(1, kAsmThreads / nent), sl = tid / nent, c = tid % nent;
+  // direct mode: scaling of this row and of the lane's column, trust-region radius (requested with the work lists)
+  double d_sr = 1.0, d_sc = 1.0, d_radius = 1.0;
+  if (direct) {
+    d_sr = T.scale_p[6 * i + a];
+    if (tid < ncb && 6 * i + tid < T.np) d_sc = T.scale_p[6 * i + tid];
+    d_radius = T.st->radius;
+  }
   double va = 0.0, vb = 0.0;  // J'J part / Schur part
   double vp = 0.0;            // fused build: the chunk partials carry J_p'J_p inside their tiles; J_p'r (lane ncb) and diag J_p'J_p (lane a) ride along
   if (sl < nsl) {
@@ -612,13 +624,52 @@ __global__ void __launch_bounds__(kAsmThreads, 6) k_assemble(Tables T) {  // (se
     double sa = 0.0, sb = 0.0, sx = 0.0;
     for (int q = 0; q < nsl; ++q) sa += part[0][q * nent + tid], sb += part[1][q * nent + tid], sx += part[2][q * nent + tid];
     const int rho = 6 * i + a;
-    if (tid < ncb) {
+    if (direct) {
+      if (tid < ncb) {
+        const int sigma = 6 * i + tid;
+        double out = 0.0;
+        if (sigma < T.np) {
+          out = d_sr * d_sc * (sa + sb);
+          if (tid == a) {
+            const double d = sa + sx;  // diag J'J
+            if (d > 0.0) {
+              const double d2 = fmin(fmax(d_sr * d_sr * d, 1e-6), 1e32) / d_radius;
+              out += d2;
+              T.D2p[rho] = d2;
+            } else {  // structurally zero column (constant / unobserved): keep the system non-singular, step = 0
+              out = 1.0;
+              T.D2p[rho] = 0.0;
+            }
+          }
+        }
+        T.Sb[size_t(rho) * ncb + tid] = out;
+        if (T.Sb2 && sigma < T.np) {  // reversed copy for the far end of the two-ended factorisation (k_finalize_reduced)
+          const int rv = T.np - 1 - sigma, cv = T.np - 1 - rho;
+          T.Sb2[size_t(rv) * ncb + (cv - 6 * (rv / 6))] = out;
+        }
+      } else if (tid == ncb) {
+        gpair[0] = sa + sx;
+      } else {
+        gpair[1] = sb;
+      }
+    } else if (tid < ncb) {
       T.xbuf[size_t(rho) * ncb + tid] = sa + sb;
       if (tid == a) T.xbuf[T.xo_dj + rho] = sa + sx;  // diag J'J: segment partials (priors, inertial; records path: visual too) + chunk partials
     } else if (tid == ncb) {
       T.xbuf[T.xo_g + rho] = sa + sx;
     } else {
       T.xbuf[T.xo_gs + rho] = sb;
+    }
+  }
+  if (direct) {
+    __syncthreads();
+    if (tid == 0) {
+      const int rho = 6 * i + a;
+      const double gp = gpair[0], gs = gpair[1];
+      T.g_full[rho] = d_sr * gp;
+      T.g_s[rho] = d_sr * (gp + gs);
+      if (T.Sb2) T.g2[T.np - 1 - rho] = d_sr * (gp + gs);
+      T.gabs[rho] = fabs(gp);
     }
   }
   if (aprof) alog[6] = wall_clock64();

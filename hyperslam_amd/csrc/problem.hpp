@@ -220,6 +220,9 @@ struct Tables {
   // gw_ptr / gw_cf then list the chunks of a group and grpQ holds one partial [tiles | -Yh yh | J_p'r | diag J_p'J_p] per chunk
   int fused, n_chunk;
   int build_stream_lg;   // fused build: log2 of the record streams per band tile, two bits per diagonal offset (kernels_build.hpp: build_streams)
+  double* ch_gmax;       // fused build: max |J_l' r| over the landmarks of chunk w (what the direct bookkeeping reads instead of 5 000 per-landmark values)
+  int bookkeep;          // k_band_factor_la: the iteration bookkeeping (cost, gradient max norm, termination tests) is done in the factorisation's
+                         // prologue — k_assemble wrote the scaled, damped system itself and k_finalize_reduced was not launched (launch_build)
   const int* ch_ptr;
   const int* ch_desc;  // n_chunk x 8: first landmark, landmarks, first control point, first residual, residuals (one 32-byte load per workgroup)
   int rank, world;

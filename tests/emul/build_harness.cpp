@@ -42,8 +42,24 @@ struct Reader {
 template <int K>
 static void run(Tables& T, int nb_vis, int R, int L, size_t lds) {
   hs_emul::launch(dim3(nb_vis), dim3(kBlock), lds, [&] { k_build_visual<K>(T, R, L, 1); });
-  hs_emul::launch(dim3(T.sp.n_cp, 6), dim3(kAsmThreads), 0, [&] { k_assemble<K>(T); });
+  hs_emul::launch(dim3(T.sp.n_cp, 6), dim3(kAsmThreads), 0, [&] { k_assemble<K>(T, 0); });
   hs_emul::launch(dim3(T.sp.n_cp + 1), dim3(kBlock), 0, [&] { k_finalize_reduced(T, 1); });
+  // Direct mode of k_assemble (scaling fixed: every linearisation of a solve but the first): the same partials scaled, damped and written in
+  // the factorisation's layout by k_assemble itself must reproduce k_finalize_reduced's output BIT FOR BIT (same operations on the same sums).
+  if (T.st->scaling_ready == 0) {  // (first pass of this process: the scaling was just fixed by the finalisation above)
+    const size_t nS = size_t(T.np) * 6 * T.bw;
+    std::vector<double> Sb(nS), g_s(T.np), g_full(T.np), D2p(T.np), gabs(T.np + 8);
+    Tables D = T;
+    D.Sb = Sb.data(), D.g_s = g_s.data(), D.g_full = g_full.data(), D.D2p = D2p.data(), D.gabs = gabs.data(), D.Sb2 = nullptr, D.g2 = nullptr;
+    hs_emul::launch(dim3(T.sp.n_cp, 6), dim3(kAsmThreads), 0, [&] { k_assemble<K>(D, 1); });
+    bool same = true;
+    for (size_t e = 0; e < nS; ++e) same &= Sb[e] == T.Sb[e];
+    for (int e = 0; e < T.np; ++e) same &= g_s[e] == T.g_s[e] && g_full[e] == T.g_full[e] && D2p[e] == T.D2p[e] && gabs[e] == T.gabs[e];
+    if (!same) {
+      fprintf(stderr, "k_assemble direct mode differs from k_finalize_reduced\n");
+      exit(7);
+    }
+  }
 }
 
 /// The candidate point two ways: k_update_visual (per chunk) against k_backsub_retract + k_cost_visual (per landmark / per residual).
@@ -162,7 +178,8 @@ int main(int argc, char** argv) {
   T.n_lm = n_lm, T.lm = lm_dev.data(), T.lm_cand = lm_dev.data(), T.lm_const = lmc_dev.data();
   T.lm_ptr = vs.lm_ptr.data(), T.lm_cfirst = vs.lm_cfirst.data(), T.lm_ncp = vs.lm_ncp.data(), T.lm_yoff = vs.lm_yoff.data(), T.cf_ptr = vs.cf_ptr.data();
   T.lm_scale = lm_scale.data(), T.lm_L = lm_L.data(), T.lm_yhat = lm_yhat.data(), T.lm_sb = lm_sb.data(), T.lm_D2 = lm_D2.data();
-  T.lm_gmax = lm_gmax.data(), T.Y = Y.data();
+  std::vector<double> ch_gmax(size_t(nb_vis) + 1);
+  T.lm_gmax = lm_gmax.data(), T.Y = Y.data(), T.ch_gmax = ch_gmax.data();
   {
     int n_obs = n_lm;
     while (n_obs > 0 && vs.lm_ptr[n_obs] == vs.lm_ptr[n_obs - 1]) --n_obs;

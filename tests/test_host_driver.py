@@ -163,8 +163,8 @@ def check_lockstep(calls, summary, n_calls, slides):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seconds,imu,order,n_calls", [(3.6, 0, 4, 35), (3.6, 1, 4, 35), (6.0, 1, 6, 59), (6.0, 1, 4, 59)],
-                         ids=["stereo_k4_sliding", "stereo_inertial_k4_sliding", "stereo_inertial_k6_6s", "stereo_inertial_k4_6s"])
+@pytest.mark.parametrize("seconds,imu,order,n_calls", [(3.6, 0, 4, 35), (3.6, 1, 4, 35), (6.0, 1, 6, 59), (6.0, 1, 4, 59), (3.6, 1, 5, 35)],
+                         ids=["stereo_k4_sliding", "stereo_inertial_k4_sliding", "stereo_inertial_k6_6s", "stereo_inertial_k4_6s", "stereo_inertial_k5_sliding"])
 def test_replay_lockstep_hip_vs_oracle(built, seconds, imu, order, n_calls):
     """BASELINE.json configs[4] (synthetic EuRoC-shaped replay): the window grows to max_window = 3.0 s and slides (control points
     are frozen and dropped, landmarks retired: abstract.cpp:139-143, optimizer.cpp:286-382); every optimize() of the HIP library is

@@ -49,6 +49,20 @@ int main(int argc, char** argv) {
   dump(out, "lm_ptr", vs.lm_ptr), dump(out, "lm_cfirst", vs.lm_cfirst), dump(out, "lm_ncp", vs.lm_ncp), dump(out, "lm_yoff", vs.lm_yoff);
   dump(out, "cf_ptr", vs.cf_ptr);
   fprintf(out, "bw 1 %d\ny_total 1 %d\n", vs.bw, vs.y_total);
+  // chunks of the fused build (build_chunks) and their dispatch order on machines of 8 and 256 compute units (order_chunks_for_dispatch)
+  const int R = argc > 3 ? atoi(argv[3]) : 138, L = argc > 4 ? atoi(argv[4]) : 14;
+  std::vector<int> ch_ptr, gw_ptr, gw_cf, ch_desc;
+  if (hs::build_chunks(vs, vi.n_cp, R, L, &ch_ptr, &gw_ptr, &gw_cf, &ch_desc)) {
+    const int n = int(ch_ptr.size()) - 1;
+    dump(out, "ch_ptr", ch_ptr), dump(out, "gw_ptr", gw_ptr), dump(out, "gw_cf", gw_cf), dump(out, "ch_desc", ch_desc);
+    for (int n_cu : {8, 256}) {
+      std::vector<int> d = ch_desc;
+      hs::order_chunks_for_dispatch(vs, vi.k, n_cu, &d, n);
+      dump(out, n_cu == 8 ? "ch_desc_cu8" : "ch_desc_cu256", d);
+    }
+  } else {
+    fprintf(out, "ch_ptr 0\n");
+  }
   fclose(out);
   return 0;
 }

@@ -183,14 +183,14 @@ __global__ void __launch_bounds__(64) k_band_backward_w(Tables T, BackJob j0, Ba
   };
   const int j_pub = (blockIdx.x == 0 && m_mid >= 0 && gridDim.x == 2) ? m_mid : -1;  // block 0 publishes the middle solution after block row m_mid
   auto flush = [&](int lo, int hi) {  // own-order rows [lo, hi) of the solution: LDS -> HBM (natural order)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wait_lds();
     for (int rho = lo + lane; rho < hi; rho += 64) T.xsol[J.reversed ? np - 1 - rho : rho] = xs[rho];
   };
   auto publish = [&]() {
     // rows [6 m_mid, 6 n_rows) of the solution: store them, release them at agent scope, raise the flag
     flush(6 * m_mid, 6 * n_rows);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_vmem();
     if (lane == 0) __hip_atomic_store(T.join_flag, T.join_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   // Rounds of D block rows; the last round may run past block row 0 (steps with j < 0 find nothing alive and store nothing).
@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(64) k_band_backward_w(Tables T, BackJob j0, Ba
   if (prof) tlog[3] = wall_clock64();
   // ---- the block that finishes last turns the solution into the step outputs (join_flag[1] advances by gridDim.x per launch) ----
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wait_vmem();
   int last = 1;
   if (gridDim.x == 2) {
     unsigned prev = 0;

@@ -57,7 +57,7 @@ HSD void sb_inverse(const Tables& T, const BackJob& J, int job, int s, double* l
   const int l = threadIdx.x & 63;
   constexpr int LD = kSbN + 1;
   // one wave: LDS operations complete in program order; only the compiler and the counters must keep it
-#define HS_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define HS_WAVE_SYNC() wait_lds()
   double* U = lds;
   double* V = lds + kSbN * LD;
   double* Tm = lds + 2 * kSbN * LD;
@@ -80,7 +80,7 @@ HSD void sb_inverse(const Tables& T, const BackJob& J, int job, int s, double* l
       w[u] = (e < kSb * 21 && 6 * jb < nr) ? J.Ubk[size_t(kSb * s + jb) * 24 + e % 21] : 0.0;
     }
     for (int e = l; e < 2 * kSbN * LD; e += 64) lds[e] = 0.0;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wave: LDS is in order; only the compiler must keep the order
+    wait_lds();  // one wave: LDS is in order; only the compiler must keep the order
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       const int e = l + 64 * u;

@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(kBlock) k_border_bb(Tables T) {
   // reset by the zero-fill workgroups of k_border_pb, in front of this kernel on the same stream): a launch of its own ended the side-stream
   // chain with 4.6 us of latency
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wait_vmem();
   if (atomicAdd(T.join_flag + 2, 1u) != gridDim.x - 1) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   double h[5] = {0, 0, 0, 0, 0};
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(kBlock) k_border_forward(Tables T, int j_lo, i
         }
       }
       if (tid < 64 && m + 1 < n_blk) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave 0: its rows of block row m + 1 are final
+        wait_lds();  // wave 0: its rows of block row m + 1 are final
         diag_solve(m + 1, wr[d]);
       }
       request(m + D, ur[d], wr[d]);
@@ -499,7 +499,7 @@ __global__ void __launch_bounds__(kBlock) k_border_forward2(Tables T, BfJob j0, 
         __syncthreads();
       }
       if (tid < 64 && m + 1 < n_rows) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_lds();
         diag_solve(m + 1, wr[d]);
       }
       request(m + D, ur[d], wr[d]);

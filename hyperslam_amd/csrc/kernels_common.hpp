@@ -44,7 +44,13 @@ HSD double wave_sum(double v) {
 
 /// Workgroup barrier that only drains LDS traffic: global loads / stores stay in flight across it (the factorisation
 /// prefetches the next band row while the current step runs; __syncthreads() would wait for vmcnt(0) every step).
+/// wait_lds / wait_vmem: this wave's LDS / global-memory operations have completed (one wave's LDS traffic is in order: between lanes of a
+/// wave this is all the synchronisation an LDS hand-over needs). The CPU emulation harness of the tests supplies its own three.
+#ifndef HS_EMULATED_DEVICE
 HSD void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+HSD void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+HSD void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
 
 /// Deterministic block sum (fixed butterfly inside each wave, waves combined in index order). Result valid on thread 0.
 HSD double block_sum(double v, double* lds /* >= blockDim/64 */) {

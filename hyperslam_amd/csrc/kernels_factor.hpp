@@ -756,7 +756,7 @@ __global__ void __launch_bounds__(la_threads(NCW)) k_band_factor_la(Tables T) {
   const bool cprof = prof_enabled(T.debug_flags, 16) && tid == 0;  // coarse phases of this workgroup -> tlog[8 (200 + 10 job) + ..]
   long long* clog = reinterpret_cast<long long*>(T.xpart) + 8 * (200 + 10 * blockIdx.x);
   if (cprof) clog[0] = wall_clock64();  // tiles requested
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wait_vmem();
   if (cprof) clog[1] = wall_clock64();  // tiles loaded
   lds_barrier();  // init
   lds_barrier();  // prologue: X_0 complete

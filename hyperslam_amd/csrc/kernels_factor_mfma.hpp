@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(64 * (NC + 3)) k_band_factor_mfma(Tables T) {
           gring[pos] = acc;
         }
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (same wave: the stores above are visible to the loads below)
+      wait_lds();  // (same wave: the stores above are visible to the loads below)
       if (l < 6) rowbuf[(i & 1) * 6 * LDX + l * LDX + W] = gring[ring_add<W>(p_i, 12) + l];  // right-hand side of block row i + 2 -> panel
       {  // W = U_ii^-1 (upper triangular, packed): lane c < 6 solves U w = e_c. U_ii sits at the pivot's own positions of X (upper part)
         const int c = l < 6 ? l : 0;
@@ -433,7 +433,7 @@ __global__ void __launch_bounds__(64 * (NC + 3)) k_band_factor_mfma(Tables T) {
         }
       }
       if (prof) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_lds();
         plog[8 * r + 4] = wall_clock64();
       }
     };
@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(64 * (NC + 3)) k_band_factor_mfma(Tables T) {
 #pragma unroll
         for (int a = 0; a < 6; ++a) dscr[6 * a + l] = v[0][a];
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave: LDS is in order, only the compiler must not reorder
+      wait_lds();  // same wave: LDS is in order, only the compiler must not reorder
       double U[21], inv[6], dmin;
       {
         int pidx = 0;

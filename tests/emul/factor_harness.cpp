@@ -1,0 +1,79 @@
+// factor_harness.cpp — TEST INFRASTRUCTURE (tests/test_emulated_factor.py): the look-ahead band Cholesky of the reduced system, compiled FROM
+// THE PRODUCT'S KERNEL SOURCE for the host (tests/emul/hip/hip_runtime.h: one std::thread per lane) and run on a band system a Python test
+// hands over.
+//   k_band_factor_la<1, NCW>     (hyperslam_amd/csrc/kernels_factor.hpp), one-ended (grid 1) and from both ends (grid 2),
+// with the jobs set up the way launch_factor (host_launch.hpp) sets them up. Output: the factor rows, the inverted diagonal blocks and the
+// forward-solved right-hand side of each job — compared by the test with numpy's Cholesky factor of the same matrix (near end: its leading
+// rows; far end: the leading rows of the reversed matrix; middle rows: the factor of the Schur complement both ends leave on them).
+// Usage: factor_harness <system.bin> <out.bin>
+#include <algorithm>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "hip/hip_runtime.h"
+
+thread_local dim3 threadIdx;
+dim3 blockIdx, blockDim, gridDim;
+
+#include "../../hyperslam_amd/csrc/kernels_common.hpp"
+#include "../../hyperslam_amd/csrc/kernels_factor.hpp"
+
+namespace hs {
+HSD void begin_iteration(const Tables&, double, double, bool) {}  // (Tables::bookkeep = 0 in the harness: never reached)
+}  // namespace hs
+
+using namespace hs;
+
+template <class T>
+static std::vector<T> read_vec(FILE* f, size_t n) {
+  std::vector<T> v(n);
+  if (n && fread(v.data(), sizeof(T), n, f) != n) {
+    fprintf(stderr, "short read\n");
+    exit(2);
+  }
+  return v;
+}
+static void write_vec(FILE* f, const std::vector<double>& v) { fwrite(v.data(), sizeof(double), v.size(), f); }
+
+int main(int argc, char** argv) {
+  if (argc < 3) return 1;
+  FILE* in = fopen(argv[1], "rb");
+  if (!in) return 1;
+  const std::vector<int> hdr = read_vec<int>(in, 4);  // np, bw, two-ended, 0
+  const int np = hdr[0], bw = hdr[1], two_ended = hdr[2], ncb = 6 * bw, n_blk = np / 6, w_mid = bw - 1;
+  const std::vector<double> Sb = read_vec<double>(in, size_t(np) * ncb), g = read_vec<double>(in, np);
+  const std::vector<double> Sb2 = read_vec<double>(in, size_t(np) * ncb), g2 = read_vec<double>(in, np);  // the reversed system
+  fclose(in);
+  const int ncw = la_compute_waves(bw);
+  if (ncw == 0 || (two_ended && n_blk < 4 * bw)) {
+    fprintf(stderr, "band width / length outside the look-ahead kernel's range\n");
+    return 3;
+  }
+  std::vector<double> Ub(size_t(np) * ncb, 0.0), Ubk(size_t(24) * n_blk, 0.0), yb(np, 0.0), Ub2 = Ub, Ubk2 = Ubk, yb2 = yb;
+  std::vector<double> win(size_t(6 * w_mid) * (ncb + 1), 0.0), xpart(8 * 1024, 0.0);
+  DevState st{};
+  unsigned join_flag = 0;
+  Tables T{};
+  T.np = np, T.bw = bw, T.st = &st, T.join_flag = &join_flag, T.join_epoch = 1, T.xpart = xpart.data();
+  const size_t la_lds = (size_t(42) * (ncb + 2) + size_t(np) + 48) * sizeof(double);  // launch_factor
+  int m = -1, mB = 0;
+  if (two_ended) {  // launch_factor: the near end takes three block rows more than the far end
+    m = std::min((n_blk - w_mid) / 2 + 3, n_blk - w_mid - w_mid), mB = n_blk - w_mid - m;
+    T.fj[0] = FactorJob{Sb.data(), g.data(), Ub.data(), Ubk.data(), yb.data(), win.data(), m + w_mid, m};
+    T.fj[1] = FactorJob{Sb2.data(), g2.data(), Ub2.data(), Ubk2.data(), yb2.data(), win.data(), mB, -1};
+  } else {
+    T.fj[0] = FactorJob{Sb.data(), g.data(), Ub.data(), Ubk.data(), yb.data(), nullptr, n_blk, -1};
+  }
+  const dim3 grid(two_ended ? 2 : 1);
+  if (ncw == 3)
+    hs_emul::launch(grid, dim3(la_threads(3)), la_lds, [&] { k_band_factor_la<1, 3>(T); }, true);
+  else
+    hs_emul::launch(grid, dim3(la_threads(4)), la_lds, [&] { k_band_factor_la<1, 4>(T); }, true);
+  FILE* out = fopen(argv[2], "wb");
+  const int res[4] = {m, mB, st.chol_failed, 0};
+  fwrite(res, sizeof(int), 4, out);
+  write_vec(out, Ub), write_vec(out, Ubk), write_vec(out, yb), write_vec(out, Ub2), write_vec(out, Ubk2), write_vec(out, yb2);
+  fclose(out);
+  return 0;
+}

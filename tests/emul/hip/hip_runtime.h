@@ -25,6 +25,7 @@
 #define __shared__ static
 #define __launch_bounds__(...)
 #define HS_DYNAMIC_LDS(name) double* name = hs_emul::dynamic_lds()
+#define HS_EMULATED_DEVICE 1  // kernels_common.hpp leaves lds_barrier / wait_lds / wait_vmem to this header
 
 struct dim3 {
   unsigned x, y, z;
@@ -143,6 +144,18 @@ inline unsigned long long __ballot(bool pred) {
 }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline void __builtin_amdgcn_wave_barrier() {}
+inline void __builtin_amdgcn_sched_barrier(int) {}
+inline void __builtin_amdgcn_s_sleep(int) { std::this_thread::yield(); }
+/// The LDS-only workgroup barrier and the wave-level waits of kernels_common.hpp: every memory operation of a host thread is complete when
+/// the next one starts, so the waits are empty and the barrier is the workgroup barrier.
+inline void lds_barrier() { __syncthreads(); }
+inline void wait_lds() {}
+inline void wait_vmem() {}
+inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+#define __HIP_MEMORY_SCOPE_AGENT 0
+#define __hip_atomic_load(ptr, order, scope) __atomic_load_n(ptr, order)
+#define __hip_atomic_store(ptr, value, order, scope) __atomic_store_n(ptr, value, order)
 inline double __builtin_amdgcn_rsq(double d) { return 1.0 / std::sqrt(d); }
 inline long long wall_clock64() { return 0; }
 inline unsigned __builtin_amdgcn_s_getreg(int) { return 0; }
@@ -162,14 +175,16 @@ using std::sqrt;
 
 namespace hs_emul {
 
-/// Runs `kernel` for every workgroup of the grid, one after the other; one thread per lane.
-inline void launch(dim3 grid, dim3 block_dim, size_t lds_bytes, const std::function<void()>& kernel) {
+/// Runs `kernel` for every workgroup of the grid, one after the other; one thread per lane. reverse_x: workgroups in descending blockIdx.x
+/// (a kernel whose workgroup 0 waits for a flag of workgroup 1 — the two-ended factorisation — needs its producer to run first).
+inline void launch(dim3 grid, dim3 block_dim, size_t lds_bytes, const std::function<void()>& kernel, bool reverse_x = false) {
   Block& b = block();
   b.lds.assign(lds_bytes / 8 + 64, 0.0);
   gridDim = grid, blockDim = block_dim;
   const int n = int(block_dim.x);
   for (unsigned by = 0; by < grid.y; ++by)
-    for (unsigned bx = 0; bx < grid.x; ++bx) {
+    for (unsigned ix = 0; ix < grid.x; ++ix) {
+      const unsigned bx = reverse_x ? grid.x - 1 - ix : ix;
       blockIdx = dim3(bx, by, 0);
       b.barrier.reset(n);
       for (int w = 0; w < (n + 63) / 64; ++w) b.wave_barrier[w].reset(n - 64 * w < 64 ? n - 64 * w : 64);

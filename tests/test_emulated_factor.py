@@ -1,0 +1,143 @@
+"""The look-ahead band Cholesky of the reduced system (hyperslam_amd/csrc/kernels_factor.hpp: k_band_factor_la — the longest kernel of an
+iteration) compiled from the product's source for the HOST (tests/emul/: one thread per lane) and checked against numpy's dense Cholesky on
+CPU: factor rows, inverted diagonal blocks and the forward-solved right-hand side, one-ended and from both ends (the far end on the reversed
+system, the middle rows as the factor of the Schur complement both ends leave on them: launch_factor's job layout, host_launch.hpp).
+The `-m gpu` tests (test_every_band_width, test_band_widths_from_both_ends) remain the parity tests of the compiled kernel; this one makes
+its index arithmetic — ring slots, look-ahead, hand-over of the far end's window in the near end's coordinates — checkable without a GPU.
+Replaces what CHOLMOD does for /root/reference/internal/hyper/optimizers/ceres/optimizer.cpp:46-48 (SPARSE_NORMAL_CHOLESKY)."""
+import os
+import shutil
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMUL = os.path.join(ROOT, "tests", "emul")
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    exe = str(tmp_path_factory.mktemp("emul_factor") / "factor_harness")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-I", EMUL, "-o", exe, os.path.join(EMUL, "factor_harness.cpp")])
+    return exe
+
+
+def banded_spd(rng, n_blk, bw):
+    """Symmetric positive definite, block (i, j) non-zero iff |i - j| < bw: a sum of window Gram matrices, as the reduced system is."""
+    n = 6 * n_blk
+    M = np.zeros((n, n))
+    for s in range(n_blk):
+        e = min(s + bw, n_blk)
+        J = rng.standard_normal((3 * (e - s), 6 * (e - s)))
+        M[6 * s:6 * e, 6 * s:6 * e] += J.T @ J
+    M += np.diag(rng.uniform(0.5, 1.5, n))
+    d = 1.0 / np.sqrt(np.diag(M))  # Jacobi scaled, like the system the kernel sees
+    return M * d[:, None] * d[None, :] + 1e-3 * np.eye(n)
+
+
+def band_rows(M, bw):
+    """Row rho stores M[rho][6 (rho / 6) + c], c < 6 bw (zero beyond the matrix): the kernels' band layout (kernels_factor.hpp header)."""
+    n, ncb = len(M), 6 * bw
+    B = np.zeros((n, ncb))
+    for r in range(n):
+        c0 = 6 * (r // 6)
+        w = min(ncb, n - c0)
+        B[r, :w] = M[r, c0:c0 + w]
+    return B
+
+
+def check_job(Ub, Ubk, yb, U, y, rows, bw, col_limit=None):
+    """Rows [0, rows) of a job against the upper factor U (job coordinates) and y = U^-T g. The kernel leaves the diagonal and the lower part
+    of a diagonal block unspecified (never read: the sweeps use the inverted blocks)."""
+    ncb = 6 * bw
+    n = len(U)
+    for r in range(rows):
+        c0 = 6 * (r // 6)
+        lim = n if col_limit is None else col_limit
+        for c in range(r - c0 + 1, ncb):
+            want = U[r, c0 + c] if c0 + c < lim else 0.0
+            assert abs(Ub[r, c] - want) <= 1e-11 * max(1.0, abs(want)), (r, c, Ub[r, c], want)
+    for i in range(rows // 6):
+        W = np.linalg.inv(U[6 * i:6 * i + 6, 6 * i:6 * i + 6])
+        for a in range(6):
+            for c in range(a, 6):
+                got = Ubk[24 * i + a * 6 - a * (a - 1) // 2 + (c - a)]
+                assert abs(got - W[a, c]) <= 1e-10 * max(1.0, abs(W[a, c])), (i, a, c)
+    assert np.allclose(yb[:rows], y[:rows], rtol=0, atol=1e-11)
+
+
+def run(exe, tmp_path, M, g, bw, two_ended):
+    n = len(M)
+    P = np.arange(n)[::-1]
+    src, dst = str(tmp_path / "sys.bin"), str(tmp_path / "out.bin")
+    with open(src, "wb") as f:
+        f.write(struct.pack("=4i", n, bw, int(two_ended), 0))
+        for a in (band_rows(M, bw), g, band_rows(M[np.ix_(P, P)], bw), g[P]):
+            f.write(np.ascontiguousarray(a, dtype="<f8").tobytes())
+    subprocess.check_call([exe, src, dst], timeout=600)
+    raw = open(dst, "rb").read()
+    m, mB, failed, _ = struct.unpack("=4i", raw[:16])
+    v = np.frombuffer(raw[16:], dtype="<f8")
+    ncb, nU, nK = 6 * bw, n * 6 * bw, 24 * (n // 6)
+    parts, o = [], 0
+    for size in (nU, nK, n, nU, nK, n):
+        parts.append(v[o:o + size])
+        o += size
+    assert failed == 0
+    return m, mB, parts[0].reshape(n, ncb), parts[1], parts[2], parts[3].reshape(n, ncb), parts[4], parts[5]
+
+
+@pytest.mark.parametrize("n_blk,bw", [(20, 4), (17, 6), (30, 14), (24, 16), (9, 5)])
+def test_one_ended_factor_against_numpy(n_blk, bw, harness, tmp_path):
+    rng = np.random.default_rng(100 * n_blk + bw)
+    M = banded_spd(rng, n_blk, bw)
+    g = rng.standard_normal(6 * n_blk)
+    _, _, Ub, Ubk, yb, _, _, _ = run(harness, tmp_path, M, g, bw, False)
+    U = np.linalg.cholesky(M).T
+    check_job(Ub, Ubk, yb, U, np.linalg.solve(U.T, g), 6 * n_blk, bw)
+
+
+@pytest.mark.parametrize("n_blk,bw", [(20, 4), (58, 14), (31, 6), (64, 16), (40, 10)])
+def test_two_ended_factor_against_numpy(n_blk, bw, harness, tmp_path):
+    rng = np.random.default_rng(7 * n_blk + bw)
+    M = banded_spd(rng, n_blk, bw)
+    n = 6 * n_blk
+    g = rng.standard_normal(n)
+    m, mB, Ub, Ubk, yb, Ub2, Ubk2, yb2 = run(harness, tmp_path, M, g, bw, True)
+    w = bw - 1
+    assert m + w + mB == n_blk and m >= mB
+    # near end: the leading rows of the factor of M; far end: the leading rows of the factor of the reversed matrix
+    U = np.linalg.cholesky(M).T
+    check_job(Ub, Ubk, yb, U, np.linalg.solve(U.T, g), 6 * m, bw)
+    P = np.arange(n)[::-1]
+    U2 = np.linalg.cholesky(M[np.ix_(P, P)]).T
+    check_job(Ub2, Ubk2, yb2, U2, np.linalg.solve(U2.T, g[P]), 6 * mB, bw)
+    # middle rows: factor of the Schur complement that eliminating both ends leaves on them (entries that coupled to the far end are zero)
+    t, mid, b = np.arange(0, 6 * m), np.arange(6 * m, 6 * (m + w)), np.arange(6 * (m + w), n)
+    A, h = M[np.ix_(mid, mid)].copy(), g[mid].copy()
+    for e in (t, b):
+        X = np.linalg.solve(M[np.ix_(e, e)], np.column_stack([M[np.ix_(e, mid)], g[e]]))
+        A -= M[np.ix_(mid, e)] @ X[:, :-1]
+        h -= M[np.ix_(mid, e)] @ X[:, -1]
+    Um = np.linalg.cholesky(A).T
+    # in the job's own coordinates: rows 6 m .. of a matrix whose leading part is irrelevant for the comparison
+    Ufull = np.zeros((6 * (m + w), 6 * (m + w)))
+    Ufull[6 * m:, 6 * m:] = Um
+    yfull = np.zeros(6 * (m + w))
+    yfull[6 * m:] = np.linalg.solve(Um.T, h)
+    ncb = 6 * bw
+    for r in range(6 * m, 6 * (m + w)):
+        c0 = 6 * (r // 6)
+        for c in range(r - c0 + 1, ncb):
+            want = Ufull[r, c0 + c] if c0 + c < 6 * (m + w) else 0.0
+            assert abs(Ub[r, c] - want) <= 1e-10 * max(1.0, abs(want)), (r, c, Ub[r, c], want)
+    assert np.allclose(yb[6 * m:6 * (m + w)], yfull[6 * m:], rtol=0, atol=1e-10)
+    for i in range(m, m + w):
+        W = np.linalg.inv(Ufull[6 * i:6 * i + 6, 6 * i:6 * i + 6])
+        for a in range(6):
+            for c in range(a, 6):
+                assert abs(Ubk[24 * i + a * 6 - a * (a - 1) // 2 + (c - a)] - W[a, c]) <= 1e-9 * max(1.0, abs(W[a, c]))

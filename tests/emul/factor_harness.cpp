@@ -2,9 +2,11 @@
 // THE PRODUCT'S KERNEL SOURCE for the host (tests/emul/hip/hip_runtime.h: one std::thread per lane) and run on a band system a Python test
 // hands over.
 //   k_band_factor_la<1, NCW>     (hyperslam_amd/csrc/kernels_factor.hpp), one-ended (grid 1) and from both ends (grid 2),
-// with the jobs set up the way launch_factor (host_launch.hpp) sets them up. Output: the factor rows, the inverted diagonal blocks and the
+//   k_band_backward_sb           (kernels_backward_sb.hpp): the sweeps in super-blocks of four block rows + their inverse builders,
+// with the jobs and launch shapes launch_factor (host_launch.hpp) uses. Output: the factor rows, the inverted diagonal blocks and the
 // forward-solved right-hand side of each job — compared by the test with numpy's Cholesky factor of the same matrix (near end: its leading
-// rows; far end: the leading rows of the reversed matrix; middle rows: the factor of the Schur complement both ends leave on them).
+// rows; far end: the leading rows of the reversed matrix; middle rows: the factor of the Schur complement both ends leave on them) — and
+// the solution, the step, the scaled step and the two sums of the model cost change, compared with numpy's solve.
 // Usage: factor_harness <system.bin> <out.bin>
 #include <algorithm>
 #include <cstdio>
@@ -18,6 +20,7 @@ dim3 blockIdx, blockDim, gridDim;
 
 #include "../../hyperslam_amd/csrc/kernels_common.hpp"
 #include "../../hyperslam_amd/csrc/kernels_factor.hpp"
+#include "../../hyperslam_amd/csrc/kernels_backward_sb.hpp"
 
 namespace hs {
 HSD void begin_iteration(const Tables&, double, double, bool) {}  // (Tables::bookkeep = 0 in the harness: never reached)
@@ -44,6 +47,7 @@ int main(int argc, char** argv) {
   const int np = hdr[0], bw = hdr[1], two_ended = hdr[2], ncb = 6 * bw, n_blk = np / 6, w_mid = bw - 1;
   const std::vector<double> Sb = read_vec<double>(in, size_t(np) * ncb), g = read_vec<double>(in, np);
   const std::vector<double> Sb2 = read_vec<double>(in, size_t(np) * ncb), g2 = read_vec<double>(in, np);  // the reversed system
+  const std::vector<double> scale_p = read_vec<double>(in, np), g_full = read_vec<double>(in, np), D2p = read_vec<double>(in, np);
   fclose(in);
   const int ncw = la_compute_waves(bw);
   if (ncw == 0 || (two_ended && n_blk < 4 * bw)) {
@@ -53,9 +57,9 @@ int main(int argc, char** argv) {
   std::vector<double> Ub(size_t(np) * ncb, 0.0), Ubk(size_t(24) * n_blk, 0.0), yb(np, 0.0), Ub2 = Ub, Ubk2 = Ubk, yb2 = yb;
   std::vector<double> win(size_t(6 * w_mid) * (ncb + 1), 0.0), xpart(8 * 1024, 0.0);
   DevState st{};
-  unsigned join_flag = 0;
+  std::vector<unsigned> join_flag(kSbFlagBase + 2 * kSbMaxBlocks, 0u);
   Tables T{};
-  T.np = np, T.bw = bw, T.st = &st, T.join_flag = &join_flag, T.join_epoch = 1, T.xpart = xpart.data();
+  T.np = np, T.bw = bw, T.st = &st, T.join_flag = join_flag.data(), T.join_epoch = 1, T.xpart = xpart.data();
   const size_t la_lds = (size_t(42) * (ncb + 2) + size_t(np) + 48) * sizeof(double);  // launch_factor
   int m = -1, mB = 0;
   if (two_ended) {  // launch_factor: the near end takes three block rows more than the far end
@@ -66,14 +70,45 @@ int main(int argc, char** argv) {
     T.fj[0] = FactorJob{Sb.data(), g.data(), Ub.data(), Ubk.data(), yb.data(), nullptr, n_blk, -1};
   }
   const dim3 grid(two_ended ? 2 : 1);
+  const std::vector<unsigned> far_first = {1, 0};  // (workgroup 0 waits at the junction for workgroup 1's window)
   if (ncw == 3)
-    hs_emul::launch(grid, dim3(la_threads(3)), la_lds, [&] { k_band_factor_la<1, 3>(T); }, true);
+    hs_emul::launch(grid, dim3(la_threads(3)), la_lds, [&] { k_band_factor_la<1, 3>(T); }, two_ended ? far_first : std::vector<unsigned>{});
   else
-    hs_emul::launch(grid, dim3(la_threads(4)), la_lds, [&] { k_band_factor_la<1, 4>(T); }, true);
+    hs_emul::launch(grid, dim3(la_threads(4)), la_lds, [&] { k_band_factor_la<1, 4>(T); }, two_ended ? far_first : std::vector<unsigned>{});
+  // ---- the sweeps (launch_factor: the inverses of the diagonal super-blocks come from extra workgroups of the same launch) ----
+  std::vector<double> Vb(size_t(sb_count(n_blk) + 1) * kSbN * kSbN, 0.0), Vb2 = Vb, xsol(np, 0.0), step_p(np, 0.0), delta_p(np, 0.0);
+  T.join_epoch = 2;
+  T.scale_p = const_cast<double*>(scale_p.data()), T.g_full = const_cast<double*>(g_full.data()), T.D2p = const_cast<double*>(D2p.data());
+  T.xsol = xsol.data(), T.step_p = step_p.data(), T.delta_p = delta_p.data();
+  if (6 * (bw - 1) > 96) {
+    fprintf(stderr, "band too wide for the super-block sweep\n");
+    return 3;
+  }
+  if (two_ended) {
+    const BackJob j0{Ub.data(), Ubk.data(), yb.data(), Vb.data(), nullptr, m + w_mid, 0, 0};
+    const BackJob j1{Ub2.data(), Ubk2.data(), yb2.data(), Vb2.data(), nullptr, mB, w_mid, 1};
+    const size_t g_lds = size_t(6 * (bw - 1)) * (6 * (bw - 1) | 1) * sizeof(double);
+    const size_t lds = std::max((2 * size_t(np) + 32) * sizeof(double) + g_lds + sb_phase_a_doubles(bw) * sizeof(double), size_t(3 * kSbN * (kSbN + 1)) * sizeof(double));
+    const unsigned n_wg = 2 + sb_count(m + w_mid) + sb_count(mB);
+    std::vector<unsigned> order;  // builders, then the near sweep (publishes the middle solution when the far one does not redo it), then the far sweep
+    for (unsigned w = 2; w < n_wg; ++w) order.push_back(w);
+    order.push_back(0), order.push_back(1);
+    hs_emul::launch(dim3(n_wg), dim3(kCholThreads), lds, [&] { k_band_backward_sb(T, j0, j1, m, 2, 0); }, order);
+  } else {
+    const BackJob j0{Ub.data(), Ubk.data(), yb.data(), Vb.data(), nullptr, n_blk, 0, 0};
+    const size_t lds = std::max((2 * size_t(np) + 32) * sizeof(double), size_t(3 * kSbN * (kSbN + 1)) * sizeof(double));
+    const unsigned n_wg = 1 + sb_count(n_blk);
+    std::vector<unsigned> order;
+    for (unsigned w = 1; w < n_wg; ++w) order.push_back(w);
+    order.push_back(0);
+    hs_emul::launch(dim3(n_wg), dim3(kCholThreads), lds, [&] { k_band_backward_sb(T, j0, j0, -1, 1, 0); }, order);
+  }
   FILE* out = fopen(argv[2], "wb");
   const int res[4] = {m, mB, st.chol_failed, 0};
   fwrite(res, sizeof(int), 4, out);
   write_vec(out, Ub), write_vec(out, Ubk), write_vec(out, yb), write_vec(out, Ub2), write_vec(out, Ubk2), write_vec(out, yb2);
+  write_vec(out, xsol), write_vec(out, step_p), write_vec(out, delta_p);
+  write_vec(out, {st.g_dot_step_pose, st.d2_step2_pose, st.g_dot_step_far, st.d2_step2_far});
   fclose(out);
   return 0;
 }

@@ -146,10 +146,11 @@ inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline void __builtin_amdgcn_wave_barrier() {}
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __builtin_amdgcn_s_sleep(int) { std::this_thread::yield(); }
-/// The LDS-only workgroup barrier and the wave-level waits of kernels_common.hpp: every memory operation of a host thread is complete when
-/// the next one starts, so the waits are empty and the barrier is the workgroup barrier.
+/// The LDS-only workgroup barrier and the wave-level waits of kernels_common.hpp. On the GPU the lanes of a wave run in lock step, so
+/// "this wave's LDS operations have completed" is all an LDS hand-over between lanes of ONE wave needs; here the lanes are threads, and the
+/// same call sites need a barrier over the wave (every live lane of the wave reaches them: they sit in wave-uniform control flow).
 inline void lds_barrier() { __syncthreads(); }
-inline void wait_lds() {}
+inline void wait_lds() { hs_emul::block().wave_barrier[threadIdx.x >> 6].arrive_and_wait(); }
 inline void wait_vmem() {}
 inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
@@ -175,16 +176,17 @@ using std::sqrt;
 
 namespace hs_emul {
 
-/// Runs `kernel` for every workgroup of the grid, one after the other; one thread per lane. reverse_x: workgroups in descending blockIdx.x
-/// (a kernel whose workgroup 0 waits for a flag of workgroup 1 — the two-ended factorisation — needs its producer to run first).
-inline void launch(dim3 grid, dim3 block_dim, size_t lds_bytes, const std::function<void()>& kernel, bool reverse_x = false) {
+/// Runs `kernel` for every workgroup of the grid, one after the other; one thread per lane. `order` (optional): the blockIdx.x values in the
+/// order they are run — a kernel whose workgroups wait for flags of other workgroups (the two-ended factorisation, the sweeps and their
+/// inverse builders) needs its producers to run first; on the GPU they are resident together.
+inline void launch(dim3 grid, dim3 block_dim, size_t lds_bytes, const std::function<void()>& kernel, const std::vector<unsigned>& order = {}) {
   Block& b = block();
   b.lds.assign(lds_bytes / 8 + 64, 0.0);
   gridDim = grid, blockDim = block_dim;
   const int n = int(block_dim.x);
   for (unsigned by = 0; by < grid.y; ++by)
     for (unsigned ix = 0; ix < grid.x; ++ix) {
-      const unsigned bx = reverse_x ? grid.x - 1 - ix : ix;
+      const unsigned bx = order.empty() ? ix : order[ix];
       blockIdx = dim3(bx, by, 0);
       b.barrier.reset(n);
       for (int w = 0; w < (n + 63) / 64; ++w) b.wave_barrier[w].reset(n - 64 * w < 64 ? n - 64 * w : 64);

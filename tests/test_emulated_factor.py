@@ -1,7 +1,9 @@
 """The look-ahead band Cholesky of the reduced system (hyperslam_amd/csrc/kernels_factor.hpp: k_band_factor_la — the longest kernel of an
 iteration) compiled from the product's source for the HOST (tests/emul/: one thread per lane) and checked against numpy's dense Cholesky on
 CPU: factor rows, inverted diagonal blocks and the forward-solved right-hand side, one-ended and from both ends (the far end on the reversed
-system, the middle rows as the factor of the Schur complement both ends leave on them: launch_factor's job layout, host_launch.hpp).
+system, the middle rows as the factor of the Schur complement both ends leave on them: launch_factor's job layout, host_launch.hpp), followed
+by the backward sweeps in super-blocks with their inverse builders (kernels_backward_sb.hpp: k_band_backward_sb, the far sweep's phase A
+included) against numpy's solve: solution, step, scaled step and both ends' shares of the model cost change.
 The `-m gpu` tests (test_every_band_width, test_band_widths_from_both_ends) remain the parity tests of the compiled kernel; this one makes
 its index arithmetic — ring slots, look-ahead, hand-over of the far end's window in the near end's coordinates — checkable without a GPU.
 Replaces what CHOLMOD does for /root/reference/internal/hyper/optimizers/ceres/optimizer.cpp:46-48 (SPARSE_NORMAL_CHOLESKY)."""
@@ -74,9 +76,11 @@ def run(exe, tmp_path, M, g, bw, two_ended):
     n = len(M)
     P = np.arange(n)[::-1]
     src, dst = str(tmp_path / "sys.bin"), str(tmp_path / "out.bin")
+    aux = np.random.default_rng(n + bw)
+    scale, g_full, d2 = aux.uniform(0.5, 2.0, n), aux.standard_normal(n), aux.uniform(0.0, 1.0, n)  # operands of the step outputs
     with open(src, "wb") as f:
         f.write(struct.pack("=4i", n, bw, int(two_ended), 0))
-        for a in (band_rows(M, bw), g, band_rows(M[np.ix_(P, P)], bw), g[P]):
+        for a in (band_rows(M, bw), g, band_rows(M[np.ix_(P, P)], bw), g[P], scale, g_full, d2):
             f.write(np.ascontiguousarray(a, dtype="<f8").tobytes())
     subprocess.check_call([exe, src, dst], timeout=600)
     raw = open(dst, "rb").read()
@@ -84,10 +88,19 @@ def run(exe, tmp_path, M, g, bw, two_ended):
     v = np.frombuffer(raw[16:], dtype="<f8")
     ncb, nU, nK = 6 * bw, n * 6 * bw, 24 * (n // 6)
     parts, o = [], 0
-    for size in (nU, nK, n, nU, nK, n):
+    for size in (nU, nK, n, nU, nK, n, n, n, n, 4):
         parts.append(v[o:o + size])
         o += size
-    assert failed == 0
+    assert failed == 0 and o == len(v)
+    # ---- the sweeps: solution, step = -x, scaled step, and the two sums of the model cost change (decide_step adds the two ends' shares) ----
+    x = np.linalg.solve(M, g)
+    xsol, step, delta, sums = parts[6:10]
+    assert np.allclose(step, -x, rtol=0, atol=1e-9 * max(1.0, np.abs(x).max()))
+    if two_ended:
+        assert np.array_equal(xsol, -step)
+    assert np.array_equal(delta, scale * step)
+    assert abs(sums[0] + sums[2] - g_full @ step) <= 1e-12 * np.abs(g_full * step).sum()
+    assert abs(sums[1] + sums[3] - (d2 * step) @ step) <= 1e-12 * (d2 * step * step).sum()
     return m, mB, parts[0].reshape(n, ncb), parts[1], parts[2], parts[3].reshape(n, ncb), parts[4], parts[5]
 
 

@@ -550,6 +550,7 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
   if (rc) return rc;
   const bool spec = speculative_solve(p);
   const bool deferred = (spec || fused_visual_only(p)) && !commit_inline(p) && !(p->T.debug_flags & 67108864);  // A/B switch 67108864: k_commit in every iteration
+  const bool fold = fold_decision_into_build(p, deferred);  // the decision of iteration i rides in k_build_visual of iteration i + 1
   rc = reset_state(p, max_iterations, 1e4, spec ? (deferred ? 2 : 1) : (deferred ? 4 : 0));
   if (rc) return rc;
   hipStream_t s = p->stream;
@@ -573,7 +574,7 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
     }
     if (stages && !p->fused) HIP_TRY(hipEventRecord(ev[4 * it + 1], s));
     hipEvent_t after_build = stages && p->fused ? ev[4 * it + 1] : nullptr;  // fused build: the linearise stage ends behind k_build_visual
-    HS_ORDER_SWITCH(p->k, rc = launch_build<K>(p, after_build, it > 0));
+    HS_ORDER_SWITCH(p->k, rc = launch_build<K>(p, after_build, it > 0, it > 0 && fold));
     if (rc) return rc;
     if (stages) HIP_TRY(hipEventRecord(ev[4 * it + 2], s));
     rc = launch_factor(p);
@@ -581,7 +582,7 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
     if (stages) HIP_TRY(hipEventRecord(ev[4 * it + 3], s));
     const bool lin_cand = spec && it + 1 < max_iterations;
     hipEvent_t* lin_ev = stages && lin_cand ? &ev[ev_cand + 2 * it] : nullptr;
-    HS_ORDER_SWITCH(p->k, rc = launch_update<K>(p, lin_cand, deferred, lin_ev));
+    HS_ORDER_SWITCH(p->k, rc = launch_update<K>(p, lin_cand, deferred, lin_ev, fold && it + 1 < max_iterations));
     if (rc) return rc;
     if (deferred && it + 1 == max_iterations) launch_commit(p);  // the last accepted candidate (also when a convergence test ended the solve early)
     if (stages || it + 1 == max_iterations) HIP_TRY(hipEventRecord(ev[4 * it + 4], s));

@@ -121,8 +121,10 @@ static bool factor_two_ended_la(const hs_problem* p) {
 /// scaling_fixed: a step of this solve has been computed (every linearisation but the first): the Jacobi scaling is fixed, and on a single
 /// shard without border unknowns whose factorisation is the two-ended look-ahead kernel k_assemble writes the scaled, damped system itself
 /// (direct mode) — no k_finalize_reduced launch; the iteration bookkeeping moves into the factorisation's prologue (Tables::bookkeep).
+/// fold: the decision of the previous iteration was not launched behind its update (launch_update, fold_decision_into_build): workgroup 0 of
+/// k_build_visual takes it, the chunk workgroups wait for its flag (Tables::fold_decision).
 template <int K>
-int launch_build(hs_problem* p, hipEvent_t after_build = nullptr, bool scaling_fixed = false) {
+int launch_build(hs_problem* p, hipEvent_t after_build = nullptr, bool scaling_fixed = false, bool fold = false) {
   const Tables& T = p->T;
   hipStream_t s = p->stream;
   p->bookkeep = false;
@@ -136,7 +138,12 @@ int launch_build(hs_problem* p, hipEvent_t after_build = nullptr, bool scaling_f
   const bool fork = !fused && T.n_lm > 0 && !pair && !side_imu;
   // Fused build: linearisation, landmark elimination and both Gram terms of the visual factors in one launch; what remains for the segment
   // Gram kernel are the prior / inertial records (none on visual-only windows: no launch)
-  if (fused) k_build_visual<K><<<p->nb_vis, kBlock, p->build_lds, s>>>(T, p->build_R, p->build_L, 1);
+  if (fused && fold) {
+    Tables Tf = T;
+    Tf.fold_decision = 1, Tf.fold_epoch = ++p->join_epoch;
+    k_build_visual<K><<<p->nb_vis + 1, kBlock, p->build_lds, s>>>(Tf, p->build_R, p->build_L, 1);
+  } else if (fused)
+    k_build_visual<K><<<p->nb_vis, kBlock, p->build_lds, s>>>(T, p->build_R, p->build_L, 1);
   if (fused && after_build) HIP_TRY(hipEventRecord(after_build, s));
   if (fork) {
     const int rc = ensure_side_stream(p);
@@ -461,6 +468,14 @@ static bool fused_visual_only(const hs_problem* p) {
   return p->fused && !T.n_pri && !T.n_ine && !T.nb;
 }
 
+/// Fused visual-only windows on one shard with deferred landmarks (k_pack_decision(3): decide + commit the control points): the decision of an
+/// iteration that another one follows is taken by workgroup 0 of that iteration's k_build_visual — nothing else reads the solver state or the
+/// current point between the update and the build, so the one-workgroup kernel and its launch boundary (11 us) leave the chain.
+/// A/B switch 32768: k_pack_decision behind every update.
+static bool fold_decision_into_build(const hs_problem* p, bool deferred_commit) {
+  return fused_visual_only(p) && deferred_commit && !p->allreduce && !p->rccl_comm && p->world == 1 && !(p->T.debug_flags & 32768);
+}
+
 /// Small problems: the decision kernel copies the accepted candidate to x itself (single shard). A/B switch 16777216: always k_commit.
 static bool commit_inline(const hs_problem* p) {
   const Tables& T = p->T;
@@ -468,7 +483,7 @@ static bool commit_inline(const hs_problem* p) {
 }
 
 template <int K>
-int launch_update(hs_problem* p, bool linearize_candidate = false, bool deferred_commit = false, hipEvent_t* lin_events = nullptr) {
+int launch_update(hs_problem* p, bool linearize_candidate = false, bool deferred_commit = false, hipEvent_t* lin_events = nullptr, bool fold_next = false) {
   const Tables& T = p->T;
   hipStream_t s = p->stream;
   if (p->fused) {  // candidate point, landmark back-substitution and the visual candidate cost per chunk, one launch
@@ -497,6 +512,7 @@ int launch_update(hs_problem* p, bool linearize_candidate = false, bool deferred
   const bool local_decision = !p->allreduce && !p->rccl_comm;  // single shard: decide in the packing kernel
   const bool inline_commit = commit_inline(p);
   const bool cps_here = p->fused && deferred_commit;  // fused path: the decision kernel commits the control points, the landmarks stay deferred
+  if (fold_next) return HS_OK;  // (fold_decision_into_build: the next iteration's k_build_visual decides, launch_build(..., fold = true))
   k_pack_decision<<<1, kBlock, 0, s>>>(T, inline_commit ? 2 : local_decision ? (cps_here ? 3 : 1) : 0);
   HIP_TRY(hipGetLastError());
   const int rc = exchange(p, T.xbuf + T.xo_dec, 5);  // candidate cost + norms + landmark-side model-cost terms

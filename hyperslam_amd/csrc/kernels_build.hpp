@@ -169,22 +169,54 @@ HSD void w_ops_apply(const WOps& x, double* wacc) {
     for (int c = 0; c < 3; ++c) wacc[3 * r + c] = fma(jp[0][r], A[c], fma(jp[1][r], A[3 + c], wacc[3 * r + c]));
 }
 
+constexpr int kFoldFlag = 3;  // T.join_flag[kFoldFlag] = Tables::fold_epoch once the decision workgroup of a fold-mode k_build_visual has written the state
+HSD void pack_decision_body(const Tables& T, int decide_here, double* red, unsigned* publish);  // kernels_update.hpp
+/// Bounded wait for the decision workgroup (see wait_for_partner, kernels_factor.hpp): 2 s, then the solve is marked as failed and the caller carries on.
+HSD void fold_wait(const Tables& T) {
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(T.join_flag + kFoldFlag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < T.fold_epoch) {
+    __builtin_amdgcn_s_sleep(2);
+    if (wall_clock64() - t0 > 200000000ll) {
+      T.st->chol_failed = 2;
+      break;
+    }
+  }
+}
+
 template <int K>
 __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int Lmax, int robustify) {
   HS_DYNAMIC_LDS(smem);
-  const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // Fold mode (Tables::fold_decision, visual-only windows on one shard, every iteration of a solve but the first): workgroup 0 of the launch
+  // is the trust-region decision of the previous iteration — the work of k_pack_decision, which was not launched behind that iteration's
+  // update (a launch boundary and a one-workgroup kernel, 11 us, off the chain) — and the chunk workgroups are 1 .. n. They request their
+  // descriptor and the inputs of their residuals (tables that no decision changes), then wait for the decision's flag before they read the
+  // solver state, the control points and the landmarks. Workgroup 0 is dispatched first and waits for nobody.
+  const int fold = T.fold_decision;
+  const int w = int(blockIdx.x) - fold, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   DevState* st = T.st;
+  if (w < 0) {
+    if (st->done) {  // (an earlier iteration ended the solve: nothing to decide, but the chunk workgroups wait for the flag before they look)
+      if (tid == 0) __hip_atomic_store(T.join_flag + kFoldFlag, T.fold_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    pack_decision_body(T, 3, smem, T.join_flag + kFoldFlag);
+    return;
+  }
   // the chunk descriptor and the solver state are requested together (the descriptor table is padded to the grid: always in bounds)
   const int4 d0 = *reinterpret_cast<const int4*>(T.ch_desc + 8 * w);
   const int4 d1 = *reinterpret_cast<const int4*>(T.ch_desc + 8 * w + 4);
   const int nres = d1.x;      // <= R (host: build_chunks)
   const int chunk_id = d1.y;  // slot of this chunk's partial (the descriptors are in dispatch order: order_chunks_for_dispatch)
-  const int st_done = st->done, st_spec = st->spec, st_accepted = st->accepted, st_ready = st->scaling_ready;
-  const double radius = st->radius;
-  if (st_done) return;
-  if (w >= T.n_chunk) {  // padding workgroups of the visual section of the cost-partial table
-    if (tid == 0) T.cost_part[w] = 0.0, T.ch_gmax[w] = 0.0;
-    return;
+  int st_done = 0, st_spec = 0, st_accepted = 0, st_ready = 0;
+  double radius = 0.0;
+  if (!fold) {
+    st_done = st->done, st_spec = st->spec, st_accepted = st->accepted, st_ready = st->scaling_ready;
+    radius = st->radius;
+    if (st_done) return;
+    if (w >= T.n_chunk) {  // padding workgroups of the visual section of the cost-partial table
+      if (tid == 0) T.cost_part[w] = 0.0, T.ch_gmax[w] = 0.0;
+      return;
+    }
   }
   constexpr int CS = build_rec_stride<K>();
   const int bw = T.bw, R6 = 6 * bw, ntile = bw * (bw + 1) / 2, nband = band_tile_count(bw, K), nseg = bw - K + 1;
@@ -216,13 +248,6 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
   if (bprof) blog[i] = wall_clock64()
   HS_BSTAMP(0);
 
-  // Deferred commit of the landmarks (DevState::spec == 4): the candidate accepted by the previous iteration is still only in lm_cand
-  // (k_update_visual copies it on its way); the control points are committed by the decision kernel and always current in T.cp
-  const bool pend = st_spec == 4 && st_accepted;
-  const double* cp_src = T.cp;
-  const double* lm_src = pend ? T.lm_cand : T.lm;
-  const bool fresh = !st_ready;
-
   // ---- 0: every table of the chunk and every input of its residuals in ONE round of independent loads ----
   const int lo = d0.x, nl = d0.y, cf = d0.z, q0 = d0.w;
   // Record t of the chunk is linearised by lane t & 63 of wave 0 (t < 64) or wave 2: a chunk holds <= 128 records, and the hardware puts
@@ -243,6 +268,26 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
     in.stamp = T.v_stamp[q];
     in.meas[0] = T.v_meas[3 * q], in.meas[1] = T.v_meas[3 * q + 1], in.meas[2] = T.v_meas[3 * q + 2];
   }
+  if (fold) {  // the decision of the previous iteration (workgroup 0 of this launch): every lane polls (one request per wave), then reads the state
+    fold_wait(T);
+    st_done = __hip_atomic_load(&st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    st_spec = __hip_atomic_load(&st->spec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    st_accepted = __hip_atomic_load(&st->accepted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    st_ready = __hip_atomic_load(&st->scaling_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    radius = __hip_atomic_load(&st->radius, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (st_done) return;
+    if (w >= T.n_chunk) {
+      if (tid == 0) T.cost_part[w] = 0.0, T.ch_gmax[w] = 0.0;
+      return;
+    }
+  }
+  // Deferred commit of the landmarks (DevState::spec == 4): the candidate accepted by the previous iteration is still only in lm_cand
+  // (k_update_visual copies it on its way); the control points are committed by the decision and always current in T.cp — in fold mode the
+  // decision workgroup copies an accepted candidate there WHILE this workgroup runs, so an accepted point is read from cp_cand
+  const bool pend = st_spec == 4 && st_accepted;
+  const double* cp_src = (fold && st_accepted) ? T.cp_cand : T.cp;
+  const double* lm_src = pend ? T.lm_cand : T.lm;
+  const bool fresh = !st_ready;
   {
     const int ncp_w = min(bw, T.sp.n_cp - cf);
     const double2* s2 = reinterpret_cast<const double2*>(cp_src + 8 * cf);

@@ -201,10 +201,10 @@ HSD void commit_control_points(const Tables& T, int idx, int stride);
 
 /// Second exchange buffer (5 doubles, additive across shards): candidate cost, |x|^2, |x - x+|^2 and the landmark-side
 /// terms of the model cost change. The replicated control-point part of the norms is contributed by rank 0 only.
-__global__ void __launch_bounds__(kBlock) k_pack_decision(Tables T, int decide_here /* no exchange between packing and deciding */) {
-  __shared__ double red[5 * (kBlock / 64)];
+/// publish (fold mode, k_build_visual's decision workgroup): the flag word raised — release, agent scope — as soon as the decision is in the
+/// solver state, BEFORE the accepted control points are copied (the waiting workgroups read an accepted point from cp_cand, nobody reads T.cp).
+HSD void pack_decision_body(const Tables& T, const int decide_here, double* red /* 5 * kBlock / 64 + 1 doubles of LDS */, unsigned* publish) {
   DevState* st = T.st;
-  if (st->done) return;
   // The partial arrays are short (one entry per workgroup of the producing kernels): one combined pass with every load of a round
   // issued before the first use (six separate strided sums cost six memory round trips, 8 us). Fixed order: bit-reproducible.
   double cand = 0.0, xs = 0.0, ss = 0.0, gd = 0.0, dd = 0.0;
@@ -231,21 +231,28 @@ __global__ void __launch_bounds__(kBlock) k_pack_decision(Tables T, int decide_h
   }
   double v5[5] = {cand, xs, ss, gd, dd};
   block_sum_n<5>(v5, red);  // (one pair of barriers for the five sums; the decision takes them from registers, not back from memory)
+  int* accepted = reinterpret_cast<int*>(red + 5 * (kBlock / 64));  // (handed over in LDS: the other waves may hold the state's cache line from their `done` test)
   if (threadIdx.x == 0) {
     double* D = T.xbuf + T.xo_dec;
 #pragma unroll
     for (int e = 0; e < 5; ++e) D[e] = v5[e];
     st->local_cand = v5[0];  // this shard's part (the exchange sums D over the shards)
     if (decide_here) decide_step(T, v5);
+    if (decide_here >= 2) *accepted = st->accepted;
+    if (publish) __hip_atomic_store(publish, T.fold_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (decide_here >= 2) {  // 2, small problems: x <- candidate right here instead of a k_commit launch behind this one;
                            // 3, fused path with deferred landmarks: the control points only (k_build_visual / k_update_visual read T.cp)
-    __shared__ int accepted;  // (handed over in LDS: the other waves may hold the state's cache line from their `done` test)
-    if (threadIdx.x == 0) accepted = st->accepted;
     __syncthreads();
-    if (accepted && decide_here == 2) commit_body(T, threadIdx.x, blockDim.x);
-    if (accepted && decide_here == 3) commit_control_points(T, threadIdx.x, blockDim.x);
+    if (*accepted && decide_here == 2) commit_body(T, threadIdx.x, blockDim.x);
+    if (*accepted && decide_here == 3) commit_control_points(T, threadIdx.x, blockDim.x);
   }
+}
+
+__global__ void __launch_bounds__(kBlock) k_pack_decision(Tables T, int decide_here /* no exchange between packing and deciding */) {
+  __shared__ double red[5 * (kBlock / 64) + 1];
+  if (T.st->done) return;
+  pack_decision_body(T, decide_here, red, nullptr);
 }
 
 /// Trust-region decision of one LM iteration (single lane): step quality, acceptance, radius update, termination tests.

@@ -223,6 +223,10 @@ struct Tables {
   double* ch_gmax;       // fused build: max |J_l' r| over the landmarks of chunk w (what the direct bookkeeping reads instead of 5 000 per-landmark values)
   int bookkeep;          // k_band_factor_la: the iteration bookkeeping (cost, gradient max norm, termination tests) is done in the factorisation's
                          // prologue — k_assemble wrote the scaled, damped system itself and k_finalize_reduced was not launched (launch_build)
+  int fold_decision;     // k_build_visual: workgroup 0 of the launch is the trust-region decision of the PREVIOUS iteration (k_pack_decision was not
+                         // launched behind its update); the chunk workgroups 1 .. wait for join_flag[kFoldFlag] >= fold_epoch before they read the
+                         // solver state and the current point (launch_update / launch_build)
+  unsigned fold_epoch;
   const int* ch_ptr;
   const int* ch_desc;  // n_chunk x 8: first landmark, landmarks, first control point, first residual, residuals (one 32-byte load per workgroup)
   int rank, world;

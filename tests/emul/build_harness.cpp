@@ -5,6 +5,7 @@
 // system, its right-hand side, the cost and the Y-hat rows — compared by the test with the oracle's reduced system of the same window.
 // Usage: build_harness <window.bin> <out.bin>
 #include <cstdio>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -62,9 +63,62 @@ static void run(Tables& T, int nb_vis, int R, int L, size_t lds) {
   }
 }
 
+struct Sizes {
+  size_t grpQ, cost_part, Y, nl;
+};
+
+/// The decision of an iteration inside the NEXT iteration's build (Tables::fold_decision: workgroup 0 of k_build_visual decides, the chunk
+/// workgroups wait for its flag) against k_pack_decision(3) followed by the plain build: solver state, control points and every output of
+/// the build must agree BIT FOR BIT — for an accepted step (the chunks then read the point from cp_cand / lm_cand while workgroup 0 copies
+/// it) and for a rejected one. U: the tables behind k_update_visual (candidate point and the partials the decision sums).
+template <int K>
+static void check_fold(const Tables& U, int nb_vis, int R, int L, size_t lds, const Sizes& z, bool accept) {
+  double cand = 0.0, d3 = 0.0, d4 = 0.0;
+  for (int i = 0; i < nb_vis; ++i) cand += U.cand_part[i];
+  for (int i = 0; i < U.n_lm_part; ++i) d3 += U.lm_part[4 * i + 2], d4 += U.lm_part[4 * i + 3];
+  DevState st0 = *U.st;
+  st0.spec = 4, st0.iteration = 1, st0.max_iterations = 8, st0.scaling_ready = 1;
+  st0.cost = accept ? 1.5 * cand : 0.5 * cand;
+  const double mcc = 2.0 * std::fabs(st0.cost - cand);  // relative decrease +-0.5
+  st0.g_dot_step_pose = -2.0 * mcc - d3 + d4, st0.d2_step2_pose = 0.0, st0.g_dot_step_far = 0.0, st0.d2_step2_far = 0.0;
+  struct Run {
+    DevState st;
+    std::vector<double> cp, grpQ, cost_part, ch_gmax, Y, lm_L, lm_yhat, lm_sb, lm_D2, lm_gmax, xbuf;
+  } run[2];
+  std::vector<unsigned> flags(8, 0u);
+  for (int v = 0; v < 2; ++v) {
+    Run& r = run[v];
+    r.st = st0;
+    r.cp.assign(U.cp, U.cp + 8 * size_t(U.sp.n_cp));
+    r.grpQ.assign(z.grpQ, 1e300), r.cost_part.assign(z.cost_part, -1.0), r.ch_gmax.assign(z.cost_part, -1.0), r.Y.assign(z.Y, 0.0);
+    r.lm_L.assign(6 * z.nl, 0.0), r.lm_yhat.assign(3 * z.nl, 0.0), r.lm_sb.assign(3 * z.nl, 0.0), r.lm_D2.assign(3 * z.nl, 0.0), r.lm_gmax.assign(z.nl, 0.0);
+    r.xbuf.assign(size_t(U.x_count1) + 8, 1e300);
+    Tables V = U;
+    V.st = &r.st, V.cp = r.cp.data(), V.grpQ = r.grpQ.data(), V.cost_part = r.cost_part.data(), V.ch_gmax = r.ch_gmax.data(), V.Y = r.Y.data();
+    V.lm_L = r.lm_L.data(), V.lm_yhat = r.lm_yhat.data(), V.lm_sb = r.lm_sb.data(), V.lm_D2 = r.lm_D2.data(), V.lm_gmax = r.lm_gmax.data(), V.xbuf = r.xbuf.data();
+    V.join_flag = flags.data();
+    if (v == 0) {
+      hs_emul::launch(dim3(1), dim3(kBlock), 0, [&] { k_pack_decision(V, 3); });
+      hs_emul::launch(dim3(nb_vis), dim3(kBlock), lds, [&] { k_build_visual<K>(V, R, L, 1); });
+    } else {
+      V.fold_decision = 1, V.fold_epoch = 5;
+      hs_emul::launch(dim3(nb_vis + 1), dim3(kBlock), lds, [&] { k_build_visual<K>(V, R, L, 1); });
+    }
+  }
+  bool same = std::memcmp(&run[0].st, &run[1].st, sizeof(DevState)) == 0 && run[0].st.accepted == (accept ? 1 : 0) && !run[0].st.done;
+  auto eq = [&](const std::vector<double>& a, const std::vector<double>& b) { same &= std::memcmp(a.data(), b.data(), a.size() * sizeof(double)) == 0; };
+  eq(run[0].cp, run[1].cp), eq(run[0].grpQ, run[1].grpQ), eq(run[0].cost_part, run[1].cost_part), eq(run[0].ch_gmax, run[1].ch_gmax), eq(run[0].Y, run[1].Y);
+  eq(run[0].lm_L, run[1].lm_L), eq(run[0].lm_yhat, run[1].lm_yhat), eq(run[0].lm_sb, run[1].lm_sb), eq(run[0].lm_D2, run[1].lm_D2), eq(run[0].lm_gmax, run[1].lm_gmax);
+  if (accept) same &= std::memcmp(run[1].cp.data(), U.cp_cand, 8 * size_t(U.sp.n_cp) * sizeof(double)) == 0;  // the accepted point was committed
+  if (!same) {
+    fprintf(stderr, "decision folded into k_build_visual differs from k_pack_decision + k_build_visual (%s step)\n", accept ? "accepted" : "rejected");
+    exit(8);
+  }
+}
+
 /// The candidate point two ways: k_update_visual (per chunk) against k_backsub_retract + k_cost_visual (per landmark / per residual).
 template <int K>
-static void run_update(Tables& T, int nb_vis, int R, int L, std::vector<double>* out) {
+static void run_update(Tables& T, int nb_vis, int R, int L, std::vector<double>* out, size_t build_lds, const Sizes& z, bool fold_check) {
   const int n_lm = T.n_lm, n_cp = T.sp.n_cp;
   std::vector<double> lm_cand_a(3 * size_t(std::max(n_lm, 1))), cp_cand_a(8 * size_t(n_cp)), cand_a(nb_vis + 1), norm_a(2 * size_t(T.n_norm_part));
   std::vector<double> lm_part_a(4 * size_t((n_lm + 3) / 4) + 4);
@@ -79,6 +133,7 @@ static void run_update(Tables& T, int nb_vis, int R, int L, std::vector<double>*
   B.lm_cand = lm_cand_b.data(), B.cp_cand = cp_cand_b.data(), B.cand_part = cand_b.data(), B.norm_part = norm_b.data(), B.lm_part = lm_part_b.data();
   B.n_lm_part = nb_vis;
   hs_emul::launch(dim3(nb_vis + B.n_norm_part), dim3(kBlock), size_t(update_lds_doubles(T.bw, R, L)) * 8, [&] { k_update_visual<K>(B, R, L, nb_vis); });
+  if (fold_check) check_fold<K>(B, nb_vis, R, L, build_lds, z, true), check_fold<K>(B, nb_vis, R, L, build_lds, z, false);
   auto sum = [](const std::vector<double>& v, size_t n, size_t stride = 1, size_t off = 0) {
     double s = 0;
     for (size_t i = 0; i < n; ++i) s += v[i * stride + off];
@@ -100,6 +155,7 @@ int main(int argc, char** argv) {
   const int k = hdr[0], n_cp = hdr[1], n_lm = hdr[2], n_px = hdr[3], n_br = hdr[4], n_cam = hdr[5], rot_c = hdr[6], tr_c = hdr[7];
   int R = hdr[8], L = hdr[9];
   const int scaling_ready = hdr[10];
+  const bool fold_check = hdr[11] != 0;  // also run the decision folded into the build against k_pack_decision + build (check_fold)
   const std::vector<double> par = rd.vec<double>(3);
   const double t0 = par[0], dt = par[1], radius = par[2];
   std::vector<double> cp = rd.vec<double>(size_t(8) * n_cp);
@@ -213,12 +269,13 @@ int main(int argc, char** argv) {
   for (int i = 0; i < np; ++i) step_p[i] = 1e-2 * std::sin(0.37 * i + 0.1) * (D2p[i] != 0.0 ? 1.0 : 0.0), delta_p[i] = -step_p[i] * scale_p[i];
   std::vector<double> norm_part(2), upd;
   T.step_p = step_p.data(), T.delta_p = delta_p.data(), T.n_norm_part = std::max((n_cp + kBlock - 1) / kBlock, 1), T.norm_part = norm_part.data();
+  const Sizes z{grpQ.size(), cost_part.size(), Y.size(), nl};
   if (k == 4)
-    run_update<4>(T, nb_vis, R, L, &upd);
+    run_update<4>(T, nb_vis, R, L, &upd, lds, z, fold_check);
   else if (k == 5)
-    run_update<5>(T, nb_vis, R, L, &upd);
+    run_update<5>(T, nb_vis, R, L, &upd, lds, z, fold_check);
   else
-    run_update<6>(T, nb_vis, R, L, &upd);
+    run_update<6>(T, nb_vis, R, L, &upd, lds, z, fold_check);
 
   FILE* out = fopen(argv[2], "wb");
   const int ohdr[8] = {bw, np, n_chunk, R, L, vs.y_total, int(lds), int(upd.size())};

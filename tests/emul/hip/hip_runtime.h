@@ -155,8 +155,21 @@ inline void wait_vmem() {}
 inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 #define __HIP_MEMORY_SCOPE_AGENT 0
-#define __hip_atomic_load(ptr, order, scope) __atomic_load_n(ptr, order)
-#define __hip_atomic_store(ptr, value, order, scope) __atomic_store_n(ptr, value, order)
+namespace hs_emul {
+template <class T>
+inline T atomic_load(const T* p, int order) {
+  T v;
+  __atomic_load(p, &v, order);
+  return v;
+}
+template <class T, class V>
+inline void atomic_store(T* p, V value, int order) {
+  const T v = T(value);
+  __atomic_store(p, &v, order);
+}
+}  // namespace hs_emul
+#define __hip_atomic_load(ptr, order, scope) hs_emul::atomic_load(ptr, order)
+#define __hip_atomic_store(ptr, value, order, scope) hs_emul::atomic_store(ptr, value, order)
 inline double __builtin_amdgcn_rsq(double d) { return 1.0 / std::sqrt(d); }
 inline long long wall_clock64() { return 0; }
 inline unsigned __builtin_amdgcn_s_getreg(int) { return 0; }
@@ -184,23 +197,29 @@ inline void launch(dim3 grid, dim3 block_dim, size_t lds_bytes, const std::funct
   b.lds.assign(lds_bytes / 8 + 64, 0.0);
   gridDim = grid, blockDim = block_dim;
   const int n = int(block_dim.x);
-  for (unsigned by = 0; by < grid.y; ++by)
-    for (unsigned ix = 0; ix < grid.x; ++ix) {
-      const unsigned bx = order.empty() ? ix : order[ix];
-      blockIdx = dim3(bx, by, 0);
-      b.barrier.reset(n);
-      for (int w = 0; w < (n + 63) / 64; ++w) b.wave_barrier[w].reset(n - 64 * w < 64 ? n - 64 * w : 64);
-      std::vector<std::thread> threads;
-      threads.reserve(n);
-      for (int t = 0; t < n; ++t)
-        threads.emplace_back([&, t] {
+  // the lane threads live for the whole launch and walk the workgroups together (creating 256 threads per workgroup dominated the run time)
+  static LiveBarrier frame;
+  frame.reset(n);
+  std::vector<std::thread> threads;
+  threads.reserve(n);
+  for (int t = 0; t < n; ++t)
+    threads.emplace_back([&, t] {
+      for (unsigned by = 0; by < grid.y; ++by)
+        for (unsigned ix = 0; ix < grid.x; ++ix) {
+          frame.arrive_and_wait();  // every lane has left the previous workgroup
+          if (t == 0) {
+            blockIdx = dim3(order.empty() ? ix : order[ix], by, 0);
+            b.barrier.reset(n);
+            for (int w = 0; w < (n + 63) / 64; ++w) b.wave_barrier[w].reset(n - 64 * w < 64 ? n - 64 * w : 64);
+          }
+          frame.arrive_and_wait();
           threadIdx = dim3(unsigned(t), 0, 0);
           kernel();
           b.wave_barrier[t >> 6].leave();
           b.barrier.leave();
-        });
-      for (std::thread& th : threads) th.join();
-    }
+        }
+    });
+  for (std::thread& th : threads) th.join();
 }
 
 }  // namespace hs_emul

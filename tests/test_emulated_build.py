@@ -36,7 +36,7 @@ def _pack_cameras(w):
     return cam
 
 
-def run_emulated_build(exe, w, radius=1e4, R=0, L=0, scaling=None):
+def run_emulated_build(exe, w, radius=1e4, R=0, L=0, scaling=None, fold=False):
     """Returns dict(S, g, cost, bw, n_chunk, Y, lm_scale, scale_p) of the emulated fused build on window `w`."""
     n_cp, n_lm = w.n_cp, len(w.landmarks)
     n_px, n_br = len(w.pixel_stamps), len(w.bearing_stamps)
@@ -44,7 +44,7 @@ def run_emulated_build(exe, w, radius=1e4, R=0, L=0, scaling=None):
     cpc = np.zeros(n_cp, i32) if w.cp_constant is None else np.asarray(w.cp_constant, i32)
     lmc = np.zeros(n_lm, i32) if w.landmark_constant is None else np.asarray(w.landmark_constant, i32)
     hdr = np.array([w.order, n_cp, n_lm, n_px, n_br, len(w.cam_T_bs), int(w.rotation_constant), int(w.translation_constant), R, L,
-                    1 if scaling is not None else 0, 0], i32)
+                    1 if scaling is not None else 0, 1 if fold else 0], i32)
     parts = [hdr, np.array([w.t0, w.dt, radius], f64), np.asarray(w.control_points, f64), cpc, _pack_cameras(w), np.asarray(w.landmarks, f64), lmc,
              np.asarray(w.pixel_stamps, f64), np.asarray(w.pixels, f64), np.asarray(w.pixel_landmark, i32), np.asarray(w.pixel_camera, i32),
              np.asarray(w.bearing_stamps, f64), np.asarray(w.bearings, f64), np.asarray(w.bearing_landmark, i32), np.asarray(w.bearing_camera, i32)]
@@ -127,3 +127,13 @@ def test_emulated_fused_build_is_reproducible(harness):
     w = synthetic.small_visual(order=4, n_cp=14, n_landmarks=40, obs_pairs=3)
     a, b = run_emulated_build(harness, w), run_emulated_build(harness, w)
     assert np.array_equal(a["S"], b["S"]) and np.array_equal(a["g"], b["g"]) and np.array_equal(a["Y"], b["Y"]) and a["cost"] == b["cost"]
+
+
+@pytest.mark.parametrize("order,R,L", [(4, 0, 0)])
+def test_emulated_decision_folded_into_build(harness, order, R, L):
+    """Iterations after the first: the trust-region decision of the previous iteration is taken by workgroup 0 of k_build_visual, the chunk
+    workgroups wait for its flag (Tables::fold_decision). The harness runs it against k_pack_decision(3) + the plain build on the same inputs,
+    once with an accepted and once with a rejected step, and exits with code 8 unless solver state, control points and every output of the
+    build agree bit for bit."""
+    w = synthetic.small_visual(order=order, n_cp=14 if order == 4 else 16, n_landmarks=30, obs_pairs=3)
+    run_emulated_build(harness, w, R=R, L=L, fold=True)

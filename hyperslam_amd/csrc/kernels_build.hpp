@@ -171,16 +171,27 @@ HSD void w_ops_apply(const WOps& x, double* wacc) {
 
 constexpr int kFoldFlag = 3;  // T.join_flag[kFoldFlag] = Tables::fold_epoch once the decision workgroup of a fold-mode k_build_visual has written the state
 HSD void pack_decision_body(const Tables& T, int decide_here, double* red, unsigned* publish);  // kernels_update.hpp
-/// Bounded wait for the decision workgroup (see wait_for_partner, kernels_factor.hpp): 2 s, then the solve is marked as failed and the caller carries on.
-HSD void fold_wait(const Tables& T) {
-  const long long t0 = wall_clock64();
-  while (__hip_atomic_load(T.join_flag + kFoldFlag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < T.fold_epoch) {
-    __builtin_amdgcn_s_sleep(2);
-    if (wall_clock64() - t0 > 200000000ll) {
-      T.st->chol_failed = 2;
-      break;
+/// Bounded wait for the decision workgroup (see wait_for_partner, kernels_factor.hpp): 2 s, then the solve is marked as failed and the caller
+/// carries on. ONE lane of the workgroup polls, with relaxed loads: every lane of every chunk workgroup polling with acquire loads (75 000 lanes,
+/// each poll an invalidation of the caches) delayed the decision workgroup itself — 0.261 instead of 0.204 ms per iteration at configs[1].
+/// The flag word carries the outcome: (epoch << 2) | (done << 1) | accepted, handed to the other lanes through `slot` (LDS).
+HSD unsigned fold_wait(const Tables& T, unsigned* slot) {
+  if (threadIdx.x == 0) {
+    const long long t0 = wall_clock64();
+    unsigned f;
+    while (((f = __hip_atomic_load(T.join_flag + kFoldFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 2) < T.fold_epoch) {
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > 200000000ll) {
+        T.st->chol_failed = 2;
+        f = (T.fold_epoch << 2) | 2u;  // give up: as if the solve had ended
+        break;
+      }
     }
+    *slot = f;
   }
+  __syncthreads();
+  if (T.debug_flags & 16384) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (A/B: an acquire per wave instead of coherent loads of the state alone)
+  return *slot;
 }
 
 template <int K>
@@ -194,11 +205,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
   const int fold = T.fold_decision;
   const int w = int(blockIdx.x) - fold, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   DevState* st = T.st;
-  if (w < 0) {
-    if (st->done) {  // (an earlier iteration ended the solve: nothing to decide, but the chunk workgroups wait for the flag before they look)
-      if (tid == 0) __hip_atomic_store(T.join_flag + kFoldFlag, T.fold_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      return;
-    }
+  if (w < 0) {  // (also when an earlier iteration ended the solve: the chunk workgroups wait for the flag before they look)
     pack_decision_body(T, 3, smem, T.join_flag + kFoldFlag);
     return;
   }
@@ -268,30 +275,35 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
     in.stamp = T.v_stamp[q];
     in.meas[0] = T.v_meas[3 * q], in.meas[1] = T.v_meas[3 * q + 1], in.meas[2] = T.v_meas[3 * q + 2];
   }
-  if (fold) {  // the decision of the previous iteration (workgroup 0 of this launch): every lane polls (one request per wave), then reads the state
-    fold_wait(T);
-    st_done = __hip_atomic_load(&st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    st_spec = __hip_atomic_load(&st->spec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    st_accepted = __hip_atomic_load(&st->accepted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    st_ready = __hip_atomic_load(&st->scaling_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    radius = __hip_atomic_load(&st->radius, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (st_done) return;
-    if (w >= T.n_chunk) {
+  // Fold mode: the decision of the previous iteration (workgroup 0 of this launch) is waited for as late as possible — behind the sort of
+  // the record slots, which only needs the records' segments — with everything else already requested: the tables no decision changes go to
+  // LDS, the point waits in registers in both versions (current / candidate of the previous iteration). Behind the flag word, which carries the
+  // outcome, only the new radius is read (a coherent load, first used phases later: it was written by a workgroup on another XCD while this
+  // one ran; no acquire fence — 1 200 waves invalidating their XCD's L2 for it cost as much as the launch this mode removes).
+  double f_c0x = 0.0, f_c0y = 0.0, f_c1x = 0.0, f_c1y = 0.0;
+  double f_l0x = 0.0, f_l0y = 0.0, f_l0z = 0.0, f_l1x = 0.0, f_l1y = 0.0, f_l1z = 0.0;  // (scalars: as an array the six doubles went to scratch memory)
+  const int ncp_w = min(bw, T.sp.n_cp - cf);  // (4 ncp_w <= kBlock: at most one 16-byte piece of the window's control points per lane)
+  if (fold) {
+    st_spec = st->spec;  // (fixed for the solve: any cached copy is current)
+    if (w >= T.n_chunk) {  // padding workgroups (zeros in a slot nobody reads once a solve has ended: no need to wait for the decision)
       if (tid == 0) T.cost_part[w] = 0.0, T.ch_gmax[w] = 0.0;
       return;
+    }
+    st_ready = 1;  // (a step has been computed: the scaling of this solve is fixed)
+    if (tid < 4 * ncp_w) {
+      const double2 c0 = reinterpret_cast<const double2*>(T.cp + 8 * cf)[tid], c1 = reinterpret_cast<const double2*>(T.cp_cand + 8 * cf)[tid];
+      f_c0x = c0.x, f_c0y = c0.y, f_c1x = c1.x, f_c1y = c1.y;
+    }
+    if (tid < nl) {
+      const double *l0 = T.lm + 3 * (lo + tid), *l1 = T.lm_cand + 3 * (lo + tid);
+      f_l0x = l0[0], f_l0y = l0[1], f_l0z = l0[2], f_l1x = l1[0], f_l1y = l1[1], f_l1z = l1[2];
     }
   }
   // Deferred commit of the landmarks (DevState::spec == 4): the candidate accepted by the previous iteration is still only in lm_cand
   // (k_update_visual copies it on its way); the control points are committed by the decision and always current in T.cp — in fold mode the
-  // decision workgroup copies an accepted candidate there WHILE this workgroup runs, so an accepted point is read from cp_cand
-  const bool pend = st_spec == 4 && st_accepted;
-  const double* cp_src = (fold && st_accepted) ? T.cp_cand : T.cp;
-  const double* lm_src = pend ? T.lm_cand : T.lm;
+  // decision workgroup copies an accepted candidate there WHILE this workgroup runs, so an accepted point is taken from cp_cand
   const bool fresh = !st_ready;
   {
-    const int ncp_w = min(bw, T.sp.n_cp - cf);
-    const double2* s2 = reinterpret_cast<const double2*>(cp_src + 8 * cf);
-    for (int e = tid; e < 4 * ncp_w; e += kBlock) reinterpret_cast<double2*>(cps_l)[e] = s2[e];
     if (tid < ncp_w) frozen[tid] = T.cp_const[cf + tid];
     for (int e = tid; e < 16 * min(T.n_cam, kBuildCams); e += kBlock) cams[e] = T.cam[e];
     if (tid <= nl) lp[tid] = T.lm_ptr[lo + tid] - q0;
@@ -301,7 +313,13 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
       double* li = Linv + kLinv * tid;
       li[6] = fresh ? 1.0 : T.lm_scale[3 * dl], li[7] = fresh ? 1.0 : T.lm_scale[3 * dl + 1], li[8] = fresh ? 1.0 : T.lm_scale[3 * dl + 2];
       li[9] = T.lm_const[dl] ? 0.0 : 1.0;
-      lmp[4 * tid] = lm_src[3 * dl], lmp[4 * tid + 1] = lm_src[3 * dl + 1], lmp[4 * tid + 2] = lm_src[3 * dl + 2];
+    }
+    if (!fold) {
+      const bool pend = st_spec == 4 && st_accepted;
+      const double* lm_src = pend ? T.lm_cand : T.lm;
+      const double2* s2 = reinterpret_cast<const double2*>(T.cp + 8 * cf);
+      for (int e = tid; e < 4 * ncp_w; e += kBlock) reinterpret_cast<double2*>(cps_l)[e] = s2[e];
+      if (tid < nl) lmp[4 * tid] = lm_src[3 * (lo + tid)], lmp[4 * tid + 1] = lm_src[3 * (lo + tid) + 1], lmp[4 * tid + 2] = lm_src[3 * (lo + tid) + 2];
     }
   }
   // stable counting sort of the record slots by (segment offset, landmark-major index): rank inside the wave from ballots
@@ -313,8 +331,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
   }
   __syncthreads();
   HS_BSTAMP(1);
-  if (wave == 1) {  // relative rotations of the window's consecutive control points: once per pair, not once per residual and pair
-    const int ncp_w = min(bw, T.sp.n_cp - cf);
+  if (wave == 1 && !fold) {  // relative rotations of the window's consecutive control points: once per pair, not once per residual and pair
     if (lane + 1 < ncp_w) relp[lane] = rel_precompute(cps_l + 8 * lane, cps_l + 8 * lane + 8);
   }
   if (wave == 0) {  // seg_start[o] = records with a smaller segment offset: inclusive scan over the lanes of wave 0
@@ -336,6 +353,16 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
     slot_lm[my_slot] = my_l;
   }
   for (int e = tid; e < nseg * (Lmax + 1); e += kBlock) pos[e] = seg_start[e / (Lmax + 1) + 1];  // default: the end of the segment's run
+  if (fold) {  // (thread 0's poll runs next to the loop above; the barrier inside the wait is the one this phase ends with anyway)
+    const unsigned f = fold_wait(T, reinterpret_cast<unsigned*>(cpart));
+    radius = __hip_atomic_load(&st->radius, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((f >> 1) & 1) return;  // the solve has ended (nothing has been written to memory yet)
+    const bool acc = f & 1;    // (spec == 4: an accepted candidate's landmarks are still only in lm_cand)
+    if (tid < 4 * ncp_w) reinterpret_cast<double2*>(cps_l)[tid] = make_double2(acc ? f_c1x : f_c0x, acc ? f_c1y : f_c0y);
+    if (tid < nl) lmp[4 * tid] = acc ? f_l1x : f_l0x, lmp[4 * tid + 1] = acc ? f_l1y : f_l0y, lmp[4 * tid + 2] = acc ? f_l1z : f_l0z;
+    __syncthreads();
+    if (wave == 1 && lane + 1 < ncp_w) relp[lane] = rel_precompute(cps_l + 8 * lane, cps_l + 8 * lane + 8);
+  }
   __syncthreads();
   HS_BSTAMP(2);
   // ---- 1: linearise into the sorted slot (no global loads from here to phase 4); pos[o][l'] = my slot for the landmarks l' between my

@@ -41,6 +41,17 @@ HSD double wave_sum(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+/// The same butterfly (same pairs, same order: bit-identical sums) with the four lower levels on the DPP cross bar: xor 8 = row_ror:8 inside
+/// a row of 16 lanes. For the reductions that sit on the iteration's chain (the decision: five sums).
+HSD double wave_sum_fast(double v) {
+  v += __shfl_xor(v, 32);
+  v += __shfl_xor(v, 16);
+  v += dpp_move<0x128>(v);
+  v += lane_xor4(v);
+  v += lane_xor2(v);
+  v += lane_xor1(v);
+  return v;
+}
 
 /// Workgroup barrier that only drains LDS traffic: global loads / stores stay in flight across it (the factorisation
 /// prefetches the next band row while the current step runs; __syncthreads() would wait for vmcnt(0) every step).
@@ -71,7 +82,7 @@ HSD void block_sum_n(double (&v)[N], double* lds /* >= N * blockDim / 64 */) {
   const int w = threadIdx.x >> 6, nw = int(blockDim.x >> 6);
 #pragma unroll
   for (int e = 0; e < N; ++e) {
-    v[e] = wave_sum(v[e]);
+    v[e] = wave_sum_fast(v[e]);
     if ((threadIdx.x & 63) == 0) lds[e * nw + w] = v[e];
   }
   __syncthreads();

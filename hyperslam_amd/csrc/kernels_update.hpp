@@ -195,6 +195,21 @@ HSD void begin_iteration(const Tables& T, double c, double gm, bool set_scaling_
   }
 }
 
+/// What decide_step reads from the solver state, as one batch of independent loads (its lane requests them with the partial sums of the
+/// decision, a memory round trip earlier than it needs them: read one after the other behind the sums they were 1.4 us of the chain).
+struct DecideIn {
+  double g_pose, g_far, d2_pose, d2_far, cost, gmax, radius, decrease_factor;
+  int chol_failed, iteration, rec_pending, invalid_streak;
+};
+HSD DecideIn decide_inputs(const DevState* st) {
+  DecideIn in;
+  in.g_pose = st->g_dot_step_pose, in.g_far = st->g_dot_step_far, in.d2_pose = st->d2_step2_pose, in.d2_far = st->d2_step2_far;
+  in.cost = st->cost, in.gmax = st->gmax, in.radius = st->radius, in.decrease_factor = st->decrease_factor;
+  in.chol_failed = st->chol_failed, in.iteration = st->iteration, in.rec_pending = st->rec_pending, in.invalid_streak = st->invalid_streak;
+  return in;
+}
+
+HSD void decide_step(const Tables& T, const double* D_known, const DecideIn& in);
 HSD void decide_step(const Tables& T, const double* D_known = nullptr);
 HSD void commit_body(const Tables& T, int idx, int stride);
 HSD void commit_control_points(const Tables& T, int idx, int stride);
@@ -205,6 +220,13 @@ HSD void commit_control_points(const Tables& T, int idx, int stride);
 /// solver state, BEFORE the accepted control points are copied (the waiting workgroups read an accepted point from cp_cand, nobody reads T.cp).
 HSD void pack_decision_body(const Tables& T, const int decide_here, double* red /* 5 * kBlock / 64 + 1 doubles of LDS */, unsigned* publish) {
   DevState* st = T.st;
+  const int done_at_entry = st->done;  // (requested with the partials below, looked at behind them: one memory round trip, not two)
+  // phase stamps of the decision workgroup of a fold-mode build (profiling builds, HS_DEBUG_FLAGS 32; tools/fold_phase_timing.py)
+  const bool dprof = prof_enabled(T.debug_flags, 32) && publish && threadIdx.x == 0;
+  long long* dlog = reinterpret_cast<long long*>(T.xpart) + 48 * 1024 + 64 * 1023;
+  if (dprof) dlog[0] = wall_clock64();
+  DecideIn din = {};
+  if (threadIdx.x == 0 && decide_here) din = decide_inputs(st);
   // The partial arrays are short (one entry per workgroup of the producing kernels): one combined pass with every load of a round
   // issued before the first use (six separate strided sums cost six memory round trips, 8 us). Fixed order: bit-reproducible.
   double cand = 0.0, xs = 0.0, ss = 0.0, gd = 0.0, dd = 0.0;
@@ -229,17 +251,26 @@ HSD void pack_decision_body(const Tables& T, const int decide_here, double* red 
       xs += nr[u].x, ss += nr[u].y;
     }
   }
+  if (done_at_entry) {  // an earlier iteration ended the solve
+    if (publish && threadIdx.x == 0) __hip_atomic_store(publish, (T.fold_epoch << 2) | 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   double v5[5] = {cand, xs, ss, gd, dd};
+  if (dprof) dlog[1] = wall_clock64();  // partials loaded
   block_sum_n<5>(v5, red);  // (one pair of barriers for the five sums; the decision takes them from registers, not back from memory)
+  if (dprof) dlog[2] = wall_clock64();  // summed
   int* accepted = reinterpret_cast<int*>(red + 5 * (kBlock / 64));  // (handed over in LDS: the other waves may hold the state's cache line from their `done` test)
   if (threadIdx.x == 0) {
     double* D = T.xbuf + T.xo_dec;
 #pragma unroll
     for (int e = 0; e < 5; ++e) D[e] = v5[e];
     st->local_cand = v5[0];  // this shard's part (the exchange sums D over the shards)
-    if (decide_here) decide_step(T, v5);
+    if (decide_here) decide_step(T, v5, din);
     if (decide_here >= 2) *accepted = st->accepted;
-    if (publish) __hip_atomic_store(publish, T.fold_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (dprof) dlog[3] = wall_clock64();  // decided
+    if (publish)  // (epoch << 2) | (done << 1) | accepted: what the waiting workgroups need at once (fold_wait, kernels_build.hpp)
+      __hip_atomic_store(publish, (T.fold_epoch << 2) | (st->done ? 2u : 0u) | (st->accepted ? 1u : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (dprof) dlog[4] = wall_clock64();  // published
   }
   if (decide_here >= 2) {  // 2, small problems: x <- candidate right here instead of a k_commit launch behind this one;
                            // 3, fused path with deferred landmarks: the control points only (k_build_visual / k_update_visual read T.cp)
@@ -251,59 +282,65 @@ HSD void pack_decision_body(const Tables& T, const int decide_here, double* red 
 
 __global__ void __launch_bounds__(kBlock) k_pack_decision(Tables T, int decide_here /* no exchange between packing and deciding */) {
   __shared__ double red[5 * (kBlock / 64) + 1];
-  if (T.st->done) return;
   pack_decision_body(T, decide_here, red, nullptr);
 }
 
 /// Trust-region decision of one LM iteration (single lane): step quality, acceptance, radius update, termination tests.
-HSD void decide_step(const Tables& T, const double* D_known) {
+HSD void decide_step(const Tables& T, const double* D_known, const DecideIn& in) {
   DevState* st = T.st;
   const double* D = D_known ? D_known : T.xbuf + T.xo_dec;  // (after an exchange: the summed terms from the buffer)
   const double cand = D[0], xs = D[1], ss = D[2];
   // model_cost_change = -g.step/2 + step'D^2 step/2 (exact for the solved system; TrustRegionMinimizer evaluates
   // -(J step).(r + J step/2), identical algebraically)
-  const double g_step = (st->g_dot_step_pose + st->g_dot_step_far) + D[3], d_step = (st->d2_step2_pose + st->d2_step2_far) + D[4];
+  const double g_step = (in.g_pose + in.g_far) + D[3], d_step = (in.d2_pose + in.d2_far) + D[4];
   const double mcc = -0.5 * g_step + 0.5 * d_step;
   st->model_cost_change = mcc;
   st->scaling_ready = 1;  // a step was computed: the Jacobi scaling of this solve is fixed from here on
-  st->step_valid = (isfinite(mcc) && !st->chol_failed && mcc > 0.0) ? 1 : 0;  // TrustRegionMinimizer: step_is_valid = model_cost_change > 0
-  const int it = st->iteration;
+  const int step_valid = (isfinite(mcc) && !in.chol_failed && mcc > 0.0) ? 1 : 0;  // TrustRegionMinimizer: step_is_valid = model_cost_change > 0
+  st->step_valid = step_valid;
+  const int it = in.iteration;
   hs_iteration& r = st->records[it];
-  r.iteration = it, r.cost = st->cost, r.cost_change = 0, r.gradient_max_norm = st->gmax, r.step_norm = 0, r.relative_decrease = 0;
-  r.step_is_valid = st->step_valid, r.step_is_successful = 0;
+  r.iteration = it, r.cost = in.cost, r.cost_change = 0, r.gradient_max_norm = in.gmax, r.step_norm = 0, r.relative_decrease = 0;
+  r.step_is_valid = step_valid, r.step_is_successful = 0;
   st->num_iterations = it;
   st->accepted = 0;
-  const int rec_pending = st->rec_pending;  // the candidate was linearised into the other record buffer (k_linearize_visual)
+  const int rec_pending = in.rec_pending;  // the candidate was linearised into the other record buffer (k_linearize_visual)
   st->rec_pending = 0;
   st->gmax_bits = 0ull, st->gmax_pose_bits = 0ull;  // the next linearisation re-accumulates them
-  if (!st->step_valid) {  // HandleInvalidStep
-    if (++st->invalid_streak >= 5) {
+  double radius = in.radius;
+  if (!step_valid) {  // HandleInvalidStep
+    if (in.invalid_streak + 1 >= 5) {
       st->done = 1, st->termination = HS_FAILURE;
     } else {
-      st->radius *= 0.5;
+      radius *= 0.5;
+      st->radius = radius;
     }
-    r.radius = st->radius;
+    st->invalid_streak = in.invalid_streak + 1;
+    r.radius = radius;
     st->iteration = it + 1;
     return;
   }
   st->invalid_streak = 0;
   st->cand_cost = cand;
-  r.step_norm = sqrt(ss);
+  const double step_norm = sqrt(ss);
+  r.step_norm = step_norm;
   // ParameterToleranceReached
-  if (r.step_norm <= 1e-8 * (sqrt(xs) + 1e-8)) {
+  if (step_norm <= 1e-8 * (sqrt(xs) + 1e-8)) {
     st->done = 1, st->termination = HS_CONVERGENCE;
-    r.radius = st->radius;
+    r.radius = radius;
     return;
   }
   // FunctionToleranceReached
-  r.cost_change = st->cost - cand;
-  if (fabs(r.cost_change) <= 1e-6 * st->cost) {
+  const double cost_change = in.cost - cand;
+  r.cost_change = cost_change;
+  if (fabs(cost_change) <= 1e-6 * in.cost) {
     st->done = 1, st->termination = HS_CONVERGENCE;
-    r.radius = st->radius;
+    r.radius = radius;
     return;
   }
-  r.relative_decrease = (st->cost - cand) / st->model_cost_change;
-  if (r.relative_decrease > 1e-3) {  // HandleSuccessfulStep
+  const double relative_decrease = (in.cost - cand) / mcc;
+  r.relative_decrease = relative_decrease;
+  if (relative_decrease > 1e-3) {  // HandleSuccessfulStep
     r.step_is_successful = 1;
     st->accepted = 1;
     st->num_successful++;
@@ -311,17 +348,19 @@ HSD void decide_step(const Tables& T, const double* D_known) {
     st->local_cost = st->local_cand;
     if (rec_pending) st->rec_sel ^= 1;  // its records are the linearisation of the new current point
     r.cost = cand;
-    const double q = 2.0 * r.relative_decrease - 1.0;
-    st->radius = fmin(1e16, st->radius / fmax(1.0 / 3.0, 1.0 - q * q * q));
+    const double q = 2.0 * relative_decrease - 1.0;
+    radius = fmin(1e16, radius / fmax(1.0 / 3.0, 1.0 - q * q * q));
     st->decrease_factor = 2.0;
   } else {
     r.cost = cand;  // TrustRegionMinimizer reports the candidate's cost for an unsuccessful step (the point itself is unchanged)
-    st->radius = st->radius / st->decrease_factor;
-    st->decrease_factor *= 2.0;
+    radius = radius / in.decrease_factor;
+    st->decrease_factor = in.decrease_factor * 2.0;
   }
-  r.radius = st->radius;
+  st->radius = radius;
+  r.radius = radius;
   st->iteration = it + 1;
 }
+HSD void decide_step(const Tables& T, const double* D_known) { decide_step(T, D_known, decide_inputs(T.st)); }
 
 /// (commit_cps: the fused path with deferred landmarks — the accepted control points go to T.cp right here)
 __global__ void __launch_bounds__(kBlock) k_decide(Tables T, int commit_cps) {

@@ -118,13 +118,15 @@ inline T __shfl_up(T v, unsigned delta) {
 }
 inline int __builtin_amdgcn_readlane(int v, int lane) { return hs_emul::wave_exchange(v, lane); }
 /// DPP move as the kernels use it (row_mask = bank_mask = 0xF, bound_ctrl off: a lane whose source is outside its row of 16 keeps `old`):
-/// quad_perm (ctrl < 0x100, two bits per lane of the quad), row_shl:n (0x100 + n: lane i reads lane i + n), row_shr:n (0x110 + n: lane i - n).
+/// quad_perm (ctrl < 0x100, two bits per lane of the quad), row_shl:n (0x100 + n: lane i reads lane i + n), row_shr:n (0x110 + n: lane i - n),
+/// row_ror:n (0x120 + n: lane i reads lane (i - n) mod 16 of its row).
 inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool) {
   const int lane = threadIdx.x & 63;
   int from = -1;
   if (ctrl < 0x100) from = (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
   else if (ctrl > 0x100 && ctrl < 0x110) from = ((lane & 15) + (ctrl - 0x100) < 16) ? lane + (ctrl - 0x100) : -1;
   else if (ctrl > 0x110 && ctrl < 0x120) from = ((lane & 15) - (ctrl - 0x110) >= 0) ? lane - (ctrl - 0x110) : -1;
+  else if (ctrl > 0x120 && ctrl < 0x130) from = (lane & ~15) | (((lane & 15) - (ctrl - 0x120)) & 15);  // row_ror:n (rotation inside the row of 16)
   const int got = hs_emul::wave_exchange(src, from < 0 ? lane : from);
   return from < 0 ? old : got;
 }
@@ -155,6 +157,7 @@ inline void wait_vmem() {}
 inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 #define __HIP_MEMORY_SCOPE_AGENT 0
+#define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(order)
 namespace hs_emul {
 template <class T>
 inline T atomic_load(const T* p, int order) {

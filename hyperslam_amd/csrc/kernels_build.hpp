@@ -190,7 +190,6 @@ HSD unsigned fold_wait(const Tables& T, unsigned* slot) {
     *slot = f;
   }
   __syncthreads();
-  if (T.debug_flags & 16384) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (A/B: an acquire per wave instead of coherent loads of the state alone)
   return *slot;
 }
 

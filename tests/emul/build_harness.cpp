@@ -12,6 +12,7 @@
 #include "hip/hip_runtime.h"
 
 thread_local dim3 threadIdx;
+thread_local unsigned hs_emul::exchange_count = 0;
 dim3 blockIdx, blockDim, gridDim;
 
 #include "../../hyperslam_amd/csrc/host_structure.hpp"

@@ -7,6 +7,7 @@
 // timing, occupancy or memory-model subtleties (x86 is sequentially consistent enough for barrier-synchronised code); the `-m gpu` tests
 // remain the parity tests proper. Nothing in the product includes or links this directory.
 #pragma once
+#include <atomic>
 #include <cmath>
 #include <condition_variable>
 #include <cstddef>
@@ -44,37 +45,48 @@ namespace hs_emul {
 /// Barrier over the threads that have not left the kernel yet (a wave that returned early does not take part on the GPU either).
 class LiveBarrier {
  public:
-  void reset(int n) { live_ = n, waiting_ = 0, phase_ = 0; }
+  void reset(int n) {
+    std::lock_guard<std::mutex> lk(m_);
+    live_ = n, waiting_ = 0, phase_.store(0);
+  }
+  // The counters change under a mutex (an arrival and a departure must not miss each other); the sleepers wait on the phase word through the
+  // futex behind std::atomic::wait and resume without the mutex (with a condition variable every wake-up of 255 threads queued for the mutex
+  // again: most of the harness's run time).
   void arrive_and_wait() {
-    std::unique_lock<std::mutex> lk(m_);
-    const unsigned ph = phase_;
-    if (++waiting_ == live_) {
-      waiting_ = 0, ++phase_;
-      cv_.notify_all();
-    } else {
-      cv_.wait(lk, [&] { return phase_ != ph; });
+    unsigned ph;
+    bool last;
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      ph = phase_.load(std::memory_order_relaxed);
+      last = ++waiting_ == live_;
+      if (last) waiting_ = 0, phase_.store(ph + 1, std::memory_order_release);
     }
+    if (last)
+      phase_.notify_all();
+    else
+      while (phase_.load(std::memory_order_acquire) == ph) phase_.wait(ph, std::memory_order_acquire);
   }
   void leave() {
-    std::unique_lock<std::mutex> lk(m_);
-    --live_;
-    if (live_ > 0 && waiting_ == live_) {
-      waiting_ = 0, ++phase_;
-      cv_.notify_all();
+    bool released = false;
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      --live_;
+      if (live_ > 0 && waiting_ == live_) waiting_ = 0, phase_.store(phase_.load(std::memory_order_relaxed) + 1, std::memory_order_release), released = true;
     }
+    if (released) phase_.notify_all();
   }
 
  private:
   std::mutex m_;
-  std::condition_variable cv_;
   int live_ = 0, waiting_ = 0;
-  unsigned phase_ = 0;
+  std::atomic<unsigned> phase_{0};
 };
 
 struct Block {
   LiveBarrier barrier;
   LiveBarrier wave_barrier[16];
-  unsigned long long wave_bits[16][64];  // value exchange of the wave intrinsics (doubles travel as bits)
+  unsigned long long wave_bits[2][16][64];  // value exchange of the wave intrinsics (doubles travel as bits); two buffers used in turn, so
+                                            // that one barrier per exchange is enough (a lane can be at most one exchange ahead of another)
   std::vector<double> lds;
 };
 inline Block& block() {
@@ -91,17 +103,18 @@ extern dim3 blockIdx, blockDim, gridDim;
 inline void __syncthreads() { hs_emul::block().barrier.arrive_and_wait(); }
 
 namespace hs_emul {
+extern thread_local unsigned exchange_count;  // exchanges this lane has taken part in within the current workgroup (selects the buffer)
 template <class T>
 inline T wave_exchange(T v, int src_lane) {
   static_assert(sizeof(T) <= 8, "value exchange through 64-bit slots");
   Block& b = block();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const unsigned buf = exchange_count++ & 1u;
   unsigned long long bits = 0;
   std::memcpy(&bits, &v, sizeof(T));
-  b.wave_bits[wave][lane] = bits;
+  b.wave_bits[buf][wave][lane] = bits;
   b.wave_barrier[wave].arrive_and_wait();
-  const unsigned long long got = b.wave_bits[wave][src_lane & 63];
-  b.wave_barrier[wave].arrive_and_wait();
+  const unsigned long long got = b.wave_bits[buf][wave][src_lane & 63];
   T out;
   std::memcpy(&out, &got, sizeof(T));
   return out;
@@ -136,12 +149,12 @@ inline double __hiloint2double(int hi, int lo) { const unsigned long long b = (s
 inline unsigned long long __ballot(bool pred) {
   hs_emul::Block& b = hs_emul::block();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  b.wave_bits[wave][lane] = pred ? 1ull : 0ull;
+  const unsigned buf = hs_emul::exchange_count++ & 1u;
+  b.wave_bits[buf][wave][lane] = pred ? 1ull : 0ull;
   b.wave_barrier[wave].arrive_and_wait();
   unsigned long long m = 0;
   const int n_lanes = int(blockDim.x) - 64 * wave < 64 ? int(blockDim.x) - 64 * wave : 64;
-  for (int l = 0; l < n_lanes; ++l) m |= b.wave_bits[wave][l] << l;
-  b.wave_barrier[wave].arrive_and_wait();
+  for (int l = 0; l < n_lanes; ++l) m |= b.wave_bits[buf][wave][l] << l;
   return m;
 }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
@@ -217,6 +230,7 @@ inline void launch(dim3 grid, dim3 block_dim, size_t lds_bytes, const std::funct
           }
           frame.arrive_and_wait();
           threadIdx = dim3(unsigned(t), 0, 0);
+          exchange_count = 0;
           kernel();
           b.wave_barrier[t >> 6].leave();
           b.barrier.leave();

@@ -25,7 +25,7 @@ def harness():
     csrc = os.path.join(ROOT, "hyperslam_amd", "csrc")
     srcs += [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp")]
     if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in srcs):
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-I", EMUL, "-o", exe, os.path.join(EMUL, "build_harness.cpp")])
+        subprocess.check_call(["g++", "-std=c++20", "-O1", "-pthread", "-I", EMUL, "-o", exe, os.path.join(EMUL, "build_harness.cpp")])
     return exe
 
 
@@ -129,7 +129,7 @@ def test_emulated_fused_build_is_reproducible(harness):
     assert np.array_equal(a["S"], b["S"]) and np.array_equal(a["g"], b["g"]) and np.array_equal(a["Y"], b["Y"]) and a["cost"] == b["cost"]
 
 
-@pytest.mark.parametrize("order,R,L", [(4, 0, 0)])
+@pytest.mark.parametrize("order,R,L", [(4, 0, 0), (6, 64, 3), (5, 0, 0)])
 def test_emulated_decision_folded_into_build(harness, order, R, L):
     """Iterations after the first: the trust-region decision of the previous iteration is taken by workgroup 0 of k_build_visual, the chunk
     workgroups wait for its flag (Tables::fold_decision). The harness runs it against k_pack_decision(3) + the plain build on the same inputs,

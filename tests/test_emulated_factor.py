@@ -24,7 +24,7 @@ def harness(tmp_path_factory):
     if shutil.which("g++") is None:
         pytest.skip("g++ not available")
     exe = str(tmp_path_factory.mktemp("emul_factor") / "factor_harness")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-I", EMUL, "-o", exe, os.path.join(EMUL, "factor_harness.cpp")])
+    subprocess.check_call(["g++", "-std=c++20", "-O1", "-pthread", "-I", EMUL, "-o", exe, os.path.join(EMUL, "factor_harness.cpp")])
     return exe
 
 

@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
   uint8_t* frozen = reinterpret_cast<uint8_t*>(pos + nseg * (Lmax + 1));  // constancy flags of the window's control points
 
   // phase timestamps (profiling builds only, HS_DEBUG_FLAGS 32; tools/build_phase_timing.py): lane 0 of every wave of the first 1024 chunks
-  const bool bprof = prof_enabled(T.debug_flags, 32) && lane == 0 && w < 1024;
+  const bool bprof = prof_enabled(T.debug_flags, 32) && lane == 0 && w < 1023;  // (row 1023: the decision workgroup of a fold-mode launch, pack_decision_body)
   long long* blog = reinterpret_cast<long long*>(T.xpart) + 48 * 1024 + 64 * w + 16 * wave;
 #define HS_BSTAMP(i) \
   if (bprof) blog[i] = wall_clock64()

@@ -23,8 +23,9 @@ t = t[t[:, 0, 0] > 0]
 t0 = min(t[:, :, 0].min(), d[0] if d[0] > 0 else t[:, :, 0].min())
 print("decision workgroup [us after the first stamp of the launch]: entry, partials loaded, summed, decided, published:", ((d - t0) * 0.01).round(2).tolist())
 start = (t[:, :, 0].min(axis=1) - t0) * 0.01
-ready = (t[:, :, 1].max(axis=1) - t0) * 0.01
-print("chunk workgroups:", len(t), " start quantiles [us]", np.percentile(start, [0, 25, 50, 75, 100]).round(2), " inputs + decision in hand (stamp 1)", np.percentile(ready, [0, 25, 50, 75, 100]).round(2),
-      " stamp 1 - start", np.percentile(ready - start, [0, 25, 50, 75, 100]).round(2))
+inputs = (t[:, :, 1].max(axis=1) - t0) * 0.01  # inputs + keys, behind the first barrier
+ready = (t[:, :, 2].max(axis=1) - t0) * 0.01   # slots sorted, decision in hand, point in LDS (fold mode: the wait sits in front of this stamp)
+print("chunk workgroups:", len(t), " start quantiles [us]", np.percentile(start, [0, 25, 50, 75, 100]).round(2), " inputs in LDS", np.percentile(inputs, [0, 25, 50, 75, 100]).round(2),
+      " sorted + decision in hand", np.percentile(ready, [0, 25, 50, 75, 100]).round(2), " of which after the inputs", np.percentile(ready - inputs, [0, 25, 50, 75, 100]).round(2))
 end = (t[:, :, 12].max(axis=1) - t0) * 0.01
 print("end quantiles", np.percentile(end, [0, 25, 50, 75, 100]).round(2))

@@ -19,6 +19,7 @@ HS_LIBRARY=$PWD/tools/libhyperslam_hip_prof.so HS_DEBUG_FLAGS=131072 bash tools/
 bash tools/kernel_stats.sh $out/${tag}_config3_kernel_stats.csv python bench.py --config 3 --steps 10 --warmup 2 --no-cpu-baseline >> $out/${tag}_kernel_stats.txt 2>&1
 [ -f tools/libhyperslam_hip_prof.so ] && python tools/chol_phase_timing.py > $out/${tag}_chol_phase_timing.txt 2>&1
 [ -f tools/libhyperslam_hip_prof.so ] && python tools/build_phase_timing.py 1 > $out/${tag}_build_phase_timing.txt 2>&1
+[ -f tools/libhyperslam_hip_prof.so ] && { python tools/fold_phase_timing.py 1; HS_DEBUG_FLAGS=32768 python tools/fold_phase_timing.py 1; python tools/fold_phase_timing.py 3; } > $out/${tag}_fold_phase_timing.txt 2>&1
 for c in 0 1 2 3; do HS_STAGE_TIMING=0 python tools/time_config.py $c; HS_STAGE_TIMING=1 python tools/time_config.py $c; done > $out/${tag}_configs.txt 2>&1
 python bench.py --config 3 --steps 20 --warmup 3 --no-cpu-baseline > $out/${tag}_bench_config3.json 2>/dev/null
 python bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline > $out/${tag}_bench_config2.json 2>/dev/null

@@ -45,14 +45,20 @@ int main(int argc, char** argv) {
   FILE* in = fopen(argv[1], "rb");
   if (!in) return 1;
   const std::vector<int> hdr = read_vec<int>(in, 4);  // np, bw, two-ended, 0
-  const int np = hdr[0], bw = hdr[1], two_ended = hdr[2], ncb = 6 * bw, n_blk = np / 6, w_mid = bw - 1;
+  // hdr[2]: bit 0 = from both ends; bits 8.. = f0, the leading block rows of constant control points (decoupled: k_factor_decoupled_rows, the
+  // chain of the one-ended kernels and the sweeps start behind them — the sliding window's frozen prefix, launch_factor)
+  const int np = hdr[0], bw = hdr[1], two_ended = hdr[2] & 1, f0 = hdr[2] >> 8, ncb = 6 * bw, n_blk = np / 6, w_mid = bw - 1;
   const std::vector<double> Sb = read_vec<double>(in, size_t(np) * ncb), g = read_vec<double>(in, np);
   const std::vector<double> Sb2 = read_vec<double>(in, size_t(np) * ncb), g2 = read_vec<double>(in, np);  // the reversed system
   const std::vector<double> scale_p = read_vec<double>(in, np), g_full = read_vec<double>(in, np), D2p = read_vec<double>(in, np);
   fclose(in);
   const int ncw = la_compute_waves(bw);
-  if (ncw == 0 || (two_ended && n_blk < 4 * bw)) {
-    fprintf(stderr, "band width / length outside the look-ahead kernel's range\n");
+  // hdr[3]: which one-ended kernel (launch_factor's rules pick one by band width and length; the test asks for each where it applies)
+  //   0 look-ahead (k_band_factor_la), 1 k_band_factor<1> (bw^2 <= 256 lanes), 2 k_band_factor<2> (bw <= 21), 3 k_band_factor_wide, 4 k_dense_factor
+  const int variant = hdr[3];
+  if ((variant == 0 && (ncw == 0 || (two_ended && n_blk < 4 * bw))) || (variant != 0 && two_ended) || (variant == 1 && bw * bw > kCholThreads) ||
+      (variant == 2 && bw > 21) || (variant == 4 && !dense_factor_fits(n_blk - f0, std::min(bw, n_blk - f0)))) {
+    fprintf(stderr, "band width / length outside the kernel's range\n");
     return 3;
   }
   std::vector<double> Ub(size_t(np) * ncb, 0.0), Ubk(size_t(24) * n_blk, 0.0), yb(np, 0.0), Ub2 = Ub, Ubk2 = Ubk, yb2 = yb;
@@ -72,20 +78,37 @@ int main(int argc, char** argv) {
   }
   const dim3 grid(two_ended ? 2 : 1);
   const std::vector<unsigned> far_first = {1, 0};  // (workgroup 0 waits at the junction for workgroup 1's window)
-  if (ncw == 3)
+  T.Sb = const_cast<double*>(Sb.data()), T.g_s = const_cast<double*>(g.data()), T.Ub = Ub.data(), T.Ubk = Ubk.data(), T.ybuf = yb.data();
+  const Tables Tfull = T;
+  if (f0 > 0) {  // launch_factor: the decoupled rows one wave each, the kernels below on the trailing sub-matrix (the band storage is row relative)
+    if (two_ended || f0 >= n_blk) return 3;
+    if (variant != 4) hs_emul::launch(dim3(f0), dim3(64), 0, [&] { k_factor_decoupled_rows(Tfull, f0); });
+    T.Sb += size_t(6 * f0) * ncb, T.g_s += 6 * f0, T.Ub += size_t(6 * f0) * ncb, T.Ubk += size_t(24) * f0, T.ybuf += 6 * f0, T.np -= 6 * f0;
+    T.fj[0] = FactorJob{T.Sb, T.g_s, T.Ub, T.Ubk, T.ybuf, nullptr, T.np / 6, -1};
+  }
+  const size_t chol_lds = (size_t(24) * (ncb + 2) + size_t(np)) * sizeof(double);  // launch_factor
+  if (variant == 1)
+    hs_emul::launch(dim3(1), dim3(kCholThreads + kCholIo), chol_lds, [&] { k_band_factor<1>(T); });
+  else if (variant == 2)
+    hs_emul::launch(dim3(1), dim3(kCholThreads + kCholIo), chol_lds, [&] { k_band_factor<2>(T); });
+  else if (variant == 3)
+    hs_emul::launch(dim3(1), dim3(kWideThreads), size_t(12) * (ncb + 2) * sizeof(double), [&] { k_band_factor_wide(T); });
+  else if (variant == 4)  // (the dense kernel writes the decoupled rows with extra workgroups of its own launch)
+    hs_emul::launch(dim3(1 + f0), dim3(kDenseThreads), (size_t(12) * (ncb + 8) + size_t(32) * (n_blk - f0)) * sizeof(double), [&] { k_dense_factor(T, f0); });
+  else if (ncw == 3)
     hs_emul::launch(grid, dim3(la_threads(3)), la_lds, [&] { k_band_factor_la<1, 3>(T); }, two_ended ? far_first : std::vector<unsigned>{});
   else
     hs_emul::launch(grid, dim3(la_threads(4)), la_lds, [&] { k_band_factor_la<1, 4>(T); }, two_ended ? far_first : std::vector<unsigned>{});
   // ---- the sweeps (launch_factor: the inverses of the diagonal super-blocks come from extra workgroups of the same launch) ----
   std::vector<double> Vb(size_t(sb_count(n_blk) + 1) * kSbN * kSbN, 0.0), Vb2 = Vb, xsol(np, 0.0), step_p(np, 0.0), delta_p(np, 0.0);
+  T = Tfull;  // (the sweeps run on the whole factor and stop above block row f0)
   T.join_epoch = 2;
   T.scale_p = const_cast<double*>(scale_p.data()), T.g_full = const_cast<double*>(g_full.data()), T.D2p = const_cast<double*>(D2p.data());
   T.xsol = xsol.data(), T.step_p = step_p.data(), T.delta_p = delta_p.data();
-  if (6 * (bw - 1) > 96) {
-    fprintf(stderr, "band too wide for the super-block sweep\n");
-    return 3;
-  }
-  if (two_ended) {
+  if (6 * (bw - 1) > 96) {  // wide bands (long feature tracks): one block row per step, one lane per pending row (launch_factor)
+    hs_emul::launch(dim3(1), dim3(kCholThreads), 2 * size_t(np) * sizeof(double), [&] { k_band_backward(T, f0); });
+    for (int i = 0; i < np; ++i) xsol[i] = -step_p[i];
+  } else if (two_ended) {
     const BackJob j0{Ub.data(), Ubk.data(), yb.data(), Vb.data(), nullptr, m + w_mid, 0, 0};
     const BackJob j1{Ub2.data(), Ubk2.data(), yb2.data(), Vb2.data(), nullptr, mB, w_mid, 1};
     const size_t g_lds = size_t(6 * (bw - 1)) * (6 * (bw - 1) | 1) * sizeof(double);
@@ -102,7 +125,7 @@ int main(int argc, char** argv) {
     std::vector<unsigned> order;
     for (unsigned w = 1; w < n_wg; ++w) order.push_back(w);
     order.push_back(0);
-    hs_emul::launch(dim3(n_wg), dim3(kCholThreads), lds, [&] { k_band_backward_sb(T, j0, j0, -1, 1, 0); }, order);
+    hs_emul::launch(dim3(n_wg), dim3(kCholThreads), lds, [&] { k_band_backward_sb(T, j0, j0, -1, 1, f0); }, order);
   }
   FILE* out = fopen(argv[2], "wb");
   const int res[4] = {m, mB, st.chol_failed, 0};

@@ -72,14 +72,14 @@ def check_job(Ub, Ubk, yb, U, y, rows, bw, col_limit=None):
     assert np.allclose(yb[:rows], y[:rows], rtol=0, atol=1e-11)
 
 
-def run(exe, tmp_path, M, g, bw, two_ended):
+def run(exe, tmp_path, M, g, bw, two_ended, variant=0, f0=0):
     n = len(M)
     P = np.arange(n)[::-1]
     src, dst = str(tmp_path / "sys.bin"), str(tmp_path / "out.bin")
     aux = np.random.default_rng(n + bw)
     scale, g_full, d2 = aux.uniform(0.5, 2.0, n), aux.standard_normal(n), aux.uniform(0.0, 1.0, n)  # operands of the step outputs
     with open(src, "wb") as f:
-        f.write(struct.pack("=4i", n, bw, int(two_ended), 0))
+        f.write(struct.pack("=4i", n, bw, int(two_ended) | (f0 << 8), variant))
         for a in (band_rows(M, bw), g, band_rows(M[np.ix_(P, P)], bw), g[P], scale, g_full, d2):
             f.write(np.ascontiguousarray(a, dtype="<f8").tobytes())
     subprocess.check_call([exe, src, dst], timeout=600)
@@ -154,3 +154,34 @@ def test_two_ended_factor_against_numpy(n_blk, bw, harness, tmp_path):
         for a in range(6):
             for c in range(a, 6):
                 assert abs(Ubk[24 * i + a * 6 - a * (a - 1) // 2 + (c - a)] - W[a, c]) <= 1e-9 * max(1.0, abs(W[a, c]))
+
+
+@pytest.mark.parametrize("variant,n_blk,bw", [(1, 20, 12), (1, 14, 16), (2, 24, 18), (2, 23, 21), (3, 20, 24), (3, 17, 30), (4, 24, 20), (4, 30, 17)])
+def test_other_band_kernels_against_numpy(variant, n_blk, bw, harness, tmp_path):
+    """The one-ended kernels launch_factor picks for other band shapes — k_band_factor<1> (every tile in one lane: bw^2 <= 256), <2> (bw <= 21),
+    k_band_factor_wide (long feature tracks: trailing window in L2) and k_dense_factor (window-wide bands of the sliding-window replay) — and,
+    from 18 control points per landmark on, the sweep with one block row per step (k_band_backward): factor, inverted diagonal blocks,
+    forward-solved right-hand side and the solution against numpy."""
+    rng = np.random.default_rng(1000 * variant + 10 * n_blk + bw)
+    M = banded_spd(rng, n_blk, bw)
+    g = rng.standard_normal(6 * n_blk)
+    _, _, Ub, Ubk, yb, _, _, _ = run(harness, tmp_path, M, g, bw, False, variant)
+    U = np.linalg.cholesky(M).T
+    check_job(Ub, Ubk, yb, U, np.linalg.solve(U.T, g), 6 * n_blk, bw)
+
+
+@pytest.mark.parametrize("variant,n_blk,bw,f0", [(0, 30, 14, 9), (1, 20, 12, 5), (2, 24, 18, 11), (3, 20, 24, 7), (4, 36, 18, 14), (0, 24, 6, 23)])
+def test_frozen_prefix_against_numpy(variant, n_blk, bw, f0, harness, tmp_path):
+    """Sliding window: the leading block rows belong to constant control points — unit diagonal, no coupling, zero right-hand side. They are
+    factored one wave each (k_factor_decoupled_rows; extra workgroups of the k_dense_factor launch), the dependency chain of the factorisation
+    and of the sweeps starts behind them (launch_factor: pointer offsets into the row-relative band storage, j_lo of the sweeps)."""
+    rng = np.random.default_rng(77 * variant + n_blk + bw + f0)
+    M = banded_spd(rng, n_blk, bw)
+    g = rng.standard_normal(6 * n_blk)
+    k = 6 * f0
+    M[:k, :], M[:, :k] = 0.0, 0.0
+    M[:k, :k] = np.eye(k)
+    g[:k] = 0.0
+    _, _, Ub, Ubk, yb, _, _, _ = run(harness, tmp_path, M, g, bw, False, variant, f0)
+    U = np.linalg.cholesky(M).T
+    check_job(Ub, Ubk, yb, U, np.linalg.solve(U.T, g), 6 * n_blk, bw)

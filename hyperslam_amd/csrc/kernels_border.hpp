@@ -328,13 +328,16 @@ __global__ void __launch_bounds__(kBlock) k_border_forward(Tables T, int j_lo, i
 #pragma unroll
     for (int k = 0; k < 6; ++k) w[k] = W[k <= da ? k * 6 - k * (k - 1) / 2 + (da - k) : 0];
   };
-  auto diag_solve = [&](int m, const double* w) {  // wave 0: z_m = U_mm^-T s_m = W' s_m, into zi[m & 1] and over s_m
+  auto diag_solve = [&](int m, const double* w) {  // wave 0 (every lane calls): z_m = U_mm^-T s_m = W' s_m, into zi[m & 1] and over s_m
+    double v = 0.0;
     if (diag) {
-      double v = 0.0;
 #pragma unroll
       for (int k = 0; k < 6; ++k) v = fma(k <= da ? w[k] : 0.0, z[(6 * m + k) * kBorderLd + dc], v);
+    }
+    wait_lds();  // every lane has read s_m before any lane overwrites it (the device runs the wave in lock step: the counter is already zero)
+    if (diag) {
       zi[m & 1][tid] = v;
-      z[(6 * m + da) * kBorderLd + dc] = v;  // (LDS operations of a wave are in order: every lane has read s_m before this store)
+      z[(6 * m + da) * kBorderLd + dc] = v;
     }
   };
   {  // z_m0
@@ -434,11 +437,14 @@ __global__ void __launch_bounds__(kBlock) k_border_forward2(Tables T, BfJob j0, 
 #pragma unroll
     for (int k = 0; k < 6; ++k) w[k] = W[k <= da ? k * 6 - k * (k - 1) / 2 + (da - k) : 0];
   };
-  auto diag_solve = [&](int m, const double* w) {
+  auto diag_solve = [&](int m, const double* w) {  // (wave 0, every lane calls: see k_border_forward)
+    double v = 0.0;
     if (diag) {
-      double v = 0.0;
 #pragma unroll
       for (int k = 0; k < 6; ++k) v = fma(k <= da ? w[k] : 0.0, z[(6 * m + k) * kBorderLd + dc], v);
+    }
+    wait_lds();
+    if (diag) {
       zi[m & 1][tid] = v;
       z[(6 * m + da) * kBorderLd + dc] = v;
     }

@@ -10,6 +10,7 @@
 // Usage: factor_harness <system.bin> <out.bin>
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -20,6 +21,10 @@ thread_local unsigned hs_emul::exchange_count = 0;
 dim3 blockIdx, blockDim, gridDim;
 
 #include "../../hyperslam_amd/csrc/kernels_common.hpp"
+#include "../../hyperslam_amd/csrc/kernels_linearize.hpp"
+#include "../../hyperslam_amd/csrc/kernels_sensor.hpp"
+#include "../../hyperslam_amd/csrc/kernels_schur.hpp"
+#include "../../hyperslam_amd/csrc/kernels_border.hpp"
 #include "../../hyperslam_amd/csrc/kernels_factor.hpp"
 #include "../../hyperslam_amd/csrc/kernels_backward_sb.hpp"
 
@@ -44,13 +49,19 @@ int main(int argc, char** argv) {
   if (argc < 3) return 1;
   FILE* in = fopen(argv[1], "rb");
   if (!in) return 1;
-  const std::vector<int> hdr = read_vec<int>(in, 4);  // np, bw, two-ended, 0
+  const std::vector<int> hdr = read_vec<int>(in, 6);  // np, bw, ends | f0 << 8, kernel variant, nb, 0
   // hdr[2]: bit 0 = from both ends; bits 8.. = f0, the leading block rows of constant control points (decoupled: k_factor_decoupled_rows, the
   // chain of the one-ended kernels and the sweeps start behind them — the sliding window's frozen prefix, launch_factor)
   const int np = hdr[0], bw = hdr[1], two_ended = hdr[2] & 1, f0 = hdr[2] >> 8, ncb = 6 * bw, n_blk = np / 6, w_mid = bw - 1;
   const std::vector<double> Sb = read_vec<double>(in, size_t(np) * ncb), g = read_vec<double>(in, np);
   const std::vector<double> Sb2 = read_vec<double>(in, size_t(np) * ncb), g2 = read_vec<double>(in, np);  // the reversed system
   const std::vector<double> scale_p = read_vec<double>(in, np), g_full = read_vec<double>(in, np), D2p = read_vec<double>(in, np);
+  // border unknowns (bias splines, gravity): S_pb (np x nb), S_bb (nb x nb), g_b, their scaling and damping, and per group of kBorderCols
+  // columns the first block row with a non-zero entry (Tables::bfwd_start)
+  const int nb = hdr[4], n_groups = (nb + kBorderCols - 1) / kBorderCols;
+  const std::vector<double> Spb = read_vec<double>(in, size_t(np) * nb), Sbb = read_vec<double>(in, size_t(nb) * nb), gb = read_vec<double>(in, nb);
+  const std::vector<double> scale_b = read_vec<double>(in, nb), D2b = read_vec<double>(in, nb);
+  const std::vector<int> bfwd_start = read_vec<int>(in, n_groups);
   fclose(in);
   const int ncw = la_compute_waves(bw);
   // hdr[3]: which one-ended kernel (launch_factor's rules pick one by band width and length; the test asks for each where it applies)
@@ -64,7 +75,7 @@ int main(int argc, char** argv) {
   std::vector<double> Ub(size_t(np) * ncb, 0.0), Ubk(size_t(24) * n_blk, 0.0), yb(np, 0.0), Ub2 = Ub, Ubk2 = Ubk, yb2 = yb;
   std::vector<double> win(size_t(6 * w_mid) * (ncb + 1), 0.0), xpart(8 * 1024, 0.0);
   DevState st{};
-  std::vector<unsigned> join_flag(kSbFlagBase + 2 * kSbMaxBlocks, 0u);
+  std::vector<unsigned> join_flag(kBfFlagBase + 512, 0u);  // (prepare(): junction word, super-block flags of the sweeps, one flag per column group of k_border_forward2)
   Tables T{};
   T.np = np, T.bw = bw, T.st = &st, T.join_flag = join_flag.data(), T.join_epoch = 1, T.xpart = xpart.data();
   const size_t la_lds = (size_t(42) * (ncb + 2) + size_t(np) + 48) * sizeof(double);  // launch_factor
@@ -99,9 +110,52 @@ int main(int argc, char** argv) {
     hs_emul::launch(grid, dim3(la_threads(3)), la_lds, [&] { k_band_factor_la<1, 3>(T); }, two_ended ? far_first : std::vector<unsigned>{});
   else
     hs_emul::launch(grid, dim3(la_threads(4)), la_lds, [&] { k_band_factor_la<1, 4>(T); }, two_ended ? far_first : std::vector<unsigned>{});
+  // ---- bordered system (launch_factor): Z = U^-T S_pb in the elimination order of the factorisation, C = S_bb - Z'Z, h = g_b - Z'y,
+  //      dense Cholesky of the border, y' = y - Z x_b ----
+  std::vector<double> Zb(size_t(np) * std::max(nb, 1), 0.0), Cb(size_t(nb) * nb + 1, 0.0), hb(nb + 1, 0.0), xb(nb + 1, 0.0), delta_b(nb + 1, 0.0);
+  std::vector<double> handover(size_t(std::max(n_groups, 1)) * 6 * w_mid * kBorderCols + 1, 0.0);
+  if (nb > 0) {
+    if (f0 > 0 || variant != 0) return 3;
+    Tables Tb = T;
+    Tb.nb = nb, Tb.Spb = const_cast<double*>(Spb.data()), Tb.Sbb = const_cast<double*>(Sbb.data()), Tb.gb_s = const_cast<double*>(gb.data());
+    Tb.Zb = Zb.data(), Tb.Cb = Cb.data(), Tb.hb = hb.data(), Tb.xb = xb.data(), Tb.bfwd_start = bfwd_start.data();
+    Tb.ybuf = yb.data(), Tb.ybuf2 = nullptr, Tb.y_split = np;
+    const int fwd_threads = std::max(128, 64 * ((6 * w_mid + 63) / 64));  // one lane per pending row
+    const int n_tiles = (nb + kSchurTile - 1) / kSchurTile;
+    if (two_ended) {
+      Tb.ybuf2 = yb2.data(), Tb.y_split = 6 * (m + w_mid);
+      Tb.join_epoch = 3;
+      hs_emul::launch(dim3(n_groups, 2), dim3(fwd_threads), size_t(np) * kBorderLd * sizeof(double), [&] {
+        k_border_forward2(Tb, BfJob{Ub.data(), Ubk.data(), m + w_mid, 0}, BfJob{Ub2.data(), Ubk2.data(), mB, 1}, m, 0, 1, handover.data());
+      });
+      hs_emul::launch(dim3(n_tiles, n_tiles), dim3(kBlock), 0, [&] { k_border_schur(Tb, 0, 1, m); });
+    } else {
+      hs_emul::launch(dim3(n_groups), dim3(fwd_threads), size_t(np) * kBorderLd * sizeof(double), [&] { k_border_forward(Tb, 0, 1); });
+      hs_emul::launch(dim3(n_tiles, n_tiles), dim3(kBlock), 0, [&] { k_border_schur(Tb, 0, 1, n_blk); });
+    }
+    {  // launch_border_solve
+      const int R = std::max(4, (nb + 1 + 15) / 16), N = 16 * R;
+      const size_t lds = (size_t(4) * N + size_t(nb) * (N + 1) + nb) * sizeof(double);
+      if (nb + 1 > 128)
+        hs_emul::launch(dim3(1), dim3(kBlock), (size_t(nb + 1) * (nb + 1) + nb) * sizeof(double), [&] { k_border_solve(Tb); });
+      else if (R == 4)
+        hs_emul::launch(dim3(1), dim3(kBlock), lds, [&] { k_border_solve_reg<4>(Tb); });
+      else if (R == 5)
+        hs_emul::launch(dim3(1), dim3(kBlock), lds, [&] { k_border_solve_reg<5>(Tb); });
+      else if (R == 6)
+        hs_emul::launch(dim3(1), dim3(kBlock), lds, [&] { k_border_solve_reg<6>(Tb); });
+      else if (R == 7)
+        hs_emul::launch(dim3(1), dim3(kBlock), lds, [&] { k_border_solve_reg<7>(Tb); });
+      else
+        hs_emul::launch(dim3(1), dim3(kBlock), lds, [&] { k_border_solve_reg<8>(Tb); });
+    }
+    hs_emul::launch(dim3((np + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, [&] { k_border_apply(Tb); });
+    T.nb = nb, T.xb = xb.data(), T.delta_b = delta_b.data(), T.scale_b = const_cast<double*>(scale_b.data()), T.gb_s = const_cast<double*>(gb.data());
+    T.D2b = const_cast<double*>(D2b.data());
+  }
   // ---- the sweeps (launch_factor: the inverses of the diagonal super-blocks come from extra workgroups of the same launch) ----
   std::vector<double> Vb(size_t(sb_count(n_blk) + 1) * kSbN * kSbN, 0.0), Vb2 = Vb, xsol(np, 0.0), step_p(np, 0.0), delta_p(np, 0.0);
-  T = Tfull;  // (the sweeps run on the whole factor and stop above block row f0)
+  if (f0 > 0) T = Tfull;  // (the sweeps run on the whole factor and stop above block row f0)
   T.join_epoch = 2;
   T.scale_p = const_cast<double*>(scale_p.data()), T.g_full = const_cast<double*>(g_full.data()), T.D2p = const_cast<double*>(D2p.data());
   T.xsol = xsol.data(), T.step_p = step_p.data(), T.delta_p = delta_p.data();
@@ -133,6 +187,13 @@ int main(int argc, char** argv) {
   write_vec(out, Ub), write_vec(out, Ubk), write_vec(out, yb), write_vec(out, Ub2), write_vec(out, Ubk2), write_vec(out, yb2);
   write_vec(out, xsol), write_vec(out, step_p), write_vec(out, delta_p);
   write_vec(out, {st.g_dot_step_pose, st.d2_step2_pose, st.g_dot_step_far, st.d2_step2_far});
+  xb.resize(nb), delta_b.resize(nb);
+  write_vec(out, xb), write_vec(out, delta_b);
+  if (getenv("HS_EMUL_DEBUG")) {
+    FILE* d = fopen(getenv("HS_EMUL_DEBUG"), "wb");
+    write_vec(d, Zb), write_vec(d, Cb), write_vec(d, hb);
+    fclose(d);
+  }
   fclose(out);
   return 0;
 }

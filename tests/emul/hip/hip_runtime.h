@@ -170,6 +170,8 @@ inline void wait_vmem() {}
 inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 #define __HIP_MEMORY_SCOPE_AGENT 0
+#define __builtin_nontemporal_load(p) (*(p))
+inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 #define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(order)
 namespace hs_emul {
 template <class T>

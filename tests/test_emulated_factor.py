@@ -6,6 +6,8 @@ by the backward sweeps in super-blocks with their inverse builders (kernels_back
 included) against numpy's solve: solution, step, scaled step and both ends' shares of the model cost change.
 The `-m gpu` tests (test_every_band_width, test_band_widths_from_both_ends) remain the parity tests of the compiled kernel; this one makes
 its index arithmetic — ring slots, look-ahead, hand-over of the far end's window in the near end's coordinates — checkable without a GPU.
+Further down: the kernels launch_factor picks for other band shapes, the sliding window's frozen prefix, and the bordered solve of windows
+with an IMU (kernels_border.hpp: forward sweep of the border columns from one or both ends, border Schur complement, dense Cholesky, y').
 Replaces what CHOLMOD does for /root/reference/internal/hyper/optimizers/ceres/optimizer.cpp:46-48 (SPARSE_NORMAL_CHOLESKY)."""
 import os
 import shutil
@@ -72,29 +74,47 @@ def check_job(Ub, Ubk, yb, U, y, rows, bw, col_limit=None):
     assert np.allclose(yb[:rows], y[:rows], rtol=0, atol=1e-11)
 
 
-def run(exe, tmp_path, M, g, bw, two_ended, variant=0, f0=0):
+def run(exe, tmp_path, M, g, bw, two_ended, variant=0, f0=0, border=None):
+    """border = (S_pb, S_bb, g_b, first non-zero block row per group of two border columns): the bordered system [M S_pb; S_pb' S_bb]."""
     n = len(M)
     P = np.arange(n)[::-1]
     src, dst = str(tmp_path / "sys.bin"), str(tmp_path / "out.bin")
     aux = np.random.default_rng(n + bw)
     scale, g_full, d2 = aux.uniform(0.5, 2.0, n), aux.standard_normal(n), aux.uniform(0.0, 1.0, n)  # operands of the step outputs
+    nb = 0 if border is None else len(border[2])
+    scale_b, d2b = aux.uniform(0.5, 2.0, nb), aux.uniform(0.0, 1.0, nb)
     with open(src, "wb") as f:
-        f.write(struct.pack("=4i", n, bw, int(two_ended) | (f0 << 8), variant))
+        f.write(struct.pack("=6i", n, bw, int(two_ended) | (f0 << 8), variant, nb, 0))
         for a in (band_rows(M, bw), g, band_rows(M[np.ix_(P, P)], bw), g[P], scale, g_full, d2):
             f.write(np.ascontiguousarray(a, dtype="<f8").tobytes())
-    subprocess.check_call([exe, src, dst], timeout=600)
+        if border is not None:
+            for a in (border[0], border[1], border[2], scale_b, d2b):
+                f.write(np.ascontiguousarray(a, dtype="<f8").tobytes())
+            f.write(np.ascontiguousarray(border[3], dtype="<i4").tobytes())
+    subprocess.check_call([exe, src, dst], timeout=180)
     raw = open(dst, "rb").read()
     m, mB, failed, _ = struct.unpack("=4i", raw[:16])
     v = np.frombuffer(raw[16:], dtype="<f8")
     ncb, nU, nK = 6 * bw, n * 6 * bw, 24 * (n // 6)
     parts, o = [], 0
-    for size in (nU, nK, n, nU, nK, n, n, n, n, 4):
+    for size in (nU, nK, n, nU, nK, n, n, n, n, 4, nb, nb):
         parts.append(v[o:o + size])
         o += size
     assert failed == 0 and o == len(v)
     # ---- the sweeps: solution, step = -x, scaled step, and the two sums of the model cost change (decide_step adds the two ends' shares) ----
-    x = np.linalg.solve(M, g)
     xsol, step, delta, sums = parts[6:10]
+    if border is not None:  # bordered solve: Z = U^-T S_pb, C = S_bb - Z'Z, dense Cholesky, y' = y - Z x_b, then the sweeps on y'
+        A = np.block([[M, border[0]], [border[0].T, border[1]]])
+        xa = np.linalg.solve(A, np.concatenate([g, border[2]]))
+        xb, delta_b = parts[10], parts[11]
+        tol = 1e-9 * max(1.0, np.abs(xa).max())
+        assert np.allclose(xb, xa[n:], rtol=0, atol=tol) and np.allclose(step, -xa[:n], rtol=0, atol=tol)
+        assert np.array_equal(delta_b, scale_b * -xb) and np.array_equal(delta, scale * step)
+        want_g, want_d = g_full @ step + border[2] @ -xb, (d2 * step) @ step + (d2b * xb) @ xb
+        assert abs(sums[0] + sums[2] - want_g) <= 1e-12 * (np.abs(g_full * step).sum() + np.abs(border[2] * xb).sum())
+        assert abs(sums[1] + sums[3] - want_d) <= 1e-12 * want_d
+        return m, mB, parts[0].reshape(n, ncb), parts[1], parts[2], parts[3].reshape(n, ncb), parts[4], parts[5]
+    x = np.linalg.solve(M, g)
     assert np.allclose(step, -x, rtol=0, atol=1e-9 * max(1.0, np.abs(x).max()))
     if two_ended:
         assert np.array_equal(xsol, -step)
@@ -185,3 +205,31 @@ def test_frozen_prefix_against_numpy(variant, n_blk, bw, f0, harness, tmp_path):
     _, _, Ub, Ubk, yb, _, _, _ = run(harness, tmp_path, M, g, bw, False, variant, f0)
     U = np.linalg.cholesky(M).T
     check_job(Ub, Ubk, yb, U, np.linalg.solve(U.T, g), 6 * n_blk, bw)
+
+
+def bordered(rng, M, n_b, n_blk):
+    """Border columns as bias points and gravity make them: a column meets a contiguous stretch of the pose rows (zero above its first block
+    row), columns come in groups of two that start together; S_bb makes the whole system positive definite."""
+    n = len(M)
+    B = np.zeros((n, n_b))
+    n_groups = (n_b + 1) // 2
+    start = np.sort(rng.integers(0, max(1, n_blk - 4), n_groups))
+    start[-1] = 0  # (gravity: every row)
+    for c in range(n_b):
+        r0 = 6 * start[c // 2]
+        r1 = n if c // 2 == n_groups - 1 else min(n, r0 + 6 * int(rng.integers(3, 9)))
+        B[r0:r1, c] = 0.1 * rng.standard_normal(r1 - r0)
+    C = B.T @ np.linalg.solve(M, B) + np.diag(rng.uniform(0.5, 1.5, n_b))
+    return B, C, rng.standard_normal(n_b), start
+
+
+@pytest.mark.parametrize("n_blk,bw,n_b,two_ended", [(24, 6, 9, False), (30, 14, 21, False), (64, 16, 57, True), (40, 10, 99, True), (31, 6, 3, True)])
+def test_bordered_solve_against_numpy(n_blk, bw, n_b, two_ended, harness, tmp_path):
+    """Windows with an IMU: the border chain behind the band factorisation — k_border_forward / k_border_forward2 (both ends, hand-over of the
+    far end's updates of the middle rows per column group), k_border_schur, k_border_solve_reg (trailing matrix in registers, two columns per
+    barrier, one-wave backward sweep), k_border_apply — and the sweeps with the border's step outputs, against numpy's solve of the whole
+    bordered system. Replaces the dense tail of CHOLMOD's factorisation for optimizer.cpp:46-48."""
+    rng = np.random.default_rng(5 * n_blk + bw + n_b)
+    M = banded_spd(rng, n_blk, bw)
+    g = rng.standard_normal(6 * n_blk)
+    run(harness, tmp_path, M, g, bw, two_ended, border=bordered(rng, M, n_b, n_blk))

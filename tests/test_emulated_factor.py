@@ -223,7 +223,8 @@ def bordered(rng, M, n_b, n_blk):
     return B, C, rng.standard_normal(n_b), start
 
 
-@pytest.mark.parametrize("n_blk,bw,n_b,two_ended", [(24, 6, 9, False), (30, 14, 21, False), (64, 16, 57, True), (40, 10, 99, True), (31, 6, 3, True)])
+@pytest.mark.parametrize("n_blk,bw,n_b,two_ended", [(24, 6, 9, False), (30, 14, 21, False), (64, 16, 57, True), (40, 10, 99, True), (31, 6, 3, True),
+                                                    (26, 5, 131, False)])  # (more than 127 border unknowns: k_border_solve, the trailing matrix in LDS)
 def test_bordered_solve_against_numpy(n_blk, bw, n_b, two_ended, harness, tmp_path):
     """Windows with an IMU: the border chain behind the band factorisation — k_border_forward / k_border_forward2 (both ends, hand-over of the
     far end's updates of the middle rows per column group), k_border_schur, k_border_solve_reg (trailing matrix in registers, two columns per

@@ -20,6 +20,8 @@ dim3 blockIdx, blockDim, gridDim;
 #include "../../hyperslam_amd/csrc/kernels_linearize.hpp"
 #include "../../hyperslam_amd/csrc/kernels_schur.hpp"
 #include "../../hyperslam_amd/csrc/kernels_build.hpp"
+#include "../../hyperslam_amd/csrc/kernels_factor.hpp"
+#include "../../hyperslam_amd/csrc/kernels_backward_sb.hpp"
 #include "../../hyperslam_amd/csrc/kernels_update.hpp"
 
 namespace hs {
@@ -119,7 +121,7 @@ static void check_fold(const Tables& U, int nb_vis, int R, int L, size_t lds, co
 
 /// The candidate point two ways: k_update_visual (per chunk) against k_backsub_retract + k_cost_visual (per landmark / per residual).
 template <int K>
-static void run_update(Tables& T, int nb_vis, int R, int L, std::vector<double>* out, size_t build_lds, const Sizes& z, bool fold_check) {
+static void run_update(Tables& T, int nb_vis, int R, int L, std::vector<double>* out, size_t build_lds, const Sizes& z, bool fold_check, bool decide) {
   const int n_lm = T.n_lm, n_cp = T.sp.n_cp;
   std::vector<double> lm_cand_a(3 * size_t(std::max(n_lm, 1))), cp_cand_a(8 * size_t(n_cp)), cand_a(nb_vis + 1), norm_a(2 * size_t(T.n_norm_part));
   std::vector<double> lm_part_a(4 * size_t((n_lm + 3) / 4) + 4);
@@ -146,6 +148,17 @@ static void run_update(Tables& T, int nb_vis, int R, int L, std::vector<double>*
   out->assign({dlm, dcp, sum(cand_a, nb_vis), sum(cand_b, nb_vis)});
   for (int e = 0; e < 4; ++e) out->push_back(sum(lm_part_a, A.n_lm_part, 4, e)), out->push_back(sum(lm_part_b, B.n_lm_part, 4, e));
   for (int e = 0; e < 2; ++e) out->push_back(sum(norm_a, T.n_norm_part, 2, e)), out->push_back(sum(norm_b, T.n_norm_part, 2, e));
+  if (decide) {  // full iteration: the trust-region decision on the fused path's partials (k_pack_decision(3): decides, commits the control points)
+    std::vector<double> cp_work(T.cp, T.cp + 8 * size_t(n_cp));
+    B.cp = cp_work.data();
+    hs_emul::launch(dim3(1), dim3(kBlock), 0, [&] { k_pack_decision(B, 3); });
+    const hs_iteration& r = B.st->records[0];
+    out->insert(out->end(), {r.cost, r.cost_change, r.gradient_max_norm, r.step_norm, r.relative_decrease, r.radius, double(r.step_is_valid), double(r.step_is_successful),
+                             B.st->cost, double(B.st->accepted), double(B.st->done)});
+    double dcp = 0;  // an accepted candidate was committed
+    for (size_t i = 0; i < 8 * size_t(n_cp); ++i) dcp = std::max(dcp, std::fabs(cp_work[i] - (B.st->accepted ? cp_cand_b[i] : T.cp[i])));
+    out->push_back(dcp);
+  }
 }
 
 int main(int argc, char** argv) {
@@ -156,7 +169,8 @@ int main(int argc, char** argv) {
   const int k = hdr[0], n_cp = hdr[1], n_lm = hdr[2], n_px = hdr[3], n_br = hdr[4], n_cam = hdr[5], rot_c = hdr[6], tr_c = hdr[7];
   int R = hdr[8], L = hdr[9];
   const int scaling_ready = hdr[10];
-  const bool fold_check = hdr[11] != 0;  // also run the decision folded into the build against k_pack_decision + build (check_fold)
+  const bool fold_check = (hdr[11] & 1) != 0;  // also run the decision folded into the build against k_pack_decision + build (check_fold)
+  const bool full_iteration = (hdr[11] & 2) != 0;  // factor + sweeps on the built system, the update along the REAL step, the decision: one LM iteration
   const std::vector<double> par = rd.vec<double>(3);
   const double t0 = par[0], dt = par[1], radius = par[2];
   std::vector<double> cp = rd.vec<double>(size_t(8) * n_cp);
@@ -268,15 +282,45 @@ int main(int argc, char** argv) {
   // a step to retract along (any vector will do for the comparison of the two update paths): step_p fabricated, delta_p = s_p o step_p
   std::vector<double> step_p(np), delta_p(np), lm_sb_dummy;
   for (int i = 0; i < np; ++i) step_p[i] = 1e-2 * std::sin(0.37 * i + 0.1) * (D2p[i] != 0.0 ? 1.0 : 0.0), delta_p[i] = -step_p[i] * scale_p[i];
+  // Full iteration: the REAL step instead — the band Cholesky of the system built above and the sweeps, with launch_factor's choices for a
+  // short window (one-ended: fewer than 4 bw block rows; look-ahead kernel where the band fits its compute waves, k_band_factor<1> otherwise)
+  const int n_blk = np / 6;
+  std::vector<double> Ub(size_t(np) * ncb, 0.0), Ubk(size_t(24) * n_blk, 0.0), ybuf(np, 0.0), Vb(size_t(sb_count(n_blk) + 1) * kSbN * kSbN, 0.0), xpart(8 * 1024, 0.0);
+  std::vector<unsigned> join_flag(kSbFlagBase + 2 * kSbMaxBlocks, 0u);
+  if (full_iteration) {
+    if (n_blk >= 4 * bw || 6 * (bw - 1) > 96) return 9;  // (two-ended / wide-band windows: tests/emul/factor_harness.cpp)
+    T.Ub = Ub.data(), T.Ubk = Ubk.data(), T.ybuf = ybuf.data(), T.join_flag = join_flag.data(), T.join_epoch = 1, T.xpart = xpart.data();
+    T.step_p = step_p.data(), T.delta_p = delta_p.data();
+    T.fj[0] = FactorJob{T.Sb, T.g_s, T.Ub, T.Ubk, T.ybuf, nullptr, n_blk, -1};
+    const size_t la_lds = (size_t(42) * (ncb + 2) + size_t(np) + 48) * sizeof(double), chol_lds = (size_t(24) * (ncb + 2) + size_t(np)) * sizeof(double);
+    const int ncw = la_compute_waves(bw);
+    if (ncw == 3)
+      hs_emul::launch(dim3(1), dim3(la_threads(3)), la_lds, [&] { k_band_factor_la<1, 3>(T); });
+    else if (ncw == 4)
+      hs_emul::launch(dim3(1), dim3(la_threads(4)), la_lds, [&] { k_band_factor_la<1, 4>(T); });
+    else if (bw * bw <= kCholThreads)
+      hs_emul::launch(dim3(1), dim3(kCholThreads + kCholIo), chol_lds, [&] { k_band_factor<1>(T); });
+    else
+      return 9;
+    T.join_epoch = 2;
+    const BackJob j0{T.Ub, T.Ubk, T.ybuf, Vb.data(), nullptr, n_blk, 0, 0};
+    const unsigned n_wg = 1 + sb_count(n_blk);
+    std::vector<unsigned> order;
+    for (unsigned w = 1; w < n_wg; ++w) order.push_back(w);
+    order.push_back(0);  // the inverse builders, then the sweep
+    hs_emul::launch(dim3(n_wg), dim3(kCholThreads), std::max((2 * size_t(np) + 32) * sizeof(double), size_t(3 * kSbN * (kSbN + 1)) * sizeof(double)),
+                    [&] { k_band_backward_sb(T, j0, j0, -1, 1, 0); }, order);
+    if (st.chol_failed) return 10;
+  }
   std::vector<double> norm_part(2), upd;
   T.step_p = step_p.data(), T.delta_p = delta_p.data(), T.n_norm_part = std::max((n_cp + kBlock - 1) / kBlock, 1), T.norm_part = norm_part.data();
   const Sizes z{grpQ.size(), cost_part.size(), Y.size(), nl};
   if (k == 4)
-    run_update<4>(T, nb_vis, R, L, &upd, lds, z, fold_check);
+    run_update<4>(T, nb_vis, R, L, &upd, lds, z, fold_check, full_iteration);
   else if (k == 5)
-    run_update<5>(T, nb_vis, R, L, &upd, lds, z, fold_check);
+    run_update<5>(T, nb_vis, R, L, &upd, lds, z, fold_check, full_iteration);
   else
-    run_update<6>(T, nb_vis, R, L, &upd, lds, z, fold_check);
+    run_update<6>(T, nb_vis, R, L, &upd, lds, z, fold_check, full_iteration);
 
   FILE* out = fopen(argv[2], "wb");
   const int ohdr[8] = {bw, np, n_chunk, R, L, vs.y_total, int(lds), int(upd.size())};

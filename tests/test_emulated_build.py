@@ -36,7 +36,7 @@ def _pack_cameras(w):
     return cam
 
 
-def run_emulated_build(exe, w, radius=1e4, R=0, L=0, scaling=None, fold=False):
+def run_emulated_build(exe, w, radius=1e4, R=0, L=0, scaling=None, fold=False, full=False):
     """Returns dict(S, g, cost, bw, n_chunk, Y, lm_scale, scale_p) of the emulated fused build on window `w`."""
     n_cp, n_lm = w.n_cp, len(w.landmarks)
     n_px, n_br = len(w.pixel_stamps), len(w.bearing_stamps)
@@ -44,7 +44,7 @@ def run_emulated_build(exe, w, radius=1e4, R=0, L=0, scaling=None, fold=False):
     cpc = np.zeros(n_cp, i32) if w.cp_constant is None else np.asarray(w.cp_constant, i32)
     lmc = np.zeros(n_lm, i32) if w.landmark_constant is None else np.asarray(w.landmark_constant, i32)
     hdr = np.array([w.order, n_cp, n_lm, n_px, n_br, len(w.cam_T_bs), int(w.rotation_constant), int(w.translation_constant), R, L,
-                    1 if scaling is not None else 0, 1 if fold else 0], i32)
+                    1 if scaling is not None else 0, (1 if fold else 0) | (2 if full else 0)], i32)
     parts = [hdr, np.array([w.t0, w.dt, radius], f64), np.asarray(w.control_points, f64), cpc, _pack_cameras(w), np.asarray(w.landmarks, f64), lmc,
              np.asarray(w.pixel_stamps, f64), np.asarray(w.pixels, f64), np.asarray(w.pixel_landmark, i32), np.asarray(w.pixel_camera, i32),
              np.asarray(w.bearing_stamps, f64), np.asarray(w.bearings, f64), np.asarray(w.bearing_landmark, i32), np.asarray(w.bearing_camera, i32)]
@@ -137,3 +137,23 @@ def test_emulated_decision_folded_into_build(harness, order, R, L):
     build agree bit for bit."""
     w = synthetic.small_visual(order=order, n_cp=14 if order == 4 else 16, n_landmarks=30, obs_pairs=3)
     run_emulated_build(harness, w, R=R, L=L, fold=True)
+
+
+@pytest.mark.parametrize("order,bearing,n_cp", [(4, False, 14), (6, False, 16), (4, True, 20), (5, False, 15)])
+def test_emulated_full_iteration_matches_oracle(harness, oracle, order, bearing, n_cp):
+    """One whole LM iteration of the product's kernel chain on the CPU — k_build_visual -> k_assemble -> k_finalize_reduced -> band Cholesky ->
+    sweeps (inverse builders + super-block sweep) -> k_update_visual along the step the sweeps delivered -> k_pack_decision — against the
+    oracle's first iteration: cost before and after, gradient max norm, step norm, step quality, new radius, acceptance."""
+    w = synthetic.small_visual(order=order, n_cp=n_cp, n_landmarks=40, obs_pairs=3, bearing=bearing)
+    out = run_emulated_build(harness, w, full=True)
+    u = out["upd"]
+    assert u[0] <= 1e-12 and u[1] == 0.0, u[:2]  # k_update_visual against k_backsub_retract + k_cost_visual along the real step
+    cost_after, cost_change, gmax, step_norm, rel_dec, radius, valid, ok, st_cost, accepted, done, dcp = u[-12:]
+    with ha.Problem(w, lib=oracle) as p:
+        s = p.solve(1)
+    r = s["iterations"][0]
+    assert s["num_iterations"] == 1 and valid == r["step_is_valid"] == 1 and ok == r["step_is_successful"] and accepted == ok and dcp == 0.0
+    for got, name in ((cost_after, "cost"), (cost_change, "cost_change"), (gmax, "gradient_max_norm"), (step_norm, "step_norm"), (rel_dec, "relative_decrease"),
+                      (radius, "radius")):
+        assert abs(got - r[name]) <= 1e-9 * max(abs(r[name]), 1e-300), (name, got, r[name])
+    assert abs(st_cost - s["final_cost"]) <= 1e-9 * s["final_cost"]

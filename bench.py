@@ -272,8 +272,9 @@ def main():
 
     # Per-stage HIP events (4 per LM iteration, each a barrier packet worth ~5.7 us of idle device) are off in the library by default.
     # One step in STAGE_EVERY of the timed region runs with them on: the live launch duration of the linearisation kernel (roofline) and
-    # the stage breakdown come from those launches, inside the timed region, at a quarter of the events' cost to `value`.
-    STAGE_EVERY = 4
+    # the stage breakdown come from those launches, inside the timed region, at an eighth of the events' cost to `value`
+    # (every 4th step until the end of round 4: 2.5 % of `value` went to the instrumentation; 25 sampled launches of 200 are plenty).
+    STAGE_EVERY = 8
 
     def step(i=0):
         staged = i % STAGE_EVERY == 0

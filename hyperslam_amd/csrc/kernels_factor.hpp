@@ -324,6 +324,48 @@ constexpr int la_threads(int ncw) { return ncw == 3 ? 6 * 64 : 7 * 64; }
 
 HSD void begin_iteration(const Tables& T, double cost, double gmax, bool set_scaling_ready);  // kernels_update.hpp
 
+/// Iteration bookkeeping inside the factorisation (Tables::bookkeep; one wave, lane l): see the comment in the body.
+HSD void factor_bookkeep(const Tables& T, int l) {
+  DevState* st = T.st;
+  // Iteration bookkeeping of a linearisation whose rows k_assemble wrote itself (no k_finalize_reduced launch): cost of the current point,
+  // gradient max norm, record of the previous iteration, termination tests — what the packing workgroup of k_finalize_reduced does
+  // (pack_exchange_body + begin_iteration). This wave has nothing to do until X_0 exists: it reduces the ~6 000 doubles alone, in a
+  // fixed order, without a workgroup barrier. The factorisation does not wait for the verdict: if a termination test fires, this one
+  // factorisation was for nothing and every later kernel of the solve exits on `done` as usual. (As a prologue of the whole workgroup —
+  // reductions across six waves, early exit — the same work cost 4.5 us on the chain.)
+  double s = 0.0, gm = 0.0;
+  for (int i0 = l; i0 < T.n_cost_part; i0 += 8 * 64) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = i0 + 64 * u < T.n_cost_part ? T.cost_part[i0 + 64 * u] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  // landmark side of the gradient: one value per chunk of the fused build (launch_build only takes this path on the fused one)
+  for (int i0 = l; i0 < T.n_chunk; i0 += 16 * 64) {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = i0 + 64 * u < T.n_chunk ? T.ch_gmax[i0 + 64 * u] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) gm = fmax(gm, v[u]);
+  }
+  for (int i0 = l; i0 < T.np; i0 += 16 * 64) {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = i0 + 64 * u < T.np ? T.gabs[i0 + 64 * u] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) gm = fmax(gm, v[u]);
+  }
+  s = wave_sum(s);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) gm = fmax(gm, __shfl_xor(gm, o));
+  if (l == 0) {
+    T.xbuf[T.xo_cost] = s;
+    st->local_cost = s;
+    begin_iteration(T, s, gm, false);
+  }
+}
+
 template <int TPT, int NCW>  // one tile per compute lane; NCW compute waves
 __global__ void __launch_bounds__(la_threads(NCW)) k_band_factor_la(Tables T) {
   HS_DYNAMIC_LDS(smem);
@@ -456,45 +498,7 @@ __global__ void __launch_bounds__(la_threads(NCW)) k_band_factor_la(Tables T) {
       lds_barrier();
       if (dump) lds_barrier();  // window written by the panel / compute waves
     } else {
-      if (T.bookkeep && blockIdx.x == 0) {
-        // Iteration bookkeeping of a linearisation whose rows k_assemble wrote itself (no k_finalize_reduced launch): cost of the current point,
-        // gradient max norm, record of the previous iteration, termination tests — what the packing workgroup of k_finalize_reduced does
-        // (pack_exchange_body + begin_iteration). This wave has nothing to do until X_0 exists: it reduces the ~6 000 doubles alone, in a
-        // fixed order, without a workgroup barrier. The factorisation does not wait for the verdict: if a termination test fires, this one
-        // factorisation was for nothing and every later kernel of the solve exits on `done` as usual. (As a prologue of the whole workgroup —
-        // reductions across six waves, early exit — the same work cost 4.5 us on the chain.)
-        double s = 0.0, gm = 0.0;
-        for (int i0 = l; i0 < T.n_cost_part; i0 += 8 * 64) {
-          double v[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = i0 + 64 * u < T.n_cost_part ? T.cost_part[i0 + 64 * u] : 0.0;
-#pragma unroll
-          for (int u = 0; u < 8; ++u) s += v[u];
-        }
-        // landmark side of the gradient: one value per chunk of the fused build (launch_build only takes this path on the fused one)
-        for (int i0 = l; i0 < T.n_chunk; i0 += 16 * 64) {
-          double v[16];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) v[u] = i0 + 64 * u < T.n_chunk ? T.ch_gmax[i0 + 64 * u] : 0.0;
-#pragma unroll
-          for (int u = 0; u < 16; ++u) gm = fmax(gm, v[u]);
-        }
-        for (int i0 = l; i0 < T.np; i0 += 16 * 64) {
-          double v[16];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) v[u] = i0 + 64 * u < T.np ? T.gabs[i0 + 64 * u] : 0.0;
-#pragma unroll
-          for (int u = 0; u < 16; ++u) gm = fmax(gm, v[u]);
-        }
-        s = wave_sum(s);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) gm = fmax(gm, __shfl_xor(gm, o));
-        if (l == 0) {
-          T.xbuf[T.xo_cost] = s;
-          st->local_cost = s;
-          begin_iteration(T, s, gm, false);
-        }
-      }
+      if (T.bookkeep && blockIdx.x == 0) factor_bookkeep(T, l);
       lds_barrier();  // init
       lds_barrier();  // prologue: X_0 complete
       for (int i = 0; i < n_steps; ++i) {

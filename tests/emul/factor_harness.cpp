@@ -26,6 +26,7 @@ dim3 blockIdx, blockDim, gridDim;
 #include "../../hyperslam_amd/csrc/kernels_schur.hpp"
 #include "../../hyperslam_amd/csrc/kernels_border.hpp"
 #include "../../hyperslam_amd/csrc/kernels_factor.hpp"
+#include "../../hyperslam_amd/csrc/kernels_factor_mx.hpp"
 #include "../../hyperslam_amd/csrc/kernels_backward_sb.hpp"
 
 namespace hs {
@@ -65,9 +66,14 @@ int main(int argc, char** argv) {
   fclose(in);
   const int ncw = la_compute_waves(bw);
   // hdr[3]: which one-ended kernel (launch_factor's rules pick one by band width and length; the test asks for each where it applies)
-  //   0 look-ahead (k_band_factor_la), 1 k_band_factor<1> (bw^2 <= 256 lanes), 2 k_band_factor<2> (bw <= 21), 3 k_band_factor_wide, 4 k_dense_factor
+  //   0 look-ahead (k_band_factor_la), 1 k_band_factor<1> (bw^2 <= 256 lanes), 2 k_band_factor<2> (bw <= 21), 3 k_band_factor_wide, 4 k_dense_factor,
+  //   5 k_band_factor_mx (trailing window in the accumulators of the f64 matrix cores; one-ended and from both ends)
   const int variant = hdr[3];
-  if ((variant == 0 && (ncw == 0 || (two_ended && n_blk < 4 * bw))) || (variant != 0 && two_ended) || (variant == 1 && bw * bw > kCholThreads) ||
+  if (variant == 5 && (!mx_fits(bw) || (two_ended && n_blk < 4 * bw) || f0 > 0)) {
+    fprintf(stderr, "band width / length outside the kernel's range\n");
+    return 3;
+  }
+  if ((variant == 0 && (ncw == 0 || (two_ended && n_blk < 4 * bw))) || (variant != 0 && variant != 5 && two_ended) || (variant == 1 && bw * bw > kCholThreads) ||
       (variant == 2 && bw > 21) || (variant == 4 && !dense_factor_fits(n_blk - f0, std::min(bw, n_blk - f0)))) {
     fprintf(stderr, "band width / length outside the kernel's range\n");
     return 3;
@@ -80,12 +86,17 @@ int main(int argc, char** argv) {
   T.np = np, T.bw = bw, T.st = &st, T.join_flag = join_flag.data(), T.join_epoch = 1, T.xpart = xpart.data();
   const size_t la_lds = (size_t(42) * (ncb + 2) + size_t(np) + 48) * sizeof(double);  // launch_factor
   int m = -1, mB = 0;
+  static const double zero = 0.0;
   if (two_ended) {  // launch_factor: the near end takes three block rows more than the far end
     m = std::min((n_blk - w_mid) / 2 + 3, n_blk - w_mid - w_mid), mB = n_blk - w_mid - m;
     T.fj[0] = FactorJob{Sb.data(), g.data(), Ub.data(), Ubk.data(), yb.data(), win.data(), m + w_mid, m};
     T.fj[1] = FactorJob{Sb2.data(), g2.data(), Ub2.data(), Ubk2.data(), yb2.data(), win.data(), mB, -1};
+    T.mj[0] = MfmaJob{Sb2.data(), g.data(), Ub.data(), Ubk.data(), yb.data(), win.data(), m + w_mid, m, m + w_mid, INT_MAX, 0, &zero};
+    T.mj[1] = MfmaJob{Sb.data(), g2.data(), Ub2.data(), Ubk2.data(), yb2.data(), win.data(), mB, -1, mB + w_mid, mB, 1, &zero};
   } else {
     T.fj[0] = FactorJob{Sb.data(), g.data(), Ub.data(), Ubk.data(), yb.data(), nullptr, n_blk, -1};
+    T.mj[0] = MfmaJob{Sb2.data(), g.data(), Ub.data(), Ubk.data(), yb.data(), nullptr, n_blk, -1, n_blk, INT_MAX, 0, &zero};
+    T.mj[1] = T.mj[0];
   }
   const dim3 grid(two_ended ? 2 : 1);
   const std::vector<unsigned> far_first = {1, 0};  // (workgroup 0 waits at the junction for workgroup 1's window)
@@ -106,6 +117,8 @@ int main(int argc, char** argv) {
     hs_emul::launch(dim3(1), dim3(kWideThreads), size_t(12) * (ncb + 2) * sizeof(double), [&] { k_band_factor_wide(T); });
   else if (variant == 4)  // (the dense kernel writes the decoupled rows with extra workgroups of its own launch)
     hs_emul::launch(dim3(1 + f0), dim3(kDenseThreads), (size_t(12) * (ncb + 8) + size_t(32) * (n_blk - f0)) * sizeof(double), [&] { k_dense_factor(T, f0); });
+  else if (variant == 5)
+    hs_emul::launch(grid, dim3(kMxThreads), size_t(kMxLds) * sizeof(double), [&] { k_band_factor_mx(T); }, two_ended ? far_first : std::vector<unsigned>{});
   else if (ncw == 3)
     hs_emul::launch(grid, dim3(la_threads(3)), la_lds, [&] { k_band_factor_la<1, 3>(T); }, two_ended ? far_first : std::vector<unsigned>{});
   else
@@ -115,7 +128,7 @@ int main(int argc, char** argv) {
   std::vector<double> Zb(size_t(np) * std::max(nb, 1), 0.0), Cb(size_t(nb) * nb + 1, 0.0), hb(nb + 1, 0.0), xb(nb + 1, 0.0), delta_b(nb + 1, 0.0);
   std::vector<double> handover(size_t(std::max(n_groups, 1)) * 6 * w_mid * kBorderCols + 1, 0.0);
   if (nb > 0) {
-    if (f0 > 0 || variant != 0) return 3;
+    if (f0 > 0 || (variant != 0 && variant != 5)) return 3;
     Tables Tb = T;
     Tb.nb = nb, Tb.Spb = const_cast<double*>(Spb.data()), Tb.Sbb = const_cast<double*>(Sbb.data()), Tb.gb_s = const_cast<double*>(gb.data());
     Tb.Zb = Zb.data(), Tb.Cb = Cb.data(), Tb.hb = hb.data(), Tb.xb = xb.data(), Tb.bfwd_start = bfwd_start.data();

@@ -143,6 +143,33 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, boo
   const int got = hs_emul::wave_exchange(src, from < 0 ? lane : from);
   return from < 0 ? old : got;
 }
+/// v_mfma_f64_16x16x4_f64 as the kernels use it (tools/microbench/mfma_probe.hip): lane l supplies A[i = l & 15][k = l >> 4] and
+/// B[k = l >> 4][j = l & 15]; register r of lane l holds D[(l >> 4) + 4 r][l & 15].
+namespace hs_emul {
+inline void wave_allgather(double v, double (&out)[64]) {
+  Block& b = block();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const unsigned buf = exchange_count++ & 1u;
+  unsigned long long bits = 0;
+  std::memcpy(&bits, &v, 8);
+  b.wave_bits[buf][wave][lane] = bits;
+  b.wave_barrier[wave].arrive_and_wait();
+  for (int l = 0; l < 64; ++l) std::memcpy(&out[l], &b.wave_bits[buf][wave][l], 8);
+}
+}  // namespace hs_emul
+typedef double hs_emul_f64x4 __attribute__((vector_size(32)));
+inline hs_emul_f64x4 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, hs_emul_f64x4 c, int, int, int) {
+  double A[64], B[64];
+  hs_emul::wave_allgather(a, A);
+  hs_emul::wave_allgather(b, B);
+  const int lane = threadIdx.x & 63, j = lane & 15, g4 = lane >> 4;
+  for (int r = 0; r < 4; ++r) {
+    double acc = c[r];
+    for (int k = 0; k < 4; ++k) acc = std::fma(A[16 * k + g4 + 4 * r], B[16 * k + j], acc);
+    c[r] = acc;
+  }
+  return c;
+}
 inline int __double2loint(double d) { unsigned long long b; std::memcpy(&b, &d, 8); return int(unsigned(b)); }
 inline int __double2hiint(double d) { unsigned long long b; std::memcpy(&b, &d, 8); return int(unsigned(b >> 32)); }
 inline double __hiloint2double(int hi, int lo) { const unsigned long long b = (static_cast<unsigned long long>(unsigned(hi)) << 32) | unsigned(lo); double d; std::memcpy(&d, &b, 8); return d; }
@@ -189,6 +216,7 @@ inline void atomic_store(T* p, V value, int order) {
 #define __hip_atomic_load(ptr, order, scope) hs_emul::atomic_load(ptr, order)
 #define __hip_atomic_store(ptr, value, order, scope) hs_emul::atomic_store(ptr, value, order)
 inline double __builtin_amdgcn_rsq(double d) { return 1.0 / std::sqrt(d); }
+inline double __builtin_amdgcn_rcp(double d) { return 1.0 / d; }
 inline long long wall_clock64() { return 0; }
 inline unsigned __builtin_amdgcn_s_getreg(int) { return 0; }
 inline double rsqrt(double d) { return 1.0 / std::sqrt(d); }

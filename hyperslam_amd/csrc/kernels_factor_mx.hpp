@@ -51,7 +51,7 @@ namespace hs {
 // ---------------------------------------------------------------------------------------------------------------------
 typedef double mx_f64x4 __attribute__((vector_size(32)));
 
-constexpr int kMxW = 96, kMxLdx = 112, kMxTiles = 21, kMxWaves = 8, kMxThreads = 64 * kMxWaves;
+constexpr int kMxW = 96, kMxLdx = 112, kMxTiles = 21, kMxWaves = 9, kMxThreads = 64 * kMxWaves;
 constexpr int kMxX = 0, kMxR = kMxX + 12 * kMxLdx, kMxS = kMxR + 12 * kMxLdx, kMxD = kMxS + 12 * kMxLdx, kMxLds = kMxD + 16;
 constexpr int kMxDiagLane = 56;  // lanes 56 .. 61 of both panel waves redo the six columns of the pivot's diagonal block
 
@@ -446,7 +446,7 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
   if (tid == 0) fail = 0;
 
   // Waves are placed round robin on the four SIMDs: SIMD 0 = waves 0, 4 (MFMA groups 0, 1), SIMD 1 = 1, 5 (MFMA groups 2, 3), SIMD 2 = 2, 6
-  // (panel, storer), SIMD 3 = 3, 7 (panel, loader). The f64 MFMAs keep the fp64 pipes of SIMDs 0 and 1 busy for most of a step: the
+  // (panel, storer), SIMD 3 = 3, 7 (panel, loader); wave 8 (SIMD 0) inverts the diagonal blocks for the sweeps. The f64 MFMAs keep the fp64 pipes of SIMDs 0 and 1 busy for most of a step: the
   // storer took 1.3 us per block row next to them; a panel wave is latency bound and leaves issue slots.
   if (hw == 0 || hw == 1 || hw == 4 || hw == 5) {
     if (hw == 0) mx_tiles_wave<0>(T, J, smem, l, n_iter);
@@ -490,10 +490,24 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
     // prologue share of this wave: X_(-1) = 0
     for (int e = l; e < 6 * LDX; e += 64) xring[6 * LDX + e] = 0.0;
     lds_barrier();  // P0
-    int p_prev = W - 6;  // ring position of block row it - 1
     auto step = [&](double (*v)[6], int it) {  // v holds block row it + 16 (fetched two iterations ago): entered in iteration it + 1
       stage_write(v, stage + ((it + 1) & 1) * 6 * LDX, it + 16);
       fetch(v, it + 18);
+      if (prof) tlog[8 * it + 5] = wall_clock64();
+      lds_barrier();
+      if (m_at >= 0 && it == m_at) {  // junction: merge, panel(m)
+        lds_barrier();
+        lds_barrier();
+      }
+    };
+    int it = 0;
+    for (; it + 1 < n_iter; it += 2) step(va, it), step(vb, it + 1);
+    if (it < n_iter) step(va, it);
+  } else if (hw == 8) {  // ================================ inverse wave ================================
+    // A short dependent chain per block row with a whole iteration to run in: it sits next to the MFMA waves of SIMD 0.
+    lds_barrier();  // P0
+    int p_prev = W - 6;  // ring position of block row it - 1
+    for (int it = 0; it < n_iter; ++it) {
       if (it >= 1) {
         // W = U_(ii)^-1, i = it - 1 (upper triangular, packed) for the sweeps: lane cw < 6 solves U w = e_cw. U_ii sits at the pivot's own
         // positions of X_i (upper part), 1 / diag comes from the panel (dinv). Entries below the diagonal go to the pad of the 24-double slot.
@@ -528,19 +542,15 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
         }
       }
       p_prev = mx_add(p_prev, 6);
-      if (prof) tlog[8 * it + 5] = wall_clock64();
       lds_barrier();
       if (m_at >= 0 && it == m_at) {  // junction: merge, panel(m)
         lds_barrier();
         lds_barrier();
       }
-    };
-    int it = 0;
-    for (; it + 1 < n_iter; it += 2) step(va, it), step(vb, it + 1);
-    if (it < n_iter) step(va, it);
+    }
   } else if (hw == 6) {  // ================================ storer ================================
     // What is not on the chain, one iteration after the panel published a block row: factor row and y -> HBM (the inverted diagonal block:
-    // loader wave); right-hand side of the trailing rows (lane l < 48 <-> ring positions 2 l, 2 l + 1: 16-byte loads and
+    // wave 8); right-hand side of the trailing rows (lane l < 48 <-> ring positions 2 l, 2 l + 1: 16-byte loads and
     // stores): g -= X' y, the entries of the block row that leaves the window -> rowbuf, those of the entering one <- stage.
     const bool has = l < 48;
     const int pos = has ? 2 * l : 0;

@@ -319,7 +319,10 @@ int launch_factor(hs_problem* p) {
     // The near end takes a few block rows more than the far end: the far end still has to hand its trailing window over (~7 us,
     // i.e. ~4 steps: window through HBM + agent-scope release) before the near end can pass the junction. With an even split
     // workgroup 0 waited 13 us there (tools/chol_phase_timing.py).
-    const int m = std::min((n_blk - w_mid) / 2 + 3, n_blk - w_mid - w_mid), mB = n_blk - w_mid - m;  // (+2 / +3 / +4: 132.0 / 130.5 / 132.1 us)
+    // (k_band_factor_la, +2 / +3 / +4: 132.0 / 130.5 / 132.1 us; k_band_factor_mx hands its window over in 4.3 us and takes 0.96 us per block row:
+    //  the far end is there 3.3 us early with +3 and 0.8 us late with +1)
+    const bool use_mx = !nt && mx_fits(T.bw) && !(T.debug_flags & 64);  // A/B switch 64: the VALU look-ahead kernel
+    const int m = std::min((n_blk - w_mid) / 2 + two_ended_lead(use_mx), n_blk - w_mid - w_mid), mB = n_blk - w_mid - m;
     Tables T2 = T;
     T2.fj[0] = FactorJob{T.Sb, T.g_s, T.Ub, T.Ubk, T.ybuf, p->d_win.p, m + w_mid, m};
     T2.fj[1] = FactorJob{p->d_Sb2.p, p->d_g2.p, p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, p->d_win.p, mB, -1};
@@ -329,7 +332,7 @@ int launch_factor(hs_problem* p) {
     T2.bookkeep = p->bookkeep && !nt ? 1 : 0;
     if (nt)
       HIP_TRY(run_mfma(T2, 2));
-    else if (mx_fits(T.bw) && (T.debug_flags & 64))  // trailing window in the accumulators of the f64 matrix cores (kernels_factor_mx.hpp)
+    else if (use_mx)  // trailing window in the accumulators of the f64 matrix cores (kernels_factor_mx.hpp)
       k_band_factor_mx<<<2, kMxThreads, size_t(kMxLds) * sizeof(double), s>>>(T2);
     else
       if (la_ncw == 3)

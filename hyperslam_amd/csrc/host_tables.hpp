@@ -691,6 +691,7 @@ int prepare(hs_problem* p) {
   //    1 skip the backward sweep          2 skip the rank-6 updates (timing of the panel chain alone; results are garbage)
   //    4 one-ended pre-look-ahead factorisation kernel                16 phase timestamps of the factorisation -> hs_debug_read
   //   32 per-workgroup timestamps of the linearise / gram kernels   1024 no side stream for the segment partials
+  //   64 two-ended factorisation on the VALU look-ahead kernel (k_band_factor_la) instead of k_band_factor_mx (bw <= 14)
   // 2048 one-ended factorisation (no second workgroup)              8192 generalised backward sweep on the one-ended factor
   // 131072 k_band_factor_mfma (trailing window in f64 MFMA tiles) instead of the VALU factorisation kernels
   // 65536 single-wave register backward sweep (k_band_backward_w) instead of the four-wave LDS sweeps

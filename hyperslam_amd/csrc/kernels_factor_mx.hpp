@@ -55,6 +55,9 @@ constexpr int kMxW = 96, kMxLdx = 112, kMxTiles = 21, kMxWaves = 9, kMxThreads =
 constexpr int kMxX = 0, kMxR = kMxX + 12 * kMxLdx, kMxS = kMxR + 12 * kMxLdx, kMxD = kMxS + 12 * kMxLdx, kMxLds = kMxD + 16;
 constexpr int kMxDiagLane = 56;  // lanes 56 .. 61 of both panel waves redo the six columns of the pivot's diagonal block
 
+/// Two-ended factorisation: block rows the near end takes more than half of the non-middle rows (launch_factor; the test harness uses the same rule).
+constexpr int two_ended_lead(bool mx) { return mx ? 2 : 3; }
+
 /// Bands this kernel holds: 16 block rows of ring = the pivot row, the one in the panel's hands, bw - 2 trailing ones, the entering one.
 constexpr bool mx_fits(int bw) { return bw >= 3 && bw <= 14; }
 
@@ -508,7 +511,7 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
     lds_barrier();  // P0
     int p_prev = W - 6;  // ring position of block row it - 1
     for (int it = 0; it < n_iter; ++it) {
-      if (it >= 1) {
+      if (it >= 1 && l < 6) {  // (six lanes: the return path of the LDS is what every wave queues for at the start of a step)
         // W = U_(ii)^-1, i = it - 1 (upper triangular, packed) for the sweeps: lane cw < 6 solves U w = e_cw. U_ii sits at the pivot's own
         // positions of X_i (upper part), 1 / diag comes from the panel (dinv). Entries below the diagonal go to the pad of the 24-double slot.
         const double* xp = xring + ((it - 1) & 1) * 6 * LDX + p_prev;
@@ -526,7 +529,7 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
           const double2 t = *reinterpret_cast<const double2*>(di + a);
           dv[a] = t.x, dv[a + 1] = t.y;
         }
-        const int cw = l < 6 ? l : 0;
+        const int cw = l;
         double w[6];
 #pragma unroll
         for (int a = 5; a >= 0; --a) {
@@ -535,11 +538,9 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
           for (int k = a + 1; k < 6; ++k) t = fma(-Ud[a][k], w[k], t);
           w[a] = t * dv[a];
         }
-        if (l < 6) {
-          double* dst = J.Ubk + size_t(it - 1) * 24;
+        double* dst = J.Ubk + size_t(it - 1) * 24;
 #pragma unroll
-          for (int a = 0; a < 6; ++a) dst[a <= cw ? a * 6 - a * (a - 1) / 2 + (cw - a) : 21 + (a >> 1)] = w[a];
-        }
+        for (int a = 0; a < 6; ++a) dst[a <= cw ? a * 6 - a * (a - 1) / 2 + (cw - a) : 21 + (a >> 1)] = w[a];
       }
       p_prev = mx_add(p_prev, 6);
       lds_barrier();
@@ -615,6 +616,9 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
     }
   } else {  // ================================ panel waves (hw 2 and 3: each alone on its SIMD) ================================
     const bool chain = hw == 3;  // wave 3: the upper half of the ring, the right-hand side, 1 / diag for the storer, `fail`
+    const bool cprof = prof_enabled(T.debug_flags, 16) && chain && l == 0;  // coarse phases of this job -> tlog[8 (200 + 10 job) + ..]
+    long long* clog = tlog + 8 * (200 + 10 * blockIdx.x);
+    if (cprof) clog[0] = wall_clock64();
     MxLane L;
     L.ring = l < 48;
     L.active = L.ring || (chain && l == 48);
@@ -641,7 +645,7 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
         }
       }
     }
-    if (chain && T.bookkeep && blockIdx.x == 0) factor_bookkeep(T, l);
+    if (chain && T.bookkeep && blockIdx.x == 0) factor_bookkeep(T, l);  // (in the inverse wave, next to the MFMA waves' prologue loads: + 4 us)
     lds_barrier();  // P0
     // panel of block row `it`: X_(it) from rowbuf[it & 1] and X_(it-1) (zeros for it = 0)
     auto panel = [&](int it, int p_it) {
@@ -663,6 +667,7 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
         if (l == 0 && !(dmin > 0.0)) fail = 1;
       }
     };
+    if (cprof) clog[1] = wall_clock64();  // prologue done
     int p_it = 0;
     for (int it = 0; it < n_iter; ++it) {
       const bool junction = m_at >= 0 && it == m_at;  // no look-ahead across the junction: row m changes there
@@ -671,14 +676,19 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
       if (prof) plog[8 * it + (chain ? 3 : 7)] = wall_clock64();
       lds_barrier();
       if (junction) {
+        if (cprof) clog[2] = wall_clock64();  // junction reached
         wait_for_partner(T);
+        if (cprof) clog[3] = wall_clock64();  // partner arrived
         mx_lane_merge(J, rowbuf, (chain ? 0 : 64) + l, m_at, p_it, bw);
         lds_barrier();  // merge done
+        if (cprof) clog[4] = wall_clock64();
         panel(it, p_it);
         lds_barrier();
+        if (cprof) clog[5] = wall_clock64();  // X_m published
       }
       p_it = mx_add(p_it, 6);
     }
+    if (cprof) clog[6] = wall_clock64();  // last block row done
     if (J.dump) mx_lane_dump(L, J, rowbuf, xring + ((n_steps - 1) & 1) * 6 * LDX, n_steps, (6 * n_steps) % W, bw);
   }
   __syncthreads();
@@ -689,6 +699,7 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
     if (tid == 0) {
       __threadfence();
       __hip_atomic_store(T.join_flag, T.join_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (prof_enabled(T.debug_flags, 16)) tlog[8 * (200 + 10 * blockIdx.x) + 7] = wall_clock64();  // window handed over
     }
   }
 }

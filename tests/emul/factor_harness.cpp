@@ -88,7 +88,7 @@ int main(int argc, char** argv) {
   int m = -1, mB = 0;
   static const double zero = 0.0;
   if (two_ended) {  // launch_factor: the near end takes three block rows more than the far end
-    m = std::min((n_blk - w_mid) / 2 + 3, n_blk - w_mid - w_mid), mB = n_blk - w_mid - m;
+    m = std::min((n_blk - w_mid) / 2 + two_ended_lead(variant == 5), n_blk - w_mid - w_mid), mB = n_blk - w_mid - m;
     T.fj[0] = FactorJob{Sb.data(), g.data(), Ub.data(), Ubk.data(), yb.data(), win.data(), m + w_mid, m};
     T.fj[1] = FactorJob{Sb2.data(), g2.data(), Ub2.data(), Ubk2.data(), yb2.data(), win.data(), mB, -1};
     T.mj[0] = MfmaJob{Sb2.data(), g.data(), Ub.data(), Ubk.data(), yb.data(), win.data(), m + w_mid, m, m + w_mid, INT_MAX, 0, &zero};

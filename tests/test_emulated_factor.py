@@ -8,6 +8,10 @@ The `-m gpu` tests (test_every_band_width, test_band_widths_from_both_ends) rema
 its index arithmetic — ring slots, look-ahead, hand-over of the far end's window in the near end's coordinates — checkable without a GPU.
 Further down: the kernels launch_factor picks for other band shapes, the sliding window's frozen prefix, and the bordered solve of windows
 with an IMU (kernels_border.hpp: forward sweep of the border columns from one or both ends, border Schur complement, dense Cholesky, y').
+Since round 5 the two-ended factorisation of bands up to 14 control points is k_band_factor_mx (kernels_factor_mx.hpp: the trailing window
+in the accumulators of the f64 matrix cores, ring coordinates, 16 compile-time phases, panel / loader / storer / inverse waves): the harness
+runs it too (variant 5; tests/emul/hip/hip_runtime.h emulates v_mfma_f64_16x16x4_f64 with the lane layout tools/microbench/mfma_probe.hip
+confirmed on the GPU), one-ended and from both ends, at every band width it holds.
 Replaces what CHOLMOD does for /root/reference/internal/hyper/optimizers/ceres/optimizer.cpp:46-48 (SPARSE_NORMAL_CHOLESKY)."""
 import os
 import shutil
@@ -26,7 +30,7 @@ def harness(tmp_path_factory):
     if shutil.which("g++") is None:
         pytest.skip("g++ not available")
     exe = str(tmp_path_factory.mktemp("emul_factor") / "factor_harness")
-    subprocess.check_call(["g++", "-std=c++20", "-O1", "-pthread", "-I", EMUL, "-o", exe, os.path.join(EMUL, "factor_harness.cpp")])
+    subprocess.check_call(["g++", "-std=c++20", "-O1", "-pthread", "-Wno-psabi", "-I", EMUL, "-o", exe, os.path.join(EMUL, "factor_harness.cpp")])
     return exe
 
 
@@ -134,13 +138,12 @@ def test_one_ended_factor_against_numpy(n_blk, bw, harness, tmp_path):
     check_job(Ub, Ubk, yb, U, np.linalg.solve(U.T, g), 6 * n_blk, bw)
 
 
-@pytest.mark.parametrize("n_blk,bw", [(20, 4), (58, 14), (31, 6), (64, 16), (40, 10)])
-def test_two_ended_factor_against_numpy(n_blk, bw, harness, tmp_path):
+def check_two_ended(n_blk, bw, harness, tmp_path, variant):
     rng = np.random.default_rng(7 * n_blk + bw)
     M = banded_spd(rng, n_blk, bw)
     n = 6 * n_blk
     g = rng.standard_normal(n)
-    m, mB, Ub, Ubk, yb, Ub2, Ubk2, yb2 = run(harness, tmp_path, M, g, bw, True)
+    m, mB, Ub, Ubk, yb, Ub2, Ubk2, yb2 = run(harness, tmp_path, M, g, bw, True, variant)
     w = bw - 1
     assert m + w + mB == n_blk and m >= mB
     # near end: the leading rows of the factor of M; far end: the leading rows of the factor of the reversed matrix
@@ -174,6 +177,30 @@ def test_two_ended_factor_against_numpy(n_blk, bw, harness, tmp_path):
         for a in range(6):
             for c in range(a, 6):
                 assert abs(Ubk[24 * i + a * 6 - a * (a - 1) // 2 + (c - a)] - W[a, c]) <= 1e-9 * max(1.0, abs(W[a, c]))
+
+
+
+@pytest.mark.parametrize("n_blk,bw", [(20, 4), (58, 14), (31, 6), (64, 16), (40, 10)])
+def test_two_ended_factor_against_numpy(n_blk, bw, harness, tmp_path):
+    check_two_ended(n_blk, bw, harness, tmp_path, 0)
+
+
+@pytest.mark.parametrize("n_blk,bw", [(12, 3), (20, 4), (31, 6), (40, 10), (55, 13), (58, 14), (128, 14)])
+def test_mx_two_ended_factor_against_numpy(n_blk, bw, harness, tmp_path):
+    """k_band_factor_mx from both ends: junction merge into accumulators, rowbuf rows and the storer's right-hand sides; the far end's window
+    handed over from all three places; the last shape is configs[1]'s (128 control points, 14 per landmark)."""
+    check_two_ended(n_blk, bw, harness, tmp_path, 5)
+
+
+@pytest.mark.parametrize("n_blk,bw", [(5, 3), (8, 3), (9, 5), (17, 6), (40, 10), (33, 13), (20, 14), (30, 14)])
+def test_mx_one_ended_factor_against_numpy(n_blk, bw, harness, tmp_path):
+    """k_band_factor_mx on one job: every phase of the ring (more than 16 block rows), systems shorter than the ring, shorter than the band."""
+    rng = np.random.default_rng(100 * n_blk + bw)
+    M = banded_spd(rng, n_blk, bw)
+    g = rng.standard_normal(6 * n_blk)
+    _, _, Ub, Ubk, yb, _, _, _ = run(harness, tmp_path, M, g, bw, False, 5)
+    U = np.linalg.cholesky(M).T
+    check_job(Ub, Ubk, yb, U, np.linalg.solve(U.T, g), 6 * n_blk, bw)
 
 
 @pytest.mark.parametrize("variant,n_blk,bw", [(1, 20, 12), (1, 14, 16), (2, 24, 18), (2, 23, 21), (3, 20, 24), (3, 17, 30), (4, 24, 20), (4, 30, 17)])

@@ -1,6 +1,6 @@
 """Phase timestamps of k_band_factor_mx (profiling build, HS_DEBUG_FLAGS = 16 | 64, 100 MHz clock): python tools/mx_phase_timing.py [config]"""
 import os, sys, ctypes as C; sys.path.insert(0, ".")
-os.environ["HS_DEBUG_FLAGS"] = str(16 | 64 | int(os.environ.get("HS_DEBUG_FLAGS", "0")))
+os.environ["HS_DEBUG_FLAGS"] = str(16 | int(os.environ.get("HS_DEBUG_FLAGS", "0")))
 import numpy as np
 os.environ.setdefault("HS_STAGE_TIMING", "1")
 import hyperslam_amd as ha
@@ -28,4 +28,8 @@ print("raw, block rows 20 .. 27 (MFMA0 start, M0 M1 M2 done, loader, storer | wa
 for i in range(20, 28):
     b = t[i, 0]
     print(i, [int(x - b) for x in t[i, [0, 2, 3, 4, 5, 1]]], [int(x - b) for x in q[i, :4]], [int(x - b) for x in q[i, 4:8]])
+names = ["prologue done", "junction reached", "partner arrived", "merged", "X_m published", "last block row", "window handed over"]
+for job in (0, 1):
+    c = t[200 + 10 * job]
+    print(f"job {job} relative to job 0's start [10 ns]:", " ".join(f"{n} {int(c[k + 1] - t[200, 0])}" for k, n in enumerate(names) if c[k + 1] > 0), " (start", int(c[0] - t[200, 0]), ")")
 print("solve_ms", s["solve_ms"])

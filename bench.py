@@ -133,6 +133,10 @@ def pmc_traffic(kernel):
         return None
 
 
+def n_cp_rows(window):
+    return int(window.control_points.shape[0])
+
+
 def rocprof_kernel_ms(kernel_prefix):
     """Average duration of the kernel in the committed rocprofv3 --kernel-trace --stats summary of this command, or None."""
     import csv
@@ -175,12 +179,18 @@ def dominant_kernel(np_rows, bw, two_ended):
         nbytes = 8.0 * (2 * np_rows * ncb + 2 * np_rows)
         flops = n_blk * (6.0 * ncb * ncb + 72.0 * ncb)
         wgs = 2 if two_ended else 1
-        threads = (7 * 64 if ", 4>" in top["Name"] else 6 * 64) if "_la<" in top["Name"] else (6 * 64 if "mfma" in top["Name"] else 256)
+        threads = (7 * 64 if ", 4>" in top["Name"] else 6 * 64) if "_la<" in top["Name"] else (8 * 64 if "_mx" in top["Name"] else 6 * 64 if "mfma" in top["Name"] else 256)
         out.update({"algorithmic_bytes_per_launch": nbytes, "algorithmic_flops_per_launch": flops,
                     "hbm": {"achieved": nbytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBS},
                     "fp64": {"achieved": flops / avg_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / avg_s / 1e12 / FP64_PEAK_TFLOPS},
                     "workgroups": wgs, "waves_launched": wgs * threads // 64, "waves_available": 256 * 4 * 8,
-                    "bound": "latency (single dependency chain: block rows x ~1.3 us, DESIGN.md §5)"})
+                    "bound": "latency (single dependency chain over the block rows: ~0.95 us per block row on k_band_factor_mx — trailing update on "
+                             "v_mfma_f64_16x16x4_f64, panel on the vector unit — 1.2 us on k_band_factor_la, DESIGN.md §5)"})
+        if "_mx" in top["Name"]:  # matrix-core share of the same launch: 2 MFMAs (K = 6 padded to 8) per active 16 x 16 tile and block row
+            n_mfma = int(n_blk * 2 * 17.25)  # (every block row of the system is applied once, on one end or the other)
+            out["mfma_f64"] = {"instructions_per_launch": n_mfma, "flops_issued": n_mfma * 2.0 * 16 * 16 * 4,
+                               "note": "21 ring tiles per end, 15 or 21 of them inside the trailing band per phase (17.25 on average); the useful part of a "
+                                       "16x16x4 tile update is 6/8 of its K and ~56 % of its area (72 x 72 upper triangle in 21 tiles)"}
     return out
 
 
@@ -361,7 +371,13 @@ def main():
         profiled = alg_bytes / (prof_ms * 1e-3) / 1e9 if prof_ms else None
         # `achieved` / `frac` are the numbers measured in THIS run (HIP events around the launch on the library's stream, inside the timed
         # region); the figures derived from the committed rocprofv3 trace of the same command stand beside them (`*_profile`).
+        # SURVEY.md 8(d)'s own figure over the same launch time, beside the builder's byte model (the contract number: 480 B per pixel block at
+        # k = 4 = 32 B in + the 448-byte record, + the shared tables once): what the kernel would be credited with if it materialised the record
+        survey_bytes = (32 + 8 * (8 + 12 * order)) * n_visual + 64 * n_cp_rows(window) + 24 * len(window.landmarks)
+        t_best_ms = prof_ms or lin_ms
         roofline = {"kernel": lin_kernel, "bound": "hbm", "achieved": live, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": live / HBM_PEAK_GBS,
+                    "survey_bytes_per_launch": survey_bytes, "achieved_survey_bytes": survey_bytes / (t_best_ms * 1e-3) / 1e9,
+                    "frac_survey_bytes": survey_bytes / (t_best_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "traffic": pmc_traffic(lin_kernel) if args.config == 1 and world == 1 else None,
                     "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_per_residual_block": b_alg, "algorithmic_bytes_model": alg_note,
                     "avg_launch_ms": lin_ms, "timing_source": "HIP events (live, this run)",

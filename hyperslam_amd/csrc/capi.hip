@@ -90,15 +90,24 @@ int hs_destroy(hs_problem* p) {
 
 const char* hs_last_error(const hs_problem* p) { return p ? p->err.c_str() : "null handle"; }
 
+/// How far a control-point stamp may be from t0 + j dt and still be that knot: 1e-6 of the spacing, or eight ulps of the largest stamp
+/// of the table where that is more (epoch-scale stamps). A hole or a non-uniform knot is off by a whole spacing.
+static double knot_tolerance(double t0, double dt, int n_cp) {
+  return std::max(1e-6 * dt, 8.0 * 2.220446049250313e-16 * std::max(std::fabs(t0), std::fabs(t0 + n_cp * dt)));
+}
+
 int hs_set_spline(hs_problem* p, int order, double t0, double dt, int n_cp, const double* cp, const uint8_t* cp_constant, int rc, int tc) {
   if (!p) return HS_ERR_INVALID;
   if (order < 2 || order > hsd::kMaxOrder) HS_FAIL(HS_ERR_INVALID, "spline order out of range");
   if (n_cp < order || !(dt > 0) || !cp) HS_FAIL(HS_ERR_INVALID, "need n_cp >= order, dt > 0 and a control-point table");
   // The basis is uniform: control point j is taken to sit at t0 + j dt, whatever its row says. A table with a hole (upstream prunes state
   // elements one by one, ceres/optimizer.cpp:330-341) or non-uniform knots would silently re-index every later control point: refused.
-  // (Stamps accumulated as t += dt differ from t0 + j dt in the last bits only: 1e-9 dt is far above that and far below a knot.)
+  // The tolerance has to cover how stamps are made, not only what a knot is: accumulated (t += dt, up to n_cp additions) or converted from
+  // integer nanoseconds, at epoch-scale magnitudes (t0 ~ 1.7e9 s: one ulp is 2.4e-7 s) — a few ulps of the largest stamp — and it stays
+  // six orders of magnitude below a knot spacing wherever the stamps resolve one.
+  const double knot_tol = knot_tolerance(t0, dt, n_cp);
   for (int j = 0; j < n_cp; ++j)
-    if (!(std::fabs(cp[8 * j + 7] - (t0 + j * dt)) <= 1e-9 * dt))
+    if (!(std::fabs(cp[8 * j + 7] - (t0 + j * dt)) <= knot_tol))
       HS_FAIL(HS_ERR_INVALID, "control-point stamps are not t0 + j dt (row " + std::to_string(j) + "): the spline basis is uniform, a table with a hole or non-uniform knots is refused");
   p->k = order, p->t0 = t0, p->dt = dt, p->n_cp = n_cp;
   p->cp.assign(cp, cp + size_t(8) * n_cp);

@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(64) k_band_backward_w(Tables T, BackJob j0, Ba
       }
     }
     if (!ok) {
-      if (lane == 0) st->chol_failed = 2;
+      if (lane == 0) give_up(st);
       return;
     }
 #pragma unroll

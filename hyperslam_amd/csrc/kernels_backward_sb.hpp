@@ -139,7 +139,7 @@ HSD void sb_wait(const Tables& T, const unsigned* flag) {
   while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < T.join_epoch) {
     __builtin_amdgcn_s_sleep(2);
     if (wall_clock64() - t0 > 200000000ll) {
-      T.st->chol_failed = 2;
+      give_up(T.st);
       break;
     }
   }

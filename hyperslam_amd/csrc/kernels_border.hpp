@@ -492,7 +492,7 @@ __global__ void __launch_bounds__(kBlock) k_border_forward2(Tables T, BfJob j0, 
           while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < T.join_epoch) {
             __builtin_amdgcn_s_sleep(4);
             if (wall_clock64() - t0 > 200000000ll) {
-              T.st->chol_failed = 2;
+              give_up(T.st);
               break;
             }
           }

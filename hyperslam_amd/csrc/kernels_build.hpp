@@ -182,8 +182,8 @@ HSD unsigned fold_wait(const Tables& T, unsigned* slot) {
     while (((f = __hip_atomic_load(T.join_flag + kFoldFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 2) < T.fold_epoch) {
       __builtin_amdgcn_s_sleep(2);
       if (wall_clock64() - t0 > 200000000ll) {
-        T.st->chol_failed = 2;
-        f = (T.fold_epoch << 2) | 2u;  // give up: as if the solve had ended
+        give_up(T.st);                 // (done + HS_FAILURE: k_assemble and everything behind it exit)
+        f = (T.fold_epoch << 2) | 2u;  // this workgroup carries on as if the decision had ended the solve
         break;
       }
     }
@@ -354,6 +354,16 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
   for (int e = tid; e < nseg * (Lmax + 1); e += kBlock) pos[e] = seg_start[e / (Lmax + 1) + 1];  // default: the end of the segment's run
   if (fold) {  // (thread 0's poll runs next to the loop above; the barrier inside the wait is the one this phase ends with anyway)
     const unsigned f = fold_wait(T, reinterpret_cast<unsigned*>(cpart));
+    // INVARIANT (what may be read behind the flag word, and how). The poll is relaxed, so nothing the decision workgroup wrote is ordered
+    // behind it by the memory model; two things are read, and each has its own reason to be right:
+    //   * the outcome (accepted / done) travels IN the flag word itself;
+    //   * st->radius, with the agent-scope (sc1) load below: on gfx942 / gfx950 such a load is served by the coherent L2 path, and the
+    //     decision workgroup wrote the radius in program order before its release store of the flag (pack_decision_body), which waits for
+    //     the write to reach that level. First use of the value is phases later.
+    // Everything else this workgroup reads (the point in both versions, the tables) comes from buffers the PREVIOUS kernel wrote and is
+    // requested before the flag is looked at. A new field read here needs one of the two mechanisms above (or an acquire in thread 0 of
+    // fold_wait, measured at 12 us per launch for one fence per wave) — a plain load would be a stale read waiting to happen. The CPU
+    // emulation runs the decision workgroup first and cannot catch a violation.
     radius = __hip_atomic_load(&st->radius, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((f >> 1) & 1) return;  // the solve has ended (nothing has been written to memory yet)
     const bool acc = f & 1;    // (spec == 4: an accepted candidate's landmarks are still only in lm_cand)

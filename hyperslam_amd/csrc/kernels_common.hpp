@@ -15,6 +15,14 @@ constexpr int kBlock = 256;
 #endif
 HSD bool prof_enabled(int debug_flags, int bit) { return HS_PROFILE_HOOKS && (debug_flags & bit); }
 
+/// A bounded wait gave up: the solve ends here (every later kernel exits on `done`, hs_solve reports the reason) — nothing downstream may
+/// consume what the workgroup that did not arrive has left half written. chol_failed = 2 is never cleared within a solve.
+HSD void give_up(DevState* st) {
+  st->chol_failed = 2;
+  st->termination = HS_FAILURE;
+  st->done = 1;
+}
+
 /// Dynamic LDS of a kernel (sized at launch). One spelling for every kernel; the CPU emulation harness of the tests (tests/emul/: the
 /// kernel sources compiled for the host with one thread per lane) supplies its own definition.
 #ifndef HS_DYNAMIC_LDS

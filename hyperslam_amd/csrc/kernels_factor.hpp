@@ -309,7 +309,7 @@ HSD void wait_for_partner(const Tables& T) {
   while (__hip_atomic_load(T.join_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < T.join_epoch) {
     __builtin_amdgcn_s_sleep(8);
     if (wall_clock64() - t0 > 200000000ll) {
-      T.st->chol_failed = 2;
+      give_up(T.st);
       break;
     }
   }

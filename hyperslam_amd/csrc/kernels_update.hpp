@@ -171,7 +171,6 @@ HSD void begin_iteration(const Tables& T, double c, double gm, bool set_scaling_
   DevState* st = T.st;
   st->cost = c;  // (speculative solves: the sum of the shards' kept costs, pack_exchange_body — equal to what decide_step took over)
   st->gmax = gm;
-  st->chol_failed = 0;    // raised by the factorisation kernels of this iteration
   if (set_scaling_ready) st->scaling_ready = 1;  // Jacobi scaling is computed at iteration 0 only (else: set by decide_step)
   if (st->iteration == 0) {
     hs_iteration& r = st->records[0];
@@ -314,6 +313,10 @@ HSD void decide_step(const Tables& T, const double* D_known, const DecideIn& in)
     } else {
       radius *= 0.5;
       st->radius = radius;
+      // The decision CONSUMES the factorisation's verdict (1 = a non-positive pivot): cleared here, behind the kernels that raise it and in
+      // front of the next iteration's — not by the next factorisation's own bookkeeping next to its far end's stores (ordering by
+      // timing). A solve that ends on it keeps the value for hs_solve's message; 2 (a bounded wait gave up) ends the solve where it is raised.
+      if (in.chol_failed == 1) st->chol_failed = 0;
     }
     st->invalid_streak = in.invalid_streak + 1;
     r.radius = radius;

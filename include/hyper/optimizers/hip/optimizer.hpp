@@ -169,7 +169,14 @@ class Optimizer<kOptimizerSuiteHIP> final : public AbstractOptimizer {
     std::vector<double> cp(8 * cps.size());
     for (std::size_t j = 0; j < cps.size(); ++j) std::copy_n(cps[j]->asVector().data(), 8, &cp[8 * j]);  // [q(4) p(3) t], stamped.hpp:35-36
     const auto t0 = cps.front()->stamp();
-    check(hs_set_spline(handle_, order, t0, separation_, static_cast<int>(cps.size()), cp.data(), cp_constant.data(), rotation_constant_, translation_constant_));
+    // A refusal here is not fatal: upstream's extension by more than one state (abstract.cpp:127-137 re-reads rbegin() after every insertion
+    // and spaces the new stamps by 1, 2, 3 ... separations) leaves a hole in the knots that no uniform basis can represent. The window is
+    // skipped with an error in the log — the state stays as it is, the next message that closes the hole is solved again — instead of
+    // aborting the process through a CHECK.
+    if (hs_set_spline(handle_, order, t0, separation_, static_cast<int>(cps.size()), cp.data(), cp_constant.data(), rotation_constant_, translation_constant_) != HS_OK) {
+      LOG(ERROR) << "hip optimizer: window skipped: " << hs_last_error(handle_);
+      return;
+    }
     // Upstream admits a message with state().range().contains(stamp) on the elements' ACCUMULATED stamps (abstract.cpp:103-106, 127-137);
     // the library derives the segment from t0 + j * separation. The two agree except in the last bits of a stamp on a knot: a stamp
     // that upstream admitted and the uniform arithmetic puts one segment outside the table is moved by those last bits.

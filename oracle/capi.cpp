@@ -1,7 +1,9 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see hs_math.hpp header). PARITY UNPINNED.
 // C entry points of the CPU restatement, mirroring include/hyperslam_hip.h one-to-one with the prefix `hso_`
 // so the parity tests drive both sides with the same tables.
+#include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -74,8 +76,9 @@ const char* hso_last_error(const hso_problem* p) { return p ? p->err.c_str() : "
 int hso_set_spline(hso_problem* p, int order, double t0, double dt, int n_cp, const double* cp, const uint8_t* cp_constant, int rot_c, int trans_c) {
   CHECK_ARG(order >= 2 && order <= kMaxOrder, "order out of range");
   CHECK_ARG(n_cp >= order && dt > 0, "need n_cp >= order and dt > 0");
-  for (int j = 0; j < n_cp; ++j)  // uniform basis: same rule and message as hs_set_spline
-    CHECK_ARG(std::fabs(cp[8 * j + 7] - (t0 + j * dt)) <= 1e-9 * dt,
+  const double knot_tol = std::max(1e-6 * dt, 8.0 * 2.220446049250313e-16 * std::max(std::fabs(t0), std::fabs(t0 + n_cp * dt)));
+  for (int j = 0; j < n_cp; ++j)  // uniform basis: same rule, tolerance and message as hs_set_spline
+    CHECK_ARG(std::fabs(cp[8 * j + 7] - (t0 + j * dt)) <= knot_tol,
               "control-point stamps are not t0 + j dt: the spline basis is uniform, a table with a hole or non-uniform knots is refused");
   Problem& P = p->P;
   P.k = order, P.t0 = t0, P.dt = dt, P.n_cp = n_cp;

@@ -337,13 +337,25 @@ def check_knot_uniformity_is_enforced(lib):
     w2.control_points = acc
     with ha.Problem(w2, lib=lib) as p:
         assert abs(p.cost() - c0) <= 1e-12 * c0  # (the oracle, like the reference, reads the knots from the rows; the product library derives them)
+    # epoch-scale stamps made from integer nanoseconds (one ulp of 1.7e9 s is 2.4e-7 s: the tolerance has to follow the magnitude of the
+    # stamps, not only the knot spacing): accepted
+    w4 = synthetic.small_visual(order=4, n_cp=14, n_landmarks=20, obs_pairs=2)
+    epoch_ns = 1_700_000_000_000_000_000
+    t0_ns = epoch_ns + int(round(w4.t0 * 1e9))
+    w4.control_points = w4.control_points.copy()
+    w4.control_points[:, 7] = [(t0_ns + j * int(round(w4.dt * 1e9))) * 1e-9 for j in range(len(w4.control_points))]
+    lo, hi = w4.t0 + w4.dt, w4.t0 + (len(w4.control_points) - 2) * w4.dt  # valid range of an order-4 spline; stamps kept off its ends
+    w4.pixel_stamps = np.clip(w4.pixel_stamps, lo + 1e-3, hi - 1e-3) + epoch_ns * 1e-9
+    w4.t0 = t0_ns * 1e-9
+    with ha.Problem(w4, lib=lib) as p:
+        assert np.isfinite(p.cost())
     for what in ("hole", "shifted"):
         bad = w.control_points.copy()
         if what == "hole":  # element 6 pruned: every later row moves up, a fresh one is appended at the end
             bad[6:-1] = w.control_points[7:]
             bad[-1, 7] = bad[-2, 7] + w.dt
         else:
-            bad[5, 7] += 1e-6 * w.dt
+            bad[5, 7] += 1e-3 * w.dt
         w3 = synthetic.small_visual(order=4, n_cp=14, n_landmarks=20, obs_pairs=2)
         w3.control_points = bad
         try:

@@ -333,7 +333,10 @@ int launch_factor(hs_problem* p) {
     if (nt)
       HIP_TRY(run_mfma(T2, 2));
     else if (use_mx)  // trailing window in the accumulators of the f64 matrix cores (kernels_factor_mx.hpp)
-      k_band_factor_mx<<<2, kMxThreads, size_t(kMxLds) * sizeof(double), s>>>(T2);
+      if (mx_wide(T.bw))
+        k_band_factor_mx<true><<<2, kMxThreads, size_t(kMxLds) * sizeof(double), s>>>(T2);
+      else
+        k_band_factor_mx<false><<<2, kMxThreads, size_t(kMxLds) * sizeof(double), s>>>(T2);
     else
       if (la_ncw == 3)
         k_band_factor_la<1, 3><<<2, la_threads(3), la_lds, s>>>(T2);

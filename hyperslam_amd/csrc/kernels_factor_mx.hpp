@@ -9,7 +9,7 @@
 namespace hs {
 
 // ---------------------------------------------------------------------------------------------------------------------
-// S = U'U for the block-banded reduced system (6 x 6 blocks, bw <= 14 band blocks), fused forward solve: same outputs as
+// S = U'U for the block-banded reduced system (6 x 6 blocks, bw <= 16 band blocks), fused forward solve: same outputs as
 // k_band_factor_la (factor rows Ub, inverted diagonal blocks Ubk, y = U^-T g; one- and two-ended operation), so the sweeps
 // behind it do not change. Replaces what CHOLMOD does for /root/reference/internal/hyper/optimizers/ceres/optimizer.cpp:46-48.
 //
@@ -59,7 +59,9 @@ constexpr int kMxDiagLane = 56;  // lanes 56 .. 61 of both panel waves redo the 
 constexpr int two_ended_lead(bool mx) { return mx ? 2 : 3; }
 
 /// Bands this kernel holds: 16 block rows of ring = the pivot row, the one in the panel's hands, bw - 2 trailing ones, the entering one.
-constexpr bool mx_fits(int bw) { return bw >= 3 && bw <= 14; }
+constexpr bool mx_fits(int bw) { return bw >= 3 && bw <= 16; }
+/// Bands of 15 and 16 control points (order-6 splines) use all 16 slots of the ring: see WIDE below.
+constexpr bool mx_wide(int bw) { return bw > 14; }
 
 template <class F, int... Is>
 HSD void mx_static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
@@ -96,9 +98,10 @@ __host__ __device__ constexpr int mx_tile_J(int q) {
 /// trailing band of the pivot row (15 of the 21 in ten of the sixteen phases) is skipped at compile time. 7 - 11 tiles per SIMD and phase.
 constexpr int kMxGroupSize[4] = {6, 5, 5, 5};
 constexpr int kMxGroupTile[4][6] = {{2, 5, 9, 10, 12, 16}, {3, 6, 14, 18, 19, -1}, {0, 4, 7, 15, 17, -1}, {1, 8, 11, 13, 20, -1}};
-/// Does tile index t (16 ring positions) hold a position of the trailing band [12, 84) of the pivot row at ring position p_i?
-__host__ __device__ constexpr bool mx_index_active(int t, int p_i) {
-  for (int off = 12; off < 84; ++off)
+/// Does tile index t (16 ring positions) hold a position of the trailing band [12, hi) of the pivot row at ring position p_i? (hi = 84: bands of
+/// up to 14 control points; 96: WIDE)
+__host__ __device__ constexpr bool mx_index_active(int t, int p_i, int hi) {
+  for (int off = 12; off < hi; ++off)
     if ((p_i + off) % kMxW / 16 == t) return true;
   return false;
 }
@@ -126,9 +129,15 @@ __host__ __device__ constexpr bool mx_hit(int t, int p) { return 16 * t <= p + 5
 // ================================ MFMA waves ================================
 /// One block row of an MFMA wave in phase PH = it mod 16 (it >= 1): apply X_(it-1) = x, extract block row it + 1 -> rb, enter block row
 /// it + 15 <- st. Ring positions: block row it at 6 PH, X_(it-1)'s own row at 6 PH - 6 = the positions the entering row takes.
-template <int G, int PH, int TW>
+///
+/// WIDE (bands of 15, 16 control points): the ring's 16 slots are all in use — the entering block row it + 15 takes its positions in the very
+/// iteration in which block row it + 1, whose band reaches it (and, at 16, block row it + 16, which enters an iteration later), leaves for the
+/// panel. Those last one or two band blocks of a row are never updated before the row becomes the pivot row (no earlier row reaches both
+/// members of the pair), so they bypass the accumulators: the loader writes them into rowbuf (k_band_factor_mx), and the extraction below
+/// leaves the twelve positions of block rows it - 1 and it alone. No tile is ever outside the band: all 21 are updated in every phase.
+template <int G, int PH, int TW, bool WIDE>
 HSD void mx_tiles_step(mx_f64x4 (&acc)[TW], const double* x, double* rb, const double* st, int l15, int g4) {
-  constexpr int W = kMxW, LDX = kMxLdx;
+  constexpr int W = kMxW, LDX = kMxLdx, HI = WIDE ? 96 : 84;
   constexpr int p_i = (6 * PH + W - 6) % W, p_row = (6 * PH + 6) % W, p_e = p_i;
   double xf[6][2], nxf[6][2];
 #pragma unroll
@@ -144,7 +153,7 @@ HSD void mx_tiles_step(mx_f64x4 (&acc)[TW], const double* x, double* rb, const d
     }
   mx_static_for<TW>([&](auto mc) {
     constexpr int m = decltype(mc)::value, q = kMxGroupTile[G][m], I = mx_tile_I(q), Jt = mx_tile_J(q);
-    if constexpr (mx_index_active(I, p_i) && mx_index_active(Jt, p_i))
+    if constexpr (mx_index_active(I, p_i, HI) && mx_index_active(Jt, p_i, HI))
       acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(nxf[I][0], xf[Jt][0], acc[m], 0, 0, 0);
   });
   // program order: second MFMA of tile m, then the hand-overs of tile m - 1 (its result is ready by then)
@@ -152,7 +161,7 @@ HSD void mx_tiles_step(mx_f64x4 (&acc)[TW], const double* x, double* rb, const d
     constexpr int m = decltype(mc)::value;
     if constexpr (m < TW) {
       constexpr int q = kMxGroupTile[G][m], I = mx_tile_I(q), Jt = mx_tile_J(q);
-      if constexpr (mx_index_active(I, p_i) && mx_index_active(Jt, p_i))
+      if constexpr (mx_index_active(I, p_i, HI) && mx_index_active(Jt, p_i, HI))
         acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(nxf[I][1], xf[Jt][1], acc[m], 0, 0, 0);
     }
     if constexpr (m >= 1) {
@@ -165,7 +174,7 @@ HSD void mx_tiles_step(mx_f64x4 (&acc)[TW], const double* x, double* rb, const d
           constexpr int d = 16 * I - p_row;
           if (d + 4 * rr + 3 >= 0 && d + 4 * rr < 6) {  // (compile time: some g4 is in range)
             const int k = d + 4 * rr + g4;
-            if (unsigned(k) < 6u) rb[k * LDX + 16 * Jt + l15] = acc[mm][rr];
+            if (unsigned(k) < 6u && (!WIDE || mx_sub(16 * Jt + l15, p_i) >= 12)) rb[k * LDX + 16 * Jt + l15] = acc[mm][rr];
           }
         }
       }
@@ -173,7 +182,8 @@ HSD void mx_tiles_step(mx_f64x4 (&acc)[TW], const double* x, double* rb, const d
         const int k = 16 * Jt - p_row + l15;
         if (unsigned(k) < 6u) {
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) rb[k * LDX + 16 * I + g4 + 4 * rr] = acc[mm][rr];
+          for (int rr = 0; rr < 4; ++rr)
+            if (!WIDE || mx_sub(16 * I + g4 + 4 * rr, p_i) >= 12) rb[k * LDX + 16 * I + g4 + 4 * rr] = acc[mm][rr];
         }
       }
       // ---- block row it + 15 <- stage: st[q][a] = pair (a, p_e + q) ----
@@ -199,7 +209,7 @@ HSD void mx_tiles_step(mx_f64x4 (&acc)[TW], const double* x, double* rb, const d
   });
 }
 
-template <int G>
+template <int G, bool WIDE>
 HSD void mx_tiles_wave(const Tables& T, const MfmaJob& J, double* smem, int l, int n_iter) {
   constexpr int TW = kMxGroupSize[G], W = kMxW, LDX = kMxLdx;
   const int bw = T.bw, ncb = 6 * bw, np = T.np, m_at = J.merge_at;
@@ -232,7 +242,7 @@ HSD void mx_tiles_wave(const Tables& T, const MfmaJob& J, double* smem, int l, i
         if ((it & 15) == PH && it < stop) {
           if (prof && G == 0) tlog[8 * it + 0] = wall_clock64();
           if ((PH != 0 || it >= 1) && (it < J.n_steps || J.dump))  // (the last iteration is the storer's; job 1 applies its last row too)
-            mx_tiles_step<G, PH, TW>(acc, xring + ((it - 1) & 1) * 6 * LDX, rowbuf + ((it + 1) & 1) * 6 * LDX, stage + (it & 1) * 6 * LDX, l15, g4);
+            mx_tiles_step<G, PH, TW, WIDE>(acc, xring + ((it - 1) & 1) * 6 * LDX, rowbuf + ((it + 1) & 1) * 6 * LDX, stage + (it & 1) * 6 * LDX, l15, g4);
           if (prof && G < 3) tlog[8 * it + 2 + G] = wall_clock64();
           lds_barrier();
           ++it;
@@ -400,7 +410,7 @@ HSD void mx_lane_dump(const MxLane& L, const MfmaJob& J, const double* rowbuf, c
   if (!L.active) return;
   double xc[6], v[6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) xc[k] = xp[k * LDX + L.col];
+  for (int k = 0; k < 6; ++k) xc[k] = (!L.ring || mx_sub(L.col, p_n) + 6 < 6 * bw) ? xp[k * LDX + L.col] : 0.0;  // (see the panel: WIDE)
   mx_lane_update(L, rowbuf + (n & 1) * 6 * LDX, xp, p_n, xc, v);
   const double* row1 = rowbuf + ((n + 1) & 1) * 6 * LDX;
   if (!L.ring) {
@@ -429,6 +439,7 @@ HSD void mx_lane_dump(const MxLane& L, const MfmaJob& J, const double* rowbuf, c
   }
 }
 
+template <bool WIDE>  // WIDE: bands of 15 and 16 control points (mx_tiles_step)
 __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
   constexpr int W = kMxW, LDX = kMxLdx;
   HS_DYNAMIC_LDS(smem);
@@ -452,10 +463,10 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
   // (panel, storer), SIMD 3 = 3, 7 (panel, loader); wave 8 (SIMD 0) inverts the diagonal blocks for the sweeps. The f64 MFMAs keep the fp64 pipes of SIMDs 0 and 1 busy for most of a step: the
   // storer took 1.3 us per block row next to them; a panel wave is latency bound and leaves issue slots.
   if (hw == 0 || hw == 1 || hw == 4 || hw == 5) {
-    if (hw == 0) mx_tiles_wave<0>(T, J, smem, l, n_iter);
-    if (hw == 4) mx_tiles_wave<1>(T, J, smem, l, n_iter);
-    if (hw == 1) mx_tiles_wave<2>(T, J, smem, l, n_iter);
-    if (hw == 5) mx_tiles_wave<3>(T, J, smem, l, n_iter);
+    if (hw == 0) mx_tiles_wave<0, WIDE>(T, J, smem, l, n_iter);
+    if (hw == 4) mx_tiles_wave<1, WIDE>(T, J, smem, l, n_iter);
+    if (hw == 1) mx_tiles_wave<2, WIDE>(T, J, smem, l, n_iter);
+    if (hw == 5) mx_tiles_wave<3, WIDE>(T, J, smem, l, n_iter);
   } else if (hw == 7) {  // ================================ loader ================================
     // lane l owns band columns t = l + 64 m of an entering block row (t < ncb; t == W: right-hand side), all six rows; what it stages is the
     // whole ring row: zeros outside the band
@@ -495,6 +506,20 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
     lds_barrier();  // P0
     auto step = [&](double (*v)[6], int it) {  // v holds block row it + 16 (fetched two iterations ago): entered in iteration it + 1
       stage_write(v, stage + ((it + 1) & 1) * 6 * LDX, it + 16);
+      if constexpr (WIDE) {
+        // The last band blocks of block row it + 1 — its pairs with block rows it + 15 (entering in this iteration) and, at 16 control points,
+        // it + 16 (staged above) — are not in the accumulators when the row leaves: straight into rowbuf, at the positions the MFMA waves skip.
+        double* rb = rowbuf + ((it + 1) & 1) * 6 * LDX;
+        const int p_it = (6 * it) % W, p_prev = (6 * it + W - 6) % W, p_next = (6 * it + 6) % W;
+        if (bw == 16 && l < 6) {  // band offset t = l of block row it + 16 is position l of block row it + 1
+#pragma unroll
+          for (int q = 0; q < 6; ++q) rb[l * LDX + p_it + q] = v[0][q];
+        }
+        if (it >= 1 && l < 36) {  // (block row 15 is resident from the prologue on: rows 0 and 1 come complete)
+          const int k = l / 6, q = l % 6;
+          rb[k * LDX + p_prev + q] = stage[(it & 1) * 6 * LDX + q * LDX + p_next + k];
+        }
+      }
       fetch(v, it + 18);
       if (prof) tlog[8 * it + 5] = wall_clock64();
       lds_barrier();
@@ -634,7 +659,8 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
         const int e = t + 128 * u;
         const bool in = e < 12 * (W + 1);
         const int j = in ? e / (6 * (W + 1)) : 0, rem = in ? e % (6 * (W + 1)) : 0, k = rem / (W + 1), pos = rem % (W + 1);
-        pv[u] = pos == W ? mx_job_rhs(J, 6 * j + k) : (pos >= 6 * j ? mx_job_value(J, np, ncb, 6 * j + k, pos) : 0.0);
+        // (position -> matrix index: the band of block row 1 wraps around the ring when it is 16 control points wide)
+        pv[u] = pos == W ? mx_job_rhs(J, 6 * j + k) : mx_job_value(J, np, ncb, 6 * j + k, pos >= 6 * j ? pos : pos + W);
       }
 #pragma unroll
       for (int u = 0; u < RU; ++u) {
@@ -656,6 +682,11 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
       if (L.diag) L.col = p_it + (l - kMxDiagLane);
 #pragma unroll
       for (int k = 0; k < 6; ++k) xc[k] = xp[k * LDX + L.col];
+      if constexpr (WIDE) {  // 16 control points: the last band block of this row sits at the positions of block row it - 1, where X_(it-1) holds U
+        const bool in_prev = !L.ring || mx_sub(L.col, p_it) + 6 < ncb;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) xc[k] = in_prev ? xc[k] : 0.0;
+      }
       mx_lane_update(L, row, xp, p_it, xc, v);
       if (prof) plog[8 * it + (chain ? 1 : 5)] = wall_clock64();
       const double dmin = mx_lane_factor(v, U, inv);

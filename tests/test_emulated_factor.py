@@ -185,14 +185,15 @@ def test_two_ended_factor_against_numpy(n_blk, bw, harness, tmp_path):
     check_two_ended(n_blk, bw, harness, tmp_path, 0)
 
 
-@pytest.mark.parametrize("n_blk,bw", [(12, 3), (20, 4), (31, 6), (40, 10), (55, 13), (58, 14), (128, 14)])
+@pytest.mark.parametrize("n_blk,bw", [(12, 3), (20, 4), (31, 6), (40, 10), (55, 13), (58, 14), (128, 14), (60, 15), (64, 16), (70, 16)])
 def test_mx_two_ended_factor_against_numpy(n_blk, bw, harness, tmp_path):
     """k_band_factor_mx from both ends: junction merge into accumulators, rowbuf rows and the storer's right-hand sides; the far end's window
-    handed over from all three places; the last shape is configs[1]'s (128 control points, 14 per landmark)."""
+    handed over from all three places; (128, 14) is configs[1]'s shape; 15 and 16 control points per landmark (order-6 windows, configs[2]) are
+    the WIDE instance: every slot of the ring in use, the last band blocks of a row through the loader."""
     check_two_ended(n_blk, bw, harness, tmp_path, 5)
 
 
-@pytest.mark.parametrize("n_blk,bw", [(5, 3), (8, 3), (9, 5), (17, 6), (40, 10), (33, 13), (20, 14), (30, 14)])
+@pytest.mark.parametrize("n_blk,bw", [(5, 3), (8, 3), (9, 5), (17, 6), (40, 10), (33, 13), (20, 14), (30, 14), (24, 15), (18, 16), (40, 16)])
 def test_mx_one_ended_factor_against_numpy(n_blk, bw, harness, tmp_path):
     """k_band_factor_mx on one job: every phase of the ring (more than 16 block rows), systems shorter than the ring, shorter than the band."""
     rng = np.random.default_rng(100 * n_blk + bw)

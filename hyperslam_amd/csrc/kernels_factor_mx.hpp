@@ -117,6 +117,17 @@ HSD double mx_job_value(const MfmaJob& J, int np, int ncb, int rho, int sigma) {
   const double v = J.L[ok ? size_t(np - 1 - sigma) * ncb + off : 0];
   return ok ? v : 0.0;
 }
+/// The same value through a pointer select (entries that enter as zeros are read from a zero in memory): no instruction depends on the
+/// loaded value, so a wave can carry on — through barriers — until it needs the register.
+HSD const double* mx_job_address(const MfmaJob& J, int np, int ncb, int rho, int sigma) {
+  if (rho > sigma) {
+    const int t = rho;
+    rho = sigma, sigma = t;
+  }
+  const int e = sigma / 6, off = 6 * e + 5 - rho;
+  const bool ok = rho >= 0 && off < ncb && e < J.enter_limit && !(rho / 6 >= J.zero_from && e >= J.zero_from);
+  return ok ? J.L + size_t(np - 1 - sigma) * ncb + off : J.zero;
+}
 HSD double mx_job_rhs(const MfmaJob& J, int rho) {
   const bool ok = rho / 6 < J.enter_limit && rho / 6 < J.zero_from;
   const double v = J.g[ok ? rho : 0];
@@ -225,10 +236,10 @@ HSD void mx_tiles_wave(const Tables& T, const MfmaJob& J, double* smem, int l, i
     constexpr int m = decltype(mc)::value, q = kMxGroupTile[G][m], I = mx_tile_I(q), Jt = mx_tile_J(q);
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
+      // (no select on the loaded value: the wave passes the barriers of the prologue and of iteration 0 — the panel's — with its 28 loads
+      //  in flight and waits for them in front of its first MFMA)
       const int a = 16 * I + g4 + 4 * rr, b = 16 * Jt + l15;
-      const bool in = a >= 12 && b >= 12;
-      const double v = mx_job_value(J, np, ncb, in ? a : 0, in ? b : 0);
-      acc[m][rr] = in ? v : 0.0;
+      acc[m][rr] = *((a >= 12 && b >= 12) ? mx_job_address(J, np, ncb, a, b) : J.zero);
     }
   });
   lds_barrier();  // P0
@@ -671,7 +682,6 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
         }
       }
     }
-    if (chain && T.bookkeep && blockIdx.x == 0) factor_bookkeep(T, l);  // (in the inverse wave, next to the MFMA waves' prologue loads: + 4 us)
     lds_barrier();  // P0
     // panel of block row `it`: X_(it) from rowbuf[it & 1] and X_(it-1) (zeros for it = 0)
     auto panel = [&](int it, int p_it) {
@@ -723,7 +733,7 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
     if (J.dump) mx_lane_dump(L, J, rowbuf, xring + ((n_steps - 1) & 1) * 6 * LDX, n_steps, (6 * n_steps) % W, bw);
   }
   __syncthreads();
-  if (tid == 0 && fail) st->chol_failed = 1;  // (cleared by k_finalize_reduced / the bookkeeping)
+  if (tid == 0 && fail) st->chol_failed = 1;  // (consumed by the decision, decide_step)
   if (J.dump) {
     __threadfence();
     __syncthreads();
@@ -733,6 +743,10 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
       if (prof_enabled(T.debug_flags, 16)) tlog[8 * (200 + 10 * blockIdx.x) + 7] = wall_clock64();  // window handed over
     }
   }
+  // Iteration bookkeeping of a directly assembled system (Tables::bookkeep, factor_bookkeep): a wave of the FAR end, behind its hand-over —
+  // that workgroup is done ~17 us before the near end, in whose prologue the ~2 us of this reduction used to sit. Nothing in this launch
+  // reads what it writes (cost, gradient norm, the record, `done`: the sweep and everything behind it do).
+  if (T.bookkeep && blockIdx.x == 1 && hw == 3) factor_bookkeep(T, l);
 }
 #undef MX_UIDX
 

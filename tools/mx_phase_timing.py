@@ -22,9 +22,9 @@ med = lambda a: float(np.median(a))
 print("units of 10 ns, medians over block rows 8 .. 55 of job 0, relative to the start of the iteration in MFMA wave 0")
 print("step:", med(np.diff(t[8:57, 0])))
 print("MFMA waves done: ", med(t[r, 2] - t0), med(t[r, 3] - t0), med(t[r, 4] - t0), " loader done:", med(t[r, 5] - t0), " storer done:", med(t[r, 1] - t0))
-print("panel wave 3 (alone on its SIMD): start", med(q[r, 0] - t0), " own column updated", med(q[r, 1] - t0), " diagonal block factored", med(q[r, 2] - t0), " solved + published", med(q[r, 3] - t0))
-print("panel wave 4 (shares SIMD 0):     start", med(q[r, 4] - t0), " own column updated", med(q[r, 5] - t0), " diagonal block factored", med(q[r, 6] - t0), " solved + published", med(q[r, 7] - t0))
-print("raw, block rows 20 .. 27 (MFMA0 start, M0 M1 M2 done, loader, storer | wave 3: start upd chol end | wave 4: start upd chol end):")
+print("panel wave 3 (SIMD 3, next to the loader): start", med(q[r, 0] - t0), " own column updated", med(q[r, 1] - t0), " diagonal block factored", med(q[r, 2] - t0), " solved + published", med(q[r, 3] - t0))
+print("panel wave 2 (SIMD 2, next to the storer): start", med(q[r, 4] - t0), " own column updated", med(q[r, 5] - t0), " diagonal block factored", med(q[r, 6] - t0), " solved + published", med(q[r, 7] - t0))
+print("raw, block rows 20 .. 27 (MFMA group 0 start, groups 0 1 2 done, loader, storer | wave 3: start upd chol end | wave 2: start upd chol end):")
 for i in range(20, 28):
     b = t[i, 0]
     print(i, [int(x - b) for x in t[i, [0, 2, 3, 4, 5, 1]]], [int(x - b) for x in q[i, :4]], [int(x - b) for x in q[i, 4:8]])

@@ -13,11 +13,13 @@ bash tools/kernel_stats.sh $out/${tag}_replay_kernel_stats.csv hyperslam_amd/hos
 bash tools/pmc_traffic.sh $out/${tag}_pmc_hbm_traffic.json $B > $out/${tag}_pmc.txt 2>&1
 bash tools/pmc_sq.sh $out/${tag}_pmc_sq.json $B >> $out/${tag}_pmc.txt 2>&1
 bash tools/pmc_sq.sh $out/${tag}_config2_pmc_sq.json python bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline >> $out/${tag}_pmc.txt 2>&1
-# matrix-core counters of the factorisation: the VALU look-ahead kernel (default) and the f64-MFMA kernel (A/B switch 131072)
-bash tools/pmc_mfma.sh $out/${tag}_pmc_mfma_valu_factor.json $B >> $out/${tag}_pmc.txt 2>&1
-HS_LIBRARY=$PWD/tools/libhyperslam_hip_prof.so HS_DEBUG_FLAGS=131072 bash tools/pmc_mfma.sh $out/${tag}_pmc_mfma_mfma_factor.json $B >> $out/${tag}_pmc.txt 2>&1
+# matrix-core counters of the factorisation: k_band_factor_mx (default since round 5: trailing window in f64-MFMA accumulators) and the VALU
+# look-ahead kernel k_band_factor_la (A/B switch 64); configs[2] runs the WIDE instance
+bash tools/pmc_mfma.sh $out/${tag}_pmc_mfma_mx_factor.json $B >> $out/${tag}_pmc.txt 2>&1
+HS_DEBUG_FLAGS=64 bash tools/pmc_mfma.sh $out/${tag}_pmc_mfma_valu_factor.json $B >> $out/${tag}_pmc.txt 2>&1
+bash tools/pmc_mfma.sh $out/${tag}_config2_pmc_mfma_mx_factor.json python bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline >> $out/${tag}_pmc.txt 2>&1
 bash tools/kernel_stats.sh $out/${tag}_config3_kernel_stats.csv python bench.py --config 3 --steps 10 --warmup 2 --no-cpu-baseline >> $out/${tag}_kernel_stats.txt 2>&1
-[ -f tools/libhyperslam_hip_prof.so ] && python tools/chol_phase_timing.py > $out/${tag}_chol_phase_timing.txt 2>&1
+[ -f tools/libhyperslam_hip_prof.so ] && { python tools/mx_phase_timing.py 1; python tools/mx_phase_timing.py 3 | tail -4; echo "--- k_band_factor_la (A/B switch 64)"; HS_DEBUG_FLAGS=80 python tools/chol_phase_timing.py; } > $out/${tag}_chol_phase_timing.txt 2>&1
 [ -f tools/libhyperslam_hip_prof.so ] && python tools/build_phase_timing.py 1 > $out/${tag}_build_phase_timing.txt 2>&1
 [ -f tools/libhyperslam_hip_prof.so ] && { python tools/fold_phase_timing.py 1; HS_DEBUG_FLAGS=32768 python tools/fold_phase_timing.py 1; python tools/fold_phase_timing.py 3; } > $out/${tag}_fold_phase_timing.txt 2>&1
 for c in 0 1 2 3; do HS_STAGE_TIMING=0 python tools/time_config.py $c; HS_STAGE_TIMING=1 python tools/time_config.py $c; done > $out/${tag}_configs.txt 2>&1
@@ -27,5 +29,5 @@ python bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline > $out/${tag}
   for a in "6.0 1 4" "6.0 0 4" "6.0 1 6" "8.0 1 4"; do ./replay $a 2>/dev/null | tail -1; HS_STAGE_TIMING=1 ./replay $a 2>/dev/null | tail -1; done
   ./replay_oracle 6.0 1 4 2>/dev/null | tail -1 ) > $out/${tag}_replay.txt 2>&1
 ( cd hyperslam_amd/host; for a in "6.0 1 4" "6.0 0 4"; do echo "replay $a"; HS_HOST_TIMING=1 ./replay $a 2>&1 >/dev/null | grep "host timing"; done ) > $out/${tag}_replay_host_split.txt 2>&1
-for a in "3.6 0 4" "3.6 1 4" "6.0 1 6" "6.0 1 4"; do hyperslam_amd/host/replay_lockstep hyperslam_amd/libhyperslam_hip.so $a > $out/${tag}_lockstep_$(echo $a | tr ' .' '__').jsonl 2>&1; done
+for a in "3.6 0 4" "3.6 1 4" "6.0 1 6" "6.0 1 4"; do  # (one run each: ~10 s) hyperslam_amd/host/replay_lockstep hyperslam_amd/libhyperslam_hip.so $a > $out/${tag}_lockstep_$(echo $a | tr ' .' '__').jsonl 2>&1; done
 echo done

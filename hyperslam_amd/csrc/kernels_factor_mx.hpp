@@ -652,8 +652,8 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
     }
   } else {  // ================================ panel waves (hw 2 and 3: each alone on its SIMD) ================================
     const bool chain = hw == 3;  // wave 3: the upper half of the ring, the right-hand side, 1 / diag for the storer, `fail`
-    const bool cprof = prof_enabled(T.debug_flags, 16) && chain && l == 0;  // coarse phases of this job -> tlog[8 (200 + 10 job) + ..]
-    long long* clog = tlog + 8 * (200 + 10 * blockIdx.x);
+    const bool cprof = prof_enabled(T.debug_flags, 16) && chain && l == 0;  // coarse phases of this job -> tlog[8 (590 + 4 job) + ..]
+    long long* clog = tlog + 8 * (590 + 4 * blockIdx.x);
     if (cprof) clog[0] = wall_clock64();
     MxLane L;
     L.ring = l < 48;
@@ -740,7 +740,7 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
     if (tid == 0) {
       __threadfence();
       __hip_atomic_store(T.join_flag, T.join_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      if (prof_enabled(T.debug_flags, 16)) tlog[8 * (200 + 10 * blockIdx.x) + 7] = wall_clock64();  // window handed over
+      if (prof_enabled(T.debug_flags, 16)) tlog[8 * (590 + 4 * blockIdx.x) + 7] = wall_clock64();  // window handed over
     }
   }
   // Iteration bookkeeping of a directly assembled system (Tables::bookkeep, factor_bookkeep): a wave of the FAR end, behind its hand-over —

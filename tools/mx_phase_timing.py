@@ -30,6 +30,6 @@ for i in range(20, 28):
     print(i, [int(x - b) for x in t[i, [0, 2, 3, 4, 5, 1]]], [int(x - b) for x in q[i, :4]], [int(x - b) for x in q[i, 4:8]])
 names = ["prologue done", "junction reached", "partner arrived", "merged", "X_m published", "last block row", "window handed over"]
 for job in (0, 1):
-    c = t[200 + 10 * job]
-    print(f"job {job} relative to job 0's start [10 ns]:", " ".join(f"{n} {int(c[k + 1] - t[200, 0])}" for k, n in enumerate(names) if c[k + 1] > 0), " (start", int(c[0] - t[200, 0]), ")")
+    c = t[590 + 4 * job]
+    print(f"job {job} relative to job 0's start [10 ns]:", " ".join(f"{n} {int(c[k + 1] - t[590, 0])}" for k, n in enumerate(names) if c[k + 1] > 0), " (start", int(c[0] - t[590, 0]), ")")
 print("solve_ms", s["solve_ms"])

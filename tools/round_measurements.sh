@@ -29,5 +29,5 @@ python bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline > $out/${tag}
   for a in "6.0 1 4" "6.0 0 4" "6.0 1 6" "8.0 1 4"; do ./replay $a 2>/dev/null | tail -1; HS_STAGE_TIMING=1 ./replay $a 2>/dev/null | tail -1; done
   ./replay_oracle 6.0 1 4 2>/dev/null | tail -1 ) > $out/${tag}_replay.txt 2>&1
 ( cd hyperslam_amd/host; for a in "6.0 1 4" "6.0 0 4"; do echo "replay $a"; HS_HOST_TIMING=1 ./replay $a 2>&1 >/dev/null | grep "host timing"; done ) > $out/${tag}_replay_host_split.txt 2>&1
-for a in "3.6 0 4" "3.6 1 4" "6.0 1 6" "6.0 1 4"; do  # (one run each: ~10 s) hyperslam_amd/host/replay_lockstep hyperslam_amd/libhyperslam_hip.so $a > $out/${tag}_lockstep_$(echo $a | tr ' .' '__').jsonl 2>&1; done
+for a in "3.6 0 4" "3.6 1 4" "6.0 1 6" "6.0 1 4"; do hyperslam_amd/host/replay_lockstep hyperslam_amd/libhyperslam_hip.so $a > $out/${tag}_lockstep_$(echo $a | tr ' .' '__').jsonl 2>&1; done
 echo done

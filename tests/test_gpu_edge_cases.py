@@ -220,6 +220,34 @@ def test_band_widths_from_both_ends(bw, imu, hip, oracle):
     compare(w, hip, oracle)
 
 
+@pytest.mark.parametrize("bw", [5, 6, 7, 8, 9, 10, 11, 12])
+def test_narrow_bands_from_both_ends(bw, hip, oracle):
+    """k_band_factor_mx (round 5: trailing window in f64-MFMA accumulators, 16 phases of a 96-position ring) on every band width below the
+    ones the tests above pin: windows of 72 control points are factored from both ends for any band of up to 16 control points."""
+    w = window_with_band(4, bw, n_cp=72)
+    with ha.Problem(w, lib=hip) as g:
+        g.cost()
+        assert g.lib.band_blocks(g.h) == bw and w.n_cp >= 4 * bw
+    compare(w, hip, oracle)
+
+
+@pytest.mark.parametrize("bw,imu", [(9, False), (14, False), (16, False), (14, True), (16, True)])
+def test_mfma_and_valu_factorisations_agree(bw, imu, hip, monkeypatch):
+    """The two two-ended factorisations of the library — k_band_factor_mx (default) and k_band_factor_la (measurement switch 64) — on the same
+    window: same accept / reject sequence, final state to 1e-9 (two summation orders of one Cholesky factorisation)."""
+    w = window_with_band(4, bw, n_cp=72, imu=imu)
+    runs = []
+    for flags in ("0", "64"):
+        monkeypatch.setenv("HS_DEBUG_FLAGS", flags)
+        with ha.Problem(w, lib=hip) as g:
+            s = g.solve(5)
+            runs.append((s, g.control_points().copy(), g.landmarks().copy()))
+    (sa, ca, la), (sb, cb, lb) = runs
+    assert sa["num_iterations"] == sb["num_iterations"] and sa["num_successful_steps"] == sb["num_successful_steps"]
+    assert abs(sa["final_cost"] - sb["final_cost"]) <= 1e-9 * abs(sb["final_cost"])
+    assert np.abs(ca - cb).max() <= 1e-9 * max(1.0, np.abs(cb).max()) and np.abs(la - lb).max() <= 1e-8 * max(1.0, np.abs(lb).max())
+
+
 @pytest.mark.parametrize("bw", [14, 15, 16, 22, 23, 24, 34])
 def test_band_widths_order6_bordered(bw, hip, oracle):
     """The same with an order-6 spline and the bordered (inertial) system."""

@@ -8,7 +8,8 @@
 //   k_border_pb / k_border_bb                border blocks of the inertial factors (bias splines, gravity)
 //   k_pack_exchange -> [all-reduce] -> k_finalize_reduced / _border -> k_cost_reduce     scaling, damping, gradient test
 //     (single shard without border unknowns: packing + bookkeeping are an extra workgroup of k_finalize_reduced, one launch)
-//   k_band_factor_la (look-ahead, one or two ends) | k_band_factor (bw <= 22) | k_band_factor_wide (bw <= 42)   S = U'U, y
+//   k_band_factor_mx (two ends, bw <= 16: trailing window in f64-MFMA accumulators) | k_band_factor_la (one end; A/B) | k_band_factor
+//   (bw <= 22) | k_band_factor_wide (bw <= 42) | k_dense_factor                                                             S = U'U, y
 //   k_border_forward / _schur / _solve / _apply                                         bordered part of the solve
 //   k_band_backward | k_band_backward_sb     U x = y (two-ended: super-blocks of four block rows, inverses built by extra workgroups), step outputs
 //   k_backsub_retract                        step for landmarks, candidate point = Plus(x, delta), norm / model-cost partials

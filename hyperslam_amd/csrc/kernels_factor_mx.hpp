@@ -17,17 +17,21 @@ namespace hs {
 // the compute waves spend 72 LDS operands per 216 FMAs of a 6 x 6 register tile, the panel wave carries two columns per lane.
 // Here the rank-6 trailing update is v_mfma_f64_16x16x4_f64 on tiles that never leave the accumulator registers: an MFMA
 // wave needs TWELVE ds_read_b64 per block row for all its operands (the A and the B operand of tile (I, J) are the same
-// register set: X_i[k][16 I + j] and X_i[k][16 J + j], lane (k, j)), and 14 MFMAs. What the matrix cores free are the issue
-// slots of three SIMDs; they go to a panel that is split the way the dependency chain asks for:
-//   waves 3 (alone on SIMD 3) and 4: the PANEL, one column per lane, 48 ring columns each (wave 3 also the right-hand side):
-//   update of the own column with X_(i-1), the 6 x 6 diagonal block of the pivot row broadcast with v_readlane from six extra lanes
-//   that redo the block's columns in BOTH waves, redundant register Cholesky, column solve, publish — and nothing else: a lone wave
-//   issues an instruction every ~6 cycles on this mix, so the length of the panel's instruction stream IS the step time (measured:
-//   480 instructions 1.5 us, a flag word behind a U published by one wave + 0.3 us). Everything that is not on the chain lives in
-//   the loader (block rows HBM -> stage, two iterations ahead) and the storer (factor row, y, inverted diagonal block -> HBM one iteration
-//   later, right-hand side of the trailing rows), which share the SIMDs of the MFMA waves. gfx950 executes the f64 MFMA on the SIMD's
-//   fp64 pipe — it has the vector FMA rate and a panel wave next to an MFMA wave stretched from 0.84 to 1.2 us (measured) — so the two
-//   panel waves have SIMDs 2 and 3 to themselves and the 21 tiles live on SIMDs 0 and 1, two MFMA waves each.
+// register set: X_i[k][16 I + j] and X_i[k][16 J + j], lane (k, j)). gfx950 executes the f64 MFMA on the SIMD's fp64 pipe — it
+// has the vector FMA rate, and a panel wave next to an MFMA wave stretched from 0.84 to 1.2 us (measured) — so the matrix cores do
+// not add arithmetic; what they remove are operand traffic and issue slots, and the SIMDs are dealt accordingly (waves are
+// placed round robin on the four SIMDs):
+//   waves 0, 4 (SIMD 0) and 1, 5 (SIMD 1)   the 21 tiles in four MFMA waves (the operand loads and hand-overs of one wave run while
+//                                           the pipe works on the other's tiles); + wave 8: inverts the diagonal blocks for the sweeps
+//   waves 2 (SIMD 2) and 3 (SIMD 3)         the PANEL, one column per lane, 48 ring columns each (wave 3 also the right-hand side):
+//                                           update of the own column with X_(i-1), the pivot's 6 x 6 diagonal block broadcast with
+//                                           v_readlane from six extra lanes that redo its columns in BOTH waves, redundant register
+//                                           Cholesky, column solve, publish — and nothing else: the panel is a latency chain (LDS loads
+//                                           -> update -> factor -> solve -> LDS writes), 0.85 us per block row; a flag word behind a U
+//                                           published by one wave cost + 0.3 us, 480 instead of 272 instructions 1.5 us
+//   wave 6 (SIMD 2) storer, wave 7 (SIMD 3) loader: factor row and y -> HBM one iteration later + the right-hand side of the trailing
+//                                           rows; block rows HBM -> stage two iterations ahead (next to the MFMA waves the storer took
+//                                           1.3 us per block row: their MFMAs keep the fp64 pipes busy for most of a step)
 // One column per lane in RING coordinates (matrix index rho lives at ring position rho mod 96 for its whole life): a lane's
 // own result of the previous block row is its operand of the next one, the right-hand side of a position lives in a
 // register of its lane, and the window slides by six positions per block row without moving anything.
@@ -51,7 +55,7 @@ namespace hs {
 // ---------------------------------------------------------------------------------------------------------------------
 typedef double mx_f64x4 __attribute__((vector_size(32)));
 
-constexpr int kMxW = 96, kMxLdx = 112, kMxTiles = 21, kMxWaves = 9, kMxThreads = 64 * kMxWaves;
+constexpr int kMxW = 96, kMxLdx = 112, kMxWaves = 9, kMxThreads = 64 * kMxWaves;
 constexpr int kMxX = 0, kMxR = kMxX + 12 * kMxLdx, kMxS = kMxR + 12 * kMxLdx, kMxD = kMxS + 12 * kMxLdx, kMxLds = kMxD + 16;
 constexpr int kMxDiagLane = 56;  // lanes 56 .. 61 of both panel waves redo the six columns of the pivot's diagonal block
 

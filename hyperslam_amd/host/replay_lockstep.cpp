@@ -12,6 +12,9 @@
 // 5-iteration trajectory is compared at 1e-6; the first windows of a replay (nothing frozen yet, stereo only) are rank
 // deficient up to the LM damping and are compared in quality only.
 //   usage: replay_lockstep <path/to/libhyperslam_hip.so> [seconds=3.6] [imu=0|1] [order=4]
+// HS_LOCKSTEP_DUMP=<file> also writes the raw end points of every call (shadow and master control points and landmarks, binary:
+// int32 call, n_cp_values, n_lm_values, then the four double arrays), so that two runs with different shadows — the HIP library and
+// oracle/liboracle_ld.so, the long-double build of the oracle — can be compared with each other (tools/lockstep_three_way.py).
 // Test infrastructure only: nothing in the product path links or loads the oracle.
 #include <dlfcn.h>
 
@@ -113,6 +116,7 @@ int main(int argc, char** argv) {
     double gravity[3] = {0, 0, 0};
   } sh;
   int worst_fixed_call = -1;
+  std::FILE* dump = std::getenv("HS_LOCKSTEP_DUMP") ? std::fopen(std::getenv("HS_LOCKSTEP_DUMP"), "wb") : nullptr;
   double worst_fixed = 0;
   int n_fixed = 0, n_free = 0;
 
@@ -151,6 +155,12 @@ int main(int argc, char** argv) {
     const double grav_rel = t.has_imu ? rel_max(sh.gravity, r.gravity, 3) : 0.0;
     const double traj = std::max(std::max(cp_rel, lm_rel), std::max(bias_rel, grav_rel));
     (gauge_fixed ? n_fixed : n_free)++;
+    if (dump) {
+      const int32_t head[3] = {call, int32_t(sh.cp.size()), int32_t(sh.lm.size())};
+      std::fwrite(head, sizeof(head), 1, dump);
+      std::fwrite(sh.cp.data(), 8, sh.cp.size(), dump), std::fwrite(sh.lm.data(), 8, sh.lm.size(), dump);
+      std::fwrite(r.cp.data(), 8, sh.cp.size(), dump), std::fwrite(r.landmarks.data(), 8, sh.lm.size(), dump);
+    }
     if (gauge_fixed && traj > worst_fixed) worst_fixed = traj, worst_fixed_call = call;
     std::printf("{\"call\": %d, \"control_points\": %d, \"frozen\": %d, \"gauge_fixed\": %s, \"landmarks\": %zu, \"blocks\": %d, \"dim\": %d, \"band_blocks\": %d, "
                 "\"window\": [%.2f, %.2f], \"gravity_constant\": %d, \"S_rel\": %.3e, \"g_rel\": %.3e, \"cost0_rel\": %.3e, \"iterations\": [%d, %d], "
@@ -171,6 +181,7 @@ int main(int argc, char** argv) {
               "\"worst_gauge_fixed_trajectory_rel\": %.3e, \"worst_gauge_fixed_call\": %d, \"window\": [%.2f, %.2f]}\n",
               seconds, int(with_imu), opt.order, master.numOptimizations(), n_fixed, n_free, worst_fixed, worst_fixed_call, master.window().lower,
               master.window().upper);
+  if (dump) std::fclose(dump);
   H.destroy(shadow);
   return 0;
 }

@@ -953,7 +953,7 @@ inline void loss_evaluate(const Loss& l, double s, double rho[3]) {
       if (s > b) {
         const double r = std::sqrt(s);
         rho[0] = 2 * l.a * r - b;
-        rho[1] = std::max(2.2250738585072014e-308, l.a / r);
+        rho[1] = std::max<double>(2.2250738585072014e-308, l.a / r);
         rho[2] = -rho[1] / (2 * s);
       } else {
         rho[0] = s, rho[1] = 1, rho[2] = 0;

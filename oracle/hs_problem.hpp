@@ -426,15 +426,26 @@ inline void cholesky_solve(const std::vector<double>& L, int n, const std::vecto
     b[i] = s / L[size_t(i) * n + i];
   }
 }
+/// Inverse of a symmetric positive definite 3x3 block through its Cholesky factor A = L L', A^-1 = L^-T L^-1: backward stable for
+/// the landmark blocks of poorly observed points (two views, little parallax: cond(V) ~ 1e8). The cofactor / determinant formula
+/// this replaced lost those digits to cancellation: with it the double build of this file stood 1.4e-6 away (landmarks, stereo
+/// replay call 32) from its own long-double build (capi_ld.cpp) and from the HIP library alike, which agree with each other to
+/// 4e-10 (profiles/r05_three_way_3_6_0_4.txt). The reference never forms this inverse: its linear solver is
+/// SPARSE_NORMAL_CHOLESKY on the full system (optimizer.cpp:28-54), the landmark elimination is this path's own formulation.
 inline bool inv3_spd(const double* A, double* inv) {
-  const double a = A[0], b = A[1], c = A[2], d = A[4], e = A[5], f = A[8];
-  const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
-  const double det = a * c00 + b * c01 + c * c02;
-  if (!(det > 0.0)) return false;
-  const double id = 1.0 / det;
-  inv[0] = c00 * id, inv[1] = c01 * id, inv[2] = c02 * id;
-  inv[3] = inv[1], inv[4] = (a * f - c * c) * id, inv[5] = (b * c - a * e) * id;
-  inv[6] = inv[2], inv[7] = inv[5], inv[8] = (a * d - b * b) * id;
+  if (!(A[0] > 0.0)) return false;
+  const double l00 = std::sqrt(A[0]), l10 = A[1] / l00, l20 = A[2] / l00;
+  const double d1 = A[4] - l10 * l10;
+  if (!(d1 > 0.0)) return false;
+  const double l11 = std::sqrt(d1), l21 = (A[5] - l20 * l10) / l11;
+  const double d2 = A[8] - l20 * l20 - l21 * l21;
+  if (!(d2 > 0.0)) return false;
+  const double l22 = std::sqrt(d2);
+  const double m00 = 1.0 / l00, m11 = 1.0 / l11, m22 = 1.0 / l22;  // M = L^-1 (lower triangular)
+  const double m10 = -l10 * m00 * m11, m21 = -l21 * m11 * m22, m20 = -(l20 * m00 + l21 * m10) * m22;
+  inv[0] = m00 * m00 + m10 * m10 + m20 * m20, inv[1] = m10 * m11 + m20 * m21, inv[2] = m20 * m22;
+  inv[3] = inv[1], inv[4] = m11 * m11 + m21 * m21, inv[5] = m21 * m22;
+  inv[6] = inv[2], inv[7] = inv[5], inv[8] = m22 * m22;
   return true;
 }
 
@@ -777,7 +788,7 @@ struct LM {
         cost = ne.cost;
         gmax = gradient_max_norm(ne, P);
         rec.cost = cost, rec.gradient_max_norm = gmax;
-        radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rec.relative_decrease - 1.0, 3));
+        radius = radius / std::max<double>(1.0 / 3.0, 1.0 - std::pow(2.0 * rec.relative_decrease - 1.0, 3));
         radius = std::min(kMaxRadius, radius);
         decrease_factor = 2.0;
       } else {

@@ -206,7 +206,11 @@ int launch_build(hs_problem* p, hipEvent_t after_build = nullptr, bool scaling_f
   if (fork) HIP_TRY(hipStreamWaitEvent(s, p->ev_join, 0));
   const bool direct = scaling_fixed && fused && !T.nb && !p->allreduce && !p->rccl_comm && p->world == 1 && factor_two_ended_la(p) &&
                       !(T.debug_flags & 4096);  // A/B switch 4096: k_finalize_reduced in every iteration
-  k_assemble<K><<<dim3(T.sp.n_cp, 6), kAsmThreads, 0, s>>>(T, direct ? 1 : 0);
+  // window-wide bands on the fused build (more than 256 window tiles): a row collects every chunk of a short window — k_assemble_wide
+  if (fused && T.bw * (T.bw + 1) / 2 > kBlock && !direct)
+    k_assemble_wide<K><<<dim3(T.sp.n_cp, 6), kAsmWideThreads, 0, s>>>(T, 0);
+  else
+    k_assemble<K><<<dim3(T.sp.n_cp, 6), kAsmThreads, 0, s>>>(T, direct ? 1 : 0);
   if (direct) {
     p->bookkeep = true;
     HIP_TRY(hipGetLastError());
@@ -551,7 +555,7 @@ static void warm_kernels_of_order() {
       reinterpret_cast<const void*>(&k_linearize_inertial<K, 4>), reinterpret_cast<const void*>(&k_landmark<K, 2, 2>),
       reinterpret_cast<const void*>(&k_landmark<K, 4, 1>), reinterpret_cast<const void*>(&k_landmark_rows<K, 4>),
       reinterpret_cast<const void*>(&k_gram_pair<K, 1>), reinterpret_cast<const void*>(&k_gram_pair<K, 2>), reinterpret_cast<const void*>(&k_gram_pair<K, 4>),
-      reinterpret_cast<const void*>(&k_seg_gram<K>), reinterpret_cast<const void*>(&k_assemble<K>), reinterpret_cast<const void*>(&k_border_pb<K>),
+      reinterpret_cast<const void*>(&k_seg_gram<K>), reinterpret_cast<const void*>(&k_assemble<K>), reinterpret_cast<const void*>(&k_assemble_wide<K>), reinterpret_cast<const void*>(&k_border_pb<K>),
       reinterpret_cast<const void*>(&k_border_bb<K>), reinterpret_cast<const void*>(&k_cost_visual<K>), reinterpret_cast<const void*>(&k_cost_prior<K>),
       reinterpret_cast<const void*>(&k_cost_inertial<K, 4>), reinterpret_cast<const void*>(&k_cost_all<K, 4>),
       reinterpret_cast<const void*>(&k_process_tracks<K>), reinterpret_cast<const void*>(&k_sample_trajectory<K>)};

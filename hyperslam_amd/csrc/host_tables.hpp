@@ -453,11 +453,16 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_v_first.upload(vs.first, s));
   HIP_TRY(p->d_v_pos.upload(vs.pos, s));
   HIP_TRY(p->d_v_seg_ptr.upload(vs.seg_ptr, s));
-  // ---- fused build (kernels_build.hpp) or the record path (long feature tracks: more than 256 window tiles; A/B switch 2147483648... see below) ----
+  // ---- fused build (kernels_build.hpp) or the record path (a lane group per J'J band tile: k bw - k (k - 1) / 2 <= 256, i.e. bands of up to 65 / 53 /
+  //      45 control points at orders 4 / 5 / 6; a landmark with more residuals than a chunk has lanes; no chunk geometry that fits the LDS) ----
+  //      Window-wide bands (the steady state of a sliding window: tracks as long as the window, bw(bw + 1) / 2 > 256 window tiles) take the
+  //      tiles of the landmark term in passes (kernels_build.hpp phase 5). HS_BUILD_PATH=records: the record path everywhere; =narrow: the
+  //      fused build for at most 256 window tiles only (round 4's rule) — measurement switches, like HS_DEBUG_FLAGS.
   {
     const int ntile_ = vs.bw * (vs.bw + 1) / 2, nband_ = k * vs.bw - k * (k - 1) / 2;
-    const char* env = std::getenv("HS_BUILD_PATH");  // "records": the record path everywhere (measurement switch, like HS_DEBUG_FLAGS)
-    p->fused = n_vis > 0 && ntile_ <= kBlock && nband_ <= kBlock && !(env && std::strcmp(env, "records") == 0);
+    const char* env = std::getenv("HS_BUILD_PATH");
+    const bool narrow_only = env && std::strcmp(env, "narrow") == 0;
+    p->fused = n_vis > 0 && nband_ <= kBlock && vs.bw <= 64 && (ntile_ <= kBlock || !narrow_only) && !(env && std::strcmp(env, "records") == 0);
   }
   if (p->fused) {
     // chunk geometry: R residuals (lanes) and L landmarks per chunk, sized for two workgroups per CU (every phase of the kernel is an LDS

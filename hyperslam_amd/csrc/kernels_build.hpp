@@ -633,78 +633,81 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
   __syncthreads();
   HS_BSTAMP(9);
   // ---- 5: Q = - sum_l Yh_l Yh_l' over the window tiles, q = - sum_l Yh_l yh_l (diagonal tiles): lane = QS * tile + stream.
-  //         Branch-free over the landmarks (a tile outside a landmark's rows reads zero rows), two landmarks in flight. ----
+  //         Branch-free over the landmarks (a tile outside a landmark's rows reads zero rows), two landmarks in flight.
+  //         Window-wide bands (long feature tracks: more tiles than lanes — 561 for 33 control points) take the tiles in passes of kBlock. ----
   const int QS = ntile <= kBlock / 2 ? 2 : 1;
-  const int q_t = tid / QS, q_s = tid - q_t * QS;
-  const bool q_ok = q_t < ntile;
-  int q_rb = 0, q_cb = 0;
-  {
-    int rem = q_ok ? q_t : 0;
-    while (rem >= bw - q_rb) rem -= bw - q_rb, ++q_rb;  // row rb holds bw - rb tiles
-    q_cb = q_rb + rem;
-  }
-  double acc[36], qacc[6];
-#pragma unroll
-  for (int e = 0; e < 36; ++e) acc[e] = 0.0;
-#pragma unroll
-  for (int e = 0; e < 6; ++e) qacc[e] = 0.0;
-  if (q_ok) {
-    const bool diag = q_rb == q_cb;
-#pragma unroll 2
-    for (int l = q_s; l < nl; l += QS) {
-      const double* Yb = Wy + size_t(l) * R6 * 3;  // (rows beyond the landmark's control points are zeros: phase 2b)
-      double A[18], B[18];
-#pragma unroll
-      for (int e = 0; e < 18; e += 2) {
-        const double2 va = *reinterpret_cast<const double2*>(Yb + 18 * q_rb + e), vb = *reinterpret_cast<const double2*>(Yb + 18 * q_cb + e);
-        A[e] = va.x, A[e + 1] = va.y, B[e] = vb.x, B[e + 1] = vb.y;
-      }
-      const double* li = Linv + kLinv * l;
-      const double y0 = li[10], y1 = li[11], y2 = li[12];
-#pragma unroll
-      for (int r = 0; r < 6; ++r) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c)
-          acc[6 * r + c] = fma(-A[3 * r + 2], B[3 * c + 2], fma(-A[3 * r + 1], B[3 * c + 1], fma(-A[3 * r], B[3 * c], acc[6 * r + c])));
-        if (diag) qacc[r] = fma(-A[3 * r + 2], y2, fma(-A[3 * r + 1], y1, fma(-A[3 * r], y0, qacc[r])));
-      }
-    }
-  }
-  if (QS == 2) {  // stream 0 + stream 1 (adjacent lanes)
-#pragma unroll
-    for (int e = 0; e < 36; ++e) acc[e] += lane_xor1(acc[e]);
-#pragma unroll
-    for (int e = 0; e < 6; ++e) qacc[e] += lane_xor1(qacc[e]);
-  }
-  HS_BSTAMP(10);
-  // ---- 6: P + Q and the three vectors of the chunk partial -> HBM ----
   double* G = T.grpQ + size_t(chunk_id) * (size_t(ntile) * 36 + 3 * R6);
-  if (q_s == 0 && q_ok) {
-    const int d = q_cb - q_rb;
-    if (d < K) {
-      const double* src = Pc + size_t(band_tile_index(q_rb, d, bw)) * 42;
-      if (d == 0) {
+  for (int q_base = 0; q_base < ntile; q_base += kBlock / QS) {
+    const int q_t = q_base + tid / QS, q_s = tid % QS;
+    const bool q_ok = q_t < ntile;
+    int q_rb = 0, q_cb = 0;
+    {
+      int rem = q_ok ? q_t : 0;
+      while (rem >= bw - q_rb) rem -= bw - q_rb, ++q_rb;  // row rb holds bw - rb tiles
+      q_cb = q_rb + rem;
+    }
+    double acc[36], qacc[6];
+#pragma unroll
+    for (int e = 0; e < 36; ++e) acc[e] = 0.0;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) qacc[e] = 0.0;
+    if (q_ok) {
+      const bool diag = q_rb == q_cb;
+#pragma unroll 2
+      for (int l = q_s; l < nl; l += QS) {
+        const double* Yb = Wy + size_t(l) * R6 * 3;  // (rows beyond the landmark's control points are zeros: phase 2b)
+        double A[18], B[18];
+#pragma unroll
+        for (int e = 0; e < 18; e += 2) {
+          const double2 va = *reinterpret_cast<const double2*>(Yb + 18 * q_rb + e), vb = *reinterpret_cast<const double2*>(Yb + 18 * q_cb + e);
+          A[e] = va.x, A[e + 1] = va.y, B[e] = vb.x, B[e + 1] = vb.y;
+        }
+        const double* li = Linv + kLinv * l;
+        const double y0 = li[10], y1 = li[11], y2 = li[12];
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
-          G[size_t(ntile) * 36 + 6 * q_rb + r] = qacc[r];
-          G[size_t(ntile) * 36 + R6 + 6 * q_rb + r] = src[36 + r];
-          G[size_t(ntile) * 36 + 2 * R6 + 6 * q_rb + r] = src[7 * r];
+#pragma unroll
+          for (int c = 0; c < 6; ++c)
+            acc[6 * r + c] = fma(-A[3 * r + 2], B[3 * c + 2], fma(-A[3 * r + 1], B[3 * c + 1], fma(-A[3 * r], B[3 * c], acc[6 * r + c])));
+          if (diag) qacc[r] = fma(-A[3 * r + 2], y2, fma(-A[3 * r + 1], y1, fma(-A[3 * r], y0, qacc[r])));
         }
       }
-#pragma unroll
-      for (int e = 0; e < 36; e += 2) {
-        const double2 v = *reinterpret_cast<const double2*>(src + e);
-        acc[e] += v.x, acc[e + 1] += v.y;
-      }
     }
-    // rows of the window, not tiles: row (rb, r) holds its (bw - rb) blocks contiguously, so that k_assemble — one lane per band entry of a
-    // scalar row — reads a chunk partial with consecutive lanes on consecutive doubles
-    double* grow = G + 36 * group_tile_index(q_rb, q_rb, bw) + 6 * (q_cb - q_rb);
-    const int rstride = 6 * (bw - q_rb);
+    if (QS == 2) {  // stream 0 + stream 1 (adjacent lanes)
 #pragma unroll
-    for (int r = 0; r < 6; ++r)
+      for (int e = 0; e < 36; ++e) acc[e] += lane_xor1(acc[e]);
 #pragma unroll
-      for (int e = 0; e < 6; e += 2) *reinterpret_cast<double2*>(grow + r * rstride + e) = make_double2(acc[6 * r + e], acc[6 * r + e + 1]);
+      for (int e = 0; e < 6; ++e) qacc[e] += lane_xor1(qacc[e]);
+    }
+    HS_BSTAMP(10);
+    // ---- 6: P + Q and the three vectors of the chunk partial -> HBM ----
+    if (q_s == 0 && q_ok) {
+      const int d = q_cb - q_rb;
+      if (d < K) {
+        const double* src = Pc + size_t(band_tile_index(q_rb, d, bw)) * 42;
+        if (d == 0) {
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+            G[size_t(ntile) * 36 + 6 * q_rb + r] = qacc[r];
+            G[size_t(ntile) * 36 + R6 + 6 * q_rb + r] = src[36 + r];
+            G[size_t(ntile) * 36 + 2 * R6 + 6 * q_rb + r] = src[7 * r];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 36; e += 2) {
+          const double2 v = *reinterpret_cast<const double2*>(src + e);
+          acc[e] += v.x, acc[e + 1] += v.y;
+        }
+      }
+      // rows of the window, not tiles: row (rb, r) holds its (bw - rb) blocks contiguously, so that k_assemble — one lane per band entry of a
+      // scalar row — reads a chunk partial with consecutive lanes on consecutive doubles
+      double* grow = G + 36 * group_tile_index(q_rb, q_rb, bw) + 6 * (q_cb - q_rb);
+      const int rstride = 6 * (bw - q_rb);
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int e = 0; e < 6; e += 2) *reinterpret_cast<double2*>(grow + r * rstride + e) = make_double2(acc[6 * r + e], acc[6 * r + e + 1]);
+    }
   }
   HS_BSTAMP(11);
   if (tid == 0) {

@@ -402,7 +402,9 @@ HSD void mx_lane_merge(const MfmaJob& J, double* rowbuf, int t, int m_at, int p_
     const bool in = e < 12 * (W + 1);
     const int j = in ? e / (6 * (W + 1)) : 0, rem = in ? e % (6 * (W + 1)) : 0, k = rem / (W + 1), pos = rem % (W + 1);
     const int da = 6 * j + k, db = pos == W ? dm : mx_sub(pos, p_m);
-    const bool ok = in && (pos == W || db < dm);
+    // (db >= 6 j: the upper part only. With 16 control points per band the positions of block row m ARE band positions of block row m + 1 —
+    //  its pairs with block row m + 16 — and the mirrored entries D[m + 1][m] would be stored, and carried along, as a band block)
+    const bool ok = in && (pos == W || (db < dm && db >= 6 * j));
     const double v = D[ok ? size_t(da) * (dm + 1) + db : 0];
     dv[u] = ok ? v : 0.0;
   }

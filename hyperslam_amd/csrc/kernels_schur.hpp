@@ -514,9 +514,13 @@ constexpr int kAsmThreads = 512, kAsmU = 6;  // lanes per scalar row, loads in f
 /// does the iteration bookkeeping itself, Tables::bookkeep): the row is scaled, damped and written in the factorisation's layout right here,
 ///     S = Sp Sraw Sp + D_p^2,  g = Sp (g_p + g_schur),  g_full = Sp g_p,  D_p^2 = clamp(Sp^2 diag(J'J), 1e-6, 1e32) / radius
 /// (what k_finalize_reduced does with a launch of its own: ~6 us on the chain of an iteration, most of it launch latency).
-template <int K>
-__global__ void __launch_bounds__(kAsmThreads, 6) k_assemble(Tables T, int direct) {  // (see kAsmThreads)
-  __shared__ double part[3][kAsmThreads];
+/// QB = 0: the kernel of every window whose rows collect a few dozen partials. QB > 0 (k_assemble_wide): window-wide bands on the fused
+/// build — a row collects every chunk of the window, ~70 sources per lane: the sources behind the first round are fetched QB at a time, the
+/// work-list entries of batch n + 1 together with the values of batch n (one memory round trip per QB sources where entry -> value per
+/// batch of kAsmU takes two). Same sources in the same order per lane: the sums are bit-identical.
+template <int K, int QB, int THREADS>
+HSD void assemble_body(const Tables& T, int direct) {
+  __shared__ double part[3][THREADS];
   __shared__ double gpair[2];
   // phase timestamps (profiling builds, HS_DEBUG_FLAGS 64; tools/assemble_phase_timing.py): lane 0 of every workgroup
   const bool aprof = prof_enabled(T.debug_flags, 64) && threadIdx.x == 0;
@@ -531,7 +535,7 @@ __global__ void __launch_bounds__(kAsmThreads, 6) k_assemble(Tables T, int direc
   const int f0 = max(0, i - K + 1), f1 = min(i, T.n_seg - 1);
   const int c0 = max(0, i - bw + 1);
   const int nent = ncb + 2;  // band entries + [J'r | Y-hat y-hat] of this row
-  const int nsl = max(1, kAsmThreads / nent), sl = tid / nent, c = tid % nent;
+  const int nsl = max(1, THREADS / nent), sl = tid / nent, c = tid % nent;
   // direct mode: scaling of this row and of the lane's column, trust-region radius (requested with the work lists)
   double d_sr = 1.0, d_sc = 1.0, d_radius = 1.0;
   if (direct) {
@@ -600,17 +604,43 @@ __global__ void __launch_bounds__(kAsmThreads, 6) k_assemble(Tables T, int direc
 #pragma unroll
       for (int u = 0; u < kAsmU; ++u) va += v[u];
     }
-    for (int q0 = sl + 2 * kAsmU * nsl; q0 < nq; q0 += kAsmU * nsl) {
-      double v[kAsmU];
+    if constexpr (QB == 0) {
+      for (int q0 = sl + 2 * kAsmU * nsl; q0 < nq; q0 += kAsmU * nsl) {
+        double v[kAsmU];
 #pragma unroll
-      for (int u = 0; u < kAsmU; ++u) {
-        const int q = q0 + u * nsl;
-        const int cf = q < nq ? T.gw_cf[q_lo + q] : 0;
-        v[u] = c == ncb && T.fused ? 0.0 : HS_GRP_VALUE(q, cf);
-        if (x_live) vp += HS_GRP_EXTRA(q, cf);
+        for (int u = 0; u < kAsmU; ++u) {
+          const int q = q0 + u * nsl;
+          const int cf = q < nq ? T.gw_cf[q_lo + q] : 0;
+          v[u] = c == ncb && T.fused ? 0.0 : HS_GRP_VALUE(q, cf);
+          if (x_live) vp += HS_GRP_EXTRA(q, cf);
+        }
+#pragma unroll
+        for (int u = 0; u < kAsmU; ++u) vb += v[u];
       }
+    } else {
+      int q0 = sl + 2 * kAsmU * nsl;
+      int cfn[QB > 0 ? QB : 1];
 #pragma unroll
-      for (int u = 0; u < kAsmU; ++u) vb += v[u];
+      for (int u = 0; u < QB; ++u) cfn[u] = q0 + u * nsl < nq ? T.gw_cf[q_lo + q0 + u * nsl] : 0;
+      for (; q0 < nq; q0 += QB * nsl) {
+        double v[QB > 0 ? QB : 1], xv[QB > 0 ? QB : 1];
+        int cfc[QB > 0 ? QB : 1];
+#pragma unroll
+        for (int u = 0; u < QB; ++u) cfc[u] = cfn[u];
+#pragma unroll
+        for (int u = 0; u < QB; ++u) v[u] = c == ncb && T.fused ? 0.0 : HS_GRP_VALUE(q0 + u * nsl, cfc[u]);
+#pragma unroll
+        for (int u = 0; u < QB; ++u) xv[u] = x_live ? HS_GRP_EXTRA(q0 + u * nsl, cfc[u]) : 0.0;
+#pragma unroll
+        for (int u = 0; u < QB; ++u) {
+          const int q = q0 + (QB + u) * nsl;
+          cfn[u] = q < nq ? T.gw_cf[q_lo + q] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < QB; ++u) vb += v[u];
+#pragma unroll
+        for (int u = 0; u < QB; ++u) vp += xv[u];
+      }
     }
 #undef HS_SEG_VALUE
 #undef HS_GRP_VALUE
@@ -673,6 +703,15 @@ __global__ void __launch_bounds__(kAsmThreads, 6) k_assemble(Tables T, int direc
     }
   }
   if (aprof) alog[6] = wall_clock64();
+}
+template <int K>
+__global__ void __launch_bounds__(kAsmThreads, 6) k_assemble(Tables T, int direct) {  // (see kAsmThreads)
+  assemble_body<K, 0, kAsmThreads>(T, direct);
+}
+constexpr int kAsmWideThreads = 1024, kAsmWideBatch = 12;  // (sixteen waves: 128 VGPRs)
+template <int K>
+__global__ void __launch_bounds__(kAsmWideThreads) k_assemble_wide(Tables T, int direct) {  // (few workgroups — a short window — and many sources per row)
+  assemble_body<K, kAsmWideBatch, kAsmWideThreads>(T, direct);
 }
 
 /// xbuf[e] = sum over the accumulation splits (fixed order => bit-reproducible). The result is additive across residual shards.

@@ -46,11 +46,16 @@ struct Reader {
 template <int K>
 static void run(Tables& T, int nb_vis, int R, int L, size_t lds) {
   hs_emul::launch(dim3(nb_vis), dim3(kBlock), lds, [&] { k_build_visual<K>(T, R, L, 1); });
-  hs_emul::launch(dim3(T.sp.n_cp, 6), dim3(kAsmThreads), 0, [&] { k_assemble<K>(T, 0); });
+  if (T.bw * (T.bw + 1) / 2 > kBlock)  // (launch_build's rule: window-wide bands take the instance with the pipelined source loop)
+    hs_emul::launch(dim3(T.sp.n_cp, 6), dim3(kAsmWideThreads), 0, [&] { k_assemble_wide<K>(T, 0); });
+  else
+    hs_emul::launch(dim3(T.sp.n_cp, 6), dim3(kAsmThreads), 0, [&] { k_assemble<K>(T, 0); });
   hs_emul::launch(dim3(T.sp.n_cp + 1), dim3(kBlock), 0, [&] { k_finalize_reduced(T, 1); });
   // Direct mode of k_assemble (scaling fixed: every linearisation of a solve but the first): the same partials scaled, damped and written in
   // the factorisation's layout by k_assemble itself must reproduce k_finalize_reduced's output BIT FOR BIT (same operations on the same sums).
-  if (T.st->scaling_ready == 0) {  // (first pass of this process: the scaling was just fixed by the finalisation above)
+  // (not for window-wide bands: k_assemble_wide deals a row's sources to more slices — another, equally fixed, summation order — and the
+  //  product never runs those windows in direct mode: launch_build)
+  if (T.st->scaling_ready == 0 && T.bw * (T.bw + 1) / 2 <= kBlock) {  // (first pass of this process: the scaling was just fixed by the finalisation above)
     const size_t nS = size_t(T.np) * 6 * T.bw;
     std::vector<double> Sb(nS), g_s(T.np), g_full(T.np), D2p(T.np), gabs(T.np + 8);
     Tables D = T;

@@ -115,6 +115,15 @@ def test_emulated_fused_build_small_chunks(harness, oracle):
     assert out["R"] == 64 and out["n_chunk"] >= 6
 
 
+@pytest.mark.parametrize("order,n_cp,span,n_lm,pairs,R,L", [(4, 42, 3.6, 14, 10, 0, 0), (6, 34, 2.4, 10, 6, 0, 0), (5, 36, 3.0, 10, 6, 64, 3)])
+def test_emulated_fused_build_window_wide_bands(harness, oracle, order, n_cp, span, n_lm, pairs, R, L):
+    """Tracks as long as the window (the steady state of the sliding window: bw = 25 .. 38 control points, 325 .. 741 window tiles): the
+    landmark term takes the tiles in passes of 256 (kernels_build.hpp phase 5)."""
+    w = synthetic.small_visual(order=order, n_cp=n_cp, n_landmarks=n_lm, obs_pairs=pairs, span=span)
+    out = _check(harness, oracle, w, R=R, L=L)
+    assert out["bw"] * (out["bw"] + 1) // 2 > 256 and out["n_chunk"] >= 4
+
+
 def test_emulated_fused_build_constants_and_radius(harness, oracle):
     """Constant control points (zero columns), constant landmarks (no elimination, translation columns intact), another radius."""
     w = synthetic.small_visual(order=4, n_cp=14, n_landmarks=30, obs_pairs=3)

@@ -424,6 +424,16 @@ def test_short_windows_with_window_wide_bands(order, bw, n_cp, imu, hip, oracle,
         cp2 = g.control_points()
     assert s1["num_successful_steps"] == s2["num_successful_steps"] and rel(cp1, cp2) < 1e-9
     assert abs(s1["final_cost"] - s2["final_cost"]) <= 1e-9 * s2["final_cost"]
+    # Both build paths: the fused build takes windows with more than 256 window tiles (bw > 22) in passes over the tiles (round 5; before, these
+    # windows went to the record path), HS_BUILD_PATH=records is the record path — same normal equations (compare: against the oracle), same steps.
+    monkeypatch.setenv("HS_DEBUG_FLAGS", "0")
+    monkeypatch.setenv("HS_BUILD_PATH", "records")
+    compare(w, hip, oracle)
+    with ha.Problem(w, lib=hip) as g:
+        s3 = g.solve(3)
+        cp3 = g.control_points()
+    assert s1["num_successful_steps"] == s3["num_successful_steps"] and rel(cp1, cp3) < 1e-9
+    assert abs(s1["final_cost"] - s3["final_cost"]) <= 1e-9 * s3["final_cost"]
 
 
 @pytest.mark.parametrize("flags,what", [(4194304, "k_landmark<K,4,1> instead of k_landmark_rows"), (8388608, "five finalisation launches instead of one"),

@@ -1,5 +1,5 @@
 """Phase timestamps of k_build_visual (HS_DEBUG_FLAGS=32, profiling build: tools/build_profiling_lib.sh).
-usage (GPU box): python tools/build_phase_timing.py [config=1]"""
+usage (GPU box): python tools/build_phase_timing.py [config=1|2|3|r]"""
 import os
 import sys, ctypes as C; sys.path.insert(0, ".")
 import numpy as np
@@ -7,8 +7,10 @@ os.environ["HS_DEBUG_FLAGS"] = str(32 | int(os.environ.get("HS_DEBUG_FLAGS", "0"
 import hyperslam_amd as ha
 from hyperslam_amd import synthetic, _lib
 _lib.PRODUCT_LIB = os.path.join("tools", "libhyperslam_hip_prof.so")
-cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-w = {1: synthetic.config1, 2: synthetic.config2, 3: synthetic.config3}[cfg]()
+# config "r": the replay's steady state — ~34 control points, 480 landmarks tracked over up to the whole window (bw ~ 33: window-wide band)
+cfg = sys.argv[1] if len(sys.argv) > 1 else "1"
+w = synthetic.small_visual(order=4, n_cp=36, n_landmarks=480, obs_pairs=18, span=3.0) if cfg == "r" else \
+    {1: synthetic.config1, 2: synthetic.config2, 3: synthetic.config3}[int(cfg)]()
 p = ha.Problem(w); p.snapshot()
 for i in range(3): p.restore(); s = p.solve(1)
 lib = _lib.load().cdll
@@ -79,4 +81,4 @@ lone = sorted(int(np.where(key == k_)[0][0]) for k_ in uniq[cnt == 1])
 print("workgroups alone on a CU:", len(lone), " indices", lone[:5], "...", lone[-5:], " contiguous:", lone == list(range(lone[0], lone[0] + len(lone))) if lone else None)
 pairs = [tuple(sorted(np.where(key == k_)[0].tolist())) for k_ in uniq[cnt == 2]]
 d = np.array([b - a for a, b in pairs])
-print("index distance of the two workgroups of a CU: min", d.min(), " median", np.median(d), " max", d.max(), " share == 256:", float((d == 256).mean()))
+if len(d): print("index distance of the two workgroups of a CU: min", d.min(), " median", np.median(d), " max", d.max(), " share == 256:", float((d == 256).mean()))

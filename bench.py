@@ -179,7 +179,7 @@ def dominant_kernel(np_rows, bw, two_ended):
         nbytes = 8.0 * (2 * np_rows * ncb + 2 * np_rows)
         flops = n_blk * (6.0 * ncb * ncb + 72.0 * ncb)
         wgs = 2 if two_ended else 1
-        threads = (7 * 64 if ", 4>" in top["Name"] else 6 * 64) if "_la<" in top["Name"] else (8 * 64 if "_mx" in top["Name"] else 6 * 64 if "mfma" in top["Name"] else 256)
+        threads = (7 * 64 if ", 4>" in top["Name"] else 6 * 64) if "_la<" in top["Name"] else (9 * 64 if "_mx" in top["Name"] else 6 * 64 if "mfma" in top["Name"] else 256)
         out.update({"algorithmic_bytes_per_launch": nbytes, "algorithmic_flops_per_launch": flops,
                     "hbm": {"achieved": nbytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBS},
                     "fp64": {"achieved": flops / avg_s / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops / avg_s / 1e12 / FP64_PEAK_TFLOPS},

@@ -2,6 +2,7 @@
 #pragma once
 #include <type_traits>
 #include "factors.hpp"
+#include "device_primitives.hpp"
 
 namespace hs {
 
@@ -23,11 +24,6 @@ HSD void give_up(DevState* st) {
   st->done = 1;
 }
 
-/// Dynamic LDS of a kernel (sized at launch). One spelling for every kernel; the CPU emulation harness of the tests (tests/emul/: the
-/// kernel sources compiled for the host with one thread per lane) supplies its own definition.
-#ifndef HS_DYNAMIC_LDS
-#define HS_DYNAMIC_LDS(name) extern __shared__ __attribute__((aligned(16))) double name[]
-#endif
 
 /// The value of lane ^ 1 / ^ 2 / ^ 4 through the DPP cross bar (vector moves; a general __shfl_xor is an LDS permute: ~80 cycles of issue per
 /// 32-bit half where these are 4). xor 4 = row_shl:4 for the lanes with bit 2 clear, row_shr:4 for the others.
@@ -61,15 +57,6 @@ HSD double wave_sum_fast(double v) {
   return v;
 }
 
-/// Workgroup barrier that only drains LDS traffic: global loads / stores stay in flight across it (the factorisation
-/// prefetches the next band row while the current step runs; __syncthreads() would wait for vmcnt(0) every step).
-/// wait_lds / wait_vmem: this wave's LDS / global-memory operations have completed (one wave's LDS traffic is in order: between lanes of a
-/// wave this is all the synchronisation an LDS hand-over needs). The CPU emulation harness of the tests supplies its own three.
-#ifndef HS_EMULATED_DEVICE
-HSD void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-HSD void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-HSD void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-#endif
 
 /// Deterministic block sum (fixed butterfly inside each wave, waves combined in index order). Result valid on thread 0.
 HSD double block_sum(double v, double* lds /* >= blockDim/64 */) {

@@ -26,7 +26,7 @@
 #define __shared__ static
 #define __launch_bounds__(...)
 #define HS_DYNAMIC_LDS(name) double* name = hs_emul::dynamic_lds()
-#define HS_EMULATED_DEVICE 1  // kernels_common.hpp leaves lds_barrier / wait_lds / wait_vmem to this header
+#define HS_DEVICE_PRIMITIVES_HPP  // the include guard of csrc/device_primitives.hpp: HS_DYNAMIC_LDS, lds_barrier, wait_lds, wait_vmem are this header's
 
 struct dim3 {
   unsigned x, y, z;

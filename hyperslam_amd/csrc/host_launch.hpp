@@ -334,6 +334,18 @@ int launch_factor(hs_problem* p) {
     T2.mj[1] = MfmaJob{T.Sb, p->d_g2.p, p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, p->d_win.p, mB, -1, mB + w_mid, mB, 1, p->d_Vb.p + size_t(T.np) * (6 * T.bw)};
     T2.join_epoch = ++p->join_epoch;
     T2.bookkeep = p->bookkeep && !nt ? 1 : 0;
+    // Bordered systems on k_band_factor_mx: the forward sweep of the border columns (k_border_forward2, 44 us behind the factorisation at
+    // configs[2]) runs on the side stream WHILE the two ends factor and follows them row by row (MfmaJob::progress, BfJob::progress).
+    // A/B switch 128: behind the factorisation on the main stream.
+    const bool pipe = use_mx && T.nb && p->side && !(T.debug_flags & 128);
+    unsigned* progress = p->d_join.p + kBfFlagBase + 512;  // near U, near W, far U, far W: kProgressStride words apart
+    const unsigned progress_base = unsigned(T2.join_epoch) << 12;
+    if (pipe) {
+      T2.mj[0].progress = progress, T2.mj[1].progress = progress + 2 * kProgressStride;
+      T2.mj[0].progress_base = T2.mj[1].progress_base = progress_base;
+      HIP_TRY(hipEventRecord(p->ev_fork, s));  // (S_pb and the band are final)
+      HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+    }
     if (nt)
       HIP_TRY(run_mfma(T2, 2));
     else if (use_mx)  // trailing window in the accumulators of the f64 matrix cores (kernels_factor_mx.hpp)
@@ -354,8 +366,16 @@ int launch_factor(hs_problem* p) {
       HIP_TRY(p->d_bf_handover.reserve(size_t(n_groups) * 6 * w_mid * kBorderCols + 1));
       const int fwd_threads = std::max(128, 64 * ((6 * w_mid + 63) / 64));  // one lane per pending row
       const int local_rows = (!p->allreduce && !p->rccl_comm && p->world == 1) ? 1 : 0;
-      k_border_forward2<<<dim3(n_groups, 2), fwd_threads, size_t(T.np) * kBorderLd * sizeof(double), s>>>(
-          Tb, BfJob{T.Ub, T.Ubk, m + w_mid, 0}, BfJob{p->d_Ub2.p, p->d_Ubk2.p, mB, 1}, m, 0, local_rows, p->d_bf_handover.p);
+      if (pipe) {  // (+ one wave that polls the factorisation's progress)
+        k_border_forward2<<<dim3(n_groups, 2), fwd_threads + 64, size_t(T.np) * kBorderLd * sizeof(double), p->side>>>(
+            Tb, BfJob{T.Ub, T.Ubk, m + w_mid, 0, progress, progress_base}, BfJob{p->d_Ub2.p, p->d_Ubk2.p, mB, 1, progress + 2 * kProgressStride, progress_base}, m, 0, local_rows,
+            p->d_bf_handover.p);
+        HIP_TRY(hipEventRecord(p->ev_join, p->side));
+        HIP_TRY(hipStreamWaitEvent(s, p->ev_join, 0));
+      } else {
+        k_border_forward2<<<dim3(n_groups, 2), fwd_threads, size_t(T.np) * kBorderLd * sizeof(double), s>>>(
+            Tb, BfJob{T.Ub, T.Ubk, m + w_mid, 0, nullptr, 0}, BfJob{p->d_Ub2.p, p->d_Ubk2.p, mB, 1, nullptr, 0}, m, 0, local_rows, p->d_bf_handover.p);
+      }
       const int n_tiles = (T.nb + kSchurTile - 1) / kSchurTile;
       k_border_schur<<<dim3(n_tiles, n_tiles), kBlock, 0, s>>>(Tb, 0, local_rows, m);  // (rows from the junction on are never skipped)
       HIP_TRY(launch_border_solve(Tb, s));

@@ -592,8 +592,8 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_win.reserve(size_t(6) * vs.bw * (ncb + 1)));
   if (!p->d_join.p) {
     // [0] two-ended factor / sweep hand-over, [1] last-block ticket of the backward sweeps, [2] of k_border_bb, [4 ..] super-block inverses
-    HIP_TRY(p->d_join.reserve(kBfFlagBase + 512));  // (+ one flag per column group of k_border_forward2)
-    HIP_TRY(hipMemsetAsync(p->d_join.p, 0, (kBfFlagBase + 512) * sizeof(unsigned), s));
+    HIP_TRY(p->d_join.reserve(kBfFlagBase + 512 + 4 * kProgressStride));  // (+ one flag per column group of k_border_forward2, + the four progress words of a pipelined sweep)
+    HIP_TRY(hipMemsetAsync(p->d_join.p, 0, (kBfFlagBase + 512 + 4 * kProgressStride) * sizeof(unsigned), s));
     p->join_epoch = 0;
   }
   // split the accumulation over enough workgroups to fill the chip (256 CUs x a few workgroups)
@@ -701,6 +701,7 @@ int prepare(hs_problem* p) {
   // 131072 k_band_factor_mfma (trailing window in f64 MFMA tiles) instead of the VALU factorisation kernels
   // 65536 single-wave register backward sweep (k_band_backward_w) instead of the four-wave LDS sweeps
   // 262144 eliminate / sweep the decoupled block rows of leading constant control points like any other     524288 border Cholesky in LDS
+  // 128 border forward sweep behind the factorisation instead of alongside it
   // 1048576 inertial branch on the main stream    2097152 banded kernels instead of k_dense_factor    4194304 k_landmark<K,4,1> instead of k_landmark_rows
   // 8388608 five finalisation launches for a bordered single shard    16777216 k_commit launch for small windows    33554432 one cost launch per factor type
   // 268435456 backward sweeps one block row per step    536870912 bordered systems one-ended    1073741824 no speculative linearisation at the candidate    67108864 k_commit in every iteration of a speculative solve

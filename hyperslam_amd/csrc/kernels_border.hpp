@@ -400,6 +400,12 @@ struct BfJob {
   const double* Ubk;
   int n_rows;    // block rows this job eliminates (near end: top + middle)
   int reversed;  // row rho of this job is row np - 1 - rho of the system
+  // Pipelined behind the factorisation (k_band_factor_mx on the main stream, this kernel on the side stream): progress[0] / progress[kProgressStride] -
+  // progress_base = leading block rows of this job whose factor row / inverted diagonal block is complete in memory (MfmaJob::progress).
+  // An extra wave of the workgroup (the last one) does nothing but poll the two words, in front of the barrier that ends a step; the factor
+  // is then read with agent-scope loads (lines of the previous iteration's factor may still sit in this XCD's L2). nullptr: the factor is complete.
+  const unsigned* progress;
+  unsigned progress_base;
 };
 constexpr int kBfFlagBase = 4 + 2 * 512;  // behind the super-block flags of the backward sweep (kernels_backward_sb.hpp)
 
@@ -414,6 +420,26 @@ __global__ void __launch_bounds__(kBlock) k_border_forward2(Tables T, BfJob j0, 
   const int n_rows = J.n_rows, nz = 6 * (n_rows + (far ? w_mid : 0));  // rows of z: own rows (+ the middle rows the far end leaves updates on)
   const int c0 = grp * kBorderCols, ncols = min(kBorderCols, nb - c0);
   const int m0 = far ? 0 : min(min(local_rows ? max(j_lo, T.bfwd_start[grp]) : j_lo, n_rows - 1), m_junction - 1);
+  constexpr int D = 4;  // operands of a step are requested D steps ahead (below)
+  const bool pipe = J.progress != nullptr;
+  const bool poller = pipe && tid >= int(blockDim.x) - 64;  // (the launch adds the wave)
+  int seen = 0;  // poller: complete block rows (factor row AND inverted block) at the last look
+  auto await = [&](int rows) {  // poller wave: until the leading `rows` block rows of the factor are complete
+    const int need = min(rows, n_rows);
+    if (seen >= need) return;
+    const long long t0 = wall_clock64();
+    for (;;) {
+      const int a = int(__hip_atomic_load(J.progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - J.progress_base);
+      const int b = int(__hip_atomic_load(J.progress + kProgressStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - J.progress_base);
+      seen = max(0, min(a, b));  // (a word of an earlier launch: negative)
+      if (seen >= need) break;
+      __builtin_amdgcn_s_sleep(16);  // (~0.4 us: a hundred pollers at full rate on the words the factorisation writes delayed its stores)
+      if (wall_clock64() - t0 > 200000000ll) {
+        give_up(T.st);
+        break;
+      }
+    }
+  };
   double* z = smem;
   for (int e = tid; e < nz * kBorderCols; e += blockDim.x) {
     const int rho = e / kBorderCols, c = e % kBorderCols;
@@ -421,21 +447,29 @@ __global__ void __launch_bounds__(kBlock) k_border_forward2(Tables T, BfJob j0, 
     const int row = far ? np - 1 - rho : rho;
     z[rho * kBorderLd + c] = (c < ncols && own) ? T.Spb[size_t(row) * nb + c0 + c] : 0.0;
   }
+  if (poller) await(m0 + D + 2);  // W of row m0, the requests of rows m0 .. m0 + D - 1 (each with W of the row behind it) and the first one of the loop
   __syncthreads();
   __shared__ __attribute__((aligned(16))) double zi[2][6 * kBorderCols];
   const int n_pend = 6 * w_mid;
-  constexpr int D = 4;
   const bool pend = tid < n_pend, diag = tid < 6 * kBorderCols;
   const int da = diag ? tid / kBorderCols : 0, dc = diag ? tid % kBorderCols : 0;
   double ur[D][6], wr[D][6];
   auto request = [&](int m, double* u, double* w) {
+    if (poller) return;  // (its loads would queue in front of the polls)
     const int mm = m < n_rows ? m : 0, mw = m + 1 < n_rows ? m + 1 : 0;
     const double* src = J.Ub + size_t(6 * mm) * ncb + 6 + (pend ? tid : 0);
-#pragma unroll
-    for (int a = 0; a < 6; ++a) u[a] = src[size_t(a) * ncb];
     const double* W = J.Ubk + size_t(mw) * 24;
+    if (pipe) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) w[k] = W[k <= da ? k * 6 - k * (k - 1) / 2 + (da - k) : 0];
+      for (int a = 0; a < 6; ++a) u[a] = __hip_atomic_load(src + size_t(a) * ncb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) w[k] = __hip_atomic_load(W + (k <= da ? k * 6 - k * (k - 1) / 2 + (da - k) : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+#pragma unroll
+      for (int a = 0; a < 6; ++a) u[a] = src[size_t(a) * ncb];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) w[k] = W[k <= da ? k * 6 - k * (k - 1) / 2 + (da - k) : 0];
+    }
   };
   auto diag_solve = [&](int m, const double* w) {  // (wave 0, every lane calls: see k_border_forward)
     double v = 0.0;
@@ -453,7 +487,10 @@ __global__ void __launch_bounds__(kBlock) k_border_forward2(Tables T, BfJob j0, 
     double w0[6];
     const double* W = J.Ubk + size_t(m0) * 24;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) w0[k] = W[k <= da ? k * 6 - k * (k - 1) / 2 + (da - k) : 0];
+    for (int k = 0; k < 6; ++k) {
+      const double* wp = W + (k <= da ? k * 6 - k * (k - 1) / 2 + (da - k) : 0);
+      w0[k] = pipe ? __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *wp;
+    }
     if (tid < 64) diag_solve(m0, w0);
   }
 #pragma unroll
@@ -509,6 +546,7 @@ __global__ void __launch_bounds__(kBlock) k_border_forward2(Tables T, BfJob j0, 
         diag_solve(m + 1, wr[d]);
       }
       request(m + D, ur[d], wr[d]);
+      if (poller) await(m + 1 + D + 2);  // what the next step requests: row m + 1 + D and W of the row behind it
       __syncthreads();
     }
   }

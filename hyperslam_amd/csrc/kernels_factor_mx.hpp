@@ -552,7 +552,12 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
     // A short dependent chain per block row with a whole iteration to run in: it sits next to the MFMA waves of SIMD 0.
     lds_barrier();  // P0
     int p_prev = W - 6;  // ring position of block row it - 1
+    const bool pub = J.progress != nullptr;  // (see the storer)
     for (int it = 0; it < n_iter; ++it) {
+      if (pub && it >= 4) {  // seven stores per iteration (six + this one): all but the last thirteen are done -> the blocks of rows 0 .. it - 4 are in memory
+        wait_vmem_all_but<13>();
+        if (l == 0) __hip_atomic_store(J.progress + kProgressStride, J.progress_base + unsigned(it - 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       if (it >= 1 && l < 6) {  // (six lanes: the return path of the LDS is what every wave queues for at the start of a step)
         // W = U_(ii)^-1, i = it - 1 (upper triangular, packed) for the sweeps: lane cw < 6 solves U w = e_cw. U_ii sits at the pivot's own
         // positions of X_i (upper part), 1 / diag comes from the panel (dinv). Entries below the diagonal go to the pad of the 24-double slot.
@@ -581,8 +586,14 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
           w[a] = t * dv[a];
         }
         double* dst = J.Ubk + size_t(it - 1) * 24;
+        if (pub) {
 #pragma unroll
-        for (int a = 0; a < 6; ++a) dst[a <= cw ? a * 6 - a * (a - 1) / 2 + (cw - a) : 21 + (a >> 1)] = w[a];
+          for (int a = 0; a < 6; ++a)
+            __hip_atomic_store(dst + (a <= cw ? a * 6 - a * (a - 1) / 2 + (cw - a) : 21 + (a >> 1)), w[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+#pragma unroll
+          for (int a = 0; a < 6; ++a) dst[a <= cw ? a * 6 - a * (a - 1) / 2 + (cw - a) : 21 + (a >> 1)] = w[a];
+        }
       }
       p_prev = mx_add(p_prev, 6);
       lds_barrier();
@@ -590,6 +601,10 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
         lds_barrier();
         lds_barrier();
       }
+    }
+    if (pub) {
+      wait_vmem();
+      if (l == 0) __hip_atomic_store(J.progress + kProgressStride, J.progress_base + unsigned(n_steps), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   } else if (hw == 6) {  // ================================ storer ================================
     // What is not on the chain, one iteration after the panel published a block row: factor row and y -> HBM (the inverted diagonal block:
@@ -601,7 +616,15 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
     g[0] = has ? mx_job_rhs(J, pos) : 0.0, g[1] = has ? mx_job_rhs(J, pos + 1) : 0.0;
     lds_barrier();  // P0
     int p_prev = W - 6;  // ring position of block row it - 1
+    // Somebody follows this job row by row (MfmaJob::progress: the forward sweep of the border columns on the side stream): the factor rows
+    // are written with agent-scope stores and the count of complete rows is published late, behind a wait that leaves the stores of the
+    // last iteration in flight (a wait for all of them would put the write-through latency on this wave in every iteration).
+    const bool pub = J.progress != nullptr;
     for (int it = 0; it < n_iter; ++it) {
+      if (pub && it >= 4) {  // eight stores per iteration (6 + y + this one): all but the last fifteen are done -> rows 0 .. it - 4 are in memory
+        wait_vmem_all_but<15>();
+        if (l == 0) __hip_atomic_store(J.progress, J.progress_base + unsigned(it - 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       const double* xp = xring + ((it - 1) & 1) * 6 * LDX;  // X_(it-1) (zeros for it = 0)
       double* rb_next = rowbuf + ((it + 1) & 1) * 6 * LDX;
       const double* stg = stage + (it & 1) * 6 * LDX;
@@ -628,8 +651,13 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
         const int c = mx_sub(pos, p_prev);  // band offset (even)
         if (has && c < ncb) {
           double* dst = J.Ub + size_t(6 * i) * ncb + c;
+          if (pub) {
 #pragma unroll
-          for (int a = 0; a < 6; ++a) *reinterpret_cast<double2*>(dst + a * ncb) = x[a];
+            for (int a = 0; a < 6; ++a) store_agent_b128(dst + a * ncb, x[a]);
+          } else {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) *reinterpret_cast<double2*>(dst + a * ncb) = x[a];
+          }
         }
         if (l < 6) {
           double yl = yv[0];
@@ -651,6 +679,10 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
         lds_barrier();  // merge done
         lds_barrier();  // panel(m) done
       }
+    }
+    if (pub) {
+      wait_vmem();
+      if (l == 0) __hip_atomic_store(J.progress, J.progress_base + unsigned(n_steps), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (J.dump) {  // right-hand sides of block rows n + 2 .. of the trailing window
       const int dm = 6 * (bw - 1), c = mx_sub(pos, (6 * n_steps) % W);

@@ -75,6 +75,8 @@ struct FactorJob {
   int merge_at;       // job 0, two-ended mode: first block row of the middle part (-1: none)
 };
 
+constexpr int kProgressStride = 32;  // unsigned words between the progress words of a job (MfmaJob::progress): a cache line each
+
 /// One job of k_band_factor_mfma (kernels_factor_mfma.hpp).
 struct MfmaJob {
   const double* L;   // lower-band rows in this job's ordering: row np-1-sigma of the OTHER ordering's upper band array, columns reversed
@@ -89,6 +91,11 @@ struct MfmaJob {
   int zero_from;     // job 1, two-ended: pairs with both block rows >= zero_from enter as zeros (INT_MAX: none)
   int dump;          // job 1, two-ended: hand the trailing window over at the end
   const double* zero;  // a double 0.0 in device memory: source of entries that enter as zeros (no select on loaded values)
+  // Bordered systems: k_border_forward2 sweeps the border columns WHILE this job factors (side stream). progress[0] / progress[kProgressStride] =
+  // progress_base + number of leading block rows whose factor row / inverted diagonal block is complete in memory at agent scope (the rows
+  // are then written with agent-scope stores). nullptr: nobody follows.
+  unsigned* progress;
+  unsigned progress_base;
 };
 
 struct Tables {

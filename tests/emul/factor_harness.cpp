@@ -81,7 +81,7 @@ int main(int argc, char** argv) {
   std::vector<double> Ub(size_t(np) * ncb, 0.0), Ubk(size_t(24) * n_blk, 0.0), yb(np, 0.0), Ub2 = Ub, Ubk2 = Ubk, yb2 = yb;
   std::vector<double> win(size_t(6 * w_mid) * (ncb + 1), 0.0), xpart(8 * 1024, 0.0);
   DevState st{};
-  std::vector<unsigned> join_flag(kBfFlagBase + 512, 0u);  // (prepare(): junction word, super-block flags of the sweeps, one flag per column group of k_border_forward2)
+  std::vector<unsigned> join_flag(kBfFlagBase + 512 + 4 * kProgressStride, 0u);  // (prepare(): junction word, super-block flags of the sweeps, one flag per column group of k_border_forward2)
   Tables T{};
   T.np = np, T.bw = bw, T.st = &st, T.join_flag = join_flag.data(), T.join_epoch = 1, T.xpart = xpart.data();
   const size_t la_lds = (size_t(42) * (ncb + 2) + size_t(np) + 48) * sizeof(double);  // launch_factor
@@ -93,6 +93,10 @@ int main(int argc, char** argv) {
     T.fj[1] = FactorJob{Sb2.data(), g2.data(), Ub2.data(), Ubk2.data(), yb2.data(), win.data(), mB, -1};
     T.mj[0] = MfmaJob{Sb2.data(), g.data(), Ub.data(), Ubk.data(), yb.data(), win.data(), m + w_mid, m, m + w_mid, INT_MAX, 0, &zero};
     T.mj[1] = MfmaJob{Sb.data(), g2.data(), Ub2.data(), Ubk2.data(), yb2.data(), win.data(), mB, -1, mB + w_mid, mB, 1, &zero};
+    if (variant == 5 && nb > 0) {  // launch_factor: a bordered system on k_band_factor_mx publishes its progress for the forward sweep of the border columns
+      T.mj[0].progress = join_flag.data() + kBfFlagBase + 512, T.mj[1].progress = T.mj[0].progress + 2 * kProgressStride;
+      T.mj[0].progress_base = T.mj[1].progress_base = 7u << 12;
+    }
   } else {
     T.fj[0] = FactorJob{Sb.data(), g.data(), Ub.data(), Ubk.data(), yb.data(), nullptr, n_blk, -1};
     T.mj[0] = MfmaJob{Sb2.data(), g.data(), Ub.data(), Ubk.data(), yb.data(), nullptr, n_blk, -1, n_blk, INT_MAX, 0, &zero};
@@ -139,9 +143,13 @@ int main(int argc, char** argv) {
     if (two_ended) {
       Tb.ybuf2 = yb2.data(), Tb.y_split = 6 * (m + w_mid);
       Tb.join_epoch = 3;
-      hs_emul::launch(dim3(n_groups, 2), dim3(fwd_threads), size_t(np) * kBorderLd * sizeof(double), [&] {
-        k_border_forward2(Tb, BfJob{Ub.data(), Ubk.data(), m + w_mid, 0}, BfJob{Ub2.data(), Ubk2.data(), mB, 1}, m, 0, 1, handover.data());
+      // (k_band_factor_mx: the sweep follows the factorisation's progress words — here the factorisation has finished; + the polling wave)
+      const unsigned* prog = variant == 5 ? T.mj[0].progress : nullptr;
+      hs_emul::launch(dim3(n_groups, 2), dim3(fwd_threads + (prog ? 64 : 0)), size_t(np) * kBorderLd * sizeof(double), [&] {
+        k_border_forward2(Tb, BfJob{Ub.data(), Ubk.data(), m + w_mid, 0, prog, 7u << 12}, BfJob{Ub2.data(), Ubk2.data(), mB, 1, prog ? prog + 2 * kProgressStride : nullptr, 7u << 12}, m, 0, 1,
+                          handover.data());
       });
+      if (prog && (prog[0] != (7u << 12) + unsigned(m + w_mid) || prog[kProgressStride] != prog[0] || prog[2 * kProgressStride] != (7u << 12) + unsigned(mB) || prog[3 * kProgressStride] != prog[2 * kProgressStride])) return 9;
       hs_emul::launch(dim3(n_tiles, n_tiles), dim3(kBlock), 0, [&] { k_border_schur(Tb, 0, 1, m); });
     } else {
       hs_emul::launch(dim3(n_groups), dim3(fwd_threads), size_t(np) * kBorderLd * sizeof(double), [&] { k_border_forward(Tb, 0, 1); });

@@ -262,3 +262,15 @@ def test_bordered_solve_against_numpy(n_blk, bw, n_b, two_ended, harness, tmp_pa
     M = banded_spd(rng, n_blk, bw)
     g = rng.standard_normal(6 * n_blk)
     run(harness, tmp_path, M, g, bw, two_ended, border=bordered(rng, M, n_b, n_blk))
+
+
+@pytest.mark.parametrize("n_blk,bw,n_b", [(64, 16, 57), (40, 10, 99), (60, 15, 21)])
+def test_mx_bordered_solve_against_numpy(n_blk, bw, n_b, harness, tmp_path):
+    """The same chain behind k_band_factor_mx, which publishes the count of complete block rows per end (MfmaJob::progress) for a forward
+    sweep of the border columns that runs next to it on the device (k_border_forward2 with its polling wave, BfJob::progress). Here the
+    factorisation has finished when the sweep starts: the words must hold the final counts (harness exit code 9) and the sweep must read
+    the factor through them."""
+    rng = np.random.default_rng(5 * n_blk + bw + n_b)
+    M = banded_spd(rng, n_blk, bw)
+    g = rng.standard_normal(6 * n_blk)
+    run(harness, tmp_path, M, g, bw, True, variant=5, border=bordered(rng, M, n_b, n_blk))

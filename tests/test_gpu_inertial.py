@@ -89,6 +89,16 @@ def test_two_ended_bordered_solve(order, n_cp, hip, oracle, monkeypatch):
     _, s1, cp1, lm1, g1, bg1, ba1 = run(hip)
     assert [it["step_is_successful"] for it in s1["iterations"]] == [it["step_is_successful"] for it in sg["iterations"]]
     assert rel(cpg, cp1) < 1e-8 and rel(lmg, lm1) < 1e-8 and rel(gg, g1) < 1e-8 and rel(bgg, bg1) < 1e-7 and rel(bag, ba1) < 1e-7
+    # The forward sweep of the border columns runs NEXT TO the factorisation and follows its progress words (round 5: k_border_forward2 on
+    # the side stream, MfmaJob::progress); A/B switch 128 runs it behind the factorisation. Same arithmetic on the same values: every run of
+    # either arrangement must give the same bits — a sweep that read a factor row before it was complete would not.
+    monkeypatch.setenv("HS_DEBUG_FLAGS", "128")
+    _, s2, cp2, lm2, g2, bg2, ba2 = run(hip)
+    monkeypatch.setenv("HS_DEBUG_FLAGS", "0")
+    for _ in range(4):
+        _, s3, cp3, lm3, g3, bg3, ba3 = run(hip)
+        assert np.array_equal(cp3, cp2) and np.array_equal(lm3, lm2) and np.array_equal(g3, g2) and np.array_equal(bg3, bg2) and np.array_equal(ba3, ba2)
+        assert [it["cost"] for it in s3["iterations"]] == [it["cost"] for it in s2["iterations"]]
 
 
 @pytest.mark.parametrize("gravity_constant", [True, False])

@@ -16,13 +16,6 @@ namespace hs {
 HSD void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 HSD void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 HSD void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-/// 16-byte store at agent scope (sc1: written through to where every XCD of the device sees it — what a relaxed agent-scope atomic store
-/// does for 8 bytes; there is no 16-byte atomic to spell it with).
-HSD void store_agent_b128(double* p, double2 v) {
-  typedef double v2f64 __attribute__((ext_vector_type(2)));
-  const v2f64 r = {v.x, v.y};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(r) : "memory");
-}
 /// All but the N most recently issued global-memory operations of this wave have completed (they complete in issue order).
 template <int N>
 HSD void wait_vmem_all_but() {

@@ -349,8 +349,12 @@ int launch_factor(hs_problem* p) {
     if (nt)
       HIP_TRY(run_mfma(T2, 2));
     else if (use_mx)  // trailing window in the accumulators of the f64 matrix cores (kernels_factor_mx.hpp)
-      if (mx_wide(T.bw))
+      if (mx_wide(T.bw) && pipe)
+        k_band_factor_mx<true, true><<<2, kMxThreads, size_t(kMxLds) * sizeof(double), s>>>(T2);
+      else if (mx_wide(T.bw))
         k_band_factor_mx<true><<<2, kMxThreads, size_t(kMxLds) * sizeof(double), s>>>(T2);
+      else if (pipe)
+        k_band_factor_mx<false, true><<<2, kMxThreads, size_t(kMxLds) * sizeof(double), s>>>(T2);
       else
         k_band_factor_mx<false><<<2, kMxThreads, size_t(kMxLds) * sizeof(double), s>>>(T2);
     else

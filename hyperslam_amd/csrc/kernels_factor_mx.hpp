@@ -456,7 +456,8 @@ HSD void mx_lane_dump(const MxLane& L, const MfmaJob& J, const double* rowbuf, c
   }
 }
 
-template <bool WIDE>  // WIDE: bands of 15 and 16 control points (mx_tiles_step)
+template <bool WIDE, bool PUB = false>  // WIDE: bands of 15 and 16 control points (mx_tiles_step); PUB: publishes its progress (MfmaJob::progress:
+                                         // a compile-time switch — as a run-time one it cost the instance without followers 6 us at configs[1])
 __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
   constexpr int W = kMxW, LDX = kMxLdx;
   HS_DYNAMIC_LDS(smem);
@@ -552,11 +553,13 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
     // A short dependent chain per block row with a whole iteration to run in: it sits next to the MFMA waves of SIMD 0.
     lds_barrier();  // P0
     int p_prev = W - 6;  // ring position of block row it - 1
-    const bool pub = J.progress != nullptr;  // (see the storer)
+    constexpr bool pub = PUB;  // (see the storer)
     for (int it = 0; it < n_iter; ++it) {
-      if (pub && it >= 4) {  // seven stores per iteration (six + this one): all but the last thirteen are done -> the blocks of rows 0 .. it - 4 are in memory
-        wait_vmem_all_but<13>();
-        if (l == 0) __hip_atomic_store(J.progress + kProgressStride, J.progress_base + unsigned(it - 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if constexpr (pub) {  // >= 6 stores per iteration (+ this one): all but the last twelve are done -> the blocks of rows 0 .. it - 4 are in memory
+        if (it >= 4) {
+          wait_vmem_all_but<12>();
+          if (l == 0) __hip_atomic_store(J.progress + kProgressStride, J.progress_base + unsigned(it - 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
       if (it >= 1 && l < 6) {  // (six lanes: the return path of the LDS is what every wave queues for at the start of a step)
         // W = U_(ii)^-1, i = it - 1 (upper triangular, packed) for the sweeps: lane cw < 6 solves U w = e_cw. U_ii sits at the pivot's own
@@ -586,7 +589,7 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
           w[a] = t * dv[a];
         }
         double* dst = J.Ubk + size_t(it - 1) * 24;
-        if (pub) {
+        if constexpr (pub) {
 #pragma unroll
           for (int a = 0; a < 6; ++a)
             __hip_atomic_store(dst + (a <= cw ? a * 6 - a * (a - 1) / 2 + (cw - a) : 21 + (a >> 1)), w[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -602,7 +605,7 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
         lds_barrier();
       }
     }
-    if (pub) {
+    if constexpr (pub) {
       wait_vmem();
       if (l == 0) __hip_atomic_store(J.progress + kProgressStride, J.progress_base + unsigned(n_steps), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -617,13 +620,16 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
     lds_barrier();  // P0
     int p_prev = W - 6;  // ring position of block row it - 1
     // Somebody follows this job row by row (MfmaJob::progress: the forward sweep of the border columns on the side stream): the factor rows
-    // are written with agent-scope stores and the count of complete rows is published late, behind a wait that leaves the stores of the
+    // are written with agent-scope stores (twelve of 8 bytes where the plain path has six of 16) and the count of complete rows is published late, behind a wait that leaves the stores of the
     // last iteration in flight (a wait for all of them would put the write-through latency on this wave in every iteration).
-    const bool pub = J.progress != nullptr;
+    constexpr bool pub = PUB;
     for (int it = 0; it < n_iter; ++it) {
-      if (pub && it >= 4) {  // eight stores per iteration (6 + y + this one): all but the last fifteen are done -> rows 0 .. it - 4 are in memory
-        wait_vmem_all_but<15>();
-        if (l == 0) __hip_atomic_store(J.progress, J.progress_base + unsigned(it - 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if constexpr (pub) {  // >= 12 stores per iteration (the factor row; + y, + this one): all but the last 24 are done -> everything iteration
+                            // it - 3 and the ones before it stored, i.e. rows 0 .. it - 4, is in memory
+        if (it >= 4) {
+          wait_vmem_all_but<24>();
+          if (l == 0) __hip_atomic_store(J.progress, J.progress_base + unsigned(it - 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
       const double* xp = xring + ((it - 1) & 1) * 6 * LDX;  // X_(it-1) (zeros for it = 0)
       double* rb_next = rowbuf + ((it + 1) & 1) * 6 * LDX;
@@ -651,9 +657,13 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
         const int c = mx_sub(pos, p_prev);  // band offset (even)
         if (has && c < ncb) {
           double* dst = J.Ub + size_t(6 * i) * ncb + c;
-          if (pub) {
+          if constexpr (pub) {
 #pragma unroll
-            for (int a = 0; a < 6; ++a) store_agent_b128(dst + a * ncb, x[a]);
+            for (int a = 0; a < 6; ++a) {  // (8-byte atomics: there is no 16-byte one, and an inline-asm dwordx4 store is invisible to the
+                                           //  compiler's hazard handling — a later write of its data registers corrupted rows on the device)
+              __hip_atomic_store(dst + a * ncb, x[a].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(dst + a * ncb + 1, x[a].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
           } else {
 #pragma unroll
             for (int a = 0; a < 6; ++a) *reinterpret_cast<double2*>(dst + a * ncb) = x[a];
@@ -680,7 +690,7 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
         lds_barrier();  // panel(m) done
       }
     }
-    if (pub) {
+    if constexpr (pub) {
       wait_vmem();
       if (l == 0) __hip_atomic_store(J.progress, J.progress_base + unsigned(n_steps), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

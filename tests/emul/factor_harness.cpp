@@ -122,7 +122,12 @@ int main(int argc, char** argv) {
   else if (variant == 4)  // (the dense kernel writes the decoupled rows with extra workgroups of its own launch)
     hs_emul::launch(dim3(1 + f0), dim3(kDenseThreads), (size_t(12) * (ncb + 8) + size_t(32) * (n_blk - f0)) * sizeof(double), [&] { k_dense_factor(T, f0); });
   else if (variant == 5)
-    hs_emul::launch(grid, dim3(kMxThreads), size_t(kMxLds) * sizeof(double), [&] { mx_wide(bw) ? k_band_factor_mx<true>(T) : k_band_factor_mx<false>(T); },
+    hs_emul::launch(grid, dim3(kMxThreads), size_t(kMxLds) * sizeof(double), [&] {
+      if (T.mj[0].progress)  // (launch_factor: the instance that publishes its progress)
+        mx_wide(bw) ? k_band_factor_mx<true, true>(T) : k_band_factor_mx<false, true>(T);
+      else
+        mx_wide(bw) ? k_band_factor_mx<true>(T) : k_band_factor_mx<false>(T);
+    },
                     two_ended ? far_first : std::vector<unsigned>{});
   else if (ncw == 3)
     hs_emul::launch(grid, dim3(la_threads(3)), la_lds, [&] { k_band_factor_la<1, 3>(T); }, two_ended ? far_first : std::vector<unsigned>{});

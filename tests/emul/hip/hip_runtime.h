@@ -196,7 +196,6 @@ inline void wait_lds() { hs_emul::block().wave_barrier[threadIdx.x >> 6].arrive_
 inline void wait_vmem() {}
 template <int N>
 inline void wait_vmem_all_but() {}
-inline void store_agent_b128(double* p, double2 v) { p[0] = v.x, p[1] = v.y; }
 inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 #define __HIP_MEMORY_SCOPE_AGENT 0

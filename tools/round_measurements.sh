@@ -30,4 +30,12 @@ python bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline > $out/${tag}
   ./replay_oracle 6.0 1 4 2>/dev/null | tail -1 ) > $out/${tag}_replay.txt 2>&1
 ( cd hyperslam_amd/host; for a in "6.0 1 4" "6.0 0 4"; do echo "replay $a"; HS_HOST_TIMING=1 ./replay $a 2>&1 >/dev/null | grep "host timing"; done ) > $out/${tag}_replay_host_split.txt 2>&1
 for a in "3.6 0 4" "3.6 1 4" "6.0 1 6" "6.0 1 4"; do hyperslam_amd/host/replay_lockstep hyperslam_amd/libhyperslam_hip.so $a > $out/${tag}_lockstep_$(echo $a | tr ' .' '__').jsonl 2>&1; done
+# round 5 additions: oracle(double) / oracle(long double) / HIP from identical tables; the pipelined border sweep against the sequential one
+# (bit identity under repetition, configs[2] timing); the fused build on window-wide bands against the record path on the replays
+python tools/lockstep_three_way.py 3.6 0 4 --out $out/${tag}_three_way_3_6_0_4.txt > /dev/null 2>&1
+python tools/stress_pipelined_sweep.py 40 > $out/${tag}_stress_pipelined_sweep.txt 2>&1
+{ for i in 1 2; do echo "pipelined (default)"; HS_STAGE_TIMING=0 python tools/time_config.py 2 | head -1; echo "sweep behind the factorisation (HS_DEBUG_FLAGS=128)"; HS_DEBUG_FLAGS=128 HS_STAGE_TIMING=0 python tools/time_config.py 2 | head -1; done; } > $out/${tag}_config2_sweep_ab.txt 2>&1
+( cd hyperslam_amd/host
+  for a in "6.0 0 4" "6.0 1 4" "6.0 1 6"; do for pth in narrow default; do echo "replay $a build path: $pth (narrow = record path above 256 window tiles, round 4's rule)"
+    if [ $pth = narrow ]; then export HS_BUILD_PATH=narrow; else unset HS_BUILD_PATH; fi; ./replay $a 2>/dev/null | tail -1; ./replay $a 2>/dev/null | tail -1; done; done; unset HS_BUILD_PATH ) > $out/${tag}_replay_build_path_ab.txt 2>&1
 echo done

@@ -337,7 +337,13 @@ int launch_factor(hs_problem* p) {
     // Bordered systems on k_band_factor_mx: the forward sweep of the border columns (k_border_forward2, 44 us behind the factorisation at
     // configs[2]) runs on the side stream WHILE the two ends factor and follows them row by row (MfmaJob::progress, BfJob::progress).
     // A/B switch 128: behind the factorisation on the main stream.
-    const bool pipe = use_mx && T.nb && p->side && !(T.debug_flags & 128);
+    // Only while the sweep's workgroups — which spin on the factorisation's progress — cannot crowd the factorisation's two workgroups out
+    // of the device (they would wait for each other until the 2 s give-up): at most half of the CUs minus a reserve, counting what one CU
+    // holds of them by LDS (another process may run the same pair on this device: the world-2-on-one-GPU tests).
+    const size_t fwd_lds = size_t(T.np) * kBorderLd * sizeof(double);
+    const int fwd_per_cu = std::max(1, int(std::min<size_t>((size_t(160) * 1024) / std::max<size_t>(fwd_lds, 1), 8)));
+    const int fwd_cus = (2 * ((T.nb + kBorderCols - 1) / kBorderCols) + fwd_per_cu - 1) / fwd_per_cu;
+    const bool pipe = use_mx && T.nb && p->side && fwd_cus <= p->n_cu / 2 - 8 && !(T.debug_flags & 128);
     unsigned* progress = p->d_join.p + kBfFlagBase + 512;  // near U, near W, far U, far W: kProgressStride words apart
     const unsigned progress_base = unsigned(T2.join_epoch) << 12;
     if (pipe) {

@@ -252,11 +252,12 @@ inline void launch(dim3 grid, dim3 block_dim, size_t lds_bytes, const std::funct
   threads.reserve(n);
   for (int t = 0; t < n; ++t)
     threads.emplace_back([&, t] {
+      for (unsigned bz = 0; bz < grid.z; ++bz)
       for (unsigned by = 0; by < grid.y; ++by)
         for (unsigned ix = 0; ix < grid.x; ++ix) {
           frame.arrive_and_wait();  // every lane has left the previous workgroup
           if (t == 0) {
-            blockIdx = dim3(order.empty() ? ix : order[ix], by, 0);
+            blockIdx = dim3(order.empty() ? ix : order[ix], by, bz);
             b.barrier.reset(n);
             for (int w = 0; w < (n + 63) / 64; ++w) b.wave_barrier[w].reset(n - 64 * w < 64 ? n - 64 * w : 64);
           }

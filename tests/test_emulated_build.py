@@ -133,7 +133,7 @@ def test_emulated_fused_build_constants_and_radius(harness, oracle):
 
 
 def test_emulated_fused_build_is_reproducible(harness):
-    w = synthetic.small_visual(order=4, n_cp=14, n_landmarks=40, obs_pairs=3)
+    w = synthetic.small_visual(order=4, n_cp=12, n_landmarks=24, obs_pairs=3)
     a, b = run_emulated_build(harness, w), run_emulated_build(harness, w)
     assert np.array_equal(a["S"], b["S"]) and np.array_equal(a["g"], b["g"]) and np.array_equal(a["Y"], b["Y"]) and a["cost"] == b["cost"]
 

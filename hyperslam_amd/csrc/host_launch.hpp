@@ -278,9 +278,10 @@ void launch_backward_w(const Tables& T, const BackJob& j0, const BackJob& j1, in
 /// Dense Cholesky of the border Schur complement + solve for the border unknowns (one workgroup).
 static hipError_t launch_border_solve(const Tables& T, hipStream_t s) {
   if (T.nb + 1 <= 128 && !(T.debug_flags & 524288)) {  // trailing matrix in registers (A/B switch 524288: the LDS version)
-    const int R = std::max(4, (T.nb + 1 + 15) / 16), N = 16 * R;
+    const int R = std::max(3, (T.nb + 1 + 15) / 16), N = 16 * R;
     const size_t lds = (size_t(4) * N + size_t(T.nb) * (N + 1) + T.nb) * sizeof(double);
     switch (R) {
+      case 3: k_border_solve_reg<3><<<1, kBlock, lds, s>>>(T); break;
       case 4: k_border_solve_reg<4><<<1, kBlock, lds, s>>>(T); break;
       case 5: k_border_solve_reg<5><<<1, kBlock, lds, s>>>(T); break;
       case 6: k_border_solve_reg<6><<<1, kBlock, lds, s>>>(T); break;
@@ -606,7 +607,7 @@ static void warm_kernels(int device) {
       reinterpret_cast<const void*>(&k_band_factor<2>), reinterpret_cast<const void*>(&k_band_factor_la<1, 3>), reinterpret_cast<const void*>(&k_band_factor_la<1, 4>),
       reinterpret_cast<const void*>(&k_band_backward), reinterpret_cast<const void*>(&k_band_backward_sb), reinterpret_cast<const void*>(&k_border_forward),
       reinterpret_cast<const void*>(&k_border_forward2),
-      reinterpret_cast<const void*>(&k_border_schur), reinterpret_cast<const void*>(&k_border_solve), reinterpret_cast<const void*>(&k_border_solve_reg<4>),
+      reinterpret_cast<const void*>(&k_border_schur), reinterpret_cast<const void*>(&k_border_solve), reinterpret_cast<const void*>(&k_border_solve_reg<3>), reinterpret_cast<const void*>(&k_border_solve_reg<4>),
       reinterpret_cast<const void*>(&k_border_solve_reg<5>), reinterpret_cast<const void*>(&k_border_solve_reg<6>), reinterpret_cast<const void*>(&k_border_solve_reg<7>),
       reinterpret_cast<const void*>(&k_border_solve_reg<8>), reinterpret_cast<const void*>(&k_border_apply), reinterpret_cast<const void*>(&k_backsub_retract),
       reinterpret_cast<const void*>(&k_pack_decision), reinterpret_cast<const void*>(&k_decide), reinterpret_cast<const void*>(&k_commit),

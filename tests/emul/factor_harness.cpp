@@ -161,10 +161,12 @@ int main(int argc, char** argv) {
       hs_emul::launch(dim3(n_tiles, n_tiles), dim3(kBlock), 0, [&] { k_border_schur(Tb, 0, 1, n_blk); });
     }
     {  // launch_border_solve
-      const int R = std::max(4, (nb + 1 + 15) / 16), N = 16 * R;
+      const int R = std::max(3, (nb + 1 + 15) / 16), N = 16 * R;
       const size_t lds = (size_t(4) * N + size_t(nb) * (N + 1) + nb) * sizeof(double);
       if (nb + 1 > 128)
         hs_emul::launch(dim3(1), dim3(kBlock), (size_t(nb + 1) * (nb + 1) + nb) * sizeof(double), [&] { k_border_solve(Tb); });
+      else if (R == 3)
+        hs_emul::launch(dim3(1), dim3(kBlock), lds, [&] { k_border_solve_reg<3>(Tb); });
       else if (R == 4)
         hs_emul::launch(dim3(1), dim3(kBlock), lds, [&] { k_border_solve_reg<4>(Tb); });
       else if (R == 5)

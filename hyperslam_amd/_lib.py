@@ -140,7 +140,9 @@ ABI_SYMBOLS = ["hs_" + n for n in list(_SIGNATURES) + list(_PRODUCT_ONLY)]
 class Library:
     """A loaded C-ABI library with typed entry points (attribute access without the prefix)."""
 
-    def __init__(self, path: str, prefix: str):
+    def __init__(self, path: str, prefix: str, strict: bool = True):
+        """strict=False: a library that exports only part of the ABI (oracle/liboracle_ld.so, the long-double referee of the tests and
+        tools/fuzz_parity.py): the entry points it lacks are simply not bound."""
         if not os.path.exists(path):
             raise FileNotFoundError(
                 f"{path} not found — build it first (python -c 'import __graft_entry__ as g; g.build()'); "
@@ -151,6 +153,8 @@ class Library:
         if prefix == "hs_":
             table.update(_PRODUCT_ONLY)
         for name, (res, args) in table.items():
+            if not strict and not hasattr(self.cdll, prefix + name):
+                continue
             fn = getattr(self.cdll, prefix + name)
             fn.restype, fn.argtypes = res, args
             setattr(self, name, fn)

@@ -1,6 +1,6 @@
 """Randomised parity sweep, HIP against the oracle (TEST TOOLING; the oracle is the checker): window shapes the fixed tests do not enumerate —
 spline order, window length, track span (band width from 4 to window-wide), observation density, bearing / pixel factors, with and without an IMU,
-frozen prefixes, constant landmarks, pose priors, rotation- / translation-only windows. Per case: cost 1e-11, reduced normal equations 1e-9, 4-iteration trajectory 1e-6 (the bars of
+frozen prefixes, constant landmarks, pose priors, rotation- / translation-only windows. Per case: cost 1e-11, residuals and local Jacobians of every residual block (sensor blocks included) 1e-9, reduced normal equations 1e-9, 4-iteration trajectory 1e-6 (the bars of
 tests/test_gpu_edge_cases.py::compare). Prints one line per case and the failures at the end; exit code = number of failures.
 usage (GPU box): python tools/fuzz_parity.py [cases=60] [seed=1]"""
 import os
@@ -63,16 +63,27 @@ def main():
             with ha.Problem(w, lib=hip) as g, ha.Problem(w, lib=oracle) as c:
                 bw = g.lib.band_blocks(g.h)
                 cg, cc = g.cost(), c.cost()
+                lin = 0.0  # residuals and Ceres-local Jacobians of every factor type present, sensor blocks included (hs_linearize), relative per array
+                for ftype in range(4):
+                    if g.num_residuals(ftype) == 0:
+                        continue
+                    robust = bool((ftype + len(w.landmarks)) & 1)
+                    lg, lc = g.linearize(ftype, robustify=robust, sensor_blocks=True), c.linearize(ftype, robustify=robust, sensor_blocks=True)
+                    for name in lc:
+                        if lc[name].dtype.kind == "i":
+                            lin = max(lin, float(np.any(lg[name] != lc[name])))
+                        elif lc[name].size:
+                            lin = max(lin, float(np.abs(lg[name] - lc[name]).max() / max(np.abs(lc[name]).max(), 1e-300)))
                 Sg, gg = g.reduced_system(1e4)
                 Sc, gc = c.reduced_system(1e4)
                 (sg, xg), (sc, xc) = end_points(g, w), end_points(c, w)
-                errs = dict(cost=abs(cg - cc) / max(cc, 1e-300), S=rel(Sg, Sc), g=rel(gg, gc), final=abs(sg["final_cost"] - sc["final_cost"]) / abs(sc["final_cost"]),
+                errs = dict(cost=abs(cg - cc) / max(cc, 1e-300), lin=lin, S=rel(Sg, Sc), g=rel(gg, gc), final=abs(sg["final_cost"] - sc["final_cost"]) / abs(sc["final_cost"]),
                             x=rel(xg, xc))
                 same = (sg["num_iterations"] == sc["num_iterations"] and sg["termination"] == sc["termination"] and
                         [i["step_is_successful"] for i in sg["iterations"]] == [i["step_is_successful"] for i in sc["iterations"]])
-                ok = errs["cost"] < 1e-11 and errs["S"] < 1e-9 and errs["g"] < 1e-9 and same and errs["final"] < 1e-6 and errs["x"] < 1e-6
+                ok = errs["cost"] < 1e-11 and errs["lin"] < 1e-9 and errs["S"] < 1e-9 and errs["g"] < 1e-9 and same and errs["final"] < 1e-6 and errs["x"] < 1e-6
                 note = ""
-                if not ok and errs["cost"] < 1e-11 and errs["S"] < 1e-9 and errs["g"] < 1e-9 and same:
+                if not ok and errs["cost"] < 1e-11 and errs["lin"] < 1e-9 and errs["S"] < 1e-9 and errs["g"] < 1e-9 and same:
                     # Same normal equations, same decisions, end points apart: an ill-conditioned window (control points no residual reaches, held by
                     # the LM damping alone) amplifies the rounding of BOTH sides. The long-double oracle is the referee: the case passes if the HIP end
                     # points are within an order of magnitude of the double oracle's own distance from it (+ 1e-7): on such windows — islands of

@@ -45,9 +45,15 @@ def attach_allreduce(problem, dist, group=None, device_memory=None):
     comm_device = device if backend == "nccl" else torch.device("cpu")
     # same band width everywhere
     problem._check(problem.lib.set_shard(problem.h, rank, world, 0), "set_shard")
-    bw = torch.tensor([problem.lib.band_blocks(problem.h)], dtype=torch.int64, device=comm_device)
+    # (max and min in one collective: a shard the library refuses — hs_band_blocks < 0, e.g. a track beyond the band limit that only this
+    #  rank's landmarks reach — must stop EVERY rank here; a rank that raised on its own would leave the others waiting in the first exchange)
+    local_bw = int(problem.lib.band_blocks(problem.h))
+    bw = torch.tensor([local_bw, -local_bw], dtype=torch.int64, device=comm_device)
     dist.all_reduce(bw, op=dist.ReduceOp.MAX, group=group)
-    problem._check(problem.lib.set_shard(problem.h, rank, world, int(bw.item())), "set_shard")
+    if -int(bw[1].item()) < 0:
+        raise RuntimeError("sharded window refused (invalid on at least one rank): " +
+                           (problem.lib.last_error(problem.h).decode() if local_bw < 0 else "another rank's shard"))
+    problem._check(problem.lib.set_shard(problem.h, rank, world, int(bw[0].item())), "set_shard")
     views = {}
 
     def hook(_user, ptr, count, stream):
@@ -89,9 +95,15 @@ def attach_rccl(problem, dist, group=None):
     backend = dist.get_backend(group)
     comm_device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
     problem._check(problem.lib.set_shard(problem.h, rank, world, 0), "set_shard")
-    bw = torch.tensor([problem.lib.band_blocks(problem.h)], dtype=torch.int64, device=comm_device)
+    # (max and min in one collective: a shard the library refuses — hs_band_blocks < 0, e.g. a track beyond the band limit that only this
+    #  rank's landmarks reach — must stop EVERY rank here; a rank that raised on its own would leave the others waiting in the first exchange)
+    local_bw = int(problem.lib.band_blocks(problem.h))
+    bw = torch.tensor([local_bw, -local_bw], dtype=torch.int64, device=comm_device)
     dist.all_reduce(bw, op=dist.ReduceOp.MAX, group=group)
-    problem._check(problem.lib.set_shard(problem.h, rank, world, int(bw.item())), "set_shard")
+    if -int(bw[1].item()) < 0:
+        raise RuntimeError("sharded window refused (invalid on at least one rank): " +
+                           (problem.lib.last_error(problem.h).decode() if local_bw < 0 else "another rank's shard"))
+    problem._check(problem.lib.set_shard(problem.h, rank, world, int(bw[0].item())), "set_shard")
     # Every step is agreed on collectively so that a rank-local failure (librccl not loadable, communicator bootstrap refused)
     # cannot leave the other ranks waiting: the function returns the same boolean on every rank.
     buf = C.create_string_buffer(128)

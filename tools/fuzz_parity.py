@@ -1,6 +1,7 @@
 """Randomised parity sweep, HIP against the oracle (TEST TOOLING; the oracle is the checker): window shapes the fixed tests do not enumerate —
 spline order, window length, track span (band width from 4 to window-wide), observation density, bearing / pixel factors, with and without an IMU,
-frozen prefixes, constant landmarks, pose priors, rotation- / translation-only windows. Per case: cost 1e-11, residuals and local Jacobians of every residual block (sensor blocks included) 1e-9, reduced normal equations 1e-9, 4-iteration trajectory 1e-6 (the bars of
+frozen prefixes, constant landmarks, pose priors, rotation- / translation-only windows. Per case: cost 1e-11, residuals and local Jacobians of every residual block (sensor blocks included), trajectory samples with derivatives and stereo
+triangulation 1e-9 (`lin`), reduced normal equations 1e-9, 4-iteration trajectory 1e-6 (the bars of
 tests/test_gpu_edge_cases.py::compare). Prints one line per case and the failures at the end; exit code = number of failures.
 usage (GPU box): python tools/fuzz_parity.py [cases=60] [seed=1]"""
 import os
@@ -74,6 +75,17 @@ def main():
                             lin = max(lin, float(np.any(lg[name] != lc[name])))
                         elif lc[name].size:
                             lin = max(lin, float(np.abs(lg[name] - lc[name]).max() / max(np.abs(lc[name]).max(), 1e-300)))
+                # trajectory samples with both derivatives (hs_sample_trajectory) and the front half of process(VisualTracks) (hs_process_tracks) on this window
+                lo, hi = w.valid_range()
+                srng = np.random.default_rng(len(w.landmarks) + 1000 * w.n_cp)
+                st = srng.uniform(lo, hi - 1e-6, 24)
+                for a_, b_ in zip(g.sample_trajectory(st, derivatives=True), c.sample_trajectory(st, derivatives=True)):
+                    lin = max(lin, float(np.abs(a_ - b_).max() / max(np.abs(b_).max(), 1e-300)))
+                if len(w.cam_T_bs) >= 2:
+                    px0 = srng.uniform([50, 50], [700, 430], (16, 2))
+                    px1 = px0 - np.c_[srng.uniform(2, 40, 16), srng.uniform(-0.5, 0.5, 16)]
+                    for a_, b_ in zip(g.process_tracks(float(st[0]), px0, px1), c.process_tracks(float(st[0]), px0, px1)):
+                        lin = max(lin, float(np.abs(a_ - b_).max() / max(np.abs(b_).max(), 1e-300)))
                 Sg, gg = g.reduced_system(1e4)
                 Sc, gc = c.reduced_system(1e4)
                 (sg, xg), (sc, xc) = end_points(g, w), end_points(c, w)

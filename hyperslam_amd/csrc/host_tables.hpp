@@ -547,9 +547,12 @@ int prepare(hs_problem* p) {
   }
   p->nb_pri = (n_pri + kBlock - 1) / kBlock;
   p->nb_cp = std::max((p->n_cp + kBlock - 1) / kBlock, 1);
-  HIP_TRY(p->d_cost_part.reserve(p->nb_vis + p->nb_pri + (n_ine + kBlock - 1) / kBlock + 1));
+  // (one slot per workgroup of the kernels that write them: the inertial ones take kInertialBlock = 64 residuals each — sized by kBlock = 256 the
+  //  table was four times too short for them, an out-of-bounds write of a few hundred bytes that the allocator's granularity hid until a
+  //  randomised sweep of large windows hit a page boundary, tools/fuzz_parity.py large)
+  HIP_TRY(p->d_cost_part.reserve(p->nb_vis + p->nb_pri + p->nb_ine + 1));
   HIP_TRY(p->d_ch_gmax.reserve(size_t(p->nb_vis) + 1));
-  HIP_TRY(p->d_cand_part.reserve(p->nb_vis + p->nb_pri + (n_ine + kBlock - 1) / kBlock + 1));
+  HIP_TRY(p->d_cand_part.reserve(p->nb_vis + p->nb_pri + p->nb_ine + 1));
   const int nb_norm = p->nb_cp;
   HIP_TRY(p->d_norm_part.reserve(2 * size_t(nb_norm)));
   const int nbd = p->has_imu ? 6 * p->n_bias + 2 : 0;
@@ -670,6 +673,8 @@ int prepare(hs_problem* p) {
   T.scale_p = p->d_scale_p.p, T.Sb = p->d_Sb.p, T.Ub = p->d_Ub.p, T.Ubk = p->d_Ubk.p, T.g_s = p->d_g_s.p, T.g_full = p->d_g_full.p, T.D2p = p->d_D2p.p, T.gabs = p->d_gabs.p;
   T.step_p = p->d_step_p.p, T.delta_p = p->d_delta_p.p;
   T.cost_part = p->d_cost_part.p, T.cand_part = p->d_cand_part.p, T.n_cost_part = p->nb_vis + p->nb_pri + p->nb_ine;
+  if (size_t(T.n_cost_part) > p->d_cost_part.cap || size_t(T.n_cost_part) > p->d_cand_part.cap)  // (the tables are sized above from the same three grid sizes)
+    HS_FAIL(HS_ERR_DEVICE, "internal: cost partial tables shorter than the grids that write them");
   T.norm_part = p->d_norm_part.p, T.n_norm_part = nb_norm;
   T.xbuf = p->d_xbuf.p;
   T.xpart = p->d_xpart.p, T.gravity_part = p->d_gravity_part.p, T.segP = p->d_segP.p, T.grpQ = p->d_grpQ.p, T.gw_ptr = p->d_gw_ptr.p, T.gw_cf = p->d_gw_cf.p, T.sw_ptr = p->d_sw_ptr.p, T.sw_seg = p->d_sw_seg.p;

@@ -3,7 +3,7 @@ spline order, window length, track span (band width from 4 to window-wide), obse
 frozen prefixes, constant landmarks, pose priors, rotation- / translation-only windows. Per case: cost 1e-11, residuals and local Jacobians of every residual block (sensor blocks included), trajectory samples with derivatives and stereo
 triangulation 1e-9 (`lin`), reduced normal equations 1e-9, 4-iteration trajectory 1e-6 (the bars of
 tests/test_gpu_edge_cases.py::compare). Prints one line per case and the failures at the end; exit code = number of failures.
-usage (GPU box): python tools/fuzz_parity.py [cases=60] [seed=1]"""
+usage (GPU box): python tools/fuzz_parity.py [cases=60] [seed=1] [large]"""
 import os
 import sys
 
@@ -18,8 +18,8 @@ def rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)) if a.size else 0.0
 
 
-def cases(n_cases, seed):
-    """The windows of a sweep (deterministic in the seed)."""
+def cases(n_cases, seed, large=False):
+    """The windows of a sweep (deterministic in the seed). large: windows of BASELINE size (100 .. 512 control points, 500 .. 5 000 landmarks)."""
     rng = np.random.default_rng(seed)
     for case in range(n_cases):
         order = int(rng.choice([4, 4, 5, 6]))
@@ -28,9 +28,12 @@ def cases(n_cases, seed):
         span = float(rng.choice([0.3, 0.6, 1.0, 1.6, 2.4, 0.1 * n_cp]))  # seconds a landmark's observations are spread over (dt = 0.1 s)
         n_lm = int(rng.integers(8, 160))
         pairs = int(rng.integers(2, 9))
+        if large:
+            n_cp, n_lm, pairs = int(rng.integers(100, 513)), int(rng.integers(500, 5001)), int(rng.integers(3, 7))
+            span = float(rng.choice([0.4, 0.8, 1.2, 1.6]))
         bearing = bool(rng.random() < 0.3)
         wseed = int(rng.integers(1, 1 << 20))
-        n_ine = int(rng.integers(40, 500)) if imu else 0
+        n_ine = (int(rng.integers(40, 500)) if not large else int(rng.integers(1000, 10001))) if imu else 0
         if imu:
             w = synthetic.small_inertial(order=order, n_cp=n_cp, n_landmarks=n_lm, obs_pairs=pairs, n_inertial=n_ine, seed=wseed)
         else:
@@ -55,11 +58,12 @@ def end_points(p, w, iters=4):
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    large = len(sys.argv) > 3 and sys.argv[3] == "large"
     hip = _lib.load()
     oracle = _lib.Library(os.path.join("oracle", "liboracle.so"), "hso_")
     referee = _lib.Library(os.path.join("oracle", "liboracle_ld.so"), "hs_", strict=False)  # the oracle in 80-bit long double
     failures = []
-    for tag, w in cases(n_cases, seed):
+    for tag, w in cases(n_cases, seed, large):
         try:
             with ha.Problem(w, lib=hip) as g, ha.Problem(w, lib=oracle) as c:
                 bw = g.lib.band_blocks(g.h)

@@ -557,6 +557,10 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_norm_part.reserve(2 * size_t(nb_norm)));
   const int nbd = p->has_imu ? 6 * p->n_bias + 2 : 0;
   if (nbd && size_t(np) * 8 * 8 > 150 * 1024) HS_FAIL(HS_ERR_INVALID, "window too long for the LDS-resident border forward sweep");
+  // (k_border_solve: the border Schur complement, augmented, in LDS — (nb + 1)^2 + nb doubles within the 150 KB the kernel may ask for: nb <= 137,
+  //  i.e. 22 bias control points; the launch used to fail inside hs_solve with "invalid argument")
+  if (nbd + 1 > 128 && (size_t(nbd + 1) * (nbd + 1) + nbd) * sizeof(double) > size_t(150) * 1024)
+    HS_FAIL(HS_ERR_INVALID, "too many border unknowns (bias control points) for the LDS-resident dense solve of the border system: at most 22 bias control points per window");
   const int x_count1 = np * (ncb + 3) + np * nbd + nbd * nbd + nbd + 1 + p->world;
   HIP_TRY(p->d_ybuf.reserve(np));
   HIP_TRY(p->d_scale_b.reserve(nbd + 1));

@@ -131,3 +131,26 @@ def test_hip_matches_literal_inertial_golden(hip):
     for case in literal_inertial_cases():
         with ha.Problem(golden_window(case), lib=hip) as p:
             check_against_literal_golden(p, case, 1e-9)
+
+
+def test_long_inertial_windows(hip, oracle):
+    """An IMU window of 20 s at one bias control point per second: 146 border unknowns — the dense solve of the border system keeps its Schur
+    complement in LDS (k_border_solve) up to 22 bias control points; beyond, the window is refused when the tables are prepared, with a message
+    (before round 5 the launch failed inside hs_solve with 'invalid argument'). 17 s (21 bias control points, 128 border unknowns) is solved: the
+    LDS-resident variant behind the register one, against the oracle. Such windows also carry thousands of inertial residuals next to the
+    visual ones — the shape on which the cost-partial tables of the inertial kernels were found too short (tools/fuzz_parity.py large)."""
+    w = synthetic.small_inertial(order=4, n_cp=170, n_landmarks=600, obs_pairs=3, n_inertial=3000, seed=51)
+    assert len(w.imu["bias_g"]) == 21
+    with ha.Problem(w, lib=hip) as g, ha.Problem(w, lib=oracle) as c:
+        assert abs(g.cost() - c.cost()) <= 1e-11 * c.cost()
+        sg, sc = g.solve(3), c.solve(3)
+        assert [i["step_is_successful"] for i in sg["iterations"]] == [i["step_is_successful"] for i in sc["iterations"]]
+        assert abs(sg["final_cost"] - sc["final_cost"]) <= 1e-6 * sc["final_cost"]
+        bg, ba = g.bias()
+        cg, ca = c.bias()
+        assert rel(g.control_points(), c.control_points()) < 1e-6 and rel(bg, cg) < 1e-6 and rel(ba, ca) < 1e-6
+    w = synthetic.small_inertial(order=4, n_cp=206, n_landmarks=100, obs_pairs=3, n_inertial=500, seed=52)
+    assert len(w.imu["bias_g"]) > 22
+    with ha.Problem(w, lib=hip) as g:
+        with pytest.raises(RuntimeError, match="too many border unknowns"):
+            g.cost()

@@ -29,7 +29,7 @@ def cases(n_cases, seed, large=False):
         n_lm = int(rng.integers(8, 160))
         pairs = int(rng.integers(2, 9))
         if large:
-            n_cp, n_lm, pairs = int(rng.integers(100, 513)), int(rng.integers(500, 5001)), int(rng.integers(3, 7))
+            n_cp, n_lm, pairs = int(rng.integers(100, 180 if imu else 513)), int(rng.integers(500, 5001)), int(rng.integers(3, 7))  # (IMU: <= 22 bias control points)
             span = float(rng.choice([0.4, 0.8, 1.2, 1.6]))
         bearing = bool(rng.random() < 0.3)
         wseed = int(rng.integers(1, 1 << 20))

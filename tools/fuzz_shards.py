@@ -2,7 +2,7 @@
 with its landmark shard of the same random window (tools/fuzz_parity.py: cases); rank 0 also solves the whole window on its own and compares —
 reduced normal equations of the first linearisation 1e-9, same accept / reject sequence, 4-iteration end points 1e-6 (control points; each rank's own
 landmarks). Windows with an IMU factor their bordered system from both ends with the border sweep next to the factorisation on every rank.
-usage (GPU box): python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 tools/fuzz_shards.py [cases=40] [seed=1]"""
+usage (GPU box): python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 tools/fuzz_shards.py [cases=40] [seed=1] [large]"""
 import os
 import sys
 
@@ -20,12 +20,13 @@ def main():
     from fuzz_parity import cases, rel
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    large = len(sys.argv) > 3 and sys.argv[3] == "large"
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
     lib = _lib.load()
     failures = 0
-    for tag, w in cases(n_cases, seed):
+    for tag, w in cases(n_cases, seed, large):
         flag = torch.zeros(1, dtype=torch.int64)
         line = ""
         try:

@@ -316,6 +316,15 @@ static int linearize_impl(hs_problem* p, int type, int robustify, const hs_linea
 /// hs_linearize with CostConfiguration::weights (exteroceptive.cpp:129-147): output = W * distance, J_w = W * J_m * J_e, then Ceres' loss
 /// corrector on the weighted residual. The device produces the unweighted, uncorrected rows (linearize_impl, robustify = 0); W (n_res x
 /// n_res) and the corrector are applied per residual block while the rows are handed out.
+/// HS_GUARD=1 (host_tables.hpp, GuardRegistry): the patterns behind every device table of the process are checked before the call returns.
+static int guard_check(hs_problem* p) {
+  if (!GuardRegistry::on()) return HS_OK;
+  size_t at = 0;
+  const size_t bytes = GuardRegistry::get().check(&at);
+  if (bytes) HS_FAIL(HS_ERR_DEVICE, "HS_GUARD: a device table of " + std::to_string(bytes) + " bytes was written past its end (first overwritten guard byte at +" + std::to_string(at) + ")");
+  return HS_OK;
+}
+
 int hs_linearize(hs_problem* p, int type, int robustify, const hs_linearization* out) {
   if (!p || !out) return HS_ERR_INVALID;
   if (type < HS_PIXEL || type > HS_INERTIAL) HS_FAIL(HS_ERR_INVALID, "unknown factor type");
@@ -487,7 +496,7 @@ int hs_cost(hs_problem* p, double* cost) {
   HIP_TRY(hipMemcpyAsync(&st, p->d_state.p, sizeof(st), hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   *cost = st.cost;
-  return HS_OK;
+  return guard_check(p);
 }
 
 int hs_reduced_system(hs_problem* p, double radius, double* S, double* g) {
@@ -530,7 +539,7 @@ int hs_reduced_system(hs_problem* p, double radius, double* S, double* g) {
       g[np + a] = gb[a];
     }
   }
-  return HS_OK;
+  return guard_check(p);
 }
 
 int hs_set_weights(hs_problem* p, int type, const double* weights) {
@@ -664,7 +673,7 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
   }
   if (st.chol_failed && st.termination == HS_FAILURE)
     p->err = st.chol_failed == 2 ? "two-ended solve: the partner workgroup did not arrive within 2 s" : "reduced system not positive definite";
-  return HS_OK;
+  return guard_check(p);
 }
 
 #if HS_PROFILE_HOOKS

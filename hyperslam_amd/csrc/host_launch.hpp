@@ -331,8 +331,8 @@ int launch_factor(hs_problem* p) {
     Tables T2 = T;
     T2.fj[0] = FactorJob{T.Sb, T.g_s, T.Ub, T.Ubk, T.ybuf, p->d_win.p, m + w_mid, m};
     T2.fj[1] = FactorJob{p->d_Sb2.p, p->d_g2.p, p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, p->d_win.p, mB, -1};
-    T2.mj[0] = MfmaJob{p->d_Sb2.p, T.g_s, T.Ub, T.Ubk, T.ybuf, p->d_win.p, m + w_mid, m, m + w_mid, INT_MAX, 0, p->d_Vb.p + size_t(T.np) * (6 * T.bw)};
-    T2.mj[1] = MfmaJob{T.Sb, p->d_g2.p, p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, p->d_win.p, mB, -1, mB + w_mid, mB, 1, p->d_Vb.p + size_t(T.np) * (6 * T.bw)};
+    T2.mj[0] = MfmaJob{p->d_Sb2.p, T.g_s, T.Ub, T.Ubk, T.ybuf, p->d_win.p, m + w_mid, m, m + w_mid, INT_MAX, 0, p->d_Vb.p + p->vb_len};
+    T2.mj[1] = MfmaJob{T.Sb, p->d_g2.p, p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, p->d_win.p, mB, -1, mB + w_mid, mB, 1, p->d_Vb.p + p->vb_len};
     T2.join_epoch = ++p->join_epoch;
     T2.bookkeep = p->bookkeep && !nt ? 1 : 0;
     // Bordered systems on k_band_factor_mx: the forward sweep of the border columns (k_border_forward2, 44 us behind the factorisation at
@@ -398,7 +398,8 @@ int launch_factor(hs_problem* p) {
     const BackJob j1{p->d_Ub2.p, p->d_Ubk2.p, p->d_ybuf2.p, p->d_Vb2.p, p->d_yt2.p, mB, w_mid, 1};
     // (the two older sweeps are kept as measurement switches for visual-only systems, the shape they were measured on; they do not write
     //  the border's step outputs)
-    const bool sweep_w = HS_AB(T.debug_flags, 65536) && !T.nb, sweep_rows = HS_AB(T.debug_flags, 268435456) && !T.nb;
+    const bool sweep_w = HS_AB(T.debug_flags, 65536) && !T.nb && p->vb_len == size_t(T.np) * (6 * T.bw),  // (its pad of zeros sits right behind np x ncb)
+                sweep_rows = HS_AB(T.debug_flags, 268435456) && !T.nb;
 #if HS_PROFILE_HOOKS
     if (sweep_w) k_premultiply<<<m + w_mid + mB, 128, 0, s>>>(T3, j0, j1, m + w_mid);
 #endif
@@ -440,7 +441,7 @@ int launch_factor(hs_problem* p) {
   } else if (nt) {
     Tables T1 = Tf;
     // (the lower-band rows come from the reversed copy, whose rows are counted from the END of the matrix: no offset)
-    T1.mj[0] = MfmaJob{p->d_Sb2.p, Tf.g_s, Tf.Ub, Tf.Ubk, Tf.ybuf, nullptr, n_blk - f0, -1, n_blk - f0, INT_MAX, 0, p->d_Vb.p + size_t(T.np) * (6 * T.bw)};
+    T1.mj[0] = MfmaJob{p->d_Sb2.p, Tf.g_s, Tf.Ub, Tf.Ubk, Tf.ybuf, nullptr, n_blk - f0, -1, n_blk - f0, INT_MAX, 0, p->d_Vb.p + p->vb_len};
     T1.mj[1] = T1.mj[0];
     HIP_TRY(run_mfma(T1, 1));
   } else if (la_ok && la_ncw == 3)

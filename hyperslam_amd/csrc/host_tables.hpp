@@ -76,11 +76,66 @@ struct UploadBatch {
 };
 thread_local UploadBatch* tl_upload_batch = nullptr;  // set by prepare() around its uploads
 
+// HS_GUARD=1 (a debugging mode of the library, read once per process): every device table is allocated at exactly the size asked for, followed
+// by kGuardBytes of a known pattern, and hs_solve / hs_cost / hs_reduced_system / hs_linearize check the patterns of every table of the process
+// before they return — a kernel that writes past the end of its table fails the call with the table's size instead of corrupting a neighbour.
+// (Reads past the end are not caught.) tests/test_gpu_edge_cases.py::test_guarded_tables and tools/fuzz_parity.py run under it.
+constexpr size_t kGuardBytes = 4096;
+struct GuardedBuffer {
+  void* base = nullptr;   // device allocation
+  size_t bytes = 0;       // size the owner asked for; the pattern follows
+};
+struct GuardRegistry {
+  std::mutex mu;
+  std::vector<GuardedBuffer*> all;
+  static GuardRegistry& get() {
+    static GuardRegistry r;
+    return r;
+  }
+  static bool on() {
+    static const bool v = [] {
+      const char* e = std::getenv("HS_GUARD");
+      return e && std::atoi(e) != 0;
+    }();
+    return v;
+  }
+  /// 0: every pattern intact; otherwise the size in bytes of a table whose pattern was overwritten (first found), offset of the first bad byte in *at.
+  size_t check(size_t* at) {
+    std::lock_guard<std::mutex> lock(mu);
+    std::vector<unsigned char> h(kGuardBytes);
+    (void)hipDeviceSynchronize();
+    for (GuardedBuffer* b : all) {
+      if (!b->base) continue;
+      if (hipMemcpy(h.data(), static_cast<char*>(b->base) + b->bytes, kGuardBytes, hipMemcpyDeviceToHost) != hipSuccess) continue;
+      for (size_t i = 0; i < kGuardBytes; ++i)
+        if (h[i] != 0xA5) {
+          *at = i;
+          return b->bytes ? b->bytes : 1;
+        }
+    }
+    return 0;
+  }
+};
+
 template <class T>
 struct DBuf {
   T* p = nullptr;
   size_t cap = 0;
+  GuardedBuffer guard;
+  DBuf() {
+    if (GuardRegistry::on()) {
+      std::lock_guard<std::mutex> lock(GuardRegistry::get().mu);
+      GuardRegistry::get().all.push_back(&guard);
+    }
+  }
+  DBuf(const DBuf&) = delete;
+  DBuf& operator=(const DBuf&) = delete;
   ~DBuf() {
+    if (GuardRegistry::on()) {
+      std::lock_guard<std::mutex> lock(GuardRegistry::get().mu);
+      auto& v = GuardRegistry::get().all;
+      v.erase(std::remove(v.begin(), v.end(), &guard), v.end());
+    }
     if (p) (void)hipFree(p);
   }
   /// Capacity grows geometrically: a sliding window changes every table size by a little at every optimize(), and an exact-fit
@@ -88,7 +143,17 @@ struct DBuf {
   hipError_t reserve(size_t n) {
     if (n <= cap) return hipSuccess;
     if (p) (void)hipFree(p);
-    p = nullptr;
+    p = nullptr, guard.base = nullptr;
+    if (GuardRegistry::on()) {  // exact fit + pattern (see GuardRegistry)
+      cap = 0;
+      hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T) + kGuardBytes);
+      if (e != hipSuccess) return e;
+      e = hipMemset(reinterpret_cast<char*>(p) + n * sizeof(T), 0xA5, kGuardBytes);
+      if (e != hipSuccess) return e;
+      e = hipDeviceSynchronize();
+      cap = n, guard.base = p, guard.bytes = n * sizeof(T);
+      return e;
+    }
     const size_t want = std::max<size_t>(std::max<size_t>(n, 256), 2 * cap);
     cap = 0;
     const hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
@@ -191,6 +256,7 @@ struct hs_problem {
   double* h_result = nullptr;
   size_t h_result_cap = 0;
   bool want_results = false, results_cached = false;
+  size_t vb_len = 0;                             // doubles of d_Vb / d_Vb2 in front of their zero pad (prepare())
   int zeroed_np = -1, zeroed_ncb = -1;           // layout / allocations for which the never-written parts of Sb2, Vb, yt were zeroed
   const void* zeroed_ptr[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
 
@@ -579,14 +645,18 @@ int prepare(hs_problem* p) {
     // Entries of the reversed copy past the end of the matrix are never written, the pads behind Vb / yt (operands of rows that do not
     // exist, k_band_backward_w) neither: they are zeroed once per allocation and layout — a sliding window keeps both from one
     // optimize() to the next, and five memsets per prepare() cost more host time than the structure tables.
-    const size_t nv = size_t(np) * ncb, pad = 64;
+    // (Vb / Vb2 also hold the inverted super-blocks of the backward sweep, 576 doubles per four block rows, the last one whole even when the
+    //  system ends inside it: for bands of four control points — windows of priors / inertial residuals only — that is MORE than np x ncb, and
+    //  the builders wrote up to 432 doubles past the table, the zero operand of k_band_factor_mx behind it included; found by HS_GUARD=1)
+    const size_t nv = size_t(np) * ncb, pad = 64, vb_len = std::max(nv, size_t(576) * ((size_t(p->n_cp) + 3) / 4 + 1));
+    p->vb_len = vb_len;
     HIP_TRY(p->d_Sb2.reserve(nv));
-    for (DBuf<double>* b : {&p->d_Vb, &p->d_Vb2}) HIP_TRY(b->reserve(nv + pad));
+    for (DBuf<double>* b : {&p->d_Vb, &p->d_Vb2}) HIP_TRY(b->reserve(vb_len + pad));
     for (DBuf<double>* b : {&p->d_yt, &p->d_yt2}) HIP_TRY(b->reserve(size_t(np) + pad));
     const void* now[5] = {p->d_Sb2.p, p->d_Vb.p, p->d_Vb2.p, p->d_yt.p, p->d_yt2.p};
     if (p->zeroed_np != np || p->zeroed_ncb != ncb || std::memcmp(now, p->zeroed_ptr, sizeof(now)) != 0) {
       HIP_TRY(hipMemsetAsync(p->d_Sb2.p, 0, p->d_Sb2.cap * sizeof(double), s));
-      for (DBuf<double>* b : {&p->d_Vb, &p->d_Vb2}) HIP_TRY(hipMemsetAsync(b->p + nv, 0, pad * sizeof(double), s));
+      for (DBuf<double>* b : {&p->d_Vb, &p->d_Vb2}) HIP_TRY(hipMemsetAsync(b->p + vb_len, 0, pad * sizeof(double), s));
       for (DBuf<double>* b : {&p->d_yt, &p->d_yt2}) HIP_TRY(hipMemsetAsync(b->p + np, 0, pad * sizeof(double), s));
       p->zeroed_np = np, p->zeroed_ncb = ncb, std::memcpy(p->zeroed_ptr, now, sizeof(now));
     }

@@ -2,6 +2,7 @@
 control points, constant or unobserved landmarks, clamped boundary stamps, minimal windows, rotation- or translation-constant
 splines, constant biases) plus degenerate inputs (empty tables)."""
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -11,6 +12,7 @@ from hyperslam_amd import synthetic
 from util import rel
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def compare(w, hip, oracle, iters=5, tol=1e-6, check_lm=True, sys_tol=1e-9):
@@ -553,3 +555,40 @@ def test_deferred_commit_when_a_solve_converges_early(hip, oracle):
         assert abs(sg["final_cost"] - sc["final_cost"]) <= 1e-9 * sc["final_cost"]
         assert rel(g.control_points(), c.control_points()) < 1e-7 and rel(g.landmarks(), c.landmarks()) < 1e-7
         assert abs(g.cost() - sg["final_cost"]) <= 1e-12 * sg["final_cost"]  # x is the point the summary reports
+
+
+def test_guarded_tables(tmp_path):
+    """HS_GUARD=1 (host_tables.hpp GuardRegistry: every device table at its exact size with a pattern behind it, checked before hs_solve / hs_cost /
+    hs_reduced_system return), in a process of its own — the mode is read once per process: windows of inertial residuals and of priors only with
+    13 and 14 control points (bands of four control points: the inverted super-blocks of the backward sweep need more room than np x ncb — the
+    overflow this mode found), an IMU window with thousands of inertial residuals next to the visual ones (the cost-partial tables the randomised
+    sweep found too short), and 60 random window shapes of tools/fuzz_parity.py."""
+    import subprocess
+    import sys
+    script = tmp_path / "guarded.py"
+    script.write_text("""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import hyperslam_amd as ha
+from hyperslam_amd import synthetic
+for n_cp, imu in ((14, True), (13, True), (13, False), (18, False)):
+    w = synthetic.small_inertial(order=4, n_cp=n_cp, n_landmarks=10, obs_pairs=2, n_inertial=120, seed=37) if imu else \
+        synthetic.small_visual(order=4, n_cp=n_cp, n_landmarks=10, obs_pairs=2, seed=37, with_priors=40)
+    for name in ("pixel_stamps", "pixels", "pixel_landmark", "pixel_camera"):
+        setattr(w, name, getattr(w, name)[:0])
+    w.landmarks = w.landmarks[:0]
+    with ha.Problem(w) as g:
+        g.cost(); g.reduced_system(1e4); s = g.solve(4)
+        assert np.isfinite(s["final_cost"])
+w = synthetic.small_inertial(order=4, n_cp=120, n_landmarks=2500, obs_pairs=4, n_inertial=6000, seed=5)
+with ha.Problem(w) as g:
+    g.cost(); s = g.solve(3)
+    assert s["final_cost"] < s["initial_cost"]
+print("guarded windows ok")
+""" % (ROOT, os.path.join(ROOT, "tools")))
+    env = dict(os.environ, HS_GUARD="1")
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0 and "guarded windows ok" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "60", "92"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0 and "60 cases, 0 failures" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]

@@ -39,15 +39,20 @@ def cases(n_cases, seed, large=False):
         else:
             w = synthetic.small_visual(order=order, n_cp=n_cp, n_landmarks=n_lm, obs_pairs=pairs, bearing=bearing, seed=wseed, span=span,
                                        with_priors=int(rng.integers(1, 40)) if rng.random() < 0.25 else 0)
+        novis = bool(rng.random() < 0.06) and not large and (imu or len(w.prior_stamps) > 0)  # windows of priors / inertial residuals only: bands of k control points
+        if novis:
+            for name in ("pixel_stamps", "pixels", "pixel_landmark", "pixel_camera", "bearing_stamps", "bearings", "bearing_landmark", "bearing_camera"):
+                setattr(w, name, getattr(w, name)[:0])
+            w.landmarks = w.landmarks[:0]
         frozen = int(rng.integers(0, max(1, n_cp // 2))) if rng.random() < 0.7 else 0
         w.cp_constant = np.r_[np.ones(max(frozen, 2), np.uint8), np.zeros(n_cp - max(frozen, 2), np.uint8)]
         if rng.random() < 0.15:
             w.rotation_constant = True
         elif rng.random() < 0.15:
             w.translation_constant = True
-        if rng.random() < 0.3:
+        if rng.random() < 0.3 and not novis:
             w.landmark_constant = (rng.random(n_lm) < 0.15).astype(np.uint8)
-        yield f"case {case:3d}: k {order} n_cp {n_cp:2d} imu {int(imu)} span {span:4.1f} lm {n_lm:3d} pairs {pairs} bearing {int(bearing)} frozen {frozen:2d}", w
+        yield f"case {case:3d}: k {order} n_cp {n_cp:2d} imu {int(imu)} span {span:4.1f} lm {n_lm:3d} pairs {pairs} bearing {int(bearing)} frozen {frozen:2d}" + (" no-visual" if novis else ""), w
 
 
 def end_points(p, w, iters=4):

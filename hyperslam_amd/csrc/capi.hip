@@ -10,6 +10,26 @@
 #include "host_tables.hpp"
 #include "host_launch.hpp"
 
+/// Rows of a residual table that satisfy `drop(i)` leave; the others keep their order.
+template <class Drop>
+static int drop_rows(int n, Drop&& drop, std::vector<double>* stamp, std::vector<double>* meas, int width, std::vector<int32_t>* a = nullptr, std::vector<int32_t>* b = nullptr) {
+  int w = 0;
+  for (int i = 0; i < n; ++i) {
+    if (drop(i)) continue;
+    if (w != i) {
+      (*stamp)[w] = (*stamp)[i];
+      for (int c = 0; c < width; ++c) (*meas)[size_t(width) * w + c] = (*meas)[size_t(width) * i + c];
+      if (a) (*a)[w] = (*a)[i];
+      if (b) (*b)[w] = (*b)[i];
+    }
+    ++w;
+  }
+  stamp->resize(w), meas->resize(size_t(width) * w);
+  if (a) a->resize(w);
+  if (b) b->resize(w);
+  return n - w;
+}
+
 extern "C" {
 
 int hs_version(void) { return 1; }
@@ -109,46 +129,60 @@ int hs_set_spline(hs_problem* p, int order, double t0, double dt, int n_cp, cons
   for (int j = 0; j < n_cp; ++j)
     if (!(std::fabs(cp[8 * j + 7] - (t0 + j * dt)) <= knot_tol))
       HS_FAIL(HS_ERR_INVALID, "control-point stamps are not t0 + j dt (row " + std::to_string(j) + "): the spline basis is uniform, a table with a hole or non-uniform knots is refused");
+  // Same knots and flags as the resident table: only the values (and the constancy mask) changed — the sorted tables, every index and size stand.
+  const bool same_structure = p->k == order && p->t0 == t0 && p->dt == dt && p->n_cp == n_cp && p->rot_const == (rc != 0) && p->trans_const == (tc != 0) &&
+                              p->cp.size() == size_t(8) * n_cp;
+  bool same_values = same_structure && std::memcmp(p->cp.data(), cp, sizeof(double) * 8 * n_cp) == 0;
+  for (int j = 0; same_values && j < n_cp; ++j) same_values = p->cp_const[j] == (cp_constant ? cp_constant[j] : 0);
+  if (same_values && !p->device_ahead) return HS_OK;  // (nothing to send: the device holds exactly this table)
   p->k = order, p->t0 = t0, p->dt = dt, p->n_cp = n_cp;
   p->cp.assign(cp, cp + size_t(8) * n_cp);
   p->cp_const.assign(n_cp, 0);
   if (cp_constant) p->cp_const.assign(cp_constant, cp_constant + n_cp);
   p->rot_const = rc != 0, p->trans_const = tc != 0;
-  p->dirty = true;
+  p->touch(same_structure ? unsigned(hs_problem::vCp) : unsigned(hs_problem::kAll));
   return HS_OK;
 }
 
 int hs_set_cameras(hs_problem* p, int n, const double* T_bs, const double* intr, const double* dist) {
   if (!p) return HS_ERR_INVALID;
   if (n < 0 || n > 0xffff || (n && (!T_bs || !intr || !dist))) HS_FAIL(HS_ERR_INVALID, "bad camera table");
+  const bool same_count = p->n_cam == n && p->cam.size() == size_t(kCamStride) * n;
+  const std::vector<double> before = p->cam;
   p->n_cam = n;
   p->cam.assign(size_t(kCamStride) * n, 0.0);
   for (int i = 0; i < n; ++i) {
     double* c = &p->cam[size_t(kCamStride) * i];
     std::memcpy(c, T_bs + 7 * i, 56), std::memcpy(c + 7, intr + 4 * i, 32), std::memcpy(c + 11, dist + 4 * i, 32);
   }
-  p->dirty = true;
+  if (same_count && before == p->cam) return HS_OK;
+  p->touch(same_count ? unsigned(hs_problem::vCam) : unsigned(hs_problem::vCam | hs_problem::kVis));  // (the visual section checks the camera indices)
   return HS_OK;
 }
 
 int hs_set_sensors(hs_problem* p, int n, const double* T_bs) {
   if (!p) return HS_ERR_INVALID;
   if (n < 0 || (n && !T_bs)) HS_FAIL(HS_ERR_INVALID, "bad sensor table");
+  const bool same_count = p->n_sensor == n && p->sensor.size() == size_t(8) * n;
+  const std::vector<double> before = p->sensor;
   p->n_sensor = n;
   p->sensor.assign(size_t(8) * n, 0.0);
   for (int i = 0; i < n; ++i) std::memcpy(&p->sensor[size_t(8) * i], T_bs + 7 * i, 56);
-  p->dirty = true;
+  if (same_count && before == p->sensor) return HS_OK;
+  p->touch(same_count ? unsigned(hs_problem::vSensor) : unsigned(hs_problem::vSensor | hs_problem::kPri));  // (the prior section checks the sensor indices)
   return HS_OK;
 }
 
 int hs_set_landmarks(hs_problem* p, int n, const double* xyz, const uint8_t* constant) {
   if (!p) return HS_ERR_INVALID;
   if (n < 0 || (n && !xyz)) HS_FAIL(HS_ERR_INVALID, "bad landmark table");
+  bool same_structure = p->n_lm == n && p->lm.size() == size_t(3) * n && p->lm_const.size() == size_t(n);
+  for (int i = 0; same_structure && i < n; ++i) same_structure = p->lm_const[i] == (constant ? constant[i] : 0);
   p->n_lm = n;
   p->lm.assign(xyz, xyz + size_t(3) * n);
   p->lm_const.assign(n, 0);
   if (constant) p->lm_const.assign(constant, constant + n);
-  p->dirty = true;
+  p->touch(same_structure ? unsigned(hs_problem::vLm) : unsigned(hs_problem::vLm | hs_problem::kVis));
   return HS_OK;
 }
 
@@ -157,28 +191,32 @@ int hs_set_imu(hs_problem* p, const double* T_bs, const double* i_g, const doubl
   if (!p) return HS_ERR_INVALID;
   if (!T_bs || !i_g || !i_a || !S_g || !X_a || !bias_g || !bias_a) HS_FAIL(HS_ERR_INVALID, "null IMU table");
   if (bias_order < 2 || bias_order > hsd::kMaxOrder || n_bias < bias_order || !(bias_dt > 0)) HS_FAIL(HS_ERR_INVALID, "bad bias spline");
+  const bool same_structure = p->has_imu && p->kb == bias_order && p->bias_t0 == bias_t0 && p->bias_dt == bias_dt && p->n_bias == n_bias &&
+                              p->bias_const == (bias_constant != 0);
   p->has_imu = true;
   std::memcpy(p->imu_T_bs, T_bs, 56), std::memcpy(p->imu_i_g, i_g, 48), std::memcpy(p->imu_i_a, i_a, 48);
   std::memcpy(p->imu_S_g, S_g, 72), std::memcpy(p->imu_X_a, X_a, 72);
   p->kb = bias_order, p->bias_t0 = bias_t0, p->bias_dt = bias_dt, p->n_bias = n_bias;
   p->bias_g.assign(bias_g, bias_g + size_t(4) * n_bias), p->bias_a.assign(bias_a, bias_a + size_t(4) * n_bias);
   p->bias_const = bias_constant != 0;
-  p->dirty = true;
+  // (new bias knots: the inertial records index them, the border of the reduced system changes size)
+  p->touch(same_structure ? unsigned(hs_problem::vImu | hs_problem::vBias) : unsigned(hs_problem::vImu | hs_problem::vBias | hs_problem::kIne | hs_problem::kTail));
   return HS_OK;
 }
 
 int hs_set_inertial_jacobian(hs_problem* p, int mode) {
   if (!p) return HS_ERR_INVALID;
   if (mode != HS_INERTIAL_AS_REFERENCE && mode != HS_INERTIAL_EXACT) HS_FAIL(HS_ERR_INVALID, "unknown inertial Jacobian mode");
-  if (mode != p->inertial_mode) p->inertial_mode = mode, p->dirty = true;
+  if (mode != p->inertial_mode) p->inertial_mode = mode, p->touch(hs_problem::kTail);
   return HS_OK;
 }
 
 int hs_set_gravity(hs_problem* p, const double* g, int constant) {
   if (!p || !g) return HS_ERR_INVALID;
+  const bool same_structure = p->gravity_const == (constant != 0);
   std::memcpy(p->gravity, g, 24);
   p->gravity_const = constant != 0;
-  p->dirty = true;
+  p->touch(same_structure ? unsigned(hs_problem::vGravity) : unsigned(hs_problem::vGravity | hs_problem::kTail));
   return HS_OK;
 }
 
@@ -186,29 +224,164 @@ int hs_set_pixel_residuals(hs_problem* p, int n, const double* st, const double*
   if (!p) return HS_ERR_INVALID;
   if (n < 0 || (n && (!st || !px || !lm || !cam))) HS_FAIL(HS_ERR_INVALID, "bad pixel residual table");
   p->px_stamp.assign(st, st + n), p->px_meas.assign(px, px + size_t(2) * n), p->px_lm.assign(lm, lm + n), p->px_cam.assign(cam, cam + n);
-  p->dirty = true;
+  p->touch(hs_problem::kVis | hs_problem::kTail);
   return HS_OK;
 }
 int hs_set_bearing_residuals(hs_problem* p, int n, const double* st, const double* b, const int32_t* lm, const int32_t* cam) {
   if (!p) return HS_ERR_INVALID;
   if (n < 0 || (n && (!st || !b || !lm || !cam))) HS_FAIL(HS_ERR_INVALID, "bad bearing residual table");
   p->br_stamp.assign(st, st + n), p->br_meas.assign(b, b + size_t(3) * n), p->br_lm.assign(lm, lm + n), p->br_cam.assign(cam, cam + n);
-  p->dirty = true;
+  p->touch(hs_problem::kVis | hs_problem::kTail);
   return HS_OK;
 }
 int hs_set_prior_residuals(hs_problem* p, int n, const double* st, const double* poses, const int32_t* sensor) {
   if (!p) return HS_ERR_INVALID;
   if (n < 0 || (n && (!st || !poses || !sensor))) HS_FAIL(HS_ERR_INVALID, "bad prior residual table");
   p->pr_stamp.assign(st, st + n), p->pr_meas.assign(poses, poses + size_t(7) * n), p->pr_sensor.assign(sensor, sensor + n);
-  p->dirty = true;
+  p->touch(hs_problem::kPri | hs_problem::kTail);
   return HS_OK;
 }
 int hs_set_inertial_residuals(hs_problem* p, int n, const double* st, const double* m) {
   if (!p) return HS_ERR_INVALID;
   if (n < 0 || (n && (!st || !m))) HS_FAIL(HS_ERR_INVALID, "bad inertial residual table");
   p->in_stamp.assign(st, st + n), p->in_meas.assign(m, m + size_t(6) * n);
-  p->dirty = true;
+  p->touch(hs_problem::kIne | hs_problem::kTail);
   return HS_OK;
+}
+
+// ---- delta interface ------------------------------------------------------------------------------------------------------------------
+// The reference keeps ceres::Problem incrementally: AddResidualBlock when an observation arrives (optimizer.cpp:189-274 <- abstract.cpp:246-259),
+// AddParameterBlock / RemoveParameterBlock when a landmark appears / leaves the window (optimizer.cpp:347-382), and optimize() only solves.
+// Same here: rows are appended to / retired from the resident tables when the caller learns of them, hs_stage() sorts and uploads between
+// solves, and an hs_solve() that finds nothing changed sends nothing (the control points, if they were re-sent with new values, only).
+
+/// The host copies of the variables follow the device before a delta call edits the tables next to them (the solve moved the point on the
+/// device; the next structural upload re-sends landmarks in a new order).
+static int pull_state(hs_problem* p) {
+  if (!p->device_ahead || p->dirty) return HS_OK;
+  std::vector<double> a(p->cp.size()), b(p->lm.size()), c(p->bias_g.size()), d(p->bias_a.size());
+  double g[3];
+  int rc = HS_OK;
+  if (!a.empty()) rc = hs_get_control_points(p, a.data());
+  if (!rc && p->n_lm) rc = hs_get_landmarks(p, b.data());
+  if (!rc && p->has_imu) rc = hs_get_bias(p, c.data(), d.data());
+  if (!rc && p->has_imu) rc = hs_get_gravity(p, g);
+  if (!rc) p->device_ahead = false;
+  return rc;
+}
+
+int hs_append_landmarks(hs_problem* p, int n, const double* xyz, const uint8_t* constant, int32_t* first_index) {
+  if (!p) return HS_ERR_INVALID;
+  if (n < 0 || (n && !xyz)) HS_FAIL(HS_ERR_INVALID, "bad landmark rows");
+  const int rc = pull_state(p);
+  if (rc) return rc;
+  if (first_index) *first_index = p->n_lm;
+  if (n == 0) return HS_OK;
+  p->lm.insert(p->lm.end(), xyz, xyz + size_t(3) * n);
+  for (int i = 0; i < n; ++i) p->lm_const.push_back(constant ? constant[i] : 0);
+  p->n_lm += n;
+  p->touch(hs_problem::kVis | hs_problem::kTail | hs_problem::vLm);
+  return HS_OK;
+}
+
+int hs_append_pixel_residuals(hs_problem* p, int n, const double* st, const double* px, const int32_t* lm, const int32_t* cam) {
+  if (!p) return HS_ERR_INVALID;
+  if (n < 0 || (n && (!st || !px || !lm || !cam))) HS_FAIL(HS_ERR_INVALID, "bad pixel residual rows");
+  if (n == 0) return HS_OK;
+  const int rc = pull_state(p);
+  if (rc) return rc;
+  p->px_stamp.insert(p->px_stamp.end(), st, st + n), p->px_meas.insert(p->px_meas.end(), px, px + size_t(2) * n);
+  p->px_lm.insert(p->px_lm.end(), lm, lm + n), p->px_cam.insert(p->px_cam.end(), cam, cam + n);
+  p->touch(hs_problem::kVis | hs_problem::kTail);
+  return HS_OK;
+}
+int hs_append_bearing_residuals(hs_problem* p, int n, const double* st, const double* b, const int32_t* lm, const int32_t* cam) {
+  if (!p) return HS_ERR_INVALID;
+  if (n < 0 || (n && (!st || !b || !lm || !cam))) HS_FAIL(HS_ERR_INVALID, "bad bearing residual rows");
+  if (n == 0) return HS_OK;
+  const int rc = pull_state(p);
+  if (rc) return rc;
+  p->br_stamp.insert(p->br_stamp.end(), st, st + n), p->br_meas.insert(p->br_meas.end(), b, b + size_t(3) * n);
+  p->br_lm.insert(p->br_lm.end(), lm, lm + n), p->br_cam.insert(p->br_cam.end(), cam, cam + n);
+  p->touch(hs_problem::kVis | hs_problem::kTail);
+  return HS_OK;
+}
+int hs_append_prior_residuals(hs_problem* p, int n, const double* st, const double* poses, const int32_t* sensor) {
+  if (!p) return HS_ERR_INVALID;
+  if (n < 0 || (n && (!st || !poses || !sensor))) HS_FAIL(HS_ERR_INVALID, "bad prior residual rows");
+  if (n == 0) return HS_OK;
+  const int rc = pull_state(p);
+  if (rc) return rc;
+  p->pr_stamp.insert(p->pr_stamp.end(), st, st + n), p->pr_meas.insert(p->pr_meas.end(), poses, poses + size_t(7) * n);
+  p->pr_sensor.insert(p->pr_sensor.end(), sensor, sensor + n);
+  p->touch(hs_problem::kPri | hs_problem::kTail);
+  return HS_OK;
+}
+int hs_append_inertial_residuals(hs_problem* p, int n, const double* st, const double* m) {
+  if (!p) return HS_ERR_INVALID;
+  if (n < 0 || (n && (!st || !m))) HS_FAIL(HS_ERR_INVALID, "bad inertial residual rows");
+  if (n == 0) return HS_OK;
+  const int rc = pull_state(p);
+  if (rc) return rc;
+  p->in_stamp.insert(p->in_stamp.end(), st, st + n), p->in_meas.insert(p->in_meas.end(), m, m + size_t(6) * n);
+  p->touch(hs_problem::kIne | hs_problem::kTail);
+  return HS_OK;
+}
+
+int hs_retire_landmarks(hs_problem* p, int n, const int32_t* ids, int32_t* remap) {
+  if (!p) return HS_ERR_INVALID;
+  if (n < 0 || (n && !ids)) HS_FAIL(HS_ERR_INVALID, "bad landmark list");
+  const int n_old = p->n_lm;
+  std::vector<int32_t> local;
+  if (!remap) local.resize(n_old), remap = local.data();
+  for (int i = 0; i < n; ++i)
+    if (ids[i] < 0 || ids[i] >= n_old) HS_FAIL(HS_ERR_INVALID, "hs_retire_landmarks: landmark outside the landmark table");
+  if (n == 0) {
+    for (int t = 0; t < n_old; ++t) remap[t] = t;
+    return HS_OK;
+  }
+  const int rc = pull_state(p);
+  if (rc) return rc;
+  for (int t = 0; t < n_old; ++t) remap[t] = 0;
+  for (int i = 0; i < n; ++i) remap[ids[i]] = -1;
+  int w = 0;
+  for (int t = 0; t < n_old; ++t) {
+    if (remap[t] < 0) continue;
+    for (int c = 0; c < 3; ++c) p->lm[size_t(3) * w + c] = p->lm[size_t(3) * t + c];
+    p->lm_const[w] = p->lm_const[t];
+    remap[t] = w++;
+  }
+  p->n_lm = w, p->lm.resize(size_t(3) * w), p->lm_const.resize(w);
+  // RemoveParameterBlock takes the residual blocks of the landmark along (optimizer.cpp:365-371, enable_fast_removal)
+  drop_rows(int(p->px_stamp.size()), [&](int i) { return remap[p->px_lm[i]] < 0; }, &p->px_stamp, &p->px_meas, 2, &p->px_lm, &p->px_cam);
+  drop_rows(int(p->br_stamp.size()), [&](int i) { return remap[p->br_lm[i]] < 0; }, &p->br_stamp, &p->br_meas, 3, &p->br_lm, &p->br_cam);
+  for (int32_t& l : p->px_lm) l = remap[l];
+  for (int32_t& l : p->br_lm) l = remap[l];
+  p->touch(hs_problem::kVis | hs_problem::kTail | hs_problem::vLm);
+  return HS_OK;
+}
+
+int hs_retire_residuals_before(hs_problem* p, int type, double stamp) {
+  if (!p) return HS_ERR_INVALID;
+  if (type < HS_PIXEL || type > HS_INERTIAL) HS_FAIL(HS_ERR_INVALID, "unknown factor type");
+  const int rc = pull_state(p);  // (the variables stay where the last solve left them)
+  if (rc) return rc;
+  int dropped = 0;
+  switch (type) {
+    case HS_PIXEL: dropped = drop_rows(int(p->px_stamp.size()), [&](int i) { return p->px_stamp[i] < stamp; }, &p->px_stamp, &p->px_meas, 2, &p->px_lm, &p->px_cam); break;
+    case HS_BEARING: dropped = drop_rows(int(p->br_stamp.size()), [&](int i) { return p->br_stamp[i] < stamp; }, &p->br_stamp, &p->br_meas, 3, &p->br_lm, &p->br_cam); break;
+    case HS_PRIOR: dropped = drop_rows(int(p->pr_stamp.size()), [&](int i) { return p->pr_stamp[i] < stamp; }, &p->pr_stamp, &p->pr_meas, 7, &p->pr_sensor); break;
+    default: dropped = drop_rows(int(p->in_stamp.size()), [&](int i) { return p->in_stamp[i] < stamp; }, &p->in_stamp, &p->in_meas, 6); break;
+  }
+  if (dropped) {
+    p->touch((type <= HS_BEARING ? hs_problem::kVis : type == HS_PRIOR ? hs_problem::kPri : hs_problem::kIne) | hs_problem::kTail);
+  }
+  return HS_OK;
+}
+
+int hs_stage(hs_problem* p) {
+  if (!p) return HS_ERR_INVALID;
+  return prepare(p);  // sorts what changed and enqueues its upload on the handle's stream; nothing is awaited
 }
 
 int hs_num_residuals(hs_problem* p, int type) {
@@ -634,6 +807,7 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
   }
   HIP_TRY(hipMemcpyAsync(&st, p->d_state.p, sizeof(st), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  if (max_iterations > 0) p->device_ahead = true;
   p->results_cached = p->want_results;  // only once every copy above has completed: a failed copy or synchronisation leaves the getters on the device path
   if (p->host_timing) {
     const auto host_t5 = std::chrono::steady_clock::now();
@@ -785,7 +959,7 @@ int hs_set_shard(hs_problem* p, int rank, int world, int min_band_blocks) {
   if (!p) return HS_ERR_INVALID;
   if (world < 1 || rank < 0 || rank >= world || min_band_blocks < 0) HS_FAIL(HS_ERR_INVALID, "bad shard description");
   p->rank = rank, p->world = world, p->min_bw = min_band_blocks;
-  p->dirty = true;
+  p->touch(hs_problem::kAll);
   return HS_OK;
 }
 
@@ -889,7 +1063,7 @@ int hs_cost_function_evaluate(hs_problem* p, int type, int idx, const double* co
   q->px_stamp.clear(), q->px_meas.clear(), q->px_lm.clear(), q->px_cam.clear(), q->br_stamp.clear(), q->br_meas.clear(), q->br_lm.clear(), q->br_cam.clear();
   q->pr_stamp.clear(), q->pr_meas.clear(), q->pr_sensor.clear(), q->in_stamp.clear(), q->in_meas.clear();
   q->has_imu = false, q->n_bias = 0, q->bias_g.clear(), q->bias_a.clear(), q->n_lm = 0, q->lm.clear(), q->lm_const.clear();
-  q->dirty = true;
+  q->touch(hs_problem::kAll);
   int rc = HS_OK;
   std::vector<double> cps(size_t(8) * k);
   for (int j = 0; j < k; ++j) std::memcpy(&cps[8 * j], parameters[j], 64);

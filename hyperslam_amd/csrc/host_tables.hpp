@@ -214,6 +214,13 @@ struct hs_problem {
   bool own_stream = false;
   std::string err;
   bool dirty = true;  // tables changed since the last prepare()
+  // What changed (prepare() redoes only that). Structure sections: the sorted visual / prior / inertial tables; kTail = sizes + Tables only.
+  // Values: tables whose content changed while every size, index and sort order stayed (a sliding window re-sends the control points before
+  // every solve; the delta interface — hs_append_* / hs_retire_* / hs_stage — keeps the rest resident between solves).
+  enum : unsigned { kVis = 1, kPri = 2, kIne = 4, kTail = 8, kStructure = 15, vCp = 16, vCam = 32, vSensor = 64, vLm = 128, vImu = 256, vGravity = 512, vBias = 1024, kValues = 2032, kAll = 2047 };
+  unsigned changed = kAll;
+  void touch(unsigned what) { changed |= what, dirty = true; }
+  bool device_ahead = false;  // hs_solve moved the point on the device and the host copies have not been refreshed since (pull_state)
 
   // host tables (caller's table order)
   int k = 0, n_cp = 0;
@@ -358,6 +365,58 @@ namespace {
 
 int mfma_window_tiles(int bw);
 
+/// Value tables whose content changed (hs_problem::changed): control points + constancy mask, cameras, sensors, landmarks (device order), IMU
+/// parameters, gravity, bias points. Sizes, indices and sort orders are those of the last structural prepare().
+static int upload_values(hs_problem* p, unsigned what) {
+  hipStream_t s = p->stream;
+  if (what & hs_problem::vCp) {
+    HIP_TRY(p->d_cp.upload(p->cp, s));
+    HIP_TRY(p->d_cp_cand.reserve(p->cp.size()));
+    HIP_TRY(p->d_cp_const.upload(p->cp_const, s));
+    p->frozen_prefix = 0;
+    while (p->frozen_prefix < p->n_cp && p->cp_const[p->frozen_prefix]) ++p->frozen_prefix;
+  }
+  if (what & hs_problem::vCam) HIP_TRY(p->d_cam.upload(p->cam, s));
+  if (what & hs_problem::vSensor) HIP_TRY(p->d_sensor.upload(p->sensor, s));
+  if (what & hs_problem::vLm) {  // landmarks in device order
+    const VisualStructure& vs = p->vs;
+    HIP_TRY(p->d_lm.reserve(size_t(3) * p->n_lm));
+    HIP_TRY(p->d_lm_const.reserve(p->n_lm));
+    if (p->n_lm) {
+      void *a0, *a1;
+      HIP_TRY(p->batch.reserve_more(size_t(p->n_lm) * 25 + 64));
+      HIP_TRY(p->batch.alloc(p->d_lm.p, size_t(p->n_lm) * 24, &a0));
+      HIP_TRY(p->batch.alloc(p->d_lm_const.p, size_t(p->n_lm), &a1));
+      double* lm_dev = static_cast<double*>(a0);
+      uint8_t* lmc_dev = static_cast<uint8_t*>(a1);
+      for (int d = 0; d < p->n_lm; ++d) {
+        const int t = vs.table_of_dev[d];
+        for (int c = 0; c < 3; ++c) lm_dev[3 * d + c] = p->lm[3 * t + c];
+        lmc_dev[d] = p->lm_const[t];
+      }
+    }
+    HIP_TRY(p->d_lm_cand.reserve(size_t(3) * p->n_lm));
+  }
+  if (what & hs_problem::vImu) {
+    std::vector<ImuParams> ip(1);
+    std::memcpy(ip[0].T_bs, p->imu_T_bs, 56), std::memcpy(ip[0].i_g, p->imu_i_g, 48), std::memcpy(ip[0].i_a, p->imu_i_a, 48);
+    std::memcpy(ip[0].S_g, p->imu_S_g, 72), std::memcpy(ip[0].X_a, p->imu_X_a, 72);
+    HIP_TRY(p->d_imu.upload(ip, s));
+  }
+  if (what & hs_problem::vGravity) {
+    std::vector<double> grav(p->gravity, p->gravity + 3);
+    HIP_TRY(p->d_gravity.upload(grav, s));
+    HIP_TRY(p->d_gravity_cand.reserve(3));
+  }
+  if (what & hs_problem::vBias) {
+    HIP_TRY(p->d_bias_g.upload(p->bias_g, s));
+    HIP_TRY(p->d_bias_a.upload(p->bias_a, s));
+    HIP_TRY(p->d_bias_g_cand.reserve(p->bias_g.size() + 1));
+    HIP_TRY(p->d_bias_a_cand.reserve(p->bias_a.size() + 1));
+  }
+  return HS_OK;
+}
+
 int prepare(hs_problem* p) {
   if (!p->dirty) return HS_OK;
   struct BatchScope {  // every DBuf::upload below goes through the staging arena; sent in one piece at the end
@@ -373,59 +432,69 @@ int prepare(hs_problem* p) {
   if (p->k < 4 || p->k > 6) HS_FAIL(HS_ERR_INVALID, "device kernels are instantiated for spline orders 4, 5 and 6");
   HIP_TRY(hipSetDevice(p->device));
   hipStream_t s = p->stream;
+  // A failed prepare() leaves `changed` as it was: the next one redoes the same sections (the tables of a refused window stay refused).
+  const unsigned what = p->changed;
+  if (!(what & hs_problem::kStructure)) {  // values only: every size, index and sort order of the resident tables stands
+    const int rc = upload_values(p, what);
+    if (rc) return rc;
+    HIP_TRY(p->batch.flush(s));
+    p->dirty = false, p->changed = 0;
+    if (p->host_timing) {
+      const double t = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
+      p->host_prepare[1] += t, p->host_ms[1] += t;
+    }
+    return HS_OK;
+  }
   const int k = p->k, n_seg = p->n_cp - k + 1;
   const int n_px = int(p->px_stamp.size()), n_br = int(p->br_stamp.size());
-  for (int i = 0; i < n_px; ++i)
-    if (p->px_cam[i] < 0 || p->px_cam[i] >= p->n_cam) HS_FAIL(HS_ERR_INVALID, "pixel residual references a camera outside the camera table");
-  for (int i = 0; i < n_br; ++i)
-    if (p->br_cam[i] < 0 || p->br_cam[i] >= p->n_cam) HS_FAIL(HS_ERR_INVALID, "bearing residual references a camera outside the camera table");
-  VisualInput in = {k, p->n_cp, p->n_lm, p->t0, p->dt, n_px, n_br, p->px_stamp.data(), p->br_stamp.data(), p->px_lm.data(), p->br_lm.data()};
-  if (!build_visual_structure(in, &p->vs, &p->err)) return HS_ERR_INVALID;
-  p->vs.bw = std::max(p->vs.bw, p->min_bw);
+  const int n_vis = n_px + n_br;
+  const int n_pri = int(p->pr_stamp.size());
+  const int n_ine = int(p->in_stamp.size());
+  if (what & hs_problem::kVis) {
+    for (int i = 0; i < n_px; ++i)
+      if (p->px_cam[i] < 0 || p->px_cam[i] >= p->n_cam) HS_FAIL(HS_ERR_INVALID, "pixel residual references a camera outside the camera table");
+    for (int i = 0; i < n_br; ++i)
+      if (p->br_cam[i] < 0 || p->br_cam[i] >= p->n_cam) HS_FAIL(HS_ERR_INVALID, "bearing residual references a camera outside the camera table");
+    VisualInput in = {k, p->n_cp, p->n_lm, p->t0, p->dt, n_px, n_br, p->px_stamp.data(), p->br_stamp.data(), p->px_lm.data(), p->br_lm.data()};
+    if (!build_visual_structure(in, &p->vs, &p->err)) return HS_ERR_INVALID;
+    p->vs.bw = std::max(p->vs.bw, p->min_bw);
+  }
   const VisualStructure& vs = p->vs;
   if (6 * vs.bw > kBlock || (size_t(42) * (6 * vs.bw + 2) + size_t(6) * p->n_cp + 48) * 8 > size_t(p->chol_lds_max))
     HS_FAIL(HS_ERR_INVALID, "landmark tracks span too many control points for the LDS-resident banded factorisation");
   if (p->n_cp > 1024)  // 64 KiB of control points staged per workgroup; 96 KiB right-hand side + 49 KiB junction block in the backward sweep
     HS_FAIL(HS_ERR_INVALID, "window too long for the LDS-resident control-point table and backward sweep (more than 1024 control points)");
-  const int n_vis = n_px + n_br;
 
-  // ---- visual tables (landmark-major): written straight into the staging arena in the upload phase below ----
-  // landmarks in device order
-  std::vector<double> lm_dev(size_t(3) * p->n_lm);
-  std::vector<uint8_t> lmc_dev(p->n_lm);
-  for (int d = 0; d < p->n_lm; ++d) {
-    const int t = vs.table_of_dev[d];
-    for (int c = 0; c < 3; ++c) lm_dev[3 * d + c] = p->lm[3 * t + c];
-    lmc_dev[d] = p->lm_const[t];
-  }
   // ---- prior tables (segment-major) ----
-  const int n_pri = int(p->pr_stamp.size());
-  p->pr_order.resize(n_pri);
-  std::vector<int> first_tab(n_pri);
-  for (int i = 0; i < n_pri; ++i) {
-    first_tab[i] = h_segment_first(p->pr_stamp[i], p->t0, p->dt, k);
-    if (first_tab[i] < 0 || first_tab[i] >= n_seg) HS_FAIL(HS_ERR_INVALID, "prior residual stamp outside the valid range of the spline");
-    if (p->pr_sensor[i] < 0 || p->pr_sensor[i] >= p->n_sensor) HS_FAIL(HS_ERR_INVALID, "prior residual references a sensor outside the sensor table");
-    p->pr_order[i] = i;
+  std::vector<double> p_stamp, p_meas;
+  std::vector<int> p_sensor;
+  if (what & hs_problem::kPri) {
+    p->pr_order.resize(n_pri);
+    std::vector<int> first_tab(n_pri);
+    for (int i = 0; i < n_pri; ++i) {
+      first_tab[i] = h_segment_first(p->pr_stamp[i], p->t0, p->dt, k);
+      if (first_tab[i] < 0 || first_tab[i] >= n_seg) HS_FAIL(HS_ERR_INVALID, "prior residual stamp outside the valid range of the spline");
+      if (p->pr_sensor[i] < 0 || p->pr_sensor[i] >= p->n_sensor) HS_FAIL(HS_ERR_INVALID, "prior residual references a sensor outside the sensor table");
+      p->pr_order[i] = i;
+    }
+    std::stable_sort(p->pr_order.begin(), p->pr_order.end(), [&](int a, int b) { return first_tab[a] < first_tab[b]; });
+    p_stamp.resize(n_pri), p_meas.resize(size_t(7) * n_pri), p_sensor.resize(n_pri);
+    p->pr_first.resize(n_pri);
+    p->pr_seg_ptr.assign(n_seg + 1, 0);
+    for (int d = 0; d < n_pri; ++d) {
+      const int t = p->pr_order[d];
+      p_stamp[d] = p->pr_stamp[t], p_sensor[d] = p->pr_sensor[t], p->pr_first[d] = first_tab[t];
+      for (int c = 0; c < 7; ++c) p_meas[7 * d + c] = p->pr_meas[7 * t + c];
+      p->pr_seg_ptr[first_tab[t] + 1]++;
+    }
+    for (int sgm = 0; sgm < n_seg; ++sgm) p->pr_seg_ptr[sgm + 1] += p->pr_seg_ptr[sgm];
   }
-  std::stable_sort(p->pr_order.begin(), p->pr_order.end(), [&](int a, int b) { return first_tab[a] < first_tab[b]; });
-  std::vector<double> p_stamp(n_pri), p_meas(size_t(7) * n_pri);
-  std::vector<int> p_sensor(n_pri);
-  p->pr_first.resize(n_pri);
-  p->pr_seg_ptr.assign(n_seg + 1, 0);
-  for (int d = 0; d < n_pri; ++d) {
-    const int t = p->pr_order[d];
-    p_stamp[d] = p->pr_stamp[t], p_sensor[d] = p->pr_sensor[t], p->pr_first[d] = first_tab[t];
-    for (int c = 0; c < 7; ++c) p_meas[7 * d + c] = p->pr_meas[7 * t + c];
-    p->pr_seg_ptr[first_tab[t] + 1]++;
-  }
-  for (int sgm = 0; sgm < n_seg; ++sgm) p->pr_seg_ptr[sgm + 1] += p->pr_seg_ptr[sgm];
   // ---- inertial tables (segment-major) ----
-  const int n_ine = int(p->in_stamp.size());
   if (n_ine && !p->has_imu) HS_FAIL(HS_ERR_STATE, "inertial residuals need hs_set_imu");
   if (n_ine && p->kb != 4) HS_FAIL(HS_ERR_INVALID, "device kernels are instantiated for bias-spline order 4");
-  std::vector<double> i_stamp(n_ine), i_meas(size_t(6) * n_ine);
-  {
+  std::vector<double> i_stamp, i_meas;
+  if (what & hs_problem::kIne) {
+    i_stamp.resize(n_ine), i_meas.resize(size_t(6) * n_ine);
     std::vector<int> ft(n_ine), fbt(n_ine);
     p->in_order.resize(n_ine);
     for (int i = 0; i < n_ine; ++i) {
@@ -458,140 +527,127 @@ int prepare(hs_problem* p) {
 
   // ---- upload ----
   const auto host_t1 = std::chrono::steady_clock::now();
-  HIP_TRY(p->d_cp.upload(p->cp, s));
-  HIP_TRY(p->d_cp_cand.reserve(p->cp.size()));
-  HIP_TRY(p->d_cp_const.upload(p->cp_const, s));
-  p->frozen_prefix = 0;
-  while (p->frozen_prefix < p->n_cp && p->cp_const[p->frozen_prefix]) ++p->frozen_prefix;
-  HIP_TRY(p->d_cam.upload(p->cam, s));
-  HIP_TRY(p->d_sensor.upload(p->sensor, s));
-  HIP_TRY(p->d_lm.upload(lm_dev, s));
-  HIP_TRY(p->d_lm_cand.reserve(lm_dev.size()));
-  HIP_TRY(p->d_lm_const.upload(lmc_dev, s));
-  HIP_TRY(p->d_lm_ptr.upload(vs.lm_ptr, s));
-  HIP_TRY(p->d_lm_cfirst.upload(vs.lm_cfirst, s));
-  HIP_TRY(p->d_lm_ncp.upload(vs.lm_ncp, s));
-  HIP_TRY(p->d_lm_yoff.upload(vs.lm_yoff, s));
-  HIP_TRY(p->d_cf_ptr.upload(vs.cf_ptr, s));
+  {  // (a structural change of the visual tables re-orders the landmarks on the device: their values go with it)
+    const int rc = upload_values(p, (what & hs_problem::kValues) | ((what & hs_problem::kVis) ? unsigned(hs_problem::vLm) : 0u));
+    if (rc) return rc;
+  }
   const size_t nl = size_t(std::max(p->n_lm, 1));
-  {
-    std::vector<double> ones(3 * nl, 1.0);  // unobserved landmarks keep scale 1 (never visited by the landmark pass)
-    HIP_TRY(p->d_lm_scale.upload(ones, s));  // (copied into the staging arena right here: the vector may go)
-  }
-  HIP_TRY(p->d_lm_L.reserve(6 * nl));
-  HIP_TRY(p->d_lm_yhat.reserve(3 * nl));
-  HIP_TRY(p->d_lm_sb.reserve(3 * nl));
-  HIP_TRY(p->d_lm_D2.reserve(3 * nl));
-  HIP_TRY(p->d_lm_part.reserve(4 * (nl + size_t(n_vis) / kBlock + 2) + 4));  // (one entry per four landmarks; fused path: per chunk, <= landmarks, padded to the grid)
-  HIP_TRY(p->d_lm_gmax.reserve(nl));
-  HIP_TRY(p->d_Y.reserve(size_t(vs.y_total) + 1));
-  if (n_vis) {
-    // [stamp | measurement (3: a pixel leaves the third entry zero) | camera | type << 16 | position in the caller's tables] per residual, gathered in
-    // landmark-major order right where the staging copy will pick them up (as vectors first they cost an allocation, a zero fill and a copy of 1 MB per call)
-    HIP_TRY(p->d_v_stamp.reserve(n_vis));
-    HIP_TRY(p->d_v_meas.reserve(size_t(3) * n_vis));
-    HIP_TRY(p->d_v_info.reserve(n_vis));
-    HIP_TRY(p->d_v_dbgpos.reserve(n_vis));
-    HIP_TRY(p->batch.reserve_more(size_t(n_vis) * (8 + 24 + 4 + 4) + 4 * 32));
-    void *a0, *a1, *a2, *a3;
-    HIP_TRY(p->batch.alloc(p->d_v_stamp.p, size_t(n_vis) * 8, &a0));
-    HIP_TRY(p->batch.alloc(p->d_v_meas.p, size_t(n_vis) * 24, &a1));
-    HIP_TRY(p->batch.alloc(p->d_v_info.p, size_t(n_vis) * 4, &a2));
-    HIP_TRY(p->batch.alloc(p->d_v_dbgpos.p, size_t(n_vis) * 4, &a3));
-    double *v_stamp = static_cast<double*>(a0), *v_meas = static_cast<double*>(a1);
-    int *v_info = static_cast<int*>(a2), *v_dbgpos = static_cast<int*>(a3);
-    for (int q = 0; q < n_vis; ++q) {
-      const int ti = vs.table_idx[q];
-      if (vs.table_type[q] == HS_PIXEL) {
-        v_stamp[q] = p->px_stamp[ti];
-        v_meas[3 * q] = p->px_meas[2 * ti], v_meas[3 * q + 1] = p->px_meas[2 * ti + 1], v_meas[3 * q + 2] = 0.0;
-        v_info[q] = p->px_cam[ti];
-        v_dbgpos[q] = ti;
-      } else {
-        v_stamp[q] = p->br_stamp[ti];
-        for (int c = 0; c < 3; ++c) v_meas[3 * q + c] = p->br_meas[3 * ti + c];
-        v_info[q] = p->br_cam[ti] | (1 << 16);
-        v_dbgpos[q] = n_px + ti;
-      }
+  if (what & hs_problem::kVis) {
+    HIP_TRY(p->d_lm_ptr.upload(vs.lm_ptr, s));
+    HIP_TRY(p->d_lm_cfirst.upload(vs.lm_cfirst, s));
+    HIP_TRY(p->d_lm_ncp.upload(vs.lm_ncp, s));
+    HIP_TRY(p->d_lm_yoff.upload(vs.lm_yoff, s));
+    HIP_TRY(p->d_cf_ptr.upload(vs.cf_ptr, s));
+    {
+      std::vector<double> ones(3 * nl, 1.0);  // unobserved landmarks keep scale 1 (never visited by the landmark pass)
+      HIP_TRY(p->d_lm_scale.upload(ones, s));  // (copied into the staging arena right here: the vector may go)
     }
-  }
-  HIP_TRY(p->d_v_lm.upload(vs.lm_dev, s));
-  HIP_TRY(p->d_v_first.upload(vs.first, s));
-  HIP_TRY(p->d_v_pos.upload(vs.pos, s));
-  HIP_TRY(p->d_v_seg_ptr.upload(vs.seg_ptr, s));
-  // ---- fused build (kernels_build.hpp) or the record path (a lane group per J'J band tile: k bw - k (k - 1) / 2 <= 256, i.e. bands of up to 65 / 53 /
-  //      45 control points at orders 4 / 5 / 6; a landmark with more residuals than a chunk has lanes; no chunk geometry that fits the LDS) ----
-  //      Window-wide bands (the steady state of a sliding window: tracks as long as the window, bw(bw + 1) / 2 > 256 window tiles) take the
-  //      tiles of the landmark term in passes (kernels_build.hpp phase 5). HS_BUILD_PATH=records: the record path everywhere; =narrow: the
-  //      fused build for at most 256 window tiles only (round 4's rule) — measurement switches, like HS_DEBUG_FLAGS.
-  {
-    const int ntile_ = vs.bw * (vs.bw + 1) / 2, nband_ = k * vs.bw - k * (k - 1) / 2;
-    const char* env = std::getenv("HS_BUILD_PATH");
-    const bool narrow_only = env && std::strcmp(env, "narrow") == 0;
-    p->fused = n_vis > 0 && nband_ <= kBlock && vs.bw <= 64 && (ntile_ <= kBlock || !narrow_only) && !(env && std::strcmp(env, "records") == 0);
-  }
-  if (p->fused) {
-    // chunk geometry: R residuals (lanes) and L landmarks per chunk, sized for two workgroups per CU (every phase of the kernel is an LDS
-    // gather: latency bound on a lone wave per SIMD). HS_BUILD_R / HS_BUILD_L: tuning overrides.
-    int R0 = k == 4 ? 128 : k == 5 ? 112 : 96, L0 = k == 4 ? 12 : k == 5 ? 11 : 10;
-    if (const char* e = std::getenv("HS_BUILD_R")) R0 = std::max(32, std::min(kBlock, std::atoi(e)));
-    if (const char* e = std::getenv("HS_BUILD_L")) L0 = std::max(1, std::min(24, std::atoi(e)));  // (<= 24: 9 L + 8 lanes of phase 2a, L lanes of one wave in 4a)
-    auto lds_bytes = [&](int r, int l) { return size_t(build_lds_layout(k, vs.bw, r, l).total_doubles) * 8; };
-    const bool overridden = std::getenv("HS_BUILD_R") || std::getenv("HS_BUILD_L");  // (a tuning run asks for exactly this geometry, one workgroup per CU if need be)
-    p->fused = choose_build_geometry(k, R0, L0, size_t(overridden ? 156 : 79) * 1024, size_t(156) * 1024, lds_bytes, &p->build_R, &p->build_L) &&
-               build_chunks(vs, p->n_cp, p->build_R, p->build_L, &p->h_ch_ptr, &p->h_gw_ptr, &p->h_gw_cf, &p->h_ch_desc);
-    p->build_lds = p->fused ? lds_bytes(p->build_R, p->build_L) : 0;
-    if (p->fused && !std::getenv("HS_BUILD_ORDER"))  // (HS_BUILD_ORDER=table: chunks in table order, measurement switch)
-      order_chunks_for_dispatch(vs, k, p->n_cu, &p->h_ch_desc, int(p->h_ch_ptr.size()) - 1);
-  }
-  if (!p->fused) {
-    HIP_TRY(p->d_v_rec.reserve(size_t(n_vis) * (8 + 12 * k) + 1));
-    HIP_TRY(p->d_v_rec_alt.reserve(size_t(n_vis) * (8 + 12 * k) + 1));
-  }
-  HIP_TRY(p->d_p_stamp.upload(p_stamp, s));
-  HIP_TRY(p->d_p_meas.upload(p_meas, s));
-  HIP_TRY(p->d_p_sensor.upload(p_sensor, s));
-  HIP_TRY(p->d_p_first.upload(p->pr_first, s));
-  HIP_TRY(p->d_p_seg_ptr.upload(p->pr_seg_ptr, s));
-  HIP_TRY(p->d_p_rec.reserve(size_t(n_pri) * (6 + 36 * k) + 1));
-  HIP_TRY(p->d_i_stamp.upload(i_stamp, s));
-  HIP_TRY(p->d_i_meas.upload(i_meas, s));
-  HIP_TRY(p->d_i_first.upload(p->in_first, s));
-  HIP_TRY(p->d_i_first_bias.upload(p->in_first_bias, s));
-  HIP_TRY(p->d_i_seg_ptr.upload(p->in_seg_ptr, s));
-  HIP_TRY(p->d_i_bias_ptr.upload(p->in_bias_ptr, s));
-  {  // k_border_forward: column b of S_pb is zero above the first pose block row its bias point (or gravity) meets a residual in
-    const int nbias = p->has_imu ? p->n_bias : 0, nbd_ = nbias ? 6 * nbias + 2 : 0;
-    const int n_wg = (nbd_ + kBorderCols - 1) / kBorderCols;
-    std::vector<int> start(std::max(n_wg, 1), 0);
-    for (int w = 0; w < n_wg; ++w) {
-      int first = p->n_cp;
-      for (int c = w * kBorderCols; c < std::min(nbd_, (w + 1) * kBorderCols); ++c) {
-        int rec = 0;  // gravity columns: the first inertial record
-        if (c < 6 * nbias) {
-          const int beta = (c < 3 * nbias ? c : c - 3 * nbias) / 3;
-          rec = p->in_bias_ptr[std::max(beta - p->kb + 1, 0)];  // first record whose bias segment reaches bias point beta
+    HIP_TRY(p->d_lm_L.reserve(6 * nl));
+    HIP_TRY(p->d_lm_yhat.reserve(3 * nl));
+    HIP_TRY(p->d_lm_sb.reserve(3 * nl));
+    HIP_TRY(p->d_lm_D2.reserve(3 * nl));
+    HIP_TRY(p->d_lm_part.reserve(4 * (nl + size_t(n_vis) / kBlock + 2) + 4));  // (one entry per four landmarks; fused path: per chunk, <= landmarks, padded to the grid)
+    HIP_TRY(p->d_lm_gmax.reserve(nl));
+    HIP_TRY(p->d_Y.reserve(size_t(vs.y_total) + 1));
+    if (n_vis) {
+      // [stamp | measurement (3: a pixel leaves the third entry zero) | camera | type << 16 | position in the caller's tables] per residual, gathered in
+      // landmark-major order right where the staging copy will pick them up (as vectors first they cost an allocation, a zero fill and a copy of 1 MB per call)
+      HIP_TRY(p->d_v_stamp.reserve(n_vis));
+      HIP_TRY(p->d_v_meas.reserve(size_t(3) * n_vis));
+      HIP_TRY(p->d_v_info.reserve(n_vis));
+      HIP_TRY(p->d_v_dbgpos.reserve(n_vis));
+      HIP_TRY(p->batch.reserve_more(size_t(n_vis) * (8 + 24 + 4 + 4) + 4 * 32));
+      void *a0, *a1, *a2, *a3;
+      HIP_TRY(p->batch.alloc(p->d_v_stamp.p, size_t(n_vis) * 8, &a0));
+      HIP_TRY(p->batch.alloc(p->d_v_meas.p, size_t(n_vis) * 24, &a1));
+      HIP_TRY(p->batch.alloc(p->d_v_info.p, size_t(n_vis) * 4, &a2));
+      HIP_TRY(p->batch.alloc(p->d_v_dbgpos.p, size_t(n_vis) * 4, &a3));
+      double *v_stamp = static_cast<double*>(a0), *v_meas = static_cast<double*>(a1);
+      int *v_info = static_cast<int*>(a2), *v_dbgpos = static_cast<int*>(a3);
+      for (int q = 0; q < n_vis; ++q) {
+        const int ti = vs.table_idx[q];
+        if (vs.table_type[q] == HS_PIXEL) {
+          v_stamp[q] = p->px_stamp[ti];
+          v_meas[3 * q] = p->px_meas[2 * ti], v_meas[3 * q + 1] = p->px_meas[2 * ti + 1], v_meas[3 * q + 2] = 0.0;
+          v_info[q] = p->px_cam[ti];
+          v_dbgpos[q] = ti;
+        } else {
+          v_stamp[q] = p->br_stamp[ti];
+          for (int c = 0; c < 3; ++c) v_meas[3 * q + c] = p->br_meas[3 * ti + c];
+          v_info[q] = p->br_cam[ti] | (1 << 16);
+          v_dbgpos[q] = n_px + ti;
         }
-        if (rec < n_ine) first = std::min(first, p->in_first[rec]);  // (records are segment-major: the earliest control point)
       }
-      start[w] = first;
     }
-    HIP_TRY(p->d_bfwd_start.upload(start, s));
+    HIP_TRY(p->d_v_lm.upload(vs.lm_dev, s));
+    HIP_TRY(p->d_v_first.upload(vs.first, s));
+    HIP_TRY(p->d_v_pos.upload(vs.pos, s));
+    HIP_TRY(p->d_v_seg_ptr.upload(vs.seg_ptr, s));
+    // ---- fused build (kernels_build.hpp) or the record path (a lane group per J'J band tile: k bw - k (k - 1) / 2 <= 256, i.e. bands of up to 65 / 53 /
+    //      45 control points at orders 4 / 5 / 6; a landmark with more residuals than a chunk has lanes; no chunk geometry that fits the LDS) ----
+    //      Window-wide bands (the steady state of a sliding window: tracks as long as the window, bw(bw + 1) / 2 > 256 window tiles) take the
+    //      tiles of the landmark term in passes (kernels_build.hpp phase 5). HS_BUILD_PATH=records: the record path everywhere; =narrow: the
+    //      fused build for at most 256 window tiles only (round 4's rule) — measurement switches, like HS_DEBUG_FLAGS.
+    {
+      const int ntile_ = vs.bw * (vs.bw + 1) / 2, nband_ = k * vs.bw - k * (k - 1) / 2;
+      const char* env = std::getenv("HS_BUILD_PATH");
+      const bool narrow_only = env && std::strcmp(env, "narrow") == 0;
+      p->fused = n_vis > 0 && nband_ <= kBlock && vs.bw <= 64 && (ntile_ <= kBlock || !narrow_only) && !(env && std::strcmp(env, "records") == 0);
+    }
+    if (p->fused) {
+      // chunk geometry: R residuals (lanes) and L landmarks per chunk, sized for two workgroups per CU (every phase of the kernel is an LDS
+      // gather: latency bound on a lone wave per SIMD). HS_BUILD_R / HS_BUILD_L: tuning overrides.
+      int R0 = k == 4 ? 128 : k == 5 ? 112 : 96, L0 = k == 4 ? 12 : k == 5 ? 11 : 10;
+      if (const char* e = std::getenv("HS_BUILD_R")) R0 = std::max(32, std::min(kBlock, std::atoi(e)));
+      if (const char* e = std::getenv("HS_BUILD_L")) L0 = std::max(1, std::min(24, std::atoi(e)));  // (<= 24: 9 L + 8 lanes of phase 2a, L lanes of one wave in 4a)
+      auto lds_bytes = [&](int r, int l) { return size_t(build_lds_layout(k, vs.bw, r, l).total_doubles) * 8; };
+      const bool overridden = std::getenv("HS_BUILD_R") || std::getenv("HS_BUILD_L");  // (a tuning run asks for exactly this geometry, one workgroup per CU if need be)
+      p->fused = choose_build_geometry(k, R0, L0, size_t(overridden ? 156 : 79) * 1024, size_t(156) * 1024, lds_bytes, &p->build_R, &p->build_L) &&
+                 build_chunks(vs, p->n_cp, p->build_R, p->build_L, &p->h_ch_ptr, &p->h_gw_ptr, &p->h_gw_cf, &p->h_ch_desc);
+      p->build_lds = p->fused ? lds_bytes(p->build_R, p->build_L) : 0;
+      if (p->fused && !std::getenv("HS_BUILD_ORDER"))  // (HS_BUILD_ORDER=table: chunks in table order, measurement switch)
+        order_chunks_for_dispatch(vs, k, p->n_cu, &p->h_ch_desc, int(p->h_ch_ptr.size()) - 1);
+    }
+    if (!p->fused) {
+      HIP_TRY(p->d_v_rec.reserve(size_t(n_vis) * (8 + 12 * k) + 1));
+      HIP_TRY(p->d_v_rec_alt.reserve(size_t(n_vis) * (8 + 12 * k) + 1));
+    }
   }
-  HIP_TRY(p->d_i_rec.reserve(size_t(n_ine) * (18 + 36 * k + 2 * p->kb) + 1));
-  {
-    std::vector<ImuParams> ip(1);
-    std::memcpy(ip[0].T_bs, p->imu_T_bs, 56), std::memcpy(ip[0].i_g, p->imu_i_g, 48), std::memcpy(ip[0].i_a, p->imu_i_a, 48);
-    std::memcpy(ip[0].S_g, p->imu_S_g, 72), std::memcpy(ip[0].X_a, p->imu_X_a, 72);
-    HIP_TRY(p->d_imu.upload(ip, s));
-    std::vector<double> grav(p->gravity, p->gravity + 3);
-    HIP_TRY(p->d_gravity.upload(grav, s));
+  if (what & hs_problem::kPri) {
+    HIP_TRY(p->d_p_stamp.upload(p_stamp, s));
+    HIP_TRY(p->d_p_meas.upload(p_meas, s));
+    HIP_TRY(p->d_p_sensor.upload(p_sensor, s));
+    HIP_TRY(p->d_p_first.upload(p->pr_first, s));
+    HIP_TRY(p->d_p_seg_ptr.upload(p->pr_seg_ptr, s));
+    HIP_TRY(p->d_p_rec.reserve(size_t(n_pri) * (6 + 36 * k) + 1));
   }
-  HIP_TRY(p->d_gravity_cand.reserve(3));
-  HIP_TRY(p->d_bias_g.upload(p->bias_g, s));
-  HIP_TRY(p->d_bias_a.upload(p->bias_a, s));
-  HIP_TRY(p->d_bias_g_cand.reserve(p->bias_g.size() + 1));
-  HIP_TRY(p->d_bias_a_cand.reserve(p->bias_a.size() + 1));
+  if (what & hs_problem::kIne) {
+    HIP_TRY(p->d_i_stamp.upload(i_stamp, s));
+    HIP_TRY(p->d_i_meas.upload(i_meas, s));
+    HIP_TRY(p->d_i_first.upload(p->in_first, s));
+    HIP_TRY(p->d_i_first_bias.upload(p->in_first_bias, s));
+    HIP_TRY(p->d_i_seg_ptr.upload(p->in_seg_ptr, s));
+    HIP_TRY(p->d_i_bias_ptr.upload(p->in_bias_ptr, s));
+    {  // k_border_forward: column b of S_pb is zero above the first pose block row its bias point (or gravity) meets a residual in
+      const int nbias = p->has_imu ? p->n_bias : 0, nbd_ = nbias ? 6 * nbias + 2 : 0;
+      const int n_wg = (nbd_ + kBorderCols - 1) / kBorderCols;
+      std::vector<int> start(std::max(n_wg, 1), 0);
+      for (int w = 0; w < n_wg; ++w) {
+        int first = p->n_cp;
+        for (int c = w * kBorderCols; c < std::min(nbd_, (w + 1) * kBorderCols); ++c) {
+          int rec = 0;  // gravity columns: the first inertial record
+          if (c < 6 * nbias) {
+            const int beta = (c < 3 * nbias ? c : c - 3 * nbias) / 3;
+            rec = p->in_bias_ptr[std::max(beta - p->kb + 1, 0)];  // first record whose bias segment reaches bias point beta
+          }
+          if (rec < n_ine) first = std::min(first, p->in_first[rec]);  // (records are segment-major: the earliest control point)
+        }
+        start[w] = first;
+      }
+      HIP_TRY(p->d_bfwd_start.upload(start, s));
+    }
+    HIP_TRY(p->d_i_rec.reserve(size_t(n_ine) * (18 + 36 * k + 2 * p->kb) + 1));
+  }
   p->nb_ine = (n_ine + kInertialBlock - 1) / kInertialBlock;
   const int np = 6 * p->n_cp, ncb = 6 * vs.bw;
   HIP_TRY(p->d_scale_p.reserve(np));
@@ -695,7 +751,8 @@ int prepare(hs_problem* p) {
     // Schur stage of 71.2 / 65.8 / 66.5 / 68.1 / 70.9 us: fewer, larger partials for k_assemble against less parallelism)
     const int per_wg = 12;
     std::vector<int> gw_ptr(p->n_cp + 1, 0), gw_cf;
-    if (p->fused) {  // the chunks of the fused build take the place of the k_group_gram workgroups
+    if (!(what & hs_problem::kVis)) {  // (the work list of the visual factors stands)
+    } else if (p->fused) {  // the chunks of the fused build take the place of the k_group_gram workgroups
       HIP_TRY(p->d_gw_ptr.upload(p->h_gw_ptr, s));
       HIP_TRY(p->d_gw_cf.upload(p->h_gw_cf, s));
       HIP_TRY(p->d_ch_ptr.upload(p->h_ch_ptr, s));
@@ -786,7 +843,8 @@ int prepare(hs_problem* p) {
   // 268435456 backward sweeps one block row per step    536870912 bordered systems one-ended    1073741824 no speculative linearisation at the candidate    67108864 k_commit in every iteration of a speculative solve
   T.st = p->d_state.p;
   HIP_TRY(p->batch.flush(s));  // (the staging arena outlives this call: no host synchronisation)
-  p->dirty = false;
+  p->dirty = false, p->changed = 0;
+  if ((what & hs_problem::kValues) == hs_problem::kValues) p->device_ahead = false;  // (every variable was just sent: host and device agree)
   if (p->host_timing) {
     const auto host_t2 = std::chrono::steady_clock::now();
     p->host_prepare[0] = std::chrono::duration<double, std::milli>(host_t1 - host_t0).count();

@@ -58,6 +58,13 @@ int HSF(get_gravity)(hs_problem*, double*);
 int HSF(sample_trajectory)(hs_problem*, int, const double*, double*, double*, double*);
 int HSF(process_tracks)(hs_problem*, double, int, const double*, const double*, double*, double*, double*);
 int HSF(set_stage_timing)(hs_problem*, int);
+int HSF(append_landmarks)(hs_problem*, int, const double*, const uint8_t*, int32_t*);
+int HSF(append_bearing_residuals)(hs_problem*, int, const double*, const double*, const int32_t*, const int32_t*);
+int HSF(append_prior_residuals)(hs_problem*, int, const double*, const double*, const int32_t*);
+int HSF(append_inertial_residuals)(hs_problem*, int, const double*, const double*);
+int HSF(retire_landmarks)(hs_problem*, int, const int32_t*, int32_t*);
+int HSF(retire_residuals_before)(hs_problem*, int, double);
+int HSF(stage)(hs_problem*);
 }
 
 namespace hyper_hip {
@@ -231,6 +238,7 @@ class Optimizer {
     Vec3 position{0, 0, 0};
     std::vector<Observation> observations;
     Stamp lower = 0, upper = 0;  // AbstractLandmark::range() (landmarks/abstract.cpp:62-99)
+    int32_t index = -1;          // row of the library's landmark table (delta interface)
   };
   struct BiasPoint {
     Stamp stamp;
@@ -242,6 +250,8 @@ class Optimizer {
       : opt_(options), cameras_(cameras), has_imu_(imu != nullptr) {
     if (imu) imu_ = *imu;
     if (HSF(create)(device, nullptr, &handle_) != HS_OK) throw std::runtime_error("hs_create failed (no usable GPU?)");
+    // HS_REPLAY_FULL_TABLES=1 (A/B and test switch): every table rebuilt and re-sent inside optimize(), as up to round 5
+    if (const char* e = std::getenv("HS_REPLAY_FULL_TABLES")) delta_ = std::atoi(e) == 0;
   }
   ~Optimizer() {
     if (handle_) HSF(destroy)(handle_);
@@ -266,9 +276,19 @@ class Optimizer {
   }
 
   // ---- AbstractOptimizer::submit (abstract.cpp:74-147) ----
-  void submit(const VisualTracks& m) { submitImpl(m.stamp, [&](Stamp s) { process(m, s); }); }
-  void submit(const InertialMeasurement& m) { submitImpl(m.stamp, [&](Stamp s) { process(m, s); }); }
-  void submit(const ManifoldMeasurement& m) { submitImpl(m.stamp, [&](Stamp s) { process(m, s); }); }
+  void submit(const VisualTracks& m) { submitImpl(m.stamp, [&](Stamp s) { process(m, s); }), stage(); }
+  void submit(const InertialMeasurement& m) { submitImpl(m.stamp, [&](Stamp s) { process(m, s); }), stage(); }
+  void submit(const ManifoldMeasurement& m) { submitImpl(m.stamp, [&](Stamp s) { process(m, s); }), stage(); }
+
+  /// End of a message (Backend::spin between two submits, backend.cpp:143-145): whatever the message changed is sorted and sent now, so that the
+  /// optimize() a later message triggers finds the tables resident.
+  void stage() {
+    if (!delta_ || !staged_dirty_) return;
+    const auto w0 = std::chrono::steady_clock::now();
+    check(HSF(stage)(handle_), "stage");
+    staged_dirty_ = false;
+    wall_stage_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+  }
 
   // ---- AbstractOptimizer::setWindow (abstract.cpp:40-62) ----
   void setWindow(const Range& window) {
@@ -280,6 +300,27 @@ class Optimizer {
     updateLandmarks(window_);
     updateState(window_);
     gravity_constant_ = window_.size() < range.size();  // abstract.cpp:57-61
+    if (delta_) pushState();
+  }
+
+  /// Delta interface: the variables and flags a window change touches (control points + constancy, sensors, bias points, gravity) — small
+  /// tables, sent whole; the residual and landmark tables follow the messages row by row (process(), updateLandmarks(), updateState()).
+  void pushState() {
+    staged_dirty_ = true;
+    uploadState();
+    static const double identity[7] = {0, 0, 0, 1, 0, 0, 0};
+    check(HSF(set_sensors)(handle_, 1, identity), "set_sensors");
+    if (has_imu_) {
+      const SE3& x = imu_.transformation;
+      const double Tb[7] = {x.q.x, x.q.y, x.q.z, x.q.w, x.p[0], x.p[1], x.p[2]};
+      std::vector<double> bg(4 * bias_.size()), ba(4 * bias_.size());
+      for (size_t j = 0; j < bias_.size(); ++j)
+        for (int c = 0; c < 4; ++c) bg[4 * j + c] = c < 3 ? bias_[j].g[c] : bias_[j].stamp, ba[4 * j + c] = c < 3 ? bias_[j].a[c] : bias_[j].stamp;
+      check(HSF(set_imu)(handle_, Tb, imu_.gyroscope_intrinsics.data(), imu_.accelerometer_intrinsics.data(), imu_.gyroscope_sensitivity.data(),
+                         imu_.accelerometer_axes_offsets.data(), imu_.bias_order, bias_.front().stamp, imu_.bias_separation, int(bias_.size()), bg.data(), ba.data(), 0),
+            "set_imu");
+      check(HSF(set_gravity)(handle_, gravity_.data(), gravity_constant_), "set_gravity");
+    }
   }
 
   /// Builds the flat tables of the current window: the content upstream keeps in ceres::Problem (parameter blocks + residual
@@ -306,7 +347,11 @@ class Optimizer {
     }
     // landmarks + bearing residuals (the runtime uses bearing factors, abstract.cpp:243-260)
     int32_t li = 0;
-    for (auto& [id, lm] : landmarks_) {
+    std::vector<Landmark*> rows;  // (delta interface: the library's row order = order of arrival minus the retired ones; identifier order otherwise)
+    for (auto& [id, lm] : landmarks_) rows.push_back(&lm);
+    if (delta_) std::sort(rows.begin(), rows.end(), [](const Landmark* a, const Landmark* b) { return a->index < b->index; });
+    for (Landmark* row : rows) {
+      Landmark& lm = *row;
       if (order) order->push_back(&lm);
       t.landmarks.insert(t.landmarks.end(), lm.position.begin(), lm.position.end());
       for (const Observation& ob : lm.observations) {
@@ -339,11 +384,16 @@ class Optimizer {
   /// CeresOptimizer::optimize (optimizer.cpp:276-280): flat tables -> hs_solve -> write back in place.
   void optimize() {
     const auto wall0 = std::chrono::steady_clock::now();
+    // Delta interface (default): the tables are already resident — appended row by row in process(), retired in setWindow(), staged at the end
+    // of submit() — and this function only solves and reads back. The flat tables are still built when a test harness observes the call.
+    const bool hooks = bool(before_solve) || bool(after_solve);
     std::vector<Landmark*> order;
-    const WindowTables t = buildTables(&order);
-    t.upload<&HSF(set_spline), &HSF(set_cameras), &HSF(set_sensors), &HSF(set_landmarks), &HSF(set_imu), &HSF(set_gravity), &HSF(set_bearing_residuals),
-             &HSF(set_pixel_residuals), &HSF(set_prior_residuals), &HSF(set_inertial_residuals)>(handle_, [&](int rc, const char* what) { check(rc, what); });
-    if (t.br_stamp.empty() && t.in_stamp.empty() && t.pr_stamp.empty()) return;  // nothing to optimise yet
+    WindowTables t;
+    if (!delta_ || hooks) t = buildTables(&order);
+    if (!delta_)
+      t.upload<&HSF(set_spline), &HSF(set_cameras), &HSF(set_sensors), &HSF(set_landmarks), &HSF(set_imu), &HSF(set_gravity), &HSF(set_bearing_residuals),
+               &HSF(set_pixel_residuals), &HSF(set_prior_residuals), &HSF(set_inertial_residuals)>(handle_, [&](int rc, const char* what) { check(rc, what); });
+    if (num_observations_ == 0 && inertials_.empty() && priors_.empty()) return;  // nothing to optimise yet
     if (before_solve) before_solve(t, num_optimizations_);
     const auto wall1 = std::chrono::steady_clock::now();
     last_iterations_.assign(size_t(opt_.max_num_iterations) + 1, hs_iteration{});
@@ -351,26 +401,40 @@ class Optimizer {
     const auto wall2 = std::chrono::steady_clock::now();
     ++num_optimizations_;
     // write back in place (the reference's solver mutates the variables through raw double*, optimizer.cpp:299-305,354-356)
-    WindowTables r = t;  // result tables: the same window at the solver's final point
     const int n_cp = int(cp_.size());
-    check(HSF(get_control_points)(handle_, r.cp.data()), "get_control_points");
+    std::vector<double>& cpv = readback_[0];
+    std::vector<double>& lmv = readback_[1];
+    std::vector<double>& bgv = readback_[2];
+    std::vector<double>& bav = readback_[3];
+    cpv.resize(size_t(8) * n_cp), lmv.resize(3 * landmarks_.size()), bgv.resize(4 * bias_.size()), bav.resize(4 * bias_.size());
+    check(HSF(get_control_points)(handle_, cpv.data()), "get_control_points");
     for (int j = 0; j < n_cp; ++j) {
-      const double* o = &r.cp[8 * j];
+      const double* o = &cpv[8 * j];
       cp_[j].T = SE3{Quat{o[0], o[1], o[2], o[3]}, {o[4], o[5], o[6]}};
     }
-    if (!order.empty()) check(HSF(get_landmarks)(handle_, r.landmarks.data()), "get_landmarks");
-    for (size_t l = 0; l < order.size(); ++l) order[l]->position = {r.landmarks[3 * l], r.landmarks[3 * l + 1], r.landmarks[3 * l + 2]};
+    if (!landmarks_.empty()) check(HSF(get_landmarks)(handle_, lmv.data()), "get_landmarks");
+    if (delta_) {
+      for (auto& [id, lm] : landmarks_) lm.position = {lmv[3 * size_t(lm.index)], lmv[3 * size_t(lm.index) + 1], lmv[3 * size_t(lm.index) + 2]};
+    } else {
+      for (size_t l = 0; l < order.size(); ++l) order[l]->position = {lmv[3 * l], lmv[3 * l + 1], lmv[3 * l + 2]};
+    }
+    double grav[3] = {gravity_[0], gravity_[1], gravity_[2]};
     if (has_imu_) {
-      check(HSF(get_bias)(handle_, r.bias_g.data(), r.bias_a.data()), "get_bias");
+      check(HSF(get_bias)(handle_, bgv.data(), bav.data()), "get_bias");
       for (size_t j = 0; j < bias_.size(); ++j)
-        for (int c = 0; c < 3; ++c) bias_[j].g[c] = r.bias_g[4 * j + c], bias_[j].a[c] = r.bias_a[4 * j + c];
-      check(HSF(get_gravity)(handle_, r.gravity), "get_gravity");
-      std::copy(r.gravity, r.gravity + 3, gravity_.begin());
+        for (int c = 0; c < 3; ++c) bias_[j].g[c] = bgv[4 * j + c], bias_[j].a[c] = bav[4 * j + c];
+      check(HSF(get_gravity)(handle_, grav), "get_gravity");
+      std::copy(grav, grav + 3, gravity_.begin());
     }
     const auto wall3 = std::chrono::steady_clock::now();
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     wall_tables_ms_ += ms(wall0, wall1), wall_solve_ms_ += ms(wall1, wall2), wall_readback_ms_ += ms(wall2, wall3);
-    if (after_solve) after_solve(t, r, last_summary_, last_iterations_, num_optimizations_ - 1);
+    if (after_solve) {
+      WindowTables r = t;  // result tables: the same window at the solver's final point
+      r.cp = cpv, r.landmarks = lmv;
+      if (has_imu_) r.bias_g = bgv, r.bias_a = bav, std::copy(grav, grav + 3, r.gravity);
+      after_solve(t, r, last_summary_, last_iterations_, num_optimizations_ - 1);
+    }
   }
   /// Observers of optimize() (test harnesses only): `before_solve` sees the tables of the window right after they were handed to
   /// the library, `after_solve` additionally the same tables at the solver's final point with its summary and iteration records.
@@ -379,6 +443,9 @@ class Optimizer {
   hs_problem* handle() const { return handle_; }
   /// Host wall-clock split of all optimize() calls so far: building + uploading the tables, hs_solve (structure, launches, sync), read-back.
   std::array<double, 3> wallSplitMs() const { return {wall_tables_ms_, wall_solve_ms_, wall_readback_ms_}; }
+  /// Host wall-clock of all hs_stage calls (between solves, off optimize()'s clock) and whether the delta interface is in use.
+  double wallStageMs() const { return wall_stage_ms_; }
+  bool deltaInterface() const { return delta_; }
 
   /// The SIGUSR1 dump of apps/hyperslam/main.cpp:52-80: the state sampled at `rate` Hz over its range, one line per sample
   /// `stamp, qx, qy, qz, qw, px, py, pz` (scientific, 20 digits, stamp = root + sample). The samples are evaluated by the
@@ -520,20 +587,38 @@ class Optimizer {
     if (cameras_.size() != 2) throw std::runtime_error("Unsupported camera configuration.");
     const int n = int(m.identifiers.size());
     if (n == 0) return;
-    uploadState();
+    if (!delta_) uploadState();  // (delta interface: the state was sent when the window last changed, pushState())
     std::vector<double> p0(2 * size_t(n)), p1(2 * size_t(n)), b0(3 * size_t(n)), b1(3 * size_t(n)), pw(3 * size_t(n));
     for (int i = 0; i < n; ++i) p0[2 * i] = m.P0[i][0], p0[2 * i + 1] = m.P0[i][1], p1[2 * i] = m.P1[i][0], p1[2 * i + 1] = m.P1[i][1];
     check(HSF(process_tracks)(handle_, stamp, n, p0.data(), p1.data(), b0.data(), b1.data(), pw.data()), "process_tracks");
+    std::vector<Landmark*> fresh, seen(n);
+    std::vector<double> fresh_xyz;
     for (int i = 0; i < n; ++i) {
       auto [it, inserted] = landmarks_.try_emplace(m.identifiers[i]);
       Landmark& lm = it->second;
       if (inserted) {
         lm.position = {pw[3 * i], pw[3 * i + 1], pw[3 * i + 2]};
         lm.lower = lm.upper = stamp;
+        fresh.push_back(&lm), fresh_xyz.insert(fresh_xyz.end(), lm.position.begin(), lm.position.end());
       }
       lm.observations.push_back({stamp, 0, {b0[3 * i], b0[3 * i + 1], b0[3 * i + 2]}});
       lm.observations.push_back({stamp, 1, {b1[3 * i], b1[3 * i + 1], b1[3 * i + 2]}});
       lm.lower = std::min(lm.lower, stamp), lm.upper = std::max(lm.upper, stamp);
+      seen[i] = &lm;
+    }
+    num_observations_ += 2 * size_t(n);
+    if (delta_) {  // addLandmark + add(VisualBearingObservation&) x 2 per track (abstract.cpp:243-260)
+      int32_t first = 0;
+      check(HSF(append_landmarks)(handle_, int(fresh.size()), fresh_xyz.data(), nullptr, &first), "append_landmarks");
+      for (size_t l = 0; l < fresh.size(); ++l) fresh[l]->index = first + int32_t(l);
+      std::vector<double> st(2 * size_t(n), stamp), br(6 * size_t(n));
+      std::vector<int32_t> li(2 * size_t(n)), cam(2 * size_t(n));
+      for (int i = 0; i < n; ++i) {
+        li[2 * i] = li[2 * i + 1] = seen[i]->index, cam[2 * i] = 0, cam[2 * i + 1] = 1;
+        for (int c = 0; c < 3; ++c) br[6 * i + c] = b0[3 * i + c], br[6 * i + 3 + c] = b1[3 * i + c];
+      }
+      check(HSF(append_bearing_residuals)(handle_, 2 * n, st.data(), br.data(), li.data(), cam.data()), "append_bearing_residuals");
+      staged_dirty_ = true;
     }
   }
   /// Control points and cameras as the library needs them for evaluation-only calls (tracks, trajectory samples).
@@ -563,6 +648,7 @@ class Optimizer {
     InertialMeasurement c = m;
     c.stamp = stamp;
     inertials_.push_back(c);
+    if (delta_) check(HSF(append_inertial_residuals)(handle_, 1, &c.stamp, c.value.data()), "append_inertial_residuals"), staged_dirty_ = true;
   }
   /// abstract.cpp:266-270: a pose measurement becomes a ManifoldObservation of the (identity-extrinsics) sensor -> pose-prior
   /// residual block (optimizer.cpp:234-251).
@@ -570,13 +656,23 @@ class Optimizer {
     ManifoldMeasurement c = m;
     c.stamp = stamp;
     priors_.push_back(c);
+    const int32_t sensor = 0;
+    if (delta_) check(HSF(append_prior_residuals)(handle_, 1, &c.stamp, c.value.data(), &sensor), "append_prior_residuals"), staged_dirty_ = true;
   }
 
   // ---- CeresOptimizer::updateLandmarks (optimizer.cpp:360-382): retire landmarks whose observation range left the window ----
   void updateLandmarks(const Range& range) {
+    std::vector<int32_t> retired;
     for (auto it = landmarks_.begin(); it != landmarks_.end();) {
       const bool intersects = it->second.upper >= range.lower && it->second.lower < range.upper;
+      if (!intersects) retired.push_back(it->second.index), num_observations_ -= it->second.observations.size();
       it = intersects ? std::next(it) : landmarks_.erase(it);
+    }
+    if (delta_ && !retired.empty()) {  // RemoveParameterBlock(landmark), its residual blocks with it (optimizer.cpp:365-371)
+      std::vector<int32_t> remap(landmarks_.size() + retired.size());
+      check(HSF(retire_landmarks)(handle_, int(retired.size()), retired.data(), remap.data()), "retire_landmarks");
+      for (auto& [id, lm] : landmarks_) lm.index = remap[size_t(lm.index)];
+      staged_dirty_ = true;
     }
   }
   // ---- CeresOptimizer::updateState (optimizer.cpp:286-345): freeze control points at or before the window's lower bound;
@@ -594,6 +690,11 @@ class Optimizer {
                        inertials_.end());
     }
     priors_.erase(std::remove_if(priors_.begin(), priors_.end(), [&](const ManifoldMeasurement& m) { return m.stamp < oldest; }), priors_.end());
+    if (delta_) {
+      if (has_imu_) check(HSF(retire_residuals_before)(handle_, HS_INERTIAL, oldest), "retire_residuals_before");
+      check(HSF(retire_residuals_before)(handle_, HS_PRIOR, oldest), "retire_residuals_before");
+      staged_dirty_ = true;
+    }
     if (has_imu_ && !inertials_.empty() && !bias_.empty()) {
       // bias points no retained inertial residual reads are not part of the problem (Ceres only holds parameter blocks some residual
       // block refers to, exteroceptive.cpp:64-76): drop them from the front so that the border of the reduced system stays as wide
@@ -642,7 +743,11 @@ class Optimizer {
   hs_summary last_summary_{};
   std::vector<hs_iteration> last_iterations_;
   int num_optimizations_ = 0;
-  double wall_tables_ms_ = 0, wall_solve_ms_ = 0, wall_readback_ms_ = 0;
+  double wall_tables_ms_ = 0, wall_solve_ms_ = 0, wall_readback_ms_ = 0, wall_stage_ms_ = 0;
+  bool delta_ = true;             // tables kept in the library through hs_append_* / hs_retire_* / hs_stage (false: rebuilt inside optimize())
+  bool staged_dirty_ = false;     // rows were appended / retired since the last hs_stage
+  size_t num_observations_ = 0;   // visual residual blocks of the window
+  std::vector<double> readback_[4];
 };
 
 }  // namespace hyper_hip

@@ -161,6 +161,55 @@ class Problem:
         self._check(L.set_inertial_residuals(h, st.shape[0], _d(st), _d(me)), "set_inertial_residuals")
         self.window = w
 
+    # -- delta interface (tables kept incrementally between solves; include/hyperslam_hip.h) ---------------------
+    def append_landmarks(self, xyz, constant=None):
+        """addLandmark (optimizer.cpp:347-358): rows appended to the landmark table; returns the index of the first new row."""
+        lm = _arr(xyz, _f64, (-1, 3))
+        c = None if constant is None else _arr(constant, np.uint8)
+        first = C.c_int32(-1)
+        self._check(self.lib.append_landmarks(self.h, lm.shape[0], _d(lm), None if c is None else _u8(c), C.byref(first)), "append_landmarks")
+        return first.value
+
+    def append_residuals(self, ftype, stamps, values, landmark=None, camera=None, sensor=None):
+        """add(observation) (optimizer.cpp:189-274): rows appended to the residual table of one factor type."""
+        st = _arr(stamps, _f64)
+        n = st.shape[0]
+        if ftype in (HS_PIXEL, HS_BEARING):
+            v = _arr(values, _f64, (-1, 2 if ftype == HS_PIXEL else 3))
+            li, ci = _arr(landmark, np.int32), _arr(camera, np.int32)
+            fn = self.lib.append_pixel_residuals if ftype == HS_PIXEL else self.lib.append_bearing_residuals
+            self._check(fn(self.h, n, _d(st), _d(v), _i(li), _i(ci)), "append_residuals")
+        elif ftype == HS_PRIOR:
+            v, si = _arr(values, _f64, (-1, 7)), _arr(sensor if sensor is not None else np.zeros(n), np.int32)
+            self._check(self.lib.append_prior_residuals(self.h, n, _d(st), _d(v), _i(si)), "append_residuals")
+        else:
+            v = _arr(values, _f64, (-1, 6))
+            self._check(self.lib.append_inertial_residuals(self.h, n, _d(st), _d(v)), "append_residuals")
+
+    def retire_landmarks(self, ids):
+        """updateLandmarks (optimizer.cpp:360-382): the landmarks leave with their residual blocks; returns new index per old row (-1: retired)."""
+        ids = _arr(ids, np.int32)
+        rows = C.c_int32(0)
+        self._check(self.lib.append_landmarks(self.h, 0, None, None, C.byref(rows)), "append_landmarks")  # (appending nothing reports the row count)
+        remap = np.zeros(max(rows.value, 1), np.int32)
+        self._check(self.lib.retire_landmarks(self.h, ids.shape[0], _i(ids), _i(remap)), "retire_landmarks")
+        return remap[:rows.value].copy()
+
+    def retire_residuals_before(self, ftype, stamp):
+        self._check(self.lib.retire_residuals_before(self.h, int(ftype), float(stamp)), "retire_residuals_before")
+
+    def stage(self):
+        """Sorts and uploads what changed since the tables were last staged (nothing is awaited)."""
+        self._check(self.lib.stage(self.h), "stage")
+
+    def set_control_points(self, control_points, cp_constant=None):
+        """The control-point table re-sent with the knots of the resident window (values + constancy mask only)."""
+        w = self.window
+        cp = _arr(control_points, _f64, (-1, 8))
+        cpc = None if cp_constant is None else _arr(cp_constant, np.uint8)
+        self._check(self.lib.set_spline(self.h, w.order, w.t0, w.dt, cp.shape[0], _d(cp), None if cpc is None else _u8(cpc),
+                                        int(w.rotation_constant), int(w.translation_constant)), "set_spline")
+
     # -- structure ---------------------------------------------------------------------------------------------
     def num_residuals(self, ftype):
         return self.lib.num_residuals(self.h, ftype)

@@ -152,6 +152,36 @@ int hs_set_bearing_residuals(hs_problem* p, int n, const double* stamps, const d
 int hs_set_prior_residuals(hs_problem* p, int n, const double* stamps, const double* poses, const int32_t* sensor);
 int hs_set_inertial_residuals(hs_problem* p, int n, const double* stamps, const double* measurements);
 
+/* ---- delta interface: tables kept incrementally between solves --------------------------------- */
+/* The reference never rebuilds its problem: CeresOptimizer::add(...) appends one residual block when AbstractOptimizer::process hands it
+ * an observation (optimizer.cpp:189-274 <- abstract.cpp:246-259, 266-292), addLandmark / updateLandmarks add and remove landmark
+ * parameter blocks as the window moves (optimizer.cpp:347-382; RemoveParameterBlock takes the landmark's residual blocks along,
+ * :365-371), updateState adds / removes state elements (:286-345), and optimize() only calls ceres::Solve (:276-280). The functions
+ * below are that interface on the flat tables: rows are appended / retired when the caller learns of them, hs_stage() sorts and
+ * uploads what changed — between solves, off optimize()'s clock — and an hs_solve() that finds the tables staged uploads nothing
+ * (a control-point table re-sent with new values and the same knots costs one small copy).
+ * The hs_set_* functions above remain the whole-table form of the same thing; both may be mixed.
+ * A delta call first brings the library's host copies of the variables (control points, landmarks, bias points, gravity) up to the
+ * result of the last hs_solve, so the state persists across solves without the caller re-sending it. */
+/* Rows appended to the landmark table; *first_index (nullable) receives the index of the first new row (= the landmark id the residual
+ * rows refer to). Replaces addLandmark (optimizer.cpp:347-358). */
+int hs_append_landmarks(hs_problem* p, int n, const double* xyz, const uint8_t* constant, int32_t* first_index);
+/* Rows appended to the residual tables: same columns as hs_set_*_residuals. Replace add(...) (optimizer.cpp:189-274). */
+int hs_append_pixel_residuals(hs_problem* p, int n, const double* stamps, const double* pixels, const int32_t* landmark, const int32_t* camera);
+int hs_append_bearing_residuals(hs_problem* p, int n, const double* stamps, const double* bearings, const int32_t* landmark, const int32_t* camera);
+int hs_append_prior_residuals(hs_problem* p, int n, const double* stamps, const double* poses, const int32_t* sensor);
+int hs_append_inertial_residuals(hs_problem* p, int n, const double* stamps, const double* measurements);
+/* Removes landmarks `ids` (table indices) together with every visual residual row that refers to them (updateLandmarks,
+ * optimizer.cpp:360-382). The remaining landmarks keep their order and move up; remap (nullable, one entry per OLD row) receives
+ * the new index of every old row, -1 for the retired ones. */
+int hs_retire_landmarks(hs_problem* p, int n, const int32_t* ids, int32_t* remap);
+/* Removes the rows of residual table `type` whose stamp is < stamp. (Ceres never removes prior / inertial residual blocks; the
+ * plugin's retirement rule for them, include/hyper/optimizers/hip/optimizer.hpp updateLandmarks, is this call.) */
+int hs_retire_residuals_before(hs_problem* p, int type, double stamp);
+/* Sorts and uploads whatever changed since the tables were last staged (enqueued on the handle's stream, nothing is awaited). hs_solve
+ * and the evaluation entry points stage by themselves when needed: calling this earlier only moves the work off their clock. */
+int hs_stage(hs_problem* p);
+
 /* ---- structure (bit-exact parity target) ------------------------------------------------------- */
 /* Restates ExteroceptiveCost::update (exteroceptive.cpp:25-99) for residual `idx` of `type`:
  * indices[4] = {static_state_idx, static_sensor_idx, dynamic_sensor_idx, static_observation_idx},

@@ -60,6 +60,22 @@ static int validate(hso_problem* p) {
     if (int rc_ = validate(p)) return rc_; \
   } while (0)
 
+template <class Keep>
+static void keep_rows(Keep&& keep, std::vector<double>* stamp, std::vector<double>* meas, int width, std::vector<int32_t>* a = nullptr, std::vector<int32_t>* b = nullptr) {
+  size_t w = 0;
+  for (size_t i = 0; i < stamp->size(); ++i) {
+    if (!keep(i)) continue;
+    (*stamp)[w] = (*stamp)[i];
+    for (int c = 0; c < width; ++c) (*meas)[width * w + c] = (*meas)[width * i + c];
+    if (a) (*a)[w] = (*a)[i];
+    if (b) (*b)[w] = (*b)[i];
+    ++w;
+  }
+  stamp->resize(w), meas->resize(width * w);
+  if (a) a->resize(w);
+  if (b) b->resize(w);
+}
+
 extern "C" {
 
 int hso_create(int, void*, hso_problem** out) {
@@ -159,6 +175,75 @@ int hso_set_inertial_residuals(hso_problem* p, int n, const double* st, const do
   P.in_stamp.assign(st, st + n), P.in_meas.assign(m, m + 6 * n);
   return HS_OK;
 }
+
+// ---- delta interface (include/hyperslam_hip.h): the oracle's variables live in the same vectors its solve updates, so a delta call has
+//      nothing to pull; hso_stage has nothing to do (no device tables) ----
+int hso_append_landmarks(hso_problem* p, int n, const double* xyz, const uint8_t* constant, int32_t* first_index) {
+  Problem& P = p->P;
+  CHECK_ARG(n >= 0 && (n == 0 || xyz), "bad landmark rows");
+  if (first_index) *first_index = P.n_lm;
+  P.lm.insert(P.lm.end(), xyz, xyz + 3 * size_t(n));
+  for (int i = 0; i < n; ++i) P.lm_const.push_back(constant ? constant[i] : 0);
+  P.n_lm += n;
+  return HS_OK;
+}
+int hso_append_pixel_residuals(hso_problem* p, int n, const double* st, const double* px, const int32_t* lm, const int32_t* cam) {
+  Problem& P = p->P;
+  P.px_stamp.insert(P.px_stamp.end(), st, st + n), P.px_meas.insert(P.px_meas.end(), px, px + 2 * size_t(n));
+  P.px_lm.insert(P.px_lm.end(), lm, lm + n), P.px_cam.insert(P.px_cam.end(), cam, cam + n);
+  return HS_OK;
+}
+int hso_append_bearing_residuals(hso_problem* p, int n, const double* st, const double* b, const int32_t* lm, const int32_t* cam) {
+  Problem& P = p->P;
+  P.br_stamp.insert(P.br_stamp.end(), st, st + n), P.br_meas.insert(P.br_meas.end(), b, b + 3 * size_t(n));
+  P.br_lm.insert(P.br_lm.end(), lm, lm + n), P.br_cam.insert(P.br_cam.end(), cam, cam + n);
+  return HS_OK;
+}
+int hso_append_prior_residuals(hso_problem* p, int n, const double* st, const double* poses, const int32_t* sensor) {
+  Problem& P = p->P;
+  P.pr_stamp.insert(P.pr_stamp.end(), st, st + n), P.pr_meas.insert(P.pr_meas.end(), poses, poses + 7 * size_t(n));
+  P.pr_sensor.insert(P.pr_sensor.end(), sensor, sensor + n);
+  return HS_OK;
+}
+int hso_append_inertial_residuals(hso_problem* p, int n, const double* st, const double* m) {
+  Problem& P = p->P;
+  P.in_stamp.insert(P.in_stamp.end(), st, st + n), P.in_meas.insert(P.in_meas.end(), m, m + 6 * size_t(n));
+  return HS_OK;
+}
+int hso_retire_landmarks(hso_problem* p, int n, const int32_t* ids, int32_t* remap) {
+  Problem& P = p->P;
+  const int n_old = P.n_lm;
+  std::vector<int32_t> local;
+  if (!remap) local.resize(n_old), remap = local.data();
+  for (int i = 0; i < n; ++i) CHECK_ARG(ids[i] >= 0 && ids[i] < n_old, "hs_retire_landmarks: landmark outside the landmark table");
+  for (int t = 0; t < n_old; ++t) remap[t] = 0;
+  for (int i = 0; i < n; ++i) remap[ids[i]] = -1;
+  int w = 0;
+  for (int t = 0; t < n_old; ++t) {
+    if (remap[t] < 0) continue;
+    for (int c = 0; c < 3; ++c) P.lm[3 * size_t(w) + c] = P.lm[3 * size_t(t) + c];
+    P.lm_const[w] = P.lm_const[t];
+    remap[t] = w++;
+  }
+  P.n_lm = w, P.lm.resize(3 * size_t(w)), P.lm_const.resize(w);
+  keep_rows([&](size_t i) { return remap[P.px_lm[i]] >= 0; }, &P.px_stamp, &P.px_meas, 2, &P.px_lm, &P.px_cam);
+  keep_rows([&](size_t i) { return remap[P.br_lm[i]] >= 0; }, &P.br_stamp, &P.br_meas, 3, &P.br_lm, &P.br_cam);
+  for (int32_t& l : P.px_lm) l = remap[l];
+  for (int32_t& l : P.br_lm) l = remap[l];
+  return HS_OK;
+}
+int hso_retire_residuals_before(hso_problem* p, int type, double stamp) {
+  Problem& P = p->P;
+  CHECK_ARG(type >= 0 && type <= 3, "unknown factor type");
+  switch (type) {
+    case HS_PIXEL: keep_rows([&](size_t i) { return !(P.px_stamp[i] < stamp); }, &P.px_stamp, &P.px_meas, 2, &P.px_lm, &P.px_cam); break;
+    case HS_BEARING: keep_rows([&](size_t i) { return !(P.br_stamp[i] < stamp); }, &P.br_stamp, &P.br_meas, 3, &P.br_lm, &P.br_cam); break;
+    case HS_PRIOR: keep_rows([&](size_t i) { return !(P.pr_stamp[i] < stamp); }, &P.pr_stamp, &P.pr_meas, 7, &P.pr_sensor); break;
+    default: keep_rows([&](size_t i) { return !(P.in_stamp[i] < stamp); }, &P.in_stamp, &P.in_meas, 6); break;
+  }
+  return HS_OK;
+}
+int hso_stage(hso_problem*) { return HS_OK; }
 
 int hso_num_residuals(hso_problem* p, int type) { return p->P.n_res(FactorType(type)); }
 int hso_dim_pose(hso_problem* p) { return p->P.dim_pose(); }

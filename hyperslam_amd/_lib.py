@@ -150,7 +150,7 @@ class Library:
     """A loaded C-ABI library with typed entry points (attribute access without the prefix)."""
 
     def __init__(self, path: str, prefix: str, strict: bool = True):
-        """strict=False: a library that exports only part of the ABI (oracle/liboracle_ld.so, the long-double referee of the tests and
+        """strict=False: a library that exports only part of the ABI (oracle/liboracle_ld.so — prefix hsl_ —, the long-double referee of the tests and
         tools/fuzz_parity.py): the entry points it lacks are simply not bound."""
         if not os.path.exists(path):
             raise FileNotFoundError(

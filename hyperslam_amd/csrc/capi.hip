@@ -128,7 +128,7 @@ int hs_set_spline(hs_problem* p, int order, double t0, double dt, int n_cp, cons
   const double knot_tol = knot_tolerance(t0, dt, n_cp);
   for (int j = 0; j < n_cp; ++j)
     if (!(std::fabs(cp[8 * j + 7] - (t0 + j * dt)) <= knot_tol))
-      HS_FAIL(HS_ERR_INVALID, "control-point stamps are not t0 + j dt (row " + std::to_string(j) + "): the spline basis is uniform, a table with a hole or non-uniform knots is refused");
+      HS_FAIL(HS_ERR_KNOTS, "control-point stamps are not t0 + j dt (row " + std::to_string(j) + "): the spline basis is uniform, a table with a hole or non-uniform knots is refused");
   // Same knots and flags as the resident table: only the values (and the constancy mask) changed — the sorted tables, every index and size stand.
   const bool same_structure = p->k == order && p->t0 == t0 && p->dt == dt && p->n_cp == n_cp && p->rot_const == (rc != 0) && p->trans_const == (tc != 0) &&
                               p->cp.size() == size_t(8) * n_cp;
@@ -486,10 +486,8 @@ static int linearize_sensor_blocks(hs_problem* p, int type, int robustify, const
 
 static int linearize_impl(hs_problem* p, int type, int robustify, const hs_linearization* out);
 
-/// hs_linearize with CostConfiguration::weights (exteroceptive.cpp:129-147): output = W * distance, J_w = W * J_m * J_e, then Ceres' loss
-/// corrector on the weighted residual. The device produces the unweighted, uncorrected rows (linearize_impl, robustify = 0); W (n_res x
-/// n_res) and the corrector are applied per residual block while the rows are handed out.
-/// HS_GUARD=1 (host_tables.hpp, GuardRegistry): the patterns behind every device table of the process are checked before the call returns.
+/// HS_GUARD=1 (host_tables.hpp, GuardRegistry): the patterns behind every device table of the process are checked before hs_solve, hs_cost,
+/// hs_reduced_system and hs_linearize return.
 static int guard_check(hs_problem* p) {
   if (!GuardRegistry::on()) return HS_OK;
   size_t at = 0;
@@ -498,17 +496,24 @@ static int guard_check(hs_problem* p) {
   return HS_OK;
 }
 
+/// hs_linearize with CostConfiguration::weights (exteroceptive.cpp:129-147): output = W * distance, J_w = W * J_m * J_e, then Ceres' loss
+/// corrector on the weighted residual. The device produces the unweighted, uncorrected rows (linearize_impl, robustify = 0); W (n_res x
+/// n_res) and the corrector are applied per residual block while the rows are handed out.
 int hs_linearize(hs_problem* p, int type, int robustify, const hs_linearization* out) {
   if (!p || !out) return HS_ERR_INVALID;
   if (type < HS_PIXEL || type > HS_INERTIAL) HS_FAIL(HS_ERR_INVALID, "unknown factor type");
   const std::vector<double>& W = p->weights[type];
-  if (W.empty()) return linearize_impl(p, type, robustify, out);
+  if (W.empty()) {
+    const int rc0 = linearize_impl(p, type, robustify, out);
+    return rc0 ? rc0 : guard_check(p);
+  }
   const int n = hs_num_residuals(p, type), nr = type == HS_PIXEL ? 2 : (type == HS_BEARING ? 1 : 6);
   hs_linearization o = *out;
   std::vector<double> r_tmp, c_tmp;
   if (!o.r) r_tmp.resize(size_t(n) * nr), o.r = r_tmp.data();
   if (!o.cost) c_tmp.resize(n), o.cost = c_tmp.data();
-  const int rc = linearize_impl(p, type, 0, &o);
+  int rc = linearize_impl(p, type, 0, &o);
+  if (!rc) rc = guard_check(p);
   if (rc) return rc;
   struct Block {
     double* J;

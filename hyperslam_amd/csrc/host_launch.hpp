@@ -346,7 +346,7 @@ int launch_factor(hs_problem* p) {
     const int fwd_cus = (2 * ((T.nb + kBorderCols - 1) / kBorderCols) + fwd_per_cu - 1) / fwd_per_cu;
     const bool pipe = use_mx && T.nb && p->side && fwd_cus <= p->n_cu / 2 - 8 && !(T.debug_flags & 128);
     unsigned* progress = p->d_join.p + kBfFlagBase + 512;  // near U, near W, far U, far W: kProgressStride words apart
-    const unsigned progress_base = unsigned(T2.join_epoch) << 12;
+    const unsigned progress_base = unsigned(T2.join_epoch) << 12;  // (epoch mod 2^20 | rows: the poller compares the epoch for equality)
     if (pipe) {
       T2.mj[0].progress = progress, T2.mj[1].progress = progress + 2 * kProgressStride;
       T2.mj[0].progress_base = T2.mj[1].progress_base = progress_base;

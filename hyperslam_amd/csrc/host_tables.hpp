@@ -838,6 +838,9 @@ int prepare(hs_problem* p) {
   // 65536 single-wave register backward sweep (k_band_backward_w) instead of the four-wave LDS sweeps
   // 262144 eliminate / sweep the decoupled block rows of leading constant control points like any other     524288 border Cholesky in LDS
   // 128 border forward sweep behind the factorisation instead of alongside it
+  // 256 phase timestamps of k_assemble (profiling builds)          512 phase timestamps of k_update_visual (profiling builds)
+  //   (64 and 128 are product A/B switches: the stamps of k_assemble / k_update_visual used to share them, so that timing one of those kernels
+  //    also changed the factorisation path)
   // 1048576 inertial branch on the main stream    2097152 banded kernels instead of k_dense_factor    4194304 k_landmark<K,4,1> instead of k_landmark_rows
   // 8388608 five finalisation launches for a bordered single shard    16777216 k_commit launch for small windows    33554432 one cost launch per factor type
   // 268435456 backward sweeps one block row per step    536870912 bordered systems one-ended    1073741824 no speculative linearisation at the candidate    67108864 k_commit in every iteration of a speculative solve

@@ -429,9 +429,14 @@ __global__ void __launch_bounds__(kBlock) k_border_forward2(Tables T, BfJob j0, 
     if (seen >= need) return;
     const long long t0 = wall_clock64();
     for (;;) {
-      const int a = int(__hip_atomic_load(J.progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - J.progress_base);
-      const int b = int(__hip_atomic_load(J.progress + kProgressStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - J.progress_base);
-      seen = max(0, min(a, b));  // (a word of an earlier launch: negative)
+      // word = launch epoch << 12 | complete rows (n_cp <= 1024 < 4096). The epoch is compared for EQUALITY: the words are never reset, and a word
+      // left by any earlier launch — however long ago, e.g. after a stretch of windows that did not take the pipelined path — counts as "nothing yet"
+      // (a signed difference to the base would read a word 2^19 or more epochs old as "everything complete").
+      const unsigned wa = __hip_atomic_load(J.progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned wb = __hip_atomic_load(J.progress + kProgressStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int a = (wa >> 12) == (J.progress_base >> 12) ? int(wa & 4095u) : 0;
+      const int b = (wb >> 12) == (J.progress_base >> 12) ? int(wb & 4095u) : 0;
+      seen = min(a, b);
       if (seen >= need) break;
       __builtin_amdgcn_s_sleep(16);  // (~0.4 us: a hundred pollers at full rate on the words the factorisation writes delayed its stores)
       if (wall_clock64() - t0 > 200000000ll) {

@@ -796,7 +796,7 @@ __global__ void __launch_bounds__(kBlock) k_update_visual(Tables T, int R, int L
     return;
   }
   // ---- chunk w ----
-  const bool uprof = prof_enabled(T.debug_flags, 128) && tid == 0 && w < 1024;  // phase stamps (profiling builds; tools/update_phase_timing.py)
+  const bool uprof = prof_enabled(T.debug_flags, 512) && tid == 0 && w < 1024;  // phase stamps (profiling builds; tools/update_phase_timing.py)
   long long* ulog = reinterpret_cast<long long*>(T.xpart) + 192 * 1024 + 16 * w;
   if (uprof) ulog[0] = wall_clock64();
   const int4 d0 = *reinterpret_cast<const int4*>(T.ch_desc + 8 * w);

@@ -548,7 +548,7 @@ __global__ void __launch_bounds__(la_threads(NCW)) k_band_factor_la(Tables T) {
       lds_barrier();
       if (dump) lds_barrier();
       for (int rho = l; rho < 6 * n_steps; rho += 64) J.ybuf[rho] = xs[rho];  // y = U^-T g
-      if (l == 0 && fail) st->chol_failed = 1;  // (cleared by k_finalize_reduced)
+      if (l == 0 && fail) st->chol_failed = 1;  // (consumed and cleared by decide_step, kernels_update.hpp: an invalid step)
     }
     return;
   }
@@ -1299,7 +1299,7 @@ __global__ void __launch_bounds__(kWideThreads) k_band_factor_wide(Tables T) {
     __syncthreads();
   }
 #undef UIDX
-  if (tid == 0 && fail) st->chol_failed = 1;  // (reset by begin_iteration; an earlier kernel of this iteration may have raised it)
+  if (tid == 0 && fail) st->chol_failed = 1;  // (consumed and cleared by decide_step, kernels_update.hpp; an earlier kernel of this iteration may have raised it)
 }
 
 /// Backward sweep U x = y (y in T.ybuf, possibly corrected by the border solve) + step outputs and model-cost reductions.

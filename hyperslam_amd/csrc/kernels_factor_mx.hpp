@@ -555,6 +555,11 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
     int p_prev = W - 6;  // ring position of block row it - 1
     constexpr bool pub = PUB;  // (see the storer)
     for (int it = 0; it < n_iter; ++it) {
+      // VMEM BUDGET (what the late publication rests on): this wave issues, per iteration, the SIX agent-scope stores of the inverted block below
+      // (one instruction each, exec never empty: lanes 0..5) + the progress store — and no load. vmcnt counts instructions of this wave in issue
+      // order, so "all but 12 outstanding" leaves at most the stores of the two previous iterations in flight. Anything that makes an iteration issue
+      // FEWER than six VMEM instructions (a store moved under a divergent branch, two stores merged into one) breaks the inference without an
+      // error: the GPU test test_two_ended_bordered_solve (bit identity against the sequential arrangement, 40 solves) is what would notice.
       if constexpr (pub) {  // >= 6 stores per iteration (+ this one): all but the last twelve are done -> the blocks of rows 0 .. it - 4 are in memory
         if (it >= 4) {
           wait_vmem_all_but<12>();
@@ -624,6 +629,8 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
     // last iteration in flight (a wait for all of them would put the write-through latency on this wave in every iteration).
     constexpr bool pub = PUB;
     for (int it = 0; it < n_iter; ++it) {
+      // VMEM BUDGET: per iteration TWELVE agent-scope 8-byte stores of the factor row (two per row a, exec never empty: the lanes of the band) + the
+      // y store + the progress store, no load — "all but 24 outstanding" leaves at most two iterations' stores in flight (see the inverse wave).
       if constexpr (pub) {  // >= 12 stores per iteration (the factor row; + y, + this one): all but the last 24 are done -> everything iteration
                             // it - 3 and the ones before it stored, i.e. rows 0 .. it - 4, is in memory
         if (it >= 4) {

@@ -523,7 +523,7 @@ HSD void assemble_body(const Tables& T, int direct) {
   __shared__ double part[3][THREADS];
   __shared__ double gpair[2];
   // phase timestamps (profiling builds, HS_DEBUG_FLAGS 64; tools/assemble_phase_timing.py): lane 0 of every workgroup
-  const bool aprof = prof_enabled(T.debug_flags, 64) && threadIdx.x == 0;
+  const bool aprof = prof_enabled(T.debug_flags, 256) && threadIdx.x == 0;
   long long* alog = reinterpret_cast<long long*>(T.xpart) + 128 * 1024 + 8 * (blockIdx.y * gridDim.x + blockIdx.x);
   if (aprof) alog[0] = wall_clock64();
   if (T.st->done) return;

@@ -233,6 +233,7 @@ class Optimizer {
     Stamp stamp;
     int32_t camera;
     Vec3 bearing;
+    uint64_t seq = 0;  // order of arrival (= row order of the library's table under the delta interface)
   };
   struct Landmark {
     Vec3 position{0, 0, 0};
@@ -350,15 +351,25 @@ class Optimizer {
     std::vector<Landmark*> rows;  // (delta interface: the library's row order = order of arrival minus the retired ones; identifier order otherwise)
     for (auto& [id, lm] : landmarks_) rows.push_back(&lm);
     if (delta_) std::sort(rows.begin(), rows.end(), [](const Landmark* a, const Landmark* b) { return a->index < b->index; });
+    struct Row {
+      uint64_t seq;
+      int32_t lm;
+      const Observation* ob;
+    };
+    std::vector<Row> obs;
     for (Landmark* row : rows) {
       Landmark& lm = *row;
       if (order) order->push_back(&lm);
       t.landmarks.insert(t.landmarks.end(), lm.position.begin(), lm.position.end());
-      for (const Observation& ob : lm.observations) {
-        t.br_stamp.push_back(ob.stamp), t.br_lm.push_back(li), t.br_cam.push_back(ob.camera);
-        t.br_bearing.insert(t.br_bearing.end(), ob.bearing.begin(), ob.bearing.end());
-      }
+      for (const Observation& ob : lm.observations) obs.push_back({ob.seq, li, &ob});
       ++li;
+    }
+    // residual rows: landmark by landmark, or — delta interface — in the order the library holds them (arrival), so that a harness that
+    // hands these tables to a second library gives it bit for bit what the first one accumulated
+    if (delta_) std::sort(obs.begin(), obs.end(), [](const Row& a, const Row& b) { return a.seq < b.seq; });
+    for (const Row& r : obs) {
+      t.br_stamp.push_back(r.ob->stamp), t.br_lm.push_back(r.lm), t.br_cam.push_back(r.ob->camera);
+      t.br_bearing.insert(t.br_bearing.end(), r.ob->bearing.begin(), r.ob->bearing.end());
     }
     for (const ManifoldMeasurement& m : priors_) t.pr_stamp.push_back(m.stamp), t.pr_pose.insert(t.pr_pose.end(), m.value.begin(), m.value.end());
     t.has_imu = has_imu_;
@@ -601,8 +612,8 @@ class Optimizer {
         lm.lower = lm.upper = stamp;
         fresh.push_back(&lm), fresh_xyz.insert(fresh_xyz.end(), lm.position.begin(), lm.position.end());
       }
-      lm.observations.push_back({stamp, 0, {b0[3 * i], b0[3 * i + 1], b0[3 * i + 2]}});
-      lm.observations.push_back({stamp, 1, {b1[3 * i], b1[3 * i + 1], b1[3 * i + 2]}});
+      lm.observations.push_back({stamp, 0, {b0[3 * i], b0[3 * i + 1], b0[3 * i + 2]}, next_seq_++});
+      lm.observations.push_back({stamp, 1, {b1[3 * i], b1[3 * i + 1], b1[3 * i + 2]}, next_seq_++});
       lm.lower = std::min(lm.lower, stamp), lm.upper = std::max(lm.upper, stamp);
       seen[i] = &lm;
     }
@@ -747,6 +758,7 @@ class Optimizer {
   bool delta_ = true;             // tables kept in the library through hs_append_* / hs_retire_* / hs_stage (false: rebuilt inside optimize())
   bool staged_dirty_ = false;     // rows were appended / retired since the last hs_stage
   size_t num_observations_ = 0;   // visual residual blocks of the window
+  uint64_t next_seq_ = 0;
   std::vector<double> readback_[4];
 };
 

@@ -69,12 +69,13 @@ int main(int argc, char** argv) {
               "\"mean_solve_ms\": %.4f, \"median_solve_ms\": %.4f, \"full_window_mean_solve_ms\": %.4f, \"max_solve_ms\": %.4f, \"residual_blocks_per_s_in_solve\": %.1f, \"wall_ms\": %.1f, "
               "\"window\": [%.2f, %.2f], \"state_range\": [%.6f, %.6f], \"position_rmse_m\": %.4f, \"last_cost\": [%.6g, %.6g], "
               "\"mean_stage_ms\": {\"linearize\": %.4f, \"schur\": %.4f, \"solve\": %.4f, \"update\": %.4f}, "
-              "\"mean_host_wall_ms\": {\"tables\": %.4f, \"hs_solve\": %.4f, \"readback\": %.4f}}\n",
+              "\"mean_host_wall_ms\": {\"tables\": %.4f, \"hs_solve\": %.4f, \"readback\": %.4f, \"stage_between_solves\": %.4f}, \"delta_interface\": %d}\n",
               seconds, int(with_imu), opt.order, optimizer.numOptimizations(), optimizer.numControlPoints(), optimizer.numLandmarks(),
               total_solve_ms / std::max(1, solves_seen), median, steady, max_solve_ms, total_solve_ms > 0 ? 1e3 * total_blocks / total_solve_ms : 0.0, wall_ms,
               optimizer.window().lower, optimizer.window().upper, optimizer.stateRange().lower, optimizer.stateRange().upper, std::sqrt(se / std::max(1, n)), optimizer.lastSummary().initial_cost,
               optimizer.lastSummary().final_cost, stages ? stage_ms[0] / std::max(1, solves_seen) : -1.0, stages ? stage_ms[1] / std::max(1, solves_seen) : -1.0,
               stages ? stage_ms[2] / std::max(1, solves_seen) : -1.0, stages ? stage_ms[3] / std::max(1, solves_seen) : -1.0, optimizer.wallSplitMs()[0] / std::max(1, solves_seen),
-              optimizer.wallSplitMs()[1] / std::max(1, solves_seen), optimizer.wallSplitMs()[2] / std::max(1, solves_seen));
+              optimizer.wallSplitMs()[1] / std::max(1, solves_seen), optimizer.wallSplitMs()[2] / std::max(1, solves_seen), optimizer.wallStageMs() / std::max(1, solves_seen),
+              int(optimizer.deltaInterface()));
   return 0;
 }

@@ -1,4 +1,4 @@
-// replay_stream.hpp — the synthetic EuRoC-shaped message stream shared by replay.cpp and replay_lockstep.cpp (BASELINE.json configs[4]).
+// replay_stream.hpp — the synthetic EuRoC-shaped message stream shared by replay.cpp and tests/harness/replay_lockstep.cpp (BASELINE.json configs[4]).
 //
 // MH_01 itself cannot be replayed (no rosbags, ground-truth blob missing, the IMU path aborts upstream — SURVEY.md §0), so the
 // stream is synthetic with the real window shape: separation 0.1 s, max_window 3.0 s (settings.yaml:145,148), <= 150 stereo tracks

@@ -189,11 +189,10 @@ class Problem:
     def retire_landmarks(self, ids):
         """updateLandmarks (optimizer.cpp:360-382): the landmarks leave with their residual blocks; returns new index per old row (-1: retired)."""
         ids = _arr(ids, np.int32)
-        rows = C.c_int32(0)
-        self._check(self.lib.append_landmarks(self.h, 0, None, None, C.byref(rows)), "append_landmarks")  # (appending nothing reports the row count)
-        remap = np.zeros(max(rows.value, 1), np.int32)
+        rows = self.num_landmarks()
+        remap = np.zeros(max(rows, 1), np.int32)
         self._check(self.lib.retire_landmarks(self.h, ids.shape[0], _i(ids), _i(remap)), "retire_landmarks")
-        return remap[:rows.value].copy()
+        return remap[:rows].copy()
 
     def retire_residuals_before(self, ftype, stamp):
         self._check(self.lib.retire_residuals_before(self.h, int(ftype), float(stamp)), "retire_residuals_before")
@@ -342,8 +341,14 @@ class Problem:
         self._check(self.lib.get_control_points(self.h, _d(cp)), "get_control_points")
         return cp
 
+    def num_landmarks(self):
+        """Rows of the library's landmark table (the delta interface appends / retires rows: not necessarily the window's)."""
+        rows = C.c_int32(0)
+        self._check(self.lib.append_landmarks(self.h, 0, None, None, C.byref(rows)), "append_landmarks")  # (appending nothing reports the row count)
+        return rows.value
+
     def landmarks(self):
-        lm = np.zeros((len(self.window.landmarks), 3))
+        lm = np.zeros((self.num_landmarks(), 3))
         if len(lm):
             self._check(self.lib.get_landmarks(self.h, _d(lm)), "get_landmarks")
         return lm

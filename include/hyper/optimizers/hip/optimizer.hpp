@@ -137,6 +137,10 @@ class Optimizer<kOptimizerSuiteHIP> final : public AbstractOptimizer {
   /// Pose priors on control points that are still free are kept either way (they may be what fixes the gauge).
   auto setRetireOldObservations(const bool retire) -> void { retire_old_observations_ = retire; }
 
+  /// Windows optimize() could not hand to the library because the control-point stamps between the oldest and the newest parameter block are
+  /// not uniform (HS_ERR_KNOTS; upstream's multi-state extension, abstract.cpp:127-137). 0 on a front-end that delivers at its own cadence.
+  [[nodiscard]] auto skippedWindows() const -> std::size_t { return skipped_windows_; }
+
   /// Knot spacing of the two bias splines updateSensor() creates (the reference has no YAML key for it; its test uses 10 state
   /// separations, tests/internal/tests/optimizers/evaluators/inertial.cpp:48-49). Takes effect for splines that are still empty.
   auto setBiasSeparation(const Stamp separation) -> void {
@@ -169,13 +173,20 @@ class Optimizer<kOptimizerSuiteHIP> final : public AbstractOptimizer {
     std::vector<double> cp(8 * cps.size());
     for (std::size_t j = 0; j < cps.size(); ++j) std::copy_n(cps[j]->asVector().data(), 8, &cp[8 * j]);  // [q(4) p(3) t], stamped.hpp:35-36
     const auto t0 = cps.front()->stamp();
-    // A refusal here is not fatal: upstream's extension by more than one state (abstract.cpp:127-137 re-reads rbegin() after every insertion
-    // and spaces the new stamps by 1, 2, 3 ... separations) leaves a hole in the knots that no uniform basis can represent. The window is
-    // skipped with an error in the log — the state stays as it is, the next message that closes the hole is solved again — instead of
-    // aborting the process through a CHECK.
-    if (hs_set_spline(handle_, order, t0, separation_, static_cast<int>(cps.size()), cp.data(), cp_constant.data(), rotation_constant_, translation_constant_) != HS_OK) {
-      LOG(ERROR) << "hip optimizer: window skipped: " << hs_last_error(handle_);
+    // ONE refusal is survivable: HS_ERR_KNOTS. Upstream's extension by more than one state (abstract.cpp:127-137 computes the new stamps as
+    // rbegin()->stamp() + i * separation with rbegin() re-read after every insertion, i.e. spaced by 1, 2, 3 ... separations) leaves a
+    // PERMANENT hole in the knots, which no uniform basis can represent: every window whose table spans the hole is skipped — the state stays
+    // as it is, estimation resumes once the hole has slid out of the window — and counted (skippedWindows()), so that the caller can see
+    // that it happened instead of reading it out of the log. Every other failure of hs_set_spline (order, sizes, null table) is a bug of
+    // this file and aborts through check(), like everywhere else.
+    if (const auto rc = hs_set_spline(handle_, order, t0, separation_, static_cast<int>(cps.size()), cp.data(), cp_constant.data(), rotation_constant_, translation_constant_);
+        rc == HS_ERR_KNOTS) {
+      ++skipped_windows_;
+      LOG(ERROR) << "hip optimizer: window " << window_.lowerBound() << " .. " << window_.upperBound() << " skipped (" << skipped_windows_
+                 << " so far): " << hs_last_error(handle_);
       return;
+    } else {
+      check(rc);
     }
     // Upstream admits a message with state().range().contains(stamp) on the elements' ACCUMULATED stamps (abstract.cpp:103-106, 127-137);
     // the library derives the segment from t0 + j * separation. The two agree except in the last bits of a stamp on a knot: a stamp
@@ -458,6 +469,7 @@ class Optimizer<kOptimizerSuiteHIP> final : public AbstractOptimizer {
   std::vector<InertialObservation<Manifold>*> inertials_;
   bool rotation_constant_{false}, translation_constant_{false}, gravity_constant_{true}, retire_old_observations_{true};
   Stamp bias_separation_{1.0};
+  std::size_t skipped_windows_{0};
 };
 
 using HipOptimizer = Optimizer<kOptimizerSuiteHIP>;

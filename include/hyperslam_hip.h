@@ -33,6 +33,7 @@ extern "C" {
 #define HS_ERR_DEVICE 2    /* HIP runtime error */
 #define HS_ERR_STATE 3     /* call order (e.g. solve before tables are set) */
 #define HS_ERR_NUMERIC 4   /* non-finite values / factorisation failure surfaced to the caller */
+#define HS_ERR_KNOTS 5     /* hs_set_spline: the control-point stamps are not t0 + j*dt (a hole or a shifted knot); nothing was changed */
 
 /* Factor types = the four in-tree evaluators (optimizer.cpp:189,212,234,253). */
 #define HS_PIXEL 0     /* VisualPixelEvaluator   pixel.cpp:16     2 rows, CartesianMetric, Huber(0.5)      optimizer.cpp:226 */
@@ -119,7 +120,9 @@ const char* hs_arch(void);
 /* ---- tables (host -> HBM) ------------------------------------------------------------------------------------ */
 /* Replaces swapState/updateState (optimizer.cpp:110-128, 286-345) + setStateManifold (backend.cpp:52-55):
  * uniform spline of order k (k control points per segment; BasisInterpolator(k-1, true)), control point j at stamp
- * t0 + j*dt. cp = n_cp x 8. cp_constant[j] != 0 freezes control point j (optimizer.cpp:323-328); may be NULL. */
+ * t0 + j*dt. cp = n_cp x 8. cp_constant[j] != 0 freezes control point j (optimizer.cpp:323-328); may be NULL.
+ * A table whose stamps are not t0 + j*dt is refused with HS_ERR_KNOTS (its own code: the one refusal a caller may want to survive,
+ * see the plugin's optimize()); every other bad argument is HS_ERR_INVALID. */
 int hs_set_spline(hs_problem* p, int order, double t0, double dt, int n_cp, const double* cp, const uint8_t* cp_constant,
                   int rotation_constant, int translation_constant);
 /* Replaces setSensorManifold for cameras (optimizer.cpp:143-155; constant blocks, camera.hpp:18).

@@ -93,9 +93,11 @@ int hso_set_spline(hso_problem* p, int order, double t0, double dt, int n_cp, co
   CHECK_ARG(order >= 2 && order <= kMaxOrder, "order out of range");
   CHECK_ARG(n_cp >= order && dt > 0, "need n_cp >= order and dt > 0");
   const double knot_tol = std::max(1e-6 * dt, 8.0 * 2.220446049250313e-16 * std::max(std::fabs(t0), std::fabs(t0 + n_cp * dt)));
-  for (int j = 0; j < n_cp; ++j)  // uniform basis: same rule, tolerance and message as hs_set_spline
-    CHECK_ARG(std::fabs(cp[8 * j + 7] - (t0 + j * dt)) <= knot_tol,
-              "control-point stamps are not t0 + j dt: the spline basis is uniform, a table with a hole or non-uniform knots is refused");
+  for (int j = 0; j < n_cp; ++j)  // uniform basis: same rule, tolerance, code and message as hs_set_spline
+    if (!(std::fabs(cp[8 * j + 7] - (t0 + j * dt)) <= knot_tol)) {
+      p->err = "control-point stamps are not t0 + j dt: the spline basis is uniform, a table with a hole or non-uniform knots is refused";
+      return HS_ERR_KNOTS;
+    }
   Problem& P = p->P;
   P.k = order, P.t0 = t0, P.dt = dt, P.n_cp = n_cp;
   P.cp.assign(cp, cp + size_t(8) * n_cp);

@@ -2,11 +2,12 @@
 // DIAGNOSTIC build of the CPU restatement with every `double` of hs_math.hpp / hs_factors.hpp / hs_problem.hpp compiled as the x87
 // 80-bit `long double` (64-bit mantissa, eps 1.08e-19): the same algorithm, the same operation order, 2048 times less rounding.
 // It answers "which side carries the error" when the HIP library and the double oracle differ by more than the lock-step bar on an
-// ill-conditioned window: hyperslam_amd/host/replay_lockstep takes this library as its shadow
-//     replay_lockstep oracle/liboracle_ld.so 3.6 0 4          double oracle (master) vs long-double oracle (shadow), CPU only
+// ill-conditioned window: tests/harness/replay_lockstep takes this library as its shadow
+//     replay_lockstep oracle/liboracle_ld.so 3.6 0 4 hsl_     double oracle (master) vs long-double oracle (shadow), CPU only
 // and tools/lockstep_three_way.py compares oracle(double), oracle(long double) and HIP from the same tables on the GPU box.
-// Exported: the subset of include/hyperslam_hip.h the lock-step harness binds, under the product names hs_* (the harness resolves
-// its shadow by those names). Inputs and outputs cross the boundary as double; nothing inside is rounded to double.
+// Exported: the subset of include/hyperslam_hip.h the lock-step harness binds, under a prefix of its own, hsl_* — NOT the product's hs_*: a
+// test library that answers to the product's names could stand in for it through LD_PRELOAD and turn a parity test green against itself.
+// Inputs and outputs cross the boundary as double; nothing inside is rounded to double.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -39,18 +40,18 @@ static void put(D* dst, const S* src, size_t n) {
 
 extern "C" {
 
-int hs_create(int, void*, hs_problem** out) {
+int hsl_create(int, void*, hs_problem** out) {
   *out = new hs_problem();
   if (const char* e = std::getenv("HS_REFERENCE_LITERAL")) (*out)->P.inertial_mode = std::atoi(e) ? HS_INERTIAL_AS_REFERENCE : HS_INERTIAL_EXACT;
   return HS_OK;
 }
-int hs_destroy(hs_problem* p) {
+int hsl_destroy(hs_problem* p) {
   delete p;
   return HS_OK;
 }
-const char* hs_last_error(const hs_problem* p) { return p ? p->err.c_str() : "null handle"; }
+const char* hsl_last_error(const hs_problem* p) { return p ? p->err.c_str() : "null handle"; }
 
-int hs_set_spline(hs_problem* p, int order, double t0, double dt, int n_cp, const double* cp, const uint8_t* cp_constant, int rot_c, int trans_c) {
+int hsl_set_spline(hs_problem* p, int order, double t0, double dt, int n_cp, const double* cp, const uint8_t* cp_constant, int rot_c, int trans_c) {
   if (order < 2 || order > kMaxOrder || n_cp < order || !(dt > 0)) return p->err = "bad spline", HS_ERR_INVALID;
   Problem& P = p->P;
   P.k = order, P.t0 = t0, P.dt = dt, P.n_cp = n_cp;
@@ -60,18 +61,18 @@ int hs_set_spline(hs_problem* p, int order, double t0, double dt, int n_cp, cons
   P.rot_const = rot_c != 0, P.trans_const = trans_c != 0;
   return HS_OK;
 }
-int hs_set_cameras(hs_problem* p, int n, const double* T, const double* in, const double* di) {
+int hsl_set_cameras(hs_problem* p, int n, const double* T, const double* in, const double* di) {
   Problem& P = p->P;
   P.n_cam = n;
   P.cam_T_bs.assign(T, T + 7 * n), P.cam_intr.assign(in, in + 4 * n), P.cam_dist.assign(di, di + 4 * n);
   return HS_OK;
 }
-int hs_set_sensors(hs_problem* p, int n, const double* T) {
+int hsl_set_sensors(hs_problem* p, int n, const double* T) {
   p->P.n_sensor = n;
   p->P.sensor_T_bs.assign(T, T + 7 * n);
   return HS_OK;
 }
-int hs_set_landmarks(hs_problem* p, int n, const double* xyz, const uint8_t* c) {
+int hsl_set_landmarks(hs_problem* p, int n, const double* xyz, const uint8_t* c) {
   Problem& P = p->P;
   P.n_lm = n;
   P.lm.assign(xyz, xyz + 3 * n);
@@ -79,7 +80,7 @@ int hs_set_landmarks(hs_problem* p, int n, const double* xyz, const uint8_t* c) 
   if (c) P.lm_const.assign(c, c + n);
   return HS_OK;
 }
-int hs_set_imu(hs_problem* p, const double* T, const double* ig, const double* ia, const double* Sg, const double* Xa, int kb, double bt0, double bdt,
+int hsl_set_imu(hs_problem* p, const double* T, const double* ig, const double* ia, const double* Sg, const double* Xa, int kb, double bt0, double bdt,
                int nb, const double* bg, const double* ba, int bias_constant) {
   if (kb < 2 || kb > kMaxOrder || nb < kb || !(bdt > 0)) return p->err = "bad bias spline", HS_ERR_INVALID;
   Problem& P = p->P;
@@ -90,40 +91,40 @@ int hs_set_imu(hs_problem* p, const double* T, const double* ig, const double* i
   P.bias_const = bias_constant != 0;
   return HS_OK;
 }
-int hs_set_gravity(hs_problem* p, const double* g, int constant) {
+int hsl_set_gravity(hs_problem* p, const double* g, int constant) {
   put(p->P.gravity, g, 3);
   p->P.gravity_const = constant != 0;
   return HS_OK;
 }
-int hs_set_pixel_residuals(hs_problem* p, int n, const double* st, const double* px, const int32_t* lm, const int32_t* cam) {
+int hsl_set_pixel_residuals(hs_problem* p, int n, const double* st, const double* px, const int32_t* lm, const int32_t* cam) {
   Problem& P = p->P;
   P.px_stamp.assign(st, st + n), P.px_meas.assign(px, px + 2 * n), P.px_lm.assign(lm, lm + n), P.px_cam.assign(cam, cam + n);
   return HS_OK;
 }
-int hs_set_bearing_residuals(hs_problem* p, int n, const double* st, const double* b, const int32_t* lm, const int32_t* cam) {
+int hsl_set_bearing_residuals(hs_problem* p, int n, const double* st, const double* b, const int32_t* lm, const int32_t* cam) {
   Problem& P = p->P;
   P.br_stamp.assign(st, st + n), P.br_meas.assign(b, b + 3 * n), P.br_lm.assign(lm, lm + n), P.br_cam.assign(cam, cam + n);
   return HS_OK;
 }
-int hs_set_prior_residuals(hs_problem* p, int n, const double* st, const double* poses, const int32_t* sensor) {
+int hsl_set_prior_residuals(hs_problem* p, int n, const double* st, const double* poses, const int32_t* sensor) {
   Problem& P = p->P;
   P.pr_stamp.assign(st, st + n), P.pr_meas.assign(poses, poses + 7 * n), P.pr_sensor.assign(sensor, sensor + n);
   return HS_OK;
 }
-int hs_set_inertial_residuals(hs_problem* p, int n, const double* st, const double* m) {
+int hsl_set_inertial_residuals(hs_problem* p, int n, const double* st, const double* m) {
   Problem& P = p->P;
   P.in_stamp.assign(st, st + n), P.in_meas.assign(m, m + 6 * n);
   return HS_OK;
 }
-int hs_dim_pose(hs_problem* p) { return p->P.dim_pose(); }
-int hs_band_blocks(hs_problem*) { return 0; }
+int hsl_dim_pose(hs_problem* p) { return p->P.dim_pose(); }
+int hsl_band_blocks(hs_problem*) { return 0; }
 
-int hs_cost(hs_problem* p, double* cost) {
+int hsl_cost(hs_problem* p, double* cost) {
   *cost = double(Solver(p->P).total_cost());
   return HS_OK;
 }
 
-int hs_reduced_system(hs_problem* p, double radius, double* S, double* g) {
+int hsl_reduced_system(hs_problem* p, double radius, double* S, double* g) {
   LM lm(p->P);
   lm.radius = radius;
   NormalEquations ne;
@@ -137,7 +138,7 @@ int hs_reduced_system(hs_problem* p, double radius, double* S, double* g) {
   return HS_OK;
 }
 
-int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteration* iterations) {
+int hsl_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteration* iterations) {
   LM lm(p->P);
   const Summary s = lm.run(max_iterations);
   std::memset(summary, 0, sizeof(*summary));
@@ -157,11 +158,11 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
   return HS_OK;
 }
 
-int hs_get_control_points(hs_problem* p, double* cp) { return put(cp, p->P.cp.data(), p->P.cp.size()), HS_OK; }
-int hs_get_landmarks(hs_problem* p, double* xyz) { return put(xyz, p->P.lm.data(), p->P.lm.size()), HS_OK; }
-int hs_get_bias(hs_problem* p, double* bg, double* ba) {
+int hsl_get_control_points(hs_problem* p, double* cp) { return put(cp, p->P.cp.data(), p->P.cp.size()), HS_OK; }
+int hsl_get_landmarks(hs_problem* p, double* xyz) { return put(xyz, p->P.lm.data(), p->P.lm.size()), HS_OK; }
+int hsl_get_bias(hs_problem* p, double* bg, double* ba) {
   return put(bg, p->P.bias_g.data(), p->P.bias_g.size()), put(ba, p->P.bias_a.data(), p->P.bias_a.size()), HS_OK;
 }
-int hs_get_gravity(hs_problem* p, double* g) { return put(g, p->P.gravity, 3), HS_OK; }
+int hsl_get_gravity(hs_problem* p, double* g) { return put(g, p->P.gravity, 3), HS_OK; }
 
 }  // extern "C"

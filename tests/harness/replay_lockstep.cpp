@@ -11,7 +11,8 @@
 // "gauge fixed" when at least k of its control points are frozen (optimizer.cpp:323-328): the solution is then unique and the
 // 5-iteration trajectory is compared at 1e-6; the first windows of a replay (nothing frozen yet, stereo only) are rank
 // deficient up to the LM damping and are compared in quality only.
-//   usage: replay_lockstep <path/to/libhyperslam_hip.so> [seconds=3.6] [imu=0|1] [order=4]
+//   usage: replay_lockstep <path/to/libhyperslam_hip.so> [seconds=3.6] [imu=0|1] [order=4] [prefix=hs_]
+//   (prefix: the shadow's symbol prefix — hs_ the product, hsl_ oracle/liboracle_ld.so, hso_ oracle/liboracle.so = the harness against itself)
 // HS_LOCKSTEP_DUMP=<file> also writes the raw end points of every call (shadow and master control points and landmarks, binary:
 // int32 call, n_cp_values, n_lm_values, then the four double arrays), so that two runs with different shadows — the HIP library and
 // oracle/liboracle_ld.so, the long-double build of the oracle — can be compared with each other (tools/lockstep_three_way.py).
@@ -20,7 +21,7 @@
 
 #include <cstring>
 
-#include "replay_stream.hpp"
+#include "../../hyperslam_amd/host/replay_stream.hpp"
 
 using namespace hyper_hip;
 
@@ -72,7 +73,7 @@ extern "C" int hso_reduced_system(hs_problem*, double, double*, double*);
 
 int main(int argc, char** argv) {
   if (argc < 2) {
-    std::fprintf(stderr, "usage: replay_lockstep <libhyperslam_hip.so> [seconds] [imu] [order]\n");
+    std::fprintf(stderr, "usage: replay_lockstep <libhyperslam_hip.so> [seconds] [imu] [order] [prefix]\n");
     return 2;
   }
   const double seconds = argc > 2 ? std::atof(argv[2]) : 3.6;
@@ -85,8 +86,8 @@ int main(int argc, char** argv) {
     std::fprintf(stderr, "dlopen failed: %s\n", dlerror());
     return 2;
   }
-  // HS_LOCKSTEP_PREFIX=hso_ with liboracle.so as the shadow turns the harness into its own CPU self-test (all differences zero)
-  const std::string prefix = std::getenv("HS_LOCKSTEP_PREFIX") ? std::getenv("HS_LOCKSTEP_PREFIX") : "hs_";
+  // prefix hso_ with liboracle.so as the shadow turns the harness into its own CPU self-test (all differences zero)
+  const std::string prefix = argc > 5 ? argv[5] : std::getenv("HS_LOCKSTEP_PREFIX") ? std::getenv("HS_LOCKSTEP_PREFIX") : "hs_";
 #define HS_RESOLVE(name) resolve(H.lib, (prefix + #name).c_str(), &H.name)
   HS_RESOLVE(create), HS_RESOLVE(destroy), HS_RESOLVE(last_error), HS_RESOLVE(set_spline), HS_RESOLVE(set_cameras), HS_RESOLVE(set_sensors);
   HS_RESOLVE(set_landmarks), HS_RESOLVE(set_imu), HS_RESOLVE(set_gravity), HS_RESOLVE(set_bearing_residuals), HS_RESOLVE(set_pixel_residuals);

@@ -205,5 +205,6 @@ def test_hip_state_persists_across_delta_calls(hip, oracle):
         sa, so = A.solve(3), O.solve(3)
         assert abs(sa["initial_cost"] - so["initial_cost"]) <= 1e-6 * so["initial_cost"]
         assert abs(sa["final_cost"] - so["final_cost"]) <= 1e-6 * so["final_cost"]
+        assert A.landmarks().shape == (w.landmarks.shape[0] + 1, 3) and np.array_equal(A.landmarks()[-1], [0.5, 0.25, 2.0])
         assert np.abs(A.landmarks() - O.landmarks()).max() < 1e-6
         assert np.abs(A.control_points() - O.control_points()).max() < 1e-6

@@ -72,9 +72,8 @@ def check_replay_pair(a, ra, b, rb, rmse_bound):
 def run_lockstep(shadow_lib, *args, prefix=None):
     """replay_lockstep: the oracle drives the replay, `shadow_lib` is fed the same tables at every optimize(). Returns (calls, summary)."""
     env = dict(os.environ)
-    if prefix:
-        env["HS_LOCKSTEP_PREFIX"] = prefix
-    out = subprocess.run([os.path.join(HOST, "replay_lockstep"), shadow_lib, *map(str, args)], capture_output=True, text=True, timeout=900, env=env)
+    out = subprocess.run([os.path.join(ROOT, "tests", "harness", "replay_lockstep"), shadow_lib, *map(str, args), prefix or "hs_"], capture_output=True, text=True,
+                         timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     rows = [json.loads(l) for l in out.stdout.strip().splitlines()]
     return rows[:-1], rows[-1]
@@ -178,7 +177,7 @@ def test_replay_lockstep_hip_vs_oracle(built, seconds, imu, order, n_calls):
 def test_long_double_oracle_is_the_same_algorithm_cpu(built):
     """oracle/liboracle_ld.so (capi_ld.cpp: the restatement compiled in 80-bit long double) as the lock-step shadow of the double
     oracle: same windows, same accept / reject sequence, normal equations and end points within double rounding of each other."""
-    calls, summary = run_lockstep(os.path.join(ROOT, "oracle", "liboracle_ld.so"), 1.0, 1, 4)
+    calls, summary = run_lockstep(os.path.join(ROOT, "oracle", "liboracle_ld.so"), 1.0, 1, 4, prefix="hsl_")
     assert summary["optimizations"] == len(calls) == 9
     for c in calls:
         assert c["cost0_rel"] < 1e-12 and c["S_rel"] < 5e-9 and c["g_rel"] < 1e-9 and c["same_decisions"], c

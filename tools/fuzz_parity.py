@@ -66,7 +66,7 @@ def main():
     large = len(sys.argv) > 3 and sys.argv[3] == "large"
     hip = _lib.load()
     oracle = _lib.Library(os.path.join("oracle", "liboracle.so"), "hso_")
-    referee = _lib.Library(os.path.join("oracle", "liboracle_ld.so"), "hs_", strict=False)  # the oracle in 80-bit long double
+    referee = _lib.Library(os.path.join("oracle", "liboracle_ld.so"), "hsl_", strict=False)  # the oracle in 80-bit long double
     failures = []
     for tag, w in cases(n_cases, seed, large):
         try:

@@ -25,7 +25,7 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
     lib = _lib.load()
-    referee = _lib.Library(os.path.join("oracle", "liboracle_ld.so"), "hs_", strict=False)
+    referee = _lib.Library(os.path.join("oracle", "liboracle_ld.so"), "hsl_", strict=False)
     failures = 0
     for tag, w in cases(n_cases, seed, large):
         flag = torch.zeros(1, dtype=torch.int64)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Three-way lock-step comparison: oracle in double (master), oracle in long double and the HIP library, from identical tables.
 
-TEST TOOLING (runs on the GPU box; uses oracle/ as the checker only). The lock-step harness (hyperslam_amd/host/replay_lockstep)
+TEST TOOLING (runs on the GPU box; uses oracle/ as the checker only). The lock-step harness (tests/harness/replay_lockstep)
 is run twice with the same master — the double oracle, whose results drive the replay, so both runs see the very same windows — once
 with libhyperslam_hip.so and once with oracle/liboracle_ld.so (capi_ld.cpp: the same restatement compiled in 80-bit long double) as
 the shadow. HS_LOCKSTEP_DUMP gives the raw end points of every call; this script prints, per gauge-fixed call,
@@ -46,7 +46,8 @@ def rel(a, b):
 
 def run(shadow, args, tmp, tag):
     env = dict(os.environ, HS_LOCKSTEP_DUMP=os.path.join(tmp, tag + ".bin"))
-    res = subprocess.run([os.path.join(ROOT, "hyperslam_amd/host/replay_lockstep"), shadow] + args, env=env, capture_output=True, text=True, check=True)
+    prefix = "hsl_" if os.path.basename(shadow) == "liboracle_ld.so" else "hs_"
+    res = subprocess.run([os.path.join(ROOT, "tests/harness/replay_lockstep"), shadow] + args + [prefix], env=env, capture_output=True, text=True, check=True)
     rows = [json.loads(l) for l in res.stdout.splitlines() if l.startswith("{")]
     return rows, read_dump(env["HS_LOCKSTEP_DUMP"])
 

@@ -1,4 +1,4 @@
-"""Phase timestamps of k_band_factor_mx (profiling build, HS_DEBUG_FLAGS = 16 | 64, 100 MHz clock): python tools/mx_phase_timing.py [config]"""
+"""Phase timestamps of k_band_factor_mx (profiling build, HS_DEBUG_FLAGS = 16, 100 MHz clock): python tools/mx_phase_timing.py [config]"""
 import os, sys, ctypes as C; sys.path.insert(0, ".")
 os.environ["HS_DEBUG_FLAGS"] = str(16 | int(os.environ.get("HS_DEBUG_FLAGS", "0")))
 import numpy as np

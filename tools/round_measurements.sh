@@ -29,7 +29,7 @@ python bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline > $out/${tag}
   for a in "6.0 1 4" "6.0 0 4" "6.0 1 6" "8.0 1 4"; do ./replay $a 2>/dev/null | tail -1; HS_STAGE_TIMING=1 ./replay $a 2>/dev/null | tail -1; done
   ./replay_oracle 6.0 1 4 2>/dev/null | tail -1 ) > $out/${tag}_replay.txt 2>&1
 ( cd hyperslam_amd/host; for a in "6.0 1 4" "6.0 0 4"; do echo "replay $a"; HS_HOST_TIMING=1 ./replay $a 2>&1 >/dev/null | grep "host timing"; done ) > $out/${tag}_replay_host_split.txt 2>&1
-for a in "3.6 0 4" "3.6 1 4" "6.0 1 6" "6.0 1 4"; do hyperslam_amd/host/replay_lockstep hyperslam_amd/libhyperslam_hip.so $a > $out/${tag}_lockstep_$(echo $a | tr ' .' '__').jsonl 2>&1; done
+for a in "3.6 0 4" "3.6 1 4" "6.0 1 6" "6.0 1 4"; do tests/harness/replay_lockstep hyperslam_amd/libhyperslam_hip.so $a > $out/${tag}_lockstep_$(echo $a | tr ' .' '__').jsonl 2>&1; done
 # round 5 additions: oracle(double) / oracle(long double) / HIP from identical tables; the pipelined border sweep against the sequential one
 # (bit identity under repetition, configs[2] timing); the fused build on window-wide bands against the record path on the replays
 python tools/lockstep_three_way.py 3.6 0 4 --out $out/${tag}_three_way_3_6_0_4.txt > /dev/null 2>&1

@@ -1,9 +1,9 @@
-"""Phase timestamps of k_update_visual (HS_DEBUG_FLAGS=128, profiling build: tools/build_profiling_lib.sh).
+"""Phase timestamps of k_update_visual (HS_DEBUG_FLAGS=512, profiling build: tools/build_profiling_lib.sh).
 usage (GPU box): python tools/update_phase_timing.py [config=1]"""
 import os
 import sys, ctypes as C; sys.path.insert(0, ".")
 import numpy as np
-os.environ["HS_DEBUG_FLAGS"] = str(128 | int(os.environ.get("HS_DEBUG_FLAGS", "0")))
+os.environ["HS_DEBUG_FLAGS"] = str(512 | int(os.environ.get("HS_DEBUG_FLAGS", "0")))
 import hyperslam_amd as ha
 from hyperslam_amd import synthetic, _lib
 _lib.PRODUCT_LIB = os.path.join("tools", "libhyperslam_hip_prof.so")

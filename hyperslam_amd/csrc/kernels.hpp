@@ -26,8 +26,9 @@
 #include "kernels_factor_mx.hpp"
 #include "kernels_backward_sb.hpp"
 #if HS_PROFILE_HOOKS  // measured alternatives (A/B switches of HS_DEBUG_FLAGS): profiling builds only, the product library carries one path per band class
-#include "kernels_backward.hpp"
-#include "kernels_factor_mfma.hpp"
+#include "../../tools/ab/kernels_backward2.hpp"
+#include "../../tools/ab/kernels_backward.hpp"
+#include "../../tools/ab/kernels_factor_mfma.hpp"
 #endif
 #include "kernels_update.hpp"
 #include "kernels_aux.hpp"

@@ -1,6 +1,8 @@
+// A/B ALTERNATIVE, PROFILING BUILDS ONLY (tools/build_profiling_lib.sh, -DHS_PROFILE_HOOKS=1; included by hyperslam_amd/csrc/kernels.hpp behind
+// that switch): k_band_backward_w / k_premultiply (single-wave register sweep, HS_DEBUG_FLAGS 65536), the measured alternative of k_band_backward_sb. Not part of the product library.
 // kernels_backward.hpp — register-resident backward sweep of the banded solve (part of kernels.hpp; included once by capi.hip through it).
 #pragma once
-#include "kernels_factor.hpp"
+#include "../../hyperslam_amd/csrc/kernels_factor.hpp"
 
 namespace hs {
 

@@ -1,9 +1,11 @@
+// A/B ALTERNATIVE, PROFILING BUILDS ONLY (tools/build_profiling_lib.sh, -DHS_PROFILE_HOOKS=1; included by hyperslam_amd/csrc/kernels.hpp behind
+// that switch): k_band_factor_mfma (round 2: trailing window in LDS-resident f64 MFMA tiles, HS_DEBUG_FLAGS 131072), which lost to k_band_factor_la and was superseded by k_band_factor_mx. Not part of the product library.
 // kernels_factor_mfma.hpp — block-banded Cholesky with the rank-6 trailing update on the f64 matrix cores (part of kernels.hpp; included once by capi.hip through it).
 #pragma once
 #include <climits>
 #include <utility>
 
-#include "kernels_factor.hpp"
+#include "../../hyperslam_amd/csrc/kernels_factor.hpp"
 
 namespace hs {
 

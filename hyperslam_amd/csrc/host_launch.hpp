@@ -428,6 +428,13 @@ int launch_factor(hs_problem* p) {
   const int f0 = (T.debug_flags & 262144) ? 0 : std::min(p->frozen_prefix, n_blk - 1);  // A/B switch 262144: eliminate every block row
   Tables Tf = T;
   const int n_eff = n_blk - f0;
+  // Small systems (the sliding window's steady state: ~33 free block rows with window-wide bands, bordered with an IMU): factorisation, border
+  // and both sweeps in ONE launch, trailing matrix in the accumulators of the f64 matrix cores (kernels_dense_mx.hpp). A/B switch 8: the kernels below.
+  if (!nt && dense_mx_fits(n_eff, T.nb) && !(T.debug_flags & 8)) {
+    k_dense_solve_mx<<<1, kDxThreads, size_t(kDxLdsDoubles) * sizeof(double), s>>>(T, f0, p->d_dense_ut.p);
+    HIP_TRY(hipGetLastError());
+    return HS_OK;
+  }
   const bool dense = !nt && !(T.debug_flags & 2097152) && T.bw > 14 && n_eff <= 2 * T.bw &&
                      dense_factor_fits(n_eff, std::min(T.bw, n_eff));  // A/B switch 2097152: banded kernels
   if (f0 > 0) {
@@ -604,7 +611,7 @@ static void warm_kernels(int device) {
       reinterpret_cast<const void*>(&k_group_gram<1>), reinterpret_cast<const void*>(&k_group_gram<2>), reinterpret_cast<const void*>(&k_group_gram<4>),
       reinterpret_cast<const void*>(&k_pack_exchange), reinterpret_cast<const void*>(&k_cost_reduce), reinterpret_cast<const void*>(&k_finalize_reduced),
       reinterpret_cast<const void*>(&k_finalize_border), reinterpret_cast<const void*>(&k_reduce_partials), reinterpret_cast<const void*>(&k_factor_decoupled_rows),
-      reinterpret_cast<const void*>(&k_dense_factor), reinterpret_cast<const void*>(&k_band_factor_wide), reinterpret_cast<const void*>(&k_band_factor<1>),
+      reinterpret_cast<const void*>(&k_dense_factor), reinterpret_cast<const void*>(&k_dense_solve_mx), reinterpret_cast<const void*>(&k_band_factor_wide), reinterpret_cast<const void*>(&k_band_factor<1>),
       reinterpret_cast<const void*>(&k_band_factor<2>), reinterpret_cast<const void*>(&k_band_factor_la<1, 3>), reinterpret_cast<const void*>(&k_band_factor_la<1, 4>),
       reinterpret_cast<const void*>(&k_band_backward), reinterpret_cast<const void*>(&k_band_backward_sb), reinterpret_cast<const void*>(&k_border_forward),
       reinterpret_cast<const void*>(&k_border_forward2),
@@ -637,6 +644,7 @@ int set_func_attributes(hs_problem* p) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_update_visual<K>), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_visual<K>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
   });
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_solve_mx), hipFuncAttributeMaxDynamicSharedMemorySize, int(kDxLdsDoubles * sizeof(double))));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_solve_reg<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_solve_reg<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_border_solve_reg<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));

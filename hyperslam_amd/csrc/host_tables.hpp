@@ -293,6 +293,7 @@ struct hs_problem {
   DBuf<double> d_Vb, d_Vb2, d_yt, d_yt2;  // block-row-scaled factors diag(U_jj^-1) U and right-hand sides for the register sweep
   DBuf<double> d_Sb2, d_g2, d_Ub2, d_Ubk2, d_ybuf2, d_win, d_xsol;  // two-ended factorisation: reversed system, its factor, junction window
   DBuf<unsigned> d_join;
+  DBuf<double> d_dense_ut;     // k_dense_solve_mx: the factor by columns (256 x 256), read back by its sweep
   DBuf<double> d_bf_handover;  // k_border_forward2: what the far end's sweep leaves on the middle rows, per column group
   unsigned join_epoch = 0;
   DBuf<int> d_gw_ptr, d_gw_cf, d_sw_ptr, d_sw_seg;
@@ -723,6 +724,7 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_ybuf2.reserve(np));
   HIP_TRY(p->d_xsol.reserve(np));
   HIP_TRY(p->d_win.reserve(size_t(6) * vs.bw * (ncb + 1)));
+  HIP_TRY(p->d_dense_ut.reserve(size_t(16 * kDxTiles) * (16 * kDxTiles)));
   if (!p->d_join.p) {
     // [0] two-ended factor / sweep hand-over, [1] last-block ticket of the backward sweeps, [2] of k_border_bb, [4 ..] super-block inverses
     HIP_TRY(p->d_join.reserve(kBfFlagBase + 512 + 4 * kProgressStride));  // (+ one flag per column group of k_border_forward2, + the four progress words of a pipelined sweep)
@@ -838,6 +840,7 @@ int prepare(hs_problem* p) {
   // 65536 single-wave register backward sweep (k_band_backward_w) instead of the four-wave LDS sweeps
   // 262144 eliminate / sweep the decoupled block rows of leading constant control points like any other     524288 border Cholesky in LDS
   // 128 border forward sweep behind the factorisation instead of alongside it
+  //   8 small systems (6 n_free + nb <= 256) on the one-ended band kernels + border chain + k_band_backward instead of k_dense_solve_mx
   // 256 phase timestamps of k_assemble (profiling builds)          512 phase timestamps of k_update_visual (profiling builds)
   //   (64 and 128 are product A/B switches: the stamps of k_assemble / k_update_visual used to share them, so that timing one of those kernels
   //    also changed the factorisation path)

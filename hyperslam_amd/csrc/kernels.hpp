@@ -24,6 +24,7 @@
 #include "kernels_border.hpp"
 #include "kernels_factor.hpp"
 #include "kernels_factor_mx.hpp"
+#include "kernels_dense_mx.hpp"
 #include "kernels_backward_sb.hpp"
 #if HS_PROFILE_HOOKS  // measured alternatives (A/B switches of HS_DEBUG_FLAGS): profiling builds only, the product library carries one path per band class
 #include "../../tools/ab/kernels_backward2.hpp"

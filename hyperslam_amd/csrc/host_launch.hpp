@@ -118,6 +118,26 @@ static bool factor_two_ended_la(const hs_problem* p) {
   return T.nb == 0 && !(T.debug_flags & 4) && la_compute_waves(T.bw) > 0 && !HS_AB(T.debug_flags, 131072) && n_blk >= 4 * T.bw && T.Sb2 && !(T.debug_flags & 2048);
 }
 
+int mfma_window_tiles(int bw);
+/// launch_factor's rule for factoring from both ends at once (every case: k_band_factor_mx / _la, bordered or not; profiling builds: _mfma).
+static bool factor_two_ended_any(const hs_problem* p) {
+  const Tables& T = p->T;
+  const int n_blk = T.np / 6;
+  const bool la_ok = !(T.debug_flags & 4) && la_compute_waves(T.bw) > 0;
+  const int nt = HS_AB(T.debug_flags, 131072) ? mfma_window_tiles(T.bw) : 0;
+  return (la_ok || nt) && (T.nb == 0 || (!nt && !(T.debug_flags & 536870912) && (T.nb + kBorderCols - 1) / kBorderCols <= 512)) && n_blk >= 4 * T.bw && T.Sb2 &&
+         !(T.debug_flags & 2048);  // (512: flag words of k_border_forward2's column groups)
+}
+/// launch_factor's rule for k_dense_solve_mx: one-ended solves of small systems — the sliding window's steady state (kernels_dense_mx.hpp).
+/// *f0 = the decoupled block rows of the leading constant control points. launch_build asks too: the finalisation kernels then write the dense
+/// copy of the system the kernel loads its tiles from (Tables::dense). A/B switch 8: the one-ended band kernels + border chain + k_band_backward.
+static bool use_dense_mx(const hs_problem* p, int* f0) {
+  const Tables& T = p->T;
+  const int n_blk = T.np / 6;
+  *f0 = (T.debug_flags & 262144) ? 0 : std::min(p->frozen_prefix, n_blk - 1);  // A/B switch 262144: eliminate every block row
+  return !factor_two_ended_any(p) && !HS_AB(T.debug_flags, 131072) && dense_mx_fits(n_blk - *f0, T.nb) && !(T.debug_flags & 8);
+}
+
 /// scaling_fixed: a step of this solve has been computed (every linearisation but the first): the Jacobi scaling is fixed, and on a single
 /// shard without border unknowns whose factorisation is the two-ended look-ahead kernel k_assemble writes the scaled, damped system itself
 /// (direct mode) — no k_finalize_reduced launch; the iteration bookkeeping moves into the factorisation's prologue (Tables::bookkeep).
@@ -232,8 +252,10 @@ int launch_build(hs_problem* p, hipEvent_t after_build = nullptr, bool scaling_f
   HIP_TRY(hipGetLastError());
   const int rc = exchange(p, T.xbuf, T.x_count1);  // one RCCL all-reduce of [S | g | diag | cost] per linearisation
   if (rc) return rc;
-  k_finalize_reduced<<<T.sp.n_cp + (reduce_here ? 1 + nb_wg : 0), kBlock, 0, s>>>(T, p->n_split);  // + 1: packing / bookkeeping workgroup, + border
-  if (T.nb && !reduce_here) k_finalize_border<<<nb_wg, kBlock, 0, s>>>(T);
+  Tables Td = T;
+  if (use_dense_mx(p, &Td.dense_f0)) Td.dense = p->d_dense_ut.p + size_t(kDenseLd) * kDenseLd;  // (second half of the scratch: the first is the factor by columns)
+  k_finalize_reduced<<<T.sp.n_cp + (reduce_here ? 1 + nb_wg : 0), kBlock, 0, s>>>(Td, p->n_split);  // + 1: packing / bookkeeping workgroup, + border
+  if (T.nb && !reduce_here) k_finalize_border<<<nb_wg, kBlock, 0, s>>>(Td);
   if (!reduce_here) k_cost_reduce<<<1, kBlock, 0, s>>>(T);
   HIP_TRY(hipGetLastError());
   return HS_OK;
@@ -308,8 +330,7 @@ int launch_factor(hs_problem* p) {
   const int nt = HS_AB(T.debug_flags, 131072) ? mfma_window_tiles(T.bw) : 0;  // A/B switch 131072 (profiling builds): k_band_factor_mfma instead of the VALU kernels
   // (bordered systems — bias splines + gravity — too: the forward sweep of the border columns follows the two-ended elimination order,
   //  k_border_forward2; A/B switch 536870912: bordered systems one-ended)
-  const bool two_ended = (la_ok || nt) && (T.nb == 0 || (!nt && !(T.debug_flags & 536870912) && (T.nb + kBorderCols - 1) / kBorderCols <= 512)) &&
-                         n_blk >= 4 * T.bw && T.Sb2 && !(T.debug_flags & 2048);  // (512: flag words of k_border_forward2's column groups)
+  const bool two_ended = factor_two_ended_any(p);
 #if HS_PROFILE_HOOKS
   auto run_mfma = [&](const Tables& TT, int grid) -> hipError_t {
     switch (nt) {
@@ -425,13 +446,17 @@ int launch_factor(hs_problem* p) {
   }
   // One-ended. Block rows of the leading constant control points are decoupled (k_factor_decoupled_rows): the dependency chain of the
   // factorisation starts behind them — the same kernels on the trailing sub-matrix (the band storage is row relative: pointer offsets).
-  const int f0 = (T.debug_flags & 262144) ? 0 : std::min(p->frozen_prefix, n_blk - 1);  // A/B switch 262144: eliminate every block row
+  int f0 = 0;
+  const bool dense_mx = use_dense_mx(p, &f0);
   Tables Tf = T;
   const int n_eff = n_blk - f0;
   // Small systems (the sliding window's steady state: ~33 free block rows with window-wide bands, bordered with an IMU): factorisation, border
-  // and both sweeps in ONE launch, trailing matrix in the accumulators of the f64 matrix cores (kernels_dense_mx.hpp). A/B switch 8: the kernels below.
-  if (!nt && dense_mx_fits(n_eff, T.nb) && !(T.debug_flags & 8)) {
-    k_dense_solve_mx<<<1, kDxThreads, size_t(kDxLdsDoubles) * sizeof(double), s>>>(T, f0, p->d_dense_ut.p);
+  // and both sweeps in ONE launch, trailing matrix in the accumulators of the f64 matrix cores (kernels_dense_mx.hpp), tiles loaded from the
+  // dense copy the finalisation kernels of launch_build wrote. A/B switch 8: the kernels below.
+  if (dense_mx) {
+    Tables Td = T;
+    Td.dense = p->d_dense_ut.p + size_t(kDenseLd) * kDenseLd, Td.dense_f0 = f0;
+    k_dense_solve_mx<<<1, kDxThreads, size_t(kDxLdsDoubles) * sizeof(double), s>>>(Td, f0, p->d_dense_ut.p);
     HIP_TRY(hipGetLastError());
     return HS_OK;
   }

@@ -724,7 +724,7 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_ybuf2.reserve(np));
   HIP_TRY(p->d_xsol.reserve(np));
   HIP_TRY(p->d_win.reserve(size_t(6) * vs.bw * (ncb + 1)));
-  HIP_TRY(p->d_dense_ut.reserve(size_t(16 * kDxTiles) * (16 * kDxTiles)));
+  HIP_TRY(p->d_dense_ut.reserve(size_t(2) * kDenseLd * kDenseLd));  // the factor by columns | the dense copy of the system (Tables::dense)
   if (!p->d_join.p) {
     // [0] two-ended factor / sweep hand-over, [1] last-block ticket of the backward sweeps, [2] of k_border_bb, [4 ..] super-block inverses
     HIP_TRY(p->d_join.reserve(kBfFlagBase + 512 + 4 * kProgressStride));  // (+ one flag per column group of k_border_forward2, + the four progress words of a pipelined sweep)

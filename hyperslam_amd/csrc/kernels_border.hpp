@@ -249,7 +249,12 @@ HSD void finalize_border_body(const Tables& T, const int wg, const int n_wg, con
       } else {
         hpb = X[T.xo_pb + e];
       }
-      T.Spb[e] = sp_of(row) * hpb * sb_of(c);
+      const double spb = sp_of(row) * hpb * sb_of(c);
+      T.Spb[e] = spb;
+      if (T.dense && row >= 6 * T.dense_f0) {
+        const int ii = row - 6 * T.dense_f0, jj = np - 6 * T.dense_f0 + c;
+        T.dense[size_t(ii) * kDenseLd + jj] = spb, T.dense[size_t(jj) * kDenseLd + ii] = spb;
+      }
     } else {
       const int b = row - np;
       const double sr = sb_of(b), sc = sb_of(c);
@@ -266,11 +271,24 @@ HSD void finalize_border_body(const Tables& T, const int wg, const int n_wg, con
         }
         const double g = X[T.xo_gb + b];
         T.gb_s[b] = sr * g;
+        if (T.dense) {  // the right-hand side as column (and row) n_dense of the dense copy
+          const int ii = np - 6 * T.dense_f0 + b, n_dense = np - 6 * T.dense_f0 + nb;
+          T.dense[size_t(ii) * kDenseLd + n_dense] = sr * g, T.dense[size_t(n_dense) * kDenseLd + ii] = sr * g;
+        }
         if (fresh) T.scale_b[b] = sr;
         T.gabs[T.np + b] = fabs(g);
       }
       T.Sbb[size_t(b) * nb + c] = out;
+      if (T.dense) T.dense[size_t(np - 6 * T.dense_f0 + b) * kDenseLd + (np - 6 * T.dense_f0 + c)] = out;
     }
+  }
+  if (T.dense) {  // padding of the dense copy behind the right-hand side column: zero against the border unknowns (the pose rows: k_finalize_reduced)
+    const int n_pose = np - 6 * T.dense_f0, n_dense = n_pose + nb, n_pad = 16 * ((n_dense + 1 + 15) / 16), n_padc = n_pad - (n_dense + 1);
+    for (int e = wg * blockDim.x + threadIdx.x; e < n_padc * nb; e += n_wg * blockDim.x) {
+      const int ii = n_dense + 1 + e / nb, jj = n_pose + e % nb;
+      T.dense[size_t(ii) * kDenseLd + jj] = 0.0, T.dense[size_t(jj) * kDenseLd + ii] = 0.0;
+    }
+    dense_padding_corner(T.dense, n_dense, n_pad, wg * blockDim.x + threadIdx.x, n_wg * blockDim.x);
   }
 }
 

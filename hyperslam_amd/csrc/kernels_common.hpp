@@ -14,6 +14,7 @@ constexpr int kBlock = 256;
 #ifndef HS_PROFILE_HOOKS
 #define HS_PROFILE_HOOKS 0
 #endif
+constexpr int kDenseLd = 256;  // leading dimension of the dense copy of a small reduced system (Tables::dense, kernels_dense_mx.hpp)
 HSD bool prof_enabled(int debug_flags, int bit) { return HS_PROFILE_HOOKS && (debug_flags & bit); }
 
 /// A bounded wait gave up: the solve ends here (every later kernel exits on `done`, hs_solve reports the reason) — nothing downstream may

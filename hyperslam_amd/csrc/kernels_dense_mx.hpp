@@ -14,12 +14,12 @@
 // factor are what the elimination produces on the way (nothing in the algebra distinguishes them).
 //
 //   data      16 x 16 tiles (I, J), I <= J, of the padded matrix (identity on the padding) live in MFMA accumulators for the whole
-//             factorisation: register r of lane l = entry (4 r + (l >> 4), l & 15) of the tile. Wave w = (a, b) owns the tiles with
-//             I mod 2 = a, J in {b, 7 - b, 8 + b, 15 - b} (2-D cyclic, the columns dealt in a zigzag: 18 or 16 tiles per wave; every step's
-//             tile row and trailing matrix are spread over all waves; a wave loads 8 + 4 operand columns per step instead of two per tile).
+//             factorisation: register r of lane l = entry (4 r + (l >> 4), l & 15) of the tile. 2-D cyclic over the eight waves (DxTiles):
+//             tile rows in two classes (five rows for the four panel waves, eleven for the others), tile columns in four — every step's tile
+//             row and trailing matrix are spread over all SIMDs; a wave loads 5 (11) + 4 operand columns per step instead of two per tile.
 //   step k    (1) the owners of tile row k write it to LDS                                                                --- barrier ---
-//             (2) panel, one lane per column of the row (the 16 columns of the diagonal tile and the right-hand side redundantly in every
-//                 wave, like the six extra lanes of k_band_factor_mx's panel): right-looking Cholesky of the 16 x 16 diagonal block fused with
+//             (2) panel, four waves (one per SIMD), one or two columns of the row per lane (the 16 columns of the diagonal tile and the
+//                 right-hand side redundantly in every panel wave, like the six extra lanes of k_band_factor_mx's panel): right-looking Cholesky of the 16 x 16 diagonal block fused with
 //                 the forward substitution of every column, pivots and multipliers broadcast with v_readlane (SGPR operands) — plain
 //                 substitution, no explicit inverse on the forward path. Sixteen extra columns start as the identity and come out as the rows
 //                 of W_k = U_kk^-1 (for the backward sweep only). The panel also updates the right-hand side (g_c -= x_c . y_k), writes
@@ -32,33 +32,60 @@
 //             model cost change: what k_band_backward wrote (kernels_factor.hpp), so that the update kernels do not change.
 // Bring-up: tests/emul/factor_harness.cpp variant 6 (the kernel source on the CPU against numpy), then tests/test_gpu_edge_cases.py.
 #pragma once
+#include <utility>
+
 #include "kernels_factor.hpp"
 
 namespace hs {
 
-constexpr int kDxThreads = 512;   // eight waves, two per SIMD
+constexpr int kDxThreads = 768;   // twelve waves, three per SIMD
 constexpr int kDxTiles = 16;      // N <= 256
 constexpr int kDxLd = 272;        // LDS row stride of a panel row (doubles)
-constexpr int kDxColsPerWave = 47;  // lanes 17 .. 63 of a panel wave: one column each (lanes 0 .. 15: diagonal tile, 16: right-hand side)
 // LDS (doubles): panel rows, double buffered | W_k rows (16 x 256) | g | y | x | pend_K (2 x 16) | block sums
 constexpr int kDxOffW = 2 * 16 * kDxLd, kDxOffG = kDxOffW + 16 * 256, kDxOffY = kDxOffG + kDxLd, kDxOffX = kDxOffY + kDxLd, kDxOffP = kDxOffX + kDxLd,
               kDxOffRed = kDxOffP + 32, kDxLdsDoubles = kDxOffRed + 32;
 typedef double dx_f64x4 __attribute__((vector_size(32)));
 
 /// Systems the kernel holds: n_free free block rows + nb border unknowns within 16 tiles of 16.
-__host__ __device__ constexpr bool dense_mx_fits(int n_free, int nb) { return n_free >= 1 && 6 * n_free + nb <= 16 * kDxTiles; }
+/// (+ 1: the right-hand side is column n_dense of the padded matrix)
+__host__ __device__ constexpr bool dense_mx_fits(int n_free, int nb) { return n_free >= 1 && 6 * n_free + nb + 1 <= 16 * kDxTiles; }
 
-/// Tiles of wave (A, B): (I, J) = (A + 2 iq, col(jq)), I <= J < 16, with the tile columns dealt to the four classes B in a zigzag —
-/// {B, 7 - B, 8 + B, 15 - B} — so that every wave holds 18 or 16 tiles (J mod 4 = B: 12 .. 20); slot of a tile in the wave's accumulator array.
-template <int A, int B>
-struct DxTiles {
-  static constexpr int col(int jq) { return 8 * (jq >> 1) + ((jq & 1) ? 7 - B : B); }
-  static constexpr int rows_of(int jq) { return (col(jq) - A) >= 0 ? (col(jq) - A) / 2 + 1 : 0; }  // tiles of tile column jq
-  // (no recursion: a recursive constexpr function is not inlined on the device, and a run-time call here turns the accumulator array into scratch memory)
-  static constexpr int first(int jq) { return (jq > 0 ? rows_of(0) : 0) + (jq > 1 ? rows_of(1) : 0) + (jq > 2 ? rows_of(2) : 0) + (jq > 3 ? rows_of(3) : 0); }
-  static constexpr int count = first(4);
-  static constexpr int slot(int iq, int jq) { return first(jq) + iq; }
+/// Tiles of a wave. Tile COLUMNS are dealt to four column classes b in a zigzag, col(b, jq) = {b, 7 - b, 8 + b, 15 - b}: one column of every
+/// group of four; tile ROWS to three row classes A — rows 3 6 9 13 for the four panel waves (which also hold 32 - 64 registers of panel columns),
+/// rows 0 2 7 10 12 15 and 1 4 5 8 11 14 for the others. A wave (A, b) holds the tiles (I, J) of its rows and columns with J in a LATER OR THE
+/// SAME group of four as I: 10 / 15 / 15 tiles; which of a row's tiles in its own group lie above the diagonal depends on b, and the code
+/// does not ask — a tile below the diagonal is loaded, updated and written out like the others and never read by anybody (17 % of the tiles).
+/// That makes the code of a row class the same for every column class: b only enters addresses. (A variant per (A, b) with exactly the tiles
+/// I <= J meant a four-way dispatch around every phase of every step, and the compiler merged the accumulator arrays of the variants behind each:
+/// 600 - 3 000 spilled registers.) A SIMD holds one wave of each row class, all of one column class: 40 tiles per SIMD.
+constexpr int kDxRow[3][6] = {{3, 6, 9, 13, 99, 99}, {0, 2, 7, 10, 12, 15}, {1, 4, 5, 8, 11, 14}};  // tile rows of a row class
+constexpr int kDxFirst[3][7] = {{0, 4, 7, 9, 10, 10, 10}, {0, 4, 8, 11, 13, 14, 15}, {0, 4, 7, 10, 12, 14, 15}};  // slot of a row's first tile (4 - row / 4 tiles per row)
+template <int A>
+struct DxRows {
+  // (tables, not loops: the slot of a tile has to fold to a constant wherever it is used — an index the compiler cannot fold puts the accumulator
+  //  array into scratch memory, and a recursive constexpr function is not even inlined on the device)
+  static constexpr int n_rows = A == 0 ? 4 : 6;
+  static constexpr int row(int iq) { return kDxRow[A][iq]; }
+  static constexpr int jq_min(int iq) { return kDxRow[A][iq] / 4; }  // first column group of the row's tiles
+  static constexpr int count = kDxFirst[A][n_rows];
+  static constexpr int slot(int iq, int jq) { return kDxFirst[A][iq] + jq - kDxRow[A][iq] / 4; }
 };
+HSD int dx_col(int b, int jq) { return 8 * (jq >> 1) + ((jq & 1) ? 7 - b : b); }
+
+/// acc += a b on the f64 matrix core. (The builtin, not inline assembly with the accumulator as a read-write operand — tried, to keep the compiler
+/// from writing the result elsewhere: the hazard recogniser does not look inside an asm statement, and four dependent v_mfma_f64_16x16x4_f64 on one
+/// accumulator need the wait states the ISA lists between them. Wrong results on the device, right ones in the emulation.)
+HSD void dx_mfma(dx_f64x4& acc, double a, double b) { acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0); }
+
+/// An assembler comment that carries a compile-time number: two blocks of code that contain different ones are different code. (The bodies of
+/// the phases below for two tile rows with equally many tiles differ in the accumulators' indices only; the compiler merged such pairs into one
+/// block with the index as a run-time value — and an accumulator array indexed at run time lives in scratch memory.)
+template <int N>
+HSD void dx_keep_apart() {
+#if !defined(HS_EMULATED_DEVICE)
+  asm volatile("; dx %0" ::"n"(N));
+#endif
+}
 
 HSD double dx_readlane(double v, int lane) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
@@ -68,125 +95,235 @@ HSD double dx_rsqrt(double d) {  // 1 / sqrt(d): hardware estimate + one Newton-
   return fma(y0 * e, fma(0.375, e, 0.5), y0);
 }
 
-/// Where the scaled, damped system lives (copies of the Tables fields: selecting between the pointers of the kernel argument itself made
-/// the compiler copy the whole 2.3 KB structure to scratch memory).
-struct DxSys {
-  const double *Sb, *Spb, *Sbb;
-  int ncb, nb, f0, n_pose, n_dense;
+/// The three phases that touch the accumulators (registers: every index a compile-time constant). lane: the lane's place in a register row of a
+/// tile, (l >> 4) rows down and (l & 15) columns in, in units of the row stride; cb[jq]: first column of the wave's tile column jq.
+template <int A>
+struct DxWave {
+  using R = DxRows<A>;
+  typedef dx_f64x4 Acc[R::count];
+  /// load: the wave's tiles from the dense copy of the scaled, damped system the finalisation kernels wrote (Tables::dense: row-major, leading
+  /// dimension 256, both triangles, identity on the padding) — a scalar row base per register row, the lane's offset, the tile column.
+  /// (Round 6 first loaded from the band / border tables directly: a region test and an address select per entry, unrolled, was 60 000 lines of ISA.)
+  static HSD void load(const double* D, unsigned lane, const int (&cb)[4], Acc& acc) {
+#pragma unroll
+    for (int iq = 0; iq < R::n_rows; ++iq) {
+      const double* row = D + 16 * R::row(iq) * kDenseLd;  // (wave uniform)
+#pragma unroll
+      for (int jq = 0; jq < 4; ++jq) {  // (constant trip counts: a bound that depends on the outer loop's variable is not unrolled)
+        if (jq < R::jq_min(iq)) continue;
+        const double* src = row + lane + unsigned(cb[jq]);
+        // (the tile as ONE value: written register by register the array stayed an object in memory — scratch)
+        acc[R::slot(iq, jq)] = dx_f64x4{src[0], src[4 * kDenseLd], src[8 * kDenseLd], src[12 * kDenseLd]};
+      }
+    }
+  }
+  /// (1) tile row k -> LDS. (The rows as template arguments — a fold over an index sequence instead of an unrolled loop — so that each row's code
+  /// can carry its own number, dx_keep_apart.)
+  template <int IQ>
+  static HSD void extract_row(int k, unsigned lane, const int (&cb)[4], double* xb, const Acc& acc) {
+    if (R::row(IQ) != k) return;
+    dx_keep_apart<R::row(IQ)>();
+#pragma unroll
+    for (int jq = 0; jq < 4; ++jq) {
+      if (jq < R::jq_min(IQ)) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xb[4 * r * kDxLd + lane + unsigned(cb[jq])] = acc[R::slot(IQ, jq)][r];
+    }
+  }
+  template <int... IQ>
+  static HSD void extract_rows(std::integer_sequence<int, IQ...>, int k, unsigned lane, const int (&cb)[4], double* xb, const Acc& acc) {
+    (extract_row<IQ>(k, lane, cb, xb, acc), ...);
+  }
+  static HSD void extract(int k, unsigned lane, const int (&cb)[4], double* xb, const Acc& acc) {
+    extract_rows(std::make_integer_sequence<int, R::n_rows>{}, k, lane, cb, xb, acc);
+  }
+  /// (3) trailing update: tile (I, J) -= X(k, I)' X(k, J) for the rows lo <= I < hi. The A operand (negated) is shared by the tiles of a row.
+  template <int IQ>
+  static HSD void update_row(int k, int lo, int hi, unsigned lane, const int (&cb)[4], const double* xb, Acc& acc) {
+    constexpr int I = R::row(IQ);
+    if (I < lo || I >= hi) return;
+    dx_keep_apart<100 + I>();
+    double aop[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) aop[s] = -xb[4 * s * kDxLd + lane + 16 * I];
+#pragma unroll
+    for (int jq = 0; jq < 4; ++jq) {
+      if (jq < R::jq_min(IQ)) continue;
+      double bop[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) bop[s] = xb[4 * s * kDxLd + lane + unsigned(cb[jq])];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) dx_mfma(acc[R::slot(IQ, jq)], aop[s], bop[s]);
+    }
+  }
+  template <int... IQ>
+  static HSD void update_rows(std::integer_sequence<int, IQ...>, int k, int lo, int hi, unsigned lane, const int (&cb)[4], const double* xb, Acc& acc) {
+    (update_row<IQ>(k, lo, hi, lane, cb, xb, acc), ...);
+  }
+  /// the tile rows lo <= I < hi with X(k, :)
+  static HSD void update(int k, int lo, int hi, unsigned lane, const int (&cb)[4], const double* xb, Acc& acc) {
+    update_rows(std::make_integer_sequence<int, R::n_rows>{}, k, lo, hi, lane, cb, xb, acc);
+  }
 };
-/// Entry (i, j), i <= j, of the padded dense system: pose rows 6 f0 .. (band storage), border columns, identity on the padding. Branch free (one
-/// load from a selected address): the tile loads of a wave are 72 of these, unrolled, and a version with a branch per region was 60 000 lines of ISA.
-HSD double dx_entry(const DxSys& Y, int i, int j) {
-  const double *sb = Y.Sb, *spb = Y.Spb, *sbb = Y.Sbb;  // (values, not fields: a select between FIELDS becomes an indexed load from a stack copy of Y)
-  const int ncb = Y.ncb, nb = Y.nb, f0 = Y.f0, n_pose = Y.n_pose, n_dense = Y.n_dense;
-  const int ri = 6 * f0 + i, c = 6 * f0 + j - 6 * (ri / 6), jb = j - n_pose, ib = i - n_pose;
-  const bool pose_col = j < n_pose, pose_row = i < n_pose, inside = j < n_dense && (!pose_col || c < ncb);
-  const size_t idx_pp = size_t(ri) * ncb + c, idx_pb = size_t(ri) * nb + jb, idx_bb = size_t(ib) * nb + jb;
-  const double* src = pose_col ? sb + idx_pp : (pose_row ? spb + idx_pb : sbb + idx_bb);
-  const double v = *(inside ? src : sb);
-  return inside ? v : ((j >= n_dense && i == j) ? 1.0 : 0.0);
+
+/// Lane r of the caller's row of sixteen lanes, for every lane of the row (DPP row_newbcast: the one DPP control the f64 instructions have).
+template <int R>
+HSD double dx_row_bcast(double v) {
+#if !defined(HS_EMULATED_DEVICE)
+  double out;
+  // (s_nop 1: a DPP read of a register the two previous vector instructions may have written needs two wait states, and the compiler's hazard
+  //  recogniser does not look inside an asm statement)
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(out) : "v"(v), "n"(R));
+  return out;
+#else
+  return hs_emul::wave_exchange(v, int((threadIdx.x & 63u) & ~15u) | R);
+#endif
+}
+/// acc += (lane R of the row's u) * m in ONE instruction (v_fmac_f64_dpp): the multiplier of the elimination goes from the diagonal tile's lane
+/// straight into the multiply-add — with v_readlane it was two scalar moves and the FMA, and the panel is instruction issue.
+template <int R>
+HSD void dx_fmac_bcast(double& acc, double u, double m) {
+#if !defined(HS_EMULATED_DEVICE)
+  // (no wait states here: the DPP operand u — entry P of the diagonal column — was written by the scaling of pivot P, at least two vector
+  //  instructions (the two negations) before the first of these)
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(u), "v"(m), "n"(R));
+#else
+  acc = fma(hs_emul::wave_exchange(u, int((threadIdx.x & 63u) & ~15u) | R), m, acc);
+#endif
 }
 
-constexpr int kDxMaxTilesPerWave = 18;
+/// Panel of step k for one wave: lane l holds column l & 15 of the diagonal tile (a copy in every row of sixteen lanes: the source of the DPP
+/// broadcasts) AND one column of its own — a trailing column of the tile row (the right-hand side is one of them: column n_dense of the
+/// padded system) or a column of the identity (-> a row of W_k = U_kk^-1). Right-looking Cholesky of the diagonal block fused with the forward
+/// substitution of every column; plain substitution, no explicit inverse on the forward path. X(k, :) goes back to LDS (operand of the update)
+/// and to memory (the factor by columns, for the sweep). Returns true when a pivot was not positive.
+template <int P, int R>
+HSD void dx_panel_rows(double (&ad)[16], double (&at)[16], double nd, double nt);
+template <int P>
+HSD void dx_panel_pivots(double (&ad)[16], double (&at)[16], bool& fail) {
+  if constexpr (P < 16) {
+    const double d = dx_row_bcast<P>(ad[P]);
+    fail |= !(d > 0.0);
+    const double rinv = dx_rsqrt(d);
+    ad[P] *= rinv, at[P] *= rinv;
+    const double nd = -ad[P], nt = -at[P];
+    dx_panel_rows<P, P + 1>(ad, at, nd, nt);
+    dx_panel_pivots<P + 1>(ad, at, fail);
+  }
+}
+template <int P, int R>
+HSD void dx_panel_rows(double (&ad)[16], double (&at)[16], double nd, double nt) {
+  if constexpr (R < 16) {
+    dx_fmac_bcast<R>(ad[R], ad[P], nd);  // u_pr = entry P of the diagonal tile's column R, from the lane of the row that holds it
+    dx_fmac_bcast<R>(at[R], ad[P], nt);
+    dx_panel_rows<P, R + 1>(ad, at, nd, nt);
+  }
+}
+HSD bool dx_panel(int k, int n_tr, int w, int l, double* xb, double* wk, double* ut) {
+  const int idx = 64 * w + l;
+  const bool trailing = idx < n_tr;
+  const int unit = (idx >= n_tr && idx < n_tr + 16) ? idx - n_tr : -1;
+  const int col = 16 * (k + 1) + (trailing ? idx : 0);
+  double ad[16], at[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    ad[r] = xb[r * kDxLd + 16 * k + (l & 15)];
+    const double v = xb[r * kDxLd + col];  // (idle and identity lanes read a column of the buffer they do not use)
+    at[r] = trailing ? v : (r == unit ? 1.0 : 0.0);
+  }
+  bool fail = false;
+  dx_panel_pivots<0>(ad, at, fail);
+  if (trailing) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xb[r * kDxLd + col] = at[r];
+    double* dst = ut + size_t(col) * kDenseLd + 16 * k;  // column col of U, rows of block k: 16 contiguous doubles
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) *reinterpret_cast<double2*>(dst + r) = make_double2(at[r], at[r + 1]);
+  }
+  if (unit >= 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wk[(16 * k + unit) * 16 + r] = at[r];
+  }
+  if (w == 0 && l < 16) {  // the diagonal tile's columns too (entries above the diagonal): the right-hand side column may be one of them
+    double* dst = ut + size_t(16 * k + l) * kDenseLd + 16 * k;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) *reinterpret_cast<double2*>(dst + r) = make_double2(ad[r], ad[r + 1]);
+  }
+  return fail;
+}
 
-/// The three phases that depend on which tiles a wave owns (compile time: the accumulators are registers). Everything else — panel, sweep,
-/// outputs — is the same code for every wave and is written once in the kernel below.
-template <int A, int B>
-struct DxWave {
-  using TL = DxTiles<A, B>;
-  static_assert(TL::count <= kDxMaxTilesPerWave, "accumulator array too short");
-  /// load: the wave's tiles from the scaled, damped system (a diagonal tile whole: the entries below its diagonal are the mirror images).
-  /// What depends on the row of an entry only is formed once per row, what depends on its column once per column.
-  static HSD void load(const DxSys& Y, int nt, int i16, int g4, dx_f64x4 (&acc)[kDxMaxTilesPerWave]) {
-    int cj[4];
-    bool pose_col[4], in_dense[4];
-#pragma unroll
-    for (int jq = 0; jq < 4; ++jq) {
-      const int j = 16 * TL::col(jq) + i16;
-      cj[jq] = 6 * Y.f0 + j, pose_col[jq] = j < Y.n_pose, in_dense[jq] = j < Y.n_dense;
+/// Factorisation loop of a wave of row class A (0: the panel waves w < 4, 1, 2: the others; the accumulator arrays differ in length, and the panel's
+/// registers must not be live next to 24 tiles): load, then per step extract / panel / update with the two barriers. Returns the panel's verdict.
+template <int A>
+HSD bool dx_factor(const double* D, int nt, int n_pad, int b, int w, int l, double* smem, double* ut, bool prof, long long* tlog) {
+  using W = DxWave<A>;
+  double* wk = smem + kDxOffW;
+  const int cb[4] = {16 * dx_col(b, 0), 16 * dx_col(b, 1), 16 * dx_col(b, 2), 16 * dx_col(b, 3)};
+  typename W::Acc acc;
+  W::load(D, unsigned((l >> 4) * kDenseLd + (l & 15)), cb, acc);
+  const unsigned lane = unsigned((l >> 4) * kDxLd + (l & 15));
+  bool fail = false;
+  if (prof) tlog[8 * 20 + 3] = wall_clock64();
+  // Look-ahead: the panel of step k + 1 runs (on the four panel waves) while everybody else applies X(k, :) to the tile rows behind k + 1 — the
+  // panel is ~3 us of one wave per SIMD, the update up to 3.5 us of matrix core in the first steps. Per step and wave:
+  //   U1  tile row k + 1 -= X(k, k + 1)' X(k, :), written to the OTHER panel buffer                                       --- barrier ---
+  //   P   panel waves: panel of step k + 1 (in place in that buffer)     U2  tile rows > k + 1 -= X(k, .)' X(k, :)  (panel waves: after the panel;
+  //       their rows are rows 3 6 9 13: wanted three steps later at the earliest)                                           --- barrier ---
+  // X(k, :) is read from its buffer through U2; the buffer is overwritten in U1 of the next step, behind the barrier.
+  W::extract(0, lane, cb, smem, acc);
+  lds_barrier();
+  if (prof) tlog[0] = wall_clock64();
+  if (A == 0 && 64 * w < n_pad - 16 + 16) fail |= dx_panel(0, n_pad - 16, w, l, smem, wk, ut);
+  if (prof) tlog[1] = wall_clock64();
+  lds_barrier();
+  for (int k = 0; k < nt; ++k) {
+    const double* xb = smem + (k & 1) * 16 * kDxLd;      // X(k, :)
+    double* xn = smem + ((k + 1) & 1) * 16 * kDxLd;      // tile row k + 1 -> X(k + 1, :)
+    if (prof) tlog[8 * k + 2] = wall_clock64();
+    if (k + 1 < nt) {
+      W::update(k, k + 1, k + 2, lane, cb, xb, acc);
+      W::extract(k + 1, lane, cb, xn, acc);
     }
-#pragma unroll
-    for (int iq = 0; iq < 8; ++iq) {
-      const int I = A + 2 * iq;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 16 * I + 4 * r + g4, ri = 6 * Y.f0 + i, six = 6 * (ri / 6);
-        const bool pose_row = i < Y.n_pose;
-        const double* row_pp = Y.Sb + (size_t(ri) * Y.ncb - six);                                                     // + cj: S[ri][.] in the band row
-        const double* row_b = (pose_row ? Y.Spb + size_t(ri) * Y.nb : Y.Sbb + size_t(i - Y.n_pose) * Y.nb) - (6 * Y.f0 + Y.n_pose);  // + cj: border column
-#pragma unroll
-        for (int jq = 0; jq < 4; ++jq) {
-          if (iq >= TL::rows_of(jq)) continue;
-          const int J = TL::col(jq), j = 16 * J + i16;
-          double v;
-          if (I == J) {
-            v = dx_entry(Y, i > j ? j : i, i > j ? i : j);
-          } else {
-            const bool inside = in_dense[jq] && (!pose_col[jq] || cj[jq] - six < Y.ncb);
-            const double* src = pose_col[jq] ? row_pp : row_b;
-            const double got = src[inside ? cj[jq] : 6 * Y.f0 + Y.n_pose];  // (outside: any address inside the tables)
-            v = inside ? got : 0.0;  // (off-diagonal tile: the padding's diagonal is not in it)
-          }
-          acc[TL::slot(iq, jq)][r] = J < nt ? v : 0.0;
-        }
-      }
-    }
+    lds_barrier();
+    if (prof) tlog[8 * (k + 1) + 0] = wall_clock64();
+    const int n_tr = n_pad - 16 * (k + 2);  // trailing columns of tile row k + 1 (+ 16 columns of the identity: W_(k+1))
+    if (A == 0 && k + 1 < nt && 64 * w < n_tr + 16) fail |= dx_panel(k + 1, n_tr, w, l, xn, wk, ut);
+    if (prof) tlog[8 * (k + 1) + 1] = wall_clock64();
+    W::update(k, k + 2, nt, lane, cb, xb, acc);
+    if (prof) tlog[8 * k + 3] = wall_clock64();
+    lds_barrier();
   }
-  /// (1) tile row k -> LDS
-  static HSD void extract(int k, int nt, int i16, int g4, double* xb, const dx_f64x4 (&acc)[kDxMaxTilesPerWave]) {
-#pragma unroll
-    for (int iq = 0; iq < 8; ++iq) {
-      if (A + 2 * iq != k) continue;
-#pragma unroll
-      for (int jq = 0; jq < 4; ++jq) {
-        if (iq >= TL::rows_of(jq)) continue;
-        const int J = TL::col(jq);
-        if (J >= nt) continue;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xb[(4 * r + g4) * kDxLd + 16 * J + i16] = acc[TL::slot(iq, jq)][r];
-      }
-    }
-  }
-  /// (3) trailing update: tile (I, J) -= X(k, I)' X(k, J), k < I <= J
-  static HSD void update(int k, int nt, int i16, int g4, const double* xb, dx_f64x4 (&acc)[kDxMaxTilesPerWave]) {
-    double bop[4][4];
-#pragma unroll
-    for (int jq = 0; jq < 4; ++jq) {
-      const int J = TL::col(jq);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) bop[jq][s] = (J > k && J < nt) ? xb[(4 * s + g4) * kDxLd + 16 * J + i16] : 0.0;
-    }
-#pragma unroll
-    for (int iq = 0; iq < 8; ++iq) {
-      const int I = A + 2 * iq;
-      if (I <= k || I >= nt) continue;
-      double aop[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) aop[s] = -xb[(4 * s + g4) * kDxLd + 16 * I + i16];
-#pragma unroll
-      for (int jq = 0; jq < 4; ++jq) {
-        if (iq >= TL::rows_of(jq)) continue;
-        if (TL::col(jq) >= nt) continue;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc[TL::slot(iq, jq)] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[s], bop[jq][s], acc[TL::slot(iq, jq)], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);  // (the operand loads of the eight tile rows hoisted to the top of the phase cost 64 registers next to 144 of tiles)
-    }
-  }
-};
+  return fail;
+}
 
-/// wave (a, b): SIMD w mod 4 holds (0, b) and (1, 3 - b)
-#define HS_DX_DISPATCH(wave, CALL)      \
-  switch (wave) {                       \
-    case 0: DxWave<0, 0>::CALL; break;  \
-    case 1: DxWave<0, 1>::CALL; break;  \
-    case 2: DxWave<0, 2>::CALL; break;  \
-    case 3: DxWave<0, 3>::CALL; break;  \
-    case 4: DxWave<1, 3>::CALL; break;  \
-    case 5: DxWave<1, 2>::CALL; break;  \
-    case 6: DxWave<1, 1>::CALL; break;  \
-    default: DxWave<1, 0>::CALL; break; \
-  }
+/// Sweep: column block K of U for row rho (scalar base + lane offset per column; zero for the rows at or below the block).
+HSD void dx_sweep_fetch(const double* ut, int rho, int K, double (&u)[16]) {
+#pragma unroll
+  for (int c = 0; c < 16; ++c) u[c] = (K >= 0 && rho < 16 * K) ? (ut + (16 * K + c) * kDenseLd)[unsigned(rho)] : 0.0;
+}
+/// Sweep, block K: x_K = W_K pend_K in lanes 0 .. 15 of every wave (W_K upper triangular: the entries left of the diagonal came out as exact
+/// zeros), then every pending row above subtracts U(:, K) x_K. One barrier. (Functions with the register sets as parameters: as lambdas that
+/// capture the arrays by reference they put them into scratch memory.)
+HSD void dx_sweep_block(int K, int rho, int w, int l, const double* ut, const double* wk, double* pk, double* xv, double& pend, const double (&u)[16],
+                        double (&u_next)[16]) {
+  if (K < 0) return;
+  if (rho >= 16 * K && rho < 16 * K + 16) pk[(K & 1) * 16 + (rho - 16 * K)] = pend;
+  dx_sweep_fetch(ut, rho, K - 2, u_next);
+  lds_barrier();
+  if (w >= 4) return;  // (the rows live in the first four waves, one per SIMD; the others only keep the barriers — running the arithmetic on their
+                       //  empty lanes too made a step three times as long: it is instruction issue)
+  const double* wr = wk + (16 * K + (l & 15)) * 16;
+  const double* pr = pk + (K & 1) * 16;
+  double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
+#pragma unroll
+  for (int c = 0; c < 16; c += 4) x0 = fma(wr[c], pr[c], x0), x1 = fma(wr[c + 1], pr[c + 1], x1), x2 = fma(wr[c + 2], pr[c + 2], x2), x3 = fma(wr[c + 3], pr[c + 3], x3);
+  const double xr = (x0 + x1) + (x2 + x3);
+  if (w == 0 && l < 16) xv[16 * K + l] = xr;
+  double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+  for (int c = 0; c < 16; c += 2) s0 = fma(u[c], dx_readlane(xr, c), s0), s1 = fma(u[c + 1], dx_readlane(xr, c + 1), s1);
+  pend -= s0 + s1;
+}
 
 /// One workgroup. f0: leading block rows of constant control points (decoupled, solution zero: the chain starts behind them).
 /// ut: 256 x 256 doubles of scratch (the factor by columns, for the sweep).
@@ -194,104 +331,44 @@ __global__ void __launch_bounds__(kDxThreads) k_dense_solve_mx(Tables T, int f0,
   HS_DYNAMIC_LDS(smem);
   DevState* st = T.st;
   if (st->done) return;
-  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, i16 = l & 15, g4 = l >> 4;
-  const int n_pose = T.np - 6 * f0, n_dense = n_pose + T.nb, nt = (n_dense + 15) / 16, n_pad = 16 * nt;
-  double* gv = smem + kDxOffG;
-  double* yv = smem + kDxOffY;
+  // (the wave index as a SCALAR: with threadIdx.x >> 6 in a vector register the dispatch to the wave's tile phases is a divergent branch for the
+  //  compiler, which then merges the accumulator arrays of all variants lane by lane — 3 000 spilled registers)
+  const int tid = threadIdx.x, l = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), i16 = l & 15;
+  const int n_pose = T.np - 6 * f0, n_dense = n_pose + T.nb, nt = (n_dense + 1 + 15) / 16, n_pad = 16 * nt;
   double* xv = smem + kDxOffX;
   double* wk = smem + kDxOffW;
-  dx_f64x4 acc[kDxMaxTilesPerWave];
-  {
-    const DxSys Y{T.Sb, T.Spb, T.Sbb, 6 * T.bw, T.nb, f0, n_pose, n_dense};
-    HS_DX_DISPATCH(w, load(Y, nt, i16, g4, acc))
-  }
-  for (int c = tid; c < kDxLd; c += kDxThreads) gv[c] = c < n_pose ? T.g_s[6 * f0 + c] : (c < n_dense ? T.gb_s[c - n_pose] : 0.0);
+  const bool prof = prof_enabled(T.debug_flags, 16) && tid == 0;  // phase stamps (profiling builds, tools/dense_mx_phase_timing.py)
+  long long* tlog = reinterpret_cast<long long*>(T.xpart) + 8 * 300;
+  if (prof) tlog[-1] = wall_clock64();
+  // wave (a, b) = (w / 4, w mod 4): SIMD w mod 4 holds one wave of each row class, all of column class b
   bool fail = false;
-  for (int k = 0; k < nt; ++k) {
-    double* xb = smem + (k & 1) * 16 * kDxLd;
-    HS_DX_DISPATCH(w, extract(k, nt, i16, g4, xb, acc))
-    lds_barrier();
-    // ---- (2) panel ----
-    const int n_tr = n_pad - 16 * (k + 1);  // trailing columns of the row
-    if (w * kDxColsPerWave < n_tr + 16) {    // (waves without a column of their own skip the panel: their SIMDs are the other waves')
-      const int idx = w * kDxColsPerWave + (l - 17);
-      const bool trailing = l >= 17 && idx < n_tr, inverse = l >= 17 && idx >= n_tr && idx < n_tr + 16;
-      const int col = l < 16 ? 16 * k + l : 16 * (k + 1) + (trailing ? idx : 0);
-      double a[16];
-      {
-        const double* src = l == 16 ? gv + 16 * k : xb + col;  // (idle and identity lanes read a column of the buffer they do not use)
-        const int stride = l == 16 ? 1 : kDxLd;
-        const bool keep = l <= 16 || trailing;
-        const int unit = inverse ? idx - n_tr : -1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const double v = src[r * stride];
-          a[r] = keep ? v : (r == unit ? 1.0 : 0.0);
-        }
-      }
-#pragma unroll
-      for (int p = 0; p < 16; ++p) {
-        const double d = dx_readlane(a[p], p);
-        fail |= !(d > 0.0);
-        a[p] *= dx_rsqrt(d);
-#pragma unroll
-        for (int r = p + 1; r < 16; ++r) a[r] = fma(-dx_readlane(a[p], r), a[p], a[r]);
-      }
-      // right-hand side of the trailing columns, X(k, :) as the operand of the update and as factor rows, W_k, y_k
-      double gc = trailing ? gv[col] : 0.0;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) gc = fma(-a[r], dx_readlane(a[r], 16), gc);
-      if (trailing) {
-        gv[col] = gc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xb[r * kDxLd + col] = a[r];
-        double* dst = ut + size_t(col) * n_pad + 16 * k;  // column `col` of U, rows of block k: 16 contiguous doubles
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) *reinterpret_cast<double2*>(dst + r) = make_double2(a[r], a[r + 1]);
-      }
-      if (inverse) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) wk[(16 * k + (idx - n_tr)) * 16 + r] = a[r];
-      }
-      if (w == 0 && l == 16) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) yv[16 * k + r] = a[r];
-      }
-    }
-    lds_barrier();
-    HS_DX_DISPATCH(w, update(k, nt, i16, g4, xb, acc))
-  }
+  if (w < 4)
+    fail = dx_factor<0>(T.dense, nt, n_pad, w, w, l, smem, ut, prof, tlog);
+  else if (w < 8)
+    dx_factor<1>(T.dense, nt, n_pad, w - 4, w, l, smem, ut, false, tlog);
+  else
+    dx_factor<2>(T.dense, nt, n_pad, w - 8, w, l, smem, ut, false, tlog);
+  if (prof) tlog[8 * 20 + 0] = wall_clock64();
   // ---- backward sweep U x = y, lane = row (the first four waves hold the rows; everybody keeps the barriers) ----
   wait_vmem();  // this wave's factor rows have left
   __threadfence();
   lds_barrier();
   double* pk = smem + kDxOffP;
   const int rho = tid;  // row of the padded system (tid < 256)
-  double pend = rho < n_pad ? yv[rho] : 0.0;
-  double un[16];
-  auto fetch = [&](int K) {  // column block K of U for this row
-#pragma unroll
-    for (int c = 0; c < 16; ++c) un[c] = (K >= 0 && rho < 16 * K) ? ut[size_t(16 * K + c) * n_pad + rho] : 0.0;
-  };
-  fetch(nt - 1);
-  for (int K = nt - 1; K >= 0; --K) {
-    if (rho >= 16 * K && rho < 16 * K + 16) pk[(K & 1) * 16 + (rho - 16 * K)] = pend;
-    double u[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) u[c] = un[c];
-    fetch(K - 1);
-    lds_barrier();
-    // x_K = W_K pend_K in lanes 0 .. 15 of every wave (W_K upper triangular: the entries left of the diagonal came out as exact zeros)
-    double xr = 0.0;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) xr = fma(wk[(16 * K + i16) * 16 + c], pk[(K & 1) * 16 + c], xr);
-    if (w == 0 && l < 16) xv[16 * K + l] = xr;
-    double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-    for (int c = 0; c < 16; c += 2) s0 = fma(u[c], dx_readlane(xr, c), s0), s1 = fma(u[c + 1], dx_readlane(xr, c + 1), s1);
-    pend -= s0 + s1;
+  // y = U^-T g is column n_dense of the factor: the right-hand side rode along as a column of the padded matrix (the dense copy carries g there
+  // and a huge diagonal entry behind it; its own unknown gets a zero right-hand side, i.e. stays zero)
+  double pend = rho < n_dense ? (ut + n_dense * kDenseLd)[unsigned(rho)] : 0.0;
+  // Column block K of U for this row comes back from memory (L2; written by the panel): requested two blocks ahead — with one block ahead
+  // a step of the sweep was 2.3 us of load latency (three ahead: four register sets of sixteen, spills). Register sets renamed by unrolling.
+  double ua[16], ub[16], uc[16];
+  dx_sweep_fetch(ut, rho, nt - 1, ua), dx_sweep_fetch(ut, rho, nt - 2, ub);
+  for (int K = nt - 1; K >= 0; K -= 3) {
+    dx_sweep_block(K, rho, w, l, ut, wk, pk, xv, pend, ua, uc);
+    dx_sweep_block(K - 1, rho, w, l, ut, wk, pk, xv, pend, ub, ua);
+    dx_sweep_block(K - 2, rho, w, l, ut, wk, pk, xv, pend, uc, ub);
   }
   lds_barrier();
+  if (prof) tlog[8 * 20 + 1] = wall_clock64();
   // ---- outputs: step = -x, delta = scale o step, the two sums of the model cost change (k_band_backward's epilogue) ----
   double gd = 0.0, dd = 0.0;
   for (int r = tid; r < 6 * f0; r += kDxThreads) T.step_p[r] = 0.0, T.delta_p[r] = 0.0;
@@ -314,8 +391,8 @@ __global__ void __launch_bounds__(kDxThreads) k_dense_solve_mx(Tables T, int f0,
     st->g_dot_step_pose = gd, st->d2_step2_pose = dd;
     if (fail) st->chol_failed = 1;  // (consumed and cleared by decide_step, kernels_update.hpp)
   }
+  if (prof) tlog[8 * 20 + 2] = wall_clock64();
 }
 
-#undef HS_DX_DISPATCH
 
 }  // namespace hs

@@ -772,6 +772,17 @@ HSD void pack_exchange_body(const Tables& T, int reduce_here) {
 }
 __global__ void __launch_bounds__(kBlock) k_pack_exchange(Tables T, int reduce_here) { pack_exchange_body(T, reduce_here); }
 
+/// Corner of the dense copy of a small system (Tables::dense) behind its n_dense unknowns: the right-hand side's own diagonal entry — the
+/// right-hand side rides through k_dense_solve_mx's factorisation as column n_dense, and any entry that keeps its pivot positive will do —
+/// zero against the padding, the identity on the padding.
+HSD void dense_padding_corner(double* D, int n_dense, int n_pad, int first, int stride) {
+  const int n = n_pad - n_dense;
+  for (int e = first; e < n * n; e += stride) {
+    const int a = e / n, b = e % n;
+    D[size_t(n_dense + a) * kDenseLd + n_dense + b] = a != b ? 0.0 : (a == 0 ? 1e300 : 1.0);
+  }
+}
+
 /// After the (optional) all-reduce: Jacobi scaling (fixed at iteration 0), LM diagonal, inactive coordinates.
 ///   S = Sp Sraw Sp + D_p^2,  g = Sp (g_p + g_schur),  g_full = Sp g_p,  D_p^2 = clamp(Sp^2 diag(J'J), 1e-6, 1e32) / radius.
 /// A workgroup past the last block row (single shard: gridDim.x = n_cp + 1 [+ border workgroups]) does the work of
@@ -814,10 +825,26 @@ __global__ void __launch_bounds__(kBlock) k_finalize_reduced(Tables T, int n_spl
       }
     }
     T.Sb[size_t(rho) * ncb + c] = out;
+    if (T.dense && i >= T.dense_f0 && sigma < T.np && sigma >= rho) {  // dense copy for k_dense_solve_mx: entry and mirror image
+      const int ii = rho - 6 * T.dense_f0, jj = sigma - 6 * T.dense_f0;
+      T.dense[size_t(ii) * kDenseLd + jj] = out, T.dense[size_t(jj) * kDenseLd + ii] = out;
+    }
     if (T.Sb2 && sigma < T.np) {  // reversed copy for the far end of the two-ended factorisation: (rho, sigma) -> (np-1-sigma, np-1-rho)
       const int rv = T.np - 1 - sigma, cv = T.np - 1 - rho;
       T.Sb2[size_t(rv) * ncb + (cv - 6 * (rv / 6))] = out;
     }
+  }
+  if (T.dense && i >= T.dense_f0) {
+    // what the band does not reach in these six rows of the dense copy — pose columns right of it, the padding columns — is zero (and so are the
+    // mirror images); the last block row also writes the identity on the padding (without border unknowns: finalize_border_body otherwise)
+    // (column / row n_dense of the dense copy is the right-hand side, written below; the padding proper starts behind it)
+    const int n_pose = T.np - 6 * T.dense_f0, n_dense = n_pose + T.nb, n_pad = 16 * ((n_dense + 1 + 15) / 16);
+    const int j0 = min(6 * (i - T.dense_f0) + ncb, n_pose), n_right = n_pose - j0, n_padc = n_pad - (n_dense + 1), per_row = n_right + n_padc;
+    for (int e = tid; e < 6 * per_row; e += kBlock) {
+      const int a = e / per_row, q = e % per_row, ii = 6 * (i - T.dense_f0) + a, jj = q < n_right ? j0 + q : n_dense + 1 + (q - n_right);
+      T.dense[size_t(ii) * kDenseLd + jj] = 0.0, T.dense[size_t(jj) * kDenseLd + ii] = 0.0;
+    }
+    if (T.nb == 0 && i == T.sp.n_cp - 1) dense_padding_corner(T.dense, n_dense, n_pad, tid, kBlock);
   }
   if (tid < 6) {
     const int rho = 6 * i + tid;
@@ -828,6 +855,10 @@ __global__ void __launch_bounds__(kBlock) k_finalize_reduced(Tables T, int n_spl
     if (T.Sb2) T.g2[T.np - 1 - rho] = sr * (gp + X[T.xo_gs + rho]);
     if (fresh) T.scale_p[rho] = sr;
     T.gabs[rho] = fabs(gp);
+    if (T.dense && i >= T.dense_f0) {  // the right-hand side as column (and row) n_dense of the dense copy
+      const int ii = rho - 6 * T.dense_f0, n_dense = T.np - 6 * T.dense_f0 + T.nb;
+      T.dense[size_t(ii) * kDenseLd + n_dense] = sr * (gp + X[T.xo_gs + rho]), T.dense[size_t(n_dense) * kDenseLd + ii] = sr * (gp + X[T.xo_gs + rho]);
+    }
   }
 }
 

@@ -236,6 +236,10 @@ struct Tables {
   unsigned fold_epoch;
   const int* ch_ptr;
   const int* ch_desc;  // n_chunk x 8: first landmark, landmarks, first control point, first residual, residuals (one 32-byte load per workgroup)
+  double* dense;   // k_dense_solve_mx will solve this linearisation (launch_build): k_finalize_reduced / finalize_border_body also write the scaled,
+                   // damped system as ONE dense row-major matrix (leading dimension 256, both triangles, identity on the padding to whole 16 x 16
+                   // tiles) of the free block rows dense_f0 .. and the border unknowns; nullptr otherwise
+  int dense_f0;
   int rank, world;
   int debug_flags;  // HS_DEBUG_FLAGS env (timing experiments; 0 in production)
   DevState* st;

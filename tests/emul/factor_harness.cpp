@@ -79,6 +79,25 @@ int main(int argc, char** argv) {
     T.scale_p = const_cast<double*>(scale_p.data()), T.g_full = const_cast<double*>(g_full.data()), T.D2p = const_cast<double*>(D2p.data());
     T.scale_b = const_cast<double*>(scale_b.data()), T.D2b = const_cast<double*>(D2b.data());
     T.step_p = step_p.data(), T.delta_p = delta_p.data(), T.xb = xb.data(), T.delta_b = delta_b.data();
+    // Tables::dense: the dense copy of the scaled, damped system the finalisation kernels write for this kernel (k_finalize_reduced,
+    // finalize_border_body: row-major, leading dimension 256, both triangles, identity on the padding; the GPU suite covers those writers)
+    std::vector<double> dense(size_t(kDenseLd) * kDenseLd, 7.0);  // (what the writers do not touch is never used)
+    {
+      const int n_pose = np - 6 * f0, n_dense = n_pose + nb, n_pad = 16 * ((n_dense + 1 + 15) / 16);
+      auto entry = [&](int i, int j) -> double {  // i <= j
+        if (j == n_dense) return i == j ? 1e300 : (i < n_pose ? g[6 * f0 + i] : gb[i - n_pose]);  // the right-hand side as column n_dense
+        if (j > n_dense) return i == j ? 1.0 : 0.0;
+        if (j < n_pose) {
+          const int ri = 6 * f0 + i, c = 6 * f0 + j - 6 * (ri / 6);
+          return c < ncb ? Sb[size_t(ri) * ncb + c] : 0.0;
+        }
+        if (i < n_pose) return Spb[size_t(6 * f0 + i) * nb + (j - n_pose)];
+        return Sbb[size_t(i - n_pose) * nb + (j - n_pose)];
+      };
+      for (int i = 0; i < n_pad; ++i)
+        for (int j = i; j < n_pad; ++j) dense[size_t(i) * kDenseLd + j] = dense[size_t(j) * kDenseLd + i] = entry(i, j);
+    }
+    T.dense = dense.data(), T.dense_f0 = f0;
     hs_emul::launch(dim3(1), dim3(kDxThreads), size_t(kDxLdsDoubles) * sizeof(double), [&] { k_dense_solve_mx(T, f0, ut.data()); });
     FILE* out = fopen(argv[2], "wb");
     const int res[4] = {-1, 0, st.chol_failed, 0};

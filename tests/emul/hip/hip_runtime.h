@@ -26,6 +26,7 @@
 #define __shared__ static
 #define __launch_bounds__(...)
 #define HS_DYNAMIC_LDS(name) double* name = hs_emul::dynamic_lds()
+#define HS_EMULATED_DEVICE 1     // (kernel sources that spell an instruction in inline assembly keep a C++ statement of it behind this)
 #define HS_DEVICE_PRIMITIVES_HPP  // the include guard of csrc/device_primitives.hpp: HS_DYNAMIC_LDS, lds_barrier, wait_lds, wait_vmem are this header's
 
 struct dim3 {
@@ -130,6 +131,7 @@ inline T __shfl_up(T v, unsigned delta) {
   return got;
 }
 inline int __builtin_amdgcn_readlane(int v, int lane) { return hs_emul::wave_exchange(v, lane); }
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // (the kernels use it on wave-uniform values only: the wave index as a scalar)
 /// DPP move as the kernels use it (row_mask = bank_mask = 0xF, bound_ctrl off: a lane whose source is outside its row of 16 keeps `old`):
 /// quad_perm (ctrl < 0x100, two bits per lane of the quad), row_shl:n (0x100 + n: lane i reads lane i + n), row_shr:n (0x110 + n: lane i - n),
 /// row_ror:n (0x120 + n: lane i reads lane (i - n) mod 16 of its row).

@@ -276,14 +276,14 @@ def test_mx_bordered_solve_against_numpy(n_blk, bw, n_b, harness, tmp_path):
     run(harness, tmp_path, M, g, bw, True, variant=5, border=bordered(rng, M, n_b, n_blk))
 
 
-@pytest.mark.parametrize("n_blk,bw,f0,n_b", [(33, 33, 0, 0), (33, 33, 0, 44), (36, 18, 14, 0), (63, 33, 30, 47), (63, 33, 30, 0), (42, 20, 0, 4), (5, 4, 0, 0),
-                                             (4, 4, 2, 2), (20, 6, 0, 9), (2, 2, 0, 45), (34, 34, 0, 52)])
+@pytest.mark.parametrize("n_blk,bw,f0,n_b", [(33, 33, 0, 0), (33, 33, 0, 44), (36, 18, 14, 0), (63, 33, 30, 47), (63, 33, 30, 0), (42, 20, 0, 3), (5, 4, 0, 0),
+                                             (4, 4, 2, 2), (20, 6, 0, 9), (2, 2, 0, 45), (34, 34, 0, 51), (42, 42, 0, 0)])
 def test_dense_solve_mx_against_numpy(n_blk, bw, f0, n_b, harness, tmp_path):
     """k_dense_solve_mx (kernels_dense_mx.hpp): the whole solve of a small reduced system — the sliding window's steady state: ~33 free block
     rows with window-wide bands behind a frozen prefix, bordered by the bias / gravity unknowns with an IMU — in one launch, trailing matrix in
     the accumulators of the f64 matrix cores, the border as the last columns of ONE dense Cholesky: 16 x 16 tiles 2-D cyclic over eight waves,
-    readlane panel, W_k rows for the sweep, padding to whole tiles (identity), every size from one tile to sixteen (256 unknowns exactly:
-    (34, 34, 0, 52)), band narrower than the window (zero corner blocks), frozen prefix (zero step on its rows)."""
+    readlane panel, W_k rows for the sweep, padding to whole tiles (identity), every size from one tile to sixteen (255 unknowns + the right-hand
+    side column: (34, 34, 0, 51), (42, 20, 0, 3)), band narrower than the window (zero corner blocks), frozen prefix (zero step on its rows)."""
     rng = np.random.default_rng(31 * n_blk + bw + 7 * f0 + n_b)
     M = banded_spd(rng, n_blk, bw)
     g = rng.standard_normal(6 * n_blk)

@@ -132,6 +132,7 @@ _SIGNATURES = {
     "band_blocks": (C.c_int, [C.c_void_p]),
 }
 _PRODUCT_ONLY = {
+    "set_guard": (C.c_int, [C.c_int]),
     "snapshot": (C.c_int, [C.c_void_p]),
     "restore": (C.c_int, [C.c_void_p]),
     "version": (C.c_int, []),

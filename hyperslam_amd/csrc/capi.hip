@@ -731,6 +731,11 @@ int hs_set_weights(hs_problem* p, int type, const double* weights) {
   return HS_OK;
 }
 
+int hs_set_guard(int enabled) {
+  GuardRegistry::flag() = enabled != 0 ? 1 : 0;
+  return HS_OK;
+}
+
 int hs_set_stage_timing(hs_problem* p, int enabled) {
   if (!p) return HS_ERR_INVALID;
   p->stage_timing = enabled != 0;

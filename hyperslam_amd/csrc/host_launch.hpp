@@ -172,6 +172,8 @@ int launch_build(hs_problem* p, hipEvent_t after_build = nullptr, bool scaling_f
     HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0));
   }
   hipStream_t sb = side_imu ? p->side : s;  // stream of the border gathers
+  // (Round 6 tried the segment Gram kernel of a fused stereo-inertial window on the side stream, behind k_linearize_inertial and next to
+  //  k_build_visual: 8 us off the main stream's chain, and the event k_assemble then waits for cost more — 1.080 against 1.038 ms per optimize().)
   if (side_imu && T.nb) {  // behind k_linearize_inertial on the side stream, next to k_landmark / the Gram kernels
     k_border_pb<K><<<dim3(T.sp.n_cp + border_zero_wgs(T), p->n_split), kPbThreads, 0, sb>>>(T);  // (+ zero-fill of the border-border block)
     k_border_bb<K><<<T.n_bias, kBlock, 0, sb>>>(T);

@@ -92,13 +92,16 @@ struct GuardRegistry {
     static GuardRegistry r;
     return r;
   }
-  static bool on() {
-    static const bool v = [] {
+  /// HS_GUARD=1 in the environment, or hs_set_guard (a process-wide switch: tables allocated while it is on carry the pattern and are checked,
+  /// the others are left alone — a test session turns it on before its first handle and has every table of every test guarded).
+  static int& flag() {
+    static int v = [] {
       const char* e = std::getenv("HS_GUARD");
-      return e && std::atoi(e) != 0;
+      return (e && std::atoi(e) != 0) ? 1 : 0;
     }();
     return v;
   }
+  static bool on() { return flag() != 0; }
   /// 0: every pattern intact; otherwise the size in bytes of a table whose pattern was overwritten (first found), offset of the first bad byte in *at.
   size_t check(size_t* at) {
     std::lock_guard<std::mutex> lock(mu);
@@ -122,16 +125,14 @@ struct DBuf {
   T* p = nullptr;
   size_t cap = 0;
   GuardedBuffer guard;
-  DBuf() {
-    if (GuardRegistry::on()) {
-      std::lock_guard<std::mutex> lock(GuardRegistry::get().mu);
-      GuardRegistry::get().all.push_back(&guard);
-    }
+  DBuf() {  // (registered whatever the mode: the switch may be turned on later, and a table without a pattern is skipped by the check)
+    std::lock_guard<std::mutex> lock(GuardRegistry::get().mu);
+    GuardRegistry::get().all.push_back(&guard);
   }
   DBuf(const DBuf&) = delete;
   DBuf& operator=(const DBuf&) = delete;
   ~DBuf() {
-    if (GuardRegistry::on()) {
+    {
       std::lock_guard<std::mutex> lock(GuardRegistry::get().mu);
       auto& v = GuardRegistry::get().all;
       v.erase(std::remove(v.begin(), v.end(), &guard), v.end());

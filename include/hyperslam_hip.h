@@ -229,6 +229,10 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
  * CANDIDATE (its records become the next iteration's linearisation when the step is accepted): that launch is booked under
  * linearize_ms, so that linearize_ms covers max_iterations launches of the linearisation kernel as on every other path. */
 int hs_set_stage_timing(hs_problem* p, int enabled);
+/* Debugging mode of the library (also HS_GUARD=1 in the environment), process wide: every device table allocated while it is on has exactly
+ * the size asked for, followed by a known pattern, and hs_solve / hs_cost / hs_reduced_system / hs_linearize check the patterns of all of them
+ * before they return (HS_ERR_DEVICE with the table's size if a kernel wrote past the end of one). Slow; meant for test suites. */
+int hs_set_guard(int enabled);
 int hs_set_allreduce(hs_problem* p, hs_allreduce_fn fn, void* user);
 /* RCCL on the data path without a host hook: rank 0 obtains a 128-byte unique id (ncclGetUniqueId), the caller distributes it
  * by any means (torch.distributed in bench.py), every rank then creates its communicator (ncclCommInitRank on the handle's

@@ -12,6 +12,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def guarded_device_tables(request):
+    """`-m gpu` runs with the library's guard mode on for EVERY test (hs_set_guard: every device table at its exact size with a checked pattern
+    behind it; subprocesses — replays, torch.distributed workers — through HS_GUARD=1): two out-of-bounds writes lived under four rounds of green
+    suites because the allocator's granularity hid them. HS_SUITE_GUARD=0 turns it off (timing experiments)."""
+    expr = request.config.getoption("-m") or ""
+    if "gpu" not in expr or "not gpu" in expr or os.environ.get("HS_SUITE_GUARD", "1") == "0":
+        yield
+        return
+    from hyperslam_amd import _lib
+    os.environ["HS_GUARD"] = "1"
+    _lib.load().set_guard(1)
+    yield
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU restatement (test infrastructure). Built on demand from oracle/ with g++."""

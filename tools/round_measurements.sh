@@ -38,4 +38,10 @@ python tools/stress_pipelined_sweep.py 40 > $out/${tag}_stress_pipelined_sweep.t
 ( cd hyperslam_amd/host
   for a in "6.0 0 4" "6.0 1 4" "6.0 1 6"; do for pth in narrow default; do echo "replay $a build path: $pth (narrow = record path above 256 window tiles, round 4's rule)"
     if [ $pth = narrow ]; then export HS_BUILD_PATH=narrow; else unset HS_BUILD_PATH; fi; ./replay $a 2>/dev/null | tail -1; ./replay $a 2>/dev/null | tail -1; done; done; unset HS_BUILD_PATH ) > $out/${tag}_replay_build_path_ab.txt 2>&1
+# round 6 additions: the dense solve of small systems (k_dense_solve_mx) — phase stamps, A/B against the round-5 chain — and the delta interface
+# (tables kept between solves: hs_append_* / hs_retire_* / hs_stage) against whole-table uploads inside optimize()
+[ -f tools/libhyperslam_hip_prof.so ] && { python tools/dense_mx_phase_timing.py 33 1; python tools/dense_mx_phase_timing.py 33 0; } > $out/${tag}_dense_mx_phase_timing.txt 2>&1
+bash tools/r06_replay_host.sh $tag
+( cd hyperslam_amd/host; for a in "6.0 0 4" "6.0 1 4" "6.0 1 6"; do echo "replay $a HS_DEBUG_FLAGS=8 (round 5: one-ended band kernels + border chain + k_band_backward)"; HS_DEBUG_FLAGS=8 ./replay $a 2>/dev/null | tail -1; echo "replay $a (k_dense_solve_mx)"; ./replay $a 2>/dev/null | tail -1; done ) > $out/${tag}_replay_dense_ab.txt 2>&1
+bash tools/kernel_stats.sh $out/${tag}_replay_stereo_kernel_stats.csv hyperslam_amd/host/replay 6.0 0 4 >> $out/${tag}_kernel_stats.txt 2>&1
 echo done

@@ -304,24 +304,34 @@ HSD void dx_sweep_fetch(const double* ut, int rho, int K, double (&u)[16]) {
 /// Sweep, block K: x_K = W_K pend_K in lanes 0 .. 15 of every wave (W_K upper triangular: the entries left of the diagonal came out as exact
 /// zeros), then every pending row above subtracts U(:, K) x_K. One barrier. (Functions with the register sets as parameters: as lambdas that
 /// capture the arrays by reference they put them into scratch memory.)
+template <int C>
+HSD void dx_sweep_apply(double& s0, double& s1, double xr, const double (&u)[16]) {
+  if constexpr (C < 16) {
+    dx_fmac_bcast<C>(s0, xr, u[C]);  // (x_K is replicated in every row of sixteen lanes: lane l holds entry l & 15)
+    dx_fmac_bcast<C + 1>(s1, xr, u[C + 1]);
+    dx_sweep_apply<C + 2>(s0, s1, xr, u);
+  }
+}
 HSD void dx_sweep_block(int K, int rho, int w, int l, const double* ut, const double* wk, double* pk, double* xv, double& pend, const double (&u)[16],
                         double (&u_next)[16]) {
   if (K < 0) return;
   if (rho >= 16 * K && rho < 16 * K + 16) pk[(K & 1) * 16 + (rho - 16 * K)] = pend;
   dx_sweep_fetch(ut, rho, K - 2, u_next);
   lds_barrier();
-  if (w >= 4) return;  // (the rows live in the first four waves, one per SIMD; the others only keep the barriers — running the arithmetic on their
-                       //  empty lanes too made a step three times as long: it is instruction issue)
   const double* wr = wk + (16 * K + (l & 15)) * 16;
   const double* pr = pk + (K & 1) * 16;
   double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
 #pragma unroll
   for (int c = 0; c < 16; c += 4) x0 = fma(wr[c], pr[c], x0), x1 = fma(wr[c + 1], pr[c + 1], x1), x2 = fma(wr[c + 2], pr[c + 2], x2), x3 = fma(wr[c + 3], pr[c + 3], x3);
-  const double xr = (x0 + x1) + (x2 + x3);
+  double xr = (x0 + x1) + (x2 + x3);
   if (w == 0 && l < 16) xv[16 * K + l] = xr;
   double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-  for (int c = 0; c < 16; c += 2) s0 = fma(u[c], dx_readlane(xr, c), s0), s1 = fma(u[c + 1], dx_readlane(xr, c + 1), s1);
+#if !defined(HS_EMULATED_DEVICE)
+  // (xr was written by the vector instruction before; the DPP reads below carry no wait states of their own. xr as an operand: the statement
+  //  stays between the addition that writes it and the multiply-adds that read it)
+  asm volatile("s_nop 4" : "+v"(xr));
+#endif
+  dx_sweep_apply<0>(s0, s1, xr, u);
   pend -= s0 + s1;
 }
 
@@ -349,10 +359,13 @@ __global__ void __launch_bounds__(kDxThreads) k_dense_solve_mx(Tables T, int f0,
   else
     dx_factor<2>(T.dense, nt, n_pad, w - 8, w, l, smem, ut, false, tlog);
   if (prof) tlog[8 * 20 + 0] = wall_clock64();
-  // ---- backward sweep U x = y, lane = row (the first four waves hold the rows; everybody keeps the barriers) ----
+  // ---- backward sweep U x = y, lane = row: the first four waves (one per SIMD) hold the 256 rows; the others have nothing left to do and
+  //      leave — a wave that has ended does not count at a barrier, and while they stayed (16 predicated loads and a barrier per block, on the
+  //      SIMDs of the row waves) a step of the sweep took longer ----
   wait_vmem();  // this wave's factor rows have left
   __threadfence();
   lds_barrier();
+  if (w >= 4) return;
   double* pk = smem + kDxOffP;
   const int rho = tid;  // row of the padded system (tid < 256)
   // y = U^-T g is column n_dense of the factor: the right-hand side rode along as a column of the padded matrix (the dense copy carries g there
@@ -371,7 +384,7 @@ __global__ void __launch_bounds__(kDxThreads) k_dense_solve_mx(Tables T, int f0,
   if (prof) tlog[8 * 20 + 1] = wall_clock64();
   // ---- outputs: step = -x, delta = scale o step, the two sums of the model cost change (k_band_backward's epilogue) ----
   double gd = 0.0, dd = 0.0;
-  for (int r = tid; r < 6 * f0; r += kDxThreads) T.step_p[r] = 0.0, T.delta_p[r] = 0.0;
+  for (int r = tid; r < 6 * f0; r += 256) T.step_p[r] = 0.0, T.delta_p[r] = 0.0;
   if (rho < n_dense) {
     const double step = -xv[rho];
     if (rho < n_pose) {
@@ -384,10 +397,12 @@ __global__ void __launch_bounds__(kDxThreads) k_dense_solve_mx(Tables T, int f0,
       gd = T.gb_s[b] * step, dd = T.D2b[b] * step * step;
     }
   }
-  double* red = smem + kDxOffRed;
-  gd = block_sum(gd, red);
-  dd = block_sum(dd, red + 8);
+  double* red = smem + kDxOffRed;  // (sums over the four row waves, in wave order: block_sum counts on the whole workgroup)
+  gd = wave_sum(gd), dd = wave_sum(dd);
+  if (l == 0) red[w] = gd, red[8 + w] = dd;
+  lds_barrier();
   if (tid == 0) {
+    gd = ((red[0] + red[1]) + red[2]) + red[3], dd = ((red[8] + red[9]) + red[10]) + red[11];
     st->g_dot_step_pose = gd, st->d2_step2_pose = dd;
     if (fail) st->chol_failed = 1;  // (consumed and cleared by decide_step, kernels_update.hpp)
   }

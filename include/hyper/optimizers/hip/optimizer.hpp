@@ -18,10 +18,14 @@
 ///
 /// How it maps onto the Ceres backend it replaces (internal/hyper/optimizers/ceres/optimizer.cpp, "cc" below):
 ///   Ceres keeps the problem structure incrementally (AddParameterBlock / AddResidualBlock / RemoveParameterBlock, cc:286-382) and
-///   mutates the variables in place through the registered double* (cc:299-305,354-356). The HIP library takes flat tables. The plugin
-///   therefore RECORDS what the virtuals are told (observations, landmarks, sensors, constancy), BUILDS the tables from the live
-///   variables at optimize() and WRITES the result back into the same variables, so that every caller above (abstract.cpp:74-147)
-///   observes exactly the side effects it observes with Ceres.
+///   mutates the variables in place through the registered double* (cc:299-305,354-356). So does this plugin, through the library's DELTA
+///   interface (hyperslam_hip.h: hs_append_* / hs_retire_* / hs_stage): add(observation) appends one row to the resident residual table,
+///   addLandmark one row to the landmark table, updateLandmarks retires rows (the landmark's residual rows with it), and optimize() sends
+///   what a window change touches — control points with their constancy mask, the bias points in use, gravity — solves and WRITES the result
+///   back into the same variables, so that every caller above (abstract.cpp:74-147) observes exactly the side effects it observes with
+///   Ceres. The residual and landmark tables are sorted and uploaded between solves (hs_stage from add(InertialObservation&) /
+///   add(ManifoldObservation&): the last call of the messages that arrive one observation at a time; a stereo frame's rows are staged by the
+///   next of those, or by hs_solve itself): optimize() finds them resident, as ceres::Solve finds its problem built.
 ///     parameter blocks   state elements in variables_ (cc:296-306)      -> hs_set_spline rows [q(4) p(3) t], constancy mask (cc:319-328)
 ///                        sensor.parameters() (cc:143-155)               -> hs_set_cameras / hs_set_sensors / hs_set_imu (all constant, camera.hpp:18, imu.hpp:18)
 ///                        imu bias elements (imu.cpp:64-81)              -> hs_set_imu bias tables (variable, cc:65-66)
@@ -113,13 +117,34 @@ class Optimizer<kOptimizerSuiteHIP> final : public AbstractOptimizer {
   auto add(VisualBearingObservation& observation) -> void final {
     landmarks_.insert(&observation.landmark());
     bearings_.push_back(&observation);
+    const auto& m = observation.measurement();
+    const double stamp = admitted(m.stamp());
+    const std::int32_t row = landmarkRow(observation.landmark()), camera = camera_index_.at(&m.sensor());
+    check(hs_append_bearing_residuals(handle_, 1, &stamp, m.variable().asVector().data(), &row, &camera));
   }
   auto add(VisualPixelObservation& observation) -> void final {
     landmarks_.insert(&observation.landmark());
     pixels_.push_back(&observation);
+    const auto& m = observation.measurement();
+    const double stamp = admitted(m.stamp());
+    const std::int32_t row = landmarkRow(observation.landmark()), camera = camera_index_.at(&m.sensor());
+    check(hs_append_pixel_residuals(handle_, 1, &stamp, m.variable().asVector().data(), &row, &camera));
   }
-  auto add(ManifoldObservation<Manifold>& observation) -> void final { priors_.push_back(&observation); }     // cc:234-251
-  auto add(InertialObservation<Manifold>& observation) -> void final { inertials_.push_back(&observation); }  // cc:253-274
+  auto add(ManifoldObservation<Manifold>& observation) -> void final {  // cc:234-251
+    priors_.push_back(&observation);
+    const auto& m = observation.measurement();
+    const double stamp = admitted(m.stamp());
+    const std::int32_t sensor = pose_sensor_index_.at(&m.sensor());
+    check(hs_append_prior_residuals(handle_, 1, &stamp, m.variable().asVector().data(), &sensor));  // SE3 [q(4) p(3)]
+    stage();
+  }
+  auto add(InertialObservation<Manifold>& observation) -> void final {  // cc:253-274
+    inertials_.push_back(&observation);
+    const auto& m = observation.measurement();
+    const double stamp = admitted(m.stamp());
+    check(hs_append_inertial_residuals(handle_, 1, &stamp, m.variable().asVector().data()));  // Tangent<SE3> [angular(3) linear(3)]
+    stage();
+  }
 
   [[nodiscard]] auto hasSensor(const Sensor& sensor) const -> bool final {  // cc:157-159
     return camera_index_.contains(&sensor) || pose_sensor_index_.contains(&sensor) || imu_ == &sensor;
@@ -148,7 +173,8 @@ class Optimizer<kOptimizerSuiteHIP> final : public AbstractOptimizer {
     bias_separation_ = separation;
   }
 
-  /// cc:276-280. Tables from the live variables -> hs_solve -> write-back in place.
+  /// cc:276-280. What a window change touches (control points, sensors, bias points in use, gravity) -> hs_solve -> write-back in place; the
+  /// residual and landmark tables are resident (add / addLandmark / updateLandmarks).
   auto optimize() -> void final {
     if (bearings_.empty() && pixels_.empty() && priors_.empty() && inertials_.empty()) return;
     const auto order = state().interpolator()->layout().outer.size;  // control points per segment (k)
@@ -188,18 +214,6 @@ class Optimizer<kOptimizerSuiteHIP> final : public AbstractOptimizer {
     } else {
       check(rc);
     }
-    // Upstream admits a message with state().range().contains(stamp) on the elements' ACCUMULATED stamps (abstract.cpp:103-106, 127-137);
-    // the library derives the segment from t0 + j * separation. The two agree except in the last bits of a stamp on a knot: a stamp
-    // that upstream admitted and the uniform arithmetic puts one segment outside the table is moved by those last bits.
-    const auto n_segments = static_cast<std::ptrdiff_t>(cps.size()) - order + 1;
-    const auto admitted = [&](Stamp stamp) {
-      const auto segment = [&](const Stamp s) { return static_cast<std::ptrdiff_t>(std::floor((s - t0) / separation_)) - (order - 1) / 2; };
-      for (auto i = 0; i < 4 && segment(stamp) >= n_segments && stamp - newest_stamp < 1e-9 * separation_; ++i)
-        stamp = std::nextafter(stamp, std::numeric_limits<Stamp>::lowest());
-      for (auto i = 0; i < 4 && segment(stamp) < 0 && oldest_stamp - stamp < 1e-9 * separation_; ++i) stamp = std::nextafter(stamp, std::numeric_limits<Stamp>::max());
-      return stamp;
-    };
-
     // ---- sensors: sensor.parameters() in Traits order (cc:143-155); constant blocks (camera.hpp:18, imu.hpp:18) ----
     std::vector<double> cam_T(7 * cameras_.size()), cam_i(4 * cameras_.size()), cam_d(4 * cameras_.size());
     for (std::size_t c = 0; c < cameras_.size(); ++c) {
@@ -213,47 +227,8 @@ class Optimizer<kOptimizerSuiteHIP> final : public AbstractOptimizer {
     for (std::size_t s = 0; s < pose_sensors_.size(); ++s) std::copy_n(pose_sensors_[s]->parameters()[0]->asVector().data(), 7, &sensor_T[7 * s]);
     check(hs_set_sensors(handle_, static_cast<int>(pose_sensors_.size()), sensor_T.data()));
 
-    // ---- landmarks: pointer -> dense id = position in the table (landmarks_ is the active set, cc:347-382) ----
-    std::unordered_map<const AbstractLandmark*, std::int32_t> landmark_id;
-    std::vector<Landmark<Position<Scalar>>*> landmark_table;
-    std::vector<double> lm;
-    for (auto* abstract_landmark : landmarks_) {
-      auto* landmark = static_cast<Landmark<Position<Scalar>>*>(abstract_landmark);
-      landmark_id.emplace(landmark, static_cast<std::int32_t>(landmark_table.size()));
-      landmark_table.push_back(landmark);
-      const auto& p = landmark->variable();
-      lm.insert(lm.end(), {p.x(), p.y(), p.z()});
-    }
-    check(hs_set_landmarks(handle_, static_cast<int>(landmark_table.size()), lm.data(), /*constant=*/nullptr));
-
-    // ---- residual tables. Residual blocks of retired landmarks went with them in updateLandmarks() (cc:365-371). ----
-    {
-      std::vector<double> stamps, values;
-      std::vector<std::int32_t> ids, cams;
-      for (const auto* o : bearings_) {
-        const auto& m = o->measurement();
-        stamps.push_back(admitted(m.stamp())), ids.push_back(landmark_id.at(&o->landmark())), cams.push_back(camera_index_.at(&m.sensor()));
-        const auto v = m.variable().asVector();
-        values.insert(values.end(), v.data(), v.data() + 3);
-      }
-      check(hs_set_bearing_residuals(handle_, static_cast<int>(stamps.size()), stamps.data(), values.data(), ids.data(), cams.data()));
-      stamps.clear(), values.clear(), ids.clear(), cams.clear();
-      for (const auto* o : pixels_) {
-        const auto& m = o->measurement();
-        stamps.push_back(admitted(m.stamp())), ids.push_back(landmark_id.at(&o->landmark())), cams.push_back(camera_index_.at(&m.sensor()));
-        const auto v = m.variable().asVector();
-        values.insert(values.end(), v.data(), v.data() + 2);
-      }
-      check(hs_set_pixel_residuals(handle_, static_cast<int>(stamps.size()), stamps.data(), values.data(), ids.data(), cams.data()));
-      stamps.clear(), values.clear(), ids.clear();
-      for (const auto* o : priors_) {
-        const auto& m = o->measurement();
-        stamps.push_back(admitted(m.stamp())), ids.push_back(pose_sensor_index_.at(&m.sensor()));
-        const auto v = m.variable().asVector();  // SE3 [q(4) p(3)]
-        values.insert(values.end(), v.data(), v.data() + 7);
-      }
-      check(hs_set_prior_residuals(handle_, static_cast<int>(stamps.size()), stamps.data(), values.data(), ids.data()));
-    }
+    // ---- landmarks and residual tables: resident in the library, row by row (addLandmark / add(...) -> hs_append_*, updateLandmarks ->
+    //      hs_retire_*). Nothing to send: the library's landmark values are those its last solve left, which are the variables' (write-back). ----
 
     // ---- IMU: static blocks {T_bs, i_g, i_a, S_g, X_a} (inertial.cpp:36-49) + the two R^3 bias splines (imu.cpp:64-81) + gravity.
     //      Ceres only sees the bias elements some residual block refers to (exteroceptive.cpp:64-76); the table holds exactly that range:
@@ -292,19 +267,9 @@ class Optimizer<kOptimizerSuiteHIP> final : public AbstractOptimizer {
                        parameters[3]->asVector().data(), parameters[4]->asVector().data(), bias_order, bias_g[3], bias_dt, static_cast<int>(n_bias), bias_g.data(),
                        bias_a.data(), /*bias_constant=*/0));  // cc:62-63 set*BiasConstant(false)
       check(hs_set_gravity(handle_, mutableEnvironment().gravity().data(), gravity_constant_ ? 1 : 0));
-      std::vector<double> stamps, values;
-      for (const auto* o : inertials_) {
-        const auto& m = o->measurement();
-        stamps.push_back(admitted(m.stamp()));
-        const auto v = m.variable().asVector();  // Tangent<SE3> [angular(3) linear(3)]
-        values.insert(values.end(), v.data(), v.data() + 6);
-      }
-      check(hs_set_inertial_residuals(handle_, static_cast<int>(stamps.size()), stamps.data(), values.data()));
-    } else if (imu_ != nullptr) {
-      // every sample has left the window (or none has arrived yet): the table of the previous call must not stay behind. The bias
-      // and gravity tables the handle may still hold are unknowns without residuals then and come back untouched
-      // (tests/test_gpu_inertial.py::test_imu_tables_without_inertial_residuals).
-      check(hs_set_inertial_residuals(handle_, 0, nullptr, nullptr));
+      // (the inertial rows themselves: appended by add(InertialObservation&), retired in updateLandmarks(). When every sample has left the window the
+      //  bias and gravity tables the handle still holds are unknowns without residuals and come back untouched,
+      //  tests/test_gpu_inertial.py::test_imu_tables_without_inertial_residuals)
     }
 
     // ---- solve (cc:38-54: trust-region LM, 5 iterations, monotonic steps) ----
@@ -316,9 +281,10 @@ class Optimizer<kOptimizerSuiteHIP> final : public AbstractOptimizer {
     check(hs_get_control_points(handle_, cp.data()));
     for (std::size_t j = 0; j < cps.size(); ++j)
       if (!cp_constant[j]) std::copy_n(&cp[8 * j], 7, cps[j]->asVector().data());  // stamp untouched (time is constant)
-    if (!landmark_table.empty()) {
+    if (!landmark_rows_.empty()) {
+      std::vector<double> lm(3 * landmark_rows_.size());
       check(hs_get_landmarks(handle_, lm.data()));
-      for (std::size_t l = 0; l < landmark_table.size(); ++l) landmark_table[l]->variable() = Position<Scalar>{lm[3 * l], lm[3 * l + 1], lm[3 * l + 2]};
+      for (std::size_t l = 0; l < landmark_rows_.size(); ++l) landmark_rows_[l]->variable() = Position<Scalar>{lm[3 * l], lm[3 * l + 1], lm[3 * l + 2]};
     }
     if (!bias_g_elements.empty()) {
       std::vector<double> bias_g(4 * bias_g_elements.size()), bias_a(4 * bias_a_elements.size());
@@ -333,6 +299,44 @@ class Optimizer<kOptimizerSuiteHIP> final : public AbstractOptimizer {
 
  private:
   auto check(const int rc) const -> void { CHECK_EQ(rc, HS_OK) << hs_last_error(handle_); }  // the reference aborts through glog CHECK
+
+  /// Sorts and uploads what the messages since the last solve changed (hs_stage: enqueued, nothing is awaited) — from the add() overrides of the
+  /// messages that bring ONE observation (inertial sample, pose measurement), i.e. at the end of AbstractOptimizer::process; a stereo frame's
+  /// rows (process(VisualTracks) calls add() once per observation, abstract.cpp:246-259, and has no last call to hang this on) are staged with
+  /// the next of those, or by hs_solve. A maintainer who prefers one explicit call adds `optimizer_->stage()` behind `submit` in Backend::spin
+  /// (backend.cpp:143-145) and makes this public.
+  auto stage() -> void { check(hs_stage(handle_)); }
+
+  /// Upstream admits a message with state().range().contains(stamp) on the elements' ACCUMULATED stamps (abstract.cpp:103-106, 127-137);
+  /// the library derives the segment from t0 + j * separation. The two agree except in the last bits of a stamp on a knot: a stamp that
+  /// upstream admitted and the uniform arithmetic puts one segment outside the state is moved by those last bits (evaluated at admission,
+  /// against the state as it is then — the state only grows at its newer end afterwards).
+  [[nodiscard]] auto admitted(Stamp stamp) const -> Stamp {
+    const auto& elements = state().elements();
+    if (elements.empty()) return stamp;
+    const auto order = static_cast<std::ptrdiff_t>(state().interpolator()->layout().outer.size);
+    const auto t0 = (*elements.begin())->stamp(), newest = (*elements.rbegin())->stamp();
+    const auto n_segments = static_cast<std::ptrdiff_t>(elements.size()) - order + 1;
+    const auto segment = [&](const Stamp s) { return static_cast<std::ptrdiff_t>(std::floor((s - t0) / separation_)) - (order - 1) / 2; };
+    for (auto i = 0; i < 4 && segment(stamp) >= n_segments && stamp - newest < 1e-9 * separation_; ++i) stamp = std::nextafter(stamp, std::numeric_limits<Stamp>::lowest());
+    for (auto i = 0; i < 4 && segment(stamp) < 0 && t0 - stamp < 1e-9 * separation_; ++i) stamp = std::nextafter(stamp, std::numeric_limits<Stamp>::max());
+    return stamp;
+  }
+
+  /// Row of a landmark in the library's table; a landmark the library does not hold (new: addLandmark; retired earlier and observed again:
+  /// AddResidualBlock registers an unknown parameter block, cc:203-209) is appended with its present value.
+  auto landmarkRow(AbstractLandmark& abstract_landmark) -> std::int32_t {
+    if (const auto itr = landmark_row_.find(&abstract_landmark); itr != landmark_row_.end()) return itr->second;
+    auto* landmark = static_cast<Landmark<Position<Scalar>>*>(&abstract_landmark);
+    const auto& p = landmark->variable();
+    const double xyz[3] = {p.x(), p.y(), p.z()};
+    std::int32_t row = -1;
+    check(hs_append_landmarks(handle_, 1, xyz, /*constant=*/nullptr, &row));
+    CHECK_EQ(static_cast<std::size_t>(row), landmark_rows_.size());
+    landmark_row_.emplace(&abstract_landmark, row);
+    landmark_rows_.push_back(landmark);
+    return row;
+  }
 
   /// createSensorManifold + setSensorManifold (cc:56-71,143-155): cameras by pointer -> index into the camera table, the IMU, and
   /// any other pose sensor (ManifoldObservation's sensor) -> index into the extrinsics table.
@@ -394,6 +398,7 @@ class Optimizer<kOptimizerSuiteHIP> final : public AbstractOptimizer {
   auto addLandmark(Landmark<Position<Scalar>>& landmark) -> void final {  // cc:347-358
     DCHECK(!landmarks_.contains(&landmark));
     landmarks_.insert(&landmark);
+    (void)landmarkRow(landmark);
   }
 
   /// cc:360-382: landmarks whose observation range left the window are retired, and RemoveParameterBlock takes their residual blocks
@@ -405,11 +410,30 @@ class Optimizer<kOptimizerSuiteHIP> final : public AbstractOptimizer {
     const auto retired = [&](const auto* observation) { return !landmarks_.contains(&observation->landmark()); };
     std::erase_if(bearings_, retired);
     std::erase_if(pixels_, retired);
+    {  // the same in the library: hs_retire_landmarks takes the rows of the landmarks and their residual rows along and reports where the others moved
+      std::vector<std::int32_t> rows, remap(landmark_rows_.size());
+      for (std::size_t l = 0; l < landmark_rows_.size(); ++l)
+        if (!landmarks_.contains(landmark_rows_[l])) rows.push_back(static_cast<std::int32_t>(l));
+      if (!rows.empty()) {
+        check(hs_retire_landmarks(handle_, static_cast<int>(rows.size()), rows.data(), remap.data()));
+        std::vector<Landmark<Position<Scalar>>*> kept(landmark_rows_.size() - rows.size());
+        for (std::size_t l = 0; l < landmark_rows_.size(); ++l) {
+          if (remap[l] < 0) {
+            landmark_row_.erase(landmark_rows_[l]);
+          } else {
+            kept[static_cast<std::size_t>(remap[l])] = landmark_rows_[l];
+            landmark_row_[landmark_rows_[l]] = remap[l];
+          }
+        }
+        landmark_rows_ = std::move(kept);
+      }
+    }
     if (!retire_old_observations_) return;
     auto oldest = range.lowerBound();
     for (const auto* landmark : landmarks_) oldest = std::min(oldest, landmark->range().lowerBound());
     const auto expired = [&](const auto* observation) { return observation->measurement().stamp() < oldest; };
     std::erase_if(inertials_, expired);
+    check(hs_retire_residuals_before(handle_, HS_INERTIAL, oldest));
     // a pose prior goes once every control point it constrains is constant (stamp <= window lower bound, cc:319-328): until then it may be
     // what anchors the gauge of the free control points
     const auto [left_padding, right_padding] = state().interpolator()->layout().outerPadding();
@@ -418,6 +442,8 @@ class Optimizer<kOptimizerSuiteHIP> final : public AbstractOptimizer {
       return expired(observation) && observation->measurement().stamp() + reach <= range.lowerBound();
     };
     std::erase_if(priors_, prior_expired);
+    // (stamp < oldest and stamp + reach <= lower bound: one threshold)
+    check(hs_retire_residuals_before(handle_, HS_PRIOR, std::min(oldest, std::nextafter(range.lowerBound() - separation_ * (right_padding + 1), std::numeric_limits<Stamp>::max()))));
   }
 
   /// CHECK(false) upstream (cc:384-386), yet AbstractOptimizer::process(InertialMeasurement) calls it whenever a bias spline is empty
@@ -467,6 +493,8 @@ class Optimizer<kOptimizerSuiteHIP> final : public AbstractOptimizer {
   std::vector<VisualPixelObservation*> pixels_;
   std::vector<ManifoldObservation<Manifold>*> priors_;
   std::vector<InertialObservation<Manifold>*> inertials_;
+  std::unordered_map<const AbstractLandmark*, std::int32_t> landmark_row_;  // rows of the library's landmark table (delta interface)
+  std::vector<Landmark<Position<Scalar>>*> landmark_rows_;
   bool rotation_constant_{false}, translation_constant_{false}, gravity_constant_{true}, retire_old_observations_{true};
   Stamp bias_separation_{1.0};
   std::size_t skipped_windows_{0};

@@ -226,13 +226,21 @@ int launch_build(hs_problem* p, hipEvent_t after_build = nullptr, bool scaling_f
     k_seg_gram<K><<<p->n_seg_wg, kBlock, kSegStage * sizeof(double), s>>>(T);
   }
   if (fork) HIP_TRY(hipStreamWaitEvent(s, p->ev_join, 0));
-  const bool direct = scaling_fixed && fused && !T.nb && !p->allreduce && !p->rccl_comm && p->world == 1 && factor_two_ended_la(p) &&
+  // (direct mode needs a factorisation that does the iteration bookkeeping: the two-ended look-ahead / matrix-core kernels, and — round 6 —
+  //  k_dense_solve_mx, which then also gets its dense copy of the system from the assembly)
+  Tables Ta = T;
+  const bool dense_mx = use_dense_mx(p, &Ta.dense_f0);
+  //  Bordered systems stay on k_finalize_reduced: with the border blocks scaled by extra workgroups of the assembly the main stream has to wait
+  //  for the side stream's border gathers BEFORE the assembly instead of behind it — measured on the stereo-inertial replay: 1.09 against
+  //  1.03 ms per optimize().)
+  const bool direct = scaling_fixed && fused && !T.nb && !p->allreduce && !p->rccl_comm && p->world == 1 && (factor_two_ended_la(p) || dense_mx) &&
                       !(T.debug_flags & 4096);  // A/B switch 4096: k_finalize_reduced in every iteration
+  if (direct && dense_mx) Ta.dense = p->d_dense_ut.p + size_t(kDenseLd) * kDenseLd;
   // window-wide bands on the fused build (more than 256 window tiles): a row collects every chunk of a short window — k_assemble_wide
-  if (fused && T.bw * (T.bw + 1) / 2 > kBlock && !direct)
-    k_assemble_wide<K><<<dim3(T.sp.n_cp, 6), kAsmWideThreads, 0, s>>>(T, 0);
+  if (fused && T.bw * (T.bw + 1) / 2 > kBlock)
+    k_assemble_wide<K><<<dim3(T.sp.n_cp, 6), kAsmWideThreads, 0, s>>>(Ta, direct ? 1 : 0);
   else
-    k_assemble<K><<<dim3(T.sp.n_cp, 6), kAsmThreads, 0, s>>>(T, direct ? 1 : 0);
+    k_assemble<K><<<dim3(T.sp.n_cp, 6), kAsmThreads, 0, s>>>(Ta, direct ? 1 : 0);
   if (direct) {
     p->bookkeep = true;
     HIP_TRY(hipGetLastError());
@@ -458,6 +466,7 @@ int launch_factor(hs_problem* p) {
   if (dense_mx) {
     Tables Td = T;
     Td.dense = p->d_dense_ut.p + size_t(kDenseLd) * kDenseLd, Td.dense_f0 = f0;
+    Td.bookkeep = p->bookkeep ? 1 : 0;
     k_dense_solve_mx<<<1, kDxThreads, size_t(kDxLdsDoubles) * sizeof(double), s>>>(Td, f0, p->d_dense_ut.p);
     HIP_TRY(hipGetLastError());
     return HS_OK;

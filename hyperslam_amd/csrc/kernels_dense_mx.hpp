@@ -365,6 +365,9 @@ __global__ void __launch_bounds__(kDxThreads) k_dense_solve_mx(Tables T, int f0,
   wait_vmem();  // this wave's factor rows have left
   __threadfence();
   lds_barrier();
+  // Iteration bookkeeping of a directly assembled system (Tables::bookkeep, factor_bookkeep: no k_finalize_reduced launch in front of this kernel):
+  // a wave that would leave here — nobody waits for its verdict (a termination test that fires makes every later kernel exit on `done`).
+  if (T.bookkeep && w == 11) factor_bookkeep(T, l);
   if (w >= 4) return;
   double* pk = smem + kDxOffP;
   const int rho = tid;  // row of the padded system (tid < 256)

@@ -504,6 +504,8 @@ __global__ void __launch_bounds__(kBlock) k_gram_pair(Tables T, int batch, int n
     seg_gram_body<K>(T, blockIdx.x - n_group);
 }
 
+HSD void dense_padding_corner(double* D, int n_dense, int n_pad, int first, int stride);  // (below, with k_finalize_reduced)
+
 constexpr int kAsmThreads = 512, kAsmU = 6;  // lanes per scalar row, loads in flight per lane (6, and at most 80 VGPRs: six waves per SIMD = three workgroups per CU —
                                               // at 97 VGPRs a CU held two, and the 768 workgroups of a 128-control-point window ran in two rounds: 13.7 us)
 
@@ -673,6 +675,10 @@ HSD void assemble_body(const Tables& T, int direct) {
           }
         }
         T.Sb[size_t(rho) * ncb + tid] = out;
+        if (T.dense && i >= T.dense_f0 && sigma < T.np && sigma >= rho) {  // dense copy for k_dense_solve_mx (k_finalize_reduced): entry and mirror image
+          const int ii = rho - 6 * T.dense_f0, jj = sigma - 6 * T.dense_f0;
+          T.dense[size_t(ii) * kDenseLd + jj] = out, T.dense[size_t(jj) * kDenseLd + ii] = out;
+        }
         if (T.Sb2 && sigma < T.np) {  // reversed copy for the far end of the two-ended factorisation (k_finalize_reduced)
           const int rv = T.np - 1 - sigma, cv = T.np - 1 - rho;
           T.Sb2[size_t(rv) * ncb + (cv - 6 * (rv / 6))] = out;
@@ -700,6 +706,19 @@ HSD void assemble_body(const Tables& T, int direct) {
       T.g_s[rho] = d_sr * (gp + gs);
       if (T.Sb2) T.g2[T.np - 1 - rho] = d_sr * (gp + gs);
       T.gabs[rho] = fabs(gp);
+      if (T.dense && i >= T.dense_f0) {  // the right-hand side as column (and row) n_dense of the dense copy
+        const int ii = rho - 6 * T.dense_f0, n_dense = T.np - 6 * T.dense_f0 + T.nb;
+        T.dense[size_t(ii) * kDenseLd + n_dense] = d_sr * (gp + gs), T.dense[size_t(n_dense) * kDenseLd + ii] = d_sr * (gp + gs);
+      }
+    }
+    if (T.dense && i >= T.dense_f0) {  // this row of the dense copy right of the band and in the padding: zero (k_finalize_reduced does six rows at once)
+      const int n_pose = T.np - 6 * T.dense_f0, n_dense = n_pose + T.nb, n_pad = 16 * ((n_dense + 1 + 15) / 16);
+      const int j0 = min(6 * (i - T.dense_f0) + ncb, n_pose), n_right = n_pose - j0, n_padc = n_pad - (n_dense + 1), ii = 6 * (i - T.dense_f0) + a;
+      for (int q = tid; q < n_right + n_padc; q += THREADS) {
+        const int jj = q < n_right ? j0 + q : n_dense + 1 + (q - n_right);
+        T.dense[size_t(ii) * kDenseLd + jj] = 0.0, T.dense[size_t(jj) * kDenseLd + ii] = 0.0;
+      }
+      if (T.nb == 0 && i == T.sp.n_cp - 1 && a == 5) dense_padding_corner(T.dense, n_dense, n_pad, tid, THREADS);
     }
   }
   if (aprof) alog[6] = wall_clock64();

@@ -573,10 +573,19 @@ template <int K>
 int launch_update(hs_problem* p, bool linearize_candidate = false, bool deferred_commit = false, hipEvent_t* lin_events = nullptr, bool fold_next = false) {
   const Tables& T = p->T;
   hipStream_t s = p->stream;
+  const bool local_decision = !p->allreduce && !p->rccl_comm;  // single shard: decide in the packing kernel
+  const bool inline_commit = commit_inline(p);
+  const bool cps_here = p->fused && deferred_commit;  // fused path: the decision kernel commits the control points, the landmarks stay deferred
+  const int decide_here = inline_commit ? 2 : local_decision ? (cps_here ? 3 : 1) : 0;
+  // Single shard, fused path (round 6): the candidate costs of the prior / inertial factors are further workgroups of k_update_visual's launch —
+  // one launch where a stereo-inertial window had three on the chain of every iteration. A/B switch 134217728: the separate launches.
+  const bool merged = p->fused && local_decision && !(T.debug_flags & 134217728);
   if (p->fused) {  // candidate point, landmark back-substitution and the visual candidate cost per chunk, one launch
-    k_update_visual<K><<<p->nb_vis + T.n_norm_part, kBlock, size_t(update_lds_doubles(T.bw, p->build_R, p->build_L)) * 8, s>>>(T, p->build_R, p->build_L, p->nb_vis);
-    if (T.n_pri) k_cost_prior<K><<<p->nb_pri, kBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.cand_part + p->nb_vis);
-    if (T.n_ine)
+    const int nb_pri = merged && T.n_pri ? p->nb_pri : 0, nb_ine = merged && T.n_ine ? p->nb_ine : 0;
+    const size_t lds = std::max(size_t(update_lds_doubles(T.bw, p->build_R, p->build_L)), size_t(8 * T.sp.n_cp + 8 * T.n_bias + 4)) * 8;
+    k_update_visual<K><<<p->nb_vis + T.n_norm_part + nb_pri + nb_ine, kBlock, lds, s>>>(T, p->build_R, p->build_L, p->nb_vis, nb_pri, nb_ine);
+    if (T.n_pri && !merged) k_cost_prior<K><<<p->nb_pri, kBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.cand_part + p->nb_vis);
+    if (T.n_ine && !merged)
       k_cost_inertial<K, 4><<<p->nb_ine, kInertialBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.bias_g_cand, T.bias_a_cand, T.gravity_cand,
                                                                           T.cand_part + p->nb_vis + p->nb_pri);
   } else
@@ -596,11 +605,8 @@ int launch_update(hs_problem* p, bool linearize_candidate = false, bool deferred
       k_cost_inertial<K, 4><<<p->nb_ine, kInertialBlock, cp_lds_bytes(p), s>>>(T, T.cp_cand, T.bias_g_cand, T.bias_a_cand, T.gravity_cand,
                                                                           T.cand_part + p->nb_vis + p->nb_pri);
   }
-  const bool local_decision = !p->allreduce && !p->rccl_comm;  // single shard: decide in the packing kernel
-  const bool inline_commit = commit_inline(p);
-  const bool cps_here = p->fused && deferred_commit;  // fused path: the decision kernel commits the control points, the landmarks stay deferred
   if (fold_next) return HS_OK;  // (fold_decision_into_build: the next iteration's k_build_visual decides, launch_build(..., fold = true))
-  k_pack_decision<<<1, kBlock, 0, s>>>(T, inline_commit ? 2 : local_decision ? (cps_here ? 3 : 1) : 0);
+  k_pack_decision<<<1, kBlock, 0, s>>>(T, decide_here);
   HIP_TRY(hipGetLastError());
   const int rc = exchange(p, T.xbuf + T.xo_dec, 5);  // candidate cost + norms + landmark-side model-cost terms
   if (rc) return rc;

@@ -847,6 +847,7 @@ int prepare(hs_problem* p) {
   //    also changed the factorisation path)
   // 1048576 inertial branch on the main stream    2097152 banded kernels instead of k_dense_factor    4194304 k_landmark<K,4,1> instead of k_landmark_rows
   // 8388608 five finalisation launches for a bordered single shard    16777216 k_commit launch for small windows    33554432 one cost launch per factor type
+  // 134217728 prior / inertial candidate costs as launches of their own behind k_update_visual (single shard, fused path)
   // 268435456 backward sweeps one block row per step    536870912 bordered systems one-ended    1073741824 no speculative linearisation at the candidate    67108864 k_commit in every iteration of a speculative solve
   T.st = p->d_state.p;
   HIP_TRY(p->batch.flush(s));  // (the staging arena outlives this call: no host synchronisation)

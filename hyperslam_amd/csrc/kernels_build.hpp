@@ -736,13 +736,69 @@ __host__ __device__ inline int update_lds_doubles(int bw, int R, int Lmax) {
   return 14 * bw + 4 * Lmax * bw + 8 * Lmax + 16 * kBuildCams + R + 8 + Lmax + 8 + 8 * bw;  // (.. + l_ncp, l_yoff: 2 Lmax ints; + relative rotations of the candidate window)
 }
 
+/// Candidate of a replicated unknown, y = Plus(x, delta): ONE spelling for the workgroups that write the candidate tables and for those that
+/// recompute it for themselves (the cost workgroups of the prior / inertial factors in the same launch, which cannot wait for the former).
+HSD void candidate_control_point(const Tables& T, int j, double* y) {
+  const double* x = T.cp + 8 * j;
+  const double* d = T.delta_p + 6 * j;
+  const Quat q = quat_plus(Quat{x[0], x[1], x[2], x[3]}, V3{d[0], d[1], d[2]});
+  y[0] = q.x, y[1] = q.y, y[2] = q.z, y[3] = q.w;
+  y[4] = x[4] + d[3], y[5] = x[5] + d[4], y[6] = x[6] + d[5];
+  y[7] = x[7];
+}
+HSD void candidate_bias_point(const Tables& T, int b /* < 2 n_bias: gyroscope, then accelerometer */, double* y) {
+  const bool acc = b >= T.n_bias;
+  const double* x = (acc ? T.bias_a : T.bias_g) + 4 * (acc ? b - T.n_bias : b);
+  const double* d = T.delta_b + 3 * b;
+  y[0] = x[0] + d[0], y[1] = x[1] + d[1], y[2] = x[2] + d[2], y[3] = x[3];
+}
+
+/// Cost workgroups of the prior / inertial factors inside k_update_visual's launch (single shard; k_cost_prior / k_cost_inertial otherwise: two
+/// more launches on the chain of an iteration, ~8 us each and almost all of it launch + first-load latency). blk: index behind the norm
+/// workgroups — [0, nb_pri) prior, then inertial (kInertialBlock residuals per workgroup, first wave). The candidate point is recomputed into LDS.
 template <int K>
-__global__ void __launch_bounds__(kBlock) k_update_visual(Tables T, int R, int Lmax, int n_vis_parts) {
-  HS_DYNAMIC_LDS(smem);
+HSD void update_cost_workgroup(const Tables& T, int blk, int nb_pri, int n_vis_parts, double* smem) {
+  const int tid = threadIdx.x;
+  __shared__ double red[kBlock / 64];
+  double* cps = smem;
+  double* bg = cps + 8 * T.sp.n_cp;
+  double* ba = bg + 4 * T.n_bias;
+  double* grav = ba + 4 * T.n_bias;
+  for (int j = tid; j < T.sp.n_cp; j += kBlock) candidate_control_point(T, j, cps + 8 * j);
+  if (T.nb > 0) {
+    for (int b = tid; b < 2 * T.n_bias; b += kBlock) candidate_bias_point(T, b, bg + 4 * b);  // (ba follows bg: b >= n_bias lands there)
+    if (tid == 0) sphere_plus(T.gravity, T.delta_b + 6 * T.n_bias, grav);
+  }
+  __syncthreads();
+  double cost = 0.0;
+  if (blk < nb_pri) {
+    const int i = blk * kBlock + tid;
+    if (i < T.n_pri) cost = prior_cost<K>(T, cps, i);
+  } else {
+    const int i = (blk - nb_pri) * kInertialBlock + tid;
+    if (tid < kInertialBlock && i < T.n_ine) {
+      InertialOut<K, 4> o;
+      o.Jp = nullptr;  // (value-only branch)
+      inertial_evaluate<K, 4, false>(T, cps, bg, ba, grav, i, false, &o);
+      cost = o.cost;
+    }
+  }
+  const double s = block_sum(cost, red);
+  if (tid == 0) T.cand_part[n_vis_parts + blk] = s;
+}
+
+/// One workgroup of the update launch; false: the solve had ended before (nothing done).
+template <int K>
+HSD bool update_visual_workgroup(const Tables& T, int R, int Lmax, int n_vis_parts, int nb_pri, double* smem) {
   const int w = blockIdx.x, tid = threadIdx.x;
   DevState* st = T.st;
+  if (int(blockIdx.x) >= n_vis_parts + T.n_norm_part) {
+    if (st->done) return false;
+    update_cost_workgroup<K>(T, blockIdx.x - n_vis_parts - T.n_norm_part, nb_pri, n_vis_parts, smem);
+    return true;
+  }
   if (int(blockIdx.x) >= n_vis_parts) {  // ---- replicated unknowns: candidate = Plus(x, delta), norms (k_backsub_retract) ----
-    if (st->done) return;
+    if (st->done) return false;
     __shared__ double red[kBlock / 64];
     const int blk = blockIdx.x - n_vis_parts;
     const int j = blk * blockDim.x + tid;
@@ -750,14 +806,10 @@ __global__ void __launch_bounds__(kBlock) k_update_visual(Tables T, int R, int L
     if (j < T.sp.n_cp) {
       const double* x = T.cp + 8 * j;
       double* y = T.cp_cand + 8 * j;
-      const double* d = T.delta_p + 6 * j;
       bool any = false;
 #pragma unroll
       for (int c = 0; c < 6; ++c) any |= (T.D2p[6 * j + c] != 0.0);
-      const Quat q = quat_plus(Quat{x[0], x[1], x[2], x[3]}, V3{d[0], d[1], d[2]});
-      y[0] = q.x, y[1] = q.y, y[2] = q.z, y[3] = q.w;
-      y[4] = x[4] + d[3], y[5] = x[5] + d[4], y[6] = x[6] + d[5];
-      y[7] = x[7];
+      candidate_control_point(T, j, y);
       if (any) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) xs = fma(x[c], x[c], xs), ss = fma(x[c] - y[c], x[c] - y[c], ss);
@@ -769,9 +821,8 @@ __global__ void __launch_bounds__(kBlock) k_update_visual(Tables T, int R, int L
         const int bi = acc ? b - T.n_bias : b;
         const double* x = (acc ? T.bias_a : T.bias_g) + 4 * bi;
         double* y = (acc ? T.bias_a_cand : T.bias_g_cand) + 4 * bi;
-        const double* d = T.delta_b + 3 * b;
         const bool any = T.D2b[3 * b] != 0.0 || T.D2b[3 * b + 1] != 0.0 || T.D2b[3 * b + 2] != 0.0;
-        y[0] = x[0] + d[0], y[1] = x[1] + d[1], y[2] = x[2] + d[2], y[3] = x[3];
+        candidate_bias_point(T, b, y);
         if (any) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) xs = fma(x[c], x[c], xs), ss = fma(x[c] - y[c], x[c] - y[c], ss);
@@ -793,7 +844,7 @@ __global__ void __launch_bounds__(kBlock) k_update_visual(Tables T, int R, int L
     for (int e = 3 * T.n_obs_lm + j; e < 3 * T.n_lm; e += T.n_norm_part * blockDim.x) T.lm_cand[e] = T.lm[e];
     xs = block_sum(xs, red), ss = block_sum(ss, red);
     if (tid == 0) T.norm_part[2 * blk] = xs, T.norm_part[2 * blk + 1] = ss;
-    return;
+    return true;
   }
   // ---- chunk w ----
   const bool uprof = prof_enabled(T.debug_flags, 512) && tid == 0 && w < 1024;  // phase stamps (profiling builds; tools/update_phase_timing.py)
@@ -802,11 +853,11 @@ __global__ void __launch_bounds__(kBlock) k_update_visual(Tables T, int R, int L
   const int4 d0 = *reinterpret_cast<const int4*>(T.ch_desc + 8 * w);
   const int nres = T.ch_desc[8 * w + 4];
   const int st_done = st->done, st_spec = st->spec, st_accepted = st->accepted;
-  if (st_done) return;
+  if (st_done) return false;
   if (w >= T.n_chunk) {  // padding workgroups of the partial tables
     if (tid == 0) T.cand_part[w] = 0.0;
     if (tid < 4) T.lm_part[4 * w + tid] = 0.0;
-    return;
+    return true;
   }
   const bool pend = st_spec == 4 && st_accepted;  // the landmarks' current point is still in lm_cand
   const int lo = d0.x, nl = d0.y, cf = d0.z, q0 = d0.w;
@@ -941,6 +992,17 @@ __global__ void __launch_bounds__(kBlock) k_update_visual(Tables T, int R, int L
     T.cand_part[w] = s;
   }
   if (uprof) ulog[6] = wall_clock64();
+  return true;
+}
+
+/// nb_pri / nb_ine: cost workgroups of the prior / inertial factors behind the norm workgroups (0: their own launches follow).
+/// (Round 6 also let the workgroup that finishes LAST take the trust-region decision — every workgroup releases its partials and draws a ticket —
+///  to save k_pack_decision's launch: an agent-scope release writes the XCD's L2 back, and ~150 of them made the launch 16 us longer (45 us from
+///  every wave) where the one-workgroup launch behind it costs 5.5. Measured on the replays, not kept: a kernel boundary does that once.)
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_update_visual(Tables T, int R, int Lmax, int n_vis_parts, int nb_pri = 0, int nb_ine = 0) {
+  HS_DYNAMIC_LDS(smem);
+  update_visual_workgroup<K>(T, R, Lmax, n_vis_parts, nb_pri, smem);
 }
 
 }  // namespace hs

@@ -10,22 +10,21 @@
 // /root/reference/internal/hyper/optimizers/ceres/optimizer.cpp:46-48 (SPARSE_NORMAL_CHOLESKY) for these windows.
 //
 // Here the bordered system [S_pp S_pb; S_pb' S_bb] x = [g_p; g_b] of N = 6 n_free + n_b <= 256 unknowns is ONE dense Cholesky solve in ONE
-// workgroup of eight waves: the border is simply the last columns of the matrix — Z = U^-T S_pb, the border Schur complement and its
+// workgroup of twelve waves: the border is simply the last columns of the matrix — Z = U^-T S_pb, the border Schur complement and its
 // factor are what the elimination produces on the way (nothing in the algebra distinguishes them).
 //
-//   data      16 x 16 tiles (I, J), I <= J, of the padded matrix (identity on the padding) live in MFMA accumulators for the whole
-//             factorisation: register r of lane l = entry (4 r + (l >> 4), l & 15) of the tile. 2-D cyclic over the eight waves (DxTiles):
-//             tile rows in two classes (five rows for the four panel waves, eleven for the others), tile columns in four — every step's tile
-//             row and trailing matrix are spread over all SIMDs; a wave loads 5 (11) + 4 operand columns per step instead of two per tile.
-//   step k    (1) the owners of tile row k write it to LDS                                                                --- barrier ---
-//             (2) panel, four waves (one per SIMD), one or two columns of the row per lane (the 16 columns of the diagonal tile and the
-//                 right-hand side redundantly in every panel wave, like the six extra lanes of k_band_factor_mx's panel): right-looking Cholesky of the 16 x 16 diagonal block fused with
-//                 the forward substitution of every column, pivots and multipliers broadcast with v_readlane (SGPR operands) — plain
-//                 substitution, no explicit inverse on the forward path. Sixteen extra columns start as the identity and come out as the rows
-//                 of W_k = U_kk^-1 (for the backward sweep only). The panel also updates the right-hand side (g_c -= x_c . y_k), writes
-//                 X(k, :) back to LDS as the operand of the update and to memory as the factor rows                        --- barrier ---
-//             (3) tile (I, J) -= X(k, I)' X(k, J) for k < I <= J: four v_mfma_f64_16x16x4_f64 per tile, A operand (negated) shared by the
-//                 tiles of a row, B operands loaded once per step.
+//   data      16 x 16 tiles (I, J) of the padded matrix (identity on the padding) live in MFMA accumulators for the whole factorisation:
+//             register r of lane l = entry (4 r + (l >> 4), l & 15) of the tile. Twelve waves, three per SIMD; tile rows in three classes,
+//             tile columns in four (DxRows): every step's tile row and trailing matrix are spread over all SIMDs.
+//   step k    (U1) tile row k + 1 gets the update of step k first and goes to LDS                                              --- barrier ---
+//             (P)  panel of step k + 1 on the four panel waves (one per SIMD, raised issue priority), ONE column of the row per lane, the
+//                  16 columns of the diagonal tile redundantly in every row of sixteen lanes: right-looking Cholesky of the diagonal
+//                  block fused with the forward substitution of every column, pivots and multipliers by DPP row broadcast inside the
+//                  multiply-add (v_fmac_f64_dpp) and inside the reciprocal square root (v_rsq_f64_dpp), hand-scheduled (dx_panel_pivots).
+//                  Sixteen extra columns start as the identity and come out as the rows of W_k = U_kk^-1 (for the backward sweep only);
+//                  the right-hand side is one more column. X(k + 1, :) goes back to LDS (operand of the update) and to memory (factor).
+//             (U2) next to the panel: tile (I, J) -= X(k, I)' X(k, J) for k + 1 < I: four v_mfma_f64_16x16x4_f64 per tile, A operand
+//                  (negated) shared by the tiles of a row                                                                     --- barrier ---
 //   sweep     U x = y in 16-row blocks from the last one: x_K = W_K pend_K, then every pending row above subtracts U(:, K) x_K — one barrier
 //             per block; the columns of U come back from memory (L2), requested one block ahead.
 //   outputs   step_p / delta_p (zero on the decoupled rows of the leading constant control points), x_b / delta_b, the two sums of the
@@ -33,6 +32,9 @@
 // Bring-up: tests/emul/factor_harness.cpp variant 6 (the kernel source on the CPU against numpy), then tests/test_gpu_edge_cases.py.
 #pragma once
 #include <utility>
+#ifndef HS_DX_EXP
+#define HS_DX_EXP 0
+#endif
 
 #include "kernels_factor.hpp"
 
@@ -51,15 +53,16 @@ typedef double dx_f64x4 __attribute__((vector_size(32)));
 __host__ __device__ constexpr bool dense_mx_fits(int n_free, int nb) { return n_free >= 1 && 6 * n_free + nb + 1 <= 16 * kDxTiles; }
 
 /// Tiles of a wave. Tile COLUMNS are dealt to four column classes b in a zigzag, col(b, jq) = {b, 7 - b, 8 + b, 15 - b}: one column of every
-/// group of four; tile ROWS to three row classes A — rows 3 6 9 13 for the four panel waves (which also hold 32 - 64 registers of panel columns),
-/// rows 0 2 7 10 12 15 and 1 4 5 8 11 14 for the others. A wave (A, b) holds the tiles (I, J) of its rows and columns with J in a LATER OR THE
-/// SAME group of four as I: 10 / 15 / 15 tiles; which of a row's tiles in its own group lie above the diagonal depends on b, and the code
+/// group of four; tile ROWS to three row classes A — rows 7 11 13 15 for the four panel waves (which also hold 64 registers of panel columns and their temporaries:
+/// with the ten tiles of rows 3 6 9 13 next to them the compiler spilled 67 - 87 registers around every panel, scratch stores and reloads ON the chain),
+/// rows 0 2 4 6 9 12 and 1 3 5 8 10 14 for the others (17 tiles are what fits next to the operands: with 18 the addresses went to scratch). A wave (A, b) holds the tiles (I, J) of its rows and columns with J in a LATER OR THE
+/// SAME group of four as I: 7 / 17 / 16 tiles; which of a row's tiles in its own group lie above the diagonal depends on b, and the code
 /// does not ask — a tile below the diagonal is loaded, updated and written out like the others and never read by anybody (17 % of the tiles).
 /// That makes the code of a row class the same for every column class: b only enters addresses. (A variant per (A, b) with exactly the tiles
 /// I <= J meant a four-way dispatch around every phase of every step, and the compiler merged the accumulator arrays of the variants behind each:
 /// 600 - 3 000 spilled registers.) A SIMD holds one wave of each row class, all of one column class: 40 tiles per SIMD.
-constexpr int kDxRow[3][6] = {{3, 6, 9, 13, 99, 99}, {0, 2, 7, 10, 12, 15}, {1, 4, 5, 8, 11, 14}};  // tile rows of a row class
-constexpr int kDxFirst[3][7] = {{0, 4, 7, 9, 10, 10, 10}, {0, 4, 8, 11, 13, 14, 15}, {0, 4, 7, 10, 12, 14, 15}};  // slot of a row's first tile (4 - row / 4 tiles per row)
+constexpr int kDxRow[3][6] = {{7, 11, 13, 15, 99, 99}, {0, 2, 4, 6, 9, 12}, {1, 3, 5, 8, 10, 14}};  // tile rows of a row class
+constexpr int kDxFirst[3][7] = {{0, 3, 5, 6, 7, 7, 7}, {0, 4, 8, 11, 14, 16, 17}, {0, 4, 8, 11, 13, 15, 16}};  // slot of a row's first tile (4 - row / 4 tiles per row)
 template <int A>
 struct DxRows {
   // (tables, not loops: the slot of a tile has to fold to a constant wherever it is used — an index the compiler cannot fold puts the accumulator
@@ -87,13 +90,6 @@ HSD void dx_keep_apart() {
 #endif
 }
 
-HSD double dx_readlane(double v, int lane) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
-}
-HSD double dx_rsqrt(double d) {  // 1 / sqrt(d): hardware estimate + one Newton-Halley step (as in the 6 x 6 panels and k_border_solve_reg)
-  const double dd = d > 0.0 ? d : 1.0, y0 = __builtin_amdgcn_rsq(dd), e = fma(-dd * y0, y0, 1.0);
-  return fma(y0 * e, fma(0.375, e, 0.5), y0);
-}
 
 /// The three phases that touch the accumulators (registers: every index a compile-time constant). lane: the lane's place in a register row of a
 /// tile, (l >> 4) rows down and (l & 15) columns in, in units of the row stride; cb[jq]: first column of the wave's tile column jq.
@@ -143,15 +139,32 @@ struct DxWave {
     constexpr int I = R::row(IQ);
     if (I < lo || I >= hi) return;
     dx_keep_apart<100 + I>();
+#if HS_DX_EXP == 3
+    if (A != 0 && lo == k + 2) return;
+#endif
     double aop[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) aop[s] = -xb[4 * s * kDxLd + lane + 16 * I];
+#if HS_DX_EXP == 4
+    if (A != 0 && lo == k + 2)
+      for (int s = 0; s < 4; ++s) aop[s] = 1e-3 * (lane + s);
+#endif
 #pragma unroll
     for (int jq = 0; jq < 4; ++jq) {
       if (jq < R::jq_min(IQ)) continue;
       double bop[4];
+#if HS_DX_EXP == 4
+      if (A != 0 && lo == k + 2) {
+        for (int s = 0; s < 4; ++s) bop[s] = 1e-3 * (lane + s + jq);
+      } else
+#endif
 #pragma unroll
       for (int s = 0; s < 4; ++s) bop[s] = xb[4 * s * kDxLd + lane + unsigned(cb[jq])];
+#if HS_DX_EXP == 5
+      if (A != 0 && lo == k + 2) {
+        for (int s = 0; s < 4; ++s) asm volatile("" ::"v"(aop[s]), "v"(bop[s]));
+      } else
+#endif
 #pragma unroll
       for (int s = 0; s < 4; ++s) dx_mfma(acc[R::slot(IQ, jq)], aop[s], bop[s]);
     }
@@ -166,29 +179,101 @@ struct DxWave {
   }
 };
 
-/// Lane r of the caller's row of sixteen lanes, for every lane of the row (DPP row_newbcast: the one DPP control the f64 instructions have).
+/// acc += (lane R of the caller's row of sixteen lanes' u) * m in ONE instruction (v_fmac_f64_dpp, DPP row_newbcast: the one DPP control the f64
+/// instructions have): the multiplier of the elimination goes from the diagonal tile's lane straight into the multiply-add — with v_readlane
+/// it was two scalar moves and the FMA, and the panel is instruction issue.
+template <int R>
+HSD void dx_fmac_bcast(double& acc, double u, double m) {
+#if !defined(HS_EMULATED_DEVICE)
+  // (no wait states in the statement: the caller keeps two instructions between the one that wrote u and this one)
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(u), "v"(m), "n"(R));
+#else
+  acc = fma(hs_emul::wave_exchange(u, int((threadIdx.x & 63u) & ~15u) | R), m, acc);
+#endif
+}
+
+/// acc -= (lane R of the row's u) * m: the negation as a source modifier of the same instruction.
+template <int R>
+HSD void dx_fnma_bcast(double& acc, double u, double m) {
+#if !defined(HS_EMULATED_DEVICE)
+  asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(u), "v"(m), "n"(R));
+#else
+  acc = fma(hs_emul::wave_exchange(u, int((threadIdx.x & 63u) & ~15u) | R), -m, acc);
+#endif
+}
+/// Lane R of the caller's row of sixteen lanes, for every lane of the row; two wait states in front (v was written by the multiply-add just before).
+/// (v_rsq_f64 assembles with a DPP control too, which would take the broadcast out of the chain — the hardware returns infinity for it:
+///  tools/microbench/dpp_f64_probe.hip. Of the f64 instructions only v_fmac_f64 and v_mov_b64 carry DPP on gfx950.)
 template <int R>
 HSD double dx_row_bcast(double v) {
 #if !defined(HS_EMULATED_DEVICE)
   double out;
-  // (s_nop 1: a DPP read of a register the two previous vector instructions may have written needs two wait states, and the compiler's hazard
-  //  recogniser does not look inside an asm statement)
   asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(out) : "v"(v), "n"(R));
   return out;
 #else
   return hs_emul::wave_exchange(v, int((threadIdx.x & 63u) & ~15u) | R);
 #endif
 }
-/// acc += (lane R of the row's u) * m in ONE instruction (v_fmac_f64_dpp): the multiplier of the elimination goes from the diagonal tile's lane
-/// straight into the multiply-add — with v_readlane it was two scalar moves and the FMA, and the panel is instruction issue.
-template <int R>
-HSD void dx_fmac_bcast(double& acc, double u, double m) {
+/// Hardware estimate of 1 / sqrt(d) as an ordered statement (one wait state behind: a transcendental result read by a vector instruction).
+HSD double dx_rsq(double d) {
 #if !defined(HS_EMULATED_DEVICE)
-  // (no wait states here: the DPP operand u — entry P of the diagonal column — was written by the scaling of pivot P, at least two vector
-  //  instructions (the two negations) before the first of these)
-  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(u), "v"(m), "n"(R));
+  double y;
+  asm volatile("v_rsq_f64_e32 %0, %1\n\ts_nop 0" : "=v"(y) : "v"(d));
+  return y;
 #else
-  acc = fma(hs_emul::wave_exchange(u, int((threadIdx.x & 63u) & ~15u) | R), m, acc);
+  return __builtin_amdgcn_rsq(d);
+#endif
+}
+/// The value is needed here, whatever the code behind does with it.
+HSD void dx_pin(double& v) {
+#if !defined(HS_EMULATED_DEVICE)
+  asm volatile("" : "+v"(v));
+#endif
+}
+/// Plain f64 instructions as ordered statements: the panel below is scheduled BY HAND (the order of the volatile statements is the order of
+/// issue), the compiler only allocates registers.
+HSD double dx_mul(double a, double b) {
+#if !defined(HS_EMULATED_DEVICE)
+  double o;
+  asm volatile("v_mul_f64 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b));
+  return o;
+#else
+  return a * b;
+#endif
+}
+HSD double dx_fma(double a, double b, double c) {
+#if !defined(HS_EMULATED_DEVICE)
+  double o;
+  asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
+  return o;
+#else
+  return fma(a, b, c);
+#endif
+}
+HSD double dx_one_minus(double a, double b) {  // 1 - a b
+#if !defined(HS_EMULATED_DEVICE)
+  double o;
+  asm volatile("v_fma_f64 %0, -%1, %2, 1.0" : "=v"(o) : "v"(a), "v"(b));
+  return o;
+#else
+  return fma(-a, b, 1.0);
+#endif
+}
+HSD double dx_half_plus(double a, double b) {  // 0.5 + a b
+#if !defined(HS_EMULATED_DEVICE)
+  double o;
+  asm volatile("v_fma_f64 %0, %1, %2, 0.5" : "=v"(o) : "v"(a), "v"(b));
+  return o;
+#else
+  return fma(a, b, 0.5);
+#endif
+}
+/// Pivot row P is final: scale it (two wait states behind the first product: the multiply-adds that follow read it through DPP).
+HSD void dx_scale2(double& a, double& b, double r) {
+#if !defined(HS_EMULATED_DEVICE)
+  asm volatile("v_mul_f64 %0, %0, %2\n\tv_mul_f64 %1, %1, %2\n\ts_nop 0" : "+v"(a), "+v"(b) : "v"(r));
+#else
+  a *= r, b *= r;
 #endif
 }
 
@@ -196,50 +281,79 @@ HSD void dx_fmac_bcast(double& acc, double u, double m) {
 /// broadcasts) AND one column of its own — a trailing column of the tile row (the right-hand side is one of them: column n_dense of the
 /// padded system) or a column of the identity (-> a row of W_k = U_kk^-1). Right-looking Cholesky of the diagonal block fused with the forward
 /// substitution of every column; plain substitution, no explicit inverse on the forward path. X(k, :) goes back to LDS (operand of the update)
-/// and to memory (the factor by columns, for the sweep). Returns true when a pivot was not positive.
-template <int P, int R>
-HSD void dx_panel_rows(double (&ad)[16], double (&at)[16], double nd, double nt);
+/// and to memory (the factor by columns, for the sweep).
+///
+/// The chain is the sixteen pivots: entry P + 1 of the diagonal must have its update of pivot P before 1 / sqrt of it can start, and that
+/// estimate + Newton-Halley step is six dependent instructions (row broadcast, rsq, y^2, e = 1 - d y^2,
+/// y e and 0.5 + 0.375 e, y + y e (...)). In program order — all 2 (15 - P) multiply-adds of pivot P, then the chain of P + 1 — a pivot
+/// was ~300 cycles, more than half of them the wave waiting for its own previous instruction. Here pivot P issues the ONE multiply-add pivot
+/// P + 1 waits for first, then deals the remaining ones into the gaps of that chain (dx_fm: multiply-add n of pivot P; five gaps).
+template <int P, int N>
+HSD void dx_fm(double (&ad)[16], double (&at)[16]) {  // n = 0: ad[P + 1], 1: at[P + 1], 2: ad[P + 2], ...
+  if constexpr (N < 2 * (15 - P)) {
+    constexpr int R = P + 1 + N / 2;
+    if constexpr (N % 2 == 0)
+      dx_fnma_bcast<R>(ad[R], ad[P], ad[P]);  // u_pr = entry P of the diagonal tile's column R, from the lane of the row that holds it
+    else
+      dx_fnma_bcast<R>(at[R], ad[P], at[P]);
+  }
+}
+template <int P, int LO, int HI>
+HSD void dx_fm_range(double (&ad)[16], double (&at)[16]) {
+  if constexpr (LO < HI) {
+    dx_fm<P, LO>(ad, at);
+    dx_fm_range<P, LO + 1, HI>(ad, at);
+  }
+}
 template <int P>
-HSD void dx_panel_pivots(double (&ad)[16], double (&at)[16], bool& fail) {
-  if constexpr (P < 16) {
-    const double d = dx_row_bcast<P>(ad[P]);
-    fail |= !(d > 0.0);
-    const double rinv = dx_rsqrt(d);
-    ad[P] *= rinv, at[P] *= rinv;
-    const double nd = -ad[P], nt = -at[P];
-    dx_panel_rows<P, P + 1>(ad, at, nd, nt);
-    dx_panel_pivots<P + 1>(ad, at, fail);
+HSD void dx_panel_pivots(double (&ad)[16], double (&at)[16], double rinv, double k375, bool& fail) {
+  fail |= !(rinv < 1e150);  // (a pivot that is not positive: estimate NaN or infinite — the caller zeroes the step of a failed factorisation)
+  dx_scale2(ad[P], at[P], rinv);
+  if constexpr (P < 15) {
+    constexpr int n = 2 * (15 - P) - 1, g = (n + 4) / 5;  // the multiply-adds behind the first, per gap
+    dx_fm<P, 0>(ad, at);
+    const double d = dx_row_bcast<P + 1>(ad[P + 1]);
+    dx_fm<P, 1>(ad, at);
+    const double y0 = dx_rsq(d);
+    dx_fm_range<P, 2, 1 + g>(ad, at);
+    const double y2 = dx_mul(y0, y0);
+    dx_fm_range<P, 1 + g, 1 + 2 * g>(ad, at);
+    const double e = dx_one_minus(d, y2);
+    dx_fm_range<P, 1 + 2 * g, 1 + 3 * g>(ad, at);
+    const double ye = dx_mul(y0, e), c = dx_half_plus(e, k375);
+    dx_fm_range<P, 1 + 3 * g, 1 + 4 * g>(ad, at);
+    const double rn = dx_fma(ye, c, y0);
+    dx_fm_range<P, 1 + 4 * g, 1 + 5 * g>(ad, at);
+    dx_panel_pivots<P + 1>(ad, at, rn, k375, fail);
   }
 }
-template <int P, int R>
-HSD void dx_panel_rows(double (&ad)[16], double (&at)[16], double nd, double nt) {
-  if constexpr (R < 16) {
-    dx_fmac_bcast<R>(ad[R], ad[P], nd);  // u_pr = entry P of the diagonal tile's column R, from the lane of the row that holds it
-    dx_fmac_bcast<R>(at[R], ad[P], nt);
-    dx_panel_rows<P, R + 1>(ad, at, nd, nt);
-  }
-}
-HSD bool dx_panel(int k, int n_tr, int w, int l, double* xb, double* wk, double* ut) {
+HSD bool dx_panel(int k, int n_tr, int w, int l, double* xb, double* wk, double* ut, bool prof = false, long long* tlog = nullptr) {
   const int idx = 64 * w + l;
   const bool trailing = idx < n_tr;
   const int unit = (idx >= n_tr && idx < n_tr + 16) ? idx - n_tr : -1;
   const int col = 16 * (k + 1) + (trailing ? idx : 0);
   double ad[16], at[16];
+  // (the panel is the chain of the step and shares its SIMD with two waves that feed the matrix core: it goes first whenever it can issue)
+  __builtin_amdgcn_s_setprio(3);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     ad[r] = xb[r * kDxLd + 16 * k + (l & 15)];
-    const double v = xb[r * kDxLd + col];  // (idle and identity lanes read a column of the buffer they do not use)
-    at[r] = trailing ? v : (r == unit ? 1.0 : 0.0);
+    at[r] = xb[r * kDxLd + col];  // (idle and identity lanes read a column of the buffer they do not use ...
+    dx_pin(at[r]);                //  ... unconditionally: left to itself the compiler wraps each of the sixteen loads into a branch on `trailing`)
   }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) at[r] = trailing ? at[r] : (r == unit ? 1.0 : 0.0);
+  if (prof) tlog[8 * k + 4] = wall_clock64();
   bool fail = false;
-  dx_panel_pivots<0>(ad, at, fail);
+  {
+    const double d = dx_row_bcast<0>(ad[0]), y0 = dx_rsq(d), y2 = dx_mul(y0, y0), k375 = 0.375, e = dx_one_minus(d, y2);
+    dx_panel_pivots<0>(ad, at, dx_fma(dx_mul(y0, e), dx_half_plus(e, k375), y0), k375, fail);
+  }
+  if (prof) tlog[8 * k + 5] = wall_clock64();
   if (trailing) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) xb[r * kDxLd + col] = at[r];
-    double* dst = ut + size_t(col) * kDenseLd + 16 * k;  // column col of U, rows of block k: 16 contiguous doubles
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) *reinterpret_cast<double2*>(dst + r) = make_double2(at[r], at[r + 1]);
-  }
+  }  // (the factor's copy in memory is written from LDS by the waves that do not have a panel: dx_store_factor_row)
   if (unit >= 0) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) wk[(16 * k + unit) * 16 + r] = at[r];
@@ -249,7 +363,23 @@ HSD bool dx_panel(int k, int n_tr, int w, int l, double* xb, double* wk, double*
 #pragma unroll
     for (int r = 0; r < 16; r += 2) *reinterpret_cast<double2*>(dst + r) = make_double2(ad[r], ad[r + 1]);
   }
+  __builtin_amdgcn_s_setprio(0);
   return fail;
+}
+
+/// X(k, :) from its LDS buffer to memory (the factor by columns, for the sweep), by the eight waves without a panel while the panel of the next
+/// step runs: thread (column, half) moves eight rows — 64 contiguous bytes, a column's two halves in neighbouring lanes. (From the panel's
+/// lanes — sixteen rows of one column each, 2 KB apart — the stores were 0.1 - 0.7 us at the end of every panel, on the chain.)
+HSD void dx_store_factor_row(int k, int n_pad, int w, int l, const double* xb, double* ut) {
+  const int t = 64 * (w - 4) + l, c = t >> 1, h = 8 * (t & 1);
+  if (c >= n_pad - 16 * (k + 1)) return;
+  const int col = 16 * (k + 1) + c;
+  double v[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] = xb[(h + r) * kDxLd + col];
+  double* dst = ut + size_t(col) * kDenseLd + 16 * k + h;
+#pragma unroll
+  for (int r = 0; r < 8; r += 2) *reinterpret_cast<double2*>(dst + r) = make_double2(v[r], v[r + 1]);
 }
 
 /// Factorisation loop of a wave of row class A (0: the panel waves w < 4, 1, 2: the others; the accumulator arrays differ in length, and the panel's
@@ -268,12 +398,12 @@ HSD bool dx_factor(const double* D, int nt, int n_pad, int b, int w, int l, doub
   // panel is ~3 us of one wave per SIMD, the update up to 3.5 us of matrix core in the first steps. Per step and wave:
   //   U1  tile row k + 1 -= X(k, k + 1)' X(k, :), written to the OTHER panel buffer                                       --- barrier ---
   //   P   panel waves: panel of step k + 1 (in place in that buffer)     U2  tile rows > k + 1 -= X(k, .)' X(k, :)  (panel waves: after the panel;
-  //       their rows are rows 3 6 9 13: wanted three steps later at the earliest)                                           --- barrier ---
+  //       their rows are rows 7 11 13 15: few tiles)                                           --- barrier ---
   // X(k, :) is read from its buffer through U2; the buffer is overwritten in U1 of the next step, behind the barrier.
   W::extract(0, lane, cb, smem, acc);
   lds_barrier();
   if (prof) tlog[0] = wall_clock64();
-  if (A == 0 && 64 * w < n_pad - 16 + 16) fail |= dx_panel(0, n_pad - 16, w, l, smem, wk, ut);
+  if (A == 0 && 64 * w < n_pad - 16 + 16) fail |= dx_panel(0, n_pad - 16, w, l, smem, wk, ut, prof, tlog);
   if (prof) tlog[1] = wall_clock64();
   lds_barrier();
   for (int k = 0; k < nt; ++k) {
@@ -287,8 +417,9 @@ HSD bool dx_factor(const double* D, int nt, int n_pad, int b, int w, int l, doub
     lds_barrier();
     if (prof) tlog[8 * (k + 1) + 0] = wall_clock64();
     const int n_tr = n_pad - 16 * (k + 2);  // trailing columns of tile row k + 1 (+ 16 columns of the identity: W_(k+1))
-    if (A == 0 && k + 1 < nt && 64 * w < n_tr + 16) fail |= dx_panel(k + 1, n_tr, w, l, xn, wk, ut);
+    if (A == 0 && k + 1 < nt && 64 * w < n_tr + 16) fail |= dx_panel(k + 1, n_tr, w, l, xn, wk, ut, prof, tlog);
     if (prof) tlog[8 * (k + 1) + 1] = wall_clock64();
+    if (A != 0) dx_store_factor_row(k, n_pad, w, l, xb, ut);
     W::update(k, k + 2, nt, lane, cb, xb, acc);
     if (prof) tlog[8 * k + 3] = wall_clock64();
     lds_barrier();
@@ -299,7 +430,11 @@ HSD bool dx_factor(const double* D, int nt, int n_pad, int b, int w, int l, doub
 /// Sweep: column block K of U for row rho (scalar base + lane offset per column; zero for the rows at or below the block).
 HSD void dx_sweep_fetch(const double* ut, int rho, int K, double (&u)[16]) {
 #pragma unroll
+#if HS_DX_EXP == 1
+  for (int c = 0; c < 16; ++c) u[c] = 1e-9 * (K + c);
+#else
   for (int c = 0; c < 16; ++c) u[c] = (K >= 0 && rho < 16 * K) ? (ut + (16 * K + c) * kDenseLd)[unsigned(rho)] : 0.0;
+#endif
 }
 /// Sweep, block K: x_K = W_K pend_K in lanes 0 .. 15 of every wave (W_K upper triangular: the entries left of the diagonal came out as exact
 /// zeros), then every pending row above subtracts U(:, K) x_K. One barrier. (Functions with the register sets as parameters: as lambdas that
@@ -352,12 +487,14 @@ __global__ void __launch_bounds__(kDxThreads) k_dense_solve_mx(Tables T, int f0,
   if (prof) tlog[-1] = wall_clock64();
   // wave (a, b) = (w / 4, w mod 4): SIMD w mod 4 holds one wave of each row class, all of column class b
   bool fail = false;
+  if (tid == 0) smem[kDxOffRed + 16] = 0.0;  // (ordered before the panel waves' verdicts by the barriers of the factorisation)
   if (w < 4)
     fail = dx_factor<0>(T.dense, nt, n_pad, w, w, l, smem, ut, prof, tlog);
   else if (w < 8)
     dx_factor<1>(T.dense, nt, n_pad, w - 4, w, l, smem, ut, false, tlog);
   else
     dx_factor<2>(T.dense, nt, n_pad, w - 8, w, l, smem, ut, false, tlog);
+  if (fail) smem[kDxOffRed + 16] = 1.0;  // (a panel wave may have skipped the panel that failed: the verdict goes through LDS)
   if (prof) tlog[8 * 20 + 0] = wall_clock64();
   // ---- backward sweep U x = y, lane = row: the first four waves (one per SIMD) hold the 256 rows; the others have nothing left to do and
   //      leave — a wave that has ended does not count at a barrier, and while they stayed (16 predicated loads and a barrier per block, on the
@@ -386,10 +523,13 @@ __global__ void __launch_bounds__(kDxThreads) k_dense_solve_mx(Tables T, int f0,
   lds_barrier();
   if (prof) tlog[8 * 20 + 1] = wall_clock64();
   // ---- outputs: step = -x, delta = scale o step, the two sums of the model cost change (k_band_backward's epilogue) ----
+  // A pivot that was not positive: 1 / sqrt of it is NaN or infinite and so is everything behind it — the step of a failed factorisation is zero
+  // (decide_step rejects it on chol_failed, the radius shrinks: Ceres' LINEAR_SOLVER_FAILURE branch).
+  fail = smem[kDxOffRed + 16] != 0.0;
   double gd = 0.0, dd = 0.0;
   for (int r = tid; r < 6 * f0; r += 256) T.step_p[r] = 0.0, T.delta_p[r] = 0.0;
   if (rho < n_dense) {
-    const double step = -xv[rho];
+    const double step = fail ? 0.0 : -xv[rho];
     if (rho < n_pose) {
       const int r = 6 * f0 + rho;
       T.step_p[r] = step, T.delta_p[r] = T.scale_p[r] * step;

@@ -132,6 +132,7 @@ inline T __shfl_up(T v, unsigned delta) {
 }
 inline int __builtin_amdgcn_readlane(int v, int lane) { return hs_emul::wave_exchange(v, lane); }
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // (the kernels use it on wave-uniform values only: the wave index as a scalar)
+inline void __builtin_amdgcn_s_setprio(int) {}  // (issue priority of a wave: nothing to emulate)
 /// DPP move as the kernels use it (row_mask = bank_mask = 0xF, bound_ctrl off: a lane whose source is outside its row of 16 keeps `old`):
 /// quad_perm (ctrl < 0x100, two bits per lane of the quad), row_shl:n (0x100 + n: lane i reads lane i + n), row_shr:n (0x110 + n: lane i - n),
 /// row_ror:n (0x120 + n: lane i reads lane (i - n) mod 16 of its row).

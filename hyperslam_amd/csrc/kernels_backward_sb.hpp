@@ -344,7 +344,7 @@ HSD void sb_sweep(const Tables& T, const BackJob& j0, const BackJob& j1, const i
       if (!published && s == s_pub) {
         if (cprof) clog[4] = wall_clock64();  // middle rows solved
         for (int rho = 6 * m_mid + tid; rho < n_own; rho += nthr) T.xsol[rho] = xout[rho];
-        __threadfence();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (every wave: its stores have reached the L2; the ONE agent-scope release — an L2 write-back on this part — is lane 0's below)
         lds_barrier();
         if (tid == 0) {
           __threadfence();

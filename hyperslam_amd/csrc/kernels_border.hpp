@@ -579,7 +579,7 @@ __global__ void __launch_bounds__(kBlock) k_border_forward2(Tables T, BfJob j0, 
   }
   if (far) {
     for (int e = tid; e < 6 * w_mid * kBorderCols; e += blockDim.x) ho[e] = z[(6 * n_rows + e / kBorderCols) * kBorderLd + e % kBorderCols];
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (every wave: its stores have reached the L2; the ONE agent-scope release — an L2 write-back on this part — is lane 0's below)
     __syncthreads();
     if (tid == 0) {
       __threadfence();

@@ -32,9 +32,6 @@
 // Bring-up: tests/emul/factor_harness.cpp variant 6 (the kernel source on the CPU against numpy), then tests/test_gpu_edge_cases.py.
 #pragma once
 #include <utility>
-#ifndef HS_DX_EXP
-#define HS_DX_EXP 0
-#endif
 
 #include "kernels_factor.hpp"
 
@@ -56,8 +53,8 @@ __host__ __device__ constexpr bool dense_mx_fits(int n_free, int nb) { return n_
 /// group of four; tile ROWS to three row classes A — rows 7 11 13 15 for the four panel waves (which also hold 64 registers of panel columns and their temporaries:
 /// with the ten tiles of rows 3 6 9 13 next to them the compiler spilled 67 - 87 registers around every panel, scratch stores and reloads ON the chain),
 /// rows 0 2 4 6 9 12 and 1 3 5 8 10 14 for the others (17 tiles are what fits next to the operands: with 18 the addresses went to scratch). A wave (A, b) holds the tiles (I, J) of its rows and columns with J in a LATER OR THE
-/// SAME group of four as I: 7 / 17 / 16 tiles; which of a row's tiles in its own group lie above the diagonal depends on b, and the code
-/// does not ask — a tile below the diagonal is loaded, updated and written out like the others and never read by anybody (17 % of the tiles).
+/// SAME group of four as I: 7 / 17 / 16 tiles; which of a row's tiles in its own group lie above the diagonal depends on b: a tile below the
+/// diagonal is loaded and written out like the others and never read by anybody (17 % of the tiles; the update skips them on a scalar test).
 /// That makes the code of a row class the same for every column class: b only enters addresses. (A variant per (A, b) with exactly the tiles
 /// I <= J meant a four-way dispatch around every phase of every step, and the compiler merged the accumulator arrays of the variants behind each:
 /// 600 - 3 000 spilled registers.) A SIMD holds one wave of each row class, all of one column class: 40 tiles per SIMD.
@@ -135,47 +132,33 @@ struct DxWave {
   }
   /// (3) trailing update: tile (I, J) -= X(k, I)' X(k, J) for the rows lo <= I < hi. The A operand (negated) is shared by the tiles of a row.
   template <int IQ>
-  static HSD void update_row(int k, int lo, int hi, unsigned lane, const int (&cb)[4], const double* xb, Acc& acc) {
+  static HSD void update_row(int k, int lo, int hi, int nt_cols, unsigned lane, const int (&cb)[4], const double* xb, Acc& acc) {
     constexpr int I = R::row(IQ);
     if (I < lo || I >= hi) return;
     dx_keep_apart<100 + I>();
-#if HS_DX_EXP == 3
-    if (A != 0 && lo == k + 2) return;
-#endif
     double aop[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) aop[s] = -xb[4 * s * kDxLd + lane + 16 * I];
-#if HS_DX_EXP == 4
-    if (A != 0 && lo == k + 2)
-      for (int s = 0; s < 4; ++s) aop[s] = 1e-3 * (lane + s);
-#endif
 #pragma unroll
     for (int jq = 0; jq < 4; ++jq) {
       if (jq < R::jq_min(IQ)) continue;
+      // (a scalar test per tile: below the diagonal — nobody reads the tile — or in the identity padding behind tile column nt_cols, where
+      //  X(k, J) is exactly zero; together 17 - 40 % of the matrix-core work of the first steps)
+      if (cb[jq] < 16 * I || cb[jq] >= 16 * nt_cols) continue;
       double bop[4];
-#if HS_DX_EXP == 4
-      if (A != 0 && lo == k + 2) {
-        for (int s = 0; s < 4; ++s) bop[s] = 1e-3 * (lane + s + jq);
-      } else
-#endif
 #pragma unroll
       for (int s = 0; s < 4; ++s) bop[s] = xb[4 * s * kDxLd + lane + unsigned(cb[jq])];
-#if HS_DX_EXP == 5
-      if (A != 0 && lo == k + 2) {
-        for (int s = 0; s < 4; ++s) asm volatile("" ::"v"(aop[s]), "v"(bop[s]));
-      } else
-#endif
 #pragma unroll
       for (int s = 0; s < 4; ++s) dx_mfma(acc[R::slot(IQ, jq)], aop[s], bop[s]);
     }
   }
   template <int... IQ>
-  static HSD void update_rows(std::integer_sequence<int, IQ...>, int k, int lo, int hi, unsigned lane, const int (&cb)[4], const double* xb, Acc& acc) {
-    (update_row<IQ>(k, lo, hi, lane, cb, xb, acc), ...);
+  static HSD void update_rows(std::integer_sequence<int, IQ...>, int k, int lo, int hi, int nt_cols, unsigned lane, const int (&cb)[4], const double* xb, Acc& acc) {
+    (update_row<IQ>(k, lo, hi, nt_cols, lane, cb, xb, acc), ...);
   }
   /// the tile rows lo <= I < hi with X(k, :)
-  static HSD void update(int k, int lo, int hi, unsigned lane, const int (&cb)[4], const double* xb, Acc& acc) {
-    update_rows(std::make_integer_sequence<int, R::n_rows>{}, k, lo, hi, lane, cb, xb, acc);
+  static HSD void update(int k, int lo, int hi, int nt_cols, unsigned lane, const int (&cb)[4], const double* xb, Acc& acc) {
+    update_rows(std::make_integer_sequence<int, R::n_rows>{}, k, lo, hi, nt_cols, lane, cb, xb, acc);
   }
 };
 
@@ -356,7 +339,7 @@ HSD bool dx_panel(int k, int n_tr, int w, int l, double* xb, double* wk, double*
   }  // (the factor's copy in memory is written from LDS by the waves that do not have a panel: dx_store_factor_row)
   if (unit >= 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) wk[(16 * k + unit) * 16 + r] = at[r];
+    for (int r = 0; r < 16; ++r) wk[(16 * k + r) * 16 + unit] = at[r];  // (W_k by columns: the sweep's lanes read entry (i, c) at 16 c + i, no two lanes of a row of sixteen in one bank)
   }
   if (w == 0 && l < 16) {  // the diagonal tile's columns too (entries above the diagonal): the right-hand side column may be one of them
     double* dst = ut + size_t(16 * k + l) * kDenseLd + 16 * k;
@@ -411,7 +394,7 @@ HSD bool dx_factor(const double* D, int nt, int n_pad, int b, int w, int l, doub
     double* xn = smem + ((k + 1) & 1) * 16 * kDxLd;      // tile row k + 1 -> X(k + 1, :)
     if (prof) tlog[8 * k + 2] = wall_clock64();
     if (k + 1 < nt) {
-      W::update(k, k + 1, k + 2, lane, cb, xb, acc);
+      W::update(k, k + 1, k + 2, nt, lane, cb, xb, acc);
       W::extract(k + 1, lane, cb, xn, acc);
     }
     lds_barrier();
@@ -420,7 +403,7 @@ HSD bool dx_factor(const double* D, int nt, int n_pad, int b, int w, int l, doub
     if (A == 0 && k + 1 < nt && 64 * w < n_tr + 16) fail |= dx_panel(k + 1, n_tr, w, l, xn, wk, ut, prof, tlog);
     if (prof) tlog[8 * (k + 1) + 1] = wall_clock64();
     if (A != 0) dx_store_factor_row(k, n_pad, w, l, xb, ut);
-    W::update(k, k + 2, nt, lane, cb, xb, acc);
+    W::update(k, k + 2, nt, nt, lane, cb, xb, acc);
     if (prof) tlog[8 * k + 3] = wall_clock64();
     lds_barrier();
   }
@@ -430,11 +413,7 @@ HSD bool dx_factor(const double* D, int nt, int n_pad, int b, int w, int l, doub
 /// Sweep: column block K of U for row rho (scalar base + lane offset per column; zero for the rows at or below the block).
 HSD void dx_sweep_fetch(const double* ut, int rho, int K, double (&u)[16]) {
 #pragma unroll
-#if HS_DX_EXP == 1
-  for (int c = 0; c < 16; ++c) u[c] = 1e-9 * (K + c);
-#else
   for (int c = 0; c < 16; ++c) u[c] = (K >= 0 && rho < 16 * K) ? (ut + (16 * K + c) * kDenseLd)[unsigned(rho)] : 0.0;
-#endif
 }
 /// Sweep, block K: x_K = W_K pend_K in lanes 0 .. 15 of every wave (W_K upper triangular: the entries left of the diagonal came out as exact
 /// zeros), then every pending row above subtracts U(:, K) x_K. One barrier. (Functions with the register sets as parameters: as lambdas that
@@ -448,18 +427,22 @@ HSD void dx_sweep_apply(double& s0, double& s1, double xr, const double (&u)[16]
   }
 }
 HSD void dx_sweep_block(int K, int rho, int w, int l, const double* ut, const double* wk, double* pk, double* xv, double& pend, const double (&u)[16],
-                        double (&u_next)[16]) {
+                        double (&u_next)[16], long long* slog = nullptr) {
   if (K < 0) return;
+  if (slog) slog[0] = wall_clock64();
   if (rho >= 16 * K && rho < 16 * K + 16) pk[(K & 1) * 16 + (rho - 16 * K)] = pend;
-  dx_sweep_fetch(ut, rho, K - 2, u_next);
+  dx_sweep_fetch(ut, rho, K - 3, u_next);
   lds_barrier();
-  const double* wr = wk + (16 * K + (l & 15)) * 16;
+  if (slog) slog[1] = wall_clock64();
+  const double* wr = wk + 16 * 16 * K + (l & 15);
   const double* pr = pk + (K & 1) * 16;
   double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
 #pragma unroll
-  for (int c = 0; c < 16; c += 4) x0 = fma(wr[c], pr[c], x0), x1 = fma(wr[c + 1], pr[c + 1], x1), x2 = fma(wr[c + 2], pr[c + 2], x2), x3 = fma(wr[c + 3], pr[c + 3], x3);
+  for (int c = 0; c < 16; c += 4)
+    x0 = fma(wr[16 * c], pr[c], x0), x1 = fma(wr[16 * c + 16], pr[c + 1], x1), x2 = fma(wr[16 * c + 32], pr[c + 2], x2), x3 = fma(wr[16 * c + 48], pr[c + 3], x3);
   double xr = (x0 + x1) + (x2 + x3);
   if (w == 0 && l < 16) xv[16 * K + l] = xr;
+  if (slog) slog[2] = wall_clock64();
   double s0 = 0.0, s1 = 0.0;
 #if !defined(HS_EMULATED_DEVICE)
   // (xr was written by the vector instruction before; the DPP reads below carry no wait states of their own. xr as an operand: the statement
@@ -468,6 +451,7 @@ HSD void dx_sweep_block(int K, int rho, int w, int l, const double* ut, const do
 #endif
   dx_sweep_apply<0>(s0, s1, xr, u);
   pend -= s0 + s1;
+  if (slog) slog[3] = wall_clock64();
 }
 
 /// One workgroup. f0: leading block rows of constant control points (decoupled, solution zero: the chain starts behind them).
@@ -500,25 +484,30 @@ __global__ void __launch_bounds__(kDxThreads) k_dense_solve_mx(Tables T, int f0,
   //      leave — a wave that has ended does not count at a barrier, and while they stayed (16 predicated loads and a barrier per block, on the
   //      SIMDs of the row waves) a step of the sweep took longer ----
   wait_vmem();  // this wave's factor rows have left
-  __threadfence();
+  // (WORKGROUP scope: writer and readers of the factor are waves of this workgroup, one CU, one L1. An agent-scope fence — __threadfence() — writes the
+  //  XCD's L2 back: ~2 us here, from twelve waves)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   lds_barrier();
   // Iteration bookkeeping of a directly assembled system (Tables::bookkeep, factor_bookkeep: no k_finalize_reduced launch in front of this kernel):
   // a wave that would leave here — nobody waits for its verdict (a termination test that fires makes every later kernel exit on `done`).
   if (T.bookkeep && w == 11) factor_bookkeep(T, l);
   if (w >= 4) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   double* pk = smem + kDxOffP;
   const int rho = tid;  // row of the padded system (tid < 256)
   // y = U^-T g is column n_dense of the factor: the right-hand side rode along as a column of the padded matrix (the dense copy carries g there
   // and a huge diagonal entry behind it; its own unknown gets a zero right-hand side, i.e. stays zero)
   double pend = rho < n_dense ? (ut + n_dense * kDenseLd)[unsigned(rho)] : 0.0;
-  // Column block K of U for this row comes back from memory (L2; written by the panel): requested two blocks ahead — with one block ahead
-  // a step of the sweep was 2.3 us of load latency (three ahead: four register sets of sixteen, spills). Register sets renamed by unrolling.
-  double ua[16], ub[16], uc[16];
-  dx_sweep_fetch(ut, rho, nt - 1, ua), dx_sweep_fetch(ut, rho, nt - 2, ub);
-  for (int K = nt - 1; K >= 0; K -= 3) {
-    dx_sweep_block(K, rho, w, l, ut, wk, pk, xv, pend, ua, uc);
-    dx_sweep_block(K - 1, rho, w, l, ut, wk, pk, xv, pend, ub, ua);
-    dx_sweep_block(K - 2, rho, w, l, ut, wk, pk, xv, pend, uc, ub);
+  // Column block K of U for this row comes back from memory (L2; written by the panel): requested three blocks ahead — with one block ahead
+  // a step of the sweep was 2.3 us of load latency. Four register sets of sixteen, renamed by unrolling (the accumulators are dead here).
+  double ua[16], ub[16], uc[16], ud[16];
+  dx_sweep_fetch(ut, rho, nt - 1, ua), dx_sweep_fetch(ut, rho, nt - 2, ub), dx_sweep_fetch(ut, rho, nt - 3, uc);
+  for (int K = nt - 1; K >= 0; K -= 4) {
+    long long* slog = (prof && nt - 1 - K < 8) ? tlog + 8 * (21 + nt - 1 - K) : nullptr;  // (profiling builds: the first eight blocks, rows 21 .. 28)
+    dx_sweep_block(K, rho, w, l, ut, wk, pk, xv, pend, ua, ud, slog);
+    dx_sweep_block(K - 1, rho, w, l, ut, wk, pk, xv, pend, ub, ua, slog ? slog + 8 : nullptr);
+    dx_sweep_block(K - 2, rho, w, l, ut, wk, pk, xv, pend, uc, ub, slog ? slog + 16 : nullptr);
+    dx_sweep_block(K - 3, rho, w, l, ut, wk, pk, xv, pend, ud, uc, slog ? slog + 24 : nullptr);
   }
   lds_barrier();
   if (prof) tlog[8 * 20 + 1] = wall_clock64();

@@ -718,7 +718,7 @@ __global__ void __launch_bounds__(la_threads(NCW)) k_band_factor_la(Tables T) {
           }
         }
       }
-      __threadfence();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (every wave: its stores have reached the L2; the ONE agent-scope release — an L2 write-back on this part — is lane 0's below)
       lds_barrier();
       if (l == 0) {
         __threadfence();

@@ -790,7 +790,7 @@ __global__ void __launch_bounds__(kMxThreads) k_band_factor_mx(Tables T) {
   __syncthreads();
   if (tid == 0 && fail) st->chol_failed = 1;  // (consumed by the decision, decide_step)
   if (J.dump) {
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (every wave: its stores have reached the L2; the ONE agent-scope release — an L2 write-back on this part — is lane 0's below)
     __syncthreads();
     if (tid == 0) {
       __threadfence();

@@ -32,3 +32,9 @@ for k in range(16):
         break
     print(f"{k:3d}: {q[0] - r[2]:8d} {q[1] - q[0]:10d} ({q[4] - q[0]:4d} {q[5] - q[4]:4d} {q[1] - q[5]:4d}) {r[3] - q[1]:8d} {(q[2] if q[3] > 0 else t[20][0]) - r[3]:8d} | {(q[2] if q[3] > 0 else t[20][0]) - r[2]:6d}")
 print("factorisation done %d, sweep done %d (+%d), outputs done %d (+%d)" % (t[20][0], t[20][1], t[20][1] - t[20][0], t[20][2], t[20][2] - t[20][1]))
+print("sweep blocks from the last: (fetch + pend -> LDS + barrier, W pend, apply U(:, K) x_K) | block")
+for i in range(8):
+    r = t[21 + i]
+    if r[3] <= 0 or r[0] <= 0:
+        break
+    print(f"{i:3d}: {r[1] - r[0]:6d} {r[2] - r[1]:6d} {r[3] - r[2]:6d} | {r[3] - r[0]:6d}")

@@ -175,6 +175,8 @@ int launch_build(hs_problem* p, hipEvent_t after_build = nullptr, bool scaling_f
   // (Round 6 tried the segment Gram kernel of a fused stereo-inertial window on the side stream, behind k_linearize_inertial and next to
   //  k_build_visual: 8 us off the main stream's chain, and the event k_assemble then waits for cost more — 1.080 against 1.038 ms per optimize().)
   if (side_imu && T.nb) {  // behind k_linearize_inertial on the side stream, next to k_landmark / the Gram kernels
+    // (Round 6 also ran both gathers as ONE launch — zero-fill moved into k_linearize_inertial, the H_bb workgroups first: 82 us at configs[2]
+    //  where the two launches take 32 + 45: the gathers do not overlap, they share whatever bounds them. Not kept.)
     k_border_pb<K><<<dim3(T.sp.n_cp + border_zero_wgs(T), p->n_split), kPbThreads, 0, sb>>>(T);  // (+ zero-fill of the border-border block)
     k_border_bb<K><<<T.n_bias, kBlock, 0, sb>>>(T);
     HIP_TRY(hipEventRecord(p->ev_join, p->side));

@@ -8,12 +8,15 @@ import csv, glob
 f = glob.glob("/tmp/hs_tl/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-# last complete iteration: from the last k_linearize_visual to the following k_commit
-idx = [i for i, n in enumerate(names) if "k_linearize_visual" in n]
-i0 = idx[-2]
+# last complete iteration but one: from a k_build_visual (k_linearize_visual on the record path) to the next
+idx = [i for i, n in enumerate(names) if "k_build_visual" in n] or [i for i, n in enumerate(names) if "k_linearize_visual" in n]
+# (side-stream kernels of the iteration may start before the build: include what runs up to 40 us before it)
+i0 = idx[-3]
 t0 = int(rows[i0]["Start_Timestamp"])
-prev_end = t0
-for r in rows[i0:idx[-1]]:
+while i0 > 0 and int(rows[i0 - 1]["Start_Timestamp"]) > t0 - 40000 and "k_commit" not in names[i0 - 1] and "k_pack_decision" not in names[i0 - 1]:
+    i0 -= 1
+prev_end = int(rows[i0]["Start_Timestamp"])
+for r in rows[i0:idx[-2]]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     print(f'{(s - t0) / 1e3:8.1f} -> {(e - t0) / 1e3:8.1f} us  dur {(e - s) / 1e3:7.1f}  gap {(s - prev_end) / 1e3:6.1f}  q{r.get("Queue_Id", "?")}  {r["Kernel_Name"][:60]}')
     prev_end = max(prev_end, e)

@@ -172,13 +172,20 @@ int launch_build(hs_problem* p, hipEvent_t after_build = nullptr, bool scaling_f
     HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0));
   }
   hipStream_t sb = side_imu ? p->side : s;  // stream of the border gathers
+  // Single shard: the border workgroups of k_finalize_reduced pick the gathers' results up through a device flag (Tables::gather_epoch) — no
+  // event between the side stream and the main stream in front of that launch. A/B switch 16384: the event.
+  const bool gather_flag = side_imu && T.nb && !p->allreduce && !p->rccl_comm && p->world == 1 && !(T.debug_flags & 16384) &&
+                           !(T.debug_flags & 8388608);
+  const unsigned gather_epoch = gather_flag ? ++p->join_epoch : 0u;
   // (Round 6 tried the segment Gram kernel of a fused stereo-inertial window on the side stream, behind k_linearize_inertial and next to
   //  k_build_visual: 8 us off the main stream's chain, and the event k_assemble then waits for cost more — 1.080 against 1.038 ms per optimize().)
   if (side_imu && T.nb) {  // behind k_linearize_inertial on the side stream, next to k_landmark / the Gram kernels
     // (Round 6 also ran both gathers as ONE launch — zero-fill moved into k_linearize_inertial, the H_bb workgroups first: 82 us at configs[2]
     //  where the two launches take 32 + 45: the gathers do not overlap, they share whatever bounds them. Not kept.)
     k_border_pb<K><<<dim3(T.sp.n_cp + border_zero_wgs(T), p->n_split), kPbThreads, 0, sb>>>(T);  // (+ zero-fill of the border-border block)
-    k_border_bb<K><<<T.n_bias, kBlock, 0, sb>>>(T);
+    Tables Tg = T;
+    Tg.gather_epoch = gather_epoch;
+    k_border_bb<K><<<T.n_bias, kBlock, 0, sb>>>(Tg);
     HIP_TRY(hipEventRecord(p->ev_join, p->side));
   }
   bool irec_ready = !side_imu;  // the segment Gram kernel reads the inertial records: wait for the side stream's linearisation once
@@ -252,7 +259,7 @@ int launch_build(hs_problem* p, hipEvent_t after_build = nullptr, bool scaling_f
     k_border_pb<K><<<dim3(T.sp.n_cp + border_zero_wgs(T), p->n_split), kPbThreads, 0, s>>>(T);
     k_border_bb<K><<<T.n_bias, kBlock, 0, s>>>(T);
   }
-  if (side_imu) HIP_TRY(hipStreamWaitEvent(s, p->ev_join, 0));  // border gathers done
+  if (side_imu && !gather_flag) HIP_TRY(hipStreamWaitEvent(s, p->ev_join, 0));  // border gathers done
   // Nothing to exchange (single shard): packing + bookkeeping are an extra workgroup of k_finalize_reduced, the border blocks further
   // ones that sum the accumulation splits themselves — one launch where the exchanging path has five (~5 us each on the chain).
   // A/B switch 8388608: the five launches.
@@ -265,6 +272,7 @@ int launch_build(hs_problem* p, hipEvent_t after_build = nullptr, bool scaling_f
   const int rc = exchange(p, T.xbuf, T.x_count1);  // one RCCL all-reduce of [S | g | diag | cost] per linearisation
   if (rc) return rc;
   Tables Td = T;
+  Td.gather_epoch = gather_epoch;
   if (use_dense_mx(p, &Td.dense_f0)) Td.dense = p->d_dense_ut.p + size_t(kDenseLd) * kDenseLd;  // (second half of the scratch: the first is the factor by columns)
   k_finalize_reduced<<<T.sp.n_cp + (reduce_here ? 1 + nb_wg : 0), kBlock, 0, s>>>(Td, p->n_split);  // + 1: packing / bookkeeping workgroup, + border
   if (T.nb && !reduce_here) k_finalize_border<<<nb_wg, kBlock, 0, s>>>(Td);

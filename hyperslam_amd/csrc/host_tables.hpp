@@ -728,8 +728,8 @@ int prepare(hs_problem* p) {
   HIP_TRY(p->d_dense_ut.reserve(size_t(2) * kDenseLd * kDenseLd));  // the factor by columns | the dense copy of the system (Tables::dense)
   if (!p->d_join.p) {
     // [0] two-ended factor / sweep hand-over, [1] last-block ticket of the backward sweeps, [2] of k_border_bb, [4 ..] super-block inverses
-    HIP_TRY(p->d_join.reserve(kBfFlagBase + 512 + 4 * kProgressStride));  // (+ one flag per column group of k_border_forward2, + the four progress words of a pipelined sweep)
-    HIP_TRY(hipMemsetAsync(p->d_join.p, 0, (kBfFlagBase + 512 + 4 * kProgressStride) * sizeof(unsigned), s));
+    HIP_TRY(p->d_join.reserve(kGatherFlag + kProgressStride));  // (+ one flag per column group of k_border_forward2, + the four progress words of a pipelined sweep, + kGatherFlag)
+    HIP_TRY(hipMemsetAsync(p->d_join.p, 0, (kGatherFlag + kProgressStride) * sizeof(unsigned), s));
     p->join_epoch = 0;
   }
   // split the accumulation over enough workgroups to fill the chip (256 CUs x a few workgroups)
@@ -848,6 +848,7 @@ int prepare(hs_problem* p) {
   // 1048576 inertial branch on the main stream    2097152 banded kernels instead of k_dense_factor    4194304 k_landmark<K,4,1> instead of k_landmark_rows
   // 8388608 five finalisation launches for a bordered single shard    16777216 k_commit launch for small windows    33554432 one cost launch per factor type
   // 134217728 prior / inertial candidate costs as launches of their own behind k_update_visual (single shard, fused path)
+  // 16384 border gathers joined to the main stream by an event instead of the device flag (Tables::gather_epoch)
   // 268435456 backward sweeps one block row per step    536870912 bordered systems one-ended    1073741824 no speculative linearisation at the candidate    67108864 k_commit in every iteration of a speculative solve
   T.st = p->d_state.p;
   HIP_TRY(p->batch.flush(s));  // (the staging arena outlives this call: no host synchronisation)

@@ -226,6 +226,27 @@ __global__ void __launch_bounds__(kBlock) k_border_bb(Tables T) {
   Hbb[size_t(ogr) * nb + ogr] = h[0], Hbb[size_t(ogr) * nb + ogr + 1] = h[1];
   Hbb[size_t(ogr + 1) * nb + ogr] = h[1], Hbb[size_t(ogr + 1) * nb + ogr + 1] = h[2];
   gb[ogr] = h[3], gb[ogr + 1] = h[4];
+  // Both gathers are complete (k_border_pb ended in front of this launch, every other workgroup of this one released its part before its
+  // ticket): say so to the border workgroups of k_finalize_reduced on the other stream (Tables::gather_epoch, gather_wait)
+  if (T.gather_epoch) __hip_atomic_store(T.join_flag + kGatherFlag, T.gather_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+/// The border workgroups of k_finalize_reduced wait here for the gathers of the side stream (round 6). As an event between the two streams the
+/// same dependency cost 13 us on the chain of every iteration — main stream idle from the end of k_assemble to the event's arrival — and the
+/// launch of k_finalize_reduced behind it; now the launch is in flight and the pose rows are done when the flag arrives. Bounded: 2 s.
+HSD void gather_wait(const Tables& T) {
+  if (threadIdx.x == 0) {
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(T.join_flag + kGatherFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != T.gather_epoch) {
+      __builtin_amdgcn_s_sleep(4);
+      if (wall_clock64() - t0 > 200000000ll) {
+        give_up(T.st);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
 /// Scaling / damping of the border blocks after the exchange:  S_pb = Sp H_pb Sb,  S_bb = Sb H_bb Sb + D_b^2,  g_b = Sb g_b.
@@ -233,6 +254,7 @@ __global__ void __launch_bounds__(kBlock) k_border_bb(Tables T) {
 HSD void finalize_border_body(const Tables& T, const int wg, const int n_wg, const int n_splits) {
   DevState* st = T.st;
   if (st->done) return;
+  if (T.gather_epoch) gather_wait(T);
   const int nb = T.nb, np = T.np;
   const double* X = T.xbuf;
   const bool fresh = !st->scaling_ready;
@@ -426,6 +448,7 @@ struct BfJob {
   unsigned progress_base;
 };
 constexpr int kBfFlagBase = 4 + 2 * 512;  // behind the super-block flags of the backward sweep (kernels_backward_sb.hpp)
+static_assert(kGatherFlag == kBfFlagBase + 512 + 4 * kProgressStride, "kGatherFlag: the word behind the progress words");
 
 __global__ void __launch_bounds__(kBlock) k_border_forward2(Tables T, BfJob j0, BfJob j1, int m_junction, int j_lo, int local_rows, double* handover) {
   HS_DYNAMIC_LDS(smem);

@@ -17,6 +17,8 @@ constexpr int kBlock = 256;
 constexpr int kDenseLd = 256;  // leading dimension of the dense copy of a small reduced system (Tables::dense, kernels_dense_mx.hpp)
 HSD bool prof_enabled(int debug_flags, int bit) { return HS_PROFILE_HOOKS && (debug_flags & bit); }
 
+constexpr int kGatherFlag = 4 + 2 * 512 + 512 + 4 * kProgressStride;  // word of T.join_flag behind every other use (kBfFlagBase + 512 + 4 kProgressStride)
+
 /// A bounded wait gave up: the solve ends here (every later kernel exits on `done`, hs_solve reports the reason) — nothing downstream may
 /// consume what the workgroup that did not arrive has left half written. chol_failed = 2 is never cleared within a solve.
 HSD void give_up(DevState* st) {

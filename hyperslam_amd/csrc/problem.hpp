@@ -216,6 +216,8 @@ struct Tables {
   double* xsol;          // np: solution of the reduced system in natural order (two-ended path)
   unsigned* join_flag;   // device word: epoch of the last finished bottom-end factorisation / published middle solution
   unsigned join_epoch;
+  unsigned gather_epoch; // != 0: the border gathers on the side stream end with this value in join_flag[kGatherFlag] (k_border_bb's last workgroup), and the
+                         // border workgroups of k_finalize_reduced wait for it there instead of the host enqueuing an event between the two streams
   double* gravity_part;  // n_bias x 5: gravity block partials of k_border_bb
   double* segP;   // per k_seg_gram workgroup: [J'J (6k x 6k) | J'r (6k)]
   const int* gw_ptr;  // n_cp + 1: workgroups of k_group_gram serving landmark group c (splits ~ landmark count)

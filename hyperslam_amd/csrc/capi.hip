@@ -750,7 +750,9 @@ int hs_solve(hs_problem* p, int max_iterations, hs_summary* summary, hs_iteratio
   int rc = prepare(p);
   if (rc) return rc;
   const bool spec = speculative_solve(p);
-  const bool deferred = (spec || fused_visual_only(p)) && !commit_inline(p) && !(p->T.debug_flags & 67108864);  // A/B switch 67108864: k_commit in every iteration
+  // (fused visual-only windows defer also when they are small enough for the decision kernel to commit inline: deferred landmarks are what lets the
+  //  decision ride in the next build — one launch less per iteration, which at the replay's window sizes is 6 us of 130)
+  const bool deferred = (fused_visual_only(p) || (spec && !commit_inline(p))) && !(p->T.debug_flags & 67108864);  // A/B switch 67108864: k_commit in every iteration
   const bool fold = fold_decision_into_build(p, deferred);  // the decision of iteration i rides in k_build_visual of iteration i + 1
   rc = reset_state(p, max_iterations, 1e4, spec ? (deferred ? 2 : 1) : (deferred ? 4 : 0));
   if (rc) return rc;

@@ -584,7 +584,7 @@ int launch_update(hs_problem* p, bool linearize_candidate = false, bool deferred
   const Tables& T = p->T;
   hipStream_t s = p->stream;
   const bool local_decision = !p->allreduce && !p->rccl_comm;  // single shard: decide in the packing kernel
-  const bool inline_commit = commit_inline(p);
+  const bool inline_commit = commit_inline(p) && !deferred_commit;  // (a deferred commit: the control points only, decide_here = 3)
   const bool cps_here = p->fused && deferred_commit;  // fused path: the decision kernel commits the control points, the landmarks stay deferred
   const int decide_here = inline_commit ? 2 : local_decision ? (cps_here ? 3 : 1) : 0;
   // Single shard, fused path (round 6): the candidate costs of the prior / inertial factors are further workgroups of k_update_visual's launch —

@@ -44,4 +44,11 @@ python tools/stress_pipelined_sweep.py 40 > $out/${tag}_stress_pipelined_sweep.t
 bash tools/r06_replay_host.sh $tag
 ( cd hyperslam_amd/host; for a in "6.0 0 4" "6.0 1 4" "6.0 1 6"; do echo "replay $a HS_DEBUG_FLAGS=8 (round 5: one-ended band kernels + border chain + k_band_backward)"; HS_DEBUG_FLAGS=8 ./replay $a 2>/dev/null | tail -1; echo "replay $a (k_dense_solve_mx)"; ./replay $a 2>/dev/null | tail -1; done ) > $out/${tag}_replay_dense_ab.txt 2>&1
 bash tools/kernel_stats.sh $out/${tag}_replay_stereo_kernel_stats.csv hyperslam_amd/host/replay 6.0 0 4 >> $out/${tag}_kernel_stats.txt 2>&1
+# later in round 6: A/B switches of the launch structure on the replays, each against the product on the same box (tools/r06_ab.sh) —
+# 134217728 prior / inertial candidate costs as launches of their own; 16384 border gathers joined by an event instead of the device flag;
+# 67108864 no deferred commit (small visual-only windows: k_pack_decision in every iteration instead of the decision folded into the next build)
+{ for f in 134217728 16384 67108864; do echo "--- A/B switch $f"; bash tools/r06_ab.sh $f 2; done; } > $out/${tag}_replay_launch_ab.txt 2>&1
+{ for i in 1 2; do echo "gather flag (default)"; HS_STAGE_TIMING=0 python tools/time_config.py 2 | head -1; echo "event between the streams (HS_DEBUG_FLAGS=16384)"; HS_DEBUG_FLAGS=16384 HS_STAGE_TIMING=0 python tools/time_config.py 2 | head -1; done; } > $out/${tag}_config2_gather_ab.txt 2>&1
+bash tools/iteration_timeline.sh 2 > $out/${tag}_timeline_config2.txt 2>&1
+hipcc --offload-arch=gfx950 -O2 -o /tmp/dpp_probe tools/microbench/dpp_f64_probe.hip > /dev/null 2>&1 && /tmp/dpp_probe > $out/${tag}_dpp_f64_probe.txt 2>&1
 echo done

@@ -333,6 +333,10 @@ HSD void mx_lane_update(const MxLane& L, const double* row, const double* xp, in
     for (int k = 0; k < 6; ++k) v[a] = fma(-B[k][a], xc[k], v[a]);
 }
 
+/// (Round 6 tried the DPP scheme of k_dense_solve_mx's panel here — the block handed to every row of sixteen lanes through LDS, right-looking
+///  Cholesky with v_fmac_f64_dpp, pivots scheduled by hand: 84 ordered instructions instead of 178 — and factor + solve took 0.52 us where this
+///  takes 0.44: on a 6 x 6 block the chain of a pivot (scale, two wait states, DPP multiply-add, two wait states, DPP move, rsq, Halley) is what
+///  counts, not the instruction count, and the compiler's schedule of the left-looking form below has the shorter one. Not kept.)
 /// The updated diagonal block sits in the diagonal lanes (lane kMxDiagLane + c: column c). Every lane factors it redundantly: the 21 entries
 /// are broadcast with v_readlane (wave-uniform values in SGPRs). U comes out with NEGATED off-diagonal entries (products of two of them are
 /// unchanged, the column solves become plain multiply-adds), inv = 1 / diag. Returns the smallest pivot.

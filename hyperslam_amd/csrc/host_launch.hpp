@@ -428,9 +428,23 @@ int launch_factor(hs_problem* p) {
         k_border_forward2<<<dim3(n_groups, 2), fwd_threads, size_t(T.np) * kBorderLd * sizeof(double), s>>>(
             Tb, BfJob{T.Ub, T.Ubk, m + w_mid, 0, nullptr, 0}, BfJob{p->d_Ub2.p, p->d_Ubk2.p, mB, 1, nullptr, 0}, m, 0, local_rows, p->d_bf_handover.p);
       }
+      // Border Schur complements of 64 .. 255 unknowns (configs[2]: 110) are factored and solved by k_dense_solve_mx in border mode (round 6:
+      // ~32 us where the register Cholesky k_border_solve_reg takes 50): k_border_schur writes C | h into the dense layout as well.
+      // A/B switch 8192 (with a border): k_border_solve_reg.
+      const bool dense_tail = T.nb >= 64 && T.nb + 1 <= 16 * kDxTiles && !(T.debug_flags & 8192);
+      if (dense_tail) {
+        Tb.dense = p->d_dense_ut.p + size_t(kDenseLd) * kDenseLd, Tb.dense_border = 1, Tb.dense_f0 = T.np / 6, Tb.bookkeep = 0;
+        if (p->dense_border_nb != T.nb) {  // (padding of the dense copy: once per structure, prepare() resets the mark)
+          k_dense_border_init<<<64, kBlock, 0, s>>>(Tb.dense, T.nb);
+          p->dense_border_nb = T.nb;
+        }
+      }
       const int n_tiles = (T.nb + kSchurTile - 1) / kSchurTile;
       k_border_schur<<<dim3(n_tiles, n_tiles), kBlock, 0, s>>>(Tb, 0, local_rows, m);  // (rows from the junction on are never skipped)
-      HIP_TRY(launch_border_solve(Tb, s));
+      if (dense_tail)
+        k_dense_solve_mx<<<1, kDxThreads, kDxLdsDoubles * sizeof(double), s>>>(Tb, T.np / 6, p->d_dense_ut.p);
+      else
+        HIP_TRY(launch_border_solve(Tb, s));
       k_border_apply<<<(T.np + kBlock / 64 - 1) / (kBlock / 64), kBlock, 0, s>>>(Tb);
     }
     Tables T3 = T2;

@@ -301,6 +301,7 @@ struct hs_problem {
   int n_seg_wg = 0, n_group_wg = 0;
   // fused build of the visual factors (kernels_build.hpp)
   bool fused = false;
+  int dense_border_nb = -1;         // border size the padding of the dense copy was written for (k_dense_border_init, launch_factor); -1: not yet
   bool bookkeep = false;            // this linearisation's rows were finalised by k_assemble: the factorisation does the iteration bookkeeping (launch_build)
   int build_R = 0, build_L = 0;     // records per pass, landmarks per chunk
   size_t build_lds = 0;
@@ -779,6 +780,7 @@ int prepare(hs_problem* p) {
 
   Tables& T = p->T;
   std::memset(&T, 0, sizeof(T));
+  p->dense_border_nb = -1;
   T.sp = Spline{k, p->n_cp, p->t0, p->dt, 1.0 / p->dt, p->rot_const, p->trans_const};
   T.basis = make_basis_coef(k);
   T.cp = p->d_cp.p, T.cp_cand = p->d_cp_cand.p, T.cp_const = p->d_cp_const.p;
@@ -846,6 +848,7 @@ int prepare(hs_problem* p) {
   //   (64 and 128 are product A/B switches: the stamps of k_assemble / k_update_visual used to share them, so that timing one of those kernels
   //    also changed the factorisation path)
   // 1048576 inertial branch on the main stream    2097152 banded kernels instead of k_dense_factor    4194304 k_landmark<K,4,1> instead of k_landmark_rows
+  // 8192 with a border: k_border_solve_reg instead of k_dense_solve_mx on the border Schur complement of a two-ended system
   // 8388608 five finalisation launches for a bordered single shard    16777216 k_commit launch for small windows    33554432 one cost launch per factor type
   // 134217728 prior / inertial candidate costs as launches of their own behind k_update_visual (single shard, fused path)
   // 16384 border gathers joined to the main stream by an event instead of the device flag (Tables::gather_epoch)

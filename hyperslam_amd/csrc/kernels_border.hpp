@@ -681,8 +681,16 @@ __global__ void __launch_bounds__(kBlock) k_border_schur(Tables T, int j_lo, int
     const double v = T.Sbb[size_t(b) * nb + c] - acc;
     T.Cb[size_t(b) * nb + c] = v;
     if (ct != bt) T.Cb[size_t(c) * nb + b] = v;
+    if (T.dense_border) {  // the same entries in the dense layout k_dense_solve_mx loads its tiles from (padding + corner: written once, prepare())
+      T.dense[size_t(b) * kDenseLd + c] = v;
+      if (ct != bt) T.dense[size_t(c) * kDenseLd + b] = v;
+    }
   }
-  if (ct == bt && tj == 0 && b < nb) T.hb[b] = T.gb_s[b] - hacc;
+  if (ct == bt && tj == 0 && b < nb) {
+    const double h = T.gb_s[b] - hacc;
+    T.hb[b] = h;
+    if (T.dense_border) T.dense[size_t(b) * kDenseLd + nb] = h, T.dense[size_t(nb) * kDenseLd + b] = h;  // right-hand side: column (and row) nb
+  }
 }
 
 /// Dense Cholesky of the border Schur complement C (nb x nb, in LDS, augmented with h as an extra row so that the forward

@@ -358,6 +358,16 @@ HSD void dx_sweep_block(int K, int rho, int w, int l, const double* ut, const do
   if (slog) slog[3] = wall_clock64();
 }
 
+/// Border mode (Tables::dense_border): the part of the dense copy that k_border_schur does not write — identity on the padding, the huge
+/// diagonal entry behind the right-hand side, zeros between — once per structure (launch_factor).
+__global__ void __launch_bounds__(kBlock) k_dense_border_init(double* D, int nb) {
+  const int n_pad = 16 * ((nb + 1 + 15) / 16);
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_pad * n_pad; e += gridDim.x * blockDim.x) {
+    const int i = e / n_pad, j = e % n_pad;
+    D[size_t(i) * kDenseLd + j] = i != j ? 0.0 : (i == nb ? 1e300 : 1.0);
+  }
+}
+
 /// One workgroup. f0: leading block rows of constant control points (decoupled, solution zero: the chain starts behind them).
 /// ut: 256 x 256 doubles of scratch (the factor by columns, for the sweep).
 __global__ void __launch_bounds__(kDxThreads) k_dense_solve_mx(Tables T, int f0, double* ut) {
@@ -419,6 +429,11 @@ __global__ void __launch_bounds__(kDxThreads) k_dense_solve_mx(Tables T, int f0,
   // A pivot that was not positive: 1 / sqrt of it is NaN or infinite and so is everything behind it — the step of a failed factorisation is zero
   // (decide_step rejects it on chol_failed, the radius shrinks: Ceres' LINEAR_SOLVER_FAILURE branch).
   fail = smem[kDxOffRed + 16] != 0.0;
+  if (T.dense_border) {  // the border Schur complement of a two-ended bordered system: x_b for k_border_apply and the sweeps, nothing else
+    if (rho < n_dense) T.xb[rho] = fail ? 0.0 : xv[rho];
+    if (tid == 0 && fail) st->chol_failed = 1;
+    return;
+  }
   double gd = 0.0, dd = 0.0;
   for (int r = tid; r < 6 * f0; r += 256) T.step_p[r] = 0.0, T.delta_p[r] = 0.0;
   if (rho < n_dense) {

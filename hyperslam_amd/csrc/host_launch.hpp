@@ -418,12 +418,15 @@ int launch_factor(hs_problem* p) {
       HIP_TRY(p->d_bf_handover.reserve(size_t(n_groups) * 6 * w_mid * kBorderCols + 1));
       const int fwd_threads = std::max(128, 64 * ((6 * w_mid + 63) / 64));  // one lane per pending row
       const int local_rows = (!p->allreduce && !p->rccl_comm && p->world == 1) ? 1 : 0;
+      // (single shard: k_border_schur picks the sweep's end up through a device flag, Tables::sweep_epoch — A/B switch 16384: an event)
+      const bool sweep_flag = pipe && !p->allreduce && !p->rccl_comm && p->world == 1 && !(T.debug_flags & 16384);
+      if (sweep_flag) Tb.sweep_epoch = ++p->join_epoch;
       if (pipe) {  // (+ one wave that polls the factorisation's progress)
         k_border_forward2<<<dim3(n_groups, 2), fwd_threads + 64, size_t(T.np) * kBorderLd * sizeof(double), p->side>>>(
             Tb, BfJob{T.Ub, T.Ubk, m + w_mid, 0, progress, progress_base}, BfJob{p->d_Ub2.p, p->d_Ubk2.p, mB, 1, progress + 2 * kProgressStride, progress_base}, m, 0, local_rows,
             p->d_bf_handover.p);
         HIP_TRY(hipEventRecord(p->ev_join, p->side));
-        HIP_TRY(hipStreamWaitEvent(s, p->ev_join, 0));
+        if (!sweep_flag) HIP_TRY(hipStreamWaitEvent(s, p->ev_join, 0));
       } else {
         k_border_forward2<<<dim3(n_groups, 2), fwd_threads, size_t(T.np) * kBorderLd * sizeof(double), s>>>(
             Tb, BfJob{T.Ub, T.Ubk, m + w_mid, 0, nullptr, 0}, BfJob{p->d_Ub2.p, p->d_Ubk2.p, mB, 1, nullptr, 0}, m, 0, local_rows, p->d_bf_handover.p);

@@ -851,7 +851,7 @@ int prepare(hs_problem* p) {
   // 8192 with a border: k_border_solve_reg instead of k_dense_solve_mx on the border Schur complement of a two-ended system
   // 8388608 five finalisation launches for a bordered single shard    16777216 k_commit launch for small windows    33554432 one cost launch per factor type
   // 134217728 prior / inertial candidate costs as launches of their own behind k_update_visual (single shard, fused path)
-  // 16384 border gathers joined to the main stream by an event instead of the device flag (Tables::gather_epoch)
+  // 16384 border gathers / pipelined border sweep joined to the main stream by events instead of device flags (Tables::gather_epoch, sweep_epoch)
   // 268435456 backward sweeps one block row per step    536870912 bordered systems one-ended    1073741824 no speculative linearisation at the candidate    67108864 k_commit in every iteration of a speculative solve
   T.st = p->d_state.p;
   HIP_TRY(p->batch.flush(s));  // (the staging arena outlives this call: no host synchronisation)

@@ -231,13 +231,11 @@ __global__ void __launch_bounds__(kBlock) k_border_bb(Tables T) {
   if (T.gather_epoch) __hip_atomic_store(T.join_flag + kGatherFlag, T.gather_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-/// The border workgroups of k_finalize_reduced wait here for the gathers of the side stream (round 6). As an event between the two streams the
-/// same dependency cost 13 us on the chain of every iteration — main stream idle from the end of k_assemble to the event's arrival — and the
-/// launch of k_finalize_reduced behind it; now the launch is in flight and the pose rows are done when the flag arrives. Bounded: 2 s.
-HSD void gather_wait(const Tables& T) {
+/// Bounded wait (2 s) of a workgroup for `*flag == epoch`, then an agent-scope acquire by every wave.
+HSD void flag_wait(const Tables& T, const unsigned* flag, unsigned epoch) {
   if (threadIdx.x == 0) {
     const long long t0 = wall_clock64();
-    while (__hip_atomic_load(T.join_flag + kGatherFlag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != T.gather_epoch) {
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
       __builtin_amdgcn_s_sleep(4);
       if (wall_clock64() - t0 > 200000000ll) {
         give_up(T.st);
@@ -248,6 +246,11 @@ HSD void gather_wait(const Tables& T) {
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
+
+/// The border workgroups of k_finalize_reduced wait here for the gathers of the side stream (round 6). As an event between the two streams the
+/// same dependency cost 13 us on the chain of every iteration — main stream idle from the end of k_assemble to the event's arrival — and the
+/// launch of k_finalize_reduced behind it; now the launch is in flight and the pose rows are done when the flag arrives. Bounded: 2 s.
+HSD void gather_wait(const Tables& T) { flag_wait(T, T.join_flag + kGatherFlag, T.gather_epoch); }
 
 /// Scaling / damping of the border blocks after the exchange:  S_pb = Sp H_pb Sb,  S_bb = Sb H_bb Sb + D_b^2,  g_b = Sb g_b.
 /// (n_splits = 0: H_pb was reduced into the exchange buffer by k_reduce_partials; > 0: summed here over the accumulation splits, same order)
@@ -608,6 +611,18 @@ __global__ void __launch_bounds__(kBlock) k_border_forward2(Tables T, BfJob j0, 
       __threadfence();
       __hip_atomic_store(const_cast<unsigned*>(flag), T.join_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
+  } else if (T.sweep_epoch) {
+    // Z is complete when the last near-end workgroup is (each of them waited for its far-end partner at the junction): ticket, and the last one
+    // tells k_border_schur on the main stream (flag_wait there) — as an event between the streams this was 11 - 13 us of every iteration.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence();
+      if (atomicAdd(T.join_flag + kGatherFlag + 1, 1u) == gridDim.x - 1) {
+        __hip_atomic_store(T.join_flag + kGatherFlag + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(T.join_flag + kGatherFlag + 2, T.sweep_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
 }
 
@@ -625,6 +640,7 @@ __global__ void __launch_bounds__(kBlock) k_border_schur(Tables T, int j_lo, int
   const int nb = T.nb, np = T.np, tid = threadIdx.x;
   const int bt = blockIdx.x, ct = blockIdx.y;
   if (ct < bt) return;  // lower tiles are written by their mirror
+  if (T.sweep_epoch) flag_wait(T, T.join_flag + kGatherFlag + 2, T.sweep_epoch);  // Z from the side stream (k_border_forward2's last workgroup)
   const int ti = tid / kSchurTile, tj = tid % kSchurTile;
   const int b = bt * kSchurTile + ti, c = ct * kSchurTile + tj;
   static_assert(kSchurTile % kBorderCols == 0, "a Schur tile covers whole column groups of the forward sweep");

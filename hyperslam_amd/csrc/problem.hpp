@@ -242,6 +242,8 @@ struct Tables {
                    // damped system as ONE dense row-major matrix (leading dimension 256, both triangles, identity on the padding to whole 16 x 16
                    // tiles) of the free block rows dense_f0 .. and the border unknowns; nullptr otherwise
   int dense_f0;
+  unsigned sweep_epoch;  // != 0: k_border_forward2 (side stream) ends with this value in join_flag[kGatherFlag + 2] and k_border_schur waits for it there
+                         // (no event between the streams behind the pipelined border sweep)
   int dense_border;      // k_dense_solve_mx on the border Schur complement of a two-ended bordered system (launch_factor): Tables::dense holds C | h, the
                          // kernel's only output is x_b (+ the factorisation's verdict)
   int rank, world;

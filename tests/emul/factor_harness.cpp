@@ -65,6 +65,32 @@ int main(int argc, char** argv) {
   const std::vector<double> scale_b = read_vec<double>(in, nb), D2b = read_vec<double>(in, nb);
   const std::vector<int> bfwd_start = read_vec<int>(in, n_groups);
   fclose(in);
+  if (hdr[3] == 7) {  // k_dense_solve_mx in border mode (Tables::dense_border): the border Schur complement C | h of a two-ended bordered system -> x_b.
+                      // Input: S_bb stands for C, g_b for h; the dense copy is filled the way launch_factor does it (k_dense_border_init once, then
+                      // k_border_schur's stores: both triangles, the right-hand side as row and column nb).
+    if (nb < 1 || nb + 1 > 16 * kDxTiles) {
+      fprintf(stderr, "border outside the kernel's range\n");
+      return 3;
+    }
+    std::vector<double> ut(size_t(256) * 256, 0.0), xb(nb + 1, 7.0), xpart(64, 0.0), dense(size_t(kDenseLd) * kDenseLd, 7.0);
+    hs_emul::launch(dim3(4), dim3(kBlock), 0, [&] { k_dense_border_init(dense.data(), nb); });
+    for (int b = 0; b < nb; ++b) {
+      for (int c = 0; c < nb; ++c) dense[size_t(b) * kDenseLd + c] = Sbb[size_t(b) * nb + c];
+      dense[size_t(b) * kDenseLd + nb] = dense[size_t(nb) * kDenseLd + b] = gb[b];
+    }
+    DevState st{};
+    Tables T{};
+    T.np = np, T.bw = bw, T.nb = nb, T.st = &st, T.xpart = xpart.data(), T.xb = xb.data();
+    T.dense = dense.data(), T.dense_f0 = np / 6, T.dense_border = 1;
+    hs_emul::launch(dim3(1), dim3(kDxThreads), size_t(kDxLdsDoubles) * sizeof(double), [&] { k_dense_solve_mx(T, np / 6, ut.data()); });
+    FILE* out = fopen(argv[2], "wb");
+    const int res[4] = {-1, 0, st.chol_failed, 0};
+    fwrite(res, sizeof(int), 4, out);
+    xb.resize(nb);
+    write_vec(out, xb);
+    fclose(out);
+    return 0;
+  }
   if (hdr[3] == 6) {  // k_dense_solve_mx (kernels_dense_mx.hpp): factorisation, border and both sweeps of a small system in one launch
     if (two_ended || !dense_mx_fits(n_blk - f0, nb)) {
       fprintf(stderr, "system outside the kernel's range\n");

@@ -298,3 +298,34 @@ def test_dense_solve_mx_against_numpy(n_blk, bw, f0, n_b, harness, tmp_path):
         border[0][:k, :] = 0.0  # (a constant control point has no Jacobian columns: its rows of S_pb are zero)
         border = (border[0], border[0].T @ np.linalg.solve(M, border[0]) + np.diag(rng.uniform(0.5, 1.5, n_b)), border[2], border[3])
     run(harness, tmp_path, M, g, bw, False, 6, f0, border=border)
+
+
+@pytest.mark.parametrize("n_b", [110, 64, 255, 17, 1])
+def test_dense_solve_mx_border_mode_against_numpy(n_b, harness, tmp_path):
+    """k_dense_solve_mx in border mode (Tables::dense_border, launch_factor): the border Schur complement C | h of a two-ended bordered system
+    (configs[2]: 110 unknowns) in the dense layout — padding by k_dense_border_init, entries as k_border_schur stores them — comes out as x_b
+    and nothing else is written."""
+    rng = np.random.default_rng(977 + n_b)
+    A = rng.standard_normal((n_b, n_b + 8))
+    C = A @ A.T + np.diag(rng.uniform(0.5, 1.5, n_b))
+    h = rng.standard_normal(n_b)
+    n_blk, bw = 4, 2
+    M = banded_spd(rng, n_blk, bw)
+    n = 6 * n_blk
+    src, dst = str(tmp_path / "sys.bin"), str(tmp_path / "out.bin")
+    P = np.arange(n)[::-1]
+    z = np.zeros(n)
+    with open(src, "wb") as f:
+        f.write(struct.pack("=6i", n, bw, 0, 7, n_b, 0))
+        for a in (band_rows(M, bw), z, band_rows(M[np.ix_(P, P)], bw), z, z, z, z):
+            f.write(np.ascontiguousarray(a, dtype="<f8").tobytes())
+        for a in (np.zeros((n, n_b)), C, h, np.ones(n_b), np.zeros(n_b)):
+            f.write(np.ascontiguousarray(a, dtype="<f8").tobytes())
+        f.write(np.zeros((n_b + 1) // 2 + 8, dtype="<i4").tobytes())
+    subprocess.check_call([harness, src, dst], timeout=180)
+    raw = open(dst, "rb").read()
+    _, _, failed, _ = struct.unpack("=4i", raw[:16])
+    xb = np.frombuffer(raw[16:], dtype="<f8")
+    assert failed == 0 and len(xb) == n_b
+    want = np.linalg.solve(C, h)
+    assert np.allclose(xb, want, rtol=0, atol=1e-10 * max(1.0, np.abs(want).max()))

@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(kPbThreads) k_border_pb(Tables T) {
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
-        const double v = wave_sum(acc[c][a]);
+        const double v = wave_sum_fast(acc[c][a]);
         if (lane == 0) out[size_t(6 * i + a) * nb + 6 * nbias + c] = v;
       }
     return;
@@ -157,10 +157,12 @@ __global__ void __launch_bounds__(kBlock) k_border_bb(Tables T) {
       }
     }
   }
-  // wave sums, then the waves in index order (fixed order: bit-reproducible); slot e of red[wave] as in the layout above
+  // wave sums, then the waves in index order (fixed order: bit-reproducible); slot e of red[wave] as in the layout above. (wave_sum_fast: the
+  // butterfly of wave_sum with four of its six levels on the DPP cross bar — as LDS permutes the 39 sums were 8 - 13 us of the kernel whatever
+  // the number of records. Sums per row of sixteen lanes + sixteen rows added up by lane 0 were tried: 59.8 us instead of 42.7. Not kept.)
 #define HS_BB_REDUCE(arr, n, base)                                   \
   _Pragma("unroll") for (int e = 0; e < (n); ++e) {                  \
-    arr[e] = wave_sum(arr[e]);                                       \
+    arr[e] = wave_sum_fast(arr[e]);                                  \
     if (lane == 0) red[wave][(base) + e] = arr[e];                   \
   }
   HS_BB_REDUCE(gg, KM, 0)

@@ -12,12 +12,14 @@ bash tools/kernel_stats.sh $out/${tag}_config2_kernel_stats.csv python bench.py 
 bash tools/kernel_stats.sh $out/${tag}_replay_kernel_stats.csv hyperslam_amd/host/replay 6.0 1 4 >> $out/${tag}_kernel_stats.txt 2>&1
 bash tools/pmc_traffic.sh $out/${tag}_pmc_hbm_traffic.json $B > $out/${tag}_pmc.txt 2>&1
 bash tools/pmc_sq.sh $out/${tag}_pmc_sq.json $B >> $out/${tag}_pmc.txt 2>&1
-bash tools/pmc_sq.sh $out/${tag}_config2_pmc_sq.json python bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline >> $out/${tag}_pmc.txt 2>&1
+# (counter passes serialise the kernels of a process: the border sweep that follows the factorisation row by row must not wait for a kernel that
+#  cannot run next to it — HS_DEBUG_FLAGS=128, the sequential arrangement, for configs[2] under --pmc)
+HS_DEBUG_FLAGS=128 bash tools/pmc_sq.sh $out/${tag}_config2_pmc_sq.json python bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline >> $out/${tag}_pmc.txt 2>&1
 # matrix-core counters of the factorisation: k_band_factor_mx (default since round 5: trailing window in f64-MFMA accumulators) and the VALU
 # look-ahead kernel k_band_factor_la (A/B switch 64); configs[2] runs the WIDE instance
 bash tools/pmc_mfma.sh $out/${tag}_pmc_mfma_mx_factor.json $B >> $out/${tag}_pmc.txt 2>&1
 HS_DEBUG_FLAGS=64 bash tools/pmc_mfma.sh $out/${tag}_pmc_mfma_valu_factor.json $B >> $out/${tag}_pmc.txt 2>&1
-bash tools/pmc_mfma.sh $out/${tag}_config2_pmc_mfma_mx_factor.json python bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline >> $out/${tag}_pmc.txt 2>&1
+HS_DEBUG_FLAGS=128 bash tools/pmc_mfma.sh $out/${tag}_config2_pmc_mfma_mx_factor.json python bench.py --config 2 --steps 20 --warmup 3 --no-cpu-baseline >> $out/${tag}_pmc.txt 2>&1
 bash tools/kernel_stats.sh $out/${tag}_config3_kernel_stats.csv python bench.py --config 3 --steps 10 --warmup 2 --no-cpu-baseline >> $out/${tag}_kernel_stats.txt 2>&1
 [ -f tools/libhyperslam_hip_prof.so ] && { python tools/mx_phase_timing.py 1; python tools/mx_phase_timing.py 3 | tail -4; echo "--- k_band_factor_la (A/B switch 64)"; HS_DEBUG_FLAGS=80 python tools/chol_phase_timing.py; } > $out/${tag}_chol_phase_timing.txt 2>&1
 [ -f tools/libhyperslam_hip_prof.so ] && python tools/build_phase_timing.py 1 > $out/${tag}_build_phase_timing.txt 2>&1

@@ -12,6 +12,14 @@ namespace hs {
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kPbThreads = 192;  // two waves of bias columns + one wave for the two gravity columns
 
+/// w[j] for j in 0 .. 3, zero outside — from registers. k_border_bb needs the weight of ONE bias control point per record, and which one
+/// (j = b - first_bias[record]) is a table entry: taken as rec[.. + j] the weight was a second memory round trip behind that entry in every
+/// batch of records; all four (the bias splines have order four on the device: 32 bytes next to each other) are requested with the entry instead.
+HSD double sel4(const double (&w)[4], int j) {
+  const double lo = j == 0 ? w[0] : w[1], hi = j == 2 ? w[2] : w[3];
+  return (j < 0 || j > 3) ? 0.0 : (j < 2 ? lo : hi);
+}
+
 template <int K>
 __global__ void __launch_bounds__(kPbThreads) k_border_pb(Tables T) {
   // block (i, split): rows 6 i .. 6 i + 5 of H_pb. Waves 0-1: thread <-> bias column, one flat loop over the records of the <= K
@@ -88,7 +96,7 @@ __global__ void __launch_bounds__(kPbThreads) k_border_pb(Tables T) {
       const double* rec = T.i_rec + size_t(pos) * IREC;
       const int j = bb - T.i_first_bias[pos];
       const bool ok = j >= 0 && j < kb;
-      const double wv = rec[6 + 36 * K + kind * kb + (ok ? j : 0)];
+      const double wv = rec[6 + 36 * K + kind * kb + (ok ? j : 0)];  // (all four weights + a select, as in k_border_bb: 54 us instead of 33 — four times the loads)
       const double wgt = ok ? wv : 0.0;
       const double* row = rec + 6 + (3 * kind + cc) * 6 * K + 6 * (i - first_of(pos));
 #pragma unroll
@@ -139,10 +147,18 @@ __global__ void __launch_bounds__(kBlock) k_border_bb(Tables T) {
     const double* wgp = rec + 6 + 36 * K;
     const double* wap = wgp + kb;
     const double* jg = wap + kb;
-    const double wgb = wgp[j], wab = wap[j];
+    double wgb, wab;
+    if (kb == 4) {  // (wave uniform; sel4: no load depends on j. A weight outside the record's window multiplies by an exact zero)
+      const double wg4[4] = {wgp[0], wgp[1], wgp[2], wgp[3]}, wa4[4] = {wap[0], wap[1], wap[2], wap[3]};
+      wgb = sel4(wg4, j), wab = sel4(wa4, j);
 #pragma unroll
-    for (int d = 0; d < KM; ++d)
-      if (d < kb && j + d < kb) gg[d] = fma(wgb, wgp[j + d], gg[d]), aa[d] = fma(wab, wap[j + d], aa[d]);
+      for (int d = 0; d < 4; ++d) gg[d] = fma(wgb, sel4(wg4, j + d), gg[d]), aa[d] = fma(wab, sel4(wa4, j + d), aa[d]);
+    } else {
+      wgb = wgp[j], wab = wap[j];
+#pragma unroll
+      for (int d = 0; d < KM; ++d)
+        if (d < kb && j + d < kb) gg[d] = fma(wgb, wgp[j + d], gg[d]), aa[d] = fma(wab, wap[j + d], aa[d]);
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       ggr[2 * c] = fma(wgb, jg[2 * c], ggr[2 * c]), ggr[2 * c + 1] = fma(wgb, jg[2 * c + 1], ggr[2 * c + 1]);

@@ -278,11 +278,11 @@ HSD void gather_wait(const Tables& T) { flag_wait(T, T.join_flag + kGatherFlag, 
 HSD void finalize_border_body(const Tables& T, const int wg, const int n_wg, const int n_splits) {
   DevState* st = T.st;
   if (st->done) return;
+  const bool fresh = !st->scaling_ready;  // (solver state: requested before the wait — it does not depend on the gathers)
+  const double radius = st->radius;
   if (T.gather_epoch) gather_wait(T);
   const int nb = T.nb, np = T.np;
   const double* X = T.xbuf;
-  const bool fresh = !st->scaling_ready;
-  const double radius = st->radius;
   auto sb_of = [&](int b) { return fresh ? 1.0 / (1.0 + sqrt(X[T.xo_bb + size_t(b) * nb + b])) : T.scale_b[b]; };
   auto sp_of = [&](int rho) { return fresh ? 1.0 / (1.0 + sqrt(X[T.xo_dj + rho])) : T.scale_p[rho]; };
   const int total = (np + nb) * nb;
@@ -291,7 +291,15 @@ HSD void finalize_border_body(const Tables& T, const int wg, const int n_wg, con
     if (row < np) {
       double hpb = 0.0;
       if (n_splits > 0) {
-        for (int k = 0; k < n_splits; ++k) hpb += T.xpart[size_t(k) * T.x_count1 + T.xo_pb + e];
+        // (every split in flight, added in split order: as a plain loop over k the loads went out one per memory round trip — with sixteen
+        //  accumulation splits the border workgroups of k_finalize_reduced took 12 - 16 us for one or two entries per lane; stamps, round 6)
+        for (int k0 = 0; k0 < n_splits; k0 += 16) {  // (n_split <= 16, prepare())
+          double v[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) v[u] = k0 + u < n_splits ? T.xpart[size_t(k0 + u) * T.x_count1 + T.xo_pb + e] : 0.0;
+#pragma unroll
+          for (int u = 0; u < 16; ++u) hpb += v[u];
+        }
       } else {
         hpb = X[T.xo_pb + e];
       }

@@ -391,8 +391,8 @@ int launch_factor(hs_problem* p) {
     if (pipe) {
       T2.mj[0].progress = progress, T2.mj[1].progress = progress + 2 * kProgressStride;
       T2.mj[0].progress_base = T2.mj[1].progress_base = progress_base;
-      HIP_TRY(hipEventRecord(p->ev_fork, s));  // (S_pb and the band are final)
-      HIP_TRY(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+      // (no event from this stream to the side stream: k_border_forward2 reads S_pb behind the first rows the factorisation publishes —
+      //  which are behind k_finalize_reduced — and everything else it touches is its own stream's or the progress protocol's)
     }
     if (nt)
       HIP_TRY(run_mfma(T2, 2));

@@ -519,13 +519,20 @@ __global__ void __launch_bounds__(kBlock) k_border_forward2(Tables T, BfJob j0, 
     }
   };
   double* z = smem;
+  if (poller) await(m0 + D + 2);  // W of row m0, the requests of rows m0 .. m0 + D - 1 (each with W of the row behind it) and the first one of the loop
+  if (pipe) {
+    // Pipelined: this launch is NOT ordered behind k_finalize_reduced by the host (round 6: the event that did it was 7 us of idle main stream
+    // between the finalisation and the factorisation) — it follows the border gathers on its own stream and may be polling long before the
+    // factorisation starts. The first rows of the factor are its proof that S_pb is final: read it behind them, with an acquire.
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
   for (int e = tid; e < nz * kBorderCols; e += blockDim.x) {
     const int rho = e / kBorderCols, c = e % kBorderCols;
     const bool own = rho < 6 * n_rows;
     const int row = far ? np - 1 - rho : rho;
     z[rho * kBorderLd + c] = (c < ncols && own) ? T.Spb[size_t(row) * nb + c0 + c] : 0.0;
   }
-  if (poller) await(m0 + D + 2);  // W of row m0, the requests of rows m0 .. m0 + D - 1 (each with W of the row behind it) and the first one of the loop
   __syncthreads();
   __shared__ __attribute__((aligned(16))) double zi[2][6 * kBorderCols];
   const int n_pend = 6 * w_mid;

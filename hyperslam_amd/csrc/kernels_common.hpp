@@ -43,14 +43,11 @@ HSD double lane_xor4(double v) {
   return (threadIdx.x & 4) ? down : up;
 }
 
+/// Sum over the wave, in every lane: a butterfly over lane ^ 32, 16, 8, 4, 2, 1 — the four lower levels on the DPP cross bar (xor 8 = row_ror:8
+/// inside a row of 16 lanes), the two upper ones as LDS permutes. (Up to round 6 wave_sum was six __shfl_xor — twelve LDS permutes, ~0.25 us —
+/// and this form, same pairs in the same order, i.e. bit-identical sums, was kept for the decision's five sums only: the 39 sums of
+/// k_border_bb were 8 - 13 us of that kernel.)
 HSD double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-/// The same butterfly (same pairs, same order: bit-identical sums) with the four lower levels on the DPP cross bar: xor 8 = row_ror:8 inside
-/// a row of 16 lanes. For the reductions that sit on the iteration's chain (the decision: five sums).
-HSD double wave_sum_fast(double v) {
   v += __shfl_xor(v, 32);
   v += __shfl_xor(v, 16);
   v += dpp_move<0x128>(v);
@@ -59,6 +56,7 @@ HSD double wave_sum_fast(double v) {
   v += lane_xor1(v);
   return v;
 }
+HSD double wave_sum_fast(double v) { return wave_sum(v); }
 
 
 /// Deterministic block sum (fixed butterfly inside each wave, waves combined in index order). Result valid on thread 0.

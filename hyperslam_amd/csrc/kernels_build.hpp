@@ -102,8 +102,8 @@ __host__ __device__ inline BuildLds build_lds_layout(int K, int bw, int R, int L
   o.linv = off, off += Lmax * kLinv;
   o.cpart = off, off += 8;                   // cost partials
   off += off & 1;
-  o.ints = off;  // int tables (two per double): lp[Lmax + 1] ncp[Lmax] yoff[Lmax] seg_start[bw + 2] wave_cnt[4][bw] slot_lm[R] pos[nseg][Lmax + 1] frozen[bw]
-  off += (3 * Lmax + 1 + (bw + 2) + 4 * bw + R + nseg * (Lmax + 1) + bw + 1) / 2 + 1;
+  o.ints = off;  // int tables (two per double): lp[Lmax + 1] ncp[Lmax] yoff[Lmax] seg_start[bw + 2] wave_cnt[4][bw] slot_lm[R] pos[nseg][Lmax + 1] frozen[bw] lane_tile[kBlock]
+  off += (3 * Lmax + 1 + (bw + 2) + 4 * bw + R + nseg * (Lmax + 1) + bw + 1 + kBlock) / 2 + 1;  // (+ lane_tile[kBlock]: phase 3's lane -> (tile, streams) table)
   o.total_doubles = off;
   return o;
 }
@@ -246,6 +246,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
   int* slot_lm = wave_cnt + 4 * bw;    // landmark of the record in sorted slot s
   int* pos = slot_lm + R;              // [nseg][Lmax + 1]: first slot of segment o whose landmark is >= l
   uint8_t* frozen = reinterpret_cast<uint8_t*>(pos + nseg * (Lmax + 1));  // constancy flags of the window's control points
+  int* lane_tile = pos + nseg * (Lmax + 1) + (bw + 3) / 4;  // phase 3 (at most 64 band tiles): rb | d << 8 | log2(streams) << 12 of the lane's tile, -1: idle
 
   // phase timestamps (profiling builds only, HS_DEBUG_FLAGS 32; tools/build_phase_timing.py): lane 0 of every wave of the first 1024 chunks
   const bool bprof = prof_enabled(T.debug_flags, 32) && lane == 0 && w < 1023;  // (row 1023: the decision workgroup of a fold-mode launch, pack_decision_body)
@@ -374,6 +375,49 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
   }
   __syncthreads();
   HS_BSTAMP(2);
+  // ---- streams of phase 3, per chunk (at most 64 band tiles: one lane of the last wave per tile, next to the linearisation, which that wave
+  //      has no part in). A tile's lanes walk the records of the segments that cover both of its blocks, and the longest lane is the phase:
+  //      with a FIXED number of streams per diagonal (build_streams: {8, 4, 4, 2} at K = 4, still the rule for wider bands) a chunk whose
+  //      landmarks were first seen late in their tracks crowds its records into two or three segments, a tile of the outer diagonal walked 30
+  //      - 60 of them on two lanes, and a quarter of the chunks of configs[1] took 35 - 38 us against a median of 30 (the slowest chunk is the
+  //      kernel time). Here: streams = the power of two >= records / T, at most 16, for the smallest T whose lanes fit the workgroup; the
+  //      tiles are placed by descending stream count, so every group is aligned to its size (the butterflies below need that). ----
+  const bool dyn = nband <= 64 && !(HS_PROFILE_HOOKS && T.debug_flags < 0);  // (A/B in profiling builds, HS_DEBUG_FLAGS sign bit: the fixed rule)
+  if (dyn && wave == 3) {
+    int t_rb = lane, t_d = 0;
+#pragma unroll
+    for (int d = 0; d + 1 < K; ++d)
+      if (t_d == d && t_rb >= bw - d) t_rb -= bw - d, t_d = d + 1;
+    const bool t_ok = lane < nband;
+    int cnt = 0;
+    if (t_ok) {
+      const int o_hi = min(t_rb, nseg - 1), o_lo = max(0, t_rb + t_d - K + 1);
+      if (o_hi >= o_lo) cnt = seg_start[o_hi + 1] - seg_start[o_lo];
+    }
+    constexpr int kCand[14] = {2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 24, 32, 64, 256};  // records per lane, tried in this order (cnt <= R <= 256: the last one always fits)
+    int lg_sel = 0;
+    bool found = false;
+#pragma unroll
+    for (int c = 0; c < 14; ++c) {
+      const int q = (cnt + kCand[c] - 1) / kCand[c];
+      const int lg = (q > 1) + (q > 2) + (q > 4) + (q > 8);
+      const int lanes = __popcll(__ballot(t_ok && lg == 0)) + 2 * __popcll(__ballot(t_ok && lg == 1)) + 4 * __popcll(__ballot(t_ok && lg == 2)) +
+                        8 * __popcll(__ballot(t_ok && lg == 3)) + 16 * __popcll(__ballot(t_ok && lg == 4));
+      if (!found && lanes <= kBlock) found = true, lg_sel = lg;
+    }
+    int base = 0, my_off = 0;
+#pragma unroll
+    for (int c = 4; c >= 0; --c) {
+      const unsigned long long m = __ballot(t_ok && lg_sel == c);
+      if (t_ok && lg_sel == c) my_off = base + (__popcll(m & ((1ull << lane) - 1ull)) << c);
+      base += __popcll(m) << c;
+    }
+#pragma unroll
+    for (int j = 0; j < kBlock / 64; ++j) lane_tile[64 * j + lane] = -1;
+    wait_lds();  // (one wave: its LDS writes land in order; the emulation needs the hand-over between its lane threads)
+    if (t_ok)
+      for (int e = 0; e < (1 << lg_sel); ++e) lane_tile[my_off + e] = t_rb | (t_d << 8) | (lg_sel << 12);
+  }
   // ---- 1: linearise into the sorted slot (no global loads from here to phase 4); pos[o][l'] = my slot for the landmarks l' between my
   //         predecessor's (exclusive) and mine ----
   if (has_rec) {
@@ -462,9 +506,17 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
     if (tid >= p_end && tid < next) p_d = d, p_off = p_end, ns_lg = lg;
     p_end = next;
   }
-  const bool p_lane = tid < p_end;
-  const int NS = 1 << ns_lg, ns0 = 1 << (T.build_stream_lg & 3);  // (ns0: the widest groups, diagonal 0)
-  const int p_rb = p_lane ? (tid - p_off) >> ns_lg : 0, p_s = (tid - p_off) & (NS - 1);
+  bool p_lane = tid < p_end;
+  int p_rb = p_lane ? (tid - p_off) >> ns_lg : 0;
+  if (dyn) {  // (the table of this chunk, written by the last wave in front of the barrier behind phase 1)
+    const int lt = lane_tile[tid];
+    p_lane = lt >= 0;
+    p_rb = p_lane ? lt & 255 : 0, p_d = p_lane ? (lt >> 8) & 15 : 0, ns_lg = p_lane ? (lt >> 12) & 7 : 0, p_off = 0;  // (groups are aligned to their size)
+  }
+  const int NS = 1 << ns_lg, ns0 = 1 << (T.build_stream_lg & 3);  // (ns0: the widest groups of the fixed rule, diagonal 0)
+  const int p_s = (tid - p_off) & (NS - 1);
+  // butterfly levels this wave needs (wave-uniform)
+  const bool lv2 = dyn ? __ballot(ns_lg > 1) != 0 : ns0 > 2, lv4 = dyn ? __ballot(ns_lg > 2) != 0 : ns0 > 4, lv8 = dyn && __ballot(ns_lg > 3) != 0;
   const int p_tb = band_tile_index(p_rb, p_d, bw);
   double pacc[36], pg[6];
 #pragma unroll
@@ -506,7 +558,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
   // the streams of a tile are adjacent lanes: butterfly sums, ((s0 + s1) + (s2 + s3)) + ... on every lane of the group; the groups of a wave
   // have different sizes, so a level is exchanged by every lane and added by the lanes whose group reaches that far
   {
-    const bool t1 = NS > 1, t2 = NS > 2, t4 = NS > 4;
+    const bool t1 = NS > 1, t2 = NS > 2, t4 = NS > 4, t8 = NS > 8;
 #pragma unroll
     for (int e = 0; e < 36; ++e) {
       const double o = lane_xor1(pacc[e]);
@@ -517,7 +569,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
       const double o = lane_xor1(pg[e]);
       pg[e] += t1 ? o : 0.0;
     }
-    if (ns0 > 2) {
+    if (lv2) {
 #pragma unroll
       for (int e = 0; e < 36; ++e) {
         const double o = lane_xor2(pacc[e]);
@@ -529,7 +581,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
         pg[e] += t2 ? o : 0.0;
       }
     }
-    if (ns0 > 4) {
+    if (lv4) {
 #pragma unroll
       for (int e = 0; e < 36; ++e) {
         const double o = lane_xor4(pacc[e]);
@@ -539,6 +591,18 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
       for (int e = 0; e < 6; ++e) {
         const double o = lane_xor4(pg[e]);
         pg[e] += t4 ? o : 0.0;
+      }
+    }
+    if (lv8) {  // (sixteen streams: lane ^ 8 = row_ror:8 inside the row of sixteen lanes)
+#pragma unroll
+      for (int e = 0; e < 36; ++e) {
+        const double o = dpp_move<0x128>(pacc[e]);
+        pacc[e] += t8 ? o : 0.0;
+      }
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        const double o = dpp_move<0x128>(pg[e]);
+        pg[e] += t8 ? o : 0.0;
       }
     }
   }

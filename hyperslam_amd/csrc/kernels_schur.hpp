@@ -739,7 +739,13 @@ __global__ void __launch_bounds__(kBlock) k_reduce_partials(Tables T, int nsp, i
   const int n = T.xo_bb;  // [Sraw | g_p | g_schur | diag | Hpb]; e0 = xo_pb when the pose part comes from k_assemble
   for (int e = e0 + blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
     double s = 0.0;
-    for (int k = 0; k < nsp; ++k) s += T.xpart[size_t(k) * T.x_count1 + e];
+    for (int k0 = 0; k0 < nsp; k0 += 16) {  // (every split in flight, added in split order — finalize_border_body: a plain loop pays a memory round trip per split)
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = k0 + u < nsp ? T.xpart[size_t(k0 + u) * T.x_count1 + e] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
+    }
     T.xbuf[e] = s;
   }
 }

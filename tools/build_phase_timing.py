@@ -82,3 +82,30 @@ print("workgroups alone on a CU:", len(lone), " indices", lone[:5], "...", lone[
 pairs = [tuple(sorted(np.where(key == k_)[0].tolist())) for k_ in uniq[cnt == 2]]
 d = np.array([b - a for a, b in pairs])
 if len(d): print("index distance of the two workgroups of a CU: min", d.min(), " median", np.median(d), " max", d.max(), " share == 256:", float((d == 256).mean()))
+# where the slow chunks run: per XCC / per shader engine, and whether the two workgroups of a CU are slow together
+slow = dur > np.percentile(dur, 50) + 2.5
+print(f"slow chunks (> median + 2.5 us): {int(slow.sum())} of {len(dur)}")
+print("  per XCC   (slow / all):", " ".join(f"{int(slow[xcc == x].sum())}/{int((xcc == x).sum())}" for x in range(8)))
+print("  per SE    (slow / all):", " ".join(f"{int(slow[se == x].sum())}/{int((se == x).sum())}" for x in range(8)))
+print("  per CU id (slow / all):", " ".join(f"{int(slow[cu == x].sum())}/{int((cu == x).sum())}" for x in range(16)))
+both = one = 0
+for k_ in uniq:
+    idx = np.where(key == k_)[0]
+    if len(idx) == 2: both += int(slow[idx].all()); one += int(slow[idx].any() and not slow[idx].all())
+print("  CUs with two chunks: both slow", both, " exactly one slow", one, "  slow chunks alone on their CU:", int(sum(slow[np.where(key == k_)[0]].any() for k_ in uniq[cnt == 1])))
+wgid = np.where(ok)[0]
+print("  workgroup index of the slow chunks (mod 256) histogram by 32:", np.bincount((wgid[slow] % 256) // 32, minlength=8))
+print("  median duration by records-in-K-segments weight is not available here; phase medians of slow vs other chunks:")
+print("   slow :", " ".join(f"{x:5.2f}" for x in np.median(ph[slow], axis=0)))
+print("   other:", " ".join(f"{x:5.2f}" for x in np.median(ph[~slow], axis=0)))
+print("  slow chunks with workgroup index < 256:", int((wgid[slow] < 256).sum()), " >= 256:", int((wgid[slow] >= 256).sum()))
+part = {}
+for k_ in uniq:
+    idx = np.where(key == k_)[0]
+    if len(idx) == 2: part[idx[0]] = idx[1]; part[idx[1]] = idx[0]
+sl = [i for i in np.where(slow)[0] if i in part]
+print("  slow chunk vs its CU partner, medians: duration %.2f / %.2f  start %.2f / %.2f  records %d / %d" % (np.median(dur[sl]), np.median([dur[part[i]] for i in sl]),
+      np.median(start[sl]), np.median([start[part[i]] for i in sl]), np.median(t[sl, 0, 13]), np.median([t[part[i], 0, 13] for i in sl])))
+print("  stamps of the slow chunk minus its partner's, median per stamp (us):", " ".join(f"{x:5.2f}" for x in np.median([(t[i, :, :13].max(axis=0) - t[part[i], :, :13].max(axis=0)) * 0.01 for i in sl], axis=0)))
+nsl = [i for i in np.where(~slow)[0] if i in part and not slow[part[i]]]
+print("  pairs without a slow chunk:", len(nsl) // 2, " workgroup indices (mod 256) histogram by 32:", np.bincount((wgid[nsl] % 256) // 32, minlength=8) // 2)

@@ -240,10 +240,12 @@ inline bool build_chunks(const VisualStructure& vs, int n_cp, int R, int L, std:
 /// Order in which the chunks are handed to the workgroups of k_build_visual / k_update_visual (descriptor w = the chunk workgroup w works on;
 /// a chunk's partial stays in the slot of its id, so k_assemble is not concerned). The kernels keep two workgroups per CU, and the hardware
 /// places workgroup w on CU w mod n_cu: with n_cu < n <= 2 n_cu chunks the workgroups n - n_cu .. n_cu - 1 have a CU to themselves (20 us
-/// per chunk instead of ~29) and w shares its CU with w + n_cu (measured: tools/build_phase_timing.py). A chunk whose records crowd into few
-/// segments — landmarks first seen near the end of the window — takes up to 40 % longer than the median one, and the slowest chunk is the
-/// kernel time: the heaviest chunks get the CUs of their own, the rest are paired heaviest with lightest. More than two rounds: heaviest first.
-/// Weight of a chunk = most records in k consecutive segments (what the longest lane of its J'J and W phases walks).
+/// per chunk instead of ~29) and w shares its CU with w + n_cu (measured: tools/build_phase_timing.py). Of the two workgroups of a CU the
+/// SECOND one ends ~6 us behind the first whatever its records are (round 6: two chunks take ~35 us of a CU's LDS + fp64 issue, and the
+/// older workgroup gets the larger share early), and the slowest chunk is the kernel time: the heaviest chunks get the CUs of their own,
+/// the rest are paired heaviest (first) with lightest (second). More than two rounds: heaviest first.
+/// Weight of a chunk = most records in k consecutive segments (what the longest lane of its W phase walks; the J'J phase deals its streams
+/// per chunk since round 6 and no longer depends on it for bands of up to 64 tiles).
 inline void order_chunks_for_dispatch(const VisualStructure& vs, int k, int n_cu, std::vector<int>* ch_desc, int n) {
   if (n <= 1 || n_cu <= 0) return;
   std::vector<int> weight(n), order(n);

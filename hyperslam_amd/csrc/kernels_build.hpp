@@ -20,7 +20,9 @@
 //   2  lane <-> (landmark, control point j'): the 6 x 3 block of W_l = sum J_p' J_l from the records of segments j' - K + 1 .. j' of that
 //      landmark (pos table: only records that contribute are visited);  lane <-> (landmark, entry): H_ll, b_l
 //   3  lane <-> (band tile (rb, cb), cb - rb < K; record stream s): P += J_p' J_p over the runs of the segments that cover both
-//      blocks; the streams of a tile sit in adjacent lanes and are combined with butterfly steps (fixed order, no LDS)
+//      blocks; the streams of a tile sit in adjacent lanes and are combined with butterfly steps (fixed order, no LDS). Streams per
+//      tile: dealt per chunk from the record counts of its tiles (<= 64 band tiles; by the wave that idles during phase 1), a fixed
+//      number per diagonal offset otherwise (build_streams)
 //   4  lane <-> landmark: damped 3 x 3 Cholesky;  lane <-> (landmark, control point): Y-hat block -> LDS and HBM (k_backsub_retract)
 //   5  lane <-> (window tile, landmark stream): Q -= Yh Yh', q -= Yh yh (two streams in adjacent lanes)
 //   6  the chunk's partial [rows of P + Q | -Yh yh | J_p'r | diag J_p'J_p] -> HBM, summed over the chunks of the overlapping groups

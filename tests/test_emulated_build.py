@@ -107,6 +107,16 @@ def test_emulated_fused_build_matches_oracle(harness, oracle, order, bearing):
     assert out["n_chunk"] >= 2
 
 
+@pytest.mark.parametrize("order,span,pairs", [(4, 0.05, 5), (6, 0.15, 4)])
+def test_emulated_fused_build_crowded_segments(harness, oracle, order, span, pairs):
+    """Every observation of a landmark inside one or two knot intervals: the records of a chunk crowd into a few segments, the J'J tiles of those
+    segments get eight or sixteen record streams from the per-chunk deal (kernels_build.hpp, streams of phase 3: the fourth butterfly level)
+    and most other tiles a single lane with nothing to walk."""
+    w = synthetic.small_visual(order=order, n_cp=14 if order == 4 else 16, n_landmarks=36, obs_pairs=pairs, span=span)
+    out = _check(harness, oracle, w)
+    assert out["n_chunk"] >= 3
+
+
 def test_emulated_fused_build_small_chunks(harness, oracle):
     """Forced tiny geometry: chunks of <= 3 landmarks and <= 64 records (landmarks with 40 residuals: one or two per chunk), records of one
     landmark spread over several waves."""

@@ -164,6 +164,7 @@ int launch_build(hs_problem* p, hipEvent_t after_build = nullptr, bool scaling_f
     k_build_visual<K><<<p->nb_vis + 1, kBlock, p->build_lds, s>>>(Tf, p->build_R, p->build_L, 1);
   } else if (fused)
     k_build_visual<K><<<p->nb_vis, kBlock, p->build_lds, s>>>(T, p->build_R, p->build_L, 1);
+  if (fused && T.wide_q) k_landmark_gram_wide<<<landmark_gram_wide_grid(T.sp.n_cp, T.bw), kGramWideThreads, 0, s>>>(T);  // window-wide bands: -Yh Yh' once per window
   if (fused && after_build) HIP_TRY(hipEventRecord(after_build, s));
   if (fork) {
     const int rc = ensure_side_stream(p);

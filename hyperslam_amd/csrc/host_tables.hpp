@@ -290,7 +290,9 @@ struct hs_problem {
   DBuf<double> d_scale_p, d_Sb, d_Ub, d_Ubk, d_g_s, d_g_full, d_D2p, d_step_p, d_delta_p;
   DBuf<double> d_cost_part, d_cand_part, d_norm_part, d_dbg, d_dbg_cost;
   DBuf<DevState> d_state;
-  DBuf<double> d_xbuf, d_xpart, d_segP, d_grpQ, d_gravity_part;
+  DBuf<double> d_xbuf, d_xpart, d_segP, d_grpQ, d_Qw, d_Yt, d_gravity_part;
+  int yt_stride = 0;
+  bool wide_q = false;  // fused build on window-wide bands: landmark term once per window (k_landmark_gram_wide; HS_WIDE_Q=0: per chunk, round 5's arrangement)
   DBuf<double> d_Vb, d_Vb2, d_yt, d_yt2;  // block-row-scaled factors diag(U_jj^-1) U and right-hand sides for the register sweep
   DBuf<double> d_Sb2, d_g2, d_Ub2, d_Ubk2, d_ybuf2, d_win, d_xsol;  // two-ended factorisation: reversed system, its factor, junction window
   DBuf<unsigned> d_join;
@@ -775,6 +777,15 @@ int prepare(hs_problem* p) {
     }
     HIP_TRY(p->d_segP.reserve(size_t(p->n_seg_wg) * (size_t(nca) * nca + nca) + 1));
     HIP_TRY(p->d_grpQ.reserve(size_t(p->n_group_wg) * (size_t(ntile) * 36 + (p->fused ? 3 : 1) * 6 * vs.bw) + 1));
+    {
+      const char* env = std::getenv("HS_WIDE_Q");
+      p->wide_q = p->fused && ntile > kBlock && !(env && std::atoi(env) == 0);
+      if (p->wide_q) {
+        HIP_TRY(p->d_Qw.reserve(size_t(6) * p->n_cp * (6 * vs.bw + 1) + 1));
+        p->yt_stride = (p->n_lm + 63) / 64 * 64;
+        HIP_TRY(p->d_Yt.reserve(size_t(18) * p->n_cp * p->yt_stride + 2));
+      }
+    }
   }
   HIP_TRY(p->d_state.reserve(1));
 
@@ -813,7 +824,7 @@ int prepare(hs_problem* p) {
     HS_FAIL(HS_ERR_DEVICE, "internal: cost partial tables shorter than the grids that write them");
   T.norm_part = p->d_norm_part.p, T.n_norm_part = nb_norm;
   T.xbuf = p->d_xbuf.p;
-  T.xpart = p->d_xpart.p, T.gravity_part = p->d_gravity_part.p, T.segP = p->d_segP.p, T.grpQ = p->d_grpQ.p, T.gw_ptr = p->d_gw_ptr.p, T.gw_cf = p->d_gw_cf.p, T.sw_ptr = p->d_sw_ptr.p, T.sw_seg = p->d_sw_seg.p;
+  T.xpart = p->d_xpart.p, T.gravity_part = p->d_gravity_part.p, T.segP = p->d_segP.p, T.grpQ = p->d_grpQ.p, T.Qw = p->d_Qw.p, T.wide_q = p->wide_q && n_vis > 0 ? 1 : 0, T.Yt = p->d_Yt.p, T.yt_stride = p->yt_stride, T.gw_ptr = p->d_gw_ptr.p, T.gw_cf = p->d_gw_cf.p, T.sw_ptr = p->d_sw_ptr.p, T.sw_seg = p->d_sw_seg.p;
   T.xo_g = np * ncb, T.xo_gs = T.xo_g + np, T.xo_dj = T.xo_gs + np, T.xo_pb = T.xo_dj + np, T.xo_bb = T.xo_pb + np * nbd;
   T.xo_gb = T.xo_bb + nbd * nbd, T.xo_cost = T.xo_gb + nbd, T.xo_gmax = T.xo_cost + 1;
   T.ybuf = p->d_ybuf.p, T.ybuf2 = nullptr, T.y_split = np;

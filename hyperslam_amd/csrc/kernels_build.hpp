@@ -695,6 +695,11 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
       *reinterpret_cast<double2*>(wr + e) = make_double2(y[e], y[e + 1]);
       *reinterpret_cast<double2*>(Y + e) = make_double2(y[e], y[e + 1]);
     }
+    if (T.wide_q) {  // the copy k_landmark_gram_wide reads with consecutive landmarks in consecutive lanes
+      double2* Yt = reinterpret_cast<double2*>(T.Yt) + size_t(cf + jb) * 9 * T.yt_stride + (lo + l);
+#pragma unroll
+      for (int e = 0; e < 9; ++e) Yt[size_t(e) * T.yt_stride] = make_double2(y[2 * e], y[2 * e + 1]);
+    }
   }
   __syncthreads();
   HS_BSTAMP(9);
@@ -717,7 +722,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
     for (int e = 0; e < 36; ++e) acc[e] = 0.0;
 #pragma unroll
     for (int e = 0; e < 6; ++e) qacc[e] = 0.0;
-    if (q_ok) {
+    if (q_ok && !T.wide_q) {  // (wide_q: the landmark term is formed once per window from the Y-hat rows in HBM, k_landmark_gram_wide)
       const bool diag = q_rb == q_cb;
 #pragma unroll 2
       for (int l = q_s; l < nl; l += QS) {
@@ -747,7 +752,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_build_visual(Tables T, int R, int
     }
     HS_BSTAMP(10);
     // ---- 6: P + Q and the three vectors of the chunk partial -> HBM ----
-    if (q_s == 0 && q_ok) {
+    if (q_s == 0 && q_ok && (!T.wide_q || q_cb - q_rb < K)) {  // (wide_q: the band tiles of J_p'J_p are all a partial holds)
       const int d = q_cb - q_rb;
       if (d < K) {
         const double* src = Pc + size_t(band_tile_index(q_rb, d, bw)) * 42;

@@ -537,7 +537,11 @@ HSD void assemble_body(const Tables& T, int direct) {
   const int f0 = max(0, i - K + 1), f1 = min(i, T.n_seg - 1);
   const int c0 = max(0, i - bw + 1);
   const int nent = ncb + 2;  // band entries + [J'r | Y-hat y-hat] of this row
-  const int nsl = max(1, THREADS / nent), sl = tid / nent, c = tid % nent;
+  // wide_q: only the 6 K band entries of J_p'J_p, J_p'r and diag J_p'J_p have sources — the lanes are dealt over THOSE entries, so that a row's
+  // ~170 chunks make 4 - 5 sources per lane (one round of loads) where the 6 bw + 2 entries of the full row left 33 per lane (three to six rounds)
+  const int nent_s = T.wide_q ? 6 * K + 2 : nent;
+  const int nsl = max(1, THREADS / nent_s), sl = tid / nent_s, cs = tid % nent_s;
+  const int c = T.wide_q ? (cs < 6 * K ? cs : ncb + (cs - 6 * K)) : cs;
   // direct mode: scaling of this row and of the lane's column, trust-region radius (requested with the work lists)
   double d_sr = 1.0, d_sc = 1.0, d_radius = 1.0;
   if (direct) {
@@ -545,6 +549,8 @@ HSD void assemble_body(const Tables& T, int direct) {
     if (tid < ncb && 6 * i + tid < T.np) d_sc = T.scale_p[6 * i + tid];
     d_radius = T.st->radius;
   }
+  double q_wide = 0.0;  // wide_q: this lane's entry of the window's landmark term (band entry tid of row 6 i + a, or the row's -Yh yh)
+  if (T.wide_q && T.n_lm > 0 && tid < nent && tid != ncb) q_wide = tid < ncb ? (6 * i + tid < T.np ? T.Qw[size_t(6 * i + a) * ncb + tid] : 0.0) : T.Qw[size_t(T.np) * ncb + 6 * i + a];  // (entries right of the matrix: never written)
   double va = 0.0, vb = 0.0;  // J'J part / Schur part
   double vp = 0.0;            // fused build: the chunk partials carry J_p'J_p inside their tiles; J_p'r (lane ncb) and diag J_p'J_p (lane a) ride along
   if (sl < nsl) {
@@ -555,7 +561,9 @@ HSD void assemble_body(const Tables& T, int direct) {
     // batch); the sums run in the same fixed order as a plain loop over p.
     const bool a_live = (c < ncb ? kk < K : c == ncb) && f1 >= f0;
     const bool x_live = T.fused && (c == ncb || c == a);  // lanes that also collect J_p'r / diag J_p'J_p of the chunk partials
-    const bool b_live = T.n_lm > 0 && (c < ncb || c == ncb + 1 || x_live);
+    // wide_q (window-wide bands on the fused build): a chunk partial holds the band tiles of J_p'J_p only, the landmark term of the whole
+    // window comes from T.Qw (k_landmark_gram_wide) and is added behind the combination of the slices
+    const bool b_live = T.n_lm > 0 && (T.wide_q ? (c < ncb && kk < K) || x_live : c < ncb || c == ncb + 1 || x_live);
     const int p_lo = a_live ? T.sw_ptr[f0] : 0, np_ = a_live ? T.sw_ptr[f1 + 1] - p_lo : 0;
     const int q_lo = b_live ? T.gw_ptr[c0] : 0, nq = b_live ? T.gw_ptr[i + 1] - q_lo : 0;
     // (plain macros, not lambdas: a by-reference closure kept these operands in scratch memory)
@@ -654,8 +662,10 @@ HSD void assemble_body(const Tables& T, int direct) {
   if (aprof) alog[5] = wall_clock64();
   if (tid < nent) {
     double sa = 0.0, sb = 0.0, sx = 0.0;
-    for (int q = 0; q < nsl; ++q) sa += part[0][q * nent + tid], sb += part[1][q * nent + tid], sx += part[2][q * nent + tid];
+    const int es = !T.wide_q ? tid : tid < 6 * K ? tid : tid >= ncb ? 6 * K + (tid - ncb) : -1;  // this entry's lane slot inside a slice
+    for (int q = 0; q < nsl && es >= 0; ++q) sa += part[0][q * nent_s + es], sb += part[1][q * nent_s + es], sx += part[2][q * nent_s + es];
     const int rho = 6 * i + a;
+    sb += q_wide;
     if (direct) {
       if (tid < ncb) {
         const int sigma = 6 * i + tid;
@@ -731,6 +741,108 @@ constexpr int kAsmWideThreads = 1024, kAsmWideBatch = 12;  // (sixteen waves: 12
 template <int K>
 __global__ void __launch_bounds__(kAsmWideThreads) k_assemble_wide(Tables T, int direct) {  // (few workgroups — a short window — and many sources per row)
   assemble_body<K, kAsmWideBatch, kAsmWideThreads>(T, direct);
+}
+
+/// wide_q — the landmark term of the reduced system for window-wide bands, ONCE per window instead of once per chunk:
+///   Q(rho, sigma) = - sum_l Yh_l(rho) . Yh_l(sigma),   q(rho) = - sum_l Yh_l(rho) . yh_l      (Yh_l: 6 ncp_l x 3 rows in T.Y, yh_l in T.lm_yhat)
+/// On a sliding window's steady state every track is as long as the window: a chunk of k_build_visual holds three landmarks, its Yh Yh' is
+/// a rank-9 update of ALL 561 window tiles, and 165 chunks sent 27 MB of such partials through HBM for a 0.3 MB reduced system — 8.7 us of a
+/// 33 us chunk to form them, 21 of k_assemble_wide's 24 us to read them back (stamps: tools/build_phase_timing.py r, assemble_phase_timing.py r).
+/// The factors are in HBM anyway (k_update_visual's back-substitution reads them): one workgroup per 6 x 6 tile (bi, bj >= bi) of the band,
+/// thread s takes the landmarks l = s, s + 128, ... that cover both blocks (table entries of four in one round, then their blocks in pairs),
+/// the 128 streams are summed through LDS in a fixed order (bit-reproducible).
+/// Output in band-row storage: Qw[(6 bi + r) * 6 bw + 6 (bj - bi) + c]; the diagonal tiles add q behind the matrix.
+constexpr int kGramWideThreads = 128;  // (two waves per tile; a 256-thread version with a wave butterfly per sum took 23 us, this one 17)
+__global__ void __launch_bounds__(kGramWideThreads) k_landmark_gram_wide(Tables T) {
+  // (the compiler takes 504 VGPRs here — every load of a thread's four landmarks in flight — i.e. one wave per SIMD, two workgroups per CU: 17 us on
+  //  the full window. Capped at two waves per SIMD (256 VGPRs) it spills: 55 us; at four: 115 us. The next step is a leaner inner loop, not a cap.)
+  constexpr int NT = kGramWideThreads, NP = NT / 32;
+  __shared__ double red[NT * 21], red2[NP * 21];
+  if (T.st->done) return;
+  const int tid = threadIdx.x;
+  const int bw = T.bw, ncb = 6 * bw, n_cp = T.sp.n_cp;
+  int t = int(blockIdx.x), bi = 0;  // block row bi holds min(bw, n_cp - bi) tiles
+  while (bi < n_cp && t >= min(bw, n_cp - bi)) t -= min(bw, n_cp - bi), ++bi;
+  if (bi >= n_cp) return;
+  const int bj = bi + t;
+  const bool diag = bi == bj;
+  double acc[36], qa[6];
+#pragma unroll
+  for (int e = 0; e < 36; ++e) acc[e] = 0.0;
+#pragma unroll
+  for (int e = 0; e < 6; ++e) qa[e] = 0.0;
+  for (int l0 = 0; l0 < T.n_obs_lm; l0 += 4 * NT) {
+    // the table entries of four landmarks in one round of loads, their blocks two landmarks at a time
+    bool on[4];
+    double y[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int l = l0 + u * NT + tid;
+      const bool in = l < T.n_obs_lm;
+      const int cf = in ? T.lm_cfirst[l] : 0, ncp = in ? T.lm_ncp[l] : 0;
+      y[u][0] = in && diag ? T.lm_yhat[3 * l] : 0.0, y[u][1] = in && diag ? T.lm_yhat[3 * l + 1] : 0.0, y[u][2] = in && diag ? T.lm_yhat[3 * l + 2] : 0.0;
+      on[u] = in && cf <= bi && bj < cf + ncp;
+    }
+    // (T.Yt: block row, pair of doubles, landmark — a wave's 64 landmarks are 1 KB of consecutive memory per load where the per-landmark layout
+    //  of T.Y made every lane its own cache line: 11 of that version's 17 us)
+    const double2* Ya = reinterpret_cast<const double2*>(T.Yt) + size_t(bi) * 9 * T.yt_stride + l0 + tid;
+    const double2* Yb = reinterpret_cast<const double2*>(T.Yt) + size_t(bj) * 9 * T.yt_stride + l0 + tid;
+#pragma unroll
+    for (int h = 0; h < 4; h += 2) {
+      double2 A2[2][9], B2[2][9];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const double2 *pa = Ya + (h + u) * NT, *pb = Yb + (h + u) * NT;
+#pragma unroll
+        for (int e = 0; e < 9; ++e)
+          A2[u][e] = on[h + u] ? pa[size_t(e) * T.yt_stride] : make_double2(0.0, 0.0), B2[u][e] = on[h + u] ? pb[size_t(e) * T.yt_stride] : make_double2(0.0, 0.0);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {  // (a landmark that does not cover the tile adds zeros: the order of the sums does not depend on the data)
+        double A[18], B[18];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) A[2 * e] = A2[u][e].x, A[2 * e + 1] = A2[u][e].y, B[2 * e] = B2[u][e].x, B[2 * e + 1] = B2[u][e].y;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c)
+            acc[6 * r + c] = fma(-A[3 * r + 2], B[3 * c + 2], fma(-A[3 * r + 1], B[3 * c + 1], fma(-A[3 * r], B[3 * c], acc[6 * r + c])));
+          qa[r] = fma(-A[3 * r + 2], y[h + u][2], fma(-A[3 * r + 1], y[h + u][1], fma(-A[3 * r], y[h + u][0], qa[r])));
+        }
+      }
+    }
+  }
+  // 42 sums over the threads, through LDS in two passes of 21 values: thread (part, v) adds the 32 threads of its part in thread order,
+  // 21 threads add the parts in part order (fixed order: bit-reproducible; 42 wave butterflies would be 250 cross-lane steps)
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int v = 0; v < 21; ++v) red[tid * 21 + v] = pass == 0 ? acc[v] : v < 15 ? acc[v < 15 ? 21 + v : 0] : qa[v < 15 ? 0 : v - 15];
+    __syncthreads();
+    if (tid < NP * 21) {
+      const int part = tid / 21, v = tid - 21 * part;
+      double sum = 0.0;
+      for (int j = 0; j < 32; ++j) sum += red[(32 * part + j) * 21 + v];
+      red2[tid] = sum;
+    }
+    __syncthreads();
+    if (tid < 21) {
+      double sum = red2[tid];
+#pragma unroll
+      for (int part = 1; part < NP; ++part) sum += red2[21 * part + tid];
+      const int g = 21 * pass + tid;
+      if (g < 36)
+        T.Qw[size_t(6 * bi + g / 6) * ncb + 6 * (bj - bi) + g % 6] = sum;
+      else if (diag)
+        T.Qw[size_t(T.np) * ncb + 6 * bi + (g - 36)] = sum;
+    }
+  }
+}
+/// Workgroups of k_landmark_gram_wide: one per band tile.
+__host__ __device__ inline int landmark_gram_wide_grid(int n_cp, int bw) {
+  int n = 0;
+  for (int bi = 0; bi < n_cp; ++bi) n += bw < n_cp - bi ? bw : n_cp - bi;
+  return n;
 }
 
 /// xbuf[e] = sum over the accumulation splits (fixed order => bit-reproducible). The result is additive across residual shards.

@@ -222,6 +222,10 @@ struct Tables {
   double* segP;   // per k_seg_gram workgroup: [J'J (6k x 6k) | J'r (6k)]
   const int* gw_ptr;  // n_cp + 1: workgroups of k_group_gram serving landmark group c (splits ~ landmark count)
   const int* gw_cf;   // group of workgroup w
+  double* Qw;     // wide_q: the landmark term of the whole window, -sum_l Yh_l Yh_l', in band-row storage [np][6 bw] followed by -sum_l Yh_l yh_l [np] (k_landmark_gram_wide)
+  double* Yt;     // wide_q: second copy of Y-hat for k_landmark_gram_wide, [control point][9 pairs of doubles][yt_stride landmarks][2] — consecutive landmarks in consecutive lanes
+  int yt_stride;  // landmarks per row of Yt (observed landmarks rounded up to 64)
+  int wide_q;     // fused build on window-wide bands: the chunk partials carry J_p'J_p only (band tiles); the landmark term is formed once per window from Y-hat
   double* grpQ;   // per k_group_gram workgroup: [upper 6x6 tiles of -sum Yh Yh' | -sum Yh yh (6 bw)]
   double* xpart;  // per-split partial copies of the H_pb part of the exchange buffer (stride x_count1); scratch for timestamps
   int xo_g, xo_gs, xo_dj, xo_pb, xo_bb, xo_gb, xo_cost, xo_gmax, xo_dec, x_count1;

@@ -46,6 +46,7 @@ struct Reader {
 template <int K>
 static void run(Tables& T, int nb_vis, int R, int L, size_t lds) {
   hs_emul::launch(dim3(nb_vis), dim3(kBlock), lds, [&] { k_build_visual<K>(T, R, L, 1); });
+  if (T.wide_q) hs_emul::launch(dim3(landmark_gram_wide_grid(T.sp.n_cp, T.bw)), dim3(kGramWideThreads), 0, [&] { k_landmark_gram_wide(T); });
   if (T.bw * (T.bw + 1) / 2 > kBlock)  // (launch_build's rule: window-wide bands take the instance with the pipelined source loop)
     hs_emul::launch(dim3(T.sp.n_cp, 6), dim3(kAsmWideThreads), 0, [&] { k_assemble_wide<K>(T, 0); });
   else
@@ -272,6 +273,11 @@ int main(int argc, char** argv) {
   T.x_count1 = x_count1, T.xo_dec = x_count1;
   T.fused = 1, T.n_chunk = n_chunk, T.ch_ptr = ch_ptr.data(), T.ch_desc = ch_desc.data();
   T.build_stream_lg = hs::build_streams_packed(vs.bw, k);
+  std::vector<double> Qw(size_t(np) * (ncb + 1) + 1, 1e300);  // (prepare()'s rule: window-wide bands form the landmark term once per window)
+  const int yt_stride = (n_lm + 63) / 64 * 64;
+  std::vector<double> Yt(size_t(18) * n_cp * yt_stride + 2, 1e300);
+  T.Yt = Yt.data(), T.yt_stride = yt_stride;
+  T.wide_q = ntile > kBlock && !(std::getenv("HS_WIDE_Q") && std::atoi(std::getenv("HS_WIDE_Q")) == 0) ? 1 : 0, T.Qw = Qw.data();
   T.rank = 0, T.world = 1, T.st = &st;
 
   const size_t lds = size_t(build_lds_layout(k, bw, R, L).total_doubles) * 8;

@@ -1,5 +1,5 @@
 """Phase timestamps of k_assemble (HS_DEBUG_FLAGS=256, profiling build: tools/build_profiling_lib.sh).
-usage (GPU box): python tools/assemble_phase_timing.py [config=1]"""
+usage (GPU box): python tools/assemble_phase_timing.py [config=1|2|3|r]   (r: the replay's steady state, window-wide band: k_assemble_wide)"""
 import os
 import sys, ctypes as C; sys.path.insert(0, ".")
 import numpy as np
@@ -7,8 +7,9 @@ os.environ["HS_DEBUG_FLAGS"] = str(256 | int(os.environ.get("HS_DEBUG_FLAGS", "0
 import hyperslam_amd as ha
 from hyperslam_amd import synthetic, _lib
 _lib.PRODUCT_LIB = os.path.join("tools", "libhyperslam_hip_prof.so")
-cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-w = {1: synthetic.config1, 2: synthetic.config2, 3: synthetic.config3}[cfg]()
+cfg = sys.argv[1] if len(sys.argv) > 1 else "1"
+w = synthetic.small_visual(order=4, n_cp=36, n_landmarks=480, obs_pairs=18, span=3.0) if cfg == "r" else \
+    {1: synthetic.config1, 2: synthetic.config2, 3: synthetic.config3}[int(cfg)]()
 p = ha.Problem(w); p.snapshot()
 for i in range(3): p.restore(); s = p.solve(1)
 lib = _lib.load().cdll

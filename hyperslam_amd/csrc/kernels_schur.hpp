@@ -754,8 +754,10 @@ __global__ void __launch_bounds__(kAsmWideThreads) k_assemble_wide(Tables T, int
 /// Output in band-row storage: Qw[(6 bi + r) * 6 bw + 6 (bj - bi) + c]; the diagonal tiles add q behind the matrix.
 constexpr int kGramWideThreads = 128;  // (two waves per tile; a 256-thread version with a wave butterfly per sum took 23 us, this one 17)
 __global__ void __launch_bounds__(kGramWideThreads) k_landmark_gram_wide(Tables T) {
-  // (the compiler takes 504 VGPRs here — every load of a thread's four landmarks in flight — i.e. one wave per SIMD, two workgroups per CU: 17 us on
-  //  the full window. Capped at two waves per SIMD (256 VGPRs) it spills: 55 us; at four: 115 us. The next step is a leaner inner loop, not a cap.)
+  // (With the four landmarks of a thread as independent code the compiler kept every load in flight: 504 VGPRs, one wave per SIMD, two
+  //  workgroups per CU, the tiles of a full window in two rounds — 17.8 us; capped at two waves per SIMD (256 VGPRs) it spilled: 55 us, at four:
+  //  115 us; a compiler barrier behind each landmark's products changed nothing (480). Hence a real loop over the thread's landmarks: the blocks
+  //  are requested with the table entries — unconditionally, from rows of T.Yt that may never have been written — and masked afterwards.)
   constexpr int NT = kGramWideThreads, NP = NT / 32;
   __shared__ double red[NT * 21], red2[NP * 21];
   if (T.st->done) return;
@@ -771,45 +773,26 @@ __global__ void __launch_bounds__(kGramWideThreads) k_landmark_gram_wide(Tables 
   for (int e = 0; e < 36; ++e) acc[e] = 0.0;
 #pragma unroll
   for (int e = 0; e < 6; ++e) qa[e] = 0.0;
-  for (int l0 = 0; l0 < T.n_obs_lm; l0 += 4 * NT) {
-    // the table entries of four landmarks in one round of loads, their blocks two landmarks at a time
-    bool on[4];
-    double y[4][3];
+#pragma unroll 1
+  for (int l = tid; l < T.n_obs_lm; l += NT) {  // a real loop, one landmark's blocks live at a time (see the note at the head of the kernel)
+    const int cf = T.lm_cfirst[l], ncp = T.lm_ncp[l];
+    const double y0 = diag ? T.lm_yhat[3 * l] : 0.0, y1 = diag ? T.lm_yhat[3 * l + 1] : 0.0, y2 = diag ? T.lm_yhat[3 * l + 2] : 0.0;
+    // (T.Yt: block row, pair of doubles, landmark — a wave's 64 landmarks are 1 KB of consecutive memory per load)
+    const double2* pa = reinterpret_cast<const double2*>(T.Yt) + size_t(bi) * 9 * T.yt_stride + l;
+    const double2* pb = reinterpret_cast<const double2*>(T.Yt) + size_t(bj) * 9 * T.yt_stride + l;
+    double2 A2[9], B2[9];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int l = l0 + u * NT + tid;
-      const bool in = l < T.n_obs_lm;
-      const int cf = in ? T.lm_cfirst[l] : 0, ncp = in ? T.lm_ncp[l] : 0;
-      y[u][0] = in && diag ? T.lm_yhat[3 * l] : 0.0, y[u][1] = in && diag ? T.lm_yhat[3 * l + 1] : 0.0, y[u][2] = in && diag ? T.lm_yhat[3 * l + 2] : 0.0;
-      on[u] = in && cf <= bi && bj < cf + ncp;
-    }
-    // (T.Yt: block row, pair of doubles, landmark — a wave's 64 landmarks are 1 KB of consecutive memory per load where the per-landmark layout
-    //  of T.Y made every lane its own cache line: 11 of that version's 17 us)
-    const double2* Ya = reinterpret_cast<const double2*>(T.Yt) + size_t(bi) * 9 * T.yt_stride + l0 + tid;
-    const double2* Yb = reinterpret_cast<const double2*>(T.Yt) + size_t(bj) * 9 * T.yt_stride + l0 + tid;
+    for (int e = 0; e < 9; ++e) A2[e] = pa[size_t(e) * T.yt_stride], B2[e] = pb[size_t(e) * T.yt_stride];  // (rows outside the landmark's track: never written, masked below)
+    const bool on = cf <= bi && bj < cf + ncp;
+    double A[18], B[18];  // (a landmark that does not cover the tile adds zeros: the order of the sums does not depend on the data)
 #pragma unroll
-    for (int h = 0; h < 4; h += 2) {
-      double2 A2[2][9], B2[2][9];
+    for (int e = 0; e < 9; ++e) A[2 * e] = on ? A2[e].x : 0.0, A[2 * e + 1] = on ? A2[e].y : 0.0, B[2 * e] = on ? B2[e].x : 0.0, B[2 * e + 1] = on ? B2[e].y : 0.0;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const double2 *pa = Ya + (h + u) * NT, *pb = Yb + (h + u) * NT;
+    for (int r = 0; r < 6; ++r) {
 #pragma unroll
-        for (int e = 0; e < 9; ++e)
-          A2[u][e] = on[h + u] ? pa[size_t(e) * T.yt_stride] : make_double2(0.0, 0.0), B2[u][e] = on[h + u] ? pb[size_t(e) * T.yt_stride] : make_double2(0.0, 0.0);
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {  // (a landmark that does not cover the tile adds zeros: the order of the sums does not depend on the data)
-        double A[18], B[18];
-#pragma unroll
-        for (int e = 0; e < 9; ++e) A[2 * e] = A2[u][e].x, A[2 * e + 1] = A2[u][e].y, B[2 * e] = B2[u][e].x, B[2 * e + 1] = B2[u][e].y;
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-#pragma unroll
-          for (int c = 0; c < 6; ++c)
-            acc[6 * r + c] = fma(-A[3 * r + 2], B[3 * c + 2], fma(-A[3 * r + 1], B[3 * c + 1], fma(-A[3 * r], B[3 * c], acc[6 * r + c])));
-          qa[r] = fma(-A[3 * r + 2], y[h + u][2], fma(-A[3 * r + 1], y[h + u][1], fma(-A[3 * r], y[h + u][0], qa[r])));
-        }
-      }
+      for (int c = 0; c < 6; ++c)
+        acc[6 * r + c] = fma(-A[3 * r + 2], B[3 * c + 2], fma(-A[3 * r + 1], B[3 * c + 1], fma(-A[3 * r], B[3 * c], acc[6 * r + c])));
+      qa[r] = fma(-A[3 * r + 2], y2, fma(-A[3 * r + 1], y1, fma(-A[3 * r], y0, qa[r])));
     }
   }
   // 42 sums over the threads, through LDS in two passes of 21 values: thread (part, v) adds the 32 threads of its part in thread order,

@@ -53,4 +53,8 @@ bash tools/kernel_stats.sh $out/${tag}_replay_stereo_kernel_stats.csv hyperslam_
 { for i in 1 2; do echo "gather flag (default)"; HS_STAGE_TIMING=0 python tools/time_config.py 2 | head -1; echo "event between the streams (HS_DEBUG_FLAGS=16384)"; HS_DEBUG_FLAGS=16384 HS_STAGE_TIMING=0 python tools/time_config.py 2 | head -1; done; } > $out/${tag}_config2_gather_ab.txt 2>&1
 bash tools/iteration_timeline.sh 2 > $out/${tag}_timeline_config2.txt 2>&1
 hipcc --offload-arch=gfx950 -O2 -o /tmp/dpp_probe tools/microbench/dpp_f64_probe.hip > /dev/null 2>&1 && /tmp/dpp_probe > $out/${tag}_dpp_f64_probe.txt 2>&1
+
+# last session of round 6: window-wide bands with the landmark term once per window (Tables::wide_q) against once per chunk (HS_WIDE_Q=0), alternating
+( cd hyperslam_amd/host; for r in 1 2; do for a in "6.0 0 4" "6.0 1 4" "6.0 1 6"; do for q in 1 0; do echo -n "replay $a HS_WIDE_Q=$q: "; HS_WIDE_Q=$q ./replay $a 2>/dev/null | tail -1 | cut -c1-160; done; done; done ) > $out/${tag}_replay_wide_q_ab.txt 2>&1
+[ -f tools/libhyperslam_hip_prof.so ] && { python tools/assemble_phase_timing.py r; python tools/build_phase_timing.py r | head -18; } > $out/${tag}_wide_band_phase_timing.txt 2>&1
 echo done
